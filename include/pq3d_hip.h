@@ -1,0 +1,222 @@
+/* pq3d_hip.h -- C ABI of libpq3d_hip.so: MI355X (gfx950) kernels for PQ3D's promptable query decoder.
+ *
+ * The reference (PQ3D, /root/reference) is pure Python on stock PyTorch ops; it defines no FFI for this
+ * path.  Each entry point below therefore cites the reference *function* whose arithmetic it replaces
+ * (file:line relative to the reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless noted;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing synchronises the device,
+ *     nothing allocates: workspaces are caller-provided; the library holds no thread-local device state and
+ *     is re-entrant (PyTorch calls backward from its autograd thread);
+ *   - return 0 on success, PQ3D_ERR_ARG (<0) for argument errors, >0 = hipError_t; pq3d_last_error() gives text;
+ *   - dtype enum: PQ3D_F32 / PQ3D_BF16 (raw bfloat16 bits); "compute type" (ct) selects the MFMA path:
+ *     PQ3D_BF16 -> v_mfma_f32_16x16x32_bf16 (fp32 accumulate), PQ3D_F32 -> v_mfma_f32_16x16x4_f32 (exact f32);
+ *   - masks are uint8 (torch.bool storage), PyTorch convention: nonzero = ignore / padded.
+ */
+#ifndef PQ3D_HIP_H
+#define PQ3D_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQ3D_F32 0
+#define PQ3D_BF16 1
+#define PQ3D_ERR_ARG (-1)
+
+#define PQ3D_ACT_NONE 0
+#define PQ3D_ACT_RELU 1
+#define PQ3D_ACT_GELU 2
+
+#define PQ3D_MAX_GROUPS 8
+
+const char* pq3d_last_error(void);
+int pq3d_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Grouped / batched GEMM with fused prologue + epilogue (nn.Linear forward and both backward GEMMs,
+ * MaskPredictionLayer einsum).  Replaces: F.linear calls inside nn.MultiheadAttention
+ * (query_encoder.py:268-270,194), MultiHeadAttentionSpatial w_qs/w_ks/w_vs/fc (transformers.py:190-193,239),
+ * FFNLayer.linear1/2 (query_encoder.py:384-388), get_mlp_head (utils.py:18-25), ObjectEncoder.input_feat_proj
+ * (object_encoder.py:71), MaskPredictionLayer (mask_head.py:53-57).
+ *
+ *   for g < groups, z < batch:
+ *     C_g[z][m][n] = epi( sum_k (A_g[z](m,k) + A2_g[z](m,k)) * (B_g[z](n,k) + B2_g[z](n,k)) )
+ *   kconcat != 0: the groups are concatenated along K instead (one output C[0]:
+ *     C[z][m][n] = epi( sum_g sum_k A_g(m,k) B_g(n,k) ), the multi-memory sum of mask_head.py:30-37).
+ *   A(m,k) is at A[m*lda + k] (transA=0) or A[k*lda + m] (transA=1); B(n,k) at B[n*ldb + k] (transB=0)
+ *   or B[k*ldb + n] (transB=1).  epi: + bias_g[n]; optional C2 <- pre-activation; act; if act_grad: multiply by
+ *   act'(aux) (aux has C's layout: ReLU uses aux>0, GELU uses the saved pre-activation); row_mask_g[z*M+m]==0
+ *   zeroes the output row; row_scale/row_fill implement mask_head.py:37-38 (C = row_fill_flag ? fill : acc*scale)
+ *   and mask_out (uint8 [batch][N][M]) receives sigmoid(C) < 0.5 (mask_head.py:43).
+ *   splitk > 1: K is split over blockIdx; C must be fp32 and is zeroed by this call, then accumulated with
+ *   atomics (no epilogue options besides alpha).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t M, N, K;
+  int32_t groups, batch;
+  int32_t ct;            /* compute type */
+  int32_t dtA, dtA2, dtB, dtC, dtC2, dtAux, dtBias;
+  int32_t transA, transB;
+  int32_t act, act_grad;
+  int32_t splitk;
+  int32_t kconcat;
+  int32_t dtB2;
+  float alpha;           /* applied to the accumulator before bias */
+  float row_fill;        /* value written to rows whose row_fill_flag != 0 */
+  int64_t lda, ldb, ldc; /* A2 shares lda; C2 / aux share ldc */
+  int64_t strideA, strideB, strideC; /* per-batch element strides (A2: strideA; C2/aux: strideC) */
+  const void* A[PQ3D_MAX_GROUPS];
+  const void* A2[PQ3D_MAX_GROUPS];
+  const void* B[PQ3D_MAX_GROUPS];
+  const void* B2[PQ3D_MAX_GROUPS];
+  const void* bias[PQ3D_MAX_GROUPS];
+  void* C[PQ3D_MAX_GROUPS];
+  void* C2[PQ3D_MAX_GROUPS];
+  const void* aux[PQ3D_MAX_GROUPS];
+  const uint8_t* row_mask[PQ3D_MAX_GROUPS];       /* [batch*M], 0 = zero the row */
+  const float* row_scale;                         /* [batch*M] or NULL (group 0 only) */
+  const uint8_t* row_fill_flag;                   /* [batch*M] or NULL */
+  uint8_t* mask_out;                              /* [batch][N][M] or NULL */
+} pq3d_gemm_desc;
+
+int pq3d_gemm(const pq3d_gemm_desc* d, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused masked multi-head attention (flash-style online softmax, never materialises [B*H,Lq,Lk]).
+ * Replaces the need_weights branch of F.multi_head_attention_forward as driven by CrossAttentionLayer
+ * (query_encoder.py:288-307, add_zero_attn=True :268-270), SelfAttentionLayer (:213-227) and, with `bias`,
+ * MultiHeadAttentionSpatial's softmax(log(clamp(loc,1e-6)) + qk/sqrt(dh)).v (transformers.py:192-237).
+ *
+ *   P[b,h,i,:] = softmax_j( scale * q[b,i,h,:].k[b,j,h,:] + bias[b,h,i,j] + mask terms  [, 0 for the zero key] )
+ *   o[b,i,h,:] = sum_j P[b,h,i,j] v[b,j,h,:]          lse[b,h,i] = log sum exp
+ *   mask terms: kpm[b,j] != 0 -> -inf; mask[b,i,j] != 0 && !(row_open && row_open[b,i]) -> -inf  (row_open
+ *   reproduces `attn_mask[attn_mask.all(-1)] = False`, query_encoder.py:83, without rewriting the mask);
+ *   zero_attn: an extra never-masked key with logit exactly 0 and value 0 (torch add_zero_attn).
+ * Tensors are addressed as base + b*sb + l*sl + h*sh + c (element strides), so both [B,L,H*dh] views of
+ * projection outputs and head-major layouts work.  dh in {16, 32, 64}.
+ * Backward (pq3d_attn_bwd) recomputes P from lse: needs o, do; writes dq/dk/dv with the strides of q/k/v,
+ * `delta` is a [B,H,Lq] fp32 workspace, dbias ([B,H,Lq,Lk] fp32, may be NULL) receives dL/dbias.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B, H, Lq, Lk, dh;
+  int32_t ct;   /* compute type */
+  int32_t dt;   /* storage dtype of q,k,v,o,do,dq,dk,dv */
+  int32_t zero_attn;
+  float scale;
+  int64_t q_sb, q_sl, q_sh;
+  int64_t k_sb, k_sl, k_sh;
+  int64_t v_sb, v_sl, v_sh;
+  int64_t o_sb, o_sl, o_sh;   /* o and do */
+  const void* q; const void* k; const void* v;
+  void* o;                    /* fwd: output; bwd: forward output (input) */
+  float* lse;                 /* [B,H,Lq] fwd: output; bwd: input */
+  const uint8_t* kpm;         /* [B,Lk] or NULL */
+  const uint8_t* mask;        /* [B,Lq,Lk] or NULL */
+  const uint8_t* row_open;    /* [B,Lq] or NULL */
+  const float* bias;          /* [B,H,Lq,Lk] or NULL */
+  /* backward only */
+  const void* dout;
+  void* dq; void* dk; void* dv;
+  float* delta;
+  float* dbias;
+} pq3d_attn_desc;
+
+int pq3d_attn_fwd(const pq3d_attn_desc* d, void* stream);
+int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
+
+/* For every (b,i): row_open[b,i] = all_j(mask[b,i,j] != 0)   (query_encoder.py:83) */
+int pq3d_mask_row_all(const uint8_t* mask, uint8_t* row_open, int64_t rows, int64_t Lk, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Residual-add + LayerNorm, optionally merged over M branches (post-norm sublayers, query_encoder.py:304-305,
+ * :224-225, :386-387, :449-450 and the parallel cross-attention mean :152 / memory-dropout mean :145-151):
+ *     y[r,:] = sum_m coef[m][r / rows_per_scene] * LN_m( x[r,:] + o_m[r,:] )        (coef NULL -> 1/M)
+ * x may be NULL (plain LN of o_m: nn.Sequential(Linear, LayerNorm) encoders, get_mlp_head's LN eps=1e-12).
+ * mean/rstd ([M,R] fp32) are saved for backward.  Backward: dx = sum_m d(x+o_m), d_o[m], dgamma[m], dbeta[m]
+ * (dgamma/dbeta are zeroed by the call and accumulated with atomics).  One 64-lane wave per row, row kept in
+ * registers (d <= 1024), two-pass statistics in fp32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t R, d, M, rows_per_scene;
+  int32_t dt_x, dt_o, dt_y;
+  float eps;
+  const void* x;
+  const void* o[PQ3D_MAX_GROUPS];
+  const float* gamma[PQ3D_MAX_GROUPS];
+  const float* beta[PQ3D_MAX_GROUPS];
+  const float* coef;
+  void* y;
+  float* mean;
+  float* rstd;
+  /* backward */
+  const float* dy;
+  float* dx;                      /* [R,d] fp32 or NULL */
+  float* d_o[PQ3D_MAX_GROUPS];    /* [R,d] fp32 each */
+  float* dgamma[PQ3D_MAX_GROUPS];
+  float* dbeta[PQ3D_MAX_GROUPS];
+} pq3d_ln_desc;
+
+int pq3d_add_ln_fwd(const pq3d_ln_desc* d, void* stream);
+int pq3d_add_ln_bwd(const pq3d_ln_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small memory-bound kernels.
+ * ------------------------------------------------------------------------------------------------ */
+/* out[n] = sum_r x[r*ld + n]  (bias gradients); out is zeroed by the call. */
+int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream);
+
+/* y[r,c] = keep(r) ? x[r,c] * scale[r] : 0, keep(r) = (!zero_flag || !zero_flag[r]) && (!keep_mask || keep_mask[r]);
+ * scale NULL -> 1.  (backward of mask_head.py:35-38 and of row-masked projections) */
+int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty, int64_t R, int64_t C, const float* scale,
+                    const uint8_t* zero_flag, const uint8_t* keep_mask, void* stream);
+
+/* dpre = dy * act'(saved): ReLU: saved = activation output (or pre-activation), GELU: saved = pre-activation. */
+int pq3d_act_bwd(const void* dy, int32_t dt_dy, const void* saved, int32_t dt_saved, void* dpre, int32_t dt_dpre,
+                 int32_t act, int64_t n, void* stream);
+
+/* y = x with columns cols[0..ncols) set to `value` (mask_head.py:28 `cls_logits[..., filter] = -inf`). */
+int pq3d_fill_cols(const float* x, float* y, int64_t R, int64_t C, const int32_t* cols, int32_t ncols, float value,
+                   void* stream);
+
+/* mask_head.py:33-37 denominators: inv_den[b,s] = 1 / (sum_m !mask_m[b,s] + 1e-8) over M uint8 masks. */
+int pq3d_mask_inv_den(const uint8_t* const* masks, int32_t M, int64_t n, float* inv_den, void* stream);
+
+/* calc_pairwise_locs (modules/utils.py:38-87; 'center', spatial_dist_norm, spatial_dim=5):
+ * centers [B,L,3] fp32 -> out [B,L,L,5] fp32. */
+int pq3d_pairwise_locs(const float* centers, int64_t center_stride, float* out, int32_t B, int32_t L, float eps,
+                       void* stream);
+
+/* Fourier positional features (position_embedding.py:127-156 + shift_scale_points :13-43):
+ * xyz [B,N,*] (row stride xyz_stride) , cmin/cmax [B,3], gauss_B [3,half] -> out [B,N,2*half] = [sin | cos]. */
+int pq3d_fourier(const float* xyz, int64_t xyz_stride, const float* cmin, const float* cmax, const float* gauss_B,
+                 float* out, int32_t B, int32_t N, int32_t half, void* stream);
+
+/* MultiHeadAttentionSpatial 'mul' fusion bias (transformers.py:196-200,226):
+ * bias[b,h,i,j] = log(max(relu(W[h,:].pl[b,i,j,:] + bw[h]), 1e-6));  backward accumulates dW [H,5], dbw [H]
+ * (zeroed by the call) from dbias. */
+int pq3d_spatial_bias_fwd(const float* pl, const float* W, const float* bw, float* bias, int32_t B, int32_t H,
+                          int32_t L, void* stream);
+int pq3d_spatial_bias_bwd(const float* pl, const float* W, const float* bw, const float* dbias, float* dW, float* dbw,
+                          int32_t B, int32_t H, int32_t L, void* stream);
+
+/* gate structure (query_encoder.py:166-170): y = (1-s)*q + s*u, s = sigmoid(g);  bwd: dq, du, dg. */
+int pq3d_gate_mix_fwd(const float* q, const float* u, const float* g, float* y, int64_t n, void* stream);
+int pq3d_gate_mix_bwd(const float* q, const float* u, const float* g, const float* dy, float* dq, float* du,
+                      float* dg, int64_t n, void* stream);
+
+/* Segment pooling torch_scatter.scatter_mean(src, index, dim=0, dim_size=S) (pcd_mask3d_encoder.py:149):
+ * src [N,C] fp32, index int64 [N] -> out [S,C] fp32; count [S] fp32 workspace/output (number of voxels per
+ * segment).  Backward: dsrc[v,:] = dout[index[v],:] / max(count,1). */
+int pq3d_scatter_mean_fwd(const float* src, const int64_t* index, float* out, float* count, int64_t N, int64_t C,
+                          int64_t S, void* stream);
+int pq3d_scatter_mean_bwd(const float* dout, const int64_t* index, const float* count, float* dsrc, int64_t N,
+                          int64_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,172 @@
+"""ctypes binding of libpq3d_hip.so (include/pq3d_hip.h).  No CPU fallback: if the library is missing or
+a call fails, a Pq3dError is raised -- the product path never routes through torch math or the oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+F32, BF16 = 0, 1
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+MAXG = 8
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpq3d_hip.so")
+
+
+class Pq3dError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32), ("batch", C.c_int32),
+        ("ct", C.c_int32),
+        ("dtA", C.c_int32), ("dtA2", C.c_int32), ("dtB", C.c_int32), ("dtC", C.c_int32), ("dtC2", C.c_int32),
+        ("dtAux", C.c_int32), ("dtBias", C.c_int32),
+        ("transA", C.c_int32), ("transB", C.c_int32), ("act", C.c_int32), ("act_grad", C.c_int32),
+        ("splitk", C.c_int32), ("kconcat", C.c_int32), ("dtB2", C.c_int32),
+        ("alpha", C.c_float), ("row_fill", C.c_float),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+        ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
+        ("A", C.c_void_p * MAXG), ("A2", C.c_void_p * MAXG), ("B", C.c_void_p * MAXG), ("B2", C.c_void_p * MAXG),
+        ("bias", C.c_void_p * MAXG), ("C", C.c_void_p * MAXG), ("C2", C.c_void_p * MAXG),
+        ("aux", C.c_void_p * MAXG), ("row_mask", C.c_void_p * MAXG),
+        ("row_scale", C.c_void_p), ("row_fill_flag", C.c_void_p), ("mask_out", C.c_void_p),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("dh", C.c_int32),
+        ("ct", C.c_int32), ("dt", C.c_int32), ("zero_attn", C.c_int32), ("scale", C.c_float),
+        ("q_sb", C.c_int64), ("q_sl", C.c_int64), ("q_sh", C.c_int64),
+        ("k_sb", C.c_int64), ("k_sl", C.c_int64), ("k_sh", C.c_int64),
+        ("v_sb", C.c_int64), ("v_sl", C.c_int64), ("v_sh", C.c_int64),
+        ("o_sb", C.c_int64), ("o_sl", C.c_int64), ("o_sh", C.c_int64),
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+        ("kpm", C.c_void_p), ("mask", C.c_void_p), ("row_open", C.c_void_p), ("bias", C.c_void_p),
+        ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+        ("delta", C.c_void_p), ("dbias", C.c_void_p),
+    ]
+
+
+class LnDesc(C.Structure):
+    _fields_ = [
+        ("R", C.c_int32), ("d", C.c_int32), ("M", C.c_int32), ("rows_per_scene", C.c_int32),
+        ("dt_x", C.c_int32), ("dt_o", C.c_int32), ("dt_y", C.c_int32), ("eps", C.c_float),
+        ("x", C.c_void_p), ("o", C.c_void_p * MAXG), ("gamma", C.c_void_p * MAXG), ("beta", C.c_void_p * MAXG),
+        ("coef", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+        ("dy", C.c_void_p), ("dx", C.c_void_p), ("d_o", C.c_void_p * MAXG), ("dgamma", C.c_void_p * MAXG),
+        ("dbeta", C.c_void_p * MAXG),
+    ]
+
+
+_lib = None
+
+_SIGS = {
+    "pq3d_gemm": [C.POINTER(GemmDesc), C.c_void_p],
+    "pq3d_attn_fwd": [C.POINTER(AttnDesc), C.c_void_p],
+    "pq3d_attn_bwd": [C.POINTER(AttnDesc), C.c_void_p],
+    "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
+    "pq3d_add_ln_fwd": [C.POINTER(LnDesc), C.c_void_p],
+    "pq3d_add_ln_bwd": [C.POINTER(LnDesc), C.c_void_p],
+    "pq3d_colsum": [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p],
+    "pq3d_scale_rows": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                        C.c_void_p, C.c_void_p],
+    "pq3d_act_bwd": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                     C.c_void_p],
+    "pq3d_fill_cols": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p],
+    "pq3d_mask_inv_den": [C.POINTER(C.c_void_p), C.c_int32, C.c_int64, C.c_void_p, C.c_void_p],
+    "pq3d_pairwise_locs": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p],
+    "pq3d_fourier": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                     C.c_int32, C.c_void_p],
+    "pq3d_spatial_bias_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                              C.c_void_p],
+    "pq3d_spatial_bias_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                              C.c_int32, C.c_int32, C.c_void_p],
+    "pq3d_gate_mix_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "pq3d_gate_mix_bwd": [C.c_void_p] * 7 + [C.c_int64, C.c_void_p],
+    "pq3d_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                              C.c_void_p],
+    "pq3d_scatter_mean_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
+}
+EXPORTS = sorted(list(_SIGS) + ["pq3d_last_error", "pq3d_version"])
+
+
+def lib() -> C.CDLL:
+    """Load (once) the in-tree shared library; raise loudly if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Pq3dError(f"{LIB_PATH} not found: build it with `python -m pq3d_amd.build` "
+                            "(there is no CPU fallback for the pq3d_amd product path)")
+        L = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.pq3d_last_error.restype = C.c_char_p
+        L.pq3d_version.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().pq3d_last_error().decode(errors="replace")
+        raise Pq3dError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise Pq3dError(f"unsupported dtype {t.dtype}")
+
+
+def tdtype(dt: int) -> torch.dtype:
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise Pq3dError("pq3d_amd kernels need device tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _fill(arr, tensors: Optional[Sequence[Optional[torch.Tensor]]]):
+    if tensors is None:
+        return
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t)
+
+
+def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C2=None, aux=None, row_mask=None,
+         transA=False, transB=False, batch=1, strideA=0, strideB=0, strideC=0, act=None, act_grad=None, splitk=1,
+         kconcat=False, alpha=1.0, row_scale=None, row_fill_flag=None, row_fill=0.0, mask_out=None) -> None:
+    d = GemmDesc()
+    d.M, d.N, d.K, d.groups, d.batch, d.ct = M, N, K, len(A), batch, ct
+    d.dtA, d.dtB, d.dtC = dt_of(A[0]), dt_of(B[0]), dt_of(Cs[0])
+    d.dtA2 = dt_of(A2[0]) if A2 and A2[0] is not None else 0
+    d.dtB2 = dt_of(B2[0]) if B2 and B2[0] is not None else 0
+    d.dtC2 = dt_of(C2[0]) if C2 and C2[0] is not None else 0
+    d.dtAux = dt_of(aux[0]) if aux and aux[0] is not None else 0
+    d.dtBias = dt_of(bias[0]) if bias and bias[0] is not None else 0
+    d.transA, d.transB = int(transA), int(transB)
+    d.act, d.act_grad, d.splitk, d.kconcat = ACT[act], ACT[act_grad], splitk, int(kconcat)
+    d.alpha, d.row_fill = alpha, row_fill
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
+    _fill(d.A, A); _fill(d.A2, A2); _fill(d.B, B); _fill(d.B2, B2); _fill(d.bias, bias); _fill(d.C, Cs)
+    _fill(d.C2, C2); _fill(d.aux, aux); _fill(d.row_mask, row_mask)
+    d.row_scale, d.row_fill_flag, d.mask_out = ptr(row_scale), ptr(row_fill_flag), ptr(mask_out)
+    check(lib().pq3d_gemm(C.byref(d), stream()), "pq3d_gemm")

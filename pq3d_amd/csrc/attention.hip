@@ -1,0 +1,468 @@
+// Fused masked multi-head attention for gfx950: forward (online softmax), backward as two recompute
+// kernels (dQ: one workgroup per query chunk looping over keys; dK/dV: one workgroup per key chunk looping
+// over queries) so no atomics are needed.  All three work on "swapped" 16x16 MFMA tiles so that softmax
+// row statistics are per-lane scalars and the probability tile in C-layout can be fed straight back as
+// the B operand of the second MFMA (no cross-lane transpose):
+//   forward / dQ :  S^T[key][query] = K . Q^T      ->  O^T[dh][query]  += V^T[dh][key]  . P^T[key][query]
+//   dK/dV        :  S  [query][key] = Q . K^T      ->  dV^T[dh][key]   += dO^T[dh][query] . P[query][key]
+// Masks: key padding [B,Lk], 3-D [B,Lq,Lk] (head broadcast) with per-row "open" override, optional fp32
+// additive bias [B,H,Lq,Lk], optional zero key (add_zero_attn) folded in as the initial state m=0, l=1.
+#include "common.h"
+
+namespace {
+
+constexpr int KB = 64;  // keys per main-loop iteration (fwd, dQ)
+constexpr int QB = 32;  // queries per main-loop iteration (dK/dV)
+constexpr int NWK = 4;  // waves per workgroup in dK/dV (16 keys each)
+
+template <typename CT, int DH> struct AT {
+  static constexpr int EPL = Mma<CT>::EPL, KSTEP = Mma<CT>::KSTEP;
+  static constexpr int DHK = ((DH + KSTEP - 1) / KSTEP) * KSTEP;  // dh rounded up to MFMA k-steps
+  static constexpr int NS = DHK / KSTEP;                          // k-steps over dh
+  static constexpr int PADE = 16 / (int)sizeof(CT);
+  static constexpr int LDR = DHK + PADE;   // row stride of a row-major [rows][dh] tile
+  static constexpr int LDT = KB + PADE;    // row stride of a transposed [dh][64] tile
+  static constexpr int LDQ = QB + PADE;    // row stride of a transposed [dh][32] tile
+  static constexpr int MT = DH / 16;       // 16-row tiles over dh
+  static constexpr int CPR = DH / EPL;     // 16-byte chunks per row
+};
+
+template <typename CT> PQ_DEV float fexp(float x);
+template <> PQ_DEV float fexp<float>(float x) { return expf(x); }
+template <> PQ_DEV float fexp<bf16_t>(float x) { return __expf(x); }
+
+// A/B fragment from a row-major tile row (k contiguous)
+template <typename CT> PQ_DEV u32x4 rfrag(const CT* row, int step, int g) {
+  return *(const u32x4*)&row[step * Mma<CT>::KSTEP + g * Mma<CT>::EPL];
+}
+// A fragment from a transposed tile row whose k index enumerates the columns of C-layout tiles:
+// bf16 step = two 16-wide tiles -> k slots {4g..4g+3} of tile 2*step and of tile 2*step+1; f32 step = one tile.
+template <typename CT> PQ_DEV u32x4 tfrag(const CT* row, int step, int g);
+template <> PQ_DEV u32x4 tfrag<bf16_t>(const bf16_t* row, int step, int g) {
+  const u32x2 lo = *(const u32x2*)&row[step * 32 + 4 * g];
+  const u32x2 hi = *(const u32x2*)&row[step * 32 + 16 + 4 * g];
+  return (u32x4){lo.x, lo.y, hi.x, hi.y};
+}
+template <> PQ_DEV u32x4 tfrag<float>(const float* row, int step, int g) {
+  return *(const u32x4*)&row[step * 16 + 4 * g];
+}
+// C-layout tiles (lane: rows 4g+r of tile t, column i) -> B fragments whose k index = tile rows.
+template <typename CT, int NTILES> struct PackP;
+template <int NTILES> struct PackP<bf16_t, NTILES> {
+  static constexpr int STEPS = NTILES / 2;
+  static PQ_DEV void run(const float (&p)[NTILES][4], u32x4 (&out)[STEPS]) {
+#pragma unroll
+    for (int u = 0; u < STEPS; ++u)
+      out[u] = (u32x4){pack_bf2(p[2 * u][0], p[2 * u][1]), pack_bf2(p[2 * u][2], p[2 * u][3]),
+                       pack_bf2(p[2 * u + 1][0], p[2 * u + 1][1]), pack_bf2(p[2 * u + 1][2], p[2 * u + 1][3])};
+  }
+};
+template <int NTILES> struct PackP<float, NTILES> {
+  static constexpr int STEPS = NTILES;
+  static PQ_DEV void run(const float (&p)[NTILES][4], u32x4 (&out)[STEPS]) {
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t)
+      out[t] = (u32x4){__float_as_uint(p[t][0]), __float_as_uint(p[t][1]), __float_as_uint(p[t][2]),
+                       __float_as_uint(p[t][3])};
+  }
+};
+
+// Cooperative global -> LDS staging of ROWS x DH elements (rows r0.., element stride sl between rows).
+// Writes a row-major copy (rm, stride LDR) and/or a transposed copy (tr, stride ldt).  Rows >= R are zero.
+template <typename CT, int DH, int ROWS>
+PQ_DEV void stage_tile(CT* rm, CT* tr, int ldt, const void* base, int dt, long off, long sl, int r0, int R, int tid,
+                       int nthreads) {
+  typedef AT<CT, DH> A;
+  for (int c = tid; c < ROWS * A::CPR; c += nthreads) {
+    const int row = c / A::CPR, kc = c % A::CPR;
+    float v[A::EPL];
+#pragma unroll
+    for (int j = 0; j < A::EPL; ++j) v[j] = 0.f;
+    if (r0 + row < R) load_elems<A::EPL>(base, dt, off + (long)(r0 + row) * sl + kc * A::EPL, A::EPL, v);
+    if (rm) *(u32x4*)&rm[row * A::LDR + kc * A::EPL] = pack_frag<CT>(v);
+    if (tr) {
+#pragma unroll
+      for (int j = 0; j < A::EPL; ++j) tr[(kc * A::EPL + j) * ldt + row] = Cvt<CT>::from(v[j]);
+    }
+  }
+}
+
+// B-operand fragments of one row (lane i = row index, g = dh slice), straight from global.
+template <typename CT, int DH>
+PQ_DEV void row_frags(u32x4* f, const void* base, int dt, long rowoff, bool valid, int g) {
+  typedef AT<CT, DH> A;
+#pragma unroll
+  for (int s = 0; s < A::NS; ++s) {
+    float v[A::EPL];
+#pragma unroll
+    for (int j = 0; j < A::EPL; ++j) v[j] = 0.f;
+    const int c0 = s * A::KSTEP + g * A::EPL;
+    if (valid && c0 < DH) load_elems<A::EPL>(base, dt, rowoff + c0, A::EPL, v);
+    f[s] = pack_frag<CT>(v);
+  }
+}
+
+template <typename CT, int DH> PQ_DEV void zero_lds(CT* p, int n, int tid, int nthreads) {
+  for (int i = tid; i < n; i += nthreads) p[i] = Cvt<CT>::from(0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename CT, int DH>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const pq3d_attn_desc d) {
+  typedef AT<CT, DH> A;
+  __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
+  __shared__ __attribute__((aligned(16))) CT Vt[DH * A::LDT];
+  __shared__ uint8_t kpm_s[KB];
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * (nthreads >> 6) + wave) * 16;
+  const int myq = q0 + li;
+  const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
+
+  if (A::DHK > DH) zero_lds<CT, DH>(Ks, KB * A::LDR, tid, nthreads);
+
+  u32x4 qf[A::NS];
+  row_frags<CT, DH>(qf, d.q, d.dt, (long)b * d.q_sb + (long)myq * d.q_sl + (long)h * d.q_sh, qvalid, lg);
+
+  float m = d.zero_attn ? 0.f : -1e30f, l = d.zero_attn ? 1.f : 0.f;
+  f32x4 acc[A::MT];
+#pragma unroll
+  for (int mt = 0; mt < A::MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool ro = (qvalid && d.row_open) ? d.row_open[(long)b * d.Lq + myq] != 0 : false;
+  const uint8_t* mrow = (d.mask && qvalid && !ro) ? d.mask + ((long)b * d.Lq + myq) * d.Lk : nullptr;
+  const float* brow = (d.bias && qvalid) ? d.bias + (((long)b * d.H + h) * d.Lq + myq) * d.Lk : nullptr;
+  const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
+
+  for (int k0 = 0; k0 < d.Lk; k0 += KB) {
+    __syncthreads();
+    stage_tile<CT, DH, KB>(Ks, nullptr, 0, d.k, d.dt, koff, d.k_sl, k0, d.Lk, tid, nthreads);
+    stage_tile<CT, DH, KB>(nullptr, Vt, A::LDT, d.v, d.dt, voff, d.v_sl, k0, d.Lk, tid, nthreads);
+    if (tid < KB) kpm_s[tid] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+    __syncthreads();
+    if (!wave_active) continue;
+
+    float p[4][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < A::NS; ++st) Mma<CT>::mma(s, rfrag<CT>(&Ks[(t * 16 + li) * A::LDR], st, lg), qf[st]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + 4 * lg + r, gk = k0 + key;
+        float x = s[r] * d.scale;
+        if (brow && gk < d.Lk) x += brow[gk];
+        const bool masked = kpm_s[key] || (mrow && gk < d.Lk && mrow[gk]);
+        x = masked ? -INFINITY : x;
+        p[t][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = fexp<CT>(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[t][r] = fexp<CT>(p[t][r] - m_new);
+        rs += p[t][r];
+      }
+    rs += __shfl_xor(rs, 16, 64);
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = m_new;
+    u32x4 pf[PackP<CT, 4>::STEPS];
+    PackP<CT, 4>::run(p, pf);
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt) {
+      acc[mt] *= alpha;
+#pragma unroll
+      for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
+        Mma<CT>::mma(acc[mt], tfrag<CT>(&Vt[(mt * 16 + li) * A::LDT], u, lg), pf[u]);
+    }
+  }
+
+  if (qvalid) {
+    const float inv = 1.f / l;
+    const long ooff = (long)b * d.o_sb + (long)myq * d.o_sl + (long)h * d.o_sh;
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) store_elem(d.o, d.dt, ooff + mt * 16 + 4 * lg + r, acc[mt][r] * inv);
+    if (lg == 0) d.lse[((long)b * d.H + h) * d.Lq + myq] = m + logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ delta
+__global__ void attn_delta_kernel(const pq3d_attn_desc d) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)d.B * d.H * d.Lq;
+  if (idx >= total) return;
+  const int q = idx % d.Lq, h = (idx / d.Lq) % d.H, b = idx / ((long)d.Lq * d.H);
+  const long off = (long)b * d.o_sb + (long)q * d.o_sl + (long)h * d.o_sh;
+  float s = 0.f;
+  for (int c = 0; c < d.dh; ++c) s += load_elem(d.o, d.dt, off + c) * load_elem(d.dout, d.dt, off + c);
+  d.delta[idx] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ (+ dbias)
+template <typename CT, int DH>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const pq3d_attn_desc d) {
+  typedef AT<CT, DH> A;
+  __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
+  __shared__ __attribute__((aligned(16))) CT Vs[KB * A::LDR];
+  __shared__ __attribute__((aligned(16))) CT Kt[DH * A::LDT];
+  __shared__ uint8_t kpm_s[KB];
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * (nthreads >> 6) + wave) * 16;
+  const int myq = q0 + li;
+  const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
+
+  if (A::DHK > DH) {
+    zero_lds<CT, DH>(Ks, KB * A::LDR, tid, nthreads);
+    zero_lds<CT, DH>(Vs, KB * A::LDR, tid, nthreads);
+  }
+  u32x4 qf[A::NS], dof[A::NS];
+  row_frags<CT, DH>(qf, d.q, d.dt, (long)b * d.q_sb + (long)myq * d.q_sl + (long)h * d.q_sh, qvalid, lg);
+  row_frags<CT, DH>(dof, d.dout, d.dt, (long)b * d.o_sb + (long)myq * d.o_sl + (long)h * d.o_sh, qvalid, lg);
+  const long sidx = ((long)b * d.H + h) * d.Lq + myq;
+  const float L = qvalid ? d.lse[sidx] : INFINITY;
+  const float Dl = qvalid ? d.delta[sidx] : 0.f;
+
+  f32x4 acc[A::MT];
+#pragma unroll
+  for (int mt = 0; mt < A::MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool ro = (qvalid && d.row_open) ? d.row_open[(long)b * d.Lq + myq] != 0 : false;
+  const uint8_t* mrow = (d.mask && qvalid && !ro) ? d.mask + ((long)b * d.Lq + myq) * d.Lk : nullptr;
+  const float* brow = (d.bias && qvalid) ? d.bias + sidx * d.Lk : nullptr;
+  float* dbrow = (d.dbias && qvalid) ? d.dbias + sidx * d.Lk : nullptr;
+  const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
+
+  for (int k0 = 0; k0 < d.Lk; k0 += KB) {
+    __syncthreads();
+    stage_tile<CT, DH, KB>(Ks, Kt, A::LDT, d.k, d.dt, koff, d.k_sl, k0, d.Lk, tid, nthreads);
+    stage_tile<CT, DH, KB>(Vs, nullptr, 0, d.v, d.dt, voff, d.v_sl, k0, d.Lk, tid, nthreads);
+    if (tid < KB) kpm_s[tid] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+    __syncthreads();
+    if (!wave_active) continue;
+
+    float ds[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < A::NS; ++st) {
+        Mma<CT>::mma(s, rfrag<CT>(&Ks[(t * 16 + li) * A::LDR], st, lg), qf[st]);
+        Mma<CT>::mma(dp, rfrag<CT>(&Vs[(t * 16 + li) * A::LDR], st, lg), dof[st]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 16 + 4 * lg + r, gk = k0 + key;
+        float x = s[r] * d.scale;
+        if (brow && gk < d.Lk) x += brow[gk];
+        const bool masked = kpm_s[key] || (mrow && gk < d.Lk && mrow[gk]);
+        const float pr = masked ? 0.f : fexp<CT>(x - L);
+        const float g = pr * (dp[r] - Dl);
+        if (dbrow && gk < d.Lk) dbrow[gk] = g;
+        ds[t][r] = g * d.scale;
+      }
+    }
+    u32x4 dsf[PackP<CT, 4>::STEPS];
+    PackP<CT, 4>::run(ds, dsf);
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+#pragma unroll
+      for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
+        Mma<CT>::mma(acc[mt], tfrag<CT>(&Kt[(mt * 16 + li) * A::LDT], u, lg), dsf[u]);
+  }
+
+  if (qvalid) {
+    const long off = (long)b * d.q_sb + (long)myq * d.q_sl + (long)h * d.q_sh;
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) store_elem(d.dq, d.dt, off + mt * 16 + 4 * lg + r, acc[mt][r]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <typename CT, int DH>
+__global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_desc d) {
+  typedef AT<CT, DH> A;
+  __shared__ __attribute__((aligned(16))) CT Qs[QB * A::LDR];
+  __shared__ __attribute__((aligned(16))) CT dOs[QB * A::LDR];
+  __shared__ __attribute__((aligned(16))) CT Qt[DH * A::LDQ];
+  __shared__ __attribute__((aligned(16))) CT dOt[DH * A::LDQ];
+  __shared__ float Ls[QB], Ds[QB];
+  __shared__ uint8_t ro_s[QB];
+  const int tid = threadIdx.x, nthreads = NWK * 64, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int key = (blockIdx.x * NWK + wave) * 16 + li;
+  const bool kvalid = key < d.Lk;
+
+  if (A::DHK > DH) {
+    zero_lds<CT, DH>(Qs, QB * A::LDR, tid, nthreads);
+    zero_lds<CT, DH>(dOs, QB * A::LDR, tid, nthreads);
+  }
+  u32x4 kf[A::NS], vf[A::NS];
+  row_frags<CT, DH>(kf, d.k, d.dt, (long)b * d.k_sb + (long)key * d.k_sl + (long)h * d.k_sh, kvalid, lg);
+  row_frags<CT, DH>(vf, d.v, d.dt, (long)b * d.v_sb + (long)key * d.v_sl + (long)h * d.v_sh, kvalid, lg);
+  const bool kmasked = kvalid ? (d.kpm ? d.kpm[(long)b * d.Lk + key] != 0 : false) : true;
+
+  f32x4 accK[A::MT], accV[A::MT];
+#pragma unroll
+  for (int mt = 0; mt < A::MT; ++mt) {
+    accK[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    accV[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const long qoff = (long)b * d.q_sb + (long)h * d.q_sh, ooff = (long)b * d.o_sb + (long)h * d.o_sh;
+  const long sbase = ((long)b * d.H + h) * d.Lq;
+
+  for (int qb = 0; qb < d.Lq; qb += QB) {
+    __syncthreads();
+    stage_tile<CT, DH, QB>(Qs, Qt, A::LDQ, d.q, d.dt, qoff, d.q_sl, qb, d.Lq, tid, nthreads);
+    stage_tile<CT, DH, QB>(dOs, dOt, A::LDQ, d.dout, d.dt, ooff, d.o_sl, qb, d.Lq, tid, nthreads);
+    if (tid < QB) {
+      const int gq = qb + tid;
+      Ls[tid] = gq < d.Lq ? d.lse[sbase + gq] : INFINITY;
+      Ds[tid] = gq < d.Lq ? d.delta[sbase + gq] : 0.f;
+      ro_s[tid] = (gq < d.Lq && d.row_open) ? d.row_open[(long)b * d.Lq + gq] : 0;
+    }
+    __syncthreads();
+
+    float pt[2][4], dst[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < A::NS; ++st) {
+        Mma<CT>::mma(s, rfrag<CT>(&Qs[(t * 16 + li) * A::LDR], st, lg), kf[st]);
+        Mma<CT>::mma(dp, rfrag<CT>(&dOs[(t * 16 + li) * A::LDR], st, lg), vf[st]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = t * 16 + 4 * lg + r, gq = qb + ql;
+        const bool inb = gq < d.Lq && kvalid;
+        float x = s[r] * d.scale;
+        if (d.bias && inb) x += d.bias[(sbase + gq) * d.Lk + key];
+        const bool masked = kmasked || (d.mask && inb && !ro_s[ql] && d.mask[((long)b * d.Lq + gq) * d.Lk + key]);
+        const float pr = masked ? 0.f : fexp<CT>(x - Ls[ql]);
+        pt[t][r] = pr;
+        dst[t][r] = pr * (dp[r] - Ds[ql]) * d.scale;
+      }
+    }
+    u32x4 pf[PackP<CT, 2>::STEPS], dsf[PackP<CT, 2>::STEPS];
+    PackP<CT, 2>::run(pt, pf);
+    PackP<CT, 2>::run(dst, dsf);
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+#pragma unroll
+      for (int u = 0; u < PackP<CT, 2>::STEPS; ++u) {
+        Mma<CT>::mma(accV[mt], tfrag<CT>(&dOt[(mt * 16 + li) * A::LDQ], u, lg), pf[u]);
+        Mma<CT>::mma(accK[mt], tfrag<CT>(&Qt[(mt * 16 + li) * A::LDQ], u, lg), dsf[u]);
+      }
+  }
+
+  if (kvalid) {
+    const long ko = (long)b * d.k_sb + (long)key * d.k_sl + (long)h * d.k_sh;
+    const long vo = (long)b * d.v_sb + (long)key * d.v_sl + (long)h * d.v_sh;
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        store_elem(d.dk, d.dt, ko + mt * 16 + 4 * lg + r, accK[mt][r]);
+        store_elem(d.dv, d.dt, vo + mt * 16 + 4 * lg + r, accV[mt][r]);
+      }
+  }
+}
+
+__global__ void mask_row_all_kernel(const uint8_t* mask, uint8_t* row_open, long rows, long Lk) {
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const uint8_t* p = mask + row * Lk;
+  int all = 1;
+  for (long j = lane; j < Lk; j += 64) all &= (p[j] != 0);
+  all = __all(all);
+  if (lane == 0) row_open[row] = all ? 1 : 0;
+}
+
+int check_desc(const pq3d_attn_desc& d) {
+  PQ_CHECK_ARG(d.B >= 0 && d.H >= 1 && d.Lq >= 0 && d.Lk >= 0, "pq3d_attn: bad sizes");
+  PQ_CHECK_ARG(d.dh == 16 || d.dh == 32 || d.dh == 64, "pq3d_attn: head dim must be 16, 32 or 64");
+  PQ_CHECK_ARG(d.ct == PQ3D_F32 || d.ct == PQ3D_BF16, "pq3d_attn: bad compute type");
+  PQ_CHECK_ARG(d.dt == PQ3D_F32 || d.dt == PQ3D_BF16, "pq3d_attn: bad storage dtype");
+  PQ_CHECK_ARG(d.q && d.k && d.v && d.o && d.lse, "pq3d_attn: null q/k/v/o/lse");
+  PQ_CHECK_ARG(d.Lk > 0 || d.zero_attn, "pq3d_attn: Lk == 0 needs zero_attn");
+  return 0;
+}
+
+template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream_t s) {
+  const int tiles = (d.Lq + 15) / 16, nw = tiles < 8 ? tiles : 8;
+  dim3 grid((tiles + nw - 1) / nw, d.H, d.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<CT, DH>), grid, dim3(nw * 64), 0, s, d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream_t s) {
+  const long total = (long)d.B * d.H * d.Lq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+  const int tiles = (d.Lq + 15) / 16, nw = tiles < 8 ? tiles : 8;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH>), dim3((tiles + nw - 1) / nw, d.H, d.B), dim3(nw * 64), 0, s, d);
+  if (d.Lk > 0)
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH>), dim3((d.Lk + NWK * 16 - 1) / (NWK * 16), d.H, d.B),
+                       dim3(NWK * 64), 0, s, d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+#define DISPATCH(fn)                                                          \
+  if (d.ct == PQ3D_BF16) {                                                    \
+    if (d.dh == 16) return fn<bf16_t, 16>(d, s);                              \
+    if (d.dh == 32) return fn<bf16_t, 32>(d, s);                              \
+    return fn<bf16_t, 64>(d, s);                                              \
+  } else {                                                                    \
+    if (d.dh == 16) return fn<float, 16>(d, s);                               \
+    if (d.dh == 32) return fn<float, 32>(d, s);                               \
+    return fn<float, 64>(d, s);                                               \
+  }
+
+}  // namespace
+
+extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_attn_fwd: null descriptor");
+  const pq3d_attn_desc d = *dp;
+  if (int e = check_desc(d)) return e;
+  if (d.B == 0 || d.Lq == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(launch_fwd)
+}
+
+extern "C" int pq3d_attn_bwd(const pq3d_attn_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_attn_bwd: null descriptor");
+  const pq3d_attn_desc d = *dp;
+  if (int e = check_desc(d)) return e;
+  PQ_CHECK_ARG(d.dout && d.dq && d.dk && d.dv && d.delta, "pq3d_attn_bwd: null dout/dq/dk/dv/delta");
+  if (d.B == 0 || d.Lq == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH(launch_bwd)
+}
+
+extern "C" int pq3d_mask_row_all(const uint8_t* mask, uint8_t* row_open, int64_t rows, int64_t Lk, void* stream) {
+  PQ_CHECK_ARG(mask && row_open && rows >= 0 && Lk >= 0, "pq3d_mask_row_all: bad args");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(mask_row_all_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mask,
+                     row_open, (long)rows, (long)Lk);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,159 @@
+// Shared device helpers for the pq3d gfx950 kernels (CDNA4 only: wave64, MFMA 16x16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pq3d_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define PQ_DEV __device__ __forceinline__
+
+PQ_DEV float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+PQ_DEV bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+PQ_DEV unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  static PQ_DEV float from(float f) { return f; }
+  static PQ_DEV float to(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+  static PQ_DEV bf16_t from(float f) { return f2bf(f); }
+  static PQ_DEV float to(bf16_t v) { return bf2f(v); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// MFMA abstraction.  One "step" consumes a 16-byte fragment per lane for A and for B:
+//   lane l: i = l & 15 (row of A / column of B), g = l >> 4 (k-group);
+//   the fragment holds EPL consecutive k elements starting at k = step*KSTEP + g*EPL.
+//   bf16: EPL = 8, KSTEP = 32 (one v_mfma_f32_16x16x32_bf16)
+//   f32 : EPL = 4, KSTEP = 16 (four v_mfma_f32_16x16x4_f32; MFMA j pairs element j of A and B, so the
+//         k order inside the step is a permutation applied identically to A and B -> same dot product).
+// C/D layout (both): lane holds C[row = 4*g + r][col = i], r = 0..3.
+// ---------------------------------------------------------------------------------------------
+template <typename CT> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int EPL = 8, KSTEP = 32;
+  typedef u32x4 Frag;
+  static PQ_DEV void mma(f32x4& c, const Frag& a, const Frag& b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int EPL = 4, KSTEP = 16;
+  typedef u32x4 Frag;
+  static PQ_DEV void mma(f32x4& c, const Frag& a, const Frag& b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+  }
+};
+
+// Load `n` (<= 8) consecutive elements of dtype `dt` (PQ3D_F32 / PQ3D_BF16) starting at element index
+// `idx` of `base` into out[0..n) as floats; elements at position >= valid are returned as 0.
+// Fast 16-byte paths when fully valid and aligned.
+template <int N>
+PQ_DEV void load_elems(const void* __restrict__ base, int dt, long idx, int valid, float (&out)[N]) {
+  if (dt == PQ3D_F32) {
+    const float* p = (const float*)base + idx;
+    if (valid >= N && ((((uintptr_t)p) & 15) == 0)) {
+#pragma unroll
+      for (int j = 0; j < N; j += 4) {
+        float4 v = *(const float4*)(p + j);
+        out[j] = v.x; out[j + 1] = v.y; out[j + 2] = v.z; out[j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) out[j] = (j < valid) ? p[j] : 0.f;
+    }
+  } else {
+    const bf16_t* p = (const bf16_t*)base + idx;
+    if (valid >= N && ((((uintptr_t)p) & (2 * N - 1)) == 0)) {
+      if (N == 8) {
+        u32x4 v = *(const u32x4*)p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          out[2 * j] = __uint_as_float(v[j] << 16);
+          out[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+        }
+      } else {
+        u32x2 v = *(const u32x2*)p;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          out[2 * j] = __uint_as_float(v[j] << 16);
+          out[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) out[j] = (j < valid) ? bf2f(p[j]) : 0.f;
+    }
+  }
+}
+
+// Pack EPL floats into one 16-byte fragment of compute type CT.
+template <typename CT> PQ_DEV u32x4 pack_frag(const float* v);
+template <> PQ_DEV u32x4 pack_frag<bf16_t>(const float* v) {
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = pack_bf2(v[2 * j], v[2 * j + 1]);
+  return r;
+}
+template <> PQ_DEV u32x4 pack_frag<float>(const float* v) {
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = __float_as_uint(v[j]);
+  return r;
+}
+
+PQ_DEV void store_elem(void* base, int dt, long idx, float v) {
+  if (dt == PQ3D_F32) ((float*)base)[idx] = v;
+  else ((bf16_t*)base)[idx] = f2bf(v);
+}
+PQ_DEV float load_elem(const void* base, int dt, long idx) {
+  return dt == PQ3D_F32 ? ((const float*)base)[idx] : bf2f(((const bf16_t*)base)[idx]);
+}
+
+PQ_DEV float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+PQ_DEV float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+PQ_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+PQ_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// host-side error plumbing (api.cpp)
+extern "C" void pq3d_set_error(const char* msg);
+#define PQ_CHECK_ARG(cond, msg)      \
+  do {                               \
+    if (!(cond)) {                   \
+      pq3d_set_error(msg);           \
+      return PQ3D_ERR_ARG;           \
+    }                                \
+  } while (0)
+#define PQ_LAUNCH_CHECK()                                  \
+  do {                                                     \
+    hipError_t e_ = hipGetLastError();                     \
+    if (e_ != hipSuccess) {                                \
+      pq3d_set_error(hipGetErrorString(e_));               \
+      return (int)e_;                                      \
+    }                                                      \
+  } while (0)

@@ -1,0 +1,365 @@
+// Small memory-bound kernels of the query-decoder path (all fp32 math, coalesced row-major access).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- colsum
+// grid (ceil(N/64), row_chunks); block 256 = 4 row-lanes x 64 columns.
+__global__ void colsum_kernel(const void* x, int dt, long R, long N, long ld, float* out) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const long col = (long)blockIdx.x * 64 + cx;
+  const long rows_per = (R + gridDim.y - 1) / gridDim.y;
+  const long r0 = (long)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+  float s = 0.f;
+  if (col < N)
+    for (long r = r0 + ry; r < r1; r += 4) s += load_elem(x, dt, r * ld + col);
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < N) unsafeAtomicAdd(&out[col], part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+}
+
+// ---------------------------------------------------------------- scale rows
+__global__ void scale_rows_kernel(const void* x, int dtx, void* y, int dty, long R, long C, const float* scale,
+                                  const uint8_t* zero_flag, const uint8_t* keep_mask) {
+  const long total = R * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const bool keep = (!zero_flag || !zero_flag[r]) && (!keep_mask || keep_mask[r]);
+    const float v = keep ? load_elem(x, dtx, i) * (scale ? scale[r] : 1.f) : 0.f;
+    store_elem(y, dty, i, v);
+  }
+}
+
+__global__ void act_bwd_kernel(const void* dy, int dt_dy, const void* saved, int dt_s, void* dpre, int dt_o, int act,
+                               long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = load_elem(dy, dt_dy, i), sv = load_elem(saved, dt_s, i);
+    float r = g;
+    if (act == PQ3D_ACT_RELU) r = sv > 0.f ? g : 0.f;
+    else if (act == PQ3D_ACT_GELU) r = g * gelu_grad_f(sv);
+    store_elem(dpre, dt_o, i, r);
+  }
+}
+
+__global__ void fill_cols_kernel(const float* x, float* y, long R, long C, const int32_t* cols, int ncols, float value) {
+  const long total = R * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    bool hit = false;
+    for (int k = 0; k < ncols; ++k) hit |= (cols[k] == c);
+    y[i] = hit ? value : x[i];
+  }
+}
+
+struct MaskPtrs { const uint8_t* p[PQ3D_MAX_GROUPS]; };
+__global__ void mask_inv_den_kernel(MaskPtrs mp, int M, long n, float* inv_den) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float den = 0.f;
+  for (int m = 0; m < M; ++m) den += mp.p[m][i] ? 0.f : 1.f;
+  inv_den[i] = 1.f / (den + 1e-8f);
+}
+
+// ---------------------------------------------------------------- pairwise locs
+// grid (ceil(L/8), B), block 256.  Every block recomputes the scene's max distance (L*L <= 4e4 pairs).
+__global__ void pairwise_locs_kernel(const float* centers, long cs, float* out, int L, float eps) {
+  __shared__ float red[4];
+  extern __shared__ float cen[];  // [L][3]
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const float* c = centers + (long)b * L * cs;
+  for (int i = tid; i < L * 3; i += blockDim.x) cen[i] = c[(long)(i / 3) * cs + (i % 3)];
+  __syncthreads();
+  float mx = 0.f;
+  for (int p = tid; p < L * L; p += blockDim.x) {
+    const int i = p / L, j = p % L;
+    const float dx = cen[3 * i] - cen[3 * j], dy = cen[3 * i + 1] - cen[3 * j + 1], dz = cen[3 * i + 2] - cen[3 * j + 2];
+    mx = fmaxf(mx, sqrtf(dx * dx + dy * dy + dz * dz + eps));
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const int i0 = blockIdx.x * 8;
+  for (int p = tid; p < 8 * L; p += blockDim.x) {
+    const int i = i0 + p / L, j = p % L;
+    if (i >= L) break;
+    const float dx = cen[3 * i] - cen[3 * j], dy = cen[3 * i + 1] - cen[3 * j + 1], dz = cen[3 * i + 2] - cen[3 * j + 2];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz + eps);
+    const float d2 = sqrtf(dx * dx + dy * dy + eps);
+    float* o = out + (((long)b * L + i) * L + j) * 5;
+    o[0] = dist / mx; o[1] = dz / dist; o[2] = d2 / dist; o[3] = dy / d2; o[4] = dx / d2;
+  }
+}
+
+// ---------------------------------------------------------------- fourier features
+__global__ void fourier_kernel(const float* xyz, long xs, const float* cmin, const float* cmax, const float* G,
+                               float* out, int B, int N, int half) {
+  const long total = (long)B * N * half;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % half);
+    const long pn = i / half;
+    const int b = (int)(pn / N);
+    const float* p = xyz + pn * xs;
+    float proj = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t = (p[c] - cmin[b * 3 + c]) / (cmax[b * 3 + c] - cmin[b * 3 + c]);
+      t *= 6.283185307179586f;
+      proj += t * G[c * half + j];
+    }
+    out[pn * 2 * half + j] = sinf(proj);
+    out[pn * 2 * half + half + j] = cosf(proj);
+  }
+}
+
+// ---------------------------------------------------------------- spatial bias
+__global__ void spatial_bias_fwd_kernel(const float* pl, const float* W, const float* bw, float* bias, int B, int H,
+                                        int L) {
+  const long LL = (long)L * L, total = (long)B * LL;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / LL, ij = i % LL;
+    float f[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) f[c] = pl[i * 5 + c];
+    for (int h = 0; h < H; ++h) {
+      float v = bw[h];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) v += W[h * 5 + c] * f[c];
+      bias[(b * H + h) * LL + ij] = logf(fmaxf(fmaxf(v, 0.f), 1e-6f));
+    }
+  }
+}
+
+// one block accumulates a grid-stride slice; per-thread partials -> LDS tree -> 6 atomics per head per block
+__global__ __launch_bounds__(256) void spatial_bias_bwd_kernel(const float* pl, const float* W, const float* bw,
+                                                               const float* dbias, float* dW, float* dbw, int B, int H,
+                                                               int L) {
+  __shared__ float red[4][6];
+  const long LL = (long)L * L, total = (long)B * LL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int h = 0; h < H; ++h) {
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const long b = i / LL, ij = i % LL;
+      float f[5];
+      float v = bw[h];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) { f[c] = pl[i * 5 + c]; v += W[h * 5 + c] * f[c]; }
+      const float g = v > 1e-6f ? dbias[(b * H + h) * LL + ij] / v : 0.f;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) acc[c] += g * f[c];
+      acc[5] += g;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float s = wave_sum(acc[c]);
+      if (lane == 0) red[wave][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      if (threadIdx.x < 5) unsafeAtomicAdd(&dW[h * 5 + threadIdx.x], s);
+      else unsafeAtomicAdd(&dbw[h], s);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- gate mix
+__global__ void gate_fwd_kernel(const float* q, const float* u, const float* g, float* y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float s = 1.f / (1.f + expf(-g[i]));
+    y[i] = (1.f - s) * q[i] + s * u[i];
+  }
+}
+__global__ void gate_bwd_kernel(const float* q, const float* u, const float* g, const float* dy, float* dq, float* du,
+                                float* dg, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float s = 1.f / (1.f + expf(-g[i]));
+    dq[i] = (1.f - s) * dy[i];
+    du[i] = s * dy[i];
+    dg[i] = dy[i] * (u[i] - q[i]) * s * (1.f - s);
+  }
+}
+
+// ---------------------------------------------------------------- scatter mean (segment pooling)
+// One thread per (voxel, 4-channel group): coalesced reads of src rows, atomics into the (L2-resident) segment
+// table.  Algorithmic bytes per scene: N*C*4 (src) + N*8 (index) + S*C*4 (out).
+__global__ void scatter_add_kernel(const float* src, const int64_t* index, float* out, float* count, long N, long C,
+                                   long S) {
+  const long total = N * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / C, c = i % C;
+    const long s = index[v];
+    if (s < 0 || s >= S) continue;
+    unsafeAtomicAdd(&out[s * C + c], src[i]);
+    if (c == 0) unsafeAtomicAdd(&count[s], 1.f);
+  }
+}
+__global__ void scatter_div_kernel(float* out, const float* count, long S, long C) {
+  const long total = S * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    out[i] /= fmaxf(count[i / C], 1.f);
+}
+__global__ void scatter_mean_bwd_kernel(const float* dout, const int64_t* index, const float* count, float* dsrc,
+                                        long N, long C) {
+  const long total = N * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long v = i / C, c = i % C, s = index[v];
+    dsrc[i] = dout[s * C + c] / fmaxf(count[s], 1.f);
+  }
+}
+
+inline unsigned grid1d(long total, int block = 256, long cap = 4096) {
+  long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+inline int memset_async(void* p, size_t bytes, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(p, 0, bytes, s);
+  if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream) {
+  PQ_CHECK_ARG(x && out && R >= 0 && N >= 1 && ld >= N, "pq3d_colsum: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = memset_async(out, sizeof(float) * N, s)) return e;
+  if (R == 0) return 0;
+  long chunks = (R + 255) / 256;
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, s, x, dt, (long)R,
+                     (long)N, (long)ld, out);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty, int64_t R, int64_t C,
+                               const float* scale, const uint8_t* zero_flag, const uint8_t* keep_mask, void* stream) {
+  PQ_CHECK_ARG(x && y && R >= 0 && C >= 1, "pq3d_scale_rows: bad args");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1d(R * C)), dim3(256), 0, (hipStream_t)stream, x, dtx, y, dty, (long)R,
+                     (long)C, scale, zero_flag, keep_mask);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_act_bwd(const void* dy, int32_t dt_dy, const void* saved, int32_t dt_saved, void* dpre,
+                            int32_t dt_dpre, int32_t act, int64_t n, void* stream) {
+  PQ_CHECK_ARG(dy && saved && dpre && n >= 0, "pq3d_act_bwd: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dy, dt_dy, saved, dt_saved,
+                     dpre, dt_dpre, act, (long)n);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_fill_cols(const float* x, float* y, int64_t R, int64_t C, const int32_t* cols, int32_t ncols,
+                              float value, void* stream) {
+  PQ_CHECK_ARG(x && y && R >= 0 && C >= 1 && ncols >= 0 && (ncols == 0 || cols), "pq3d_fill_cols: bad args");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(fill_cols_kernel, dim3(grid1d(R * C)), dim3(256), 0, (hipStream_t)stream, x, y, (long)R, (long)C,
+                     cols, ncols, value);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_mask_inv_den(const uint8_t* const* masks, int32_t M, int64_t n, float* inv_den, void* stream) {
+  PQ_CHECK_ARG(masks && M >= 1 && M <= PQ3D_MAX_GROUPS && inv_den && n >= 0, "pq3d_mask_inv_den: bad args");
+  if (n == 0) return 0;
+  MaskPtrs mp;
+  for (int m = 0; m < PQ3D_MAX_GROUPS; ++m) mp.p[m] = m < M ? masks[m] : nullptr;
+  hipLaunchKernelGGL(mask_inv_den_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mp, M,
+                     (long)n, inv_den);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_pairwise_locs(const float* centers, int64_t center_stride, float* out, int32_t B, int32_t L,
+                                  float eps, void* stream) {
+  PQ_CHECK_ARG(centers && out && B >= 0 && L >= 0 && center_stride >= 3, "pq3d_pairwise_locs: bad args");
+  PQ_CHECK_ARG((size_t)L * 3 * sizeof(float) <= 48 * 1024, "pq3d_pairwise_locs: L too large");
+  if (B == 0 || L == 0) return 0;
+  hipLaunchKernelGGL(pairwise_locs_kernel, dim3((L + 7) / 8, B), dim3(256), sizeof(float) * 3 * L, (hipStream_t)stream,
+                     centers, (long)center_stride, out, L, eps);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_fourier(const float* xyz, int64_t xyz_stride, const float* cmin, const float* cmax,
+                            const float* gauss_B, float* out, int32_t B, int32_t N, int32_t half, void* stream) {
+  PQ_CHECK_ARG(xyz && cmin && cmax && gauss_B && out && xyz_stride >= 3 && half >= 1, "pq3d_fourier: bad args");
+  if (B == 0 || N == 0) return 0;
+  hipLaunchKernelGGL(fourier_kernel, dim3(grid1d((long)B * N * half)), dim3(256), 0, (hipStream_t)stream, xyz,
+                     (long)xyz_stride, cmin, cmax, gauss_B, out, B, N, half);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_spatial_bias_fwd(const float* pl, const float* W, const float* bw, float* bias, int32_t B,
+                                     int32_t H, int32_t L, void* stream) {
+  PQ_CHECK_ARG(pl && W && bw && bias && H >= 1, "pq3d_spatial_bias_fwd: bad args");
+  if (B == 0 || L == 0) return 0;
+  hipLaunchKernelGGL(spatial_bias_fwd_kernel, dim3(grid1d((long)B * L * L)), dim3(256), 0, (hipStream_t)stream, pl, W,
+                     bw, bias, B, H, L);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_spatial_bias_bwd(const float* pl, const float* W, const float* bw, const float* dbias, float* dW,
+                                     float* dbw, int32_t B, int32_t H, int32_t L, void* stream) {
+  PQ_CHECK_ARG(pl && W && bw && dbias && dW && dbw && H >= 1, "pq3d_spatial_bias_bwd: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (int e = memset_async(dW, sizeof(float) * H * 5, s)) return e;
+  if (int e = memset_async(dbw, sizeof(float) * H, s)) return e;
+  if (B == 0 || L == 0) return 0;
+  hipLaunchKernelGGL(spatial_bias_bwd_kernel, dim3(grid1d((long)B * L * L, 256, 128)), dim3(256), 0, s, pl, W, bw,
+                     dbias, dW, dbw, B, H, L);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_gate_mix_fwd(const float* q, const float* u, const float* g, float* y, int64_t n, void* stream) {
+  PQ_CHECK_ARG(q && u && g && y && n >= 0, "pq3d_gate_mix_fwd: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, q, u, g, y, (long)n);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pq3d_gate_mix_bwd(const float* q, const float* u, const float* g, const float* dy, float* dq, float* du,
+                                 float* dg, int64_t n, void* stream) {
+  PQ_CHECK_ARG(q && u && g && dy && dq && du && dg && n >= 0, "pq3d_gate_mix_bwd: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, q, u, g, dy, dq, du, dg,
+                     (long)n);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_scatter_mean_fwd(const float* src, const int64_t* index, float* out, float* count, int64_t N,
+                                     int64_t C, int64_t S, void* stream) {
+  PQ_CHECK_ARG(src && index && out && count && N >= 0 && C >= 1 && S >= 0, "pq3d_scatter_mean_fwd: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (S == 0) return 0;
+  if (int e = memset_async(out, sizeof(float) * S * C, s)) return e;
+  if (int e = memset_async(count, sizeof(float) * S, s)) return e;
+  if (N > 0)
+    hipLaunchKernelGGL(scatter_add_kernel, dim3(grid1d(N * C, 256, 8192)), dim3(256), 0, s, src, index, out, count,
+                       (long)N, (long)C, (long)S);
+  hipLaunchKernelGGL(scatter_div_kernel, dim3(grid1d(S * C)), dim3(256), 0, s, out, count, (long)S, (long)C);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pq3d_scatter_mean_bwd(const float* dout, const int64_t* index, const float* count, float* dsrc,
+                                     int64_t N, int64_t C, void* stream) {
+  PQ_CHECK_ARG(dout && index && count && dsrc && N >= 0 && C >= 1, "pq3d_scatter_mean_bwd: bad args");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(grid1d(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dout,
+                     index, count, dsrc, (long)N, (long)C);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,187 @@
+// Residual-add + LayerNorm (merged over M branches), forward and backward.  HBM-bound: one wave per row,
+// the row lives in registers (d <= 1024 -> <= 16 values per lane), wave shuffles for the statistics,
+// fp32 math throughout.  Algorithmic bytes per row: (1 + M) reads + 1 write of d elements.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXPL = 16;  // values per lane -> d <= 1024
+constexpr int WPB = 4;     // waves (rows in flight) per block
+
+struct RowStats { float mean, rstd; };
+
+template <int PL>
+PQ_DEV RowStats row_stats(const float (&v)[PL], int d, int lane, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < PL; ++j) s += (lane + 64 * j < d) ? v[j] : 0.f;
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    const float t = v[j] - mean;
+    q += (lane + 64 * j < d) ? t * t : 0.f;
+  }
+  const float var = wave_sum(q) / (float)d;
+  return {mean, 1.f / sqrtf(var + eps)};
+}
+
+template <int PL>
+__global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc d) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (row >= d.R) return;
+  const long base = row * d.d;
+  float xr[PL], y[PL];
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    const int c = lane + 64 * j;
+    xr[j] = (d.x && c < d.d) ? load_elem(d.x, d.dt_x, base + c) : 0.f;
+    y[j] = 0.f;
+  }
+  const long scene = row / d.rows_per_scene, nscene = d.R / d.rows_per_scene;
+  for (int m = 0; m < d.M; ++m) {
+    float v[PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = c < d.d ? xr[j] + load_elem(d.o[m], d.dt_o, base + c) : 0.f;
+    }
+    const RowStats st = row_stats<PL>(v, d.d, lane, d.eps);
+    const float w = d.coef ? d.coef[m * nscene + scene] : 1.f / (float)d.M;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d.d) y[j] += w * ((v[j] - st.mean) * st.rstd * d.gamma[m][c] + d.beta[m][c]);
+    }
+    if (lane == 0) {
+      d.mean[(long)m * d.R + row] = st.mean;
+      d.rstd[(long)m * d.R + row] = st.rstd;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    const int c = lane + 64 * j;
+    if (c < d.d) store_elem(d.y, d.dt_y, base + c, y[j]);
+  }
+}
+
+// Backward: each wave walks rows with a grid stride, keeps per-lane partial dgamma/dbeta for its columns in
+// registers for all M branches is too much (M*PL*2) -> loop branches outermost within a row, accumulate the
+// parameter grads of one branch at a time into LDS-free registers by making m the OUTER loop of the kernel
+// (blockIdx.y = m).  dx (sum over branches) is then accumulated with atomics only when M > 1.
+template <int PL>
+__global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.y;
+  const long wave_id = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+  const long nscene = d.R / d.rows_per_scene;
+  float dg[PL], db[PL], gam[PL];
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    const int c = lane + 64 * j;
+    dg[j] = 0.f; db[j] = 0.f;
+    gam[j] = c < d.d ? d.gamma[m][c] : 0.f;
+  }
+  for (long row = wave_id; row < d.R; row += nwaves) {
+    const long base = row * d.d;
+    const float mean = d.mean[(long)m * d.R + row], rstd = d.rstd[(long)m * d.R + row];
+    const float w = d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M;
+    float xh[PL], dz[PL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d.d) {
+        const float v = (d.x ? load_elem(d.x, d.dt_x, base + c) : 0.f) + load_elem(d.o[m], d.dt_o, base + c);
+        const float du = w * d.dy[base + c];
+        xh[j] = (v - mean) * rstd;
+        dg[j] += du * xh[j];
+        db[j] += du;
+        dz[j] = du * gam[j];
+        s1 += dz[j];
+        s2 += dz[j] * xh[j];
+      } else { xh[j] = 0.f; dz[j] = 0.f; }
+    }
+    s1 = wave_sum(s1) / (float)d.d;
+    s2 = wave_sum(s2) / (float)d.d;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d.d) {
+        const float g = rstd * (dz[j] - s1 - xh[j] * s2);
+        d.d_o[m][base + c] = g;
+        if (d.dx) {
+          if (d.M == 1) d.dx[base + c] = g;
+          else unsafeAtomicAdd(&d.dx[base + c], g);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    const int c = lane + 64 * j;
+    if (c < d.d) {
+      unsafeAtomicAdd(&d.dgamma[m][c], dg[j]);
+      unsafeAtomicAdd(&d.dbeta[m][c], db[j]);
+    }
+  }
+}
+
+int check_ln(const pq3d_ln_desc& d, bool bwd) {
+  PQ_CHECK_ARG(d.R >= 0 && d.d >= 1 && d.d <= 64 * MAXPL, "pq3d_add_ln: d must be in [1,1024]");
+  PQ_CHECK_ARG(d.M >= 1 && d.M <= PQ3D_MAX_GROUPS, "pq3d_add_ln: M out of range");
+  PQ_CHECK_ARG(d.rows_per_scene >= 1 && (d.R % d.rows_per_scene) == 0, "pq3d_add_ln: R % rows_per_scene != 0");
+  PQ_CHECK_ARG(d.mean && d.rstd, "pq3d_add_ln: null mean/rstd");
+  for (int m = 0; m < d.M; ++m) {
+    PQ_CHECK_ARG(d.o[m] && d.gamma[m] && d.beta[m], "pq3d_add_ln: null o/gamma/beta");
+    if (bwd) PQ_CHECK_ARG(d.d_o[m] && d.dgamma[m] && d.dbeta[m], "pq3d_add_ln_bwd: null grads");
+  }
+  if (bwd) PQ_CHECK_ARG(d.dy != nullptr, "pq3d_add_ln_bwd: null dy");
+  else PQ_CHECK_ARG(d.y != nullptr, "pq3d_add_ln_fwd: null y");
+  return 0;
+}
+
+#define LN_DISPATCH(kernel, grid)                                                             \
+  if (d.d <= 64) hipLaunchKernelGGL((kernel<1>), grid, dim3(WPB * 64), 0, s, d);              \
+  else if (d.d <= 128) hipLaunchKernelGGL((kernel<2>), grid, dim3(WPB * 64), 0, s, d);        \
+  else if (d.d <= 256) hipLaunchKernelGGL((kernel<4>), grid, dim3(WPB * 64), 0, s, d);        \
+  else if (d.d <= 512) hipLaunchKernelGGL((kernel<8>), grid, dim3(WPB * 64), 0, s, d);        \
+  else hipLaunchKernelGGL((kernel<16>), grid, dim3(WPB * 64), 0, s, d);
+
+}  // namespace
+
+extern "C" int pq3d_add_ln_fwd(const pq3d_ln_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_add_ln_fwd: null descriptor");
+  const pq3d_ln_desc d = *dp;
+  if (int e = check_ln(d, false)) return e;
+  if (d.R == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((d.R + WPB - 1) / WPB));
+  LN_DISPATCH(add_ln_fwd_kernel, grid)
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_add_ln_bwd: null descriptor");
+  const pq3d_ln_desc d = *dp;
+  if (int e = check_ln(d, true)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  for (int m = 0; m < d.M; ++m) {
+    hipError_t e = hipMemsetAsync(d.dgamma[m], 0, sizeof(float) * d.d, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d.dbeta[m], 0, sizeof(float) * d.d, s);
+    if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
+  }
+  if (d.R == 0) return 0;
+  if (d.dx && d.M > 1) {
+    hipError_t e = hipMemsetAsync(d.dx, 0, sizeof(float) * (size_t)d.R * d.d, s);
+    if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
+  }
+  long nb = (d.R + WPB - 1) / WPB;
+  if (nb > 128) nb = 128;  // each wave strides over rows; bounds the number of parameter-grad atomics
+  dim3 grid((unsigned)nb, d.M);
+  LN_DISPATCH(add_ln_bwd_kernel, grid)
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

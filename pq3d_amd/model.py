@@ -1,0 +1,224 @@
+"""Query3DUnified: the hot-path top level (model/query3d_unified.py:30-238) on the HIP modules.
+
+``cfg`` is any attribute/dict-style config with the reference's layout (``cfg.model.memories``,
+``cfg.model.unified_encoder.args`` ...; OmegaConf DictConfig, a plain nested dict or ``Cfg`` below).
+Modules are looked up by the reference's class *names* in ``REGISTRY`` (modules/build.py:24-31)."""
+from __future__ import annotations
+
+from copy import copy
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import modules as M
+from . import ops
+
+
+class Cfg(dict):
+    """Nested attribute dict with .get (stands in for OmegaConf's DictConfig)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in {**(d or {}), **kw}.items():
+            self[k] = Cfg(v) if isinstance(v, dict) and not isinstance(v, Cfg) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+REGISTRY = {c.__name__: c for c in (M.QueryMaskEncoder, M.QueryEncoder, M.MaskHeadSegLevel, M.GroundHead,
+                                    M.ObjectEncoder)}
+
+
+def _to_dict(c):
+    try:
+        from omegaconf import OmegaConf  # type: ignore
+        if OmegaConf.is_config(c):
+            return OmegaConf.to_container(c, resolve=True)
+    except ImportError:
+        pass
+    return {k: (_to_dict(v) if isinstance(v, dict) else v) for k, v in dict(c).items()}
+
+
+def build_module_by_name(cfg):
+    """modules/build.py:24-31."""
+    if cfg.name not in REGISTRY:
+        raise NotImplementedError(f"Unknown module: {cfg.name}")
+    kwargs = _to_dict(cfg.args) if hasattr(cfg, "args") or "args" in cfg else {}
+    return REGISTRY[cfg.name](cfg, **kwargs)
+
+
+def no_decay_param_group(parameters, lr, name=""):
+    """optim/utils.py:1-18."""
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    decay_params, no_decay_params = [], []
+    for n, p in parameters:
+        if not p.requires_grad:
+            continue
+        (no_decay_params if any(nd in n for nd in no_decay) else decay_params).append(p)
+    return [{"params": decay_params, "name": name, "weight_decay": 0.01, "lr": lr},
+            {"params": no_decay_params, "name": name, "weight_decay": 0.0, "lr": lr}]
+
+
+class Query3DUnified(nn.Module):
+    """model/query3d_unified.py:30-238.  Supported inputs: offline voxel features (``use_offline_voxel_fts``),
+    mv / pc segment features, and a pre-encoded prompt memory (``data_dict['prompt_feat']`` [B,T,d]) in place of the
+    out-of-scope CLIP text encoder.  Heads: 'mask', 'ground' (the T5 'generation' body is third-party, §8f-3)."""
+
+    def __init__(self, cfg, compute: str = "bf16"):
+        super().__init__()
+        self.cfg = cfg
+        self.memories = list(cfg.model.memories)
+        self.heads = list(cfg.model.heads)
+        self.use_offline_voxel_fts = cfg.model.get("use_offline_voxel_fts", False)
+        self.use_offline_attn_mask = cfg.model.get("use_offline_attn_mask", False)
+        self.inputs = self.memories[:]
+        self.pairwise_rel_type = cfg.model.obj_loc.pairwise_rel_type
+        self.spatial_dim = cfg.model.obj_loc.spatial_dim
+        self.num_heads = cfg.model.unified_encoder.args.num_attention_heads
+        self.skip_query_encoder_mask_pred = cfg.model.get("skip_query_encoder_mask_pred", False)
+        for inp in self.inputs:
+            if inp == "prompt":
+                continue  # text encoder out of scope: prompt memory arrives pre-encoded
+            if inp == "voxel" and not self.use_offline_voxel_fts:
+                raise NotImplementedError("online voxel backbone (MinkowskiEngine) is out of scope; "
+                                          "set use_offline_voxel_fts")
+            setattr(self, inp + "_encoder", build_module_by_name(cfg.model.get(inp + "_encoder")))
+        self.dim_loc = cfg.model.obj_loc.dim_loc
+        self.hidden_size = hidden_size = cfg.model.hidden_size
+        if self.dim_loc > 3:
+            self.coord_encoder = nn.Sequential(nn.Linear(3, hidden_size), nn.LayerNorm(hidden_size))
+            self.box_encoder = nn.Sequential(nn.Linear(3, hidden_size), nn.LayerNorm(hidden_size))
+        else:
+            self.coord_encoder = M.CoordinateEncoder(hidden_size)
+        self.unified_encoder = build_module_by_name(cfg.model.unified_encoder)
+        for head in self.heads:
+            if head == "generation":
+                raise NotImplementedError("generation head (HF T5 body) is a 'next' row (SURVEY §8f-3)")
+            setattr(self, head + "_head", build_module_by_name(cfg.model.get(head + "_head")))
+        self.compute = compute
+        M.set_compute(self, compute)
+
+    @property
+    def ct(self):
+        return M.CT[self.compute]
+
+    def _pos(self, locs, coord_min, coord_max, box_times=1):
+        if self.dim_loc > 3:
+            ct = self.ct
+            c = ops.linear(locs[:, :, :3].contiguous(), self.coord_encoder[0].weight, self.coord_encoder[0].bias, ct=ct)
+            b = ops.linear(locs[:, :, 3:6].contiguous(), self.box_encoder[0].weight, self.box_encoder[0].bias, ct=ct)
+            B = locs.shape[0]
+            coef = torch.tensor([[1.0] * B, [float(box_times)] * B], device=locs.device)
+            return ops.add_layernorm(None, [c, b], [self.coord_encoder[1].weight, self.box_encoder[1].weight],
+                                     [self.coord_encoder[1].bias, self.box_encoder[1].bias],
+                                     eps=self.coord_encoder[1].eps, coef=coef)
+        return self.coord_encoder(locs[:, :, :3], input_range=[coord_min, coord_max])
+
+    def forward(self, data_dict):
+        input_dict = {}
+        mask = data_dict["query_pad_masks"].logical_not()
+        query_locs = data_dict["query_locs"][:, :, :self.dim_loc]
+        coord_min, coord_max = data_dict["coord_min"], data_dict["coord_max"]
+        query_pos = self._pos(query_locs, coord_min, coord_max)
+        input_dict["query"] = (torch.zeros_like(query_pos), mask, query_pos)
+        # NB dim_loc > 3: the reference adds the box embedding to fts_pos twice (query3d_unified.py:128,131-132)
+        fts_pos = self._pos(data_dict["seg_center"], coord_min, coord_max, box_times=2)
+        for inp in self.inputs:
+            if inp == "prompt":
+                feat, mask, pos = data_dict["prompt_feat"], data_dict["prompt_pad_masks"].logical_not(), None
+            elif inp in ("mv", "pc"):
+                feat = getattr(self, inp + "_encoder")(obj_feats=data_dict[inp + "_seg_fts"])
+                mask, pos = data_dict[inp + "_seg_pad_masks"].logical_not(), fts_pos
+            elif inp == "voxel":
+                feat = self.voxel_encoder(data_dict["voxel_seg_fts"])
+                mask, pos = data_dict["voxel_seg_pad_masks"].logical_not(), fts_pos
+            else:
+                raise NotImplementedError(f"Unknow input type: {inp}")
+            input_dict[inp] = [feat, mask, pos]
+        offline_attn_masks = data_dict["offline_attn_mask"] if self.use_offline_attn_mask else None
+        seg_fts_for_match = []
+        for inp in self.inputs:
+            if inp in ("voxel", "mv", "pc"):
+                feats = copy(input_dict[inp][:])
+                if isinstance(feats[0], list):
+                    feats[0] = feats[0][-1]
+                seg_fts_for_match.append(feats)
+        if hasattr(self, "mask_head"):
+            seg_masks = data_dict["seg_pad_masks"].logical_not()
+            # k_proj(seg feats) is layer-invariant: project once, reuse in all L*n_b+1 mask-head calls
+            keys = self.mask_head.project_keys(seg_fts_for_match)
+            mask_head_partial = partial(self.mask_head, seg_fts_for_match=seg_fts_for_match, seg_masks=seg_masks,
+                                        offline_attn_masks=offline_attn_masks,
+                                        skip_prediction=self.skip_query_encoder_mask_pred, keys=keys)
+        else:
+            mask_head_partial = None
+        if self.unified_encoder.spatial_selfattn:
+            pairwise_locs = M.calc_pairwise_locs(query_locs[:, :, :3], None, pairwise_rel_type=self.pairwise_rel_type,
+                                                 spatial_dist_norm=True, spatial_dim=self.spatial_dim)
+        else:
+            pairwise_locs = None
+
+        query, predictions_class, predictions_mask = self.unified_encoder(input_dict, pairwise_locs, mask_head_partial)
+
+        for head in self.heads:
+            if head == "ground":
+                logits = self.ground_head(query, data_dict["query_pad_masks"])
+                data_dict["ground_logits"] = logits
+                data_dict["og3d_logits"] = logits
+                data_dict["ground_label"] = data_dict.get("tgt_object_id")
+            elif head == "mask":
+                if self.skip_query_encoder_mask_pred:
+                    predictions_class, predictions_mask = [], []
+                pred_logits, pred_masks, _ = mask_head_partial(query=query, skip_prediction=False)
+                predictions_class.append(pred_logits)
+                predictions_mask.append(pred_masks)
+                data_dict["predictions_class"] = predictions_class
+                data_dict["predictions_mask"] = predictions_mask
+            else:
+                raise NotImplementedError(f"Unknow head type: {head}")
+        data_dict["query_embeds"] = query  # extra key (the reference does not expose the final query)
+        return data_dict
+
+    def get_opt_params(self):
+        """model/query3d_unified.py:224-238."""
+        def get_lr(c, default_lr):
+            return default_lr if c is None or c.get("lr") is None else c.get("lr")
+
+        groups = []
+        for name, module in self._modules.items():
+            lr = get_lr(self.cfg.model.get(name), self.cfg.solver.lr)
+            groups += no_decay_param_group(module.named_parameters(), lr, name=name)
+        n = sum(len(g["params"]) for g in groups)
+        assert n == len(list(self.parameters())), "Some parameters are not optimized!"
+        return groups
+
+
+def make_cfg(*, d, H, L, memories, heads, d_in=None, spatial=True, structure="parallel", use_self_mask=False,
+             num_blocks=1, dim_loc=3, C=201, foc=(), drop_test=(), offline_attn=False, skip_pred=False,
+             activation="relu", ground_hidden=None) -> Cfg:
+    """Config with the reference YAML layout (configs/instseg_sceneverse.yaml:92-155) for synthetic runs."""
+    d_in = d_in or {m: d for m in memories}
+    model = {"name": "Query3DUnified", "memories": list(memories), "heads": list(heads), "hidden_size": d,
+             "use_offline_voxel_fts": True, "use_offline_attn_mask": offline_attn,
+             "skip_query_encoder_mask_pred": skip_pred,
+             "obj_loc": {"spatial_dim": 5, "dim_loc": dim_loc, "pairwise_rel_type": "center"},
+             "unified_encoder": {"name": "QueryMaskEncoder", "args": {
+                 "hidden_size": d, "num_attention_heads": H, "num_layers": L, "spatial_selfattn": spatial,
+                 "memories": list(memories), "structure": structure, "use_self_mask": use_self_mask,
+                 "num_blocks": num_blocks, "drop_memories_test": list(drop_test), "activation": activation}},
+             "mask_head": {"name": "MaskHeadSegLevel", "args": {"hidden_size": d, "num_targets": C,
+                                                                 "memories_for_match": list(memories),
+                                                                 "filter_out_classes": list(foc)}},
+             "ground_head": {"name": "GroundHead", "args": {"input_size": d, "hidden_size": ground_hidden or d // 2,
+                                                             "dropout": 0.3}}}
+    for m in memories:
+        if m != "prompt":
+            model[f"{m}_encoder"] = {"name": "ObjectEncoder", "args": {
+                "input_feat_size": d_in[m], "hidden_size": d, "use_projection": True, "use_cls_head": False,
+                "dropout": 0.1}}
+    return Cfg({"model": model, "solver": {"lr": 1e-4}})

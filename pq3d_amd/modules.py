@@ -1,0 +1,510 @@
+"""nn.Modules of the promptable query decoder with the reference's class names, constructor signatures,
+forward contracts and state_dict keys, computing through the HIP kernels in ``ops``.
+
+nn.Linear / nn.LayerNorm / nn.Sequential instances below are *parameter containers* only (they give the
+reference's state_dict key names and let DDP / optimisers see ordinary leaf Parameters); their forward() is
+never called.  ``compute`` selects the MFMA path: 'bf16' (bf16 operands, fp32 accumulate / softmax / LayerNorm /
+residual stream) or 'fp32' (exact-f32 MFMA everywhere).
+
+Dropout: the reference trains with p=0.1; these modules implement the p=0 (eval / parity) arithmetic only and
+ignore the ``dropout`` constructor arguments (DESIGN.md "out of scope").
+"""
+from __future__ import annotations
+
+import copy
+import math
+from functools import partial
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import BF16, F32
+
+CT = {"bf16": BF16, "fp32": F32}
+
+
+def set_compute(module: nn.Module, compute: str) -> nn.Module:
+    """Select 'bf16' or 'fp32' MFMA path for every pq3d module below ``module``."""
+    assert compute in CT
+    for m in module.modules():
+        if hasattr(m, "compute"):
+            m.compute = compute
+    return module
+
+
+def _init_weights_bert(module: nn.Module, std: float = 0.02) -> None:
+    """modules/weights.py:3-20."""
+    if isinstance(module, nn.Linear):
+        module.weight.data.normal_(mean=0.0, std=std)
+        if module.bias is not None:
+            module.bias.data.zero_()
+    elif isinstance(module, nn.LayerNorm):
+        module.bias.data.zero_()
+        module.weight.data.fill_(1.0)
+
+
+def layer_repeat(module: nn.Module, N: int, share_layer: bool = False) -> nn.ModuleList:
+    """modules/utils.py:28-32 (deep copies: all repeats start identical)."""
+    if share_layer:
+        return nn.ModuleList([module] * N)
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N - 1)] + [module])
+
+
+def get_mlp_head(input_size: int, hidden_size: int, output_size: int, dropout: float = 0) -> nn.Sequential:
+    """Parameter container with the key layout of modules/utils.py:18-25 ('0', '2', '4')."""
+    return nn.Sequential(nn.Linear(input_size, hidden_size), nn.ReLU(), nn.LayerNorm(hidden_size, eps=1e-12),
+                         nn.Dropout(dropout), nn.Linear(hidden_size, output_size))
+
+
+def mlp_head_forward(seq: nn.Sequential, x: torch.Tensor, ct: int, fill_flag=None, fill_value=0.0) -> torch.Tensor:
+    h = ops.linear(x, seq[0].weight, seq[0].bias, ct=ct, act="relu", out_dtype=torch.float32)
+    h = ops.add_layernorm(None, [h], [seq[2].weight], [seq[2].bias], eps=seq[2].eps)
+    return ops.linear(h, seq[4].weight, seq[4].bias, ct=ct, fill_flag=fill_flag, fill_value=fill_value)
+
+
+def linear_ln_forward(seq: nn.Sequential, x: torch.Tensor, ct: int) -> torch.Tensor:
+    """nn.Sequential(Linear, LayerNorm) as used by the encoders (object_encoder.py:34, query3d_unified.py:20,63-70)."""
+    y = ops.linear(x, seq[0].weight, seq[0].bias, ct=ct)
+    return ops.add_layernorm(None, [y], [seq[1].weight], [seq[1].bias], eps=seq[1].eps)
+
+
+def _xavier(module: nn.Module) -> None:
+    for p in module.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+class _MHAParams(nn.Module):
+    """Parameter layout of nn.MultiheadAttention (packed in_proj + out_proj)."""
+
+    def __init__(self, d_model: int, nhead: int):
+        super().__init__()
+        assert d_model % nhead == 0
+        self.embed_dim, self.num_heads = d_model, nhead
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = nn.Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+def _split_mask(mask: Optional[torch.Tensor], B: int, H: int):
+    """2-D mask -> key padding; 3-D [B,Lq,Lk] or the reference's [B*H,Lq,Lk] (head-broadcast) -> attn mask."""
+    if mask is None:
+        return None, None
+    if mask.ndim == 2:
+        return mask, None
+    if mask.shape[0] == B * H and H > 1:
+        mask = mask.view(B, H, *mask.shape[1:])[:, 0]
+    return None, mask
+
+
+class _PostNormBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.compute = "bf16"
+
+    @property
+    def ct(self) -> int:
+        return CT[self.compute]
+
+
+class CrossAttentionLayer(_PostNormBase):
+    """query_encoder.py:257-351 (post-norm, add_zero_attn=True)."""
+
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False, batch_first=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("pre-norm is not used by the reference decoder (prenorm=False)")
+        self.multihead_attn = _MHAParams(d_model, nhead)
+        self.norm = nn.LayerNorm(d_model)
+        self.nhead = nhead
+        _xavier(self)
+
+    def branch(self, tgt, memory, attn_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
+               row_open=None) -> torch.Tensor:
+        """out_proj(MHA(tgt+query_pos, memory+pos, memory)) -- the pre-residual branch output, fp32."""
+        ct, d = self.ct, tgt.shape[-1]
+        w, b = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
+        ad = ops.act_dtype(ct)
+        q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=ct, out_dtype=ad)
+        k = ops.linear(memory, w[d:2 * d], b[d:2 * d], x2=pos, ct=ct, out_dtype=ad)
+        v = ops.linear(memory, w[2 * d:], b[2 * d:], ct=ct, out_dtype=ad)
+        o = ops.attention(q, k, v, H=self.nhead, ct=ct, zero_attn=True, kpm=memory_key_padding_mask, mask=attn_mask,
+                          row_open=row_open)
+        return ops.linear(o, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, ct=ct)
+
+    def forward(self, tgt, memory, attn_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
+                row_open=None):
+        o = self.branch(tgt, memory, attn_mask, memory_key_padding_mask, pos, query_pos, row_open)
+        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps, coef=None)
+
+
+class SelfAttentionLayer(_PostNormBase):
+    """query_encoder.py:184-254 (stock MHA, no zero-attn)."""
+
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False, batch_first=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("pre-norm is not used by the reference decoder (prenorm=False)")
+        self.self_attn = _MHAParams(d_model, nhead)
+        self.norm = nn.LayerNorm(d_model)
+        self.nhead = nhead
+        _xavier(self)
+
+    def forward(self, tgt, attn_mask=None, tgt_key_padding_mask=None, query_pos=None):
+        ct, d = self.ct, tgt.shape[-1]
+        w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
+        ad = ops.act_dtype(ct)
+        q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=ct, out_dtype=ad)
+        k = ops.linear(tgt, w[d:2 * d], b[d:2 * d], x2=query_pos, ct=ct, out_dtype=ad)
+        v = ops.linear(tgt, w[2 * d:], b[2 * d:], ct=ct, out_dtype=ad)
+        o = ops.attention(q, k, v, H=self.nhead, ct=ct, kpm=tgt_key_padding_mask, mask=attn_mask)
+        o = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, ct=ct)
+        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+
+
+class MultiHeadAttentionSpatial(_PostNormBase):
+    """modules/layers/transformers.py:158-240, spatial_attn_fusion='mul', spatial_multihead=True."""
+
+    def __init__(self, d_model, n_head, dropout=0.1, spatial_multihead=True, spatial_dim=5, spatial_attn_fusion="mul"):
+        super().__init__()
+        if spatial_attn_fusion != "mul" or not spatial_multihead or spatial_dim != 5:
+            raise NotImplementedError("only the configuration the decoder instantiates is implemented "
+                                      "(fusion='mul', multihead, spatial_dim=5; query_encoder.py:411-416)")
+        assert d_model % n_head == 0
+        self.n_head, self.d_model = n_head, d_model
+        self.w_qs, self.w_ks, self.w_vs = (nn.Linear(d_model, d_model) for _ in range(3))
+        self.fc = nn.Linear(d_model, d_model)
+        self.pairwise_loc_fc = nn.Linear(spatial_dim, n_head)
+
+    def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, q_pos=None, k_pos=None):
+        """Returns only the output (the reference also returns the fused attention map, which the decoder
+        discards, query_encoder.py:447).  q_pos/k_pos are added to q/k inside the projection kernels."""
+        ct, ad = self.ct, ops.act_dtype(self.ct)
+        qh = ops.linear(q, self.w_qs.weight, self.w_qs.bias, x2=q_pos, ct=ct, out_dtype=ad)
+        kh = ops.linear(k, self.w_ks.weight, self.w_ks.bias, x2=k_pos, ct=ct, out_dtype=ad)
+        vh = ops.linear(v, self.w_vs.weight, self.w_vs.bias, ct=ct, out_dtype=ad)
+        bias = ops.spatial_bias(pairwise_locs, self.pairwise_loc_fc.weight, self.pairwise_loc_fc.bias)
+        o = ops.attention(qh, kh, vh, H=self.n_head, ct=ct, kpm=key_padding_mask, bias=bias)
+        return ops.linear(o, self.fc.weight, self.fc.bias, ct=ct)
+
+
+class SpatialSelfAttentionLayer(_PostNormBase):
+    """query_encoder.py:402-483."""
+
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False, batch_first=False,
+                 spatial_multihead=True, spatial_dim=5, spatial_attn_fusion="mul"):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("pre-norm is not used by the reference decoder (prenorm=False)")
+        self.self_attn = MultiHeadAttentionSpatial(d_model, nhead, dropout=dropout, spatial_multihead=spatial_multihead,
+                                                   spatial_dim=spatial_dim, spatial_attn_fusion=spatial_attn_fusion)
+        self.norm = nn.LayerNorm(d_model)
+        _xavier(self)
+
+    def forward(self, tgt, attn_mask=None, tgt_key_padding_mask=None, query_pos=None, pairwise_locs=None):
+        o = self.self_attn(tgt, tgt, tgt, pairwise_locs, key_padding_mask=tgt_key_padding_mask, q_pos=query_pos,
+                           k_pos=query_pos)
+        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+
+
+class FFNLayer(_PostNormBase):
+    """query_encoder.py:354-399."""
+
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("pre-norm is not used by the reference decoder (prenorm=False)")
+        if activation not in ("relu", "gelu"):
+            raise RuntimeError(f"activation function currently support relu/gelu, not {activation}")
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        self.activation = activation
+        _xavier(self)
+
+    def forward(self, tgt):
+        ct = self.ct
+        h = ops.linear(tgt, self.linear1.weight, self.linear1.bias, ct=ct, act=self.activation,
+                       out_dtype=ops.act_dtype(ct))
+        y = ops.linear(h, self.linear2.weight, self.linear2.bias, ct=ct)
+        return ops.add_layernorm(tgt, [y], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+
+
+class QueryEncoderLayer(_PostNormBase):
+    """query_encoder.py:96-181."""
+
+    def __init__(self, d_model, nhead, memories, dim_feedforward=2048, dropout=0.1, activation="relu", prenorm=False,
+                 spatial_selfattn=False, structure="mixed", memory_dropout=0, drop_memories_test=[]):
+        super().__init__()
+        if spatial_selfattn:
+            self.self_attn = SpatialSelfAttentionLayer(d_model, nhead, dropout=dropout, activation=activation,
+                                                       normalize_before=prenorm, batch_first=True)
+        else:
+            self.self_attn = SelfAttentionLayer(d_model, nhead, dropout=dropout, activation=activation,
+                                                normalize_before=prenorm, batch_first=True)
+        ca = CrossAttentionLayer(d_model, nhead, dropout=dropout, activation=activation, normalize_before=prenorm,
+                                 batch_first=True)
+        self.cross_attn_list = layer_repeat(ca, len(memories))
+        self.memory2ca = {m: c for m, c in zip(memories, self.cross_attn_list)}
+        self.ffn = FFNLayer(d_model, dim_feedforward, dropout=dropout, activation=activation, normalize_before=prenorm)
+        self.structure = structure
+        self.memories = list(memories)
+        self.memory_dropout = memory_dropout
+        self.drop_memories_test = list(drop_memories_test)
+        if structure == "gate":
+            self.gate_proj = nn.Linear(d_model, d_model)
+
+    def forward(self, query, input_dict, pairwise_locs=None):
+        _, query_masks, query_pos = input_dict["query"][:3]
+        B, H = query.shape[0], self.cross_attn_list[0].nhead if len(self.cross_attn_list) else 1
+        row_open = input_dict.get("_attn_row_open")
+
+        def ca_args(memory):
+            feat, mask, pos = input_dict[memory][:3]
+            kpm, am = _split_mask(mask, B, H)
+            return dict(memory=feat, attn_mask=am, memory_key_padding_mask=kpm, pos=pos, query_pos=query_pos,
+                        row_open=row_open if am is not None else None)
+
+        def sequential_ca(q, memories):
+            for m in memories:
+                q = self.memory2ca[m](q, **ca_args(m))
+            return q
+
+        def parallel_ca(q, memories):
+            assert "prompt" not in memories
+            cas = [self.memory2ca[m] for m in memories]
+            outs = [ca.branch(q, **ca_args(m)) for ca, m in zip(cas, memories)]
+            coef = None
+            if self.training and self.memory_dropout > 0.0:  # query_encoder.py:145-151
+                keep = torch.rand(B, len(memories), device=q.device) > self.memory_dropout
+                keep = torch.logical_or(keep, keep.sum(1, keepdim=True) == 0)
+                coef = (keep / keep.sum(1, keepdim=True)).t().contiguous().float()  # [M,B]
+            return ops.add_layernorm(q, outs, [c.norm.weight for c in cas], [c.norm.bias for c in cas],
+                                     eps=cas[0].norm.eps, coef=coef)
+
+        memories = self.memories if self.training else [m for m in self.memories if m not in self.drop_memories_test]
+        if self.structure == "sequential":
+            query = sequential_ca(query, memories)
+        elif self.structure == "parallel":
+            query = parallel_ca(query, memories)
+        elif self.structure == "mixed":
+            query = parallel_ca(query, [m for m in memories if m != "prompt"])
+            query = sequential_ca(query, ["prompt"])
+        elif self.structure == "gate":
+            prompt = sequential_ca(query, ["prompt"])
+            gate = ops.linear(prompt, self.gate_proj.weight, self.gate_proj.bias, ct=self.ct)
+            update = parallel_ca(query, [m for m in self.memories if m != "prompt"])
+            query = ops.gate_mix(query, update, gate)
+        else:
+            raise NotImplementedError(f"Unknow structure type: {self.structure}")
+
+        if isinstance(self.self_attn, SpatialSelfAttentionLayer):
+            query = self.self_attn(query, tgt_key_padding_mask=query_masks, query_pos=query_pos,
+                                   pairwise_locs=pairwise_locs)
+        else:
+            query = self.self_attn(query, tgt_key_padding_mask=query_masks, query_pos=query_pos)
+        return self.ffn(query)
+
+
+class QueryMaskEncoder(nn.Module):
+    """query_encoder.py:52-94.  forward(input_dict, pairwise_locs, mask_head=None) ->
+    (query, predictions_class, predictions_mask); mutates input_dict[memory][1] like the reference, except that the
+    self-mask is kept as [B,Nq,Ns] (head broadcast in-kernel) and fully-masked rows are opened through a [B,Nq] flag
+    (input_dict['_attn_row_open']) instead of rewriting / repeat_interleaving the mask."""
+
+    def __init__(self, cfg, memories=[], memory_dropout=0.0, hidden_size=768, num_attention_heads=12, num_layers=4,
+                 share_layer=False, spatial_selfattn=False, structure="sequential", drop_memories_test=[],
+                 use_self_mask=False, num_blocks=1, activation="relu", compute="bf16"):
+        super().__init__()
+        self.spatial_selfattn = spatial_selfattn
+        layer = QueryEncoderLayer(hidden_size, num_attention_heads, memories, spatial_selfattn=spatial_selfattn,
+                                  structure=structure, memory_dropout=memory_dropout,
+                                  drop_memories_test=drop_memories_test, activation=activation)
+        self.unified_encoder = layer_repeat(layer, num_layers, share_layer)
+        self.apply(_init_weights_bert)
+        self.memory_dropout = memory_dropout
+        self.scene_meomories = [x for x in memories if x != "prompt"]
+        self.drop_memories_test = drop_memories_test
+        self.use_self_mask = use_self_mask
+        self.num_heads = num_attention_heads
+        self.num_blocks = num_blocks
+        set_compute(self, compute)
+
+    def forward(self, input_dict, pairwise_locs, mask_head=None):
+        predictions_class, predictions_mask = [], []
+        query = input_dict["query"][0]
+        voxel_feat = input_dict["voxel"][0] if "voxel" in input_dict.keys() else None
+        attn_mask = None
+        for _block in range(self.num_blocks):
+            for i, layer in enumerate(self.unified_encoder):
+                if mask_head is not None:
+                    output_class, outputs_mask, attn_mask = mask_head(query)
+                    predictions_class.append(output_class)
+                    predictions_mask.append(outputs_mask)
+                if self.use_self_mask:
+                    if attn_mask.shape[0] != query.shape[0]:
+                        attn_mask = attn_mask.view(query.shape[0], -1, *attn_mask.shape[1:])[:, 0]
+                    input_dict["_attn_row_open"] = ops.mask_row_all(attn_mask)
+                    for memory in input_dict.keys():
+                        if memory in ("query", "prompt") or memory.startswith("_"):
+                            continue
+                        input_dict[memory][1] = attn_mask
+                if isinstance(voxel_feat, list):
+                    input_dict["voxel"][0] = voxel_feat[i]
+                query = layer(query, input_dict, pairwise_locs)
+        return query, predictions_class, predictions_mask
+
+
+class QueryEncoder(nn.Module):
+    """query_encoder.py:11-49 (no mask head / self mask)."""
+
+    def __init__(self, cfg, memories=[], memory_dropout=0.0, hidden_size=768, num_attention_heads=12, num_layers=4,
+                 share_layer=False, spatial_selfattn=False, structure="sequential", drop_memories_test=[],
+                 compute="bf16"):
+        super().__init__()
+        self.spatial_selfattn = spatial_selfattn
+        layer = QueryEncoderLayer(hidden_size, num_attention_heads, memories, spatial_selfattn=spatial_selfattn,
+                                  structure=structure)
+        self.unified_encoder = layer_repeat(layer, num_layers, share_layer)
+        self.apply(_init_weights_bert)
+        set_compute(self, compute)
+
+    def forward(self, input_dict, pairwise_locs):
+        query = input_dict["query"][0]
+        voxel_feat = input_dict["voxel"][0] if "voxel" in input_dict.keys() else None
+        for i, layer in enumerate(self.unified_encoder):
+            if isinstance(voxel_feat, list):
+                input_dict["voxel"][0] = voxel_feat[i]
+            query = layer(query, input_dict, pairwise_locs)
+        return query
+
+
+# ------------------------------------------------------------------------------------------------ heads
+class MaskPredictionLayer(nn.Module):
+    """mask_head.py:46-57 (parameter container; the einsum runs inside ops.mask_logits)."""
+
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.q_proj = nn.Linear(hidden_size, hidden_size)
+        self.k_proj = nn.Linear(hidden_size, hidden_size, False)
+
+
+class MaskHeadSegLevel(_PostNormBase):
+    """modules/heads/mask_head.py:11-44."""
+
+    def __init__(self, cfg, hidden_size, num_targets, memories_for_match=["voxel"], filter_out_classes=None,
+                 dropout=0.1):
+        super().__init__()
+        self.cls_head = get_mlp_head(hidden_size, hidden_size, num_targets, dropout=dropout)
+        self.filter_out_classes = filter_out_classes
+        memories_for_match = [m for m in memories_for_match if m in ("voxel", "mv", "pc")]
+        self.mask_pred_list = layer_repeat(MaskPredictionLayer(hidden_size), len(memories_for_match))
+        self.num_targets = num_targets
+
+    def project_keys(self, seg_fts_for_match):
+        """k_proj of every matching memory (rows of padded segments zeroed) + the masked-mean denominators.
+        Layer-invariant unless the voxel memory is multi-scale: callers may compute it once per forward."""
+        ct = self.ct
+        keys = [ops.linear(feat, mp.k_proj.weight, None, ct=ct, out_dtype=ops.act_dtype(ct),
+                           row_mask=mask.logical_not())
+                for (feat, mask, _pos), mp in zip(seg_fts_for_match, self.mask_pred_list)]
+        inv_den = ops.mask_inv_den([f[1] for f in seg_fts_for_match])
+        return keys, inv_den
+
+    def forward(self, query, seg_fts_for_match, seg_masks, offline_attn_masks=None, skip_prediction=False, keys=None):
+        if skip_prediction:
+            return None, None, offline_attn_masks
+        ct = self.ct
+        foc = self.filter_out_classes
+        cls_logits = mlp_head_forward(self.cls_head, query, ct)
+        if foc is None:  # reference quirk: x[..., None] = -inf overwrites every logit (mask_head.py:28)
+            foc = list(range(self.num_targets))
+        if len(foc):
+            cols = torch.tensor(list(foc), dtype=torch.int32, device=query.device)
+            cls_logits = ops.fill_cols(cls_logits, cols, float("-inf"))
+        k_list, inv_den = keys if keys is not None else self.project_keys(seg_fts_for_match)
+        q_list = [ops.linear(query, mp.q_proj.weight, mp.q_proj.bias, ct=ct, out_dtype=ops.act_dtype(ct))
+                  for mp in self.mask_pred_list[:len(k_list)]]
+        mask_logits, attn_mask = ops.mask_logits(k_list, q_list, inv_den, seg_masks, ct=ct)
+        if offline_attn_masks is not None:
+            attn_mask = offline_attn_masks
+        return cls_logits, mask_logits, attn_mask
+
+
+class GroundHead(_PostNormBase):
+    """modules/heads/grounding_head.py:43-55."""
+
+    def __init__(self, cfg, input_size=768, hidden_size=768, dropout=0.3):
+        super().__init__()
+        self.og3d_head = get_mlp_head(input_size, hidden_size, 1, dropout=dropout)
+
+    def forward(self, obj_embeds, obj_masks=None, **kwargs):
+        flag = obj_masks.logical_not() if obj_masks is not None else None
+        return mlp_head_forward(self.og3d_head, obj_embeds, self.ct, fill_flag=flag,
+                                fill_value=float("-inf")).squeeze(2)
+
+
+# ------------------------------------------------------------------------------------------------ input side
+class ObjectEncoder(_PostNormBase):
+    """modules/vision/object_encoder.py:15-79, projection path (backbone='none')."""
+
+    def __init__(self, cfg, backbone="none", input_feat_size=768, hidden_size=768, freeze_backbone=False,
+                 use_projection=False, tgt_cls_num=607, pretrained=None, dropout=0.1, use_cls_head=True):
+        super().__init__()
+        if backbone != "none":
+            raise NotImplementedError("PointNet++ backbone is out of scope (SURVEY §2 row 10)")
+        if use_cls_head:
+            self.cls_head = get_mlp_head(input_feat_size, input_feat_size // 2, tgt_cls_num, dropout=0.3)
+        self.use_projection = use_projection
+        if use_projection:
+            self.input_feat_proj = nn.Sequential(nn.Linear(input_feat_size, hidden_size), nn.LayerNorm(hidden_size))
+        else:
+            assert input_feat_size == hidden_size, "input_feat_size should be equal to hidden_size!"
+        self.apply(_init_weights_bert)
+        if pretrained:
+            self.load_state_dict(torch.load(pretrained), strict=False)
+
+    def forward(self, obj_feats, data_dict=None, **kwargs):
+        obj_embeds = linear_ln_forward(self.input_feat_proj, obj_feats, self.ct) if self.use_projection else obj_feats
+        if hasattr(self, "cls_head"):
+            return obj_embeds, mlp_head_forward(self.cls_head, obj_feats, self.ct)
+        return obj_embeds
+
+
+class PositionEmbeddingCoordsSine(nn.Module):
+    """position_embedding.py:46-179, pos_type='fourier', normalize=True (buffer gauss_B [3, d_pos/2])."""
+
+    def __init__(self, d_pos, d_in=3, gauss_scale=1.0):
+        super().__init__()
+        assert d_pos % 2 == 0
+        self.register_buffer("gauss_B", torch.empty(d_in, d_pos // 2).normal_() * gauss_scale)
+
+    def forward(self, xyz, input_range):
+        return ops.fourier(xyz, input_range[0], input_range[1], self.gauss_B)  # [B,N,d] (already permuted)
+
+
+class CoordinateEncoder(_PostNormBase):
+    """model/query3d_unified.py:15-27."""
+
+    def __init__(self, hidden_size, use_projection=True):
+        super().__init__()
+        self.pos_enc = PositionEmbeddingCoordsSine(d_pos=hidden_size)
+        if use_projection:
+            self.feat_proj = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.LayerNorm(hidden_size))
+
+    def forward(self, coords, input_range):
+        pos = self.pos_enc(coords, input_range)
+        if hasattr(self, "feat_proj"):
+            pos = linear_ln_forward(self.feat_proj, pos, self.ct)
+        return pos
+
+
+def calc_pairwise_locs(obj_centers, obj_whls=None, eps=1e-10, pairwise_rel_type="center", spatial_dist_norm=True,
+                       spatial_dim=5):
+    """modules/utils.py:38-87 for the configuration on the path."""
+    if pairwise_rel_type != "center" or not spatial_dist_norm or spatial_dim != 5:
+        raise NotImplementedError("only pairwise_rel_type='center', spatial_dist_norm=True, spatial_dim=5")
+    return ops.pairwise_locs(obj_centers.float(), eps)

@@ -1,0 +1,408 @@
+"""torch.autograd.Function wrappers around the C-ABI kernels.  PyTorch supplies device memory, streams and the
+autograd tape only; every FLOP below runs in libpq3d_hip.so.  Shapes follow the reference's batch-first
+[B, L, d] convention; masks are torch.bool with the PyTorch meaning True = ignore."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from ._lib import BF16, F32
+
+_empty = torch.empty
+
+
+def act_dtype(ct: int) -> torch.dtype:
+    """Storage dtype of MFMA-operand activations (Q/K/V/O, FFN hidden) for a compute type."""
+    return torch.bfloat16 if ct == BF16 else torch.float32
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else t.contiguous()
+
+
+def _splitk(tiles: int, k: int, ct: int) -> int:
+    nkt = max(1, k // (64 if ct == BF16 else 32))
+    return max(1, min(nkt // 2 if nkt >= 2 else 1, 512 // max(tiles, 1), 64))
+
+
+# ------------------------------------------------------------------------------------------------ small kernels
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    R, N = x2d.shape
+    out = _empty(N, dtype=torch.float32, device=x2d.device)
+    L.check(L.lib().pq3d_colsum(L.ptr(x2d), L.dt_of(x2d), R, N, N, L.ptr(out), L.stream()), "pq3d_colsum")
+    return out
+
+
+def scale_rows(x: torch.Tensor, rows: int, out_dtype: torch.dtype, scale=None, zero_flag=None, keep_mask=None):
+    y = _empty(x.shape, dtype=out_dtype, device=x.device)
+    L.check(L.lib().pq3d_scale_rows(L.ptr(x), L.dt_of(x), L.ptr(y), L.dt_of(y), rows, x.numel() // max(rows, 1),
+                                    L.ptr(scale), L.ptr(zero_flag), L.ptr(keep_mask), L.stream()), "pq3d_scale_rows")
+    return y
+
+
+def act_bwd(dy: torch.Tensor, saved: torch.Tensor, act: str, out_dtype: torch.dtype) -> torch.Tensor:
+    out = _empty(dy.shape, dtype=out_dtype, device=dy.device)
+    L.check(L.lib().pq3d_act_bwd(L.ptr(dy), L.dt_of(dy), L.ptr(saved), L.dt_of(saved), L.ptr(out), L.dt_of(out),
+                                 L.ACT[act], dy.numel(), L.stream()), "pq3d_act_bwd")
+    return out
+
+
+def mask_row_all(mask: torch.Tensor) -> torch.Tensor:
+    """[B,Lq,Lk] bool -> [B,Lq] bool, True where the whole row is masked (query_encoder.py:83)."""
+    mask = mask.contiguous()
+    out = _empty(mask.shape[:-1], dtype=torch.bool, device=mask.device)
+    L.check(L.lib().pq3d_mask_row_all(L.ptr(mask), L.ptr(out), out.numel(), mask.shape[-1], L.stream()),
+            "pq3d_mask_row_all")
+    return out
+
+
+def mask_inv_den(masks: Sequence[torch.Tensor]) -> torch.Tensor:
+    masks = [m.contiguous() for m in masks]
+    arr = (C.c_void_p * len(masks))(*[L.ptr(m) for m in masks])
+    out = _empty(masks[0].shape, dtype=torch.float32, device=masks[0].device)
+    L.check(L.lib().pq3d_mask_inv_den(arr, len(masks), out.numel(), L.ptr(out), L.stream()), "pq3d_mask_inv_den")
+    return out
+
+
+def pairwise_locs(centers: torch.Tensor, eps: float = 1e-10) -> torch.Tensor:
+    """calc_pairwise_locs (modules/utils.py:38-87, 'center', spatial_dim=5).  centers [B,L,>=3] fp32."""
+    assert centers.dtype == torch.float32 and centers.stride(-1) == 1
+    B, Lq = centers.shape[:2]
+    if centers.stride(0) != Lq * centers.stride(1):
+        centers = centers.contiguous()
+    out = _empty(B, Lq, Lq, 5, dtype=torch.float32, device=centers.device)
+    L.check(L.lib().pq3d_pairwise_locs(L.ptr(centers), centers.stride(1), L.ptr(out), B, Lq, eps, L.stream()),
+            "pq3d_pairwise_locs")
+    return out
+
+
+def fourier(xyz: torch.Tensor, cmin: torch.Tensor, cmax: torch.Tensor, gauss_B: torch.Tensor) -> torch.Tensor:
+    """Fourier features [sin | cos] of normalised coordinates (position_embedding.py:127-156); no grad."""
+    assert xyz.dtype == torch.float32 and xyz.stride(-1) == 1
+    B, N = xyz.shape[:2]
+    if xyz.stride(0) != N * xyz.stride(1):
+        xyz = xyz.contiguous()
+    half = gauss_B.shape[1]
+    out = _empty(B, N, 2 * half, dtype=torch.float32, device=xyz.device)
+    L.check(L.lib().pq3d_fourier(L.ptr(xyz), xyz.stride(1), L.ptr(_c(cmin.float())), L.ptr(_c(cmax.float())),
+                                 L.ptr(_c(gauss_B)), L.ptr(out), B, N, half, L.stream()), "pq3d_fourier")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ linear
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value):
+        x, x2, w, fill_flag = _c(x), _c(x2), _c(w), _c(fill_flag)
+        K = x.shape[-1]
+        R = x.numel() // K
+        N = w.shape[0]
+        y = _empty(*x.shape[:-1], N, dtype=out_dtype, device=x.device)
+        pre = _empty(y.shape, dtype=out_dtype, device=x.device) if act == "gelu" else None
+        rm = _c(row_mask)
+        L.gemm(M=R, N=N, K=K, A=[x], A2=[x2], B=[w], bias=[b], Cs=[y], C2=[pre], row_mask=[rm], ct=ct,
+               lda=K, ldb=K, ldc=N, act=act, row_fill_flag=fill_flag, row_fill=fill_value)
+        ctx.save_for_backward(x, x2, w, pre if act == "gelu" else (y if act == "relu" else None), rm, fill_flag)
+        ctx.ct, ctx.act, ctx.has_b = ct, act, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, w, saved, rm, fill_flag = ctx.saved_tensors
+        ct = ctx.ct
+        N, K = w.shape
+        R = x.numel() // K
+        g = dy.contiguous()
+        if ctx.act in ("relu", "gelu"):
+            g = act_bwd(g, saved, ctx.act, act_dtype(ct))
+        if rm is not None or fill_flag is not None:
+            g = scale_rows(g, R, g.dtype, keep_mask=rm, zero_flag=fill_flag)
+        dx = dx2 = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
+            dx = _empty(x.shape, dtype=x.dtype, device=x.device)
+            L.gemm(M=R, N=K, K=N, A=[g], B=[w], Cs=[dx], ct=ct, lda=N, ldb=K, ldc=K, transB=True)
+            dx2 = dx if (x2 is not None and ctx.needs_input_grad[3]) else None
+            if not ctx.needs_input_grad[0]:
+                dx = None
+        if ctx.needs_input_grad[1]:
+            dw = _empty(N, K, dtype=torch.float32, device=x.device)
+            tiles = ((N + 63) // 64) * ((K + 63) // 64)
+            L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True,
+                   transB=True, splitk=_splitk(tiles, R, ct))
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = colsum(g.view(R, N))
+        return dx, dw, db, dx2, None, None, None, None, None, None
+
+
+def linear(x, w, b=None, *, ct: int, x2=None, act: Optional[str] = None, out_dtype=torch.float32, row_mask=None,
+           fill_flag=None, fill_value=0.0):
+    """y = act((x + x2) @ w.T + b); rows where row_mask == False are zeroed; rows where fill_flag == True are
+    set to fill_value (masked_fill of whole rows).  (F.linear call sites, see include/pq3d_hip.h)"""
+    return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias) -> L.AttnDesc:
+    B, Lq, dm = q.shape
+    Lk = k.shape[1]
+    d = L.AttnDesc()
+    d.B, d.H, d.Lq, d.Lk, d.dh = B, H, Lq, Lk, dm // H
+    d.ct, d.dt, d.zero_attn, d.scale = ct, L.dt_of(q), int(zero_attn), scale
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        assert t.stride(-1) == 1
+        setattr(d, name + "_sb", t.stride(0)); setattr(d, name + "_sl", t.stride(1)); setattr(d, name + "_sh", dm // H)
+    d.q, d.k, d.v, d.o, d.lse = L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse)
+    d.kpm, d.mask, d.row_open, d.bias = L.ptr(kpm), L.ptr(mask), L.ptr(row_open), L.ptr(bias)
+    return d
+
+
+class _Attention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, bias, kpm, mask, row_open, H, zero_attn, scale, ct):
+        q, k, v, bias, kpm, mask, row_open = map(_c, (q, k, v, bias, kpm, mask, row_open))
+        B, Lq, dm = q.shape
+        o = _empty(q.shape, dtype=q.dtype, device=q.device)
+        lse = _empty(B, H, Lq, dtype=torch.float32, device=q.device)
+        d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias)
+        L.check(L.lib().pq3d_attn_fwd(C.byref(d), L.stream()), "pq3d_attn_fwd")
+        ctx.save_for_backward(q, k, v, o, lse, bias, kpm, mask, row_open)
+        ctx.cfg = (H, zero_attn, scale, ct)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, bias, kpm, mask, row_open = ctx.saved_tensors
+        H, zero_attn, scale, ct = ctx.cfg
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        dbias = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[3]) else None
+        d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias)
+        d.dout, d.dq, d.dk, d.dv, d.delta, d.dbias = map(L.ptr, (do, dq, dk, dv, delta, dbias))
+        L.check(L.lib().pq3d_attn_bwd(C.byref(d), L.stream()), "pq3d_attn_bwd")
+        return dq, dk, dv, dbias, None, None, None, None, None, None, None
+
+
+def attention(q, k, v, *, H: int, ct: int, scale: Optional[float] = None, zero_attn=False, kpm=None, mask=None,
+              row_open=None, bias=None):
+    """softmax(scale q.k^T + bias + masks [, zero key]) v over heads packed in the last dim (see pq3d_attn_fwd)."""
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1] // H)
+    return _Attention.apply(q, k, v, bias, kpm, mask, row_open, H, bool(zero_attn), float(scale), ct)
+
+
+# ------------------------------------------------------------------------------------------------ add + layernorm
+def _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd) -> L.LnDesc:
+    d = L.LnDesc()
+    dm = os_[0].shape[-1]
+    d.R, d.d, d.M, d.rows_per_scene = os_[0].numel() // dm, dm, len(os_), rows_per_scene
+    d.dt_x = L.dt_of(x) if x is not None else 0
+    d.dt_o, d.dt_y, d.eps = L.dt_of(os_[0]), (L.dt_of(y) if y is not None else 0), eps
+    d.x, d.coef, d.y, d.mean, d.rstd = L.ptr(x), L.ptr(coef), L.ptr(y), L.ptr(mean), L.ptr(rstd)
+    for m in range(len(os_)):
+        d.o[m], d.gamma[m], d.beta[m] = L.ptr(os_[m]), L.ptr(gammas[m]), L.ptr(betas[m])
+    return d
+
+
+class _AddLN(Function):
+    @staticmethod
+    def forward(ctx, x, coef, eps, rows_per_scene, out_dtype, M, *t):
+        os_ = [_c(a) for a in t[:M]]
+        gammas, betas = [_c(a) for a in t[M:2 * M]], [_c(a) for a in t[2 * M:3 * M]]
+        x, coef = _c(x), _c(coef)
+        dm = os_[0].shape[-1]
+        R = os_[0].numel() // dm
+        y = _empty(os_[0].shape, dtype=out_dtype, device=os_[0].device)
+        mean = _empty(M, R, dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd)
+        L.check(L.lib().pq3d_add_ln_fwd(C.byref(d), L.stream()), "pq3d_add_ln_fwd")
+        ctx.save_for_backward(x, coef, mean, rstd, *os_, *gammas, *betas)
+        ctx.cfg = (eps, rows_per_scene, M)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        eps, rows_per_scene, M = ctx.cfg
+        x, coef, mean, rstd = ctx.saved_tensors[:4]
+        t = ctx.saved_tensors[4:]
+        os_, gammas, betas = t[:M], t[M:2 * M], t[2 * M:3 * M]
+        dy = dy.contiguous().float()
+        dev = dy.device
+        dx = _empty(os_[0].shape, dtype=torch.float32, device=dev) if x is not None else None
+        d_os = [_empty(o.shape, dtype=torch.float32, device=dev) for o in os_]
+        dgs = [torch.empty_like(g) for g in gammas]
+        dbs = [torch.empty_like(b) for b in betas]
+        d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd)
+        d.dy, d.dx = L.ptr(dy), L.ptr(dx)
+        for m in range(M):
+            d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_os[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
+        L.check(L.lib().pq3d_add_ln_bwd(C.byref(d), L.stream()), "pq3d_add_ln_bwd")
+        if x is not None and x.dtype != torch.float32:
+            dx = dx.to(x.dtype)
+        d_os = [g if g.dtype == o.dtype else g.to(o.dtype) for g, o in zip(d_os, os_)]
+        return (dx, None, None, None, None, None, *d_os, *dgs, *dbs)
+
+
+def add_layernorm(x, os_: Sequence[torch.Tensor], gammas, betas, *, eps=1e-5, coef=None, rows_per_scene=None,
+                  out_dtype=torch.float32):
+    """y = sum_m coef[m, scene] * LN_m(x + o_m)   (coef None -> mean over the M branches; x may be None)."""
+    M = len(os_)
+    if rows_per_scene is None:
+        rows_per_scene = os_[0].shape[-2] if os_[0].dim() >= 2 else 1
+    return _AddLN.apply(x, coef, float(eps), int(rows_per_scene), out_dtype, M, *os_, *gammas, *betas)
+
+
+# ------------------------------------------------------------------------------------------------ mask logits
+class _MaskLogits(Function):
+    @staticmethod
+    def forward(ctx, inv_den, seg_pad, ct, M, *kq):
+        ks, qs = [_c(a) for a in kq[:M]], [_c(a) for a in kq[M:]]
+        B, Ns, dm = ks[0].shape
+        Nq = qs[0].shape[1]
+        logits = _empty(B, Ns, Nq, dtype=torch.float32, device=ks[0].device)
+        amask = _empty(B, Nq, Ns, dtype=torch.bool, device=ks[0].device)
+        L.gemm(M=Ns, N=Nq, K=dm, A=ks, B=qs, Cs=[logits] + [None] * (M - 1), ct=ct, lda=dm, ldb=dm, ldc=Nq, batch=B,
+               strideA=Ns * dm, strideB=Nq * dm, strideC=Ns * Nq, kconcat=True, row_scale=inv_den,
+               row_fill_flag=seg_pad, row_fill=-1e6, mask_out=amask)
+        ctx.save_for_backward(inv_den, seg_pad, *ks, *qs)
+        ctx.cfg = (ct, M)
+        ctx.mark_non_differentiable(amask)
+        return logits, amask
+
+    @staticmethod
+    def backward(ctx, dl, _dmask):
+        ct, M = ctx.cfg
+        inv_den, seg_pad = ctx.saved_tensors[:2]
+        ks, qs = ctx.saved_tensors[2:2 + M], ctx.saved_tensors[2 + M:]
+        B, Ns, dm = ks[0].shape
+        Nq = qs[0].shape[1]
+        g = scale_rows(dl.contiguous(), B * Ns, act_dtype(ct), scale=inv_den, zero_flag=seg_pad)
+        dks = [torch.empty_like(k) for k in ks]
+        dqs = [torch.empty_like(q) for q in qs]
+        L.gemm(M=Ns, N=dm, K=Nq, A=[g] * M, B=list(qs), Cs=dks, ct=ct, lda=Nq, ldb=dm, ldc=dm, transB=True, batch=B,
+               strideA=Ns * Nq, strideB=Nq * dm, strideC=Ns * dm)
+        L.gemm(M=Nq, N=dm, K=Ns, A=[g] * M, B=list(ks), Cs=dqs, ct=ct, lda=Nq, ldb=dm, ldc=dm, transA=True,
+               transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * dm, strideC=Nq * dm)
+        return (None, None, None, None, *dks, *dqs)
+
+
+def mask_logits(ks: Sequence[torch.Tensor], qs: Sequence[torch.Tensor], inv_den, seg_pad, *, ct: int):
+    """mask_head.py:30-43: logits[b,s,q] = pad ? -1e6 : inv_den[b,s] * sum_m k_m[b,s,:].q_m[b,q,:];
+    attn_mask[b,q,s] = sigmoid(logits) < 0.5.  k_m rows of invalid segments must already be zero."""
+    return _MaskLogits.apply(inv_den, seg_pad, ct, len(ks), *ks, *qs)
+
+
+# ------------------------------------------------------------------------------------------------ spatial bias
+class _SpatialBias(Function):
+    @staticmethod
+    def forward(ctx, pl, W, bw):
+        pl, W, bw = _c(pl), _c(W), _c(bw)
+        B, Lq = pl.shape[:2]
+        H = W.shape[0]
+        bias = _empty(B, H, Lq, Lq, dtype=torch.float32, device=pl.device)
+        L.check(L.lib().pq3d_spatial_bias_fwd(L.ptr(pl), L.ptr(W), L.ptr(bw), L.ptr(bias), B, H, Lq, L.stream()),
+                "pq3d_spatial_bias_fwd")
+        ctx.save_for_backward(pl, W, bw)
+        return bias
+
+    @staticmethod
+    def backward(ctx, dbias):
+        pl, W, bw = ctx.saved_tensors
+        B, Lq = pl.shape[:2]
+        dW, dbw = torch.empty_like(W), torch.empty_like(bw)
+        L.check(L.lib().pq3d_spatial_bias_bwd(L.ptr(pl), L.ptr(W), L.ptr(bw), L.ptr(dbias.contiguous()), L.ptr(dW),
+                                              L.ptr(dbw), B, W.shape[0], Lq, L.stream()), "pq3d_spatial_bias_bwd")
+        return None, dW, dbw
+
+
+def spatial_bias(pl, W, bw):
+    """log(clamp(relu(pairwise_loc_fc(pl)), 1e-6)) laid out [B,H,L,L] (transformers.py:196-200,226)."""
+    return _SpatialBias.apply(pl, W, bw)
+
+
+# ------------------------------------------------------------------------------------------------ misc differentiable
+class _GateMix(Function):
+    @staticmethod
+    def forward(ctx, q, u, g):
+        q, u, g = _c(q), _c(u), _c(g)
+        y = torch.empty_like(q)
+        L.check(L.lib().pq3d_gate_mix_fwd(L.ptr(q), L.ptr(u), L.ptr(g), L.ptr(y), q.numel(), L.stream()),
+                "pq3d_gate_mix_fwd")
+        ctx.save_for_backward(q, u, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        q, u, g = ctx.saved_tensors
+        dq, du, dg = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        L.check(L.lib().pq3d_gate_mix_bwd(L.ptr(q), L.ptr(u), L.ptr(g), L.ptr(dy.contiguous()), L.ptr(dq), L.ptr(du),
+                                          L.ptr(dg), q.numel(), L.stream()), "pq3d_gate_mix_bwd")
+        return dq, du, dg
+
+
+def gate_mix(q, u, g):
+    """(1 - sigmoid(g)) * q + sigmoid(g) * u   (query_encoder.py:167-170)."""
+    return _GateMix.apply(q, u, g)
+
+
+class _FillCols(Function):
+    @staticmethod
+    def forward(ctx, x, cols, value):
+        x = _c(x)
+        y = torch.empty_like(x)
+        C_ = x.shape[-1]
+        L.check(L.lib().pq3d_fill_cols(L.ptr(x), L.ptr(y), x.numel() // C_, C_, L.ptr(cols), cols.numel(), value,
+                                       L.stream()), "pq3d_fill_cols")
+        ctx.save_for_backward(cols)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cols,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        C_ = dy.shape[-1]
+        L.check(L.lib().pq3d_fill_cols(L.ptr(dy), L.ptr(dx), dy.numel() // C_, C_, L.ptr(cols), cols.numel(), 0.0,
+                                       L.stream()), "pq3d_fill_cols")
+        return dx, None, None
+
+
+def fill_cols(x, cols: torch.Tensor, value: float):
+    """x[..., cols] = value, out of place (mask_head.py:28)."""
+    return _FillCols.apply(x, cols, float(value))
+
+
+class _ScatterMean(Function):
+    @staticmethod
+    def forward(ctx, src, index, dim_size):
+        src, index = _c(src), _c(index)
+        N, C_ = src.shape
+        out = _empty(dim_size, C_, dtype=torch.float32, device=src.device)
+        count = _empty(dim_size, dtype=torch.float32, device=src.device)
+        L.check(L.lib().pq3d_scatter_mean_fwd(L.ptr(src), L.ptr(index), L.ptr(out), L.ptr(count), N, C_, dim_size,
+                                              L.stream()), "pq3d_scatter_mean_fwd")
+        ctx.save_for_backward(index, count)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        index, count = ctx.saved_tensors
+        dout = dout.contiguous()
+        N, C_ = index.numel(), dout.shape[1]
+        dsrc = _empty(N, C_, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().pq3d_scatter_mean_bwd(L.ptr(dout), L.ptr(index), L.ptr(count), L.ptr(dsrc), N, C_,
+                                              L.stream()), "pq3d_scatter_mean_bwd")
+        return dsrc, None, None
+
+
+def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
+    """torch_scatter.scatter_mean(src, index, dim=0, dim_size) for [N,C] fp32 voxel features
+    (pcd_mask3d_encoder.py:149)."""
+    assert src.dtype == torch.float32 and index.dtype == torch.int64 and src.dim() == 2
+    return _ScatterMean.apply(src, index, int(dim_size))

@@ -1,0 +1,91 @@
+"""Deterministic synthetic weights and inputs (SURVEY §8c fixture plan, §8d synthetic inputs).
+
+Used by the golden-fixture generator, the tests and ``bench.py``.  Everything is drawn from
+``numpy.random.default_rng`` keyed by (seed, crc32(name)) so a tensor's values depend only on
+its *name and shape*, never on module construction order: the same call fills the reference
+modules (golden generation), the oracle's flat dict and the HIP modules.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Mapping, Sequence
+
+import numpy as np
+import torch
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def synth_tensor(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor:
+    """matrices ~ N(0,0.05) (so attention is not degenerate), biases ~ N(0,0.02),
+    LayerNorm gamma ~ U(0.5,1.5), Fourier ``gauss_B`` ~ N(0,1)."""
+    r = _rng(seed, name)
+    shape = tuple(int(s) for s in shape)
+    if name.endswith("gauss_B"):
+        a = r.standard_normal(shape)
+    elif len(shape) >= 2:
+        a = 0.05 * r.standard_normal(shape)
+    elif name.endswith("weight"):
+        a = r.uniform(0.5, 1.5, shape)
+    else:
+        a = 0.02 * r.standard_normal(shape)
+    return torch.from_numpy(a.astype(np.float32))
+
+
+def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0) -> Dict[str, torch.Tensor]:
+    return {k: synth_tensor(k, tuple(v), seed) for k, v in shapes.items()}
+
+
+def fill_module(module: torch.nn.Module, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Overwrite every parameter/buffer of ``module`` with its synthetic value; returns the dict."""
+    sd = module.state_dict()
+    new = synth_state_dict({k: v.shape for k, v in sd.items()}, seed)
+    module.load_state_dict(new, strict=True)
+    return new
+
+
+def state_checksum(sd: Mapping[str, torch.Tensor]) -> float:
+    """Order-independent fingerprint stored in fixtures to detect RNG drift."""
+    return float(sum(float(v.double().abs().sum()) for v in sd.values()))
+
+
+def synth_data_dict(B: int, n_seg: int, n_q: int, d_in: Mapping[str, int], seed: int = 1234,
+                    memories: Sequence[str] = ("voxel", "mv", "pc"), prompt_len: int = 0, d_model: int = 0,
+                    full_valid: bool = False, query_valid_min: int | None = None,
+                    loc_dim: int = 3) -> Dict[str, torch.Tensor]:
+    """SURVEY §8d synthetic inputs.  Pad masks here are the data_dict convention: True = valid."""
+    r = np.random.default_rng(seed)
+    valid_len = r.integers(n_seg // 2, n_seg + 1, size=B)
+    valid_len[0] = n_seg
+    if full_valid:
+        valid_len[:] = n_seg
+    seg_valid = np.arange(n_seg)[None, :] < valid_len[:, None]
+    dd: Dict[str, torch.Tensor] = {}
+    for m in memories:
+        if m == "prompt":
+            continue
+        f = r.standard_normal((B, n_seg, d_in[m])).astype(np.float32)
+        f[~seg_valid] = 0.0
+        dd[f"{m}_seg_fts"] = torch.from_numpy(f)
+        dd[f"{m}_seg_pad_masks"] = torch.from_numpy(seg_valid.copy())
+    dd["seg_pad_masks"] = torch.from_numpy(seg_valid.copy())
+    dd["seg_center"] = torch.from_numpy(r.uniform(0, 4, (B, n_seg, loc_dim)).astype(np.float32))
+    dd["query_locs"] = torch.from_numpy(r.uniform(0, 4, (B, n_q, loc_dim)).astype(np.float32))
+    dd["coord_min"] = torch.zeros(B, 3)
+    dd["coord_max"] = torch.full((B, 3), 4.0)
+    if query_valid_min is None:
+        qv = np.ones((B, n_q), dtype=bool)
+    else:
+        ql = r.integers(query_valid_min, n_q + 1, size=B)
+        qv = np.arange(n_q)[None, :] < ql[:, None]
+    dd["query_pad_masks"] = torch.from_numpy(qv)
+    if prompt_len:
+        pl = r.integers(max(1, prompt_len // 4), prompt_len + 1, size=B)
+        pv = np.arange(prompt_len)[None, :] < pl[:, None]
+        pf = r.standard_normal((B, prompt_len, d_model)).astype(np.float32)
+        pf[~pv] = 0.0
+        dd["prompt_feat"] = torch.from_numpy(pf)
+        dd["prompt_pad_masks"] = torch.from_numpy(pv)
+    return dd

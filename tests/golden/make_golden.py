@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING the reference (runs in the build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/F*.npz
+
+The reference (a Python project, /root/reference) cannot travel to the GPU box, so its outputs
+on seeded synthetic inputs are committed as small ``.npz`` fixtures.  This script contains only
+(1) the import recipe of SURVEY §8c (stand-ins for packages that are *not installed* here and are
+only imported, never executed, on this path) and (2) our own synthetic input/weight generator.
+Weights are NOT stored: they are regenerated from ``pq3d_amd.synth`` (name+seed keyed) and a
+checksum is stored to detect RNG drift.  Large tensors are stored as a strided sample + moments
+(see ``compress``); tests apply the same compression to what they compare.
+"""
+from __future__ import annotations
+
+import builtins
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from pq3d_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+MAX_FULL = 8192   # outputs
+MAX_GRAD = 1024   # per-parameter gradient sample (moments cover the rest)
+
+
+# ----------------------------------------------------------------------------- import recipe
+class _Registry(dict):
+    def __init__(self, name):
+        super().__init__()
+        self._name = name
+
+    def register(self, obj=None):
+        def deco(o):
+            self[o.__name__] = o
+            return o
+        return deco if obj is None else deco(obj)
+
+    def get(self, name):
+        return self[name]
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("fvcore"); mod("fvcore.common"); mod("fvcore.common.registry", Registry=_Registry)
+    oc = type("OmegaConf", (), {"to_container": staticmethod(lambda c, resolve=True: dict(c))})
+    mod("omegaconf", OmegaConf=oc)
+    me = mod("MinkowskiEngine")
+    mod("MinkowskiEngine.MinkowskiPooling", MinkowskiAvgPooling=object)
+    me.MinkowskiPooling = sys.modules["MinkowskiEngine.MinkowskiPooling"]
+    for pkg in ["modules", "modules.grounding", "modules.heads", "modules.vision", "modules.third_party",
+                "modules.third_party.mask3d", "modules.layers", "data", "data.datasets", "optim", "model"]:
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules[pkg] = m
+    builtins.__POINTNET2_SETUP__ = True
+    ns = types.SimpleNamespace()
+    ns.qe = importlib.import_module("modules.grounding.query_encoder")
+    ns.mh = importlib.import_module("modules.heads.mask_head")
+    ns.gh = importlib.import_module("modules.heads.grounding_head")
+    ns.oe = importlib.import_module("modules.vision.object_encoder")
+    ns.model = importlib.import_module("model.query3d_unified")
+    ns.utils = importlib.import_module("modules.utils")
+    return ns
+
+
+class Cfg(dict):
+    """attribute dict with .get, nested."""
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in {**(d or {}), **kw}.items():
+            self[k] = Cfg(v) if isinstance(v, dict) and not isinstance(v, Cfg) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+# ----------------------------------------------------------------------------- helpers
+def compress(t: torch.Tensor, cap: int = MAX_FULL) -> dict:
+    a = t.detach().double().cpu().numpy()
+    fin = np.isfinite(a)
+    af = np.where(fin, a, 0.0)
+    flat = a.reshape(-1)
+    stride = max(1, -(-flat.size // cap))
+    return {"sample": flat[::stride].astype(np.float32), "stride": np.int64(stride),
+            "shape": np.array(a.shape, dtype=np.int64), "sum": np.float64(af.sum()),
+            "l2": np.float64(np.sqrt((af ** 2).sum())), "ninf": np.int64((~fin).sum())}
+
+
+def put(out: dict, key: str, t, cap: int = MAX_FULL):
+    if t.dtype == torch.bool:
+        out[key + "/bool"] = np.packbits(t.cpu().numpy().reshape(-1))
+        out[key + "/shape"] = np.array(t.shape, dtype=np.int64)
+        return
+    for k, v in compress(t, cap).items():
+        out[f"{key}/{k}"] = v
+
+
+def loss_weight(name, shape, seed=99):
+    return synth.synth_tensor("lossw." + name, shape, seed) * 20.0  # ~N(0,1)
+
+
+def save(name, out):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(out)} arrays")
+
+
+def model_cfg(d, H, L, memories, heads, d_in, *, spatial, structure, use_self_mask=False, num_blocks=1,
+              dim_loc=3, C=21, foc=(), drop_test=(), offline_attn=False, skip_pred=False):
+    enc = lambda m: {"name": "ObjectEncoder", "args": {"input_feat_size": d_in[m], "hidden_size": d,
+                                                       "use_projection": True, "use_cls_head": False,
+                                                       "dropout": 0.1}}
+    m = {"name": "Query3DUnified", "memories": list(memories), "heads": list(heads), "hidden_size": d,
+         "use_offline_voxel_fts": True, "use_offline_attn_mask": offline_attn,
+         "skip_query_encoder_mask_pred": skip_pred,
+         "obj_loc": {"spatial_dim": 5, "dim_loc": dim_loc, "pairwise_rel_type": "center"},
+         "unified_encoder": {"name": "QueryMaskEncoder", "args": {
+             "hidden_size": d, "num_attention_heads": H, "num_layers": L, "spatial_selfattn": spatial,
+             "memories": list(memories), "structure": structure, "use_self_mask": use_self_mask,
+             "num_blocks": num_blocks, "drop_memories_test": list(drop_test)}},
+         "mask_head": {"name": "MaskHeadSegLevel", "args": {"hidden_size": d, "num_targets": C,
+                                                             "memories_for_match": list(memories),
+                                                             "filter_out_classes": list(foc)}},
+         "ground_head": {"name": "GroundHead", "args": {"input_size": d, "hidden_size": d // 2 * 3 // 3,
+                                                         "dropout": 0.3}}}
+    for mem in memories:
+        if mem != "prompt":
+            m[f"{mem}_encoder"] = enc(mem)
+    return Cfg({"model": m, "solver": {"lr": 1e-4}})
+
+
+def run_model_case(ref, name, *, B, Ns, Nq, d, H, L, memories, heads, spatial, structure, train_grads=True,
+                   seed=0, data_seed=1234, query_valid_min=None, **kw):
+    d_in = {m: d for m in memories}
+    cfg = model_cfg(d, H, L, memories, heads, d_in, spatial=spatial, structure=structure, **kw)
+    torch.manual_seed(0)
+    model = ref.model.Query3DUnified(cfg)
+    sd = synth.fill_module(model, seed)
+    model.eval()  # dropout off: parity is only defined at p=0
+    dd = synth.synth_data_dict(B, Ns, Nq, d_in, seed=data_seed, memories=memories,
+                               query_valid_min=query_valid_min, loc_dim=kw.get("dim_loc", 3))
+    dd["tgt_object_id"] = torch.zeros(B, dtype=torch.long)
+    if kw.get("offline_attn"):
+        r = np.random.default_rng(data_seed + 7)
+        om = r.random((B, Nq, Ns)) < 0.6
+        om[:, 1, :] = True  # an all-True row: exercises query_encoder.py:83
+        dd["offline_attn_mask"] = torch.from_numpy(om)
+    captured = []
+    hooks = [layer.register_forward_hook(lambda _m, _i, o: captured.append(o))
+             for layer in model.unified_encoder.unified_encoder]
+    run_dd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in dd.items()}
+    res = model(run_dd)
+    for h in hooks:
+        h.remove()
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd)),
+           "meta/args": np.array(repr(dict(B=B, Ns=Ns, Nq=Nq, d=d, H=H, L=L, memories=list(memories),
+                                           heads=list(heads), spatial=spatial, structure=structure,
+                                           seed=seed, data_seed=data_seed, query_valid_min=query_valid_min,
+                                           **kw)))}
+    for i, q in enumerate(captured):
+        put(out, f"layer_query/{i}", q)
+    loss = 0.0
+    if "ground" in heads:
+        put(out, "ground_logits", res["ground_logits"])
+        gl = res["ground_logits"]
+        gl = torch.where(torch.isfinite(gl), gl, torch.zeros_like(gl))
+        loss = loss + (gl * loss_weight("ground", gl.shape)).mean()
+    if "mask" in heads:
+        for i, (c, m) in enumerate(zip(res["predictions_class"], res["predictions_mask"])):
+            put(out, f"pred_class/{i}", c)
+            put(out, f"pred_mask/{i}", m)
+            cf = torch.where(torch.isfinite(c), c, torch.zeros_like(c))
+            loss = loss + (cf * loss_weight(f"cls{i}", c.shape)).mean() \
+                + (m.clamp(min=-50.0) * loss_weight(f"mask{i}", m.shape)).mean()
+    loss = loss + (captured[-1] * loss_weight("query", captured[-1].shape)).mean()
+    out["loss"] = np.float64(loss.item())
+    if train_grads:
+        model.zero_grad()
+        loss.backward()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                put(out, "grad/" + n, p.grad, MAX_GRAD)
+    save(name, out)
+
+
+def run_encoder_case(ref, name, *, B, Ns, Nq, d, H, L, memories, structure, spatial, T=12, seed=0,
+                     data_seed=4321):
+    """QueryMaskEncoder alone with a pre-encoded prompt memory (structures sequential/mixed/gate)."""
+    torch.manual_seed(0)
+    enc = ref.qe.QueryMaskEncoder(None, memories=list(memories), hidden_size=d, num_attention_heads=H,
+                                  num_layers=L, spatial_selfattn=spatial, structure=structure)
+    sd = synth.fill_module(enc, seed)
+    enc.eval()
+    r = np.random.default_rng(data_seed)
+    t = lambda *s: torch.from_numpy(r.standard_normal(s).astype(np.float32))
+    dd = synth.synth_data_dict(B, Ns, Nq, {m: d for m in memories}, seed=data_seed, memories=memories,
+                               prompt_len=T, d_model=d)
+    qpos, fpos = t(B, Nq, d), t(B, Ns, d)
+    input_dict = {"query": (torch.zeros(B, Nq, d), dd["query_pad_masks"].logical_not(), qpos)}
+    for m in memories:
+        if m == "prompt":
+            input_dict[m] = [dd["prompt_feat"], dd["prompt_pad_masks"].logical_not(), None]
+        else:
+            input_dict[m] = [dd[f"{m}_seg_fts"], dd[f"{m}_seg_pad_masks"].logical_not(), fpos]
+    pl = ref.utils.calc_pairwise_locs(dd["query_locs"], None, pairwise_rel_type="center",
+                                      spatial_dist_norm=True, spatial_dim=5) if spatial else None
+    query, _, _ = enc(input_dict, pl, None)
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd)),
+           "meta/args": np.array(repr(dict(B=B, Ns=Ns, Nq=Nq, d=d, H=H, L=L, memories=list(memories),
+                                           structure=structure, spatial=spatial, T=T, seed=seed,
+                                           data_seed=data_seed)))}
+    put(out, "qpos", qpos); put(out, "fpos", fpos)
+    put(out, "query", query)
+    loss = (query * loss_weight("query", query.shape)).mean()
+    enc.zero_grad(); loss.backward()
+    for n, p in enc.named_parameters():
+        if p.grad is not None:
+            put(out, "grad/" + n, p.grad, MAX_GRAD)
+    save(name, out)
+
+
+def run_misc_case(ref, name):
+    """F6: calc_pairwise_locs, CoordinateEncoder (Fourier), dim_loc=6 encoders, GroundHead masks."""
+    out = {}
+    r = np.random.default_rng(5)
+    locs = torch.from_numpy(r.uniform(0, 4, (2, 19, 3)).astype(np.float32))
+    put(out, "pairwise_locs", ref.utils.calc_pairwise_locs(locs, None, pairwise_rel_type="center",
+                                                            spatial_dist_norm=True, spatial_dim=5))
+    torch.manual_seed(0)
+    ce = ref.model.CoordinateEncoder(64)
+    sd = synth.fill_module(ce, 3)
+    cmin = torch.tensor([[0., 0., 0.], [-1., -1., 0.]]); cmax = torch.tensor([[4., 4., 4.], [5., 4., 3.]])
+    put(out, "coord_enc", ce(locs, input_range=[cmin, cmax]))
+    out["meta/weights_checksum"] = np.float64(synth.state_checksum(sd))
+    out["locs"] = locs.numpy(); out["cmin"] = cmin.numpy(); out["cmax"] = cmax.numpy()
+    save(name, out)
+
+
+def main():
+    ref = import_reference()
+    # F1: BASELINE config 1 exactly (1 layer, B2, Ns128, Nq16, d64, H4, one stream, non-spatial, sequential)
+    run_model_case(ref, "F1_c1", B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=["ground"],
+                   spatial=False, structure="sequential")
+    # F2: c1 shapes + spatial self-attn + 3 memories parallel + self-mask + mask head, 2 layers x 2 blocks
+    run_model_case(ref, "F2_c1_mask", B=2, Ns=128, Nq=16, d=64, H=4, L=2, memories=["voxel", "mv", "pc"],
+                   heads=["mask"], spatial=True, structure="parallel", use_self_mask=True, num_blocks=2,
+                   foc=(0, 2))
+    # F3: structures with a prompt memory
+    for s in ("sequential", "mixed", "gate"):
+        run_encoder_case(ref, f"F3_{s}", B=2, Ns=96, Nq=20, d=64, H=4, L=2,
+                         memories=["voxel", "mv", "prompt"], structure=s, spatial=(s != "sequential"))
+    # F4: B=2 slice of config 2 (d256,H8,L4,Nq100,3 memories parallel, spatial, 2-D masks), Ns shrunk to 320
+    run_model_case(ref, "F4_c2_slice", B=2, Ns=320, Nq=100, d=256, H=8, L=4, memories=["voxel", "mv", "pc"],
+                   heads=["ground"], spatial=True, structure="parallel")
+    # F4b: config-4 flavour: self-mask + mask head every layer (C=201), d256
+    run_model_case(ref, "F4b_c4_slice", B=2, Ns=200, Nq=40, d=256, H=8, L=2, memories=["voxel", "mv", "pc"],
+                   heads=["mask"], spatial=True, structure="parallel", use_self_mask=True, C=201, foc=(0, 2))
+    # F5: edge cases
+    run_model_case(ref, "F5_offline_mask", B=2, Ns=72, Nq=13, d=64, H=4, L=2, memories=["voxel", "pc"],
+                   heads=["mask"], spatial=True, structure="parallel", use_self_mask=True, offline_attn=True,
+                   foc=(), query_valid_min=7)
+    run_model_case(ref, "F5_skip_pred", B=2, Ns=72, Nq=13, d=64, H=4, L=2, memories=["voxel", "pc"],
+                   heads=["mask"], spatial=False, structure="sequential", use_self_mask=True,
+                   offline_attn=True, skip_pred=True, foc=(1,))
+    run_model_case(ref, "F5_drop_mem", B=3, Ns=50, Nq=9, d=64, H=4, L=1, memories=["voxel", "mv", "pc"],
+                   heads=["ground"], spatial=True, structure="parallel", drop_test=("mv",),
+                   query_valid_min=4, train_grads=False)
+    run_model_case(ref, "F5_dimloc6", B=2, Ns=40, Nq=8, d=64, H=4, L=1, memories=["voxel"], heads=["ground"],
+                   spatial=True, structure="parallel", dim_loc=6)
+    run_misc_case(ref, "F6_misc")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""CPU: the oracle (oracle/pq3d_oracle.py) against every golden fixture generated from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pq3d_oracle as O
+from pq3d_amd import synth
+from tests import util
+
+TOL = dict(atol=1e-5, rtol=1e-5)
+MODEL_FIXTURES = [f for f in util.fixtures() if not f.startswith(("F3_", "F6_"))]
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_model_fixture(name):
+    z, args = util.load_fixture(name)
+    _cfg, _model, sd, dd = util.model_case(args)
+    assert abs(synth.state_checksum(sd) - float(z["meta/weights_checksum"])) < 1e-6 * float(z["meta/weights_checksum"]), \
+        "synthetic weight generator drifted from the one that produced the fixtures"
+    grads = any(k.startswith("grad/") for k in z.files)
+    out, collect, loss, g = util.run_oracle(args, sd, dd, grads=grads)
+    for i, q in enumerate(collect):
+        util.check_against(z, f"layer_query/{i}", q, **TOL)
+    if "ground" in args["heads"]:
+        util.check_against(z, "ground_logits", out["ground_logits"], **TOL)
+    if "mask" in args["heads"]:
+        assert len(out["predictions_mask"]) == sum(1 for k in z.files if k.startswith("pred_mask/") and k.endswith("/sum"))
+        for i, (c, m) in enumerate(zip(out["predictions_class"], out["predictions_mask"])):
+            util.check_against(z, f"pred_class/{i}", c, **TOL)
+            util.check_against(z, f"pred_mask/{i}", m, atol=1e-4, rtol=1e-5)
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5 * max(1.0, abs(float(z["loss"])))
+    if grads:
+        names = sorted(k[5:-4] for k in z.files if k.startswith("grad/") and k.endswith("/sum"))
+        assert names == sorted(g.keys()), "oracle parameter-gradient set differs from the reference's"
+        for n in names:
+            util.check_against(z, "grad/" + n, g[n], atol=2e-6, rtol=2e-5, cap=util.MAX_GRAD)
+
+
+@pytest.mark.parametrize("name", util.fixtures("F3_"))
+def test_encoder_structures(name):
+    z, a = util.load_fixture(name)
+    d, B, Ns, Nq, T = a["d"], a["B"], a["Ns"], a["Nq"], a["T"]
+    from pq3d_amd.modules import QueryMaskEncoder
+    enc = QueryMaskEncoder(None, memories=a["memories"], hidden_size=d, num_attention_heads=a["H"],
+                           num_layers=a["L"], spatial_selfattn=a["spatial"], structure=a["structure"])
+    sd = synth.fill_module(enc, a["seed"])
+    assert abs(synth.state_checksum(sd) - float(z["meta/weights_checksum"])) < 1e-6 * float(z["meta/weights_checksum"])
+    r = np.random.default_rng(a["data_seed"])
+    t = lambda *s: torch.from_numpy(r.standard_normal(s).astype(np.float32))
+    dd = synth.synth_data_dict(B, Ns, Nq, {m: d for m in a["memories"]}, seed=a["data_seed"], memories=a["memories"],
+                               prompt_len=T, d_model=d)
+    qpos, fpos = t(B, Nq, d), t(B, Ns, d)
+    util.check_against(z, "qpos", qpos, atol=0, rtol=0)
+    input_dict = {"query": (torch.zeros(B, Nq, d), dd["query_pad_masks"].logical_not(), qpos)}
+    for m in a["memories"]:
+        if m == "prompt":
+            input_dict[m] = [dd["prompt_feat"], dd["prompt_pad_masks"].logical_not(), None]
+        else:
+            input_dict[m] = [dd[f"{m}_seg_fts"], dd[f"{m}_seg_pad_masks"].logical_not(), fpos]
+    pl = O.calc_pairwise_locs(dd["query_locs"]) if a["spatial"] else None
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    query, _, _ = O.query_mask_encoder(sdo, "", input_dict, pl, None, memories=a["memories"], H=a["H"],
+                                       num_layers=a["L"], structure=a["structure"], spatial_selfattn=a["spatial"])
+    util.check_against(z, "query", query, **TOL)
+    (query * util.loss_weight("query", query.shape)).mean().backward()
+    for k, v in sdo.items():
+        n = k
+        if f"grad/{n}/sum" in z.files:
+            util.check_against(z, "grad/" + n, v.grad, atol=2e-6, rtol=2e-5, cap=util.MAX_GRAD)
+        else:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, n
+
+
+def test_misc_fixture():
+    z, _ = util.load_fixture("F6_misc")
+    locs, cmin, cmax = (torch.from_numpy(z[k]) for k in ("locs", "cmin", "cmax"))
+    util.check_against(z, "pairwise_locs", O.calc_pairwise_locs(locs), atol=1e-6, rtol=1e-6)
+    from pq3d_amd.modules import CoordinateEncoder
+    sd = synth.fill_module(CoordinateEncoder(64), 3)
+    util.check_against(z, "coord_enc", O.coordinate_encoder(sd, "", locs, cmin, cmax), **TOL)
+
+
+def test_scatter_mean_matches_definition():
+    r = np.random.default_rng(0)
+    src = torch.from_numpy(r.standard_normal((500, 7)).astype(np.float32))
+    idx = torch.from_numpy(r.integers(0, 40, 500))
+    out = O.scatter_mean(src, idx, 48)
+    for s in (0, 5, 39, 47):
+        sel = src[idx == s]
+        exp = sel.mean(0) if len(sel) else torch.zeros(7)
+        assert torch.allclose(out[s], exp, atol=1e-6)
