@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- decoder forward+backward scenes/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one forward+backward of Query3DUnified (encoders + 4-layer promptable query decoder) on one batch
+of synthetic scenes (BASELINE config 2: B=8 scenes/GPU, N_seg=1024, N_q=100, d=256, H=8, L=4, three memories,
+parallel cross-attention, spatial self-attention, 2-D padding masks, loss = mean(query)), bf16 MFMA operands with
+fp32 accumulation, inputs resident in HBM, followed by the data-parallel gradient exchange (flat-buffer RCCL
+all-reduce, N > 1).  The step is captured once into a HIP graph and replayed.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pq3d_amd import synth  # noqa: E402
+from pq3d_amd.model import Query3DUnified, make_cfg  # noqa: E402
+from pq3d_amd.parallel import FlatGradAllReducer  # noqa: E402
+from pq3d_amd.profiler import KernelTimer  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+CONFIGS = {
+    # name: (B, N_seg, N_q, d, H, L, memories, heads, use_self_mask)
+    "c2": dict(B=8, Ns=1024, Nq=100, d=256, H=8, L=4, memories=["voxel", "mv", "pc"], heads=[], use_self_mask=False),
+    "c4": dict(B=4, Ns=4096, Nq=200, d=256, H=8, L=4, memories=["voxel", "mv", "pc"], heads=["mask"],
+               use_self_mask=True),
+    "c1": dict(B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=[], use_self_mask=False, spatial=False,
+               structure="sequential"),
+}
+
+
+def step_flops(c) -> float:
+    """SURVEY §8d closed form (multiply-add = 2 FLOP; STEP = 3 x FWD)."""
+    B, Ns, Nq, d, H, L, M = c["B"], c["Ns"], c["Nq"], c["d"], c["H"], c["L"], len(c["memories"])
+    F, C = 2048, 201
+    ca = M * (2 * B * d * d * (2 * Nq + 2 * Ns) + 4 * B * Nq * (Ns + 1) * d)
+    sa = 8 * B * Nq * d * d + 4 * B * Nq * Nq * d + (2 * B * Nq * Nq * 5 * H if c.get("spatial", True) else 0)
+    ffn = 4 * B * Nq * d * F
+    mh = 2 * B * Nq * (d * d + d * C) + M * (2 * B * d * d * (Nq + Ns) + 2 * B * Ns * Nq * d)
+    enc = M * 2 * B * Ns * d * d + 2 * B * (Nq + Ns) * d * d + 2 * B * (Nq + Ns) * 3 * (d // 2)
+    calls = (L + 1) if "mask" in c["heads"] else 0
+    return 3.0 * (L * (ca + sa + ffn) + calls * mh + enc)
+
+
+def build(c, compute, device, seed):
+    cfg = make_cfg(d=c["d"], H=c["H"], L=c["L"], memories=c["memories"], heads=c["heads"],
+                   spatial=c.get("spatial", True), structure=c.get("structure", "parallel"),
+                   use_self_mask=c["use_self_mask"], C=201, foc=[0, 2])
+    model = Query3DUnified(cfg, compute=compute)
+    sd = synth.fill_module(model, 0)
+    model.to(device)
+    dd = synth.synth_data_dict(c["B"], c["Ns"], c["Nq"], {m: c["d"] for m in c["memories"]}, seed=seed,
+                               memories=c["memories"])
+    return model, sd, dd
+
+
+def loss_fn(out, heads):
+    loss = out["query_embeds"].mean() if "query_embeds" in out else out["query"].mean()
+    if "mask" in heads:
+        for cl, m in zip(out["predictions_class"], out["predictions_mask"]):
+            loss = loss + m.clamp(min=-50.0).mean() + torch.where(torch.isfinite(cl), cl, torch.zeros_like(cl)).mean()
+    return loss
+
+
+def cpu_baseline(c, sd, dd, steps, warmup):
+    """The oracle (CPU restatement of the reference path, pinned to the reference's outputs by the golden
+    fixtures) timed on this host's cores: forward+backward, fp32, dropout 0 -- same workload, bounded sample."""
+    from oracle import pq3d_oracle as O  # CPU baseline leg only
+    ocfg = dict(memories=c["memories"], heads=c["heads"], hidden_size=c["d"], num_heads=c["H"], num_layers=c["L"],
+                structure=c.get("structure", "parallel"), spatial_selfattn=c.get("spatial", True),
+                use_self_mask=c["use_self_mask"], filter_out_classes=[0, 2])
+    sdo = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("gauss_B")) for k, v in sd.items()}
+    times = []
+    for i in range(warmup + steps):
+        for v in sdo.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = O.query3d_unified_forward(sdo, ocfg, dict(dd))
+        loss_fn(out, c["heads"]).backward()
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": c["B"] / med, "unit": "scenes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "ms_per_step": med * 1e3,
+            "sample": f"{steps} timed fwd+bwd steps (median) of the same {c['B']}-scene batch after {warmup} warm-up, "
+                      f"fp32, torch CPU ops, dropout 0"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="timed CPU-baseline steps (0 disables)")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    c = dict(CONFIGS[args.config])
+    model, sd, dd_cpu = build(c, args.compute, dev, seed=1234 + rank)
+    dd = {k: v.to(dev) for k, v in dd_cpu.items()}
+    params = [p for p in model.parameters() if p.requires_grad]
+    reducer = FlatGradAllReducer(params)
+
+    def fwd_bwd():
+        model.zero_grad(set_to_none=True)
+        out = model(dict(dd))
+        loss_fn(out, c["heads"]).backward()
+        reducer.pack()
+
+    graph = None
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fwd_bwd()
+            graph = g
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            torch.cuda.synchronize()
+            graph = None
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            fwd_bwd()
+        reducer.all_reduce()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    value = c["B"] * world * args.steps / dt
+
+    result = None
+    if rank == 0:
+        flops = step_flops(c)
+        peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_TFLOPS
+        # per-kernel attribution: eager profiled pass with HIP events on the launch stream
+        with KernelTimer() as kt:
+            for _ in range(args.profile_steps):
+                fwd_bwd()
+        summ = kt.summary()
+        tot = sum(v["ms"] for v in summ.values())
+        (kname, kkey), top = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        per_launch_ms = top["ms"] / top["calls"]
+        if top["flops"] > 0:
+            ach = top["flops"] / top["calls"] / (per_launch_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "traffic": None}
+        else:
+            ach = top["bytes"] / top["calls"] / (per_launch_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                    "traffic": None}
+        roof.update({"kernel": kname, "shape": kkey, "avg_launch_us": per_launch_ms * 1e3,
+                     "launches_per_step": top["calls"] / args.profile_steps,
+                     "share_of_kernel_time": top["ms"] / tot,
+                     "kernel_ms_per_step_eager_events": tot / args.profile_steps})
+        fams = {}
+        for (n, _k), v in summ.items():
+            f = fams.setdefault(n, dict(ms=0.0, calls=0))
+            f["ms"] += v["ms"] / args.profile_steps
+            f["calls"] += v["calls"] / args.profile_steps
+        result = {
+            "metric": "decoder fwd+bwd scenes/sec at (N_seg=1024,N_q=100,d=256,L=4)" if args.config == "c2"
+            else f"decoder fwd+bwd scenes/sec ({args.config})",
+            "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {args.config}: B={c['B']} scenes/GPU, N_seg={c['Ns']}, "
+                                   f"N_q={c['Nq']}, d={c['d']}, H={c['H']}, L={c['L']}, memories={c['memories']}, "
+                                   f"parallel cross-attn + spatial self-attn + FFN2048, heads={c['heads']}, "
+                                   f"fwd+bwd+grad-pack{'+RCCL all-reduce' if world > 1 else ''}",
+                       "global_batch": c["B"] * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                       "dropout": 0.0, "activation": "relu"},
+            "step_algorithmic_gflop": flops / 1e9,
+            "step_roofline_frac": flops * world / (dt / args.steps) / (peak * 1e12 * world),
+            "roofline": roof,
+            "kernel_families_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(fams.items())},
+        }
+        if world == 1 and args.cpu_steps > 0:
+            result["cpu_baseline"] = cpu_baseline(c, sd, dd_cpu, args.cpu_steps, 2)
+            result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -169,4 +169,10 @@ def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C
     _fill(d.A, A); _fill(d.A2, A2); _fill(d.B, B); _fill(d.B2, B2); _fill(d.bias, bias); _fill(d.C, Cs)
     _fill(d.C2, C2); _fill(d.aux, aux); _fill(d.row_mask, row_mask)
     d.row_scale, d.row_fill_flag, d.mask_out = ptr(row_scale), ptr(row_fill_flag), ptr(mask_out)
-    check(lib().pq3d_gemm(C.byref(d), stream()), "pq3d_gemm")
+    from .profiler import timed
+    nb = (M * K * (2 if d.dtA else 4) + N * K * (2 if d.dtB else 4)) * len(A) * batch + \
+        M * N * (2 if d.dtC else 4) * (1 if kconcat else len(A)) * batch
+    key = f"M{M}N{N}K{K}g{len(A)}b{batch}{'T' if transA else 'N'}{'T' if transB else 'N'}" \
+          f"{'k' if kconcat else ''}{'s%d' % splitk if splitk > 1 else ''}ct{ct}"
+    check(timed("pq3d_gemm", key, 2.0 * M * N * K * len(A) * batch, nb, lib().pq3d_gemm, C.byref(d), stream()),
+          "pq3d_gemm")

@@ -101,6 +101,7 @@ class Query3DUnified(nn.Module):
                 raise NotImplementedError("generation head (HF T5 body) is a 'next' row (SURVEY §8f-3)")
             setattr(self, head + "_head", build_module_by_name(cfg.model.get(head + "_head")))
         self.compute = compute
+        self._coef_cache = {}
         M.set_compute(self, compute)
 
     @property
@@ -112,8 +113,10 @@ class Query3DUnified(nn.Module):
             ct = self.ct
             c = ops.linear(locs[:, :, :3].contiguous(), self.coord_encoder[0].weight, self.coord_encoder[0].bias, ct=ct)
             b = ops.linear(locs[:, :, 3:6].contiguous(), self.box_encoder[0].weight, self.box_encoder[0].bias, ct=ct)
-            B = locs.shape[0]
-            coef = torch.tensor([[1.0] * B, [float(box_times)] * B], device=locs.device)
+            key = (locs.shape[0], box_times, locs.device)
+            if key not in self._coef_cache:  # cached: no H2D copy inside a captured HIP graph
+                self._coef_cache[key] = torch.tensor([[1.0] * key[0], [float(box_times)] * key[0]], device=locs.device)
+            coef = self._coef_cache[key]
             return ops.add_layernorm(None, [c, b], [self.coord_encoder[1].weight, self.box_encoder[1].weight],
                                      [self.coord_encoder[1].bias, self.box_encoder[1].bias],
                                      eps=self.coord_encoder[1].eps, coef=coef)

@@ -403,6 +403,9 @@ class MaskHeadSegLevel(_PostNormBase):
         memories_for_match = [m for m in memories_for_match if m in ("voxel", "mv", "pc")]
         self.mask_pred_list = layer_repeat(MaskPredictionLayer(hidden_size), len(memories_for_match))
         self.num_targets = num_targets
+        # reference quirk: filter_out_classes=None makes x[..., None] = -inf overwrite every logit (mask_head.py:28)
+        foc = list(range(num_targets)) if filter_out_classes is None else list(filter_out_classes)
+        self.register_buffer("_foc_cols", torch.tensor(foc, dtype=torch.int32), persistent=False)
 
     def project_keys(self, seg_fts_for_match):
         """k_proj of every matching memory (rows of padded segments zeroed) + the masked-mean denominators.
@@ -418,13 +421,9 @@ class MaskHeadSegLevel(_PostNormBase):
         if skip_prediction:
             return None, None, offline_attn_masks
         ct = self.ct
-        foc = self.filter_out_classes
         cls_logits = mlp_head_forward(self.cls_head, query, ct)
-        if foc is None:  # reference quirk: x[..., None] = -inf overwrites every logit (mask_head.py:28)
-            foc = list(range(self.num_targets))
-        if len(foc):
-            cols = torch.tensor(list(foc), dtype=torch.int32, device=query.device)
-            cls_logits = ops.fill_cols(cls_logits, cols, float("-inf"))
+        if self._foc_cols.numel():
+            cls_logits = ops.fill_cols(cls_logits, self._foc_cols, float("-inf"))
         k_list, inv_den = keys if keys is not None else self.project_keys(seg_fts_for_match)
         q_list = [ops.linear(query, mp.q_proj.weight, mp.q_proj.bias, ct=ct, out_dtype=ops.act_dtype(ct))
                   for mp in self.mask_pred_list[:len(k_list)]]

@@ -12,6 +12,7 @@ from torch.autograd import Function
 
 from . import _lib as L
 from ._lib import BF16, F32
+from .profiler import timed
 
 _empty = torch.empty
 
@@ -169,7 +170,11 @@ class _Attention(Function):
         o = _empty(q.shape, dtype=q.dtype, device=q.device)
         lse = _empty(B, H, Lq, dtype=torch.float32, device=q.device)
         d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias)
-        L.check(L.lib().pq3d_attn_fwd(C.byref(d), L.stream()), "pq3d_attn_fwd")
+        Lk = k.shape[1]
+        fl = 4.0 * B * Lq * Lk * dm
+        nb = (q.numel() * 2 + k.numel() * 2) * q.element_size()
+        L.check(timed("pq3d_attn_fwd", f"B{B}H{H}Lq{Lq}Lk{Lk}dh{dm // H}ct{ct}", fl, nb, L.lib().pq3d_attn_fwd,
+                      C.byref(d), L.stream()), "pq3d_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, bias, kpm, mask, row_open)
         ctx.cfg = (H, zero_attn, scale, ct)
         return o
@@ -184,7 +189,12 @@ class _Attention(Function):
         dbias = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[3]) else None
         d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias)
         d.dout, d.dq, d.dk, d.dv, d.delta, d.dbias = map(L.ptr, (do, dq, dk, dv, delta, dbias))
-        L.check(L.lib().pq3d_attn_bwd(C.byref(d), L.stream()), "pq3d_attn_bwd")
+        B, Lq, dm = q.shape
+        Lk = k.shape[1]
+        fl = 14.0 * B * Lq * Lk * dm  # dQ kernel: S, dP, dQ (6) + dK/dV kernel: S, dP, dK, dV (8) per B*Lq*Lk*d
+        nb = (q.numel() * 3 + k.numel() * 4) * q.element_size()
+        L.check(timed("pq3d_attn_bwd", f"B{B}H{H}Lq{Lq}Lk{Lk}dh{dm // H}ct{ct}", fl, nb, L.lib().pq3d_attn_bwd,
+                      C.byref(d), L.stream()), "pq3d_attn_bwd")
         return dq, dk, dv, dbias, None, None, None, None, None, None, None
 
 
@@ -221,7 +231,9 @@ class _AddLN(Function):
         mean = _empty(M, R, dtype=torch.float32, device=y.device)
         rstd = torch.empty_like(mean)
         d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd)
-        L.check(L.lib().pq3d_add_ln_fwd(C.byref(d), L.stream()), "pq3d_add_ln_fwd")
+        nb = (M + 1 + (x is not None)) * R * dm * 4.0
+        L.check(timed("pq3d_add_ln_fwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_fwd, C.byref(d), L.stream()),
+                "pq3d_add_ln_fwd")
         ctx.save_for_backward(x, coef, mean, rstd, *os_, *gammas, *betas)
         ctx.cfg = (eps, rows_per_scene, M)
         return y
@@ -242,7 +254,10 @@ class _AddLN(Function):
         d.dy, d.dx = L.ptr(dy), L.ptr(dx)
         for m in range(M):
             d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_os[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
-        L.check(L.lib().pq3d_add_ln_bwd(C.byref(d), L.stream()), "pq3d_add_ln_bwd")
+        R, dm = os_[0].numel() // os_[0].shape[-1], os_[0].shape[-1]
+        nb = (3 * M + 1 + (x is not None)) * R * dm * 4.0
+        L.check(timed("pq3d_add_ln_bwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_bwd, C.byref(d), L.stream()),
+                "pq3d_add_ln_bwd")
         if x is not None and x.dtype != torch.float32:
             dx = dx.to(x.dtype)
         d_os = [g if g.dtype == o.dtype else g.to(o.dtype) for g, o in zip(d_os, os_)]

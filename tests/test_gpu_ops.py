@@ -1,0 +1,261 @@
+"""GPU: every C-ABI kernel against the oracle / a plain fp32-fp64 restatement, through the ctypes boundary.
+fp32 compute type must match to ~1e-5 (exact-f32 MFMA); bf16 compute type to bf16-operand tolerance."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pq3d_oracle as O
+from pq3d_amd import ops
+from pq3d_amd._lib import BF16, F32
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def tol(ct):
+    return dict(atol=2e-5, rtol=2e-5) if ct == F32 else dict(atol=3e-2, rtol=3e-2)
+
+
+def close(a, b, ct, what="", scale_norm=True, **kw):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    t = {**tol(ct), **kw}
+    fin = torch.isfinite(b)
+    assert torch.equal(fin, torch.isfinite(a)), f"{what}: non-finite pattern differs"
+    s = max(1.0, float(b[fin].abs().max())) if scale_norm and fin.any() else 1.0
+    err = float((a[fin] - b[fin]).abs().max()) if fin.any() else 0.0
+    assert err <= t["atol"] * s + t["rtol"] * s, f"{what}: max err {err:.3e} (scale {s:.2e})"
+
+
+# ---------------------------------------------------------------------------------------------- GEMM / linear
+@pytest.mark.parametrize("ct", [F32, BF16])
+@pytest.mark.parametrize("R,K,N", [(100, 64, 64), (200, 256, 201), (37, 3, 64), (64, 2048, 256), (129, 5, 8),
+                                   (1, 64, 1)])
+@pytest.mark.parametrize("act", [None, "relu", "gelu"])
+def test_linear_fwd_bwd(ct, R, K, N, act):
+    x, x2, w, b = rnd(R, K), rnd(R, K, seed=1), rnd(N, K, scale=0.1), rnd(N, scale=0.1)
+    gy = rnd(R, N, seed=3)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, x2, w, b)]
+    pre = (ref_in[0] + ref_in[1]) @ ref_in[2].t() + ref_in[3]
+    yr = O.activation(pre, act) if act else pre
+    yr.backward(gy.double())
+    dev = [t.to(DEV).requires_grad_(True) for t in (x, x2, w, b)]
+    y = ops.linear(dev[0], dev[1 + 1], dev[3], x2=dev[1], ct=ct, act=act)
+    y.backward(gy.to(DEV))
+    close(y, yr, ct, "y")
+    for name, a, r in zip(("dx", "dx2", "dw", "db"), dev, ref_in):
+        close(a.grad, r.grad, ct, name)
+
+
+@pytest.mark.parametrize("ct", [F32, BF16])
+def test_linear_row_mask_fill_and_bf16_out(ct):
+    R, K, N = 150, 64, 96
+    x, w = rnd(R, K), rnd(N, K, scale=0.1)
+    keep = torch.rand(R) > 0.3
+    fill = torch.rand(R) > 0.8
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = ops.linear(xd, wd, None, ct=ct, row_mask=keep.to(DEV), out_dtype=ops.act_dtype(ct))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = (xr @ wr.t()) * keep[:, None]
+    close(y, yr, ct, "row_mask")
+    gy = rnd(R, N, seed=5)
+    y.backward(gy.to(DEV).to(y.dtype))
+    yr.backward(gy)
+    close(xd.grad, xr.grad, ct, "dx")
+    close(wd.grad, wr.grad, ct, "dw")
+    y2 = ops.linear(xd, wd, None, ct=ct, fill_flag=fill.to(DEV), fill_value=float("-inf"))
+    close(y2, (x @ w.t()).masked_fill(fill[:, None], float("-inf")), ct, "fill")
+
+
+@pytest.mark.parametrize("ct", [F32, BF16])
+def test_mask_logits(ct):
+    B, Ns, Nq, d, M = 2, 75, 21, 64, 3
+    ks = [rnd(B, Ns, d, seed=m) for m in range(M)]
+    qs = [rnd(B, Nq, d, seed=10 + m) for m in range(M)]
+    masks = [torch.rand(B, Ns) > 0.7 for _ in range(M)]
+    seg_pad = masks[0] & masks[1] & masks[2]
+    ksm = [k * (~m)[..., None] for k, m in zip(ks, masks)]
+    kd = [k.to(DEV).to(ops.act_dtype(ct)).requires_grad_(True) for k in ksm]
+    qd = [q.to(DEV).to(ops.act_dtype(ct)).requires_grad_(True) for q in qs]
+    inv_den = ops.mask_inv_den([m.to(DEV) for m in masks])
+    den = sum((~m).float() for m in masks)
+    close(inv_den, 1.0 / (den + 1e-8), F32, "inv_den", scale_norm=False, rtol=1e-6, atol=1e-3)
+    logits, amask = ops.mask_logits(kd, qd, inv_den, seg_pad.to(DEV), ct=ct)
+    kr = [k.detach().float().cpu().requires_grad_(True) for k in kd]
+    qr = [q.detach().float().cpu().requires_grad_(True) for q in qd]
+    lr = sum(torch.einsum("bld,bmd->blm", k, q) for k, q in zip(kr, qr)) / (den[..., None] + 1e-8)
+    lr = lr.masked_fill(seg_pad[..., None], -1e6)
+    close(logits, lr, ct, "logits", scale_norm=False, atol=2e-4 if ct == F32 else 0.15, rtol=1e-5 if ct == F32 else 2e-2)
+    ar = torch.sigmoid(logits.detach().cpu()).permute(0, 2, 1) < 0.5
+    assert torch.equal(amask.cpu(), ar)
+    gy = rnd(B, Ns, Nq, seed=9)
+    logits.backward(gy.to(DEV))
+    lr.backward(gy)
+    for a, r in zip(kd + qd, kr + qr):
+        close(a.grad, r.grad, ct, "dk/dq")
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, H, scale, zero_attn, kpm, mask, row_open, bias):
+    B, Lq, d = q.shape
+    Lk, dh = k.shape[1], d // H
+    sp = lambda t: t.view(B, -1, H, dh).permute(0, 2, 1, 3)
+    s = (sp(q) @ sp(k).transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias
+    if mask is not None:
+        m = mask.clone()
+        if row_open is not None:
+            m[row_open] = False
+        s = s.masked_fill(m[:, None], float("-inf"))
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    vv = sp(v)
+    if zero_attn:
+        s = torch.cat([s, s.new_zeros(B, H, Lq, 1)], -1)
+        vv = torch.cat([vv, vv.new_zeros(B, H, 1, dh)], 2)
+    o = torch.softmax(s, -1) @ vv
+    return o.permute(0, 2, 1, 3).reshape(B, Lq, d)
+
+
+@pytest.mark.parametrize("ct", [F32, BF16])
+@pytest.mark.parametrize("H,dh", [(4, 16), (8, 32), (2, 64)])
+@pytest.mark.parametrize("Lq,Lk,mode", [(16, 128, "kpm"), (100, 130, "mask3d"), (37, 70, "bias"), (200, 333, "kpm"),
+                                        (20, 20, "self")])
+def test_attention_fwd_bwd(ct, H, dh, Lq, Lk, mode):
+    B, d = 2, H * dh
+    q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
+    g = torch.Generator().manual_seed(Lq * Lk + H)
+    kpm = mask = row_open = bias = None
+    zero_attn = mode in ("kpm", "mask3d")
+    if mode in ("kpm", "self", "bias"):
+        kpm = torch.arange(Lk)[None, :] >= torch.tensor([Lk, max(1, Lk // 2)])[:, None]
+    if mode == "mask3d":
+        mask = torch.rand(B, Lq, Lk, generator=g) < 0.6
+        mask[:, 1, :] = True
+        mask[0, 3, :] = True
+        row_open = mask.all(-1)
+    if mode == "bias":
+        bias = torch.randn(B, H, Lq, Lk, generator=g)
+    ad = ops.act_dtype(ct)
+    qd, kd, vd = (t.to(DEV).to(ad).requires_grad_(True) for t in (q, k, v))
+    bd = bias.to(DEV).requires_grad_(True) if bias is not None else None
+    todev = lambda t: None if t is None else t.to(DEV)
+    o = ops.attention(qd, kd, vd, H=H, ct=ct, zero_attn=zero_attn, kpm=todev(kpm), mask=todev(mask),
+                      row_open=todev(row_open), bias=bd)
+    qr, kr, vr = (t.detach().double().cpu().requires_grad_(True) for t in (qd, kd, vd))
+    br = bias.double().requires_grad_(True) if bias is not None else None
+    orf = attn_ref(qr, kr, vr, H, 1 / math.sqrt(dh), zero_attn, kpm, mask, row_open, br)
+    close(o, orf, ct, "o")
+    go = rnd(B, Lq, d, seed=7)
+    o.backward(go.to(DEV).to(ad))
+    orf.backward(go.to(ad).double())
+    close(qd.grad, qr.grad, ct, "dq")
+    close(kd.grad, kr.grad, ct, "dk")
+    close(vd.grad, vr.grad, ct, "dv")
+    if bias is not None:
+        close(bd.grad, br.grad, ct, "dbias")
+
+
+def test_attention_fully_masked_row_with_zero_attn_is_zero():
+    B, H, dh, Lq, Lk = 1, 4, 16, 16, 40
+    q, k, v = (rnd(B, L, H * dh, seed=s).to(DEV) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3)))
+    kpm = torch.ones(B, Lk, dtype=torch.bool, device=DEV)
+    o = ops.attention(q, k, v, H=H, ct=F32, zero_attn=True, kpm=kpm)
+    assert float(o.abs().max()) == 0.0
+
+
+def test_mask_row_all():
+    m = torch.rand(3, 17, 130) < 0.5
+    m[1, 4] = True
+    m[2, 0] = True
+    assert torch.equal(ops.mask_row_all(m.to(DEV)).cpu(), m.all(-1))
+
+
+# ---------------------------------------------------------------------------------------------- layernorm
+@pytest.mark.parametrize("d", [64, 256, 768, 100])
+@pytest.mark.parametrize("M,with_x,with_coef", [(1, True, False), (3, True, False), (2, False, True), (3, True, True)])
+def test_add_layernorm(d, M, with_x, with_coef):
+    B, Lq = 3, 11
+    x = rnd(B, Lq, d) if with_x else None
+    os_ = [rnd(B, Lq, d, seed=5 + m) for m in range(M)]
+    gam = [rnd(d, seed=20 + m).abs() + 0.5 for m in range(M)]
+    bet = [rnd(d, seed=30 + m) for m in range(M)]
+    coef = torch.rand(M, B) + 0.1 if with_coef else None
+    leaves = [t.to(DEV).requires_grad_(True) for t in ([x] if with_x else []) + os_ + gam + bet]
+    xd = leaves[0] if with_x else None
+    rest = leaves[1:] if with_x else leaves
+    y = ops.add_layernorm(xd, rest[:M], rest[M:2 * M], rest[2 * M:], eps=1e-5,
+                          coef=coef.to(DEV) if with_coef else None)
+    refl = [t.clone().double().requires_grad_(True) for t in ([x] if with_x else []) + os_ + gam + bet]
+    xr = refl[0] if with_x else 0.0
+    rr = refl[1:] if with_x else refl
+    yr = 0
+    for m in range(M):
+        w = coef[m].double()[:, None, None] if with_coef else 1.0 / M
+        yr = yr + w * O.layer_norm(xr + rr[m], rr[M + m], rr[2 * M + m])
+    close(y, yr, F32, "y")
+    gy = rnd(B, Lq, d, seed=77)
+    y.backward(gy.to(DEV))
+    yr.backward(gy.double())
+    for a, r in zip(leaves, refl):
+        close(a.grad, r.grad, F32, "grad", atol=5e-5, rtol=5e-5)
+
+
+# ---------------------------------------------------------------------------------------------- misc
+def test_pairwise_locs_and_fourier_and_spatial_bias():
+    c = torch.rand(2, 23, 3) * 4
+    close(ops.pairwise_locs(c.to(DEV)), O.calc_pairwise_locs(c), F32, "pairwise", atol=2e-6, rtol=2e-6)
+    G = torch.randn(3, 32)
+    cmin, cmax = torch.tensor([[0., 0, 0], [-1, -1, 0]]), torch.tensor([[4., 4, 4], [5, 4, 3]])
+    close(ops.fourier(c.to(DEV), cmin.to(DEV), cmax.to(DEV), G.to(DEV)), O.fourier_embed(c, G, cmin, cmax), F32,
+          "fourier", atol=2e-5, rtol=0)
+    pl = O.calc_pairwise_locs(c)
+    W, bw = rnd(4, 5), rnd(4)
+    Wd, bd = W.to(DEV).requires_grad_(True), bw.to(DEV).requires_grad_(True)
+    bias = ops.spatial_bias(pl.to(DEV), Wd, bd)
+    Wr, br = W.clone().requires_grad_(True), bw.clone().requires_grad_(True)
+    ref = torch.log(torch.clamp(torch.relu(pl @ Wr.t() + br), min=1e-6)).permute(0, 3, 1, 2)
+    close(bias, ref, F32, "spatial bias", atol=1e-5, rtol=1e-5)
+    gy = rnd(*ref.shape, seed=4)
+    bias.backward(gy.to(DEV))
+    ref.backward(gy)
+    close(Wd.grad, Wr.grad, F32, "dW", atol=1e-4, rtol=1e-4)
+    close(bd.grad, br.grad, F32, "dbw", atol=1e-4, rtol=1e-4)
+
+
+def test_gate_fill_colsum_scatter():
+    q, u, g = rnd(5, 7, 16), rnd(5, 7, 16, seed=1), rnd(5, 7, 16, seed=2)
+    dl = [t.to(DEV).requires_grad_(True) for t in (q, u, g)]
+    rl = [t.clone().requires_grad_(True) for t in (q, u, g)]
+    y = ops.gate_mix(*dl)
+    s = torch.sigmoid(rl[2])
+    yr = (1 - s) * rl[0] + s * rl[1]
+    close(y, yr, F32, "gate")
+    y.sum().backward(); yr.sum().backward()
+    for a, r in zip(dl, rl):
+        close(a.grad, r.grad, F32, "gate grad")
+    x = rnd(9, 21).to(DEV).requires_grad_(True)
+    cols = torch.tensor([0, 2, 20], dtype=torch.int32, device=DEV)
+    f = ops.fill_cols(x, cols, float("-inf"))
+    assert torch.isinf(f[:, [0, 2, 20]]).all() and torch.equal(f[:, 1], x[:, 1])
+    torch.where(torch.isfinite(f), f, torch.zeros_like(f)).sum().backward()
+    assert float(x.grad[:, [0, 2, 20]].abs().max()) == 0 and float(x.grad[:, 1].min()) == 1
+    big = rnd(1000, 130)
+    close(ops.colsum(big.to(DEV)), big.sum(0), F32, "colsum", atol=1e-4, rtol=1e-5)
+    src = rnd(5000, 96)
+    idx = torch.randint(0, 300, (5000,))
+    sd = src.to(DEV).requires_grad_(True)
+    out = ops.scatter_mean(sd, idx.to(DEV), 320)
+    sr = src.clone().requires_grad_(True)
+    outr = O.scatter_mean(sr, idx, 320)
+    close(out, outr, F32, "scatter_mean", atol=1e-5, rtol=1e-5)
+    gy = rnd(320, 96, seed=3)
+    out.backward(gy.to(DEV)); outr.backward(gy)
+    close(sd.grad, sr.grad, F32, "scatter_mean grad")
