@@ -106,7 +106,15 @@ def test_bf16_model_close_to_oracle(name):
     assert rel(out["query_embeds"], collect[-1]) < 2e-2
     assert rel(out["ground_logits"], oout["ground_logits"]) < 2e-2
     assert abs(loss.item() - oloss.item()) < 2e-2 * max(1.0, abs(oloss.item()))
-    worst = max((rel(g[n], og[n]), n) for n in og)
+    # gradients that are mathematically ~0 (softmax is invariant to a key-side bias) are rounding noise in both
+    # implementations: normalise by the larger of the tensor's own scale and 1e-2 x the global gradient scale
+    gmax = max(float(v.abs().max()) for v in og.values())
+
+    def grel(a, b):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        return float((a - b).abs().max() / max(float(b.abs().max()), 1e-2 * gmax))
+
+    worst = max((grel(g[n], og[n]), n) for n in og)
     assert worst[0] < 6e-2, f"worst gradient {worst}"
 
 

@@ -40,9 +40,14 @@ def close(a, b, ct, what="", scale_norm=True, **kw):
 @pytest.mark.parametrize("act", [None, "relu", "gelu"])
 def test_linear_fwd_bwd(ct, R, K, N, act):
     x, x2, w, b = rnd(R, K), rnd(R, K, seed=1), rnd(N, K, scale=0.1), rnd(N, scale=0.1)
+    if ct == BF16:  # bf16-representable operands so that the activation kink is hit identically on both sides
+        x, x2, w = (t.bfloat16().float() for t in (x, x2, w))
     gy = rnd(R, N, seed=3)
     ref_in = [t.clone().double().requires_grad_(True) for t in (x, x2, w, b)]
-    pre = (ref_in[0] + ref_in[1]) @ ref_in[2].t() + ref_in[3]
+    xs = ref_in[0] + ref_in[1]
+    if ct == BF16:  # the kernel rounds the fp32 sum x + x2 to bf16 when staging the MFMA operand
+        xs = xs + ((xs.float().bfloat16().double() - xs).detach())
+    pre = xs @ ref_in[2].t() + ref_in[3]
     yr = O.activation(pre, act) if act else pre
     yr.backward(gy.double())
     dev = [t.to(DEV).requires_grad_(True) for t in (x, x2, w, b)]

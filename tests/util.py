@@ -65,6 +65,7 @@ def model_case(args, device="cpu"):
     cfg = make_cfg(d=d, H=args["H"], L=args["L"], memories=args["memories"], heads=args["heads"],
                    spatial=args["spatial"], structure=args["structure"], ground_hidden=d // 2 * 3 // 3, **kw)
     model = Query3DUnified(cfg, compute="fp32")
+    model.eval()  # the fixtures were generated in eval mode (drop_memories_test applies, dropout off)
     sd = synth.fill_module(model, args["seed"])
     dd = synth.synth_data_dict(args["B"], args["Ns"], args["Nq"], {m: d for m in args["memories"]},
                                seed=args["data_seed"], memories=args["memories"],
