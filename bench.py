@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8, help="timed CPU-baseline steps (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--dump-kernels", default=None, help="write the per-(entry point, shape) timing table here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,6 +206,15 @@ def main():
                      "launches_per_step": top["calls"] / args.profile_steps,
                      "share_of_kernel_time": top["ms"] / tot,
                      "kernel_ms_per_step_eager_events": tot / args.profile_steps})
+        if args.dump_kernels:
+            with open(args.dump_kernels, "w") as f:
+                f.write(f"{'entry point':18s} {'shape':44s} {'calls/step':>10s} {'us/launch':>10s} {'ms/step':>8s} "
+                        f"{'TFLOP/s':>8s} {'GB/s':>8s}\n")
+                for (n, k), v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                    us = v["ms"] / v["calls"] * 1e3
+                    f.write(f"{n:18s} {k:44s} {v['calls'] / args.profile_steps:10.1f} {us:10.1f} "
+                            f"{v['ms'] / args.profile_steps:8.3f} {v['flops'] / v['calls'] / us / 1e6:8.2f} "
+                            f"{v['bytes'] / v['calls'] / us / 1e3:8.1f}\n")
         fams = {}
         for (n, _k), v in summ.items():
             f = fams.setdefault(n, dict(ms=0.0, calls=0))

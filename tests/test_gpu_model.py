@@ -89,33 +89,41 @@ def test_fp32_encoder_structures(name):
             util.check_against(z, "grad/" + n, p.grad, atol=5e-6, rtol=5e-5, cap=util.MAX_GRAD)
 
 
-@pytest.mark.parametrize("name", ["F1_c1", "F4_c2_slice", "F5_dimloc6"])
-def test_bf16_model_close_to_oracle(name):
-    """bf16 MFMA operands, fp32 accumulate: scale-normalised error of outputs and gradients (2-D masks only)."""
+@pytest.mark.parametrize("name", ["F1_c1", "F4_c2_slice", "F5_dimloc6", "F2_c1_mask", "F4b_c4_slice"])
+def test_bf16_model_matches_rounding_oracle(name):
+    """bf16 MFMA operands, fp32 accumulate/softmax/LayerNorm.  Checked against the oracle run with the SAME operand
+    rounding points (oracle.operand_rounding(bf16)): then ReLU kinks and self-mask thresholds are hit identically
+    and the remaining difference is accumulation order + where P is rounded -> outputs within 1e-3 of output scale
+    (north_star "1e-3 bf16"); parameter gradients (backward intermediates are also bf16) within 3e-2."""
     z, args = util.load_fixture(name)
     _cfg, model, sd, dd = util.model_case(args)
     set_compute(model, "bf16")
     out, loss, g = run_hip(model, args, dd)
-    oout, collect, oloss, og = util.run_oracle(args, sd, dd)
+    oout, collect, oloss, og = util.run_oracle(args, sd, dd, emulate=torch.bfloat16)
 
-    def rel(a, b):
+    def rel(a, b, floor=0.0):
         a, b = a.detach().float().cpu(), b.detach().float().cpu()
-        fin = torch.isfinite(b)
-        return float((a[fin] - b[fin]).abs().max() / b[fin].abs().max().clamp(min=1e-6))
+        fin = torch.isfinite(b) & (b > -1e5)
+        assert torch.equal(torch.isfinite(b), torch.isfinite(a))
+        return float((a[fin] - b[fin]).abs().max() / max(float(b[fin].abs().max()), floor, 1e-6))
 
-    assert rel(out["query_embeds"], collect[-1]) < 2e-2
-    assert rel(out["ground_logits"], oout["ground_logits"]) < 2e-2
-    assert abs(loss.item() - oloss.item()) < 2e-2 * max(1.0, abs(oloss.item()))
+    assert rel(out["query_embeds"], collect[-1]) < 2e-3
+    if "ground" in args["heads"]:
+        assert rel(out["ground_logits"], oout["ground_logits"]) < 2e-3
+    if "mask" in args["heads"]:
+        flips = 0.0
+        for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
+            assert rel(m, r) < 3e-3
+            flips = max(flips, float(((m.float().cpu() < 0) != (r < 0)).float().mean()))
+        assert flips < 1e-3, f"self-mask bit-flip rate vs rounding oracle {flips:.5f}"
+        for c, r in zip(out["predictions_class"], oout["predictions_class"]):
+            assert rel(c, r) < 3e-3
+    assert abs(loss.item() - oloss.item()) < 3e-3 * max(1.0, abs(oloss.item()))
     # gradients that are mathematically ~0 (softmax is invariant to a key-side bias) are rounding noise in both
     # implementations: normalise by the larger of the tensor's own scale and 1e-2 x the global gradient scale
     gmax = max(float(v.abs().max()) for v in og.values())
-
-    def grel(a, b):
-        a, b = a.detach().float().cpu(), b.detach().float().cpu()
-        return float((a - b).abs().max() / max(float(b.abs().max()), 1e-2 * gmax))
-
-    worst = max((grel(g[n], og[n]), n) for n in og)
-    assert worst[0] < 6e-2, f"worst gradient {worst}"
+    worst = max((rel(g[n], og[n], floor=1e-2 * gmax), n) for n in og)
+    assert worst[0] < 3e-2, f"worst gradient {worst}"
 
 
 def test_bf16_self_mask_first_call_and_flip_rate():
@@ -124,12 +132,12 @@ def test_bf16_self_mask_first_call_and_flip_rate():
     set_compute(model, "bf16")
     out, _loss, _g = run_hip(model, args, dd, grads=False)
     oout, _c, _l, _ = util.run_oracle(args, sd, dd, grads=False)
-    m0, r0 = out["predictions_mask"][0].float().cpu(), oout["predictions_mask"][0]
+    m0, r0 = out["predictions_mask"][0].detach().float().cpu(), oout["predictions_mask"][0]
     live = r0 > -1e5
     assert float((m0[live] - r0[live]).abs().max()) < 2e-2 * float(r0[live].abs().max())
     flips = float(((m0 < 0) != (r0 < 0))[live].float().mean())
     assert flips < 0.02, f"self-mask bit-flip rate vs fp32 oracle {flips:.4f}"
-    c0, cr = out["predictions_class"][0].float().cpu(), oout["predictions_class"][0]
+    c0, cr = out["predictions_class"][0].detach().float().cpu(), oout["predictions_class"][0]
     fin = torch.isfinite(cr)
     assert torch.equal(fin, torch.isfinite(c0))
     assert float((c0[fin] - cr[fin]).abs().max()) < 2e-2 * float(cr[fin].abs().max())

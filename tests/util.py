@@ -103,7 +103,11 @@ def synthetic_loss(out, heads, last_query):
     return loss + (last_query * loss_weight("query", last_query.shape).to(last_query.device)).mean()
 
 
-def run_oracle(args, sd, dd, grads=True):
+def run_oracle(args, sd, dd, grads=True, emulate=None):
+    """emulate=torch.bfloat16 rounds every matmul operand like the HIP bf16 path does (see oracle.operand_rounding)."""
+    if emulate is not None:
+        with O.operand_rounding(emulate):
+            return run_oracle(args, sd, dd, grads)
     sdo = {k: v.clone().requires_grad_(grads and v.dtype.is_floating_point and not k.endswith("gauss_B"))
            for k, v in sd.items()}
     collect = []
