@@ -67,38 +67,56 @@ template <int NTILES> struct PackP<float, NTILES> {
   }
 };
 
-// Cooperative global -> LDS staging of ROWS x DH elements (rows r0.., element stride sl between rows).
-// Writes a row-major copy (rm, stride LDR) and/or a transposed copy (tr, stride ldt).  Rows >= R are zero.
-template <typename CT, int DH, int ROWS>
-PQ_DEV void stage_tile(CT* rm, CT* tr, int ldt, const void* base, int dt, long off, long sl, int r0, int R, int tid,
-                       int nthreads) {
+// Cooperative global -> register -> LDS staging of ROWS x DH elements of type CT (rows r0.., element stride sl
+// between rows).  load() issues branch-free 16-byte loads (row index clamped to R-1: out-of-range rows hold finite
+// duplicates and are neutralised by the masks); store() writes a row-major copy (stride LDR) and/or a transposed
+// copy (stride ldt).  Splitting the two lets the next tile's loads fly during the current tile's MFMAs.
+template <typename CT, int DH, int ROWS, int NTHREADS>
+struct TileRegs {
   typedef AT<CT, DH> A;
-  for (int c = tid; c < ROWS * A::CPR; c += nthreads) {
-    const int row = c / A::CPR, kc = c % A::CPR;
-    float v[A::EPL];
+  static constexpr int TOTAL = ROWS * A::CPR;
+  static constexpr int MAXC = (TOTAL + NTHREADS - 1) / NTHREADS;
+  u32x4 reg[MAXC];
+  PQ_DEV void load(const void* base, long off, long sl, int r0, int R, int tid) {
 #pragma unroll
-    for (int j = 0; j < A::EPL; ++j) v[j] = 0.f;
-    if (r0 + row < R) load_elems<A::EPL>(base, dt, off + (long)(r0 + row) * sl + kc * A::EPL, A::EPL, v);
-    if (rm) *(u32x4*)&rm[row * A::LDR + kc * A::EPL] = pack_frag<CT>(v);
-    if (tr) {
-#pragma unroll
-      for (int j = 0; j < A::EPL; ++j) tr[(kc * A::EPL + j) * ldt + row] = Cvt<CT>::from(v[j]);
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = tid + i * NTHREADS;
+      if (c < TOTAL) {
+        const int row = c / A::CPR, kc = c % A::CPR;
+        const int gr = min(r0 + row, R - 1);
+        reg[i] = *(const u32x4*)((const CT*)base + off + (long)gr * sl + kc * A::EPL);
+      }
     }
   }
-}
+  PQ_DEV void store(CT* rm, CT* tr, int ldt, int tid) const {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = tid + i * NTHREADS;
+      if (c < TOTAL) {
+        const int row = c / A::CPR, kc = c % A::CPR;
+        if (rm) *(u32x4*)&rm[row * A::LDR + kc * A::EPL] = reg[i];
+        if (tr) {
+#pragma unroll
+          for (int j = 0; j < A::EPL; ++j) {
+            if constexpr (sizeof(CT) == 2)
+              tr[(kc * A::EPL + j) * ldt + row] = (CT)((reg[i][j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            else
+              tr[(kc * A::EPL + j) * ldt + row] = __uint_as_float(reg[i][j]);
+          }
+        }
+      }
+    }
+  }
+};
 
-// B-operand fragments of one row (lane i = row index, g = dh slice), straight from global.
+// B-operand fragments of one row (lane i = row index, g = dh slice), straight from global (typed 16-byte loads).
 template <typename CT, int DH>
-PQ_DEV void row_frags(u32x4* f, const void* base, int dt, long rowoff, bool valid, int g) {
+PQ_DEV void row_frags(u32x4* f, const void* base, long rowoff, int g) {
   typedef AT<CT, DH> A;
 #pragma unroll
   for (int s = 0; s < A::NS; ++s) {
-    float v[A::EPL];
-#pragma unroll
-    for (int j = 0; j < A::EPL; ++j) v[j] = 0.f;
     const int c0 = s * A::KSTEP + g * A::EPL;
-    if (valid && c0 < DH) load_elems<A::EPL>(base, dt, rowoff + c0, A::EPL, v);
-    f[s] = pack_frag<CT>(v);
+    f[s] = (c0 < DH) ? *(const u32x4*)((const CT*)base + rowoff + c0) : (u32x4){0, 0, 0, 0};
   }
 }
 
@@ -107,23 +125,24 @@ template <typename CT, int DH> PQ_DEV void zero_lds(CT* p, int n, int tid, int n
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename CT, int DH>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const pq3d_attn_desc d) {
+template <typename CT, int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
   __shared__ __attribute__((aligned(16))) CT Vt[DH * A::LDT];
   __shared__ uint8_t kpm_s[KB];
-  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int nthreads = NW * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * (nthreads >> 6) + wave) * 16;
+  const int q0 = (blockIdx.x * NW + wave) * 16;
   const int myq = q0 + li;
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
 
   if (A::DHK > DH) zero_lds<CT, DH>(Ks, KB * A::LDR, tid, nthreads);
 
   u32x4 qf[A::NS];
-  row_frags<CT, DH>(qf, d.q, d.dt, (long)b * d.q_sb + (long)myq * d.q_sl + (long)h * d.q_sh, qvalid, lg);
+  row_frags<CT, DH>(qf, d.q, (long)b * d.q_sb + (long)min(myq, d.Lq - 1) * d.q_sl + (long)h * d.q_sh, lg);
 
   float m = d.zero_attn ? 0.f : -1e30f, l = d.zero_attn ? 1.f : 0.f;
   f32x4 acc[A::MT];
@@ -135,12 +154,22 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const pq3d_attn_desc d) {
   const float* brow = (d.bias && qvalid) ? d.bias + (((long)b * d.H + h) * d.Lq + myq) * d.Lk : nullptr;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
 
+  TileRegs<CT, DH, KB, nthreads> kr, vr;
+  uint8_t kpm_r = 1;
+  auto prefetch = [&](int k0) {
+    kr.load(d.k, koff, d.k_sl, k0, d.Lk, tid);
+    vr.load(d.v, voff, d.v_sl, k0, d.Lk, tid);
+    if (tid < KB) kpm_r = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+  };
+  if (d.Lk > 0) prefetch(0);
+
   for (int k0 = 0; k0 < d.Lk; k0 += KB) {
     __syncthreads();
-    stage_tile<CT, DH, KB>(Ks, nullptr, 0, d.k, d.dt, koff, d.k_sl, k0, d.Lk, tid, nthreads);
-    stage_tile<CT, DH, KB>(nullptr, Vt, A::LDT, d.v, d.dt, voff, d.v_sl, k0, d.Lk, tid, nthreads);
-    if (tid < KB) kpm_s[tid] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+    kr.store(Ks, nullptr, 0, tid);
+    vr.store(nullptr, Vt, A::LDT, tid);
+    if (tid < KB) kpm_s[tid] = kpm_r;
     __syncthreads();
+    if (k0 + KB < d.Lk) prefetch(k0 + KB);
     if (!wave_active) continue;
 
     float p[4][4];
@@ -200,29 +229,48 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const pq3d_attn_desc d) {
 }
 
 // ------------------------------------------------------------------------------------------------ delta
+template <typename CT, int DH>
 __global__ void attn_delta_kernel(const pq3d_attn_desc d) {
+  typedef AT<CT, DH> A;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)d.B * d.H * d.Lq;
   if (idx >= total) return;
   const int q = idx % d.Lq, h = (idx / d.Lq) % d.H, b = idx / ((long)d.Lq * d.H);
   const long off = (long)b * d.o_sb + (long)q * d.o_sl + (long)h * d.o_sh;
+  u32x4 ro[A::CPR], rd[A::CPR];
+#pragma unroll
+  for (int c = 0; c < A::CPR; ++c) {
+    ro[c] = *(const u32x4*)((const CT*)d.o + off + c * A::EPL);
+    rd[c] = *(const u32x4*)((const CT*)d.dout + off + c * A::EPL);
+  }
   float s = 0.f;
-  for (int c = 0; c < d.dh; ++c) s += load_elem(d.o, d.dt, off + c) * load_elem(d.dout, d.dt, off + c);
+#pragma unroll
+  for (int c = 0; c < A::CPR; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (sizeof(CT) == 2) {
+        s += __uint_as_float(ro[c][j] << 16) * __uint_as_float(rd[c][j] << 16);
+        s += __uint_as_float(ro[c][j] & 0xffff0000u) * __uint_as_float(rd[c][j] & 0xffff0000u);
+      } else {
+        s += __uint_as_float(ro[c][j]) * __uint_as_float(rd[c][j]);
+      }
+    }
   d.delta[idx] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ dQ (+ dbias)
-template <typename CT, int DH>
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const pq3d_attn_desc d) {
+template <typename CT, int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
   __shared__ __attribute__((aligned(16))) CT Vs[KB * A::LDR];
   __shared__ __attribute__((aligned(16))) CT Kt[DH * A::LDT];
   __shared__ uint8_t kpm_s[KB];
-  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int nthreads = NW * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * (nthreads >> 6) + wave) * 16;
+  const int q0 = (blockIdx.x * NW + wave) * 16;
   const int myq = q0 + li;
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
 
@@ -231,8 +279,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const pq3d_attn_desc d
     zero_lds<CT, DH>(Vs, KB * A::LDR, tid, nthreads);
   }
   u32x4 qf[A::NS], dof[A::NS];
-  row_frags<CT, DH>(qf, d.q, d.dt, (long)b * d.q_sb + (long)myq * d.q_sl + (long)h * d.q_sh, qvalid, lg);
-  row_frags<CT, DH>(dof, d.dout, d.dt, (long)b * d.o_sb + (long)myq * d.o_sl + (long)h * d.o_sh, qvalid, lg);
+  const int cq = min(myq, d.Lq - 1);
+  row_frags<CT, DH>(qf, d.q, (long)b * d.q_sb + (long)cq * d.q_sl + (long)h * d.q_sh, lg);
+  row_frags<CT, DH>(dof, d.dout, (long)b * d.o_sb + (long)cq * d.o_sl + (long)h * d.o_sh, lg);
   const long sidx = ((long)b * d.H + h) * d.Lq + myq;
   const float L = qvalid ? d.lse[sidx] : INFINITY;
   const float Dl = qvalid ? d.delta[sidx] : 0.f;
@@ -247,12 +296,22 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const pq3d_attn_desc d
   float* dbrow = (d.dbias && qvalid) ? d.dbias + sidx * d.Lk : nullptr;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
 
+  TileRegs<CT, DH, KB, nthreads> kr, vr;
+  uint8_t kpm_r = 1;
+  auto prefetch = [&](int k0) {
+    kr.load(d.k, koff, d.k_sl, k0, d.Lk, tid);
+    vr.load(d.v, voff, d.v_sl, k0, d.Lk, tid);
+    if (tid < KB) kpm_r = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+  };
+  if (d.Lk > 0) prefetch(0);
+
   for (int k0 = 0; k0 < d.Lk; k0 += KB) {
     __syncthreads();
-    stage_tile<CT, DH, KB>(Ks, Kt, A::LDT, d.k, d.dt, koff, d.k_sl, k0, d.Lk, tid, nthreads);
-    stage_tile<CT, DH, KB>(Vs, nullptr, 0, d.v, d.dt, voff, d.v_sl, k0, d.Lk, tid, nthreads);
-    if (tid < KB) kpm_s[tid] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+    kr.store(Ks, Kt, A::LDT, tid);
+    vr.store(Vs, nullptr, 0, tid);
+    if (tid < KB) kpm_s[tid] = kpm_r;
     __syncthreads();
+    if (k0 + KB < d.Lk) prefetch(k0 + KB);
     if (!wave_active) continue;
 
     float ds[4][4];
@@ -304,7 +363,8 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   __shared__ __attribute__((aligned(16))) CT dOt[DH * A::LDQ];
   __shared__ float Ls[QB], Ds[QB];
   __shared__ uint8_t ro_s[QB];
-  const int tid = threadIdx.x, nthreads = NWK * 64, lane = tid & 63, wave = tid >> 6;
+  constexpr int nthreads = NWK * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int key = (blockIdx.x * NWK + wave) * 16 + li;
@@ -315,8 +375,9 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
     zero_lds<CT, DH>(dOs, QB * A::LDR, tid, nthreads);
   }
   u32x4 kf[A::NS], vf[A::NS];
-  row_frags<CT, DH>(kf, d.k, d.dt, (long)b * d.k_sb + (long)key * d.k_sl + (long)h * d.k_sh, kvalid, lg);
-  row_frags<CT, DH>(vf, d.v, d.dt, (long)b * d.v_sb + (long)key * d.v_sl + (long)h * d.v_sh, kvalid, lg);
+  const int ck = min(key, d.Lk - 1);
+  row_frags<CT, DH>(kf, d.k, (long)b * d.k_sb + (long)ck * d.k_sl + (long)h * d.k_sh, lg);
+  row_frags<CT, DH>(vf, d.v, (long)b * d.v_sb + (long)ck * d.v_sl + (long)h * d.v_sh, lg);
   const bool kmasked = kvalid ? (d.kpm ? d.kpm[(long)b * d.Lk + key] != 0 : false) : true;
 
   f32x4 accK[A::MT], accV[A::MT];
@@ -328,17 +389,28 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   const long qoff = (long)b * d.q_sb + (long)h * d.q_sh, ooff = (long)b * d.o_sb + (long)h * d.o_sh;
   const long sbase = ((long)b * d.H + h) * d.Lq;
 
-  for (int qb = 0; qb < d.Lq; qb += QB) {
-    __syncthreads();
-    stage_tile<CT, DH, QB>(Qs, Qt, A::LDQ, d.q, d.dt, qoff, d.q_sl, qb, d.Lq, tid, nthreads);
-    stage_tile<CT, DH, QB>(dOs, dOt, A::LDQ, d.dout, d.dt, ooff, d.o_sl, qb, d.Lq, tid, nthreads);
+  TileRegs<CT, DH, QB, nthreads> qr, dor;
+  float l_r = INFINITY, d_r = 0.f;
+  uint8_t ro_r = 0;
+  auto prefetch = [&](int qb) {
+    qr.load(d.q, qoff, d.q_sl, qb, d.Lq, tid);
+    dor.load(d.dout, ooff, d.o_sl, qb, d.Lq, tid);
     if (tid < QB) {
       const int gq = qb + tid;
-      Ls[tid] = gq < d.Lq ? d.lse[sbase + gq] : INFINITY;
-      Ds[tid] = gq < d.Lq ? d.delta[sbase + gq] : 0.f;
-      ro_s[tid] = (gq < d.Lq && d.row_open) ? d.row_open[(long)b * d.Lq + gq] : 0;
+      l_r = gq < d.Lq ? d.lse[sbase + gq] : INFINITY;
+      d_r = gq < d.Lq ? d.delta[sbase + gq] : 0.f;
+      ro_r = (gq < d.Lq && d.row_open) ? d.row_open[(long)b * d.Lq + gq] : 0;
     }
+  };
+  prefetch(0);
+
+  for (int qb = 0; qb < d.Lq; qb += QB) {
     __syncthreads();
+    qr.store(Qs, Qt, A::LDQ, tid);
+    dor.store(dOs, dOt, A::LDQ, tid);
+    if (tid < QB) { Ls[tid] = l_r; Ds[tid] = d_r; ro_s[tid] = ro_r; }
+    __syncthreads();
+    if (qb + QB < d.Lq) prefetch(qb + QB);
 
     float pt[2][4], dst[2][4];
 #pragma unroll
@@ -403,22 +475,31 @@ int check_desc(const pq3d_attn_desc& d) {
   PQ_CHECK_ARG(d.ct == PQ3D_F32 || d.ct == PQ3D_BF16, "pq3d_attn: bad compute type");
   PQ_CHECK_ARG(d.dt == PQ3D_F32 || d.dt == PQ3D_BF16, "pq3d_attn: bad storage dtype");
   PQ_CHECK_ARG(d.q && d.k && d.v && d.o && d.lse, "pq3d_attn: null q/k/v/o/lse");
+  PQ_CHECK_ARG(d.dt == d.ct, "pq3d_attn: storage dtype of q/k/v/o must equal the compute type");
+  {
+    const int epl = d.ct == PQ3D_BF16 ? 8 : 4;
+    const int64_t st[] = {d.q_sb, d.q_sl, d.q_sh, d.k_sb, d.k_sl, d.k_sh, d.v_sb, d.v_sl, d.v_sh, d.o_sb, d.o_sl, d.o_sh};
+    for (int64_t x : st) PQ_CHECK_ARG(x % epl == 0, "pq3d_attn: strides must be multiples of 16 bytes");
+    const void* ps[] = {d.q, d.k, d.v, d.o};
+    for (const void* p : ps) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_attn: q/k/v/o must be 16-byte aligned");
+  }
   PQ_CHECK_ARG(d.Lk > 0 || d.zero_attn, "pq3d_attn: Lk == 0 needs zero_attn");
   return 0;
 }
 
 template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream_t s) {
-  const int tiles = (d.Lq + 15) / 16, nw = tiles < 8 ? tiles : 8;
-  dim3 grid((tiles + nw - 1) / nw, d.H, d.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<CT, DH>), grid, dim3(nw * 64), 0, s, d);
+  const int tiles = (d.Lq + 15) / 16;
+  if (tiles > 4) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8>), dim3((tiles + 7) / 8, d.H, d.B), dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4>), dim3(1, d.H, d.B), dim3(256), 0, s, d);
   PQ_LAUNCH_CHECK();
   return 0;
 }
 template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream_t s) {
   const long total = (long)d.B * d.H * d.Lq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
-  const int tiles = (d.Lq + 15) / 16, nw = tiles < 8 ? tiles : 8;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH>), dim3((tiles + nw - 1) / nw, d.H, d.B), dim3(nw * 64), 0, s, d);
+  hipLaunchKernelGGL((attn_delta_kernel<CT, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+  const int tiles = (d.Lq + 15) / 16;
+  if (tiles > 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8>), dim3((tiles + 7) / 8, d.H, d.B), dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4>), dim3(1, d.H, d.B), dim3(256), 0, s, d);
   if (d.Lk > 0)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH>), dim3((d.Lk + NWK * 16 - 1) / (NWK * 16), d.H, d.B),
                        dim3(NWK * 64), 0, s, d);
@@ -453,6 +534,7 @@ extern "C" int pq3d_attn_bwd(const pq3d_attn_desc* dp, void* stream) {
   const pq3d_attn_desc d = *dp;
   if (int e = check_desc(d)) return e;
   PQ_CHECK_ARG(d.dout && d.dq && d.dk && d.dv && d.delta, "pq3d_attn_bwd: null dout/dq/dk/dv/delta");
+  PQ_CHECK_ARG((((uintptr_t)d.dout) & 15) == 0, "pq3d_attn_bwd: dout must be 16-byte aligned");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH(launch_bwd)

@@ -1,10 +1,15 @@
-// Grouped / batched MFMA GEMM with fused prologue (A + A2, dtype conversion) and epilogue
+// Grouped / batched MFMA GEMM with fused prologue (A + A2, B + B2, dtype conversion) and epilogue
 // (bias, activation, activation-gradient, row masks, mask-head fill/threshold, split-K atomics).
 // One kernel family serves every nn.Linear forward/backward on the path and the mask-head einsum.
 //
 // Tiling: 64x64 output tile per 256-thread workgroup (4 waves as 2x2, each wave a 32x32 sub-tile = 2x2 MFMA
-// 16x16 tiles), K-step of 128 bytes of compute type per LDS row (64 bf16 / 32 f32), register-prefetched so the
-// next tile's global loads overlap the current tile's MFMAs.  LDS rows are padded by 16 B.
+// 16x16 tiles), K-step of 128 bytes of compute type per LDS row (64 bf16 / 32 f32).  LDS rows padded by 16 B.
+// Staging is register-prefetched: the raw 16-byte global loads of tile t+1 are issued (branch-free, so they all
+// go out back to back) before the MFMAs of tile t and are converted/added/packed only when they are written to
+// LDS -- the HBM round trip hides under the MFMAs instead of being paid once per load.
+//   FAST path  : operands 16-byte aligned, leading dims / K (or M,N for transposed operands) multiples of the
+//                chunk -> unconditional vector loads from clamped addresses + select.
+//   generic    : guarded scalar loads (K = 3 or 5 projections, odd shapes).
 #include "common.h"
 
 namespace {
@@ -19,137 +24,169 @@ template <typename CT> struct Tile {
   static constexpr int CPR = BKE / EPL;                     // 16-byte chunks per row (= 8)
 };
 
-// Stage one operand tile (ROWS x BKE) from global into two packed 16-byte registers per thread.
-// Non-transposed: element (r,k) at base[off + r*ld + k].  Transposed: at base[off + k*ld + r].
-template <typename CT, bool TR>
-PQ_DEV void stage_load(u32x4 (&reg)[2], const void* base, const void* base2, int dt, int dt2, long off, long ld,
-                       int r0, int R, int k0, int K, int tid) {
+// ---- raw chunk of EPL source elements -------------------------------------------------------------------
+template <typename TS, int EPL> struct Raw;
+template <> struct Raw<float, 8> {
+  float4 a, b;
+  PQ_DEV void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+  PQ_DEV void to_float(float* v) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+};
+template <> struct Raw<float, 4> {
+  float4 a;
+  PQ_DEV void load(const float* p) { a = *(const float4*)p; }
+  PQ_DEV void to_float(float* v) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+};
+template <> struct Raw<bf16_t, 8> {
+  u32x4 a;
+  PQ_DEV void load(const bf16_t* p) { a = *(const u32x4*)p; }
+  PQ_DEV void to_float(float* v) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(a[j] << 16); v[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u); }
+  }
+};
+template <> struct Raw<bf16_t, 4> {
+  u32x2 a;
+  PQ_DEV void load(const bf16_t* p) { a = *(const u32x2*)p; }
+  PQ_DEV void to_float(float* v) const {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { v[2 * j] = __uint_as_float(a[j] << 16); v[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u); }
+  }
+};
+
+// ---- FAST stager: branch-free raw loads, conversion at store time ------------------------------------------
+template <typename CT, typename TS, typename TS2, bool TR>
+struct FastStage {
   typedef Tile<CT> T;
+  Raw<TS, T::EPL> r[2];
+  Raw<TS2, T::EPL> r2[2];
+  bool kvalid[2];
+
+  PQ_DEV void load(const void* base, const void* base2, long off, long ld, int r0, int R, int k0, int K, int tid) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int c = tid + it * NT;
-    float v[T::EPL];
-#pragma unroll
-    for (int j = 0; j < T::EPL; ++j) v[j] = 0.f;
-    if (!TR) {
-      const int row = c / T::CPR, kc = c % T::CPR;
-      const int gr = r0 + row, gk = k0 + kc * T::EPL;
-      if (gr < R && gk < K) {
-        const int valid = min(T::EPL, K - gk);
-        load_elems<T::EPL>(base, dt, off + (long)gr * ld + gk, valid, v);
-        if (base2) {
-          float w[T::EPL];
-          load_elems<T::EPL>(base2, dt2, off + (long)gr * ld + gk, valid, w);
-#pragma unroll
-          for (int j = 0; j < T::EPL; ++j) v[j] += w[j];
-        }
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + it * NT;
+      long idx;
+      if (!TR) {
+        const int row = c / T::CPR, kc = c % T::CPR;
+        const int gr = min(r0 + row, R - 1), gk = k0 + kc * T::EPL;
+        kvalid[it] = gk < K;
+        idx = off + (long)gr * ld + (kvalid[it] ? gk : 0);
+      } else {
+        constexpr int RC = BM / T::EPL;
+        const int kk = c / RC, rc = c % RC;
+        const int gk = k0 + kk, gr = min(r0 + rc * T::EPL, R - T::EPL);
+        kvalid[it] = gk < K;
+        idx = off + (long)(kvalid[it] ? gk : 0) * ld + gr;
       }
-    } else {
-      constexpr int RC = BM / T::EPL;  // row-chunks per k (BM == BN)
-      const int kk = c / RC, rc = c % RC;
-      const int gk = k0 + kk, gr = r0 + rc * T::EPL;
-      if (gk < K && gr < R) {
-        const int valid = min(T::EPL, R - gr);
-        load_elems<T::EPL>(base, dt, off + (long)gk * ld + gr, valid, v);
-        if (base2) {
-          float w[T::EPL];
-          load_elems<T::EPL>(base2, dt2, off + (long)gk * ld + gr, valid, w);
+      r[it].load((const TS*)base + idx);
+      if (base2) r2[it].load((const TS2*)base2 + idx);
+    }
+  }
+  PQ_DEV void store(CT* lds, bool has2, int tid) const {
 #pragma unroll
-          for (int j = 0; j < T::EPL; ++j) v[j] += w[j];
-        }
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + it * NT;
+      float v[T::EPL];
+      r[it].to_float(v);
+      if (has2) {
+        float w[T::EPL];
+        r2[it].to_float(w);
+#pragma unroll
+        for (int j = 0; j < T::EPL; ++j) v[j] += w[j];
+      }
+      if (!kvalid[it]) {
+#pragma unroll
+        for (int j = 0; j < T::EPL; ++j) v[j] = 0.f;
+      }
+      if (!TR) {
+        const int row = c / T::CPR, kc = c % T::CPR;
+        *(u32x4*)&lds[row * T::LDK + kc * T::EPL] = pack_frag<CT>(v);
+      } else {
+        constexpr int RC = BM / T::EPL;
+        const int kk = c / RC, rc = c % RC;
+#pragma unroll
+        for (int j = 0; j < T::EPL; ++j) lds[(rc * T::EPL + j) * T::LDK + kk] = Cvt<CT>::from(v[j]);
       }
     }
-    reg[it] = pack_frag<CT>(v);
   }
-}
+};
 
+// ---- generic stager: guarded scalar loads, runtime dtypes --------------------------------------------------
 template <typename CT, bool TR>
-PQ_DEV void stage_store(const u32x4 (&reg)[2], CT* lds, int tid) {
+struct SlowStage {
   typedef Tile<CT> T;
+  u32x4 reg[2];
+  PQ_DEV void load(const void* base, const void* base2, int dt, int dt2, long off, long ld, int r0, int R, int k0,
+                   int K, int tid) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int c = tid + it * NT;
-    if (!TR) {
-      const int row = c / T::CPR, kc = c % T::CPR;
-      *(u32x4*)&lds[row * T::LDK + kc * T::EPL] = reg[it];
-    } else {
-      constexpr int RC = BM / T::EPL;
-      const int kk = c / RC, rc = c % RC;
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + it * NT;
+      float v[T::EPL];
+#pragma unroll
+      for (int j = 0; j < T::EPL; ++j) v[j] = 0.f;
+      long idx = 0;
+      int valid = 0;
+      if (!TR) {
+        const int row = c / T::CPR, kc = c % T::CPR;
+        const int gr = r0 + row, gk = k0 + kc * T::EPL;
+        if (gr < R && gk < K) { valid = min(T::EPL, K - gk); idx = off + (long)gr * ld + gk; }
+      } else {
+        constexpr int RC = BM / T::EPL;
+        const int kk = c / RC, rc = c % RC;
+        const int gk = k0 + kk, gr = r0 + rc * T::EPL;
+        if (gk < K && gr < R) { valid = min(T::EPL, R - gr); idx = off + (long)gk * ld + gr; }
+      }
 #pragma unroll
       for (int j = 0; j < T::EPL; ++j) {
-        if constexpr (sizeof(CT) == 2)
-          lds[(rc * T::EPL + j) * T::LDK + kk] = (CT)((reg[it][j >> 1] >> (16 * (j & 1))) & 0xffffu);
-        else
-          lds[(rc * T::EPL + j) * T::LDK + kk] = __uint_as_float(reg[it][j]);
+        if (j < valid) {
+          v[j] = load_elem(base, dt, idx + j);
+          if (base2) v[j] += load_elem(base2, dt2, idx + j);
+        }
+      }
+      reg[it] = pack_frag<CT>(v);
+    }
+  }
+  PQ_DEV void store(CT* lds, int tid) const {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + it * NT;
+      if (!TR) {
+        const int row = c / T::CPR, kc = c % T::CPR;
+        *(u32x4*)&lds[row * T::LDK + kc * T::EPL] = reg[it];
+      } else {
+        constexpr int RC = BM / T::EPL;
+        const int kk = c / RC, rc = c % RC;
+#pragma unroll
+        for (int j = 0; j < T::EPL; ++j) {
+          if constexpr (sizeof(CT) == 2)
+            lds[(rc * T::EPL + j) * T::LDK + kk] = (CT)((reg[it][j >> 1] >> (16 * (j & 1))) & 0xffffu);
+          else
+            lds[(rc * T::EPL + j) * T::LDK + kk] = __uint_as_float(reg[it][j]);
+        }
       }
     }
   }
+};
+
+template <typename CT>
+PQ_DEV void mma_tile(f32x4 (&acc)[2][2], const CT* As, const CT* Bs, int wm, int wn, int li, int lg) {
+  typedef Tile<CT> T;
+#pragma unroll
+  for (int ks = 0; ks < T::BKE / T::KSTEP; ++ks) {
+    u32x4 fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)&As[(wm + i * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *(const u32x4*)&Bs[(wn + j * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) Mma<CT>::mma(acc[i][j], fa[i], fb[j]);
+  }
 }
 
-template <typename CT, bool TA, bool TB>
-__global__ __launch_bounds__(NT) void gemm_kernel(const pq3d_gemm_desc d) {
-  typedef Tile<CT> T;
-  __shared__ __attribute__((aligned(16))) CT As[BM * T::LDK];
-  __shared__ __attribute__((aligned(16))) CT Bs[BN * T::LDK];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  const int g = d.kconcat ? 0 : blockIdx.z / d.batch, z = d.kconcat ? blockIdx.z : blockIdx.z % d.batch;
-  const int tiles_m = (d.M + BM - 1) / BM;
-  const int m0 = (blockIdx.x % tiles_m) * BM, n0 = (blockIdx.x / tiles_m) * BN;
-
-  const int nkt = (d.K + T::BKE - 1) / T::BKE;
-  int kt0 = 0, kt1 = nkt;
-  if (d.splitk > 1) {
-    const int per = (nkt + d.splitk - 1) / d.splitk;
-    kt0 = blockIdx.y * per;
-    kt1 = min(nkt, kt0 + per);
-    if (kt0 >= kt1) return;
-  }
-
-  const int ng = d.kconcat ? d.groups : 1;  // groups walked inside the K loop
-  const long offA = (long)z * d.strideA, offB = (long)z * d.strideB;
-  const int nit = (kt1 - kt0) * ng;         // flattened (group, k-tile) iterations
-
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  u32x4 ra[2], rb[2];
-  auto load_it = [&](int it) {
-    const int gg = d.kconcat ? it / (kt1 - kt0) : g;
-    const int kt = kt0 + (d.kconcat ? it % (kt1 - kt0) : it);
-    stage_load<CT, TA>(ra, d.A[gg], d.A2[gg], d.dtA, d.dtA2, offA, d.lda, m0, d.M, kt * T::BKE, d.K, tid);
-    stage_load<CT, TB>(rb, d.B[gg], d.B2[gg], d.dtB, d.dtB2, offB, d.ldb, n0, d.N, kt * T::BKE, d.K, tid);
-  };
-  load_it(0);
-
-  for (int it = 0; it < nit; ++it) {
-    stage_store<CT, TA>(ra, As, tid);
-    stage_store<CT, TB>(rb, Bs, tid);
-    __syncthreads();
-    if (it + 1 < nit) load_it(it + 1);
-#pragma unroll
-    for (int ks = 0; ks < T::BKE / T::KSTEP; ++ks) {
-      u32x4 fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        fa[i] = *(const u32x4*)&As[(wm + i * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        fb[j] = *(const u32x4*)&Bs[(wn + j * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) Mma<CT>::mma(acc[i][j], fa[i], fb[j]);
-    }
-    __syncthreads();
-  }
-
-  // ------------------------------------------------------------------ epilogue
+PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], int g, int z, int m0, int n0, int wm, int wn,
+                     int li, int lg) {
   void* C = d.C[g];
   void* C2 = d.C2[g];
   const void* aux = d.aux[g];
@@ -188,14 +225,144 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const pq3d_gemm_desc d) {
   }
 }
 
-template <typename CT>
-int launch_ct(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s) {
-  if (!d.transA && !d.transB) hipLaunchKernelGGL((gemm_kernel<CT, false, false>), grid, dim3(NT), 0, s, d);
-  else if (!d.transA && d.transB) hipLaunchKernelGGL((gemm_kernel<CT, false, true>), grid, dim3(NT), 0, s, d);
-  else if (d.transA && d.transB) hipLaunchKernelGGL((gemm_kernel<CT, true, true>), grid, dim3(NT), 0, s, d);
-  else hipLaunchKernelGGL((gemm_kernel<CT, true, false>), grid, dim3(NT), 0, s, d);
-  PQ_LAUNCH_CHECK();
-  return 0;
+struct BlockCoords {
+  int g, z, m0, n0, kt0, kt1, ng;
+  bool active;
+};
+template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_gemm_desc& d) {
+  typedef Tile<CT> T;
+  BlockCoords b;
+  b.g = d.kconcat ? 0 : blockIdx.z / d.batch;
+  b.z = d.kconcat ? blockIdx.z : blockIdx.z % d.batch;
+  const int tiles_m = (d.M + BM - 1) / BM;
+  b.m0 = (blockIdx.x % tiles_m) * BM;
+  b.n0 = (blockIdx.x / tiles_m) * BN;
+  const int nkt = (d.K + T::BKE - 1) / T::BKE;
+  b.kt0 = 0; b.kt1 = nkt; b.active = true;
+  if (d.splitk > 1) {
+    const int per = (nkt + d.splitk - 1) / d.splitk;
+    b.kt0 = blockIdx.y * per;
+    b.kt1 = min(nkt, b.kt0 + per);
+    b.active = b.kt0 < b.kt1;
+  }
+  b.ng = d.kconcat ? d.groups : 1;
+  return b;
+}
+
+template <typename CT, typename TA, typename TA2, typename TB, typename TB2, bool TRA, bool TRB>
+__global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
+  typedef Tile<CT> T;
+  __shared__ __attribute__((aligned(16))) CT As[BM * T::LDK];
+  __shared__ __attribute__((aligned(16))) CT Bs[BN * T::LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const BlockCoords b = block_coords<CT>(d);
+  if (!b.active) return;
+  const long offA = (long)b.z * d.strideA, offB = (long)b.z * d.strideB;
+  const int nk = b.kt1 - b.kt0, nit = nk * b.ng;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  FastStage<CT, TA, TA2, TRA> sa;
+  FastStage<CT, TB, TB2, TRB> sb;
+  bool hasA2 = false, hasB2 = false;
+  auto load_it = [&](int it) {
+    const int gg = d.kconcat ? it / nk : b.g;
+    const int kt = b.kt0 + (d.kconcat ? it % nk : it);
+    hasA2 = d.A2[gg] != nullptr;
+    hasB2 = d.B2[gg] != nullptr;
+    sa.load(d.A[gg], d.A2[gg], offA, d.lda, b.m0, d.M, kt * T::BKE, d.K, tid);
+    sb.load(d.B[gg], d.B2[gg], offB, d.ldb, b.n0, d.N, kt * T::BKE, d.K, tid);
+  };
+  load_it(0);
+  for (int it = 0; it < nit; ++it) {
+    sa.store(As, hasA2, tid);
+    sb.store(Bs, hasB2, tid);
+    __syncthreads();
+    if (it + 1 < nit) load_it(it + 1);
+    mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
+    __syncthreads();
+  }
+  epilogue(d, acc, b.g, b.z, b.m0, b.n0, wm, wn, li, lg);
+}
+
+template <typename CT, bool TRA, bool TRB>
+__global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_gemm_desc d) {
+  typedef Tile<CT> T;
+  __shared__ __attribute__((aligned(16))) CT As[BM * T::LDK];
+  __shared__ __attribute__((aligned(16))) CT Bs[BN * T::LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const BlockCoords b = block_coords<CT>(d);
+  if (!b.active) return;
+  const long offA = (long)b.z * d.strideA, offB = (long)b.z * d.strideB;
+  const int nk = b.kt1 - b.kt0, nit = nk * b.ng;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  SlowStage<CT, TRA> sa;
+  SlowStage<CT, TRB> sb;
+  auto load_it = [&](int it) {
+    const int gg = d.kconcat ? it / nk : b.g;
+    const int kt = b.kt0 + (d.kconcat ? it % nk : it);
+    sa.load(d.A[gg], d.A2[gg], d.dtA, d.dtA2, offA, d.lda, b.m0, d.M, kt * T::BKE, d.K, tid);
+    sb.load(d.B[gg], d.B2[gg], d.dtB, d.dtB2, offB, d.ldb, b.n0, d.N, kt * T::BKE, d.K, tid);
+  };
+  load_it(0);
+  for (int it = 0; it < nit; ++it) {
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+    __syncthreads();
+    if (it + 1 < nit) load_it(it + 1);
+    mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
+    __syncthreads();
+  }
+  epilogue(d, acc, b.g, b.z, b.m0, b.n0, wm, wn, li, lg);
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Can every group use unconditional 16-byte loads?
+template <typename CT> bool fast_ok(const pq3d_gemm_desc& d) {
+  constexpr int EPL = Mma<CT>::EPL;
+  if (d.transA && !d.transB) return false;
+  if (d.lda % EPL || d.ldb % EPL || d.strideA % EPL || d.strideB % EPL) return false;
+  if ((!d.transA || !d.transB) && (d.K % EPL)) return false;
+  if (d.transA && (d.M % EPL || d.M < EPL)) return false;
+  if (d.transB && (d.N % EPL || d.N < EPL)) return false;
+  for (int g = 0; g < d.groups; ++g) {
+    if (!aligned16(d.A[g]) || !aligned16(d.B[g])) return false;
+    if (d.A2[g] && (!aligned16(d.A2[g]) || d.dtA2 != PQ3D_F32)) return false;
+    if (d.B2[g] && (!aligned16(d.B2[g]) || d.dtB2 != PQ3D_F32)) return false;
+  }
+  return true;
+}
+
+#define LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(NT), 0, s, d)
+
+template <typename CT, typename TA, typename TB>
+void launch_fast_layout(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s) {
+  // optional addends A2 / B2 are always fp32 on the fast path (residual-stream position encodings)
+  if (!d.transA && !d.transB) LAUNCH(gemm_fast_kernel<CT, TA, float, TB, float, false, false>);
+  else if (!d.transA && d.transB) LAUNCH(gemm_fast_kernel<CT, TA, float, TB, float, false, true>);
+  else LAUNCH(gemm_fast_kernel<CT, TA, float, TB, float, true, true>);
+}
+
+template <typename CT> void launch_slow(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s) {
+  if (!d.transA && !d.transB) LAUNCH(gemm_slow_kernel<CT, false, false>);
+  else if (!d.transA && d.transB) LAUNCH(gemm_slow_kernel<CT, false, true>);
+  else if (d.transA && d.transB) LAUNCH(gemm_slow_kernel<CT, true, true>);
+  else LAUNCH(gemm_slow_kernel<CT, true, false>);
 }
 
 }  // namespace
@@ -212,8 +379,8 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
     PQ_CHECK_ARG(d.A[g] && d.B[g] && (d.C[g] || (d.kconcat && g > 0)), "pq3d_gemm: null A/B/C");
     PQ_CHECK_ARG(!d.act_grad || d.aux[g], "pq3d_gemm: act_grad needs aux");
   }
-  PQ_CHECK_ARG(!(d.kconcat && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");
   if (d.splitk < 1) d.splitk = 1;
+  PQ_CHECK_ARG(!(d.kconcat && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");
   hipStream_t s = (hipStream_t)stream;
   if (d.splitk > 1) {
     PQ_CHECK_ARG(d.dtC == PQ3D_F32, "pq3d_gemm: split-K needs fp32 C");
@@ -226,5 +393,20 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   }
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   dim3 grid(tiles, d.splitk, (d.kconcat ? 1 : d.groups) * d.batch);
-  return d.ct == PQ3D_BF16 ? launch_ct<bf16_t>(d, grid, s) : launch_ct<float>(d, grid, s);
+  if (d.ct == PQ3D_BF16) {
+    if (fast_ok<bf16_t>(d)) {
+      const bool af = d.dtA == PQ3D_F32, bf = d.dtB == PQ3D_F32;
+      if (af && bf) launch_fast_layout<bf16_t, float, float>(d, grid, s);
+      else if (af && !bf) launch_fast_layout<bf16_t, float, bf16_t>(d, grid, s);
+      else if (!af && bf) launch_fast_layout<bf16_t, bf16_t, float>(d, grid, s);
+      else launch_fast_layout<bf16_t, bf16_t, bf16_t>(d, grid, s);
+    } else {
+      launch_slow<bf16_t>(d, grid, s);
+    }
+  } else {
+    if (fast_ok<float>(d) && d.dtA == PQ3D_F32 && d.dtB == PQ3D_F32) launch_fast_layout<float, float, float>(d, grid, s);
+    else launch_slow<float>(d, grid, s);
+  }
+  PQ_LAUNCH_CHECK();
+  return 0;
 }
