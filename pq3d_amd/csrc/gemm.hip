@@ -185,14 +185,62 @@ PQ_DEV void mma_tile(f32x4 (&acc)[2][2], const CT* As, const CT* Bs, int wm, int
   }
 }
 
+// Epilogue.  All global reads it needs (bias, row flags, activation-gradient operand) are gathered into registers
+// FIRST, in straight-line code, so they are issued together and waited for once -- not one round trip per element.
 PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], int g, int z, int m0, int n0, int wm, int wn,
                      int li, int lg) {
   void* C = d.C[g];
+  const long offC = (long)z * d.strideC;
+  if (d.splitk > 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn + j * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm + i * 16 + lg * 4 + r;
+          if (row < d.M && col < d.N) unsafeAtomicAdd((float*)C + offC + (long)row * d.ldc + col, acc[i][j][r] * d.alpha);
+        }
+      }
+    return;
+  }
   void* C2 = d.C2[g];
   const void* aux = d.aux[g];
   const void* bias = d.bias[g];
   const uint8_t* rmask = d.row_mask[g];
-  const long offC = (long)z * d.strideC;
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = min(n0 + wn + j * 16 + li, d.N - 1);
+    bv[j] = bias ? load_elem(bias, d.dtBias, col) : 0.f;
+  }
+  float rs[2][4];      // per-row multiplier (row_mask * row_scale)
+  bool rfill[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long ri = (long)z * d.M + min(m0 + wm + i * 16 + lg * 4 + r, d.M - 1);
+      float m = 1.f;
+      if (rmask) m = rmask[ri] ? 1.f : 0.f;
+      if (d.row_scale) m *= d.row_scale[ri];
+      rs[i][r] = m;
+      rfill[i][r] = d.row_fill_flag ? d.row_fill_flag[ri] != 0 : false;
+    }
+  float av[2][2][4];
+  if (d.act_grad) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(m0 + wm + i * 16 + lg * 4 + r, d.M - 1), col = min(n0 + wn + j * 16 + li, d.N - 1);
+          av[i][j][r] = load_elem(aux, d.dtAux, offC + (long)row * d.ldc + col);
+        }
+  }
+  const bool row_ops = rmask || d.row_scale;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -202,22 +250,15 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], int g, i
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm + i * 16 + lg * 4 + r;
         if (row >= d.M || col >= d.N) continue;
-        float v = acc[i][j][r] * d.alpha;
+        float v = acc[i][j][r] * d.alpha + bv[j];
         const long ci = offC + (long)row * d.ldc + col;
-        if (d.splitk > 1) {
-          unsafeAtomicAdd((float*)C + ci, v);
-          continue;
-        }
-        if (bias) v += load_elem(bias, d.dtBias, col);
         if (C2) store_elem(C2, d.dtC2, ci, v);
         if (d.act == PQ3D_ACT_RELU) v = fmaxf(v, 0.f);
         else if (d.act == PQ3D_ACT_GELU) v = gelu_f(v);
-        if (d.act_grad == PQ3D_ACT_RELU) v = load_elem(aux, d.dtAux, ci) > 0.f ? v : 0.f;
-        else if (d.act_grad == PQ3D_ACT_GELU) v *= gelu_grad_f(load_elem(aux, d.dtAux, ci));
-        const long ri = (long)z * d.M + row;
-        if (rmask && rmask[ri] == 0) v = 0.f;
-        if (d.row_scale) v *= d.row_scale[ri];
-        if (d.row_fill_flag && d.row_fill_flag[ri]) v = d.row_fill;
+        if (d.act_grad == PQ3D_ACT_RELU) v = av[i][j][r] > 0.f ? v : 0.f;
+        else if (d.act_grad == PQ3D_ACT_GELU) v *= gelu_grad_f(av[i][j][r]);
+        if (row_ops) v *= rs[i][r];
+        if (rfill[i][r]) v = d.row_fill;
         store_elem(C, d.dtC, ci, v);
         if (d.mask_out) d.mask_out[((long)z * d.N + col) * d.M + row] = (1.f / (1.f + __expf(-v)) < 0.5f) ? 1 : 0;
       }

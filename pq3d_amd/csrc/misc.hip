@@ -4,19 +4,31 @@
 namespace {
 
 // ---------------------------------------------------------------- colsum
-// grid (ceil(N/64), row_chunks); block 256 = 4 row-lanes x 64 columns.
-__global__ void colsum_kernel(const void* x, int dt, long R, long N, long ld, float* out) {
-  __shared__ float part[4][64];
+// grid ceil(N/64); block 1024 = 16 row-lanes x 64 columns; each thread strides over rows with 4 independent loads in
+// flight, then a 16-way LDS tree.  No atomics, no memset: deterministic.
+template <typename T>
+__global__ __launch_bounds__(1024) void colsum_kernel(const T* x, long R, long N, long ld, float* out) {
+  __shared__ float part[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const long col = (long)blockIdx.x * 64 + cx;
-  const long rows_per = (R + gridDim.y - 1) / gridDim.y;
-  const long r0 = (long)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
-  float s = 0.f;
-  if (col < N)
-    for (long r = r0 + ry; r < r1; r += 4) s += load_elem(x, dt, r * ld + col);
-  part[ry][cx] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < N) {
+    long r = ry;
+    for (; r + 48 < R; r += 64) {
+      const float a = Cvt<T>::to(x[r * ld + col]), b = Cvt<T>::to(x[(r + 16) * ld + col]);
+      const float c = Cvt<T>::to(x[(r + 32) * ld + col]), e = Cvt<T>::to(x[(r + 48) * ld + col]);
+      s0 += a; s1 += b; s2 += c; s3 += e;
+    }
+    for (; r < R; r += 16) s0 += Cvt<T>::to(x[r * ld + col]);
+  }
+  part[ry][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (ry == 0 && col < N) unsafeAtomicAdd(&out[col], part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]);
+  if (ry == 0 && col < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][cx];
+    out[col] = t;
+  }
 }
 
 // ---------------------------------------------------------------- scale rows
@@ -228,12 +240,9 @@ inline int memset_async(void* p, size_t bytes, hipStream_t s) {
 extern "C" int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream) {
   PQ_CHECK_ARG(x && out && R >= 0 && N >= 1 && ld >= N, "pq3d_colsum: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (int e = memset_async(out, sizeof(float) * N, s)) return e;
-  if (R == 0) return 0;
-  long chunks = (R + 255) / 256;
-  if (chunks > 64) chunks = 64;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)chunks), dim3(256), 0, s, x, dt, (long)R,
-                     (long)N, (long)ld, out);
+  dim3 grid((unsigned)((N + 63) / 64));
+  if (dt == PQ3D_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(1024), 0, s, (const float*)x, (long)R, (long)N, (long)ld, out);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(1024), 0, s, (const bf16_t*)x, (long)R, (long)N, (long)ld, out);
   PQ_LAUNCH_CHECK();
   return 0;
 }

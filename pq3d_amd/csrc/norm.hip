@@ -178,8 +178,9 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
     hipError_t e = hipMemsetAsync(d.dx, 0, sizeof(float) * (size_t)d.R * d.d, s);
     if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
   }
-  long nb = (d.R + WPB - 1) / WPB;
-  if (nb > 128) nb = 128;  // each wave strides over rows; bounds the number of parameter-grad atomics
+  long nb = (d.R + 4 * WPB - 1) / (4 * WPB);  // ~4 rows per wave: bounds the parameter-grad atomics per column
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb, d.M);
   LN_DISPATCH(add_ln_bwd_kernel, grid)
   PQ_LAUNCH_CHECK();

@@ -56,7 +56,7 @@ def test_fp32_model_matches_golden(name):
         names = sorted(k[5:-4] for k in z.files if k.startswith("grad/") and k.endswith("/sum"))
         assert names == sorted(g.keys()), "parameter-gradient set differs from the reference's"
         for n in names:
-            util.check_against(z, "grad/" + n, g[n], atol=1e-5, rtol=1e-4, cap=util.MAX_GRAD)
+            util.check_against(z, "grad/" + n, g[n], atol=1e-5, rtol=3e-4, cap=util.MAX_GRAD)
 
 
 @pytest.mark.parametrize("name", util.fixtures("F3_"))
