@@ -30,7 +30,8 @@ extern "C" {
 #define PQ3D_ACT_RELU 1
 #define PQ3D_ACT_GELU 2
 
-#define PQ3D_MAX_GROUPS 8
+#define PQ3D_MAX_GROUPS 32
+#define PQ3D_ACT_ADD 3 /* act_grad mode: C = acc + aux (fused residual / gradient accumulation) */
 
 const char* pq3d_last_error(void);
 int pq3d_version(void);
@@ -44,8 +45,11 @@ int pq3d_version(void);
  *
  *   for g < groups, z < batch:
  *     C_g[z][m][n] = epi( sum_k (A_g[z](m,k) + A2_g[z](m,k)) * (B_g[z](n,k) + B2_g[z](n,k)) )
- *   kconcat != 0: the groups are concatenated along K instead (one output C[0]:
- *     C[z][m][n] = epi( sum_g sum_k A_g(m,k) B_g(n,k) ), the multi-memory sum of mask_head.py:30-37).
+ *   kconcat = c > 0: every c consecutive groups are concatenated along K into one output (groups/c outputs, taken
+ *     from C[0], C[c], C[2c], ...):  C_o[z][m][n] = epi( sum_{g in [o*c,(o+1)*c)} sum_k A_g(m,k) B_g(n,k) ) --
+ *     the multi-memory sum of mask_head.py:30-37 and the "sum over consumers" of input gradients.
+ *   accumulate != 0 (split-K only): C is NOT zeroed by the call -- the atomics add onto its current contents
+ *     (parameter-gradient accumulation across layers / shared-weight blocks into a pre-zeroed arena).
  *   A(m,k) is at A[m*lda + k] (transA=0) or A[k*lda + m] (transA=1); B(n,k) at B[n*ldb + k] (transB=0)
  *   or B[k*ldb + n] (transB=1).  epi: + bias_g[n]; optional C2 <- pre-activation; act; if act_grad: multiply by
  *   act'(aux) (aux has C's layout: ReLU uses aux>0, GELU uses the saved pre-activation); row_mask_g[z*M+m]==0
@@ -63,6 +67,7 @@ typedef struct {
   int32_t act, act_grad;
   int32_t splitk;
   int32_t kconcat;
+  int32_t accumulate;
   int32_t dtB2;
   float alpha;           /* applied to the accumulator before bias */
   float row_fill;        /* value written to rows whose row_fill_flag != 0 */
@@ -106,6 +111,7 @@ typedef struct {
   int32_t ct;   /* compute type */
   int32_t dt;   /* storage dtype of q,k,v,o,do,dq,dk,dv */
   int32_t zero_attn;
+  int32_t mask_bmod; /* > 0: `mask` / `row_open` are shared by groups of scenes (memories stacked along B) */
   float scale;
   int64_t q_sb, q_sl, q_sh;
   int64_t k_sb, k_sl, k_sh;
@@ -115,7 +121,7 @@ typedef struct {
   void* o;                    /* fwd: output; bwd: forward output (input) */
   float* lse;                 /* [B,H,Lq] fwd: output; bwd: input */
   const uint8_t* kpm;         /* [B,Lk] or NULL */
-  const uint8_t* mask;        /* [B,Lq,Lk] or NULL */
+  const uint8_t* mask;        /* [B,Lq,Lk] or NULL; with mask_bmod > 0: [mask_bmod,Lq,Lk] indexed by b % mask_bmod */
   const uint8_t* row_open;    /* [B,Lq] or NULL */
   const float* bias;          /* [B,H,Lq,Lk] or NULL */
   /* backward only */
@@ -158,6 +164,7 @@ typedef struct {
   float* d_o[PQ3D_MAX_GROUPS];    /* [R,d] fp32 each */
   float* dgamma[PQ3D_MAX_GROUPS];
   float* dbeta[PQ3D_MAX_GROUPS];
+  int32_t accumulate;             /* != 0: dgamma/dbeta are accumulated onto (not zeroed by the call) */
 } pq3d_ln_desc;
 
 int pq3d_add_ln_fwd(const pq3d_ln_desc* d, void* stream);
@@ -166,8 +173,12 @@ int pq3d_add_ln_bwd(const pq3d_ln_desc* d, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Small memory-bound kernels.
  * ------------------------------------------------------------------------------------------------ */
-/* out[n] = sum_r x[r*ld + n]  (bias gradients); out is zeroed by the call. */
+/* out[n] = sum_r x[r*ld + n]  (bias gradients). */
 int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream);
+/* Grouped form: out_g[n] (+)= sum_r x_g[r*ld + n] for g < groups (host arrays of device pointers);
+ * accumulate != 0 adds onto out_g (one writer per element: no atomics needed). */
+int pq3d_colsum_grouped(const void* const* x, float* const* out, int32_t groups, int32_t dt, int64_t R, int64_t N,
+                        int64_t ld, int32_t accumulate, void* stream);
 
 /* y[r,c] = keep(r) ? x[r,c] * scale[r] : 0, keep(r) = (!zero_flag || !zero_flag[r]) && (!keep_mask || keep_mask[r]);
  * scale NULL -> 1.  (backward of mask_head.py:35-38 and of row-masked projections) */
@@ -202,6 +213,9 @@ int pq3d_spatial_bias_fwd(const float* pl, const float* W, const float* bw, floa
                           int32_t L, void* stream);
 int pq3d_spatial_bias_bwd(const float* pl, const float* W, const float* bw, const float* dbias, float* dW, float* dbw,
                           int32_t B, int32_t H, int32_t L, void* stream);
+/* same, accumulating onto dW/dbw instead of zeroing them first */
+int pq3d_spatial_bias_bwd_acc(const float* pl, const float* W, const float* bw, const float* dbias, float* dW,
+                              float* dbw, int32_t B, int32_t H, int32_t L, void* stream);
 
 /* gate structure (query_encoder.py:166-170): y = (1-s)*q + s*u, s = sigmoid(g);  bwd: dq, du, dg. */
 int pq3d_gate_mix_fwd(const float* q, const float* u, const float* g, float* y, int64_t n, void* stream);

@@ -9,8 +9,8 @@ from typing import Optional, Sequence
 import torch
 
 F32, BF16 = 0, 1
-ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
-MAXG = 8
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "add": 3}
+MAXG = 32
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpq3d_hip.so")
 
@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
         ("dtA", C.c_int32), ("dtA2", C.c_int32), ("dtB", C.c_int32), ("dtC", C.c_int32), ("dtC2", C.c_int32),
         ("dtAux", C.c_int32), ("dtBias", C.c_int32),
         ("transA", C.c_int32), ("transB", C.c_int32), ("act", C.c_int32), ("act_grad", C.c_int32),
-        ("splitk", C.c_int32), ("kconcat", C.c_int32), ("dtB2", C.c_int32),
+        ("splitk", C.c_int32), ("kconcat", C.c_int32), ("accumulate", C.c_int32), ("dtB2", C.c_int32),
         ("alpha", C.c_float), ("row_fill", C.c_float),
         ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
         ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
 class AttnDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("dh", C.c_int32),
-        ("ct", C.c_int32), ("dt", C.c_int32), ("zero_attn", C.c_int32), ("scale", C.c_float),
+        ("ct", C.c_int32), ("dt", C.c_int32), ("zero_attn", C.c_int32), ("mask_bmod", C.c_int32), ("scale", C.c_float),
         ("q_sb", C.c_int64), ("q_sl", C.c_int64), ("q_sh", C.c_int64),
         ("k_sb", C.c_int64), ("k_sl", C.c_int64), ("k_sh", C.c_int64),
         ("v_sb", C.c_int64), ("v_sl", C.c_int64), ("v_sh", C.c_int64),
@@ -59,7 +59,7 @@ class LnDesc(C.Structure):
         ("x", C.c_void_p), ("o", C.c_void_p * MAXG), ("gamma", C.c_void_p * MAXG), ("beta", C.c_void_p * MAXG),
         ("coef", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
         ("dy", C.c_void_p), ("dx", C.c_void_p), ("d_o", C.c_void_p * MAXG), ("dgamma", C.c_void_p * MAXG),
-        ("dbeta", C.c_void_p * MAXG),
+        ("dbeta", C.c_void_p * MAXG), ("accumulate", C.c_int32),
     ]
 
 
@@ -73,6 +73,8 @@ _SIGS = {
     "pq3d_add_ln_fwd": [C.POINTER(LnDesc), C.c_void_p],
     "pq3d_add_ln_bwd": [C.POINTER(LnDesc), C.c_void_p],
     "pq3d_colsum": [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p],
+    "pq3d_colsum_grouped": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                            C.c_int64, C.c_int32, C.c_void_p],
     "pq3d_scale_rows": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                         C.c_void_p, C.c_void_p],
     "pq3d_act_bwd": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
@@ -86,6 +88,8 @@ _SIGS = {
                               C.c_void_p],
     "pq3d_spatial_bias_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                               C.c_int32, C.c_int32, C.c_void_p],
+    "pq3d_spatial_bias_bwd_acc": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_void_p],
     "pq3d_gate_mix_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "pq3d_gate_mix_bwd": [C.c_void_p] * 7 + [C.c_int64, C.c_void_p],
     "pq3d_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
@@ -152,17 +156,23 @@ def _fill(arr, tensors: Optional[Sequence[Optional[torch.Tensor]]]):
 
 def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C2=None, aux=None, row_mask=None,
          transA=False, transB=False, batch=1, strideA=0, strideB=0, strideC=0, act=None, act_grad=None, splitk=1,
-         kconcat=False, alpha=1.0, row_scale=None, row_fill_flag=None, row_fill=0.0, mask_out=None) -> None:
+         kconcat=0, accumulate=False, alpha=1.0, row_scale=None, row_fill_flag=None, row_fill=0.0,
+         mask_out=None) -> None:
+    """kconcat: number of consecutive groups concatenated along K per output (True = all groups)."""
+    if kconcat is True:
+        kconcat = len(A)
+    kconcat = int(kconcat or 0)
     d = GemmDesc()
     d.M, d.N, d.K, d.groups, d.batch, d.ct = M, N, K, len(A), batch, ct
     d.dtA, d.dtB, d.dtC = dt_of(A[0]), dt_of(B[0]), dt_of(Cs[0])
-    d.dtA2 = dt_of(A2[0]) if A2 and A2[0] is not None else 0
-    d.dtB2 = dt_of(B2[0]) if B2 and B2[0] is not None else 0
-    d.dtC2 = dt_of(C2[0]) if C2 and C2[0] is not None else 0
-    d.dtAux = dt_of(aux[0]) if aux and aux[0] is not None else 0
-    d.dtBias = dt_of(bias[0]) if bias and bias[0] is not None else 0
+    first = lambda ts: next((t for t in (ts or []) if t is not None), None)
+    d.dtA2 = dt_of(first(A2)) if first(A2) is not None else 0
+    d.dtB2 = dt_of(first(B2)) if first(B2) is not None else 0
+    d.dtC2 = dt_of(first(C2)) if first(C2) is not None else 0
+    d.dtAux = dt_of(first(aux)) if first(aux) is not None else 0
+    d.dtBias = dt_of(first(bias)) if first(bias) is not None else 0
     d.transA, d.transB = int(transA), int(transB)
-    d.act, d.act_grad, d.splitk, d.kconcat = ACT[act], ACT[act_grad], splitk, int(kconcat)
+    d.act, d.act_grad, d.splitk, d.kconcat, d.accumulate = ACT[act], ACT[act_grad], splitk, kconcat, int(accumulate)
     d.alpha, d.row_fill = alpha, row_fill
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
     d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
@@ -171,8 +181,8 @@ def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C
     d.row_scale, d.row_fill_flag, d.mask_out = ptr(row_scale), ptr(row_fill_flag), ptr(mask_out)
     from .profiler import timed
     nb = (M * K * (2 if d.dtA else 4) + N * K * (2 if d.dtB else 4)) * len(A) * batch + \
-        M * N * (2 if d.dtC else 4) * (1 if kconcat else len(A)) * batch
+        M * N * (2 if d.dtC else 4) * (len(A) // max(kconcat, 1)) * batch
     key = f"M{M}N{N}K{K}g{len(A)}b{batch}{'T' if transA else 'N'}{'T' if transB else 'N'}" \
-          f"{'k' if kconcat else ''}{'s%d' % splitk if splitk > 1 else ''}ct{ct}"
+          f"{'k%d' % kconcat if kconcat else ''}{'s%d' % splitk if splitk > 1 else ''}ct{ct}"
     check(timed("pq3d_gemm", key, 2.0 * M * N * K * len(A) * batch, nb, lib().pq3d_gemm, C.byref(d), stream()),
           "pq3d_gemm")

@@ -149,8 +149,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
 #pragma unroll
   for (int mt = 0; mt < A::MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bool ro = (qvalid && d.row_open) ? d.row_open[(long)b * d.Lq + myq] != 0 : false;
-  const uint8_t* mrow = (d.mask && qvalid && !ro) ? d.mask + ((long)b * d.Lq + myq) * d.Lk : nullptr;
+  const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
+  const bool ro = (qvalid && d.row_open) ? d.row_open[(long)bm * d.Lq + myq] != 0 : false;
+  const uint8_t* mrow = (d.mask && qvalid && !ro) ? d.mask + ((long)bm * d.Lq + myq) * d.Lk : nullptr;
   const float* brow = (d.bias && qvalid) ? d.bias + (((long)b * d.H + h) * d.Lq + myq) * d.Lk : nullptr;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
 
@@ -290,8 +291,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
 #pragma unroll
   for (int mt = 0; mt < A::MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bool ro = (qvalid && d.row_open) ? d.row_open[(long)b * d.Lq + myq] != 0 : false;
-  const uint8_t* mrow = (d.mask && qvalid && !ro) ? d.mask + ((long)b * d.Lq + myq) * d.Lk : nullptr;
+  const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
+  const bool ro = (qvalid && d.row_open) ? d.row_open[(long)bm * d.Lq + myq] != 0 : false;
+  const uint8_t* mrow = (d.mask && qvalid && !ro) ? d.mask + ((long)bm * d.Lq + myq) * d.Lk : nullptr;
   const float* brow = (d.bias && qvalid) ? d.bias + sidx * d.Lk : nullptr;
   float* dbrow = (d.dbias && qvalid) ? d.dbias + sidx * d.Lk : nullptr;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   }
   const long qoff = (long)b * d.q_sb + (long)h * d.q_sh, ooff = (long)b * d.o_sb + (long)h * d.o_sh;
   const long sbase = ((long)b * d.H + h) * d.Lq;
+  const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
 
   TileRegs<CT, DH, QB, nthreads> qr, dor;
   float l_r = INFINITY, d_r = 0.f;
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
       const int gq = qb + tid;
       l_r = gq < d.Lq ? d.lse[sbase + gq] : INFINITY;
       d_r = gq < d.Lq ? d.delta[sbase + gq] : 0.f;
-      ro_r = (gq < d.Lq && d.row_open) ? d.row_open[(long)b * d.Lq + gq] : 0;
+      ro_r = (gq < d.Lq && d.row_open) ? d.row_open[(long)bm * d.Lq + gq] : 0;
     }
   };
   prefetch(0);
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
         const bool inb = gq < d.Lq && kvalid;
         float x = s[r] * d.scale;
         if (d.bias && inb) x += d.bias[(sbase + gq) * d.Lk + key];
-        const bool masked = kmasked || (d.mask && inb && !ro_s[ql] && d.mask[((long)b * d.Lq + gq) * d.Lk + key]);
+        const bool masked = kmasked || (d.mask && inb && !ro_s[ql] && d.mask[((long)bm * d.Lq + gq) * d.Lk + key]);
         const float pr = masked ? 0.f : fexp<CT>(x - Ls[ql]);
         pt[t][r] = pr;
         dst[t][r] = pr * (dp[r] - Ds[ql]) * d.scale;

@@ -13,14 +13,18 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define PQ_DEV __device__ __forceinline__
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
 PQ_DEV float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-PQ_DEV bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even with NaN handling in hardware: native __bf16 conversions lower to ONE
+// v_cvt_pk_bf16_f32 per pair on gfx950 (a hand-rolled bit trick with a NaN branch costs a divergent exec-mask
+// sequence per element and dominated the GEMM staging loop).
+PQ_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+PQ_DEV unsigned pack_bf2(float lo, float hi) {
+  const f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
 }
-PQ_DEV unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {

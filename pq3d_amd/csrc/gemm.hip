@@ -257,6 +257,7 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], int g, i
         else if (d.act == PQ3D_ACT_GELU) v = gelu_f(v);
         if (d.act_grad == PQ3D_ACT_RELU) v = av[i][j][r] > 0.f ? v : 0.f;
         else if (d.act_grad == PQ3D_ACT_GELU) v *= gelu_grad_f(av[i][j][r]);
+        else if (d.act_grad == PQ3D_ACT_ADD) v += av[i][j][r];
         if (row_ops) v *= rs[i][r];
         if (rfill[i][r]) v = d.row_fill;
         store_elem(C, d.dtC, ci, v);
@@ -273,8 +274,9 @@ struct BlockCoords {
 template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_gemm_desc& d) {
   typedef Tile<CT> T;
   BlockCoords b;
-  b.g = d.kconcat ? 0 : blockIdx.z / d.batch;
-  b.z = d.kconcat ? blockIdx.z : blockIdx.z % d.batch;
+  b.ng = d.kconcat > 0 ? d.kconcat : 1;           // groups walked inside the K loop
+  b.g = (blockIdx.z / d.batch) * b.ng;            // first group of this output
+  b.z = blockIdx.z % d.batch;
   const int tiles_m = (d.M + BM - 1) / BM;
   b.m0 = (blockIdx.x % tiles_m) * BM;
   b.n0 = (blockIdx.x / tiles_m) * BN;
@@ -286,7 +288,6 @@ template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_gemm_desc& d) 
     b.kt1 = min(nkt, b.kt0 + per);
     b.active = b.kt0 < b.kt1;
   }
-  b.ng = d.kconcat ? d.groups : 1;
   return b;
 }
 
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   FastStage<CT, TB, TB2, TRB> sb;
   bool hasA2 = false, hasB2 = false;
   auto load_it = [&](int it) {
-    const int gg = d.kconcat ? it / nk : b.g;
-    const int kt = b.kt0 + (d.kconcat ? it % nk : it);
+    const int gg = b.g + it / nk;
+    const int kt = b.kt0 + it % nk;
     hasA2 = d.A2[gg] != nullptr;
     hasB2 = d.B2[gg] != nullptr;
     sa.load(d.A[gg], d.A2[gg], offA, d.lda, b.m0, d.M, kt * T::BKE, d.K, tid);
@@ -354,8 +355,8 @@ __global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_gemm_desc d) {
   SlowStage<CT, TRA> sa;
   SlowStage<CT, TRB> sb;
   auto load_it = [&](int it) {
-    const int gg = d.kconcat ? it / nk : b.g;
-    const int kt = b.kt0 + (d.kconcat ? it % nk : it);
+    const int gg = b.g + it / nk;
+    const int kt = b.kt0 + it % nk;
     sa.load(d.A[gg], d.A2[gg], d.dtA, d.dtA2, offA, d.lda, b.m0, d.M, kt * T::BKE, d.K, tid);
     sb.load(d.B[gg], d.B2[gg], d.dtB, d.dtB2, offB, d.ldb, b.n0, d.N, kt * T::BKE, d.K, tid);
   };
@@ -416,24 +417,26 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   PQ_CHECK_ARG(d.batch >= 1, "pq3d_gemm: batch < 1");
   PQ_CHECK_ARG(d.ct == PQ3D_F32 || d.ct == PQ3D_BF16, "pq3d_gemm: bad compute type");
   if (d.M == 0 || d.N == 0) return 0;
+  const int kc = d.kconcat > 0 ? d.kconcat : 1;
+  PQ_CHECK_ARG(d.groups % kc == 0, "pq3d_gemm: groups must be a multiple of kconcat");
   for (int g = 0; g < d.groups; ++g) {
-    PQ_CHECK_ARG(d.A[g] && d.B[g] && (d.C[g] || (d.kconcat && g > 0)), "pq3d_gemm: null A/B/C");
-    PQ_CHECK_ARG(!d.act_grad || d.aux[g], "pq3d_gemm: act_grad needs aux");
+    PQ_CHECK_ARG(d.A[g] && d.B[g] && (d.C[g] || (g % kc) != 0), "pq3d_gemm: null A/B/C");
+    PQ_CHECK_ARG(!d.act_grad || d.aux[g] || (g % kc) != 0, "pq3d_gemm: act_grad needs aux");
   }
   if (d.splitk < 1) d.splitk = 1;
-  PQ_CHECK_ARG(!(d.kconcat && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");
+  PQ_CHECK_ARG(!(kc > 1 && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");
   hipStream_t s = (hipStream_t)stream;
   if (d.splitk > 1) {
     PQ_CHECK_ARG(d.dtC == PQ3D_F32, "pq3d_gemm: split-K needs fp32 C");
     PQ_CHECK_ARG(d.ldc == d.N && (d.batch == 1 || d.strideC == (int64_t)d.M * d.N),
                  "pq3d_gemm: split-K needs contiguous C");
-    for (int g = 0; g < d.groups; ++g) {
+    for (int g = 0; g < d.groups && !d.accumulate; ++g) {
       hipError_t e = hipMemsetAsync(d.C[g], 0, sizeof(float) * (size_t)d.batch * d.M * d.N, s);
       if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
     }
   }
   const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-  dim3 grid(tiles, d.splitk, (d.kconcat ? 1 : d.groups) * d.batch);
+  dim3 grid(tiles, d.splitk, (d.groups / kc) * d.batch);
   if (d.ct == PQ3D_BF16) {
     if (fast_ok<bf16_t>(d)) {
       const bool af = d.dtA == PQ3D_F32, bf = d.dtB == PQ3D_F32;

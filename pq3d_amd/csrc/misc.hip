@@ -6,9 +6,12 @@ namespace {
 // ---------------------------------------------------------------- colsum
 // grid ceil(N/64); block 1024 = 16 row-lanes x 64 columns; each thread strides over rows with 4 independent loads in
 // flight, then a 16-way LDS tree.  No atomics, no memset: deterministic.
+struct ColsumPtrs { const void* x[PQ3D_MAX_GROUPS]; float* out[PQ3D_MAX_GROUPS]; };
 template <typename T>
-__global__ __launch_bounds__(1024) void colsum_kernel(const T* x, long R, long N, long ld, float* out) {
+__global__ __launch_bounds__(1024) void colsum_kernel(const ColsumPtrs cp, long R, long N, long ld, int accumulate) {
   __shared__ float part[16][64];
+  const T* x = (const T*)cp.x[blockIdx.y];
+  float* out = cp.out[blockIdx.y];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const long col = (long)blockIdx.x * 64 + cx;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -27,7 +30,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const T* x, long R, long N
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += part[k][cx];
-    out[col] = t;
+    out[col] = accumulate ? out[col] + t : t;
   }
 }
 
@@ -239,10 +242,24 @@ inline int memset_async(void* p, size_t bytes, hipStream_t s) {
 
 extern "C" int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream) {
   PQ_CHECK_ARG(x && out && R >= 0 && N >= 1 && ld >= N, "pq3d_colsum: bad args");
+  const void* xs[1] = {x};
+  float* outs[1] = {out};
+  return pq3d_colsum_grouped(xs, outs, 1, dt, R, N, ld, 0, stream);
+}
+
+extern "C" int pq3d_colsum_grouped(const void* const* x, float* const* out, int32_t groups, int32_t dt, int64_t R,
+                                   int64_t N, int64_t ld, int32_t accumulate, void* stream) {
+  PQ_CHECK_ARG(x && out && groups >= 1 && groups <= PQ3D_MAX_GROUPS && R >= 0 && N >= 1 && ld >= N,
+               "pq3d_colsum_grouped: bad args");
+  ColsumPtrs cp;
+  for (int g = 0; g < groups; ++g) {
+    PQ_CHECK_ARG(x[g] && out[g], "pq3d_colsum_grouped: null pointer");
+    cp.x[g] = x[g]; cp.out[g] = out[g];
+  }
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)((N + 63) / 64));
-  if (dt == PQ3D_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(1024), 0, s, (const float*)x, (long)R, (long)N, (long)ld, out);
-  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(1024), 0, s, (const bf16_t*)x, (long)R, (long)N, (long)ld, out);
+  dim3 grid((unsigned)((N + 63) / 64), groups);
+  if (dt == PQ3D_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(1024), 0, s, cp, (long)R, (long)N, (long)ld, accumulate);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(1024), 0, s, cp, (long)R, (long)N, (long)ld, accumulate);
   PQ_LAUNCH_CHECK();
   return 0;
 }
@@ -325,6 +342,13 @@ extern "C" int pq3d_spatial_bias_bwd(const float* pl, const float* W, const floa
   hipStream_t s = (hipStream_t)stream;
   if (int e = memset_async(dW, sizeof(float) * H * 5, s)) return e;
   if (int e = memset_async(dbw, sizeof(float) * H, s)) return e;
+  return pq3d_spatial_bias_bwd_acc(pl, W, bw, dbias, dW, dbw, B, H, L, stream);
+}
+
+extern "C" int pq3d_spatial_bias_bwd_acc(const float* pl, const float* W, const float* bw, const float* dbias,
+                                         float* dW, float* dbw, int32_t B, int32_t H, int32_t L, void* stream) {
+  PQ_CHECK_ARG(pl && W && bw && dbias && dW && dbw && H >= 1, "pq3d_spatial_bias_bwd_acc: bad args");
+  hipStream_t s = (hipStream_t)stream;
   if (B == 0 || L == 0) return 0;
   hipLaunchKernelGGL(spatial_bias_bwd_kernel, dim3(grid1d((long)B * L * L, 256, 128)), dim3(256), 0, s, pl, W, bw,
                      dbias, dW, dbw, B, H, L);

@@ -168,7 +168,7 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   const pq3d_ln_desc d = *dp;
   if (int e = check_ln(d, true)) return e;
   hipStream_t s = (hipStream_t)stream;
-  for (int m = 0; m < d.M; ++m) {
+  for (int m = 0; m < d.M && !d.accumulate; ++m) {
     hipError_t e = hipMemsetAsync(d.dgamma[m], 0, sizeof(float) * d.d, s);
     if (e == hipSuccess) e = hipMemsetAsync(d.dbeta[m], 0, sizeof(float) * d.d, s);
     if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }

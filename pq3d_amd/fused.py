@@ -1,0 +1,603 @@
+"""Fused forward/backward executor for the parallel-structure query decoder (QueryMaskEncoder, query_encoder.py:52-181,
++ MaskHeadSegLevel, mask_head.py:11-57) -- the production fast path.
+
+The modular path (modules.py + ops.py: one autograd Function per kernel) is launch-bound: ~900 dependent dispatches
+per config-2 step.  This executor runs the same arithmetic with a hand-written backward so that
+  * the M scene memories of a layer are ONE launch each for Q-projection, attention, out-projection, LayerNorm
+    (grouped GEMM / memories stacked along the attention batch);
+  * K/V projections of every (layer, memory) are hoisted out of the layer loop into ONE grouped GEMM (their inputs
+    are layer-invariant), and their backward is one K-concatenated GEMM per gradient;
+  * input gradients that sum over consumers are produced by K-concatenated GEMMs / the "+ aux" epilogue instead
+    of separate add kernels;
+  * every parameter gradient is accumulated (split-K atomics / accumulating column sums) into one flat fp32 arena
+    that is zeroed once per backward -- no per-GEMM memsets, no autograd slice/zero/add kernels for the packed
+    in_proj weights, and weight sharing across num_blocks accumulates for free.
+It is numerically the same computation as the modular path (same kernels, same rounding points).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from . import ops
+from ._lib import BF16, F32
+from .profiler import timed
+
+MAXG = L.MAXG
+
+
+def _chunks(seq, n):
+    for i in range(0, len(seq), n):
+        yield seq[i:i + n]
+
+
+def _gemm_groups(n_per_call_limit, **kw):
+    """L.gemm over arbitrarily many groups (split into calls of <= limit groups; kconcat chains handled by caller)."""
+    L.gemm(**kw)
+
+
+def _colsum_acc(xs: Sequence[torch.Tensor], outs: Sequence[torch.Tensor], rows: int) -> None:
+    """outs[g] += column sums of xs[g] viewed as [rows, N] (bias gradients into the arena)."""
+    N = xs[0].numel() // rows
+    for xc, oc in zip(_chunks(list(xs), MAXG), _chunks(list(outs), MAXG)):
+        xa = (C.c_void_p * len(xc))(*[L.ptr(t) for t in xc])
+        oa = (C.c_void_p * len(oc))(*[L.ptr(t) for t in oc])
+        L.check(L.lib().pq3d_colsum_grouped(xa, oa, len(xc), L.dt_of(xc[0]), rows, N, N, 1, L.stream()),
+                "pq3d_colsum_grouped")
+
+
+def _splitk(tiles: int, k: int, ct: int, groups: int) -> int:
+    nkt = max(1, k // (64 if ct == BF16 else 32))
+    return max(1, min(nkt // 2 if nkt >= 2 else 1, max(1, 768 // max(tiles * groups, 1)), 64))
+
+
+def _dw_acc(gs, xs, x2s, outs, ct):
+    """outs[g][N,K] += gs[g]^T @ (xs[g] + x2s[g])  (grouped split-K, accumulating atomics)."""
+    N, K = outs[0].shape
+    R = gs[0].numel() // N
+    tiles = ((N + 63) // 64) * ((K + 63) // 64)
+    for i in range(0, len(gs), MAXG):
+        g_, x_, o_ = gs[i:i + MAXG], xs[i:i + MAXG], outs[i:i + MAXG]
+        x2_ = x2s[i:i + MAXG] if x2s is not None else None
+        L.gemm(M=N, N=K, K=R, A=g_, B=x_, B2=x2_, Cs=o_, ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
+               splitk=max(2, _splitk(tiles, R, ct, len(g_))), accumulate=True)
+
+
+class FusedSpec:
+    """Static description of one fused decoder invocation (non-tensor state handed to the Function)."""
+
+    def __init__(self, enc, mh, mems, ct, act, use_self_mask, num_blocks, spatial, mh_count, offline, skip_pred):
+        self.enc, self.mh, self.mems, self.ct, self.act = enc, mh, list(mems), ct, act
+        self.use_self_mask, self.num_blocks, self.spatial = use_self_mask, num_blocks, spatial
+        self.mh_count, self.offline, self.skip_pred = mh_count, offline, skip_pred
+
+
+def _mh_forward(spec, x, keys, inv_den, seg_pad, rec):
+    """One MaskHeadSegLevel call on the fused path; returns (cls, mlog, amask)."""
+    mh, ct, ad = spec.mh, spec.ct, ops.act_dtype(spec.ct)
+    B, Nq, d = x.shape
+    R = B * Nq
+    c0, c2, c4 = mh.cls_head[0], mh.cls_head[2], mh.cls_head[4]
+    h1 = torch.empty(B, Nq, c0.out_features, dtype=torch.float32, device=x.device)
+    L.gemm(M=R, N=c0.out_features, K=d, A=[x], B=[c0.weight.detach()], bias=[c0.bias.detach()], Cs=[h1], ct=ct,
+           lda=d, ldb=d, ldc=c0.out_features, act="relu")
+    h2, mean, rstd = _ln_fwd(None, [h1], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq)
+    C_ = c4.out_features
+    cls_raw = torch.empty(B, Nq, C_, dtype=torch.float32, device=x.device)
+    L.gemm(M=R, N=C_, K=c0.out_features, A=[h2], B=[c4.weight.detach()], bias=[c4.bias.detach()], Cs=[cls_raw], ct=ct,
+           lda=c0.out_features, ldb=c0.out_features, ldc=C_)
+    cls = cls_raw
+    if mh._foc_cols.numel():
+        cls = torch.empty_like(cls_raw)
+        L.check(L.lib().pq3d_fill_cols(L.ptr(cls_raw), L.ptr(cls), R, C_, L.ptr(mh._foc_cols), mh._foc_cols.numel(),
+                                       float("-inf"), L.stream()), "pq3d_fill_cols")
+    Mm = len(keys)
+    mps = list(mh.mask_pred_list)[:Mm]
+    qm = torch.empty(Mm, B, Nq, d, dtype=ad, device=x.device)
+    L.gemm(M=R, N=d, K=d, A=[x] * Mm, B=[mp.q_proj.weight.detach() for mp in mps],
+           bias=[mp.q_proj.bias.detach() for mp in mps], Cs=[qm[m] for m in range(Mm)], ct=ct, lda=d, ldb=d, ldc=d)
+    Ns = keys[0].shape[1]
+    mlog = torch.empty(B, Ns, Nq, dtype=torch.float32, device=x.device)
+    amask = torch.empty(B, Nq, Ns, dtype=torch.bool, device=x.device)
+    L.gemm(M=Ns, N=Nq, K=d, A=list(keys), B=[qm[m] for m in range(Mm)], Cs=[mlog] + [None] * (Mm - 1), ct=ct, lda=d,
+           ldb=d, ldc=Nq, batch=B, strideA=Ns * d, strideB=Nq * d, strideC=Ns * Nq, kconcat=Mm, row_scale=inv_den,
+           row_fill_flag=seg_pad, row_fill=-1e6, mask_out=amask)
+    rec.update(mh_x=x, mh_h1=h1, mh_h2=h2, mh_mean=mean, mh_rstd=rstd, mh_qm=qm)
+    return cls, mlog, amask
+
+
+def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.float32):
+    M = len(os_)
+    dm = os_[0].shape[-1]
+    R = os_[0].numel() // dm
+    y = torch.empty(os_[0].shape, dtype=out_dtype, device=os_[0].device)
+    mean = torch.empty(M, R, dtype=torch.float32, device=y.device)
+    rstd = torch.empty_like(mean)
+    d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd)
+    nb = (M + 1 + (x is not None)) * R * dm * 4.0
+    L.check(timed("pq3d_add_ln_fwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_fwd, C.byref(d), L.stream()),
+            "pq3d_add_ln_fwd")
+    return y, mean, rstd
+
+
+def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dgs, dbs, want_dx=True):
+    """Returns (dx or None, d_o [M,...] fp32 stacked); dgamma/dbeta accumulate into the arena views dgs/dbs."""
+    M = len(os_)
+    dm = os_[0].shape[-1]
+    R = os_[0].numel() // dm
+    dev = dy.device
+    d_o = torch.empty(M, *os_[0].shape, dtype=torch.float32, device=dev)
+    dx = torch.empty(os_[0].shape, dtype=torch.float32, device=dev) if (x is not None and want_dx) else None
+    d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd)
+    d.dy, d.dx, d.accumulate = L.ptr(dy), L.ptr(dx), 1
+    for m in range(M):
+        d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_o[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
+    nb = (3 * M + 1 + (x is not None)) * R * dm * 4.0
+    L.check(timed("pq3d_add_ln_bwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_bwd, C.byref(d), L.stream()),
+            "pq3d_add_ln_bwd")
+    return dx, d_o
+
+
+def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None, bias=None, mask_bmod=0, bwd=None):
+    d = ops._attn_desc(q, k, v, o, lse, H, ct, zero_attn, 1.0 / math.sqrt(q.shape[-1] // H), kpm, mask, row_open, bias)
+    d.mask_bmod = mask_bmod
+    B, Lq, dm = q.shape
+    Lk = k.shape[1]
+    key = f"B{B}H{H}Lq{Lq}Lk{Lk}dh{dm // H}ct{ct}"
+    if bwd is None:
+        L.check(timed("pq3d_attn_fwd", key, 4.0 * B * Lq * Lk * dm, (q.numel() * 2 + k.numel() * 2) * q.element_size(),
+                      L.lib().pq3d_attn_fwd, C.byref(d), L.stream()), "pq3d_attn_fwd")
+    else:
+        d.dout, d.dq, d.dk, d.dv, d.delta, d.dbias = map(L.ptr, bwd)
+        L.check(timed("pq3d_attn_bwd", key, 14.0 * B * Lq * Lk * dm, (q.numel() * 3 + k.numel() * 4) * q.element_size(),
+                      L.lib().pq3d_attn_bwd, C.byref(d), L.stream()), "pq3d_attn_bwd")
+
+
+class _FusedDecoder(Function):
+    """inputs: spec, x0, qpos, qmask, pos, pairwise_locs, seg_pad, offline_mask, coef, M feats, M masks, *params."""
+
+    @staticmethod
+    def forward(ctx, spec: FusedSpec, x0, qpos, qmask, pos, pl, seg_pad, offline_mask, coef, *rest):
+        enc, ct = spec.enc, spec.ct
+        ad = ops.act_dtype(ct)
+        M = len(spec.mems)
+        feats, masks, params = list(rest[:M]), list(rest[M:2 * M]), rest[2 * M:]
+        layers = list(enc.unified_encoder)
+        Ln = len(layers)
+        H = enc.num_heads
+        B, Nq, d = qpos.shape
+        Ns = feats[0].shape[1]
+        R, Rk = B * Nq, B * Ns
+        dev = qpos.device
+        mem_idx = [layers[0].memories.index(m) for m in spec.mems]
+        cas = [[layers[i].cross_attn_list[j] for j in mem_idx] for i in range(Ln)]
+        x0, qpos, pos = ops._c(x0), ops._c(qpos), ops._c(pos)
+        feats = [ops._c(f) for f in feats]
+        masks = [ops._c(m) for m in masks]
+        qmask = ops._c(qmask)
+
+        # ---- hoisted K/V projections: KV[l, 0|1, m] = (feat_m [+ pos]) @ W{k,v}_{l,m}^T + b
+        KV = torch.empty(Ln, 2, M, B, Ns, d, dtype=ad, device=dev)
+        A, A2, Bw, bs, Cs = [], [], [], [], []
+        for i in range(Ln):
+            for j, ca in enumerate(cas[i]):
+                w, b = ca.multihead_attn.in_proj_weight.detach(), ca.multihead_attn.in_proj_bias.detach()
+                A += [feats[j], feats[j]]
+                A2 += [pos, None]
+                Bw += [w[d:2 * d], w[2 * d:]]
+                bs += [b[d:2 * d], b[2 * d:]]
+                Cs += [KV[i, 0, j], KV[i, 1, j]]
+        for s in range(0, len(A), MAXG):
+            L.gemm(M=Rk, N=d, K=d, A=A[s:s + MAXG], A2=A2[s:s + MAXG], B=Bw[s:s + MAXG], bias=bs[s:s + MAXG],
+                   Cs=Cs[s:s + MAXG], ct=ct, lda=d, ldb=d, ldc=d)
+        kpm_all = torch.cat(masks, 0) if not spec.use_self_mask else None
+
+        # ---- mask-head keys (layer-invariant)
+        keys = inv_den = None
+        if spec.mh is not None:
+            mps = list(spec.mh.mask_pred_list)[:spec.mh_count]
+            valid = [m.logical_not() for m in masks[:spec.mh_count]]
+            keys_buf = torch.empty(spec.mh_count, B, Ns, d, dtype=ad, device=dev)
+            L.gemm(M=Rk, N=d, K=d, A=feats[:spec.mh_count], B=[mp.k_proj.weight.detach() for mp in mps],
+                   Cs=[keys_buf[m] for m in range(spec.mh_count)], row_mask=valid, ct=ct, lda=d, ldb=d, ldc=d)
+            keys = [keys_buf[m] for m in range(spec.mh_count)]
+            inv_den = ops.mask_inv_den(masks[:spec.mh_count])
+            ctx.mh_valid = valid
+
+        tape: List[dict] = []
+        pcls, pmask = [], []
+        x = x0
+        attn_mask = row_open = None
+        for blk in range(spec.num_blocks):
+            for i, layer in enumerate(layers):
+                rec: Dict[str, object] = {"i": i, "x_in": x}
+                if spec.mh is not None and not spec.skip_pred:
+                    cls, mlog, amask = _mh_forward(spec, x, keys, inv_den, seg_pad, rec)
+                    pcls.append(cls)
+                    pmask.append(mlog)
+                    attn_mask = offline_mask if spec.offline else amask
+                elif spec.offline:
+                    attn_mask = offline_mask
+                if spec.use_self_mask:
+                    row_open = ops.mask_row_all(attn_mask)
+                rec["attn_mask"], rec["row_open"] = attn_mask, row_open
+                # -- cross attention over the M memories: 4 launches
+                q_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+                ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cas[i]]
+                bsl = [ca.multihead_attn.in_proj_bias.detach() for ca in cas[i]]
+                L.gemm(M=R, N=d, K=d, A=[x] * M, A2=[qpos] * M, B=[w[:d] for w in ws], bias=[b[:d] for b in bsl],
+                       Cs=[q_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
+                o_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+                lse = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
+                if spec.use_self_mask:
+                    _attn(q_all.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
+                          o_all.view(M * B, Nq, d), lse, H, ct, True, mask=attn_mask, row_open=row_open, mask_bmod=B)
+                else:
+                    _attn(q_all.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
+                          o_all.view(M * B, Nq, d), lse, H, ct, True, kpm=kpm_all)
+                op_all = torch.empty(M, B, Nq, d, dtype=torch.float32, device=dev)
+                L.gemm(M=R, N=d, K=d, A=[o_all[m] for m in range(M)],
+                       B=[ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
+                       bias=[ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]],
+                       Cs=[op_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
+                x1, mean_c, rstd_c = _ln_fwd(x, [op_all[m] for m in range(M)], [ca.norm.weight.detach() for ca in cas[i]],
+                                             [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps, coef, Nq)
+                rec.update(q_all=q_all, o_all=o_all, lse=lse, op_all=op_all, mean_c=mean_c, rstd_c=rstd_c, x1=x1)
+                # -- self attention: 5 launches (spatial) / 4
+                sa = layer.self_attn
+                qkv = torch.empty(3, B, Nq, d, dtype=ad, device=dev)
+                if spec.spatial:
+                    msa = sa.self_attn
+                    Wl = [msa.w_qs.weight.detach(), msa.w_ks.weight.detach(), msa.w_vs.weight.detach()]
+                    bl = [msa.w_qs.bias.detach(), msa.w_ks.bias.detach(), msa.w_vs.bias.detach()]
+                    Wo, bo = msa.fc.weight.detach(), msa.fc.bias.detach()
+                else:
+                    w, b = sa.self_attn.in_proj_weight.detach(), sa.self_attn.in_proj_bias.detach()
+                    Wl, bl = [w[:d], w[d:2 * d], w[2 * d:]], [b[:d], b[d:2 * d], b[2 * d:]]
+                    Wo, bo = sa.self_attn.out_proj.weight.detach(), sa.self_attn.out_proj.bias.detach()
+                L.gemm(M=R, N=d, K=d, A=[x1] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=ct,
+                       lda=d, ldb=d, ldc=d)
+                sbias = None
+                if spec.spatial:
+                    sbias = torch.empty(B, H, Nq, Nq, dtype=torch.float32, device=dev)
+                    L.check(L.lib().pq3d_spatial_bias_fwd(L.ptr(pl), L.ptr(msa.pairwise_loc_fc.weight.detach()),
+                                                          L.ptr(msa.pairwise_loc_fc.bias.detach()), L.ptr(sbias), B, H, Nq,
+                                                          L.stream()), "pq3d_spatial_bias_fwd")
+                o_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
+                lse_s = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+                _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ct, False, kpm=qmask, bias=sbias)
+                f = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                L.gemm(M=R, N=d, K=d, A=[o_s], B=[Wo], bias=[bo], Cs=[f], ct=ct, lda=d, ldb=d, ldc=d)
+                x2, mean_s, rstd_s = _ln_fwd(x1, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq)
+                rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
+                # -- FFN: 3 launches
+                ffn = layer.ffn
+                F_ = ffn.linear1.out_features
+                h = torch.empty(B, Nq, F_, dtype=ad, device=dev)
+                pre = torch.empty_like(h) if spec.act == "gelu" else None
+                L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
+                       C2=[pre], ct=ct, lda=d, ldb=d, ldc=F_, act=spec.act)
+                y = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()], Cs=[y],
+                       ct=ct, lda=F_, ldb=F_, ldc=d)
+                x3, mean_f, rstd_f = _ln_fwd(x2, [y], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq)
+                rec.update(h=h, pre=pre, y=y, mean_f=mean_f, rstd_f=rstd_f)
+                tape.append(rec)
+                x = x3
+        final_rec = None
+        if spec.mh is not None:
+            final_rec = {"x_in": x}
+            cls, mlog, _ = _mh_forward(spec, x, keys, inv_den, seg_pad, final_rec)
+            if spec.skip_pred:
+                pcls, pmask = [], []
+            pcls.append(cls)
+            pmask.append(mlog)
+        ctx.spec, ctx.tape, ctx.final_rec = spec, tape, final_rec
+        ctx.KV, ctx.keys, ctx.inv_den, ctx.kpm_all = KV, keys, inv_den, kpm_all
+        ctx.cas, ctx.n_mh = cas, len(pcls)
+        ctx.params = params
+        ctx.save_for_backward(x0, qpos, qmask, pos, pl, seg_pad, coef, *feats, *masks)
+        ctx.M = M
+        return (x, *pcls, *pmask)
+
+    @staticmethod
+    def backward(ctx, dxf, *dheads):
+        spec, tape = ctx.spec, ctx.tape
+        enc, ct = spec.enc, spec.ct
+        ad = ops.act_dtype(ct)
+        M = ctx.M
+        sv = ctx.saved_tensors
+        x0, qpos, qmask, pos, pl, seg_pad, coef = sv[:7]
+        feats, masks = list(sv[7:7 + M]), list(sv[7 + M:7 + 2 * M])
+        params = ctx.params
+        layers = list(enc.unified_encoder)
+        Ln, H = len(layers), enc.num_heads
+        B, Nq, d = qpos.shape
+        Ns = feats[0].shape[1]
+        R, Rk = B * Nq, B * Ns
+        dev = qpos.device
+        cas, KV = ctx.cas, ctx.KV
+        n_mh = ctx.n_mh
+        dcls, dmlog = list(dheads[:n_mh]), list(dheads[n_mh:2 * n_mh])
+
+        # ---- gradient arena: one flat zeroed fp32 buffer, every parameter gradient is a view of it
+        sizes = [p.numel() for p in params]
+        arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        gv, off = {}, 0
+        for p, n in zip(params, sizes):
+            gv[id(p)] = arena[off:off + n].view(p.shape)
+            off += n
+        G = lambda p: gv[id(p)]
+
+        dx = dxf.contiguous().float() if dxf is not None else torch.zeros(B, Nq, d, device=dev)
+        dqpos_parts: List[torch.Tensor] = []
+        n_app = len(tape)
+        dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=ad, device=dev)
+        dkeys = None  # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
+
+        def mh_backward(rec, dc, dm, dx_in):
+            """Backprop one mask-head call; returns dx_in + its contribution to d(query)."""
+            nonlocal dkeys
+            mh = spec.mh
+            c0, c2, c4 = mh.cls_head[0], mh.cls_head[2], mh.cls_head[4]
+            x_in = rec["mh_x"]
+            Hd, C_ = c0.out_features, c4.out_features
+            cur = dx_in
+            if dc is not None:
+                dcl = dc.contiguous()
+                if mh._foc_cols.numel():
+                    t = torch.empty_like(dcl)
+                    L.check(L.lib().pq3d_fill_cols(L.ptr(dcl), L.ptr(t), R, C_, L.ptr(mh._foc_cols),
+                                                   mh._foc_cols.numel(), 0.0, L.stream()), "pq3d_fill_cols")
+                    dcl = t
+                dh2 = torch.empty(B, Nq, Hd, dtype=torch.float32, device=dev)
+                L.gemm(M=R, N=Hd, K=C_, A=[dcl], B=[c4.weight.detach()], Cs=[dh2], ct=ct, lda=C_, ldb=Hd, ldc=Hd, transB=True)
+                _dw_acc([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct)
+                _colsum_acc([dcl], [G(c4.bias)], R)
+                _, dh1 = _ln_bwd(None, [rec["mh_h1"]], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq,
+                                 rec["mh_mean"], rec["mh_rstd"], dh2, [G(c2.weight)], [G(c2.bias)])
+                dpre = ops.act_bwd(dh1[0], rec["mh_h1"], "relu", ad)
+                nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                L.gemm(M=R, N=d, K=Hd, A=[dpre], B=[c0.weight.detach()], Cs=[nxt], aux=[cur], act_grad="add", ct=ct,
+                       lda=Hd, ldb=d, ldc=d, transB=True)
+                _dw_acc([dpre], [x_in], None, [G(c0.weight)], ct)
+                _colsum_acc([dpre], [G(c0.bias)], R)
+                cur = nxt
+            if dm is not None:
+                Mm = spec.mh_count
+                mps = list(mh.mask_pred_list)[:Mm]
+                qm = rec["mh_qm"]
+                g = ops.scale_rows(dm.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=seg_pad)
+                # d keys: g @ q_m (accumulated over calls through the "+ aux" epilogue)
+                newk = torch.empty(Mm, B, Ns, d, dtype=torch.float32, device=dev)
+                L.gemm(M=Ns, N=d, K=Nq, A=[g] * Mm, B=[qm[m] for m in range(Mm)], Cs=[newk[m] for m in range(Mm)],
+                       aux=[dkeys[m] for m in range(Mm)] if dkeys is not None else None,
+                       act_grad="add" if dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
+                       strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
+                dkeys = newk
+                dqm = torch.empty(Mm, B, Nq, d, dtype=ad, device=dev)
+                L.gemm(M=Nq, N=d, K=Ns, A=[g] * Mm, B=list(ctx.keys), Cs=[dqm[m] for m in range(Mm)], ct=ct, lda=Nq,
+                       ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d)
+                nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                L.gemm(M=R, N=d, K=d, A=[dqm[m] for m in range(Mm)], B=[mp.q_proj.weight.detach() for mp in mps],
+                       Cs=[nxt] + [None] * (Mm - 1), aux=[cur] + [None] * (Mm - 1), act_grad="add", ct=ct, lda=d, ldb=d,
+                       ldc=d, transB=True, kconcat=Mm)
+                _dw_acc([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct)
+                _colsum_acc([dqm[m] for m in range(Mm)], [G(mp.q_proj.bias) for mp in mps], R)
+                cur = nxt
+            return cur
+
+        if ctx.final_rec is not None:
+            dx = mh_backward(ctx.final_rec, dcls[-1], dmlog[-1], dx)
+
+        for a in range(n_app - 1, -1, -1):
+            rec = tape[a]
+            i = rec["i"]
+            layer = layers[i]
+            x_in, x1, x2 = rec["x_in"], rec["x1"], rec["x2"]
+            # ---------------- FFN backward
+            ffn = layer.ffn
+            F_ = ffn.linear1.out_features
+            dx2r, dy = _ln_bwd(x2, [rec["y"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None,
+                               Nq, rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)])
+            dy = dy[0]
+            dhp = torch.empty(B, Nq, F_, dtype=ad, device=dev)
+            L.gemm(M=R, N=F_, K=d, A=[dy], B=[ffn.linear2.weight.detach()], Cs=[dhp],
+                   aux=[rec["pre"] if spec.act == "gelu" else rec["h"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
+                   transB=True)
+            _dw_acc([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct)
+            _colsum_acc([dy], [G(ffn.linear2.bias)], R)
+            dx2 = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], aux=[dx2r], act_grad="add", ct=ct,
+                   lda=F_, ldb=d, ldc=d, transB=True)
+            _dw_acc([dhp], [x2], None, [G(ffn.linear1.weight)], ct)
+            _colsum_acc([dhp], [G(ffn.linear1.bias)], R)
+            # ---------------- self-attention backward
+            sa = layer.self_attn
+            if spec.spatial:
+                msa = sa.self_attn
+                Wl = [msa.w_qs.weight, msa.w_ks.weight, msa.w_vs.weight]
+                GW = [G(w) for w in Wl]
+                Gb = [G(msa.w_qs.bias), G(msa.w_ks.bias), G(msa.w_vs.bias)]
+                Wl = [w.detach() for w in Wl]
+                Wo, GWo, Gbo = msa.fc.weight.detach(), G(msa.fc.weight), G(msa.fc.bias)
+            else:
+                w, gw, gb = sa.self_attn.in_proj_weight.detach(), G(sa.self_attn.in_proj_weight), G(sa.self_attn.in_proj_bias)
+                Wl = [w[:d], w[d:2 * d], w[2 * d:]]
+                GW = [gw[:d], gw[d:2 * d], gw[2 * d:]]
+                Gb = [gb[:d], gb[d:2 * d], gb[2 * d:]]
+                Wo, GWo, Gbo = sa.self_attn.out_proj.weight.detach(), G(sa.self_attn.out_proj.weight), G(sa.self_attn.out_proj.bias)
+            dx1r, df = _ln_bwd(x1, [rec["f"]], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
+                               rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)])
+            df = df[0]
+            do_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+            _dw_acc([df], [rec["o_s"]], None, [GWo], ct)
+            _colsum_acc([df], [Gbo], R)
+            qkv = rec["qkv"]
+            dqkv = torch.empty(3, B, Nq, d, dtype=ad, device=dev)
+            delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+            dsb = torch.empty_like(rec["sbias"]) if spec.spatial else None
+            _attn(qkv[0], qkv[1], qkv[2], rec["o_s"], rec["lse_s"], H, ct, False, kpm=qmask, bias=rec["sbias"],
+                  bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb))
+            if spec.spatial:
+                L.check(L.lib().pq3d_spatial_bias_bwd_acc(L.ptr(pl), L.ptr(msa.pairwise_loc_fc.weight.detach()),
+                                                          L.ptr(msa.pairwise_loc_fc.bias.detach()), L.ptr(dsb),
+                                                          L.ptr(G(msa.pairwise_loc_fc.weight)),
+                                                          L.ptr(G(msa.pairwise_loc_fc.bias)), B, H, Nq, L.stream()),
+                        "pq3d_spatial_bias_bwd_acc")
+            tmpv = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)       # dv @ Wv + residual grad
+            L.gemm(M=R, N=d, K=d, A=[dqkv[2]], B=[Wl[2]], Cs=[tmpv], aux=[dx1r], act_grad="add", ct=ct, lda=d, ldb=d,
+                   ldc=d, transB=True)
+            gqk = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)        # pure d(x1 + qpos) from q, k
+            dx1 = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1]], B=[Wl[0], Wl[1]], Cs=[dx1, None], C2=[gqk, None],
+                   aux=[tmpv, None], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=2)
+            dqpos_parts.append(gqk)
+            _dw_acc([dqkv[0], dqkv[1], dqkv[2]], [x1] * 3, [qpos, qpos, None], GW, ct)
+            _colsum_acc([dqkv[0], dqkv[1], dqkv[2]], Gb, R)
+            # ---------------- cross-attention backward (M memories per launch)
+            cl = cas[i]
+            dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
+                               [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef, Nq, rec["mean_c"], rec["rstd_c"],
+                               dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl])
+            do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
+                   Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+            _dw_acc([dop[m] for m in range(M)], [rec["o_all"][m] for m in range(M)], None,
+                    [G(ca.multihead_attn.out_proj.weight) for ca in cl], ct)
+            _colsum_acc([dop[m] for m in range(M)], [G(ca.multihead_attn.out_proj.bias) for ca in cl], R)
+            dq_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+            delta_c = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
+            mb = dict(mask=rec["attn_mask"], row_open=rec["row_open"], mask_bmod=B) if spec.use_self_mask \
+                else dict(kpm=ctx.kpm_all)
+            _attn(rec["q_all"].view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
+                  rec["o_all"].view(M * B, Nq, d), rec["lse"], H, ct, True,
+                  bwd=(do_all.view(M * B, Nq, d), dq_all.view(M * B, Nq, d), dKV[a, 0].view(M * B, Ns, d),
+                       dKV[a, 1].view(M * B, Ns, d), delta_c, None), **mb)
+            ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cl]
+            gq = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+            dxn = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[dq_all[m] for m in range(M)], B=[w[:d] for w in ws], Cs=[dxn] + [None] * (M - 1),
+                   C2=[gq] + [None] * (M - 1), aux=[dxr] + [None] * (M - 1), act_grad="add", ct=ct, lda=d, ldb=d, ldc=d,
+                   transB=True, kconcat=M)
+            dqpos_parts.append(gq)
+            _dw_acc([dq_all[m] for m in range(M)], [x_in] * M, [qpos] * M,
+                    [G(ca.multihead_attn.in_proj_weight)[:d] for ca in cl], ct)
+            _colsum_acc([dq_all[m] for m in range(M)], [G(ca.multihead_attn.in_proj_bias)[:d] for ca in cl], R)
+            dx = dxn
+            # ---------------- mask-head call that preceded this layer
+            if spec.mh is not None and not spec.skip_pred:
+                dx = mh_backward(rec, dcls[a], dmlog[a], dx)
+
+        # ---- hoisted K/V projection backward (sum over all applications)
+        need_feat = [ctx.needs_input_grad[9 + m] for m in range(M)]
+        dfeats: List[Optional[torch.Tensor]] = [None] * M
+        Akv, Bkv, Xf, X2, GWs, Gbs = [], [], [], [], [], []
+        for a in range(n_app):
+            i = tape[a]["i"]
+            for j, ca in enumerate(cas[i]):
+                w = ca.multihead_attn.in_proj_weight.detach()
+                gw, gb = G(ca.multihead_attn.in_proj_weight), G(ca.multihead_attn.in_proj_bias)
+                Akv += [dKV[a, 0, j], dKV[a, 1, j]]
+                Bkv += [w[d:2 * d], w[2 * d:]]
+                Xf += [feats[j], feats[j]]
+                X2 += [pos, None]
+                GWs += [gw[d:2 * d], gw[2 * d:]]
+                Gbs += [gb[d:2 * d], gb[2 * d:]]
+        _dw_acc(Akv, Xf, X2, GWs, ct)
+        _colsum_acc(Akv, Gbs, Rk)
+        # d feat_m = sum_a (dK_{a,m} Wk + dV_{a,m} Wv) [+ mask-head key path]
+        for j in range(M):
+            if not need_feat[j]:
+                continue
+            Aj = [Akv[2 * (a * M + j) + t] for a in range(n_app) for t in (0, 1)]
+            Bj = [Bkv[2 * (a * M + j) + t] for a in range(n_app) for t in (0, 1)]
+            if dkeys is not None and j < spec.mh_count:
+                mp = list(spec.mh.mask_pred_list)[j]
+                dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
+                Aj.append(dkm)
+                Bj.append(mp.k_proj.weight.detach())
+                _dw_acc([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
+            out = None
+            for s in range(0, len(Aj), MAXG):
+                nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
+                n = len(Aj[s:s + MAXG])
+                L.gemm(M=Rk, N=d, K=d, A=Aj[s:s + MAXG], B=Bj[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
+                       aux=([out] + [None] * (n - 1)) if out is not None else None,
+                       act_grad="add" if out is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=n)
+                out = nxt
+            dfeats[j] = out
+        if dkeys is not None:  # k_proj weight grads for memories whose features need no grad
+            for j in range(spec.mh_count):
+                if not need_feat[j]:
+                    mp = list(spec.mh.mask_pred_list)[j]
+                    dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
+                    _dw_acc([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
+        dpos = None
+        if pos is not None and ctx.needs_input_grad[4]:
+            Ak, Bk = Akv[0::2], Bkv[0::2]
+            for s in range(0, len(Ak), MAXG):
+                nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
+                n = len(Ak[s:s + MAXG])
+                L.gemm(M=Rk, N=d, K=d, A=Ak[s:s + MAXG], B=Bk[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
+                       aux=([dpos] + [None] * (n - 1)) if dpos is not None else None,
+                       act_grad="add" if dpos is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=n)
+                dpos = nxt
+        dqpos = None
+        if ctx.needs_input_grad[2]:
+            dqpos = torch.stack(dqpos_parts, 0).sum(0) if len(dqpos_parts) > 1 else dqpos_parts[0]
+        dx0 = dx if ctx.needs_input_grad[1] else None
+        pgrads = [gv[id(p)] if p.requires_grad else None for p in params]
+        return (None, dx0, dqpos, None, dpos, None, None, None, None, *dfeats, *([None] * M), *pgrads)
+
+
+def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_match=None, seg_masks=None,
+                  offline_attn_masks=None, skip_prediction=False):
+    """Run QueryMaskEncoder (+ MaskHeadSegLevel) through the fused executor.  Returns
+    (query, predictions_class, predictions_mask) exactly like QueryMaskEncoder.forward followed by the final
+    mask-head call.  Raises NotImplementedError for configurations it does not cover (callers fall back to the
+    modular path)."""
+    layer0 = enc.unified_encoder[0]
+    if layer0.structure != "parallel":
+        raise NotImplementedError("fused path covers structure='parallel'")
+    training = enc.training
+    mems = [m for m in layer0.memories if training or m not in layer0.drop_memories_test]
+    if not mems or any(m == "prompt" for m in mems):
+        raise NotImplementedError("fused path needs scene memories only")
+    x0, qmask, qpos = input_dict["query"][:3]
+    feats = [input_dict[m][0] for m in mems]
+    masks = [input_dict[m][1] for m in mems]
+    poss = [input_dict[m][2] for m in mems]
+    if any(isinstance(f, list) for f in feats) or any(m.ndim != 2 for m in masks):
+        raise NotImplementedError("fused path: multi-scale voxel features / pre-set 3-D masks")
+    if any(p is not poss[0] for p in poss) or len({tuple(f.shape) for f in feats}) != 1:
+        raise NotImplementedError("fused path: memories must share one position tensor and one shape")
+    if len(mems) * len(enc.unified_encoder) * 2 > 4 * MAXG:
+        raise NotImplementedError("fused path: too many (layer, memory) groups")
+    mh_count = 0
+    if mask_head is not None:
+        if seg_fts_for_match is None or any(sf[0] is not feats[k] for k, sf in enumerate(seg_fts_for_match)):
+            raise NotImplementedError("fused path: mask-head memories must be the leading scene memories")
+        mh_count = len(seg_fts_for_match)
+    if enc.use_self_mask and mask_head is None:
+        raise NotImplementedError("use_self_mask without a mask head")
+    coef = None
+    if training and layer0.memory_dropout > 0.0:
+        keep = torch.rand(x0.shape[0], len(mems), device=x0.device) > layer0.memory_dropout
+        keep = torch.logical_or(keep, keep.sum(1, keepdim=True) == 0)
+        coef = (keep / keep.sum(1, keepdim=True)).t().contiguous().float()
+    ct = L.BF16 if layer0.compute == "bf16" else L.F32
+    spec = FusedSpec(enc, mask_head, mems, ct, layer0.ffn.activation, enc.use_self_mask, enc.num_blocks,
+                     enc.spatial_selfattn, mh_count, offline_attn_masks is not None, skip_prediction)
+    params = [p for p in enc.parameters()] + ([p for p in mask_head.parameters()] if mask_head is not None else [])
+    outs = _FusedDecoder.apply(spec, x0, qpos, qmask, poss[0], pairwise_locs, seg_masks, offline_attn_masks, coef,
+                               *feats, *masks, *params)
+    query = outs[0]
+    n = (len(outs) - 1) // 2
+    return query, list(outs[1:1 + n]), list(outs[1 + n:1 + 2 * n])

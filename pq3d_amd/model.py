@@ -153,11 +153,14 @@ class Query3DUnified(nn.Module):
                 seg_fts_for_match.append(feats)
         if hasattr(self, "mask_head"):
             seg_masks = data_dict["seg_pad_masks"].logical_not()
-            # k_proj(seg feats) is layer-invariant: project once, reuse in all L*n_b+1 mask-head calls
-            keys = self.mask_head.project_keys(seg_fts_for_match)
             mask_head_partial = partial(self.mask_head, seg_fts_for_match=seg_fts_for_match, seg_masks=seg_masks,
                                         offline_attn_masks=offline_attn_masks,
-                                        skip_prediction=self.skip_query_encoder_mask_pred, keys=keys)
+                                        skip_prediction=self.skip_query_encoder_mask_pred)
+            enc = self.unified_encoder
+            fusable = getattr(enc, "fused", False) and enc.unified_encoder[0].structure == "parallel"
+            if not fusable:
+                # modular path: k_proj(seg feats) is layer-invariant -> project once, reuse in all mask-head calls
+                mask_head_partial.keywords["keys"] = self.mask_head.project_keys(seg_fts_for_match)
         else:
             mask_head_partial = None
         if self.unified_encoder.spatial_selfattn:
@@ -177,7 +180,10 @@ class Query3DUnified(nn.Module):
             elif head == "mask":
                 if self.skip_query_encoder_mask_pred:
                     predictions_class, predictions_mask = [], []
-                pred_logits, pred_masks, _ = mask_head_partial(query=query, skip_prediction=False)
+                if getattr(self.unified_encoder, "_fused_final", None) is not None:
+                    pred_logits, pred_masks = self.unified_encoder._fused_final  # computed inside the fused executor
+                else:
+                    pred_logits, pred_masks, _ = mask_head_partial(query=query, skip_prediction=False)
                 predictions_class.append(pred_logits)
                 predictions_mask.append(pred_masks)
                 data_dict["predictions_class"] = predictions_class

@@ -331,9 +331,38 @@ class QueryMaskEncoder(nn.Module):
         self.use_self_mask = use_self_mask
         self.num_heads = num_attention_heads
         self.num_blocks = num_blocks
+        self.fused = True          # use the fused executor (fused.py) whenever the configuration allows it
+        self._fused_final = None   # (cls, mask_logits) of the trailing mask-head call computed by the fused path
         set_compute(self, compute)
 
+    def _try_fused(self, input_dict, pairwise_locs, mask_head):
+        """Fused executor for structure='parallel' with `mask_head` either None or a functools.partial of a
+        MaskHeadSegLevel (what Query3DUnified builds).  Returns None when the configuration is not covered."""
+        from . import fused as F
+        mh_mod, kw = None, {}
+        if mask_head is not None:
+            owner = getattr(getattr(mask_head, "func", None), "__self__", None)
+            if not (isinstance(mask_head, partial) and isinstance(owner, MaskHeadSegLevel) and not mask_head.args):
+                return None
+            mh_mod, kw = owner, dict(mask_head.keywords)
+            kw.pop("keys", None)
+        try:
+            query, pcls, pmask = F.fused_decoder(self, input_dict, pairwise_locs, mh_mod,
+                                                 kw.get("seg_fts_for_match"), kw.get("seg_masks"),
+                                                 kw.get("offline_attn_masks"), kw.get("skip_prediction", False))
+        except NotImplementedError:
+            return None
+        if mh_mod is not None:
+            self._fused_final = (pcls[-1], pmask[-1])
+            pcls, pmask = pcls[:-1], pmask[:-1]
+        return query, pcls, pmask
+
     def forward(self, input_dict, pairwise_locs, mask_head=None):
+        self._fused_final = None
+        if self.fused:
+            out = self._try_fused(input_dict, pairwise_locs, mask_head)
+            if out is not None:
+                return out
         predictions_class, predictions_mask = [], []
         query = input_dict["query"][0]
         voxel_feat = input_dict["voxel"][0] if "voxel" in input_dict.keys() else None

@@ -65,7 +65,7 @@ int main(void) {
 
 def test_argument_errors_are_reported(lib):
     d = _lib.GemmDesc()
-    d.groups, d.batch, d.M, d.N, d.K = 99, 1, 4, 4, 4
+    d.groups, d.batch, d.M, d.N, d.K = 999, 1, 4, 4, 4
     rc = lib.pq3d_gemm(ctypes.byref(d), None)
     assert rc == -1 and b"groups" in lib.pq3d_last_error()
     a = _lib.AttnDesc()

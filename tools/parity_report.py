@@ -47,6 +47,10 @@ def main():
                 gmax = max(float(v.abs().max()) for v in og.values())
                 g = dict(model.named_parameters())
                 wg, wn = max((rel(g[n].grad, og[n], floor=1e-2 * gmax), n) for n in og)
+                nmax = max(float(v.norm()) for v in og.values())
+                l2, l2n = max((float((g[n].grad.detach().float().cpu() - og[n]).norm()
+                                     / max(float(og[n].norm()), 1e-2 * nmax)), n) for n in og)
+                wn = f"{wn}  | worst relL2 {l2:.2e} {l2n}"
             vs = "oracle fp32" if emu is None else "oracle bf16-round"
             print(f"{name:18s} {compute:8s} {vs:16s} {q:9.2e} {head:9.2e} {ml:10.2e} {fl:10.2e} {le:9.2e} {wg:10.2e}  {wn}")
 
