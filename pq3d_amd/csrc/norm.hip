@@ -72,6 +72,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
 // (blockIdx.y = m).  dx (sum over branches) is then accumulated with atomics only when M > 1.
 template <int PL>
 __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc d) {
+  __shared__ float red[2][WPB][64 * PL];
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.y;
   const long wave_id = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
@@ -118,13 +119,20 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
       }
     }
   }
+  // block-level reduction of the parameter-gradient partials, then ONE atomic per column per block
+  const int wave = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < PL; ++j) {
-    const int c = lane + 64 * j;
-    if (c < d.d) {
-      unsafeAtomicAdd(&d.dgamma[m][c], dg[j]);
-      unsafeAtomicAdd(&d.dbeta[m][c], db[j]);
-    }
+    red[0][wave][lane + 64 * j] = dg[j];
+    red[1][wave][lane + 64 * j] = db[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d.d; c += WPB * 64) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; }
+    unsafeAtomicAdd(&d.dgamma[m][c], sg);
+    unsafeAtomicAdd(&d.dbeta[m][c], sb);
   }
 }
 
@@ -178,8 +186,8 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
     hipError_t e = hipMemsetAsync(d.dx, 0, sizeof(float) * (size_t)d.R * d.d, s);
     if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
   }
-  long nb = (d.R + 4 * WPB - 1) / (4 * WPB);  // ~4 rows per wave: bounds the parameter-grad atomics per column
-  if (nb > 1024) nb = 1024;
+  long nb = (d.R + 8 * WPB - 1) / (8 * WPB);  // ~8 rows per wave; one atomic per column per block
+  if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb, d.M);
   LN_DISPATCH(add_ln_bwd_kernel, grid)
