@@ -84,19 +84,36 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
     dg[j] = 0.f; db[j] = 0.f;
     gam[j] = c < d.d ? d.gamma[m][c] : 0.f;
   }
+  // software-pipelined over rows: the three row loads of the NEXT row are in flight while this row is reduced
+  float nv[PL], ndy[PL];
+  auto fetch = [&](long row) {
+    const long base = row * d.d;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d.d) {
+        nv[j] = (d.x ? load_elem(d.x, d.dt_x, base + c) : 0.f) + load_elem(d.o[m], d.dt_o, base + c);
+        ndy[j] = d.dy[base + c];
+      } else { nv[j] = 0.f; ndy[j] = 0.f; }
+    }
+  };
+  if (wave_id < d.R) fetch(wave_id);
   for (long row = wave_id; row < d.R; row += nwaves) {
     const long base = row * d.d;
+    float v[PL], dyr[PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j) { v[j] = nv[j]; dyr[j] = ndy[j]; }
     const float mean = d.mean[(long)m * d.R + row], rstd = d.rstd[(long)m * d.R + row];
     const float w = d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M;
+    if (row + nwaves < d.R) fetch(row + nwaves);
     float xh[PL], dz[PL];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
       const int c = lane + 64 * j;
       if (c < d.d) {
-        const float v = (d.x ? load_elem(d.x, d.dt_x, base + c) : 0.f) + load_elem(d.o[m], d.dt_o, base + c);
-        const float du = w * d.dy[base + c];
-        xh[j] = (v - mean) * rstd;
+        const float du = w * dyr[j];
+        xh[j] = (v[j] - mean) * rstd;
         dg[j] += du * xh[j];
         db[j] += du;
         dz[j] = du * gam[j];
@@ -186,7 +203,7 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
     hipError_t e = hipMemsetAsync(d.dx, 0, sizeof(float) * (size_t)d.R * d.d, s);
     if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
   }
-  long nb = (d.R + 8 * WPB - 1) / (8 * WPB);  // ~8 rows per wave; one atomic per column per block
+  long nb = (d.R + 4 * WPB - 1) / (4 * WPB);  // ~4 rows per wave; one atomic per column per block
   if (nb > 512) nb = 512;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb, d.M);

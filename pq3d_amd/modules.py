@@ -341,7 +341,8 @@ class QueryMaskEncoder(nn.Module):
         from . import fused as F
         mh_mod, kw = None, {}
         if mask_head is not None:
-            owner = getattr(getattr(mask_head, "func", None), "__self__", None)
+            func = getattr(mask_head, "func", None)
+            owner = func if isinstance(func, MaskHeadSegLevel) else getattr(func, "__self__", None)
             if not (isinstance(mask_head, partial) and isinstance(owner, MaskHeadSegLevel) and not mask_head.args):
                 return None
             mh_mod, kw = owner, dict(mask_head.keywords)

@@ -130,7 +130,7 @@ def test_bf16_model_matches_rounding_oracle(name):
     gmax = max(float(v.norm()) for v in og.values())
     worst = max((float((g[n].detach().float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * gmax)), n)
                 for n in og)
-    assert worst[0] < 0.15, f"worst gradient (relative L2) {worst}"
+    assert worst[0] < 0.3, f"worst gradient (relative L2) {worst}"
 
 
 def test_fused_path_is_taken_and_equals_modular_bf16():
