@@ -44,7 +44,16 @@ def _gemm_groups(n_per_call_limit, **kw):
 def _colsum_acc(xs: Sequence[torch.Tensor], outs: Sequence[torch.Tensor], rows: int) -> None:
     """outs[g] += column sums of xs[g] viewed as [rows, N] (bias gradients into the arena)."""
     N = xs[0].numel() // rows
-    for xc, oc in zip(_chunks(list(xs), MAXG), _chunks(list(outs), MAXG)):
+    # a launch adds with one (non-atomic) writer per output element: outputs must be unique within a launch
+    # (shared weights across num_blocks put the same bias slice in several groups) -> greedy batching
+    batches, cur, seen = [], ([], []), set()
+    for xt, ot in zip(xs, outs):
+        if ot.data_ptr() in seen or len(cur[0]) == MAXG:
+            batches.append(cur)
+            cur, seen = ([], []), set()
+        cur[0].append(xt); cur[1].append(ot); seen.add(ot.data_ptr())
+    batches.append(cur)
+    for xc, oc in batches:
         xa = (C.c_void_p * len(xc))(*[L.ptr(t) for t in xc])
         oa = (C.c_void_p * len(oc))(*[L.ptr(t) for t in oc])
         L.check(L.lib().pq3d_colsum_grouped(xa, oa, len(xc), L.dt_of(xc[0]), rows, N, N, 1, L.stream()),
