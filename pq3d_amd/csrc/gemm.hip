@@ -12,6 +12,14 @@
 //   generic    : guarded scalar loads (K = 3 or 5 projections, odd shapes).
 #include "common.h"
 
+#ifdef PQ3D_DEBUG_TIMING
+__device__ long long pq3d_dbg[16];
+#define DBG_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) pq3d_dbg[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pq3d_dbg), sizeof(long long) * 16); }
+#else
+#define DBG_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int BM = 64, BN = 64, NT = 256;
@@ -185,85 +193,131 @@ PQ_DEV void mma_tile(f32x4 (&acc)[2][2], const CT* As, const CT* Bs, int wm, int
   }
 }
 
-// Epilogue.  All global reads it needs (bias, row flags, activation-gradient operand) are gathered into registers
-// FIRST, in straight-line code, so they are issued together and waited for once -- not one round trip per element.
-PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], int g, int z, int m0, int n0, int wm, int wn,
-                     int li, int lg) {
-  void* C = d.C[g];
-  const long offC = (long)z * d.strideC;
-  if (d.splitk > 1) {
+// Epilogue.  The accumulators (MFMA C-layout: 4 consecutive rows x 1 column per lane) are first transposed through
+// LDS (the staging tiles are dead by then) so that every thread owns 16 CONTIGUOUS columns of one row: bias / aux /
+// row-flag reads and the C / C2 stores become a handful of 16-byte vector operations instead of 16 scalar,
+// branch-wrapped element accesses (which cost 14k cycles -- more than the whole K loop -- in the first version).
+constexpr int CLD = BN + 4;  // padded fp32 row of the transposed C tile
+
+template <int NV> PQ_DEV void load_vec(const void* p, int dt, long idx, bool vec_ok, int nvalid, float* v) {
+  if (dt == PQ3D_F32) {
+    const float* q = (const float*)p + idx;
+    if (vec_ok) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < NV; j += 4) { const float4 t = *(const float4*)(q + j); v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w; }
+    } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn + j * 16 + li;
+      for (int j = 0; j < NV; ++j) v[j] = j < nvalid ? q[j] : 0.f;
+    }
+  } else {
+    const bf16_t* q = (const bf16_t*)p + idx;
+    if (vec_ok) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wm + i * 16 + lg * 4 + r;
-          if (row < d.M && col < d.N) unsafeAtomicAdd((float*)C + offC + (long)row * d.ldc + col, acc[i][j][r] * d.alpha);
-        }
+      for (int j = 0; j < NV; j += 8) {
+        const u32x4 t = *(const u32x4*)(q + j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[j + 2 * k] = __uint_as_float(t[k] << 16); v[j + 2 * k + 1] = __uint_as_float(t[k] & 0xffff0000u); }
       }
-    return;
-  }
-  void* C2 = d.C2[g];
-  const void* aux = d.aux[g];
-  const void* bias = d.bias[g];
-  const uint8_t* rmask = d.row_mask[g];
-  float bv[2];
+    } else {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = min(n0 + wn + j * 16 + li, d.N - 1);
-    bv[j] = bias ? load_elem(bias, d.dtBias, col) : 0.f;
+      for (int j = 0; j < NV; ++j) v[j] = j < nvalid ? bf2f(q[j]) : 0.f;
+    }
   }
-  float rs[2][4];      // per-row multiplier (row_mask * row_scale)
-  bool rfill[2][4];
+}
+template <int NV> PQ_DEV void store_vec(void* p, int dt, long idx, bool vec_ok, int nvalid, const float* v) {
+  if (dt == PQ3D_F32) {
+    float* q = (float*)p + idx;
+    if (vec_ok) {
+#pragma unroll
+      for (int j = 0; j < NV; j += 4) *(float4*)(q + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) if (j < nvalid) q[j] = v[j];
+    }
+  } else {
+    bf16_t* q = (bf16_t*)p + idx;
+    if (vec_ok) {
+#pragma unroll
+      for (int j = 0; j < NV; j += 8)
+        *(u32x4*)(q + j) = (u32x4){pack_bf2(v[j], v[j + 1]), pack_bf2(v[j + 2], v[j + 3]), pack_bf2(v[j + 4], v[j + 5]), pack_bf2(v[j + 6], v[j + 7])};
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) if (j < nvalid) q[j] = f2bf(v[j]);
+    }
+  }
+}
+
+PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* Ct, int g, int z, int m0, int n0, int wm,
+                     int wn, int li, int lg, int tid) {
+  // ---- C-layout registers -> LDS [64][CLD] (conflict-free: consecutive lanes hit consecutive banks)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long ri = (long)z * d.M + min(m0 + wm + i * 16 + lg * 4 + r, d.M - 1);
-      float m = 1.f;
-      if (rmask) m = rmask[ri] ? 1.f : 0.f;
-      if (d.row_scale) m *= d.row_scale[ri];
-      rs[i][r] = m;
-      rfill[i][r] = d.row_fill_flag ? d.row_fill_flag[ri] != 0 : false;
-    }
-  float av[2][2][4];
-  if (d.act_grad) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int r = 0; r < 4; ++r) Ct[(wm + i * 16 + lg * 4 + r) * CLD + wn + j * 16 + li] = acc[i][j][r] * d.alpha;
+  __syncthreads();
+  const int lrow = tid >> 2, lcol = (tid & 3) * 16;
+  const int row = m0 + lrow, col = n0 + lcol;
+  if (row >= d.M || col >= d.N) return;
+  const int nvalid = min(16, d.N - col);
+  float v[16];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < 16; j += 4) { const float4 t = *(const float4*)&Ct[lrow * CLD + lcol + j]; v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w; }
+  void* C = d.C[g];
+  const long ci = (long)z * d.strideC + (long)row * d.ldc + col;
+  // vector path: full 16-column segment, 16-byte aligned for the widest participant
+  const bool vec_ok = nvalid == 16 && (d.ldc % 8 == 0) && (d.strideC % 8 == 0) && (col % 8 == 0);
+  if (d.splitk > 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = min(m0 + wm + i * 16 + lg * 4 + r, d.M - 1), col = min(n0 + wn + j * 16 + li, d.N - 1);
-          av[i][j][r] = load_elem(aux, d.dtAux, offC + (long)row * d.ldc + col);
-        }
+    for (int j = 0; j < 16; ++j) if (j < nvalid) unsafeAtomicAdd((float*)C + ci + j, v[j]);
+    return;
   }
-  const bool row_ops = rmask || d.row_scale;
+  if (d.bias[g]) {
+    float bv[16];
+    load_vec<16>(d.bias[g], d.dtBias, col, nvalid == 16 && (col % 8 == 0), nvalid, bv);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 16; ++j) v[j] += bv[j];
+  }
+  if (d.C2[g]) store_vec<16>(d.C2[g], d.dtC2, ci, vec_ok, nvalid, v);
+  if (d.act == PQ3D_ACT_RELU) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn + j * 16 + li;
+    for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
+  } else if (d.act == PQ3D_ACT_GELU) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm + i * 16 + lg * 4 + r;
-        if (row >= d.M || col >= d.N) continue;
-        float v = acc[i][j][r] * d.alpha + bv[j];
-        const long ci = offC + (long)row * d.ldc + col;
-        if (C2) store_elem(C2, d.dtC2, ci, v);
-        if (d.act == PQ3D_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (d.act == PQ3D_ACT_GELU) v = gelu_f(v);
-        if (d.act_grad == PQ3D_ACT_RELU) v = av[i][j][r] > 0.f ? v : 0.f;
-        else if (d.act_grad == PQ3D_ACT_GELU) v *= gelu_grad_f(av[i][j][r]);
-        else if (d.act_grad == PQ3D_ACT_ADD) v += av[i][j][r];
-        if (row_ops) v *= rs[i][r];
-        if (rfill[i][r]) v = d.row_fill;
-        store_elem(C, d.dtC, ci, v);
-        if (d.mask_out) d.mask_out[((long)z * d.N + col) * d.M + row] = (1.f / (1.f + __expf(-v)) < 0.5f) ? 1 : 0;
-      }
+    for (int j = 0; j < 16; ++j) v[j] = gelu_f(v[j]);
+  }
+  if (d.act_grad) {
+    float av[16];
+    load_vec<16>(d.aux[g], d.dtAux, ci, vec_ok, nvalid, av);
+    if (d.act_grad == PQ3D_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = av[j] > 0.f ? v[j] : 0.f;
+    } else if (d.act_grad == PQ3D_ACT_GELU) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] *= gelu_grad_f(av[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] += av[j];
     }
+  }
+  const long ri = (long)z * d.M + row;
+  float rsc = 1.f;
+  if (d.row_mask[g]) rsc = d.row_mask[g][ri] ? 1.f : 0.f;
+  if (d.row_scale) rsc *= d.row_scale[ri];
+  if (d.row_mask[g] || d.row_scale) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] *= rsc;
+  }
+  if (d.row_fill_flag && d.row_fill_flag[ri]) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = d.row_fill;
+  }
+  store_vec<16>(C, d.dtC, ci, vec_ok, nvalid, v);
+  if (d.mask_out) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nvalid) d.mask_out[((long)z * d.N + col + j) * d.M + row] = (1.f / (1.f + __expf(-v[j])) < 0.5f) ? 1 : 0;
   }
 }
 
@@ -271,20 +325,22 @@ struct BlockCoords {
   int g, z, m0, n0, kt0, kt1, ng;
   bool active;
 };
+// grid = (m tiles, n tiles, outputs * batch * splitk): no integer division unless batch > 1 or split-K is used
 template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_gemm_desc& d) {
   typedef Tile<CT> T;
   BlockCoords b;
-  b.ng = d.kconcat > 0 ? d.kconcat : 1;           // groups walked inside the K loop
-  b.g = (blockIdx.z / d.batch) * b.ng;            // first group of this output
-  b.z = blockIdx.z % d.batch;
-  const int tiles_m = (d.M + BM - 1) / BM;
-  b.m0 = (blockIdx.x % tiles_m) * BM;
-  b.n0 = (blockIdx.x / tiles_m) * BN;
+  b.ng = d.kconcat > 0 ? d.kconcat : 1;  // groups walked inside the K loop
+  int zz = blockIdx.z, split = 0;
+  if (d.splitk > 1) { split = zz % d.splitk; zz /= d.splitk; }
+  if (d.batch > 1) { b.z = zz % d.batch; zz /= d.batch; } else b.z = 0;
+  b.g = zz * b.ng;
+  b.m0 = blockIdx.x * BM;
+  b.n0 = blockIdx.y * BN;
   const int nkt = (d.K + T::BKE - 1) / T::BKE;
   b.kt0 = 0; b.kt1 = nkt; b.active = true;
   if (d.splitk > 1) {
     const int per = (nkt + d.splitk - 1) / d.splitk;
-    b.kt0 = blockIdx.y * per;
+    b.kt0 = split * per;
     b.kt1 = min(nkt, b.kt0 + per);
     b.active = b.kt0 < b.kt1;
   }
@@ -296,6 +352,8 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   typedef Tile<CT> T;
   __shared__ __attribute__((aligned(16))) CT As[BM * T::LDK];
   __shared__ __attribute__((aligned(16))) CT Bs[BN * T::LDK];
+  static_assert(sizeof(CT) * (BM + BN) * T::LDK >= sizeof(float) * BM * CLD, "C tile must fit in the staging LDS");
+  DBG_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -310,27 +368,43 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  FastStage<CT, TA, TA2, TRA> sa;
-  FastStage<CT, TB, TB2, TRB> sb;
-  bool hasA2 = false, hasB2 = false;
-  auto load_it = [&](int it) {
-    const int gg = b.g + it / nk;
-    const int kt = b.kt0 + it % nk;
-    hasA2 = d.A2[gg] != nullptr;
-    hasB2 = d.B2[gg] != nullptr;
-    sa.load(d.A[gg], d.A2[gg], offA, d.lda, b.m0, d.M, kt * T::BKE, d.K, tid);
-    sb.load(d.B[gg], d.B2[gg], offB, d.ldb, b.n0, d.N, kt * T::BKE, d.K, tid);
+  // two register stages: tile t+1 and t+2 are in flight while tile t is multiplied
+  FastStage<CT, TA, TA2, TRA> sa0, sa1;
+  FastStage<CT, TB, TB2, TRB> sb0, sb1;
+  bool h0a = false, h0b = false, h1a = false, h1b = false;
+  int lg_ = b.g, lk_ = b.kt0, issued = 0;  // next (group, k-tile) to load
+  auto issue = [&](FastStage<CT, TA, TA2, TRA>& sa, FastStage<CT, TB, TB2, TRB>& sb, bool& ha, bool& hb) {
+    ha = d.A2[lg_] != nullptr;
+    hb = d.B2[lg_] != nullptr;
+    sa.load(d.A[lg_], d.A2[lg_], offA, d.lda, b.m0, d.M, lk_ * T::BKE, d.K, tid);
+    sb.load(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, lk_ * T::BKE, d.K, tid);
+    ++issued;
+    if (++lk_ == b.kt1) { lk_ = b.kt0; ++lg_; }
   };
-  load_it(0);
-  for (int it = 0; it < nit; ++it) {
-    sa.store(As, hasA2, tid);
-    sb.store(Bs, hasB2, tid);
+  issue(sa0, sb0, h0a, h0b);
+  if (nit > 1) issue(sa1, sb1, h1a, h1b);
+  DBG_STAMP(1);
+  for (int it = 0; it < nit; it += 2) {
+    sa0.store(As, h0a, tid);
+    sb0.store(Bs, h0b, tid);
+    if (it == 0) DBG_STAMP(2);
     __syncthreads();
-    if (it + 1 < nit) load_it(it + 1);
+    if (issued < nit) issue(sa0, sb0, h0a, h0b);
     mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
     __syncthreads();
+    if (it == 0) DBG_STAMP(3);
+    if (it + 1 < nit) {
+      sa1.store(As, h1a, tid);
+      sb1.store(Bs, h1b, tid);
+      __syncthreads();
+      if (issued < nit) issue(sa1, sb1, h1a, h1b);
+      mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
+      __syncthreads();
+    }
   }
-  epilogue(d, acc, b.g, b.z, b.m0, b.n0, wm, wn, li, lg);
+  DBG_STAMP(4);
+  epilogue(d, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
+  DBG_STAMP(5);
 }
 
 template <typename CT, bool TRA, bool TRB>
@@ -354,22 +428,22 @@ __global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_gemm_desc d) {
 
   SlowStage<CT, TRA> sa;
   SlowStage<CT, TRB> sb;
-  auto load_it = [&](int it) {
-    const int gg = b.g + it / nk;
-    const int kt = b.kt0 + it % nk;
-    sa.load(d.A[gg], d.A2[gg], d.dtA, d.dtA2, offA, d.lda, b.m0, d.M, kt * T::BKE, d.K, tid);
-    sb.load(d.B[gg], d.B2[gg], d.dtB, d.dtB2, offB, d.ldb, b.n0, d.N, kt * T::BKE, d.K, tid);
+  int lg_ = b.g, lk_ = b.kt0;
+  auto load_next = [&]() {
+    sa.load(d.A[lg_], d.A2[lg_], d.dtA, d.dtA2, offA, d.lda, b.m0, d.M, lk_ * T::BKE, d.K, tid);
+    sb.load(d.B[lg_], d.B2[lg_], d.dtB, d.dtB2, offB, d.ldb, b.n0, d.N, lk_ * T::BKE, d.K, tid);
+    if (++lk_ == b.kt1) { lk_ = b.kt0; ++lg_; }
   };
-  load_it(0);
+  load_next();
   for (int it = 0; it < nit; ++it) {
     sa.store(As, tid);
     sb.store(Bs, tid);
     __syncthreads();
-    if (it + 1 < nit) load_it(it + 1);
+    if (it + 1 < nit) load_next();
     mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
     __syncthreads();
   }
-  epilogue(d, acc, b.g, b.z, b.m0, b.n0, wm, wn, li, lg);
+  epilogue(d, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
 }
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -435,8 +509,7 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
       if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
     }
   }
-  const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-  dim3 grid(tiles, d.splitk, (d.groups / kc) * d.batch);
+  dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (d.groups / kc) * d.batch * d.splitk);
   if (d.ct == PQ3D_BF16) {
     if (fast_ok<bf16_t>(d)) {
       const bool af = d.dtA == PQ3D_F32, bf = d.dtB == PQ3D_F32;
