@@ -267,7 +267,8 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* C
   void* C = d.C[g];
   const long ci = (long)z * d.strideC + (long)row * d.ldc + col;
   // vector path: full 16-column segment, 16-byte aligned for the widest participant
-  const bool vec_ok = nvalid == 16 && (d.ldc % 8 == 0) && (d.strideC % 8 == 0) && (col % 8 == 0);
+  const uintptr_t pbits = (uintptr_t)C | (uintptr_t)d.C2[g] | (uintptr_t)d.aux[g];
+  const bool vec_ok = nvalid == 16 && (d.ldc % 8 == 0) && (d.strideC % 8 == 0) && (col % 8 == 0) && (pbits & 15) == 0;
   if (d.splitk > 1) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) if (j < nvalid) unsafeAtomicAdd((float*)C + ci + j, v[j]);
@@ -275,7 +276,7 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* C
   }
   if (d.bias[g]) {
     float bv[16];
-    load_vec<16>(d.bias[g], d.dtBias, col, nvalid == 16 && (col % 8 == 0), nvalid, bv);
+    load_vec<16>(d.bias[g], d.dtBias, col, nvalid == 16 && (col % 8 == 0) && (((uintptr_t)d.bias[g]) & 15) == 0, nvalid, bv);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] += bv[j];
   }
