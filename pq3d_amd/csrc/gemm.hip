@@ -249,6 +249,23 @@ template <int NV> PQ_DEV void store_vec(void* p, int dt, long idx, bool vec_ok, 
 
 PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* Ct, int g, int z, int m0, int n0, int wm,
                      int wn, int li, int lg, int tid) {
+  if (d.splitk > 1) {
+    // split-K: atomics straight from the C-layout registers -- there the 16 lanes of a group hit 16 CONSECUTIVE
+    // addresses per instruction (the row-per-thread layout below would scatter every atomic over 64 cache lines)
+    float* C = (float*)d.C[g] + (long)z * d.strideC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn + j * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm + i * 16 + lg * 4 + r;
+          if (row < d.M && col < d.N) unsafeAtomicAdd(C + (long)row * d.ldc + col, acc[i][j][r] * d.alpha);
+        }
+      }
+    return;
+  }
   // ---- C-layout registers -> LDS [64][CLD] (conflict-free: consecutive lanes hit consecutive banks)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -269,11 +286,6 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* C
   // vector path: full 16-column segment, 16-byte aligned for the widest participant
   const uintptr_t pbits = (uintptr_t)C | (uintptr_t)d.C2[g] | (uintptr_t)d.aux[g];
   const bool vec_ok = nvalid == 16 && (d.ldc % 8 == 0) && (d.strideC % 8 == 0) && (col % 8 == 0) && (pbits & 15) == 0;
-  if (d.splitk > 1) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) if (j < nvalid) unsafeAtomicAdd((float*)C + ci + j, v[j]);
-    return;
-  }
   if (d.bias[g]) {
     float bv[16];
     load_vec<16>(d.bias[g], d.dtBias, col, nvalid == 16 && (col % 8 == 0) && (((uintptr_t)d.bias[g]) & 15) == 0, nvalid, bv);
