@@ -215,9 +215,9 @@ def test_add_layernorm(d, M, with_x, with_coef):
 
 # ---------------------------------------------------------------------------------------------- misc
 def test_pairwise_locs_and_fourier_and_spatial_bias():
-    c = torch.rand(2, 23, 3) * 4
+    c = torch.rand(2, 23, 3, generator=torch.Generator().manual_seed(11)) * 4
     close(ops.pairwise_locs(c.to(DEV)), O.calc_pairwise_locs(c), F32, "pairwise", atol=2e-6, rtol=2e-6)
-    G = torch.randn(3, 32)
+    G = torch.randn(3, 32, generator=torch.Generator().manual_seed(12))
     cmin, cmax = torch.tensor([[0., 0, 0], [-1, -1, 0]]), torch.tensor([[4., 4, 4], [5, 4, 3]])
     close(ops.fourier(c.to(DEV), cmin.to(DEV), cmax.to(DEV), G.to(DEV)), O.fourier_embed(c, G, cmin, cmax), F32,
           "fourier", atol=2e-5, rtol=0)
@@ -226,8 +226,14 @@ def test_pairwise_locs_and_fourier_and_spatial_bias():
     Wd, bd = W.to(DEV).requires_grad_(True), bw.to(DEV).requires_grad_(True)
     bias = ops.spatial_bias(pl.to(DEV), Wd, bd)
     Wr, br = W.clone().requires_grad_(True), bw.clone().requires_grad_(True)
-    ref = torch.log(torch.clamp(torch.relu(pl @ Wr.t() + br), min=1e-6)).permute(0, 3, 1, 2)
-    close(bias, ref, F32, "spatial bias", atol=1e-5, rtol=1e-5)
+    pre = pl @ Wr.t() + br
+    ref = torch.log(torch.clamp(torch.relu(pre), min=1e-6)).permute(0, 3, 1, 2)
+    # log() next to the relu/clamp corner (0 < v < 1e-3) amplifies the fp32 rounding of v without bound: compare
+    # the well-conditioned points at 1e-5 and the corner points loosely
+    wc = ((pre > 1e-3) | (pre < -1e-3)).permute(0, 3, 1, 2)
+    close(torch.where(wc.to(DEV), bias, torch.zeros_like(bias)), torch.where(wc, ref, torch.zeros_like(ref)), F32,
+          "spatial bias", atol=1e-5, rtol=1e-5)
+    close(bias, ref, F32, "spatial bias (corner points)", atol=5e-3, rtol=0)
     gy = rnd(*ref.shape, seed=4)
     bias.backward(gy.to(DEV))
     ref.backward(gy)
