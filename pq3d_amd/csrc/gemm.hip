@@ -62,6 +62,38 @@ template <> struct Raw<bf16_t, 4> {
 };
 
 // ---- FAST stager: branch-free raw loads, conversion at store time ------------------------------------------
+// Chunk addresses are computed ONCE per (group, block) by Cursor::init and then only advanced by a constant byte
+// stride per K-tile: the per-tile cost is 2-4 vector loads + one 32-bit compare per chunk (the first version redid
+// the 64-bit row*ld multiply-adds for every chunk of every tile, ~1000 cycles per K-tile).
+template <typename CT, typename TS, typename TS2, bool TR>
+struct Cursor {
+  typedef Tile<CT> T;
+  const TS* p[2];
+  const TS2* p2[2];
+  int kofs[2];   // k index of the chunk inside the tile
+  long step, step2;  // elements to advance per K-tile
+  PQ_DEV void init(const void* base, const void* base2, long off, long ld, int r0, int R, int k0, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + it * NT;
+      long idx;
+      if (!TR) {
+        const int row = c / T::CPR, kc = c % T::CPR;
+        kofs[it] = kc * T::EPL;
+        idx = off + (long)min(r0 + row, R - 1) * ld + k0 + kofs[it];
+      } else {
+        constexpr int RC = BM / T::EPL;
+        const int kk = c / RC, rc = c % RC;
+        kofs[it] = kk;
+        idx = off + (long)(k0 + kk) * ld + min(r0 + rc * T::EPL, R - T::EPL);
+      }
+      p[it] = (const TS*)base + idx;
+      p2[it] = base2 ? (const TS2*)base2 + idx : nullptr;
+    }
+    step = TR ? (long)T::BKE * ld : (long)T::BKE;
+  }
+};
+
 template <typename CT, typename TS, typename TS2, bool TR>
 struct FastStage {
   typedef Tile<CT> T;
@@ -69,25 +101,21 @@ struct FastStage {
   Raw<TS2, T::EPL> r2[2];
   bool kvalid[2];
 
-  PQ_DEV void load(const void* base, const void* base2, long off, long ld, int r0, int R, int k0, int K, int tid) {
+  // loads the tile the cursor points at (k0 = its first k index) and advances the cursor by one tile
+  PQ_DEV void load(Cursor<CT, TS, TS2, TR>& cur, int k0, int K) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int c = tid + it * NT;
-      long idx;
-      if (!TR) {
-        const int row = c / T::CPR, kc = c % T::CPR;
-        const int gr = min(r0 + row, R - 1), gk = k0 + kc * T::EPL;
-        kvalid[it] = gk < K;
-        idx = off + (long)gr * ld + (kvalid[it] ? gk : 0);
-      } else {
-        constexpr int RC = BM / T::EPL;
-        const int kk = c / RC, rc = c % RC;
-        const int gk = k0 + kk, gr = min(r0 + rc * T::EPL, R - T::EPL);
-        kvalid[it] = gk < K;
-        idx = off + (long)(kvalid[it] ? gk : 0) * ld + gr;
+      kvalid[it] = k0 + cur.kofs[it] < K;
+      // out-of-range k chunks re-read the (valid) first tile position and are zeroed at store time
+      const long back = kvalid[it] ? 0 : (TR ? (long)(k0 + cur.kofs[it]) : (long)k0 + cur.kofs[it]);
+      const TS* q = kvalid[it] ? cur.p[it] : cur.p[it] - (TR ? back * (cur.step / T::BKE) : back);
+      r[it].load(q);
+      if (cur.p2[it]) {
+        const TS2* q2 = kvalid[it] ? cur.p2[it] : cur.p2[it] - (TR ? back * (cur.step / T::BKE) : back);
+        r2[it].load(q2);
       }
-      r[it].load((const TS*)base + idx);
-      if (base2) r2[it].load((const TS2*)base2 + idx);
+      cur.p[it] += cur.step;
+      if (cur.p2[it]) cur.p2[it] += cur.step;
     }
   }
   PQ_DEV void store(CT* lds, bool has2, int tid) const {
@@ -384,15 +412,23 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   // two register stages: tile t+1 and t+2 are in flight while tile t is multiplied
   FastStage<CT, TA, TA2, TRA> sa0, sa1;
   FastStage<CT, TB, TB2, TRB> sb0, sb1;
+  Cursor<CT, TA, TA2, TRA> ca;
+  Cursor<CT, TB, TB2, TRB> cb;
   bool h0a = false, h0b = false, h1a = false, h1b = false;
   int lg_ = b.g, lk_ = b.kt0, issued = 0;  // next (group, k-tile) to load
+  ca.init(d.A[lg_], d.A2[lg_], offA, d.lda, b.m0, d.M, b.kt0 * T::BKE, tid);
+  cb.init(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
   auto issue = [&](FastStage<CT, TA, TA2, TRA>& sa, FastStage<CT, TB, TB2, TRB>& sb, bool& ha, bool& hb) {
-    ha = d.A2[lg_] != nullptr;
-    hb = d.B2[lg_] != nullptr;
-    sa.load(d.A[lg_], d.A2[lg_], offA, d.lda, b.m0, d.M, lk_ * T::BKE, d.K, tid);
-    sb.load(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, lk_ * T::BKE, d.K, tid);
+    ha = ca.p2[0] != nullptr;
+    hb = cb.p2[0] != nullptr;
+    sa.load(ca, lk_ * T::BKE, d.K);
+    sb.load(cb, lk_ * T::BKE, d.K);
     ++issued;
-    if (++lk_ == b.kt1) { lk_ = b.kt0; ++lg_; }
+    if (++lk_ == b.kt1 && issued < nit) {   // next group of a K-concatenated product
+      lk_ = b.kt0; ++lg_;
+      ca.init(d.A[lg_], d.A2[lg_], offA, d.lda, b.m0, d.M, b.kt0 * T::BKE, tid);
+      cb.init(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
+    }
   };
   issue(sa0, sb0, h0a, h0b);
   if (nit > 1) issue(sa1, sb1, h1a, h1b);

@@ -10,13 +10,14 @@ L.LIB_PATH = out
 lib = L.lib()
 lib.pq3d_debug_read.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 dev = "cuda"
-for (M, N, K) in [(64, 64, 64), (800, 256, 256), (800, 256, 2048)]:
-    A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev) * 0.05; Cc = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    bi = torch.zeros(N, device=dev)
-    for rep in range(3):
-        L.gemm(M=M, N=N, K=K, A=[A], B=[B], bias=[bi], Cs=[Cc], ct=L.BF16, lda=K, ldb=K, ldc=N)
+for (M, N, K, da, db, a2) in [(800, 256, 2048, "f", "f", 0), (800, 256, 2048, "b", "b", 0), (800, 256, 2048, "f", "f", 1), (800, 256, 2048, "b", "f", 0), (64, 64, 2048, "b", "b", 0), (8192, 256, 2048, "b", "b", 0)]:
+    dt = lambda c: torch.float32 if c == "f" else torch.bfloat16
+    A = torch.randn(M, K, device=dev).to(dt(da)); B = (torch.randn(N, K, device=dev) * 0.05).to(dt(db)); Cc = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    A2 = torch.randn(M, K, device=dev) if a2 else None
+    for rep in range(2):
+        L.gemm(M=M, N=N, K=K, A=[A], A2=[A2], B=[B], Cs=[Cc], ct=L.BF16, lda=K, ldb=K, ldc=N)
         torch.cuda.synchronize()
         buf = (ctypes.c_longlong * 16)()
         lib.pq3d_debug_read(buf)
         v = list(buf)[:6]
-        print(M, N, K, "rep", rep, "deltas (cycles @100MHz memtime?):", [v[i + 1] - v[i] for i in range(5)], "total", v[5] - v[0])
+    print(M, N, K, da, db, "A2" if a2 else "--", "deltas:", [v[i + 1] - v[i] for i in range(5)], "per-iter", (v[4] - v[3]) // 31, "total", v[5] - v[0])
