@@ -62,17 +62,21 @@ template <> struct Raw<bf16_t, 4> {
 };
 
 // ---- FAST stager: branch-free raw loads, conversion at store time ------------------------------------------
-// Chunk addresses are computed ONCE per (group, block) by Cursor::init and then only advanced by a constant byte
-// stride per K-tile: the per-tile cost is 2-4 vector loads + one 32-bit compare per chunk (the first version redid
-// the 64-bit row*ld multiply-adds for every chunk of every tile, ~1000 cycles per K-tile).
-template <typename CT, typename TS, typename TS2, bool TR>
+// Chunk addresses are computed once per (group, block) by Cursor::init and then only advanced by a constant stride.
+// HAS2 (optional fp32 addend A2 / B2) is a COMPILE-TIME property of the kernel: with a run-time "is there an
+// addend" branch around its loads the compiler cannot count outstanding loads and drains vmcnt to 0 before every
+// LDS store, which serialises the software pipeline.  Groups without an addend inside a HAS2 launch re-read the
+// primary operand with scale 0.
+template <typename CT, typename TS, bool TR, bool HAS2>
 struct Cursor {
   typedef Tile<CT> T;
   const TS* p[2];
-  const TS2* p2[2];
+  const float* p2[2];
   int kofs[2];   // k index of the chunk inside the tile
-  long step, step2;  // elements to advance per K-tile
+  long step;     // elements to advance per K-tile
+  float scale2;  // 1 if this group has an addend, else 0
   PQ_DEV void init(const void* base, const void* base2, long off, long ld, int r0, int R, int k0, int tid) {
+    scale2 = base2 ? 1.f : 0.f;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int c = tid + it * NT;
@@ -88,60 +92,74 @@ struct Cursor {
         idx = off + (long)(k0 + kk) * ld + min(r0 + rc * T::EPL, R - T::EPL);
       }
       p[it] = (const TS*)base + idx;
-      p2[it] = base2 ? (const TS2*)base2 + idx : nullptr;
+      // no addend for this group: point at fp32-readable memory of the same extent only if the primary is fp32;
+      // otherwise fall back to the primary's base (always mapped; values are multiplied by 0)
+      if (HAS2) p2[it] = base2 ? (const float*)base2 + idx : (const float*)base;
     }
     step = TR ? (long)T::BKE * ld : (long)T::BKE;
+    if (HAS2 && !base2) step2_zero = true; else step2_zero = false;
   }
+  bool step2_zero;
 };
 
-template <typename CT, typename TS, typename TS2, bool TR>
+template <typename CT, typename TS, bool TR, bool HAS2>
 struct FastStage {
   typedef Tile<CT> T;
   Raw<TS, T::EPL> r[2];
-  Raw<TS2, T::EPL> r2[2];
+  Raw<float, T::EPL> r2[2];
   bool kvalid[2];
+  float scale2;
 
   // loads the tile the cursor points at (k0 = its first k index) and advances the cursor by one tile
-  PQ_DEV void load(Cursor<CT, TS, TS2, TR>& cur, int k0, int K) {
+  PQ_DEV void load(Cursor<CT, TS, TR, HAS2>& cur, int k0, int K) {
+    scale2 = cur.scale2;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       kvalid[it] = k0 + cur.kofs[it] < K;
-      // out-of-range k chunks re-read the (valid) first tile position and are zeroed at store time
-      const long back = kvalid[it] ? 0 : (TR ? (long)(k0 + cur.kofs[it]) : (long)k0 + cur.kofs[it]);
-      const TS* q = kvalid[it] ? cur.p[it] : cur.p[it] - (TR ? back * (cur.step / T::BKE) : back);
-      r[it].load(q);
-      if (cur.p2[it]) {
-        const TS2* q2 = kvalid[it] ? cur.p2[it] : cur.p2[it] - (TR ? back * (cur.step / T::BKE) : back);
-        r2[it].load(q2);
-      }
+      // out-of-range k chunks re-read the chunk's position in k-tile 0 (valid) and are zeroed at store time
+      const long back = kvalid[it] ? 0 : (long)(k0 + cur.kofs[it]) * (TR ? cur.step / T::BKE : 1);
+      r[it].load(cur.p[it] - back);
+      if (HAS2) r2[it].load(cur.step2_zero ? cur.p2[it] : cur.p2[it] - back);
       cur.p[it] += cur.step;
-      if (cur.p2[it]) cur.p2[it] += cur.step;
+      if (HAS2 && !cur.step2_zero) cur.p2[it] += cur.step;
     }
   }
-  PQ_DEV void store(CT* lds, bool has2, int tid) const {
+  PQ_DEV void store(CT* lds, int tid) const {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int c = tid + it * NT;
-      float v[T::EPL];
-      r[it].to_float(v);
-      if (has2) {
-        float w[T::EPL];
-        r2[it].to_float(w);
+      u32x4 packed;
+      if constexpr (!HAS2 && sizeof(TS) == sizeof(CT)) {
+        packed = __builtin_bit_cast(u32x4, r[it]);   // source already in compute type: straight through
+        if (!kvalid[it]) packed = (u32x4){0, 0, 0, 0};
+      } else {
+        float v[T::EPL];
+        r[it].to_float(v);
+        if (HAS2) {
+          float w[T::EPL];
+          r2[it].to_float(w);
 #pragma unroll
-        for (int j = 0; j < T::EPL; ++j) v[j] += w[j];
-      }
-      if (!kvalid[it]) {
+          for (int j = 0; j < T::EPL; ++j) v[j] += scale2 * w[j];
+        }
+        if (!kvalid[it]) {
 #pragma unroll
-        for (int j = 0; j < T::EPL; ++j) v[j] = 0.f;
+          for (int j = 0; j < T::EPL; ++j) v[j] = 0.f;
+        }
+        packed = pack_frag<CT>(v);
       }
       if (!TR) {
         const int row = c / T::CPR, kc = c % T::CPR;
-        *(u32x4*)&lds[row * T::LDK + kc * T::EPL] = pack_frag<CT>(v);
+        *(u32x4*)&lds[row * T::LDK + kc * T::EPL] = packed;
       } else {
         constexpr int RC = BM / T::EPL;
         const int kk = c / RC, rc = c % RC;
 #pragma unroll
-        for (int j = 0; j < T::EPL; ++j) lds[(rc * T::EPL + j) * T::LDK + kk] = Cvt<CT>::from(v[j]);
+        for (int j = 0; j < T::EPL; ++j) {
+          if constexpr (sizeof(CT) == 2)
+            lds[(rc * T::EPL + j) * T::LDK + kk] = (CT)((packed[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+          else
+            lds[(rc * T::EPL + j) * T::LDK + kk] = __uint_as_float(packed[j]);
+        }
       }
     }
   }
@@ -388,7 +406,7 @@ template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_gemm_desc& d) 
   return b;
 }
 
-template <typename CT, typename TA, typename TA2, typename TB, typename TB2, bool TRA, bool TRB>
+template <typename CT, typename TA, typename TB, bool TRA, bool TRB, bool HA2, bool HB2>
 __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   typedef Tile<CT> T;
   __shared__ __attribute__((aligned(16))) CT As[BM * T::LDK];
@@ -410,17 +428,14 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // two register stages: tile t+1 and t+2 are in flight while tile t is multiplied
-  FastStage<CT, TA, TA2, TRA> sa0, sa1;
-  FastStage<CT, TB, TB2, TRB> sb0, sb1;
-  Cursor<CT, TA, TA2, TRA> ca;
-  Cursor<CT, TB, TB2, TRB> cb;
-  bool h0a = false, h0b = false, h1a = false, h1b = false;
+  FastStage<CT, TA, TRA, HA2> sa0, sa1;
+  FastStage<CT, TB, TRB, HB2> sb0, sb1;
+  Cursor<CT, TA, TRA, HA2> ca;
+  Cursor<CT, TB, TRB, HB2> cb;
   int lg_ = b.g, lk_ = b.kt0, issued = 0;  // next (group, k-tile) to load
   ca.init(d.A[lg_], d.A2[lg_], offA, d.lda, b.m0, d.M, b.kt0 * T::BKE, tid);
   cb.init(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
-  auto issue = [&](FastStage<CT, TA, TA2, TRA>& sa, FastStage<CT, TB, TB2, TRB>& sb, bool& ha, bool& hb) {
-    ha = ca.p2[0] != nullptr;
-    hb = cb.p2[0] != nullptr;
+  auto issue = [&](FastStage<CT, TA, TRA, HA2>& sa, FastStage<CT, TB, TRB, HB2>& sb) {
     sa.load(ca, lk_ * T::BKE, d.K);
     sb.load(cb, lk_ * T::BKE, d.K);
     ++issued;
@@ -430,23 +445,23 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
       cb.init(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
     }
   };
-  issue(sa0, sb0, h0a, h0b);
-  if (nit > 1) issue(sa1, sb1, h1a, h1b);
+  issue(sa0, sb0);
+  if (nit > 1) issue(sa1, sb1);
   DBG_STAMP(1);
   for (int it = 0; it < nit; it += 2) {
-    sa0.store(As, h0a, tid);
-    sb0.store(Bs, h0b, tid);
+    sa0.store(As, tid);
+    sb0.store(Bs, tid);
     if (it == 0) DBG_STAMP(2);
     __syncthreads();
-    if (issued < nit) issue(sa0, sb0, h0a, h0b);
+    if (issued < nit) issue(sa0, sb0);
     mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
     __syncthreads();
     if (it == 0) DBG_STAMP(3);
     if (it + 1 < nit) {
-      sa1.store(As, h1a, tid);
-      sb1.store(Bs, h1b, tid);
+      sa1.store(As, tid);
+      sb1.store(Bs, tid);
       __syncthreads();
-      if (issued < nit) issue(sa1, sb1, h1a, h1b);
+      if (issued < nit) issue(sa1, sb1);
       mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
       __syncthreads();
     }
@@ -497,9 +512,10 @@ __global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_gemm_desc d) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// Can every group use unconditional 16-byte loads?
-template <typename CT> bool fast_ok(const pq3d_gemm_desc& d) {
+// Can every group use unconditional 16-byte loads?  Addends must be fp32 and accompany an fp32 primary operand.
+template <typename CT> bool fast_ok(const pq3d_gemm_desc& d, bool& a2, bool& b2) {
   constexpr int EPL = Mma<CT>::EPL;
+  a2 = b2 = false;
   if (d.transA && !d.transB) return false;
   if (d.lda % EPL || d.ldb % EPL || d.strideA % EPL || d.strideB % EPL) return false;
   if ((!d.transA || !d.transB) && (d.K % EPL)) return false;
@@ -507,20 +523,28 @@ template <typename CT> bool fast_ok(const pq3d_gemm_desc& d) {
   if (d.transB && (d.N % EPL || d.N < EPL)) return false;
   for (int g = 0; g < d.groups; ++g) {
     if (!aligned16(d.A[g]) || !aligned16(d.B[g])) return false;
-    if (d.A2[g] && (!aligned16(d.A2[g]) || d.dtA2 != PQ3D_F32)) return false;
-    if (d.B2[g] && (!aligned16(d.B2[g]) || d.dtB2 != PQ3D_F32)) return false;
+    if (d.A2[g]) { a2 = true; if (!aligned16(d.A2[g]) || d.dtA2 != PQ3D_F32 || d.dtA != PQ3D_F32) return false; }
+    if (d.B2[g]) { b2 = true; if (!aligned16(d.B2[g]) || d.dtB2 != PQ3D_F32 || d.dtB != PQ3D_F32) return false; }
   }
+  if (a2 && b2) return false;
+  if (a2 && (d.transA || d.transB)) return false;    // A2 only occurs in forward projections (NT)
+  if (b2 && !(d.transA && d.transB)) return false;   // B2 only in weight-gradient GEMMs (TT)
   return true;
 }
 
 #define LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(NT), 0, s, d)
 
 template <typename CT, typename TA, typename TB>
-void launch_fast_layout(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s) {
-  // optional addends A2 / B2 are always fp32 on the fast path (residual-stream position encodings)
-  if (!d.transA && !d.transB) LAUNCH(gemm_fast_kernel<CT, TA, float, TB, float, false, false>);
-  else if (!d.transA && d.transB) LAUNCH(gemm_fast_kernel<CT, TA, float, TB, float, false, true>);
-  else LAUNCH(gemm_fast_kernel<CT, TA, float, TB, float, true, true>);
+void launch_fast_layout(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s, bool a2, bool b2) {
+  if (!d.transA && !d.transB) {
+    if constexpr (sizeof(TA) == 4) { if (a2) { LAUNCH(gemm_fast_kernel<CT, TA, TB, false, false, true, false>); return; } }
+    LAUNCH(gemm_fast_kernel<CT, TA, TB, false, false, false, false>);
+  } else if (!d.transA && d.transB) {
+    LAUNCH(gemm_fast_kernel<CT, TA, TB, false, true, false, false>);
+  } else {
+    if constexpr (sizeof(TB) == 4) { if (b2) { LAUNCH(gemm_fast_kernel<CT, TA, TB, true, true, false, true>); return; } }
+    LAUNCH(gemm_fast_kernel<CT, TA, TB, true, true, false, false>);
+  }
 }
 
 template <typename CT> void launch_slow(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s) {
@@ -559,18 +583,20 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
     }
   }
   dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (d.groups / kc) * d.batch * d.splitk);
+  bool a2 = false, b2 = false;
   if (d.ct == PQ3D_BF16) {
-    if (fast_ok<bf16_t>(d)) {
+    if (fast_ok<bf16_t>(d, a2, b2)) {
       const bool af = d.dtA == PQ3D_F32, bf = d.dtB == PQ3D_F32;
-      if (af && bf) launch_fast_layout<bf16_t, float, float>(d, grid, s);
-      else if (af && !bf) launch_fast_layout<bf16_t, float, bf16_t>(d, grid, s);
-      else if (!af && bf) launch_fast_layout<bf16_t, bf16_t, float>(d, grid, s);
-      else launch_fast_layout<bf16_t, bf16_t, bf16_t>(d, grid, s);
+      if (af && bf) launch_fast_layout<bf16_t, float, float>(d, grid, s, a2, b2);
+      else if (af && !bf) launch_fast_layout<bf16_t, float, bf16_t>(d, grid, s, a2, b2);
+      else if (!af && bf) launch_fast_layout<bf16_t, bf16_t, float>(d, grid, s, a2, b2);
+      else launch_fast_layout<bf16_t, bf16_t, bf16_t>(d, grid, s, a2, b2);
     } else {
       launch_slow<bf16_t>(d, grid, s);
     }
   } else {
-    if (fast_ok<float>(d) && d.dtA == PQ3D_F32 && d.dtB == PQ3D_F32) launch_fast_layout<float, float, float>(d, grid, s);
+    if (fast_ok<float>(d, a2, b2) && d.dtA == PQ3D_F32 && d.dtB == PQ3D_F32)
+      launch_fast_layout<float, float, float>(d, grid, s, a2, b2);
     else launch_slow<float>(d, grid, s);
   }
   PQ_LAUNCH_CHECK();
