@@ -9,6 +9,16 @@
 // additive bias [B,H,Lq,Lk], optional zero key (add_zero_attn) folded in as the initial state m=0, l=1.
 #include "common.h"
 
+#ifdef PQ3D_DEBUG_TIMING
+__device__ long long pq3d_adbg[16];
+#define ADBG(i, v) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) pq3d_adbg[i] = (v); } while (0)
+#define ANOW() __builtin_readcyclecounter()
+extern "C" int pq3d_attn_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pq3d_adbg), sizeof(long long) * 16); }
+#else
+#define ADBG(i, v)
+#define ANOW() 0ll
+#endif
+
 namespace {
 
 constexpr int KB = 64;  // keys per main-loop iteration (fwd, dQ)
@@ -124,13 +134,57 @@ template <typename CT, int DH> PQ_DEV void zero_lds(CT* p, int n, int tid, int n
   for (int i = tid; i < n; i += nthreads) p[i] = Cvt<CT>::from(0.f);
 }
 
+// Mask / bias fetch for the swapped layout (lane = query li; its keys in tile t are 4*lg + r, r = 0..3): everything
+// that depends on WHETHER a mask or bias exists is a uniform branch around a block of loads (issued together), the
+// per-element work is pure ALU.  Key-padding and 3-D mask bytes travel as one 32-bit word per (lane, tile).
+struct MaskBias {
+  uint32_t mw[4];     // byte r of mw[t] != 0  -> key (t, r) masked for this lane's query
+  float bb[4][4];     // additive bias
+};
+PQ_DEV void fetch_mask_bias(MaskBias& mb, const pq3d_attn_desc& d, const uint8_t* kpm_s, int b, int bm, int h, int myq,
+                            bool qvalid, bool ro, int k0, int lg) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) mb.mw[t] = *(const uint32_t*)&kpm_s[t * 16 + 4 * lg];
+  if (d.mask) {
+    const bool use = qvalid && !ro;
+    const uint8_t* mr = d.mask + ((long)bm * d.Lq + min(myq, d.Lq - 1)) * d.Lk;
+    const bool vec = (d.Lk & 3) == 0 && ((((uintptr_t)d.mask) & 3) == 0);
+    uint32_t w[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int gk0 = k0 + t * 16 + 4 * lg;
+      if (vec) {
+        w[t] = *(const uint32_t*)(mr + min(gk0, d.Lk - 4));
+      } else {
+        w[t] = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[t] |= (uint32_t)mr[min(gk0 + r, d.Lk - 1)] << (8 * r);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) mb.mw[t] |= use ? w[t] : 0u;   // keys >= Lk are already masked through kpm_s
+  }
+  if (d.bias) {
+    const float* br = d.bias + (((long)b * d.H + h) * d.Lq + min(myq, d.Lq - 1)) * d.Lk;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mb.bb[t][r] = br[min(k0 + t * 16 + 4 * lg + r, d.Lk - 1)];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mb.bb[t][r] = 0.f;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <typename CT, int DH, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
   __shared__ __attribute__((aligned(16))) CT Vt[DH * A::LDT];
-  __shared__ uint8_t kpm_s[KB];
+  __shared__ __attribute__((aligned(4))) uint8_t kpm_s[KB];
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -151,8 +205,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
 
   const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
   const bool ro = (qvalid && d.row_open) ? d.row_open[(long)bm * d.Lq + myq] != 0 : false;
-  const uint8_t* mrow = (d.mask && qvalid && !ro) ? d.mask + ((long)bm * d.Lq + myq) * d.Lk : nullptr;
-  const float* brow = (d.bias && qvalid) ? d.bias + (((long)b * d.H + h) * d.Lq + myq) * d.Lk : nullptr;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
 
   TileRegs<CT, DH, KB, nthreads> kr, vr;
@@ -163,18 +215,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
     if (tid < KB) kpm_r = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
   };
   if (d.Lk > 0) prefetch(0);
+  long long t_start = ANOW(), t_stage = 0, t_s = 0, t_sm = 0, t_pv = 0, t0 = 0;
+  (void)t_start; (void)t0;
 
   for (int k0 = 0; k0 < d.Lk; k0 += KB) {
+    t0 = ANOW();
     __syncthreads();
     kr.store(Ks, nullptr, 0, tid);
     vr.store(nullptr, Vt, A::LDT, tid);
     if (tid < KB) kpm_s[tid] = kpm_r;
     __syncthreads();
     if (k0 + KB < d.Lk) prefetch(k0 + KB);
+    t_stage += ANOW() - t0; t0 = ANOW();
     if (!wave_active) continue;
 
     float p[4][4];
     float mx = -INFINITY;
+    MaskBias mb;
+    fetch_mask_bias(mb, d, kpm_s, b, bm, h, myq, qvalid, ro, k0, lg);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -182,15 +240,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
       for (int st = 0; st < A::NS; ++st) Mma<CT>::mma(s, rfrag<CT>(&Ks[(t * 16 + li) * A::LDR], st, lg), qf[st]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = t * 16 + 4 * lg + r, gk = k0 + key;
-        float x = s[r] * d.scale;
-        if (brow && gk < d.Lk) x += brow[gk];
-        const bool masked = kpm_s[key] || (mrow && gk < d.Lk && mrow[gk]);
-        x = masked ? -INFINITY : x;
+        const float x = ((mb.mw[t] >> (8 * r)) & 0xffu) ? -INFINITY : s[r] * d.scale + mb.bb[t][r];
         p[t][r] = x;
         mx = fmaxf(mx, x);
       }
     }
+    t_s += ANOW() - t0; t0 = ANOW();
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
@@ -209,6 +264,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
     m = m_new;
     u32x4 pf[PackP<CT, 4>::STEPS];
     PackP<CT, 4>::run(p, pf);
+    t_sm += ANOW() - t0; t0 = ANOW();
 #pragma unroll
     for (int mt = 0; mt < A::MT; ++mt) {
       acc[mt] *= alpha;
@@ -216,7 +272,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
       for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
         Mma<CT>::mma(acc[mt], tfrag<CT>(&Vt[(mt * 16 + li) * A::LDT], u, lg), pf[u]);
     }
+    t_pv += ANOW() - t0;
   }
+  ADBG(0, t_stage); ADBG(1, t_s); ADBG(2, t_sm); ADBG(3, t_pv); ADBG(4, ANOW() - t_start);
 
   if (qvalid) {
     const float inv = 1.f / l;
@@ -266,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
   __shared__ __attribute__((aligned(16))) CT Vs[KB * A::LDR];
   __shared__ __attribute__((aligned(16))) CT Kt[DH * A::LDT];
-  __shared__ uint8_t kpm_s[KB];
+  __shared__ __attribute__((aligned(4))) uint8_t kpm_s[KB];
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -293,9 +351,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
 
   const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
   const bool ro = (qvalid && d.row_open) ? d.row_open[(long)bm * d.Lq + myq] != 0 : false;
-  const uint8_t* mrow = (d.mask && qvalid && !ro) ? d.mask + ((long)bm * d.Lq + myq) * d.Lk : nullptr;
-  const float* brow = (d.bias && qvalid) ? d.bias + sidx * d.Lk : nullptr;
-  float* dbrow = (d.dbias && qvalid) ? d.dbias + sidx * d.Lk : nullptr;
+  float* dbrow = d.dbias ? d.dbias + (((long)b * d.H + h) * d.Lq + min(myq, d.Lq - 1)) * d.Lk : nullptr;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
 
   TileRegs<CT, DH, KB, nthreads> kr, vr;
@@ -317,6 +373,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
     if (!wave_active) continue;
 
     float ds[4][4];
+    MaskBias mb;
+    fetch_mask_bias(mb, d, kpm_s, b, bm, h, myq, qvalid, ro, k0, lg);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -327,16 +385,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = t * 16 + 4 * lg + r, gk = k0 + key;
-        float x = s[r] * d.scale;
-        if (brow && gk < d.Lk) x += brow[gk];
-        const bool masked = kpm_s[key] || (mrow && gk < d.Lk && mrow[gk]);
-        const float pr = masked ? 0.f : fexp<CT>(x - L);
+        const bool masked = ((mb.mw[t] >> (8 * r)) & 0xffu) != 0;
+        const float pr = masked ? 0.f : fexp<CT>(s[r] * d.scale + mb.bb[t][r] - L);
         const float g = pr * (dp[r] - Dl);
-        if (dbrow && gk < d.Lk) dbrow[gk] = g;
-        ds[t][r] = g * d.scale;
+        ds[t][r] = g;
       }
     }
+    if (dbrow && qvalid) {   // uniform on dbias; 4 consecutive keys per (lane, tile)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gk = k0 + t * 16 + 4 * lg + r;
+          if (gk < d.Lk) dbrow[gk] = ds[t][r];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[t][r] *= d.scale;
     u32x4 dsf[PackP<CT, 4>::STEPS];
     PackP<CT, 4>::run(ds, dsf);
 #pragma unroll
@@ -416,6 +483,29 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
     if (qb + QB < d.Lq) prefetch(qb + QB);
 
     float pt[2][4], dst[2][4];
+    // mask / bias for this lane's key against the 8 queries (t, r) it sees: uniform branches around grouped loads
+    bool mk[2][4];
+    float bb[2][4];
+    const int ckey = min(key, d.Lk - 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { mk[t][r] = kmasked; bb[t][r] = 0.f; }
+    if (d.mask) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = t * 16 + 4 * lg + r, gq = min(qb + ql, d.Lq - 1);
+          mk[t][r] |= (!ro_s[ql]) && (d.mask[((long)bm * d.Lq + gq) * d.Lk + ckey] != 0);
+        }
+    }
+    if (d.bias) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bb[t][r] = d.bias[(sbase + min(qb + t * 16 + 4 * lg + r, d.Lq - 1)) * d.Lk + ckey];
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -426,12 +516,8 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ql = t * 16 + 4 * lg + r, gq = qb + ql;
-        const bool inb = gq < d.Lq && kvalid;
-        float x = s[r] * d.scale;
-        if (d.bias && inb) x += d.bias[(sbase + gq) * d.Lk + key];
-        const bool masked = kmasked || (d.mask && inb && !ro_s[ql] && d.mask[((long)bm * d.Lq + gq) * d.Lk + key]);
-        const float pr = masked ? 0.f : fexp<CT>(x - Ls[ql]);
+        const int ql = t * 16 + 4 * lg + r;
+        const float pr = mk[t][r] ? 0.f : fexp<CT>(s[r] * d.scale + bb[t][r] - Ls[ql]);   // Ls = +inf past Lq
         pt[t][r] = pr;
         dst[t][r] = pr * (dp[r] - Ds[ql]) * d.scale;
       }
