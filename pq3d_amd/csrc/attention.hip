@@ -56,6 +56,27 @@ template <> PQ_DEV u32x4 tfrag<bf16_t>(const bf16_t* row, int step, int g) {
 template <> PQ_DEV u32x4 tfrag<float>(const float* row, int step, int g) {
   return *(const u32x4*)&row[step * 16 + 4 * g];
 }
+// bf16 only: the same fragment straight from a ROW-MAJOR tile (row = k index, e.g. key; column = the 16-wide output
+// chunk col0) through the gfx950 hardware transposing LDS read.  Measured semantics (tools/probes/tr_probe.hip):
+// a lane (i, g) pointing at row base + i/4, columns 4*(i%4).. receives tile[base + j][i], j = 0..3.  Two reads
+// give the 8 k-slots {4g+j} and {16+4g+j} of step `row0/32`, so transposed LDS copies (2-byte scattered stores
+// with 8-way bank conflicts) are not needed at all.
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
+PQ_DEV u32x4 tfrag_tr(const bf16_t* tile, int ldr, int row0, int col0, int li, int lg) {
+  const bf16_t* p0 = tile + (row0 + 4 * lg + (li >> 2)) * ldr + col0 + 4 * (li & 3);
+  const v4i16_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)p0);
+  const v4i16_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(p0 + 16 * ldr));
+  const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
+  return (u32x4){lo.x, lo.y, hi.x, hi.y};
+}
+// A fragment of the transposed operand for step u, output chunk mt: bf16 -> tr read of the row-major tile `rm`
+// (row stride ldr); f32 -> plain read of the transposed copy `tr` (row stride ldt).
+template <typename CT> PQ_DEV u32x4 tfrag_any(const CT* rm, int ldr, const CT* tr, int ldt, int u, int mt, int li, int lg) {
+  if constexpr (sizeof(CT) == 2) return tfrag_tr((const bf16_t*)rm, ldr, u * 32, mt * 16, li, lg);
+  else return tfrag<CT>(&tr[(mt * 16 + li) * ldt], u, lg);
+}
+
 // C-layout tiles (lane: rows 4g+r of tile t, column i) -> B fragments whose k index = tile rows.
 template <typename CT, int NTILES> struct PackP;
 template <int NTILES> struct PackP<bf16_t, NTILES> {
@@ -182,8 +203,10 @@ PQ_DEV void fetch_mask_bias(MaskBias& mb, const pq3d_attn_desc& d, const uint8_t
 template <typename CT, int DH, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
+  constexpr bool TRR = sizeof(CT) == 2;  // bf16: row-major V + transposing reads; f32: transposed LDS copy
   __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
-  __shared__ __attribute__((aligned(16))) CT Vt[DH * A::LDT];
+  __shared__ __attribute__((aligned(16))) CT Vs[TRR ? KB * A::LDR : 8];
+  __shared__ __attribute__((aligned(16))) CT Vt[TRR ? 8 : DH * A::LDT];
   __shared__ __attribute__((aligned(4))) uint8_t kpm_s[KB];
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -222,7 +245,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
     t0 = ANOW();
     __syncthreads();
     kr.store(Ks, nullptr, 0, tid);
-    vr.store(nullptr, Vt, A::LDT, tid);
+    if (TRR) vr.store(Vs, nullptr, 0, tid);
+    else vr.store(nullptr, Vt, A::LDT, tid);
     if (tid < KB) kpm_s[tid] = kpm_r;
     __syncthreads();
     if (k0 + KB < d.Lk) prefetch(k0 + KB);
@@ -270,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
       acc[mt] *= alpha;
 #pragma unroll
       for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
-        Mma<CT>::mma(acc[mt], tfrag<CT>(&Vt[(mt * 16 + li) * A::LDT], u, lg), pf[u]);
+        Mma<CT>::mma(acc[mt], tfrag_any<CT>(Vs, A::LDR, Vt, A::LDT, u, mt, li, lg), pf[u]);
     }
     t_pv += ANOW() - t0;
   }
@@ -321,9 +345,10 @@ __global__ void attn_delta_kernel(const pq3d_attn_desc d) {
 template <typename CT, int DH, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
+  constexpr bool TRR = sizeof(CT) == 2;
   __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
   __shared__ __attribute__((aligned(16))) CT Vs[KB * A::LDR];
-  __shared__ __attribute__((aligned(16))) CT Kt[DH * A::LDT];
+  __shared__ __attribute__((aligned(16))) CT Kt[TRR ? 8 : DH * A::LDT];
   __shared__ __attribute__((aligned(4))) uint8_t kpm_s[KB];
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -365,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
 
   for (int k0 = 0; k0 < d.Lk; k0 += KB) {
     __syncthreads();
-    kr.store(Ks, Kt, A::LDT, tid);
+    kr.store(Ks, TRR ? nullptr : Kt, A::LDT, tid);
     vr.store(Vs, nullptr, 0, tid);
     if (tid < KB) kpm_s[tid] = kpm_r;
     __syncthreads();
@@ -410,7 +435,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
     for (int mt = 0; mt < A::MT; ++mt)
 #pragma unroll
       for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
-        Mma<CT>::mma(acc[mt], tfrag<CT>(&Kt[(mt * 16 + li) * A::LDT], u, lg), dsf[u]);
+        Mma<CT>::mma(acc[mt], tfrag_any<CT>(Ks, A::LDR, Kt, A::LDT, u, mt, li, lg), dsf[u]);
   }
 
   if (qvalid) {
@@ -426,10 +451,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
 template <typename CT, int DH>
 __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
+  constexpr bool TRR = sizeof(CT) == 2;
   __shared__ __attribute__((aligned(16))) CT Qs[QB * A::LDR];
   __shared__ __attribute__((aligned(16))) CT dOs[QB * A::LDR];
-  __shared__ __attribute__((aligned(16))) CT Qt[DH * A::LDQ];
-  __shared__ __attribute__((aligned(16))) CT dOt[DH * A::LDQ];
+  __shared__ __attribute__((aligned(16))) CT Qt[TRR ? 8 : DH * A::LDQ];
+  __shared__ __attribute__((aligned(16))) CT dOt[TRR ? 8 : DH * A::LDQ];
   __shared__ float Ls[QB], Ds[QB];
   __shared__ uint8_t ro_s[QB];
   constexpr int nthreads = NWK * 64;
@@ -476,8 +502,8 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
 
   for (int qb = 0; qb < d.Lq; qb += QB) {
     __syncthreads();
-    qr.store(Qs, Qt, A::LDQ, tid);
-    dor.store(dOs, dOt, A::LDQ, tid);
+    qr.store(Qs, TRR ? nullptr : Qt, A::LDQ, tid);
+    dor.store(dOs, TRR ? nullptr : dOt, A::LDQ, tid);
     if (tid < QB) { Ls[tid] = l_r; Ds[tid] = d_r; ro_s[tid] = ro_r; }
     __syncthreads();
     if (qb + QB < d.Lq) prefetch(qb + QB);
@@ -529,8 +555,8 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
     for (int mt = 0; mt < A::MT; ++mt)
 #pragma unroll
       for (int u = 0; u < PackP<CT, 2>::STEPS; ++u) {
-        Mma<CT>::mma(accV[mt], tfrag<CT>(&dOt[(mt * 16 + li) * A::LDQ], u, lg), pf[u]);
-        Mma<CT>::mma(accK[mt], tfrag<CT>(&Qt[(mt * 16 + li) * A::LDQ], u, lg), dsf[u]);
+        Mma<CT>::mma(accV[mt], tfrag_any<CT>(dOs, A::LDR, dOt, A::LDQ, u, mt, li, lg), pf[u]);
+        Mma<CT>::mma(accK[mt], tfrag_any<CT>(Qs, A::LDR, Qt, A::LDQ, u, mt, li, lg), dsf[u]);
       }
   }
 
