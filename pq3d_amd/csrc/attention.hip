@@ -155,6 +155,32 @@ template <typename CT, int DH> PQ_DEV void zero_lds(CT* p, int n, int tid, int n
   for (int i = tid; i < n; i += nthreads) p[i] = Cvt<CT>::from(0.f);
 }
 
+// Software pipeline shared by the three attention kernels: LDS double buffering (ONE barrier per tile) and two
+// register sets, so the global loads of tile t+3 are issued while tile t is being multiplied and are only waited for
+// two iterations later.  load(tile, set) issues loads into register set `set`; store(set, buf) writes that set to LDS
+// buffer `buf`; compute(tile, buf) consumes a buffer.  `set` / `buf` arrive as integral constants so every register
+// array index is static.
+template <int V> struct IC { static constexpr int value = V; };
+template <typename LoadF, typename StoreF, typename ComputeF>
+PQ_DEV void pipeline2(int n, LoadF load, StoreF store, ComputeF compute) {
+  if (n <= 0) return;
+  load(0, IC<0>{});
+  if (n > 1) load(1, IC<1>{});
+  store(IC<0>{}, IC<0>{});
+  if (n > 2) load(2, IC<0>{});
+  __syncthreads();
+  for (int t = 0; t < n; t += 2) {
+    compute(t, IC<0>{});
+    if (t + 1 < n) { store(IC<1>{}, IC<1>{}); if (t + 3 < n) load(t + 3, IC<1>{}); }
+    __syncthreads();
+    if (t + 1 < n) {
+      compute(t + 1, IC<1>{});
+      if (t + 2 < n) { store(IC<0>{}, IC<0>{}); if (t + 4 < n) load(t + 4, IC<0>{}); }
+      __syncthreads();
+    }
+  }
+}
+
 // Mask / bias fetch for the swapped layout (lane = query li; its keys in tile t are 4*lg + r, r = 0..3): everything
 // that depends on WHETHER a mask or bias exists is a uniform branch around a block of loads (issued together), the
 // per-element work is pure ALU.  Key-padding and 3-D mask bytes travel as one 32-bit word per (lane, tile).
@@ -204,10 +230,10 @@ template <typename CT, int DH, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;  // bf16: row-major V + transposing reads; f32: transposed LDS copy
-  __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
-  __shared__ __attribute__((aligned(16))) CT Vs[TRR ? KB * A::LDR : 8];
-  __shared__ __attribute__((aligned(16))) CT Vt[TRR ? 8 : DH * A::LDT];
-  __shared__ __attribute__((aligned(4))) uint8_t kpm_s[KB];
+  constexpr int KSZ = KB * A::LDR, VSZ = TRR ? KB * A::LDR : DH * A::LDT;
+  __shared__ __attribute__((aligned(16))) CT Kbuf[2 * KSZ];
+  __shared__ __attribute__((aligned(16))) CT Vbuf[2 * VSZ];
+  __shared__ __attribute__((aligned(4))) uint8_t kpm_buf[2 * KB];
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -216,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
   const int myq = q0 + li;
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
 
-  if (A::DHK > DH) zero_lds<CT, DH>(Ks, KB * A::LDR, tid, nthreads);
+  if (A::DHK > DH) { zero_lds<CT, DH>(Kbuf, 2 * KSZ, tid, nthreads); __syncthreads(); }
 
   u32x4 qf[A::NS];
   row_frags<CT, DH>(qf, d.q, (long)b * d.q_sb + (long)min(myq, d.Lq - 1) * d.q_sl + (long)h * d.q_sh, lg);
@@ -230,57 +256,55 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
   const bool ro = (qvalid && d.row_open) ? d.row_open[(long)bm * d.Lq + myq] != 0 : false;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
 
-  TileRegs<CT, DH, KB, nthreads> kr, vr;
-  uint8_t kpm_r = 1;
-  auto prefetch = [&](int k0) {
-    kr.load(d.k, koff, d.k_sl, k0, d.Lk, tid);
-    vr.load(d.v, voff, d.v_sl, k0, d.Lk, tid);
-    if (tid < KB) kpm_r = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+  TileRegs<CT, DH, KB, nthreads> kr[2], vr[2];
+  uint8_t kpm_r[2] = {1, 1};
+  auto load = [&](int t, auto set) {
+    constexpr int S = decltype(set)::value;
+    const int k0 = t * KB;
+    kr[S].load(d.k, koff, d.k_sl, k0, d.Lk, tid);
+    vr[S].load(d.v, voff, d.v_sl, k0, d.Lk, tid);
+    if (tid < KB) kpm_r[S] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
   };
-  if (d.Lk > 0) prefetch(0);
-  long long t_start = ANOW(), t_stage = 0, t_s = 0, t_sm = 0, t_pv = 0, t0 = 0;
-  (void)t_start; (void)t0;
-
-  for (int k0 = 0; k0 < d.Lk; k0 += KB) {
-    t0 = ANOW();
-    __syncthreads();
-    kr.store(Ks, nullptr, 0, tid);
-    if (TRR) vr.store(Vs, nullptr, 0, tid);
-    else vr.store(nullptr, Vt, A::LDT, tid);
-    if (tid < KB) kpm_s[tid] = kpm_r;
-    __syncthreads();
-    if (k0 + KB < d.Lk) prefetch(k0 + KB);
-    t_stage += ANOW() - t0; t0 = ANOW();
-    if (!wave_active) continue;
-
+  auto store = [&](auto set, auto buf) {
+    constexpr int S = decltype(set)::value, Bf = decltype(buf)::value;
+    kr[S].store(Kbuf + Bf * KSZ, nullptr, 0, tid);
+    if (TRR) vr[S].store(Vbuf + Bf * VSZ, nullptr, 0, tid);
+    else vr[S].store(nullptr, Vbuf + Bf * VSZ, A::LDT, tid);
+    if (tid < KB) kpm_buf[Bf * KB + tid] = kpm_r[S];
+  };
+  auto compute = [&](int t, auto buf) {
+    constexpr int Bf = decltype(buf)::value;
+    if (!wave_active) return;
+    const CT* Ks = Kbuf + Bf * KSZ;
+    const CT* Vs = Vbuf + Bf * VSZ;
+    const int k0 = t * KB;
     float p[4][4];
     float mx = -INFINITY;
     MaskBias mb;
-    fetch_mask_bias(mb, d, kpm_s, b, bm, h, myq, qvalid, ro, k0, lg);
+    fetch_mask_bias(mb, d, kpm_buf + Bf * KB, b, bm, h, myq, qvalid, ro, k0, lg);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < 4; ++tt) {
+      f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int st = 0; st < A::NS; ++st) Mma<CT>::mma(s, rfrag<CT>(&Ks[(t * 16 + li) * A::LDR], st, lg), qf[st]);
+      for (int st = 0; st < A::NS; ++st) Mma<CT>::mma(sc, rfrag<CT>(&Ks[(tt * 16 + li) * A::LDR], st, lg), qf[st]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float x = ((mb.mw[t] >> (8 * r)) & 0xffu) ? -INFINITY : s[r] * d.scale + mb.bb[t][r];
-        p[t][r] = x;
+        const float x = ((mb.mw[tt] >> (8 * r)) & 0xffu) ? -INFINITY : sc[r] * d.scale + mb.bb[tt][r];
+        p[tt][r] = x;
         mx = fmaxf(mx, x);
       }
     }
-    t_s += ANOW() - t0; t0 = ANOW();
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
     const float alpha = fexp<CT>(m - m_new);
     float rs = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[t][r] = fexp<CT>(p[t][r] - m_new);
-        rs += p[t][r];
+        p[tt][r] = fexp<CT>(p[tt][r] - m_new);
+        rs += p[tt][r];
       }
     rs += __shfl_xor(rs, 16, 64);
     rs += __shfl_xor(rs, 32, 64);
@@ -288,17 +312,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
     m = m_new;
     u32x4 pf[PackP<CT, 4>::STEPS];
     PackP<CT, 4>::run(p, pf);
-    t_sm += ANOW() - t0; t0 = ANOW();
 #pragma unroll
     for (int mt = 0; mt < A::MT; ++mt) {
       acc[mt] *= alpha;
 #pragma unroll
       for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
-        Mma<CT>::mma(acc[mt], tfrag_any<CT>(Vs, A::LDR, Vt, A::LDT, u, mt, li, lg), pf[u]);
+        Mma<CT>::mma(acc[mt], tfrag_any<CT>(Vs, A::LDR, Vs, A::LDT, u, mt, li, lg), pf[u]);
     }
-    t_pv += ANOW() - t0;
-  }
-  ADBG(0, t_stage); ADBG(1, t_s); ADBG(2, t_sm); ADBG(3, t_pv); ADBG(4, ANOW() - t_start);
+  };
+  pipeline2((d.Lk + KB - 1) / KB, load, store, compute);
 
   if (qvalid) {
     const float inv = 1.f / l;
@@ -346,10 +368,11 @@ template <typename CT, int DH, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
-  __shared__ __attribute__((aligned(16))) CT Ks[KB * A::LDR];
-  __shared__ __attribute__((aligned(16))) CT Vs[KB * A::LDR];
-  __shared__ __attribute__((aligned(16))) CT Kt[TRR ? 8 : DH * A::LDT];
-  __shared__ __attribute__((aligned(4))) uint8_t kpm_s[KB];
+  constexpr int KSZ = KB * A::LDR, TSZ = TRR ? 8 : DH * A::LDT;
+  __shared__ __attribute__((aligned(16))) CT Kbuf[2 * KSZ];
+  __shared__ __attribute__((aligned(16))) CT Vbuf[2 * KSZ];
+  __shared__ __attribute__((aligned(16))) CT Ktbuf[2 * TSZ];
+  __shared__ __attribute__((aligned(4))) uint8_t kpm_buf[2 * KB];
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -359,8 +382,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
 
   if (A::DHK > DH) {
-    zero_lds<CT, DH>(Ks, KB * A::LDR, tid, nthreads);
-    zero_lds<CT, DH>(Vs, KB * A::LDR, tid, nthreads);
+    zero_lds<CT, DH>(Kbuf, 2 * KSZ, tid, nthreads);
+    zero_lds<CT, DH>(Vbuf, 2 * KSZ, tid, nthreads);
+    __syncthreads();
   }
   u32x4 qf[A::NS], dof[A::NS];
   const int cq = min(myq, d.Lq - 1);
@@ -379,56 +403,59 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   float* dbrow = d.dbias ? d.dbias + (((long)b * d.H + h) * d.Lq + min(myq, d.Lq - 1)) * d.Lk : nullptr;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
 
-  TileRegs<CT, DH, KB, nthreads> kr, vr;
-  uint8_t kpm_r = 1;
-  auto prefetch = [&](int k0) {
-    kr.load(d.k, koff, d.k_sl, k0, d.Lk, tid);
-    vr.load(d.v, voff, d.v_sl, k0, d.Lk, tid);
-    if (tid < KB) kpm_r = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+  TileRegs<CT, DH, KB, nthreads> kr[2], vr[2];
+  uint8_t kpm_r[2] = {1, 1};
+  auto load = [&](int t, auto set) {
+    constexpr int S = decltype(set)::value;
+    const int k0 = t * KB;
+    kr[S].load(d.k, koff, d.k_sl, k0, d.Lk, tid);
+    vr[S].load(d.v, voff, d.v_sl, k0, d.Lk, tid);
+    if (tid < KB) kpm_r[S] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
   };
-  if (d.Lk > 0) prefetch(0);
-
-  for (int k0 = 0; k0 < d.Lk; k0 += KB) {
-    __syncthreads();
-    kr.store(Ks, TRR ? nullptr : Kt, A::LDT, tid);
-    vr.store(Vs, nullptr, 0, tid);
-    if (tid < KB) kpm_s[tid] = kpm_r;
-    __syncthreads();
-    if (k0 + KB < d.Lk) prefetch(k0 + KB);
-    if (!wave_active) continue;
-
+  auto store = [&](auto set, auto buf) {
+    constexpr int S = decltype(set)::value, Bf = decltype(buf)::value;
+    kr[S].store(Kbuf + Bf * KSZ, TRR ? nullptr : Ktbuf + Bf * TSZ, A::LDT, tid);
+    vr[S].store(Vbuf + Bf * KSZ, nullptr, 0, tid);
+    if (tid < KB) kpm_buf[Bf * KB + tid] = kpm_r[S];
+  };
+  auto compute = [&](int t, auto buf) {
+    constexpr int Bf = decltype(buf)::value;
+    if (!wave_active) return;
+    const CT* Ks = Kbuf + Bf * KSZ;
+    const CT* Vs = Vbuf + Bf * KSZ;
+    const CT* Kt = Ktbuf + Bf * TSZ;
+    const int k0 = t * KB;
     float ds[4][4];
     MaskBias mb;
-    fetch_mask_bias(mb, d, kpm_s, b, bm, h, myq, qvalid, ro, k0, lg);
+    fetch_mask_bias(mb, d, kpm_buf + Bf * KB, b, bm, h, myq, qvalid, ro, k0, lg);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < 4; ++tt) {
+      f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < A::NS; ++st) {
-        Mma<CT>::mma(s, rfrag<CT>(&Ks[(t * 16 + li) * A::LDR], st, lg), qf[st]);
-        Mma<CT>::mma(dp, rfrag<CT>(&Vs[(t * 16 + li) * A::LDR], st, lg), dof[st]);
+        Mma<CT>::mma(sc, rfrag<CT>(&Ks[(tt * 16 + li) * A::LDR], st, lg), qf[st]);
+        Mma<CT>::mma(dp, rfrag<CT>(&Vs[(tt * 16 + li) * A::LDR], st, lg), dof[st]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool masked = ((mb.mw[t] >> (8 * r)) & 0xffu) != 0;
-        const float pr = masked ? 0.f : fexp<CT>(s[r] * d.scale + mb.bb[t][r] - L);
-        const float g = pr * (dp[r] - Dl);
-        ds[t][r] = g;
+        const bool masked = ((mb.mw[tt] >> (8 * r)) & 0xffu) != 0;
+        const float pr = masked ? 0.f : fexp<CT>(sc[r] * d.scale + mb.bb[tt][r] - L);
+        ds[tt][r] = pr * (dp[r] - Dl);
       }
     }
     if (dbrow && qvalid) {   // uniform on dbias; 4 consecutive keys per (lane, tile)
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int gk = k0 + t * 16 + 4 * lg + r;
-          if (gk < d.Lk) dbrow[gk] = ds[t][r];
+          const int gk = k0 + tt * 16 + 4 * lg + r;
+          if (gk < d.Lk) dbrow[gk] = ds[tt][r];
         }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ds[t][r] *= d.scale;
+      for (int r = 0; r < 4; ++r) ds[tt][r] *= d.scale;
     u32x4 dsf[PackP<CT, 4>::STEPS];
     PackP<CT, 4>::run(ds, dsf);
 #pragma unroll
@@ -436,7 +463,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
 #pragma unroll
       for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
         Mma<CT>::mma(acc[mt], tfrag_any<CT>(Ks, A::LDR, Kt, A::LDT, u, mt, li, lg), dsf[u]);
-  }
+  };
+  pipeline2((d.Lk + KB - 1) / KB, load, store, compute);
 
   if (qvalid) {
     const long off = (long)b * d.q_sb + (long)myq * d.q_sl + (long)h * d.q_sh;
@@ -452,12 +480,13 @@ template <typename CT, int DH>
 __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
-  __shared__ __attribute__((aligned(16))) CT Qs[QB * A::LDR];
-  __shared__ __attribute__((aligned(16))) CT dOs[QB * A::LDR];
-  __shared__ __attribute__((aligned(16))) CT Qt[TRR ? 8 : DH * A::LDQ];
-  __shared__ __attribute__((aligned(16))) CT dOt[TRR ? 8 : DH * A::LDQ];
-  __shared__ float Ls[QB], Ds[QB];
-  __shared__ uint8_t ro_s[QB];
+  constexpr int QSZ = QB * A::LDR, TSZ = TRR ? 8 : DH * A::LDQ;
+  __shared__ __attribute__((aligned(16))) CT Qbuf[2 * QSZ];
+  __shared__ __attribute__((aligned(16))) CT dObuf[2 * QSZ];
+  __shared__ __attribute__((aligned(16))) CT Qtbuf[2 * TSZ];
+  __shared__ __attribute__((aligned(16))) CT dOtbuf[2 * TSZ];
+  __shared__ float Lbuf[2 * QB], Dbuf[2 * QB];
+  __shared__ uint8_t robuf[2 * QB];
   constexpr int nthreads = NWK * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -466,13 +495,14 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   const bool kvalid = key < d.Lk;
 
   if (A::DHK > DH) {
-    zero_lds<CT, DH>(Qs, QB * A::LDR, tid, nthreads);
-    zero_lds<CT, DH>(dOs, QB * A::LDR, tid, nthreads);
+    zero_lds<CT, DH>(Qbuf, 2 * QSZ, tid, nthreads);
+    zero_lds<CT, DH>(dObuf, 2 * QSZ, tid, nthreads);
+    __syncthreads();
   }
   u32x4 kf[A::NS], vf[A::NS];
-  const int ck = min(key, d.Lk - 1);
-  row_frags<CT, DH>(kf, d.k, (long)b * d.k_sb + (long)ck * d.k_sl + (long)h * d.k_sh, lg);
-  row_frags<CT, DH>(vf, d.v, (long)b * d.v_sb + (long)ck * d.v_sl + (long)h * d.v_sh, lg);
+  const int ckey = min(key, d.Lk - 1);
+  row_frags<CT, DH>(kf, d.k, (long)b * d.k_sb + (long)ckey * d.k_sl + (long)h * d.k_sh, lg);
+  row_frags<CT, DH>(vf, d.v, (long)b * d.v_sb + (long)ckey * d.v_sl + (long)h * d.v_sh, lg);
   const bool kmasked = kvalid ? (d.kpm ? d.kpm[(long)b * d.Lk + key] != 0 : false) : true;
 
   f32x4 accK[A::MT], accV[A::MT];
@@ -485,67 +515,74 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   const long sbase = ((long)b * d.H + h) * d.Lq;
   const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
 
-  TileRegs<CT, DH, QB, nthreads> qr, dor;
-  float l_r = INFINITY, d_r = 0.f;
-  uint8_t ro_r = 0;
-  auto prefetch = [&](int qb) {
-    qr.load(d.q, qoff, d.q_sl, qb, d.Lq, tid);
-    dor.load(d.dout, ooff, d.o_sl, qb, d.Lq, tid);
+  TileRegs<CT, DH, QB, nthreads> qr[2], dor[2];
+  float l_r[2] = {INFINITY, INFINITY}, d_r[2] = {0.f, 0.f};
+  uint8_t ro_r[2] = {0, 0};
+  auto load = [&](int t, auto set) {
+    constexpr int S = decltype(set)::value;
+    const int qb = t * QB;
+    qr[S].load(d.q, qoff, d.q_sl, qb, d.Lq, tid);
+    dor[S].load(d.dout, ooff, d.o_sl, qb, d.Lq, tid);
     if (tid < QB) {
       const int gq = qb + tid;
-      l_r = gq < d.Lq ? d.lse[sbase + gq] : INFINITY;
-      d_r = gq < d.Lq ? d.delta[sbase + gq] : 0.f;
-      ro_r = (gq < d.Lq && d.row_open) ? d.row_open[(long)bm * d.Lq + gq] : 0;
+      l_r[S] = gq < d.Lq ? d.lse[sbase + gq] : INFINITY;
+      d_r[S] = gq < d.Lq ? d.delta[sbase + gq] : 0.f;
+      ro_r[S] = (gq < d.Lq && d.row_open) ? d.row_open[(long)bm * d.Lq + gq] : 0;
     }
   };
-  prefetch(0);
-
-  for (int qb = 0; qb < d.Lq; qb += QB) {
-    __syncthreads();
-    qr.store(Qs, TRR ? nullptr : Qt, A::LDQ, tid);
-    dor.store(dOs, TRR ? nullptr : dOt, A::LDQ, tid);
-    if (tid < QB) { Ls[tid] = l_r; Ds[tid] = d_r; ro_s[tid] = ro_r; }
-    __syncthreads();
-    if (qb + QB < d.Lq) prefetch(qb + QB);
-
+  auto store = [&](auto set, auto buf) {
+    constexpr int S = decltype(set)::value, Bf = decltype(buf)::value;
+    qr[S].store(Qbuf + Bf * QSZ, TRR ? nullptr : Qtbuf + Bf * TSZ, A::LDQ, tid);
+    dor[S].store(dObuf + Bf * QSZ, TRR ? nullptr : dOtbuf + Bf * TSZ, A::LDQ, tid);
+    if (tid < QB) { Lbuf[Bf * QB + tid] = l_r[S]; Dbuf[Bf * QB + tid] = d_r[S]; robuf[Bf * QB + tid] = ro_r[S]; }
+  };
+  auto compute = [&](int t, auto buf) {
+    constexpr int Bf = decltype(buf)::value;
+    const CT* Qs = Qbuf + Bf * QSZ;
+    const CT* dOs = dObuf + Bf * QSZ;
+    const CT* Qt = Qtbuf + Bf * TSZ;
+    const CT* dOt = dOtbuf + Bf * TSZ;
+    const float* Ls = Lbuf + Bf * QB;
+    const float* Ds = Dbuf + Bf * QB;
+    const uint8_t* ro_s = robuf + Bf * QB;
+    const int qb = t * QB;
     float pt[2][4], dst[2][4];
-    // mask / bias for this lane's key against the 8 queries (t, r) it sees: uniform branches around grouped loads
+    // mask / bias for this lane's key against the 8 queries (tt, r) it sees: uniform branches around grouped loads
     bool mk[2][4];
     float bb[2][4];
-    const int ckey = min(key, d.Lk - 1);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { mk[t][r] = kmasked; bb[t][r] = 0.f; }
+      for (int r = 0; r < 4; ++r) { mk[tt][r] = kmasked; bb[tt][r] = 0.f; }
     if (d.mask) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ql = t * 16 + 4 * lg + r, gq = min(qb + ql, d.Lq - 1);
-          mk[t][r] |= (!ro_s[ql]) && (d.mask[((long)bm * d.Lq + gq) * d.Lk + ckey] != 0);
+          const int ql = tt * 16 + 4 * lg + r, gq = min(qb + ql, d.Lq - 1);
+          mk[tt][r] |= (!ro_s[ql]) && (d.mask[((long)bm * d.Lq + gq) * d.Lk + ckey] != 0);
         }
     }
     if (d.bias) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bb[t][r] = d.bias[(sbase + min(qb + t * 16 + 4 * lg + r, d.Lq - 1)) * d.Lk + ckey];
+        for (int r = 0; r < 4; ++r) bb[tt][r] = d.bias[(sbase + min(qb + tt * 16 + 4 * lg + r, d.Lq - 1)) * d.Lk + ckey];
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < 2; ++tt) {
+      f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < A::NS; ++st) {
-        Mma<CT>::mma(s, rfrag<CT>(&Qs[(t * 16 + li) * A::LDR], st, lg), kf[st]);
-        Mma<CT>::mma(dp, rfrag<CT>(&dOs[(t * 16 + li) * A::LDR], st, lg), vf[st]);
+        Mma<CT>::mma(sc, rfrag<CT>(&Qs[(tt * 16 + li) * A::LDR], st, lg), kf[st]);
+        Mma<CT>::mma(dp, rfrag<CT>(&dOs[(tt * 16 + li) * A::LDR], st, lg), vf[st]);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ql = t * 16 + 4 * lg + r;
-        const float pr = mk[t][r] ? 0.f : fexp<CT>(s[r] * d.scale + bb[t][r] - Ls[ql]);   // Ls = +inf past Lq
-        pt[t][r] = pr;
-        dst[t][r] = pr * (dp[r] - Ds[ql]) * d.scale;
+        const int ql = tt * 16 + 4 * lg + r;
+        const float pr = mk[tt][r] ? 0.f : fexp<CT>(sc[r] * d.scale + bb[tt][r] - Ls[ql]);   // Ls = +inf past Lq
+        pt[tt][r] = pr;
+        dst[tt][r] = pr * (dp[r] - Ds[ql]) * d.scale;
       }
     }
     u32x4 pf[PackP<CT, 2>::STEPS], dsf[PackP<CT, 2>::STEPS];
@@ -558,7 +595,8 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
         Mma<CT>::mma(accV[mt], tfrag_any<CT>(dOs, A::LDR, dOt, A::LDQ, u, mt, li, lg), pf[u]);
         Mma<CT>::mma(accK[mt], tfrag_any<CT>(Qs, A::LDR, Qt, A::LDQ, u, mt, li, lg), dsf[u]);
       }
-  }
+  };
+  pipeline2((d.Lq + QB - 1) / QB, load, store, compute);
 
   if (kvalid) {
     const long ko = (long)b * d.k_sb + (long)key * d.k_sl + (long)h * d.k_sh;
