@@ -1,0 +1,105 @@
+"""GPU: parity at BASELINE.json's full sizes.
+
+config 2 (B8, N_seg 1024, N_q 100, d256, H8, L4, 3 memories, 2-D masks) and config 4 (B4, N_seg 4096, N_q 200,
+mask head every layer, self-mask): the fp32 compute type is compared with the oracle run live on the host CPU (a few
+seconds), bf16 through size-independent properties: fused == modular execution path, padded segments never influence
+the result (changing padded feature rows leaves every output bit-identical), permutation equivariance over scenes."""
+import pytest
+import torch
+
+from pq3d_amd import synth
+from pq3d_amd.model import Query3DUnified, make_cfg
+from pq3d_amd.modules import set_compute
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+C2 = dict(B=8, Ns=1024, Nq=100, d=256, H=8, L=4, memories=["voxel", "mv", "pc"], heads=["ground"], spatial=True,
+          structure="parallel", seed=0, data_seed=1234)
+C4 = dict(B=4, Ns=4096, Nq=200, d=256, H=8, L=4, memories=["voxel", "mv", "pc"], heads=["mask"], spatial=True,
+          structure="parallel", use_self_mask=True, C=201, foc=(0, 2), seed=0, data_seed=1234)
+
+
+def build(args, compute, fused=True):
+    _cfg, model, sd, dd = util.model_case(args)
+    set_compute(model, compute)
+    model.unified_encoder.fused = fused
+    model.to(DEV)
+    return model, sd, dd
+
+
+def run(model, args, dd, grads=True):
+    model.zero_grad()
+    out = model({k: v.to(DEV) for k, v in dd.items()})
+    loss = util.synthetic_loss(out, args["heads"], out["query_embeds"])
+    if grads:
+        loss.backward()
+    return out, loss
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    fin = torch.isfinite(b) & (b > -1e5)
+    assert torch.equal(torch.isfinite(b), torch.isfinite(a))
+    return float((a[fin] - b[fin]).abs().max() / max(float(b[fin].abs().max()), 1e-6))
+
+
+@pytest.mark.parametrize("args", [C2, C4], ids=["c2", "c4"])
+def test_fp32_fullsize_matches_oracle(args):
+    model, sd, dd = build(args, "fp32")
+    out, loss = run(model, args, dd)
+    oout, collect, oloss, og = util.run_oracle(args, sd, dd)
+    assert rel(out["query_embeds"], collect[-1]) < 2e-5
+    if "ground" in args["heads"]:
+        assert rel(out["ground_logits"], oout["ground_logits"]) < 2e-5
+    if "mask" in args["heads"]:
+        assert len(out["predictions_mask"]) == args["L"] + 1
+        for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
+            assert rel(m, r) < 5e-5
+            assert float(((m.detach().cpu() < 0) != (r < 0)).float().mean()) < 1e-5   # self-mask bits
+        for c, r in zip(out["predictions_class"], oout["predictions_class"]):
+            assert rel(c, r) < 2e-5
+    assert abs(loss.item() - oloss.item()) < 2e-5 * max(1.0, abs(oloss.item()))
+    g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert sorted(g) == sorted(og)
+    gmax = max(float(v.norm()) for v in og.values())
+    worst = max((float((g[n].cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-3 * gmax)), n) for n in og)
+    assert worst[0] < 2e-3, f"worst gradient (relative L2) {worst}"
+
+
+@pytest.mark.parametrize("args", [C2, C4], ids=["c2", "c4"])
+def test_bf16_fullsize_fused_equals_modular(args):
+    res = []
+    for fused in (True, False):
+        model, sd, dd = build(args, "bf16", fused)
+        out, loss = run(model, args, dd)
+        res.append((out, loss, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (o1, l1, g1), (o2, l2, g2) = res
+    assert rel(o1["query_embeds"], o2["query_embeds"]) < 2e-3
+    if "mask" in args["heads"]:
+        for a, b in zip(o1["predictions_mask"], o2["predictions_mask"]):
+            assert rel(a, b) < 2e-3
+    assert abs(l1.item() - l2.item()) < 2e-4 * max(1.0, abs(l2.item()))
+    gmax = max(float(v.norm()) for v in g2.values())
+    for n in g2:
+        assert float((g1[n] - g2[n]).norm()) <= 3e-2 * max(float(g2[n].norm()), 1e-2 * gmax), n
+
+
+def test_bf16_c2_padding_invariance_and_scene_permutation():
+    """Rows of padded segments must not influence anything (masks), and scenes are independent (batch sharding is
+    exact): both are bit-level properties of the kernels, checked at the full config-2 size."""
+    model, sd, dd = build(C2, "bf16")
+    with torch.no_grad():
+        base = model({k: v.to(DEV) for k, v in dd.items()})["query_embeds"].clone()
+        dd2 = {k: v.clone() for k, v in dd.items()}
+        pad = ~dd2["seg_pad_masks"]
+        for m in C2["memories"]:
+            dd2[f"{m}_seg_fts"][pad] = 7.5            # garbage in padded rows
+        dd2["seg_center"][pad] = -3.0
+        out2 = model({k: v.to(DEV) for k, v in dd2.items()})["query_embeds"]
+        assert torch.equal(base, out2), "padded segments leaked into the result"
+        perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4])
+        dd3 = {k: (v[perm].clone() if torch.is_tensor(v) and v.shape[0] == C2["B"] else v) for k, v in dd.items()}
+        out3 = model({k: v.to(DEV) for k, v in dd3.items()})["query_embeds"]
+        assert torch.equal(base[perm.to(DEV)], out3), "scenes are not independent"
