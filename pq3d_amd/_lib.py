@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
         ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
         ("A", C.c_void_p * MAXG), ("A2", C.c_void_p * MAXG), ("B", C.c_void_p * MAXG), ("B2", C.c_void_p * MAXG),
         ("bias", C.c_void_p * MAXG), ("C", C.c_void_p * MAXG), ("C2", C.c_void_p * MAXG),
-        ("aux", C.c_void_p * MAXG), ("row_mask", C.c_void_p * MAXG),
+        ("aux", C.c_void_p * MAXG), ("row_mask", C.c_void_p * MAXG), ("colsum", C.c_void_p * MAXG),
         ("row_scale", C.c_void_p), ("row_fill_flag", C.c_void_p), ("mask_out", C.c_void_p),
     ]
 
@@ -157,7 +157,7 @@ def _fill(arr, tensors: Optional[Sequence[Optional[torch.Tensor]]]):
 def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C2=None, aux=None, row_mask=None,
          transA=False, transB=False, batch=1, strideA=0, strideB=0, strideC=0, act=None, act_grad=None, splitk=1,
          kconcat=0, accumulate=False, alpha=1.0, row_scale=None, row_fill_flag=None, row_fill=0.0,
-         mask_out=None) -> None:
+         mask_out=None, colsum=None) -> None:
     """kconcat: number of consecutive groups concatenated along K per output (True = all groups)."""
     if kconcat is True:
         kconcat = len(A)
@@ -177,7 +177,7 @@ def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C
     d.lda, d.ldb, d.ldc = lda, ldb, ldc
     d.strideA, d.strideB, d.strideC = strideA, strideB, strideC
     _fill(d.A, A); _fill(d.A2, A2); _fill(d.B, B); _fill(d.B2, B2); _fill(d.bias, bias); _fill(d.C, Cs)
-    _fill(d.C2, C2); _fill(d.aux, aux); _fill(d.row_mask, row_mask)
+    _fill(d.C2, C2); _fill(d.aux, aux); _fill(d.row_mask, row_mask); _fill(d.colsum, colsum)
     d.row_scale, d.row_fill_flag, d.mask_out = ptr(row_scale), ptr(row_fill_flag), ptr(mask_out)
     from .profiler import timed
     nb = (M * K * (2 if d.dtA else 4) + N * K * (2 if d.dtB else 4)) * len(A) * batch + \

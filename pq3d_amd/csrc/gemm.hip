@@ -124,6 +124,16 @@ struct FastStage {
       if (HAS2 && !cur.step2_zero) cur.p2[it] += cur.step;
     }
   }
+  // bias-gradient side product of a transposed A operand: per-thread partial sums over k of its chunk's EPL rows
+  PQ_DEV void accum(float (&bs)[2][T::EPL]) const {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float v[T::EPL];
+      r[it].to_float(v);
+#pragma unroll
+      for (int j = 0; j < T::EPL; ++j) bs[it][j] += kvalid[it] ? v[j] : 0.f;
+    }
+  }
   PQ_DEV void store(CT* lds, int tid) const {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -445,10 +455,20 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
       cb.init(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
     }
   };
+  // fused bias gradient (weight-gradient GEMMs): colsum[m] += sum_k A(m,k), taken from the staged A registers by
+  // the blocks of the first n-tile column; saves one column-sum launch per linear layer
+  float* cs_out = nullptr;
+  if constexpr (TRA) { if (blockIdx.y == 0) cs_out = d.colsum[b.g]; }
+  float bsum[2][T::EPL];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < T::EPL; ++j) bsum[i][j] = 0.f;
   issue(sa0, sb0);
   if (nit > 1) issue(sa1, sb1);
   DBG_STAMP(1);
   for (int it = 0; it < nit; it += 2) {
+    if constexpr (TRA) { if (cs_out) sa0.accum(bsum); }
     sa0.store(As, tid);
     sb0.store(Bs, tid);
     if (it == 0) DBG_STAMP(2);
@@ -458,6 +478,7 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
     __syncthreads();
     if (it == 0) DBG_STAMP(3);
     if (it + 1 < nit) {
+      if constexpr (TRA) { if (cs_out) sa1.accum(bsum); }
       sa1.store(As, tid);
       sb1.store(Bs, tid);
       __syncthreads();
@@ -467,6 +488,23 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
     }
   }
   DBG_STAMP(4);
+  if constexpr (TRA) {
+    if (cs_out) {   // uniform per block.  Threads sharing a row-chunk (same rc) reduce through LDS, then 64 atomics.
+      float* cs = (float*)Bs;
+      if (tid < BM) cs[tid] = 0.f;
+      __syncthreads();
+      constexpr int RC = BM / T::EPL;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rc = (tid + i * NT) % RC;
+#pragma unroll
+        for (int j = 0; j < T::EPL; ++j) atomicAdd(&cs[rc * T::EPL + j], bsum[i][j]);
+      }
+      __syncthreads();
+      if (tid < BM && b.m0 + tid < d.M) unsafeAtomicAdd(&cs_out[b.m0 + tid], cs[tid] * d.alpha);
+      __syncthreads();
+    }
+  }
   epilogue(d, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
   DBG_STAMP(5);
 }
@@ -572,6 +610,10 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   }
   if (d.splitk < 1) d.splitk = 1;
   PQ_CHECK_ARG(!(kc > 1 && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");
+  bool any_cs = false;
+  for (int g = 0; g < d.groups; ++g) any_cs |= d.colsum[g] != nullptr;
+  PQ_CHECK_ARG(!any_cs || (d.transA && d.transB && kc == 1 && d.batch == 1),
+               "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated GEMM");
   hipStream_t s = (hipStream_t)stream;
   if (d.splitk > 1) {
     PQ_CHECK_ARG(d.dtC == PQ3D_F32, "pq3d_gemm: split-K needs fp32 C");
@@ -592,12 +634,13 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
       else if (!af && bf) launch_fast_layout<bf16_t, bf16_t, float>(d, grid, s, a2, b2);
       else launch_fast_layout<bf16_t, bf16_t, bf16_t>(d, grid, s, a2, b2);
     } else {
+      PQ_CHECK_ARG(!any_cs, "pq3d_gemm: colsum needs the aligned fast path");
       launch_slow<bf16_t>(d, grid, s);
     }
   } else {
     if (fast_ok<float>(d, a2, b2) && d.dtA == PQ3D_F32 && d.dtB == PQ3D_F32)
       launch_fast_layout<float, float, float>(d, grid, s, a2, b2);
-    else launch_slow<float>(d, grid, s);
+    else { PQ_CHECK_ARG(!any_cs, "pq3d_gemm: colsum needs the aligned fast path"); launch_slow<float>(d, grid, s); }
   }
   PQ_LAUNCH_CHECK();
   return 0;

@@ -65,16 +65,23 @@ def _splitk(tiles: int, k: int, ct: int, groups: int) -> int:
     return max(1, min(nkt // 2 if nkt >= 2 else 1, max(1, 768 // max(tiles * groups, 1)), 64))
 
 
-def _dw_acc(gs, xs, x2s, outs, ct):
-    """outs[g][N,K] += gs[g]^T @ (xs[g] + x2s[g])  (grouped split-K, accumulating atomics)."""
+def _dw_acc(gs, xs, x2s, outs, ct, bias_outs=None):
+    """outs[g][N,K] += gs[g]^T @ (xs[g] + x2s[g])  (grouped split-K, accumulating atomics) and, fused into the same
+    launch, bias_outs[g][N] += column sums of gs[g] (the bias gradient of the same linear layer)."""
     N, K = outs[0].shape
     R = gs[0].numel() // N
     tiles = ((N + 63) // 64) * ((K + 63) // 64)
+    epl = 8 if ct == BF16 else 4
+    fusable = bias_outs is not None and N % epl == 0 and K % epl == 0 and N >= epl and K >= epl and \
+        all(t.data_ptr() % 16 == 0 for t in list(gs) + list(xs))
     for i in range(0, len(gs), MAXG):
         g_, x_, o_ = gs[i:i + MAXG], xs[i:i + MAXG], outs[i:i + MAXG]
         x2_ = x2s[i:i + MAXG] if x2s is not None else None
         L.gemm(M=N, N=K, K=R, A=g_, B=x_, B2=x2_, Cs=o_, ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
-               splitk=max(2, _splitk(tiles, R, ct, len(g_))), accumulate=True)
+               splitk=max(2, _splitk(tiles, R, ct, len(g_))), accumulate=True,
+               colsum=bias_outs[i:i + MAXG] if fusable else None)
+    if bias_outs is not None and not fusable:
+        _colsum_acc(gs, bias_outs, R)
 
 
 class FusedSpec:
@@ -366,16 +373,14 @@ class _FusedDecoder(Function):
                     dcl = t
                 dh2 = torch.empty(B, Nq, Hd, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=Hd, K=C_, A=[dcl], B=[c4.weight.detach()], Cs=[dh2], ct=ct, lda=C_, ldb=Hd, ldc=Hd, transB=True)
-                _dw_acc([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct)
-                _colsum_acc([dcl], [G(c4.bias)], R)
+                _dw_acc([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct, [G(c4.bias)])
                 _, dh1 = _ln_bwd(None, [rec["mh_h1"]], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq,
                                  rec["mh_mean"], rec["mh_rstd"], dh2, [G(c2.weight)], [G(c2.bias)])
                 dpre = ops.act_bwd(dh1[0], rec["mh_h1"], "relu", ad)
                 nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=d, K=Hd, A=[dpre], B=[c0.weight.detach()], Cs=[nxt], aux=[cur], act_grad="add", ct=ct,
                        lda=Hd, ldb=d, ldc=d, transB=True)
-                _dw_acc([dpre], [x_in], None, [G(c0.weight)], ct)
-                _colsum_acc([dpre], [G(c0.bias)], R)
+                _dw_acc([dpre], [x_in], None, [G(c0.weight)], ct, [G(c0.bias)])
                 cur = nxt
             if dm is not None:
                 Mm = spec.mh_count
@@ -396,8 +401,8 @@ class _FusedDecoder(Function):
                 L.gemm(M=R, N=d, K=d, A=[dqm[m] for m in range(Mm)], B=[mp.q_proj.weight.detach() for mp in mps],
                        Cs=[nxt] + [None] * (Mm - 1), aux=[cur] + [None] * (Mm - 1), act_grad="add", ct=ct, lda=d, ldb=d,
                        ldc=d, transB=True, kconcat=Mm)
-                _dw_acc([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct)
-                _colsum_acc([dqm[m] for m in range(Mm)], [G(mp.q_proj.bias) for mp in mps], R)
+                _dw_acc([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct,
+                        [G(mp.q_proj.bias) for mp in mps])
                 cur = nxt
             return cur
 
@@ -419,13 +424,11 @@ class _FusedDecoder(Function):
             L.gemm(M=R, N=F_, K=d, A=[dy], B=[ffn.linear2.weight.detach()], Cs=[dhp],
                    aux=[rec["pre"] if spec.act == "gelu" else rec["h"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
                    transB=True)
-            _dw_acc([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct)
-            _colsum_acc([dy], [G(ffn.linear2.bias)], R)
+            _dw_acc([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
             dx2 = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
             L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], aux=[dx2r], act_grad="add", ct=ct,
                    lda=F_, ldb=d, ldc=d, transB=True)
-            _dw_acc([dhp], [x2], None, [G(ffn.linear1.weight)], ct)
-            _colsum_acc([dhp], [G(ffn.linear1.bias)], R)
+            _dw_acc([dhp], [x2], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
             # ---------------- self-attention backward
             sa = layer.self_attn
             if spec.spatial:
@@ -446,8 +449,7 @@ class _FusedDecoder(Function):
             df = df[0]
             do_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
             L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
-            _dw_acc([df], [rec["o_s"]], None, [GWo], ct)
-            _colsum_acc([df], [Gbo], R)
+            _dw_acc([df], [rec["o_s"]], None, [GWo], ct, [Gbo])
             qkv = rec["qkv"]
             dqkv = torch.empty(3, B, Nq, d, dtype=ad, device=dev)
             delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
@@ -468,8 +470,7 @@ class _FusedDecoder(Function):
             L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1]], B=[Wl[0], Wl[1]], Cs=[dx1, None], C2=[gqk, None],
                    aux=[tmpv, None], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=2)
             dqpos_parts.append(gqk)
-            _dw_acc([dqkv[0], dqkv[1], dqkv[2]], [x1] * 3, [qpos, qpos, None], GW, ct)
-            _colsum_acc([dqkv[0], dqkv[1], dqkv[2]], Gb, R)
+            _dw_acc([dqkv[0], dqkv[1], dqkv[2]], [x1] * 3, [qpos, qpos, None], GW, ct, Gb)
             # ---------------- cross-attention backward (M memories per launch)
             cl = cas[i]
             dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
@@ -479,8 +480,8 @@ class _FusedDecoder(Function):
             L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
                    Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
             _dw_acc([dop[m] for m in range(M)], [rec["o_all"][m] for m in range(M)], None,
-                    [G(ca.multihead_attn.out_proj.weight) for ca in cl], ct)
-            _colsum_acc([dop[m] for m in range(M)], [G(ca.multihead_attn.out_proj.bias) for ca in cl], R)
+                    [G(ca.multihead_attn.out_proj.weight) for ca in cl], ct,
+                    [G(ca.multihead_attn.out_proj.bias) for ca in cl])
             dq_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
             delta_c = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
             mb = dict(mask=rec["attn_mask"], row_open=rec["row_open"], mask_bmod=B) if spec.use_self_mask \
@@ -497,8 +498,8 @@ class _FusedDecoder(Function):
                    transB=True, kconcat=M)
             dqpos_parts.append(gq)
             _dw_acc([dq_all[m] for m in range(M)], [x_in] * M, [qpos] * M,
-                    [G(ca.multihead_attn.in_proj_weight)[:d] for ca in cl], ct)
-            _colsum_acc([dq_all[m] for m in range(M)], [G(ca.multihead_attn.in_proj_bias)[:d] for ca in cl], R)
+                    [G(ca.multihead_attn.in_proj_weight)[:d] for ca in cl], ct,
+                    [G(ca.multihead_attn.in_proj_bias)[:d] for ca in cl])
             dx = dxn
             # ---------------- mask-head call that preceded this layer
             if spec.mh is not None and not spec.skip_pred:
@@ -519,8 +520,7 @@ class _FusedDecoder(Function):
                 X2 += [pos, None]
                 GWs += [gw[d:2 * d], gw[2 * d:]]
                 Gbs += [gb[d:2 * d], gb[2 * d:]]
-        _dw_acc(Akv, Xf, X2, GWs, ct)
-        _colsum_acc(Akv, Gbs, Rk)
+        _dw_acc(Akv, Xf, X2, GWs, ct, Gbs)
         # d feat_m = sum_a (dK_{a,m} Wk + dV_{a,m} Wv) [+ mask-head key path]
         for j in range(M):
             if not need_feat[j]:
