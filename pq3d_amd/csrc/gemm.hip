@@ -124,16 +124,6 @@ struct FastStage {
       if (HAS2 && !cur.step2_zero) cur.p2[it] += cur.step;
     }
   }
-  // bias-gradient side product of a transposed A operand: per-thread partial sums over k of its chunk's EPL rows
-  PQ_DEV void accum(float (&bs)[2][T::EPL]) const {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      float v[T::EPL];
-      r[it].to_float(v);
-#pragma unroll
-      for (int j = 0; j < T::EPL; ++j) bs[it][j] += kvalid[it] ? v[j] : 0.f;
-    }
-  }
   PQ_DEV void store(CT* lds, int tid) const {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -459,50 +449,44 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   // the blocks of the first n-tile column; saves one column-sum launch per linear layer
   float* cs_out = nullptr;
   if constexpr (TRA) { if (blockIdx.y == 0) cs_out = d.colsum[b.g]; }
-  float bsum[2][T::EPL];
+  float bsum = 0.f;
+  // thread t sums BKE/4 k-values of row t/4 of the staged A tile (read back from LDS next to the MFMAs)
+  auto rowsum = [&]() {
+    const CT* rp = &As[(tid >> 2) * T::LDK + (tid & 3) * (T::BKE / 4)];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < T::EPL; ++j) bsum[i][j] = 0.f;
+    for (int j = 0; j < T::BKE / 4; ++j) bsum += Cvt<CT>::to(rp[j]);
+  };
   issue(sa0, sb0);
   if (nit > 1) issue(sa1, sb1);
   DBG_STAMP(1);
   for (int it = 0; it < nit; it += 2) {
-    if constexpr (TRA) { if (cs_out) sa0.accum(bsum); }
     sa0.store(As, tid);
     sb0.store(Bs, tid);
     if (it == 0) DBG_STAMP(2);
     __syncthreads();
     if (issued < nit) issue(sa0, sb0);
+    if constexpr (TRA) { if (cs_out) rowsum(); }
     mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
     __syncthreads();
     if (it == 0) DBG_STAMP(3);
     if (it + 1 < nit) {
-      if constexpr (TRA) { if (cs_out) sa1.accum(bsum); }
       sa1.store(As, tid);
       sb1.store(Bs, tid);
       __syncthreads();
       if (issued < nit) issue(sa1, sb1);
+      if constexpr (TRA) { if (cs_out) rowsum(); }
       mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
       __syncthreads();
     }
   }
   DBG_STAMP(4);
   if constexpr (TRA) {
-    if (cs_out) {   // uniform per block.  Threads sharing a row-chunk (same rc) reduce through LDS, then 64 atomics.
-      float* cs = (float*)Bs;
-      if (tid < BM) cs[tid] = 0.f;
-      __syncthreads();
-      constexpr int RC = BM / T::EPL;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rc = (tid + i * NT) % RC;
-#pragma unroll
-        for (int j = 0; j < T::EPL; ++j) atomicAdd(&cs[rc * T::EPL + j], bsum[i][j]);
-      }
-      __syncthreads();
-      if (tid < BM && b.m0 + tid < d.M) unsafeAtomicAdd(&cs_out[b.m0 + tid], cs[tid] * d.alpha);
-      __syncthreads();
+    if (cs_out) {   // uniform per block: 4 neighbouring lanes hold the quarters of one row
+      float v = bsum;
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      const int row = b.m0 + (tid >> 2);
+      if ((tid & 3) == 0 && row < d.M) unsafeAtomicAdd(&cs_out[row], v * d.alpha);
     }
   }
   epilogue(d, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
