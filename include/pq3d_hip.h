@@ -188,6 +188,12 @@ int pq3d_colsum_grouped(const void* const* x, float* const* out, int32_t groups,
 int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty, int64_t R, int64_t C, const float* scale,
                     const uint8_t* zero_flag, const uint8_t* keep_mask, void* stream);
 
+/* Grouped elementwise add + cast: out_g[i] = (dt_out)(a_g[i] + b_g[i]) for g < groups (b_g may be NULL); fp32 inputs.
+ * Used once per forward to materialise the layer-invariant bf16 MFMA operands (feat + pos) and (feat) of every scene
+ * memory, so the hoisted K/V projection GEMMs read 2 B instead of 8 B per element. */
+int pq3d_add_cast(const float* const* a, const float* const* b, void* const* out, int32_t groups, int32_t dt_out,
+                  int64_t n, void* stream);
+
 /* dpre = dy * act'(saved): ReLU: saved = activation output (or pre-activation), GELU: saved = pre-activation. */
 int pq3d_act_bwd(const void* dy, int32_t dt_dy, const void* saved, int32_t dt_saved, void* dpre, int32_t dt_dpre,
                  int32_t act, int64_t n, void* stream);

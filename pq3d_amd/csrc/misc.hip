@@ -46,6 +46,33 @@ __global__ void scale_rows_kernel(const void* x, int dtx, void* y, int dty, long
   }
 }
 
+struct AddCastPtrs { const float* a[PQ3D_MAX_GROUPS]; const float* b[PQ3D_MAX_GROUPS]; void* out[PQ3D_MAX_GROUPS]; };
+// 8 elements per thread: two float4 loads per input, one 16-byte (bf16) or two 16-byte (fp32) stores
+__global__ void add_cast_kernel(const AddCastPtrs p, int dt_out, long n) {
+  const float* a = p.a[blockIdx.y];
+  const float* b = p.b[blockIdx.y];
+  void* out = p.out[blockIdx.y];
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
+    float v[8];
+    if (i + 8 <= n) {
+      const float4 a0 = *(const float4*)(a + i), a1 = *(const float4*)(a + i + 4);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      if (b) {
+        const float4 b0 = *(const float4*)(b + i), b1 = *(const float4*)(b + i + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (dt_out == PQ3D_BF16)
+        *(u32x4*)((bf16_t*)out + i) = (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      else {
+        *(float4*)((float*)out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)out + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    } else {
+      for (long j = i; j < n; ++j) store_elem(out, dt_out, j, a[j] + (b ? b[j] : 0.f));
+    }
+  }
+}
+
 __global__ void act_bwd_kernel(const void* dy, int dt_dy, const void* saved, int dt_s, void* dpre, int dt_o, int act,
                                long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -270,6 +297,22 @@ extern "C" int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty,
   if (R == 0) return 0;
   hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1d(R * C)), dim3(256), 0, (hipStream_t)stream, x, dtx, y, dty, (long)R,
                      (long)C, scale, zero_flag, keep_mask);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_add_cast(const float* const* a, const float* const* b, void* const* out, int32_t groups,
+                             int32_t dt_out, int64_t n, void* stream) {
+  PQ_CHECK_ARG(a && out && groups >= 1 && groups <= PQ3D_MAX_GROUPS && n >= 0, "pq3d_add_cast: bad args");
+  PQ_CHECK_ARG((n % 8) == 0, "pq3d_add_cast: n must be a multiple of 8");
+  AddCastPtrs p;
+  for (int g = 0; g < groups; ++g) {
+    PQ_CHECK_ARG(a[g] && out[g], "pq3d_add_cast: null pointer");
+    p.a[g] = a[g]; p.b[g] = b ? b[g] : nullptr; p.out[g] = out[g];
+  }
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_cast_kernel, dim3(grid1d(n / 8, 256, 1024), groups), dim3(256), 0, (hipStream_t)stream, p,
+                     dt_out, (long)n);
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -197,14 +197,30 @@ class _FusedDecoder(Function):
         masks = [ops._c(m) for m in masks]
         qmask = ops._c(qmask)
 
+        # ---- layer-invariant MFMA operands, rounded once: kin_m = (feat_m + pos), vin_m = feat_m in the activation
+        # dtype (bf16 path: the 2*L*M hoisted GEMMs and their weight-gradient GEMM then read 2 B/element, not 8)
+        if ct == BF16 and (B * Ns * d) % 8 == 0:
+            kvin = torch.empty(2, M, B, Ns, d, dtype=ad, device=dev)
+            srcs = [feats[j] for j in range(M)] * 2
+            adds = [pos] * M + [None] * M
+            outs = [kvin[0, j] for j in range(M)] + [kvin[1, j] for j in range(M)]
+            if pos is None:
+                adds = [None] * (2 * M)
+            arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
+            L.check(L.lib().pq3d_add_cast(arr(srcs), arr(adds), arr(outs), 2 * M, L.BF16, B * Ns * d, L.stream()),
+                    "pq3d_add_cast")
+            kin, vin, kin2 = [kvin[0, j] for j in range(M)], [kvin[1, j] for j in range(M)], [None] * M
+        else:
+            kin, vin, kin2 = feats, feats, [pos] * M
+        ctx.kin, ctx.vin, ctx.kin2 = kin, vin, kin2
         # ---- hoisted K/V projections: KV[l, 0|1, m] = (feat_m [+ pos]) @ W{k,v}_{l,m}^T + b
         KV = torch.empty(Ln, 2, M, B, Ns, d, dtype=ad, device=dev)
         A, A2, Bw, bs, Cs = [], [], [], [], []
         for i in range(Ln):
             for j, ca in enumerate(cas[i]):
                 w, b = ca.multihead_attn.in_proj_weight.detach(), ca.multihead_attn.in_proj_bias.detach()
-                A += [feats[j], feats[j]]
-                A2 += [pos, None]
+                A += [kin[j], vin[j]]
+                A2 += [kin2[j], None]
                 Bw += [w[d:2 * d], w[2 * d:]]
                 bs += [b[d:2 * d], b[2 * d:]]
                 Cs += [KV[i, 0, j], KV[i, 1, j]]
@@ -516,8 +532,8 @@ class _FusedDecoder(Function):
                 gw, gb = G(ca.multihead_attn.in_proj_weight), G(ca.multihead_attn.in_proj_bias)
                 Akv += [dKV[a, 0, j], dKV[a, 1, j]]
                 Bkv += [w[d:2 * d], w[2 * d:]]
-                Xf += [feats[j], feats[j]]
-                X2 += [pos, None]
+                Xf += [ctx.kin[j], ctx.vin[j]]
+                X2 += [ctx.kin2[j], None]
                 GWs += [gw[d:2 * d], gw[2 * d:]]
                 Gbs += [gb[d:2 * d], gb[2 * d:]]
         _dw_acc(Akv, Xf, X2, GWs, ct, Gbs)
