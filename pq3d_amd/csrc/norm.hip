@@ -203,11 +203,10 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
     hipError_t e = hipMemsetAsync(d.dx, 0, sizeof(float) * (size_t)d.R * d.d, s);
     if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
   }
-  // rows per wave: few for short inputs (latency-bound row chain), many for long ones (the per-column atomics of
-  // the parameter gradients are the bottleneck there: one atomic per column per block)
-  const int rpw = d.R >= 4096 ? 16 : 4;
+  // two rows per wave (software-pipelined); one atomic per column per block for the parameter gradients
+  const int rpw = d.R >= 4096 ? 4 : 2;   // measured: 2 rows/wave is best for R=800, 4 for R=8192 (atomics)
   long nb = (d.R + rpw * WPB - 1) / (rpw * WPB);
-  if (nb > 512) nb = 512;
+  if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb, d.M);
   LN_DISPATCH(add_ln_bwd_kernel, grid)
