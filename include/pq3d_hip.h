@@ -83,8 +83,8 @@ typedef struct {
   const void* aux[PQ3D_MAX_GROUPS];
   const uint8_t* row_mask[PQ3D_MAX_GROUPS];       /* [batch*M], 0 = zero the row */
   float* colsum[PQ3D_MAX_GROUPS];                 /* transA GEMMs only, or NULL: colsum_g[m] += sum_k A_g(m,k) -- the
-                                                     bias gradient sum_r dY[r][m] of the same linear, accumulated with
-                                                     atomics (caller zeroes or accumulates) */
+                                                     bias gradient sum_r dY[r][m] of the same linear (split-K launches
+                                                     only; zeroed by the call unless `accumulate`, then atomics) */
   const float* row_scale;                         /* [batch*M] or NULL (group 0 only) */
   const uint8_t* row_fill_flag;                   /* [batch*M] or NULL */
   uint8_t* mask_out;                              /* [batch][N][M] or NULL */

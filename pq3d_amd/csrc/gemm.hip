@@ -596,8 +596,8 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   PQ_CHECK_ARG(!(kc > 1 && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");
   bool any_cs = false;
   for (int g = 0; g < d.groups; ++g) any_cs |= d.colsum[g] != nullptr;
-  PQ_CHECK_ARG(!any_cs || (d.transA && d.transB && kc == 1 && d.batch == 1),
-               "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated GEMM");
+  PQ_CHECK_ARG(!any_cs || (d.transA && d.transB && kc == 1 && d.batch == 1 && d.splitk > 1),
+               "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated split-K GEMM");
   hipStream_t s = (hipStream_t)stream;
   if (d.splitk > 1) {
     PQ_CHECK_ARG(d.dtC == PQ3D_F32, "pq3d_gemm: split-K needs fp32 C");
@@ -605,6 +605,7 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
                  "pq3d_gemm: split-K needs contiguous C");
     for (int g = 0; g < d.groups && !d.accumulate; ++g) {
       hipError_t e = hipMemsetAsync(d.C[g], 0, sizeof(float) * (size_t)d.batch * d.M * d.N, s);
+      if (e == hipSuccess && d.colsum[g]) e = hipMemsetAsync(d.colsum[g], 0, sizeof(float) * (size_t)d.M, s);
       if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
     }
   }

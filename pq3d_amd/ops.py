@@ -130,12 +130,21 @@ class _Linear(Function):
             dx2 = dx if (x2 is not None and ctx.needs_input_grad[3]) else None
             if not ctx.needs_input_grad[0]:
                 dx = None
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = _empty(N, K, dtype=torch.float32, device=x.device)
             tiles = ((N + 63) // 64) * ((K + 63) // 64)
+            epl = 8 if ct == BF16 else 4
+            # the bias gradient rides on the weight-gradient GEMM when its fast (aligned) path applies
+            fuse = want_db and N % epl == 0 and K % epl == 0 and N >= epl and K >= epl and \
+                g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and (x2 is None or x2.dtype == torch.float32) and \
+                (x2 is None or x.dtype == torch.float32)
+            if fuse:
+                db = _empty(N, dtype=torch.float32, device=x.device)
             L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True,
-                   transB=True, splitk=_splitk(tiles, R, ct))
-        if ctx.has_b and ctx.needs_input_grad[2]:
+                   transB=True, splitk=max(2, _splitk(tiles, R, ct)) if fuse else _splitk(tiles, R, ct),
+                   colsum=[db] if fuse else None)
+        if want_db and db is None:
             db = colsum(g.view(R, N))
         return dx, dw, db, dx2, None, None, None, None, None, None
 
