@@ -142,6 +142,10 @@ def main():
     dd = {k: v.to(dev) for k, v in dd_cpu.items()}
     params = [p for p in model.parameters() if p.requires_grad]
     reducer = FlatGradAllReducer(params)
+    # the fused decoder writes its parameter gradients straight into the reducer's flat buffer (no pack copy)
+    enc = model.unified_encoder
+    enc.grad_arena = reducer.slots()
+    enc.grad_arena_buffers = reducer.flat
 
     def fwd_bwd():
         model.zero_grad(set_to_none=True)

@@ -173,38 +173,56 @@ __global__ void spatial_bias_fwd_kernel(const float* pl, const float* W, const f
   }
 }
 
-// one block accumulates a grid-stride slice; per-thread partials -> LDS tree -> 6 atomics per head per block
+// Single pass: each thread reads its (b,i,j) feature vector ONCE and updates all heads' 6 partial sums in registers
+// (H <= 16), then one wave reduction + LDS tree per block and 6*H atomics per block.  (The first version looped
+// over heads outside the element loop and re-read pl H times: 29 us for 80k elements.)
+template <int HMAX>
 __global__ __launch_bounds__(256) void spatial_bias_bwd_kernel(const float* pl, const float* W, const float* bw,
                                                                const float* dbias, float* dW, float* dbw, int B, int H,
                                                                int L) {
-  __shared__ float red[4][6];
+  __shared__ float red[4][HMAX * 6];
   const long LL = (long)L * L, total = (long)B * LL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int h = 0; h < H; ++h) {
-    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-      const long b = i / LL, ij = i % LL;
-      float f[5];
-      float v = bw[h];
+  float acc[HMAX][6];
+  float w[HMAX][6];
 #pragma unroll
-      for (int c = 0; c < 5; ++c) { f[c] = pl[i * 5 + c]; v += W[h * 5 + c] * f[c]; }
-      const float g = v > 1e-6f ? dbias[(b * H + h) * LL + ij] / v : 0.f;
-#pragma unroll
-      for (int c = 0; c < 5; ++c) acc[c] += g * f[c];
-      acc[5] += g;
-    }
+  for (int h = 0; h < HMAX; ++h)
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      const float s = wave_sum(acc[c]);
-      if (lane == 0) red[wave][c] = s;
+      acc[h][c] = 0.f;
+      w[h][c] = h < H ? (c < 5 ? W[h * 5 + c] : bw[h]) : 0.f;
     }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-      const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-      if (threadIdx.x < 5) unsafeAtomicAdd(&dW[h * 5 + threadIdx.x], s);
-      else unsafeAtomicAdd(&dbw[h], s);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / LL, ij = i % LL;
+    float f[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) f[c] = pl[i * 5 + c];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+      if (h < H) {
+        float v = w[h][5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) v += w[h][c] * f[c];
+        const float g = v > 1e-6f ? dbias[(b * H + h) * LL + ij] / v : 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) acc[h][c] += g * f[c];
+        acc[h][5] += g;
+      }
     }
-    __syncthreads();
+  }
+#pragma unroll
+  for (int h = 0; h < HMAX; ++h)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float sres = wave_sum(acc[h][c]);
+      if (lane == 0) red[wave][h * 6 + c] = sres;
+    }
+  __syncthreads();
+  if (threadIdx.x < H * 6) {
+    const int t = threadIdx.x, h = t / 6, c = t % 6;
+    const float sres = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    if (c < 5) unsafeAtomicAdd(&dW[h * 5 + c], sres);
+    else unsafeAtomicAdd(&dbw[h], sres);
   }
 }
 
@@ -393,8 +411,13 @@ extern "C" int pq3d_spatial_bias_bwd_acc(const float* pl, const float* W, const 
   PQ_CHECK_ARG(pl && W && bw && dbias && dW && dbw && H >= 1, "pq3d_spatial_bias_bwd_acc: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (B == 0 || L == 0) return 0;
-  hipLaunchKernelGGL(spatial_bias_bwd_kernel, dim3(grid1d((long)B * L * L, 256, 128)), dim3(256), 0, s, pl, W, bw,
-                     dbias, dW, dbw, B, H, L);
+  PQ_CHECK_ARG(H <= 16, "pq3d_spatial_bias_bwd: at most 16 heads");
+  if (H <= 8)
+    hipLaunchKernelGGL(spatial_bias_bwd_kernel<8>, dim3(grid1d((long)B * L * L, 256, 512)), dim3(256), 0, s, pl, W, bw,
+                       dbias, dW, dbw, B, H, L);
+  else
+    hipLaunchKernelGGL(spatial_bias_bwd_kernel<16>, dim3(grid1d((long)B * L * L, 256, 512)), dim3(256), 0, s, pl, W, bw,
+                       dbias, dW, dbw, B, H, L);
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -359,11 +359,21 @@ class _FusedDecoder(Function):
 
         # ---- gradient arena: one flat zeroed fp32 buffer, every parameter gradient is a view of it
         sizes = [p.numel() for p in params]
-        arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        gv, off = {}, 0
-        for p, n in zip(params, sizes):
-            gv[id(p)] = arena[off:off + n].view(p.shape)
-            off += n
+        ext = getattr(enc, "grad_arena", None)   # {id(param): (flat, offset, numel)} of a DP reducer's flat buffers
+        gv = {}
+        if ext is not None and all(id(p) in ext for p in params):
+            # gradients go straight into the data-parallel flat buffer (zeroed here): no pack copy afterwards
+            for t in getattr(enc, "grad_arena_buffers", ()):
+                t.zero_()
+            for p in params:
+                flat, o_, n_ = ext[id(p)]
+                gv[id(p)] = flat[o_:o_ + n_].view(p.shape)
+        else:
+            arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            off = 0
+            for p, n in zip(params, sizes):
+                gv[id(p)] = arena[off:off + n].view(p.shape)
+                off += n
         G = lambda p: gv[id(p)]
 
         dx = dxf.contiguous().float() if dxf is not None else torch.zeros(B, Nq, d, device=dev)

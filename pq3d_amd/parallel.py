@@ -30,17 +30,33 @@ class FlatGradAllReducer:
         self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
                      for b in self.buckets if b]
 
+    def slots(self):
+        """{id(param): (flat buffer, element offset, numel)} -- hand this to the fused executor
+        (``encoder.grad_arena``): it then writes parameter gradients straight into the flat buffer (fresh view
+        objects per backward, so autograd adopts them without a copy) and pack() skips them."""
+        out = {}
+        for flat, bucket in zip(self.flat, self.buckets):
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                out[id(p)] = (flat, off, n)
+                off += n
+        return out
+
     def pack(self) -> None:
-        """Copy every .grad into the flat buffers (capturable: fixed addresses, one foreach copy per bucket)."""
+        """Copy every .grad into the flat buffers (capturable: fixed addresses, one foreach copy per bucket).
+        Gradients that already ARE views of the flat buffer (written in place by the fused executor) are skipped."""
         for flat, bucket in zip(self.flat, self.buckets):
             views, grads, off = [], [], 0
             for p in bucket:
                 n = p.numel()
+                v = flat[off:off + n].view_as(p)
                 if p.grad is not None:
-                    views.append(flat[off:off + n].view_as(p))
-                    grads.append(p.grad)
+                    if p.grad.data_ptr() != v.data_ptr():
+                        views.append(v)
+                        grads.append(p.grad)
                 else:
-                    flat[off:off + n].zero_()
+                    v.zero_()
                 off += n
             if views:
                 torch._foreach_copy_(views, grads)
