@@ -153,17 +153,30 @@ struct FastStage {
       } else {
         constexpr int RC = BM / T::EPL;
         const int kk = c / RC, rc = c % RC;
+        if constexpr (sizeof(CT) == 2) {
+          // bf16: keep the operand in its native [k][m] orientation (one 16-byte LDS write); the MFMA fragments are
+          // fetched with the transposing LDS read (mma_tile)
+          *(u32x4*)&lds[kk * T::LDK + rc * T::EPL] = packed;
+        } else {
 #pragma unroll
-        for (int j = 0; j < T::EPL; ++j) {
-          if constexpr (sizeof(CT) == 2)
-            lds[(rc * T::EPL + j) * T::LDK + kk] = (CT)((packed[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-          else
-            lds[(rc * T::EPL + j) * T::LDK + kk] = __uint_as_float(packed[j]);
+          for (int j = 0; j < T::EPL; ++j) lds[(rc * T::EPL + j) * T::LDK + kk] = __uint_as_float(packed[j]);
         }
       }
     }
   }
 };
+
+// bf16 fragment (row `r0 + li` of the operand, k-slots 8*lg..8*lg+7 of k-step ks) from a [k][m]-oriented LDS tile via
+// ds_read_b64_tr_b16 (lane (li,lg) pointing at row base + li/4, columns 4*(li%4).. receives tile[base + j][li]).
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
+PQ_DEV u32x4 km_frag(const bf16_t* tile, int ldk, int r0, int ks, int li, int lg) {
+  const bf16_t* p0 = tile + (ks * 32 + 8 * lg + (li >> 2)) * ldk + r0 + 4 * (li & 3);
+  const v4i16_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)p0);
+  const v4i16_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(p0 + 4 * ldk));
+  const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
+  return (u32x4){lo.x, lo.y, hi.x, hi.y};
+}
 
 // ---- generic stager: guarded scalar loads, runtime dtypes --------------------------------------------------
 template <typename CT, bool TR>
@@ -222,16 +235,22 @@ struct SlowStage {
   }
 };
 
-template <typename CT>
+template <typename CT, bool KMA, bool KMB>
 PQ_DEV void mma_tile(f32x4 (&acc)[2][2], const CT* As, const CT* Bs, int wm, int wn, int li, int lg) {
   typedef Tile<CT> T;
 #pragma unroll
   for (int ks = 0; ks < T::BKE / T::KSTEP; ++ks) {
     u32x4 fa[2], fb[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i] = *(const u32x4*)&As[(wm + i * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL];
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (KMA && sizeof(CT) == 2) fa[i] = km_frag((const bf16_t*)As, T::LDK, wm + i * 16, ks, li, lg);
+      else fa[i] = *(const u32x4*)&As[(wm + i * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL];
+    }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j] = *(const u32x4*)&Bs[(wn + j * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL];
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (KMB && sizeof(CT) == 2) fb[j] = km_frag((const bf16_t*)Bs, T::LDK, wn + j * 16, ks, li, lg);
+      else fb[j] = *(const u32x4*)&Bs[(wn + j * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -452,9 +471,15 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   float bsum = 0.f;
   // thread t sums BKE/4 k-values of row t/4 of the staged A tile (read back from LDS next to the MFMAs)
   auto rowsum = [&]() {
-    const CT* rp = &As[(tid >> 2) * T::LDK + (tid & 3) * (T::BKE / 4)];
+    if constexpr (sizeof(CT) == 2) {   // [k][m] tile: thread = (m = tid % 64, k quarter = tid / 64)
+      const CT* cp = &As[(tid >> 6) * (T::BKE / 4) * T::LDK + (tid & 63)];
 #pragma unroll
-    for (int j = 0; j < T::BKE / 4; ++j) bsum += Cvt<CT>::to(rp[j]);
+      for (int j = 0; j < T::BKE / 4; ++j) bsum += Cvt<CT>::to(cp[j * T::LDK]);
+    } else {                           // [m][k] tile: thread = (m = tid / 4, k quarter = tid % 4)
+      const CT* rp = &As[(tid >> 2) * T::LDK + (tid & 3) * (T::BKE / 4)];
+#pragma unroll
+      for (int j = 0; j < T::BKE / 4; ++j) bsum += Cvt<CT>::to(rp[j]);
+    }
   };
   issue(sa0, sb0);
   if (nit > 1) issue(sa1, sb1);
@@ -466,7 +491,7 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
     __syncthreads();
     if (issued < nit) issue(sa0, sb0);
     if constexpr (TRA) { if (cs_out) rowsum(); }
-    mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
+    mma_tile<CT, TRA, TRB>(acc, As, Bs, wm, wn, li, lg);
     __syncthreads();
     if (it == 0) DBG_STAMP(3);
     if (it + 1 < nit) {
@@ -475,18 +500,27 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
       __syncthreads();
       if (issued < nit) issue(sa1, sb1);
       if constexpr (TRA) { if (cs_out) rowsum(); }
-      mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
+      mma_tile<CT, TRA, TRB>(acc, As, Bs, wm, wn, li, lg);
       __syncthreads();
     }
   }
   DBG_STAMP(4);
   if constexpr (TRA) {
-    if (cs_out) {   // uniform per block: 4 neighbouring lanes hold the quarters of one row
-      float v = bsum;
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      const int row = b.m0 + (tid >> 2);
-      if ((tid & 3) == 0 && row < d.M) unsafeAtomicAdd(&cs_out[row], v * d.alpha);
+    if (cs_out) {   // uniform per block
+      if constexpr (sizeof(CT) == 2) {   // the 4 waves hold the 4 k-quarters of row m = lane: reduce through LDS
+        float* red = (float*)Bs;
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 64 && b.m0 + tid < d.M)
+          unsafeAtomicAdd(&cs_out[b.m0 + tid], (red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192]) * d.alpha);
+        __syncthreads();
+      } else {                           // 4 neighbouring lanes hold the quarters of one row
+        float v = bsum;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        const int row = b.m0 + (tid >> 2);
+        if ((tid & 3) == 0 && row < d.M) unsafeAtomicAdd(&cs_out[row], v * d.alpha);
+      }
     }
   }
   epilogue(d, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
@@ -526,7 +560,7 @@ __global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_gemm_desc d) {
     sb.store(Bs, tid);
     __syncthreads();
     if (it + 1 < nit) load_next();
-    mma_tile<CT>(acc, As, Bs, wm, wn, li, lg);
+    mma_tile<CT, false, false>(acc, As, Bs, wm, wn, li, lg);
     __syncthreads();
   }
   epilogue(d, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
