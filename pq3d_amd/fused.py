@@ -84,6 +84,28 @@ def _dw_acc(gs, xs, x2s, outs, ct, bias_outs=None):
         _colsum_acc(gs, bias_outs, R)
 
 
+class _DwQueue:
+    """Deferred weight-gradient GEMMs.  Every dW = g^T (x [+ x2]) of the backward pass only feeds the gradient arena,
+    so they are queued and flushed at the end as a few grouped launches per (shape, dtype) bucket instead of one
+    launch per linear layer (c2: 41 launches -> 6)."""
+
+    def __init__(self, ct):
+        self.ct, self.buckets = ct, {}
+
+    def add(self, gs, xs, x2s, outs, ct=None, bias_outs=None):
+        for i in range(len(gs)):
+            N, K = outs[i].shape
+            key = (N, K, gs[i].numel() // N, gs[i].dtype, xs[i].dtype, bias_outs is not None)
+            b = self.buckets.setdefault(key, ([], [], [], [], []))
+            b[0].append(gs[i]); b[1].append(xs[i]); b[2].append(x2s[i] if x2s is not None else None)
+            b[3].append(outs[i]); b[4].append(bias_outs[i] if bias_outs is not None else None)
+
+    def flush(self):
+        for key, (g, x, x2, o, bo) in self.buckets.items():
+            _dw_acc(g, x, x2 if any(t is not None for t in x2) else None, o, self.ct, bo if key[5] else None)
+        self.buckets = {}
+
+
 class FusedSpec:
     """Static description of one fused decoder invocation (non-tensor state handed to the Function)."""
 
@@ -376,6 +398,7 @@ class _FusedDecoder(Function):
                 off += n
         G = lambda p: gv[id(p)]
 
+        dwq = _DwQueue(ct)
         dx = dxf.contiguous().float() if dxf is not None else torch.zeros(B, Nq, d, device=dev)
         dqpos_parts: List[torch.Tensor] = []
         n_app = len(tape)
@@ -399,14 +422,14 @@ class _FusedDecoder(Function):
                     dcl = t
                 dh2 = torch.empty(B, Nq, Hd, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=Hd, K=C_, A=[dcl], B=[c4.weight.detach()], Cs=[dh2], ct=ct, lda=C_, ldb=Hd, ldc=Hd, transB=True)
-                _dw_acc([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct, [G(c4.bias)])
+                dwq.add([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct, [G(c4.bias)])
                 _, dh1 = _ln_bwd(None, [rec["mh_h1"]], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq,
                                  rec["mh_mean"], rec["mh_rstd"], dh2, [G(c2.weight)], [G(c2.bias)])
                 dpre = ops.act_bwd(dh1[0], rec["mh_h1"], "relu", ad)
                 nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=d, K=Hd, A=[dpre], B=[c0.weight.detach()], Cs=[nxt], aux=[cur], act_grad="add", ct=ct,
                        lda=Hd, ldb=d, ldc=d, transB=True)
-                _dw_acc([dpre], [x_in], None, [G(c0.weight)], ct, [G(c0.bias)])
+                dwq.add([dpre], [x_in], None, [G(c0.weight)], ct, [G(c0.bias)])
                 cur = nxt
             if dm is not None:
                 Mm = spec.mh_count
@@ -427,7 +450,7 @@ class _FusedDecoder(Function):
                 L.gemm(M=R, N=d, K=d, A=[dqm[m] for m in range(Mm)], B=[mp.q_proj.weight.detach() for mp in mps],
                        Cs=[nxt] + [None] * (Mm - 1), aux=[cur] + [None] * (Mm - 1), act_grad="add", ct=ct, lda=d, ldb=d,
                        ldc=d, transB=True, kconcat=Mm)
-                _dw_acc([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct,
+                dwq.add([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct,
                         [G(mp.q_proj.bias) for mp in mps])
                 cur = nxt
             return cur
@@ -450,11 +473,11 @@ class _FusedDecoder(Function):
             L.gemm(M=R, N=F_, K=d, A=[dy], B=[ffn.linear2.weight.detach()], Cs=[dhp],
                    aux=[rec["pre"] if spec.act == "gelu" else rec["h"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
                    transB=True)
-            _dw_acc([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
+            dwq.add([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
             dx2 = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
             L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], aux=[dx2r], act_grad="add", ct=ct,
                    lda=F_, ldb=d, ldc=d, transB=True)
-            _dw_acc([dhp], [x2], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
+            dwq.add([dhp], [x2], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
             # ---------------- self-attention backward
             sa = layer.self_attn
             if spec.spatial:
@@ -475,7 +498,7 @@ class _FusedDecoder(Function):
             df = df[0]
             do_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
             L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
-            _dw_acc([df], [rec["o_s"]], None, [GWo], ct, [Gbo])
+            dwq.add([df], [rec["o_s"]], None, [GWo], ct, [Gbo])
             qkv = rec["qkv"]
             dqkv = torch.empty(3, B, Nq, d, dtype=ad, device=dev)
             delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
@@ -496,7 +519,7 @@ class _FusedDecoder(Function):
             L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1]], B=[Wl[0], Wl[1]], Cs=[dx1, None], C2=[gqk, None],
                    aux=[tmpv, None], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=2)
             dqpos_parts.append(gqk)
-            _dw_acc([dqkv[0], dqkv[1], dqkv[2]], [x1] * 3, [qpos, qpos, None], GW, ct, Gb)
+            dwq.add([dqkv[0], dqkv[1], dqkv[2]], [x1] * 3, [qpos, qpos, None], GW, ct, Gb)
             # ---------------- cross-attention backward (M memories per launch)
             cl = cas[i]
             dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
@@ -505,7 +528,7 @@ class _FusedDecoder(Function):
             do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
             L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
                    Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
-            _dw_acc([dop[m] for m in range(M)], [rec["o_all"][m] for m in range(M)], None,
+            dwq.add([dop[m] for m in range(M)], [rec["o_all"][m] for m in range(M)], None,
                     [G(ca.multihead_attn.out_proj.weight) for ca in cl], ct,
                     [G(ca.multihead_attn.out_proj.bias) for ca in cl])
             dq_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
@@ -523,7 +546,7 @@ class _FusedDecoder(Function):
                    C2=[gq] + [None] * (M - 1), aux=[dxr] + [None] * (M - 1), act_grad="add", ct=ct, lda=d, ldb=d, ldc=d,
                    transB=True, kconcat=M)
             dqpos_parts.append(gq)
-            _dw_acc([dq_all[m] for m in range(M)], [x_in] * M, [qpos] * M,
+            dwq.add([dq_all[m] for m in range(M)], [x_in] * M, [qpos] * M,
                     [G(ca.multihead_attn.in_proj_weight)[:d] for ca in cl], ct,
                     [G(ca.multihead_attn.in_proj_bias)[:d] for ca in cl])
             dx = dxn
@@ -546,7 +569,7 @@ class _FusedDecoder(Function):
                 X2 += [ctx.kin2[j], None]
                 GWs += [gw[d:2 * d], gw[2 * d:]]
                 Gbs += [gb[d:2 * d], gb[2 * d:]]
-        _dw_acc(Akv, Xf, X2, GWs, ct, Gbs)
+        dwq.add(Akv, Xf, X2, GWs, ct, Gbs)
         # d feat_m = sum_a (dK_{a,m} Wk + dV_{a,m} Wv) [+ mask-head key path]
         for j in range(M):
             if not need_feat[j]:
@@ -558,7 +581,7 @@ class _FusedDecoder(Function):
                 dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
                 Aj.append(dkm)
                 Bj.append(mp.k_proj.weight.detach())
-                _dw_acc([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
+                dwq.add([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
             out = None
             for s in range(0, len(Aj), MAXG):
                 nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
@@ -573,7 +596,7 @@ class _FusedDecoder(Function):
                 if not need_feat[j]:
                     mp = list(spec.mh.mask_pred_list)[j]
                     dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
-                    _dw_acc([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
+                    dwq.add([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
         dpos = None
         if pos is not None and ctx.needs_input_grad[4]:
             Ak, Bk = Akv[0::2], Bkv[0::2]
@@ -587,6 +610,7 @@ class _FusedDecoder(Function):
         dqpos = None
         if ctx.needs_input_grad[2]:
             dqpos = torch.stack(dqpos_parts, 0).sum(0) if len(dqpos_parts) > 1 else dqpos_parts[0]
+        dwq.flush()
         dx0 = dx if ctx.needs_input_grad[1] else None
         pgrads = [gv[id(p)] if p.requires_grad else None for p in params]
         return (None, dx0, dqpos, None, dpos, None, None, None, None, *dfeats, *([None] * M), *pgrads)
