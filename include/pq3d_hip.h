@@ -168,6 +168,10 @@ typedef struct {
   float* dgamma[PQ3D_MAX_GROUPS];
   float* dbeta[PQ3D_MAX_GROUPS];
   int32_t accumulate;             /* != 0: dgamma/dbeta are accumulated onto (not zeroed by the call) */
+  int32_t independent;            /* != 0: the M branches are independent problems sharing one launch:
+                                     ys[m] = LN_m(x + o_m) (no sum, coef ignored); backward reads dys[m], dx unused */
+  void* ys[PQ3D_MAX_GROUPS];
+  const float* dys[PQ3D_MAX_GROUPS];
 } pq3d_ln_desc;
 
 int pq3d_add_ln_fwd(const pq3d_ln_desc* d, void* stream);

@@ -59,7 +59,8 @@ class LnDesc(C.Structure):
         ("x", C.c_void_p), ("o", C.c_void_p * MAXG), ("gamma", C.c_void_p * MAXG), ("beta", C.c_void_p * MAXG),
         ("coef", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
         ("dy", C.c_void_p), ("dx", C.c_void_p), ("d_o", C.c_void_p * MAXG), ("dgamma", C.c_void_p * MAXG),
-        ("dbeta", C.c_void_p * MAXG), ("accumulate", C.c_int32),
+        ("dbeta", C.c_void_p * MAXG), ("accumulate", C.c_int32), ("independent", C.c_int32),
+        ("ys", C.c_void_p * MAXG), ("dys", C.c_void_p * MAXG),
     ]
 
 

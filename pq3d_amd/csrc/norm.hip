@@ -40,7 +40,8 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
     y[j] = 0.f;
   }
   const long scene = row / d.rows_per_scene, nscene = d.R / d.rows_per_scene;
-  for (int m = 0; m < d.M; ++m) {
+  const int mlo = d.independent ? blockIdx.y : 0, mhi = d.independent ? blockIdx.y + 1 : d.M;
+  for (int m = mlo; m < mhi; ++m) {
     float v[PL];
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
       v[j] = c < d.d ? xr[j] + load_elem(d.o[m], d.dt_o, base + c) : 0.f;
     }
     const RowStats st = row_stats<PL>(v, d.d, lane, d.eps);
-    const float w = d.coef ? d.coef[m * nscene + scene] : 1.f / (float)d.M;
+    const float w = d.independent ? 1.f : (d.coef ? d.coef[m * nscene + scene] : 1.f / (float)d.M);
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
       const int c = lane + 64 * j;
@@ -59,10 +60,11 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
       d.rstd[(long)m * d.R + row] = st.rstd;
     }
   }
+  void* yout = d.independent ? d.ys[blockIdx.y] : d.y;
 #pragma unroll
   for (int j = 0; j < PL; ++j) {
     const int c = lane + 64 * j;
-    if (c < d.d) store_elem(d.y, d.dt_y, base + c, y[j]);
+    if (c < d.d) store_elem(yout, d.dt_y, base + c, y[j]);
   }
 }
 
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
     gam[j] = c < d.d ? d.gamma[m][c] : 0.f;
   }
   // software-pipelined over rows: the three row loads of the NEXT row are in flight while this row is reduced
+  const float* dyp = d.independent ? d.dys[m] : d.dy;
   float nv[PL], ndy[PL];
   auto fetch = [&](long row) {
     const long base = row * d.d;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
       const int c = lane + 64 * j;
       if (c < d.d) {
         nv[j] = (d.x ? load_elem(d.x, d.dt_x, base + c) : 0.f) + load_elem(d.o[m], d.dt_o, base + c);
-        ndy[j] = d.dy[base + c];
+        ndy[j] = dyp[base + c];
       } else { nv[j] = 0.f; ndy[j] = 0.f; }
     }
   };
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
 #pragma unroll
     for (int j = 0; j < PL; ++j) { v[j] = nv[j]; dyr[j] = ndy[j]; }
     const float mean = d.mean[(long)m * d.R + row], rstd = d.rstd[(long)m * d.R + row];
-    const float w = d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M;
+    const float w = d.independent ? 1.f : (d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M);
     if (row + nwaves < d.R) fetch(row + nwaves);
     float xh[PL], dz[PL];
     float s1 = 0.f, s2 = 0.f;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
       if (c < d.d) {
         const float g = rstd * (dz[j] - s1 - xh[j] * s2);
         d.d_o[m][base + c] = g;
-        if (d.dx) {
+        if (d.dx && !d.independent) {
           if (d.M == 1) d.dx[base + c] = g;
           else unsafeAtomicAdd(&d.dx[base + c], g);
         }
@@ -162,7 +165,9 @@ int check_ln(const pq3d_ln_desc& d, bool bwd) {
     PQ_CHECK_ARG(d.o[m] && d.gamma[m] && d.beta[m], "pq3d_add_ln: null o/gamma/beta");
     if (bwd) PQ_CHECK_ARG(d.d_o[m] && d.dgamma[m] && d.dbeta[m], "pq3d_add_ln_bwd: null grads");
   }
-  if (bwd) PQ_CHECK_ARG(d.dy != nullptr, "pq3d_add_ln_bwd: null dy");
+  if (d.independent) {
+    for (int m = 0; m < d.M; ++m) PQ_CHECK_ARG(bwd ? d.dys[m] != nullptr : d.ys[m] != nullptr, "pq3d_add_ln: null ys/dys");
+  } else if (bwd) PQ_CHECK_ARG(d.dy != nullptr, "pq3d_add_ln_bwd: null dy");
   else PQ_CHECK_ARG(d.y != nullptr, "pq3d_add_ln_fwd: null y");
   return 0;
 }
@@ -182,7 +187,7 @@ extern "C" int pq3d_add_ln_fwd(const pq3d_ln_desc* dp, void* stream) {
   if (int e = check_ln(d, false)) return e;
   if (d.R == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)((d.R + WPB - 1) / WPB));
+  dim3 grid((unsigned)((d.R + WPB - 1) / WPB), d.independent ? d.M : 1);
   LN_DISPATCH(add_ln_fwd_kernel, grid)
   PQ_LAUNCH_CHECK();
   return 0;
@@ -199,7 +204,7 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
     if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
   }
   if (d.R == 0) return 0;
-  if (d.dx && d.M > 1) {
+  if (d.dx && d.M > 1 && !d.independent) {
     hipError_t e = hipMemsetAsync(d.dx, 0, sizeof(float) * (size_t)d.R * d.d, s);
     if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
   }

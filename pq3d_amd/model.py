@@ -122,23 +122,57 @@ class Query3DUnified(nn.Module):
                                      eps=self.coord_encoder[1].eps, coef=coef)
         return self.coord_encoder(locs[:, :, :3], input_range=[coord_min, coord_max])
 
+    def _pos_pair(self, query_locs, seg_locs, coord_min, coord_max):
+        """CoordinateEncoder on queries and segments in ONE Linear+LN pass (same weights, rows concatenated)."""
+        ce = self.coord_encoder
+        B, Nq, Ns, d = query_locs.shape[0], query_locs.shape[1], seg_locs.shape[1], self.hidden_size
+        if not hasattr(ce, "feat_proj"):
+            return ce(query_locs[:, :, :3], [coord_min, coord_max]), ce(seg_locs[:, :, :3], [coord_min, coord_max])
+        buf = torch.empty(B * (Nq + Ns), d, dtype=torch.float32, device=query_locs.device)
+        ops.fourier(query_locs[:, :, :3], coord_min, coord_max, ce.pos_enc.gauss_B, out=buf[:B * Nq].view(B, Nq, d))
+        ops.fourier(seg_locs[:, :, :3], coord_min, coord_max, ce.pos_enc.gauss_B, out=buf[B * Nq:].view(B, Ns, d))
+        y = M.linear_ln_forward(ce.feat_proj, buf, self.ct)
+        return y[:B * Nq].view(B, Nq, d), y[B * Nq:].view(B, Ns, d)
+
+    def _encode_scene_memories(self, data_dict):
+        """ObjectEncoder projections of all scene memories; same-shape encoders share grouped launches."""
+        names = [m for m in self.inputs if m in ("mv", "pc", "voxel")]
+        encs = [getattr(self, m + "_encoder") for m in names]
+        xs = [data_dict[m + "_seg_fts"] for m in names]
+        same = len(names) > 1 and all(isinstance(e, M.ObjectEncoder) and e.use_projection and not hasattr(e, "cls_head")
+                                      for e in encs) and len({tuple(x.shape) for x in xs}) == 1
+        if not same:
+            out = {}
+            for m, e, x in zip(names, encs, xs):
+                r = e(obj_feats=x) if m != "voxel" else e(x)
+                out[m] = r[0] if isinstance(r, tuple) else r
+            return out
+        seqs = [e.input_feat_proj for e in encs]
+        ys = ops.linear_ln_group(xs, [q[0].weight for q in seqs], [q[0].bias for q in seqs],
+                                 [q[1].weight for q in seqs], [q[1].bias for q in seqs], ct=self.ct, eps=seqs[0][1].eps)
+        return dict(zip(names, ys))
+
     def forward(self, data_dict):
         input_dict = {}
         mask = data_dict["query_pad_masks"].logical_not()
         query_locs = data_dict["query_locs"][:, :, :self.dim_loc]
         coord_min, coord_max = data_dict["coord_min"], data_dict["coord_max"]
-        query_pos = self._pos(query_locs, coord_min, coord_max)
+        if self.dim_loc > 3:
+            query_pos = self._pos(query_locs, coord_min, coord_max)
+            # NB dim_loc > 3: the reference adds the box embedding to fts_pos twice (query3d_unified.py:128,131-132)
+            fts_pos = self._pos(data_dict["seg_center"], coord_min, coord_max, box_times=2)
+        else:
+            query_pos, fts_pos = self._pos_pair(query_locs, data_dict["seg_center"], coord_min, coord_max)
         input_dict["query"] = (torch.zeros_like(query_pos), mask, query_pos)
-        # NB dim_loc > 3: the reference adds the box embedding to fts_pos twice (query3d_unified.py:128,131-132)
-        fts_pos = self._pos(data_dict["seg_center"], coord_min, coord_max, box_times=2)
+        enc_out = self._encode_scene_memories(data_dict)
         for inp in self.inputs:
             if inp == "prompt":
                 feat, mask, pos = data_dict["prompt_feat"], data_dict["prompt_pad_masks"].logical_not(), None
             elif inp in ("mv", "pc"):
-                feat = getattr(self, inp + "_encoder")(obj_feats=data_dict[inp + "_seg_fts"])
+                feat = enc_out[inp]
                 mask, pos = data_dict[inp + "_seg_pad_masks"].logical_not(), fts_pos
             elif inp == "voxel":
-                feat = self.voxel_encoder(data_dict["voxel_seg_fts"])
+                feat = enc_out[inp]
                 mask, pos = data_dict["voxel_seg_pad_masks"].logical_not(), fts_pos
             else:
                 raise NotImplementedError(f"Unknow input type: {inp}")

@@ -82,14 +82,15 @@ def pairwise_locs(centers: torch.Tensor, eps: float = 1e-10) -> torch.Tensor:
     return out
 
 
-def fourier(xyz: torch.Tensor, cmin: torch.Tensor, cmax: torch.Tensor, gauss_B: torch.Tensor) -> torch.Tensor:
+def fourier(xyz: torch.Tensor, cmin: torch.Tensor, cmax: torch.Tensor, gauss_B: torch.Tensor, out=None) -> torch.Tensor:
     """Fourier features [sin | cos] of normalised coordinates (position_embedding.py:127-156); no grad."""
     assert xyz.dtype == torch.float32 and xyz.stride(-1) == 1
     B, N = xyz.shape[:2]
     if xyz.stride(0) != N * xyz.stride(1):
         xyz = xyz.contiguous()
     half = gauss_B.shape[1]
-    out = _empty(B, N, 2 * half, dtype=torch.float32, device=xyz.device)
+    if out is None:
+        out = _empty(B, N, 2 * half, dtype=torch.float32, device=xyz.device)
     L.check(L.lib().pq3d_fourier(L.ptr(xyz), xyz.stride(1), L.ptr(_c(cmin.float())), L.ptr(_c(cmax.float())),
                                  L.ptr(_c(gauss_B)), L.ptr(out), B, N, half, L.stream()), "pq3d_fourier")
     return out
@@ -430,3 +431,80 @@ def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch
     (pcd_mask3d_encoder.py:149)."""
     assert src.dtype == torch.float32 and index.dtype == torch.int64 and src.dim() == 2
     return _ScatterMean.apply(src, index, int(dim_size))
+
+
+# ------------------------------------------------------------------------------------------------ grouped Linear + LN
+class _LinearLNGroup(Function):
+    """G independent nn.Sequential(Linear, LayerNorm) encoders of identical shape in 2 launches forward
+    (grouped GEMM, independent-branch LayerNorm) and 2 backward (LayerNorm backward, grouped weight-gradient GEMM with
+    fused bias gradients) -- ObjectEncoder.input_feat_proj of every scene memory (object_encoder.py:34,71)."""
+
+    @staticmethod
+    def forward(ctx, ct, eps, G, need_dx, *t):
+        xs = [_c(a) for a in t[:G]]
+        Ws, bs, gam, bet = t[G:2 * G], t[2 * G:3 * G], t[3 * G:4 * G], t[4 * G:5 * G]
+        K = xs[0].shape[-1]
+        R = xs[0].numel() // K
+        N = Ws[0].shape[0]
+        dev = xs[0].device
+        lin = _empty(G, *xs[0].shape[:-1], N, dtype=torch.float32, device=dev)
+        L.gemm(M=R, N=N, K=K, A=xs, B=[_c(w) for w in Ws], bias=list(bs), Cs=[lin[g] for g in range(G)], ct=ct, lda=K,
+               ldb=K, ldc=N)
+        ys = _empty(G, *xs[0].shape[:-1], N, dtype=torch.float32, device=dev)
+        mean = _empty(G, R, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        d = _ln_desc(None, [lin[g] for g in range(G)], [_c(a) for a in gam], [_c(a) for a in bet], None, eps, R, None,
+                     mean, rstd)
+        d.independent = 1
+        d.dt_y = F32
+        for g in range(G):
+            d.ys[g] = L.ptr(ys[g])
+        L.check(timed("pq3d_add_ln_fwd", f"R{R}d{N}M{G}i", 0.0, 2.0 * G * R * N * 4, L.lib().pq3d_add_ln_fwd, C.byref(d),
+                      L.stream()), "pq3d_add_ln_fwd")
+        ctx.save_for_backward(lin, mean, rstd, *xs, *Ws, *gam, *bet)
+        ctx.cfg = (ct, eps, G, need_dx)
+        return tuple(ys[g] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        ct, eps, G, need_dx = ctx.cfg
+        lin, mean, rstd = ctx.saved_tensors[:3]
+        t = ctx.saved_tensors[3:]
+        xs, Ws, gam, bet = t[:G], t[G:2 * G], t[2 * G:3 * G], t[3 * G:4 * G]
+        K = xs[0].shape[-1]
+        R = xs[0].numel() // K
+        N = Ws[0].shape[0]
+        dev = lin.device
+        dys = [(_c(g).float() if g is not None else torch.zeros(lin.shape[1:], device=dev)) for g in dys]
+        dlin = _empty(lin.shape, dtype=torch.float32, device=dev)
+        dgs = [torch.empty_like(a) for a in gam]
+        dbs = [torch.empty_like(a) for a in bet]
+        d = _ln_desc(None, [lin[g] for g in range(G)], list(gam), list(bet), None, eps, R, None, mean, rstd)
+        d.independent = 1
+        for g in range(G):
+            d.dys[g], d.d_o[g], d.dgamma[g], d.dbeta[g] = L.ptr(dys[g]), L.ptr(dlin[g]), L.ptr(dgs[g]), L.ptr(dbs[g])
+        L.check(timed("pq3d_add_ln_bwd", f"R{R}d{N}M{G}i", 0.0, 3.0 * G * R * N * 4, L.lib().pq3d_add_ln_bwd, C.byref(d),
+                      L.stream()), "pq3d_add_ln_bwd")
+        dWs = [_empty(N, K, dtype=torch.float32, device=dev) for _ in range(G)]
+        dbl = [_empty(N, dtype=torch.float32, device=dev) for _ in range(G)]
+        tiles = ((N + 63) // 64) * ((K + 63) // 64)
+        epl = 8 if ct == BF16 else 4
+        fuse = N % epl == 0 and K % epl == 0 and all(x.data_ptr() % 16 == 0 for x in xs)
+        L.gemm(M=N, N=K, K=R, A=[dlin[g] for g in range(G)], B=list(xs), Cs=dWs, ct=ct, lda=N, ldb=K, ldc=K, transA=True,
+               transB=True, splitk=max(2, _splitk(tiles * G, R, ct)), colsum=dbl if fuse else None)
+        if not fuse:
+            dbl = [colsum(dlin[g].view(R, N)) for g in range(G)]
+        dxs = [None] * G
+        if need_dx:
+            dxb = _empty(G, *xs[0].shape, dtype=xs[0].dtype, device=dev)
+            L.gemm(M=R, N=K, K=N, A=[dlin[g] for g in range(G)], B=list(Ws), Cs=[dxb[g] for g in range(G)], ct=ct,
+                   lda=N, ldb=K, ldc=K, transB=True)
+            dxs = [dxb[g] for g in range(G)]
+        return (None, None, None, None, *dxs, *dWs, *dbl, *dgs, *dbs)
+
+
+def linear_ln_group(xs, Ws, bs, gammas, betas, *, ct: int, eps: float = 1e-5):
+    """[LayerNorm_g(x_g @ W_g^T + b_g)] for G same-shape encoders in grouped launches."""
+    G = len(xs)
+    need_dx = any(x.requires_grad for x in xs)
+    return _LinearLNGroup.apply(ct, float(eps), G, need_dx, *xs, *Ws, *bs, *gammas, *betas)
