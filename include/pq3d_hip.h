@@ -198,6 +198,10 @@ int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty, int64_t R,
 int pq3d_add_cast(const float* const* a, const float* const* b, void* const* out, int32_t groups, int32_t dt_out,
                   int64_t n, void* stream);
 
+/* out[r,:] = x[r,:] + bias[:]  (fp32): seeds the output of a split-K GEMM with residual + bias so that
+ * LayerNorm(x + h W2^T + b2) (query_encoder.py:385-387) needs no separate epilogue pass. */
+int pq3d_bias_add_rows(const float* x, const float* bias, float* out, int64_t R, int64_t N, void* stream);
+
 /* dpre = dy * act'(saved): ReLU: saved = activation output (or pre-activation), GELU: saved = pre-activation. */
 int pq3d_act_bwd(const void* dy, int32_t dt_dy, const void* saved, int32_t dt_saved, void* dpre, int32_t dt_dpre,
                  int32_t act, int64_t n, void* stream);

@@ -80,6 +80,7 @@ _SIGS = {
                         C.c_void_p, C.c_void_p],
     "pq3d_add_cast": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                       C.c_int64, C.c_void_p],
+    "pq3d_bias_add_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_act_bwd": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                      C.c_void_p],
     "pq3d_fill_cols": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p],

@@ -73,6 +73,15 @@ __global__ void add_cast_kernel(const AddCastPtrs p, int dt_out, long n) {
   }
 }
 
+__global__ void bias_add_rows_kernel(const float* x, const float* bias, float* out, long R, long N) {
+  const long n4 = N / 4, total = R * n4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long c = (i % n4) * 4;
+    const float4 a = *(const float4*)(x + i * 4), b = *(const float4*)(bias + c);
+    *(float4*)(out + i * 4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
 __global__ void act_bwd_kernel(const void* dy, int dt_dy, const void* saved, int dt_s, void* dpre, int dt_o, int act,
                                long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -331,6 +340,15 @@ extern "C" int pq3d_add_cast(const float* const* a, const float* const* b, void*
   if (n == 0) return 0;
   hipLaunchKernelGGL(add_cast_kernel, dim3(grid1d(n / 8, 256, 1024), groups), dim3(256), 0, (hipStream_t)stream, p,
                      dt_out, (long)n);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_bias_add_rows(const float* x, const float* bias, float* out, int64_t R, int64_t N, void* stream) {
+  PQ_CHECK_ARG(x && bias && out && R >= 0 && N >= 4 && (N % 4) == 0, "pq3d_bias_add_rows: bad args (N % 4 == 0)");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(bias_add_rows_kernel, dim3(grid1d(R * N / 4)), dim3(256), 0, (hipStream_t)stream, x, bias, out,
+                     (long)R, (long)N);
   PQ_LAUNCH_CHECK();
   return 0;
 }

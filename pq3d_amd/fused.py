@@ -163,14 +163,15 @@ def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.fl
     return y, mean, rstd
 
 
-def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dgs, dbs, want_dx=True):
-    """Returns (dx or None, d_o [M,...] fp32 stacked); dgamma/dbeta accumulate into the arena views dgs/dbs."""
+def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dgs, dbs, want_dx=True, dup_dx=False):
+    """Returns (dx or None, d_o [M,...] fp32 stacked); dgamma/dbeta accumulate into the arena views dgs/dbs.
+    dup_dx: also write the (single-branch) input gradient to a second buffer even without a residual input."""
     M = len(os_)
     dm = os_[0].shape[-1]
     R = os_[0].numel() // dm
     dev = dy.device
     d_o = torch.empty(M, *os_[0].shape, dtype=torch.float32, device=dev)
-    dx = torch.empty(os_[0].shape, dtype=torch.float32, device=dev) if (x is not None and want_dx) else None
+    dx = torch.empty(os_[0].shape, dtype=torch.float32, device=dev) if ((x is not None and want_dx) or dup_dx) else None
     d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd)
     d.dy, d.dx, d.accumulate = L.ptr(dy), L.ptr(dx), 1
     for m in range(M):
@@ -336,11 +337,19 @@ class _FusedDecoder(Function):
                 pre = torch.empty_like(h) if spec.act == "gelu" else None
                 L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
                        C2=[pre], ct=ct, lda=d, ldb=d, ldc=F_, act=spec.act)
-                y = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()], Cs=[y],
-                       ct=ct, lda=F_, ldb=F_, ldc=d)
-                x3, mean_f, rstd_f = _ln_fwd(x2, [y], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq)
-                rec.update(h=h, pre=pre, y=y, mean_f=mean_f, rstd_f=rstd_f)
+                # z = x2 + b2 + h W2^T: K = F is long and the grid small, so K is split 4 ways (atomics) onto an output
+                # seeded with residual + bias; LayerNorm then reads one tensor
+                z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                if d % 4 == 0:
+                    L.check(L.lib().pq3d_bias_add_rows(L.ptr(x2), L.ptr(ffn.linear2.bias.detach()), L.ptr(z), R, d,
+                                                       L.stream()), "pq3d_bias_add_rows")
+                    L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], Cs=[z], ct=ct, lda=F_, ldb=F_, ldc=d,
+                           splitk=4, accumulate=True)
+                else:
+                    L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()],
+                           Cs=[z], aux=[x2], act_grad="add", ct=ct, lda=F_, ldb=F_, ldc=d)
+                x3, mean_f, rstd_f = _ln_fwd(None, [z], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq)
+                rec.update(h=h, pre=pre, z=z, mean_f=mean_f, rstd_f=rstd_f)
                 tape.append(rec)
                 x = x3
         final_rec = None
@@ -466,17 +475,18 @@ class _FusedDecoder(Function):
             # ---------------- FFN backward
             ffn = layer.ffn
             F_ = ffn.linear1.out_features
-            dx2r, dy = _ln_bwd(x2, [rec["y"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None,
-                               Nq, rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)])
-            dy = dy[0]
+            dx2r, dy = _ln_bwd(None, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None,
+                               Nq, rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
+                               dup_dx=True)
+            dy = dy[0]   # d z: gradient of the linear2 output AND (second copy dx2r) of the residual branch
             dhp = torch.empty(B, Nq, F_, dtype=ad, device=dev)
             L.gemm(M=R, N=F_, K=d, A=[dy], B=[ffn.linear2.weight.detach()], Cs=[dhp],
                    aux=[rec["pre"] if spec.act == "gelu" else rec["h"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
                    transB=True)
             dwq.add([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
-            dx2 = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-            L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], aux=[dx2r], act_grad="add", ct=ct,
-                   lda=F_, ldb=d, ldc=d, transB=True)
+            dx2 = dx2r   # dx2 = dx2r + dhp W1: split-K accumulated in place onto the residual-branch gradient
+            L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], ct=ct, lda=F_, ldb=d, ldc=d,
+                   transB=True, splitk=4, accumulate=True)
             dwq.add([dhp], [x2], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
             # ---------------- self-attention backward
             sa = layer.self_attn
