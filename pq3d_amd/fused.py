@@ -337,17 +337,12 @@ class _FusedDecoder(Function):
                 pre = torch.empty_like(h) if spec.act == "gelu" else None
                 L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
                        C2=[pre], ct=ct, lda=d, ldb=d, ldc=F_, act=spec.act)
-                # z = x2 + b2 + h W2^T: K = F is long and the grid small, so K is split 4 ways (atomics) onto an output
-                # seeded with residual + bias; LayerNorm then reads one tensor
+                # z = x2 + b2 + h W2^T in one GEMM (residual through the "+aux" epilogue): LayerNorm then reads one
+                # tensor.  Deliberately NOT split-K: atomics would make the forward pass non-deterministic at rounding
+                # level and cost the bit-exact padding-invariance / scene-independence properties (tests).
                 z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                if d % 4 == 0:
-                    L.check(L.lib().pq3d_bias_add_rows(L.ptr(x2), L.ptr(ffn.linear2.bias.detach()), L.ptr(z), R, d,
-                                                       L.stream()), "pq3d_bias_add_rows")
-                    L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], Cs=[z], ct=ct, lda=F_, ldb=F_, ldc=d,
-                           splitk=4, accumulate=True)
-                else:
-                    L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()],
-                           Cs=[z], aux=[x2], act_grad="add", ct=ct, lda=F_, ldb=F_, ldc=d)
+                L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()],
+                       Cs=[z], aux=[x2], act_grad="add", ct=ct, lda=F_, ldb=F_, ldc=d)
                 x3, mean_f, rstd_f = _ln_fwd(None, [z], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq)
                 rec.update(h=h, pre=pre, z=z, mean_f=mean_f, rstd_f=rstd_f)
                 tape.append(rec)
