@@ -155,6 +155,46 @@ template <typename CT, int DH> PQ_DEV void zero_lds(CT* p, int n, int tid, int n
   for (int i = tid; i < n; i += nthreads) p[i] = Cvt<CT>::from(0.f);
 }
 
+// Cross-lane reductions over the 4 lane groups (lanes l, l^16, l^32, l^48) with the gfx950 VALU lane swaps instead of
+// LDS-crossbar shuffles: permlaneN_swap(x, x) leaves {x[l], x[l^N]} in the two results on every lane (measured,
+// tools/probes/permlane_probe.hip), so one swap + one max/add is a complete xor-N step.
+typedef unsigned u32pair __attribute__((ext_vector_type(2)));
+PQ_DEV float group_max(float v) {
+  u32pair a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u32pair b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+PQ_DEV float group_sum(float v) {
+  u32pair a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  u32pair b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// Key blocks (64 keys) that contain at least one non-padded key, in order; fully padded blocks contribute nothing
+// to softmax / gradients and are skipped (loads and MFMAs).  Built once per workgroup from the key-padding mask.
+// Returns the number of active blocks; act[] (LDS) holds their indices.  All threads must call it.
+PQ_DEV int active_key_blocks(const uint8_t* kpm_row, int Lk, uint8_t* flag /*[nkb]*/, uint16_t* act /*[nkb]*/, int* cnt,
+                             int tid, int nthreads) {
+  const int nkb = (Lk + KB - 1) / KB;
+  if (!kpm_row) return -nkb;   // no key-padding mask: every block is active (negative = identity mapping)
+  for (int i = tid; i < nkb; i += nthreads) flag[i] = 0;
+  __syncthreads();
+  for (int j = tid; j < Lk; j += nthreads)
+    if (!kpm_row[j]) flag[j / KB] = 1;   // benign race: all writers store 1
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int i = 0; i < nkb; ++i)
+      if (flag[i]) act[n++] = (uint16_t)i;
+    *cnt = n;
+  }
+  __syncthreads();
+  return *cnt;
+}
+constexpr int MAXKB = 256;  // key blocks per scene supported by the skip list (Lk <= 16384)
+
 // Software pipeline shared by the three attention kernels: LDS double buffering (ONE barrier per tile) and two
 // register sets, so the global loads of tile t+3 are issued while tile t is being multiplied and are only waited for
 // two iterations later.  load(tile, set) issues loads into register set `set`; store(set, buf) writes that set to LDS
@@ -234,6 +274,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
   __shared__ __attribute__((aligned(16))) CT Kbuf[2 * KSZ];
   __shared__ __attribute__((aligned(16))) CT Vbuf[2 * VSZ];
   __shared__ __attribute__((aligned(4))) uint8_t kpm_buf[2 * KB];
+  __shared__ uint8_t blk_flag[MAXKB];
+  __shared__ uint16_t blk_act[MAXKB];
+  __shared__ int blk_cnt;
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -243,11 +286,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
 
   if (A::DHK > DH) { zero_lds<CT, DH>(Kbuf, 2 * KSZ, tid, nthreads); __syncthreads(); }
+  const int nact = active_key_blocks(d.kpm ? d.kpm + (long)b * d.Lk : nullptr, d.Lk, blk_flag, blk_act, &blk_cnt, tid,
+                                     nthreads);
+  auto kblock = [&](int t) { return nact < 0 ? t : (int)blk_act[t]; };
 
   u32x4 qf[A::NS];
   row_frags<CT, DH>(qf, d.q, (long)b * d.q_sb + (long)min(myq, d.Lq - 1) * d.q_sl + (long)h * d.q_sh, lg);
 
-  float m = d.zero_attn ? 0.f : -1e30f, l = d.zero_attn ? 1.f : 0.f;
+  // m is uniform over the 4 lanes of a query; l is a PER-LANE partial row sum, reduced once after the loop
+  float m = d.zero_attn ? 0.f : -1e30f, l = (d.zero_attn && lg == 0) ? 1.f : 0.f;
   f32x4 acc[A::MT];
 #pragma unroll
   for (int mt = 0; mt < A::MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -260,7 +307,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
   uint8_t kpm_r[2] = {1, 1};
   auto load = [&](int t, auto set) {
     constexpr int S = decltype(set)::value;
-    const int k0 = t * KB;
+    const int k0 = kblock(t) * KB;
     kr[S].load(d.k, koff, d.k_sl, k0, d.Lk, tid);
     vr[S].load(d.v, voff, d.v_sl, k0, d.Lk, tid);
     if (tid < KB) kpm_r[S] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
@@ -277,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
     if (!wave_active) return;
     const CT* Ks = Kbuf + Bf * KSZ;
     const CT* Vs = Vbuf + Bf * VSZ;
-    const int k0 = t * KB;
+    const int k0 = kblock(t) * KB;
     float p[4][4];
     float mx = -INFINITY;
     MaskBias mb;
@@ -294,8 +341,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
         mx = fmaxf(mx, x);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = group_max(mx);
     const float m_new = fmaxf(m, mx);
     const float alpha = fexp<CT>(m - m_new);
     float rs = 0.f;
@@ -306,9 +352,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
         p[tt][r] = fexp<CT>(p[tt][r] - m_new);
         rs += p[tt][r];
       }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    l = l * alpha + rs;
+    l = l * alpha + rs;   // per-lane partial (alpha is uniform over the query's 4 lanes)
     m = m_new;
     u32x4 pf[PackP<CT, 4>::STEPS];
     PackP<CT, 4>::run(p, pf);
@@ -320,7 +364,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
         Mma<CT>::mma(acc[mt], tfrag_any<CT>(Vs, A::LDR, Vs, A::LDT, u, mt, li, lg), pf[u]);
     }
   };
-  pipeline2((d.Lk + KB - 1) / KB, load, store, compute);
+  pipeline2(nact < 0 ? -nact : nact, load, store, compute);
+  l = group_sum(l);
 
   if (qvalid) {
     const float inv = 1.f / l;
@@ -373,6 +418,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   __shared__ __attribute__((aligned(16))) CT Vbuf[2 * KSZ];
   __shared__ __attribute__((aligned(16))) CT Ktbuf[2 * TSZ];
   __shared__ __attribute__((aligned(4))) uint8_t kpm_buf[2 * KB];
+  __shared__ uint8_t blk_flag[MAXKB];
+  __shared__ uint16_t blk_act[MAXKB];
+  __shared__ int blk_cnt;
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -386,13 +434,32 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
     zero_lds<CT, DH>(Vbuf, 2 * KSZ, tid, nthreads);
     __syncthreads();
   }
-  u32x4 qf[A::NS], dof[A::NS];
+  const int nact = active_key_blocks(d.kpm ? d.kpm + (long)b * d.Lk : nullptr, d.Lk, blk_flag, blk_act, &blk_cnt, tid,
+                                     nthreads);
+  auto kblock = [&](int t) { return nact < 0 ? t : (int)blk_act[t]; };
+  u32x4 qf[A::NS], dof[A::NS], of[A::NS];
   const int cq = min(myq, d.Lq - 1);
   row_frags<CT, DH>(qf, d.q, (long)b * d.q_sb + (long)cq * d.q_sl + (long)h * d.q_sh, lg);
   row_frags<CT, DH>(dof, d.dout, (long)b * d.o_sb + (long)cq * d.o_sl + (long)h * d.o_sh, lg);
+  row_frags<CT, DH>(of, d.o, (long)b * d.o_sb + (long)cq * d.o_sl + (long)h * d.o_sh, lg);
   const long sidx = ((long)b * d.H + h) * d.Lq + myq;
   const float L = qvalid ? d.lse[sidx] : INFINITY;
-  const float Dl = qvalid ? d.delta[sidx] : 0.f;
+  // delta = rowsum(dO * O), fused here (the lane's dO/O fragments cover its dh slice; reduce over the 4 lane groups)
+  // and published for the dK/dV kernel that runs after this one
+  float Dl = 0.f;
+#pragma unroll
+  for (int st = 0; st < A::NS; ++st)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (sizeof(CT) == 2) {
+        Dl += __uint_as_float(dof[st][j] << 16) * __uint_as_float(of[st][j] << 16);
+        Dl += __uint_as_float(dof[st][j] & 0xffff0000u) * __uint_as_float(of[st][j] & 0xffff0000u);
+      } else {
+        Dl += __uint_as_float(dof[st][j]) * __uint_as_float(of[st][j]);
+      }
+    }
+  Dl = group_sum(Dl);
+  if (qvalid && lg == 0) d.delta[sidx] = Dl;
 
   f32x4 acc[A::MT];
 #pragma unroll
@@ -407,7 +474,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   uint8_t kpm_r[2] = {1, 1};
   auto load = [&](int t, auto set) {
     constexpr int S = decltype(set)::value;
-    const int k0 = t * KB;
+    const int k0 = kblock(t) * KB;
     kr[S].load(d.k, koff, d.k_sl, k0, d.Lk, tid);
     vr[S].load(d.v, voff, d.v_sl, k0, d.Lk, tid);
     if (tid < KB) kpm_r[S] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
@@ -424,7 +491,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
     const CT* Ks = Kbuf + Bf * KSZ;
     const CT* Vs = Vbuf + Bf * KSZ;
     const CT* Kt = Ktbuf + Bf * TSZ;
-    const int k0 = t * KB;
+    const int k0 = kblock(t) * KB;
     float ds[4][4];
     MaskBias mb;
     fetch_mask_bias(mb, d, kpm_buf + Bf * KB, b, bm, h, myq, qvalid, ro, k0, lg);
@@ -464,7 +531,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
       for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
         Mma<CT>::mma(acc[mt], tfrag_any<CT>(Ks, A::LDR, Kt, A::LDT, u, mt, li, lg), dsf[u]);
   };
-  pipeline2((d.Lk + KB - 1) / KB, load, store, compute);
+  pipeline2(nact < 0 ? -nact : nact, load, store, compute);
+  if (dbrow && nact >= 0 && qvalid && wave_active) {   // bias gradient of skipped (fully padded) key blocks is zero
+    const int nkb = (d.Lk + KB - 1) / KB;
+    for (int kb = 0; kb < nkb; ++kb)
+      if (!blk_flag[kb])
+        for (int j = lg; j < KB; j += 4)
+          if (kb * KB + j < d.Lk) dbrow[kb * KB + j] = 0.f;
+  }
 
   if (qvalid) {
     const long off = (long)b * d.q_sb + (long)myq * d.q_sl + (long)h * d.q_sh;
@@ -504,6 +578,14 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   row_frags<CT, DH>(kf, d.k, (long)b * d.k_sb + (long)ckey * d.k_sl + (long)h * d.k_sh, lg);
   row_frags<CT, DH>(vf, d.v, (long)b * d.v_sb + (long)ckey * d.v_sl + (long)h * d.v_sh, lg);
   const bool kmasked = kvalid ? (d.kpm ? d.kpm[(long)b * d.Lk + key] != 0 : false) : true;
+  if (__syncthreads_and(kmasked)) {   // whole 64-key chunk padded: its dK, dV are exactly zero
+    if (kvalid) {
+      const long ko = (long)b * d.k_sb + (long)key * d.k_sl + (long)h * d.k_sh;
+      const long vo = (long)b * d.v_sb + (long)key * d.v_sl + (long)h * d.v_sh;
+      for (int c = lg; c < DH; c += 4) { store_elem(d.dk, d.dt, ko + c, 0.f); store_elem(d.dv, d.dt, vo + c, 0.f); }
+    }
+    return;
+  }
 
   f32x4 accK[A::MT], accV[A::MT];
 #pragma unroll
@@ -637,6 +719,7 @@ int check_desc(const pq3d_attn_desc& d) {
     for (const void* p : ps) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_attn: q/k/v/o must be 16-byte aligned");
   }
   PQ_CHECK_ARG(d.Lk > 0 || d.zero_attn, "pq3d_attn: Lk == 0 needs zero_attn");
+  PQ_CHECK_ARG(d.Lk <= MAXKB * KB, "pq3d_attn: Lk too large for the key-block skip list");
   return 0;
 }
 
@@ -648,9 +731,7 @@ template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream
   return 0;
 }
 template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream_t s) {
-  const long total = (long)d.B * d.H * d.Lq;
-  hipLaunchKernelGGL((attn_delta_kernel<CT, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
-  const int tiles = (d.Lq + 15) / 16;
+  const int tiles = (d.Lq + 15) / 16;   // the dQ kernel also produces delta = rowsum(dO * O) for the dK/dV kernel
   if (tiles > 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8>), dim3((tiles + 7) / 8, d.H, d.B), dim3(512), 0, s, d);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4>), dim3(1, d.H, d.B), dim3(256), 0, s, d);
   if (d.Lk > 0)
