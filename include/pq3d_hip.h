@@ -132,6 +132,12 @@ typedef struct {
   void* dq; void* dk; void* dv;
   float* delta;
   float* dbias;
+  /* key split: ksplit > 1 runs `ksplit` workgroups per (scene, head, query chunk), each over a slice of the key
+   * blocks, and a small combine kernel merges the partial softmax states / dQ sums.  `ws` is a caller-provided fp32
+   * workspace of at least ksplit * B * H * Lq * (dh + 2) elements.  Raises occupancy when B*H*ceil(Lq/128) is far
+   * below the CU count and shortens the serial key loop; results are deterministic.  dbias requires ksplit == 1. */
+  int32_t ksplit;
+  float* ws;
 } pq3d_attn_desc;
 
 int pq3d_attn_fwd(const pq3d_attn_desc* d, void* stream);

@@ -48,7 +48,7 @@ class AttnDesc(C.Structure):
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
         ("kpm", C.c_void_p), ("mask", C.c_void_p), ("row_open", C.c_void_p), ("bias", C.c_void_p),
         ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
-        ("delta", C.c_void_p), ("dbias", C.c_void_p),
+        ("delta", C.c_void_p), ("dbias", C.c_void_p), ("ksplit", C.c_int32), ("ws", C.c_void_p),
     ]
 
 

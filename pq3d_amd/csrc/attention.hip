@@ -281,20 +281,26 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * NW + wave) * 16;
+  const int KS = d.ksplit > 1 ? d.ksplit : 1;
+  const int split = blockIdx.x % KS, qchunk = blockIdx.x / KS;
+  const int q0 = (qchunk * NW + wave) * 16;
   const int myq = q0 + li;
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
 
   if (A::DHK > DH) { zero_lds<CT, DH>(Kbuf, 2 * KSZ, tid, nthreads); __syncthreads(); }
   const int nact = active_key_blocks(d.kpm ? d.kpm + (long)b * d.Lk : nullptr, d.Lk, blk_flag, blk_act, &blk_cnt, tid,
                                      nthreads);
-  auto kblock = [&](int t) { return nact < 0 ? t : (int)blk_act[t]; };
+  const int ntot = nact < 0 ? -nact : nact;
+  const int t_lo = (int)((long)ntot * split / KS), t_hi = (int)((long)ntot * (split + 1) / KS);   // this split's slice
+  auto kblock = [&](int t) { return nact < 0 ? t_lo + t : (int)blk_act[t_lo + t]; };
 
   u32x4 qf[A::NS];
   row_frags<CT, DH>(qf, d.q, (long)b * d.q_sb + (long)min(myq, d.Lq - 1) * d.q_sl + (long)h * d.q_sh, lg);
 
-  // m is uniform over the 4 lanes of a query; l is a PER-LANE partial row sum, reduced once after the loop
-  float m = d.zero_attn ? 0.f : -1e30f, l = (d.zero_attn && lg == 0) ? 1.f : 0.f;
+  // m is uniform over the 4 lanes of a query; l is a PER-LANE partial row sum, reduced once after the loop.
+  // The zero key (add_zero_attn) is the initial state of split 0 only.
+  const bool zero0 = d.zero_attn && split == 0;
+  float m = zero0 ? 0.f : -1e30f, l = (zero0 && lg == 0) ? 1.f : 0.f;
   f32x4 acc[A::MT];
 #pragma unroll
   for (int mt = 0; mt < A::MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -364,10 +370,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
         Mma<CT>::mma(acc[mt], tfrag_any<CT>(Vs, A::LDR, Vs, A::LDT, u, mt, li, lg), pf[u]);
     }
   };
-  pipeline2(nact < 0 ? -nact : nact, load, store, compute);
+  pipeline2(t_hi - t_lo, load, store, compute);
   l = group_sum(l);
 
-  if (qvalid) {
+  if (!qvalid) return;
+  if (KS == 1) {
     const float inv = 1.f / l;
     const long ooff = (long)b * d.o_sb + (long)myq * d.o_sl + (long)h * d.o_sh;
 #pragma unroll
@@ -375,7 +382,46 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
 #pragma unroll
       for (int r = 0; r < 4; ++r) store_elem(d.o, d.dt, ooff + mt * 16 + 4 * lg + r, acc[mt][r] * inv);
     if (lg == 0) d.lse[((long)b * d.H + h) * d.Lq + myq] = m + logf(l);
+  } else {   // partial softmax state (un-normalised O, running max, row sum) for the combine kernel
+    const long rows = (long)d.B * d.H * d.Lq, ridx = (((long)split * d.B + b) * d.H + h) * d.Lq + myq;
+    float* po = d.ws + ridx * DH;
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+      *(float4*)(po + mt * 16 + 4 * lg) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    if (lg == 0) {
+      d.ws[(long)KS * rows * DH + ridx] = m;
+      d.ws[(long)KS * rows * (DH + 1) + ridx] = l;
+    }
   }
+}
+
+// merges the `ksplit` partial states of attn_fwd_kernel: one thread per (row, 4-channel group)
+template <int DH>
+__global__ void attn_fwd_combine_kernel(const pq3d_attn_desc d) {
+  const long rows = (long)d.B * d.H * d.Lq;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * (DH / 4)) return;
+  const long row = idx / (DH / 4);
+  const int c0 = (int)(idx % (DH / 4)) * 4;
+  const int KS = d.ksplit;
+  const float* pm = d.ws + (long)KS * rows * DH;
+  const float* pl = d.ws + (long)KS * rows * (DH + 1);
+  float M = -INFINITY;
+  for (int s = 0; s < KS; ++s) M = fmaxf(M, pm[s * rows + row]);
+  float Lsum = 0.f;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < KS; ++s) {
+    const float w = expf(pm[s * rows + row] - M);
+    Lsum += pl[s * rows + row] * w;
+    const float4 p = *(const float4*)(d.ws + (s * rows + row) * DH + c0);
+    o.x += p.x * w; o.y += p.y * w; o.z += p.z * w; o.w += p.w * w;
+  }
+  const float inv = 1.f / Lsum;
+  const int q = (int)(row % d.Lq), h = (int)((row / d.Lq) % d.H), b = (int)(row / ((long)d.Lq * d.H));
+  const long ooff = (long)b * d.o_sb + (long)q * d.o_sl + (long)h * d.o_sh + c0;
+  store_elem(d.o, d.dt, ooff, o.x * inv); store_elem(d.o, d.dt, ooff + 1, o.y * inv);
+  store_elem(d.o, d.dt, ooff + 2, o.z * inv); store_elem(d.o, d.dt, ooff + 3, o.w * inv);
+  if (c0 == 0) d.lse[row] = M + logf(Lsum);
 }
 
 // ------------------------------------------------------------------------------------------------ delta
@@ -425,7 +471,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = (blockIdx.x * NW + wave) * 16;
+  const int KS = d.ksplit > 1 ? d.ksplit : 1;
+  const int split = blockIdx.x % KS, qchunk = blockIdx.x / KS;
+  const int q0 = (qchunk * NW + wave) * 16;
   const int myq = q0 + li;
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
 
@@ -436,7 +484,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   }
   const int nact = active_key_blocks(d.kpm ? d.kpm + (long)b * d.Lk : nullptr, d.Lk, blk_flag, blk_act, &blk_cnt, tid,
                                      nthreads);
-  auto kblock = [&](int t) { return nact < 0 ? t : (int)blk_act[t]; };
+  const int ntot = nact < 0 ? -nact : nact;
+  const int t_lo = (int)((long)ntot * split / KS), t_hi = (int)((long)ntot * (split + 1) / KS);
+  auto kblock = [&](int t) { return nact < 0 ? t_lo + t : (int)blk_act[t_lo + t]; };
   u32x4 qf[A::NS], dof[A::NS], of[A::NS];
   const int cq = min(myq, d.Lq - 1);
   row_frags<CT, DH>(qf, d.q, (long)b * d.q_sb + (long)cq * d.q_sl + (long)h * d.q_sh, lg);
@@ -459,7 +509,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
       }
     }
   Dl = group_sum(Dl);
-  if (qvalid && lg == 0) d.delta[sidx] = Dl;
+  if (qvalid && lg == 0 && split == 0) d.delta[sidx] = Dl;
 
   f32x4 acc[A::MT];
 #pragma unroll
@@ -531,7 +581,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
       for (int u = 0; u < PackP<CT, 4>::STEPS; ++u)
         Mma<CT>::mma(acc[mt], tfrag_any<CT>(Ks, A::LDR, Kt, A::LDT, u, mt, li, lg), dsf[u]);
   };
-  pipeline2(nact < 0 ? -nact : nact, load, store, compute);
+  pipeline2(t_hi - t_lo, load, store, compute);
   if (dbrow && nact >= 0 && qvalid && wave_active) {   // bias gradient of skipped (fully padded) key blocks is zero
     const int nkb = (d.Lk + KB - 1) / KB;
     for (int kb = 0; kb < nkb; ++kb)
@@ -540,13 +590,37 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
           if (kb * KB + j < d.Lk) dbrow[kb * KB + j] = 0.f;
   }
 
-  if (qvalid) {
+  if (!qvalid) return;
+  if (KS == 1) {
     const long off = (long)b * d.q_sb + (long)myq * d.q_sl + (long)h * d.q_sh;
 #pragma unroll
     for (int mt = 0; mt < A::MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) store_elem(d.dq, d.dt, off + mt * 16 + 4 * lg + r, acc[mt][r]);
+  } else {   // partial dQ of this key slice, summed by attn_dq_combine_kernel
+    float* po = d.ws + ((((long)split * d.B + b) * d.H + h) * d.Lq + myq) * DH;
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+      *(float4*)(po + mt * 16 + 4 * lg) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
   }
+}
+
+template <int DH>
+__global__ void attn_dq_combine_kernel(const pq3d_attn_desc d) {
+  const long rows = (long)d.B * d.H * d.Lq;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * (DH / 4)) return;
+  const long row = idx / (DH / 4);
+  const int c0 = (int)(idx % (DH / 4)) * 4;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < d.ksplit; ++s) {
+    const float4 p = *(const float4*)(d.ws + (s * rows + row) * DH + c0);
+    o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+  }
+  const int q = (int)(row % d.Lq), h = (int)((row / d.Lq) % d.H), b = (int)(row / ((long)d.Lq * d.H));
+  const long off = (long)b * d.q_sb + (long)q * d.q_sl + (long)h * d.q_sh + c0;
+  store_elem(d.dq, d.dt, off, o.x); store_elem(d.dq, d.dt, off + 1, o.y);
+  store_elem(d.dq, d.dt, off + 2, o.z); store_elem(d.dq, d.dt, off + 3, o.w);
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -720,20 +794,31 @@ int check_desc(const pq3d_attn_desc& d) {
   }
   PQ_CHECK_ARG(d.Lk > 0 || d.zero_attn, "pq3d_attn: Lk == 0 needs zero_attn");
   PQ_CHECK_ARG(d.Lk <= MAXKB * KB, "pq3d_attn: Lk too large for the key-block skip list");
+  PQ_CHECK_ARG(d.ksplit <= 1 || (d.ws != nullptr && d.ksplit <= 64), "pq3d_attn: ksplit needs a workspace (ksplit <= 64)");
+  PQ_CHECK_ARG(d.ksplit <= 1 || d.dbias == nullptr, "pq3d_attn: dbias requires ksplit == 1");
   return 0;
 }
 
 template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream_t s) {
-  const int tiles = (d.Lq + 15) / 16;
-  if (tiles > 4) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8>), dim3((tiles + 7) / 8, d.H, d.B), dim3(512), 0, s, d);
-  else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4>), dim3(1, d.H, d.B), dim3(256), 0, s, d);
+  const int tiles = (d.Lq + 15) / 16, ks = d.ksplit > 1 ? d.ksplit : 1;
+  if (tiles > 4) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8>), dim3(((tiles + 7) / 8) * ks, d.H, d.B), dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4>), dim3(ks, d.H, d.B), dim3(256), 0, s, d);
+  if (ks > 1) {
+    const long n = (long)d.B * d.H * d.Lq * (DH / 4);
+    hipLaunchKernelGGL((attn_fwd_combine_kernel<DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+  }
   PQ_LAUNCH_CHECK();
   return 0;
 }
 template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream_t s) {
   const int tiles = (d.Lq + 15) / 16;   // the dQ kernel also produces delta = rowsum(dO * O) for the dK/dV kernel
-  if (tiles > 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8>), dim3((tiles + 7) / 8, d.H, d.B), dim3(512), 0, s, d);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4>), dim3(1, d.H, d.B), dim3(256), 0, s, d);
+  const int ks = d.ksplit > 1 ? d.ksplit : 1;
+  if (tiles > 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8>), dim3(((tiles + 7) / 8) * ks, d.H, d.B), dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4>), dim3(ks, d.H, d.B), dim3(256), 0, s, d);
+  if (ks > 1) {
+    const long n = (long)d.B * d.H * d.Lq * (DH / 4);
+    hipLaunchKernelGGL((attn_dq_combine_kernel<DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+  }
   if (d.Lk > 0)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH>), dim3((d.Lk + NWK * 16 - 1) / (NWK * 16), d.H, d.B),
                        dim3(NWK * 64), 0, s, d);

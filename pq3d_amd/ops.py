@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -158,6 +159,9 @@ def linear(x, w, b=None, *, ct: int, x2=None, act: Optional[str] = None, out_dty
 
 
 # ------------------------------------------------------------------------------------------------ attention
+_ATTN_KSPLIT = int(os.environ.get("PQ3D_ATTN_KSPLIT", "0"))   # experiments only; 0 = built-in rule
+
+
 def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias) -> L.AttnDesc:
     B, Lq, dm = q.shape
     Lk = k.shape[1]
@@ -169,6 +173,15 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
         setattr(d, name + "_sb", t.stride(0)); setattr(d, name + "_sl", t.stride(1)); setattr(d, name + "_sh", dm // H)
     d.q, d.k, d.v, d.o, d.lse = L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse)
     d.kpm, d.mask, d.row_open, d.bias = L.ptr(kpm), L.ptr(mask), L.ptr(row_open), L.ptr(bias)
+    # key split (not with dbias).  The factor depends on the key length ONLY, never on the batch: a scene's result
+    # must not change with how scenes are batched or sharded over ranks (tests/test_gpu_fullsize.py).  Measured on
+    # c2 (16 key blocks) and c4 (64): 2 splits is the sweet spot, more only adds combine traffic.
+    nkb = (Lk + 63) // 64
+    ks = (_ATTN_KSPLIT or (1 if nkb < 8 else 2 if nkb < 256 else 4)) if bias is None else 1
+    if ks > 1:
+        ws = _empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
+        d.ksplit, d.ws = ks, L.ptr(ws)
+        d._ws_keepalive = ws
     return d
 
 
