@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # the oracle (torch CPU ops on small tensors) gets catastrophically slow with one thread per hardware thread on
+    # the 128/256-CPU GPU hosts; 16 is near the optimum everywhere we measured
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
