@@ -129,6 +129,11 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=8, help="timed CPU-baseline steps (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--dump-kernels", default=None, help="write the per-(entry point, shape) timing table here")
+    ap.add_argument("--dropout", default="off", choices=["off", "reference"],
+                    help="headline run: 'off' = p=0 (the parity-checked arithmetic); 'reference' = the reference's "
+                         "train-mode probabilities (0.1 in the decoder layers and encoders, 0.1/0.3 in the heads)")
+    ap.add_argument("--no-dropout-leg", action="store_true",
+                    help="skip the extra train-mode-dropout timing reported next to the headline (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,6 +149,14 @@ def main():
     c = dict(CONFIGS[args.config])
     model, sd, dd_cpu = build(c, args.compute, dev, seed=1234 + rank)
     dd = {k: v.to(dev) for k, v in dd_cpu.items()}
+    model.train()
+    ref_dropout = {m: m.dropout_p for m in model.modules() if hasattr(m, "dropout_p")}   # constructor defaults
+
+    def set_dropout_mode(mode):
+        for m, p in ref_dropout.items():
+            m.dropout_p = p if mode == "reference" else 0.0
+
+    set_dropout_mode(args.dropout)
     params = [p for p in model.parameters() if p.requires_grad]
     reducer = FlatGradAllReducer(params)
     # the fused decoder writes its parameter gradients straight into the reducer's flat buffer (no pack copy)
@@ -157,25 +170,29 @@ def main():
         loss_fn(out, c["heads"]).backward()
         reducer.pack()
 
-    graph = None
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(3):
-            fwd_bwd()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    if not args.no_graph:
+    def capture():
+        """3 eager steps on a side stream (allocator + autograd warm-up), then capture one step as a HIP graph."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if args.no_graph:
+            return None
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fwd_bwd()
-            graph = g
+            return g
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             torch.cuda.synchronize()
-            graph = None
+            return None
+
+    graph = capture()
 
     def step():
         if graph is not None:
@@ -265,12 +282,39 @@ def main():
                                    f"parallel cross-attn + spatial self-attn + FFN2048, heads={c['heads']}, "
                                    f"fwd+bwd+grad-pack{'+RCCL all-reduce' if world > 1 else ''}",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
-                       "dropout": 0.0, "activation": "relu"},
+                       "dropout": 0.0 if args.dropout == "off" else "reference train mode (0.1 / heads 0.1, 0.3)",
+                       "activation": "relu"},
             "step_algorithmic_gflop": flops / 1e9,
             "step_roofline_frac": flops * world / (dt / args.steps) / (peak * 1e12 * world),
             "roofline": roof,
             "kernel_families_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(fams.items())},
         }
+        if world == 1:
+            # the same step launched eagerly (no HIP graph): what a trainer that cannot capture graphs would see
+            def timed_loop(fn, n):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n * 1e3
+            n_e = max(3, args.steps // 5)
+            fwd_bwd()
+            result["eager_ms_per_step"] = timed_loop(fwd_bwd, n_e)
+            if args.dropout == "off" and not args.no_dropout_leg:
+                # train-mode dropout as the reference trains (reported separately from the parity-checked
+                # p=0 headline): masks are generated inside the attention / LayerNorm / GEMM-epilogue kernels
+                set_dropout_mode("reference")
+                g2 = capture()
+                run2 = g2.replay if g2 is not None else fwd_bwd
+                for _ in range(args.warmup):
+                    run2()
+                ms2 = timed_loop(run2, args.steps)
+                result["train_mode_dropout"] = {
+                    "p": {"decoder_layers": 0.1, "mask_head_cls": 0.1, "ground_head": 0.3, "object_encoders": 0.1},
+                    "ms_per_step": ms2, "value": c["B"] / (ms2 * 1e-3), "unit": "scenes/s", "hip_graph": g2 is not None,
+                    "note": "parity of the dropout arithmetic: tests/test_gpu_dropout.py (same masks fed to the oracle)"}
+                set_dropout_mode(args.dropout)
         if world == 1 and args.cpu_steps > 0:
             result["cpu_baseline"] = cpu_baseline(c, sd, dd_cpu, args.cpu_steps, 2)
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]

@@ -37,6 +37,34 @@ const char* pq3d_last_error(void);
 int pq3d_version(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dropout (train mode of the reference: nn.Dropout in every sublayer, query_encoder.py:198,224,273,304,366,385-386,
+ * transformers.py:239-241, and nn.MultiheadAttention(dropout=p), query_encoder.py:195,268; utils.py:23;
+ * object_encoder.py:72-73).  Counter-based, so the backward pass regenerates the forward's mask instead of
+ * storing it.  A dropout *site* is a 2-D array [rows, cols]; element (r, c) is KEPT iff
+ *     half16(word(r, c >> 1), c & 1) >= round(p * 65536)
+ *     word(r, j) = mix(r * ceil(cols / 2) + j; k0, k1)        (rows * ceil(cols/2) must be < 2^32)
+ *     mix(i; k0, k1): h = i ^ k0; h ^= h>>16; h *= 0x7feb352d; h ^= h>>15; h += k1; h *= 0x846ca68b; h ^= h>>16
+ *     k0 = fin(lo32(seed) ^ (site * 0x9E3779B1)),  k1 = fin(k0 + hi32(seed) + 0x85ebca6b)
+ *     fin(h):  h ^= h>>16; h *= 0x7feb352d; h ^= h>>15; h *= 0x846ca68b; h ^= h>>16
+ * and kept values are multiplied by 1/(1-p) (torch semantics).  `seed` is a DEVICE pointer to one 64-bit word: a
+ * captured HIP graph draws fresh masks on every replay once the host (or a captured kernel) bumps the word.
+ * p == 0 or seed == NULL turns the site off.  Kernels that fuse dropout document which array is the site.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  float p;
+  uint32_t site;
+  const uint64_t* seed;
+} pq3d_dropout;
+
+/* keep[r*cols + c] = 1 if element (r, c) of the site is kept (tests / debugging; same hash as the fused sites). */
+int pq3d_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, const pq3d_dropout* dr, void* stream);
+/* y = dropout(x) elementwise over a [rows, cols] site (also its own backward: dx = dropout(dy) with the same
+ * descriptor).  Used where the reference applies nn.Dropout to a tensor no kernel of ours produces last
+ * (get_mlp_head, utils.py:23; ObjectEncoder, object_encoder.py:72-73). */
+int pq3d_dropout_apply(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
+                       const pq3d_dropout* dr, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Grouped / batched GEMM with fused prologue + epilogue (nn.Linear forward and both backward GEMMs,
  * MaskPredictionLayer einsum).  Replaces: F.linear calls inside nn.MultiheadAttention
  * (query_encoder.py:268-270,194), MultiHeadAttentionSpatial w_qs/w_ks/w_vs/fc (transformers.py:190-193,239),
@@ -88,6 +116,9 @@ typedef struct {
   const float* row_scale;                         /* [batch*M] or NULL (group 0 only) */
   const uint8_t* row_fill_flag;                   /* [batch*M] or NULL */
   uint8_t* mask_out;                              /* [batch][N][M] or NULL */
+  /* dropout applied to the activated output (site = C viewed as [batch*M, N], site id drop.site + group):
+   * FFNLayer's self.dropout(self.activation(self.linear1(x))), query_encoder.py:385.  Not with split-K. */
+  pq3d_dropout drop;
 } pq3d_gemm_desc;
 
 int pq3d_gemm(const pq3d_gemm_desc* d, void* stream);
@@ -138,6 +169,13 @@ typedef struct {
    * below the CU count and shortens the serial key loop; results are deterministic.  dbias requires ksplit == 1. */
   int32_t ksplit;
   float* ws;
+  /* attention-probability dropout of nn.MultiheadAttention (functional.py: dropout(softmax(..)) before @ v): the
+   * site is the probability matrix viewed as [B*H*Lq, Lk] (the zero key of add_zero_attn has no value row, so
+   * dropping it is a no-op and it draws nothing).  drop_bmod > 0: scenes are stacked groups of drop_bmod along the
+   * batch (memories of one layer): batch entry b uses site drop.site + b / drop_bmod and row index of scene
+   * b % drop_bmod, so a stacked launch draws exactly the masks the per-memory launches would. */
+  pq3d_dropout drop;
+  int32_t drop_bmod;
 } pq3d_attn_desc;
 
 int pq3d_attn_fwd(const pq3d_attn_desc* d, void* stream);
@@ -178,6 +216,9 @@ typedef struct {
                                      ys[m] = LN_m(x + o_m) (no sum, coef ignored); backward reads dys[m], dx unused */
   void* ys[PQ3D_MAX_GROUPS];
   const float* dys[PQ3D_MAX_GROUPS];
+  /* residual dropout: y = LN(x + dropout(o_m)) (tgt + self.dropout(tgt2), query_encoder.py:224,304,386); the site
+   * is o_m viewed as [R, d], site id drop.site + m.  The backward regenerates the mask for d_o. */
+  pq3d_dropout drop;
 } pq3d_ln_desc;
 
 int pq3d_add_ln_fwd(const pq3d_ln_desc* d, void* stream);

@@ -19,6 +19,32 @@ class Pq3dError(RuntimeError):
     pass
 
 
+class Dropout(C.Structure):
+    """pq3d_dropout: p, site id, device pointer to the 64-bit seed word."""
+    _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_void_p)]
+
+
+class Drop:
+    """Host-side handle of one dropout site: probability, site id and the device seed tensor (int64[1])."""
+    __slots__ = ("p", "site", "seed")
+
+    def __init__(self, p: float, site: int, seed: torch.Tensor):
+        self.p, self.site, self.seed = float(p), int(site), seed
+
+    def at(self, site_add: int) -> "Drop":
+        return Drop(self.p, self.site + site_add, self.seed)
+
+    def c(self) -> Dropout:
+        d = Dropout()
+        d.p, d.site, d.seed = self.p, self.site & 0xFFFFFFFF, ptr(self.seed)
+        return d
+
+
+def set_drop(field: Dropout, drop: Optional["Drop"]) -> None:
+    if drop is not None and drop.p > 0.0:
+        field.p, field.site, field.seed = drop.p, drop.site & 0xFFFFFFFF, ptr(drop.seed)
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32), ("batch", C.c_int32),
@@ -34,6 +60,7 @@ class GemmDesc(C.Structure):
         ("bias", C.c_void_p * MAXG), ("C", C.c_void_p * MAXG), ("C2", C.c_void_p * MAXG),
         ("aux", C.c_void_p * MAXG), ("row_mask", C.c_void_p * MAXG), ("colsum", C.c_void_p * MAXG),
         ("row_scale", C.c_void_p), ("row_fill_flag", C.c_void_p), ("mask_out", C.c_void_p),
+        ("drop", Dropout),
     ]
 
 
@@ -49,6 +76,7 @@ class AttnDesc(C.Structure):
         ("kpm", C.c_void_p), ("mask", C.c_void_p), ("row_open", C.c_void_p), ("bias", C.c_void_p),
         ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
         ("delta", C.c_void_p), ("dbias", C.c_void_p), ("ksplit", C.c_int32), ("ws", C.c_void_p),
+        ("drop", Dropout), ("drop_bmod", C.c_int32),
     ]
 
 
@@ -61,6 +89,7 @@ class LnDesc(C.Structure):
         ("dy", C.c_void_p), ("dx", C.c_void_p), ("d_o", C.c_void_p * MAXG), ("dgamma", C.c_void_p * MAXG),
         ("dbeta", C.c_void_p * MAXG), ("accumulate", C.c_int32), ("independent", C.c_int32),
         ("ys", C.c_void_p * MAXG), ("dys", C.c_void_p * MAXG),
+        ("drop", Dropout),
     ]
 
 
@@ -99,6 +128,9 @@ _SIGS = {
     "pq3d_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                               C.c_void_p],
     "pq3d_scatter_mean_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
+    "pq3d_dropout_mask": [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Dropout), C.c_void_p],
+    "pq3d_dropout_apply": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout),
+                           C.c_void_p],
 }
 EXPORTS = sorted(list(_SIGS) + ["pq3d_last_error", "pq3d_version"])
 
@@ -161,7 +193,7 @@ def _fill(arr, tensors: Optional[Sequence[Optional[torch.Tensor]]]):
 def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C2=None, aux=None, row_mask=None,
          transA=False, transB=False, batch=1, strideA=0, strideB=0, strideC=0, act=None, act_grad=None, splitk=1,
          kconcat=0, accumulate=False, alpha=1.0, row_scale=None, row_fill_flag=None, row_fill=0.0,
-         mask_out=None, colsum=None) -> None:
+         mask_out=None, colsum=None, drop=None) -> None:
     """kconcat: number of consecutive groups concatenated along K per output (True = all groups)."""
     if kconcat is True:
         kconcat = len(A)
@@ -183,6 +215,7 @@ def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C
     _fill(d.A, A); _fill(d.A2, A2); _fill(d.B, B); _fill(d.B2, B2); _fill(d.bias, bias); _fill(d.C, Cs)
     _fill(d.C2, C2); _fill(d.aux, aux); _fill(d.row_mask, row_mask); _fill(d.colsum, colsum)
     d.row_scale, d.row_fill_flag, d.mask_out = ptr(row_scale), ptr(row_fill_flag), ptr(mask_out)
+    set_drop(d.drop, drop)
     from .profiler import timed
     nb = (M * K * (2 if d.dtA else 4) + N * K * (2 if d.dtB else 4)) * len(A) * batch + \
         M * N * (2 if d.dtC else 4) * (len(A) // max(kconcat, 1)) * batch

@@ -266,7 +266,7 @@ PQ_DEV void fetch_mask_bias(MaskBias& mb, const pq3d_attn_desc& d, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename CT, int DH, int NW>
+template <typename CT, int DH, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;  // bf16: row-major V + transposing reads; f32: transposed LDS copy
@@ -308,6 +308,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
   const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
   const bool ro = (qvalid && d.row_open) ? d.row_open[(long)bm * d.Lq + myq] != 0 : false;
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
+  // attention-probability dropout: this lane's query is one row of the [B*H*Lq, Lk] site
+  DropState dst;
+  uint32_t drow = 0;
+  if constexpr (DROP) {
+    dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, d.Lk);
+    drow = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * d.Lq + min(myq, d.Lq - 1));
+  }
 
   TileRegs<CT, DH, KB, nthreads> kr[2], vr[2];
   uint8_t kpm_r[2] = {1, 1};
@@ -360,6 +367,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
       }
     l = l * alpha + rs;   // per-lane partial (alpha is uniform over the query's 4 lanes)
     m = m_new;
+    if constexpr (DROP) {   // the softmax denominator keeps every key; only the value contraction sees the mask
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const uint32_t cp = (uint32_t)(k0 + tt * 16 + 4 * lg) >> 1;
+        const uint32_t w0 = drop_word(dst, drow, cp), w1 = drop_word(dst, drow, cp + 1);
+        p[tt][0] = drop_keep_lo(dst, w0) ? p[tt][0] : 0.f;
+        p[tt][1] = drop_keep_hi(dst, w0) ? p[tt][1] : 0.f;
+        p[tt][2] = drop_keep_lo(dst, w1) ? p[tt][2] : 0.f;
+        p[tt][3] = drop_keep_hi(dst, w1) ? p[tt][3] : 0.f;
+      }
+    }
     u32x4 pf[PackP<CT, 4>::STEPS];
     PackP<CT, 4>::run(p, pf);
 #pragma unroll
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
 
   if (!qvalid) return;
   if (KS == 1) {
-    const float inv = 1.f / l;
+    const float inv = (DROP ? dst.scale : 1.f) / l;
     const long ooff = (long)b * d.o_sb + (long)myq * d.o_sl + (long)h * d.o_sh;
 #pragma unroll
     for (int mt = 0; mt < A::MT; ++mt)
@@ -416,7 +434,7 @@ __global__ void attn_fwd_combine_kernel(const pq3d_attn_desc d) {
     const float4 p = *(const float4*)(d.ws + (s * rows + row) * DH + c0);
     o.x += p.x * w; o.y += p.y * w; o.z += p.z * w; o.w += p.w * w;
   }
-  const float inv = 1.f / Lsum;
+  const float inv = ((d.drop.p > 0.f && d.drop.seed) ? 1.f / (1.f - d.drop.p) : 1.f) / Lsum;
   const int q = (int)(row % d.Lq), h = (int)((row / d.Lq) % d.H), b = (int)(row / ((long)d.Lq * d.H));
   const long ooff = (long)b * d.o_sb + (long)q * d.o_sl + (long)h * d.o_sh + c0;
   store_elem(d.o, d.dt, ooff, o.x * inv); store_elem(d.o, d.dt, ooff + 1, o.y * inv);
@@ -455,7 +473,7 @@ __global__ void attn_delta_kernel(const pq3d_attn_desc d) {
 }
 
 // ------------------------------------------------------------------------------------------------ dQ (+ dbias)
-template <typename CT, int DH, int NW>
+template <typename CT, int DH, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
@@ -518,6 +536,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
   const bool ro = (qvalid && d.row_open) ? d.row_open[(long)bm * d.Lq + myq] != 0 : false;
   float* dbrow = d.dbias ? d.dbias + (((long)b * d.H + h) * d.Lq + min(myq, d.Lq - 1)) * d.Lk : nullptr;
+  DropState dst;
+  uint32_t drow = 0;
+  if constexpr (DROP) {
+    dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, d.Lk);
+    drow = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * d.Lq + min(myq, d.Lq - 1));
+  }
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
 
   TileRegs<CT, DH, KB, nthreads> kr[2], vr[2];
@@ -552,6 +576,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
       for (int st = 0; st < A::NS; ++st) {
         Mma<CT>::mma(sc, rfrag<CT>(&Ks[(tt * 16 + li) * A::LDR], st, lg), qf[st]);
         Mma<CT>::mma(dp, rfrag<CT>(&Vs[(tt * 16 + li) * A::LDR], st, lg), dof[st]);
+      }
+      if constexpr (DROP) {   // dP = keep * dPd / (1-p); delta = rowsum(dO * O) already includes the mask
+        const uint32_t cp = (uint32_t)(k0 + tt * 16 + 4 * lg) >> 1;
+        const uint32_t w0 = drop_word(dst, drow, cp), w1 = drop_word(dst, drow, cp + 1);
+        dp[0] = drop_keep_lo(dst, w0) ? dp[0] * dst.scale : 0.f;
+        dp[1] = drop_keep_hi(dst, w0) ? dp[1] * dst.scale : 0.f;
+        dp[2] = drop_keep_lo(dst, w1) ? dp[2] * dst.scale : 0.f;
+        dp[3] = drop_keep_hi(dst, w1) ? dp[3] * dst.scale : 0.f;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -624,7 +656,7 @@ __global__ void attn_dq_combine_kernel(const pq3d_attn_desc d) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <typename CT, int DH>
+template <typename CT, int DH, bool DROP>
 __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
@@ -670,6 +702,12 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   const long qoff = (long)b * d.q_sb + (long)h * d.q_sh, ooff = (long)b * d.o_sb + (long)h * d.o_sh;
   const long sbase = ((long)b * d.H + h) * d.Lq;
   const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
+  DropState dst;
+  uint32_t drow0 = 0;
+  if constexpr (DROP) {
+    dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, d.Lk);
+    drow0 = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * d.Lq);
+  }
 
   TileRegs<CT, DH, QB, nthreads> qr[2], dor[2];
   float l_r[2] = {INFINITY, INFINITY}, d_r[2] = {0.f, 0.f};
@@ -702,7 +740,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
     const float* Ds = Dbuf + Bf * QB;
     const uint8_t* ro_s = robuf + Bf * QB;
     const int qb = t * QB;
-    float pt[2][4], dst[2][4];
+    float pt[2][4], dsk[2][4];
     // mask / bias for this lane's key against the 8 queries (tt, r) it sees: uniform branches around grouped loads
     bool mk[2][4];
     float bb[2][4];
@@ -737,13 +775,15 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
       for (int r = 0; r < 4; ++r) {
         const int ql = tt * 16 + 4 * lg + r;
         const float pr = mk[tt][r] ? 0.f : fexp<CT>(sc[r] * d.scale + bb[tt][r] - Ls[ql]);   // Ls = +inf past Lq
-        pt[tt][r] = pr;
-        dst[tt][r] = pr * (dp[r] - Ds[ql]) * d.scale;
+        float kc = 1.f;   // dropout factor of (query, key): 0 or 1/(1-p)
+        if constexpr (DROP) kc = drop_keep(dst, drow0 + (uint32_t)min(qb + ql, d.Lq - 1), (uint32_t)ckey) ? dst.scale : 0.f;
+        pt[tt][r] = pr * kc;
+        dsk[tt][r] = pr * (dp[r] * kc - Ds[ql]) * d.scale;
       }
     }
     u32x4 pf[PackP<CT, 2>::STEPS], dsf[PackP<CT, 2>::STEPS];
     PackP<CT, 2>::run(pt, pf);
-    PackP<CT, 2>::run(dst, dsf);
+    PackP<CT, 2>::run(dsk, dsf);
 #pragma unroll
     for (int mt = 0; mt < A::MT; ++mt)
 #pragma unroll
@@ -796,13 +836,22 @@ int check_desc(const pq3d_attn_desc& d) {
   PQ_CHECK_ARG(d.Lk <= MAXKB * KB, "pq3d_attn: Lk too large for the key-block skip list");
   PQ_CHECK_ARG(d.ksplit <= 1 || (d.ws != nullptr && d.ksplit <= 64), "pq3d_attn: ksplit needs a workspace (ksplit <= 64)");
   PQ_CHECK_ARG(d.ksplit <= 1 || d.dbias == nullptr, "pq3d_attn: dbias requires ksplit == 1");
+  PQ_CHECK_DROP(d.drop, (int64_t)(d.drop_bmod > 0 ? d.drop_bmod : d.B) * d.H * d.Lq, d.Lk, "pq3d_attn");
+  PQ_CHECK_ARG(d.drop_bmod <= 0 || d.B % d.drop_bmod == 0, "pq3d_attn: B must be a multiple of drop_bmod");
   return 0;
 }
 
 template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream_t s) {
   const int tiles = (d.Lq + 15) / 16, ks = d.ksplit > 1 ? d.ksplit : 1;
-  if (tiles > 4) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8>), dim3(((tiles + 7) / 8) * ks, d.H, d.B), dim3(512), 0, s, d);
-  else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4>), dim3(ks, d.H, d.B), dim3(256), 0, s, d);
+  const bool dr = d.drop.p > 0.f && d.drop.seed;
+  const dim3 g8(((tiles + 7) / 8) * ks, d.H, d.B), g4(ks, d.H, d.B);
+  if (tiles > 4) {
+    if (dr) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8, true>), g8, dim3(512), 0, s, d);
+    else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8, false>), g8, dim3(512), 0, s, d);
+  } else {
+    if (dr) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4, true>), g4, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4, false>), g4, dim3(256), 0, s, d);
+  }
   if (ks > 1) {
     const long n = (long)d.B * d.H * d.Lq * (DH / 4);
     hipLaunchKernelGGL((attn_fwd_combine_kernel<DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
@@ -813,15 +862,24 @@ template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream
 template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream_t s) {
   const int tiles = (d.Lq + 15) / 16;   // the dQ kernel also produces delta = rowsum(dO * O) for the dK/dV kernel
   const int ks = d.ksplit > 1 ? d.ksplit : 1;
-  if (tiles > 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8>), dim3(((tiles + 7) / 8) * ks, d.H, d.B), dim3(512), 0, s, d);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4>), dim3(ks, d.H, d.B), dim3(256), 0, s, d);
+  const bool dr = d.drop.p > 0.f && d.drop.seed;
+  const dim3 g8(((tiles + 7) / 8) * ks, d.H, d.B), g4(ks, d.H, d.B);
+  if (tiles > 4) {
+    if (dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8, true>), g8, dim3(512), 0, s, d);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8, false>), g8, dim3(512), 0, s, d);
+  } else {
+    if (dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4, true>), g4, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4, false>), g4, dim3(256), 0, s, d);
+  }
   if (ks > 1) {
     const long n = (long)d.B * d.H * d.Lq * (DH / 4);
     hipLaunchKernelGGL((attn_dq_combine_kernel<DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
   }
-  if (d.Lk > 0)
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH>), dim3((d.Lk + NWK * 16 - 1) / (NWK * 16), d.H, d.B),
-                       dim3(NWK * 64), 0, s, d);
+  if (d.Lk > 0) {
+    const dim3 gk((d.Lk + NWK * 16 - 1) / (NWK * 16), d.H, d.B);
+    if (dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH, true>), gk, dim3(NWK * 64), 0, s, d);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH, false>), gk, dim3(NWK * 64), 0, s, d);
+  }
   PQ_LAUNCH_CHECK();
   return 0;
 }

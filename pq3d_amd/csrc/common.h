@@ -144,6 +144,41 @@ PQ_DEV float wave_max(float v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Counter-based dropout (definition in include/pq3d_hip.h).  One 32-bit hash word decides TWO neighbouring
+// columns (16 bits each), so a kernel that owns consecutive columns pays ~5 integer ops per element.
+// ---------------------------------------------------------------------------------------------
+PQ_DEV uint32_t drop_fin(uint32_t h) {
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+struct DropState {
+  uint32_t k0, k1, thresh, half;
+  float scale;
+};
+PQ_DEV DropState drop_init(const pq3d_dropout& dr, uint32_t site_add, long cols) {
+  DropState s;
+  const uint64_t seed = *dr.seed;
+  s.k0 = drop_fin((uint32_t)seed ^ ((dr.site + site_add) * 0x9E3779B1u));
+  s.k1 = drop_fin(s.k0 + (uint32_t)(seed >> 32) + 0x85ebca6bu);
+  s.thresh = (uint32_t)(dr.p * 65536.f + 0.5f);
+  s.half = (uint32_t)((cols + 1) >> 1);
+  s.scale = 1.f / (1.f - dr.p);
+  return s;
+}
+PQ_DEV uint32_t drop_word(const DropState& s, uint32_t row, uint32_t colpair) {
+  uint32_t h = (row * s.half + colpair) ^ s.k0;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h += s.k1; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+PQ_DEV bool drop_keep_lo(const DropState& s, uint32_t w) { return (w & 0xffffu) >= s.thresh; }
+PQ_DEV bool drop_keep_hi(const DropState& s, uint32_t w) { return (w >> 16) >= s.thresh; }
+PQ_DEV bool drop_keep(const DropState& s, uint32_t row, uint32_t col) {
+  const uint32_t w = drop_word(s, row, col >> 1);
+  return (col & 1) ? drop_keep_hi(s, w) : drop_keep_lo(s, w);
+}
+PQ_DEV bool drop_on(const pq3d_dropout& dr) { return dr.p > 0.f && dr.seed != nullptr; }
+
 // host-side error plumbing (api.cpp)
 extern "C" void pq3d_set_error(const char* msg);
 #define PQ_CHECK_ARG(cond, msg)      \
@@ -153,6 +188,9 @@ extern "C" void pq3d_set_error(const char* msg);
       return PQ3D_ERR_ARG;           \
     }                                \
   } while (0)
+#define PQ_CHECK_DROP(dr, rows, cols, what)                                                                   \
+  PQ_CHECK_ARG(!((dr).p > 0.f && (dr).seed) || ((dr).p < 1.f && (double)(rows) * (double)(((cols) + 1) / 2) < 4294967296.0), \
+               what ": dropout needs p < 1 and rows * ceil(cols/2) < 2^32")
 #define PQ_LAUNCH_CHECK()                                  \
   do {                                                     \
     hipError_t e_ = hipGetLastError();                     \

@@ -365,6 +365,16 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* C
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = gelu_f(v[j]);
   }
+  if (drop_on(d.drop)) {   // dropout of the activated output; col is a multiple of 16, so pairs never straddle threads
+    const DropState ds = drop_init(d.drop, g, d.N);
+    const uint32_t drow = (uint32_t)((long)z * d.M + row);
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+      const uint32_t w = drop_word(ds, drow, (uint32_t)(col + j) >> 1);
+      v[j] = drop_keep_lo(ds, w) ? v[j] * ds.scale : 0.f;
+      v[j + 1] = drop_keep_hi(ds, w) ? v[j + 1] * ds.scale : 0.f;
+    }
+  }
   if (d.act_grad) {
     float av[16];
     load_vec<16>(d.aux[g], d.dtAux, ci, vec_ok, nvalid, av);
@@ -628,6 +638,8 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   }
   if (d.splitk < 1) d.splitk = 1;
   PQ_CHECK_ARG(!(kc > 1 && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");
+  PQ_CHECK_ARG(!(d.drop.p > 0.f && d.drop.seed) || d.splitk == 1, "pq3d_gemm: dropout is not available with split-K");
+  PQ_CHECK_DROP(d.drop, (int64_t)d.batch * d.M, d.N, "pq3d_gemm");
   bool any_cs = false;
   for (int g = 0; g < d.groups; ++g) any_cs |= d.colsum[g] != nullptr;
   PQ_CHECK_ARG(!any_cs || (d.transA && d.transB && kc == 1 && d.batch == 1 && d.splitk > 1),

@@ -480,3 +480,45 @@ extern "C" int pq3d_scatter_mean_bwd(const float* dout, const int64_t* index, co
   PQ_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ dropout
+namespace {
+__global__ void dropout_mask_kernel(uint8_t* keep, long rows, long cols, const pq3d_dropout dr) {
+  const DropState s = drop_init(dr, 0, cols);
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    keep[i] = drop_keep(s, (uint32_t)(i / cols), (uint32_t)(i % cols)) ? 1 : 0;
+}
+__global__ void dropout_apply_kernel(const void* x, int dtx, void* y, int dty, long rows, long cols, const pq3d_dropout dr) {
+  const DropState s = drop_init(dr, 0, cols);
+  const long half = (cols + 1) >> 1, n = rows * half;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / half, j = i % half;
+    const uint32_t w = drop_word(s, (uint32_t)r, (uint32_t)j);
+    const long e = r * cols + 2 * j;
+    store_elem(y, dty, e, drop_keep_lo(s, w) ? load_elem(x, dtx, e) * s.scale : 0.f);
+    if (2 * j + 1 < cols) store_elem(y, dty, e + 1, drop_keep_hi(s, w) ? load_elem(x, dtx, e + 1) * s.scale : 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int pq3d_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, const pq3d_dropout* dr, void* stream) {
+  PQ_CHECK_ARG(keep && dr && dr->seed && rows >= 0 && cols >= 1 && dr->p >= 0.f, "pq3d_dropout_mask: bad args");
+  PQ_CHECK_DROP(*dr, rows, cols, "pq3d_dropout_mask");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid1d(rows * cols, 256, 8192)), dim3(256), 0, (hipStream_t)stream, keep,
+                     (long)rows, (long)cols, *dr);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_dropout_apply(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
+                                  const pq3d_dropout* dr, void* stream) {
+  PQ_CHECK_ARG(x && y && dr && dr->seed && rows >= 0 && cols >= 1 && dr->p > 0.f, "pq3d_dropout_apply: bad args");
+  PQ_CHECK_DROP(*dr, rows, cols, "pq3d_dropout_apply");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid1d(rows * ((cols + 1) / 2), 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, x, dt_x, y, dt_y, (long)rows, (long)cols, *dr);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

@@ -41,13 +41,21 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
   }
   const long scene = row / d.rows_per_scene, nscene = d.R / d.rows_per_scene;
   const int mlo = d.independent ? blockIdx.y : 0, mhi = d.independent ? blockIdx.y + 1 : d.M;
+  const bool drop = drop_on(d.drop);
   for (int m = mlo; m < mhi; ++m) {
-    float v[PL];
+    float v[PL], ov[PL];
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
       const int c = lane + 64 * j;
-      v[j] = c < d.d ? xr[j] + load_elem(d.o[m], d.dt_o, base + c) : 0.f;
+      ov[j] = c < d.d ? load_elem(d.o[m], d.dt_o, base + c) : 0.f;
     }
+    if (drop) {   // uniform branch around pure ALU: residual dropout of branch m (site drop.site + m)
+      const DropState ds = drop_init(d.drop, m, d.d);
+#pragma unroll
+      for (int j = 0; j < PL; ++j) ov[j] = drop_keep(ds, (uint32_t)row, (uint32_t)(lane + 64 * j)) ? ov[j] * ds.scale : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < PL; ++j) v[j] = (lane + 64 * j < d.d) ? xr[j] + ov[j] : 0.f;
     const RowStats st = row_stats<PL>(v, d.d, lane, d.eps);
     const float w = d.independent ? 1.f : (d.coef ? d.coef[m * nscene + scene] : 1.f / (float)d.M);
 #pragma unroll
@@ -88,17 +96,34 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
   }
   // software-pipelined over rows: the three row loads of the NEXT row are in flight while this row is reduced
   const float* dyp = d.independent ? d.dys[m] : d.dy;
+  const bool drop = drop_on(d.drop);
+  DropState dst;
+  if (drop) dst = drop_init(d.drop, m, d.d);
   float nv[PL], ndy[PL];
+  unsigned nkeep = 0xffffffffu;   // bit j: column lane + 64 j of the fetched row survived the residual dropout
   auto fetch = [&](long row) {
     const long base = row * d.d;
+    float xv[PL], ov[PL];
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
       const int c = lane + 64 * j;
       if (c < d.d) {
-        nv[j] = (d.x ? load_elem(d.x, d.dt_x, base + c) : 0.f) + load_elem(d.o[m], d.dt_o, base + c);
+        xv[j] = d.x ? load_elem(d.x, d.dt_x, base + c) : 0.f;
+        ov[j] = load_elem(d.o[m], d.dt_o, base + c);
         ndy[j] = dyp[base + c];
-      } else { nv[j] = 0.f; ndy[j] = 0.f; }
+      } else { xv[j] = 0.f; ov[j] = 0.f; ndy[j] = 0.f; }
     }
+    if (drop) {
+      nkeep = 0;
+#pragma unroll
+      for (int j = 0; j < PL; ++j) {
+        const bool k = drop_keep(dst, (uint32_t)row, (uint32_t)(lane + 64 * j));
+        nkeep |= (unsigned)k << j;
+        ov[j] = k ? ov[j] * dst.scale : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PL; ++j) nv[j] = xv[j] + ov[j];
   };
   if (wave_id < d.R) fetch(wave_id);
   for (long row = wave_id; row < d.R; row += nwaves) {
@@ -106,6 +131,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
     float v[PL], dyr[PL];
 #pragma unroll
     for (int j = 0; j < PL; ++j) { v[j] = nv[j]; dyr[j] = ndy[j]; }
+    const unsigned keep = nkeep;
     const float mean = d.mean[(long)m * d.R + row], rstd = d.rstd[(long)m * d.R + row];
     const float w = d.independent ? 1.f : (d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M);
     if (row + nwaves < d.R) fetch(row + nwaves);
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
       const int c = lane + 64 * j;
       if (c < d.d) {
         const float g = rstd * (dz[j] - s1 - xh[j] * s2);
-        d.d_o[m][base + c] = g;
+        d.d_o[m][base + c] = drop ? (((keep >> j) & 1u) ? g * dst.scale : 0.f) : g;
         if (d.dx && !d.independent) {
           if (d.M == 1) d.dx[base + c] = g;
           else unsafeAtomicAdd(&d.dx[base + c], g);
@@ -161,6 +187,7 @@ int check_ln(const pq3d_ln_desc& d, bool bwd) {
   PQ_CHECK_ARG(d.M >= 1 && d.M <= PQ3D_MAX_GROUPS, "pq3d_add_ln: M out of range");
   PQ_CHECK_ARG(d.rows_per_scene >= 1 && (d.R % d.rows_per_scene) == 0, "pq3d_add_ln: R % rows_per_scene != 0");
   PQ_CHECK_ARG(d.mean && d.rstd, "pq3d_add_ln: null mean/rstd");
+  PQ_CHECK_DROP(d.drop, d.R, d.d, "pq3d_add_ln");
   for (int m = 0; m < d.M; ++m) {
     PQ_CHECK_ARG(d.o[m] && d.gamma[m] && d.beta[m], "pq3d_add_ln: null o/gamma/beta");
     if (bwd) PQ_CHECK_ARG(d.d_o[m] && d.dgamma[m] && d.dbeta[m], "pq3d_add_ln_bwd: null grads");

@@ -109,14 +109,23 @@ class _DwQueue:
 class FusedSpec:
     """Static description of one fused decoder invocation (non-tensor state handed to the Function)."""
 
-    def __init__(self, enc, mh, mems, ct, act, use_self_mask, num_blocks, spatial, mh_count, offline, skip_pred):
+    def __init__(self, enc, mh, mems, ct, act, use_self_mask, num_blocks, spatial, mh_count, offline, skip_pred,
+                 drop_base=None, mh_drop=False):
         self.enc, self.mh, self.mems, self.ct, self.act = enc, mh, list(mems), ct, act
         self.use_self_mask, self.num_blocks, self.spatial = use_self_mask, num_blocks, spatial
         self.mh_count, self.offline, self.skip_pred = mh_count, offline, skip_pred
+        self.drop_base = drop_base   # dropout-site base of the encoder when train-mode dropout is active, else None
+        self.mh_drop = mh_drop       # mask head's cls_head dropout active
+
+    def drop(self, module, app, kind, device, m=0):
+        """Dropout site of `module` (its own p) at layer application `app`, or None when dropout is off."""
+        if self.drop_base is None or not (module.dropout_p > 0.0):
+            return None
+        return ops.make_drop(module.dropout_p, ops.drop_site(self.drop_base, app, kind, m), device)
 
 
-def _mh_forward(spec, x, keys, inv_den, seg_pad, rec):
-    """One MaskHeadSegLevel call on the fused path; returns (cls, mlog, amask)."""
+def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
+    """One MaskHeadSegLevel call (number `call` of this forward) on the fused path; returns (cls, mlog, amask)."""
     mh, ct, ad = spec.mh, spec.ct, ops.act_dtype(spec.ct)
     B, Nq, d = x.shape
     R = B * Nq
@@ -125,6 +134,10 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec):
     L.gemm(M=R, N=c0.out_features, K=d, A=[x], B=[c0.weight.detach()], bias=[c0.bias.detach()], Cs=[h1], ct=ct,
            lda=d, ldb=d, ldc=c0.out_features, act="relu")
     h2, mean, rstd = _ln_fwd(None, [h1], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq)
+    hdrop = None
+    if spec.mh_drop:   # nn.Dropout between LayerNorm and the classifier (utils.py:23), site (mask-head base, call)
+        hdrop = ops.make_drop(mh.dropout_p, ops.drop_site(mh._drop_base, call, ops.DROP_MLP_HEAD), x.device)
+        h2 = ops._dropout_apply(h2, hdrop)
     C_ = c4.out_features
     cls_raw = torch.empty(B, Nq, C_, dtype=torch.float32, device=x.device)
     L.gemm(M=R, N=C_, K=c0.out_features, A=[h2], B=[c4.weight.detach()], bias=[c4.bias.detach()], Cs=[cls_raw], ct=ct,
@@ -145,25 +158,26 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec):
     L.gemm(M=Ns, N=Nq, K=d, A=list(keys), B=[qm[m] for m in range(Mm)], Cs=[mlog] + [None] * (Mm - 1), ct=ct, lda=d,
            ldb=d, ldc=Nq, batch=B, strideA=Ns * d, strideB=Nq * d, strideC=Ns * Nq, kconcat=Mm, row_scale=inv_den,
            row_fill_flag=seg_pad, row_fill=-1e6, mask_out=amask)
-    rec.update(mh_x=x, mh_h1=h1, mh_h2=h2, mh_mean=mean, mh_rstd=rstd, mh_qm=qm)
+    rec.update(mh_x=x, mh_h1=h1, mh_h2=h2, mh_mean=mean, mh_rstd=rstd, mh_qm=qm, mh_drop=hdrop)
     return cls, mlog, amask
 
 
-def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.float32):
+def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.float32, drop=None):
     M = len(os_)
     dm = os_[0].shape[-1]
     R = os_[0].numel() // dm
     y = torch.empty(os_[0].shape, dtype=out_dtype, device=os_[0].device)
     mean = torch.empty(M, R, dtype=torch.float32, device=y.device)
     rstd = torch.empty_like(mean)
-    d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd)
+    d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd, drop)
     nb = (M + 1 + (x is not None)) * R * dm * 4.0
     L.check(timed("pq3d_add_ln_fwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_fwd, C.byref(d), L.stream()),
             "pq3d_add_ln_fwd")
     return y, mean, rstd
 
 
-def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dgs, dbs, want_dx=True, dup_dx=False):
+def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dgs, dbs, want_dx=True, dup_dx=False,
+            drop=None):
     """Returns (dx or None, d_o [M,...] fp32 stacked); dgamma/dbeta accumulate into the arena views dgs/dbs.
     dup_dx: also write the (single-branch) input gradient to a second buffer even without a residual input."""
     M = len(os_)
@@ -172,7 +186,7 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
     dev = dy.device
     d_o = torch.empty(M, *os_[0].shape, dtype=torch.float32, device=dev)
     dx = torch.empty(os_[0].shape, dtype=torch.float32, device=dev) if ((x is not None and want_dx) or dup_dx) else None
-    d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd)
+    d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd, drop)
     d.dy, d.dx, d.accumulate = L.ptr(dy), L.ptr(dx), 1
     for m in range(M):
         d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_o[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
@@ -182,8 +196,10 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
     return dx, d_o
 
 
-def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None, bias=None, mask_bmod=0, bwd=None):
-    d = ops._attn_desc(q, k, v, o, lse, H, ct, zero_attn, 1.0 / math.sqrt(q.shape[-1] // H), kpm, mask, row_open, bias)
+def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None, bias=None, mask_bmod=0, bwd=None,
+          drop=None, drop_bmod=0):
+    d = ops._attn_desc(q, k, v, o, lse, H, ct, zero_attn, 1.0 / math.sqrt(q.shape[-1] // H), kpm, mask, row_open, bias,
+                       drop, drop_bmod)
     d.mask_bmod = mask_bmod
     B, Lq, dm = q.shape
     Lk = k.shape[1]
@@ -270,9 +286,19 @@ class _FusedDecoder(Function):
         attn_mask = row_open = None
         for blk in range(spec.num_blocks):
             for i, layer in enumerate(layers):
+                app = blk * Ln + i
                 rec: Dict[str, object] = {"i": i, "x_in": x}
+                # dropout sites of this layer application (None when dropout is off); memories are stacked along the
+                # attention batch in groups of B -> drop_bmod=B gives memory j the site of slot j
+                dr_ca = spec.drop(cas[i][0], app, ops.DROP_CA_ATTN, dev)
+                dr_cr = spec.drop(cas[i][0], app, ops.DROP_CA_RES, dev)
+                dr_sa = None if spec.spatial else spec.drop(layer.self_attn, app, ops.DROP_SA_ATTN, dev)
+                dr_sr = spec.drop(layer.self_attn, app, ops.DROP_SA_RES, dev)
+                dr_fi = spec.drop(layer.ffn, app, ops.DROP_FFN_INNER, dev)
+                dr_fr = spec.drop(layer.ffn, app, ops.DROP_FFN_RES, dev)
+                rec.update(dr_ca=dr_ca, dr_cr=dr_cr, dr_sa=dr_sa, dr_sr=dr_sr, dr_fi=dr_fi, dr_fr=dr_fr)
                 if spec.mh is not None and not spec.skip_pred:
-                    cls, mlog, amask = _mh_forward(spec, x, keys, inv_den, seg_pad, rec)
+                    cls, mlog, amask = _mh_forward(spec, x, keys, inv_den, seg_pad, rec, app)
                     pcls.append(cls)
                     pmask.append(mlog)
                     attn_mask = offline_mask if spec.offline else amask
@@ -291,17 +317,19 @@ class _FusedDecoder(Function):
                 lse = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
                 if spec.use_self_mask:
                     _attn(q_all.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
-                          o_all.view(M * B, Nq, d), lse, H, ct, True, mask=attn_mask, row_open=row_open, mask_bmod=B)
+                          o_all.view(M * B, Nq, d), lse, H, ct, True, mask=attn_mask, row_open=row_open, mask_bmod=B,
+                          drop=dr_ca, drop_bmod=B)
                 else:
                     _attn(q_all.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
-                          o_all.view(M * B, Nq, d), lse, H, ct, True, kpm=kpm_all)
+                          o_all.view(M * B, Nq, d), lse, H, ct, True, kpm=kpm_all, drop=dr_ca, drop_bmod=B)
                 op_all = torch.empty(M, B, Nq, d, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=d, K=d, A=[o_all[m] for m in range(M)],
                        B=[ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
                        bias=[ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]],
                        Cs=[op_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
                 x1, mean_c, rstd_c = _ln_fwd(x, [op_all[m] for m in range(M)], [ca.norm.weight.detach() for ca in cas[i]],
-                                             [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps, coef, Nq)
+                                             [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps, coef, Nq,
+                                             drop=dr_cr)
                 rec.update(q_all=q_all, o_all=o_all, lse=lse, op_all=op_all, mean_c=mean_c, rstd_c=rstd_c, x1=x1)
                 # -- self attention: 5 launches (spatial) / 4
                 sa = layer.self_attn
@@ -325,10 +353,11 @@ class _FusedDecoder(Function):
                                                           L.stream()), "pq3d_spatial_bias_fwd")
                 o_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
                 lse_s = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
-                _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ct, False, kpm=qmask, bias=sbias)
+                _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ct, False, kpm=qmask, bias=sbias, drop=dr_sa)
                 f = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=d, K=d, A=[o_s], B=[Wo], bias=[bo], Cs=[f], ct=ct, lda=d, ldb=d, ldc=d)
-                x2, mean_s, rstd_s = _ln_fwd(x1, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq)
+                x2, mean_s, rstd_s = _ln_fwd(x1, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
+                                             drop=dr_sr)
                 rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
                 # -- FFN: 3 launches
                 ffn = layer.ffn
@@ -336,21 +365,30 @@ class _FusedDecoder(Function):
                 h = torch.empty(B, Nq, F_, dtype=ad, device=dev)
                 pre = torch.empty_like(h) if spec.act == "gelu" else None
                 L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
-                       C2=[pre], ct=ct, lda=d, ldb=d, ldc=F_, act=spec.act)
+                       C2=[pre], ct=ct, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi)
                 # z = x2 + b2 + h W2^T in one GEMM (residual through the "+aux" epilogue): LayerNorm then reads one
                 # tensor.  Deliberately NOT split-K: atomics would make the forward pass non-deterministic at rounding
                 # level and cost the bit-exact padding-invariance / scene-independence properties (tests).
+                # With residual dropout the branch output must be dropped BEFORE the residual is added, so the add moves
+                # back into the LayerNorm kernel (z = branch only).
                 z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()],
-                       Cs=[z], aux=[x2], act_grad="add", ct=ct, lda=F_, ldb=F_, ldc=d)
-                x3, mean_f, rstd_f = _ln_fwd(None, [z], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq)
+                if dr_fr is None:
+                    L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()],
+                           Cs=[z], aux=[x2], act_grad="add", ct=ct, lda=F_, ldb=F_, ldc=d)
+                    x3, mean_f, rstd_f = _ln_fwd(None, [z], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()],
+                                                 ffn.norm.eps, None, Nq)
+                else:
+                    L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()],
+                           Cs=[z], ct=ct, lda=F_, ldb=F_, ldc=d)
+                    x3, mean_f, rstd_f = _ln_fwd(x2, [z], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()],
+                                                 ffn.norm.eps, None, Nq, drop=dr_fr)
                 rec.update(h=h, pre=pre, z=z, mean_f=mean_f, rstd_f=rstd_f)
                 tape.append(rec)
                 x = x3
         final_rec = None
         if spec.mh is not None:
             final_rec = {"x_in": x}
-            cls, mlog, _ = _mh_forward(spec, x, keys, inv_den, seg_pad, final_rec)
+            cls, mlog, _ = _mh_forward(spec, x, keys, inv_den, seg_pad, final_rec, spec.num_blocks * Ln)
             if spec.skip_pred:
                 pcls, pmask = [], []
             pcls.append(cls)
@@ -427,6 +465,8 @@ class _FusedDecoder(Function):
                 dh2 = torch.empty(B, Nq, Hd, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=Hd, K=C_, A=[dcl], B=[c4.weight.detach()], Cs=[dh2], ct=ct, lda=C_, ldb=Hd, ldc=Hd, transB=True)
                 dwq.add([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct, [G(c4.bias)])
+                if rec.get("mh_drop") is not None:
+                    dh2 = ops._dropout_apply(dh2, rec["mh_drop"])
                 _, dh1 = _ln_bwd(None, [rec["mh_h1"]], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq,
                                  rec["mh_mean"], rec["mh_rstd"], dh2, [G(c2.weight)], [G(c2.bias)])
                 dpre = ops.act_bwd(dh1[0], rec["mh_h1"], "relu", ad)
@@ -470,14 +510,21 @@ class _FusedDecoder(Function):
             # ---------------- FFN backward
             ffn = layer.ffn
             F_ = ffn.linear1.out_features
-            dx2r, dy = _ln_bwd(None, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None,
-                               Nq, rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
-                               dup_dx=True)
+            if rec["dr_fr"] is None:
+                dx2r, dy = _ln_bwd(None, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps,
+                                   None, Nq, rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
+                                   dup_dx=True)
+            else:   # dx2r = residual-branch gradient, dy = dropout-masked gradient of the linear2 output
+                dx2r, dy = _ln_bwd(x2, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps,
+                                   None, Nq, rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
+                                   drop=rec["dr_fr"])
             dy = dy[0]   # d z: gradient of the linear2 output AND (second copy dx2r) of the residual branch
             dhp = torch.empty(B, Nq, F_, dtype=ad, device=dev)
+            # inner dropout (ReLU only on this path): the saved h is post-dropout, so [h > 0] already carries the
+            # keep-mask and only the 1/(1-p) factor is left -> alpha
             L.gemm(M=R, N=F_, K=d, A=[dy], B=[ffn.linear2.weight.detach()], Cs=[dhp],
                    aux=[rec["pre"] if spec.act == "gelu" else rec["h"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
-                   transB=True)
+                   transB=True, alpha=1.0 / (1.0 - rec["dr_fi"].p) if rec["dr_fi"] is not None else 1.0)
             dwq.add([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
             dx2 = dx2r   # dx2 = dx2r + dhp W1: split-K accumulated in place onto the residual-branch gradient
             L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], ct=ct, lda=F_, ldb=d, ldc=d,
@@ -499,7 +546,8 @@ class _FusedDecoder(Function):
                 Gb = [gb[:d], gb[d:2 * d], gb[2 * d:]]
                 Wo, GWo, Gbo = sa.self_attn.out_proj.weight.detach(), G(sa.self_attn.out_proj.weight), G(sa.self_attn.out_proj.bias)
             dx1r, df = _ln_bwd(x1, [rec["f"]], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
-                               rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)])
+                               rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)],
+                               drop=rec["dr_sr"])
             df = df[0]
             do_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
             L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
@@ -509,7 +557,7 @@ class _FusedDecoder(Function):
             delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
             dsb = torch.empty_like(rec["sbias"]) if spec.spatial else None
             _attn(qkv[0], qkv[1], qkv[2], rec["o_s"], rec["lse_s"], H, ct, False, kpm=qmask, bias=rec["sbias"],
-                  bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb))
+                  bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb), drop=rec["dr_sa"])
             if spec.spatial:
                 L.check(L.lib().pq3d_spatial_bias_bwd_acc(L.ptr(pl), L.ptr(msa.pairwise_loc_fc.weight.detach()),
                                                           L.ptr(msa.pairwise_loc_fc.bias.detach()), L.ptr(dsb),
@@ -529,7 +577,7 @@ class _FusedDecoder(Function):
             cl = cas[i]
             dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
                                [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef, Nq, rec["mean_c"], rec["rstd_c"],
-                               dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl])
+                               dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl], drop=rec["dr_cr"])
             do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
             L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
                    Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
@@ -543,7 +591,7 @@ class _FusedDecoder(Function):
             _attn(rec["q_all"].view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
                   rec["o_all"].view(M * B, Nq, d), rec["lse"], H, ct, True,
                   bwd=(do_all.view(M * B, Nq, d), dq_all.view(M * B, Nq, d), dKV[a, 0].view(M * B, Ns, d),
-                       dKV[a, 1].view(M * B, Ns, d), delta_c, None), **mb)
+                       dKV[a, 1].view(M * B, Ns, d), delta_c, None), drop=rec["dr_ca"], drop_bmod=B, **mb)
             ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cl]
             gq = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
             dxn = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
@@ -657,8 +705,19 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
         keep = torch.logical_or(keep, keep.sum(1, keepdim=True) == 0)
         coef = (keep / keep.sum(1, keepdim=True)).t().contiguous().float()
     ct = L.BF16 if layer0.compute == "bf16" else L.F32
+    drop_base, mh_drop = None, False
+    if training:   # the caller (QueryMaskEncoder.forward) has opened the RNG epoch (modules.begin_dropout_step)
+        layers_ = list(enc.unified_encoder)
+        ps = [m.dropout_p for l_ in layers_ for m in (list(l_.cross_attn_list) + [l_.self_attn, l_.ffn])]
+        if any(p_ > 0.0 for p_ in ps):
+            if layer0.ffn.activation != "relu" and any(l_.ffn.dropout_p > 0.0 for l_ in layers_):
+                raise NotImplementedError("fused path: FFN dropout is implemented for ReLU")
+            if any(len({c.dropout_p for c in l_.cross_attn_list}) > 1 for l_ in layers_):
+                raise NotImplementedError("fused path: one dropout probability per layer's cross-attention list")
+            drop_base = enc._drop_base
+        mh_drop = mask_head is not None and mask_head.dropout_p > 0.0
     spec = FusedSpec(enc, mask_head, mems, ct, layer0.ffn.activation, enc.use_self_mask, enc.num_blocks,
-                     enc.spatial_selfattn, mh_count, offline_attn_masks is not None, skip_prediction)
+                     enc.spatial_selfattn, mh_count, offline_attn_masks is not None, skip_prediction, drop_base, mh_drop)
     params = [p for p in enc.parameters()] + ([p for p in mask_head.parameters()] if mask_head is not None else [])
     outs = _FusedDecoder.apply(spec, x0, qpos, qmask, poss[0], pairwise_locs, seg_masks, offline_attn_masks, coef,
                                *feats, *masks, *params)

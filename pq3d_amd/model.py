@@ -87,7 +87,10 @@ class Query3DUnified(nn.Module):
             if inp == "voxel" and not self.use_offline_voxel_fts:
                 raise NotImplementedError("online voxel backbone (MinkowskiEngine) is out of scope; "
                                           "set use_offline_voxel_fts")
-            setattr(self, inp + "_encoder", build_module_by_name(cfg.model.get(inp + "_encoder")))
+            enc = build_module_by_name(cfg.model.get(inp + "_encoder"))
+            if hasattr(enc, "_drop_base"):   # one dropout-site range per encoder instance
+                enc._drop_base = M.DROP_BASE_OBJ_ENC + (self.inputs.index(inp) << 12)
+            setattr(self, inp + "_encoder", enc)
         self.dim_loc = cfg.model.obj_loc.dim_loc
         self.hidden_size = hidden_size = cfg.model.hidden_size
         if self.dim_loc > 3:
@@ -150,10 +153,14 @@ class Query3DUnified(nn.Module):
         seqs = [e.input_feat_proj for e in encs]
         ys = ops.linear_ln_group(xs, [q[0].weight for q in seqs], [q[0].bias for q in seqs],
                                  [q[1].weight for q in seqs], [q[1].bias for q in seqs], ct=self.ct, eps=seqs[0][1].eps)
+        if self.training:   # ObjectEncoder's output dropout (object_encoder.py:72-73), same sites as the per-encoder path
+            ys = [ops.dropout(y, e._drop(e._head_ctx(y.device), ops.DROP_ENC_OUT, y.device)) for y, e in zip(ys, encs)]
         return dict(zip(names, ys))
 
     def forward(self, data_dict):
         input_dict = {}
+        if self.training:
+            M.begin_dropout_step(self, data_dict["query_locs"].device)
         mask = data_dict["query_pad_masks"].logical_not()
         query_locs = data_dict["query_locs"][:, :, :self.dim_loc]
         coord_min, coord_max = data_dict["coord_min"], data_dict["coord_max"]

@@ -6,8 +6,11 @@ reference's state_dict key names and let DDP / optimisers see ordinary leaf Para
 never called.  ``compute`` selects the MFMA path: 'bf16' (bf16 operands, fp32 accumulate / softmax / LayerNorm /
 residual stream) or 'fp32' (exact-f32 MFMA everywhere).
 
-Dropout: the reference trains with p=0.1; these modules implement the p=0 (eval / parity) arithmetic only and
-ignore the ``dropout`` constructor arguments (DESIGN.md "out of scope").
+Dropout: in train mode every nn.Dropout / MultiheadAttention(dropout=p) site of the reference is applied INSIDE the
+kernels (attention probabilities, residual branches before add+LayerNorm, FFN hidden) from a counter-based generator
+(include/pq3d_hip.h "Dropout", ops.DropRNG): same distribution as torch's, different random stream.  Site ids are
+structural -- (module base, layer application, kind, memory) -> ops.drop_site -- so the fused executor, the modular
+path and the test-side mask generator agree.  eval() or p == 0 turns it off.
 """
 from __future__ import annotations
 
@@ -23,6 +26,10 @@ from . import ops
 from ._lib import BF16, F32
 
 CT = {"bf16": BF16, "fp32": F32}
+# dropout-site bases of the module roles (a second instance of a role in one model may be given its own
+# ``_drop_base``; instances sharing a base draw identical masks for identical shapes)
+DROP_BASE_ENCODER, DROP_BASE_MASK_HEAD, DROP_BASE_GROUND_HEAD, DROP_BASE_OBJ_ENC, DROP_BASE_LAYER = \
+    (1 << 20, 2 << 20, 3 << 20, 4 << 20, 5 << 20)
 
 
 def set_compute(module: nn.Module, compute: str) -> nn.Module:
@@ -32,6 +39,29 @@ def set_compute(module: nn.Module, compute: str) -> nn.Module:
         if hasattr(m, "compute"):
             m.compute = compute
     return module
+
+
+def set_dropout(module: nn.Module, p: float) -> nn.Module:
+    """Override every dropout probability below ``module`` (layers, heads, encoders); memory_dropout is untouched."""
+    for m in module.modules():
+        if hasattr(m, "dropout_p"):
+            m.dropout_p = float(p)
+        if hasattr(m, "cls_dropout_p"):
+            m.cls_dropout_p = float(p)
+    return module
+
+
+def begin_dropout_step(owner: nn.Module, device, extra: Sequence[nn.Module] = ()) -> None:
+    """Start of a training forward of a top-level module: make the dropout RNG epoch new for this call (unless a
+    parent module already did for this step) and tell the dropout-bearing children that their site ids are managed
+    structurally in this epoch (heads then use (base, call index) instead of advancing the RNG themselves)."""
+    rng = ops.drop_rng(device)
+    if rng.epoch == getattr(owner, "_drop_epoch", -1):
+        rng.advance()
+    owner._drop_epoch = rng.epoch
+    for m in list(owner.modules()) + list(extra):
+        if isinstance(m, _PostNormBase):
+            m._drop_managed = rng.epoch
 
 
 def _init_weights_bert(module: nn.Module, std: float = 0.02) -> None:
@@ -58,9 +88,11 @@ def get_mlp_head(input_size: int, hidden_size: int, output_size: int, dropout: f
                          nn.Dropout(dropout), nn.Linear(hidden_size, output_size))
 
 
-def mlp_head_forward(seq: nn.Sequential, x: torch.Tensor, ct: int, fill_flag=None, fill_value=0.0) -> torch.Tensor:
+def mlp_head_forward(seq: nn.Sequential, x: torch.Tensor, ct: int, fill_flag=None, fill_value=0.0,
+                     drop=None) -> torch.Tensor:
     h = ops.linear(x, seq[0].weight, seq[0].bias, ct=ct, act="relu", out_dtype=torch.float32)
     h = ops.add_layernorm(None, [h], [seq[2].weight], [seq[2].bias], eps=seq[2].eps)
+    h = ops.dropout(h, drop)   # nn.Dropout between LayerNorm and the last Linear (utils.py:23)
     return ops.linear(h, seq[4].weight, seq[4].bias, ct=ct, fill_flag=fill_flag, fill_value=fill_value)
 
 
@@ -104,10 +136,41 @@ class _PostNormBase(nn.Module):
     def __init__(self):
         super().__init__()
         self.compute = "bf16"
+        self.dropout_p = 0.0
+        self._drop_base = DROP_BASE_LAYER
+        self._drop_epoch = -1
+        self._drop_managed = -1    # RNG epoch in which a parent manages this module's dropout sites
+        self._drop_call = 0        # call index within a managed epoch (mask head: layer application)
 
     @property
     def ct(self) -> int:
         return CT[self.compute]
+
+    def _drop_ctx(self, device, ctx=None, p=None):
+        """(site base, layer application) for this call, or None when dropout is inactive.  A caller higher up (the
+        encoder) hands its ctx down; a module used on its own makes sure the RNG epoch is fresh for every call."""
+        if not self.training or not ((self.dropout_p if p is None else p) > 0.0):
+            return None
+        if ctx is not None:
+            return ctx
+        rng = ops.drop_rng(device)
+        if rng.epoch == self._drop_epoch:
+            rng.advance()
+        self._drop_epoch = rng.epoch
+        return (self._drop_base, 0)
+
+    def _head_ctx(self, device, p=None):
+        """ctx for a head / encoder: structural (base, call) when a parent manages this epoch, else standalone."""
+        if not self.training or not ((self.dropout_p if p is None else p) > 0.0):
+            return None
+        if self._drop_managed == ops.drop_rng(device).epoch:
+            return (self._drop_base, self._drop_call)
+        return self._drop_ctx(device, None, p)
+
+    def _drop(self, ctx, kind, device, m=0, p=None):
+        if ctx is None:
+            return None
+        return ops.make_drop(self.dropout_p if p is None else p, ops.drop_site(ctx[0], ctx[1], kind, m), device)
 
 
 class CrossAttentionLayer(_PostNormBase):
@@ -120,10 +183,11 @@ class CrossAttentionLayer(_PostNormBase):
         self.multihead_attn = _MHAParams(d_model, nhead)
         self.norm = nn.LayerNorm(d_model)
         self.nhead = nhead
+        self.dropout_p = float(dropout)
         _xavier(self)
 
     def branch(self, tgt, memory, attn_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
-               row_open=None) -> torch.Tensor:
+               row_open=None, _drop=None, _m=0) -> torch.Tensor:
         """out_proj(MHA(tgt+query_pos, memory+pos, memory)) -- the pre-residual branch output, fp32."""
         ct, d = self.ct, tgt.shape[-1]
         w, b = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
@@ -132,13 +196,15 @@ class CrossAttentionLayer(_PostNormBase):
         k = ops.linear(memory, w[d:2 * d], b[d:2 * d], x2=pos, ct=ct, out_dtype=ad)
         v = ops.linear(memory, w[2 * d:], b[2 * d:], ct=ct, out_dtype=ad)
         o = ops.attention(q, k, v, H=self.nhead, ct=ct, zero_attn=True, kpm=memory_key_padding_mask, mask=attn_mask,
-                          row_open=row_open)
+                          row_open=row_open, drop=self._drop(_drop, ops.DROP_CA_ATTN, tgt.device, _m))
         return ops.linear(o, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, ct=ct)
 
     def forward(self, tgt, memory, attn_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
-                row_open=None):
-        o = self.branch(tgt, memory, attn_mask, memory_key_padding_mask, pos, query_pos, row_open)
-        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps, coef=None)
+                row_open=None, _drop=None, _m=0):
+        ctx = self._drop_ctx(tgt.device, _drop)
+        o = self.branch(tgt, memory, attn_mask, memory_key_padding_mask, pos, query_pos, row_open, _drop=ctx, _m=_m)
+        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps, coef=None,
+                                 drop=self._drop(ctx, ops.DROP_CA_RES, tgt.device, _m))
 
 
 class SelfAttentionLayer(_PostNormBase):
@@ -151,18 +217,22 @@ class SelfAttentionLayer(_PostNormBase):
         self.self_attn = _MHAParams(d_model, nhead)
         self.norm = nn.LayerNorm(d_model)
         self.nhead = nhead
+        self.dropout_p = float(dropout)
         _xavier(self)
 
-    def forward(self, tgt, attn_mask=None, tgt_key_padding_mask=None, query_pos=None):
+    def forward(self, tgt, attn_mask=None, tgt_key_padding_mask=None, query_pos=None, _drop=None):
         ct, d = self.ct, tgt.shape[-1]
+        ctx = self._drop_ctx(tgt.device, _drop)
         w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
         ad = ops.act_dtype(ct)
         q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=ct, out_dtype=ad)
         k = ops.linear(tgt, w[d:2 * d], b[d:2 * d], x2=query_pos, ct=ct, out_dtype=ad)
         v = ops.linear(tgt, w[2 * d:], b[2 * d:], ct=ct, out_dtype=ad)
-        o = ops.attention(q, k, v, H=self.nhead, ct=ct, kpm=tgt_key_padding_mask, mask=attn_mask)
+        o = ops.attention(q, k, v, H=self.nhead, ct=ct, kpm=tgt_key_padding_mask, mask=attn_mask,
+                          drop=self._drop(ctx, ops.DROP_SA_ATTN, tgt.device))
         o = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, ct=ct)
-        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
+                                 drop=self._drop(ctx, ops.DROP_SA_RES, tgt.device))
 
 
 class MultiHeadAttentionSpatial(_PostNormBase):
@@ -202,12 +272,15 @@ class SpatialSelfAttentionLayer(_PostNormBase):
         self.self_attn = MultiHeadAttentionSpatial(d_model, nhead, dropout=dropout, spatial_multihead=spatial_multihead,
                                                    spatial_dim=spatial_dim, spatial_attn_fusion=spatial_attn_fusion)
         self.norm = nn.LayerNorm(d_model)
+        self.dropout_p = float(dropout)   # residual dropout only: MultiHeadAttentionSpatial never drops its weights
         _xavier(self)
 
-    def forward(self, tgt, attn_mask=None, tgt_key_padding_mask=None, query_pos=None, pairwise_locs=None):
+    def forward(self, tgt, attn_mask=None, tgt_key_padding_mask=None, query_pos=None, pairwise_locs=None, _drop=None):
+        ctx = self._drop_ctx(tgt.device, _drop)
         o = self.self_attn(tgt, tgt, tgt, pairwise_locs, key_padding_mask=tgt_key_padding_mask, q_pos=query_pos,
                            k_pos=query_pos)
-        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+        return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
+                                 drop=self._drop(ctx, ops.DROP_SA_RES, tgt.device))
 
 
 class FFNLayer(_PostNormBase):
@@ -223,14 +296,17 @@ class FFNLayer(_PostNormBase):
         self.linear2 = nn.Linear(dim_feedforward, d_model)
         self.norm = nn.LayerNorm(d_model)
         self.activation = activation
+        self.dropout_p = float(dropout)
         _xavier(self)
 
-    def forward(self, tgt):
+    def forward(self, tgt, _drop=None):
         ct = self.ct
+        ctx = self._drop_ctx(tgt.device, _drop)
         h = ops.linear(tgt, self.linear1.weight, self.linear1.bias, ct=ct, act=self.activation,
-                       out_dtype=ops.act_dtype(ct))
+                       out_dtype=ops.act_dtype(ct), drop=self._drop(ctx, ops.DROP_FFN_INNER, tgt.device))
         y = ops.linear(h, self.linear2.weight, self.linear2.bias, ct=ct)
-        return ops.add_layernorm(tgt, [y], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+        return ops.add_layernorm(tgt, [y], [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
+                                 drop=self._drop(ctx, ops.DROP_FFN_RES, tgt.device))
 
 
 class QueryEncoderLayer(_PostNormBase):
@@ -254,11 +330,13 @@ class QueryEncoderLayer(_PostNormBase):
         self.memories = list(memories)
         self.memory_dropout = memory_dropout
         self.drop_memories_test = list(drop_memories_test)
+        self.dropout_p = float(dropout)
         if structure == "gate":
             self.gate_proj = nn.Linear(d_model, d_model)
 
-    def forward(self, query, input_dict, pairwise_locs=None):
+    def forward(self, query, input_dict, pairwise_locs=None, _drop=None):
         _, query_masks, query_pos = input_dict["query"][:3]
+        dctx = self._drop_ctx(query.device, _drop)
         B, H = query.shape[0], self.cross_attn_list[0].nhead if len(self.cross_attn_list) else 1
         row_open = input_dict.get("_attn_row_open")
 
@@ -268,22 +346,25 @@ class QueryEncoderLayer(_PostNormBase):
             return dict(memory=feat, attn_mask=am, memory_key_padding_mask=kpm, pos=pos, query_pos=query_pos,
                         row_open=row_open if am is not None else None)
 
+        # dropout sites of the cross-attention sublayers: memory slot = position in the list handed to parallel_ca
+        # (what the fused executor stacks), 4 + position for sequential_ca
         def sequential_ca(q, memories):
-            for m in memories:
-                q = self.memory2ca[m](q, **ca_args(m))
+            for j, m in enumerate(memories):
+                q = self.memory2ca[m](q, **ca_args(m), _drop=dctx, _m=4 + j)
             return q
 
         def parallel_ca(q, memories):
             assert "prompt" not in memories
             cas = [self.memory2ca[m] for m in memories]
-            outs = [ca.branch(q, **ca_args(m)) for ca, m in zip(cas, memories)]
+            outs = [ca.branch(q, **ca_args(m), _drop=dctx, _m=j) for j, (ca, m) in enumerate(zip(cas, memories))]
             coef = None
             if self.training and self.memory_dropout > 0.0:  # query_encoder.py:145-151
                 keep = torch.rand(B, len(memories), device=q.device) > self.memory_dropout
                 keep = torch.logical_or(keep, keep.sum(1, keepdim=True) == 0)
                 coef = (keep / keep.sum(1, keepdim=True)).t().contiguous().float()  # [M,B]
             return ops.add_layernorm(q, outs, [c.norm.weight for c in cas], [c.norm.bias for c in cas],
-                                     eps=cas[0].norm.eps, coef=coef)
+                                     eps=cas[0].norm.eps, coef=coef,
+                                     drop=cas[0]._drop(dctx, ops.DROP_CA_RES, q.device) if cas else None)
 
         memories = self.memories if self.training else [m for m in self.memories if m not in self.drop_memories_test]
         if self.structure == "sequential":
@@ -303,10 +384,10 @@ class QueryEncoderLayer(_PostNormBase):
 
         if isinstance(self.self_attn, SpatialSelfAttentionLayer):
             query = self.self_attn(query, tgt_key_padding_mask=query_masks, query_pos=query_pos,
-                                   pairwise_locs=pairwise_locs)
+                                   pairwise_locs=pairwise_locs, _drop=dctx)
         else:
-            query = self.self_attn(query, tgt_key_padding_mask=query_masks, query_pos=query_pos)
-        return self.ffn(query)
+            query = self.self_attn(query, tgt_key_padding_mask=query_masks, query_pos=query_pos, _drop=dctx)
+        return self.ffn(query, _drop=dctx)
 
 
 class QueryMaskEncoder(nn.Module):
@@ -333,6 +414,7 @@ class QueryMaskEncoder(nn.Module):
         self.num_blocks = num_blocks
         self.fused = True          # use the fused executor (fused.py) whenever the configuration allows it
         self._fused_final = None   # (cls, mask_logits) of the trailing mask-head call computed by the fused path
+        self._drop_base, self._drop_epoch = DROP_BASE_ENCODER, -1
         set_compute(self, compute)
 
     def _try_fused(self, input_dict, pairwise_locs, mask_head):
@@ -360,6 +442,16 @@ class QueryMaskEncoder(nn.Module):
 
     def forward(self, input_dict, pairwise_locs, mask_head=None):
         self._fused_final = None
+        mh_owner = None
+        if isinstance(mask_head, partial):
+            func = mask_head.func
+            mh_owner = func if isinstance(func, MaskHeadSegLevel) else getattr(func, "__self__", None)
+            mh_owner = mh_owner if isinstance(mh_owner, MaskHeadSegLevel) else None
+        n_app = self.num_blocks * len(self.unified_encoder)
+        if self.training:
+            begin_dropout_step(self, input_dict["query"][0].device, [mh_owner] if mh_owner is not None else ())
+        if mh_owner is not None:
+            mh_owner._drop_call = n_app   # the trailing call the model makes after the encoder
         if self.fused:
             out = self._try_fused(input_dict, pairwise_locs, mask_head)
             if out is not None:
@@ -370,7 +462,10 @@ class QueryMaskEncoder(nn.Module):
         attn_mask = None
         for _block in range(self.num_blocks):
             for i, layer in enumerate(self.unified_encoder):
+                app = _block * len(self.unified_encoder) + i
                 if mask_head is not None:
+                    if mh_owner is not None:
+                        mh_owner._drop_call = app
                     output_class, outputs_mask, attn_mask = mask_head(query)
                     predictions_class.append(output_class)
                     predictions_mask.append(outputs_mask)
@@ -384,7 +479,9 @@ class QueryMaskEncoder(nn.Module):
                         input_dict[memory][1] = attn_mask
                 if isinstance(voxel_feat, list):
                     input_dict["voxel"][0] = voxel_feat[i]
-                query = layer(query, input_dict, pairwise_locs)
+                query = layer(query, input_dict, pairwise_locs, _drop=(self._drop_base, app) if self.training else None)
+        if mh_owner is not None:
+            mh_owner._drop_call = n_app
         return query, predictions_class, predictions_mask
 
 
@@ -400,15 +497,18 @@ class QueryEncoder(nn.Module):
                                   structure=structure)
         self.unified_encoder = layer_repeat(layer, num_layers, share_layer)
         self.apply(_init_weights_bert)
+        self._drop_base, self._drop_epoch = DROP_BASE_ENCODER, -1
         set_compute(self, compute)
 
     def forward(self, input_dict, pairwise_locs):
         query = input_dict["query"][0]
+        if self.training:
+            begin_dropout_step(self, query.device)
         voxel_feat = input_dict["voxel"][0] if "voxel" in input_dict.keys() else None
         for i, layer in enumerate(self.unified_encoder):
             if isinstance(voxel_feat, list):
                 input_dict["voxel"][0] = voxel_feat[i]
-            query = layer(query, input_dict, pairwise_locs)
+            query = layer(query, input_dict, pairwise_locs, _drop=(self._drop_base, i) if self.training else None)
         return query
 
 
@@ -433,6 +533,7 @@ class MaskHeadSegLevel(_PostNormBase):
         memories_for_match = [m for m in memories_for_match if m in ("voxel", "mv", "pc")]
         self.mask_pred_list = layer_repeat(MaskPredictionLayer(hidden_size), len(memories_for_match))
         self.num_targets = num_targets
+        self.dropout_p, self._drop_base = float(dropout), DROP_BASE_MASK_HEAD
         # reference quirk: filter_out_classes=None makes x[..., None] = -inf overwrite every logit (mask_head.py:28)
         foc = list(range(num_targets)) if filter_out_classes is None else list(filter_out_classes)
         self.register_buffer("_foc_cols", torch.tensor(foc, dtype=torch.int32), persistent=False)
@@ -451,7 +552,8 @@ class MaskHeadSegLevel(_PostNormBase):
         if skip_prediction:
             return None, None, offline_attn_masks
         ct = self.ct
-        cls_logits = mlp_head_forward(self.cls_head, query, ct)
+        cls_logits = mlp_head_forward(self.cls_head, query, ct,
+                                      drop=self._drop(self._head_ctx(query.device), ops.DROP_MLP_HEAD, query.device))
         if self._foc_cols.numel():
             cls_logits = ops.fill_cols(cls_logits, self._foc_cols, float("-inf"))
         k_list, inv_den = keys if keys is not None else self.project_keys(seg_fts_for_match)
@@ -469,11 +571,13 @@ class GroundHead(_PostNormBase):
     def __init__(self, cfg, input_size=768, hidden_size=768, dropout=0.3):
         super().__init__()
         self.og3d_head = get_mlp_head(input_size, hidden_size, 1, dropout=dropout)
+        self.dropout_p, self._drop_base = float(dropout), DROP_BASE_GROUND_HEAD
 
     def forward(self, obj_embeds, obj_masks=None, **kwargs):
         flag = obj_masks.logical_not() if obj_masks is not None else None
-        return mlp_head_forward(self.og3d_head, obj_embeds, self.ct, fill_flag=flag,
-                                fill_value=float("-inf")).squeeze(2)
+        dev = obj_embeds.device
+        return mlp_head_forward(self.og3d_head, obj_embeds, self.ct, fill_flag=flag, fill_value=float("-inf"),
+                                drop=self._drop(self._head_ctx(dev), ops.DROP_MLP_HEAD, dev)).squeeze(2)
 
 
 # ------------------------------------------------------------------------------------------------ input side
@@ -487,6 +591,7 @@ class ObjectEncoder(_PostNormBase):
             raise NotImplementedError("PointNet++ backbone is out of scope (SURVEY §2 row 10)")
         if use_cls_head:
             self.cls_head = get_mlp_head(input_feat_size, input_feat_size // 2, tgt_cls_num, dropout=0.3)
+        self.dropout_p, self.cls_dropout_p, self._drop_base = float(dropout), 0.3, DROP_BASE_OBJ_ENC
         self.use_projection = use_projection
         if use_projection:
             self.input_feat_proj = nn.Sequential(nn.Linear(input_feat_size, hidden_size), nn.LayerNorm(hidden_size))
@@ -498,8 +603,13 @@ class ObjectEncoder(_PostNormBase):
 
     def forward(self, obj_feats, data_dict=None, **kwargs):
         obj_embeds = linear_ln_forward(self.input_feat_proj, obj_feats, self.ct) if self.use_projection else obj_feats
+        dev = obj_feats.device
+        ctx = self._head_ctx(dev, max(self.dropout_p, self.cls_dropout_p if hasattr(self, "cls_head") else 0.0))
+        if self.dropout_p > 0:   # object_encoder.py:72-73
+            obj_embeds = ops.dropout(obj_embeds, self._drop(ctx, ops.DROP_ENC_OUT, dev))
         if hasattr(self, "cls_head"):
-            return obj_embeds, mlp_head_forward(self.cls_head, obj_feats, self.ct)
+            return obj_embeds, mlp_head_forward(self.cls_head, obj_feats, self.ct,
+                                                drop=self._drop(ctx, ops.DROP_MLP_HEAD, dev, p=self.cls_dropout_p))
         return obj_embeds
 
 

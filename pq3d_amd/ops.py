@@ -32,6 +32,89 @@ def _splitk(tiles: int, k: int, ct: int) -> int:
     return max(1, min(nkt // 2 if nkt >= 2 else 1, 512 // max(tiles, 1), 64))
 
 
+# ------------------------------------------------------------------------------------------------ dropout
+class DropRNG:
+    """Per-device dropout state (include/pq3d_hip.h "Dropout").  ``seed`` is the int64 device word the kernels hash;
+    advance() bumps it ON THE DEVICE (capturable: a replayed HIP graph draws new masks every step) and snapshots it
+    into ``cur`` -- the tensor dropout sites actually point at, so a backward pass that runs after a later forward
+    still regenerates its own masks.  The initial value comes from torch's CPU generator (torch.manual_seed)."""
+
+    def __init__(self, device):
+        self.seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+        self.cur = self.seed.clone()
+        self.epoch = 0
+
+    def advance(self) -> None:
+        self.seed.add_(1)
+        self.cur = self.seed.clone()
+        self.epoch += 1
+
+    def set_seed(self, value: int) -> None:
+        self.seed.fill_(int(value))
+        self.cur = self.seed.clone()
+        self.epoch += 1
+
+
+_DROP_RNG = {}
+
+
+def drop_rng(device) -> DropRNG:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    st = _DROP_RNG.get(device)
+    if st is None:
+        st = _DROP_RNG[device] = DropRNG(device)
+    return st
+
+
+# dropout-site numbering inside one decoder forward: (layer application, kind, memory) -> site id.  The fused and
+# the modular executors (and the oracle-side mask generator in tests) all use this one function.
+DROP_CA_ATTN, DROP_CA_RES, DROP_SA_ATTN, DROP_SA_RES, DROP_FFN_INNER, DROP_FFN_RES, DROP_MLP_HEAD, DROP_ENC_OUT = range(8)
+
+
+def drop_site(base: int, app: int, kind: int, m: int = 0) -> int:
+    return base + (app * 16 + kind) * 8 + m
+
+
+def make_drop(p: float, site: int, device) -> Optional[L.Drop]:
+    return L.Drop(p, site, drop_rng(device).cur) if p and p > 0.0 else None
+
+
+def dropout_mask(rows: int, cols: int, drop: L.Drop) -> torch.Tensor:
+    """keep-mask [rows, cols] (bool) of a dropout site -- what the fused kernels draw (tests, debugging)."""
+    keep = _empty(rows, cols, dtype=torch.bool, device=drop.seed.device)
+    dc = drop.c()
+    L.check(L.lib().pq3d_dropout_mask(L.ptr(keep), rows, cols, C.byref(dc), L.stream()), "pq3d_dropout_mask")
+    return keep
+
+
+def _dropout_apply(x: torch.Tensor, drop: L.Drop, out_dtype=None) -> torch.Tensor:
+    x = x.contiguous()
+    y = _empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    cols = x.shape[-1]
+    dc = drop.c()
+    L.check(L.lib().pq3d_dropout_apply(L.ptr(x), L.dt_of(x), L.ptr(y), L.dt_of(y), x.numel() // cols, cols, C.byref(dc),
+                                       L.stream()), "pq3d_dropout_apply")
+    return y
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, drop):
+        ctx.drop = drop
+        return _dropout_apply(x, drop)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _dropout_apply(dy, ctx.drop), None
+
+
+def dropout(x: torch.Tensor, drop: Optional[L.Drop]) -> torch.Tensor:
+    """nn.Dropout over the last dim as the site's column axis (site = x viewed as [rows, x.shape[-1]])."""
+    return x if drop is None else _Dropout.apply(x, drop)
+
+
 # ------------------------------------------------------------------------------------------------ small kernels
 def colsum(x2d: torch.Tensor) -> torch.Tensor:
     R, N = x2d.shape
@@ -100,7 +183,7 @@ def fourier(xyz: torch.Tensor, cmin: torch.Tensor, cmax: torch.Tensor, gauss_B: 
 # ------------------------------------------------------------------------------------------------ linear
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value):
+    def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value, drop=None):
         x, x2, w, fill_flag = _c(x), _c(x2), _c(w), _c(fill_flag)
         K = x.shape[-1]
         R = x.numel() // K
@@ -109,9 +192,9 @@ class _Linear(Function):
         pre = _empty(y.shape, dtype=out_dtype, device=x.device) if act == "gelu" else None
         rm = _c(row_mask)
         L.gemm(M=R, N=N, K=K, A=[x], A2=[x2], B=[w], bias=[b], Cs=[y], C2=[pre], row_mask=[rm], ct=ct,
-               lda=K, ldb=K, ldc=N, act=act, row_fill_flag=fill_flag, row_fill=fill_value)
+               lda=K, ldb=K, ldc=N, act=act, row_fill_flag=fill_flag, row_fill=fill_value, drop=drop)
         ctx.save_for_backward(x, x2, w, pre if act == "gelu" else (y if act == "relu" else None), rm, fill_flag)
-        ctx.ct, ctx.act, ctx.has_b = ct, act, b is not None
+        ctx.ct, ctx.act, ctx.has_b, ctx.drop = ct, act, b is not None, drop
         return y
 
     @staticmethod
@@ -121,6 +204,8 @@ class _Linear(Function):
         N, K = w.shape
         R = x.numel() // K
         g = dy.contiguous()
+        if ctx.drop is not None:   # dropout sits after the activation: undo it first (mask * 1/(1-p))
+            g = _dropout_apply(g, ctx.drop)
         if ctx.act in ("relu", "gelu"):
             g = act_bwd(g, saved, ctx.act, act_dtype(ct))
         if rm is not None or fill_flag is not None:
@@ -148,21 +233,21 @@ class _Linear(Function):
                    colsum=[db] if fuse else None)
         if want_db and db is None:
             db = colsum(g.view(R, N))
-        return dx, dw, db, dx2, None, None, None, None, None, None
+        return dx, dw, db, dx2, None, None, None, None, None, None, None
 
 
 def linear(x, w, b=None, *, ct: int, x2=None, act: Optional[str] = None, out_dtype=torch.float32, row_mask=None,
-           fill_flag=None, fill_value=0.0):
+           fill_flag=None, fill_value=0.0, drop: Optional[L.Drop] = None):
     """y = act((x + x2) @ w.T + b); rows where row_mask == False are zeroed; rows where fill_flag == True are
     set to fill_value (masked_fill of whole rows).  (F.linear call sites, see include/pq3d_hip.h)"""
-    return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value))
+    return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value), drop)
 
 
 # ------------------------------------------------------------------------------------------------ attention
 _ATTN_KSPLIT = int(os.environ.get("PQ3D_ATTN_KSPLIT", "0"))   # experiments only; 0 = built-in rule
 
 
-def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias) -> L.AttnDesc:
+def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, drop=None, drop_bmod=0) -> L.AttnDesc:
     B, Lq, dm = q.shape
     Lk = k.shape[1]
     d = L.AttnDesc()
@@ -173,6 +258,8 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
         setattr(d, name + "_sb", t.stride(0)); setattr(d, name + "_sl", t.stride(1)); setattr(d, name + "_sh", dm // H)
     d.q, d.k, d.v, d.o, d.lse = L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse)
     d.kpm, d.mask, d.row_open, d.bias = L.ptr(kpm), L.ptr(mask), L.ptr(row_open), L.ptr(bias)
+    L.set_drop(d.drop, drop)
+    d.drop_bmod = drop_bmod
     # key split (not with dbias).  The factor depends on the key length ONLY, never on the batch: a scene's result
     # must not change with how scenes are batched or sharded over ranks (tests/test_gpu_fullsize.py).  Measured on
     # c2 (16 key blocks) and c4 (64): 2 splits is the sweet spot, more only adds combine traffic.
@@ -187,12 +274,12 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
 
 class _Attention(Function):
     @staticmethod
-    def forward(ctx, q, k, v, bias, kpm, mask, row_open, H, zero_attn, scale, ct):
+    def forward(ctx, q, k, v, bias, kpm, mask, row_open, H, zero_attn, scale, ct, drop=None):
         q, k, v, bias, kpm, mask, row_open = map(_c, (q, k, v, bias, kpm, mask, row_open))
         B, Lq, dm = q.shape
         o = _empty(q.shape, dtype=q.dtype, device=q.device)
         lse = _empty(B, H, Lq, dtype=torch.float32, device=q.device)
-        d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias)
+        d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, drop)
         Lk = k.shape[1]
         fl = 4.0 * B * Lq * Lk * dm
         nb = (q.numel() * 2 + k.numel() * 2) * q.element_size()
@@ -200,6 +287,7 @@ class _Attention(Function):
                       C.byref(d), L.stream()), "pq3d_attn_fwd")
         ctx.save_for_backward(q, k, v, o, lse, bias, kpm, mask, row_open)
         ctx.cfg = (H, zero_attn, scale, ct)
+        ctx.drop = drop
         return o
 
     @staticmethod
@@ -210,7 +298,7 @@ class _Attention(Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty_like(lse)
         dbias = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[3]) else None
-        d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias)
+        d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, ctx.drop)
         d.dout, d.dq, d.dk, d.dv, d.delta, d.dbias = map(L.ptr, (do, dq, dk, dv, delta, dbias))
         B, Lq, dm = q.shape
         Lk = k.shape[1]
@@ -218,20 +306,21 @@ class _Attention(Function):
         nb = (q.numel() * 3 + k.numel() * 4) * q.element_size()
         L.check(timed("pq3d_attn_bwd", f"B{B}H{H}Lq{Lq}Lk{Lk}dh{dm // H}ct{ct}", fl, nb, L.lib().pq3d_attn_bwd,
                       C.byref(d), L.stream()), "pq3d_attn_bwd")
-        return dq, dk, dv, dbias, None, None, None, None, None, None, None
+        return dq, dk, dv, dbias, None, None, None, None, None, None, None, None
 
 
 def attention(q, k, v, *, H: int, ct: int, scale: Optional[float] = None, zero_attn=False, kpm=None, mask=None,
-              row_open=None, bias=None):
+              row_open=None, bias=None, drop: Optional[L.Drop] = None):
     """softmax(scale q.k^T + bias + masks [, zero key]) v over heads packed in the last dim (see pq3d_attn_fwd)."""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1] // H)
-    return _Attention.apply(q, k, v, bias, kpm, mask, row_open, H, bool(zero_attn), float(scale), ct)
+    return _Attention.apply(q, k, v, bias, kpm, mask, row_open, H, bool(zero_attn), float(scale), ct, drop)
 
 
 # ------------------------------------------------------------------------------------------------ add + layernorm
-def _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd) -> L.LnDesc:
+def _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd, drop=None) -> L.LnDesc:
     d = L.LnDesc()
+    L.set_drop(d.drop, drop)
     dm = os_[0].shape[-1]
     d.R, d.d, d.M, d.rows_per_scene = os_[0].numel() // dm, dm, len(os_), rows_per_scene
     d.dt_x = L.dt_of(x) if x is not None else 0
@@ -244,7 +333,7 @@ def _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd) ->
 
 class _AddLN(Function):
     @staticmethod
-    def forward(ctx, x, coef, eps, rows_per_scene, out_dtype, M, *t):
+    def forward(ctx, x, coef, eps, rows_per_scene, out_dtype, M, drop, *t):
         os_ = [_c(a) for a in t[:M]]
         gammas, betas = [_c(a) for a in t[M:2 * M]], [_c(a) for a in t[2 * M:3 * M]]
         x, coef = _c(x), _c(coef)
@@ -253,12 +342,13 @@ class _AddLN(Function):
         y = _empty(os_[0].shape, dtype=out_dtype, device=os_[0].device)
         mean = _empty(M, R, dtype=torch.float32, device=y.device)
         rstd = torch.empty_like(mean)
-        d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd)
+        d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd, drop)
         nb = (M + 1 + (x is not None)) * R * dm * 4.0
         L.check(timed("pq3d_add_ln_fwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_fwd, C.byref(d), L.stream()),
                 "pq3d_add_ln_fwd")
         ctx.save_for_backward(x, coef, mean, rstd, *os_, *gammas, *betas)
         ctx.cfg = (eps, rows_per_scene, M)
+        ctx.drop = drop
         return y
 
     @staticmethod
@@ -273,7 +363,7 @@ class _AddLN(Function):
         d_os = [_empty(o.shape, dtype=torch.float32, device=dev) for o in os_]
         dgs = [torch.empty_like(g) for g in gammas]
         dbs = [torch.empty_like(b) for b in betas]
-        d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd)
+        d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd, ctx.drop)
         d.dy, d.dx = L.ptr(dy), L.ptr(dx)
         for m in range(M):
             d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_os[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
@@ -284,16 +374,17 @@ class _AddLN(Function):
         if x is not None and x.dtype != torch.float32:
             dx = dx.to(x.dtype)
         d_os = [g if g.dtype == o.dtype else g.to(o.dtype) for g, o in zip(d_os, os_)]
-        return (dx, None, None, None, None, None, *d_os, *dgs, *dbs)
+        return (dx, None, None, None, None, None, None, *d_os, *dgs, *dbs)
 
 
 def add_layernorm(x, os_: Sequence[torch.Tensor], gammas, betas, *, eps=1e-5, coef=None, rows_per_scene=None,
-                  out_dtype=torch.float32):
-    """y = sum_m coef[m, scene] * LN_m(x + o_m)   (coef None -> mean over the M branches; x may be None)."""
+                  out_dtype=torch.float32, drop: Optional[L.Drop] = None):
+    """y = sum_m coef[m, scene] * LN_m(x + dropout_m(o_m))   (coef None -> mean over the M branches; x may be None;
+    branch m draws dropout site drop.site + m)."""
     M = len(os_)
     if rows_per_scene is None:
         rows_per_scene = os_[0].shape[-2] if os_[0].dim() >= 2 else 1
-    return _AddLN.apply(x, coef, float(eps), int(rows_per_scene), out_dtype, M, *os_, *gammas, *betas)
+    return _AddLN.apply(x, coef, float(eps), int(rows_per_scene), out_dtype, M, drop, *os_, *gammas, *betas)
 
 
 # ------------------------------------------------------------------------------------------------ mask logits

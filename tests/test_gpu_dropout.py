@@ -1,0 +1,325 @@
+"""GPU: train-mode dropout (include/pq3d_hip.h "Dropout").
+
+The reference draws its keep-masks from torch's RNG stream, which cannot be reproduced; what CAN be checked exactly is
+(1) the generator: keep rate, independence across sites / seeds, determinism, graph-replay behaviour, and
+(2) the arithmetic around the masks: every fused dropout site (attention probabilities, residual branches inside
+    add+LayerNorm, FFN hidden, MLP heads, encoder outputs), forward and backward, against torch / the oracle with the
+    SAME masks (read back with pq3d_dropout_mask and injected through oracle.dropout_hook).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import pq3d_oracle as O
+from pq3d_amd import _lib as L
+from pq3d_amd import modules as M
+from pq3d_amd import ops
+from tests import util
+from tests.test_gpu_model import run_hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def seed_tensor(v=1234567):
+    return torch.tensor([v], dtype=torch.int64, device=DEV)
+
+
+def keep_of(p, site, seed, shape):
+    cols = shape[-1]
+    rows = math.prod(shape) // cols
+    return ops.dropout_mask(rows, cols, L.Drop(p, site, seed)).view(shape)
+
+
+# ------------------------------------------------------------------------------------------------ generator
+@pytest.mark.parametrize("p", [0.1, 0.3, 0.5])
+def test_mask_statistics(p):
+    seed = seed_tensor()
+    rows, cols = 4096, 1023   # odd column count: the last pair of every row is half used
+    k0 = ops.dropout_mask(rows, cols, L.Drop(p, 7, seed)).float()
+    n = rows * cols
+    sigma = math.sqrt(p * (1 - p) / n)
+    assert abs(k0.mean().item() - (1 - p)) < 5 * sigma + 1e-5          # 1e-5: p is quantised to 1/65536
+    # per-row and per-column rates (catches structure along either axis)
+    assert (k0.mean(1) - (1 - p)).abs().max().item() < 6 * math.sqrt(p * (1 - p) / cols)
+    assert (k0.mean(0) - (1 - p)).abs().max().item() < 6 * math.sqrt(p * (1 - p) / rows)
+    # neighbouring columns share one hash word (two 16-bit halves): they must still be independent
+    a, b = k0[:, 0:-1:2], k0[:, 1::2]
+    cov = ((a - a.mean()) * (b - b.mean())).mean().item()
+    assert abs(cov) < 5 * p * (1 - p) / math.sqrt(a.numel())
+    # another site / another seed: independent masks; same site + seed: identical
+    k1 = ops.dropout_mask(rows, cols, L.Drop(p, 8, seed)).float()
+    k2 = ops.dropout_mask(rows, cols, L.Drop(p, 7, seed_tensor(1234568))).float()
+    for other in (k1, k2):
+        cov = ((k0 - k0.mean()) * (other - other.mean())).mean().item()
+        assert abs(cov) < 5 * p * (1 - p) / math.sqrt(n)
+    assert torch.equal(k0, ops.dropout_mask(rows, cols, L.Drop(p, 7, seed)).float())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_dropout_apply_and_autograd(dt):
+    seed, p = seed_tensor(5), 0.25
+    x = torch.randn(3, 50, 77, device=DEV).to(dt).requires_grad_(True)
+    drop = L.Drop(p, 3, seed)
+    y = ops.dropout(x, drop)
+    keep = keep_of(p, 3, seed, x.shape)
+    ref = (x.detach().float() * keep / (1 - p)).to(dt)
+    assert torch.equal(y.detach(), ref)
+    g = torch.randn_like(x)
+    y.backward(g)
+    assert torch.equal(x.grad, (g.float() * keep / (1 - p)).to(dt))
+
+
+# ------------------------------------------------------------------------------------------------ fused sites, op level
+def torch_attention(q, k, v, H, kpm, zero_attn, keep, p):
+    B, Lq, d = q.shape
+    Lk, dh = k.shape[1], d // H
+    sp = lambda t: t.view(B, -1, H, dh).permute(0, 2, 1, 3)
+    s = sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(dh)
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    vv = sp(v)
+    if zero_attn:
+        s = torch.cat([s, s.new_zeros(B, H, Lq, 1)], -1)
+        vv = torch.cat([vv, vv.new_zeros(B, H, 1, dh)], 2)
+    a = torch.softmax(s, -1)
+    if keep is not None:
+        a = torch.cat([a[..., :Lk] * keep.view(B, H, Lq, Lk) / (1 - p), a[..., Lk:]], -1)
+    return (a @ vv).permute(0, 2, 1, 3).reshape(B, Lq, d)
+
+
+@pytest.mark.parametrize("Lq,Lk,zero", [(37, 150, True), (100, 1024, True), (40, 40, False), (200, 600, True)])
+def test_attention_dropout_fp32(Lq, Lk, zero):
+    """forward + dQ/dK/dV with the probability dropout fused in (incl. the key-split path at Lk >= 512)."""
+    torch.manual_seed(Lq * 1000 + Lk)
+    B, H, d, p = 3, 4, 64, 0.2
+    seed = seed_tensor(99)
+    q, k, v = (torch.randn(B, L_, d, device=DEV, requires_grad=True) for L_ in (Lq, Lk, Lk))
+    kpm = torch.zeros(B, Lk, dtype=torch.bool, device=DEV)
+    kpm[1, Lk // 2:] = True
+    kpm[2, Lk - 3:] = True
+    drop = L.Drop(p, 11, seed)
+    o = ops.attention(q, k, v, H=H, ct=L.F32, zero_attn=zero, kpm=kpm, drop=drop)
+    keep = keep_of(p, 11, seed, (B * H * Lq, Lk))
+    qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    ref = torch_attention(qr, kr, vr, H, kpm, zero, keep, p)
+    assert (o - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    g = torch.randn_like(o)
+    o.backward(g)
+    ref.backward(g)
+    for a, b, n in ((q.grad, qr.grad, "dq"), (k.grad, kr.grad, "dk"), (v.grad, vr.grad, "dv")):
+        assert (a - b).abs().max().item() < 5e-5 * max(1.0, b.abs().max().item()), n
+    # and p > 0 really changes the result
+    o0 = ops.attention(q, k, v, H=H, ct=L.F32, zero_attn=zero, kpm=kpm)
+    assert (o0 - o).abs().max().item() > 1e-3
+
+
+def test_attention_dropout_stacked_equals_separate_bf16():
+    """drop_bmod: memories stacked along the batch draw the masks of the per-memory launches (fused == modular)."""
+    from pq3d_amd import fused as F
+    torch.manual_seed(3)
+    Mm, B, H, Lq, Lk, d, p = 3, 2, 8, 50, 192, 256, 0.1
+    seed = seed_tensor(17)
+    q, k, v = (torch.randn(Mm * B, L_, d, device=DEV).bfloat16() for L_ in (Lq, Lk, Lk))
+    o = torch.empty_like(q)
+    lse = torch.empty(Mm * B, H, Lq, device=DEV)
+    F._attn(q, k, v, o, lse, H, L.BF16, True, drop=L.Drop(p, 40, seed), drop_bmod=B)
+    for m in range(Mm):
+        sl = slice(m * B, (m + 1) * B)
+        om = ops.attention(q[sl], k[sl], v[sl], H=H, ct=L.BF16, zero_attn=True, drop=L.Drop(p, 40 + m, seed))
+        assert torch.equal(om, o[sl]), m
+
+
+@pytest.mark.parametrize("Mb", [1, 3])
+def test_add_ln_residual_dropout(Mb):
+    torch.manual_seed(Mb)
+    B, Nq, d, p = 4, 33, 256, 0.3
+    seed = seed_tensor(21)
+    x = torch.randn(B, Nq, d, device=DEV, requires_grad=True)
+    os_ = [torch.randn(B, Nq, d, device=DEV, requires_grad=True) for _ in range(Mb)]
+    gs = [torch.randn(d, device=DEV, requires_grad=True) for _ in range(Mb)]
+    bs = [torch.randn(d, device=DEV, requires_grad=True) for _ in range(Mb)]
+    y = ops.add_layernorm(x, os_, gs, bs, eps=1e-5, drop=L.Drop(p, 100, seed))
+    leaves = [x] + os_ + gs + bs
+    ref_leaves = [t.detach().clone().requires_grad_(True) for t in leaves]
+    xr, osr, gsr, bsr = ref_leaves[0], ref_leaves[1:1 + Mb], ref_leaves[1 + Mb:1 + 2 * Mb], ref_leaves[1 + 2 * Mb:]
+    ref = 0
+    for m in range(Mb):
+        keep = keep_of(p, 100 + m, seed, (B * Nq, d)).view(B, Nq, d)
+        ref = ref + torch.nn.functional.layer_norm(xr + osr[m] * keep / (1 - p), (d,), gsr[m], bsr[m], 1e-5) / Mb
+    assert (y - ref).abs().max().item() < 2e-5
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref.backward(g)
+    for a, b in zip(leaves, ref_leaves):
+        assert (a.grad - b.grad).abs().max().item() < 1e-4 * max(1.0, b.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu"])
+def test_linear_activation_dropout(act):
+    torch.manual_seed(5)
+    R, K, N, p = 150, 64, 200, 0.4   # N = 200: partial 64-column tile + vector/tail epilogue paths
+    seed = seed_tensor(8)
+    x = torch.randn(2, R // 2, K, device=DEV, requires_grad=True)
+    w = (torch.randn(N, K, device=DEV) / 8).requires_grad_(True)
+    b = torch.randn(N, device=DEV, requires_grad=True)
+    y = ops.linear(x, w, b, ct=L.F32, act=act, drop=L.Drop(p, 9, seed))
+    keep = keep_of(p, 9, seed, (R, N)).view(2, R // 2, N)
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    pre = xr @ wr.t() + br
+    ref = (torch.relu(pre) if act == "relu" else torch.nn.functional.gelu(pre)) * keep / (1 - p)
+    assert (y - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref.backward(g)
+    for a, c in ((x, xr), (w, wr), (b, br)):
+        assert (a.grad - c.grad).abs().max().item() < 1e-4 * max(1.0, c.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ model level
+KIND = {"ca_attn": ops.DROP_CA_ATTN, "ca_res": ops.DROP_CA_RES, "sa_attn": ops.DROP_SA_ATTN, "sa_res": ops.DROP_SA_RES,
+        "ffn_inner": ops.DROP_FFN_INNER, "ffn_res": ops.DROP_FFN_RES}
+
+
+def oracle_hook(model, used):
+    """oracle.dropout_hook callback that reads every mask back from the HIP generator (same seed word, same sites)."""
+    seed = ops.drop_rng(torch.device(DEV)).cur
+    layer0 = model.unified_encoder.unified_encoder[0]
+
+    def hook(tag, app, m, x):
+        if tag in KIND:
+            mod = {"ca": layer0.cross_attn_list[0], "sa": layer0.self_attn, "ff": layer0.ffn}[tag[:2]]
+            p, site = mod.dropout_p, ops.drop_site(M.DROP_BASE_ENCODER, app, KIND[tag], m)
+        elif tag == "mask_head_cls":
+            p, site = model.mask_head.dropout_p, ops.drop_site(M.DROP_BASE_MASK_HEAD, app, ops.DROP_MLP_HEAD)
+        elif tag == "ground_head":
+            p, site = model.ground_head.dropout_p, ops.drop_site(M.DROP_BASE_GROUND_HEAD, 0, ops.DROP_MLP_HEAD)
+        elif tag.startswith("obj_enc_out:"):
+            enc = getattr(model, tag.split(":")[1].rstrip("."))
+            p, site = enc.dropout_p, ops.drop_site(enc._drop_base, 0, ops.DROP_ENC_OUT)
+        else:
+            raise AssertionError(tag)
+        if not p > 0.0:
+            return x
+        used.add(tag.split(":")[0])
+        keep = keep_of(p, site, seed, tuple(x.shape)).cpu()
+        return x * keep / (1 - p)
+    return hook
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    fin = torch.isfinite(b) & (b > -1e5)
+    assert torch.equal(torch.isfinite(b), torch.isfinite(a))
+    return float((a[fin] - b[fin]).abs().max() / max(float(b[fin].abs().max()), 1e-6))
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "modular"])
+@pytest.mark.parametrize("name", ["F1_c1", "F2_c1_mask", "F4_c2_slice", "F5_dimloc6"])
+def test_fp32_train_mode_matches_oracle_with_same_masks(name, fused):
+    """Whole model in train() mode (dropout 0.1 in the decoder layers, 0.1 / 0.3 in the heads, 0.1 on the encoder
+    outputs) against the oracle fed the very same keep-masks: outputs and every parameter gradient."""
+    _z, args = util.load_fixture(name)
+    args = dict(args, drop_test=())
+    _cfg, model, sd, dd = util.model_case(args)
+    model.train()
+    model.unified_encoder.fused = fused
+    out, loss, g = run_hip(model, args, dd)
+    used = set()
+    with O.dropout_hook(oracle_hook(model, used)):
+        oout, collect, oloss, og = util.run_oracle(dict(args, training=True), sd, dd)
+    want = {"ca_attn", "ca_res", "sa_res", "ffn_inner", "ffn_res", "obj_enc_out"}
+    want |= {"sa_attn"} if not args["spatial"] else set()
+    want |= {"mask_head_cls"} if "mask" in args["heads"] else set()
+    want |= {"ground_head"} if "ground" in args["heads"] else set()
+    assert want <= used, f"dropout sites never exercised: {want - used}"
+    tol = 2e-5
+    if "mask" in args["heads"] and args.get("use_self_mask"):
+        flips = max(float(((m.detach().cpu() < 0) != (r < 0)).float().mean())
+                    for m, r in zip(out["predictions_mask"], oout["predictions_mask"]))
+        assert flips < 1e-4
+        tol = 2e-5 if flips == 0 else 2e-3
+    assert rel(out["query_embeds"], collect[-1]) < tol
+    if "ground" in args["heads"]:
+        assert rel(out["ground_logits"], oout["ground_logits"]) < tol
+    if "mask" in args["heads"]:
+        for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
+            assert rel(m, r) < max(tol, 5e-5)
+        for c, r in zip(out["predictions_class"], oout["predictions_class"]):
+            assert rel(c, r) < tol
+    assert abs(loss.item() - oloss.item()) < tol * max(1.0, abs(oloss.item()))
+    assert sorted(g) == sorted(og)
+    gmax = max(float(v.norm()) for v in og.values())
+    worst = max((float((g[n].cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-3 * gmax))
+                 / (3.0 if "pairwise_loc_fc" in n else 1.0), n) for n in og)
+    assert worst[0] < (1e-3 if tol < 1e-4 else 2e-2), f"worst gradient (relative L2, scaled) {worst}"
+    # the run really was stochastic: eval mode gives a different answer
+    model.eval()
+    with torch.no_grad():
+        ev = model({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in dd.items()})["query_embeds"]
+    assert rel(ev, out["query_embeds"]) > 1e-2
+
+
+def test_bf16_train_mode_fused_equals_modular_and_is_reproducible():
+    """Same seed word -> the fused executor and the modular path draw identical masks (structural site ids), and a
+    re-run with the same seed reproduces the step; a new epoch changes it."""
+    _z, args = util.load_fixture("F4b_c4_slice")
+    args = dict(args, drop_test=())
+    res = []
+    for fused in (True, False, True):
+        _cfg, model, sd, dd = util.model_case(args)
+        M.set_compute(model, "bf16")
+        model.train()
+        model.unified_encoder.fused = fused
+        rng = ops.drop_rng(torch.device(DEV))
+        rng.set_seed(424242)            # new epoch with a known seed word: the model's first forward does not advance it
+        out, loss, g = run_hip(model, args, dd)
+        res.append((out["query_embeds"].detach().clone(), [m.detach().clone() for m in out["predictions_mask"]], g))
+    (q1, m1, g1), (q2, m2, g2), (q3, m3, g3) = res
+    assert torch.equal(q1, q3) and all(torch.equal(a, b) for a, b in zip(m1, m3)), "same seed must reproduce the step"
+    assert rel(q1, q2) < 2e-2
+    flips = max(float(((a < 0) != (b < 0)).float().mean()) for a, b in zip(m1, m2))
+    assert flips < 1e-2
+    gmax = max(float(v.norm()) for v in g2.values())
+    for n in g2:
+        assert float((g1[n] - g2[n]).norm()) <= 0.3 * max(float(g2[n].norm()), 1e-2 * gmax), n
+    # next step (epoch advanced by the model itself): different masks
+    out4, _, _ = run_hip(model, args, dd, grads=False)
+    assert rel(out4["query_embeds"], q3) > 1e-2
+
+
+def test_hip_graph_replay_draws_new_masks():
+    """The seed word lives on the device and is bumped by a captured kernel: every replay of a captured training
+    step uses fresh masks, and the captured backward regenerates exactly the masks of its own forward."""
+    _z, args = util.load_fixture("F4_c2_slice")
+    _cfg, model, sd, dd = util.model_case(dict(args, drop_test=()))
+    M.set_compute(model, "bf16")
+    model.train().to(DEV)
+    ddv = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in dd.items()}
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        out = model(dict(ddv))
+        out["query_embeds"].float().square().mean().backward()
+        return out["query_embeds"]
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        q = step()
+    outs, grads = [], []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        outs.append(q.clone())
+        grads.append(next(p.grad for p in model.parameters() if p.grad is not None).clone())
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+    assert not torch.equal(grads[0], grads[1])
+    assert all(torch.isfinite(o).all() for o in outs)

@@ -72,7 +72,7 @@ def test_fp32_encoder_structures(name):
     enc = QueryMaskEncoder(None, memories=a["memories"], hidden_size=d, num_attention_heads=a["H"],
                            num_layers=a["L"], spatial_selfattn=a["spatial"], structure=a["structure"], compute="fp32")
     synth.fill_module(enc, a["seed"])
-    enc.to(DEV)
+    enc.to(DEV).eval()   # fixtures were generated in eval mode (dropout off)
     r = np.random.default_rng(a["data_seed"])
     t = lambda *s: torch.from_numpy(r.standard_normal(s).astype(np.float32))
     dd = synth.synth_data_dict(B, Ns, Nq, {m: d for m in a["memories"]}, seed=a["data_seed"], memories=a["memories"],

@@ -85,7 +85,7 @@ def oracle_cfg(args):
                 num_blocks=args.get("num_blocks", 1), drop_memories_test=args.get("drop_test", ()),
                 use_offline_attn_mask=args.get("offline_attn", False),
                 skip_query_encoder_mask_pred=args.get("skip_pred", False), filter_out_classes=list(args.get("foc", ())),
-                activation=args.get("activation", "relu"))
+                activation=args.get("activation", "relu"), training=args.get("training", False))
 
 
 def synthetic_loss(out, heads, last_query):
