@@ -294,6 +294,44 @@ int pq3d_scatter_mean_fwd(const float* src, const int64_t* index, float* out, fl
 int pq3d_scatter_mean_bwd(const float* dout, const int64_t* index, const float* count, float* dsrc, int64_t N,
                           int64_t C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer side of the training step around the path: what Query3DTrainer.backward does after
+ * loss.backward() (trainer/query3d_trainer.py:18-28): clip_grad_norm_(grad_norm) (trainer/build.py:144-145),
+ * torch.optim.AdamW.step() with the parameter groups of optim/utils.py:1-18 (weight decay 0.01 except biases /
+ * LayerNorm), LambdaLR.step() with optim/scheduler.py:5-17.  All on ONE flat fp32 buffer holding the parameter groups
+ * back to back (pq3d_opt_segments: end offset, lr multiplier vs hp.lr -- get_opt_params' per-module lr,
+ * query3d_unified.py:224-238 -- and weight decay per group); step-dependent scalars stay in device memory
+ * (HIP-graph capturable):
+ *   pq3d_sumsq_partials : partials[1024] <- partial sums of g^2 (two-pass, deterministic)
+ *   pq3d_train_scalars  : t = ++(*step); lr = hp.lr * lambda(t-1); scalars[0..5] <- lr, lr/(1-b1^t), 1/sqrt(1-b2^t),
+ *                         clip = min(1, max_grad_norm/(||g||+1e-6)) (1 if max_grad_norm <= 0), ||g||
+ *   pq3d_adamw          : per element of group s: g' = clip*g; p *= 1 - lr*lr_mul_s*wd_s; m += (1-b1)(g'-m);
+ *                         v = b2 v + (1-b2) g'^2; p -= lr*lr_mul_s/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ *                         (torch.optim.AdamW, amsgrad=False, maximize=False)
+ * ------------------------------------------------------------------------------------------------ */
+#define PQ3D_SCHED_CONSTANT 0
+#define PQ3D_SCHED_WARMUP_COSINE 1
+#define PQ3D_SCHED_WARMUP_EXP 2
+#define PQ3D_SUMSQ_PARTIALS 1024
+#define PQ3D_MAX_OPT_SEGMENTS 16
+typedef struct {
+  int32_t n;                                 /* groups in use */
+  int64_t end[PQ3D_MAX_OPT_SEGMENTS];        /* exclusive end offset (elements) of group s in the flat buffer */
+  float lr_mul[PQ3D_MAX_OPT_SEGMENTS];       /* group lr / hp.lr */
+  float weight_decay[PQ3D_MAX_OPT_SEGMENTS];
+} pq3d_opt_segments;
+typedef struct {
+  float lr, beta1, beta2, eps;
+  float max_grad_norm;   /* <= 0: no clipping */
+  int32_t sched;         /* PQ3D_SCHED_* */
+  int32_t warmup_steps, total_steps;
+  float sched_gamma;     /* warmup_exp only */
+} pq3d_adamw_hp;
+int pq3d_sumsq_partials(const float* g, int64_t n, float* partials, void* stream);
+int pq3d_train_scalars(const pq3d_adamw_hp* hp, int64_t* step, const float* partials, float* scalars, void* stream);
+int pq3d_adamw(float* p, const float* g, float* m, float* v, int64_t n, const pq3d_adamw_hp* hp,
+               const pq3d_opt_segments* segs, const float* scalars, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

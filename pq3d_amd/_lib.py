@@ -45,6 +45,24 @@ def set_drop(field: Dropout, drop: Optional["Drop"]) -> None:
         field.p, field.site, field.seed = drop.p, drop.site & 0xFFFFFFFF, ptr(drop.seed)
 
 
+MAX_OPT_SEGMENTS = 16
+
+
+class OptSegments(C.Structure):
+    _fields_ = [("n", C.c_int32), ("end", C.c_int64 * MAX_OPT_SEGMENTS), ("lr_mul", C.c_float * MAX_OPT_SEGMENTS),
+                ("weight_decay", C.c_float * MAX_OPT_SEGMENTS)]
+
+
+class AdamWHp(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("max_grad_norm", C.c_float), ("sched", C.c_int32),
+                ("warmup_steps", C.c_int32), ("total_steps", C.c_int32), ("sched_gamma", C.c_float)]
+
+
+SCHED = {"constant": 0, "warmup_cosine": 1, "warmup_exp": 2}
+SUMSQ_PARTIALS = 1024
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32), ("batch", C.c_int32),
@@ -128,6 +146,10 @@ _SIGS = {
     "pq3d_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                               C.c_void_p],
     "pq3d_scatter_mean_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
+    "pq3d_sumsq_partials": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
+    "pq3d_train_scalars": [C.POINTER(AdamWHp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "pq3d_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AdamWHp), C.POINTER(OptSegments),
+                   C.c_void_p, C.c_void_p],
     "pq3d_dropout_mask": [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Dropout), C.c_void_p],
     "pq3d_dropout_apply": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout),
                            C.c_void_p],

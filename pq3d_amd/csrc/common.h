@@ -179,6 +179,19 @@ PQ_DEV bool drop_keep(const DropState& s, uint32_t row, uint32_t col) {
 }
 PQ_DEV bool drop_on(const pq3d_dropout& dr) { return dr.p > 0.f && dr.seed != nullptr; }
 
+// Zero-fill of up to PQ_ZERO_MAX fp32 buffers in ONE kernel launch (misc.hip).  Used instead of hipMemsetAsync: memset
+// nodes of a captured HIP graph were observed to take effect only on the first replay on this stack (ROCm 7.x; see
+// tools/probes/graph_memset_probe.py), which silently corrupted split-K / atomics outputs of later replays.
+#define PQ_ZERO_MAX 64
+struct ZeroList {
+  int n = 0;
+  float* ptr[PQ_ZERO_MAX];
+  long count[PQ_ZERO_MAX];
+  void add(void* p, long cnt) { if (p && cnt > 0 && n < PQ_ZERO_MAX) { ptr[n] = (float*)p; count[n] = cnt; ++n; } }
+  bool full() const { return n >= PQ_ZERO_MAX; }
+};
+int pq3d_zero_launch(const ZeroList& z, hipStream_t s);   // returns 0 or a hipError_t (error text set)
+
 // host-side error plumbing (api.cpp)
 extern "C" void pq3d_set_error(const char* msg);
 #define PQ_CHECK_ARG(cond, msg)      \

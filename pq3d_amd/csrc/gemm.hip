@@ -649,10 +649,16 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
     PQ_CHECK_ARG(d.dtC == PQ3D_F32, "pq3d_gemm: split-K needs fp32 C");
     PQ_CHECK_ARG(d.ldc == d.N && (d.batch == 1 || d.strideC == (int64_t)d.M * d.N),
                  "pq3d_gemm: split-K needs contiguous C");
-    for (int g = 0; g < d.groups && !d.accumulate; ++g) {
-      hipError_t e = hipMemsetAsync(d.C[g], 0, sizeof(float) * (size_t)d.batch * d.M * d.N, s);
-      if (e == hipSuccess && d.colsum[g]) e = hipMemsetAsync(d.colsum[g], 0, sizeof(float) * (size_t)d.M, s);
-      if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
+    if (!d.accumulate) {   // one zero-fill launch for every output (not hipMemsetAsync: see common.h ZeroList)
+      ZeroList z;
+      for (int g = 0; g < d.groups; ++g) {
+        z.add(d.C[g], (long)d.batch * d.M * d.N);
+        z.add(d.colsum[g], (long)d.M);
+        if (z.n + 2 > PQ_ZERO_MAX || g + 1 == d.groups) {
+          if (int e = pq3d_zero_launch(z, s)) return e;
+          z.n = 0;
+        }
+      }
     }
   }
   dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (d.groups / kc) * d.batch * d.splitk);

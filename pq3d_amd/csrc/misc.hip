@@ -286,13 +286,38 @@ inline unsigned grid1d(long total, int block = 256, long cap = 4096) {
   if (g < 1) g = 1;
   return (unsigned)g;
 }
-inline int memset_async(void* p, size_t bytes, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(p, 0, bytes, s);
-  if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
-  return 0;
+inline int memset_async(void* p, size_t bytes, hipStream_t s) {   // fp32 buffers only (bytes % 4 == 0)
+  ZeroList z;
+  z.add(p, (long)(bytes / 4));
+  return pq3d_zero_launch(z, s);
+}
+
+__global__ __launch_bounds__(256) void zero_kernel(const ZeroList z) {
+  float* p = z.ptr[blockIdx.y];
+  const long n = z.count[blockIdx.y];
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 1024;
+  if ((((uintptr_t)p) & 15) == 0) {
+    for (; i + 3 < n; i += stride) *(float4*)(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (; i < n; i += stride)
+      for (long j = i; j < min(i + 4, n); ++j) p[j] = 0.f;
+  } else {
+    for (; i < n; i += stride)
+      for (long j = i; j < min(i + 4, n); ++j) p[j] = 0.f;
+  }
 }
 
 }  // namespace
+
+int pq3d_zero_launch(const ZeroList& z, hipStream_t s) {
+  if (z.n == 0) return 0;
+  long mx = 0;
+  for (int i = 0; i < z.n; ++i) mx = z.count[i] > mx ? z.count[i] : mx;
+  hipLaunchKernelGGL(zero_kernel, dim3(grid1d((mx + 3) / 4, 256, 1024), z.n), dim3(256), 0, s, z);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
 
 extern "C" int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream) {
   PQ_CHECK_ARG(x && out && R >= 0 && N >= 1 && ld >= N, "pq3d_colsum: bad args");

@@ -225,16 +225,14 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   const pq3d_ln_desc d = *dp;
   if (int e = check_ln(d, true)) return e;
   hipStream_t s = (hipStream_t)stream;
-  for (int m = 0; m < d.M && !d.accumulate; ++m) {
-    hipError_t e = hipMemsetAsync(d.dgamma[m], 0, sizeof(float) * d.d, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d.dbeta[m], 0, sizeof(float) * d.d, s);
-    if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
+  {   // zero the atomics targets in one launch (not hipMemsetAsync: see common.h ZeroList)
+    ZeroList z;
+    for (int m = 0; m < d.M && !d.accumulate; ++m) { z.add(d.dgamma[m], d.d); z.add(d.dbeta[m], d.d); }
+    if (z.full()) { if (int e = pq3d_zero_launch(z, s)) return e; z.n = 0; }
+    if (d.R > 0 && d.dx && d.M > 1 && !d.independent) z.add(d.dx, (long)d.R * d.d);
+    if (int e = pq3d_zero_launch(z, s)) return e;
   }
   if (d.R == 0) return 0;
-  if (d.dx && d.M > 1 && !d.independent) {
-    hipError_t e = hipMemsetAsync(d.dx, 0, sizeof(float) * (size_t)d.R * d.d, s);
-    if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
-  }
   // two rows per wave (software-pipelined); one atomic per column per block for the parameter gradients
   const int rpw = d.R >= 4096 ? 4 : 2;   // measured: 2 rows/wave is best for R=800, 4 for R=8192 (atomics)
   long nb = (d.R + rpw * WPB - 1) / (rpw * WPB);

@@ -15,12 +15,15 @@ import torch.distributed as dist
 
 
 class FlatGradAllReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
+                 keep_order: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.buckets: List[List[torch.nn.Parameter]] = [[]]
         size = 0
-        for p in reversed(self.params):  # reverse registration order ~ order gradients become ready
+        # default: reverse registration order ~ order gradients become ready; keep_order: the caller's layout (the
+        # flat optimizer wants parameter groups back to back)
+        for p in (self.params if keep_order else reversed(self.params)):
             nb = p.numel() * 4
             if size + nb > bucket_bytes and self.buckets[-1]:
                 self.buckets.append([])

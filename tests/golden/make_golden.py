@@ -30,6 +30,7 @@ from pq3d_amd import synth  # noqa: E402
 REF = "/root/reference"
 MAX_FULL = 8192   # outputs
 MAX_GRAD = 1024   # per-parameter gradient sample (moments cover the rest)
+MAX_TRAIN = 256   # per-parameter weight-update sample of the F7 train-step fixtures
 
 
 # ----------------------------------------------------------------------------- import recipe
@@ -77,6 +78,8 @@ def import_reference():
     ns.oe = importlib.import_module("modules.vision.object_encoder")
     ns.model = importlib.import_module("model.query3d_unified")
     ns.utils = importlib.import_module("modules.utils")
+    ns.optim_utils = importlib.import_module("optim.utils")       # no_decay_param_group
+    ns.sched = importlib.import_module("optim.scheduler")         # warmup_cosine / get_scheduler
     return ns
 
 
@@ -203,6 +206,74 @@ def run_model_case(ref, name, *, B, Ns, Nq, d, H, L, memories, heads, spatial, s
     save(name, out)
 
 
+def run_train_case(ref, name, *, B, Ns, Nq, d, H, L, memories, heads, spatial, structure, steps=3, lr=1e-2,
+                   grad_norm=None, grad_norm_frac=0.5, warmup_steps=2, total_steps=10, head_lr=None, seed=0,
+                   data_seed=1234, **kw):
+    """F7: the optimizer side of Query3DTrainer (trainer/query3d_trainer.py:18-28) run with the REFERENCE's own
+    objects: model.get_opt_params() (-> optim.utils.no_decay_param_group), torch.optim.AdamW(betas=(0.9, 0.98)),
+    optim.scheduler.get_scheduler('warmup_cosine'), torch clip_grad_norm_, in the trainer's order, for `steps` steps
+    on one batch (eval-mode forward: dropout draws are not reproducible outside torch).  `head_lr` gives the ground
+    head its own learning rate through cfg.model.ground_head.lr (get_opt_params' per-module lr)."""
+    d_in = {m: d for m in memories}
+    cfg = model_cfg(d, H, L, memories, heads, d_in, spatial=spatial, structure=structure, **kw)
+    cfg["solver"] = Cfg({"lr": lr, "optim": {"name": "AdamW", "args": {"betas": [0.9, 0.98]}},
+                         "sched": {"name": "warmup_cosine", "args": {"warmup_steps": warmup_steps}}})
+    cfg["num_gpu"] = 1
+    if head_lr is not None:
+        cfg.model.ground_head["lr"] = head_lr
+    torch.manual_seed(0)
+    model = ref.model.Query3DUnified(cfg)
+    sd = synth.fill_module(model, seed)
+    model.eval()
+    dd = synth.synth_data_dict(B, Ns, Nq, d_in, seed=data_seed, memories=memories, loc_dim=kw.get("dim_loc", 3))
+    dd["tgt_object_id"] = torch.zeros(B, dtype=torch.long)
+    optimizer = torch.optim.AdamW(model.get_opt_params(), betas=(0.9, 0.98))
+    scheduler = ref.sched.get_scheduler(cfg, optimizer, total_steps)
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd))}
+    init = {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    def loss_of(res, last_q):
+        loss = 0.0
+        if "ground" in heads:
+            gl = res["ground_logits"]
+            gl = torch.where(torch.isfinite(gl), gl, torch.zeros_like(gl))
+            loss = loss + (gl * loss_weight("ground", gl.shape)).mean()
+        if "mask" in heads:
+            for i, (c, m) in enumerate(zip(res["predictions_class"], res["predictions_mask"])):
+                cf = torch.where(torch.isfinite(c), c, torch.zeros_like(c))
+                loss = loss + (cf * loss_weight(f"cls{i}", c.shape)).mean() \
+                    + (m.clamp(min=-50.0) * loss_weight(f"mask{i}", m.shape)).mean()
+        return loss + (last_q * loss_weight("query", last_q.shape)).mean()
+
+    losses, norms, lrs = [], [], []
+    for s in range(steps):
+        captured = []
+        hook = model.unified_encoder.unified_encoder[-1].register_forward_hook(lambda _m, _i, o: captured.append(o))
+        res = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in dd.items()})
+        hook.remove()
+        loss = loss_of(res, captured[-1])
+        optimizer.zero_grad()
+        loss.backward()
+        if s == 0 and grad_norm is None:   # make the clip active: a fixed fraction of the first step's norm
+            g0 = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+            grad_norm = float(np.float32(grad_norm_frac * float(g0)))
+        lrs.append(scheduler.get_last_lr()[0])
+        norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)))
+        optimizer.step()
+        scheduler.step()
+        losses.append(loss.item())
+        for n, p in model.named_parameters():
+            put(out, f"delta/{s}/{n}", p.detach() - init[n], MAX_TRAIN)
+    out["loss"] = np.array(losses, dtype=np.float64)
+    out["grad_norm"] = np.array(norms, dtype=np.float64)
+    out["lr"] = np.array(lrs, dtype=np.float64)
+    out["meta/args"] = np.array(repr(dict(B=B, Ns=Ns, Nq=Nq, d=d, H=H, L=L, memories=list(memories), heads=list(heads),
+                                          spatial=spatial, structure=structure, seed=seed, data_seed=data_seed,
+                                          steps=steps, lr=lr, grad_norm=grad_norm, warmup_steps=warmup_steps,
+                                          total_steps=total_steps, head_lr=head_lr, **kw)))
+    save(name, out)
+
+
 def run_encoder_case(ref, name, *, B, Ns, Nq, d, H, L, memories, structure, spatial, T=12, seed=0,
                      data_seed=4321):
     """QueryMaskEncoder alone with a pre-encoded prompt memory (structures sequential/mixed/gate)."""
@@ -288,6 +359,11 @@ def main():
     run_model_case(ref, "F5_dimloc6", B=2, Ns=40, Nq=8, d=64, H=4, L=1, memories=["voxel"], heads=["ground"],
                    spatial=True, structure="parallel", dim_loc=6)
     run_misc_case(ref, "F6_misc")
+    # F7: three optimizer steps (clip + AdamW + warmup_cosine) with the reference's optimizer / scheduler objects
+    run_train_case(ref, "F7_adamw_c1", B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=["ground"],
+                   spatial=False, structure="sequential", head_lr=3e-3)
+    run_train_case(ref, "F7_adamw_mask", B=2, Ns=96, Nq=12, d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask"],
+                   spatial=True, structure="parallel", use_self_mask=False, foc=(0, 2), warmup_steps=0, total_steps=6)
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ from pq3d_amd import synth
 from pq3d_amd.model import Query3DUnified, make_cfg
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MAX_FULL, MAX_GRAD = 8192, 1024  # must match tests/golden/make_golden.py
+MAX_FULL, MAX_GRAD, MAX_TRAIN = 8192, 1024, 256  # must match tests/golden/make_golden.py
 
 
 def fixtures(prefix=""):
