@@ -132,6 +132,11 @@ def main():
     ap.add_argument("--dropout", default="off", choices=["off", "reference"],
                     help="headline run: 'off' = p=0 (the parity-checked arithmetic); 'reference' = the reference's "
                          "train-mode probabilities (0.1 in the decoder layers and encoders, 0.1/0.3 in the heads)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline measurement + roofline pass (no eager / dropout / optimizer legs); what the "
+                         "rocprofv3 runs under profiles/ use so that the trace holds the headline step only")
+    ap.add_argument("--no-optimizer-leg", action="store_true",
+                    help="skip the extra full-training-step (with optimizer) timing reported next to the headline")
     ap.add_argument("--no-dropout-leg", action="store_true",
                     help="skip the extra train-mode-dropout timing reported next to the headline (N=1 only)")
     args = ap.parse_args()
@@ -289,7 +294,7 @@ def main():
             "roofline": roof,
             "kernel_families_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(fams.items())},
         }
-        if world == 1:
+        if world == 1 and not args.headline_only:
             # the same step launched eagerly (no HIP graph): what a trainer that cannot capture graphs would see
             def timed_loop(fn, n):
                 torch.cuda.synchronize()
@@ -315,6 +320,38 @@ def main():
                     "ms_per_step": ms2, "value": c["B"] / (ms2 * 1e-3), "unit": "scenes/s", "hip_graph": g2 is not None,
                     "note": "parity of the dropout arithmetic: tests/test_gpu_dropout.py (same masks fed to the oracle)"}
                 set_dropout_mode(args.dropout)
+            if not args.no_optimizer_leg:
+                # the full training step of the reference's trainer (fwd + bwd + clip_grad_norm_ + AdamW + LR schedule,
+                # trainer/query3d_trainer.py:18-28) in ONE HIP graph: pq3d_amd/trainer.py
+                from pq3d_amd.trainer import TrainStep
+                ts = TrainStep(model, lambda out: loss_fn(out, c["heads"]), lr=1e-4, grad_norm=80.0,
+                               sched="warmup_cosine", warmup_steps=0, total_steps=10 ** 6)
+                sside = torch.cuda.Stream()
+                sside.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(sside):
+                    for _ in range(2):
+                        ts.step(dd)
+                torch.cuda.current_stream().wait_stream(sside)
+                torch.cuda.synchronize()
+                g3 = None
+                if not args.no_graph:
+                    try:
+                        g3 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g3):
+                            ts.step(dd)
+                    except Exception as e:  # noqa: BLE001
+                        print(f"[bench] train-step graph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+                        torch.cuda.synchronize()
+                        g3 = None
+                run3 = g3.replay if g3 is not None else (lambda: ts.step(dd))
+                for _ in range(args.warmup):
+                    run3()
+                ms3 = timed_loop(run3, args.steps)
+                result["train_step_with_optimizer"] = {
+                    "ms_per_step": ms3, "value": c["B"] / (ms3 * 1e-3), "unit": "scenes/s", "hip_graph": g3 is not None,
+                    "optimizer": "AdamW(betas=(0.9,0.98), wd 0.01) + clip_grad_norm_(80) + warmup_cosine, 3 kernels on "
+                                 "one flat fp32 buffer", "params": int(ts.flat_p.numel()),
+                    "finite": bool(torch.isfinite(ts.flat_p).all())}
         if world == 1 and args.cpu_steps > 0:
             result["cpu_baseline"] = cpu_baseline(c, sd, dd_cpu, args.cpu_steps, 2)
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
