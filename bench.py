@@ -38,6 +38,10 @@ CONFIGS = {
     "c2": dict(B=8, Ns=1024, Nq=100, d=256, H=8, L=4, memories=["voxel", "mv", "pc"], heads=[], use_self_mask=False),
     "c4": dict(B=4, Ns=4096, Nq=200, d=256, H=8, L=4, memories=["voxel", "mv", "pc"], heads=["mask"],
                use_self_mask=True),
+    # c5 (BASELINE config 5, per GPU): 6 layers + caption head; decoder on the HIP kernels, HF T5-small body (random init,
+    # teacher-forced T_r = 32) on stock PyTorch-ROCm ops and reported separately ("t5_body")
+    "c5": dict(B=16, Ns=2048, Nq=100, d=256, H=8, L=6, memories=["voxel", "mv", "pc"], heads=["generation"],
+               use_self_mask=False, Tr=32),
     "c1": dict(B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=[], use_self_mask=False, spatial=False,
                structure="sequential"),
 }
@@ -65,11 +69,17 @@ def build(c, compute, device, seed):
     model.to(device)
     dd = synth.synth_data_dict(c["B"], c["Ns"], c["Nq"], {m: c["d"] for m in c["memories"]}, seed=seed,
                                memories=c["memories"])
+    if "generation" in c["heads"]:
+        g = torch.Generator().manual_seed(seed)
+        dd["response"] = torch.randint(2, 32000, (c["B"], c["Tr"]), generator=g)
     return model, sd, dd
 
 
 def loss_fn(out, heads):
     loss = out["query_embeds"].mean() if "query_embeds" in out else out["query"].mean()
+    if "generation" in heads:   # generation_loss: token cross-entropy of the teacher-forced logits
+        lg = out["generation_logits"]
+        loss = loss + torch.nn.functional.cross_entropy(lg.flatten(0, 1).float(), out["generation_label"].flatten())
     if "mask" in heads:
         for cl, m in zip(out["predictions_class"], out["predictions_mask"]):
             loss = loss + m.clamp(min=-50.0).mean() + torch.where(torch.isfinite(cl), cl, torch.zeros_like(cl)).mean()
@@ -352,7 +362,21 @@ def main():
                     "optimizer": "AdamW(betas=(0.9,0.98), wd 0.01) + clip_grad_norm_(80) + warmup_cosine, 3 kernels on "
                                  "one flat fp32 buffer", "params": int(ts.flat_p.numel()),
                     "finite": bool(torch.isfinite(ts.flat_p).all())}
-        if world == 1 and args.cpu_steps > 0:
+        if world == 1 and "generation" in c["heads"] and not args.headline_only:
+            # the third-party body alone (fwd + bwd of the head on a detached query), eager
+            gh = model.generation_head
+            qd = torch.randn(c["B"], c["Nq"], c["d"], device=dev, requires_grad=True)
+
+            def head_only():
+                lg = gh(qd, dd["query_pad_masks"], dd["response"])
+                torch.nn.functional.cross_entropy(lg.flatten(0, 1).float(), dd["response"].flatten()).backward()
+            for _ in range(3):
+                head_only()
+            result["t5_body"] = {"ms_per_step_eager": timed_loop(head_only, max(3, args.steps // 5)),
+                                 "impl": "HF T5ForConditionalGeneration (t5-small architecture, random init) on stock "
+                                         "PyTorch-ROCm ops; input_proj on the HIP kernels",
+                                 "params": sum(p.numel() for p in gh.parameters())}
+        if world == 1 and args.cpu_steps > 0 and "generation" not in c["heads"]:
             result["cpu_baseline"] = cpu_baseline(c, sd, dd_cpu, args.cpu_steps, 2)
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
         print(json.dumps(result))

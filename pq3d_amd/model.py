@@ -31,7 +31,7 @@ class Cfg(dict):
 
 
 REGISTRY = {c.__name__: c for c in (M.QueryMaskEncoder, M.QueryEncoder, M.MaskHeadSegLevel, M.GroundHead,
-                                    M.ObjectEncoder)}
+                                    M.ObjectEncoder, M.T5)}
 
 
 def _to_dict(c):
@@ -67,7 +67,8 @@ def no_decay_param_group(parameters, lr, name=""):
 class Query3DUnified(nn.Module):
     """model/query3d_unified.py:30-238.  Supported inputs: offline voxel features (``use_offline_voxel_fts``),
     mv / pc segment features, and a pre-encoded prompt memory (``data_dict['prompt_feat']`` [B,T,d]) in place of the
-    out-of-scope CLIP text encoder.  Heads: 'mask', 'ground' (the T5 'generation' body is third-party, §8f-3)."""
+    out-of-scope CLIP text encoder.  Heads: 'mask', 'ground', 'generation' (input_proj on the HIP kernels, the HF T5
+    decoder body on stock PyTorch-ROCm ops, §8f-3)."""
 
     def __init__(self, cfg, compute: str = "bf16"):
         super().__init__()
@@ -100,8 +101,6 @@ class Query3DUnified(nn.Module):
             self.coord_encoder = M.CoordinateEncoder(hidden_size)
         self.unified_encoder = build_module_by_name(cfg.model.unified_encoder)
         for head in self.heads:
-            if head == "generation":
-                raise NotImplementedError("generation head (HF T5 body) is a 'next' row (SURVEY §8f-3)")
             setattr(self, head + "_head", build_module_by_name(cfg.model.get(head + "_head")))
         self.compute = compute
         self._coef_cache = {}
@@ -218,6 +217,11 @@ class Query3DUnified(nn.Module):
                 data_dict["ground_logits"] = logits
                 data_dict["og3d_logits"] = logits
                 data_dict["ground_label"] = data_dict.get("tgt_object_id")
+            elif head == "generation":   # query3d_unified.py:201-206
+                label = data_dict["response"]
+                logits = self.generation_head(query, data_dict["query_pad_masks"], label if self.training else None)
+                data_dict["generation_logits"] = logits
+                data_dict["generation_label"] = label
             elif head == "mask":
                 if self.skip_query_encoder_mask_pred:
                     predictions_class, predictions_mask = [], []
@@ -250,7 +254,7 @@ class Query3DUnified(nn.Module):
 
 def make_cfg(*, d, H, L, memories, heads, d_in=None, spatial=True, structure="parallel", use_self_mask=False,
              num_blocks=1, dim_loc=3, C=201, foc=(), drop_test=(), offline_attn=False, skip_pred=False,
-             activation="relu", ground_hidden=None) -> Cfg:
+             activation="relu", ground_hidden=None, t5=None) -> Cfg:
     """Config with the reference YAML layout (configs/instseg_sceneverse.yaml:92-155) for synthetic runs."""
     d_in = d_in or {m: d for m in memories}
     model = {"name": "Query3DUnified", "memories": list(memories), "heads": list(heads), "hidden_size": d,
@@ -266,6 +270,10 @@ def make_cfg(*, d, H, L, memories, heads, d_in=None, spatial=True, structure="pa
                                                                  "filter_out_classes": list(foc)}},
              "ground_head": {"name": "GroundHead", "args": {"input_size": d, "hidden_size": ground_hidden or d // 2,
                                                              "dropout": 0.3}}}
+    if "generation" in heads:   # unified_tasks_sceneverse.yaml:174-181 (t5: dict -> explicit HF config, offline)
+        model["generation_head"] = {"name": "T5", "args": {"variant": "t5-small", "input_size": d,
+                                                            "use_projection": True, **({"hf_config": t5} if t5 else {})},
+                                    "lr": 1e-5}
     for m in memories:
         if m != "prompt":
             model[f"{m}_encoder"] = {"name": "ObjectEncoder", "args": {

@@ -580,6 +580,54 @@ class GroundHead(_PostNormBase):
                                 drop=self._drop(self._head_ctx(dev), ops.DROP_MLP_HEAD, dev)).squeeze(2)
 
 
+T5_ARCH = {   # architectures of the HF checkpoints the reference names (used only when the checkpoint is not on disk)
+    "t5-small": dict(vocab_size=32128, d_model=512, d_kv=64, d_ff=2048, num_layers=6, num_decoder_layers=6, num_heads=8,
+                     decoder_start_token_id=0, pad_token_id=0, eos_token_id=1),
+    "t5-base": dict(vocab_size=32128, d_model=768, d_kv=64, d_ff=3072, num_layers=12, num_decoder_layers=12, num_heads=12,
+                    decoder_start_token_id=0, pad_token_id=0, eos_token_id=1),
+}
+
+
+class T5(_PostNormBase):
+    """modules/heads/generation_head.py:8-30.  The in-repo part -- ``input_proj`` = Linear(d -> d_model) + LayerNorm --
+    runs on the HIP kernels; the decoder body is the third-party HF ``T5ForConditionalGeneration`` exactly as the
+    reference uses it (encoder bypassed through ``encoder_outputs``, cross-attending to the N_q query tokens under
+    ``attention_mask``), on stock PyTorch-ROCm ops: hand-written kernels for it are SURVEY 8f-3 ("next").
+    ``variant`` is loaded with ``from_pretrained`` when it is available locally; without network the same architecture
+    is built with random weights (``T5_ARCH`` or an explicit ``hf_config`` dict) -- state_dict keys are identical, so
+    a reference checkpoint loads over it."""
+
+    def __init__(self, cfg, variant="t5-small", input_size=768, use_projection=True, hf_config=None, **kwargs):
+        super().__init__()
+        from transformers import T5Config, T5ForConditionalGeneration   # third-party body (transformers, requirements.txt:63)
+        if hf_config is not None:
+            self.model = T5ForConditionalGeneration(T5Config(**dict(hf_config)))
+        else:
+            try:
+                self.model = T5ForConditionalGeneration.from_pretrained(variant, local_files_only=True)
+            except Exception:  # noqa: BLE001 -- not cached and no network: same architecture, random init
+                if variant not in T5_ARCH:
+                    raise
+                self.model = T5ForConditionalGeneration(T5Config(**T5_ARCH[variant]))
+        self.model.config.update(kwargs)
+        hidden_size = self.model.config.d_model
+        self.use_projection = use_projection
+        if use_projection:
+            self.input_proj = nn.Sequential(nn.Linear(input_size, hidden_size), nn.LayerNorm(hidden_size))
+        else:
+            assert input_size == hidden_size, "input_feat_size should be equal to hidden_size!"
+
+    def forward(self, query_embeds, attention_masks, labels=None):
+        from transformers.modeling_outputs import BaseModelOutput
+        if self.use_projection:
+            query_embeds = linear_ln_forward(self.input_proj, query_embeds, self.ct)
+        enc = BaseModelOutput(last_hidden_state=query_embeds)
+        if labels is not None:
+            return self.model(encoder_outputs=enc, attention_mask=attention_masks, labels=labels).logits
+        outputs = self.model.generate(encoder_outputs=enc, attention_mask=attention_masks, do_sample=False)
+        return outputs[:, 1:]   # remove the decoder start token (generation_head.py:29)
+
+
 # ------------------------------------------------------------------------------------------------ input side
 class ObjectEncoder(_PostNormBase):
     """modules/vision/object_encoder.py:15-79, projection path (backbone='none')."""

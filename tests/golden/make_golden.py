@@ -327,6 +327,49 @@ def run_misc_case(ref, name):
     save(name, out)
 
 
+T5_TINY = dict(vocab_size=128, d_model=64, d_kv=16, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=4,
+               decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
+
+
+def run_t5_case(ref, name, *, B=2, Nq=10, d=48, T=5, seed=11):
+    """F8: the reference's generation head class (modules/heads/generation_head.py:8-30) -- in-repo input_proj + the
+    way it drives the HF T5 decoder (encoder_outputs / attention_mask / labels; greedy generate, start token removed).
+    The pretrained checkpoint cannot be fetched here, so `from_pretrained` is pointed at a random-init T5 of a tiny
+    architecture (weights are synthetic in every fixture anyway); the third-party body itself stays whatever the
+    installed transformers computes ("parity unpinned" for row 12's body)."""
+    from transformers import T5Config, T5ForConditionalGeneration
+    orig = T5ForConditionalGeneration.from_pretrained
+    T5ForConditionalGeneration.from_pretrained = classmethod(lambda cls, variant, **kw: cls(T5Config(**T5_TINY)))
+    try:
+        gh = importlib.import_module("modules.heads.generation_head")
+        torch.manual_seed(0)
+        head = gh.T5(None, variant="tiny", input_size=d, use_projection=True)
+    finally:
+        T5ForConditionalGeneration.from_pretrained = orig
+    sd = synth.fill_module(head, seed)
+    head.eval()
+    r = np.random.default_rng(seed)
+    q = torch.from_numpy(r.standard_normal((B, Nq, d)).astype(np.float32)).requires_grad_(True)
+    mask = torch.ones(B, Nq, dtype=torch.bool)
+    mask[1, Nq - 3:] = False
+    labels = torch.from_numpy(r.integers(2, T5_TINY["vocab_size"], (B, T)))
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd)),
+           "meta/args": np.array(repr(dict(B=B, Nq=Nq, d=d, T=T, seed=seed, hf_config=T5_TINY))),
+           "q": q.detach().numpy(), "mask": mask.numpy(), "labels": labels.numpy()}
+    put(out, "input_proj", head.input_proj(q))
+    logits = head(q, mask, labels)
+    put(out, "logits", logits)
+    loss = (logits * loss_weight("t5logits", logits.shape)).mean()
+    loss.backward()
+    out["loss"] = np.float64(loss.item())
+    put(out, "grad/q", q.grad, MAX_GRAD)
+    for n, p in head.input_proj.named_parameters():
+        put(out, "grad/input_proj." + n, p.grad, MAX_GRAD)
+    with torch.no_grad():
+        out["generated"] = head(q.detach(), mask, None).numpy()
+    save(name, out)
+
+
 def main():
     ref = import_reference()
     # F1: BASELINE config 1 exactly (1 layer, B2, Ns128, Nq16, d64, H4, one stream, non-spatial, sequential)
@@ -362,6 +405,7 @@ def main():
     # F7: three optimizer steps (clip + AdamW + warmup_cosine) with the reference's optimizer / scheduler objects
     run_train_case(ref, "F7_adamw_c1", B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=["ground"],
                    spatial=False, structure="sequential", head_lr=3e-3)
+    run_t5_case(ref, "F8_t5_head")
     run_train_case(ref, "F7_adamw_mask", B=2, Ns=96, Nq=12, d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask"],
                    spatial=True, structure="parallel", use_self_mask=False, foc=(0, 2), warmup_steps=0, total_steps=6)
 

@@ -8,7 +8,7 @@ from pq3d_amd import synth
 from tests import util
 
 TOL = dict(atol=1e-5, rtol=1e-5)
-MODEL_FIXTURES = [f for f in util.fixtures() if not f.startswith(("F3_", "F6_", "F7_"))]
+MODEL_FIXTURES = [f for f in util.fixtures() if not f.startswith(("F3_", "F6_", "F7_", "F8_"))]
 
 
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
@@ -89,3 +89,15 @@ def test_scatter_mean_matches_definition():
         sel = src[idx == s]
         exp = sel.mean(0) if len(sel) else torch.zeros(7)
         assert torch.allclose(out[s], exp, atol=1e-6)
+
+
+def test_t5_input_proj_against_reference_head():
+    """F8: the in-repo part of the generation head (generation_head.py:16,22); the HF body is third-party."""
+    z, a = util.load_fixture("F8_t5_head")
+    from pq3d_amd import synth
+    import ast
+    names = {"input_proj.0.weight": (a["hf_config"]["d_model"], a["d"]), "input_proj.0.bias": (a["hf_config"]["d_model"],),
+             "input_proj.1.weight": (a["hf_config"]["d_model"],), "input_proj.1.bias": (a["hf_config"]["d_model"],)}
+    sd = synth.synth_state_dict(names, a["seed"])
+    y = O.t5_input_proj({"generation_head." + k: v for k, v in sd.items()}, "generation_head.", torch.from_numpy(z["q"]))
+    util.check_against(z, "input_proj", y, atol=1e-5, rtol=1e-5)
