@@ -332,6 +332,66 @@ int pq3d_train_scalars(const pq3d_adamw_hp* hp, int64_t* step, const float* part
 int pq3d_adamw(float* p, const float* g, float* m, float* v, int64_t n, const pq3d_adamw_hp* hp,
                const pq3d_opt_segments* segs, const float* scalars, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Instance-segmentation set criterion on the path's outputs (configs/instseg_sceneverse.yaml:160-175):
+ * HungarianMatcher cost matrix (modules/third_party/mask3d/matcher.py:104-184, num_points = -1) and the matched
+ * losses of SetCriterion (criterion.py:136-206).  Per prediction layer, with X = mask logits [B, Ns, Nq] (segments
+ * first), T = padded target masks [B, Nt, Ns] (0/1 floats), seg_len[b] = segments of scene b (matcher.py:139-148 uses
+ * the first tgt_mask.shape[1] columns), n_inst[b] = targets of scene b:
+ *   pq3d_mask_cost_prep : sig = sigma(X) (0 past seg_len), partial column sums of softplus(X) and sigma(X)
+ *                         ([B, nsplit, Nq], nsplit = pq3d_mask_cost_nsplit(Ns))
+ *   pq3d_gemm (ct F32, groups 2, batch B, A = T, B = X | sig with transB): TX = T X, TS = T sigma(X)   [B, Nt, Nq]
+ *   pq3d_match_cost     : cost_mask = (sum_s softplus(x) - TX)/S  (== batch_sigmoid_ce_loss: pos - neg = -x),
+ *                         cost_dice = 1 - (2 TS + 1)/(sum sigma + sum T + 1), cost_class = -softmax(cls)[label]
+ *                         (-1 for ignore_label), cost = w_mask cm + w_class cc + w_dice cd     [B, Nq, Nt]
+ *   (host)              : scipy.optimize.linear_sum_assignment per scene, as the reference
+ *   losses              : sigmoid_ce_loss / dice_loss of a matched pair (criterion.py:27-70) ARE cost_mask / cost_dice at
+ *                         that pair -> gathers; pq3d_matched_mask_grad writes d loss / d X (zero off the matched columns);
+ *   pq3d_cross_entropy_fwd/bwd : loss_labels (criterion.py:136-163), F.cross_entropy with ignore_index, per-row
+ *                         loss + logsumexp; dlogits = scale[0] * (softmax - onehot) on non-ignored rows.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t B, Nq, Nt, Ns, C, nsplit;
+  float w_class, w_mask, w_dice;
+  int64_t ignore_label;
+  const float* TX;          /* [B, Nt, Nq] */
+  const float* TS;          /* [B, Nt, Nq] */
+  const float* sp_part;     /* [B, nsplit, Nq] */
+  const float* sg_part;     /* [B, nsplit, Nq] */
+  const float* t_sum;       /* [B, Nt] = sum_s T */
+  const int32_t* seg_len;   /* [B] */
+  const int32_t* n_inst;    /* [B] */
+  const float* cls_logits;  /* [B, Nq, C] (may hold -inf at filtered classes) */
+  const int64_t* labels;    /* [B, Nt] */
+  float* cost;              /* [B, Nq, Nt]; entries t >= n_inst[b] are 0 */
+  float* cost_mask;
+  float* cost_dice;
+} pq3d_match_cost_desc;
+typedef struct {
+  int32_t B, Ns, Nq, Nt, Nm;   /* Nm = row length of q_idx / t_idx */
+  const float* sig;            /* [B, Ns, Nq] from pq3d_mask_cost_prep */
+  const float* T;              /* [B, Nt, Ns] */
+  const float* TS;             /* [B, Nt, Nq] */
+  const float* sig_sum;        /* [B, Nq] (sum of sg_part over splits) */
+  const float* t_sum;          /* [B, Nt] */
+  const int32_t* seg_len;      /* [B] */
+  const int32_t* q_idx;        /* [B, Nm] matched queries */
+  const int32_t* t_idx;        /* [B, Nm] matched targets */
+  const int32_t* n_match;      /* [B] */
+  const float* g_mask;         /* [B] upstream gradient x 1/(n_match_b * B) of the BCE term (the 1/S_b is applied inside) */
+  const float* g_dice;         /* [B] same for the dice term */
+  float* dX;                   /* [B, Ns, Nq], fully written */
+} pq3d_mask_grad_desc;
+int pq3d_mask_cost_prep(const float* X, const int32_t* seg_len, float* sig, float* sp_part, float* sg_part, int32_t B,
+                        int32_t Ns, int32_t Nq, void* stream);
+int32_t pq3d_mask_cost_nsplit(int32_t Ns);
+int pq3d_match_cost(const pq3d_match_cost_desc* d, void* stream);
+int pq3d_matched_mask_grad(const pq3d_mask_grad_desc* d, void* stream);
+int pq3d_cross_entropy_fwd(const float* logits, const int64_t* target, int64_t R, int32_t C, int64_t ignore_index,
+                           float* row_loss, float* lse, void* stream);
+int pq3d_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, int64_t R, int32_t C,
+                           int64_t ignore_index, const float* scale, float* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

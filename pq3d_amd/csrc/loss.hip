@@ -1,0 +1,220 @@
+// Instance-segmentation set criterion around the path's outputs: the Hungarian cost matrix of
+// HungarianMatcher.memory_efficient_forward (modules/third_party/mask3d/matcher.py:104-184) and the matched losses of
+// SetCriterion (criterion.py:136-206), re-derived so that ONE grouped fp32 MFMA GEMM per prediction layer carries all
+// the segment-dimension work:
+//     pos - neg = softplus(-x) - softplus(x) = -x   =>
+//     cost_mask[q,t] = ( sum_s softplus(x_sq) - (T X)[t,q] ) / S            (batch_sigmoid_ce_loss, matcher.py:37-60)
+//     cost_dice[q,t] = 1 - (2 (T sigma(X))[t,q] + 1) / (sum_s sigma(x_sq) + sum_s T_ts + 1)      (matcher.py:12-28)
+// with X = mask logits [S, Nq] of one scene (segments first, as the mask head writes them), T = target masks [Nt, S].
+// With num_points = -1 (all points, the shipped config) the matched losses sigmoid_ce_loss / dice_loss
+// (criterion.py:27-70) are exactly the matched ENTRIES of those two matrices, so the forward losses are gathers and
+// only the gradient needs a second pass over the logits.  The assignment itself (scipy LSA in the reference) stays on
+// the host.  Kernels here are HBM-bound streaming / reductions; the contraction is pq3d_gemm (ct = F32).
+#include "common.h"
+
+namespace {
+
+constexpr int PREP_ROWS = 256;   // segments per block of the prep kernel
+
+PQ_DEV float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+PQ_DEV float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// sig[b,s,q] = sigma(x) (0 for s >= len_b); partial column sums over this block's rows of softplus(x) and sigma(x)
+__global__ __launch_bounds__(256) void mask_cost_prep_kernel(const float* __restrict__ X, const int32_t* __restrict__ seg_len,
+                                                             float* __restrict__ sig, float* __restrict__ sp_part,
+                                                             float* __restrict__ sg_part, int Ns, int Nq, int nsplit) {
+  __shared__ float red[2][4][64];
+  const int b = blockIdx.z, split = blockIdx.y, q = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int len = min(seg_len[b], Ns);
+  const int s0 = split * PREP_ROWS, s1 = min(s0 + PREP_ROWS, Ns);
+  float sp = 0.f, sg = 0.f;
+  if (q < Nq) {
+    for (int s = s0 + rg; s < s1; s += 4) {
+      const long i = ((long)b * Ns + s) * Nq + q;
+      const float x = X[i];
+      const bool in = s < len;
+      const float g = in ? sigmoid_f(x) : 0.f;
+      sig[i] = g;
+      sg += g;
+      sp += in ? softplus_f(x) : 0.f;
+    }
+  }
+  red[0][rg][threadIdx.x & 63] = sp;
+  red[1][rg][threadIdx.x & 63] = sg;
+  __syncthreads();
+  if (threadIdx.x < 64 && q < Nq) {
+    const long o = ((long)b * nsplit + split) * Nq + q;
+    sp_part[o] = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+    sg_part[o] = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+  }
+}
+
+// one wave per (scene, query): class-probability row statistics, then the Nt costs of that query
+__global__ __launch_bounds__(64) void match_cost_kernel(const pq3d_match_cost_desc d) {
+  const int q = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const float* lg = d.cls_logits + ((long)b * d.Nq + q) * d.C;
+  float mx = -INFINITY;
+  for (int c = lane; c < d.C; c += 64) mx = fmaxf(mx, lg[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < d.C; c += 64) se += expf(lg[c] - mx);
+  se = wave_sum(se);
+  float sp = 0.f, sg = 0.f;   // finish the deterministic two-stage column sums
+  for (int i = 0; i < d.nsplit; ++i) {
+    sp += d.sp_part[((long)b * d.nsplit + i) * d.Nq + q];
+    sg += d.sg_part[((long)b * d.nsplit + i) * d.Nq + q];
+  }
+  const int nt = d.n_inst[b];
+  const float inv_s = 1.f / (float)min(d.seg_len[b], d.Ns);
+  for (int t = lane; t < d.Nt; t += 64) {
+    const long o = ((long)b * d.Nq + q) * d.Nt + t;
+    if (t >= nt) { d.cost[o] = 0.f; d.cost_mask[o] = 0.f; d.cost_dice[o] = 0.f; continue; }
+    const long gi = ((long)b * d.Nt + t) * d.Nq + q;
+    const float cm = (sp - d.TX[gi]) * inv_s;
+    const float cd = 1.f - (2.f * d.TS[gi] + 1.f) / (sg + d.t_sum[(long)b * d.Nt + t] + 1.f);
+    const long lab = d.labels[(long)b * d.Nt + t];
+    const float cc = lab == d.ignore_label ? -1.f : -expf(lg[lab] - mx) / se;   // -softmax prob; "perfect match" if ignored
+    d.cost_mask[o] = cm;
+    d.cost_dice[o] = cd;
+    d.cost[o] = d.w_mask * cm + d.w_class * cc + d.w_dice * cd;
+  }
+}
+
+// dX[b,s,q_j] = gm_b * (sigma - T)/S_b + gd_b * sigma(1-sigma) * (-(2 T D - (2 TS + 1)) / D^2),  D = sig_sum + t_sum + 1;
+// every other entry of dX is zero.  Block = (64-segment tile, scene): X / dX tiles go through LDS so that both the
+// [S, Nq]-major logits and the [Nt, S]-major targets are read and written coalesced.
+__global__ __launch_bounds__(256) void matched_mask_grad_kernel(const pq3d_mask_grad_desc d) {
+  extern __shared__ float lds[];   // [64][Nq + 1] sigma tile, then [64][Nq + 1] gradient tile
+  const int b = blockIdx.y, s0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int ld = d.Nq + 1;
+  float* sg_t = lds;
+  float* g_t = lds + 64 * ld;
+  const int len = min(d.seg_len[b], d.Ns);
+  for (int i = tid; i < 64 * d.Nq; i += 256) {
+    const int r = i / d.Nq, c = i % d.Nq;
+    const int s = s0 + r;
+    sg_t[r * ld + c] = s < d.Ns ? d.sig[((long)b * d.Ns + s) * d.Nq + c] : 0.f;
+    g_t[r * ld + c] = 0.f;
+  }
+  __syncthreads();
+  const int nm = d.n_match[b];
+  const float gm = d.g_mask[b] / (float)len, gd = d.g_dice[b];
+  const int sl = tid & 63, s = s0 + sl;
+  if (s < len) {
+    for (int j = tid >> 6; j < nm; j += 4) {
+      const int q = d.q_idx[(long)b * d.Nm + j], t = d.t_idx[(long)b * d.Nm + j];
+      const float sg = sg_t[sl * ld + q];
+      const float tv = d.T[((long)b * d.Nt + t) * d.Ns + s];
+      const float ssum = d.sig_sum[(long)b * d.Nq + q], D = ssum + d.t_sum[(long)b * d.Nt + t] + 1.f;
+      const float num = 2.f * d.TS[((long)b * d.Nt + t) * d.Nq + q] + 1.f;
+      g_t[sl * ld + q] = gm * (sg - tv) + gd * sg * (1.f - sg) * (-(2.f * tv * D - num) / (D * D));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * d.Nq; i += 256) {
+    const int r = i / d.Nq, c = i % d.Nq;
+    if (s0 + r < d.Ns) d.dX[((long)b * d.Ns + s0 + r) * d.Nq + c] = g_t[r * ld + c];
+  }
+}
+
+// cross entropy over rows (F.cross_entropy(..., ignore_index)): one wave per row
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                    long R, int C, long ignore, float* __restrict__ row_loss,
+                                                    float* __restrict__ lse) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = logits + row * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, x[c]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < C; c += 64) se += expf(x[c] - mx);
+  se = wave_sum(se);
+  if (lane == 0) {
+    const float l = mx + logf(se);
+    lse[row] = l;
+    const long t = target[row];
+    row_loss[row] = t == ignore ? 0.f : l - x[t];
+  }
+}
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                    const float* __restrict__ lse, long R, int C, long ignore,
+                                                    const float* __restrict__ scale, float* __restrict__ dlogits) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  const long t = target[row];
+  const float sc = t == ignore ? 0.f : scale[0];
+  const float l = lse[row];
+  for (int c = lane; c < C; c += 64) {
+    const float x = logits[row * C + c];
+    dlogits[row * C + c] = sc == 0.f ? 0.f : sc * (expf(x - l) - (c == t ? 1.f : 0.f));
+  }
+}
+
+}  // namespace
+
+extern "C" int pq3d_mask_cost_prep(const float* X, const int32_t* seg_len, float* sig, float* sp_part, float* sg_part,
+                                   int32_t B, int32_t Ns, int32_t Nq, void* stream) {
+  PQ_CHECK_ARG(X && seg_len && sig && sp_part && sg_part && B >= 0 && Ns >= 1 && Nq >= 1, "pq3d_mask_cost_prep: bad args");
+  if (B == 0) return 0;
+  const int nsplit = (Ns + PREP_ROWS - 1) / PREP_ROWS;
+  hipLaunchKernelGGL(mask_cost_prep_kernel, dim3((Nq + 63) / 64, nsplit, B), dim3(256), 0, (hipStream_t)stream, X, seg_len,
+                     sig, sp_part, sg_part, Ns, Nq, nsplit);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t pq3d_mask_cost_nsplit(int32_t Ns) { return (Ns + PREP_ROWS - 1) / PREP_ROWS; }
+
+extern "C" int pq3d_match_cost(const pq3d_match_cost_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_match_cost: null descriptor");
+  const pq3d_match_cost_desc d = *dp;
+  PQ_CHECK_ARG(d.TX && d.TS && d.sp_part && d.sg_part && d.t_sum && d.seg_len && d.n_inst && d.cls_logits && d.labels &&
+               d.cost && d.cost_mask && d.cost_dice, "pq3d_match_cost: null pointer");
+  PQ_CHECK_ARG(d.B >= 0 && d.Nq >= 1 && d.Nt >= 1 && d.C >= 1 && d.Ns >= 1 && d.nsplit == (d.Ns + PREP_ROWS - 1) / PREP_ROWS,
+               "pq3d_match_cost: bad sizes");
+  if (d.B == 0) return 0;
+  hipLaunchKernelGGL(match_cost_kernel, dim3(d.Nq, d.B), dim3(64), 0, (hipStream_t)stream, d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_matched_mask_grad(const pq3d_mask_grad_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_matched_mask_grad: null descriptor");
+  const pq3d_mask_grad_desc d = *dp;
+  PQ_CHECK_ARG(d.sig && d.T && d.TS && d.sig_sum && d.t_sum && d.seg_len && d.q_idx && d.t_idx && d.n_match && d.g_mask &&
+               d.g_dice && d.dX, "pq3d_matched_mask_grad: null pointer");
+  PQ_CHECK_ARG(d.B >= 0 && d.Ns >= 1 && d.Nq >= 1 && d.Nt >= 1 && d.Nm >= 1, "pq3d_matched_mask_grad: bad sizes");
+  const size_t lds = (size_t)2 * 64 * (d.Nq + 1) * sizeof(float);
+  PQ_CHECK_ARG(lds <= 160 * 1024, "pq3d_matched_mask_grad: Nq too large for the LDS tile (<= 319)");
+  if (d.B == 0) return 0;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)matched_mask_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(matched_mask_grad_kernel, dim3((d.Ns + 63) / 64, d.B), dim3(256), lds, (hipStream_t)stream, d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_cross_entropy_fwd(const float* logits, const int64_t* target, int64_t R, int32_t C, int64_t ignore_index,
+                                      float* row_loss, float* lse, void* stream) {
+  PQ_CHECK_ARG(logits && target && row_loss && lse && R >= 0 && C >= 1, "pq3d_cross_entropy_fwd: bad args");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, target, (long)R,
+                     C, (long)ignore_index, row_loss, lse);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, int64_t R, int32_t C,
+                                      int64_t ignore_index, const float* scale, float* dlogits, void* stream) {
+  PQ_CHECK_ARG(logits && target && lse && scale && dlogits && R >= 0 && C >= 1, "pq3d_cross_entropy_bwd: bad args");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, target, lse,
+                     (long)R, C, (long)ignore_index, scale, dlogits);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

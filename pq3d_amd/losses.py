@@ -1,0 +1,232 @@
+"""Instance-segmentation set criterion on the decoder's outputs: drop-in counterparts of
+``HungarianMatcher`` (modules/third_party/mask3d/matcher.py:67-215), ``SetCriterion`` (criterion.py:95-270) and
+``InstSegLoss`` (optim/loss/instseg_loss.py:9-52) for the shipped configuration (criterion_type 'set',
+num_points = -1, class_weights = -1).
+
+Where the reference loops over scenes and layers with a dozen torch ops each ((L n_b + 1) x B cost matrices per step,
+each followed by a device->host copy), this runs, per prediction layer, three launches for the cost matrices of ALL
+scenes (include/pq3d_hip.h: prep, one grouped fp32 MFMA GEMM, cost), ONE device->host copy for all layers, the
+assignments on the host (scipy, as the reference), then the losses as gathers of the already computed cost entries
+plus one gradient kernel per layer.  No CPU fallback for the device part."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from scipy.optimize import linear_sum_assignment
+from torch.autograd import Function
+
+from . import _lib as L
+
+
+class HungarianMatcher(nn.Module):
+    """matcher.py:67-103 (parameter holder; the cost matrix is built by SetCriterion's fused path)."""
+
+    def __init__(self, cost_class: float = 1, cost_mask: float = 1, cost_dice: float = 1, num_points: int = 0,
+                 ignore_label: int = -100):
+        super().__init__()
+        assert cost_class != 0 or cost_mask != 0 or cost_dice != 0, "all costs cant be 0"
+        if num_points != -1:
+            raise NotImplementedError("random point sub-sampling (num_points != -1) is not used by the shipped config")
+        self.cost_class, self.cost_mask, self.cost_dice = cost_class, cost_mask, cost_dice
+        self.num_points, self.ignore_label = num_points, ignore_label
+
+
+def _targets_to_device(instance_labels: Sequence[torch.Tensor], segment_masks: Sequence[torch.Tensor], Ns: int, device):
+    """list of [n_b] labels / [n_b, S_b] masks -> padded T [B,Nt,Ns] fp32, labels [B,Nt], seg_len, n_inst (int32)."""
+    B = len(segment_masks)
+    n_inst = [int(m.shape[0]) for m in segment_masks]
+    seg_len = [int(m.shape[1]) for m in segment_masks]
+    assert max(seg_len) <= Ns, "target masks have more segments than the prediction"
+    Nt = max(max(n_inst), 1)
+    T = torch.zeros(B, Nt, Ns, dtype=torch.float32)
+    lab = torch.zeros(B, Nt, dtype=torch.int64)
+    for b in range(B):
+        T[b, :n_inst[b], :seg_len[b]] = segment_masks[b].float().cpu()
+        lab[b, :n_inst[b]] = instance_labels[b].cpu()
+    T = T.to(device)
+    return T, lab.to(device), torch.tensor(seg_len, dtype=torch.int32, device=device), \
+        torch.tensor(n_inst, dtype=torch.int32, device=device), n_inst, T.sum(-1)
+
+
+class _LayerCosts:
+    """Device buffers of one prediction layer kept for the loss / gradient stage."""
+    __slots__ = ("sig", "TS", "sig_sum", "cost_mask", "cost_dice")
+
+
+def _layer_costs(X, logits, T, labels, seg_len, n_inst_dev, t_sum, w, ignore_label):
+    B, Ns, Nq = X.shape
+    Nt, Ccls = T.shape[1], logits.shape[-1]
+    dev = X.device
+    nsplit = L.lib().pq3d_mask_cost_nsplit(Ns)
+    sig = torch.empty_like(X)
+    sp_part = torch.empty(B, nsplit, Nq, dtype=torch.float32, device=dev)
+    sg_part = torch.empty_like(sp_part)
+    L.check(L.lib().pq3d_mask_cost_prep(L.ptr(X), L.ptr(seg_len), L.ptr(sig), L.ptr(sp_part), L.ptr(sg_part), B, Ns, Nq,
+                                        L.stream()), "pq3d_mask_cost_prep")
+    TXS = torch.empty(2, B, Nt, Nq, dtype=torch.float32, device=dev)
+    L.gemm(M=Nt, N=Nq, K=Ns, A=[T, T], B=[X, sig], Cs=[TXS[0], TXS[1]], ct=L.F32, lda=Ns, ldb=Nq, ldc=Nq, transB=True,
+           batch=B, strideA=Nt * Ns, strideB=Ns * Nq, strideC=Nt * Nq)
+    cost = torch.empty(3, B, Nq, Nt, dtype=torch.float32, device=dev)
+    d = L.MatchCostDesc()
+    d.B, d.Nq, d.Nt, d.Ns, d.C, d.nsplit = B, Nq, Nt, Ns, Ccls, nsplit
+    d.w_class, d.w_mask, d.w_dice, d.ignore_label = w[0], w[1], w[2], ignore_label
+    d.TX, d.TS, d.sp_part, d.sg_part, d.t_sum = map(L.ptr, (TXS[0], TXS[1], sp_part, sg_part, t_sum))
+    d.seg_len, d.n_inst, d.cls_logits, d.labels = map(L.ptr, (seg_len, n_inst_dev, logits, labels))
+    d.cost, d.cost_mask, d.cost_dice = L.ptr(cost[0]), L.ptr(cost[1]), L.ptr(cost[2])
+    L.check(L.lib().pq3d_match_cost(C.byref(d), L.stream()), "pq3d_match_cost")
+    lc = _LayerCosts()
+    lc.sig, lc.TS, lc.sig_sum, lc.cost_mask, lc.cost_dice = sig, TXS[1], sg_part.sum(1), cost[1], cost[2]
+    return cost[0], lc
+
+
+class _SetCriterionFn(Function):
+    """(mask logits of every layer, class logits of every layer) -> losses [n_layers, 3] = (ce, mask, dice)."""
+
+    @staticmethod
+    def forward(ctx, crit, T, labels, seg_len, n_inst_dev, n_inst, t_sum, n_layers, *preds):
+        masks = [p.contiguous().float() for p in preds[:n_layers]]
+        logits = [p.contiguous().float() for p in preds[n_layers:]]
+        B, Ns, Nq = masks[0].shape
+        Nt, dev = T.shape[1], T.device
+        m = crit.matcher
+        w = (float(m.cost_class), float(m.cost_mask), float(m.cost_dice))
+        costs, lcs = [], []
+        for X, lg in zip(masks, logits):
+            c, lc = _layer_costs(X, lg, T, labels, seg_len, n_inst_dev, t_sum, w, m.ignore_label)
+            costs.append(c)
+            lcs.append(lc)
+        host = torch.stack(costs, 0).cpu().numpy()     # the ONE device->host copy of the step: [layers, B, Nq, Nt]
+        Nm = max(min(Nq, max(n_inst)), 1)
+        q_idx = np.zeros((n_layers, B, Nm), dtype=np.int32)
+        t_idx = np.zeros((n_layers, B, Nm), dtype=np.int32)
+        n_match = np.zeros((n_layers, B), dtype=np.int32)
+        indices: List[List[Tuple[torch.Tensor, torch.Tensor]]] = []
+        for l in range(n_layers):
+            per = []
+            for b in range(B):
+                i, j = linear_sum_assignment(host[l, b, :, :n_inst[b]])    # scipy, as matcher.py:184
+                q_idx[l, b, :len(i)], t_idx[l, b, :len(j)], n_match[l, b] = i, j, len(i)
+                per.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+            indices.append(per)
+        q_idx_d, t_idx_d = torch.from_numpy(q_idx).to(dev), torch.from_numpy(t_idx).to(dev)
+        n_match_d = torch.from_numpy(n_match).to(dev)
+        valid = (torch.arange(Nm, device=dev)[None, None, :] < n_match_d[:, :, None])          # [layers, B, Nm]
+        bidx = torch.arange(B, device=dev)[:, None].expand(B, Nm)
+        losses = torch.zeros(n_layers, 3, dtype=torch.float32, device=dev)
+        tgt_all, lse_all, cnt_all = [], [], []
+        nmf = n_match_d.float().clamp(min=1.0)
+        for l in range(n_layers):
+            qi, ti = q_idx_d[l].long(), t_idx_d[l].long()
+            # matched-pair losses ARE the matched entries of the cost matrices (criterion.py:27-70, num_points = -1)
+            cm = lcs[l].cost_mask[bidx, qi, ti] * valid[l]
+            cd = lcs[l].cost_dice[bidx, qi, ti] * valid[l]
+            losses[l, 1] = (cm.sum(1) / nmf[l]).mean()
+            losses[l, 2] = (cd.sum(1) / nmf[l]).mean()
+            # classification (criterion.py:136-163): unmatched queries -> no-object class (= num_classes)
+            tgt = torch.full((B, Nq), crit.num_classes, dtype=torch.int64, device=dev)
+            lab_m = labels[bidx, ti]
+            tgt[bidx[valid[l]], qi[valid[l]]] = lab_m[valid[l]]
+            Ccls = logits[l].shape[-1]
+            row_loss = torch.empty(B * Nq, dtype=torch.float32, device=dev)
+            lse = torch.empty_like(row_loss)
+            L.check(L.lib().pq3d_cross_entropy_fwd(L.ptr(logits[l]), L.ptr(tgt), B * Nq, Ccls, crit.ignore_label,
+                                                   L.ptr(row_loss), L.ptr(lse), L.stream()), "pq3d_cross_entropy_fwd")
+            cnt = (tgt != crit.ignore_label).sum().clamp(min=1).float()
+            losses[l, 0] = row_loss.sum() / cnt
+            tgt_all.append(tgt); lse_all.append(lse); cnt_all.append(cnt)
+        ctx.crit, ctx.n_layers, ctx.lcs = crit, n_layers, lcs
+        ctx.masks, ctx.logits, ctx.tgt, ctx.lse, ctx.cnt = masks, logits, tgt_all, lse_all, cnt_all
+        ctx.targets = (T, seg_len, t_sum, q_idx_d, t_idx_d, n_match_d, Nm)
+        ctx.in_dtypes = [p.dtype for p in preds]
+        ctx.indices = indices
+        crit._last_indices = indices
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        T, seg_len, t_sum, q_idx_d, t_idx_d, n_match_d, Nm = ctx.targets
+        n_layers = ctx.n_layers
+        B, Ns, Nq = ctx.masks[0].shape
+        Nt = T.shape[1]
+        g = g.contiguous().float()
+        nmf = n_match_d.float().clamp(min=1.0)
+        dmasks, dlogits = [], []
+        for l in range(n_layers):
+            lc = ctx.lcs[l]
+            dX = torch.empty_like(ctx.masks[l])
+            gm = (g[l, 1] / (nmf[l] * B)).contiguous()      # d loss_mask / d (sum_s bce)  (1/S_b inside the kernel)
+            gd = (g[l, 2] / (nmf[l] * B)).contiguous()
+            d = L.MaskGradDesc()
+            d.B, d.Ns, d.Nq, d.Nt, d.Nm = B, Ns, Nq, Nt, Nm
+            d.sig, d.T, d.TS, d.sig_sum, d.t_sum, d.seg_len = map(L.ptr, (lc.sig, T, lc.TS, lc.sig_sum, t_sum, seg_len))
+            qi, ti, nm = q_idx_d[l].contiguous(), t_idx_d[l].contiguous(), n_match_d[l].contiguous()
+            d.q_idx, d.t_idx, d.n_match, d.g_mask, d.g_dice, d.dX = map(L.ptr, (qi, ti, nm, gm, gd, dX))
+            L.check(L.lib().pq3d_matched_mask_grad(C.byref(d), L.stream()), "pq3d_matched_mask_grad")
+            dmasks.append(dX)
+            dl = torch.empty_like(ctx.logits[l])
+            scale = (g[l, 0] / ctx.cnt[l]).reshape(1).contiguous()
+            L.check(L.lib().pq3d_cross_entropy_bwd(L.ptr(ctx.logits[l]), L.ptr(ctx.tgt[l]), L.ptr(ctx.lse[l]), B * Nq,
+                                                   dl.shape[-1], ctx.crit.ignore_label, L.ptr(scale), L.ptr(dl),
+                                                   L.stream()), "pq3d_cross_entropy_bwd")
+            dlogits.append(dl)
+        grads = [t.to(dt) for t, dt in zip(dmasks + dlogits, ctx.in_dtypes)]
+        return (None,) * 8 + tuple(grads)
+
+
+class SetCriterion(nn.Module):
+    """criterion.py:95-270: forward(predictions_mask, predictions_class, instance_labels, segment_masks) ->
+    (losses dict with 'loss_ce', 'loss_mask', 'loss_dice' and the '_i' auxiliary copies, indices of the last layer)."""
+
+    def __init__(self, num_classes, matcher, weight_dict, losses, num_points, class_weights, ignore_label):
+        super().__init__()
+        if num_points != -1 or class_weights != -1:
+            raise NotImplementedError("only num_points = -1, class_weights = -1 (configs/instseg_sceneverse.yaml:163-168)")
+        self.num_classes, self.matcher, self.weight_dict, self.losses = num_classes, matcher, weight_dict, list(losses)
+        self.num_points, self.class_weights, self.ignore_label = num_points, class_weights, ignore_label
+        self._last_indices = None
+
+    def forward(self, predictions_mask, predictions_class, instance_labels, segment_masks):
+        n = len(predictions_mask)
+        # reference order: the LAST prediction is the main output, the others are the auxiliary '_i' losses
+        order = [n - 1] + list(range(n - 1))
+        masks = [predictions_mask[i] for i in order]
+        logits = [predictions_class[i] for i in order]
+        dev = masks[0].device
+        T, labels, seg_len, n_inst_dev, n_inst, t_sum = _targets_to_device(instance_labels, segment_masks,
+                                                                         masks[0].shape[1], dev)
+        out = _SetCriterionFn.apply(self, T, labels, seg_len, n_inst_dev, n_inst, t_sum, n, *masks, *logits)
+        names = {"labels": [(0, "loss_ce")], "masks": [(1, "loss_mask"), (2, "loss_dice")]}
+        losses: Dict[str, torch.Tensor] = {}
+        for l in range(n):
+            suffix = "" if l == 0 else f"_{l - 1}"
+            for kind in self.losses:
+                for col, name in names[kind]:
+                    losses[name + suffix] = out[l, col]
+        return losses, self._last_indices[0]
+
+
+class InstSegLoss(nn.Module):
+    """optim/loss/instseg_loss.py:9-52 (criterion_type 'set')."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        loss_cfg = cfg.model.get(self.__class__.__name__)
+        self.criterion_type = loss_cfg.get("criterion_type", "set")
+        if self.criterion_type != "set":
+            raise NotImplementedError("criterion_type 'direct' (ground-truth masks, no matching) is not built yet")
+        matcher = HungarianMatcher(**dict(loss_cfg.matcher))
+        self.weight_dict = {"loss_ce": matcher.cost_class, "loss_mask": matcher.cost_mask, "loss_dice": matcher.cost_dice}
+        self.set_criterion = SetCriterion(matcher=matcher, weight_dict=self.weight_dict, **dict(loss_cfg.criterion))
+
+    def forward(self, data_dict):
+        losses, indices = self.set_criterion(data_dict["predictions_mask"], data_dict["predictions_class"],
+                                             data_dict["instance_labels"], data_dict["segment_masks"])
+        data_dict["indices"] = indices
+        for k in list(losses.keys()):
+            losses[k] = losses[k] * self.weight_dict[k.split("_")[0] + "_" + k.split("_")[1]]
+        return [sum(losses.values()), losses]

@@ -89,3 +89,20 @@ def synth_data_dict(B: int, n_seg: int, n_q: int, d_in: Mapping[str, int], seed:
         dd["prompt_feat"] = torch.from_numpy(pf)
         dd["prompt_pad_masks"] = torch.from_numpy(pv)
     return dd
+
+
+def criterion_inputs(seed=21, B=3, Ns=70, Nq=12, C=21, n_layers=3, seg_len=(70, 55, 61), n_inst=(5, 9, 3)):
+    """Synthetic predictions / targets of the F9 criterion fixture (also rebuilt by the tests)."""
+    r = np.random.default_rng(seed)
+    masks, logits = [], []
+    for _ in range(n_layers):
+        m = (r.standard_normal((B, Ns, Nq)) * 2.0).astype(np.float32)
+        for b in range(B):
+            m[b, seg_len[b]:] = -1e6          # what the mask head writes for padded segments (mask_head.py:38)
+        lg = r.standard_normal((B, Nq, C)).astype(np.float32)
+        lg[..., [0, 2]] = -np.inf              # filter_out_classes (mask_head.py:28)
+        masks.append(torch.from_numpy(m)); logits.append(torch.from_numpy(lg))
+    labels = [torch.from_numpy(r.integers(3, C - 1, n_inst[b])) for b in range(B)]
+    labels[1][2] = -100                        # one ignored target
+    seg = [torch.from_numpy((r.random((n_inst[b], seg_len[b])) < 0.2).astype(np.int64)) for b in range(B)]
+    return masks, logits, labels, seg

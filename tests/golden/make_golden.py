@@ -327,6 +327,34 @@ def run_misc_case(ref, name):
     save(name, out)
 
 
+def run_criterion_case(ref, name):
+    """F9: the reference's own HungarianMatcher + SetCriterion + InstSegLoss weighting (stage-1 settings,
+    configs/instseg_sceneverse.yaml:160-175) on synthetic predictions of 3 layers x 3 ragged scenes."""
+    tv = types.ModuleType("torchvision"); tv.__version__ = "0.15.0"
+    sys.modules.setdefault("torchvision", tv)
+    matcher_mod = importlib.import_module("modules.third_party.mask3d.matcher")
+    crit_mod = importlib.import_module("modules.third_party.mask3d.criterion")
+    masks, logits, labels, seg = synth.criterion_inputs()
+    masks = [m.requires_grad_(True) for m in masks]
+    logits = [l.requires_grad_(True) for l in logits]
+    matcher = matcher_mod.HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=2.0, num_points=-1, ignore_label=-100)
+    wd = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 2.0}
+    crit = crit_mod.SetCriterion(num_classes=20, matcher=matcher, weight_dict=wd, losses=["labels", "masks"],
+                                 num_points=-1, class_weights=-1, ignore_label=-100)
+    losses, indices = crit(masks, logits, labels, seg)
+    total = sum(v * wd["_".join(k.split("_")[:2])] for k, v in losses.items())    # instseg_loss.py:48-51
+    total.backward()
+    out = {"total": np.float64(total.item())}
+    for k, v in losses.items():
+        out["loss/" + k] = np.float64(v.item())
+    for b, (i, j) in enumerate(indices):
+        out[f"indices/{b}/q"] = i.numpy(); out[f"indices/{b}/t"] = j.numpy()
+    for l in range(len(masks)):
+        put(out, f"grad/mask/{l}", masks[l].grad, MAX_FULL)
+        put(out, f"grad/logits/{l}", torch.nan_to_num(logits[l].grad), MAX_GRAD)
+    save(name, out)
+
+
 T5_TINY = dict(vocab_size=128, d_model=64, d_kv=16, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=4,
                decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
 
@@ -406,6 +434,7 @@ def main():
     run_train_case(ref, "F7_adamw_c1", B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=["ground"],
                    spatial=False, structure="sequential", head_lr=3e-3)
     run_t5_case(ref, "F8_t5_head")
+    run_criterion_case(ref, "F9_set_criterion")
     run_train_case(ref, "F7_adamw_mask", B=2, Ns=96, Nq=12, d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask"],
                    spatial=True, structure="parallel", use_self_mask=False, foc=(0, 2), warmup_steps=0, total_steps=6)
 

@@ -1,0 +1,80 @@
+"""GPU: the HIP set criterion (pq3d_amd/losses.py: cost-matrix kernels + grouped fp32 MFMA GEMM, host LSA, losses as
+gathers of the cost entries, gradient kernels) against fixture F9 (reference classes) and the loss oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle as LO
+from pq3d_amd import synth
+from pq3d_amd.losses import HungarianMatcher, SetCriterion
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+W = dict(cost_class=2.0, cost_mask=5.0, cost_dice=2.0)
+WD = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 2.0}
+
+
+def make_criterion():
+    matcher = HungarianMatcher(num_points=-1, ignore_label=-100, **W)
+    return SetCriterion(num_classes=20, matcher=matcher, weight_dict=WD, losses=["labels", "masks"], num_points=-1,
+                        class_weights=-1, ignore_label=-100)
+
+
+def test_set_criterion_matches_reference_fixture():
+    z, _ = util.load_fixture("F9_set_criterion")
+    masks, logits, labels, seg = synth.criterion_inputs()
+    masks = [m.to(DEV).requires_grad_(True) for m in masks]
+    logits = [l.to(DEV).requires_grad_(True) for l in logits]
+    losses, idx = make_criterion()(masks, logits, labels, seg)
+    total = sum(v * WD["_".join(k.split("_")[:2])] for k, v in losses.items())
+    total.backward()
+    assert abs(total.item() - float(z["total"])) <= 2e-5 * abs(float(z["total"]))
+    assert sorted(losses) == sorted(k[5:] for k in z.files if k.startswith("loss/"))
+    for k, v in losses.items():
+        assert abs(v.item() - float(z["loss/" + k])) <= 1e-5 * max(1.0, abs(float(z["loss/" + k]))), k
+    for b, (i, j) in enumerate(idx):
+        assert np.array_equal(i.numpy(), z[f"indices/{b}/q"]) and np.array_equal(j.numpy(), z[f"indices/{b}/t"])
+    for l in range(len(masks)):
+        util.check_against(z, f"grad/mask/{l}", masks[l].grad, atol=1e-7, rtol=2e-4)
+        util.check_against(z, f"grad/logits/{l}", torch.nan_to_num(logits[l].grad), atol=1e-7, rtol=2e-4, cap=util.MAX_GRAD)
+
+
+@pytest.mark.parametrize("B,Ns,Nq,C,nl", [(2, 300, 100, 201, 2), (4, 1024, 200, 201, 3)])
+def test_set_criterion_matches_oracle_at_larger_sizes(B, Ns, Nq, C, nl):
+    """cost matrices, assignments, losses and gradients at decoder-like sizes (ragged scenes, more targets than the
+    block sizes of the kernels, Nq not a multiple of 64)."""
+    r = np.random.default_rng(B * 1000 + Ns)
+    seg_len = [Ns] + [int(x) for x in r.integers(Ns // 2, Ns, B - 1)]
+    n_inst = [int(x) for x in r.integers(3, min(Nq, 90), B)]
+    masks, logits, labels, seg = synth.criterion_inputs(seed=B + Ns, B=B, Ns=Ns, Nq=Nq, C=C, n_layers=nl, seg_len=seg_len,
+                                                        n_inst=n_inst)
+    crit = make_criterion()
+    crit.num_classes = C - 1
+    dm = [m.to(DEV).requires_grad_(True) for m in masks]
+    dl = [l.to(DEV).requires_grad_(True) for l in logits]
+    losses, idx = crit(dm, dl, labels, seg)
+    sum(v * WD["_".join(k.split("_")[:2])] for k, v in losses.items()).backward()
+    om = [m.clone().requires_grad_(True) for m in masks]
+    ol = [l.clone().requires_grad_(True) for l in logits]
+    olosses, oidx = LO.set_criterion(om, ol, labels, seg, num_classes=C - 1, **W)
+    LO.instseg_loss(olosses, **W)[0].backward()
+    for (i, j), (oi, oj) in zip(idx, oidx):
+        assert torch.equal(i, oi) and torch.equal(j, oj)
+    for k in olosses:
+        assert abs(losses[k].item() - olosses[k].item()) <= 2e-5 * max(1.0, abs(olosses[k].item())), k
+    for a, b in zip(dm + dl, om + ol):
+        ga, gb = torch.nan_to_num(a.grad.cpu()), torch.nan_to_num(b.grad)
+        assert float((ga - gb).abs().max()) <= 1e-6 + 2e-4 * float(gb.abs().max())
+
+
+def test_cost_matrix_entries_match_oracle():
+    from pq3d_amd import losses as HL
+    masks, logits, labels, seg = synth.criterion_inputs(seed=5, B=2, Ns=520, Nq=70, C=21, n_layers=1, seg_len=(520, 333),
+                                                        n_inst=(11, 40))
+    T, lab, seg_len, n_inst_dev, n_inst, t_sum = HL._targets_to_device(labels, seg, 520, DEV)
+    cost, lc = HL._layer_costs(masks[0].to(DEV), logits[0].to(DEV), T, lab, seg_len, n_inst_dev, t_sum, (2.0, 5.0, 2.0), -100)
+    for b in range(2):
+        ref = LO.cost_matrix(logits[0][b], masks[0][b], labels[b], seg[b], **W)
+        got = cost[b, :, :n_inst[b]].cpu()
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
