@@ -52,54 +52,47 @@ def _targets_to_device(instance_labels: Sequence[torch.Tensor], segment_masks: S
         torch.tensor(n_inst, dtype=torch.int32, device=device), n_inst, T.sum(-1)
 
 
-class _LayerCosts:
-    """Device buffers of one prediction layer kept for the loss / gradient stage."""
-    __slots__ = ("sig", "TS", "sig_sum", "cost_mask", "cost_dice")
-
-
-def _layer_costs(X, logits, T, labels, seg_len, n_inst_dev, t_sum, w, ignore_label):
+def _layer_costs(X, logits, T, labels, seg_len, n_inst_dev, t_sum, w, ignore_label, out=None):
+    """Cost matrices of one prediction layer for all scenes: out[0] = total, out[1] = mask (BCE) term, out[2] = dice term
+    ([3, B, Nq, Nt]).  Also returns what the gradient stage needs: sigma(X), T sigma(X), column sums of sigma(X)."""
     B, Ns, Nq = X.shape
     Nt, Ccls = T.shape[1], logits.shape[-1]
     dev = X.device
     nsplit = L.lib().pq3d_mask_cost_nsplit(Ns)
     sig = torch.empty_like(X)
-    sp_part = torch.empty(B, nsplit, Nq, dtype=torch.float32, device=dev)
-    sg_part = torch.empty_like(sp_part)
-    L.check(L.lib().pq3d_mask_cost_prep(L.ptr(X), L.ptr(seg_len), L.ptr(sig), L.ptr(sp_part), L.ptr(sg_part), B, Ns, Nq,
+    part = torch.empty(2, B, nsplit, Nq, dtype=torch.float32, device=dev)
+    L.check(L.lib().pq3d_mask_cost_prep(L.ptr(X), L.ptr(seg_len), L.ptr(sig), L.ptr(part[0]), L.ptr(part[1]), B, Ns, Nq,
                                         L.stream()), "pq3d_mask_cost_prep")
     TXS = torch.empty(2, B, Nt, Nq, dtype=torch.float32, device=dev)
     L.gemm(M=Nt, N=Nq, K=Ns, A=[T, T], B=[X, sig], Cs=[TXS[0], TXS[1]], ct=L.F32, lda=Ns, ldb=Nq, ldc=Nq, transB=True,
            batch=B, strideA=Nt * Ns, strideB=Ns * Nq, strideC=Nt * Nq)
-    cost = torch.empty(3, B, Nq, Nt, dtype=torch.float32, device=dev)
+    cost = out if out is not None else torch.empty(3, B, Nq, Nt, dtype=torch.float32, device=dev)
     d = L.MatchCostDesc()
     d.B, d.Nq, d.Nt, d.Ns, d.C, d.nsplit = B, Nq, Nt, Ns, Ccls, nsplit
     d.w_class, d.w_mask, d.w_dice, d.ignore_label = w[0], w[1], w[2], ignore_label
-    d.TX, d.TS, d.sp_part, d.sg_part, d.t_sum = map(L.ptr, (TXS[0], TXS[1], sp_part, sg_part, t_sum))
+    d.TX, d.TS, d.sp_part, d.sg_part, d.t_sum = map(L.ptr, (TXS[0], TXS[1], part[0], part[1], t_sum))
     d.seg_len, d.n_inst, d.cls_logits, d.labels = map(L.ptr, (seg_len, n_inst_dev, logits, labels))
     d.cost, d.cost_mask, d.cost_dice = L.ptr(cost[0]), L.ptr(cost[1]), L.ptr(cost[2])
     L.check(L.lib().pq3d_match_cost(C.byref(d), L.stream()), "pq3d_match_cost")
-    lc = _LayerCosts()
-    lc.sig, lc.TS, lc.sig_sum, lc.cost_mask, lc.cost_dice = sig, TXS[1], sg_part.sum(1), cost[1], cost[2]
-    return cost[0], lc
+    return cost, (sig, TXS[1], part[1].sum(1))
 
 
 class _SetCriterionFn(Function):
-    """(mask logits of every layer, class logits of every layer) -> losses [n_layers, 3] = (ce, mask, dice)."""
+    """(mask logits of every layer, class logits of every layer) -> losses [n_layers, 3] = (ce, mask, dice).
+    Everything that is not a kernel of ours is vectorised over layers (a handful of small index ops per step)."""
 
     @staticmethod
     def forward(ctx, crit, T, labels, seg_len, n_inst_dev, n_inst, t_sum, n_layers, *preds):
         masks = [p.contiguous().float() for p in preds[:n_layers]]
         logits = [p.contiguous().float() for p in preds[n_layers:]]
         B, Ns, Nq = masks[0].shape
-        Nt, dev = T.shape[1], T.device
+        Nt, dev, Ccls = T.shape[1], T.device, logits[0].shape[-1]
         m = crit.matcher
         w = (float(m.cost_class), float(m.cost_mask), float(m.cost_dice))
-        costs, lcs = [], []
-        for X, lg in zip(masks, logits):
-            c, lc = _layer_costs(X, lg, T, labels, seg_len, n_inst_dev, t_sum, w, m.ignore_label)
-            costs.append(c)
-            lcs.append(lc)
-        host = torch.stack(costs, 0).cpu().numpy()     # the ONE device->host copy of the step: [layers, B, Nq, Nt]
+        cost_all = torch.empty(n_layers, 3, B, Nq, Nt, dtype=torch.float32, device=dev)
+        keep = [_layer_costs(X, lg, T, labels, seg_len, n_inst_dev, t_sum, w, m.ignore_label, out=cost_all[l])[1]
+                for l, (X, lg) in enumerate(zip(masks, logits))]
+        host = cost_all[:, 0].cpu().numpy()            # the ONE device->host copy of the step: [layers, B, Nq, Nt]
         Nm = max(min(Nq, max(n_inst)), 1)
         q_idx = np.zeros((n_layers, B, Nm), dtype=np.int32)
         t_idx = np.zeros((n_layers, B, Nm), dtype=np.int32)
@@ -112,65 +105,59 @@ class _SetCriterionFn(Function):
                 q_idx[l, b, :len(i)], t_idx[l, b, :len(j)], n_match[l, b] = i, j, len(i)
                 per.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
             indices.append(per)
-        q_idx_d, t_idx_d = torch.from_numpy(q_idx).to(dev), torch.from_numpy(t_idx).to(dev)
-        n_match_d = torch.from_numpy(n_match).to(dev)
-        valid = (torch.arange(Nm, device=dev)[None, None, :] < n_match_d[:, :, None])          # [layers, B, Nm]
-        bidx = torch.arange(B, device=dev)[:, None].expand(B, Nm)
-        losses = torch.zeros(n_layers, 3, dtype=torch.float32, device=dev)
-        tgt_all, lse_all, cnt_all = [], [], []
+        packed = torch.from_numpy(np.concatenate([q_idx.reshape(-1), t_idx.reshape(-1), n_match.reshape(-1)])).to(dev)
+        nqt = n_layers * B * Nm
+        q_idx_d, t_idx_d = packed[:nqt].view(n_layers, B, Nm), packed[nqt:2 * nqt].view(n_layers, B, Nm)
+        n_match_d = packed[2 * nqt:].view(n_layers, B)
+        valid = torch.arange(Nm, device=dev)[None, None, :] < n_match_d[:, :, None]             # [layers, B, Nm]
+        lidx = torch.arange(n_layers, device=dev)[:, None, None].expand(n_layers, B, Nm)
+        bidx = torch.arange(B, device=dev)[None, :, None].expand(n_layers, B, Nm)
+        qi, ti = q_idx_d.long(), t_idx_d.long()
         nmf = n_match_d.float().clamp(min=1.0)
+        # matched-pair losses ARE the matched entries of the cost matrices (criterion.py:27-70 with num_points = -1)
+        pair = cost_all[:, 1:3][lidx, :, bidx, qi, ti] * valid[..., None]                        # [layers, B, Nm, 2]
+        losses = torch.zeros(n_layers, 3, dtype=torch.float32, device=dev)
+        losses[:, 1:3] = (pair.sum(2) / nmf[..., None]).mean(1)
+        # classification (criterion.py:136-163): unmatched queries -> the no-object class (= num_classes)
+        tgt = torch.full((n_layers, B, Nq), crit.num_classes, dtype=torch.int64, device=dev)
+        tgt[lidx[valid], bidx[valid], qi[valid]] = labels[bidx[valid], ti[valid]]
+        row_loss = torch.empty(n_layers, B * Nq, dtype=torch.float32, device=dev)
+        lse = torch.empty_like(row_loss)
         for l in range(n_layers):
-            qi, ti = q_idx_d[l].long(), t_idx_d[l].long()
-            # matched-pair losses ARE the matched entries of the cost matrices (criterion.py:27-70, num_points = -1)
-            cm = lcs[l].cost_mask[bidx, qi, ti] * valid[l]
-            cd = lcs[l].cost_dice[bidx, qi, ti] * valid[l]
-            losses[l, 1] = (cm.sum(1) / nmf[l]).mean()
-            losses[l, 2] = (cd.sum(1) / nmf[l]).mean()
-            # classification (criterion.py:136-163): unmatched queries -> no-object class (= num_classes)
-            tgt = torch.full((B, Nq), crit.num_classes, dtype=torch.int64, device=dev)
-            lab_m = labels[bidx, ti]
-            tgt[bidx[valid[l]], qi[valid[l]]] = lab_m[valid[l]]
-            Ccls = logits[l].shape[-1]
-            row_loss = torch.empty(B * Nq, dtype=torch.float32, device=dev)
-            lse = torch.empty_like(row_loss)
-            L.check(L.lib().pq3d_cross_entropy_fwd(L.ptr(logits[l]), L.ptr(tgt), B * Nq, Ccls, crit.ignore_label,
-                                                   L.ptr(row_loss), L.ptr(lse), L.stream()), "pq3d_cross_entropy_fwd")
-            cnt = (tgt != crit.ignore_label).sum().clamp(min=1).float()
-            losses[l, 0] = row_loss.sum() / cnt
-            tgt_all.append(tgt); lse_all.append(lse); cnt_all.append(cnt)
-        ctx.crit, ctx.n_layers, ctx.lcs = crit, n_layers, lcs
-        ctx.masks, ctx.logits, ctx.tgt, ctx.lse, ctx.cnt = masks, logits, tgt_all, lse_all, cnt_all
-        ctx.targets = (T, seg_len, t_sum, q_idx_d, t_idx_d, n_match_d, Nm)
+            L.check(L.lib().pq3d_cross_entropy_fwd(L.ptr(logits[l]), L.ptr(tgt[l]), B * Nq, Ccls, crit.ignore_label,
+                                                   L.ptr(row_loss[l]), L.ptr(lse[l]), L.stream()), "pq3d_cross_entropy_fwd")
+        cnt = (tgt != crit.ignore_label).sum((1, 2)).clamp(min=1).float()
+        losses[:, 0] = row_loss.sum(1) / cnt
+        ctx.crit, ctx.n_layers, ctx.keep = crit, n_layers, keep
+        ctx.masks, ctx.logits, ctx.tgt, ctx.lse, ctx.cnt = masks, logits, tgt, lse, cnt
+        ctx.targets = (T, seg_len, t_sum, q_idx_d.contiguous(), t_idx_d.contiguous(), n_match_d.contiguous(), nmf, Nm)
         ctx.in_dtypes = [p.dtype for p in preds]
-        ctx.indices = indices
         crit._last_indices = indices
         return losses
 
     @staticmethod
     def backward(ctx, g):
-        T, seg_len, t_sum, q_idx_d, t_idx_d, n_match_d, Nm = ctx.targets
+        T, seg_len, t_sum, q_idx_d, t_idx_d, n_match_d, nmf, Nm = ctx.targets
         n_layers = ctx.n_layers
         B, Ns, Nq = ctx.masks[0].shape
         Nt = T.shape[1]
         g = g.contiguous().float()
-        nmf = n_match_d.float().clamp(min=1.0)
+        gmd = (g[:, 1:3, None] / (nmf[:, None, :] * B)).contiguous()    # [layers, 2, B]; the 1/S_b is applied in-kernel
+        scale = (g[:, 0] / ctx.cnt).contiguous()                        # [layers]
         dmasks, dlogits = [], []
         for l in range(n_layers):
-            lc = ctx.lcs[l]
+            sig, TS, sig_sum = ctx.keep[l]
             dX = torch.empty_like(ctx.masks[l])
-            gm = (g[l, 1] / (nmf[l] * B)).contiguous()      # d loss_mask / d (sum_s bce)  (1/S_b inside the kernel)
-            gd = (g[l, 2] / (nmf[l] * B)).contiguous()
             d = L.MaskGradDesc()
             d.B, d.Ns, d.Nq, d.Nt, d.Nm = B, Ns, Nq, Nt, Nm
-            d.sig, d.T, d.TS, d.sig_sum, d.t_sum, d.seg_len = map(L.ptr, (lc.sig, T, lc.TS, lc.sig_sum, t_sum, seg_len))
-            qi, ti, nm = q_idx_d[l].contiguous(), t_idx_d[l].contiguous(), n_match_d[l].contiguous()
-            d.q_idx, d.t_idx, d.n_match, d.g_mask, d.g_dice, d.dX = map(L.ptr, (qi, ti, nm, gm, gd, dX))
+            d.sig, d.T, d.TS, d.sig_sum, d.t_sum, d.seg_len = map(L.ptr, (sig, T, TS, sig_sum, t_sum, seg_len))
+            d.q_idx, d.t_idx, d.n_match = L.ptr(q_idx_d[l]), L.ptr(t_idx_d[l]), L.ptr(n_match_d[l])
+            d.g_mask, d.g_dice, d.dX = L.ptr(gmd[l, 0]), L.ptr(gmd[l, 1]), L.ptr(dX)
             L.check(L.lib().pq3d_matched_mask_grad(C.byref(d), L.stream()), "pq3d_matched_mask_grad")
             dmasks.append(dX)
             dl = torch.empty_like(ctx.logits[l])
-            scale = (g[l, 0] / ctx.cnt[l]).reshape(1).contiguous()
             L.check(L.lib().pq3d_cross_entropy_bwd(L.ptr(ctx.logits[l]), L.ptr(ctx.tgt[l]), L.ptr(ctx.lse[l]), B * Nq,
-                                                   dl.shape[-1], ctx.crit.ignore_label, L.ptr(scale), L.ptr(dl),
+                                                   dl.shape[-1], ctx.crit.ignore_label, L.ptr(scale[l:l + 1]), L.ptr(dl),
                                                    L.stream()), "pq3d_cross_entropy_bwd")
             dlogits.append(dl)
         grads = [t.to(dt) for t, dt in zip(dmasks + dlogits, ctx.in_dtypes)]
