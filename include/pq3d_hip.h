@@ -348,49 +348,64 @@ int pq3d_adamw(float* p, const float* g, float* m, float* v, int64_t n, const pq
  *   losses              : sigmoid_ce_loss / dice_loss of a matched pair (criterion.py:27-70) ARE cost_mask / cost_dice at
  *                         that pair -> gathers; pq3d_matched_mask_grad writes d loss / d X (zero off the matched columns);
  *   pq3d_cross_entropy_fwd/bwd : loss_labels (criterion.py:136-163), F.cross_entropy with ignore_index, per-row
- *                         loss + logsumexp; dlogits = scale[0] * (softmax - onehot) on non-ignored rows.
+ *                         loss + logsumexp; dlogits = scale[layer] * (softmax - onehot) on non-ignored rows.
  * ------------------------------------------------------------------------------------------------ */
+/* All entry points below process `layers` (<= PQ3D_MAX_GROUPS) prediction layers of one step in ONE launch: the targets
+ * (T, t_sum, seg_len, n_inst, labels) are shared, per-layer inputs arrive as pointer arrays, per-layer intermediates
+ * are stacked along a leading `layers` dimension. */
 typedef struct {
-  int32_t B, Nq, Nt, Ns, C, nsplit;
+  int32_t layers, B, Ns, Nq, nsplit;
+  const float* X[PQ3D_MAX_GROUPS];   /* mask logits [B, Ns, Nq] of each layer */
+  const int32_t* seg_len;            /* [B] */
+  float* sig;                        /* [layers, B, Ns, Nq] */
+  float* sp_part;                    /* [layers, B, nsplit, Nq] */
+  float* sg_part;                    /* [layers, B, nsplit, Nq] */
+} pq3d_mask_prep_desc;
+typedef struct {
+  int32_t layers, B, Nq, Nt, Ns, C, nsplit;
   float w_class, w_mask, w_dice;
   int64_t ignore_label;
-  const float* TX;          /* [B, Nt, Nq] */
-  const float* TS;          /* [B, Nt, Nq] */
-  const float* sp_part;     /* [B, nsplit, Nq] */
-  const float* sg_part;     /* [B, nsplit, Nq] */
+  const float* TXS;         /* [layers, 2, B, Nt, Nq]: T X and T sigma(X) (pq3d_gemm outputs) */
+  const float* sp_part;     /* [layers, B, nsplit, Nq] */
+  const float* sg_part;     /* [layers, B, nsplit, Nq] */
   const float* t_sum;       /* [B, Nt] = sum_s T */
   const int32_t* seg_len;   /* [B] */
   const int32_t* n_inst;    /* [B] */
-  const float* cls_logits;  /* [B, Nq, C] (may hold -inf at filtered classes) */
+  const float* cls_logits[PQ3D_MAX_GROUPS];  /* [B, Nq, C] per layer (may hold -inf at filtered classes) */
   const int64_t* labels;    /* [B, Nt] */
-  float* cost;              /* [B, Nq, Nt]; entries t >= n_inst[b] are 0 */
-  float* cost_mask;
-  float* cost_dice;
+  float* cost;              /* [layers, 3, B, Nq, Nt]: total, mask term, dice term; entries t >= n_inst[b] are 0 */
 } pq3d_match_cost_desc;
 typedef struct {
-  int32_t B, Ns, Nq, Nt, Nm;   /* Nm = row length of q_idx / t_idx */
-  const float* sig;            /* [B, Ns, Nq] from pq3d_mask_cost_prep */
+  int32_t layers, B, Ns, Nq, Nt, Nm;   /* Nm = row length of q_idx / t_idx */
+  const float* sig;            /* [layers, B, Ns, Nq] from pq3d_mask_cost_prep */
   const float* T;              /* [B, Nt, Ns] */
-  const float* TS;             /* [B, Nt, Nq] */
-  const float* sig_sum;        /* [B, Nq] (sum of sg_part over splits) */
+  const float* TXS;            /* [layers, 2, B, Nt, Nq] */
+  const float* sig_sum;        /* [layers, B, Nq] (sg_part summed over splits) */
   const float* t_sum;          /* [B, Nt] */
   const int32_t* seg_len;      /* [B] */
-  const int32_t* q_idx;        /* [B, Nm] matched queries */
-  const int32_t* t_idx;        /* [B, Nm] matched targets */
-  const int32_t* n_match;      /* [B] */
-  const float* g_mask;         /* [B] upstream gradient x 1/(n_match_b * B) of the BCE term (the 1/S_b is applied inside) */
-  const float* g_dice;         /* [B] same for the dice term */
-  float* dX;                   /* [B, Ns, Nq], fully written */
+  const int32_t* q_idx;        /* [layers, B, Nm] matched queries */
+  const int32_t* t_idx;        /* [layers, B, Nm] matched targets */
+  const int32_t* n_match;      /* [layers, B] */
+  const float* g;              /* [layers, 2, B]: upstream gradient x 1/(n_match_b * B) of the BCE term and of the dice
+                                  term (the BCE term's 1/S_b is applied inside) */
+  float* dX[PQ3D_MAX_GROUPS];  /* [B, Ns, Nq] per layer, fully written */
 } pq3d_mask_grad_desc;
-int pq3d_mask_cost_prep(const float* X, const int32_t* seg_len, float* sig, float* sp_part, float* sg_part, int32_t B,
-                        int32_t Ns, int32_t Nq, void* stream);
+typedef struct {
+  int32_t layers, C;
+  int64_t R, ignore_index;
+  const float* logits[PQ3D_MAX_GROUPS];  /* [R, C] per layer */
+  const int64_t* target;                 /* [layers, R] */
+  float* row_loss;                       /* [layers, R] (forward) */
+  float* lse;                            /* [layers, R] written by forward, read by backward */
+  const float* scale;                    /* [layers] (backward) */
+  float* dlogits[PQ3D_MAX_GROUPS];       /* [R, C] per layer (backward) */
+} pq3d_ce_desc;
+int pq3d_mask_cost_prep(const pq3d_mask_prep_desc* d, void* stream);
 int32_t pq3d_mask_cost_nsplit(int32_t Ns);
 int pq3d_match_cost(const pq3d_match_cost_desc* d, void* stream);
 int pq3d_matched_mask_grad(const pq3d_mask_grad_desc* d, void* stream);
-int pq3d_cross_entropy_fwd(const float* logits, const int64_t* target, int64_t R, int32_t C, int64_t ignore_index,
-                           float* row_loss, float* lse, void* stream);
-int pq3d_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, int64_t R, int32_t C,
-                           int64_t ignore_index, const float* scale, float* dlogits, void* stream);
+int pq3d_cross_entropy_fwd(const pq3d_ce_desc* d, void* stream);
+int pq3d_cross_entropy_bwd(const pq3d_ce_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,20 +63,33 @@ SCHED = {"constant": 0, "warmup_cosine": 1, "warmup_exp": 2}
 SUMSQ_PARTIALS = 1024
 
 
+class MaskPrepDesc(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("B", C.c_int32), ("Ns", C.c_int32), ("Nq", C.c_int32), ("nsplit", C.c_int32),
+                ("X", C.c_void_p * MAXG), ("seg_len", C.c_void_p), ("sig", C.c_void_p), ("sp_part", C.c_void_p),
+                ("sg_part", C.c_void_p)]
+
+
 class MatchCostDesc(C.Structure):
-    _fields_ = [("B", C.c_int32), ("Nq", C.c_int32), ("Nt", C.c_int32), ("Ns", C.c_int32), ("C", C.c_int32),
-                ("nsplit", C.c_int32), ("w_class", C.c_float), ("w_mask", C.c_float), ("w_dice", C.c_float),
-                ("ignore_label", C.c_int64),
-                ("TX", C.c_void_p), ("TS", C.c_void_p), ("sp_part", C.c_void_p), ("sg_part", C.c_void_p),
-                ("t_sum", C.c_void_p), ("seg_len", C.c_void_p), ("n_inst", C.c_void_p), ("cls_logits", C.c_void_p),
-                ("labels", C.c_void_p), ("cost", C.c_void_p), ("cost_mask", C.c_void_p), ("cost_dice", C.c_void_p)]
+    _fields_ = [("layers", C.c_int32), ("B", C.c_int32), ("Nq", C.c_int32), ("Nt", C.c_int32), ("Ns", C.c_int32),
+                ("C", C.c_int32), ("nsplit", C.c_int32), ("w_class", C.c_float), ("w_mask", C.c_float),
+                ("w_dice", C.c_float), ("ignore_label", C.c_int64),
+                ("TXS", C.c_void_p), ("sp_part", C.c_void_p), ("sg_part", C.c_void_p), ("t_sum", C.c_void_p),
+                ("seg_len", C.c_void_p), ("n_inst", C.c_void_p), ("cls_logits", C.c_void_p * MAXG), ("labels", C.c_void_p),
+                ("cost", C.c_void_p)]
 
 
 class MaskGradDesc(C.Structure):
-    _fields_ = [("B", C.c_int32), ("Ns", C.c_int32), ("Nq", C.c_int32), ("Nt", C.c_int32), ("Nm", C.c_int32),
-                ("sig", C.c_void_p), ("T", C.c_void_p), ("TS", C.c_void_p), ("sig_sum", C.c_void_p), ("t_sum", C.c_void_p),
+    _fields_ = [("layers", C.c_int32), ("B", C.c_int32), ("Ns", C.c_int32), ("Nq", C.c_int32), ("Nt", C.c_int32),
+                ("Nm", C.c_int32),
+                ("sig", C.c_void_p), ("T", C.c_void_p), ("TXS", C.c_void_p), ("sig_sum", C.c_void_p), ("t_sum", C.c_void_p),
                 ("seg_len", C.c_void_p), ("q_idx", C.c_void_p), ("t_idx", C.c_void_p), ("n_match", C.c_void_p),
-                ("g_mask", C.c_void_p), ("g_dice", C.c_void_p), ("dX", C.c_void_p)]
+                ("g", C.c_void_p), ("dX", C.c_void_p * MAXG)]
+
+
+class CeDesc(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("C", C.c_int32), ("R", C.c_int64), ("ignore_index", C.c_int64),
+                ("logits", C.c_void_p * MAXG), ("target", C.c_void_p), ("row_loss", C.c_void_p), ("lse", C.c_void_p),
+                ("scale", C.c_void_p), ("dlogits", C.c_void_p * MAXG)]
 
 
 class GemmDesc(C.Structure):
@@ -166,14 +179,12 @@ _SIGS = {
     "pq3d_train_scalars": [C.POINTER(AdamWHp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "pq3d_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AdamWHp), C.POINTER(OptSegments),
                    C.c_void_p, C.c_void_p],
-    "pq3d_mask_cost_prep": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
-                            C.c_void_p],
+    "pq3d_mask_cost_prep": [C.POINTER(MaskPrepDesc), C.c_void_p],
     "pq3d_mask_cost_nsplit": [C.c_int32],
     "pq3d_match_cost": [C.POINTER(MatchCostDesc), C.c_void_p],
     "pq3d_matched_mask_grad": [C.POINTER(MaskGradDesc), C.c_void_p],
-    "pq3d_cross_entropy_fwd": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
-    "pq3d_cross_entropy_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p,
-                               C.c_void_p],
+    "pq3d_cross_entropy_fwd": [C.POINTER(CeDesc), C.c_void_p],
+    "pq3d_cross_entropy_bwd": [C.POINTER(CeDesc), C.c_void_p],
     "pq3d_dropout_mask": [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Dropout), C.c_void_p],
     "pq3d_dropout_apply": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout),
                            C.c_void_p],

@@ -15,17 +15,22 @@
 namespace {
 
 constexpr int PREP_ROWS = 256;   // segments per block of the prep kernel
+constexpr int GRAD_ROWS = 16;    // segments per block of the gradient kernel (LDS tile 2 x 16 x (Nq+1) floats)
 
 PQ_DEV float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 PQ_DEV float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
 // sig[b,s,q] = sigma(x) (0 for s >= len_b); partial column sums over this block's rows of softplus(x) and sigma(x)
-__global__ __launch_bounds__(256) void mask_cost_prep_kernel(const float* __restrict__ X, const int32_t* __restrict__ seg_len,
-                                                             float* __restrict__ sig, float* __restrict__ sp_part,
-                                                             float* __restrict__ sg_part, int Ns, int Nq, int nsplit) {
+__global__ __launch_bounds__(256) void mask_cost_prep_kernel(const pq3d_mask_prep_desc d) {
   __shared__ float red[2][4][64];
-  const int b = blockIdx.z, split = blockIdx.y, q = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-  const int len = min(seg_len[b], Ns);
+  const int Ns = d.Ns, Nq = d.Nq, nsplit = d.nsplit;
+  const int layer = blockIdx.z / d.B, bb = blockIdx.z % d.B;
+  const float* __restrict__ X = d.X[layer];
+  float* __restrict__ sig = d.sig + (long)layer * d.B * Ns * Nq;
+  float* __restrict__ sp_part = d.sp_part + (long)layer * d.B * nsplit * Nq;
+  float* __restrict__ sg_part = d.sg_part + (long)layer * d.B * nsplit * Nq;
+  const int b = bb, split = blockIdx.y, q = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int len = min(d.seg_len[b], Ns);
   const int s0 = split * PREP_ROWS, s1 = min(s0 + PREP_ROWS, Ns);
   float sp = 0.f, sg = 0.f;
   if (q < Nq) {
@@ -50,7 +55,26 @@ __global__ __launch_bounds__(256) void mask_cost_prep_kernel(const float* __rest
 }
 
 // one wave per (scene, query): class-probability row statistics, then the Nt costs of that query
-__global__ __launch_bounds__(64) void match_cost_kernel(const pq3d_match_cost_desc d) {
+__global__ __launch_bounds__(64) void match_cost_kernel(const pq3d_match_cost_desc dd) {
+  // per-layer views of the stacked buffers
+  struct {
+    int B, Nq, Nt, Ns, C, nsplit;
+    float w_class, w_mask, w_dice;
+    long ignore_label;
+    const float *TX, *TS, *sp_part, *sg_part, *t_sum, *cls_logits;
+    const int32_t *seg_len, *n_inst;
+    const int64_t* labels;
+    float *cost, *cost_mask, *cost_dice;
+  } d;
+  const int layer = blockIdx.z;
+  d.B = dd.B; d.Nq = dd.Nq; d.Nt = dd.Nt; d.Ns = dd.Ns; d.C = dd.C; d.nsplit = dd.nsplit;
+  d.w_class = dd.w_class; d.w_mask = dd.w_mask; d.w_dice = dd.w_dice; d.ignore_label = dd.ignore_label;
+  const long txs = (long)dd.B * dd.Nt * dd.Nq, prt = (long)dd.B * dd.nsplit * dd.Nq, cst = (long)dd.B * dd.Nq * dd.Nt;
+  d.TX = dd.TXS + (long)layer * 2 * txs; d.TS = d.TX + txs;
+  d.sp_part = dd.sp_part + (long)layer * prt; d.sg_part = dd.sg_part + (long)layer * prt;
+  d.t_sum = dd.t_sum; d.seg_len = dd.seg_len; d.n_inst = dd.n_inst; d.labels = dd.labels;
+  d.cls_logits = dd.cls_logits[layer];
+  d.cost = dd.cost + (long)layer * 3 * cst; d.cost_mask = d.cost + cst; d.cost_dice = d.cost + 2 * cst;
   const int q = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const float* lg = d.cls_logits + ((long)b * d.Nq + q) * d.C;
   float mx = -INFINITY;
@@ -81,16 +105,32 @@ __global__ __launch_bounds__(64) void match_cost_kernel(const pq3d_match_cost_de
 }
 
 // dX[b,s,q_j] = gm_b * (sigma - T)/S_b + gd_b * sigma(1-sigma) * (-(2 T D - (2 TS + 1)) / D^2),  D = sig_sum + t_sum + 1;
-// every other entry of dX is zero.  Block = (64-segment tile, scene): X / dX tiles go through LDS so that both the
+// every other entry of dX is zero.  Block = (16-segment tile, scene, layer): X / dX tiles go through LDS so that both the
 // [S, Nq]-major logits and the [Nt, S]-major targets are read and written coalesced.
-__global__ __launch_bounds__(256) void matched_mask_grad_kernel(const pq3d_mask_grad_desc d) {
-  extern __shared__ float lds[];   // [64][Nq + 1] sigma tile, then [64][Nq + 1] gradient tile
-  const int b = blockIdx.y, s0 = blockIdx.x * 64, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void matched_mask_grad_kernel(const pq3d_mask_grad_desc dd) {
+  extern __shared__ float lds[];   // [GRAD_ROWS][Nq + 1] sigma tile, then the same for the gradient tile
+  struct {
+    int B, Ns, Nq, Nt, Nm;
+    const float *sig, *T, *TS, *sig_sum, *t_sum, *g_mask, *g_dice;
+    const int32_t *seg_len, *q_idx, *t_idx, *n_match;
+    float* dX;
+  } d;
+  const int layer = blockIdx.z;
+  d.B = dd.B; d.Ns = dd.Ns; d.Nq = dd.Nq; d.Nt = dd.Nt; d.Nm = dd.Nm;
+  d.sig = dd.sig + (long)layer * dd.B * dd.Ns * dd.Nq;
+  d.T = dd.T; d.t_sum = dd.t_sum; d.seg_len = dd.seg_len;
+  d.TS = dd.TXS + ((long)layer * 2 + 1) * dd.B * dd.Nt * dd.Nq;
+  d.sig_sum = dd.sig_sum + (long)layer * dd.B * dd.Nq;
+  d.q_idx = dd.q_idx + (long)layer * dd.B * dd.Nm; d.t_idx = dd.t_idx + (long)layer * dd.B * dd.Nm;
+  d.n_match = dd.n_match + (long)layer * dd.B;
+  d.g_mask = dd.g + (long)layer * 2 * dd.B; d.g_dice = d.g_mask + dd.B;
+  d.dX = dd.dX[layer];
+  const int b = blockIdx.y, s0 = blockIdx.x * GRAD_ROWS, tid = threadIdx.x;
   const int ld = d.Nq + 1;
   float* sg_t = lds;
-  float* g_t = lds + 64 * ld;
+  float* g_t = lds + GRAD_ROWS * ld;
   const int len = min(d.seg_len[b], d.Ns);
-  for (int i = tid; i < 64 * d.Nq; i += 256) {
+  for (int i = tid; i < GRAD_ROWS * d.Nq; i += 256) {
     const int r = i / d.Nq, c = i % d.Nq;
     const int s = s0 + r;
     sg_t[r * ld + c] = s < d.Ns ? d.sig[((long)b * d.Ns + s) * d.Nq + c] : 0.f;
@@ -99,9 +139,9 @@ __global__ __launch_bounds__(256) void matched_mask_grad_kernel(const pq3d_mask_
   __syncthreads();
   const int nm = d.n_match[b];
   const float gm = d.g_mask[b] / (float)len, gd = d.g_dice[b];
-  const int sl = tid & 63, s = s0 + sl;
+  const int sl = tid % GRAD_ROWS, s = s0 + sl;
   if (s < len) {
-    for (int j = tid >> 6; j < nm; j += 4) {
+    for (int j = tid / GRAD_ROWS; j < nm; j += 256 / GRAD_ROWS) {
       const int q = d.q_idx[(long)b * d.Nm + j], t = d.t_idx[(long)b * d.Nm + j];
       const float sg = sg_t[sl * ld + q];
       const float tv = d.T[((long)b * d.Nt + t) * d.Ns + s];
@@ -111,16 +151,20 @@ __global__ __launch_bounds__(256) void matched_mask_grad_kernel(const pq3d_mask_
     }
   }
   __syncthreads();
-  for (int i = tid; i < 64 * d.Nq; i += 256) {
+  for (int i = tid; i < GRAD_ROWS * d.Nq; i += 256) {
     const int r = i / d.Nq, c = i % d.Nq;
     if (s0 + r < d.Ns) d.dX[((long)b * d.Ns + s0 + r) * d.Nq + c] = g_t[r * ld + c];
   }
 }
 
 // cross entropy over rows (F.cross_entropy(..., ignore_index)): one wave per row
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
-                                                    long R, int C, long ignore, float* __restrict__ row_loss,
-                                                    float* __restrict__ lse) {
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const pq3d_ce_desc d) {
+  const long R = d.R, ignore = d.ignore_index;
+  const int C = d.C, layer = blockIdx.y;
+  const float* __restrict__ logits = d.logits[layer];
+  const int64_t* __restrict__ target = d.target + (long)layer * R;
+  float* __restrict__ row_loss = d.row_loss + (long)layer * R;
+  float* __restrict__ lse = d.lse + (long)layer * R;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   const int lane = threadIdx.x & 63;
@@ -138,14 +182,18 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     row_loss[row] = t == ignore ? 0.f : l - x[t];
   }
 }
-__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
-                                                    const float* __restrict__ lse, long R, int C, long ignore,
-                                                    const float* __restrict__ scale, float* __restrict__ dlogits) {
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const pq3d_ce_desc d) {
+  const long R = d.R, ignore = d.ignore_index;
+  const int C = d.C, layer = blockIdx.y;
+  const float* __restrict__ logits = d.logits[layer];
+  const int64_t* __restrict__ target = d.target + (long)layer * R;
+  const float* __restrict__ lse = d.lse + (long)layer * R;
+  float* __restrict__ dlogits = d.dlogits[layer];
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   const int lane = threadIdx.x & 63;
   const long t = target[row];
-  const float sc = t == ignore ? 0.f : scale[0];
+  const float sc = t == ignore ? 0.f : d.scale[layer];
   const float l = lse[row];
   for (int c = lane; c < C; c += 64) {
     const float x = logits[row * C + c];
@@ -155,13 +203,21 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 
 }  // namespace
 
-extern "C" int pq3d_mask_cost_prep(const float* X, const int32_t* seg_len, float* sig, float* sp_part, float* sg_part,
-                                   int32_t B, int32_t Ns, int32_t Nq, void* stream) {
-  PQ_CHECK_ARG(X && seg_len && sig && sp_part && sg_part && B >= 0 && Ns >= 1 && Nq >= 1, "pq3d_mask_cost_prep: bad args");
-  if (B == 0) return 0;
-  const int nsplit = (Ns + PREP_ROWS - 1) / PREP_ROWS;
-  hipLaunchKernelGGL(mask_cost_prep_kernel, dim3((Nq + 63) / 64, nsplit, B), dim3(256), 0, (hipStream_t)stream, X, seg_len,
-                     sig, sp_part, sg_part, Ns, Nq, nsplit);
+static int check_layers(int layers, const char* who) {
+  if (layers < 1 || layers > PQ3D_MAX_GROUPS) { pq3d_set_error(who); return PQ3D_ERR_ARG; }
+  return 0;
+}
+
+extern "C" int pq3d_mask_cost_prep(const pq3d_mask_prep_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_mask_cost_prep: null descriptor");
+  const pq3d_mask_prep_desc d = *dp;
+  if (int e = check_layers(d.layers, "pq3d_mask_cost_prep: layers must be in [1, PQ3D_MAX_GROUPS]")) return e;
+  PQ_CHECK_ARG(d.seg_len && d.sig && d.sp_part && d.sg_part && d.B >= 0 && d.Ns >= 1 && d.Nq >= 1 &&
+               d.nsplit == (d.Ns + PREP_ROWS - 1) / PREP_ROWS, "pq3d_mask_cost_prep: bad args");
+  for (int l = 0; l < d.layers; ++l) PQ_CHECK_ARG(d.X[l] != nullptr, "pq3d_mask_cost_prep: null X");
+  if (d.B == 0) return 0;
+  hipLaunchKernelGGL(mask_cost_prep_kernel, dim3((d.Nq + 63) / 64, d.nsplit, d.layers * d.B), dim3(256), 0,
+                     (hipStream_t)stream, d);
   PQ_LAUNCH_CHECK();
   return 0;
 }
@@ -171,12 +227,14 @@ extern "C" int32_t pq3d_mask_cost_nsplit(int32_t Ns) { return (Ns + PREP_ROWS - 
 extern "C" int pq3d_match_cost(const pq3d_match_cost_desc* dp, void* stream) {
   PQ_CHECK_ARG(dp != nullptr, "pq3d_match_cost: null descriptor");
   const pq3d_match_cost_desc d = *dp;
-  PQ_CHECK_ARG(d.TX && d.TS && d.sp_part && d.sg_part && d.t_sum && d.seg_len && d.n_inst && d.cls_logits && d.labels &&
-               d.cost && d.cost_mask && d.cost_dice, "pq3d_match_cost: null pointer");
+  if (int e = check_layers(d.layers, "pq3d_match_cost: layers must be in [1, PQ3D_MAX_GROUPS]")) return e;
+  PQ_CHECK_ARG(d.TXS && d.sp_part && d.sg_part && d.t_sum && d.seg_len && d.n_inst && d.labels && d.cost,
+               "pq3d_match_cost: null pointer");
+  for (int l = 0; l < d.layers; ++l) PQ_CHECK_ARG(d.cls_logits[l] != nullptr, "pq3d_match_cost: null cls_logits");
   PQ_CHECK_ARG(d.B >= 0 && d.Nq >= 1 && d.Nt >= 1 && d.C >= 1 && d.Ns >= 1 && d.nsplit == (d.Ns + PREP_ROWS - 1) / PREP_ROWS,
                "pq3d_match_cost: bad sizes");
   if (d.B == 0) return 0;
-  hipLaunchKernelGGL(match_cost_kernel, dim3(d.Nq, d.B), dim3(64), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(match_cost_kernel, dim3(d.Nq, d.B, d.layers), dim3(64), 0, (hipStream_t)stream, d);
   PQ_LAUNCH_CHECK();
   return 0;
 }
@@ -184,37 +242,46 @@ extern "C" int pq3d_match_cost(const pq3d_match_cost_desc* dp, void* stream) {
 extern "C" int pq3d_matched_mask_grad(const pq3d_mask_grad_desc* dp, void* stream) {
   PQ_CHECK_ARG(dp != nullptr, "pq3d_matched_mask_grad: null descriptor");
   const pq3d_mask_grad_desc d = *dp;
-  PQ_CHECK_ARG(d.sig && d.T && d.TS && d.sig_sum && d.t_sum && d.seg_len && d.q_idx && d.t_idx && d.n_match && d.g_mask &&
-               d.g_dice && d.dX, "pq3d_matched_mask_grad: null pointer");
+  if (int e = check_layers(d.layers, "pq3d_matched_mask_grad: layers must be in [1, PQ3D_MAX_GROUPS]")) return e;
+  PQ_CHECK_ARG(d.sig && d.T && d.TXS && d.sig_sum && d.t_sum && d.seg_len && d.q_idx && d.t_idx && d.n_match && d.g,
+               "pq3d_matched_mask_grad: null pointer");
+  for (int l = 0; l < d.layers; ++l) PQ_CHECK_ARG(d.dX[l] != nullptr, "pq3d_matched_mask_grad: null dX");
   PQ_CHECK_ARG(d.B >= 0 && d.Ns >= 1 && d.Nq >= 1 && d.Nt >= 1 && d.Nm >= 1, "pq3d_matched_mask_grad: bad sizes");
-  const size_t lds = (size_t)2 * 64 * (d.Nq + 1) * sizeof(float);
-  PQ_CHECK_ARG(lds <= 160 * 1024, "pq3d_matched_mask_grad: Nq too large for the LDS tile (<= 319)");
+  const size_t lds = (size_t)2 * GRAD_ROWS * (d.Nq + 1) * sizeof(float);
+  PQ_CHECK_ARG(lds <= 160 * 1024, "pq3d_matched_mask_grad: Nq too large for the LDS tile");
   if (d.B == 0) return 0;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)matched_mask_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(matched_mask_grad_kernel, dim3((d.Ns + 63) / 64, d.B), dim3(256), lds, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(matched_mask_grad_kernel, dim3((d.Ns + GRAD_ROWS - 1) / GRAD_ROWS, d.B, d.layers), dim3(256), lds, (hipStream_t)stream, d);
   PQ_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int pq3d_cross_entropy_fwd(const float* logits, const int64_t* target, int64_t R, int32_t C, int64_t ignore_index,
-                                      float* row_loss, float* lse, void* stream) {
-  PQ_CHECK_ARG(logits && target && row_loss && lse && R >= 0 && C >= 1, "pq3d_cross_entropy_fwd: bad args");
-  if (R == 0) return 0;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, target, (long)R,
-                     C, (long)ignore_index, row_loss, lse);
+static int check_ce(const pq3d_ce_desc& d, bool bwd) {
+  if (int e = check_layers(d.layers, "pq3d_cross_entropy: layers must be in [1, PQ3D_MAX_GROUPS]")) return e;
+  PQ_CHECK_ARG(d.target && d.lse && d.R >= 0 && d.C >= 1, "pq3d_cross_entropy: bad args");
+  PQ_CHECK_ARG(bwd ? d.scale != nullptr : d.row_loss != nullptr, "pq3d_cross_entropy: null row_loss / scale");
+  for (int l = 0; l < d.layers; ++l)
+    PQ_CHECK_ARG(d.logits[l] && (!bwd || d.dlogits[l]), "pq3d_cross_entropy: null logits / dlogits");
+  return 0;
+}
+extern "C" int pq3d_cross_entropy_fwd(const pq3d_ce_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_cross_entropy_fwd: null descriptor");
+  const pq3d_ce_desc d = *dp;
+  if (int e = check_ce(d, false)) return e;
+  if (d.R == 0) return 0;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)((d.R + 3) / 4), d.layers), dim3(256), 0, (hipStream_t)stream, d);
   PQ_LAUNCH_CHECK();
   return 0;
 }
-
-extern "C" int pq3d_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, int64_t R, int32_t C,
-                                      int64_t ignore_index, const float* scale, float* dlogits, void* stream) {
-  PQ_CHECK_ARG(logits && target && lse && scale && dlogits && R >= 0 && C >= 1, "pq3d_cross_entropy_bwd: bad args");
-  if (R == 0) return 0;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, target, lse,
-                     (long)R, C, (long)ignore_index, scale, dlogits);
+extern "C" int pq3d_cross_entropy_bwd(const pq3d_ce_desc* dp, void* stream) {
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_cross_entropy_bwd: null descriptor");
+  const pq3d_ce_desc d = *dp;
+  if (int e = check_ce(d, true)) return e;
+  if (d.R == 0) return 0;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((d.R + 3) / 4), d.layers), dim3(256), 0, (hipStream_t)stream, d);
   PQ_LAUNCH_CHECK();
   return 0;
 }

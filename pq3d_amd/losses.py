@@ -4,10 +4,10 @@
 num_points = -1, class_weights = -1).
 
 Where the reference loops over scenes and layers with a dozen torch ops each ((L n_b + 1) x B cost matrices per step,
-each followed by a device->host copy), this runs, per prediction layer, three launches for the cost matrices of ALL
-scenes (include/pq3d_hip.h: prep, one grouped fp32 MFMA GEMM, cost), ONE device->host copy for all layers, the
-assignments on the host (scipy, as the reference), then the losses as gathers of the already computed cost entries
-plus one gradient kernel per layer.  No CPU fallback for the device part."""
+each followed by a device->host copy), this runs three launches for the cost matrices of ALL layers and scenes
+(include/pq3d_hip.h: prep, one grouped + batched fp32 MFMA GEMM, cost), ONE device->host copy, the assignments on
+the host (scipy, as the reference), then the losses as gathers of the already computed cost entries plus one
+gradient launch and two cross-entropy launches.  No CPU fallback for the device part."""
 from __future__ import annotations
 
 import ctypes as C
@@ -52,46 +52,55 @@ def _targets_to_device(instance_labels: Sequence[torch.Tensor], segment_masks: S
         torch.tensor(n_inst, dtype=torch.int32, device=device), n_inst, T.sum(-1)
 
 
-def _layer_costs(X, logits, T, labels, seg_len, n_inst_dev, t_sum, w, ignore_label, out=None):
-    """Cost matrices of one prediction layer for all scenes: out[0] = total, out[1] = mask (BCE) term, out[2] = dice term
-    ([3, B, Nq, Nt]).  Also returns what the gradient stage needs: sigma(X), T sigma(X), column sums of sigma(X)."""
-    B, Ns, Nq = X.shape
-    Nt, Ccls = T.shape[1], logits.shape[-1]
-    dev = X.device
+def _costs(masks, logits, T, labels, seg_len, n_inst_dev, t_sum, w, ignore_label):
+    """Cost matrices of ALL prediction layers and scenes in three launches: cost[l] = (total, mask term, dice term)
+    [layers, 3, B, Nq, Nt].  Also returns what the gradient stage needs: sigma(X), (T X | T sigma(X)), sum_s sigma."""
+    n_layers = len(masks)
+    B, Ns, Nq = masks[0].shape
+    Nt, Ccls = T.shape[1], logits[0].shape[-1]
+    dev = T.device
+    assert n_layers <= L.MAXG // 2, "too many prediction layers for one grouped launch"
     nsplit = L.lib().pq3d_mask_cost_nsplit(Ns)
-    sig = torch.empty_like(X)
-    part = torch.empty(2, B, nsplit, Nq, dtype=torch.float32, device=dev)
-    L.check(L.lib().pq3d_mask_cost_prep(L.ptr(X), L.ptr(seg_len), L.ptr(sig), L.ptr(part[0]), L.ptr(part[1]), B, Ns, Nq,
-                                        L.stream()), "pq3d_mask_cost_prep")
-    TXS = torch.empty(2, B, Nt, Nq, dtype=torch.float32, device=dev)
-    L.gemm(M=Nt, N=Nq, K=Ns, A=[T, T], B=[X, sig], Cs=[TXS[0], TXS[1]], ct=L.F32, lda=Ns, ldb=Nq, ldc=Nq, transB=True,
+    sig = torch.empty(n_layers, B, Ns, Nq, dtype=torch.float32, device=dev)
+    part = torch.empty(2, n_layers, B, nsplit, Nq, dtype=torch.float32, device=dev)
+    p = L.MaskPrepDesc()
+    p.layers, p.B, p.Ns, p.Nq, p.nsplit = n_layers, B, Ns, Nq, nsplit
+    for l in range(n_layers):
+        p.X[l] = L.ptr(masks[l])
+    p.seg_len, p.sig, p.sp_part, p.sg_part = L.ptr(seg_len), L.ptr(sig), L.ptr(part[0]), L.ptr(part[1])
+    L.check(L.lib().pq3d_mask_cost_prep(C.byref(p), L.stream()), "pq3d_mask_cost_prep")
+    # ONE grouped + batched exact-f32 MFMA GEMM: groups = (layer, X | sigma(X)), batch = scenes
+    TXS = torch.empty(n_layers, 2, B, Nt, Nq, dtype=torch.float32, device=dev)
+    Bops = [t for l in range(n_layers) for t in (masks[l], sig[l])]
+    Cs = [TXS[l, k] for l in range(n_layers) for k in (0, 1)]
+    L.gemm(M=Nt, N=Nq, K=Ns, A=[T] * (2 * n_layers), B=Bops, Cs=Cs, ct=L.F32, lda=Ns, ldb=Nq, ldc=Nq, transB=True,
            batch=B, strideA=Nt * Ns, strideB=Ns * Nq, strideC=Nt * Nq)
-    cost = out if out is not None else torch.empty(3, B, Nq, Nt, dtype=torch.float32, device=dev)
+    cost = torch.empty(n_layers, 3, B, Nq, Nt, dtype=torch.float32, device=dev)
     d = L.MatchCostDesc()
-    d.B, d.Nq, d.Nt, d.Ns, d.C, d.nsplit = B, Nq, Nt, Ns, Ccls, nsplit
+    d.layers, d.B, d.Nq, d.Nt, d.Ns, d.C, d.nsplit = n_layers, B, Nq, Nt, Ns, Ccls, nsplit
     d.w_class, d.w_mask, d.w_dice, d.ignore_label = w[0], w[1], w[2], ignore_label
-    d.TX, d.TS, d.sp_part, d.sg_part, d.t_sum = map(L.ptr, (TXS[0], TXS[1], part[0], part[1], t_sum))
-    d.seg_len, d.n_inst, d.cls_logits, d.labels = map(L.ptr, (seg_len, n_inst_dev, logits, labels))
-    d.cost, d.cost_mask, d.cost_dice = L.ptr(cost[0]), L.ptr(cost[1]), L.ptr(cost[2])
+    d.TXS, d.sp_part, d.sg_part, d.t_sum = map(L.ptr, (TXS, part[0], part[1], t_sum))
+    d.seg_len, d.n_inst, d.labels, d.cost = map(L.ptr, (seg_len, n_inst_dev, labels, cost))
+    for l in range(n_layers):
+        d.cls_logits[l] = L.ptr(logits[l])
     L.check(L.lib().pq3d_match_cost(C.byref(d), L.stream()), "pq3d_match_cost")
-    return cost, (sig, TXS[1], part[1].sum(1))
+    return cost, (sig, TXS, part[1].sum(2))
 
 
 class _SetCriterionFn(Function):
     """(mask logits of every layer, class logits of every layer) -> losses [n_layers, 3] = (ce, mask, dice).
-    Everything that is not a kernel of ours is vectorised over layers (a handful of small index ops per step)."""
+    Six kernel launches per step (prep, GEMM, cost, CE forward | mask gradient, CE backward) + a handful of small
+    index ops vectorised over layers."""
 
     @staticmethod
     def forward(ctx, crit, T, labels, seg_len, n_inst_dev, n_inst, t_sum, n_layers, *preds):
         masks = [p.contiguous().float() for p in preds[:n_layers]]
         logits = [p.contiguous().float() for p in preds[n_layers:]]
         B, Ns, Nq = masks[0].shape
-        Nt, dev, Ccls = T.shape[1], T.device, logits[0].shape[-1]
+        dev, Ccls = T.device, logits[0].shape[-1]
         m = crit.matcher
         w = (float(m.cost_class), float(m.cost_mask), float(m.cost_dice))
-        cost_all = torch.empty(n_layers, 3, B, Nq, Nt, dtype=torch.float32, device=dev)
-        keep = [_layer_costs(X, lg, T, labels, seg_len, n_inst_dev, t_sum, w, m.ignore_label, out=cost_all[l])[1]
-                for l, (X, lg) in enumerate(zip(masks, logits))]
+        cost_all, keep = _costs(masks, logits, T, labels, seg_len, n_inst_dev, t_sum, w, m.ignore_label)
         host = cost_all[:, 0].cpu().numpy()            # the ONE device->host copy of the step: [layers, B, Nq, Nt]
         Nm = max(min(Nq, max(n_inst)), 1)
         q_idx = np.zeros((n_layers, B, Nm), dtype=np.int32)
@@ -123,9 +132,12 @@ class _SetCriterionFn(Function):
         tgt[lidx[valid], bidx[valid], qi[valid]] = labels[bidx[valid], ti[valid]]
         row_loss = torch.empty(n_layers, B * Nq, dtype=torch.float32, device=dev)
         lse = torch.empty_like(row_loss)
+        ce = L.CeDesc()
+        ce.layers, ce.C, ce.R, ce.ignore_index = n_layers, Ccls, B * Nq, crit.ignore_label
         for l in range(n_layers):
-            L.check(L.lib().pq3d_cross_entropy_fwd(L.ptr(logits[l]), L.ptr(tgt[l]), B * Nq, Ccls, crit.ignore_label,
-                                                   L.ptr(row_loss[l]), L.ptr(lse[l]), L.stream()), "pq3d_cross_entropy_fwd")
+            ce.logits[l] = L.ptr(logits[l])
+        ce.target, ce.row_loss, ce.lse = L.ptr(tgt), L.ptr(row_loss), L.ptr(lse)
+        L.check(L.lib().pq3d_cross_entropy_fwd(C.byref(ce), L.stream()), "pq3d_cross_entropy_fwd")
         cnt = (tgt != crit.ignore_label).sum((1, 2)).clamp(min=1).float()
         losses[:, 0] = row_loss.sum(1) / cnt
         ctx.crit, ctx.n_layers, ctx.keep = crit, n_layers, keep
@@ -141,25 +153,25 @@ class _SetCriterionFn(Function):
         n_layers = ctx.n_layers
         B, Ns, Nq = ctx.masks[0].shape
         Nt = T.shape[1]
+        sig, TXS, sig_sum = ctx.keep
         g = g.contiguous().float()
         gmd = (g[:, 1:3, None] / (nmf[:, None, :] * B)).contiguous()    # [layers, 2, B]; the 1/S_b is applied in-kernel
         scale = (g[:, 0] / ctx.cnt).contiguous()                        # [layers]
-        dmasks, dlogits = [], []
+        dmasks = [torch.empty_like(m) for m in ctx.masks]
+        dlogits = [torch.empty_like(t) for t in ctx.logits]
+        d = L.MaskGradDesc()
+        d.layers, d.B, d.Ns, d.Nq, d.Nt, d.Nm = n_layers, B, Ns, Nq, Nt, Nm
+        d.sig, d.T, d.TXS, d.sig_sum, d.t_sum, d.seg_len = map(L.ptr, (sig, T, TXS, sig_sum.contiguous(), t_sum, seg_len))
+        d.q_idx, d.t_idx, d.n_match, d.g = map(L.ptr, (q_idx_d, t_idx_d, n_match_d, gmd))
         for l in range(n_layers):
-            sig, TS, sig_sum = ctx.keep[l]
-            dX = torch.empty_like(ctx.masks[l])
-            d = L.MaskGradDesc()
-            d.B, d.Ns, d.Nq, d.Nt, d.Nm = B, Ns, Nq, Nt, Nm
-            d.sig, d.T, d.TS, d.sig_sum, d.t_sum, d.seg_len = map(L.ptr, (sig, T, TS, sig_sum, t_sum, seg_len))
-            d.q_idx, d.t_idx, d.n_match = L.ptr(q_idx_d[l]), L.ptr(t_idx_d[l]), L.ptr(n_match_d[l])
-            d.g_mask, d.g_dice, d.dX = L.ptr(gmd[l, 0]), L.ptr(gmd[l, 1]), L.ptr(dX)
-            L.check(L.lib().pq3d_matched_mask_grad(C.byref(d), L.stream()), "pq3d_matched_mask_grad")
-            dmasks.append(dX)
-            dl = torch.empty_like(ctx.logits[l])
-            L.check(L.lib().pq3d_cross_entropy_bwd(L.ptr(ctx.logits[l]), L.ptr(ctx.tgt[l]), L.ptr(ctx.lse[l]), B * Nq,
-                                                   dl.shape[-1], ctx.crit.ignore_label, L.ptr(scale[l:l + 1]), L.ptr(dl),
-                                                   L.stream()), "pq3d_cross_entropy_bwd")
-            dlogits.append(dl)
+            d.dX[l] = L.ptr(dmasks[l])
+        L.check(L.lib().pq3d_matched_mask_grad(C.byref(d), L.stream()), "pq3d_matched_mask_grad")
+        ce = L.CeDesc()
+        ce.layers, ce.C, ce.R, ce.ignore_index = n_layers, dlogits[0].shape[-1], B * Nq, ctx.crit.ignore_label
+        for l in range(n_layers):
+            ce.logits[l], ce.dlogits[l] = L.ptr(ctx.logits[l]), L.ptr(dlogits[l])
+        ce.target, ce.lse, ce.scale = L.ptr(ctx.tgt), L.ptr(ctx.lse), L.ptr(scale)
+        L.check(L.lib().pq3d_cross_entropy_bwd(C.byref(ce), L.stream()), "pq3d_cross_entropy_bwd")
         grads = [t.to(dt) for t, dt in zip(dmasks + dlogits, ctx.in_dtypes)]
         return (None,) * 8 + tuple(grads)
 

@@ -73,8 +73,8 @@ def test_cost_matrix_entries_match_oracle():
     masks, logits, labels, seg = synth.criterion_inputs(seed=5, B=2, Ns=520, Nq=70, C=21, n_layers=1, seg_len=(520, 333),
                                                         n_inst=(11, 40))
     T, lab, seg_len, n_inst_dev, n_inst, t_sum = HL._targets_to_device(labels, seg, 520, DEV)
-    cost, _ = HL._layer_costs(masks[0].to(DEV), logits[0].to(DEV), T, lab, seg_len, n_inst_dev, t_sum, (2.0, 5.0, 2.0), -100)
+    cost, _ = HL._costs([masks[0].to(DEV)], [logits[0].to(DEV)], T, lab, seg_len, n_inst_dev, t_sum, (2.0, 5.0, 2.0), -100)
     for b in range(2):
         ref = LO.cost_matrix(logits[0][b], masks[0][b], labels[b], seg[b], **W)
-        got = cost[0, b, :, :n_inst[b]].cpu()
+        got = cost[0, 0, b, :, :n_inst[b]].cpu()
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
