@@ -228,28 +228,33 @@ struct MaskBias {
   uint32_t mw[4];     // byte r of mw[t] != 0  -> key (t, r) masked for this lane's query
   float bb[4][4];     // additive bias
 };
-PQ_DEV void fetch_mask_bias(MaskBias& mb, const pq3d_attn_desc& d, const uint8_t* kpm_s, int b, int bm, int h, int myq,
-                            bool qvalid, bool ro, int k0, int lg) {
+// The 3-D mask words of one key block for this lane's query (4 x 4 key bytes).  Issued by the pipeline's load stage two
+// to three tiles ahead of their use: as dependent loads inside the compute stage they cost +38 % (forward) / +63 %
+// (backward) at config-4 shapes (tools/probes/attn_mask_cost_probe.py).  Caller guarantees d.mask != nullptr.
+PQ_DEV void load_mask_words(uint32_t (&w)[4], const pq3d_attn_desc& d, int bm, int myq, int k0, int lg) {
+  const uint8_t* mr = d.mask + ((long)bm * d.Lq + min(myq, d.Lq - 1)) * d.Lk;
+  const bool vec = (d.Lk & 3) == 0 && ((((uintptr_t)d.mask) & 3) == 0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int gk0 = k0 + t * 16 + 4 * lg;
+    if (vec) {
+      w[t] = *(const uint32_t*)(mr + min(gk0, d.Lk - 4));
+    } else {
+      w[t] = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[t] |= (uint32_t)mr[min(gk0 + r, d.Lk - 1)] << (8 * r);
+    }
+  }
+}
+template <bool MASK3>
+PQ_DEV void fetch_mask_bias(MaskBias& mb, const pq3d_attn_desc& d, const uint8_t* kpm_s, const uint32_t (&mwords)[4],
+                            int b, int h, int myq, bool qvalid, bool ro, int k0, int lg) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) mb.mw[t] = *(const uint32_t*)&kpm_s[t * 16 + 4 * lg];
-  if (d.mask) {
+  if constexpr (MASK3) {
     const bool use = qvalid && !ro;
-    const uint8_t* mr = d.mask + ((long)bm * d.Lq + min(myq, d.Lq - 1)) * d.Lk;
-    const bool vec = (d.Lk & 3) == 0 && ((((uintptr_t)d.mask) & 3) == 0);
-    uint32_t w[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int gk0 = k0 + t * 16 + 4 * lg;
-      if (vec) {
-        w[t] = *(const uint32_t*)(mr + min(gk0, d.Lk - 4));
-      } else {
-        w[t] = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[t] |= (uint32_t)mr[min(gk0 + r, d.Lk - 1)] << (8 * r);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) mb.mw[t] |= use ? w[t] : 0u;   // keys >= Lk are already masked through kpm_s
+    for (int t = 0; t < 4; ++t) mb.mw[t] |= use ? mwords[t] : 0u;   // keys >= Lk are already masked through kpm_s
   }
   if (d.bias) {
     const float* br = d.bias + (((long)b * d.H + h) * d.Lq + min(myq, d.Lq - 1)) * d.Lk;
@@ -266,7 +271,7 @@ PQ_DEV void fetch_mask_bias(MaskBias& mb, const pq3d_attn_desc& d, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename CT, int DH, int NW, bool DROP>
+template <typename CT, int DH, int NW, bool DROP, bool MASK3>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;  // bf16: row-major V + transposing reads; f32: transposed LDS copy
@@ -318,12 +323,20 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
 
   TileRegs<CT, DH, KB, nthreads> kr[2], vr[2];
   uint8_t kpm_r[2] = {1, 1};
+  // 3-D mask words in flight (per register set); those of the tiles sitting in the two LDS buffers are parked in LDS
+  // too (each lane reads back exactly what it wrote).  MASK3 is a template parameter so that launches without a 3-D
+  // mask keep their register / LDS budget (occupancy).
+  uint32_t mask_r[MASK3 ? 2 : 1][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { mask_r[0][t] = 0; if constexpr (MASK3) mask_r[1][t] = 0; }
+  __shared__ uint32_t mask_lds[MASK3 ? 2 * 4 * nthreads : 1];
   auto load = [&](int t, auto set) {
     constexpr int S = decltype(set)::value;
     const int k0 = kblock(t) * KB;
     kr[S].load(d.k, koff, d.k_sl, k0, d.Lk, tid);
     vr[S].load(d.v, voff, d.v_sl, k0, d.Lk, tid);
     if (tid < KB) kpm_r[S] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+    if constexpr (MASK3) load_mask_words(mask_r[S], d, bm, myq, k0, lg);
   };
   auto store = [&](auto set, auto buf) {
     constexpr int S = decltype(set)::value, Bf = decltype(buf)::value;
@@ -331,6 +344,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
     if (TRR) vr[S].store(Vbuf + Bf * VSZ, nullptr, 0, tid);
     else vr[S].store(nullptr, Vbuf + Bf * VSZ, A::LDT, tid);
     if (tid < KB) kpm_buf[Bf * KB + tid] = kpm_r[S];
+    if constexpr (MASK3) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mask_lds[(Bf * 4 + t) * nthreads + tid] = mask_r[S][t];
+    }
   };
   auto compute = [&](int t, auto buf) {
     constexpr int Bf = decltype(buf)::value;
@@ -341,7 +358,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
     float p[4][4];
     float mx = -INFINITY;
     MaskBias mb;
-    fetch_mask_bias(mb, d, kpm_buf + Bf * KB, b, bm, h, myq, qvalid, ro, k0, lg);
+    uint32_t mwords[4] = {0, 0, 0, 0};
+    if constexpr (MASK3) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mwords[t] = mask_lds[(Bf * 4 + t) * nthreads + tid];
+    }
+    fetch_mask_bias<MASK3>(mb, d, kpm_buf + Bf * KB, mwords, b, h, myq, qvalid, ro, k0, lg);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
       f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -473,7 +495,7 @@ __global__ void attn_delta_kernel(const pq3d_attn_desc d) {
 }
 
 // ------------------------------------------------------------------------------------------------ dQ (+ dbias)
-template <typename CT, int DH, int NW, bool DROP>
+template <typename CT, int DH, int NW, bool DROP, bool MASK3>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
@@ -546,18 +568,30 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
 
   TileRegs<CT, DH, KB, nthreads> kr[2], vr[2];
   uint8_t kpm_r[2] = {1, 1};
+  // 3-D mask words in flight (per register set); those of the tiles sitting in the two LDS buffers are parked in LDS
+  // too (each lane reads back exactly what it wrote).  MASK3 is a template parameter so that launches without a 3-D
+  // mask keep their register / LDS budget (occupancy).
+  uint32_t mask_r[MASK3 ? 2 : 1][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { mask_r[0][t] = 0; if constexpr (MASK3) mask_r[1][t] = 0; }
+  __shared__ uint32_t mask_lds[MASK3 ? 2 * 4 * nthreads : 1];
   auto load = [&](int t, auto set) {
     constexpr int S = decltype(set)::value;
     const int k0 = kblock(t) * KB;
     kr[S].load(d.k, koff, d.k_sl, k0, d.Lk, tid);
     vr[S].load(d.v, voff, d.v_sl, k0, d.Lk, tid);
     if (tid < KB) kpm_r[S] = (k0 + tid < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + k0 + tid] : 0) : 1;
+    if constexpr (MASK3) load_mask_words(mask_r[S], d, bm, myq, k0, lg);
   };
   auto store = [&](auto set, auto buf) {
     constexpr int S = decltype(set)::value, Bf = decltype(buf)::value;
     kr[S].store(Kbuf + Bf * KSZ, TRR ? nullptr : Ktbuf + Bf * TSZ, A::LDT, tid);
     vr[S].store(Vbuf + Bf * KSZ, nullptr, 0, tid);
     if (tid < KB) kpm_buf[Bf * KB + tid] = kpm_r[S];
+    if constexpr (MASK3) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mask_lds[(Bf * 4 + t) * nthreads + tid] = mask_r[S][t];
+    }
   };
   auto compute = [&](int t, auto buf) {
     constexpr int Bf = decltype(buf)::value;
@@ -568,7 +602,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
     const int k0 = kblock(t) * KB;
     float ds[4][4];
     MaskBias mb;
-    fetch_mask_bias(mb, d, kpm_buf + Bf * KB, b, bm, h, myq, qvalid, ro, k0, lg);
+    uint32_t mwords[4] = {0, 0, 0, 0};
+    if constexpr (MASK3) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mwords[t] = mask_lds[(Bf * 4 + t) * nthreads + tid];
+    }
+    fetch_mask_bias<MASK3>(mb, d, kpm_buf + Bf * KB, mwords, b, h, myq, qvalid, ro, k0, lg);
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
       f32x4 sc = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -656,7 +695,7 @@ __global__ void attn_dq_combine_kernel(const pq3d_attn_desc d) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <typename CT, int DH, bool DROP>
+template <typename CT, int DH, bool DROP, bool MASK3>
 __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
@@ -667,6 +706,8 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   __shared__ __attribute__((aligned(16))) CT dOtbuf[2 * TSZ];
   __shared__ float Lbuf[2 * QB], Dbuf[2 * QB];
   __shared__ uint8_t robuf[2 * QB];
+  constexpr int MLD = NWK * 16 + 8;   // padded row of the staged 3-D mask tile [QB queries][64 keys] (bytes)
+  __shared__ __attribute__((aligned(8))) uint8_t mbuf[MASK3 ? 2 * QB * MLD : 8];
   constexpr int nthreads = NWK * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -712,11 +753,29 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   TileRegs<CT, DH, QB, nthreads> qr[2], dor[2];
   float l_r[2] = {INFINITY, INFINITY}, d_r[2] = {0.f, 0.f};
   uint8_t ro_r[2] = {0, 0};
+  // 3-D mask tile of this key chunk for the 32 queries of a tile: thread (row = tid / 8, 8-key chunk = tid % 8) moves 8
+  // bytes global -> register -> LDS with the Q / dO tiles (prefetched 2-3 tiles ahead) instead of 8 dependent 1-byte
+  // loads per lane inside the compute stage
+  u32x2 mk_r[MASK3 ? 2 : 1];
+  const int key0 = blockIdx.x * NWK * 16;
+  const bool mvec = MASK3 && (d.Lk & 7) == 0 && d.Lk >= 8 && ((((uintptr_t)d.mask) & 7) == 0);
   auto load = [&](int t, auto set) {
     constexpr int S = decltype(set)::value;
     const int qb = t * QB;
     qr[S].load(d.q, qoff, d.q_sl, qb, d.Lq, tid);
     dor[S].load(d.dout, ooff, d.o_sl, qb, d.Lq, tid);
+    if constexpr (MASK3) {
+      const uint8_t* mr = d.mask + ((long)bm * d.Lq + min(qb + (tid >> 3), d.Lq - 1)) * d.Lk;
+      const int kc = key0 + (tid & 7) * 8;
+      if (mvec) {
+        mk_r[S] = *(const u32x2*)(mr + min(kc, d.Lk - 8));   // clamped: keys >= Lk are masked through kvalid anyway
+      } else {
+        uint32_t w2[2] = {0, 0};   // rare path (Lk not a multiple of 8): rolled loop, keeps the register count down
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) w2[j >> 2] |= (uint32_t)mr[min(kc + j, d.Lk - 1)] << (8 * (j & 3));
+        mk_r[S] = (u32x2){w2[0], w2[1]};
+      }
+    }
     if (tid < QB) {
       const int gq = qb + tid;
       l_r[S] = gq < d.Lq ? d.lse[sbase + gq] : INFINITY;
@@ -729,6 +788,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
     qr[S].store(Qbuf + Bf * QSZ, TRR ? nullptr : Qtbuf + Bf * TSZ, A::LDQ, tid);
     dor[S].store(dObuf + Bf * QSZ, TRR ? nullptr : dOtbuf + Bf * TSZ, A::LDQ, tid);
     if (tid < QB) { Lbuf[Bf * QB + tid] = l_r[S]; Dbuf[Bf * QB + tid] = d_r[S]; robuf[Bf * QB + tid] = ro_r[S]; }
+    if constexpr (MASK3) *(u32x2*)&mbuf[(Bf * QB + (tid >> 3)) * MLD + (tid & 7) * 8] = mk_r[S];
   };
   auto compute = [&](int t, auto buf) {
     constexpr int Bf = decltype(buf)::value;
@@ -748,13 +808,14 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { mk[tt][r] = kmasked; bb[tt][r] = 0.f; }
-    if (d.mask) {
+    if constexpr (MASK3) {
+      const uint8_t* ms = mbuf + Bf * QB * MLD + wave * 16 + li;   // this lane's key column of the staged tile
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ql = tt * 16 + 4 * lg + r, gq = min(qb + ql, d.Lq - 1);
-          mk[tt][r] |= (!ro_s[ql]) && (d.mask[((long)bm * d.Lq + gq) * d.Lk + ckey] != 0);
+          const int ql = tt * 16 + 4 * lg + r;
+          mk[tt][r] |= (!ro_s[ql]) && (ms[ql * MLD] != 0);
         }
     }
     if (d.bias) {
@@ -841,17 +902,16 @@ int check_desc(const pq3d_attn_desc& d) {
   return 0;
 }
 
+template <typename CT, int DH, bool DROP, bool MASK3> void launch_fwd_k(const pq3d_attn_desc& d, hipStream_t s, int tiles, int ks) {
+  const dim3 g8(((tiles + 7) / 8) * ks, d.H, d.B), g4(ks, d.H, d.B);
+  if (tiles > 4) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8, DROP, MASK3>), g8, dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4, DROP, MASK3>), g4, dim3(256), 0, s, d);
+}
 template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream_t s) {
   const int tiles = (d.Lq + 15) / 16, ks = d.ksplit > 1 ? d.ksplit : 1;
-  const bool dr = d.drop.p > 0.f && d.drop.seed;
-  const dim3 g8(((tiles + 7) / 8) * ks, d.H, d.B), g4(ks, d.H, d.B);
-  if (tiles > 4) {
-    if (dr) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8, true>), g8, dim3(512), 0, s, d);
-    else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 8, false>), g8, dim3(512), 0, s, d);
-  } else {
-    if (dr) hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4, true>), g4, dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((attn_fwd_kernel<CT, DH, 4, false>), g4, dim3(256), 0, s, d);
-  }
+  const bool dr = d.drop.p > 0.f && d.drop.seed, m3 = d.mask != nullptr;
+  if (dr) { if (m3) launch_fwd_k<CT, DH, true, true>(d, s, tiles, ks); else launch_fwd_k<CT, DH, true, false>(d, s, tiles, ks); }
+  else { if (m3) launch_fwd_k<CT, DH, false, true>(d, s, tiles, ks); else launch_fwd_k<CT, DH, false, false>(d, s, tiles, ks); }
   if (ks > 1) {
     const long n = (long)d.B * d.H * d.Lq * (DH / 4);
     hipLaunchKernelGGL((attn_fwd_combine_kernel<DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
@@ -859,27 +919,25 @@ template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream
   PQ_LAUNCH_CHECK();
   return 0;
 }
-template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream_t s) {
-  const int tiles = (d.Lq + 15) / 16;   // the dQ kernel also produces delta = rowsum(dO * O) for the dK/dV kernel
-  const int ks = d.ksplit > 1 ? d.ksplit : 1;
-  const bool dr = d.drop.p > 0.f && d.drop.seed;
+template <typename CT, int DH, bool DROP, bool MASK3> void launch_bwd_k(const pq3d_attn_desc& d, hipStream_t s, int tiles, int ks) {
   const dim3 g8(((tiles + 7) / 8) * ks, d.H, d.B), g4(ks, d.H, d.B);
-  if (tiles > 4) {
-    if (dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8, true>), g8, dim3(512), 0, s, d);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8, false>), g8, dim3(512), 0, s, d);
-  } else {
-    if (dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4, true>), g4, dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4, false>), g4, dim3(256), 0, s, d);
-  }
+  if (tiles > 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 8, DROP, MASK3>), g8, dim3(512), 0, s, d);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<CT, DH, 4, DROP, MASK3>), g4, dim3(256), 0, s, d);
   if (ks > 1) {
     const long n = (long)d.B * d.H * d.Lq * (DH / 4);
     hipLaunchKernelGGL((attn_dq_combine_kernel<DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
   }
   if (d.Lk > 0) {
     const dim3 gk((d.Lk + NWK * 16 - 1) / (NWK * 16), d.H, d.B);
-    if (dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH, true>), gk, dim3(NWK * 64), 0, s, d);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH, false>), gk, dim3(NWK * 64), 0, s, d);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH, DROP, MASK3>), gk, dim3(NWK * 64), 0, s, d);
   }
+}
+template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream_t s) {
+  const int tiles = (d.Lq + 15) / 16;   // the dQ kernel also produces delta = rowsum(dO * O) for the dK/dV kernel
+  const int ks = d.ksplit > 1 ? d.ksplit : 1;
+  const bool dr = d.drop.p > 0.f && d.drop.seed, m3 = d.mask != nullptr;
+  if (dr) { if (m3) launch_bwd_k<CT, DH, true, true>(d, s, tiles, ks); else launch_bwd_k<CT, DH, true, false>(d, s, tiles, ks); }
+  else { if (m3) launch_bwd_k<CT, DH, false, true>(d, s, tiles, ks); else launch_bwd_k<CT, DH, false, false>(d, s, tiles, ks); }
   PQ_LAUNCH_CHECK();
   return 0;
 }
