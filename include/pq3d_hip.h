@@ -407,6 +407,19 @@ int pq3d_matched_mask_grad(const pq3d_mask_grad_desc* d, void* stream);
 int pq3d_cross_entropy_fwd(const pq3d_ce_desc* d, void* stream);
 int pq3d_cross_entropy_bwd(const pq3d_ce_desc* d, void* stream);
 
+/* Padded mask losses without matching: batch_mask_loss / batch_dice_loss (optim/loss/instseg_loss.py:54-85), used by
+ * DirectCriterion (:88-133) and the stage-2 mask_loss (optim/loss/query3d_loss.py:28-39).  X [B, S, N] mask logits
+ * (segments first = pred_masks before the reference's permute(0, 2, 1)), T [B, N, S] float targets, P [B, N, S] uint8
+ * padding mask (0 = padding pixel / instance).
+ *   pq3d_padded_mask_sums : part[B, ceil(S/64), N, 4] partial sums over 64-segment tiles of
+ *                           (bce(x,t) p, p, sigma(x) t p, (sigma(x) + t) p); summing over tiles gives sums[B, N, 4]
+ *   pq3d_padded_mask_grad : dX = p (gm[b,n] (sigma - t) + gd[b,n] sigma (1 - sigma) d dice_score-term), with gm / gd the
+ *                           upstream gradients already divided by the caller's normalisers. */
+int pq3d_padded_mask_sums(const float* X, const float* T, const uint8_t* P, float* part, int32_t B, int32_t S, int32_t N,
+                          void* stream);
+int pq3d_padded_mask_grad(const float* X, const float* T, const uint8_t* P, const float* sums, const float* gm,
+                          const float* gd, float* dX, int32_t B, int32_t S, int32_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,3 +84,56 @@ def instseg_loss(losses: Dict[str, Tensor], *, cost_class: float, cost_mask: flo
     wd = {"loss_ce": cost_class, "loss_mask": cost_mask, "loss_dice": cost_dice}
     weighted = {k: v * wd["_".join(k.split("_")[:2])] for k, v in losses.items()}
     return sum(weighted.values()), weighted
+
+
+# ---- padded (direct) losses -------------------------------------------------------------------------------------
+def batch_dice_loss(logits: Tensor, targets: Tensor, padding_mask: Tensor) -> Tensor:
+    """optim/loss/instseg_loss.py:54-75 (logits [B, N, S])."""
+    probs = logits.sigmoid()
+    inter = (probs * targets * padding_mask).sum(-1)
+    union = ((probs + targets) * padding_mask).sum(-1)
+    dice = 1.0 - (2.0 * inter + 1e-6) / (union + 1e-6)
+    inst = padding_mask.sum(-1) > 0
+    dice = torch.where(inst, dice, torch.zeros_like(dice))
+    return dice.sum() / inst.sum()
+
+
+def batch_mask_loss(logits: Tensor, targets: Tensor, padding_mask: Tensor) -> Tensor:
+    """optim/loss/instseg_loss.py:77-85."""
+    loss = F.binary_cross_entropy_with_logits(logits, targets, reduction="none")
+    loss = (loss * padding_mask).sum(-1) / (padding_mask.sum(-1) + 1e-6)
+    inst = padding_mask.sum(-1) > 0
+    loss = torch.where(inst, loss, torch.zeros_like(loss))
+    return loss.sum() / inst.sum()
+
+
+def direct_criterion(predictions_mask, predictions_class, target_masks, target_masks_pad_masks, target_labels, *,
+                     ignore_label: int = -100) -> Dict[str, Tensor]:
+    """DirectCriterion.forward (optim/loss/instseg_loss.py:88-133), losses = ['labels', 'masks']."""
+    def one(lg, mk):
+        lab = target_labels.clone()
+        if ignore_label != -100:
+            lab[lab == ignore_label] = -100
+        pm = mk.permute(0, 2, 1)
+        return {"loss_ce": F.cross_entropy(lg.reshape(-1, lg.shape[-1]), lab.reshape(-1)),
+                "loss_mask": batch_mask_loss(pm, target_masks, target_masks_pad_masks),
+                "loss_dice": batch_dice_loss(pm, target_masks, target_masks_pad_masks)}
+    losses = one(predictions_class[-1], predictions_mask[-1])
+    for i in range(len(predictions_mask) - 1):
+        losses.update({f"{k}_{i}": v for k, v in one(predictions_class[i], predictions_mask[i]).items()})
+    return losses
+
+
+def mask_loss(data_dict) -> Tensor:
+    """optim/loss/query3d_loss.py:28-39."""
+    mask_gt = data_dict["gt_attn_mask"].logical_not()
+    total = 0
+    for mask_pred, mask_cls in zip(data_dict["predictions_mask"], data_dict["predictions_class"]):
+        mp = mask_pred.permute(0, 2, 1)
+        total = total + batch_mask_loss(mp, mask_gt.float(), data_dict["padding_mask"]) * 5 \
+            + batch_dice_loss(mp, mask_gt.float(), data_dict["padding_mask"]) * 2
+        ce = F.cross_entropy(mask_cls.reshape(-1, mask_cls.shape[-1]), data_dict["instance_labels"].reshape(-1),
+                             reduction="none")
+        om = data_dict["obj_masks"].reshape(-1)
+        total = total + (ce * om).sum() / (om.sum() + 1e-6) * 2
+    return total

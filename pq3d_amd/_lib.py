@@ -185,6 +185,9 @@ _SIGS = {
     "pq3d_matched_mask_grad": [C.POINTER(MaskGradDesc), C.c_void_p],
     "pq3d_cross_entropy_fwd": [C.POINTER(CeDesc), C.c_void_p],
     "pq3d_cross_entropy_bwd": [C.POINTER(CeDesc), C.c_void_p],
+    "pq3d_padded_mask_sums": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    "pq3d_padded_mask_grad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                              C.c_int32, C.c_int32, C.c_void_p],
     "pq3d_dropout_mask": [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Dropout), C.c_void_p],
     "pq3d_dropout_apply": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout),
                            C.c_void_p],

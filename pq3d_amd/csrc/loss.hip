@@ -157,6 +157,72 @@ __global__ __launch_bounds__(256) void matched_mask_grad_kernel(const pq3d_mask_
   }
 }
 
+// ---- padded (no matching) mask losses: batch_mask_loss / batch_dice_loss (optim/loss/instseg_loss.py:54-85) -------
+// X [B, S, N] mask logits (segments first), T / P [B, N, S] targets / padding mask.  Per (scene, instance):
+//   sums[0] = sum_s bce(x, t) p,  sums[1] = sum_s p,  sums[2] = sum_s sigma(x) t p,  sums[3] = sum_s (sigma(x) + t) p
+// Block = (64-segment tile, scene): the X tile goes through LDS so both the [S, N]-major logits and the [N, S]-major
+// targets are read coalesced; per-tile partial sums go to part[B, tiles, N, 4] (deterministic two-stage reduction).
+__global__ __launch_bounds__(256) void padded_mask_sums_kernel(const float* __restrict__ X, const float* __restrict__ T,
+                                                               const uint8_t* __restrict__ P, float* __restrict__ part,
+                                                               int S, int N, int ntiles) {
+  extern __shared__ float lds[];   // [64][N + 1]
+  const int b = blockIdx.y, tile = blockIdx.x, s0 = tile * 64, tid = threadIdx.x, ld = N + 1;
+  for (int i = tid; i < 64 * N; i += 256) {
+    const int r = i / N, c = i % N;
+    lds[r * ld + c] = s0 + r < S ? X[((long)b * S + s0 + r) * N + c] : 0.f;
+  }
+  __syncthreads();
+  const int sl = tid & 63, s = s0 + sl;
+  for (int n = tid >> 6; n < N; n += 4) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s < S) {
+      const long ti = ((long)b * N + n) * S + s;
+      const float p = P[ti] ? 1.f : 0.f, t = T[ti], x = lds[sl * ld + n];
+      const float sg = sigmoid_f(x);
+      v[0] = (softplus_f(x) - x * t) * p;   // BCE with logits = softplus(x) - x t
+      v[1] = p;
+      v[2] = sg * t * p;
+      v[3] = (sg + t) * p;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = wave_sum(v[j]);
+    if (sl == 0) *(float4*)&part[(((long)b * ntiles + tile) * N + n) * 4] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+// dX[b,s,n] = p * ( gm[b,n] (sigma - t) + gd[b,n] sigma (1 - sigma) (-(2 t U - I2) / U^2) ),  U = sums[3] + 1e-6,
+// I2 = 2 sums[2] + 1e-6 (dice_score = I2 / U)
+__global__ __launch_bounds__(256) void padded_mask_grad_kernel(const float* __restrict__ X, const float* __restrict__ T,
+                                                               const uint8_t* __restrict__ P, const float* __restrict__ sums,
+                                                               const float* __restrict__ gm, const float* __restrict__ gd,
+                                                               float* __restrict__ dX, int S, int N) {
+  extern __shared__ float lds[];   // [GRAD_ROWS][N + 1]
+  const int b = blockIdx.y, s0 = blockIdx.x * GRAD_ROWS, tid = threadIdx.x, ld = N + 1;
+  for (int i = tid; i < GRAD_ROWS * N; i += 256) {
+    const int r = i / N, c = i % N;
+    lds[r * ld + c] = s0 + r < S ? X[((long)b * S + s0 + r) * N + c] : 0.f;
+  }
+  __syncthreads();
+  const int sl = tid % GRAD_ROWS, s = s0 + sl;
+  if (s < S) {
+    for (int n = tid / GRAD_ROWS; n < N; n += 256 / GRAD_ROWS) {
+      const long ti = ((long)b * N + n) * S + s;
+      float g = 0.f;
+      if (P[ti]) {
+        const float t = T[ti], sg = sigmoid_f(lds[sl * ld + n]);
+        const float* sm = sums + ((long)b * N + n) * 4;
+        const float U = sm[3] + 1e-6f, I2 = 2.f * sm[2] + 1e-6f;
+        g = gm[(long)b * N + n] * (sg - t) + gd[(long)b * N + n] * sg * (1.f - sg) * (-(2.f * t * U - I2) / (U * U));
+      }
+      lds[sl * ld + n] = g;   // each (row, n) is read and rewritten by the same thread
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < GRAD_ROWS * N; i += 256) {
+    const int r = i / N, c = i % N;
+    if (s0 + r < S) dX[((long)b * S + s0 + r) * N + c] = lds[r * ld + c];
+  }
+}
+
 // cross entropy over rows (F.cross_entropy(..., ignore_index)): one wave per row
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const pq3d_ce_desc d) {
   const long R = d.R, ignore = d.ignore_index;
@@ -282,6 +348,34 @@ extern "C" int pq3d_cross_entropy_bwd(const pq3d_ce_desc* dp, void* stream) {
   if (int e = check_ce(d, true)) return e;
   if (d.R == 0) return 0;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((d.R + 3) / 4), d.layers), dim3(256), 0, (hipStream_t)stream, d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_padded_mask_sums(const float* X, const float* T, const uint8_t* P, float* part, int32_t B, int32_t S,
+                                     int32_t N, void* stream) {
+  PQ_CHECK_ARG(X && T && P && part && B >= 0 && S >= 1 && N >= 1, "pq3d_padded_mask_sums: bad args");
+  const size_t lds = (size_t)64 * (N + 1) * sizeof(float);
+  PQ_CHECK_ARG(lds <= 160 * 1024, "pq3d_padded_mask_sums: N too large for the LDS tile");
+  if (B == 0) return 0;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)padded_mask_sums_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { pq3d_set_error(hipGetErrorString(e)); return (int)e; }
+  }
+  const int ntiles = (S + 63) / 64;
+  hipLaunchKernelGGL(padded_mask_sums_kernel, dim3(ntiles, B), dim3(256), lds, (hipStream_t)stream, X, T, P, part, S, N, ntiles);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_padded_mask_grad(const float* X, const float* T, const uint8_t* P, const float* sums, const float* gm,
+                                     const float* gd, float* dX, int32_t B, int32_t S, int32_t N, void* stream) {
+  PQ_CHECK_ARG(X && T && P && sums && gm && gd && dX && B >= 0 && S >= 1 && N >= 1, "pq3d_padded_mask_grad: bad args");
+  const size_t lds = (size_t)GRAD_ROWS * (N + 1) * sizeof(float);
+  PQ_CHECK_ARG(lds <= 64 * 1024, "pq3d_padded_mask_grad: N too large for the LDS tile");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(padded_mask_grad_kernel, dim3((S + GRAD_ROWS - 1) / GRAD_ROWS, B), dim3(256), lds, (hipStream_t)stream,
+                     X, T, P, sums, gm, gd, dX, S, N);
   PQ_LAUNCH_CHECK();
   return 0;
 }

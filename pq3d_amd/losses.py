@@ -229,3 +229,149 @@ class InstSegLoss(nn.Module):
         for k in list(losses.keys()):
             losses[k] = losses[k] * self.weight_dict[k.split("_")[0] + "_" + k.split("_")[1]]
         return [sum(losses.values()), losses]
+
+
+# ------------------------------------------------------------------------------------------------ padded (direct) losses
+class _PaddedMaskLoss(Function):
+    """(X [B,S,N] mask logits, T [B,N,S], P [B,N,S] bool) -> (batch_mask_loss, batch_dice_loss)
+    (optim/loss/instseg_loss.py:54-85): two launches forward (tile sums + tiny finalize ops), one backward."""
+
+    @staticmethod
+    def forward(ctx, X, T, P):
+        X = X.contiguous().float()
+        T = T.contiguous().float()
+        P = P.contiguous()
+        if P.dtype != torch.bool:
+            P = P != 0
+        B, S, N = X.shape
+        nt = (S + 63) // 64
+        part = torch.empty(B, nt, N, 4, dtype=torch.float32, device=X.device)
+        L.check(L.lib().pq3d_padded_mask_sums(L.ptr(X), L.ptr(T), L.ptr(P), L.ptr(part), B, S, N, L.stream()),
+                "pq3d_padded_mask_sums")
+        sums = part.sum(1)                                   # [B, N, 4]
+        sb, sp, si, su = sums.unbind(-1)
+        valid = sp > 0
+        cnt = valid.sum().float()
+        lm = torch.where(valid, sb / (sp + 1e-6), torch.zeros_like(sb)).sum() / cnt
+        dice = 1.0 - (2.0 * si + 1e-6) / (su + 1e-6)
+        ld = torch.where(valid, dice, torch.zeros_like(dice)).sum() / cnt
+        ctx.save_for_backward(X, T, P, sums.contiguous(), valid, cnt)
+        return lm, ld
+
+    @staticmethod
+    def backward(ctx, gm_, gd_):
+        X, T, P, sums, valid, cnt = ctx.saved_tensors
+        B, S, N = X.shape
+        sp = sums[..., 1]
+        gm = (torch.where(valid, gm_ / (cnt * (sp + 1e-6)), torch.zeros_like(sp))).contiguous()
+        gd = (torch.where(valid, gd_ / cnt, torch.zeros_like(sp))).contiguous()
+        dX = torch.empty_like(X)
+        L.check(L.lib().pq3d_padded_mask_grad(L.ptr(X), L.ptr(T), L.ptr(P), L.ptr(sums), L.ptr(gm), L.ptr(gd), L.ptr(dX),
+                                              B, S, N, L.stream()), "pq3d_padded_mask_grad")
+        return dX, None, None
+
+
+def padded_mask_losses(pred_masks: torch.Tensor, targets: torch.Tensor, padding_mask: torch.Tensor):
+    """(batch_mask_loss, batch_dice_loss) for pred_masks in the model's own layout [B, S, N] (segments first)."""
+    return _PaddedMaskLoss.apply(pred_masks, targets, padding_mask)
+
+
+def _segments_first(logits: torch.Tensor) -> torch.Tensor:
+    """The reference passes pred_masks.permute(0, 2, 1) ([B, N, S]); undo the view (no copy when it is one)."""
+    return logits.permute(0, 2, 1)
+
+
+def batch_mask_loss(logits, targets, padding_mask):
+    """optim/loss/instseg_loss.py:77-85; logits [B, N, S] as in the reference."""
+    return padded_mask_losses(_segments_first(logits), targets, padding_mask)[0]
+
+
+def batch_dice_loss(logits, targets, padding_mask):
+    """optim/loss/instseg_loss.py:54-75; logits [B, N, S] as in the reference."""
+    return padded_mask_losses(_segments_first(logits), targets, padding_mask)[1]
+
+
+def cross_entropy_rows(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """F.cross_entropy(logits.view(-1, C), labels.view(-1), ignore_index) through the CE kernels (mean over kept rows)."""
+    return _RowCE.apply(logits, labels, ignore_index)
+
+
+class _RowCE(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        x = logits.contiguous().float().view(-1, logits.shape[-1])
+        t = labels.contiguous().view(-1).long()
+        R, Ccls = x.shape
+        row_loss = torch.empty(R, dtype=torch.float32, device=x.device)
+        lse = torch.empty_like(row_loss)
+        ce = L.CeDesc()
+        ce.layers, ce.C, ce.R, ce.ignore_index = 1, Ccls, R, ignore_index
+        ce.logits[0], ce.target, ce.row_loss, ce.lse = L.ptr(x), L.ptr(t), L.ptr(row_loss), L.ptr(lse)
+        L.check(L.lib().pq3d_cross_entropy_fwd(C.byref(ce), L.stream()), "pq3d_cross_entropy_fwd")
+        cnt = (t != ignore_index).sum().float()
+        ctx.save_for_backward(x, t, lse, cnt)
+        ctx.ignore_index, ctx.shape, ctx.dtype = ignore_index, logits.shape, logits.dtype
+        return row_loss.sum() / cnt
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, lse, cnt = ctx.saved_tensors
+        dl = torch.empty_like(x)
+        scale = (g / cnt).reshape(1).float().contiguous()
+        ce = L.CeDesc()
+        ce.layers, ce.C, ce.R, ce.ignore_index = 1, x.shape[1], x.shape[0], ctx.ignore_index
+        ce.logits[0], ce.dlogits[0], ce.target, ce.lse, ce.scale = L.ptr(x), L.ptr(dl), L.ptr(t), L.ptr(lse), L.ptr(scale)
+        L.check(L.lib().pq3d_cross_entropy_bwd(C.byref(ce), L.stream()), "pq3d_cross_entropy_bwd")
+        return dl.view(ctx.shape).to(ctx.dtype), None, None
+
+
+class DirectCriterion(nn.Module):
+    """optim/loss/instseg_loss.py:88-133: ground-truth masks, no Hungarian matching (query i <-> instance i)."""
+
+    def __init__(self, losses, ignore_label, **kwargs):
+        super().__init__()
+        self.losses, self.ignore_label = list(losses), ignore_label
+
+    def loss_labels(self, logits, labels):
+        if self.ignore_label != -100:
+            labels = torch.where(labels == self.ignore_label, torch.full_like(labels, -100), labels)
+        return {"loss_ce": cross_entropy_rows(logits, labels, -100)}
+
+    def loss_masks(self, pred_masks, gt_masks, padding_mask):
+        lm, ld = padded_mask_losses(pred_masks, gt_masks, padding_mask)     # pred_masks [B, S, N] as the model emits them
+        return {"loss_mask": lm, "loss_dice": ld}
+
+    def get_loss(self, loss, outputs, targets):
+        if loss == "labels":
+            return self.loss_labels(outputs["pred_logits"], targets["labels"])
+        if loss == "masks":
+            return self.loss_masks(outputs["pred_masks"], targets["masks"], targets["padding_mask"])
+        raise AssertionError(loss)
+
+    def forward(self, predictions_mask, predictions_class, target_masks, target_masks_pad_masks, target_labels):
+        losses = {}
+        targets = {"labels": target_labels, "masks": target_masks, "padding_mask": target_masks_pad_masks}
+        for loss in self.losses:
+            losses.update(self.get_loss(loss, {"pred_logits": predictions_class[-1], "pred_masks": predictions_mask[-1]},
+                                        targets))
+        for i in range(len(predictions_mask) - 1):
+            for loss in self.losses:
+                l_dict = self.get_loss(loss, {"pred_logits": predictions_class[i], "pred_masks": predictions_mask[i]},
+                                       targets)
+                losses.update({k + f"_{i}": v for k, v in l_dict.items()})
+        return losses
+
+
+def mask_loss(data_dict):
+    """optim/loss/query3d_loss.py:28-39 (stage-2 'mask_loss': 5 x BCE + 2 x dice + 2 x object-masked class CE per layer)."""
+    mask_gt = data_dict["gt_attn_mask"].logical_not().float()
+    labels = torch.where(data_dict["obj_masks"].bool(), data_dict["instance_labels"],
+                         torch.full_like(data_dict["instance_labels"], -100))
+    total = 0
+    for mask_pred, mask_cls in zip(data_dict["predictions_mask"], data_dict["predictions_class"]):
+        lm, ld = padded_mask_losses(mask_pred, mask_gt, data_dict["padding_mask"])
+        total = total + lm * 5 + ld * 2
+        # (CE(none) * obj_masks).sum() / (obj_masks.sum() + 1e-6): rows outside obj_masks are ignored rows of the CE kernel
+        n = data_dict["obj_masks"].sum().float()
+        total = total + cross_entropy_rows(mask_cls, labels, -100) * (n / (n + 1e-6)) * 2
+    return total

@@ -106,3 +106,22 @@ def criterion_inputs(seed=21, B=3, Ns=70, Nq=12, C=21, n_layers=3, seg_len=(70, 
     labels[1][2] = -100                        # one ignored target
     seg = [torch.from_numpy((r.random((n_inst[b], seg_len[b])) < 0.2).astype(np.int64)) for b in range(B)]
     return masks, logits, labels, seg
+
+
+def direct_loss_inputs(seed=31, B=3, S=70, N=12, C=21, n_layers=2, seg_len=(70, 55, 61), n_inst=(5, 12, 3)):
+    """Synthetic predictions / padded targets of the F10 fixture (DirectCriterion and the stage-2 mask_loss)."""
+    r = np.random.default_rng(seed)
+    masks, logits = [], []
+    for _ in range(n_layers):
+        masks.append(torch.from_numpy((r.standard_normal((B, S, N)) * 2.0).astype(np.float32)))
+        logits.append(torch.from_numpy(r.standard_normal((B, N, C)).astype(np.float32)))
+    tgt = torch.zeros(B, N, S)
+    pad = torch.zeros(B, N, S, dtype=torch.bool)          # False for padding pixels and padding instances
+    labels = torch.full((B, N), -100, dtype=torch.int64)
+    for b in range(B):
+        tgt[b, :n_inst[b], :seg_len[b]] = torch.from_numpy((r.random((n_inst[b], seg_len[b])) < 0.25).astype(np.float32))
+        pad[b, :n_inst[b], :seg_len[b]] = True
+        labels[b, :n_inst[b]] = torch.from_numpy(r.integers(0, C, n_inst[b]))
+    obj_masks = labels >= 0
+    lab2 = labels.clamp(min=0)
+    return masks, logits, tgt, pad, labels, obj_masks, lab2

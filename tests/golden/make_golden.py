@@ -355,6 +355,35 @@ def run_criterion_case(ref, name):
     save(name, out)
 
 
+def run_direct_loss_case(ref, name):
+    """F10: the reference's DirectCriterion (optim/loss/instseg_loss.py:88-133), batch_mask_loss / batch_dice_loss and
+    the stage-2 mask_loss (optim/loss/query3d_loss.py:28-39) on padded synthetic targets."""
+    tv = types.ModuleType("torchvision"); tv.__version__ = "0.15.0"
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("optim.loss", types.ModuleType("optim.loss"))
+    sys.modules["optim.loss"].__path__ = [os.path.join(REF, "optim", "loss")]
+    il = importlib.import_module("optim.loss.instseg_loss")
+    ql = importlib.import_module("optim.loss.query3d_loss")
+    masks, logits, tgt, pad, labels, obj_masks, lab2 = synth.direct_loss_inputs()
+    masks = [m.requires_grad_(True) for m in masks]
+    logits = [l.requires_grad_(True) for l in logits]
+    crit = il.DirectCriterion(losses=["labels", "masks"], ignore_label=-100)
+    losses = crit(masks, logits, tgt, pad, labels.clone())
+    wd = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 2.0}
+    total = sum(v * wd["_".join(k.split("_")[:2])] for k, v in losses.items())
+    dd = {"gt_attn_mask": tgt.logical_not(), "instance_labels": lab2, "obj_masks": obj_masks, "padding_mask": pad,
+          "predictions_mask": masks, "predictions_class": logits}
+    ml = ql.mask_loss(dd)
+    (total + ml).backward()
+    out = {"total": np.float64(total.item()), "mask_loss": np.float64(ml.item())}
+    for k, v in losses.items():
+        out["loss/" + k] = np.float64(v.item())
+    for l in range(len(masks)):
+        put(out, f"grad/mask/{l}", masks[l].grad, MAX_FULL)
+        put(out, f"grad/logits/{l}", logits[l].grad, MAX_GRAD)
+    save(name, out)
+
+
 T5_TINY = dict(vocab_size=128, d_model=64, d_kv=16, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=4,
                decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
 
@@ -435,6 +464,7 @@ def main():
                    spatial=False, structure="sequential", head_lr=3e-3)
     run_t5_case(ref, "F8_t5_head")
     run_criterion_case(ref, "F9_set_criterion")
+    run_direct_loss_case(ref, "F10_direct_losses")
     run_train_case(ref, "F7_adamw_mask", B=2, Ns=96, Nq=12, d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask"],
                    spatial=True, structure="parallel", use_self_mask=False, foc=(0, 2), warmup_steps=0, total_steps=6)
 

@@ -78,3 +78,39 @@ def test_cost_matrix_entries_match_oracle():
         ref = LO.cost_matrix(logits[0][b], masks[0][b], labels[b], seg[b], **W)
         got = cost[0, 0, b, :, :n_inst[b]].cpu()
         assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_direct_criterion_and_stage2_mask_loss_match_reference_fixture():
+    from pq3d_amd.losses import DirectCriterion, mask_loss
+    z, _ = util.load_fixture("F10_direct_losses")
+    masks, logits, tgt, pad, labels, obj_masks, lab2 = synth.direct_loss_inputs()
+    masks = [m.to(DEV).requires_grad_(True) for m in masks]
+    logits = [l.to(DEV).requires_grad_(True) for l in logits]
+    tgt, pad, labels, obj_masks, lab2 = (t.to(DEV) for t in (tgt, pad, labels, obj_masks, lab2))
+    losses = DirectCriterion(losses=["labels", "masks"], ignore_label=-100)(masks, logits, tgt, pad, labels)
+    total = sum(v * WD["_".join(k.split("_")[:2])] for k, v in losses.items())
+    ml = mask_loss({"gt_attn_mask": tgt.logical_not(), "instance_labels": lab2, "obj_masks": obj_masks, "padding_mask": pad,
+                    "predictions_mask": masks, "predictions_class": logits})
+    (total + ml).backward()
+    assert abs(total.item() - float(z["total"])) <= 2e-5 * abs(float(z["total"]))
+    assert abs(ml.item() - float(z["mask_loss"])) <= 2e-5 * abs(float(z["mask_loss"]))
+    for k, v in losses.items():
+        assert abs(v.item() - float(z["loss/" + k])) <= 1e-5 * max(1.0, abs(float(z["loss/" + k]))), k
+    for l in range(len(masks)):
+        util.check_against(z, f"grad/mask/{l}", masks[l].grad, atol=1e-7, rtol=2e-4)
+        util.check_against(z, f"grad/logits/{l}", logits[l].grad, atol=1e-7, rtol=2e-4, cap=util.MAX_GRAD)
+
+
+def test_padded_mask_losses_match_oracle_at_decoder_sizes():
+    from pq3d_amd.losses import padded_mask_losses
+    masks, logits, tgt, pad, labels, obj_masks, lab2 = synth.direct_loss_inputs(seed=3, B=4, S=1500, N=200, C=21, n_layers=1,
+                                                                               seg_len=(1500, 900, 1333, 64),
+                                                                               n_inst=(200, 37, 5, 150))
+    x = masks[0].to(DEV).requires_grad_(True)
+    lm, ld = padded_mask_losses(x, tgt.to(DEV), pad.to(DEV))
+    (3 * lm + 7 * ld).backward()
+    xo = masks[0].clone().requires_grad_(True)
+    om, od = LO.batch_mask_loss(xo.permute(0, 2, 1), tgt, pad), LO.batch_dice_loss(xo.permute(0, 2, 1), tgt, pad)
+    (3 * om + 7 * od).backward()
+    assert abs(lm.item() - om.item()) <= 2e-5 * abs(om.item()) and abs(ld.item() - od.item()) <= 2e-5 * abs(od.item())
+    assert float((x.grad.cpu() - xo.grad).abs().max()) <= 1e-7 + 2e-4 * float(xo.grad.abs().max())

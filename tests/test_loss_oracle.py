@@ -31,3 +31,22 @@ def test_set_criterion_oracle_matches_reference():
     for l in range(len(masks)):
         util.check_against(z, f"grad/mask/{l}", masks[l].grad, atol=1e-7, rtol=1e-4)
         util.check_against(z, f"grad/logits/{l}", torch.nan_to_num(logits[l].grad), atol=1e-7, rtol=1e-4, cap=util.MAX_GRAD)
+
+
+def test_direct_losses_oracle_matches_reference():
+    z, _ = util.load_fixture("F10_direct_losses")
+    masks, logits, tgt, pad, labels, obj_masks, lab2 = synth.direct_loss_inputs()
+    masks = [m.requires_grad_(True) for m in masks]
+    logits = [l.requires_grad_(True) for l in logits]
+    losses = LO.direct_criterion(masks, logits, tgt, pad, labels)
+    total, _ = LO.instseg_loss(losses, **W)
+    ml = LO.mask_loss({"gt_attn_mask": tgt.logical_not(), "instance_labels": lab2, "obj_masks": obj_masks,
+                       "padding_mask": pad, "predictions_mask": masks, "predictions_class": logits})
+    (total + ml).backward()
+    assert abs(total.item() - float(z["total"])) <= 1e-5 * abs(float(z["total"]))
+    assert abs(ml.item() - float(z["mask_loss"])) <= 1e-5 * abs(float(z["mask_loss"]))
+    for k, v in losses.items():
+        assert abs(v.item() - float(z["loss/" + k])) <= 2e-6 * max(1.0, abs(float(z["loss/" + k]))), k
+    for l in range(len(masks)):
+        util.check_against(z, f"grad/mask/{l}", masks[l].grad, atol=1e-7, rtol=1e-4)
+        util.check_against(z, f"grad/logits/{l}", logits[l].grad, atol=1e-7, rtol=1e-4, cap=util.MAX_GRAD)
