@@ -115,3 +115,31 @@ def test_bf16_c2_padding_invariance_and_scene_permutation():
         dd3 = {k: (v[perm].clone() if torch.is_tensor(v) and v.shape[0] == C2["B"] else v) for k, v in dd.items()}
         out3 = model({k: v.to(DEV) for k, v in dd3.items()})["query_embeds"]
         assert torch.equal(base[perm.to(DEV)], out3), "scenes are not independent"
+
+
+@pytest.mark.parametrize("compute,tol", [("fp32", 1e-5), ("bf16", 1e-2)])
+def test_batch_sharding_reproduces_full_batch_gradients(compute, tol):
+    """SURVEY 8e by construction on one GPU: running the two halves of a batch separately (what two data-parallel ranks
+    do) and averaging their gradients equals the full-batch step -- scenes never interact (forward bit-exact per scene),
+    so the only difference is the summation order of the parameter gradients.  fp32: 5e-7 measured.  bf16: the split-K
+    atomics of the backward make two IDENTICAL runs differ by ~2e-3 (an fp32 ulp flips a bf16 rounding downstream), and
+    sharded-vs-full sits at exactly that run-to-run level."""
+    args = dict(C2, B=4)
+    model, sd, dd = build(args, compute)
+    ddv = {k: v.to(DEV) for k, v in dd.items()}
+
+    def grads(sl):
+        model.zero_grad(set_to_none=True)
+        out = model({k: (v[sl] if torch.is_tensor(v) and v.shape[0] == args["B"] else v) for k, v in ddv.items()})
+        out["query_embeds"].float().square().mean().backward()
+        return out["query_embeds"].detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()
+                                                      if p.grad is not None}
+
+    q_full, g_full = grads(slice(0, 4))
+    q_a, g_a = grads(slice(0, 2))
+    q_b, g_b = grads(slice(2, 4))
+    assert torch.equal(q_full[:2], q_a) and torch.equal(q_full[2:], q_b), "scenes must not interact"
+    gmax = max(float(v.norm()) for v in g_full.values())
+    for n in g_full:
+        avg = 0.5 * (g_a[n] + g_b[n])     # all-reduce(mean) of the two ranks; loss = mean over the local scenes
+        assert float((avg - g_full[n]).norm()) <= tol * max(float(g_full[n].norm()), 1e-2 * gmax), n
