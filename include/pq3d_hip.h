@@ -420,6 +420,18 @@ int pq3d_padded_mask_sums(const float* X, const float* T, const uint8_t* P, floa
 int pq3d_padded_mask_grad(const float* X, const float* T, const uint8_t* P, const float* sums, const float* gm,
                           const float* gd, float* dX, int32_t B, int32_t S, int32_t N, void* stream);
 
+/* Ragged -> padded collate on the device: pad_sequence / pad_sequence_2d (data/data_utils.py:337-382) as
+ * used by InstSegDatasetWrapper.collate_fn (data/datasets/instseg_wrapper.py:27-81) for segment features, centres, labels
+ * and target masks.  The ragged batch is packed: sample b occupies rows offsets[b] .. offsets[b+1] of src [total, D]
+ * (1-D) or h[b] x w[b] x D elements starting at element offset offsets[b] (2-D).  out = [B, L, D] / [B, H, W, D] filled
+ * with the element at *pad_value (host pointer, elem_size bytes) outside the samples; mask (optional) = 1 where padded
+ * ("True as masked").  Elements are copied as opaque 1/2/4/8-byte units (any dtype). */
+int pq3d_pad_sequence(const void* src, const int64_t* offsets, void* out, uint8_t* mask, int32_t B, int64_t L, int64_t D,
+                      int32_t elem_size, const void* pad_value, void* stream);
+int pq3d_pad_sequence_2d(const void* src, const int64_t* offsets, const int32_t* heights, const int32_t* widths, void* out,
+                         uint8_t* mask, int32_t B, int64_t H, int64_t W, int64_t D, int32_t elem_size, const void* pad_value,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

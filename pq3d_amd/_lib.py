@@ -188,6 +188,10 @@ _SIGS = {
     "pq3d_padded_mask_sums": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "pq3d_padded_mask_grad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                               C.c_int32, C.c_int32, C.c_void_p],
+    "pq3d_pad_sequence": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                          C.c_void_p, C.c_void_p],
+    "pq3d_pad_sequence_2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                             C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p],
     "pq3d_dropout_mask": [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Dropout), C.c_void_p],
     "pq3d_dropout_apply": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout),
                            C.c_void_p],

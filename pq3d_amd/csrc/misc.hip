@@ -1,4 +1,6 @@
 // Small memory-bound kernels of the query-decoder path (all fp32 math, coalesced row-major access).
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -544,6 +546,77 @@ extern "C" int pq3d_dropout_apply(const void* x, int32_t dt_x, void* y, int32_t 
   if (rows == 0) return 0;
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid1d(rows * ((cols + 1) / 2), 256, 8192)), dim3(256), 0,
                      (hipStream_t)stream, x, dt_x, y, dt_y, (long)rows, (long)cols, *dr);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ ragged -> padded
+// pad_sequence / pad_sequence_2d of the reference's collate (data/data_utils.py:337-382) for an on-device ragged batch:
+// samples packed back to back, per-sample extents in small device arrays.  Pure copies, typed by element size.
+namespace {
+template <typename E>
+__global__ __launch_bounds__(256) void pad_sequence_kernel(const E* __restrict__ src, const int64_t* __restrict__ offsets,
+                                                           E* __restrict__ out, uint8_t* __restrict__ mask, long L, long D,
+                                                           E pad) {
+  const int b = blockIdx.y;
+  const long n = offsets[b + 1] - offsets[b], base = offsets[b] * D;
+  const long total = L * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / D;
+    out[(long)b * total + i] = row < n ? src[base + i] : pad;
+    if (mask && i % D == 0) mask[(long)b * L + row] = row >= n ? 1 : 0;   // True as masked (data_utils.py:352)
+  }
+}
+template <typename E>
+__global__ __launch_bounds__(256) void pad_sequence_2d_kernel(const E* __restrict__ src, const int64_t* __restrict__ offsets,
+                                                              const int32_t* __restrict__ hs, const int32_t* __restrict__ ws,
+                                                              E* __restrict__ out, uint8_t* __restrict__ mask, long H, long W,
+                                                              long D, E pad) {
+  const int b = blockIdx.y;
+  const long h = hs[b], w = ws[b], base = offsets[b];
+  const long total = H * W * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long c = i % D, col = (i / D) % W, row = i / (D * W);
+    const bool in = row < h && col < w;
+    out[(long)b * total + i] = in ? src[base + (row * w + col) * D + c] : pad;
+    if (mask && c == 0) mask[((long)b * H + row) * W + col] = in ? 0 : 1;
+  }
+}
+template <typename E> E pad_as(const void* p) { E v; memcpy(&v, p, sizeof(E)); return v; }
+}  // namespace
+
+extern "C" int pq3d_pad_sequence(const void* src, const int64_t* offsets, void* out, uint8_t* mask, int32_t B, int64_t L,
+                                 int64_t D, int32_t elem_size, const void* pad_value, void* stream) {
+  PQ_CHECK_ARG(offsets && out && pad_value && B >= 0 && L >= 0 && D >= 1, "pq3d_pad_sequence: bad args");
+  PQ_CHECK_ARG(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8, "pq3d_pad_sequence: element size");
+  if (B == 0 || L == 0) return 0;
+  PQ_CHECK_ARG(src != nullptr, "pq3d_pad_sequence: null src");
+  dim3 grid(grid1d(L * D, 256, 2048), B);
+  hipStream_t s = (hipStream_t)stream;
+#define PQ_PAD1(E) hipLaunchKernelGGL(pad_sequence_kernel<E>, grid, dim3(256), 0, s, (const E*)src, offsets, (E*)out, mask, \
+                                      (long)L, (long)D, pad_as<E>(pad_value))
+  if (elem_size == 1) PQ_PAD1(uint8_t); else if (elem_size == 2) PQ_PAD1(uint16_t);
+  else if (elem_size == 4) PQ_PAD1(uint32_t); else PQ_PAD1(uint64_t);
+#undef PQ_PAD1
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_pad_sequence_2d(const void* src, const int64_t* offsets, const int32_t* heights, const int32_t* widths,
+                                    void* out, uint8_t* mask, int32_t B, int64_t H, int64_t W, int64_t D, int32_t elem_size,
+                                    const void* pad_value, void* stream) {
+  PQ_CHECK_ARG(offsets && heights && widths && out && pad_value && B >= 0 && H >= 0 && W >= 0 && D >= 1,
+               "pq3d_pad_sequence_2d: bad args");
+  PQ_CHECK_ARG(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8, "pq3d_pad_sequence_2d: element size");
+  if (B == 0 || H == 0 || W == 0) return 0;
+  PQ_CHECK_ARG(src != nullptr, "pq3d_pad_sequence_2d: null src");
+  dim3 grid(grid1d(H * W * D, 256, 2048), B);
+  hipStream_t s = (hipStream_t)stream;
+#define PQ_PAD2(E) hipLaunchKernelGGL(pad_sequence_2d_kernel<E>, grid, dim3(256), 0, s, (const E*)src, offsets, heights, widths, \
+                                      (E*)out, mask, (long)H, (long)W, (long)D, pad_as<E>(pad_value))
+  if (elem_size == 1) PQ_PAD2(uint8_t); else if (elem_size == 2) PQ_PAD2(uint16_t);
+  else if (elem_size == 4) PQ_PAD2(uint32_t); else PQ_PAD2(uint64_t);
+#undef PQ_PAD2
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -125,3 +125,17 @@ def direct_loss_inputs(seed=31, B=3, S=70, N=12, C=21, n_layers=2, seg_len=(70, 
     obj_masks = labels >= 0
     lab2 = labels.clamp(min=0)
     return masks, logits, tgt, pad, labels, obj_masks, lab2
+
+
+def collate_inputs(seed=41):
+    """Ragged per-sample tensors of the F11 collate fixture: segment features, centres, labels (int64), pad masks (bool),
+    instance x segment target masks (int64, 2-D ragged)."""
+    r = np.random.default_rng(seed)
+    lens = [37, 5, 64, 1]
+    feats = [torch.from_numpy(r.standard_normal((n, 24)).astype(np.float32)) for n in lens]
+    centers = [torch.from_numpy(r.uniform(0, 4, (n, 3)).astype(np.float32)) for n in lens]
+    labels = [torch.from_numpy(r.integers(0, 200, n)) for n in lens]
+    valid = [torch.ones(n, dtype=torch.bool) for n in lens]
+    ninst = [4, 9, 2, 1]
+    seg_masks = [torch.from_numpy((r.random((k, n)) < 0.3).astype(np.int64)) for k, n in zip(ninst, lens)]
+    return feats, centers, labels, valid, seg_masks

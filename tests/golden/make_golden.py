@@ -384,6 +384,24 @@ def run_direct_loss_case(ref, name):
     save(name, out)
 
 
+def run_collate_case(ref, name):
+    """F11: the reference's pad_sequence / pad_sequence_2d (data/data_utils.py:337-382) as collate_fn uses them
+    (instseg_wrapper.py:41-66): float features, centres, int64 labels padded with -100, bool masks, 2-D target masks."""
+    du = importlib.import_module("data.data_utils")
+    feats, centers, labels, valid, seg_masks = synth.collate_inputs()
+    out = {}
+    out["feats"] = du.pad_sequence(feats).numpy()
+    c, m = du.pad_sequence(centers, return_mask=True)
+    out["centers"], out["centers_mask"] = c.numpy(), m.numpy()
+    out["labels"] = du.pad_sequence(labels, pad=-100).numpy()
+    out["valid"] = du.pad_sequence(valid).numpy()
+    out["feats_len80"] = du.pad_sequence(feats, max_len=80, pad=1.5).numpy()
+    sm, pm = du.pad_sequence_2d(seg_masks, return_mask=True)
+    out["seg_masks"], out["seg_masks_mask"] = sm.numpy(), pm.numpy()
+    out["seg_masks_f"] = du.pad_sequence_2d([s_.float() for s_ in seg_masks], max_height=12, max_width=70, pad=-1).numpy()
+    save(name, out)
+
+
 T5_TINY = dict(vocab_size=128, d_model=64, d_kv=16, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=4,
                decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
 
@@ -465,6 +483,7 @@ def main():
     run_t5_case(ref, "F8_t5_head")
     run_criterion_case(ref, "F9_set_criterion")
     run_direct_loss_case(ref, "F10_direct_losses")
+    run_collate_case(ref, "F11_collate")
     run_train_case(ref, "F7_adamw_mask", B=2, Ns=96, Nq=12, d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask"],
                    spatial=True, structure="parallel", use_self_mask=False, foc=(0, 2), warmup_steps=0, total_steps=6)
 
