@@ -275,11 +275,20 @@ int pq3d_fourier(const float* xyz, int64_t xyz_stride, const float* cmin, const 
  * (zeroed by the call) from dbias. */
 int pq3d_spatial_bias_fwd(const float* pl, const float* W, const float* bw, float* bias, int32_t B, int32_t H,
                           int32_t L, void* stream);
+/* `groups` layers sharing pairwise_locs in one launch (host pointer arrays of device pointers) */
+int pq3d_spatial_bias_fwd_grouped(const float* pl, const float* const* W, const float* const* bw, float* const* bias,
+                                  int32_t groups, int32_t B, int32_t H, int32_t L, void* stream);
 int pq3d_spatial_bias_bwd(const float* pl, const float* W, const float* bw, const float* dbias, float* dW, float* dbw,
                           int32_t B, int32_t H, int32_t L, void* stream);
 /* same, accumulating onto dW/dbw instead of zeroing them first */
 int pq3d_spatial_bias_bwd_acc(const float* pl, const float* W, const float* bw, const float* dbias, float* dW,
                               float* dbw, int32_t B, int32_t H, int32_t L, void* stream);
+/* the same for `groups` (<= PQ3D_MAX_GROUPS) layers sharing pairwise_locs in ONE launch (accumulating; host pointer
+ * arrays of device pointers): the fused executor defers the layers' spatial-bias parameter gradients to the end of the
+ * backward pass */
+int pq3d_spatial_bias_bwd_grouped(const float* pl, const float* const* W, const float* const* bw,
+                                  const float* const* dbias, float* const* dW, float* const* dbw, int32_t groups,
+                                  int32_t B, int32_t H, int32_t L, void* stream);
 
 /* gate structure (query_encoder.py:166-170): y = (1-s)*q + s*u, s = sigmoid(g);  bwd: dq, du, dg. */
 int pq3d_gate_mix_fwd(const float* q, const float* u, const float* g, float* y, int64_t n, void* stream);

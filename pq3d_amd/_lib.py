@@ -170,6 +170,9 @@ _SIGS = {
                               C.c_int32, C.c_int32, C.c_void_p],
     "pq3d_spatial_bias_bwd_acc": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p],
+    "pq3d_spatial_bias_fwd_grouped": [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3 + [C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                                                   C.c_void_p],
+    "pq3d_spatial_bias_bwd_grouped": [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5 + [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "pq3d_gate_mix_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "pq3d_gate_mix_bwd": [C.c_void_p] * 7 + [C.c_int64, C.c_void_p],
     "pq3d_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,

@@ -167,8 +167,15 @@ __global__ void fourier_kernel(const float* xyz, long xs, const float* cmin, con
 }
 
 // ---------------------------------------------------------------- spatial bias
-__global__ void spatial_bias_fwd_kernel(const float* pl, const float* W, const float* bw, float* bias, int B, int H,
-                                        int L) {
+struct SbFwdGroups {
+  const float* W[PQ3D_MAX_GROUPS];
+  const float* bw[PQ3D_MAX_GROUPS];
+  float* bias[PQ3D_MAX_GROUPS];
+};
+__global__ void spatial_bias_fwd_kernel(const float* pl, const SbFwdGroups gr, int B, int H, int L) {
+  const float* W = gr.W[blockIdx.y];
+  const float* bw = gr.bw[blockIdx.y];
+  float* bias = gr.bias[blockIdx.y];
   const long LL = (long)L * L, total = (long)B * LL;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long b = i / LL, ij = i % LL;
@@ -187,10 +194,23 @@ __global__ void spatial_bias_fwd_kernel(const float* pl, const float* W, const f
 // Single pass: each thread reads its (b,i,j) feature vector ONCE and updates all heads' 6 partial sums in registers
 // (H <= 16), then one wave reduction + LDS tree per block and 6*H atomics per block.  (The first version looped
 // over heads outside the element loop and re-read pl H times: 29 us for 80k elements.)
+// (measured: capping the grid at 64 blocks to cut the 6*H contended atomics per block made it slower, 20 -> 28 us: one
+// element per thread is what hides the load latency; the layers of a step are batched into one launch instead)
+constexpr long SB_BLOCKS = 512;
+struct SbGroups {
+  const float* W[PQ3D_MAX_GROUPS];
+  const float* bw[PQ3D_MAX_GROUPS];
+  const float* dbias[PQ3D_MAX_GROUPS];
+  float* dW[PQ3D_MAX_GROUPS];
+  float* dbw[PQ3D_MAX_GROUPS];
+};
 template <int HMAX>
-__global__ __launch_bounds__(256) void spatial_bias_bwd_kernel(const float* pl, const float* W, const float* bw,
-                                                               const float* dbias, float* dW, float* dbw, int B, int H,
-                                                               int L) {
+__global__ __launch_bounds__(256) void spatial_bias_bwd_kernel(const float* pl, const SbGroups gr, int B, int H, int L) {
+  const float* W = gr.W[blockIdx.y];
+  const float* bw = gr.bw[blockIdx.y];
+  const float* dbias = gr.dbias[blockIdx.y];
+  float* dW = gr.dW[blockIdx.y];
+  float* dbw = gr.dbw[blockIdx.y];
   __shared__ float red[4][HMAX * 6];
   const long LL = (long)L * L, total = (long)B * LL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -432,14 +452,26 @@ extern "C" int pq3d_fourier(const float* xyz, int64_t xyz_stride, const float* c
   return 0;
 }
 
-extern "C" int pq3d_spatial_bias_fwd(const float* pl, const float* W, const float* bw, float* bias, int32_t B,
-                                     int32_t H, int32_t L, void* stream) {
-  PQ_CHECK_ARG(pl && W && bw && bias && H >= 1, "pq3d_spatial_bias_fwd: bad args");
+extern "C" int pq3d_spatial_bias_fwd_grouped(const float* pl, const float* const* W, const float* const* bw,
+                                             float* const* bias, int32_t groups, int32_t B, int32_t H, int32_t L,
+                                             void* stream) {
+  PQ_CHECK_ARG(pl && W && bw && bias && H >= 1 && groups >= 1 && groups <= PQ3D_MAX_GROUPS,
+               "pq3d_spatial_bias_fwd_grouped: bad args");
+  SbFwdGroups gr;
+  for (int g = 0; g < groups; ++g) {
+    PQ_CHECK_ARG(W[g] && bw[g] && bias[g], "pq3d_spatial_bias_fwd_grouped: null pointer");
+    gr.W[g] = W[g]; gr.bw[g] = bw[g]; gr.bias[g] = bias[g];
+  }
   if (B == 0 || L == 0) return 0;
-  hipLaunchKernelGGL(spatial_bias_fwd_kernel, dim3(grid1d((long)B * L * L)), dim3(256), 0, (hipStream_t)stream, pl, W,
-                     bw, bias, B, H, L);
+  hipLaunchKernelGGL(spatial_bias_fwd_kernel, dim3(grid1d((long)B * L * L), groups), dim3(256), 0, (hipStream_t)stream, pl,
+                     gr, B, H, L);
   PQ_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int pq3d_spatial_bias_fwd(const float* pl, const float* W, const float* bw, float* bias, int32_t B,
+                                     int32_t H, int32_t L, void* stream) {
+  return pq3d_spatial_bias_fwd_grouped(pl, &W, &bw, &bias, 1, B, H, L, stream);
 }
 
 extern "C" int pq3d_spatial_bias_bwd(const float* pl, const float* W, const float* bw, const float* dbias, float* dW,
@@ -451,20 +483,32 @@ extern "C" int pq3d_spatial_bias_bwd(const float* pl, const float* W, const floa
   return pq3d_spatial_bias_bwd_acc(pl, W, bw, dbias, dW, dbw, B, H, L, stream);
 }
 
-extern "C" int pq3d_spatial_bias_bwd_acc(const float* pl, const float* W, const float* bw, const float* dbias,
-                                         float* dW, float* dbw, int32_t B, int32_t H, int32_t L, void* stream) {
-  PQ_CHECK_ARG(pl && W && bw && dbias && dW && dbw && H >= 1, "pq3d_spatial_bias_bwd_acc: bad args");
+extern "C" int pq3d_spatial_bias_bwd_grouped(const float* pl, const float* const* W, const float* const* bw,
+                                             const float* const* dbias, float* const* dW, float* const* dbw,
+                                             int32_t groups, int32_t B, int32_t H, int32_t L, void* stream) {
+  PQ_CHECK_ARG(pl && W && bw && dbias && dW && dbw && H >= 1 && groups >= 1 && groups <= PQ3D_MAX_GROUPS,
+               "pq3d_spatial_bias_bwd_grouped: bad args");
+  SbGroups gr;
+  for (int g = 0; g < groups; ++g) {
+    PQ_CHECK_ARG(W[g] && bw[g] && dbias[g] && dW[g] && dbw[g], "pq3d_spatial_bias_bwd_grouped: null pointer");
+    gr.W[g] = W[g]; gr.bw[g] = bw[g]; gr.dbias[g] = dbias[g]; gr.dW[g] = dW[g]; gr.dbw[g] = dbw[g];
+  }
   hipStream_t s = (hipStream_t)stream;
   if (B == 0 || L == 0) return 0;
   PQ_CHECK_ARG(H <= 16, "pq3d_spatial_bias_bwd: at most 16 heads");
   if (H <= 8)
-    hipLaunchKernelGGL(spatial_bias_bwd_kernel<8>, dim3(grid1d((long)B * L * L, 256, 512)), dim3(256), 0, s, pl, W, bw,
-                       dbias, dW, dbw, B, H, L);
+    hipLaunchKernelGGL(spatial_bias_bwd_kernel<8>, dim3(grid1d((long)B * L * L, 256, SB_BLOCKS), groups), dim3(256), 0, s, pl,
+                       gr, B, H, L);
   else
-    hipLaunchKernelGGL(spatial_bias_bwd_kernel<16>, dim3(grid1d((long)B * L * L, 256, 512)), dim3(256), 0, s, pl, W, bw,
-                       dbias, dW, dbw, B, H, L);
+    hipLaunchKernelGGL(spatial_bias_bwd_kernel<16>, dim3(grid1d((long)B * L * L, 256, SB_BLOCKS), groups), dim3(256), 0, s, pl,
+                       gr, B, H, L);
   PQ_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int pq3d_spatial_bias_bwd_acc(const float* pl, const float* W, const float* bw, const float* dbias,
+                                         float* dW, float* dbw, int32_t B, int32_t H, int32_t L, void* stream) {
+  return pq3d_spatial_bias_bwd_grouped(pl, &W, &bw, &dbias, &dW, &dbw, 1, B, H, L, stream);
 }
 
 extern "C" int pq3d_gate_mix_fwd(const float* q, const float* u, const float* g, float* y, int64_t n, void* stream) {

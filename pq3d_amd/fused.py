@@ -280,6 +280,19 @@ class _FusedDecoder(Function):
             inv_den = ops.mask_inv_den(masks[:spec.mh_count])
             ctx.mh_valid = valid
 
+        # ---- spatial attention bias log(clamp(relu(W_l . pairwise_locs))) of every layer: one grouped launch (depends on
+        # the layer's weights only, not on the query state, and is shared by the blocks that re-traverse the layers)
+        sbias_all = None
+        if spec.spatial:
+            sbias_all = torch.empty(Ln, B, H, Nq, Nq, dtype=torch.float32, device=dev)
+            fcs = [layers[i].self_attn.self_attn.pairwise_loc_fc for i in range(Ln)]
+            for i0 in range(0, Ln, MAXG):
+                n_ = min(MAXG, Ln - i0)
+                arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
+                L.check(L.lib().pq3d_spatial_bias_fwd_grouped(
+                    L.ptr(pl), arr([fc.weight.detach() for fc in fcs[i0:i0 + n_]]),
+                    arr([fc.bias.detach() for fc in fcs[i0:i0 + n_]]), arr([sbias_all[i0 + k] for k in range(n_)]), n_, B, H,
+                    Nq, L.stream()), "pq3d_spatial_bias_fwd_grouped")
         tape: List[dict] = []
         pcls, pmask = [], []
         x = x0
@@ -345,12 +358,7 @@ class _FusedDecoder(Function):
                     Wo, bo = sa.self_attn.out_proj.weight.detach(), sa.self_attn.out_proj.bias.detach()
                 L.gemm(M=R, N=d, K=d, A=[x1] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=ct,
                        lda=d, ldb=d, ldc=d)
-                sbias = None
-                if spec.spatial:
-                    sbias = torch.empty(B, H, Nq, Nq, dtype=torch.float32, device=dev)
-                    L.check(L.lib().pq3d_spatial_bias_fwd(L.ptr(pl), L.ptr(msa.pairwise_loc_fc.weight.detach()),
-                                                          L.ptr(msa.pairwise_loc_fc.bias.detach()), L.ptr(sbias), B, H, Nq,
-                                                          L.stream()), "pq3d_spatial_bias_fwd")
+                sbias = sbias_all[i] if spec.spatial else None   # layer-invariant across blocks: computed once above
                 o_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
                 lse_s = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
                 _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ct, False, kpm=qmask, bias=sbias, drop=dr_sa)
@@ -441,6 +449,7 @@ class _FusedDecoder(Function):
         G = lambda p: gv[id(p)]
 
         dwq = _DwQueue(ct)
+        sb_queue = []   # (W, b, d bias, dW, db) of every spatial self-attention application
         dx = dxf.contiguous().float() if dxf is not None else torch.zeros(B, Nq, d, device=dev)
         dqpos_parts: List[torch.Tensor] = []
         n_app = len(tape)
@@ -558,12 +567,9 @@ class _FusedDecoder(Function):
             dsb = torch.empty_like(rec["sbias"]) if spec.spatial else None
             _attn(qkv[0], qkv[1], qkv[2], rec["o_s"], rec["lse_s"], H, ct, False, kpm=qmask, bias=rec["sbias"],
                   bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb), drop=rec["dr_sa"])
-            if spec.spatial:
-                L.check(L.lib().pq3d_spatial_bias_bwd_acc(L.ptr(pl), L.ptr(msa.pairwise_loc_fc.weight.detach()),
-                                                          L.ptr(msa.pairwise_loc_fc.bias.detach()), L.ptr(dsb),
-                                                          L.ptr(G(msa.pairwise_loc_fc.weight)),
-                                                          L.ptr(G(msa.pairwise_loc_fc.bias)), B, H, Nq, L.stream()),
-                        "pq3d_spatial_bias_bwd_acc")
+            if spec.spatial:   # deferred: one grouped launch for all layer applications at the end of the backward
+                sb_queue.append((msa.pairwise_loc_fc.weight.detach(), msa.pairwise_loc_fc.bias.detach(), dsb,
+                                 G(msa.pairwise_loc_fc.weight), G(msa.pairwise_loc_fc.bias)))
             tmpv = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)       # dv @ Wv + residual grad
             L.gemm(M=R, N=d, K=d, A=[dqkv[2]], B=[Wl[2]], Cs=[tmpv], aux=[dx1r], act_grad="add", ct=ct, lda=d, ldb=d,
                    ldc=d, transB=True)
@@ -664,6 +670,11 @@ class _FusedDecoder(Function):
         if ctx.needs_input_grad[2]:
             dqpos = torch.stack(dqpos_parts, 0).sum(0) if len(dqpos_parts) > 1 else dqpos_parts[0]
         dwq.flush()
+        for i0 in range(0, len(sb_queue), MAXG):
+            chunk = sb_queue[i0:i0 + MAXG]
+            arrs = [(C.c_void_p * len(chunk))(*[L.ptr(t[k]) for t in chunk]) for k in range(5)]
+            L.check(L.lib().pq3d_spatial_bias_bwd_grouped(L.ptr(pl), *arrs, len(chunk), B, H, Nq, L.stream()),
+                    "pq3d_spatial_bias_bwd_grouped")
         dx0 = dx if ctx.needs_input_grad[1] else None
         pgrads = [gv[id(p)] if p.requires_grad else None for p in params]
         return (None, dx0, dqpos, None, dpos, None, None, None, None, *dfeats, *([None] * M), *pgrads)
