@@ -114,6 +114,7 @@ class FusedSpec:
         self.enc, self.mh, self.mems, self.ct, self.act = enc, mh, list(mems), ct, act
         self.use_self_mask, self.num_blocks, self.spatial = use_self_mask, num_blocks, spatial
         self.mh_count, self.offline, self.skip_pred = mh_count, offline, skip_pred
+        self.stacked_kpm = None      # optional [M, B, Ns] key-padding masks of the memories, stacked (set by fused_decoder)
         self.drop_base = drop_base   # dropout-site base of the encoder when train-mode dropout is active, else None
         self.mh_drop = mh_drop       # mask head's cls_head dropout active
 
@@ -266,7 +267,10 @@ class _FusedDecoder(Function):
         for s in range(0, len(A), MAXG):
             L.gemm(M=Rk, N=d, K=d, A=A[s:s + MAXG], A2=A2[s:s + MAXG], B=Bw[s:s + MAXG], bias=bs[s:s + MAXG],
                    Cs=Cs[s:s + MAXG], ct=ct, lda=d, ldb=d, ldc=d)
-        kpm_all = torch.cat(masks, 0) if not spec.use_self_mask else None
+        kpm_all = None
+        if not spec.use_self_mask:
+            st = spec.stacked_kpm   # [M, B, Ns] already stacked by the model (same memory order): no copy
+            kpm_all = st.reshape(M * B, Ns) if st is not None else torch.cat(masks, 0)
 
         # ---- mask-head keys (layer-invariant)
         keys = inv_den = None
@@ -729,6 +733,10 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
         mh_drop = mask_head is not None and mask_head.dropout_p > 0.0
     spec = FusedSpec(enc, mask_head, mems, ct, layer0.ffn.activation, enc.use_self_mask, enc.num_blocks,
                      enc.spatial_selfattn, mh_count, offline_attn_masks is not None, skip_prediction, drop_base, mh_drop)
+    st = input_dict.get("_stacked_scene_kpm")
+    if st is not None and list(st[1]) == list(mems) and st[0].is_contiguous() and \
+            all(masks[j].data_ptr() == st[0][j].data_ptr() for j in range(len(mems))):
+        spec.stacked_kpm = st[0]
     params = [p for p in enc.parameters()] + ([p for p in mask_head.parameters()] if mask_head is not None else [])
     outs = _FusedDecoder.apply(spec, x0, qpos, qmask, poss[0], pairwise_locs, seg_masks, offline_attn_masks, coef,
                                *feats, *masks, *params)

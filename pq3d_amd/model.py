@@ -104,6 +104,7 @@ class Query3DUnified(nn.Module):
             setattr(self, head + "_head", build_module_by_name(cfg.model.get(head + "_head")))
         self.compute = compute
         self._coef_cache = {}
+        self._zeros_cache = {}
         M.set_compute(self, compute)
 
     @property
@@ -161,6 +162,15 @@ class Query3DUnified(nn.Module):
         if self.training:
             M.begin_dropout_step(self, data_dict["query_locs"].device)
         mask = data_dict["query_pad_masks"].logical_not()
+        # the scene-memory pad masks ('True = valid' in data_dict) are inverted in ONE stacked op; the fused executor
+        # then takes the stack as the memories-stacked key-padding mask without another copy
+        scene = [m for m in self.inputs if m in ("mv", "pc", "voxel")]
+        keys = [m + "_seg_pad_masks" for m in scene] + (["seg_pad_masks"] if hasattr(self, "mask_head") else [])
+        inv = {}
+        if len(keys) > 1 and len({(tuple(data_dict[k].shape), data_dict[k].dtype) for k in keys}) == 1:
+            stacked = torch.stack([data_dict[k] for k in keys], 0).logical_not()
+            inv = {k: stacked[j] for j, k in enumerate(keys)}
+            input_dict["_stacked_scene_kpm"] = (stacked[:len(scene)], scene)
         query_locs = data_dict["query_locs"][:, :, :self.dim_loc]
         coord_min, coord_max = data_dict["coord_min"], data_dict["coord_max"]
         if self.dim_loc > 3:
@@ -169,17 +179,22 @@ class Query3DUnified(nn.Module):
             fts_pos = self._pos(data_dict["seg_center"], coord_min, coord_max, box_times=2)
         else:
             query_pos, fts_pos = self._pos_pair(query_locs, data_dict["seg_center"], coord_min, coord_max)
-        input_dict["query"] = (torch.zeros_like(query_pos), mask, query_pos)
+        zkey = (tuple(query_pos.shape), query_pos.device)
+        if zkey not in self._zeros_cache:      # the learnable-query content starts at zero (query3d_unified.py:121): constant
+            self._zeros_cache[zkey] = torch.zeros_like(query_pos)
+        input_dict["query"] = (self._zeros_cache[zkey], mask, query_pos)
         enc_out = self._encode_scene_memories(data_dict)
         for inp in self.inputs:
             if inp == "prompt":
                 feat, mask, pos = data_dict["prompt_feat"], data_dict["prompt_pad_masks"].logical_not(), None
             elif inp in ("mv", "pc"):
                 feat = enc_out[inp]
-                mask, pos = data_dict[inp + "_seg_pad_masks"].logical_not(), fts_pos
+                k = inp + "_seg_pad_masks"
+                mask, pos = inv[k] if k in inv else data_dict[k].logical_not(), fts_pos
             elif inp == "voxel":
                 feat = enc_out[inp]
-                mask, pos = data_dict["voxel_seg_pad_masks"].logical_not(), fts_pos
+                mask = inv["voxel_seg_pad_masks"] if "voxel_seg_pad_masks" in inv else data_dict["voxel_seg_pad_masks"].logical_not()
+                pos = fts_pos
             else:
                 raise NotImplementedError(f"Unknow input type: {inp}")
             input_dict[inp] = [feat, mask, pos]
@@ -192,7 +207,7 @@ class Query3DUnified(nn.Module):
                     feats[0] = feats[0][-1]
                 seg_fts_for_match.append(feats)
         if hasattr(self, "mask_head"):
-            seg_masks = data_dict["seg_pad_masks"].logical_not()
+            seg_masks = inv["seg_pad_masks"] if "seg_pad_masks" in inv else data_dict["seg_pad_masks"].logical_not()
             mask_head_partial = partial(self.mask_head, seg_fts_for_match=seg_fts_for_match, seg_masks=seg_masks,
                                         offline_attn_masks=offline_attn_masks,
                                         skip_prediction=self.skip_query_encoder_mask_pred)
