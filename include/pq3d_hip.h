@@ -216,6 +216,10 @@ typedef struct {
                                      ys[m] = LN_m(x + o_m) (no sum, coef ignored); backward reads dys[m], dx unused */
   void* ys[PQ3D_MAX_GROUPS];
   const float* dys[PQ3D_MAX_GROUPS];
+  /* sum_branches != 0: o[0..M) are PARTIAL SUMS of a single branch (the producing GEMM split its K range over M
+   * groups without atomics): y = LN(x + dropout(sum_m o_m)) with gamma[0] / beta[0], statistics at index 0; backward
+   * writes d_o[0] = gradient w.r.t. the sum, dx, dgamma[0], dbeta[0]. */
+  int32_t sum_branches;
   /* residual dropout: y = LN(x + dropout(o_m)) (tgt + self.dropout(tgt2), query_encoder.py:224,304,386); the site
    * is o_m viewed as [R, d], site id drop.site + m.  The backward regenerates the mask for d_o. */
   pq3d_dropout drop;

@@ -40,7 +40,9 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
     y[j] = 0.f;
   }
   const long scene = row / d.rows_per_scene, nscene = d.R / d.rows_per_scene;
-  const int mlo = d.independent ? blockIdx.y : 0, mhi = d.independent ? blockIdx.y + 1 : d.M;
+  // sum_branches: the M inputs are PARTIAL SUMS of one branch (deterministic K-split of the producing GEMM): one
+  // LayerNorm of x + dropout(sum_m o_m), statistics / gamma / beta of index 0
+  const int mlo = d.independent ? blockIdx.y : 0, mhi = d.independent ? blockIdx.y + 1 : (d.sum_branches ? 1 : d.M);
   const bool drop = drop_on(d.drop);
   for (int m = mlo; m < mhi; ++m) {
     float v[PL], ov[PL];
@@ -48,6 +50,14 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
     for (int j = 0; j < PL; ++j) {
       const int c = lane + 64 * j;
       ov[j] = c < d.d ? load_elem(d.o[m], d.dt_o, base + c) : 0.f;
+    }
+    if (d.sum_branches) {
+      for (int p = 1; p < d.M; ++p)
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+          const int c = lane + 64 * j;
+          ov[j] += c < d.d ? load_elem(d.o[p], d.dt_o, base + c) : 0.f;
+        }
     }
     if (drop) {   // uniform branch around pure ALU: residual dropout of branch m (site drop.site + m)
       const DropState ds = drop_init(d.drop, m, d.d);
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
 #pragma unroll
     for (int j = 0; j < PL; ++j) v[j] = (lane + 64 * j < d.d) ? xr[j] + ov[j] : 0.f;
     const RowStats st = row_stats<PL>(v, d.d, lane, d.eps);
-    const float w = d.independent ? 1.f : (d.coef ? d.coef[m * nscene + scene] : 1.f / (float)d.M);
+    const float w = (d.independent || d.sum_branches) ? 1.f : (d.coef ? d.coef[m * nscene + scene] : 1.f / (float)d.M);
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
       const int c = lane + 64 * j;
@@ -113,6 +123,14 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
         ndy[j] = dyp[base + c];
       } else { xv[j] = 0.f; ov[j] = 0.f; ndy[j] = 0.f; }
     }
+    if (d.sum_branches) {
+      for (int p = 1; p < d.M; ++p)
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+          const int c = lane + 64 * j;
+          if (c < d.d) ov[j] += load_elem(d.o[p], d.dt_o, base + c);
+        }
+    }
     if (drop) {
       nkeep = 0;
 #pragma unroll
@@ -133,7 +151,8 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
     for (int j = 0; j < PL; ++j) { v[j] = nv[j]; dyr[j] = ndy[j]; }
     const unsigned keep = nkeep;
     const float mean = d.mean[(long)m * d.R + row], rstd = d.rstd[(long)m * d.R + row];
-    const float w = d.independent ? 1.f : (d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M);
+    const float w = (d.independent || d.sum_branches) ? 1.f
+                    : (d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M);
     if (row + nwaves < d.R) fetch(row + nwaves);
     float xh[PL], dz[PL];
     float s1 = 0.f, s2 = 0.f;
@@ -159,7 +178,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
         const float g = rstd * (dz[j] - s1 - xh[j] * s2);
         d.d_o[m][base + c] = drop ? (((keep >> j) & 1u) ? g * dst.scale : 0.f) : g;
         if (d.dx && !d.independent) {
-          if (d.M == 1) d.dx[base + c] = g;
+          if (d.M == 1 || d.sum_branches) d.dx[base + c] = g;
           else unsafeAtomicAdd(&d.dx[base + c], g);
         }
       }
@@ -188,9 +207,11 @@ int check_ln(const pq3d_ln_desc& d, bool bwd) {
   PQ_CHECK_ARG(d.rows_per_scene >= 1 && (d.R % d.rows_per_scene) == 0, "pq3d_add_ln: R % rows_per_scene != 0");
   PQ_CHECK_ARG(d.mean && d.rstd, "pq3d_add_ln: null mean/rstd");
   PQ_CHECK_DROP(d.drop, d.R, d.d, "pq3d_add_ln");
+  PQ_CHECK_ARG(!(d.sum_branches && (d.independent || d.coef)), "pq3d_add_ln: sum_branches excludes independent / coef");
   for (int m = 0; m < d.M; ++m) {
-    PQ_CHECK_ARG(d.o[m] && d.gamma[m] && d.beta[m], "pq3d_add_ln: null o/gamma/beta");
-    if (bwd) PQ_CHECK_ARG(d.d_o[m] && d.dgamma[m] && d.dbeta[m], "pq3d_add_ln_bwd: null grads");
+    const bool first = m == 0 || !d.sum_branches;   // sum mode: one gamma / beta / d_o (index 0)
+    PQ_CHECK_ARG(d.o[m] && (!first || (d.gamma[m] && d.beta[m])), "pq3d_add_ln: null o/gamma/beta");
+    if (bwd && first) PQ_CHECK_ARG(d.d_o[m] && d.dgamma[m] && d.dbeta[m], "pq3d_add_ln_bwd: null grads");
   }
   if (d.independent) {
     for (int m = 0; m < d.M; ++m) PQ_CHECK_ARG(bwd ? d.dys[m] != nullptr : d.ys[m] != nullptr, "pq3d_add_ln: null ys/dys");
@@ -227,9 +248,9 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   {   // zero the atomics targets in one launch (not hipMemsetAsync: see common.h ZeroList)
     ZeroList z;
-    for (int m = 0; m < d.M && !d.accumulate; ++m) { z.add(d.dgamma[m], d.d); z.add(d.dbeta[m], d.d); }
+    for (int m = 0; m < (d.sum_branches ? 1 : d.M) && !d.accumulate; ++m) { z.add(d.dgamma[m], d.d); z.add(d.dbeta[m], d.d); }
     if (z.full()) { if (int e = pq3d_zero_launch(z, s)) return e; z.n = 0; }
-    if (d.R > 0 && d.dx && d.M > 1 && !d.independent) z.add(d.dx, (long)d.R * d.d);
+    if (d.R > 0 && d.dx && d.M > 1 && !d.independent && !d.sum_branches) z.add(d.dx, (long)d.R * d.d);
     if (int e = pq3d_zero_launch(z, s)) return e;
   }
   if (d.R == 0) return 0;
@@ -238,7 +259,7 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   long nb = (d.R + rpw * WPB - 1) / (rpw * WPB);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
-  dim3 grid((unsigned)nb, d.M);
+  dim3 grid((unsigned)nb, d.sum_branches ? 1 : d.M);
   LN_DISPATCH(add_ln_bwd_kernel, grid)
   PQ_LAUNCH_CHECK();
   return 0;

@@ -163,7 +163,7 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
     return cls, mlog, amask
 
 
-def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.float32, drop=None):
+def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.float32, drop=None, sum_branches=False):
     M = len(os_)
     dm = os_[0].shape[-1]
     R = os_[0].numel() // dm
@@ -171,6 +171,7 @@ def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.fl
     mean = torch.empty(M, R, dtype=torch.float32, device=y.device)
     rstd = torch.empty_like(mean)
     d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd, drop)
+    d.sum_branches = int(sum_branches)
     nb = (M + 1 + (x is not None)) * R * dm * 4.0
     L.check(timed("pq3d_add_ln_fwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_fwd, C.byref(d), L.stream()),
             "pq3d_add_ln_fwd")
@@ -178,18 +179,18 @@ def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.fl
 
 
 def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dgs, dbs, want_dx=True, dup_dx=False,
-            drop=None):
+            drop=None, sum_branches=False):
     """Returns (dx or None, d_o [M,...] fp32 stacked); dgamma/dbeta accumulate into the arena views dgs/dbs.
     dup_dx: also write the (single-branch) input gradient to a second buffer even without a residual input."""
     M = len(os_)
     dm = os_[0].shape[-1]
     R = os_[0].numel() // dm
     dev = dy.device
-    d_o = torch.empty(M, *os_[0].shape, dtype=torch.float32, device=dev)
+    d_o = torch.empty(1 if sum_branches else M, *os_[0].shape, dtype=torch.float32, device=dev)
     dx = torch.empty(os_[0].shape, dtype=torch.float32, device=dev) if ((x is not None and want_dx) or dup_dx) else None
     d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd, drop)
-    d.dy, d.dx, d.accumulate = L.ptr(dy), L.ptr(dx), 1
-    for m in range(M):
+    d.dy, d.dx, d.accumulate, d.sum_branches = L.ptr(dy), L.ptr(dx), 1, int(sum_branches)
+    for m in range(1 if sum_branches else M):
         d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_o[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
     nb = (3 * M + 1 + (x is not None)) * R * dm * 4.0
     L.check(timed("pq3d_add_ln_bwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_bwd, C.byref(d), L.stream()),
@@ -378,22 +379,21 @@ class _FusedDecoder(Function):
                 pre = torch.empty_like(h) if spec.act == "gelu" else None
                 L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
                        C2=[pre], ct=ct, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi)
-                # z = x2 + b2 + h W2^T in one GEMM (residual through the "+aux" epilogue): LayerNorm then reads one
-                # tensor.  Deliberately NOT split-K: atomics would make the forward pass non-deterministic at rounding
-                # level and cost the bit-exact padding-invariance / scene-independence properties (tests).
-                # With residual dropout the branch output must be dropped BEFORE the residual is added, so the add moves
-                # back into the LayerNorm kernel (z = branch only).
-                z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                if dr_fr is None:
-                    L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()],
-                           Cs=[z], aux=[x2], act_grad="add", ct=ct, lda=F_, ldb=F_, ldc=d)
-                    x3, mean_f, rstd_f = _ln_fwd(None, [z], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()],
-                                                 ffn.norm.eps, None, Nq)
-                else:
-                    L.gemm(M=R, N=d, K=F_, A=[h], B=[ffn.linear2.weight.detach()], bias=[ffn.linear2.bias.detach()],
-                           Cs=[z], ct=ct, lda=F_, ldb=F_, ldc=d)
-                    x3, mean_f, rstd_f = _ln_fwd(x2, [z], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()],
-                                                 ffn.norm.eps, None, Nq, drop=dr_fr)
+                # linear2 has K = F = 2048 on only M/64 x d/64 = 52 tiles: a long serial k-loop on a fifth of the chip.  Its K
+                # range is split over KS groups of ONE grouped launch (no atomics: each group owns an output), and the
+                # LayerNorm kernel adds the partial sums (+ residual, + dropout of the summed branch) in a fixed order --
+                # deterministic, so the bit-exact padding-invariance / scene-independence properties hold.
+                KS = 4 if F_ % (4 * 64) == 0 else 1
+                zp = torch.empty(KS, B, Nq, d, dtype=torch.float32, device=dev)
+                Fk = F_ // KS
+                hv, w2 = h.view(R, F_), ffn.linear2.weight.detach()
+                L.gemm(M=R, N=d, K=Fk, A=[hv[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
+                       B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
+                       bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=ct, lda=F_,
+                       ldb=F_, ldc=d)
+                z = [zp[k] for k in range(KS)]
+                x3, mean_f, rstd_f = _ln_fwd(x2, z, [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps,
+                                             None, Nq, drop=dr_fr, sum_branches=True)
                 rec.update(h=h, pre=pre, z=z, mean_f=mean_f, rstd_f=rstd_f)
                 tape.append(rec)
                 x = x3
@@ -523,15 +523,11 @@ class _FusedDecoder(Function):
             # ---------------- FFN backward
             ffn = layer.ffn
             F_ = ffn.linear1.out_features
-            if rec["dr_fr"] is None:
-                dx2r, dy = _ln_bwd(None, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps,
-                                   None, Nq, rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
-                                   dup_dx=True)
-            else:   # dx2r = residual-branch gradient, dy = dropout-masked gradient of the linear2 output
-                dx2r, dy = _ln_bwd(x2, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps,
-                                   None, Nq, rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
-                                   drop=rec["dr_fr"])
-            dy = dy[0]   # d z: gradient of the linear2 output AND (second copy dx2r) of the residual branch
+            # dx2r = residual-branch gradient, dy = (dropout-masked) gradient of the linear2 output (sum of the partials)
+            dx2r, dy = _ln_bwd(x2, rec["z"], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq,
+                               rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
+                               drop=rec["dr_fr"], sum_branches=True)
+            dy = dy[0]
             dhp = torch.empty(B, Nq, F_, dtype=ad, device=dev)
             # inner dropout (ReLU only on this path): the saved h is post-dropout, so [h > 0] already carries the
             # keep-mask and only the 1/(1-p) factor is left -> alpha

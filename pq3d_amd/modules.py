@@ -304,9 +304,15 @@ class FFNLayer(_PostNormBase):
         ctx = self._drop_ctx(tgt.device, _drop)
         h = ops.linear(tgt, self.linear1.weight, self.linear1.bias, ct=ct, act=self.activation,
                        out_dtype=ops.act_dtype(ct), drop=self._drop(ctx, ops.DROP_FFN_INNER, tgt.device))
-        y = ops.linear(h, self.linear2.weight, self.linear2.bias, ct=ct)
-        return ops.add_layernorm(tgt, [y], [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
-                                 drop=self._drop(ctx, ops.DROP_FFN_RES, tgt.device))
+        # linear2's K range is split into 4 partial GEMMs whose fp32 outputs the LayerNorm kernel adds in a fixed order
+        # (same rounding as the fused executor, which runs the 4 parts as one grouped launch: fused.py)
+        F_ = h.shape[-1]
+        KS = 4 if F_ % (4 * 64) == 0 else 1
+        Fk = F_ // KS
+        ys = [ops.linear(h[..., k * Fk:(k + 1) * Fk], self.linear2.weight[:, k * Fk:(k + 1) * Fk],
+                         self.linear2.bias if k == 0 else None, ct=ct) for k in range(KS)]
+        return ops.add_layernorm(tgt, ys, [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
+                                 drop=self._drop(ctx, ops.DROP_FFN_RES, tgt.device), sum_branches=True)
 
 
 class QueryEncoderLayer(_PostNormBase):

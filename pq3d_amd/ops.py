@@ -327,15 +327,18 @@ def _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd, dr
     d.dt_o, d.dt_y, d.eps = L.dt_of(os_[0]), (L.dt_of(y) if y is not None else 0), eps
     d.x, d.coef, d.y, d.mean, d.rstd = L.ptr(x), L.ptr(coef), L.ptr(y), L.ptr(mean), L.ptr(rstd)
     for m in range(len(os_)):
-        d.o[m], d.gamma[m], d.beta[m] = L.ptr(os_[m]), L.ptr(gammas[m]), L.ptr(betas[m])
+        d.o[m] = L.ptr(os_[m])
+    for m in range(len(gammas)):     # fewer than len(os_) in sum_branches mode (one LayerNorm over partial sums)
+        d.gamma[m], d.beta[m] = L.ptr(gammas[m]), L.ptr(betas[m])
     return d
 
 
 class _AddLN(Function):
     @staticmethod
-    def forward(ctx, x, coef, eps, rows_per_scene, out_dtype, M, drop, *t):
+    def forward(ctx, x, coef, eps, rows_per_scene, out_dtype, M, drop, sum_branches, *t):
+        G = 1 if sum_branches else M      # sum_branches: the M inputs are partial sums of ONE branch -> one gamma / beta
         os_ = [_c(a) for a in t[:M]]
-        gammas, betas = [_c(a) for a in t[M:2 * M]], [_c(a) for a in t[2 * M:3 * M]]
+        gammas, betas = [_c(a) for a in t[M:M + G]], [_c(a) for a in t[M + G:M + 2 * G]]
         x, coef = _c(x), _c(coef)
         dm = os_[0].shape[-1]
         R = os_[0].numel() // dm
@@ -343,29 +346,30 @@ class _AddLN(Function):
         mean = _empty(M, R, dtype=torch.float32, device=y.device)
         rstd = torch.empty_like(mean)
         d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd, drop)
+        d.sum_branches = int(sum_branches)
         nb = (M + 1 + (x is not None)) * R * dm * 4.0
         L.check(timed("pq3d_add_ln_fwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_fwd, C.byref(d), L.stream()),
                 "pq3d_add_ln_fwd")
         ctx.save_for_backward(x, coef, mean, rstd, *os_, *gammas, *betas)
-        ctx.cfg = (eps, rows_per_scene, M)
+        ctx.cfg = (eps, rows_per_scene, M, G, bool(sum_branches))
         ctx.drop = drop
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        eps, rows_per_scene, M = ctx.cfg
+        eps, rows_per_scene, M, G, sum_branches = ctx.cfg
         x, coef, mean, rstd = ctx.saved_tensors[:4]
         t = ctx.saved_tensors[4:]
-        os_, gammas, betas = t[:M], t[M:2 * M], t[2 * M:3 * M]
+        os_, gammas, betas = t[:M], t[M:M + G], t[M + G:M + 2 * G]
         dy = dy.contiguous().float()
         dev = dy.device
         dx = _empty(os_[0].shape, dtype=torch.float32, device=dev) if x is not None else None
-        d_os = [_empty(o.shape, dtype=torch.float32, device=dev) for o in os_]
+        d_os = [_empty(o.shape, dtype=torch.float32, device=dev) for o in os_[:G]]
         dgs = [torch.empty_like(g) for g in gammas]
         dbs = [torch.empty_like(b) for b in betas]
         d = _ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd, ctx.drop)
-        d.dy, d.dx = L.ptr(dy), L.ptr(dx)
-        for m in range(M):
+        d.dy, d.dx, d.sum_branches = L.ptr(dy), L.ptr(dx), int(sum_branches)
+        for m in range(G):
             d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_os[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
         R, dm = os_[0].numel() // os_[0].shape[-1], os_[0].shape[-1]
         nb = (3 * M + 1 + (x is not None)) * R * dm * 4.0
@@ -373,18 +377,22 @@ class _AddLN(Function):
                 "pq3d_add_ln_bwd")
         if x is not None and x.dtype != torch.float32:
             dx = dx.to(x.dtype)
+        if sum_branches:      # every partial sum receives the gradient of the sum
+            d_os = [d_os[0]] * M
         d_os = [g if g.dtype == o.dtype else g.to(o.dtype) for g, o in zip(d_os, os_)]
-        return (dx, None, None, None, None, None, None, *d_os, *dgs, *dbs)
+        return (dx, None, None, None, None, None, None, None, *d_os, *dgs, *dbs)
 
 
 def add_layernorm(x, os_: Sequence[torch.Tensor], gammas, betas, *, eps=1e-5, coef=None, rows_per_scene=None,
-                  out_dtype=torch.float32, drop: Optional[L.Drop] = None):
+                  out_dtype=torch.float32, drop: Optional[L.Drop] = None, sum_branches: bool = False):
     """y = sum_m coef[m, scene] * LN_m(x + dropout_m(o_m))   (coef None -> mean over the M branches; x may be None;
-    branch m draws dropout site drop.site + m)."""
+    branch m draws dropout site drop.site + m).  sum_branches: os_ are partial sums of ONE branch (a K-split GEMM):
+    y = LN(x + dropout(sum_m o_m)) with gammas[0] / betas[0]."""
     M = len(os_)
     if rows_per_scene is None:
         rows_per_scene = os_[0].shape[-2] if os_[0].dim() >= 2 else 1
-    return _AddLN.apply(x, coef, float(eps), int(rows_per_scene), out_dtype, M, drop, *os_, *gammas, *betas)
+    return _AddLN.apply(x, coef, float(eps), int(rows_per_scene), out_dtype, M, drop, bool(sum_branches), *os_, *gammas,
+                        *betas)
 
 
 # ------------------------------------------------------------------------------------------------ mask logits
