@@ -117,7 +117,7 @@ def test_bf16_c2_padding_invariance_and_scene_permutation():
         assert torch.equal(base[perm.to(DEV)], out3), "scenes are not independent"
 
 
-@pytest.mark.parametrize("compute,tol", [("fp32", 1e-5), ("bf16", 1e-2)])
+@pytest.mark.parametrize("compute,tol", [("fp32", 1e-5), ("bf16", 3e-2)])
 def test_batch_sharding_reproduces_full_batch_gradients(compute, tol):
     """SURVEY 8e by construction on one GPU: running the two halves of a batch separately (what two data-parallel ranks
     do) and averaging their gradients equals the full-batch step -- scenes never interact (forward bit-exact per scene),
