@@ -220,6 +220,7 @@ typedef struct {
    * groups without atomics): y = LN(x + dropout(sum_m o_m)) with gamma[0] / beta[0], statistics at index 0; backward
    * writes d_o[0] = gradient w.r.t. the sum, dx, dgamma[0], dbeta[0]. */
   int32_t sum_branches;
+  float* osum;   /* forward, sum_branches only, optional: receives sum_m o_m [R, d] (fp32) */
   /* residual dropout: y = LN(x + dropout(o_m)) (tgt + self.dropout(tgt2), query_encoder.py:224,304,386); the site
    * is o_m viewed as [R, d], site id drop.site + m.  The backward regenerates the mask for d_o. */
   pq3d_dropout drop;

@@ -58,6 +58,13 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
           const int c = lane + 64 * j;
           ov[j] += c < d.d ? load_elem(d.o[p], d.dt_o, base + c) : 0.f;
         }
+      if (d.osum) {   // the summed branch, kept for the backward pass (which then reads one tensor instead of M)
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+          const int c = lane + 64 * j;
+          if (c < d.d) d.osum[base + c] = ov[j];
+        }
+      }
     }
     if (drop) {   // uniform branch around pure ALU: residual dropout of branch m (site drop.site + m)
       const DropState ds = drop_init(d.drop, m, d.d);

@@ -163,7 +163,8 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
     return cls, mlog, amask
 
 
-def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.float32, drop=None, sum_branches=False):
+def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.float32, drop=None, sum_branches=False,
+            osum=None):
     M = len(os_)
     dm = os_[0].shape[-1]
     R = os_[0].numel() // dm
@@ -171,7 +172,7 @@ def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.fl
     mean = torch.empty(M, R, dtype=torch.float32, device=y.device)
     rstd = torch.empty_like(mean)
     d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, y, mean, rstd, drop)
-    d.sum_branches = int(sum_branches)
+    d.sum_branches, d.osum = int(sum_branches), L.ptr(osum)
     nb = (M + 1 + (x is not None)) * R * dm * 4.0
     L.check(timed("pq3d_add_ln_fwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_fwd, C.byref(d), L.stream()),
             "pq3d_add_ln_fwd")
@@ -391,9 +392,10 @@ class _FusedDecoder(Function):
                        B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
                        bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=ct, lda=F_,
                        ldb=F_, ldc=d)
-                z = [zp[k] for k in range(KS)]
-                x3, mean_f, rstd_f = _ln_fwd(x2, z, [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps,
-                                             None, Nq, drop=dr_fr, sum_branches=True)
+                z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)   # sum of the partials, kept for the backward
+                x3, mean_f, rstd_f = _ln_fwd(x2, [zp[k] for k in range(KS)], [ffn.norm.weight.detach()],
+                                             [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq, drop=dr_fr,
+                                             sum_branches=True, osum=z)
                 rec.update(h=h, pre=pre, z=z, mean_f=mean_f, rstd_f=rstd_f)
                 tape.append(rec)
                 x = x3
@@ -524,9 +526,9 @@ class _FusedDecoder(Function):
             ffn = layer.ffn
             F_ = ffn.linear1.out_features
             # dx2r = residual-branch gradient, dy = (dropout-masked) gradient of the linear2 output (sum of the partials)
-            dx2r, dy = _ln_bwd(x2, rec["z"], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq,
-                               rec["mean_f"], rec["rstd_f"], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
-                               drop=rec["dr_fr"], sum_branches=True)
+            dx2r, dy = _ln_bwd(x2, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq,
+                               rec["mean_f"][:1], rec["rstd_f"][:1], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
+                               drop=rec["dr_fr"])
             dy = dy[0]
             dhp = torch.empty(B, Nq, F_, dtype=ad, device=dev)
             # inner dropout (ReLU only on this path): the saved h is post-dropout, so [h > 0] already carries the
