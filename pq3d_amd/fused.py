@@ -25,7 +25,7 @@ from torch.autograd import Function
 
 from . import _lib as L
 from . import ops
-from ._lib import BF16, F32
+from ._lib import BF16
 from .profiler import timed
 
 MAXG = L.MAXG

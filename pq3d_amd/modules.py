@@ -15,9 +15,8 @@ path and the test-side mask generator agree.  eval() or p == 0 turns it off.
 from __future__ import annotations
 
 import copy
-import math
 from functools import partial
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn

@@ -6,7 +6,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 from torch.autograd import Function

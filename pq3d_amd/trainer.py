@@ -17,7 +17,7 @@ flat gradient buffer, which is also what the data-parallel all-reduce operates o
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, Optional, Sequence
 
 import torch
 

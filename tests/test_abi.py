@@ -5,10 +5,8 @@ import ctypes
 import os
 import re
 import subprocess
-import sys
 
 import pytest
-import torch
 
 from pq3d_amd import _lib, build
 from tests import util

@@ -7,8 +7,6 @@ the result (changing padded feature rows leaves every output bit-identical), per
 import pytest
 import torch
 
-from pq3d_amd import synth
-from pq3d_amd.model import Query3DUnified, make_cfg
 from pq3d_amd.modules import set_compute
 from tests import util
 

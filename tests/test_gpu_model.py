@@ -11,7 +11,6 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import pq3d_oracle as O
 from pq3d_amd import synth
 from pq3d_amd.modules import QueryMaskEncoder, set_compute
 from tests import util
