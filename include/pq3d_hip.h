@@ -446,6 +446,37 @@ int pq3d_pad_sequence_2d(const void* src, const int64_t* offsets, const int32_t*
                          uint8_t* mask, int32_t B, int64_t H, int64_t W, int64_t D, int32_t elem_size, const void* pad_value,
                          void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * PointNet++ point-set operators (the reference's only native code:
+ * modules/third_party/pointnet2/_ext_src/src, bound in bindings.cpp:6-19 and wrapped by pointnet2_utils.py).  fp32
+ * coordinates / features, int32 indices, tensors laid out as those wrappers pass them.
+ *   pq3d_furthest_point_sampling : xyz [B,N,3] -> idx [B,M]; starts at point 0, skips points with |p|^2 <= 1e-3, running
+ *                                  min squared distance initialised to 1e10 (sampling_gpu.cu:70-172, sampling.cpp);
+ *                                  ties go to the smaller index; N <= 8192
+ *   pq3d_ball_query              : first `nsample` point indices (in index order) with squared distance < radius^2 from
+ *                                  each centre new_xyz [B,M,3]; unfilled slots repeat the first hit
+ *                                  (ball_query_gpu.cu:9-44) -> idx [B,M,nsample]
+ *   pq3d_gather_points(_grad)    : out[b,c,i] = points[b,c,idx[b,i]], idx [B,L]: gather_points (L = m,
+ *                                  sampling_gpu.cu:8-20) and group_points (L = npoint*nsample, group_points_gpu.cu:8-30);
+ *                                  the gradient scatter-adds into a zeroed [B,C,N]
+ *   pq3d_three_nn                : 3 nearest known [B,M,3] of every unknown [B,N,3]: SQUARED distances + indices
+ *                                  (interpolate_gpu.cu:9-58; the Python wrapper takes the sqrt)
+ *   pq3d_three_interpolate(_grad): out[b,c,i] = sum_k points[b,c,idx[b,i,k]] weight[b,i,k] (interpolate_gpu.cu:72-143)
+ * ------------------------------------------------------------------------------------------------ */
+int pq3d_furthest_point_sampling(const float* xyz, int32_t* idx, int32_t B, int32_t N, int32_t M, void* stream);
+int pq3d_ball_query(const float* new_xyz, const float* xyz, int32_t* idx, int32_t B, int32_t N, int32_t M, float radius,
+                    int32_t nsample, void* stream);
+int pq3d_gather_points(const float* points, const int32_t* idx, float* out, int32_t B, int32_t C, int32_t N, int64_t L,
+                       void* stream);
+int pq3d_gather_points_grad(const float* grad_out, const int32_t* idx, float* grad_points, int32_t B, int32_t C, int32_t N,
+                            int64_t L, void* stream);
+int pq3d_three_nn(const float* unknown, const float* known, float* dist2, int32_t* idx, int32_t B, int32_t N, int32_t M,
+                  void* stream);
+int pq3d_three_interpolate(const float* points, const int32_t* idx, const float* weight, float* out, int32_t B, int32_t C,
+                           int32_t M, int32_t N, void* stream);
+int pq3d_three_interpolate_grad(const float* grad_out, const int32_t* idx, const float* weight, float* grad_points, int32_t B,
+                                int32_t C, int32_t M, int32_t N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
