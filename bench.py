@@ -38,8 +38,8 @@ CONFIGS = {
     "c2": dict(B=8, Ns=1024, Nq=100, d=256, H=8, L=4, memories=["voxel", "mv", "pc"], heads=[], use_self_mask=False),
     "c4": dict(B=4, Ns=4096, Nq=200, d=256, H=8, L=4, memories=["voxel", "mv", "pc"], heads=["mask"],
                use_self_mask=True),
-    # c5 (BASELINE config 5, per GPU): 6 layers + caption head; decoder on the HIP kernels, HF T5-small body (random init,
-    # teacher-forced T_r = 32) on stock PyTorch-ROCm ops and reported separately ("t5_body")
+    # c5 (BASELINE config 5, per GPU): 6 layers + caption head (T5-small decoder, random init, teacher-forced T_r = 32), all on
+    # the HIP kernels; the caption body alone is also timed separately ("t5_body")
     "c5": dict(B=16, Ns=2048, Nq=100, d=256, H=8, L=6, memories=["voxel", "mv", "pc"], heads=["generation"],
                use_self_mask=False, Tr=32),
     "c1": dict(B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=[], use_self_mask=False, spatial=False,
@@ -373,8 +373,8 @@ def main():
             for _ in range(3):
                 head_only()
             result["t5_body"] = {"ms_per_step_eager": timed_loop(head_only, max(3, args.steps // 5)),
-                                 "impl": "HF T5ForConditionalGeneration (t5-small architecture, random init) on stock "
-                                         "PyTorch-ROCm ops; input_proj on the HIP kernels",
+                                 "impl": "T5-small decoder (random init, HF parameter layout) restated on the HIP kernels "
+                                         "(pq3d_amd/t5.py) + input_proj; teacher-forced, T_r = %d" % c["Tr"],
                                  "params": sum(p.numel() for p in gh.parameters())}
         if world == 1 and args.cpu_steps > 0 and "generation" not in c["heads"]:
             result["cpu_baseline"] = cpu_baseline(c, sd, dd_cpu, args.cpu_steps, 2)

@@ -477,6 +477,21 @@ int pq3d_three_interpolate(const float* points, const int32_t* idx, const float*
 int pq3d_three_interpolate_grad(const float* grad_out, const int32_t* idx, const float* weight, float* grad_points, int32_t B,
                                 int32_t C, int32_t M, int32_t N, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pieces of the generation head's decoder body (third-party arithmetic: HF transformers
+ * T5ForConditionalGeneration as driven by modules/heads/generation_head.py:20-30) that the kernels above do not cover:
+ *   pq3d_rmsnorm_fwd/bwd  : T5LayerNorm  y = x rsqrt(mean(x^2) + eps) w  (saves rstd [R]); backward writes dx and adds
+ *                           (accumulate != 0) or stores the weight gradient
+ *   pq3d_embedding_fwd / _bwd_acc : token embedding rows and their scatter-add gradient (dtable is accumulated into)
+ * Everything else of the body is pq3d_gemm (bias-free projections, LM head), pq3d_attn_fwd/bwd (scale 1, additive
+ * relative-position + causal bias, key padding) and pq3d_cross_entropy_*.
+ * ------------------------------------------------------------------------------------------------ */
+int pq3d_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t R, int32_t d, float eps, void* stream);
+int pq3d_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw, int64_t R,
+                     int32_t d, int32_t accumulate, void* stream);
+int pq3d_embedding_fwd(const float* table, const int64_t* ids, float* out, int64_t R, int32_t d, void* stream);
+int pq3d_embedding_bwd_acc(const float* dout, const int64_t* ids, float* dtable, int64_t R, int32_t d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -664,3 +664,34 @@ extern "C" int pq3d_pad_sequence_2d(const void* src, const int64_t* offsets, con
   PQ_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ embedding rows
+// out[r,:] = table[ids[r],:] (nn.Embedding of the T5 decoder input tokens) and its scatter-add gradient.
+namespace {
+__global__ void embedding_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids, float* __restrict__ out,
+                                     long R, int d) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < R * d; i += (long)gridDim.x * blockDim.x)
+    out[i] = table[ids[i / d] * d + i % d];
+}
+__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ ids, float* __restrict__ dtable,
+                                     long R, int d) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < R * d; i += (long)gridDim.x * blockDim.x)
+    unsafeAtomicAdd(&dtable[ids[i / d] * d + i % d], dout[i]);
+}
+}  // namespace
+extern "C" int pq3d_embedding_fwd(const float* table, const int64_t* ids, float* out, int64_t R, int32_t d, void* stream) {
+  PQ_CHECK_ARG(table && ids && out && R >= 0 && d >= 1, "pq3d_embedding_fwd: bad args");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid1d(R * d)), dim3(256), 0, (hipStream_t)stream, table, ids, out, (long)R, d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pq3d_embedding_bwd_acc(const float* dout, const int64_t* ids, float* dtable, int64_t R, int32_t d,
+                                      void* stream) {
+  PQ_CHECK_ARG(dout && ids && dtable && R >= 0 && d >= 1, "pq3d_embedding_bwd_acc: bad args");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid1d(R * d)), dim3(256), 0, (hipStream_t)stream, dout, ids, dtable, (long)R,
+                     d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

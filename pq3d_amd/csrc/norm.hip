@@ -271,3 +271,107 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   PQ_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ RMSNorm (T5)
+// T5LayerNorm (HF transformers modeling_t5.py, the generation head's third-party body):
+// y = x * rsqrt(mean(x^2) + eps) * w -- no mean subtraction, no bias.  One wave per row, fp32.
+namespace {
+template <int PL>
+__global__ __launch_bounds__(WPB * 64) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ y, float* __restrict__ rstd, long R, int d,
+                                                               float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float v[PL], s = 0.f;
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    const int c = lane + 64 * j;
+    v[j] = c < d ? x[row * d + c] : 0.f;
+    s += v[j] * v[j];
+  }
+  const float r = 1.f / sqrtf(wave_sum(s) / (float)d + eps);
+#pragma unroll
+  for (int j = 0; j < PL; ++j) {
+    const int c = lane + 64 * j;
+    if (c < d) y[row * d + c] = v[j] * r * w[c];
+  }
+  if (lane == 0) rstd[row] = r;
+}
+// dx = r (g - xh mean(g xh)),  g = dy w,  xh = x r;  dw += sum_rows dy xh
+template <int PL>
+__global__ __launch_bounds__(WPB * 64) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ rstd, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, float* __restrict__ dw, long R, int d) {
+  __shared__ float red[WPB][64 * PL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wave_id = (long)blockIdx.x * WPB + wave, nwaves = (long)gridDim.x * WPB;
+  float acc[PL], wv[PL];
+#pragma unroll
+  for (int j = 0; j < PL; ++j) { acc[j] = 0.f; wv[j] = (lane + 64 * j < d) ? w[lane + 64 * j] : 0.f; }
+  for (long row = wave_id; row < R; row += nwaves) {
+    const float r = rstd[row];
+    float xh[PL], g[PL], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      const float dyv = c < d ? dy[row * d + c] : 0.f;
+      xh[j] = c < d ? x[row * d + c] * r : 0.f;
+      g[j] = dyv * wv[j];
+      acc[j] += dyv * xh[j];
+      s += g[j] * xh[j];
+    }
+    s = wave_sum(s) / (float)d;
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d) dx[row * d + c] = r * (g[j] - xh[j] * s);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PL; ++j) red[wave][lane + 64 * j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += WPB * 64) {
+    float sres = 0.f;
+#pragma unroll
+    for (int wv_ = 0; wv_ < WPB; ++wv_) sres += red[wv_][c];
+    unsafeAtomicAdd(&dw[c], sres);
+  }
+}
+}  // namespace
+
+#define RMS_DISPATCH(kernel, grid, ...)                                                                  \
+  if (d <= 64) hipLaunchKernelGGL((kernel<1>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);                \
+  else if (d <= 128) hipLaunchKernelGGL((kernel<2>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);          \
+  else if (d <= 256) hipLaunchKernelGGL((kernel<4>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);          \
+  else if (d <= 512) hipLaunchKernelGGL((kernel<8>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);          \
+  else hipLaunchKernelGGL((kernel<16>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);
+
+extern "C" int pq3d_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t R, int32_t d, float eps,
+                                void* stream) {
+  PQ_CHECK_ARG(x && w && y && rstd && R >= 0 && d >= 1 && d <= 64 * MAXPL, "pq3d_rmsnorm_fwd: bad args (d <= 1024)");
+  if (R == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)((R + WPB - 1) / WPB));
+  RMS_DISPATCH(rmsnorm_fwd_kernel, grid, x, w, y, rstd, (long)R, d, eps)
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw,
+                                int64_t R, int32_t d, int32_t accumulate, void* stream) {
+  PQ_CHECK_ARG(x && w && rstd && dy && dx && dw && R >= 0 && d >= 1 && d <= 64 * MAXPL, "pq3d_rmsnorm_bwd: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    ZeroList z;
+    z.add(dw, d);
+    if (int e = pq3d_zero_launch(z, s)) return e;
+  }
+  if (R == 0) return 0;
+  long nb = (R + 2 * WPB - 1) / (2 * WPB);
+  if (nb > 1024) nb = 1024;
+  dim3 grid((unsigned)nb);
+  RMS_DISPATCH(rmsnorm_bwd_kernel, grid, x, w, rstd, dy, dx, dw, (long)R, d)
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

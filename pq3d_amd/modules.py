@@ -595,15 +595,18 @@ T5_ARCH = {   # architectures of the HF checkpoints the reference names (used on
 
 class T5(_PostNormBase):
     """modules/heads/generation_head.py:8-30.  The in-repo part -- ``input_proj`` = Linear(d -> d_model) + LayerNorm --
-    runs on the HIP kernels; the decoder body is the third-party HF ``T5ForConditionalGeneration`` exactly as the
-    reference uses it (encoder bypassed through ``encoder_outputs``, cross-attending to the N_q query tokens under
-    ``attention_mask``), on stock PyTorch-ROCm ops: hand-written kernels for it are SURVEY 8f-3 ("next").
+    runs on the HIP kernels, and so does the teacher-forced decoder body (``body='hip'``, pq3d_amd/t5.py: the
+    third-party HF ``T5ForConditionalGeneration`` decoder restated on this package's ops, reading the HF module's
+    parameters); greedy generation (eval, labels=None) and ``body='hf'`` run the stock HF model exactly as the reference
+    uses it (encoder bypassed through ``encoder_outputs``, cross-attending to the N_q query tokens).
     ``variant`` is loaded with ``from_pretrained`` when it is available locally; without network the same architecture
     is built with random weights (``T5_ARCH`` or an explicit ``hf_config`` dict) -- state_dict keys are identical, so
     a reference checkpoint loads over it."""
 
-    def __init__(self, cfg, variant="t5-small", input_size=768, use_projection=True, hf_config=None, **kwargs):
+    def __init__(self, cfg, variant="t5-small", input_size=768, use_projection=True, hf_config=None, body="hip", **kwargs):
         super().__init__()
+        assert body in ("hip", "hf")
+        self.body = body   # 'hip': teacher-forced decoder on this package's kernels (pq3d_amd/t5.py); 'hf': stock HF forward
         from transformers import T5Config, T5ForConditionalGeneration   # third-party body (transformers, requirements.txt:63)
         if hf_config is not None:
             self.model = T5ForConditionalGeneration(T5Config(**dict(hf_config)))
@@ -626,6 +629,15 @@ class T5(_PostNormBase):
         from transformers.modeling_outputs import BaseModelOutput
         if self.use_projection:
             query_embeds = linear_ln_forward(self.input_proj, query_embeds, self.ct)
+        if labels is not None and self.body == "hip":
+            from . import t5
+            if self.training:   # standalone use: make sure every call draws from a fresh RNG epoch (a parent model's
+                rng = ops.drop_rng(query_embeds.device)   # begin_dropout_step marks this module as managed instead)
+                if self._drop_managed != rng.epoch:
+                    if rng.epoch == self._drop_epoch:
+                        rng.advance()
+                    self._drop_epoch = rng.epoch
+            return t5.decoder_logits(self.model, query_embeds, attention_masks, labels, self.ct, self.training)
         enc = BaseModelOutput(last_hidden_state=query_embeds)
         if labels is not None:
             return self.model(encoder_outputs=enc, attention_mask=attention_masks, labels=labels).logits

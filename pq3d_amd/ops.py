@@ -183,8 +183,9 @@ def fourier(xyz: torch.Tensor, cmin: torch.Tensor, cmax: torch.Tensor, gauss_B: 
 # ------------------------------------------------------------------------------------------------ linear
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value, drop=None):
-        x, x2, w, fill_flag = _c(x), _c(x2), _c(w), _c(fill_flag)
+    def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value, drop=None, residual=None):
+        x, x2, w, fill_flag, residual = _c(x), _c(x2), _c(w), _c(fill_flag), _c(residual)
+        assert residual is None or (act is None and drop is None), "residual add excludes activation / dropout"
         K = x.shape[-1]
         R = x.numel() // K
         N = w.shape[0]
@@ -192,7 +193,9 @@ class _Linear(Function):
         pre = _empty(y.shape, dtype=out_dtype, device=x.device) if act == "gelu" else None
         rm = _c(row_mask)
         L.gemm(M=R, N=N, K=K, A=[x], A2=[x2], B=[w], bias=[b], Cs=[y], C2=[pre], row_mask=[rm], ct=ct,
-               lda=K, ldb=K, ldc=N, act=act, row_fill_flag=fill_flag, row_fill=fill_value, drop=drop)
+               lda=K, ldb=K, ldc=N, act=act, row_fill_flag=fill_flag, row_fill=fill_value, drop=drop,
+               aux=[residual] if residual is not None else None, act_grad="add" if residual is not None else None)
+        ctx.has_res = residual is not None
         ctx.save_for_backward(x, x2, w, pre if act == "gelu" else (y if act == "relu" else None), rm, fill_flag)
         ctx.ct, ctx.act, ctx.has_b, ctx.drop = ct, act, b is not None, drop
         return y
@@ -233,14 +236,16 @@ class _Linear(Function):
                    colsum=[db] if fuse else None)
         if want_db and db is None:
             db = colsum(g.view(R, N))
-        return dx, dw, db, dx2, None, None, None, None, None, None, None
+        dres = dy.contiguous() if (ctx.has_res and ctx.needs_input_grad[11]) else None
+        return dx, dw, db, dx2, None, None, None, None, None, None, None, dres
 
 
 def linear(x, w, b=None, *, ct: int, x2=None, act: Optional[str] = None, out_dtype=torch.float32, row_mask=None,
-           fill_flag=None, fill_value=0.0, drop: Optional[L.Drop] = None):
+           fill_flag=None, fill_value=0.0, drop: Optional[L.Drop] = None, residual=None):
     """y = act((x + x2) @ w.T + b); rows where row_mask == False are zeroed; rows where fill_flag == True are
-    set to fill_value (masked_fill of whole rows).  (F.linear call sites, see include/pq3d_hip.h)"""
-    return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value), drop)
+    set to fill_value (masked_fill of whole rows); residual (same shape as y) is added in the GEMM epilogue.
+    (F.linear call sites, see include/pq3d_hip.h)"""
+    return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value), drop, residual)
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -620,3 +625,58 @@ def linear_ln_group(xs, Ws, bs, gammas, betas, *, ct: int, eps: float = 1e-5):
     G = len(xs)
     need_dx = any(x.requires_grad for x in xs)
     return _LinearLNGroup.apply(ct, float(eps), G, need_dx, *xs, *Ws, *bs, *gammas, *betas)
+
+
+# ------------------------------------------------------------------------------------------------ T5 body pieces
+class _RMSNorm(Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        x, w = _c(x).float(), _c(w).float()
+        d_ = x.shape[-1]
+        R = x.numel() // d_
+        y = torch.empty_like(x)
+        rstd = _empty(R, dtype=torch.float32, device=x.device)
+        L.check(L.lib().pq3d_rmsnorm_fwd(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(rstd), R, d_, eps, L.stream()), "pq3d_rmsnorm_fwd")
+        ctx.save_for_backward(x, w, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, rstd = ctx.saved_tensors
+        d_ = x.shape[-1]
+        dy = dy.contiguous().float()
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        L.check(L.lib().pq3d_rmsnorm_bwd(L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dy), L.ptr(dx), L.ptr(dw), x.numel() // d_, d_,
+                                         0, L.stream()), "pq3d_rmsnorm_bwd")
+        return dx, dw, None
+
+
+def rmsnorm(x, w, eps: float = 1e-6):
+    """T5LayerNorm: x * rsqrt(mean(x^2) + eps) * w (fp32)."""
+    return _RMSNorm.apply(x, w, float(eps))
+
+
+class _Embedding(Function):
+    @staticmethod
+    def forward(ctx, table, ids):
+        table, ids = _c(table).float(), _c(ids).long()
+        d_ = table.shape[1]
+        out = _empty(*ids.shape, d_, dtype=torch.float32, device=table.device)
+        L.check(L.lib().pq3d_embedding_fwd(L.ptr(table), L.ptr(ids), L.ptr(out), ids.numel(), d_, L.stream()),
+                "pq3d_embedding_fwd")
+        ctx.save_for_backward(ids)
+        ctx.shape = table.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dt = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        dout = dout.contiguous().float()
+        L.check(L.lib().pq3d_embedding_bwd_acc(L.ptr(dout), L.ptr(ids), L.ptr(dt), ids.numel(), ctx.shape[1], L.stream()),
+                "pq3d_embedding_bwd_acc")
+        return dt, None
+
+
+def embedding(table, ids):
+    return _Embedding.apply(table, ids)

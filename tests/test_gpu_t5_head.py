@@ -12,9 +12,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def test_t5_head_matches_reference_head():
+@pytest.mark.parametrize("body", ["hip", "hf"])
+def test_t5_head_matches_reference_head(body):
+    """body='hip': input_proj AND the teacher-forced T5 decoder on the HIP kernels; 'hf': stock HF body."""
     z, a = util.load_fixture("F8_t5_head")
-    head = T5(None, variant="tiny", input_size=a["d"], use_projection=True, hf_config=a["hf_config"])
+    head = T5(None, variant="tiny", input_size=a["d"], use_projection=True, hf_config=a["hf_config"], body=body)
     head.compute = "fp32"
     sd = synth.fill_module(head, a["seed"])
     assert abs(synth.state_checksum(sd) - float(z["meta/weights_checksum"])) < 1e-6 * float(z["meta/weights_checksum"])
@@ -52,3 +54,25 @@ def test_model_with_generation_head_trains():
     with torch.no_grad():
         toks = model({k: v.to(DEV) for k, v in dd.items()})["generation_logits"]
     assert toks.dtype == torch.long and toks.shape[0] == 2
+
+
+def test_t5_hip_body_train_mode_and_bf16():
+    """dropout active (train mode) and bf16 operands: finite, stochastic, and close to the fp32 eval logits in bf16."""
+    z, a = util.load_fixture("F8_t5_head")
+    head = T5(None, variant="tiny", input_size=a["d"], use_projection=True, hf_config=a["hf_config"], body="hip")
+    synth.fill_module(head, a["seed"])
+    head.to(DEV)
+    q = torch.from_numpy(z["q"]).to(DEV)
+    mask, labels = torch.from_numpy(z["mask"]).to(DEV), torch.from_numpy(z["labels"]).to(DEV)
+    head.compute = "bf16"
+    head.eval()
+    ref = head(q, mask, labels)
+    g = torch.from_numpy(z["logits/sample"]).float()
+    assert float((ref.detach().float().cpu().flatten()[:: max(1, ref.numel() // g.numel() + (ref.numel() % g.numel() > 0))][:g.numel()]
+                  - g).abs().max()) < 5e-2 * float(g.abs().max())
+    head.train()
+    a1, a2 = head(q, mask, labels), head(q, mask, labels)
+    assert torch.isfinite(a1).all() and not torch.equal(a1, a2)
+    qg = q.clone().requires_grad_(True)
+    head(qg, mask, labels).float().square().mean().backward()
+    assert torch.isfinite(qg.grad).all() and all(p.grad is None or torch.isfinite(p.grad).all() for p in head.parameters())
