@@ -597,8 +597,9 @@ class T5(_PostNormBase):
     """modules/heads/generation_head.py:8-30.  The in-repo part -- ``input_proj`` = Linear(d -> d_model) + LayerNorm --
     runs on the HIP kernels, and so does the teacher-forced decoder body (``body='hip'``, pq3d_amd/t5.py: the
     third-party HF ``T5ForConditionalGeneration`` decoder restated on this package's ops, reading the HF module's
-    parameters); greedy generation (eval, labels=None) and ``body='hf'`` run the stock HF model exactly as the reference
-    uses it (encoder bypassed through ``encoder_outputs``, cross-attending to the N_q query tokens).
+    parameters) and greedy generation (labels=None: KV-cache decode step in a HIP graph, t5.GreedyDecoder);
+    ``body='hf'`` runs the stock HF model exactly as the reference uses it (encoder bypassed through
+    ``encoder_outputs``, cross-attending to the N_q query tokens).
     ``variant`` is loaded with ``from_pretrained`` when it is available locally; without network the same architecture
     is built with random weights (``T5_ARCH`` or an explicit ``hf_config`` dict) -- state_dict keys are identical, so
     a reference checkpoint loads over it."""
@@ -618,6 +619,7 @@ class T5(_PostNormBase):
                     raise
                 self.model = T5ForConditionalGeneration(T5Config(**T5_ARCH[variant]))
         self.model.config.update(kwargs)
+        self._greedy = {}
         hidden_size = self.model.config.d_model
         self.use_projection = use_projection
         if use_projection:
@@ -638,6 +640,14 @@ class T5(_PostNormBase):
                         rng.advance()
                     self._drop_epoch = rng.epoch
             return t5.decoder_logits(self.model, query_embeds, attention_masks, labels, self.ct, self.training)
+        if labels is None and self.body == "hip":   # greedy generation: KV-cache decode step replayed from a HIP graph
+            from . import t5
+            B, N, _ = query_embeds.shape
+            key = (B, N, t5.new_token_budget(self.model), self.ct, str(query_embeds.device), self.model.shared.weight.data_ptr())
+            if key not in self._greedy:
+                self._greedy.clear()                # one resident decoder (static caches + graphs) at a time
+                self._greedy[key] = t5.GreedyDecoder(self.model, B, N, self.ct, key[2], query_embeds.device)
+            return self._greedy[key](query_embeds, attention_masks)
         enc = BaseModelOutput(last_hidden_state=query_embeds)
         if labels is not None:
             return self.model(encoder_outputs=enc, attention_mask=attention_masks, labels=labels).logits

@@ -76,3 +76,64 @@ def test_t5_hip_body_train_mode_and_bf16():
     qg = q.clone().requires_grad_(True)
     head(qg, mask, labels).float().square().mean().backward()
     assert torch.isfinite(qg.grad).all() and all(p.grad is None or torch.isfinite(p.grad).all() for p in head.parameters())
+
+
+def _hf_generate(head, q, mask, n_new):
+    from transformers.modeling_outputs import BaseModelOutput
+    enc = torch.nn.Sequential(*head.input_proj)(q) if head.use_projection else q
+    out = head.model.generate(encoder_outputs=BaseModelOutput(last_hidden_state=enc), attention_mask=mask, do_sample=False,
+                              max_new_tokens=n_new)
+    return out[:, 1:]
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_greedy_decoder_matches_hf_generate(use_graph):
+    """KV-cache greedy decoding on the HIP kernels == HF generate (stock PyTorch-ROCm, fp32) token for token: several
+    calls through the same captured graph (state reset), ragged encoder masks, and EOS / pad bookkeeping with an EOS id
+    that the random-init model actually emits."""
+    from pq3d_amd import t5
+    _z, a = util.load_fixture("F8_t5_head")
+    head = T5(None, variant="tiny", input_size=a["d"], use_projection=True, hf_config=a["hf_config"], body="hip")
+    head.compute = "fp32"
+    synth.fill_module(head, 5)
+    head.to(DEV).eval()
+    B, N, n_new = 5, 13, 23
+    g = torch.Generator().manual_seed(1)
+    dec = None
+    for trial in range(3):
+        q = torch.randn(B, N, a["d"], generator=g).to(DEV)
+        mask = (torch.arange(N)[None] < torch.tensor([N, 3, 7, N, 1])[:, None]).to(DEV)
+        with torch.no_grad():
+            ref = _hf_generate(head, q, mask, n_new)
+            if trial == 1:      # make EOS reachable: the token sequence 0 emits at its 3rd step becomes the EOS id
+                head.model.generation_config.eos_token_id = int(ref[0, 2])
+                ref = _hf_generate(head, q, mask, n_new)
+                dec = None
+            if dec is None:
+                dec = t5.GreedyDecoder(head.model, B, N, head.ct, n_new, DEV, use_graph=use_graph)
+            enc = torch.nn.Sequential(*head.input_proj)(q)
+            got = dec(enc, mask)
+        assert got.shape == ref.shape, (trial, got.shape, ref.shape)
+        assert torch.equal(got, ref), (trial, got, ref)
+    assert (ref == head.model.generation_config.eos_token_id).any() and ref.shape[1] <= n_new
+
+
+def test_greedy_generation_through_the_head_and_budget():
+    """T5.forward(labels=None) routes to the HIP decoder; the reference's ``max_new_tokens`` kwarg (config.update) sets
+    the budget; tokens are self-consistent with the teacher-forced logits (argmax of position t given the prefix)."""
+    from pq3d_amd import t5
+    _z, a = util.load_fixture("F8_t5_head")
+    head = T5(None, variant="tiny", input_size=a["d"], use_projection=True, hf_config=a["hf_config"], body="hip", max_new_tokens=9)
+    head.compute = "fp32"
+    synth.fill_module(head, 2)
+    head.to(DEV).eval()
+    assert t5.new_token_budget(head.model) == 9
+    q = torch.randn(3, 6, a["d"], generator=torch.Generator().manual_seed(0)).to(DEV)
+    mask = torch.ones(3, 6, dtype=torch.bool, device=DEV)
+    with torch.no_grad():
+        toks = head(q, mask, None)
+        assert toks.shape == (3, 9) and toks.dtype == torch.long
+        logits = head(q, mask, toks)
+    assert torch.equal(logits.argmax(-1), toks)
+    with torch.no_grad():
+        assert torch.equal(head(q, mask, None), toks)     # cached decoder, replayed
