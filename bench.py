@@ -155,12 +155,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
+    # PQ3D_BENCH_BACKEND=gloo is a test hook (tests/test_gpu_bench_multirank.py): it lets two ranks share ONE GPU so the
+    # whole N > 1 flow (sharded inputs, gradient all-reduce, barriers, max-over-ranks timing, rank-0 JSON) is exercised on
+    # a single-GPU box.  RCCL itself refuses two ranks on one device; the driver's N > 1 runs use the default 'nccl'.
+    backend = os.environ.get("PQ3D_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     c = dict(CONFIGS[args.config])
     model, sd, dd_cpu = build(c, args.compute, dev, seed=1234 + rank)
     dd = {k: v.to(dev) for k, v in dd_cpu.items()}
@@ -234,6 +242,13 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     value = c["B"] * world * args.steps / dt
+    grads_identical = None
+    if world > 1:   # after the all-reduce every rank must hold the same (mean) gradient: fingerprint min == max over ranks
+        fp = torch.stack([torch.stack([f.double().sum(), f.double().abs().sum()]) for f in reducer.flat]).flatten()
+        lo, hi = fp.clone(), fp.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        grads_identical = bool(torch.equal(lo, hi)) and bool(torch.isfinite(fp).all()) and bool((fp[1::2] > 0).all())
 
     result = None
     if rank == 0:
@@ -301,6 +316,7 @@ def main():
                        "activation": "relu"},
             "step_algorithmic_gflop": flops / 1e9,
             "step_roofline_frac": flops * world / (dt / args.steps) / (peak * 1e12 * world),
+            **({"grads_identical_across_ranks": grads_identical} if world > 1 else {}),
             "roofline": roof,
             "kernel_families_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(fams.items())},
         }

@@ -476,6 +476,18 @@ int pq3d_three_interpolate(const float* points, const int32_t* idx, const float*
                            int32_t M, int32_t N, void* stream);
 int pq3d_three_interpolate_grad(const float* grad_out, const int32_t* idx, const float* weight, float* grad_points, int32_t B,
                                 int32_t C, int32_t M, int32_t N, void* stream);
+/* Row form of the set-abstraction grouping for the frozen PointNet++ backbone (modules/layers/pointnet.py:22-63,
+ * pointnet2_modules.py:23-70; QueryAndGroup / GroupAll of pointnet2_utils.py:291-419 with use_xyz): the SharedMLP's 1x1
+ * convolutions become row GEMMs (pq3d_gemm), so grouping writes channels-last rows.
+ *   pq3d_group_rows    : out[(b,p,s), :] = [xyz[b,j] - new_xyz[b,p] (3), feats[b,j,0:C], 0 ... (to Kp)], j = idx[b,p,s];
+ *                        new_xyz == NULL: no centring; idx == NULL (GroupAll): j = s, ns == N.  xyz [B,N,3] fp32,
+ *                        feats rows [B,N,feat_stride] (dt_f), out [B*np*ns, Kp] (dt_o)
+ *   pq3d_group_maxpool : out[g, c] = max_s rows[g, s, c]  (F.max_pool2d over the samples, pointnet2_modules.py:62-65)
+ */
+int pq3d_group_rows(const float* xyz, const float* new_xyz, const void* feats, int32_t dt_f, int64_t feat_stride,
+                    const int32_t* idx, void* out, int32_t dt_o, int32_t B, int32_t N, int32_t C, int32_t np, int32_t ns,
+                    int32_t Kp, void* stream);
+int pq3d_group_maxpool(const void* rows, void* out, int32_t dt, int64_t G, int32_t ns, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pieces of the generation head's decoder body (third-party arithmetic: HF transformers

@@ -84,3 +84,48 @@ def three_interpolate(points: np.ndarray, idx: np.ndarray, weight: np.ndarray) -
     for k in range(3):
         out += gather_points(points, idx[:, :, k]) * weight[:, None, :, k]
     return out
+
+
+# ------------------------------------------------------------------------------------------------ the tokenizer network
+def pointnetpp_forward(sd, pc: np.ndarray, sa_n_points, sa_n_samples, sa_radii, n_layers=3, eps: float = 1e-5,
+                       prefix: str = "", trace: dict | None = None) -> np.ndarray:
+    """PointNetPP.forward (modules/layers/pointnet.py:55-63) with frozen BatchNorm: per stage furthest-point sampling +
+    gather of the centres (pointnet2_modules.py:48-53), QueryAndGroup / GroupAll with use_xyz
+    (pointnet2_utils.py:331-358, 396-419), SharedMLP = [1x1 conv (no bias) -> BatchNorm2d(eval) -> ReLU] x 3
+    (pytorch_utils.py:11-36), max over the samples (pointnet2_modules.py:62-65); then fc on the flattened
+    [C, npoint] features.  fp64 accumulation in the matmuls is avoided on purpose: fp32 like the reference.
+    ``sd``: the module's state_dict as numpy arrays.  The learnable layers of this function ARE pinned (fixture F12 runs
+    the reference's own SharedMLP / fc modules); the point-set operators feeding them are the unpinned ones above."""
+    pc = pc.astype(np.float32)
+    xyz, feats = pc[..., :3], np.transpose(pc[..., 3:], (0, 2, 1)) if pc.shape[-1] > 3 else None     # [B,N,3], [B,C,N]
+    for i, (npoint, nsample, radius) in enumerate(zip(sa_n_points, sa_n_samples, sa_radii)):
+        if npoint is not None:
+            fps = furthest_point_sampling(xyz, npoint)
+            new_xyz = np.take_along_axis(xyz, fps[..., None].astype(np.int64), 1)
+            idx = ball_query(new_xyz, xyz, radius, nsample)
+            gx = group_points(np.ascontiguousarray(np.transpose(xyz, (0, 2, 1))), idx)               # [B,3,np,ns]
+            gx = gx - np.transpose(new_xyz, (0, 2, 1))[..., None]
+            x = np.concatenate([gx, group_points(np.ascontiguousarray(feats), idx)], 1) if feats is not None else gx
+            if trace is not None:
+                trace[f"fps/{i}"], trace[f"ball/{i}"] = fps, idx
+        else:
+            new_xyz = None
+            gx = np.transpose(xyz, (0, 2, 1))[:, :, None, :]                                          # [B,3,1,N]
+            x = np.concatenate([gx, feats[:, :, None, :]], 1) if feats is not None else gx
+        for j in range(n_layers):
+            k = f"{prefix}encoder.{i}.mlps.0.layer{j}."
+            W = sd[k + "conv.weight"][:, :, 0, 0].astype(np.float32)
+            x = np.einsum("oc,bcps->bops", W, x).astype(np.float32)
+            if (k + "conv.bias") in sd:
+                x = x + sd[k + "conv.bias"][None, :, None, None]
+            if (k + "bn.bn.weight") in sd:
+                inv = (1.0 / np.sqrt(sd[k + "bn.bn.running_var"].astype(np.float32) + np.float32(eps))).astype(np.float32)
+                x = (x - sd[k + "bn.bn.running_mean"][None, :, None, None]) * inv[None, :, None, None] \
+                    * sd[k + "bn.bn.weight"][None, :, None, None] + sd[k + "bn.bn.bias"][None, :, None, None]
+            x = np.maximum(x, 0).astype(np.float32)
+        feats = x.max(-1)                                                                             # [B,C,np]
+        if trace is not None:
+            trace[f"pooled/{i}"] = feats
+        xyz = new_xyz
+    flat = feats.reshape(feats.shape[0], -1)
+    return (flat @ sd[prefix + "fc.weight"].T.astype(np.float32) + sd[prefix + "fc.bias"]).astype(np.float32)

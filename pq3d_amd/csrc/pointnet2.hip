@@ -285,3 +285,65 @@ extern "C" int pq3d_three_interpolate_grad(const float* grad_out, const int32_t*
   PQ_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ set-abstraction rows
+// The frozen PointNet++ backbone (modules/layers/pointnet.py:22-63) runs its SharedMLPs as row GEMMs: one row per
+// (cloud, centre, sample), channels last.  group_rows builds those rows straight from the ball-query indices (centred
+// xyz first, then the point features, zero-padded to Kp so the GEMM's K is a multiple of 8); group_maxpool is the
+// max over the samples of a group, producing the next stage's [cloud, point, channel] feature rows.
+__global__ void __launch_bounds__(256) group_rows_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                          const void* __restrict__ feats, int dt_f, long feat_stride,
+                                                          const int32_t* __restrict__ idx, void* __restrict__ out, int dt_o,
+                                                          int N, int C, int np, int ns, int Kp, long total) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long row = e / Kp;
+    const int c = (int)(e - row * Kp);
+    const long g = row / ns;            // (cloud, centre)
+    const int b = (int)(g / np);
+    const int j = idx ? idx[row] : (int)(row - g * ns);   // GroupAll: sample s is point s
+    float v = 0.f;
+    if (c < 3) {
+      v = xyz[((long)b * N + j) * 3 + c];
+      if (new_xyz) v -= new_xyz[g * 3 + c];
+    } else if (c < 3 + C) {
+      v = load_elem(feats, dt_f, ((long)b * N + j) * feat_stride + (c - 3));
+    }
+    store_elem(out, dt_o, e, v);
+  }
+}
+
+__global__ void __launch_bounds__(256) group_maxpool_kernel(const void* __restrict__ rows, void* __restrict__ out, int dt,
+                                                             long G, int ns, int C) {
+  const long total = G * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long g = e / C;
+    const int c = (int)(e - g * C);
+    float m = -INFINITY;
+    for (int s = 0; s < ns; ++s) m = fmaxf(m, load_elem(rows, dt, (g * ns + s) * C + c));
+    store_elem(out, dt, e, m);
+  }
+}
+
+extern "C" int pq3d_group_rows(const float* xyz, const float* new_xyz, const void* feats, int32_t dt_f, int64_t feat_stride,
+                               const int32_t* idx, void* out, int32_t dt_o, int32_t B, int32_t N, int32_t C, int32_t np,
+                               int32_t ns, int32_t Kp, void* stream) {
+  PQ_CHECK_ARG(xyz && out && B >= 0 && N >= 1 && C >= 0 && np >= 1 && ns >= 1 && Kp >= 3 + C, "pq3d_group_rows: bad args");
+  PQ_CHECK_ARG(C == 0 || (feats && feat_stride >= C), "pq3d_group_rows: features missing");
+  PQ_CHECK_ARG(idx || ns == N, "pq3d_group_rows: without indices every point is a sample (ns == N)");
+  PQ_CHECK_ARG((dt_f == PQ3D_F32 || dt_f == PQ3D_BF16) && (dt_o == PQ3D_F32 || dt_o == PQ3D_BF16), "pq3d_group_rows: bad dtype");
+  const long total = (long)B * np * ns * Kp;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(group_rows_kernel, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, feats,
+                     dt_f, (long)feat_stride, idx, out, dt_o, N, C, np, ns, Kp, total);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_group_maxpool(const void* rows, void* out, int32_t dt, int64_t G, int32_t ns, int32_t C, void* stream) {
+  PQ_CHECK_ARG(rows && out && G >= 0 && ns >= 1 && C >= 1 && (dt == PQ3D_F32 || dt == PQ3D_BF16), "pq3d_group_maxpool: bad args");
+  if (G == 0) return 0;
+  hipLaunchKernelGGL(group_maxpool_kernel, dim3(blocks_for((long)G * C, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rows, out,
+                     dt, (long)G, ns, C);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

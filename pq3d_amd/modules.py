@@ -662,8 +662,16 @@ class ObjectEncoder(_PostNormBase):
     def __init__(self, cfg, backbone="none", input_feat_size=768, hidden_size=768, freeze_backbone=False,
                  use_projection=False, tgt_cls_num=607, pretrained=None, dropout=0.1, use_cls_head=True):
         super().__init__()
-        if backbone != "none":
-            raise NotImplementedError("PointNet++ backbone is out of scope (SURVEY §2 row 10)")
+        self.freeze_backbone = freeze_backbone
+        if backbone == "pointnet++":       # object_encoder.py:22-28: the frozen point tokenizer on the HIP kernels
+            from .pointnetpp import POINTNETPP_TOKENIZER, PointNetPP
+            if not freeze_backbone:
+                raise NotImplementedError("backbone='pointnet++' is provided as the frozen tokenizer only "
+                                          "(freeze_backbone=True, as configs/unified_tasks_sceneverse.yaml:147-148 uses it)")
+            self.backbone = PointNetPP(**{k: [list(x) if isinstance(x, list) else x for x in v]
+                                          for k, v in POINTNETPP_TOKENIZER.items()})
+        elif backbone != "none":
+            raise NotImplementedError(f"backbone {backbone!r}")
         if use_cls_head:
             self.cls_head = get_mlp_head(input_feat_size, input_feat_size // 2, tgt_cls_num, dropout=0.3)
         self.dropout_p, self.cls_dropout_p, self._drop_base = float(dropout), 0.3, DROP_BASE_OBJ_ENC
@@ -673,10 +681,24 @@ class ObjectEncoder(_PostNormBase):
         else:
             assert input_feat_size == hidden_size, "input_feat_size should be equal to hidden_size!"
         self.apply(_init_weights_bert)
-        if pretrained:
-            self.load_state_dict(torch.load(pretrained), strict=False)
+        if pretrained:                     # object_encoder.py:41-53 (key mapping of the three shipped checkpoints)
+            state_dict = {}
+            for k, v in torch.load(pretrained, map_location="cpu").items():
+                if k[0] in ["0", "2", "4"]:
+                    k = "cls_head." + k
+                k = k.replace("vision_encoder.vis_cls_head.", "cls_head.").replace("point_cls_head.", "cls_head.")
+                state_dict[k.replace("point_feature_extractor.", "backbone.")] = v
+            self.load_state_dict(state_dict, strict=False)
 
     def forward(self, obj_feats, data_dict=None, **kwargs):
+        if hasattr(self, "backbone"):      # object_encoder.py:56-69: [B, O, P, 3+C] point clouds -> [B, O, 768], frozen
+            self.backbone.compute = self.compute
+            for m in self.backbone.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+            B_, O_ = obj_feats.shape[:2]
+            with torch.no_grad():
+                obj_feats = self.backbone(obj_feats.flatten(0, 1)).view(B_, O_, -1)
         obj_embeds = linear_ln_forward(self.input_feat_proj, obj_feats, self.ct) if self.use_projection else obj_feats
         dev = obj_feats.device
         ctx = self._head_ctx(dev, max(self.dropout_p, self.cls_dropout_p if hasattr(self, "cls_head") else 0.0))

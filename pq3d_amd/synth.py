@@ -20,11 +20,18 @@ def _rng(seed: int, name: str) -> np.random.Generator:
 
 def synth_tensor(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor:
     """matrices ~ N(0,0.05) (so attention is not degenerate), biases ~ N(0,0.02),
-    LayerNorm gamma ~ U(0.5,1.5), Fourier ``gauss_B`` ~ N(0,1)."""
+    LayerNorm / BatchNorm gamma ~ U(0.5,1.5), Fourier ``gauss_B`` ~ N(0,1), BatchNorm running_var ~ U(0.5,1.5),
+    running_mean ~ N(0,0.1)."""
     r = _rng(seed, name)
     shape = tuple(int(s) for s in shape)
+    if name.endswith("num_batches_tracked"):
+        return torch.zeros(shape, dtype=torch.int64)
     if name.endswith("gauss_B"):
         a = r.standard_normal(shape)
+    elif name.endswith("running_var"):
+        a = r.uniform(0.5, 1.5, shape)
+    elif name.endswith("running_mean"):
+        a = 0.1 * r.standard_normal(shape)
     elif len(shape) >= 2:
         a = 0.05 * r.standard_normal(shape)
     elif name.endswith("weight"):
@@ -139,3 +146,13 @@ def collate_inputs(seed=41):
     ninst = [4, 9, 2, 1]
     seg_masks = [torch.from_numpy((r.random((k, n)) < 0.3).astype(np.int64)) for k, n in zip(ninst, lens)]
     return feats, centers, labels, valid, seg_masks
+
+
+def pointcloud_inputs(M: int = 4, P: int = 300, C: int = 3, seed: int = 21) -> torch.Tensor:
+    """Object point clouds [M, P, 3 + C] for the PointNet++ tokenizer: xyz uniform in a unit cube (so radius-0.2 balls
+    hold fewer than nsample points and the fill rule is exercised), one cloud squeezed to a thin slab, colours in [0,1]."""
+    r = np.random.default_rng(seed)
+    xyz = r.uniform(-0.5, 0.5, (M, P, 3))
+    xyz[M - 1, :, 2] *= 0.05
+    rgb = r.uniform(0.0, 1.0, (M, P, C))
+    return torch.from_numpy(np.concatenate([xyz, rgb], -1).astype(np.float32))

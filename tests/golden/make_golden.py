@@ -445,6 +445,54 @@ def run_t5_case(ref, name, *, B=2, Nq=10, d=48, T=5, seed=11):
     save(name, out)
 
 
+POINTNETPP_SPEC = dict(sa_n_points=[32, 16, None], sa_n_samples=[32, 32, None], sa_radii=[0.2, 0.4, None],
+                       sa_mlps=[[3, 64, 64, 128], [128, 128, 128, 256], [256, 256, 512, 768]])   # object_encoder.py:23-28
+
+
+def run_pointnetpp_case(ref, name, *, seed=13):
+    """F12: the reference's PointNetPP tokenizer (modules/layers/pointnet.py:22-63) at its shipped hyper-parameters,
+    frozen (BatchNorm eval).  The module tree, SharedMLP stacks and fc ARE the reference's own objects (imported with
+    the reference's setup-time switch ``__POINTNET2_SETUP__`` so pointnet2_utils tolerates the missing CUDA extension);
+    the CUDA-only point-set operators in between (furthest_point_sample, ball_query, grouping_operation) cannot run here
+    and are supplied by oracle/pointnet2_oracle.py -- their index outputs are stored under ``oracle/`` to say so."""
+    import builtins
+    builtins.__POINTNET2_SETUP__ = True
+    pn = importlib.import_module("modules.layers.pointnet")
+    from oracle import pointnet2_oracle as po
+    torch.manual_seed(0)
+    net = pn.PointNetPP(**{k: [list(x) if isinstance(x, list) else x for x in v] for k, v in POINTNETPP_SPEC.items()})
+    sd = synth.fill_module(net, seed)
+    net.eval()
+    pc = synth.pointcloud_inputs()
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd)),
+           "meta/args": np.array(repr(dict(seed=seed, spec=POINTNETPP_SPEC))),
+           "meta/keys": np.array(repr([(k, tuple(v.shape)) for k, v in net.state_dict().items()])),
+           "pc": pc.numpy()}
+    with torch.no_grad():
+        xyz, feats = pn.break_up_pc(pc)
+        for i, sa in enumerate(net.encoder):
+            if sa.npoint is not None:
+                fps = po.furthest_point_sampling(xyz.numpy(), sa.npoint)
+                new_xyz = torch.gather(xyz, 1, torch.from_numpy(fps).long().unsqueeze(-1).expand(-1, -1, 3))
+                idx = po.ball_query(new_xyz.numpy(), xyz.numpy(), POINTNETPP_SPEC["sa_radii"][i], POINTNETPP_SPEC["sa_n_samples"][i])
+                out[f"oracle/fps/{i}"], out[f"oracle/ball/{i}"] = fps, idx
+                B_, np_, ns_ = idx.shape
+                li = torch.from_numpy(idx).long().view(B_, 1, -1)
+                gx = torch.gather(xyz.transpose(1, 2), 2, li.expand(-1, 3, -1)).view(B_, 3, np_, ns_)
+                gx = gx - new_xyz.transpose(1, 2).unsqueeze(-1)                       # pointnet2_utils.py:345-347
+                gf = torch.gather(feats, 2, li.expand(-1, feats.shape[1], -1)).view(B_, feats.shape[1], np_, ns_)
+                new_features = torch.cat([gx, gf], dim=1)                            # pointnet2_utils.py:353-356
+            else:
+                new_xyz = None
+                new_features = sa.groupers[0](xyz, new_xyz, feats)                    # the reference's GroupAll (pure torch)
+            new_features = sa.mlps[0](new_features)                                   # the reference's SharedMLP
+            new_features = torch.nn.functional.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(-1)
+            out[f"pooled/{i}"] = new_features.numpy()
+            xyz, feats = new_xyz, new_features
+        out["out"] = net.fc(feats.view(feats.size(0), -1)).numpy()
+    save(name, out)
+
+
 def main():
     ref = import_reference()
     # F1: BASELINE config 1 exactly (1 layer, B2, Ns128, Nq16, d64, H4, one stream, non-spatial, sequential)
@@ -484,6 +532,7 @@ def main():
     run_criterion_case(ref, "F9_set_criterion")
     run_direct_loss_case(ref, "F10_direct_losses")
     run_collate_case(ref, "F11_collate")
+    run_pointnetpp_case(ref, "F12_pointnetpp")
     run_train_case(ref, "F7_adamw_mask", B=2, Ns=96, Nq=12, d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask"],
                    spatial=True, structure="parallel", use_self_mask=False, foc=(0, 2), warmup_steps=0, total_steps=6)
 

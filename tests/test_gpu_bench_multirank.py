@@ -1,0 +1,38 @@
+"""GPU: the N > 1 flow of bench.py end to end on ONE GPU -- two ranks launched exactly as the driver launches them
+(python -m torch.distributed.run ... bench.py --gpus 2), sharing the device through the gloo test hook
+(PQ3D_BENCH_BACKEND, see bench.py; RCCL refuses two ranks on one device).  Checks the contract fields and that the
+all-reduced gradient is identical on both ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("config", ["c1", "c2"])
+def test_bench_two_ranks_one_gpu(config):
+    env = dict(os.environ, PQ3D_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--config", config, "--headline-only"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]            # rank 0 prints ONE JSON line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["warmup"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["parallelism"] == "dp2" and r["config"]["global_batch"] % 2 == 0
+    assert r["value"] > 0 and abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert r["grads_identical_across_ranks"] is True
+    assert "cpu_baseline" not in r                       # rank-0 / N=1 only

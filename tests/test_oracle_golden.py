@@ -8,7 +8,7 @@ from pq3d_amd import synth
 from tests import util
 
 TOL = dict(atol=1e-5, rtol=1e-5)
-MODEL_FIXTURES = [f for f in util.fixtures() if not f.startswith(("F3_", "F6_", "F7_", "F8_", "F9_", "F10_", "F11_"))]
+MODEL_FIXTURES = [f for f in util.fixtures() if not f.startswith(("F3_", "F6_", "F7_", "F8_", "F9_", "F10_", "F11_", "F12_"))]
 
 
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
