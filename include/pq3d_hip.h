@@ -224,6 +224,8 @@ typedef struct {
   /* residual dropout: y = LN(x + dropout(o_m)) (tgt + self.dropout(tgt2), query_encoder.py:224,304,386); the site
    * is o_m viewed as [R, d], site id drop.site + m.  The backward regenerates the mask for d_o. */
   pq3d_dropout drop;
+  int32_t dx_zeroed;   /* backward, M > 1 summed branches: dx (accumulated with atomics by the M branch blocks) was
+                          already zeroed by the caller -- one zero-fill for a whole backward pass instead of one per call */
 } pq3d_ln_desc;
 
 int pq3d_add_ln_fwd(const pq3d_ln_desc* d, void* stream);

@@ -136,7 +136,7 @@ class LnDesc(C.Structure):
         ("dy", C.c_void_p), ("dx", C.c_void_p), ("d_o", C.c_void_p * MAXG), ("dgamma", C.c_void_p * MAXG),
         ("dbeta", C.c_void_p * MAXG), ("accumulate", C.c_int32), ("independent", C.c_int32),
         ("ys", C.c_void_p * MAXG), ("dys", C.c_void_p * MAXG),
-        ("sum_branches", C.c_int32), ("osum", C.c_void_p), ("drop", Dropout),
+        ("sum_branches", C.c_int32), ("osum", C.c_void_p), ("drop", Dropout), ("dx_zeroed", C.c_int32),
     ]
 
 

@@ -257,7 +257,7 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
     ZeroList z;
     for (int m = 0; m < (d.sum_branches ? 1 : d.M) && !d.accumulate; ++m) { z.add(d.dgamma[m], d.d); z.add(d.dbeta[m], d.d); }
     if (z.full()) { if (int e = pq3d_zero_launch(z, s)) return e; z.n = 0; }
-    if (d.R > 0 && d.dx && d.M > 1 && !d.independent && !d.sum_branches) z.add(d.dx, (long)d.R * d.d);
+    if (d.R > 0 && d.dx && d.M > 1 && !d.independent && !d.sum_branches && !d.dx_zeroed) z.add(d.dx, (long)d.R * d.d);
     if (int e = pq3d_zero_launch(z, s)) return e;
   }
   if (d.R == 0) return 0;

@@ -180,7 +180,7 @@ def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.fl
 
 
 def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dgs, dbs, want_dx=True, dup_dx=False,
-            drop=None, sum_branches=False):
+            drop=None, sum_branches=False, dx_zeroed=None):
     """Returns (dx or None, d_o [M,...] fp32 stacked); dgamma/dbeta accumulate into the arena views dgs/dbs.
     dup_dx: also write the (single-branch) input gradient to a second buffer even without a residual input."""
     M = len(os_)
@@ -190,6 +190,8 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
     d_o = torch.empty(1 if sum_branches else M, *os_[0].shape, dtype=torch.float32, device=dev)
     dx = torch.empty(os_[0].shape, dtype=torch.float32, device=dev) if ((x is not None and want_dx) or dup_dx) else None
     d = ops._ln_desc(x, os_, gammas, betas, coef, eps, rows_per_scene, None, mean, rstd, drop)
+    if dx_zeroed is not None and dx is not None:   # a slice of the caller's buffer zeroed once for the whole backward
+        dx, d.dx_zeroed = dx_zeroed, 1
     d.dy, d.dx, d.accumulate, d.sum_branches = L.ptr(dy), L.ptr(dx), 1, int(sum_branches)
     for m in range(1 if sum_branches else M):
         d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_o[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
@@ -460,6 +462,9 @@ class _FusedDecoder(Function):
         dqpos_parts: List[torch.Tensor] = []
         n_app = len(tape)
         dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=ad, device=dev)
+        # input gradients of the M-branch cross-attention LayerNorms are accumulated with atomics by the M branch blocks:
+        # ONE zero-fill for all layer applications instead of one per LayerNorm backward call
+        dxr_zero = torch.zeros(n_app, B, Nq, d, dtype=torch.float32, device=dev) if M > 1 else None
         dkeys = None  # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
 
         def mh_backward(rec, dc, dm, dx_in):
@@ -585,7 +590,8 @@ class _FusedDecoder(Function):
             cl = cas[i]
             dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
                                [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef, Nq, rec["mean_c"], rec["rstd_c"],
-                               dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl], drop=rec["dr_cr"])
+                               dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl], drop=rec["dr_cr"],
+                               dx_zeroed=dxr_zero[a] if dxr_zero is not None else None)
             do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
             L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
                    Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)

@@ -135,7 +135,8 @@ class Query3DUnified(nn.Module):
         ops.fourier(query_locs[:, :, :3], coord_min, coord_max, ce.pos_enc.gauss_B, out=buf[:B * Nq].view(B, Nq, d))
         ops.fourier(seg_locs[:, :, :3], coord_min, coord_max, ce.pos_enc.gauss_B, out=buf[B * Nq:].view(B, Ns, d))
         y = M.linear_ln_forward(ce.feat_proj, buf, self.ct)
-        return y[:B * Nq].view(B, Nq, d), y[B * Nq:].view(B, Ns, d)
+        yq, ys = ops.split_rows(y, B * Nq)
+        return yq.view(B, Nq, d), ys.view(B, Ns, d)
 
     def _encode_scene_memories(self, data_dict):
         """ObjectEncoder projections of all scene memories; same-shape encoders share grouped launches."""

@@ -55,12 +55,15 @@ def begin_dropout_step(owner: nn.Module, device, extra: Sequence[nn.Module] = ()
     parent module already did for this step) and tell the dropout-bearing children that their site ids are managed
     structurally in this epoch (heads then use (base, call index) instead of advancing the RNG themselves)."""
     rng = ops.drop_rng(device)
-    if rng.epoch == getattr(owner, "_drop_epoch", -1):
+    mods = [m for m in list(owner.modules()) + list(extra) if isinstance(m, _PostNormBase)]
+    # nothing draws from the generator when every rate is zero: skip the (device-side) epoch advance then
+    active = any(getattr(m, "dropout_p", 0.0) > 0 or getattr(m, "cls_dropout_p", 0.0) > 0 for m in mods) or \
+        any(isinstance(m, nn.Dropout) and m.p > 0 for m in owner.modules())
+    if active and rng.epoch == getattr(owner, "_drop_epoch", -1):
         rng.advance()
-    owner._drop_epoch = rng.epoch
-    for m in list(owner.modules()) + list(extra):
-        if isinstance(m, _PostNormBase):
-            m._drop_managed = rng.epoch
+    owner._drop_epoch = rng.epoch if active else -1
+    for m in mods:
+        m._drop_managed = rng.epoch
 
 
 def _init_weights_bert(module: nn.Module, std: float = 0.02) -> None:

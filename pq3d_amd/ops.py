@@ -266,10 +266,11 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
     L.set_drop(d.drop, drop)
     d.drop_bmod = drop_bmod
     # key split (not with dbias).  The factor depends on the key length ONLY, never on the batch: a scene's result
-    # must not change with how scenes are batched or sharded over ranks (tests/test_gpu_fullsize.py).  Measured on
-    # c2 (16 key blocks) and c4 (64): 2 splits is the sweet spot, more only adds combine traffic.
+    # must not change with how scenes are batched or sharded over ranks (tests/test_gpu_fullsize.py).  Measured
+    # (tools/probes/attn_bench.py + bench.py): c2 (16 key blocks) and c5 (32) are fastest with 2 splits, c4 (64) with 4
+    # (forward 70 -> 57 us, step 5.56 -> 5.43 ms); 8 only adds combine traffic.
     nkb = (Lk + 63) // 64
-    ks = (_ATTN_KSPLIT or (1 if nkb < 8 else 2 if nkb < 256 else 4)) if bias is None else 1
+    ks = (_ATTN_KSPLIT or (1 if nkb < 8 else 2 if nkb < 64 else 4)) if bias is None else 1
     if ks > 1:
         ws = _empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
         d.ksplit, d.ws = ks, L.ptr(ws)
@@ -594,21 +595,25 @@ class _LinearLNGroup(Function):
         dev = lin.device
         dys = [(_c(g).float() if g is not None else torch.zeros(lin.shape[1:], device=dev)) for g in dys]
         dlin = _empty(lin.shape, dtype=torch.float32, device=dev)
-        dgs = [torch.empty_like(a) for a in gam]
-        dbs = [torch.empty_like(a) for a in bet]
+        # every atomics target of this backward (LayerNorm parameter gradients, split-K weight gradients, bias column
+        # sums) lives in ONE zero-filled buffer: a single fill instead of a zero launch per kernel
+        zb = torch.zeros(G * (3 * N + N * K), dtype=torch.float32, device=dev)
+        dgs = [zb[g * N:(g + 1) * N] for g in range(G)]
+        dbs = [zb[(G + g) * N:(G + g + 1) * N] for g in range(G)]
         d = _ln_desc(None, [lin[g] for g in range(G)], list(gam), list(bet), None, eps, R, None, mean, rstd)
         d.independent = 1
+        d.accumulate = 1
         for g in range(G):
             d.dys[g], d.d_o[g], d.dgamma[g], d.dbeta[g] = L.ptr(dys[g]), L.ptr(dlin[g]), L.ptr(dgs[g]), L.ptr(dbs[g])
         L.check(timed("pq3d_add_ln_bwd", f"R{R}d{N}M{G}i", 0.0, 3.0 * G * R * N * 4, L.lib().pq3d_add_ln_bwd, C.byref(d),
                       L.stream()), "pq3d_add_ln_bwd")
-        dWs = [_empty(N, K, dtype=torch.float32, device=dev) for _ in range(G)]
-        dbl = [_empty(N, dtype=torch.float32, device=dev) for _ in range(G)]
+        dbl = [zb[(2 * G + g) * N:(2 * G + g + 1) * N] for g in range(G)]
+        dWs = [zb[3 * G * N + g * N * K:3 * G * N + (g + 1) * N * K].view(N, K) for g in range(G)]
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
         epl = 8 if ct == BF16 else 4
         fuse = N % epl == 0 and K % epl == 0 and all(x.data_ptr() % 16 == 0 for x in xs)
         L.gemm(M=N, N=K, K=R, A=[dlin[g] for g in range(G)], B=list(xs), Cs=dWs, ct=ct, lda=N, ldb=K, ldc=K, transA=True,
-               transB=True, splitk=max(2, _splitk(tiles * G, R, ct)), colsum=dbl if fuse else None)
+               transB=True, splitk=max(2, _splitk(tiles * G, R, ct)), colsum=dbl if fuse else None, accumulate=True)
         if not fuse:
             dbl = [colsum(dlin[g].view(R, N)) for g in range(G)]
         dxs = [None] * G
@@ -625,6 +630,29 @@ def linear_ln_group(xs, Ws, bs, gammas, betas, *, ct: int, eps: float = 1e-5):
     G = len(xs)
     need_dx = any(x.requires_grad for x in xs)
     return _LinearLNGroup.apply(ct, float(eps), G, need_dx, *xs, *Ws, *bs, *gammas, *betas)
+
+
+class _SplitRows(Function):
+    """(y[:n], y[n:]) of a row matrix whose backward is ONE concatenation -- autograd's two slice backwards would each
+    zero-fill a full-size buffer, copy their part in, and then add the two (5 launches)."""
+
+    @staticmethod
+    def forward(ctx, y, n):
+        ctx.n, ctx.shape = n, tuple(y.shape)
+        return y[:n], y[n:]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        n, (rows, d_) = ctx.n, ctx.shape
+        if da is None and db is None:
+            return None, None
+        da = da.reshape(n, d_) if da is not None else db.new_zeros(n, d_)
+        db = db.reshape(rows - n, d_) if db is not None else da.new_zeros(rows - n, d_)
+        return torch.cat([da, db], 0), None
+
+
+def split_rows(y, n: int):
+    return _SplitRows.apply(y, int(n))
 
 
 # ------------------------------------------------------------------------------------------------ T5 body pieces

@@ -133,8 +133,8 @@ def attn_ref(q, k, v, H, scale, zero_attn, kpm, mask, row_open, bias):
 @pytest.mark.parametrize("H,dh", [(4, 16), (8, 32), (2, 64)])
 @pytest.mark.parametrize("Lq,Lk,mode", [(16, 128, "kpm"), (100, 130, "mask3d"), (37, 70, "bias"), (200, 333, "kpm"),
                                         (20, 20, "self"),
-                                        # key-split paths: 2 splits (>= 8 key blocks), ragged length; 4 splits (256 = the supported maximum)
-                                        (100, 1100, "mask3d"), (9, 16384, "kpm"), (1, 50, "bias")])
+                                        # key-split paths: 2 splits (>= 8 key blocks), ragged length; 4 splits (>= 64 key blocks), incl. the supported maximum
+                                        (100, 1100, "mask3d"), (40, 4200, "mask3d"), (9, 16384, "kpm"), (1, 50, "bias")])
 def test_attention_fwd_bwd(ct, H, dh, Lq, Lk, mode):
     B, d = 2, H * dh
     q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
