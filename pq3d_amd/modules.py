@@ -57,7 +57,8 @@ def begin_dropout_step(owner: nn.Module, device, extra: Sequence[nn.Module] = ()
     rng = ops.drop_rng(device)
     mods = [m for m in list(owner.modules()) + list(extra) if isinstance(m, _PostNormBase)]
     # nothing draws from the generator when every rate is zero: skip the (device-side) epoch advance then
-    active = any(getattr(m, "dropout_p", 0.0) > 0 or getattr(m, "cls_dropout_p", 0.0) > 0 for m in mods) or \
+    active = any(getattr(m, "dropout_p", 0.0) > 0 or (hasattr(m, "cls_head") and getattr(m, "cls_dropout_p", 0.0) > 0)
+                 for m in mods) or \
         any(isinstance(m, nn.Dropout) and m.p > 0 for m in owner.modules())
     if active and rng.epoch == getattr(owner, "_drop_epoch", -1):
         rng.advance()
@@ -100,8 +101,9 @@ def mlp_head_forward(seq: nn.Sequential, x: torch.Tensor, ct: int, fill_flag=Non
 
 def linear_ln_forward(seq: nn.Sequential, x: torch.Tensor, ct: int) -> torch.Tensor:
     """nn.Sequential(Linear, LayerNorm) as used by the encoders (object_encoder.py:34, query3d_unified.py:20,63-70)."""
-    y = ops.linear(x, seq[0].weight, seq[0].bias, ct=ct)
-    return ops.add_layernorm(None, [y], [seq[1].weight], [seq[1].bias], eps=seq[1].eps)
+    # the one-encoder case of the grouped Linear+LN op: 2 launches forward; its backward zero-fills every atomics target
+    # (LayerNorm parameter gradients, split-K weight gradient, bias column sums) with ONE fill
+    return ops.linear_ln_group([x], [seq[0].weight], [seq[0].bias], [seq[1].weight], [seq[1].bias], ct=ct, eps=seq[1].eps)[0]
 
 
 def _xavier(module: nn.Module) -> None:
