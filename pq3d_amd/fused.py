@@ -214,7 +214,7 @@ def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None,
                       L.lib().pq3d_attn_fwd, C.byref(d), L.stream()), "pq3d_attn_fwd")
     else:
         d.dout, d.dq, d.dk, d.dv, d.delta, d.dbias = map(L.ptr, bwd)
-        L.check(timed("pq3d_attn_bwd", key, 14.0 * B * Lq * Lk * dm, (q.numel() * 3 + k.numel() * 4) * q.element_size(),
+        L.check(timed("pq3d_attn_bwd", key, 8.0 * B * Lq * Lk * dm, (q.numel() * 3 + k.numel() * 4) * q.element_size(),
                       L.lib().pq3d_attn_bwd, C.byref(d), L.stream()), "pq3d_attn_bwd")
 
 

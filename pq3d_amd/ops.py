@@ -308,7 +308,9 @@ class _Attention(Function):
         d.dout, d.dq, d.dk, d.dv, d.delta, d.dbias = map(L.ptr, (do, dq, dk, dv, delta, dbias))
         B, Lq, dm = q.shape
         Lk = k.shape[1]
-        fl = 14.0 * B * Lq * Lk * dm  # dQ kernel: S, dP, dQ (6) + dK/dV kernel: S, dP, dK, dV (8) per B*Lq*Lk*d
+        # ALGORITHMIC flops (backward = 2 x forward = 8 B Lq Lk d); the two recompute kernels EXECUTE 14:
+        # dQ kernel S, dP, dQ (6) + dK/dV kernel S, dP, dK, dV (8)
+        fl = 8.0 * B * Lq * Lk * dm
         nb = (q.numel() * 3 + k.numel() * 4) * q.element_size()
         L.check(timed("pq3d_attn_bwd", f"B{B}H{H}Lq{Lq}Lk{Lk}dh{dm // H}ct{ct}", fl, nb, L.lib().pq3d_attn_bwd,
                       C.byref(d), L.stream()), "pq3d_attn_bwd")
