@@ -309,6 +309,16 @@ int pq3d_scatter_mean_fwd(const float* src, const int64_t* index, float* out, fl
                           int64_t S, void* stream);
 int pq3d_scatter_mean_bwd(const float* dout, const int64_t* index, const float* count, float* dsrc, int64_t N,
                           int64_t C, void* stream);
+/* Multi-scale segment pooling (PCDMask3DSegLevelEncoder.forward, pcd_mask3d_encoder.py:133-152): the reference
+ * up-samples a coarse level to full resolution with (4 - hlevel) MinkowskiPoolingTranspose(kernel 2, stride 2) calls --
+ * every fine voxel receives the feature of its one coarse ancestor -- and then scatter_means over point2segment.  Here
+ * the up-sampling is the index composition parent[v] (fine voxel -> row of the coarse level): out[s,:] =
+ * mean_{v: index[v]==s} src[parent[v],:]; src [Nc,C] fp32.  Backward scatter-adds dout[index[v]]/count into a zeroed
+ * dsrc [Nc,C].  Rows with an out-of-range segment or parent are skipped. */
+int pq3d_upsample_scatter_mean_fwd(const float* src, const int64_t* parent, const int64_t* index, float* out, float* count,
+                                   int64_t N, int64_t Nc, int64_t C, int64_t S, void* stream);
+int pq3d_upsample_scatter_mean_bwd(const float* dout, const int64_t* parent, const int64_t* index, const float* count,
+                                   float* dsrc, int64_t N, int64_t Nc, int64_t C, int64_t S, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer side of the training step around the path: what Query3DTrainer.backward does after

@@ -178,6 +178,10 @@ _SIGS = {
     "pq3d_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                               C.c_void_p],
     "pq3d_scatter_mean_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
+    "pq3d_upsample_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                       C.c_int64, C.c_int64, C.c_void_p],
+    "pq3d_upsample_scatter_mean_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                       C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_sumsq_partials": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "pq3d_train_scalars": [C.POINTER(AdamWHp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "pq3d_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AdamWHp), C.POINTER(OptSegments),

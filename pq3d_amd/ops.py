@@ -553,6 +553,66 @@ def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch
     return _ScatterMean.apply(src, index, int(dim_size))
 
 
+class _UpsampleScatterMean(Function):
+    @staticmethod
+    def forward(ctx, src, parent, index, dim_size):
+        src, parent, index = _c(src), _c(parent), _c(index)
+        Nc, C_ = src.shape
+        N = index.numel()
+        out = _empty(dim_size, C_, dtype=torch.float32, device=src.device)
+        count = _empty(dim_size, dtype=torch.float32, device=src.device)
+        L.check(L.lib().pq3d_upsample_scatter_mean_fwd(L.ptr(src), L.ptr(parent), L.ptr(index), L.ptr(out), L.ptr(count), N,
+                                                       Nc, C_, dim_size, L.stream()), "pq3d_upsample_scatter_mean_fwd")
+        ctx.save_for_backward(parent, index, count)
+        ctx.nc = Nc
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        parent, index, count = ctx.saved_tensors
+        dout = dout.contiguous()
+        C_ = dout.shape[1]
+        dsrc = _empty(ctx.nc, C_, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().pq3d_upsample_scatter_mean_bwd(L.ptr(dout), L.ptr(parent), L.ptr(index), L.ptr(count), L.ptr(dsrc),
+                                                       index.numel(), ctx.nc, C_, dout.shape[0], L.stream()),
+                "pq3d_upsample_scatter_mean_bwd")
+        return dsrc, None, None, None
+
+
+def upsample_scatter_mean(src: torch.Tensor, parent: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
+    """scatter_mean(upsample(src), index): ``src`` [Nc, C] are the features of a COARSE voxel level, ``parent`` [N] the
+    coarse row of every full-resolution voxel (the composition of the stride-2 pooling maps, see
+    ``compose_parents`` / ``parents_from_coords``), ``index`` [N] its segment (pcd_mask3d_encoder.py:133-152 without
+    the up-sampled intermediate)."""
+    assert src.dtype == torch.float32 and parent.dtype == torch.int64 and index.dtype == torch.int64 and src.dim() == 2
+    assert parent.numel() == index.numel()
+    return _UpsampleScatterMean.apply(src, parent, index, int(dim_size))
+
+
+def compose_parents(maps) -> torch.Tensor:
+    """Fine -> coarse row index through a chain of per-level parent maps [fine->l1, l1->l2, ...] (index composition in
+    place of repeated MinkowskiPoolingTranspose)."""
+    p = maps[0]
+    for m in maps[1:]:
+        p = m[p]
+    return p
+
+
+def parents_from_coords(fine: torch.Tensor, coarse: torch.Tensor, stride: int) -> torch.Tensor:
+    """Row of ``coarse`` [Nc, 1+3] (batch, x, y, z; tensor stride ``stride``) that holds each voxel of ``fine`` [N, 1+3]:
+    the coarse voxel at floor(xyz / stride) * stride in the same batch item -- the coordinate map a stride-2^k
+    MinkowskiEngine pooling / transposed pooling pair uses.  -1 where the coarse level has no such voxel."""
+    def key(c):
+        c = c.long()
+        q = torch.div(c[:, 1:], stride, rounding_mode="floor") + (1 << 19)
+        return ((c[:, 0] << 60) | (q[:, 0] << 40) | (q[:, 1] << 20) | q[:, 2])
+    kc, kf = key(coarse), key(fine)
+    order = torch.argsort(kc)
+    pos = torch.searchsorted(kc[order], kf).clamp_(max=kc.numel() - 1)
+    hit = order[pos]
+    return torch.where(kc[hit] == kf, hit, torch.full_like(hit, -1))
+
+
 # ------------------------------------------------------------------------------------------------ grouped Linear + LN
 class _LinearLNGroup(Function):
     """G independent nn.Sequential(Linear, LayerNorm) encoders of identical shape in 2 launches forward

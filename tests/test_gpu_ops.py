@@ -272,3 +272,36 @@ def test_gate_fill_colsum_scatter():
     gy = rnd(320, 96, seed=3)
     out.backward(gy.to(DEV)); outr.backward(gy)
     close(sd.grad, sr.grad, F32, "scatter_mean grad")
+
+
+def test_multiscale_segment_pool_matches_oracle():
+    """Voxel -> segment pooling of a coarse backbone level through the composed parent index
+    (pcd_mask3d_encoder.py:133-152) against the oracle's materialised up-sampling + scatter_mean; two scenes batched
+    through offset segment ids; gradient w.r.t. the coarse features; parents recovered from coordinates."""
+    g = torch.Generator().manual_seed(5)
+    fine = torch.cat([torch.cat([torch.full((n, 1), b), torch.randint(-40, 40, (n, 3), generator=g)], 1)
+                      for b, n in ((0, 3000), (1, 2200))]).unique(dim=0)
+    N = fine.shape[0]
+    maps, coords, cur = [], [], fine
+    for lvl in range(1, 4):                      # strides 2, 4, 8: the chain of stride-2 poolings
+        cc, par = O.pooling_transpose_parents(cur, 2 ** lvl)
+        maps.append(par); coords.append(cc); cur = cc
+    S = 57
+    seg = torch.randint(0, S, (N,), generator=g) + fine[:, 0] * S          # segment ids offset per scene
+    for lvl in (1, 3):
+        Nc = coords[lvl - 1].shape[0]
+        feat = rnd(Nc, 96, seed=lvl)
+        parent = ops.compose_parents([m.to(DEV) for m in maps[:lvl]])
+        assert torch.equal(parent.cpu(), ops.compose_parents(maps[:lvl]))
+        # the same map straight from the coordinates of the two levels
+        assert torch.equal(ops.parents_from_coords(fine.to(DEV), coords[lvl - 1].to(DEV), 2 ** lvl), parent)
+        fd = feat.to(DEV).requires_grad_(True)
+        out = ops.upsample_scatter_mean(fd, parent, seg.to(DEV), 2 * S)
+        fr = feat.clone().requires_grad_(True)
+        outr = O.multiscale_segment_pool(fr, ops.compose_parents(maps[:lvl]), seg, 2 * S)
+        close(out, outr, F32, f"multiscale pool level {lvl}", atol=1e-5, rtol=1e-5)
+        gy = rnd(2 * S, 96, seed=9)
+        out.backward(gy.to(DEV)); outr.backward(gy)
+        close(fd.grad, fr.grad, F32, f"multiscale pool grad level {lvl}", atol=1e-5, rtol=1e-5)
+    missing = ops.parents_from_coords(torch.tensor([[0, 1000, 0, 0]], device=DEV), coords[0].to(DEV), 2)
+    assert int(missing[0]) == -1
