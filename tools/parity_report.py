@@ -21,7 +21,9 @@ def main():
     dev = "cuda"
     print(f"{'fixture':18s} {'compute':8s} {'vs':16s} {'query':>9s} {'head':>9s} {'mask-logit':>10s} {'flip-rate':>10s} "
           f"{'loss':>9s} {'worst-grad':>10s}  worst-grad-name")
-    for name in [f for f in util.fixtures() if not f.startswith(("F3_", "F6_"))]:
+    model_fixtures = [f for f in util.fixtures()
+                      if not f.startswith(("F3_", "F6_", "F7_", "F8_", "F9_", "F10_", "F11_", "F12_"))]
+    for name in model_fixtures:
         z, args = util.load_fixture(name)
         for compute, emu in (("fp32", None), ("bf16", torch.bfloat16), ("bf16", None)):
             _cfg, model, sd, dd = util.model_case(args)
