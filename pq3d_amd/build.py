@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpq3d_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "loss.hip", "pointnet2.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "loss.hip", "pointnet2.hip", "gemm128.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-Wno-unused-result"]
 

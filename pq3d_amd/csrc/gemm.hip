@@ -20,6 +20,8 @@ extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol
 #define DBG_STAMP(i)
 #endif
 
+bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s);   // gemm128.hip
+
 namespace {
 
 constexpr int BM = 64, BN = 64, NT = 256;
@@ -645,6 +647,10 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   PQ_CHECK_ARG(!any_cs || (d.transA && d.transB && kc == 1 && d.batch == 1 && d.splitk > 1),
                "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated split-K GEMM");
   hipStream_t s = (hipStream_t)stream;
+  if (pq3d_gemm_nt128_try(d, s)) {   // plain big bf16 NT products: 128x128 tiles (gemm128.hip), same bits
+    PQ_LAUNCH_CHECK();
+    return 0;
+  }
   if (d.splitk > 1) {
     PQ_CHECK_ARG(d.dtC == PQ3D_F32, "pq3d_gemm: split-K needs fp32 C");
     PQ_CHECK_ARG(d.ldc == d.N && (d.batch == 1 || d.strideC == (int64_t)d.M * d.N),

@@ -259,13 +259,24 @@ class _FusedDecoder(Function):
         ctx.kin, ctx.vin, ctx.kin2 = kin, vin, kin2
         # ---- hoisted K/V projections: KV[l, 0|1, m] = (feat_m [+ pos]) @ W{k,v}_{l,m}^T + b
         KV = torch.empty(Ln, 2, M, B, Ns, d, dtype=ad, device=dev)
+        # bf16 path: the K/V rows of every in_proj_weight are rounded ONCE (one launch) instead of by each of the M/64 row
+        # tiles that read them; with both operands in bf16 the projection takes the 128x128-tile kernel (gemm128.hip),
+        # whose output is bit-identical to converting in flight
+        wkv = None
+        if kin2[0] is None and ct == BF16 and Ln * M <= MAXG and (2 * d * d) % 8 == 0:
+            wkv = torch.empty(Ln, M, 2 * d, d, dtype=ad, device=dev)
+            srcs = [ca.multihead_attn.in_proj_weight.detach()[d:] for i in range(Ln) for ca in cas[i]]
+            outs = [wkv[i, j] for i in range(Ln) for j in range(M)]
+            arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
+            L.check(L.lib().pq3d_add_cast(arr(srcs), arr([None] * len(srcs)), arr(outs), len(srcs), L.BF16, 2 * d * d,
+                                          L.stream()), "pq3d_add_cast")
         A, A2, Bw, bs, Cs = [], [], [], [], []
         for i in range(Ln):
             for j, ca in enumerate(cas[i]):
                 w, b = ca.multihead_attn.in_proj_weight.detach(), ca.multihead_attn.in_proj_bias.detach()
                 A += [kin[j], vin[j]]
                 A2 += [kin2[j], None]
-                Bw += [w[d:2 * d], w[2 * d:]]
+                Bw += [w[d:2 * d], w[2 * d:]] if wkv is None else [wkv[i, j, :d], wkv[i, j, d:]]
                 bs += [b[d:2 * d], b[2 * d:]]
                 Cs += [KV[i, 0, j], KV[i, 1, j]]
         for s in range(0, len(A), MAXG):

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import pq3d_oracle as O
+from pq3d_amd import _lib as L
 from pq3d_amd import ops
 from pq3d_amd._lib import BF16, F32
 
@@ -305,3 +306,20 @@ def test_multiscale_segment_pool_matches_oracle():
         close(fd.grad, fr.grad, F32, f"multiscale pool grad level {lvl}", atol=1e-5, rtol=1e-5)
     missing = ops.parents_from_coords(torch.tensor([[0, 1000, 0, 0]], device=DEV), coords[0].to(DEV), 2)
     assert int(missing[0]) == -1
+
+
+@pytest.mark.parametrize("M,N,K,G", [(8192, 256, 256, 6), (2100, 128, 64, 32), (4096, 512, 128, 2)])
+def test_gemm_nt128_tile_matches_64_tile_bit_for_bit(M, N, K, G):
+    """Big plain bf16 NT products take the 128x128-tile kernel (gemm128.hip) when both operands are bf16; with fp32 weights
+    the 64x64-tile kernel converts them in flight.  Same rounding points, same k order -> identical bits; also vs torch."""
+    A = [rnd(M, K, seed=g).to(DEV).bfloat16() for g in range(G)]
+    W = [(rnd(N, K, seed=100 + g) * 0.1).to(DEV) for g in range(G)]
+    b = [rnd(N, seed=200 + g).to(DEV) for g in range(G)]
+    C_new = torch.zeros(G, M, N, dtype=torch.bfloat16, device=DEV)
+    C_old = torch.zeros_like(C_new)
+    L.gemm(M=M, N=N, K=K, A=A, B=[w.bfloat16() for w in W], bias=b, Cs=[C_new[g] for g in range(G)], ct=BF16, lda=K, ldb=K, ldc=N)
+    L.gemm(M=M, N=N, K=K, A=A, B=W, bias=b, Cs=[C_old[g] for g in range(G)], ct=BF16, lda=K, ldb=K, ldc=N)
+    assert torch.equal(C_new, C_old), float((C_new.float() - C_old.float()).abs().max())
+    for g in (0, G - 1):
+        ref = A[g].float() @ W[g].bfloat16().float().T + b[g]
+        close(C_new[g].float(), ref, BF16, "gemm128")
