@@ -21,6 +21,7 @@ extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol
 #endif
 
 bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s);   // gemm128.hip
+bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, hipStream_t s);   // gemm128.hip
 
 namespace {
 
@@ -666,6 +667,10 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
         }
       }
     }
+  }
+  if (pq3d_gemm_tt128_try(d, s)) {   // big bf16 weight-gradient products: 128x128 tiles, own split factor
+    PQ_LAUNCH_CHECK();
+    return 0;
   }
   dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (d.groups / kc) * d.batch * d.splitk);
   bool a2 = false, b2 = false;

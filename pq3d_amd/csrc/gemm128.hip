@@ -92,7 +92,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
+// ---- TT variant: weight gradients  C[m][n] (fp32) += alpha * sum_k A[k][m] * B[k][n]  (dW = dY^T X), split-K with
+// atomics onto a zeroed / accumulating C, optional fused bias gradient colsum[m] += alpha * sum_k A[k][m].
+// Both operands are row-major [K, *] bf16 (k strided): the tiles stay in that orientation in LDS ([k][m], one 16-byte
+// write per chunk) and the MFMA fragments come from the transposing LDS read, as in gemm.hip's TT path.
+constexpr int LDM = TM + 8;   // padded [k][m] row (bf16 elements)
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
+PQ_DEV u32x4 km_frag128(const bf16_t* tile, int r0, int ks, int li, int lg) {
+  const bf16_t* p0 = tile + (ks * 32 + 8 * lg + (li >> 2)) * LDM + r0 + 4 * (li & 3);
+  const v4i16_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)p0);
+  const v4i16_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(p0 + 4 * LDM));
+  const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
+  return (u32x4){lo.x, lo.y, hi.x, hi.y};
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_tt128_kernel(const pq3d_gemm_desc d,
+                                                                                                    const int nsplit) {
+  __shared__ __attribute__((aligned(16))) bf16_t As[TK * LDM];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[TK * LDM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int split = blockIdx.z % nsplit, g = blockIdx.z / nsplit, m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const int nkt = d.K / TK, per = (nkt + nsplit - 1) / nsplit;
+  const int kt0 = split * per, kt1 = min(nkt, kt0 + per);
+  if (kt0 >= kt1) return;
+  const bf16_t* A = (const bf16_t*)d.A[g];
+  const bf16_t* B = (const bf16_t*)d.B[g];
+  // staging: thread -> (k row = tid / 16 of a 16-row pass, 16-byte chunk = tid % 16 of the 128-wide m / n slice)
+  const int srow = tid >> 4, sch = (tid & 15) * 8;
+  const long astep = 16 * d.lda, bstep = 16 * d.ldb;
+  const bf16_t* ap = A + (long)srow * d.lda + m0 + sch;
+  const bf16_t* bp = B + (long)srow * d.ldb + n0 + sch;
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const bf16_t* a0 = ap + (long)kt * TK * d.lda;
+    const bf16_t* b0 = bp + (long)kt * TK * d.ldb;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      ra[p] = *(const u32x4*)(a0 + p * astep);
+      rb[p] = *(const u32x4*)(b0 + p * bstep);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float* cs_out = blockIdx.y == 0 ? d.colsum[g] : nullptr;   // uniform per block
+  float bsum = 0.f;
+
+  gload(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *(u32x4*)&As[(p * 16 + srow) * LDM + sch] = ra[p];
+      *(u32x4*)&Bs[(p * 16 + srow) * LDM + sch] = rb[p];
+    }
+    __syncthreads();
+    if (kt + 1 < kt1) gload(kt + 1);
+    if (cs_out && tid < TM) {   // bias gradient: column sums of the staged A tile
+#pragma unroll 8
+      for (int k = 0; k < TK; ++k) bsum += bf2f(As[k * LDM + tid]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < TK / 32; ++ks) {
+      u32x4 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = km_frag128(As, wm + i * 16, ks, li, lg);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = km_frag128(Bs, wn + j * 16, ks, li, lg);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<bf16_t>::mma(acc[i][j], af[i], bf[j]);
+    }
+    __syncthreads();
+  }
+  if (cs_out && tid < TM) unsafeAtomicAdd(&cs_out[m0 + tid], bsum * d.alpha);
+  float* C = (float*)d.C[g];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* crow = C + (long)(m0 + wm + i * 16 + 4 * lg + r) * d.ldc + n0 + wn + li;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) unsafeAtomicAdd(crow + j * 16, acc[i][j][r] * d.alpha);
+    }
+}
+
 }  // namespace
+
+// Weight-gradient products (split-K launches; C already zeroed by pq3d_gemm unless it accumulates).  The split factor
+// is this kernel's own: ~3 workgroups per CU with at least 4 k-tiles each.
+bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
+  if (d.ct != PQ3D_BF16 || d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16 || d.dtC != PQ3D_F32) return false;
+  if (!d.transA || !d.transB || d.batch != 1 || d.kconcat > 1 || d.splitk <= 1 || d.act || d.act_grad) return false;
+  if (d.M % TM || d.N % TN || d.K % TK || d.K < 8 * TK || d.ldc != d.N) return false;
+  if (d.lda % 8 || d.ldb % 8) return false;
+  if (d.row_scale || d.row_fill_flag || d.mask_out) return false;
+  for (int g = 0; g < d.groups; ++g) {
+    if (d.A2[g] || d.B2[g] || d.C2[g] || d.aux[g] || d.row_mask[g] || d.bias[g]) return false;
+    if ((((uintptr_t)d.A[g]) | ((uintptr_t)d.B[g])) & 15) return false;
+  }
+  const long tiles = (long)(d.M / TM) * (d.N / TN) * d.groups;
+  const int nkt = d.K / TK;
+  int nsplit = (int)((768 + tiles - 1) / tiles);
+  if (nsplit > nkt / 4) nsplit = nkt / 4;
+  if (nsplit < 1) nsplit = 1;
+  if (tiles * nsplit < 256) return false;   // too small to fill the chip: the 64x64 tile spreads it better
+  hipLaunchKernelGGL(gemm_tt128_kernel, dim3(d.M / TM, d.N / TN, d.groups * nsplit), dim3(256), 0, s, d, nsplit);
+  return true;
+}
 
 // Eligibility is decided here so that pq3d_gemm stays the single entry point (gemm.hip calls this first).
 bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {

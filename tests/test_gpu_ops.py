@@ -323,3 +323,23 @@ def test_gemm_nt128_tile_matches_64_tile_bit_for_bit(M, N, K, G):
     for g in (0, G - 1):
         ref = A[g].float() @ W[g].bfloat16().float().T + b[g]
         close(C_new[g].float(), ref, BF16, "gemm128")
+
+
+@pytest.mark.parametrize("R,M,N,G,acc", [(8192, 256, 256, 6, False), (4096, 128, 256, 12, True), (1024, 256, 128, 32, True)])
+def test_gemm_tt128_weight_gradient_tile(R, M, N, G, acc):
+    """Big bf16 weight-gradient products dW = dY^T X (+ fused bias gradient) take the 128x128-tile split-K kernel
+    (gemm128.hip): products of bf16 values are exact in fp32, so the result matches the fp32 matmul of the same bf16
+    operands up to the summation order; accumulate=True adds onto the existing contents."""
+    gs = [rnd(R, M, seed=g).to(DEV).bfloat16() for g in range(G)]
+    xs = [rnd(R, N, seed=50 + g).to(DEV).bfloat16() for g in range(G)]
+    base = rnd(G, M, N, seed=7).to(DEV) if acc else torch.zeros(G, M, N, device=DEV)
+    dW = base.clone() if acc else torch.full((G, M, N), 123.0, device=DEV)      # non-accumulating call must overwrite
+    cb = torch.zeros(G, M, device=DEV) if acc else torch.full((G, M), -5.0, device=DEV)
+    L.gemm(M=M, N=N, K=R, A=gs, B=xs, Cs=[dW[g] for g in range(G)], ct=BF16, lda=M, ldb=N, ldc=N, transA=True, transB=True,
+           splitk=2, accumulate=acc, colsum=[cb[g] for g in range(G)])
+    for g in (0, G // 2, G - 1):
+        ref = base[g] + gs[g].float().T @ xs[g].float()
+        err = float((dW[g] - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-5, (g, err)
+        refb = gs[g].float().sum(0)
+        assert float((cb[g] - refb).abs().max()) / float(refb.abs().max()) < 2e-5
