@@ -14,16 +14,18 @@ namespace {
 constexpr int TM = 128, TN = 128, TK = 64, LDT = TK + 8;   // padded LDS row: 144 B -> conflict-free 16-byte fragment reads
 constexpr int LDC = TN + 8;                                 // bf16 C staging row
 
+template <bool F32OUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_nt128_kernel(const pq3d_gemm_desc d) {
   __shared__ __attribute__((aligned(16))) bf16_t As[TM * LDT];
   __shared__ __attribute__((aligned(16))) bf16_t Bs[TN * LDT];
   static_assert(sizeof(bf16_t) * TM * LDC <= sizeof(bf16_t) * (TM + TN) * LDT, "C staging must fit in the operand tiles");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int g = blockIdx.z, m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const int kc = d.kconcat > 0 ? d.kconcat : 1;   // kc consecutive groups are concatenated along K into one output
+  const int g = blockIdx.z * kc, m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
   const bf16_t* A = (const bf16_t*)d.A[g];
   const bf16_t* B = (const bf16_t*)d.B[g];
-  const int nkt = d.K / TK;
+  const int nk1 = d.K / TK, nkt = nk1 * kc;
 
   // staging: thread -> (row = tid / 8 of a 32-row pass, 16-byte chunk = tid % 8 of the 64-wide k slice)
   const int srow = tid >> 3, sch = (tid & 7) * 8;
@@ -33,7 +35,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (int p = 0; p < 4; ++p) aoff[p] = min(m0 + p * 32 + srow, d.M - 1) * (int)d.lda + sch;   // rows past M: clamped
   const int boff = (n0 + srow) * (int)d.ldb + sch, bstep = 32 * (int)d.ldb;
   u32x4 ra[4], rb[4];
-  auto gload = [&](int kt) {
+  auto gload = [&](int t) {
+    int kt = t;
+    if (kc > 1) {   // uniform: switch to the operands of the group this k-tile belongs to
+      const int gi = t / nk1;
+      kt = t - gi * nk1;
+      A = (const bf16_t*)d.A[g + gi];
+      B = (const bf16_t*)d.B[g + gi];
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       ra[p] = *(const u32x4*)(A + aoff[p] + kt * TK);
@@ -70,25 +79,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
   }
 
-  // epilogue: + bias, round to bf16, transpose through LDS so that every row leaves as 256 contiguous bytes
-  bf16_t* Ct = As;   // [TM][LDC] over both operand tiles (all fragment reads are behind the barrier above)
+  // epilogue: + bias, transpose through LDS (the operand tiles are dead: all fragment reads are behind the barrier
+  // above) so that every row leaves in whole 16-byte pieces of contiguous columns
   const float* bias = (const float*)d.bias[g];
+  if constexpr (!F32OUT) {
+    bf16_t* Ct = As;   // [TM][LDC] bf16
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = wn + j * 16 + li;
-    const float bn = bias ? bias[n0 + col] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const int col = wn + j * 16 + li;
+      const float bn = bias ? bias[n0 + col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ct[(wm + i * 16 + 4 * lg + r) * LDC + col] = f2bf(acc[i][j][r] * d.alpha + bn);
-  }
-  __syncthreads();
-  bf16_t* C = (bf16_t*)d.C[g];
-  const int crow = tid >> 4, cch = (tid & 15) * 8;
+        for (int r = 0; r < 4; ++r) Ct[(wm + i * 16 + 4 * lg + r) * LDC + col] = f2bf(acc[i][j][r] * d.alpha + bn);
+    }
+    __syncthreads();
+    bf16_t* C = (bf16_t*)d.C[g];
+    const int crow = tid >> 4, cch = (tid & 15) * 8;
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int row = p * 16 + crow;
-    if (m0 + row < d.M) *(u32x4*)(C + (long)(m0 + row) * d.ldc + n0 + cch) = *(const u32x4*)&Ct[row * LDC + cch];
+    for (int p = 0; p < 8; ++p) {
+      const int row = p * 16 + crow;
+      if (m0 + row < d.M) *(u32x4*)(C + (long)(m0 + row) * d.ldc + n0 + cch) = *(const u32x4*)&Ct[row * LDC + cch];
+    }
+  } else {
+    constexpr int LDF = TN + 4;
+    static_assert(sizeof(float) * 64 * LDF <= sizeof(bf16_t) * (TM + TN) * LDT, "fp32 half tile must fit");
+    float* Cf = (float*)As;   // [64][LDF] fp32: the 128 rows leave in two halves
+    float* C = (float*)d.C[g];
+    const int crow = tid >> 5, cch = (tid & 31) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (wm == h * 64) {   // the two waves that own this half
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = wn + j * 16 + li;
+          const float bn = bias ? bias[n0 + col] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cf[(i * 16 + 4 * lg + r) * LDF + col] = acc[i][j][r] * d.alpha + bn;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int row = p * 8 + crow;
+        if (m0 + h * 64 + row < d.M)
+          *(float4*)(C + (long)(m0 + h * 64 + row) * d.ldc + n0 + cch) = *(const float4*)&Cf[row * LDF + cch];
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -207,8 +247,10 @@ bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
 
 // Eligibility is decided here so that pq3d_gemm stays the single entry point (gemm.hip calls this first).
 bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
-  if (d.ct != PQ3D_BF16 || d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16 || d.dtC != PQ3D_BF16) return false;
-  if (d.transA || d.transB || d.batch != 1 || d.kconcat > 1 || d.splitk > 1 || d.act || d.act_grad) return false;
+  if (d.ct != PQ3D_BF16 || d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16) return false;
+  if (d.dtC != PQ3D_BF16 && d.dtC != PQ3D_F32) return false;
+  const int kc = d.kconcat > 0 ? d.kconcat : 1;
+  if (d.transA || d.transB || d.batch != 1 || d.splitk > 1 || d.act || d.act_grad) return false;
   if (d.M < TM || d.N % TN || d.K % TK || d.K < TK) return false;
   if (d.lda % 8 || d.ldb % 8 || d.ldc % 8) return false;
   if ((long)d.M * d.lda >= (1L << 31) || (long)d.N * d.ldb >= (1L << 31)) return false;
@@ -216,11 +258,15 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   for (int g = 0; g < d.groups; ++g) {
     if (d.A2[g] || d.B2[g] || d.C2[g] || d.aux[g] || d.row_mask[g] || d.colsum[g]) return false;
     if (d.bias[g] && d.dtBias != PQ3D_F32) return false;
-    if ((((uintptr_t)d.A[g]) | ((uintptr_t)d.B[g]) | ((uintptr_t)d.C[g])) & 15) return false;
+    if ((((uintptr_t)d.A[g]) | ((uintptr_t)d.B[g])) & 15) return false;
+    if ((g % kc) == 0 && (((uintptr_t)d.C[g]) & 15)) return false;
   }
-  // worth it only when the launch still fills the chip: at least ~2 workgroups per CU
-  const long tiles = (long)((d.M + TM - 1) / TM) * (d.N / TN) * d.groups;
-  if (tiles < 512) return false;
-  hipLaunchKernelGGL(gemm_nt128_kernel, dim3((d.M + TM - 1) / TM, d.N / TN, d.groups), dim3(256), 0, s, d);
+  // worth it only when the launch still fills the chip: >= 2 workgroups per CU, or >= 1 per CU with a long K loop
+  const long tiles = (long)((d.M + TM - 1) / TM) * (d.N / TN) * (d.groups / kc);
+  const long nkt = (long)(d.K / TK) * kc;
+  if (tiles < 512 && !(tiles >= 256 && nkt >= 16) && !(tiles >= 128 && nkt >= 32)) return false;
+  const dim3 grid((d.M + TM - 1) / TM, d.N / TN, d.groups / kc);
+  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL(gemm_nt128_kernel<true>, grid, dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(gemm_nt128_kernel<false>, grid, dim3(256), 0, s, d);
   return true;
 }

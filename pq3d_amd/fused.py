@@ -257,6 +257,7 @@ class _FusedDecoder(Function):
         else:
             kin, vin, kin2 = feats, feats, [pos] * M
         ctx.kin, ctx.vin, ctx.kin2 = kin, vin, kin2
+        ctx.wkv = None
         # ---- hoisted K/V projections: KV[l, 0|1, m] = (feat_m [+ pos]) @ W{k,v}_{l,m}^T + b
         KV = torch.empty(Ln, 2, M, B, Ns, d, dtype=ad, device=dev)
         # bf16 path: the K/V rows of every in_proj_weight are rounded ONCE (one launch) instead of by each of the M/64 row
@@ -270,6 +271,7 @@ class _FusedDecoder(Function):
             arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
             L.check(L.lib().pq3d_add_cast(arr(srcs), arr([None] * len(srcs)), arr(outs), len(srcs), L.BF16, 2 * d * d,
                                           L.stream()), "pq3d_add_cast")
+        ctx.wkv = wkv
         A, A2, Bw, bs, Cs = [], [], [], [], []
         for i in range(Ln):
             for j, ca in enumerate(cas[i]):
@@ -648,7 +650,19 @@ class _FusedDecoder(Function):
                 GWs += [gw[d:2 * d], gw[2 * d:]]
                 Gbs += [gb[d:2 * d], gb[2 * d:]]
         dwq.add(Akv, Xf, X2, GWs, ct, Gbs)
+        # bf16 path: the input-gradient products read TRANSPOSED bf16 copies of the K/V weights (one copy launch from the
+        # forward's pre-cast rows), which turns them into plain NT products -- the 128x128-tile kernel's layout -- and the
+        # memories then share launches (K-concatenation per memory, several outputs per launch)
+        tposed = ctx.wkv is not None and dKV.dtype == torch.bfloat16
+        if tposed:
+            wkvT = ctx.wkv.view(Ln, M, 2, d, d).transpose(-1, -2).contiguous()   # [l, m, t][k_in][n_out]
+            Bkv = [wkvT[tape[a]["i"], j, t] for a in range(n_app) for j in range(M) for t in (0, 1)]
+            kT = None
+            if dkeys is not None:
+                kT = torch.stack([mp.k_proj.weight.detach() for mp in list(spec.mh.mask_pred_list)[:spec.mh_count]]) \
+                    .transpose(1, 2).contiguous().to(ad)
         # d feat_m = sum_a (dK_{a,m} Wk + dV_{a,m} Wv) [+ mask-head key path]
+        jobs = []
         for j in range(M):
             if not need_feat[j]:
                 continue
@@ -658,17 +672,32 @@ class _FusedDecoder(Function):
                 mp = list(spec.mh.mask_pred_list)[j]
                 dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
                 Aj.append(dkm)
-                Bj.append(mp.k_proj.weight.detach())
+                Bj.append(kT[j] if tposed else mp.k_proj.weight.detach())
                 dwq.add([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
-            out = None
-            for s in range(0, len(Aj), MAXG):
-                nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
-                n = len(Aj[s:s + MAXG])
-                L.gemm(M=Rk, N=d, K=d, A=Aj[s:s + MAXG], B=Bj[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
-                       aux=([out] + [None] * (n - 1)) if out is not None else None,
-                       act_grad="add" if out is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=n)
-                out = nxt
-            dfeats[j] = out
+            jobs.append((j, Aj, Bj))
+        per = len(jobs[0][1]) if jobs else 0
+        if tposed and jobs and per <= MAXG and all(len(jb[1]) == per for jb in jobs):
+            cap = max(1, MAXG // per)   # memories per launch
+            for c0 in range(0, len(jobs), cap):
+                chunk = jobs[c0:c0 + cap]
+                outs = [torch.empty(B, Ns, d, dtype=torch.float32, device=dev) for _ in chunk]
+                L.gemm(M=Rk, N=d, K=d, A=[t_ for jb in chunk for t_ in jb[1]], B=[t_ for jb in chunk for t_ in jb[2]],
+                       Cs=[c_ for o_ in outs for c_ in [o_] + [None] * (per - 1)], ct=ct, lda=d, ldb=d, ldc=d,
+                       kconcat=per)
+                for jb, o_ in zip(chunk, outs):
+                    dfeats[jb[0]] = o_
+        else:
+            for j, Aj, Bj in jobs:
+                out = None
+                for s in range(0, len(Aj), MAXG):
+                    nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
+                    n = len(Aj[s:s + MAXG])
+                    L.gemm(M=Rk, N=d, K=d, A=Aj[s:s + MAXG], B=Bj[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
+                           aux=([out] + [None] * (n - 1)) if out is not None else None,
+                           act_grad="add" if out is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=not tposed,
+                           kconcat=n)
+                    out = nxt
+                dfeats[j] = out
         if dkeys is not None:  # k_proj weight grads for memories whose features need no grad
             for j in range(spec.mh_count):
                 if not need_feat[j]:
@@ -683,7 +712,8 @@ class _FusedDecoder(Function):
                 n = len(Ak[s:s + MAXG])
                 L.gemm(M=Rk, N=d, K=d, A=Ak[s:s + MAXG], B=Bk[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
                        aux=([dpos] + [None] * (n - 1)) if dpos is not None else None,
-                       act_grad="add" if dpos is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=n)
+                       act_grad="add" if dpos is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=not tposed,
+                       kconcat=n)
                 dpos = nxt
         dqpos = None
         if ctx.needs_input_grad[2]:

@@ -343,3 +343,19 @@ def test_gemm_tt128_weight_gradient_tile(R, M, N, G, acc):
         assert err < 2e-5, (g, err)
         refb = gs[g].float().sum(0)
         assert float((cb[g] - refb).abs().max()) / float(refb.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("M,kc,outs", [(8192, 8, 3), (8200, 8, 3), (2050, 12, 1)])
+def test_gemm_nt128_kconcat_fp32_out(M, kc, outs):
+    """K-concatenated NT products with fp32 output on the 128x128-tile kernel (the decoder's input-gradient sums over
+    layers): sum over kc (A_g, B_g) pairs per output, several outputs per launch, ragged last row tile."""
+    d = 256
+    G = kc * outs
+    A = [rnd(M, d, seed=g).to(DEV).bfloat16() for g in range(G)]
+    Bt = [(rnd(d, d, seed=300 + g) * 0.1).to(DEV).bfloat16() for g in range(G)]       # [n_out, k]
+    C = torch.full((outs, M, d), 7.0, device=DEV)
+    L.gemm(M=M, N=d, K=d, A=A, B=Bt, Cs=[c for o in range(outs) for c in [C[o]] + [None] * (kc - 1)], ct=BF16, lda=d, ldb=d,
+           ldc=d, kconcat=kc)
+    for o in range(outs):
+        ref = sum(A[o * kc + g].float() @ Bt[o * kc + g].float().T for g in range(kc))
+        assert float((C[o] - ref).abs().max()) / float(ref.abs().max()) < 2e-5
