@@ -264,7 +264,7 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   // worth it only when the launch still fills the chip: >= 2 workgroups per CU, or >= 1 per CU with a long K loop
   const long tiles = (long)((d.M + TM - 1) / TM) * (d.N / TN) * (d.groups / kc);
   const long nkt = (long)(d.K / TK) * kc;
-  if (tiles < 512 && !(tiles >= 256 && nkt >= 16) && !(tiles >= 128 && nkt >= 32)) return false;
+  if (tiles < 512 && !(tiles >= 256 && nkt >= 16)) return false;   // (128 tiles x 48 k-tiles measured equal to the 64x64 tile)
   const dim3 grid((d.M + TM - 1) / TM, d.N / TN, d.groups / kc);
   if (d.dtC == PQ3D_F32) hipLaunchKernelGGL(gemm_nt128_kernel<true>, grid, dim3(256), 0, s, d);
   else hipLaunchKernelGGL(gemm_nt128_kernel<false>, grid, dim3(256), 0, s, d);
