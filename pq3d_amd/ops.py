@@ -216,7 +216,9 @@ class _Linear(Function):
         dx = dx2 = dw = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
             dx = _empty(x.shape, dtype=x.dtype, device=x.device)
-            L.gemm(M=R, N=K, K=N, A=[g], B=[w], Cs=[dx], ct=ct, lda=N, ldb=K, ldc=K, transB=True)
+            # a long reduction over few output tiles (LM head: 512 x 512 outputs, N = 32128) is split over K
+            sk = _splitk(((R + 63) // 64) * ((K + 63) // 64), N, ct) if (dx.dtype == torch.float32 and N >= 8192) else 1
+            L.gemm(M=R, N=K, K=N, A=[g], B=[w], Cs=[dx], ct=ct, lda=N, ldb=K, ldc=K, transB=True, splitk=sk)
             dx2 = dx if (x2 is not None and ctx.needs_input_grad[3]) else None
             if not ctx.needs_input_grad[0]:
                 dx = None
