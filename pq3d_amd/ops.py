@@ -250,6 +250,68 @@ def linear(x, w, b=None, *, ct: int, x2=None, act: Optional[str] = None, out_dty
     return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value), drop, residual)
 
 
+class _LinearGroup(Function):
+    """[x_g @ W_g^T] for G bias-free same-shape linears in grouped launches (T5 q/k/v projections; the cross-attention
+    K/V projections of ALL decoder layers, which share the encoder tokens).  Backward: one K-concatenated product for
+    the inputs that are the same tensor (d x = sum_g dy_g W_g), one grouped split-K product for all weight gradients."""
+
+    @staticmethod
+    def forward(ctx, ct, out_dtype, G, *t):
+        xs, Ws = [_c(a) for a in t[:G]], [_c(w) for w in t[G:2 * G]]
+        K = xs[0].shape[-1]
+        R = xs[0].numel() // K
+        N = Ws[0].shape[0]
+        out = _empty(G, *xs[0].shape[:-1], N, dtype=out_dtype, device=xs[0].device)
+        for s in range(0, G, L.MAXG):
+            e = min(G, s + L.MAXG)
+            L.gemm(M=R, N=N, K=K, A=xs[s:e], B=Ws[s:e], Cs=[out[g] for g in range(s, e)], ct=ct, lda=K, ldb=K, ldc=N)
+        ctx.same_x = all(x.data_ptr() == xs[0].data_ptr() for x in xs)
+        ctx.save_for_backward(*xs, *Ws)
+        ctx.cfg = (ct, G)
+        return tuple(out[g] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        ct, G = ctx.cfg
+        xs, Ws = ctx.saved_tensors[:G], ctx.saved_tensors[G:]
+        K = xs[0].shape[-1]
+        R = xs[0].numel() // K
+        N = Ws[0].shape[0]
+        dev = xs[0].device
+        ad = act_dtype(ct)
+        gs = [(_c(g).to(ad) if g is not None else torch.zeros(R, N, dtype=ad, device=dev)) for g in dys]
+        need_dx = any(ctx.needs_input_grad[3 + g] for g in range(G))
+        dxs = [None] * G
+        if need_dx and ctx.same_x and G <= L.MAXG:      # d x = sum_g dy_g W_g: one K-concatenated product
+            dx = _empty(xs[0].shape, dtype=xs[0].dtype, device=dev)
+            L.gemm(M=R, N=K, K=N, A=gs, B=list(Ws), Cs=[dx] + [None] * (G - 1), ct=ct, lda=N, ldb=K, ldc=K, transB=True,
+                   kconcat=G)
+            dxs[0] = dx          # the same tensor was passed G times: autograd sums the slots, so only one carries it
+        elif need_dx:
+            dxb = _empty(G, *xs[0].shape, dtype=xs[0].dtype, device=dev)
+            for s in range(0, G, L.MAXG):
+                e = min(G, s + L.MAXG)
+                L.gemm(M=R, N=K, K=N, A=gs[s:e], B=list(Ws[s:e]), Cs=[dxb[g] for g in range(s, e)], ct=ct, lda=N, ldb=K,
+                       ldc=K, transB=True)
+            if ctx.same_x:
+                dxs[0] = dxb.sum(0)
+            else:
+                dxs = [dxb[g] for g in range(G)]
+        dWb = torch.zeros(G, N, K, dtype=torch.float32, device=dev)
+        tiles = ((N + 63) // 64) * ((K + 63) // 64)
+        for s in range(0, G, L.MAXG):
+            e = min(G, s + L.MAXG)
+            L.gemm(M=N, N=K, K=R, A=gs[s:e], B=list(xs[s:e]), Cs=[dWb[g] for g in range(s, e)], ct=ct, lda=N, ldb=K, ldc=K,
+                   transA=True, transB=True, splitk=max(2, _splitk(tiles * (e - s), R, ct)), accumulate=True)
+        return (None, None, None, *dxs, *[dWb[g] for g in range(G)])
+
+
+def linear_group(xs, Ws, *, ct: int, out_dtype=torch.float32):
+    """[x_g @ W_g^T for g] -- bias-free linears of one shape in grouped launches."""
+    G = len(xs)
+    return _LinearGroup.apply(ct, out_dtype, G, *xs, *Ws)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 _ATTN_KSPLIT = int(os.environ.get("PQ3D_ATTN_KSPLIT", "0"))   # experiments only; 0 = built-in rule
 

@@ -84,19 +84,24 @@ def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], 
     self_bias = pos_bias.masked_fill(causal, float("-inf")).unsqueeze(0).expand(B, H, T, T).contiguous()
     enc_kpm = enc_valid.logical_not().contiguous() if enc_valid is not None else None
     ad = ops.act_dtype(ct)
-    for blk in dec.block:
+    # cross-attention K/V projections of ALL layers read the same encoder tokens: one grouped launch (and one
+    # K-concatenated input-gradient product, one grouped weight-gradient product in the backward)
+    xkv = ops.linear_group([enc] * (2 * len(dec.block)),
+                           [w_.weight for blk in dec.block for w_ in (blk.layer[1].EncDecAttention.k,
+                                                                       blk.layer[1].EncDecAttention.v)], ct=ct, out_dtype=ad)
+    for li, blk in enumerate(dec.block):
         sa, ca, ff = blk.layer[0], blk.layer[1], blk.layer[2]
         # -- self attention
         h = ops.rmsnorm(x, sa.layer_norm.weight, cfg.layer_norm_epsilon)
         A = sa.SelfAttention
-        q, k, v = (ops.linear(h, w_.weight, None, ct=ct, out_dtype=ad) for w_ in (A.q, A.k, A.v))
+        q, k, v = ops.linear_group([h, h, h], [A.q.weight, A.k.weight, A.v.weight], ct=ct, out_dtype=ad)
         o = ops.attention(q, k, v, H=H, ct=ct, scale=1.0, bias=self_bias, drop=next_drop())
         x = proj_residual(o, A.o.weight)
         # -- cross attention to the projected query tokens (no position bias)
         h = ops.rmsnorm(x, ca.layer_norm.weight, cfg.layer_norm_epsilon)
         A = ca.EncDecAttention
         q = ops.linear(h, A.q.weight, None, ct=ct, out_dtype=ad)
-        k, v = (ops.linear(enc, w_.weight, None, ct=ct, out_dtype=ad) for w_ in (A.k, A.v))
+        k, v = xkv[2 * li], xkv[2 * li + 1]
         o = ops.attention(q, k, v, H=H, ct=ct, scale=1.0, kpm=enc_kpm, drop=next_drop())
         x = proj_residual(o, A.o.weight)
         # -- feed forward
