@@ -520,9 +520,13 @@ class _FusedDecoder(Function):
                        act_grad="add" if dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
                        strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
                 dkeys = newk
-                dqm = torch.empty(Mm, B, Nq, d, dtype=ad, device=dev)
+                # [Nq x d] outputs per (memory, scene) over a reduction of Ns segments: few tiles, long K -> split-K into an
+                # fp32 buffer once Ns is large (c4: 192 workgroups x 64 k-tiles otherwise)
+                sk = min(8, Ns // 512) if Ns >= 1024 else 1
+                dqm = torch.empty(Mm, B, Nq, d, dtype=torch.float32 if sk > 1 else ad, device=dev)
                 L.gemm(M=Nq, N=d, K=Ns, A=[g] * Mm, B=list(ctx.keys), Cs=[dqm[m] for m in range(Mm)], ct=ct, lda=Nq,
-                       ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d)
+                       ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d,
+                       splitk=sk)
                 nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=d, K=d, A=[dqm[m] for m in range(Mm)], B=[mp.q_proj.weight.detach() for mp in mps],
                        Cs=[nxt] + [None] * (Mm - 1), aux=[cur] + [None] * (Mm - 1), act_grad="add", ct=ct, lda=d, ldb=d,
