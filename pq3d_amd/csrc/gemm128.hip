@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }  // namespace
 
 // Weight-gradient products (split-K launches; C already zeroed by pq3d_gemm unless it accumulates).  The split factor
-// is this kernel's own: ~3 workgroups per CU with at least 4 k-tiles each.
+// is this kernel's own: ~1.5 workgroups per CU with at least 4 k-tiles each.
 bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   if (d.ct != PQ3D_BF16 || d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16 || d.dtC != PQ3D_F32) return false;
   if (!d.transA || !d.transB || d.batch != 1 || d.kconcat > 1 || d.splitk <= 1 || d.act || d.act_grad) return false;
@@ -237,7 +237,7 @@ bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   }
   const long tiles = (long)(d.M / TM) * (d.N / TN) * d.groups;
   const int nkt = d.K / TK;
-  int nsplit = (int)((768 + tiles - 1) / tiles);
+  int nsplit = (int)((384 + tiles - 1) / tiles);   // measured (tools/probes/dw_bench.py): 1.5 workgroups per CU; more splits lose to the atomics
   if (nsplit > nkt / 4) nsplit = nkt / 4;
   if (nsplit < 1) nsplit = 1;
   if (tiles * nsplit < 256) return false;   // too small to fill the chip: the 64x64 tile spreads it better
