@@ -3,7 +3,7 @@
 //
 // Why a second tile shape: at K = 256 a 64x64 tile loads 64 KB of operands for 8 KB of output (8 B of L2 traffic per
 // output byte -- 786 MB for the c2 hoisted projection, which is L2-bandwidth time, not MFMA time); 128x128 halves that.
-// Only the plain case lives here (no prologue adds, no activation / masks / split-K) so the register budget goes to the
+// Only the plain case lives here (bias / ReLU epilogue; no prologue adds, no GELU / masks / split-K) so the register budget goes to the
 // 4x4 accumulator block per wave (64 VGPRs) instead of options; everything else stays in gemm.hip.  The k order (one
 // accumulator per output, 32-wide MFMA steps in sequence) is gemm.hip's, so both kernels produce the same bits.
 // Bound: L2 -> LDS traffic / HBM write of C; algorithmic bytes per group: (M + N) * K * 2 + M * N * 2.
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // epilogue: + bias, transpose through LDS (the operand tiles are dead: all fragment reads are behind the barrier
   // above) so that every row leaves in whole 16-byte pieces of contiguous columns
   const float* bias = (const float*)d.bias[g];
+  const bool relu = d.act == PQ3D_ACT_RELU;
   if constexpr (!F32OUT) {
     bf16_t* Ct = As;   // [TM][LDC] bf16
 #pragma unroll
@@ -91,7 +92,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ct[(wm + i * 16 + 4 * lg + r) * LDC + col] = f2bf(acc[i][j][r] * d.alpha + bn);
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r] * d.alpha + bn;
+          Ct[(wm + i * 16 + 4 * lg + r) * LDC + col] = f2bf(relu ? fmaxf(v, 0.f) : v);
+        }
     }
     __syncthreads();
     bf16_t* C = (bf16_t*)d.C[g];
@@ -117,7 +121,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cf[(i * 16 + 4 * lg + r) * LDF + col] = acc[i][j][r] * d.alpha + bn;
+            for (int r = 0; r < 4; ++r) {
+              const float v = acc[i][j][r] * d.alpha + bn;
+              Cf[(i * 16 + 4 * lg + r) * LDF + col] = relu ? fmaxf(v, 0.f) : v;
+            }
         }
       }
       __syncthreads();
@@ -250,7 +257,7 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   if (d.ct != PQ3D_BF16 || d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16) return false;
   if (d.dtC != PQ3D_BF16 && d.dtC != PQ3D_F32) return false;
   const int kc = d.kconcat > 0 ? d.kconcat : 1;
-  if (d.transA || d.transB || d.batch != 1 || d.splitk > 1 || d.act || d.act_grad) return false;
+  if (d.transA || d.transB || d.batch != 1 || d.splitk > 1 || (d.act != PQ3D_ACT_NONE && d.act != PQ3D_ACT_RELU) || d.act_grad) return false;
   if (d.M < TM || d.N % TN || d.K % TK || d.K < TK) return false;
   if (d.lda % 8 || d.ldb % 8 || d.ldc % 8) return false;
   if ((long)d.M * d.lda >= (1L << 31) || (long)d.N * d.ldb >= (1L << 31)) return false;

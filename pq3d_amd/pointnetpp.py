@@ -122,7 +122,7 @@ class PointNetPP(nn.Module):
         bn = layer.bn.bn if hasattr(layer, "bn") else None
         src = [conv.weight] + ([conv.bias] if conv.bias is not None else []) + \
               ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
-        key = tuple((t.data_ptr(), t._version) for t in src)
+        key = tuple((t.data_ptr(), t._version) for t in src) + (self.ct,)
         hit = self._folded.get(id(layer))
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
@@ -134,7 +134,10 @@ class PointNetPP(nn.Module):
         Kp = (W.shape[1] + 7) // 8 * 8
         Wp = torch.zeros(W.shape[0], Kp, device=W.device)
         Wp[:, :W.shape[1]] = W
-        self._folded[id(layer)] = (key, Wp.contiguous(), b.contiguous())
+        Wp = Wp.contiguous()
+        if self.ct == ops.BF16:   # rounded once here instead of by every row tile (and eligible for the 128x128-tile GEMM)
+            Wp = Wp.to(torch.bfloat16)
+        self._folded[id(layer)] = (key, Wp, b.contiguous())
         return Wp, b
 
     def _mlp(self, rows, mlp: SharedMLP):
