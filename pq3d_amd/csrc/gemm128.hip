@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     static_assert(sizeof(float) * 64 * LDF <= sizeof(bf16_t) * (TM + TN) * LDT, "fp32 half tile must fit");
     float* Cf = (float*)As;   // [64][LDF] fp32: the 128 rows leave in two halves
     float* C = (float*)d.C[g];
+    const float* aux = d.act_grad == PQ3D_ACT_ADD ? (const float*)d.aux[g] : nullptr;
     const int crow = tid >> 5, cch = (tid & 31) * 4;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -131,8 +132,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const int row = p * 8 + crow;
-        if (m0 + h * 64 + row < d.M)
-          *(float4*)(C + (long)(m0 + h * 64 + row) * d.ldc + n0 + cch) = *(const float4*)&Cf[row * LDF + cch];
+        if (m0 + h * 64 + row < d.M) {
+          const long off = (long)(m0 + h * 64 + row) * d.ldc + n0 + cch;
+          float4 v = *(const float4*)&Cf[row * LDF + cch];
+          if (aux) {   // act_grad == ADD: C = product + aux (gradient accumulation), read as whole 16-byte pieces
+            const float4 x = *(const float4*)(aux + off);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+          }
+          *(float4*)(C + off) = v;
+        }
       }
       __syncthreads();
     }
@@ -257,13 +265,17 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   if (d.ct != PQ3D_BF16 || d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16) return false;
   if (d.dtC != PQ3D_BF16 && d.dtC != PQ3D_F32) return false;
   const int kc = d.kconcat > 0 ? d.kconcat : 1;
-  if (d.transA || d.transB || d.batch != 1 || d.splitk > 1 || (d.act != PQ3D_ACT_NONE && d.act != PQ3D_ACT_RELU) || d.act_grad) return false;
+  if (d.transA || d.transB || d.batch != 1 || d.splitk > 1 || (d.act != PQ3D_ACT_NONE && d.act != PQ3D_ACT_RELU)) return false;
+  const bool add = d.act_grad == PQ3D_ACT_ADD;   // "+ aux" epilogue: fp32 output and fp32 aux only
+  if (d.act_grad && !(add && d.dtC == PQ3D_F32 && d.dtAux == PQ3D_F32 && d.act == PQ3D_ACT_NONE)) return false;
   if (d.M < TM || d.N % TN || d.K % TK || d.K < TK) return false;
   if (d.lda % 8 || d.ldb % 8 || d.ldc % 8) return false;
   if ((long)d.M * d.lda >= (1L << 31) || (long)d.N * d.ldb >= (1L << 31)) return false;
   if (d.row_scale || d.row_fill_flag || d.mask_out || (d.drop.p > 0.f && d.drop.seed)) return false;
   for (int g = 0; g < d.groups; ++g) {
-    if (d.A2[g] || d.B2[g] || d.C2[g] || d.aux[g] || d.row_mask[g] || d.colsum[g]) return false;
+    if (d.A2[g] || d.B2[g] || d.C2[g] || d.row_mask[g] || d.colsum[g]) return false;
+    if (d.aux[g] && !(add && (g % kc) == 0 && (((uintptr_t)d.aux[g]) & 15) == 0)) return false;
+    if (add && (g % kc) == 0 && !d.aux[g]) return false;
     if (d.bias[g] && d.dtBias != PQ3D_F32) return false;
     if ((((uintptr_t)d.A[g]) | ((uintptr_t)d.B[g])) & 15) return false;
     if ((g % kc) == 0 && (((uintptr_t)d.C[g]) & 15)) return false;

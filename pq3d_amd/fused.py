@@ -680,7 +680,30 @@ class _FusedDecoder(Function):
                 dwq.add([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
             jobs.append((j, Aj, Bj))
         per = len(jobs[0][1]) if jobs else 0
-        if tposed and jobs and per <= MAXG and all(len(jb[1]) == per for jb in jobs):
+        want_dpos = pos is not None and ctx.needs_input_grad[4]
+        dpos = None
+        nk, nv = n_app, n_app + (1 if dkeys is not None else 0)
+        if tposed and want_dpos and len(jobs) == M and nk * M <= MAXG and nv * M <= MAXG and \
+                (dkeys is None or spec.mh_count == M):
+            # the position embedding enters every memory's KEY input, so d pos = sum_m (K part of d feat_m): form the K
+            # parts once (one launch, M outputs), add them into the V parts through the "+ aux" epilogue (second launch)
+            # and sum them for d pos -- instead of a third product over all (layer, memory) key terms
+            Kp = torch.empty(M, B, Ns, d, dtype=torch.float32, device=dev)
+            L.gemm(M=Rk, N=d, K=d, A=[jb[1][2 * a] for jb in jobs for a in range(n_app)],
+                   B=[jb[2][2 * a] for jb in jobs for a in range(n_app)],
+                   Cs=[c_ for j in range(M) for c_ in [Kp[j]] + [None] * (nk - 1)], ct=ct, lda=d, ldb=d, ldc=d, kconcat=nk)
+            outs = [torch.empty(B, Ns, d, dtype=torch.float32, device=dev) for _ in range(M)]
+            vA = [[jb[1][2 * a + 1] for a in range(n_app)] + jb[1][2 * n_app:] for jb in jobs]
+            vB = [[jb[2][2 * a + 1] for a in range(n_app)] + jb[2][2 * n_app:] for jb in jobs]
+            L.gemm(M=Rk, N=d, K=d, A=[t_ for l_ in vA for t_ in l_], B=[t_ for l_ in vB for t_ in l_],
+                   Cs=[c_ for o_ in outs for c_ in [o_] + [None] * (nv - 1)],
+                   aux=[c_ for j in range(M) for c_ in [Kp[j]] + [None] * (nv - 1)], act_grad="add", ct=ct, lda=d, ldb=d,
+                   ldc=d, kconcat=nv)
+            for jb, o_ in zip(jobs, outs):
+                dfeats[jb[0]] = o_
+            dpos = Kp.sum(0)
+            want_dpos = False
+        elif tposed and jobs and per <= MAXG and all(len(jb[1]) == per for jb in jobs):
             cap = max(1, MAXG // per)   # memories per launch
             for c0 in range(0, len(jobs), cap):
                 chunk = jobs[c0:c0 + cap]
@@ -708,8 +731,7 @@ class _FusedDecoder(Function):
                     mp = list(spec.mh.mask_pred_list)[j]
                     dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
                     dwq.add([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
-        dpos = None
-        if pos is not None and ctx.needs_input_grad[4]:
+        if want_dpos:
             Ak, Bk = Akv[0::2], Bkv[0::2]
             for s in range(0, len(Ak), MAXG):
                 nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)

@@ -359,3 +359,10 @@ def test_gemm_nt128_kconcat_fp32_out(M, kc, outs):
     for o in range(outs):
         ref = sum(A[o * kc + g].float() @ Bt[o * kc + g].float().T for g in range(kc))
         assert float((C[o] - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    # "+ aux" epilogue (gradient accumulation onto an earlier product)
+    aux = rnd(outs, M, d, seed=9).to(DEV)
+    C2 = torch.empty_like(C)
+    L.gemm(M=M, N=d, K=d, A=A, B=Bt, Cs=[c for o in range(outs) for c in [C2[o]] + [None] * (kc - 1)],
+           aux=[c for o in range(outs) for c in [aux[o]] + [None] * (kc - 1)], act_grad="add", ct=BF16, lda=d, ldb=d, ldc=d,
+           kconcat=kc)
+    assert float((C2 - (C + aux)).abs().max()) <= 2e-6 * float(C.abs().max())
