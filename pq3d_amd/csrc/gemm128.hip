@@ -1,12 +1,17 @@
-// 128x128-tile bf16 NT GEMM for the big streaming projections (hoisted K/V projections, mask-head keys):
-//   C_g[m][n] (bf16) = sum_k A_g[m][k] * B_g[n][k] + bias_g[n],   A, B bf16 with k contiguous, K % 64 == 0, N % 128 == 0.
+// 128x128-tile bf16 GEMMs for the big streaming products of the path (chosen inside pq3d_gemm when both operands are
+// bf16 and the launch still fills the chip):
+//   gemm_nt128_kernel : C_o[m][n] = act( sum_{g in o} sum_k A_g[m][k] B_g[n][k] + bias[n] ) [+ aux],  k contiguous in A and B;
+//                       hoisted K/V projections, their input gradients (K-concatenated over layers, fp32 out, "+ aux"),
+//                       the PointNet++ tokenizer's SharedMLP layers (ReLU)
+//   gemm_tt128_kernel : C[m][n] += sum_k A[k][m] B[k][n]  (weight gradients dW = dY^T X, split-K atomics, bias gradient)
 //
 // Why a second tile shape: at K = 256 a 64x64 tile loads 64 KB of operands for 8 KB of output (8 B of L2 traffic per
 // output byte -- 786 MB for the c2 hoisted projection, which is L2-bandwidth time, not MFMA time); 128x128 halves that.
-// Only the plain case lives here (bias / ReLU epilogue; no prologue adds, no GELU / masks / split-K) so the register budget goes to the
-// 4x4 accumulator block per wave (64 VGPRs) instead of options; everything else stays in gemm.hip.  The k order (one
-// accumulator per output, 32-wide MFMA steps in sequence) is gemm.hip's, so both kernels produce the same bits.
-// Bound: L2 -> LDS traffic / HBM write of C; algorithmic bytes per group: (M + N) * K * 2 + M * N * 2.
+// Only the plain cases live here (no prologue adds, GELU, masks) so the register budget goes to the 4x4 accumulator
+// block per wave (64 registers, 3 waves per SIMD) instead of options; everything else stays in gemm.hip.  The k order
+// (one accumulator per output, 32-wide MFMA steps in sequence) is gemm.hip's, so the NT kernel produces the same bits.
+// K % 64 == 0, N % 128 == 0 (M % 128 == 0 for TT).  Bound: L2 -> LDS traffic / HBM write of C; algorithmic bytes per
+// group: (M + N) * K * 2 + M * N * {2, 4}.
 #include "common.h"
 
 namespace {
