@@ -23,7 +23,7 @@ namespace {
 
 constexpr int KB = 64;  // keys per main-loop iteration (fwd, dQ)
 constexpr int QB = 32;  // queries per main-loop iteration (dK/dV)
-constexpr int NWK = 4;  // waves per workgroup in dK/dV (16 keys each)
+// dK/dV: 16 keys per wave; 4 waves (64 keys) per workgroup for short key sequences, 8 (128 keys) for long ones
 
 template <typename CT, int DH> struct AT {
   static constexpr int EPL = Mma<CT>::EPL, KSTEP = Mma<CT>::KSTEP;
@@ -695,7 +695,7 @@ __global__ void attn_dq_combine_kernel(const pq3d_attn_desc d) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <typename CT, int DH, bool DROP, bool MASK3>
+template <typename CT, int DH, bool DROP, bool MASK3, int NWK>
 __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_desc d) {
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   row_frags<CT, DH>(kf, d.k, (long)b * d.k_sb + (long)ckey * d.k_sl + (long)h * d.k_sh, lg);
   row_frags<CT, DH>(vf, d.v, (long)b * d.v_sb + (long)ckey * d.v_sl + (long)h * d.v_sh, lg);
   const bool kmasked = kvalid ? (d.kpm ? d.kpm[(long)b * d.Lk + key] != 0 : false) : true;
-  if (__syncthreads_and(kmasked)) {   // whole 64-key chunk padded: its dK, dV are exactly zero
+  if (__syncthreads_and(kmasked)) {   // whole key chunk padded: its dK, dV are exactly zero
     if (kvalid) {
       const long ko = (long)b * d.k_sb + (long)key * d.k_sl + (long)h * d.k_sh;
       const long vo = (long)b * d.v_sb + (long)key * d.v_sl + (long)h * d.v_sh;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   TileRegs<CT, DH, QB, nthreads> qr[2], dor[2];
   float l_r[2] = {INFINITY, INFINITY}, d_r[2] = {0.f, 0.f};
   uint8_t ro_r[2] = {0, 0};
-  // 3-D mask tile of this key chunk for the 32 queries of a tile: thread (row = tid / 8, 8-key chunk = tid % 8) moves 8
+  // 3-D mask tile of this key chunk for the 32 queries of a tile: thread (row = tid / (2 NWK), 8-key chunk = tid % (2 NWK)) moves 8
   // bytes global -> register -> LDS with the Q / dO tiles (prefetched 2-3 tiles ahead) instead of 8 dependent 1-byte
   // loads per lane inside the compute stage
   u32x2 mk_r[MASK3 ? 2 : 1];
@@ -765,8 +765,8 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
     qr[S].load(d.q, qoff, d.q_sl, qb, d.Lq, tid);
     dor[S].load(d.dout, ooff, d.o_sl, qb, d.Lq, tid);
     if constexpr (MASK3) {
-      const uint8_t* mr = d.mask + ((long)bm * d.Lq + min(qb + (tid >> 3), d.Lq - 1)) * d.Lk;
-      const int kc = key0 + (tid & 7) * 8;
+      const uint8_t* mr = d.mask + ((long)bm * d.Lq + min(qb + tid / (NWK * 2), d.Lq - 1)) * d.Lk;
+      const int kc = key0 + (tid % (NWK * 2)) * 8;
       if (mvec) {
         mk_r[S] = *(const u32x2*)(mr + min(kc, d.Lk - 8));   // clamped: keys >= Lk are masked through kvalid anyway
       } else {
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
     qr[S].store(Qbuf + Bf * QSZ, TRR ? nullptr : Qtbuf + Bf * TSZ, A::LDQ, tid);
     dor[S].store(dObuf + Bf * QSZ, TRR ? nullptr : dOtbuf + Bf * TSZ, A::LDQ, tid);
     if (tid < QB) { Lbuf[Bf * QB + tid] = l_r[S]; Dbuf[Bf * QB + tid] = d_r[S]; robuf[Bf * QB + tid] = ro_r[S]; }
-    if constexpr (MASK3) *(u32x2*)&mbuf[(Bf * QB + (tid >> 3)) * MLD + (tid & 7) * 8] = mk_r[S];
+    if constexpr (MASK3) *(u32x2*)&mbuf[(Bf * QB + tid / (NWK * 2)) * MLD + (tid % (NWK * 2)) * 8] = mk_r[S];
   };
   auto compute = [&](int t, auto buf) {
     constexpr int Bf = decltype(buf)::value;
@@ -927,9 +927,12 @@ template <typename CT, int DH, bool DROP, bool MASK3> void launch_bwd_k(const pq
     const long n = (long)d.B * d.H * d.Lq * (DH / 4);
     hipLaunchKernelGGL((attn_dq_combine_kernel<DH>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
   }
-  if (d.Lk > 0) {
-    const dim3 gk((d.Lk + NWK * 16 - 1) / (NWK * 16), d.H, d.B);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH, DROP, MASK3>), gk, dim3(NWK * 64), 0, s, d);
+  if (d.Lk > 256) {   // measured (c4, B12 Lq200 Lk4096, 3-D mask): 128 keys per workgroup -1.4 % of the step; Lk = 100: 64
+    const dim3 gk((d.Lk + 127) / 128, d.H, d.B);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH, DROP, MASK3, 8>), gk, dim3(512), 0, s, d);
+  } else if (d.Lk > 0) {
+    const dim3 gk((d.Lk + 63) / 64, d.H, d.B);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<CT, DH, DROP, MASK3, 4>), gk, dim3(256), 0, s, d);
   }
 }
 template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream_t s) {
