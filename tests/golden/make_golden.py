@@ -122,8 +122,11 @@ def loss_weight(name, shape, seed=99):
     return synth.synth_tensor("lossw." + name, shape, seed) * 20.0  # ~N(0,1)
 
 
+OUT_DIR = os.environ.get("PQ3D_GOLDEN_OUT", HERE)   # tests/test_golden_regen.py regenerates into a scratch directory
+
+
 def save(name, out):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(out)} arrays")
 
