@@ -366,3 +366,20 @@ def test_gemm_nt128_kconcat_fp32_out(M, kc, outs):
            aux=[c for o in range(outs) for c in [aux[o]] + [None] * (kc - 1)], act_grad="add", ct=BF16, lda=d, ldb=d, ldc=d,
            kconcat=kc)
     assert float((C2 - (C + aux)).abs().max()) <= 2e-6 * float(C.abs().max())
+
+
+def test_upsample_scatter_mean_skips_out_of_range_rows():
+    """Voxels whose parent (-1: the coarse level has no such voxel) or segment id is out of range contribute nothing,
+    forward and backward; empty segments are zero."""
+    src = rnd(6, 8, seed=1).to(DEV).requires_grad_(True)
+    parent = torch.tensor([0, 5, -1, 2, 2, 7, 3], device=DEV)          # 7 and -1 are out of range for 6 coarse rows
+    seg = torch.tensor([1, 1, 1, 9, 0, 0, -2], device=DEV)              # 9 and -2 are out of range for 4 segments
+    out = ops.upsample_scatter_mean(src, parent, seg, 4)
+    want = torch.zeros(4, 8, device=DEV)
+    want[1] = (src[0] + src[5]).detach() / 2
+    want[0] = src[2].detach()
+    assert torch.allclose(out, want, atol=1e-6) and float(out[2:].detach().abs().max()) == 0.0
+    out.sum().backward()
+    g = torch.zeros(6, 8, device=DEV)
+    g[0] = 0.5; g[5] = 0.5; g[2] = 1.0
+    assert torch.allclose(src.grad, g, atol=1e-6)

@@ -85,3 +85,26 @@ def test_object_encoder_with_pointnet_backbone_and_refusals():
         net.eval()(pc)
     with pytest.raises(RuntimeError):
         net.requires_grad_(False)(pc.cpu())
+
+
+@pytest.mark.gpu
+def test_group_rows_and_maxpool_edge_cases():
+    """Row grouping without point features (xyz only), GroupAll (no indices, no centring), bf16 rows, and the max-pool
+    over samples, against direct torch indexing."""
+    from pq3d_amd import pointnetpp as PP
+    g = torch.Generator().manual_seed(0)
+    B, N, npnt, ns = 3, 50, 7, 5
+    xyz = torch.randn(B, N, 3, generator=g).cuda()
+    new_xyz = torch.randn(B, npnt, 3, generator=g).cuda()
+    idx = torch.randint(0, N, (B, npnt, ns), generator=g).int().cuda()
+    rows = PP.group_rows(xyz, new_xyz, None, 0, idx, npnt, ns, torch.float32)          # xyz only: Kp = 8
+    assert rows.shape == (B * npnt * ns, 8)
+    ref = torch.gather(xyz, 1, idx.long().view(B, -1, 1).expand(-1, -1, 3)).view(B, npnt, ns, 3) - new_xyz[:, :, None, :]
+    assert torch.equal(rows[:, :3].view(B, npnt, ns, 3), ref) and float(rows[:, 3:].abs().max()) == 0.0
+    feats = torch.randn(B, N, 9, generator=g).cuda()                                     # strided view: 5 of 9 columns
+    rows_all = PP.group_rows(xyz, None, feats[..., 2:7], 5, None, 1, N, torch.bfloat16)  # GroupAll, bf16 rows
+    assert rows_all.shape == (B * N, 8)
+    want = torch.cat([xyz, feats[..., 2:7]], -1).view(B * N, 8).bfloat16()
+    assert torch.equal(rows_all, want)
+    pooled = PP.group_maxpool(rows_all, B, N)
+    assert torch.equal(pooled, want.view(B, N, 8).max(1).values)
