@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=8, help="timed CPU-baseline steps (0 disables)")
+    ap.add_argument("--cpu-steps", type=int, default=32, help="timed CPU-baseline steps (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--dump-kernels", default=None, help="write the per-(entry point, shape) timing table here")
     ap.add_argument("--dropout", default="off", choices=["off", "reference"],
