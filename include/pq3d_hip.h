@@ -352,6 +352,11 @@ typedef struct {
   int32_t sched;         /* PQ3D_SCHED_* */
   int32_t warmup_steps, total_steps;
   float sched_gamma;     /* warmup_exp only */
+  int32_t sched_stride;  /* scheduler steps per optimizer step (<= 0: 1).  The reference prepares its LambdaLR through
+                            accelerate (trainer/build.py:123), whose AcceleratedScheduler.step() advances the wrapped
+                            scheduler num_processes times per optimizer step: the factor in effect for optimizer step k
+                            is lambda(k * num_gpu, warmup * num_gpu, total) -- which is why optim/scheduler.py:20
+                            multiplies the warm-up by num_gpu.  Adam's bias correction still counts optimizer steps. */
 } pq3d_adamw_hp;
 int pq3d_sumsq_partials(const float* g, int64_t n, float* partials, void* stream);
 int pq3d_train_scalars(const pq3d_adamw_hp* hp, int64_t* step, const float* partials, float* scalars, void* stream);

@@ -59,12 +59,17 @@ class AdamWState:
 
 def adamw_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], st: AdamWState, *, lr: float, betas=(0.9, 0.98),
                eps: float = 1e-8, grad_norm: Optional[float] = None, sched: str = "warmup_cosine", warmup_steps: int = 0,
-               total_steps: int = 1, gamma: float = 1.0, lr_of: Optional[Dict[str, float]] = None):
+               total_steps: int = 1, gamma: float = 1.0, lr_of: Optional[Dict[str, float]] = None,
+               num_gpu: int = 1):
     """One optimizer + scheduler step IN PLACE on ``params`` (fp32 tensors keyed by parameter name).
-    Returns (lr used, gradient norm before clipping)."""
+    Returns (lr used, gradient norm before clipping).  ``num_gpu`` > 1 reproduces the reference's multi-process
+    schedule: get_scheduler scales the warm-up by num_gpu (optim/scheduler.py:20) and the accelerate-prepared
+    scheduler (trainer/build.py:123) steps the LambdaLR num_gpu times per optimizer step, so the factor of optimizer
+    step k is lambda(k * num_gpu, warmup_steps * num_gpu, total_steps)."""
     names = [n for n in params if n in grads]
     coef, total = clip_coef([grads[n] for n in names], grad_norm)
-    fac = lr_factor(sched, st.t, warmup_steps, total_steps, gamma)   # LambdaLR: lambda(number of steps taken so far)
+    # LambdaLR: lambda(number of scheduler steps taken so far)
+    fac = lr_factor(sched, st.t * num_gpu, warmup_steps * num_gpu, total_steps, gamma)
     st.t += 1
     b1, b2 = betas
     bc1, bc2 = 1.0 - b1 ** st.t, 1.0 - b2 ** st.t

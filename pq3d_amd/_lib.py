@@ -56,7 +56,8 @@ class OptSegments(C.Structure):
 class AdamWHp(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("max_grad_norm", C.c_float), ("sched", C.c_int32),
-                ("warmup_steps", C.c_int32), ("total_steps", C.c_int32), ("sched_gamma", C.c_float)]
+                ("warmup_steps", C.c_int32), ("total_steps", C.c_int32), ("sched_gamma", C.c_float),
+                ("sched_stride", C.c_int32)]
 
 
 SCHED = {"constant": 0, "warmup_cosine": 1, "warmup_exp": 2}

@@ -39,7 +39,7 @@ __global__ void train_scalars_kernel(const pq3d_adamw_hp hp, long long* step, co
   *step = t;
   // LambdaLR: the factor in effect for optimizer step t is lambda(t - 1)   (optim/scheduler.py:5-17)
   double fac = 1.0;
-  const double st = (double)done, wu = (double)hp.warmup_steps, tot = (double)hp.total_steps;
+  const double st = (double)done * (double)(hp.sched_stride > 0 ? hp.sched_stride : 1), wu = (double)hp.warmup_steps, tot = (double)hp.total_steps;
   if (hp.sched != PQ3D_SCHED_CONSTANT) {
     if (st <= wu && hp.warmup_steps > 0) fac = st / wu;
     else if (hp.sched == PQ3D_SCHED_WARMUP_COSINE) fac = fmax(0.5 * (1.0 + cos((st - wu) / (tot - wu) * 3.14159265358979323846)), 1e-5);

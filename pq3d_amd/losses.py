@@ -209,23 +209,31 @@ class SetCriterion(nn.Module):
 
 
 class InstSegLoss(nn.Module):
-    """optim/loss/instseg_loss.py:9-52 (criterion_type 'set')."""
+    """optim/loss/instseg_loss.py:9-52: criterion_type 'set' (Hungarian matching, stage 1) or 'direct' (ground-truth
+    masks, query i <-> instance i, configs/instseg_sceneverse_gt.yaml:160)."""
 
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
         loss_cfg = cfg.model.get(self.__class__.__name__)
         self.criterion_type = loss_cfg.get("criterion_type", "set")
-        if self.criterion_type != "set":
-            raise NotImplementedError("criterion_type 'direct' (ground-truth masks, no matching) is not built yet")
+        assert self.criterion_type in ["set", "direct"]
         matcher = HungarianMatcher(**dict(loss_cfg.matcher))
         self.weight_dict = {"loss_ce": matcher.cost_class, "loss_mask": matcher.cost_mask, "loss_dice": matcher.cost_dice}
-        self.set_criterion = SetCriterion(matcher=matcher, weight_dict=self.weight_dict, **dict(loss_cfg.criterion))
+        if self.criterion_type == "set":
+            self.set_criterion = SetCriterion(matcher=matcher, weight_dict=self.weight_dict, **dict(loss_cfg.criterion))
+        else:   # instseg_loss.py:34-35: DirectCriterion(**loss_cfg.criterion) swallows the set criterion's other keys
+            self.direct_criterion = DirectCriterion(**dict(loss_cfg.criterion))
 
     def forward(self, data_dict):
-        losses, indices = self.set_criterion(data_dict["predictions_mask"], data_dict["predictions_class"],
-                                             data_dict["instance_labels"], data_dict["segment_masks"])
-        data_dict["indices"] = indices
+        if self.criterion_type == "direct":   # instseg_loss.py:41-43
+            losses = self.direct_criterion(data_dict["predictions_mask"], data_dict["predictions_class"],
+                                           data_dict["target_masks"], data_dict["target_masks_pad_masks"],
+                                           data_dict["target_labels"])
+        else:
+            losses, indices = self.set_criterion(data_dict["predictions_mask"], data_dict["predictions_class"],
+                                                 data_dict["instance_labels"], data_dict["segment_masks"])
+            data_dict["indices"] = indices
         for k in list(losses.keys()):
             losses[k] = losses[k] * self.weight_dict[k.split("_")[0] + "_" + k.split("_")[1]]
         return [sum(losses.values()), losses]

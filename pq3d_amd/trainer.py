@@ -65,7 +65,10 @@ class TrainStep:
         self.hp.lr, self.hp.beta1, self.hp.beta2, self.hp.eps = lr, betas[0], betas[1], eps
         self.hp.max_grad_norm = float(grad_norm) if grad_norm else 0.0
         self.hp.sched = L.SCHED[sched]
-        self.hp.warmup_steps = int(warmup_steps) * int(num_gpu)     # optim/scheduler.py:20
+        # optim/scheduler.py:20 scales the warm-up by num_gpu because accelerate's prepared scheduler (trainer/build.py:123)
+        # advances the LambdaLR num_gpu times per optimizer step: factor of optimizer step k = lambda(k * num_gpu)
+        self.hp.warmup_steps = int(warmup_steps) * int(num_gpu)
+        self.hp.sched_stride = int(num_gpu)
         self.hp.total_steps, self.hp.sched_gamma = int(total_steps), float(sched_gamma)
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
         self.partials = torch.zeros(L.SUMSQ_PARTIALS, dtype=torch.float32, device=dev)

@@ -387,6 +387,38 @@ def run_direct_loss_case(ref, name):
     save(name, out)
 
 
+INIT_CASES = {   # name -> (module attribute in the import namespace / pq3d_amd.modules, class name, torch seed, args, kwargs)
+    "enc_spatial_parallel": ("qe", "QueryMaskEncoder", 7, (), dict(memories=["voxel", "mv", "pc"], hidden_size=64,
+                             num_attention_heads=4, num_layers=3, spatial_selfattn=True, structure="parallel",
+                             use_self_mask=True, num_blocks=2)),
+    "enc_plain_mixed": ("qe", "QueryMaskEncoder", 3, (), dict(memories=["voxel", "prompt"], hidden_size=64,
+                        num_attention_heads=4, num_layers=2, spatial_selfattn=False, structure="mixed")),
+    "enc_gate": ("qe", "QueryMaskEncoder", 11, (), dict(memories=["mv", "prompt"], hidden_size=32, num_attention_heads=2,
+                 num_layers=2, spatial_selfattn=True, structure="gate")),
+    "mask_head": ("mh", "MaskHeadSegLevel", 5, (64, 21), dict(memories_for_match=["voxel", "mv"], filter_out_classes=[0, 2])),
+    "ground_head": ("gh", "GroundHead", 9, (), dict(input_size=64, hidden_size=48, dropout=0.3)),
+    "object_encoder": ("oe", "ObjectEncoder", 13, (), dict(backbone="none", input_feat_size=96, hidden_size=64,
+                       use_projection=True, use_cls_head=True, tgt_cls_num=17)),
+}
+MAX_INIT = 512
+
+
+def run_init_case(ref, name):
+    """F16: the reference's own INITIAL weights (per-sublayer xavier ``_reset_parameters``, ``layer_repeat``
+    deep copies, then ``_init_weights_bert`` -- modules/weights.py:3-20, modules/utils.py:28-32, query_encoder.py:61) under a
+    fixed torch seed.  The HIP modules mirror the reference's construction order, so the same seed must give the same
+    state_dict bit for bit (tests/test_init_parity.py)."""
+    out = {}
+    for case, (mod, cls, seed, a, kw) in INIT_CASES.items():
+        torch.manual_seed(seed)
+        m = getattr(getattr(ref, mod), cls)(Cfg({}), *a, **kw)
+        sd = m.state_dict()
+        out[f"{case}/keys"] = np.array(sorted(sd.keys()))
+        for k, v in sd.items():
+            put(out, f"{case}/{k}", v, MAX_INIT)
+    save(name, out)
+
+
 def run_collate_case(ref, name):
     """F11: the reference's pad_sequence / pad_sequence_2d (data/data_utils.py:337-382) as collate_fn uses them
     (instseg_wrapper.py:41-66): float features, centres, int64 labels padded with -100, bool masks, 2-D target masks."""
@@ -538,6 +570,7 @@ def main():
     run_pointnetpp_case(ref, "F12_pointnetpp")
     run_train_case(ref, "F7_adamw_mask", B=2, Ns=96, Nq=12, d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask"],
                    spatial=True, structure="parallel", use_self_mask=False, foc=(0, 2), warmup_steps=0, total_steps=6)
+    run_init_case(ref, "F16_init")
 
 
 if __name__ == "__main__":

@@ -92,9 +92,6 @@ def test_no_cpu_fallback():
     _cfg, model, _sd, dd = util.model_case(args)
     with pytest.raises(_lib.Pq3dError):
         model(dd)
-    src = "".join(open(os.path.join(ROOT, "pq3d_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "pq3d_amd"))
-                  if f.endswith(".py"))
-    assert "oracle" not in src.replace("or the oracle", "").replace("through the oracle", "") or True
     for f in os.listdir(os.path.join(ROOT, "pq3d_amd")):
         if f.endswith(".py"):
             text = open(os.path.join(ROOT, "pq3d_amd", f)).read()

@@ -114,3 +114,33 @@ def test_padded_mask_losses_match_oracle_at_decoder_sizes():
     (3 * om + 7 * od).backward()
     assert abs(lm.item() - om.item()) <= 2e-5 * abs(om.item()) and abs(ld.item() - od.item()) <= 2e-5 * abs(od.item())
     assert float((x.grad.cpu() - xo.grad).abs().max()) <= 1e-7 + 2e-4 * float(xo.grad.abs().max())
+
+
+def _loss_cfg(criterion_type):
+    """cfg.model.InstSegLoss as configs/instseg_sceneverse.yaml:157-168 / instseg_sceneverse_gt.yaml:160 lay it out."""
+    from pq3d_amd.model import Cfg
+    return Cfg({"model": {"InstSegLoss": {
+        "criterion_type": criterion_type,
+        "matcher": dict(num_points=-1, ignore_label=-100, **W),
+        "criterion": dict(num_classes=20, losses=["labels", "masks"], num_points=-1, class_weights=-1, ignore_label=-100)}}})
+
+
+def test_instseg_loss_wrapper_direct_and_set_match_reference_fixtures():
+    """InstSegLoss.forward (optim/loss/instseg_loss.py:38-52): 'direct' -> DirectCriterion on target_masks /
+    target_masks_pad_masks / target_labels (fixture F10's weighted total), 'set' -> SetCriterion + indices (F9)."""
+    from pq3d_amd.losses import InstSegLoss
+    z, _ = util.load_fixture("F10_direct_losses")
+    masks, logits, tgt, pad, labels, _om, _l2 = synth.direct_loss_inputs()
+    dd = {"predictions_mask": [m.to(DEV).requires_grad_(True) for m in masks],
+          "predictions_class": [l.to(DEV).requires_grad_(True) for l in logits],
+          "target_masks": tgt.to(DEV), "target_masks_pad_masks": pad.to(DEV), "target_labels": labels.to(DEV)}
+    total, losses = InstSegLoss(_loss_cfg("direct"))(dd)
+    assert abs(total.item() - float(z["total"])) <= 2e-5 * abs(float(z["total"]))
+    assert "indices" not in dd and sorted(losses) == sorted(k[5:] for k in z.files if k.startswith("loss/"))
+    z9, _ = util.load_fixture("F9_set_criterion")
+    masks, logits, labels9, seg = synth.criterion_inputs()
+    dd = {"predictions_mask": [m.to(DEV) for m in masks], "predictions_class": [l.to(DEV) for l in logits],
+          "instance_labels": labels9, "segment_masks": seg}
+    total9, _ = InstSegLoss(_loss_cfg("set"))(dd)
+    assert abs(total9.item() - float(z9["total"])) <= 2e-5 * abs(float(z9["total"]))
+    assert len(dd["indices"]) == len(labels9)

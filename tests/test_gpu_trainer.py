@@ -131,3 +131,22 @@ def test_graph_replayed_gradients_equal_eager_gradients():
         assert torch.isfinite(ts.flat_g).all(), f"replay {i}"
         # same kernels, same inputs: only the order of split-K atomics may differ
         assert float((ts.flat_g - ref).abs().max()) <= 2e-3 * scale, f"replay {i}"
+
+
+@pytest.mark.parametrize("num_gpu", [2, 8])
+def test_multi_process_lr_schedule_matches_oracle(num_gpu):
+    """num_gpu > 1: warm-up scaled by num_gpu AND num_gpu scheduler steps per optimizer step (accelerate-prepared
+    LambdaLR, trainer/build.py:123): the device-side schedule must give train_oracle's learning rates (which
+    tests/test_train_oracle.py pins to torch's LambdaLR driven the way accelerate drives it)."""
+    from oracle import train_oracle as T
+    _z, args = util.load_fixture("F7_adamw_c1")
+    cfg, model, sd, dd = util.model_case(args)
+    model.to(DEV).eval()
+    ddv = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in dd.items()}
+    ts = TrainStep(model, lambda out: out["query_embeds"].mean(), lr=1e-3, grad_norm=None, sched="warmup_cosine",
+                   warmup_steps=2, total_steps=40, num_gpu=num_gpu)
+    st = T.AdamWState()
+    for s in range(9):
+        ts.step(ddv)
+        want, _ = T.adamw_step({}, {}, st, lr=1e-3, sched="warmup_cosine", warmup_steps=2, total_steps=40, num_gpu=num_gpu)
+        assert abs(float(ts.last_lr) - want) <= 1e-9 + 1e-6 * want, (s, float(ts.last_lr), want)

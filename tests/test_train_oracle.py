@@ -53,3 +53,31 @@ def test_weight_decay_groups_follow_reference_quirk():
     assert T.weight_decay_of("unified_encoder.unified_encoder.0.ffn.norm.bias") == 0.0
     assert T.weight_decay_of("unified_encoder.unified_encoder.0.ffn.linear1.weight") == 0.01
     assert np.isclose(T.warmup_cosine(0, 2, 10), 0.0) and np.isclose(T.warmup_cosine(2, 2, 10), 1.0)
+
+
+@pytest.mark.parametrize("num_gpu,sched,gamma", [(2, "warmup_cosine", 1.0), (8, "warmup_cosine", 1.0), (4, "warmup_exp", 0.1)])
+def test_multi_process_schedule_matches_accelerate_prepared_lambdalr(num_gpu, sched, gamma):
+    """The reference's scheduler under num_gpu processes: get_scheduler multiplies the warm-up by num_gpu
+    (optim/scheduler.py:20) and trainer/build.py:123 hands the LambdaLR to accelerate, whose AcceleratedScheduler steps
+    it num_processes times per optimizer step.  Pinned two ways: (1) the installed accelerate really does that (source
+    check), (2) a torch LambdaLR driven that way gives exactly train_oracle.adamw_step's learning rates."""
+    import inspect
+    from accelerate.scheduler import AcceleratedScheduler
+    src = inspect.getsource(AcceleratedScheduler.step)
+    assert "num_processes" in src and "for _ in range(num_processes)" in src
+    warm, total, lr0, steps = 3, 40, 1e-3, 12
+    p = torch.nn.Parameter(torch.zeros(4))
+    opt = torch.optim.AdamW([p], lr=lr0)
+    fn = {"warmup_cosine": lambda s: T.warmup_cosine(s, warm * num_gpu, total),
+          "warmup_exp": lambda s: T.warmup_exp(s, warm * num_gpu, total, gamma)}[sched]
+    lam = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=fn)
+    st = T.AdamWState()
+    params = {"w": torch.zeros(4)}
+    for _ in range(steps):
+        want = opt.param_groups[0]["lr"]          # lr the optimizer step of this iteration uses
+        opt.step()
+        for _ in range(num_gpu):                  # AcceleratedScheduler.step (split_batches=False)
+            lam.step()
+        got, _ = T.adamw_step(params, {"w": torch.ones(4)}, st, lr=lr0, sched=sched, warmup_steps=warm, total_steps=total,
+                              gamma=gamma, num_gpu=num_gpu)
+        assert abs(got - want) <= 1e-12, (got, want)
