@@ -24,6 +24,13 @@ extern "C" {
 
 #define PQ3D_F32 0
 #define PQ3D_BF16 1
+/* compute type only (pq3d_gemm): split-bf16.  Each fp32 operand element x is staged as hi = bf16(x), lo = bf16(x - hi)
+ * and the product is formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulate): ~2^-17 relative
+ * per term instead of 2^-9, i.e. fp32-grade results from the bf16 matrix cores at 3x the MFMA work.  Used by the
+ * 'bf16' compute mode for the query-side projections / FFN / heads (M = B*N_q rows: launch-latency-bound, the extra
+ * MFMAs are free), which is what holds the per-sublayer parity of that mode at <= 1e-3 (tests/test_gpu_sublayer_parity.py).
+ * Operands must be fp32; layouts the split kernel does not cover run on the exact-f32 MFMA path (same accuracy). */
+#define PQ3D_BF16X3 2
 #define PQ3D_ERR_ARG (-1)
 
 #define PQ3D_ACT_NONE 0

@@ -8,7 +8,7 @@ from typing import Optional, Sequence
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "add": 3}
 MAXG = 32
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -167,6 +167,37 @@ struct FastStage {
       }
     }
   }
+  // Split-bf16 staging (compute type PQ3D_BF16X3, row-major fp32 operands only): every fp32 element x (+ addend) is written
+  // as hi = bf16(x) and lo = bf16(x - hi) into two tiles; the MFMA loop forms hi*hi + hi*lo + lo*hi, i.e. the product
+  // of the operands to ~2^-17 relative instead of 2^-9 -- fp32-grade results from the bf16 matrix cores.
+  PQ_DEV void store_split(CT* lds_hi, CT* lds_lo, int tid) const {
+    static_assert(!TR && sizeof(TS) == 4 && sizeof(CT) == 2, "split staging: row-major fp32 source, bf16 MFMA");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + it * NT;
+      float v[T::EPL], w[T::EPL];
+      r[it].to_float(v);
+      if (HAS2) {
+        r2[it].to_float(w);
+#pragma unroll
+        for (int j = 0; j < T::EPL; ++j) v[j] += scale2 * w[j];
+      }
+      if (!kvalid[it]) {
+#pragma unroll
+        for (int j = 0; j < T::EPL; ++j) v[j] = 0.f;
+      }
+      const u32x4 hi = pack_frag<CT>(v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w[2 * j] = v[2 * j] - __uint_as_float(hi[j] << 16);
+        w[2 * j + 1] = v[2 * j + 1] - __uint_as_float(hi[j] & 0xffff0000u);
+      }
+      const u32x4 lo = pack_frag<CT>(w);
+      const int row = c / T::CPR, kc = c % T::CPR;
+      *(u32x4*)&lds_hi[row * T::LDK + kc * T::EPL] = hi;
+      *(u32x4*)&lds_lo[row * T::LDK + kc * T::EPL] = lo;
+    }
+  }
 };
 
 // bf16 fragment (row `r0 + li` of the operand, k-slots 8*lg..8*lg+7 of k-step ks) from a [k][m]-oriented LDS tile via
@@ -258,6 +289,36 @@ PQ_DEV void mma_tile(f32x4 (&acc)[2][2], const CT* As, const CT* Bs, int wm, int
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) Mma<CT>::mma(acc[i][j], fa[i], fb[j]);
+  }
+}
+
+// split-bf16 product of one staged tile: acc += Ahi.Bhi + Ahi.Blo + Alo.Bhi (the lo.lo term is below fp32 round-off)
+PQ_DEV void mma_tile_x3(f32x4 (&acc)[2][2], const bf16_t* Ah, const bf16_t* Al, const bf16_t* Bh, const bf16_t* Bl, int wm,
+                        int wn, int li, int lg) {
+  typedef Tile<bf16_t> T;
+#pragma unroll
+  for (int ks = 0; ks < T::BKE / T::KSTEP; ++ks) {
+    u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (wm + i * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL;
+      ah[i] = *(const u32x4*)&Ah[o];
+      al[i] = *(const u32x4*)&Al[o];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = (wn + j * 16 + li) * T::LDK + ks * T::KSTEP + lg * T::EPL;
+      bh[j] = *(const u32x4*)&Bh[o];
+      bl[j] = *(const u32x4*)&Bl[o];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        Mma<bf16_t>::mma(acc[i][j], al[i], bh[j]);
+        Mma<bf16_t>::mma(acc[i][j], ah[i], bl[j]);
+        Mma<bf16_t>::mma(acc[i][j], ah[i], bh[j]);
+      }
   }
 }
 
@@ -438,12 +499,17 @@ template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_gemm_desc& d) 
   return b;
 }
 
-template <typename CT, typename TA, typename TB, bool TRA, bool TRB, bool HA2, bool HB2>
+template <typename CT, typename TA, typename TB, bool TRA, bool TRB, bool HA2, bool HB2, bool X3 = false>
 __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   typedef Tile<CT> T;
-  __shared__ __attribute__((aligned(16))) CT As[BM * T::LDK];
-  __shared__ __attribute__((aligned(16))) CT Bs[BN * T::LDK];
+  // X3 (split-bf16): hi tiles first, lo tiles behind them -- one contiguous block, so the C tile of the epilogue still
+  // overlays the start of the staging LDS
+  __shared__ __attribute__((aligned(16))) CT As[(X3 ? 2 : 1) * (BM + BN) * T::LDK];
+  CT* const Bs = As + BM * T::LDK;
+  CT* const Al = As + (BM + BN) * T::LDK;
+  CT* const Bl = Al + BM * T::LDK;
   static_assert(sizeof(CT) * (BM + BN) * T::LDK >= sizeof(float) * BM * CLD, "C tile must fit in the staging LDS");
+  static_assert(!X3 || (!TRA && !TRB && sizeof(CT) == 2 && sizeof(TA) == 4 && sizeof(TB) == 4), "X3: NT, fp32 operands");
   DBG_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -497,23 +563,29 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   issue(sa0, sb0);
   if (nit > 1) issue(sa1, sb1);
   DBG_STAMP(1);
+  auto put = [&](const FastStage<CT, TA, TRA, HA2>& sa, const FastStage<CT, TB, TRB, HB2>& sb) {
+    if constexpr (X3) { sa.store_split(As, Al, tid); sb.store_split(Bs, Bl, tid); }
+    else { sa.store(As, tid); sb.store(Bs, tid); }
+  };
+  auto mult = [&]() {
+    if constexpr (X3) mma_tile_x3(acc, (const bf16_t*)As, (const bf16_t*)Al, (const bf16_t*)Bs, (const bf16_t*)Bl, wm, wn, li, lg);
+    else mma_tile<CT, TRA, TRB>(acc, As, Bs, wm, wn, li, lg);
+  };
   for (int it = 0; it < nit; it += 2) {
-    sa0.store(As, tid);
-    sb0.store(Bs, tid);
+    put(sa0, sb0);
     if (it == 0) DBG_STAMP(2);
     __syncthreads();
     if (issued < nit) issue(sa0, sb0);
     if constexpr (TRA) { if (cs_out) rowsum(); }
-    mma_tile<CT, TRA, TRB>(acc, As, Bs, wm, wn, li, lg);
+    mult();
     __syncthreads();
     if (it == 0) DBG_STAMP(3);
     if (it + 1 < nit) {
-      sa1.store(As, tid);
-      sb1.store(Bs, tid);
+      put(sa1, sb1);
       __syncthreads();
       if (issued < nit) issue(sa1, sb1);
       if constexpr (TRA) { if (cs_out) rowsum(); }
-      mma_tile<CT, TRA, TRB>(acc, As, Bs, wm, wn, li, lg);
+      mult();
       __syncthreads();
     }
   }
@@ -631,7 +703,7 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   PQ_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K >= 0, "pq3d_gemm: negative dims");
   PQ_CHECK_ARG(d.groups >= 1 && d.groups <= PQ3D_MAX_GROUPS, "pq3d_gemm: groups out of range");
   PQ_CHECK_ARG(d.batch >= 1, "pq3d_gemm: batch < 1");
-  PQ_CHECK_ARG(d.ct == PQ3D_F32 || d.ct == PQ3D_BF16, "pq3d_gemm: bad compute type");
+  PQ_CHECK_ARG(d.ct == PQ3D_F32 || d.ct == PQ3D_BF16 || d.ct == PQ3D_BF16X3, "pq3d_gemm: bad compute type");
   if (d.M == 0 || d.N == 0) return 0;
   const int kc = d.kconcat > 0 ? d.kconcat : 1;
   PQ_CHECK_ARG(d.groups % kc == 0, "pq3d_gemm: groups must be a multiple of kconcat");
@@ -648,6 +720,22 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   PQ_CHECK_ARG(!any_cs || (d.transA && d.transB && kc == 1 && d.batch == 1 && d.splitk > 1),
                "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated split-K GEMM");
   hipStream_t s = (hipStream_t)stream;
+  if (d.ct == PQ3D_BF16X3) {
+    // split-bf16: C = A.B^T of fp32 operands to fp32-grade accuracy on the bf16 matrix cores (3 MFMAs per product term
+    // pair).  Available for the aligned row-major (NT) layout with fp32 A and B; anything else runs the exact-f32 MFMA
+    // path, which has the same accuracy contract.
+    bool a2 = false, b2 = false;
+    const bool ok = !d.transA && !d.transB && d.dtA == PQ3D_F32 && d.dtB == PQ3D_F32 && d.splitk == 1 && !any_cs &&
+                    fast_ok<bf16_t>(d, a2, b2);
+    if (ok) {
+      dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (d.groups / kc) * d.batch);
+      if (a2) LAUNCH(gemm_fast_kernel<bf16_t, float, float, false, false, true, false, true>);
+      else LAUNCH(gemm_fast_kernel<bf16_t, float, float, false, false, false, false, true>);
+      PQ_LAUNCH_CHECK();
+      return 0;
+    }
+    d.ct = PQ3D_F32;
+  }
   if (pq3d_gemm_nt128_try(d, s)) {   // plain big bf16 NT products: 128x128 tiles (gemm128.hip), same bits
     PQ_LAUNCH_CHECK();
     return 0;

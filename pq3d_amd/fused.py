@@ -115,6 +115,10 @@ class FusedSpec:
         self.use_self_mask, self.num_blocks, self.spatial = use_self_mask, num_blocks, spatial
         self.mh_count, self.offline, self.skip_pred = mh_count, offline, skip_pred
         self.stacked_kpm = None      # optional [M, B, Ns] key-padding masks of the memories, stacked (set by fused_decoder)
+        # memory inputs are passed as U unique source tensors: src[i][j] = source of memory j in layer i (a multi-scale
+        # voxel memory has one source per layer, query_encoder.py:90-91), mh_src[k] = source of mask-head memory k
+        # (the LAST scale of a multi-scale memory, query3d_unified.py:163-165)
+        self.src, self.mh_src, self.n_src = None, None, len(self.mems)
         self.drop_base = drop_base   # dropout-site base of the encoder when train-mode dropout is active, else None
         self.mh_drop = mh_drop       # mask head's cls_head dropout active
 
@@ -127,7 +131,9 @@ class FusedSpec:
 
 def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
     """One MaskHeadSegLevel call (number `call` of this forward) on the fused path; returns (cls, mlog, amask)."""
-    mh, ct, ad = spec.mh, spec.ct, ops.act_dtype(spec.ct)
+    mh = spec.mh
+    ct = ops.small_ct(spec.ct)     # query-side GEMMs: split-bf16 in 'bf16' mode (fp32 operands and outputs)
+    ad = ops.act_dtype(ct)
     B, Nq, d = x.shape
     R = B * Nq
     c0, c2, c4 = mh.cls_head[0], mh.cls_head[2], mh.cls_head[4]
@@ -225,10 +231,12 @@ class _FusedDecoder(Function):
     def forward(ctx, spec: FusedSpec, x0, qpos, qmask, pos, pl, seg_pad, offline_mask, coef, *rest):
         enc, ct = spec.enc, spec.ct
         ad = ops.act_dtype(ct)
-        M = len(spec.mems)
-        feats, masks, params = list(rest[:M]), list(rest[M:2 * M]), rest[2 * M:]
+        M, U = len(spec.mems), spec.n_src
+        feats, masks, params = list(rest[:U]), list(rest[U:U + M]), rest[U + M:]   # feats: the U unique sources
         layers = list(enc.unified_encoder)
         Ln = len(layers)
+        src = spec.src if spec.src is not None else [list(range(M)) for _ in range(Ln)]
+        mh_src = spec.mh_src if spec.mh_src is not None else list(range(M))
         H = enc.num_heads
         B, Nq, d = qpos.shape
         Ns = feats[0].shape[1]
@@ -236,26 +244,28 @@ class _FusedDecoder(Function):
         dev = qpos.device
         mem_idx = [layers[0].memories.index(m) for m in spec.mems]
         cas = [[layers[i].cross_attn_list[j] for j in mem_idx] for i in range(Ln)]
+        cq = ops.small_ct(ct)   # query-side GEMMs (M = B*N_q rows): split-bf16 in 'bf16' mode, exact f32 otherwise
         x0, qpos, pos = ops._c(x0), ops._c(qpos), ops._c(pos)
         feats = [ops._c(f) for f in feats]
+        mh_feats = [feats[u] for u in mh_src]
         masks = [ops._c(m) for m in masks]
         qmask = ops._c(qmask)
 
         # ---- layer-invariant MFMA operands, rounded once: kin_m = (feat_m + pos), vin_m = feat_m in the activation
         # dtype (bf16 path: the 2*L*M hoisted GEMMs and their weight-gradient GEMM then read 2 B/element, not 8)
-        if ct == BF16 and (B * Ns * d) % 8 == 0:
-            kvin = torch.empty(2, M, B, Ns, d, dtype=ad, device=dev)
-            srcs = [feats[j] for j in range(M)] * 2
-            adds = [pos] * M + [None] * M
-            outs = [kvin[0, j] for j in range(M)] + [kvin[1, j] for j in range(M)]
+        if ct == BF16 and (B * Ns * d) % 8 == 0 and 2 * U <= MAXG:
+            kvin = torch.empty(2, U, B, Ns, d, dtype=ad, device=dev)
+            srcs = [feats[u] for u in range(U)] * 2
+            adds = [pos] * U + [None] * U
+            outs = [kvin[0, u] for u in range(U)] + [kvin[1, u] for u in range(U)]
             if pos is None:
-                adds = [None] * (2 * M)
+                adds = [None] * (2 * U)
             arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
-            L.check(L.lib().pq3d_add_cast(arr(srcs), arr(adds), arr(outs), 2 * M, L.BF16, B * Ns * d, L.stream()),
+            L.check(L.lib().pq3d_add_cast(arr(srcs), arr(adds), arr(outs), 2 * U, L.BF16, B * Ns * d, L.stream()),
                     "pq3d_add_cast")
-            kin, vin, kin2 = [kvin[0, j] for j in range(M)], [kvin[1, j] for j in range(M)], [None] * M
+            kin, vin, kin2 = [kvin[0, u] for u in range(U)], [kvin[1, u] for u in range(U)], [None] * U
         else:
-            kin, vin, kin2 = feats, feats, [pos] * M
+            kin, vin, kin2 = feats, feats, [pos] * U
         ctx.kin, ctx.vin, ctx.kin2 = kin, vin, kin2
         ctx.wkv = None
         # ---- hoisted K/V projections: KV[l, 0|1, m] = (feat_m [+ pos]) @ W{k,v}_{l,m}^T + b
@@ -276,8 +286,8 @@ class _FusedDecoder(Function):
         for i in range(Ln):
             for j, ca in enumerate(cas[i]):
                 w, b = ca.multihead_attn.in_proj_weight.detach(), ca.multihead_attn.in_proj_bias.detach()
-                A += [kin[j], vin[j]]
-                A2 += [kin2[j], None]
+                A += [kin[src[i][j]], vin[src[i][j]]]
+                A2 += [kin2[src[i][j]], None]
                 Bw += [w[d:2 * d], w[2 * d:]] if wkv is None else [wkv[i, j, :d], wkv[i, j, d:]]
                 bs += [b[d:2 * d], b[2 * d:]]
                 Cs += [KV[i, 0, j], KV[i, 1, j]]
@@ -294,9 +304,10 @@ class _FusedDecoder(Function):
         if spec.mh is not None:
             mps = list(spec.mh.mask_pred_list)[:spec.mh_count]
             valid = [m.logical_not() for m in masks[:spec.mh_count]]
-            keys_buf = torch.empty(spec.mh_count, B, Ns, d, dtype=ad, device=dev)
-            L.gemm(M=Rk, N=d, K=d, A=feats[:spec.mh_count], B=[mp.k_proj.weight.detach() for mp in mps],
-                   Cs=[keys_buf[m] for m in range(spec.mh_count)], row_mask=valid, ct=ct, lda=d, ldb=d, ldc=d)
+            cq = ops.small_ct(ct)   # fp32-grade keys (split-bf16): see MaskHeadSegLevel.project_keys
+            keys_buf = torch.empty(spec.mh_count, B, Ns, d, dtype=ops.act_dtype(cq), device=dev)
+            L.gemm(M=Rk, N=d, K=d, A=mh_feats[:spec.mh_count], B=[mp.k_proj.weight.detach() for mp in mps],
+                   Cs=[keys_buf[m] for m in range(spec.mh_count)], row_mask=valid, ct=cq, lda=d, ldb=d, ldc=d)
             keys = [keys_buf[m] for m in range(spec.mh_count)]
             inv_den = ops.mask_inv_den(masks[:spec.mh_count])
             ctx.mh_valid = valid
@@ -346,7 +357,7 @@ class _FusedDecoder(Function):
                 ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cas[i]]
                 bsl = [ca.multihead_attn.in_proj_bias.detach() for ca in cas[i]]
                 L.gemm(M=R, N=d, K=d, A=[x] * M, A2=[qpos] * M, B=[w[:d] for w in ws], bias=[b[:d] for b in bsl],
-                       Cs=[q_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
+                       Cs=[q_all[m] for m in range(M)], ct=cq, lda=d, ldb=d, ldc=d)
                 o_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
                 lse = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
                 if spec.use_self_mask:
@@ -362,12 +373,13 @@ class _FusedDecoder(Function):
                        bias=[ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]],
                        Cs=[op_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
                 x1, mean_c, rstd_c = _ln_fwd(x, [op_all[m] for m in range(M)], [ca.norm.weight.detach() for ca in cas[i]],
-                                             [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps, coef, Nq,
-                                             drop=dr_cr)
+                                             [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps,
+                                             coef[app] if coef is not None else None, Nq, drop=dr_cr)
                 rec.update(q_all=q_all, o_all=o_all, lse=lse, op_all=op_all, mean_c=mean_c, rstd_c=rstd_c, x1=x1)
                 # -- self attention: 5 launches (spatial) / 4
                 sa = layer.self_attn
-                qkv = torch.empty(3, B, Nq, d, dtype=ad, device=dev)
+                # N_q x N_q scores per scene: projections at fp32 grade, attention core on the exact-f32 MFMA path
+                qkv = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
                 if spec.spatial:
                     msa = sa.self_attn
                     Wl = [msa.w_qs.weight.detach(), msa.w_ks.weight.detach(), msa.w_vs.weight.detach()]
@@ -377,24 +389,24 @@ class _FusedDecoder(Function):
                     w, b = sa.self_attn.in_proj_weight.detach(), sa.self_attn.in_proj_bias.detach()
                     Wl, bl = [w[:d], w[d:2 * d], w[2 * d:]], [b[:d], b[d:2 * d], b[2 * d:]]
                     Wo, bo = sa.self_attn.out_proj.weight.detach(), sa.self_attn.out_proj.bias.detach()
-                L.gemm(M=R, N=d, K=d, A=[x1] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=ct,
+                L.gemm(M=R, N=d, K=d, A=[x1] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=cq,
                        lda=d, ldb=d, ldc=d)
                 sbias = sbias_all[i] if spec.spatial else None   # layer-invariant across blocks: computed once above
-                o_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
+                o_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 lse_s = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
-                _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ct, False, kpm=qmask, bias=sbias, drop=dr_sa)
+                _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, L.F32, False, kpm=qmask, bias=sbias, drop=dr_sa)
                 f = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=d, A=[o_s], B=[Wo], bias=[bo], Cs=[f], ct=ct, lda=d, ldb=d, ldc=d)
+                L.gemm(M=R, N=d, K=d, A=[o_s], B=[Wo], bias=[bo], Cs=[f], ct=cq, lda=d, ldb=d, ldc=d)
                 x2, mean_s, rstd_s = _ln_fwd(x1, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
                                              drop=dr_sr)
                 rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
                 # -- FFN: 3 launches
                 ffn = layer.ffn
                 F_ = ffn.linear1.out_features
-                h = torch.empty(B, Nq, F_, dtype=ad, device=dev)
+                h = torch.empty(B, Nq, F_, dtype=ops.act_dtype(cq), device=dev)
                 pre = torch.empty_like(h) if spec.act == "gelu" else None
                 L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
-                       C2=[pre], ct=ct, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi)
+                       C2=[pre], ct=cq, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi)
                 # linear2 has K = F = 2048 on only M/64 x d/64 = 52 tiles: a long serial k-loop on a fifth of the chip.  Its K
                 # range is split over KS groups of ONE grouped launch (no atomics: each group owns an output), and the
                 # LayerNorm kernel adds the partial sums (+ residual, + dropout of the summed branch) in a fixed order --
@@ -405,7 +417,7 @@ class _FusedDecoder(Function):
                 hv, w2 = h.view(R, F_), ffn.linear2.weight.detach()
                 L.gemm(M=R, N=d, K=Fk, A=[hv[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
                        B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
-                       bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=ct, lda=F_,
+                       bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=cq, lda=F_,
                        ldb=F_, ldc=d)
                 z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)   # sum of the partials, kept for the backward
                 x3, mean_f, rstd_f = _ln_fwd(x2, [zp[k] for k in range(KS)], [ffn.norm.weight.detach()],
@@ -427,7 +439,7 @@ class _FusedDecoder(Function):
         ctx.cas, ctx.n_mh = cas, len(pcls)
         ctx.params = params
         ctx.save_for_backward(x0, qpos, qmask, pos, pl, seg_pad, coef, *feats, *masks)
-        ctx.M = M
+        ctx.M, ctx.U, ctx.src, ctx.mh_src, ctx.mh_feats = M, U, src, mh_src, mh_feats
         return (x, *pcls, *pmask)
 
     @staticmethod
@@ -435,10 +447,10 @@ class _FusedDecoder(Function):
         spec, tape = ctx.spec, ctx.tape
         enc, ct = spec.enc, spec.ct
         ad = ops.act_dtype(ct)
-        M = ctx.M
+        M, U, src, mh_src = ctx.M, ctx.U, ctx.src, ctx.mh_src
         sv = ctx.saved_tensors
         x0, qpos, qmask, pos, pl, seg_pad, coef = sv[:7]
-        feats, masks = list(sv[7:7 + M]), list(sv[7 + M:7 + 2 * M])
+        feats, masks = list(sv[7:7 + U]), list(sv[7 + U:7 + U + M])
         params = ctx.params
         layers = list(enc.unified_encoder)
         Ln, H = len(layers), enc.num_heads
@@ -582,14 +594,14 @@ class _FusedDecoder(Function):
                                rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)],
                                drop=rec["dr_sr"])
             df = df[0]
-            do_s = torch.empty(B, Nq, d, dtype=ad, device=dev)
+            do_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
             L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
             dwq.add([df], [rec["o_s"]], None, [GWo], ct, [Gbo])
             qkv = rec["qkv"]
-            dqkv = torch.empty(3, B, Nq, d, dtype=ad, device=dev)
+            dqkv = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
             delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
             dsb = torch.empty_like(rec["sbias"]) if spec.spatial else None
-            _attn(qkv[0], qkv[1], qkv[2], rec["o_s"], rec["lse_s"], H, ct, False, kpm=qmask, bias=rec["sbias"],
+            _attn(qkv[0], qkv[1], qkv[2], rec["o_s"], rec["lse_s"], H, L.F32, False, kpm=qmask, bias=rec["sbias"],
                   bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb), drop=rec["dr_sa"])
             if spec.spatial:   # deferred: one grouped launch for all layer applications at the end of the backward
                 sb_queue.append((msa.pairwise_loc_fc.weight.detach(), msa.pairwise_loc_fc.bias.detach(), dsb,
@@ -606,7 +618,8 @@ class _FusedDecoder(Function):
             # ---------------- cross-attention backward (M memories per launch)
             cl = cas[i]
             dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
-                               [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef, Nq, rec["mean_c"], rec["rstd_c"],
+                               [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef[a] if coef is not None else None,
+                               Nq, rec["mean_c"], rec["rstd_c"],
                                dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl], drop=rec["dr_cr"],
                                dx_zeroed=dxr_zero[a] if dxr_zero is not None else None)
             do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
@@ -639,8 +652,9 @@ class _FusedDecoder(Function):
                 dx = mh_backward(rec, dcls[a], dmlog[a], dx)
 
         # ---- hoisted K/V projection backward (sum over all applications)
-        need_feat = [ctx.needs_input_grad[9 + m] for m in range(M)]
-        dfeats: List[Optional[torch.Tensor]] = [None] * M
+        need_feat = [ctx.needs_input_grad[9 + u] for u in range(U)]
+        dfeats: List[Optional[torch.Tensor]] = [None] * U
+        single = U == M and all(src[i][j] == j for i in range(Ln) for j in range(M)) and mh_src[:M] == list(range(M))[:len(mh_src)]
         Akv, Bkv, Xf, X2, GWs, Gbs = [], [], [], [], [], []
         for a in range(n_app):
             i = tape[a]["i"]
@@ -649,8 +663,8 @@ class _FusedDecoder(Function):
                 gw, gb = G(ca.multihead_attn.in_proj_weight), G(ca.multihead_attn.in_proj_bias)
                 Akv += [dKV[a, 0, j], dKV[a, 1, j]]
                 Bkv += [w[d:2 * d], w[2 * d:]]
-                Xf += [ctx.kin[j], ctx.vin[j]]
-                X2 += [ctx.kin2[j], None]
+                Xf += [ctx.kin[src[i][j]], ctx.vin[src[i][j]]]
+                X2 += [ctx.kin2[src[i][j]], None]
                 GWs += [gw[d:2 * d], gw[2 * d:]]
                 Gbs += [gb[d:2 * d], gb[2 * d:]]
         dwq.add(Akv, Xf, X2, GWs, ct, Gbs)
@@ -665,25 +679,28 @@ class _FusedDecoder(Function):
             if dkeys is not None:
                 kT = torch.stack([mp.k_proj.weight.detach() for mp in list(spec.mh.mask_pred_list)[:spec.mh_count]]) \
                     .transpose(1, 2).contiguous().to(ad)
-        # d feat_m = sum_a (dK_{a,m} Wk + dV_{a,m} Wv) [+ mask-head key path]
+        # d source_u = sum over the (application, memory) pairs that read it of (dK Wk + dV Wv) [+ mask-head key path]
         jobs = []
-        for j in range(M):
-            if not need_feat[j]:
+        for u in range(U):
+            if not need_feat[u]:
                 continue
-            Aj = [Akv[2 * (a * M + j) + t] for a in range(n_app) for t in (0, 1)]
-            Bj = [Bkv[2 * (a * M + j) + t] for a in range(n_app) for t in (0, 1)]
-            if dkeys is not None and j < spec.mh_count:
+            pairs = [(a, j) for a in range(n_app) for j in range(M) if src[tape[a]["i"]][j] == u]
+            Aj = [Akv[2 * (a * M + j) + t] for a, j in pairs for t in (0, 1)]
+            Bj = [Bkv[2 * (a * M + j) + t] for a, j in pairs for t in (0, 1)]
+            for j in range(spec.mh_count if dkeys is not None else 0):
+                if mh_src[j] != u:
+                    continue
                 mp = list(spec.mh.mask_pred_list)[j]
                 dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
                 Aj.append(dkm)
                 Bj.append(kT[j] if tposed else mp.k_proj.weight.detach())
-                dwq.add([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
-            jobs.append((j, Aj, Bj))
+                dwq.add([dkm], [ctx.mh_feats[j]], None, [G(mp.k_proj.weight)], ct)
+            jobs.append((u, Aj, Bj))
         per = len(jobs[0][1]) if jobs else 0
         want_dpos = pos is not None and ctx.needs_input_grad[4]
         dpos = None
         nk, nv = n_app, n_app + (1 if dkeys is not None else 0)
-        if tposed and want_dpos and len(jobs) == M and nk * M <= MAXG and nv * M <= MAXG and \
+        if single and tposed and want_dpos and len(jobs) == M and nk * M <= MAXG and nv * M <= MAXG and \
                 (dkeys is None or spec.mh_count == M):
             # the position embedding enters every memory's KEY input, so d pos = sum_m (K part of d feat_m): form the K
             # parts once (one launch, M outputs), add them into the V parts through the "+ aux" epilogue (second launch)
@@ -703,7 +720,7 @@ class _FusedDecoder(Function):
                 dfeats[jb[0]] = o_
             dpos = Kp.sum(0)
             want_dpos = False
-        elif tposed and jobs and per <= MAXG and all(len(jb[1]) == per for jb in jobs):
+        elif tposed and jobs and 0 < per <= MAXG and all(len(jb[1]) == per for jb in jobs):
             cap = max(1, MAXG // per)   # memories per launch
             for c0 in range(0, len(jobs), cap):
                 chunk = jobs[c0:c0 + cap]
@@ -716,6 +733,8 @@ class _FusedDecoder(Function):
         else:
             for j, Aj, Bj in jobs:
                 out = None
+                if not Aj:   # a source no layer reads (e.g. a surplus scale): zero gradient
+                    out = torch.zeros(B, Ns, d, dtype=torch.float32, device=dev)
                 for s in range(0, len(Aj), MAXG):
                     nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
                     n = len(Aj[s:s + MAXG])
@@ -727,10 +746,10 @@ class _FusedDecoder(Function):
                 dfeats[j] = out
         if dkeys is not None:  # k_proj weight grads for memories whose features need no grad
             for j in range(spec.mh_count):
-                if not need_feat[j]:
+                if not need_feat[mh_src[j]]:
                     mp = list(spec.mh.mask_pred_list)[j]
                     dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
-                    dwq.add([dkm], [feats[j]], None, [G(mp.k_proj.weight)], ct)
+                    dwq.add([dkm], [ctx.mh_feats[j]], None, [G(mp.k_proj.weight)], ct)
         if want_dpos:
             Ak, Bk = Akv[0::2], Bkv[0::2]
             for s in range(0, len(Ak), MAXG):
@@ -772,24 +791,54 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
     feats = [input_dict[m][0] for m in mems]
     masks = [input_dict[m][1] for m in mems]
     poss = [input_dict[m][2] for m in mems]
-    if any(isinstance(f, list) for f in feats) or any(m.ndim != 2 for m in masks):
-        raise NotImplementedError("fused path: multi-scale voxel features / pre-set 3-D masks")
-    if any(p is not poss[0] for p in poss) or len({tuple(f.shape) for f in feats}) != 1:
+    if any(m.ndim != 2 for m in masks):
+        raise NotImplementedError("fused path: pre-set 3-D masks")
+    Ln_ = len(enc.unified_encoder)
+    # unique source tensors: a multi-scale voxel memory (list: one [B, N_seg, d] tensor per layer, the last one for the
+    # mask head -- pcd_mask3d_encoder.py:133-154, query_encoder.py:90-91) contributes one source per scale
+    uniq, src = [], [[0] * len(mems) for _ in range(Ln_)]
+
+    def uid(t):
+        for k, q in enumerate(uniq):
+            if q is t:
+                return k
+        uniq.append(t)
+        return len(uniq) - 1
+    for j, f in enumerate(feats):
+        if isinstance(f, (list, tuple)):
+            if len(f) < Ln_:
+                raise NotImplementedError("fused path: a multi-scale memory needs one scale per layer")
+            for i in range(Ln_):
+                src[i][j] = uid(f[i])
+        else:
+            for i in range(Ln_):
+                src[i][j] = uid(f)
+    if any(p is not poss[0] for p in poss) or len({tuple(f.shape) for f in uniq}) != 1:
         raise NotImplementedError("fused path: memories must share one position tensor and one shape")
-    if len(mems) * len(enc.unified_encoder) * 2 > 4 * MAXG:
+    if len(mems) * Ln_ * 2 > 4 * MAXG:
         raise NotImplementedError("fused path: too many (layer, memory) groups")
-    mh_count = 0
+    mh_count, mh_src = 0, []
     if mask_head is not None:
-        if seg_fts_for_match is None or any(sf[0] is not feats[k] for k, sf in enumerate(seg_fts_for_match)):
-            raise NotImplementedError("fused path: mask-head memories must be the leading scene memories")
-        mh_count = len(seg_fts_for_match)
+        if seg_fts_for_match is None:
+            raise NotImplementedError("fused path: mask head without seg_fts_for_match")
+        mh_count = min(len(seg_fts_for_match), len(mask_head.mask_pred_list))   # mask_head.py:31: zip() truncates
+        for k, sf in enumerate(seg_fts_for_match[:mh_count]):
+            want = feats[k][-1] if (k < len(feats) and isinstance(feats[k], (list, tuple))) else (feats[k] if k < len(feats) else None)
+            if sf[0] is not want:
+                raise NotImplementedError("fused path: mask-head memories must be the leading scene memories")
+            mh_src.append(uid(sf[0]))
     if enc.use_self_mask and mask_head is None:
         raise NotImplementedError("use_self_mask without a mask head")
     coef = None
     if training and layer0.memory_dropout > 0.0:
-        keep = torch.rand(x0.shape[0], len(mems), device=x0.device) > layer0.memory_dropout
-        keep = torch.logical_or(keep, keep.sum(1, keepdim=True) == 0)
-        coef = (keep / keep.sum(1, keepdim=True)).t().contiguous().float()
+        # query_encoder.py:145-151: every layer application draws its own per-(scene, memory) keep mask -> [apps, M, B]
+        from .modules import memory_keep_coef
+        hook = getattr(enc, "memory_keep_hook", None)
+        n_app = enc.num_blocks * len(enc.unified_encoder)
+        B_ = x0.shape[0]
+        coef = torch.stack([memory_keep_coef(B_, len(mems), layer0.memory_dropout, x0.device,
+                                             hook(a, B_, len(mems), x0.device) if hook is not None else None)
+                            for a in range(n_app)]).contiguous()
     ct = L.BF16 if layer0.compute == "bf16" else L.F32
     drop_base, mh_drop = None, False
     if training:   # the caller (QueryMaskEncoder.forward) has opened the RNG epoch (modules.begin_dropout_step)
@@ -808,9 +857,10 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
     if st is not None and list(st[1]) == list(mems) and st[0].is_contiguous() and \
             all(masks[j].data_ptr() == st[0][j].data_ptr() for j in range(len(mems))):
         spec.stacked_kpm = st[0]
+    spec.src, spec.mh_src, spec.n_src = src, mh_src, len(uniq)
     params = [p for p in enc.parameters()] + ([p for p in mask_head.parameters()] if mask_head is not None else [])
     outs = _FusedDecoder.apply(spec, x0, qpos, qmask, poss[0], pairwise_locs, seg_masks, offline_attn_masks, coef,
-                               *feats, *masks, *params)
+                               *uniq, *masks, *params)
     query = outs[0]
     n = (len(outs) - 1) // 2
     return query, list(outs[1:1 + n]), list(outs[1 + n:1 + 2 * n])

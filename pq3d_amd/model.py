@@ -114,6 +114,7 @@ class Query3DUnified(nn.Module):
     def _pos(self, locs, coord_min, coord_max, box_times=1):
         if self.dim_loc > 3:
             ct = self.ct
+            ct = ops.small_ct(ct)
             c = ops.linear(locs[:, :, :3].contiguous(), self.coord_encoder[0].weight, self.coord_encoder[0].bias, ct=ct)
             b = ops.linear(locs[:, :, 3:6].contiguous(), self.box_encoder[0].weight, self.box_encoder[0].bias, ct=ct)
             key = (locs.shape[0], box_times, locs.device)
@@ -153,7 +154,8 @@ class Query3DUnified(nn.Module):
             return out
         seqs = [e.input_feat_proj for e in encs]
         ys = ops.linear_ln_group(xs, [q[0].weight for q in seqs], [q[0].bias for q in seqs],
-                                 [q[1].weight for q in seqs], [q[1].bias for q in seqs], ct=self.ct, eps=seqs[0][1].eps)
+                                 [q[1].weight for q in seqs], [q[1].bias for q in seqs], ct=ops.small_ct(self.ct),
+                                 eps=seqs[0][1].eps)   # split-bf16 in 'bf16' mode: see modules.linear_ln_forward
         if self.training:   # ObjectEncoder's output dropout (object_encoder.py:72-73), same sites as the per-encoder path
             ys = [ops.dropout(y, e._drop(e._head_ctx(y.device), ops.DROP_ENC_OUT, y.device)) for y, e in zip(ys, encs)]
         return dict(zip(names, ys))

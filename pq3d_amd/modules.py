@@ -99,6 +99,7 @@ def get_mlp_head(input_size: int, hidden_size: int, output_size: int, dropout: f
 
 def mlp_head_forward(seq: nn.Sequential, x: torch.Tensor, ct: int, fill_flag=None, fill_value=0.0,
                      drop=None) -> torch.Tensor:
+    ct = ops.small_ct(ct)   # heads run on the B*N_q query rows: split-bf16 in 'bf16' mode
     h = ops.linear(x, seq[0].weight, seq[0].bias, ct=ct, act="relu", out_dtype=torch.float32)
     h = ops.add_layernorm(None, [h], [seq[2].weight], [seq[2].bias], eps=seq[2].eps)
     h = ops.dropout(h, drop)   # nn.Dropout between LayerNorm and the last Linear (utils.py:23)
@@ -108,8 +109,13 @@ def mlp_head_forward(seq: nn.Sequential, x: torch.Tensor, ct: int, fill_flag=Non
 def linear_ln_forward(seq: nn.Sequential, x: torch.Tensor, ct: int) -> torch.Tensor:
     """nn.Sequential(Linear, LayerNorm) as used by the encoders (object_encoder.py:34, query3d_unified.py:20,63-70)."""
     # the one-encoder case of the grouped Linear+LN op: 2 launches forward; its backward zero-fills every atomics target
-    # (LayerNorm parameter gradients, split-K weight gradient, bias column sums) with ONE fill
-    return ops.linear_ln_group([x], [seq[0].weight], [seq[0].bias], [seq[1].weight], [seq[1].bias], ct=ct, eps=seq[1].eps)[0]
+    # (LayerNorm parameter gradients, split-K weight gradient, bias column sums) with ONE fill.
+    # 'bf16' mode: split-bf16 forward product.  The encoder outputs (segment features, positions, caption-head input) feed
+    # every layer's keys and values, so their operand rounding (1.1e-3 per Linear) would sit under everything downstream:
+    # 3.6e-3 of the final query at config 2 by itself (measured with the oracle's rounding emulation); 3 MFMAs on these
+    # B*N_seg x d_in x d products cost ~25 us per step.
+    return ops.linear_ln_group([x], [seq[0].weight], [seq[0].bias], [seq[1].weight], [seq[1].bias], ct=ops.small_ct(ct),
+                               eps=seq[1].eps)[0]
 
 
 def _xavier(module: nn.Module) -> None:
@@ -155,6 +161,11 @@ class _PostNormBase(nn.Module):
     @property
     def ct(self) -> int:
         return CT[self.compute]
+
+    @property
+    def ct_q(self) -> int:
+        """Compute type of the query-side GEMMs (M = B*N_q rows): split-bf16 in 'bf16' mode (ops.small_ct)."""
+        return ops.small_ct(CT[self.compute])
 
     def _drop_ctx(self, device, ctx=None, p=None):
         """(site base, layer application) for this call, or None when dropout is inactive.  A caller higher up (the
@@ -202,7 +213,9 @@ class CrossAttentionLayer(_PostNormBase):
         ct, d = self.ct, tgt.shape[-1]
         w, b = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
         ad = ops.act_dtype(ct)
-        q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=ct, out_dtype=ad)
+        # the query projection (B*N_q rows) is formed at fp32 grade (split-bf16) and rounded once to the attention
+        # operand type; K / V (B*N_seg rows: the bulk of the FLOPs) are single bf16 products
+        q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=self.ct_q, out_dtype=ad)
         k = ops.linear(memory, w[d:2 * d], b[d:2 * d], x2=pos, ct=ct, out_dtype=ad)
         v = ops.linear(memory, w[2 * d:], b[2 * d:], ct=ct, out_dtype=ad)
         o = ops.attention(q, k, v, H=self.nhead, ct=ct, zero_attn=True, kpm=memory_key_padding_mask, mask=attn_mask,
@@ -231,14 +244,15 @@ class SelfAttentionLayer(_PostNormBase):
         _xavier(self)
 
     def forward(self, tgt, attn_mask=None, tgt_key_padding_mask=None, query_pos=None, _drop=None):
-        ct, d = self.ct, tgt.shape[-1]
+        # self-attention works on N_q x N_q scores per scene (a negligible share of the FLOPs): projections at fp32 grade
+        # (split-bf16 in 'bf16' mode), the attention core on the exact-f32 MFMA path in both modes
+        ct, d = self.ct_q, tgt.shape[-1]
         ctx = self._drop_ctx(tgt.device, _drop)
         w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
-        ad = ops.act_dtype(ct)
-        q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=ct, out_dtype=ad)
-        k = ops.linear(tgt, w[d:2 * d], b[d:2 * d], x2=query_pos, ct=ct, out_dtype=ad)
-        v = ops.linear(tgt, w[2 * d:], b[2 * d:], ct=ct, out_dtype=ad)
-        o = ops.attention(q, k, v, H=self.nhead, ct=ct, kpm=tgt_key_padding_mask, mask=attn_mask,
+        q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=ct)
+        k = ops.linear(tgt, w[d:2 * d], b[d:2 * d], x2=query_pos, ct=ct)
+        v = ops.linear(tgt, w[2 * d:], b[2 * d:], ct=ct)
+        o = ops.attention(q, k, v, H=self.nhead, ct=F32, kpm=tgt_key_padding_mask, mask=attn_mask,
                           drop=self._drop(ctx, ops.DROP_SA_ATTN, tgt.device))
         o = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, ct=ct)
         return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
@@ -262,12 +276,12 @@ class MultiHeadAttentionSpatial(_PostNormBase):
     def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, q_pos=None, k_pos=None):
         """Returns only the output (the reference also returns the fused attention map, which the decoder
         discards, query_encoder.py:447).  q_pos/k_pos are added to q/k inside the projection kernels."""
-        ct, ad = self.ct, ops.act_dtype(self.ct)
-        qh = ops.linear(q, self.w_qs.weight, self.w_qs.bias, x2=q_pos, ct=ct, out_dtype=ad)
-        kh = ops.linear(k, self.w_ks.weight, self.w_ks.bias, x2=k_pos, ct=ct, out_dtype=ad)
-        vh = ops.linear(v, self.w_vs.weight, self.w_vs.bias, ct=ct, out_dtype=ad)
+        ct = self.ct_q   # as SelfAttentionLayer: fp32-grade projections, exact-f32 attention core
+        qh = ops.linear(q, self.w_qs.weight, self.w_qs.bias, x2=q_pos, ct=ct)
+        kh = ops.linear(k, self.w_ks.weight, self.w_ks.bias, x2=k_pos, ct=ct)
+        vh = ops.linear(v, self.w_vs.weight, self.w_vs.bias, ct=ct)
         bias = ops.spatial_bias(pairwise_locs, self.pairwise_loc_fc.weight, self.pairwise_loc_fc.bias)
-        o = ops.attention(qh, kh, vh, H=self.n_head, ct=ct, kpm=key_padding_mask, bias=bias)
+        o = ops.attention(qh, kh, vh, H=self.n_head, ct=F32, kpm=key_padding_mask, bias=bias)
         return ops.linear(o, self.fc.weight, self.fc.bias, ct=ct)
 
 
@@ -310,7 +324,7 @@ class FFNLayer(_PostNormBase):
         _xavier(self)
 
     def forward(self, tgt, _drop=None):
-        ct = self.ct
+        ct = self.ct_q   # split-bf16 in 'bf16' mode: the ReLU kink is hit at fp32 grade, the hidden activations stay fp32
         ctx = self._drop_ctx(tgt.device, _drop)
         h = ops.linear(tgt, self.linear1.weight, self.linear1.bias, ct=ct, act=self.activation,
                        out_dtype=ops.act_dtype(ct), drop=self._drop(ctx, ops.DROP_FFN_INNER, tgt.device))
@@ -323,6 +337,17 @@ class FFNLayer(_PostNormBase):
                          self.linear2.bias if k == 0 else None, ct=ct) for k in range(KS)]
         return ops.add_layernorm(tgt, ys, [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
                                  drop=self._drop(ctx, ops.DROP_FFN_RES, tgt.device), sum_branches=True)
+
+
+def memory_keep_coef(B: int, M: int, p: float, device, keep=None) -> torch.Tensor:
+    """Training-time memory dropout of the parallel cross-attention (query_encoder.py:145-151): per (scene, memory)
+    Bernoulli keep with at least one memory kept per scene (a scene that drew none keeps all), returned as the weights
+    of the masked mean, [M, B] fp32.  ``keep`` [B, M] bool overrides the draw."""
+    if keep is None:
+        keep = torch.rand(B, M, device=device) > p
+    keep = keep.to(device=device, dtype=torch.bool)
+    keep = torch.logical_or(keep, keep.sum(1, keepdim=True) == 0)
+    return (keep / keep.sum(1, keepdim=True)).t().contiguous().float()
 
 
 class QueryEncoderLayer(_PostNormBase):
@@ -350,7 +375,9 @@ class QueryEncoderLayer(_PostNormBase):
         if structure == "gate":
             self.gate_proj = nn.Linear(d_model, d_model)
 
-    def forward(self, query, input_dict, pairwise_locs=None, _drop=None):
+    def forward(self, query, input_dict, pairwise_locs=None, _drop=None, _mem_keep=None):
+        """``_mem_keep`` [B, len(scene memories)] bool: externally drawn training-time memory-dropout mask (tests feed
+        the same mask to the oracle); None -> drawn here with torch.rand as the reference does (:145)."""
         _, query_masks, query_pos = input_dict["query"][:3]
         dctx = self._drop_ctx(query.device, _drop)
         B, H = query.shape[0], self.cross_attn_list[0].nhead if len(self.cross_attn_list) else 1
@@ -375,9 +402,7 @@ class QueryEncoderLayer(_PostNormBase):
             outs = [ca.branch(q, **ca_args(m), _drop=dctx, _m=j) for j, (ca, m) in enumerate(zip(cas, memories))]
             coef = None
             if self.training and self.memory_dropout > 0.0:  # query_encoder.py:145-151
-                keep = torch.rand(B, len(memories), device=q.device) > self.memory_dropout
-                keep = torch.logical_or(keep, keep.sum(1, keepdim=True) == 0)
-                coef = (keep / keep.sum(1, keepdim=True)).t().contiguous().float()  # [M,B]
+                coef = memory_keep_coef(B, len(memories), self.memory_dropout, q.device, _mem_keep)  # [M,B]
             return ops.add_layernorm(q, outs, [c.norm.weight for c in cas], [c.norm.bias for c in cas],
                                      eps=cas[0].norm.eps, coef=coef,
                                      drop=cas[0]._drop(dctx, ops.DROP_CA_RES, q.device) if cas else None)
@@ -392,7 +417,7 @@ class QueryEncoderLayer(_PostNormBase):
             query = sequential_ca(query, ["prompt"])
         elif self.structure == "gate":
             prompt = sequential_ca(query, ["prompt"])
-            gate = ops.linear(prompt, self.gate_proj.weight, self.gate_proj.bias, ct=self.ct)
+            gate = ops.linear(prompt, self.gate_proj.weight, self.gate_proj.bias, ct=self.ct_q)
             update = parallel_ca(query, [m for m in self.memories if m != "prompt"])
             query = ops.gate_mix(query, update, gate)
         else:
@@ -428,6 +453,8 @@ class QueryMaskEncoder(nn.Module):
         self.use_self_mask = use_self_mask
         self.num_heads = num_attention_heads
         self.num_blocks = num_blocks
+        # test hook: callable(app, B, M, device) -> [B, M] bool keep-mask of layer application `app` (None: torch.rand)
+        self.memory_keep_hook = None
         self.fused = True          # use the fused executor (fused.py) whenever the configuration allows it
         self._fused_final = None   # (cls, mask_logits) of the trailing mask-head call computed by the fused path
         self._drop_base, self._drop_epoch = DROP_BASE_ENCODER, -1
@@ -495,7 +522,11 @@ class QueryMaskEncoder(nn.Module):
                         input_dict[memory][1] = attn_mask
                 if isinstance(voxel_feat, list):
                     input_dict["voxel"][0] = voxel_feat[i]
-                query = layer(query, input_dict, pairwise_locs, _drop=(self._drop_base, app) if self.training else None)
+                mk = None
+                if self.training and layer.memory_dropout > 0.0 and self.memory_keep_hook is not None:
+                    mk = self.memory_keep_hook(app, query.shape[0], len(layer.memories), query.device)
+                query = layer(query, input_dict, pairwise_locs, _drop=(self._drop_base, app) if self.training else None,
+                              _mem_keep=mk)
         if mh_owner is not None:
             mh_owner._drop_call = n_app
         return query, predictions_class, predictions_mask
@@ -513,10 +544,49 @@ class QueryEncoder(nn.Module):
                                   structure=structure)
         self.unified_encoder = layer_repeat(layer, num_layers, share_layer)
         self.apply(_init_weights_bert)
+        self.memory_dropout = memory_dropout
+        self.scene_meomories = [x for x in memories if x != "prompt"]
+        self.drop_memories_test = drop_memories_test
+        self.memory_drop_hook = None   # test hook: callable(memory, B, device) -> [B] bool drop-mask (None: torch.rand)
         self._drop_base, self._drop_epoch = DROP_BASE_ENCODER, -1
         set_compute(self, compute)
 
+    def dropout_memory(self, input_dict):
+        """query_encoder.py:26-37: zero the features AND the position rows of dropped scenes -- training: per (scene,
+        memory) Bernoulli(memory_dropout); eval: every scene of the memories in ``drop_memories_test``.  The reference
+        writes in place, and the scene memories share ONE position tensor (query3d_unified.py:124-153), so a scene dropped
+        for any memory loses its positions for all memories that share the tensor: reproduced by zeroing shared position
+        tensors once with the union of their memories' masks.  (Out of place here: the inputs may require grad.)"""
+        masks = {}
+        for memory in self.scene_meomories:
+            feat = input_dict[memory][0]
+            B, dev = feat.shape[0], feat.device
+            if self.training:
+                dm = self.memory_drop_hook(memory, B, dev) if self.memory_drop_hook is not None \
+                    else torch.rand(B, device=dev) < self.memory_dropout
+            else:
+                dm = torch.full((B,), memory in self.drop_memories_test, dtype=torch.bool, device=dev)
+            masks[memory] = dm.to(device=dev, dtype=torch.bool)
+        pos_union = {}
+        for memory in self.scene_meomories:
+            pos = input_dict[memory][2]
+            if pos is not None:
+                k = id(pos)
+                pos_union[k] = masks[memory] if k not in pos_union else (pos_union[k] | masks[memory])
+        new_pos = {}
+        for memory in self.scene_meomories:
+            feat, mask, pos = input_dict[memory][:3]
+            keep = masks[memory].logical_not().to(feat.dtype)[:, None, None]
+            if pos is not None:
+                k = id(pos)
+                if k not in new_pos:
+                    new_pos[k] = pos * pos_union[k].logical_not().to(pos.dtype)[:, None, None]
+                pos = new_pos[k]
+            input_dict[memory] = [feat * keep, mask, pos] + list(input_dict[memory][3:])
+
     def forward(self, input_dict, pairwise_locs):
+        if (self.training and self.memory_dropout > 0) or (not self.training and self.drop_memories_test):
+            self.dropout_memory(input_dict)
         query = input_dict["query"][0]
         if self.training:
             begin_dropout_step(self, query.device)
@@ -557,7 +627,12 @@ class MaskHeadSegLevel(_PostNormBase):
     def project_keys(self, seg_fts_for_match):
         """k_proj of every matching memory (rows of padded segments zeroed) + the masked-mean denominators.
         Layer-invariant unless the voxel memory is multi-scale: callers may compute it once per forward."""
-        ct = self.ct
+        # split-bf16 in 'bf16' mode (fp32 keys): the mask logits decide the self-masks of every following layer, and a
+        # single-bf16 key projection alone costs 1.4e-3 of their scale (profiles/parity_r02.txt); the projection is
+        # layer-invariant (computed once per forward)
+        ct = self.ct_q
+        n = len(self.mask_pred_list)   # mask_head.py:31: zip() truncates to the shorter of the two lists
+        seg_fts_for_match = list(seg_fts_for_match)[:n]
         keys = [ops.linear(feat, mp.k_proj.weight, None, ct=ct, out_dtype=ops.act_dtype(ct),
                            row_mask=mask.logical_not())
                 for (feat, mask, _pos), mp in zip(seg_fts_for_match, self.mask_pred_list)]
@@ -567,8 +642,8 @@ class MaskHeadSegLevel(_PostNormBase):
     def forward(self, query, seg_fts_for_match, seg_masks, offline_attn_masks=None, skip_prediction=False, keys=None):
         if skip_prediction:
             return None, None, offline_attn_masks
-        ct = self.ct
-        cls_logits = mlp_head_forward(self.cls_head, query, ct,
+        ct = self.ct_q
+        cls_logits = mlp_head_forward(self.cls_head, query, self.ct,
                                       drop=self._drop(self._head_ctx(query.device), ops.DROP_MLP_HEAD, query.device))
         if self._foc_cols.numel():
             cls_logits = ops.fill_cols(cls_logits, self._foc_cols, float("-inf"))

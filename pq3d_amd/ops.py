@@ -12,15 +12,29 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
-from ._lib import BF16, F32
+from ._lib import BF16, BF16X3, F32
 from .profiler import timed
 
 _empty = torch.empty
 
 
 def act_dtype(ct: int) -> torch.dtype:
-    """Storage dtype of MFMA-operand activations (Q/K/V/O, FFN hidden) for a compute type."""
+    """Storage dtype of MFMA-operand activations (Q/K/V/O, FFN hidden) for a compute type.  Split-bf16 (BF16X3)
+    products take fp32 operands (they are split into hi + lo bf16 parts inside the GEMM staging path)."""
     return torch.bfloat16 if ct == BF16 else torch.float32
+
+
+def bwd_ct(ct: int) -> int:
+    """Compute type of the BACKWARD products of an op whose forward ran at ``ct``: split-bf16 is a forward-accuracy
+    device (it keeps ReLU kinks / mask thresholds / softmax inputs at fp32 grade); gradients are formed with single
+    bf16 products (fp32 accumulate), whose ~1e-3 relative error is far inside the 2e-2 gradient tolerance."""
+    return BF16 if ct == BF16X3 else ct
+
+
+def small_ct(ct: int) -> int:
+    """Compute type of the query-side (M = B*N_q rows) projections / FFN / head GEMMs for a module compute type:
+    'bf16' -> split-bf16 (these launches are latency-bound, the extra MFMAs are free), 'fp32' -> exact f32."""
+    return BF16X3 if ct == BF16 else ct
 
 
 def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -203,7 +217,7 @@ class _Linear(Function):
     @staticmethod
     def backward(ctx, dy):
         x, x2, w, saved, rm, fill_flag = ctx.saved_tensors
-        ct = ctx.ct
+        ct = bwd_ct(ctx.ct)
         N, K = w.shape
         R = x.numel() // K
         g = dy.contiguous()
@@ -273,6 +287,7 @@ class _LinearGroup(Function):
     @staticmethod
     def backward(ctx, *dys):
         ct, G = ctx.cfg
+        ct = bwd_ct(ct)
         xs, Ws = ctx.saved_tensors[:G], ctx.saved_tensors[G:]
         K = xs[0].shape[-1]
         R = xs[0].numel() // K
@@ -487,6 +502,7 @@ class _MaskLogits(Function):
     @staticmethod
     def backward(ctx, dl, _dmask):
         ct, M = ctx.cfg
+        ct = bwd_ct(ct)
         inv_den, seg_pad = ctx.saved_tensors[:2]
         ks, qs = ctx.saved_tensors[2:2 + M], ctx.saved_tensors[2 + M:]
         B, Ns, dm = ks[0].shape
@@ -712,6 +728,7 @@ class _LinearLNGroup(Function):
     @staticmethod
     def backward(ctx, *dys):
         ct, eps, G, need_dx = ctx.cfg
+        ct = bwd_ct(ct)
         lin, mean, rstd = ctx.saved_tensors[:3]
         t = ctx.saved_tensors[3:]
         xs, Ws, gam, bet = t[:G], t[G:2 * G], t[2 * G:3 * G], t[3 * G:4 * G]

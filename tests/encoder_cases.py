@@ -1,0 +1,148 @@
+"""Encoder-level parity cases F13 (multi-scale voxel memory, num_blocks 3, self-mask + mask head) and F14 (training-time
+memory dropout with keep masks fixed from outside): runners for the oracle (CPU) and the HIP modules (GPU), both fed the
+inputs the fixture generator fed the reference (tests/golden/make_golden.py).  Test infrastructure."""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+
+from oracle import pq3d_oracle as O
+from pq3d_amd import modules as M
+from pq3d_amd import synth
+from tests import util
+from tests.golden.make_golden import encoder_level_inputs, memory_keep_draws
+
+
+def _loss(query, pcls, pmask, dev="cpu"):
+    loss = (query * util.loss_weight("query", query.shape).to(dev)).mean()
+    for i, (c, m_) in enumerate(zip(pcls, pmask)):
+        cf = torch.where(torch.isfinite(c), c, torch.zeros_like(c))
+        loss = loss + (cf * util.loss_weight(f"cls{i}", c.shape).to(dev)).mean() \
+            + (m_.clamp(min=-50.0) * util.loss_weight(f"mask{i}", m_.shape).to(dev)).mean()
+    return loss
+
+
+# ---------------------------------------------------------------------------------------------- F13
+def f13_state(a):
+    enc = M.QueryMaskEncoder(None, memories=a["memories"], hidden_size=a["d"], num_attention_heads=a["H"],
+                             num_layers=a["L"], spatial_selfattn=True, structure="parallel", use_self_mask=True,
+                             num_blocks=a["nb"], compute="fp32")
+    mh = M.MaskHeadSegLevel(None, a["d"], a["C"], memories_for_match=a["memories"], filter_out_classes=list(a["foc"]))
+    sd = {**{"unified_encoder." + k: v for k, v in synth.fill_module(enc, a["seed"]).items()},
+          **{"mask_head." + k: v for k, v in synth.fill_module(mh, a["seed"] + 1).items()}}
+    return enc, mh, sd
+
+
+def f13_inputs(a):
+    return encoder_level_inputs(B=a["B"], Ns=a["Ns"], Nq=a["Nq"], d=a["d"], memories=a["memories"], n_scales=a["L"] + 1,
+                                data_seed=a["data_seed"])
+
+
+def f13_oracle(a, sd):
+    feats, pad, qpos, fpos, centers = f13_inputs(a)
+    for f in feats["voxel"]:
+        f.requires_grad_(True)
+    feats["mv"].requires_grad_(True)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    B, Nq, d = qpos.shape
+    input_dict = {"query": (torch.zeros(B, Nq, d), torch.zeros(B, Nq, dtype=torch.bool), qpos)}
+    for m in a["memories"]:
+        input_dict[m] = [feats[m], pad.clone(), fpos]
+    sfm = [[feats[m][-1] if isinstance(feats[m], list) else feats[m], pad.clone(), fpos] for m in a["memories"]]
+    mh = lambda q: O.mask_head_seg_level(sdo, "mask_head.", q, sfm, pad, None, False, list(a["foc"]))
+    pl = O.calc_pairwise_locs(centers)
+    query, pcls, pmask = O.query_mask_encoder(sdo, "unified_encoder.", input_dict, pl, mh, memories=a["memories"], H=a["H"],
+                                              num_layers=a["L"], structure="parallel", spatial_selfattn=True,
+                                              use_self_mask=True, num_blocks=a["nb"])
+    c, m_, _ = mh(query)
+    pcls, pmask = pcls + [c], pmask + [m_]
+    loss = _loss(query, pcls, pmask)
+    loss.backward()
+    g = {k: v.grad for k, v in sdo.items() if v.grad is not None}
+    gin = {f"voxel/{i}": (f.grad if f.grad is not None else torch.zeros_like(f)) for i, f in enumerate(feats["voxel"])}
+    gin["mv"] = feats["mv"].grad
+    return query, pcls, pmask, loss, g, gin
+
+
+def f13_hip(a, compute, fused, dev="cuda"):
+    enc, mh, _sd = f13_state(a)
+    M.set_compute(enc, compute); M.set_compute(mh, compute)
+    enc.to(dev).eval(); mh.to(dev).eval()
+    enc.fused = fused
+    feats, pad, qpos, fpos, centers = f13_inputs(a)
+    vox = [f.to(dev).requires_grad_(True) for f in feats["voxel"]]
+    fd = {"voxel": vox, "mv": feats["mv"].to(dev).requires_grad_(True), "pc": feats["pc"].to(dev)}
+    pad, qpos, fpos = pad.to(dev), qpos.to(dev), fpos.to(dev)
+    B, Nq, d = qpos.shape
+    input_dict = {"query": (torch.zeros(B, Nq, d, device=dev), torch.zeros(B, Nq, dtype=torch.bool, device=dev), qpos)}
+    for m in a["memories"]:
+        input_dict[m] = [fd[m], pad, fpos]
+    sfm = [[fd[m][-1] if isinstance(fd[m], list) else fd[m], pad, fpos] for m in a["memories"]]
+    mhp = partial(mh, seg_fts_for_match=sfm, seg_masks=pad, offline_attn_masks=None, skip_prediction=False)
+    pl = M.calc_pairwise_locs(centers.to(dev))
+    query, pcls, pmask = enc(input_dict, pl, mhp)
+    if enc._fused_final is not None:
+        c, m_ = enc._fused_final
+    else:
+        c, m_, _ = mhp(query=query)
+    pcls, pmask = list(pcls) + [c], list(pmask) + [m_]
+    loss = _loss(query, pcls, pmask, dev)
+    loss.backward()
+    g = {"unified_encoder." + n: p.grad for n, p in enc.named_parameters() if p.grad is not None}
+    g.update({"mask_head." + n: p.grad for n, p in mh.named_parameters() if p.grad is not None})
+    gin = {f"voxel/{i}": (f.grad if f.grad is not None else torch.zeros_like(f)) for i, f in enumerate(vox)}
+    gin["mv"] = fd["mv"].grad
+    return query, pcls, pmask, loss, g, gin
+
+
+# ---------------------------------------------------------------------------------------------- F14
+def f14_keep(a):
+    """[apps, B, M] bool keep masks of the fixture (keep = draw > p, before the 'nothing kept keeps all' rule)."""
+    return memory_keep_draws(a["B"], len(a["memories"]), a["L"], a["data_seed"]) > a["p"]
+
+
+def f14_inputs(a):
+    return encoder_level_inputs(B=a["B"], Ns=a["Ns"], Nq=a["Nq"], d=a["d"], memories=a["memories"], n_scales=0,
+                                data_seed=a["data_seed"])
+
+
+def f14_module(a, compute="fp32"):
+    enc = M.QueryMaskEncoder(None, memories=a["memories"], memory_dropout=a["p"], hidden_size=a["d"],
+                             num_attention_heads=a["H"], num_layers=a["L"], spatial_selfattn=True, structure="parallel",
+                             compute=compute)
+    sd = synth.fill_module(enc, a["seed"])
+    return enc, sd
+
+
+def f14_oracle(a, sd):
+    feats, pad, qpos, fpos, centers = f14_inputs(a)
+    keep = f14_keep(a)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    B, Nq, d = qpos.shape
+    input_dict = {"query": (torch.zeros(B, Nq, d), torch.zeros(B, Nq, dtype=torch.bool), qpos)}
+    for m in a["memories"]:
+        input_dict[m] = [feats[m], pad.clone(), fpos]
+    query, _, _ = O.query_mask_encoder(sdo, "", input_dict, O.calc_pairwise_locs(centers), None, memories=a["memories"],
+                                       H=a["H"], num_layers=a["L"], structure="parallel", spatial_selfattn=True,
+                                       training=True, memory_keep=lambda app: keep[app])
+    (query * util.loss_weight("query", query.shape)).mean().backward()
+    return query, {k: v.grad for k, v in sdo.items() if v.grad is not None}
+
+
+def f14_hip(a, compute, fused, dev="cuda"):
+    enc, _sd = f14_module(a, compute)
+    M.set_dropout(enc, 0.0)          # every nn.Dropout-equivalent site off; memory_dropout stays at p
+    enc.to(dev).train()
+    enc.fused = fused
+    keep = f14_keep(a).to(dev)
+    enc.memory_keep_hook = lambda app, B, Mm, device: keep[app]
+    feats, pad, qpos, fpos, centers = f14_inputs(a)
+    pad, qpos, fpos = pad.to(dev), qpos.to(dev), fpos.to(dev)
+    B, Nq, d = qpos.shape
+    input_dict = {"query": (torch.zeros(B, Nq, d, device=dev), torch.zeros(B, Nq, dtype=torch.bool, device=dev), qpos)}
+    for m in a["memories"]:
+        input_dict[m] = [feats[m].to(dev), pad, fpos]
+    query, _, _ = enc(input_dict, M.calc_pairwise_locs(centers.to(dev)), None)
+    (query * util.loss_weight("query", query.shape).to(dev)).mean().backward()
+    return query, {n: p.grad for n, p in enc.named_parameters() if p.grad is not None}

@@ -157,8 +157,13 @@ def model_cfg(d, H, L, memories, heads, d_in, *, spatial, structure, use_self_ma
 
 def run_model_case(ref, name, *, B, Ns, Nq, d, H, L, memories, heads, spatial, structure, train_grads=True,
                    seed=0, data_seed=1234, query_valid_min=None, **kw):
-    d_in = {m: d for m in memories}
+    d_in = dict(kw.pop("d_in", None) or {m: d for m in memories})
+    if any(v != d for v in d_in.values()):
+        kw_din = {"d_in": d_in}
+    else:
+        kw_din = {}
     cfg = model_cfg(d, H, L, memories, heads, d_in, spatial=spatial, structure=structure, **kw)
+    kw = {**kw, **kw_din}
     torch.manual_seed(0)
     model = ref.model.Query3DUnified(cfg)
     sd = synth.fill_module(model, seed)
@@ -310,6 +315,131 @@ def run_encoder_case(ref, name, *, B, Ns, Nq, d, H, L, memories, structure, spat
     for n, p in enc.named_parameters():
         if p.grad is not None:
             put(out, "grad/" + n, p.grad, MAX_GRAD)
+    save(name, out)
+
+
+def encoder_level_inputs(*, B, Ns, Nq, d, memories, n_scales, data_seed):
+    """Synthetic inputs of the encoder-level cases F13 / F14 (shared with the tests): scene memories with ragged valid
+    lengths, the voxel memory optionally as a LIST of `n_scales` tensors (multi-scale), query / segment positions."""
+    r = np.random.default_rng(data_seed)
+    t = lambda *sh: torch.from_numpy(r.standard_normal(sh).astype(np.float32))
+    vl = r.integers(Ns // 2, Ns + 1, size=B); vl[0] = Ns
+    pad = torch.from_numpy(np.arange(Ns)[None, :] >= vl[:, None])       # True = padded
+    feats = {}
+    for m in memories:
+        n = n_scales if (m == "voxel" and n_scales) else 1
+        fl = []
+        for _ in range(n):
+            f = t(B, Ns, d); f[pad] = 0.0
+            fl.append(f)
+        feats[m] = fl if (m == "voxel" and n_scales) else fl[0]
+    qpos, fpos = t(B, Nq, d), t(B, Ns, d)
+    centers = torch.from_numpy(r.uniform(0, 4, (B, Nq, 3)).astype(np.float32))
+    return feats, pad, qpos, fpos, centers
+
+
+def run_multiscale_case(ref, name, *, B=2, Ns=72, Nq=13, d=64, H=4, L=4, nb=3, memories=("voxel", "mv", "pc"), C=21,
+                        foc=(0, 2), seed=0, data_seed=77):
+    """F13: the stage-1 decoder configuration (configs/instseg_sceneverse.yaml:114,141-146: hlevels [0,1,2,3] -> 5 scales,
+    num_blocks 3, self-mask) at encoder level: QueryMaskEncoder + MaskHeadSegLevel of the reference with the voxel memory
+    as a multi-scale LIST (layer i attends voxel_feat[i], query_encoder.py:90-91; the mask head matches against the last
+    scale, query3d_unified.py:163-165).  The list itself stands in for PCDMask3DSegLevelEncoder's output (its Minkowski
+    backbone cannot run here)."""
+    from functools import partial
+    torch.manual_seed(0)
+    enc = ref.qe.QueryMaskEncoder(None, memories=list(memories), hidden_size=d, num_attention_heads=H, num_layers=L,
+                                  spatial_selfattn=True, structure="parallel", use_self_mask=True, num_blocks=nb)
+    mh = ref.mh.MaskHeadSegLevel(None, d, C, memories_for_match=list(memories), filter_out_classes=list(foc))
+    sd = {**{"unified_encoder." + k: v for k, v in synth.fill_module(enc, seed).items()},
+          **{"mask_head." + k: v for k, v in synth.fill_module(mh, seed + 1).items()}}
+    enc.eval(); mh.eval()
+    feats, pad, qpos, fpos, centers = encoder_level_inputs(B=B, Ns=Ns, Nq=Nq, d=d, memories=memories, n_scales=L + 1,
+                                                           data_seed=data_seed)
+    for f in feats["voxel"]:
+        f.requires_grad_(True)
+    feats["mv"].requires_grad_(True)
+    input_dict = {"query": (torch.zeros(B, Nq, d), torch.zeros(B, Nq, dtype=torch.bool), qpos)}
+    for m in memories:
+        input_dict[m] = [feats[m], pad.clone(), fpos]
+    sfm = [[feats[m][-1] if isinstance(feats[m], list) else feats[m], pad.clone(), fpos] for m in memories]
+    mhp = partial(mh, seg_fts_for_match=sfm, seg_masks=pad, offline_attn_masks=None, skip_prediction=False)
+    pl = ref.utils.calc_pairwise_locs(centers, None, pairwise_rel_type="center", spatial_dist_norm=True, spatial_dim=5)
+    query, pcls, pmask = enc(input_dict, pl, mhp)
+    c, m_, _ = mhp(query=query)
+    pcls, pmask = pcls + [c], pmask + [m_]
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd)),
+           "meta/args": np.array(repr(dict(B=B, Ns=Ns, Nq=Nq, d=d, H=H, L=L, nb=nb, memories=list(memories), C=C,
+                                           foc=list(foc), seed=seed, data_seed=data_seed)))}
+    put(out, "query", query)
+    loss = (query * loss_weight("query", query.shape)).mean()
+    for i, (c, m_) in enumerate(zip(pcls, pmask)):
+        put(out, f"pred_class/{i}", c); put(out, f"pred_mask/{i}", m_)
+        cf = torch.where(torch.isfinite(c), c, torch.zeros_like(c))
+        loss = loss + (cf * loss_weight(f"cls{i}", c.shape)).mean() + (m_.clamp(min=-50.0) * loss_weight(f"mask{i}", m_.shape)).mean()
+    out["loss"] = np.float64(loss.item())
+    enc.zero_grad(); mh.zero_grad(); loss.backward()
+    for pre, mod in (("unified_encoder.", enc), ("mask_head.", mh)):
+        for n, p in mod.named_parameters():
+            if p.grad is not None:
+                put(out, "grad/" + pre + n, p.grad, MAX_GRAD)
+    for i, f in enumerate(feats["voxel"]):
+        put(out, f"grad_in/voxel/{i}", f.grad if f.grad is not None else torch.zeros_like(f), MAX_GRAD)
+    put(out, "grad_in/mv", feats["mv"].grad, MAX_GRAD)
+    save(name, out)
+
+
+def memory_keep_draws(B, M, n_app, seed):
+    """Uniform draws behind the training-time memory-dropout masks of F14 (keep = draw > memory_dropout); one (application,
+    scene) row is forced below the threshold for every memory (-> the 'nothing kept keeps all' rule, query_encoder.py:147)."""
+    r = np.random.default_rng(seed)
+    u = r.random((n_app, B, M)).astype(np.float32)
+    u[0, 1, :] = 0.05
+    return torch.from_numpy(u)
+
+
+def run_memory_dropout_case(ref, name, *, B=3, Ns=60, Nq=11, d=64, H=4, L=2, p=0.6, memories=("voxel", "mv", "pc"),
+                            seed=0, data_seed=91):
+    """F14: training-mode memory dropout of the parallel cross-attention (query_encoder.py:145-151; stage 2 ships 0.6,
+    configs/unified_tasks_sceneverse.yaml:162) with the keep masks fixed from outside: torch.rand is patched for the
+    [B, M] draws the layers make, every nn.Dropout / attention-dropout probability is 0 so nothing else is random."""
+    torch.manual_seed(0)
+    enc = ref.qe.QueryMaskEncoder(None, memories=list(memories), memory_dropout=p, hidden_size=d, num_attention_heads=H,
+                                  num_layers=L, spatial_selfattn=True, structure="parallel")
+    sd = synth.fill_module(enc, seed)
+    enc.train()
+    for mod in enc.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    feats, pad, qpos, fpos, centers = encoder_level_inputs(B=B, Ns=Ns, Nq=Nq, d=d, memories=memories, n_scales=0,
+                                                           data_seed=data_seed)
+    input_dict = {"query": (torch.zeros(B, Nq, d), torch.zeros(B, Nq, dtype=torch.bool), qpos)}
+    for m in memories:
+        input_dict[m] = [feats[m], pad.clone(), fpos]
+    pl = ref.utils.calc_pairwise_locs(centers, None, pairwise_rel_type="center", spatial_dist_norm=True, spatial_dim=5)
+    draws = memory_keep_draws(B, len(memories), L, data_seed)
+    it = iter(draws)
+    orig = torch.rand
+
+    def fake_rand(*size, **kw):
+        if tuple(size) == (B, len(memories)):
+            return next(it)
+        return orig(*size, **kw)
+    torch.rand = fake_rand
+    try:
+        query, _, _ = enc(input_dict, pl, None)
+    finally:
+        torch.rand = orig
+    assert next(it, None) is None, "the reference did not draw one mask per layer"
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd)),
+           "meta/args": np.array(repr(dict(B=B, Ns=Ns, Nq=Nq, d=d, H=H, L=L, p=p, memories=list(memories), seed=seed,
+                                           data_seed=data_seed)))}
+    put(out, "query", query)
+    (query * loss_weight("query", query.shape)).mean().backward()
+    for n, q in enc.named_parameters():
+        if q.grad is not None:
+            put(out, "grad/" + n, q.grad, MAX_GRAD)
     save(name, out)
 
 
@@ -571,6 +701,15 @@ def main():
     run_train_case(ref, "F7_adamw_mask", B=2, Ns=96, Nq=12, d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask"],
                    spatial=True, structure="parallel", use_self_mask=False, foc=(0, 2), warmup_steps=0, total_steps=6)
     run_init_case(ref, "F16_init")
+    run_multiscale_case(ref, "F13_multiscale")
+    run_memory_dropout_case(ref, "F14_memory_dropout")
+    # F15: shipped widths (configs/instseg_sceneverse.yaml:95,121,130,140): d_in 128 (offline voxel) / 768 (mv, pc) != d,
+    # and d = 768 with 12 heads (d_h = 64)
+    run_model_case(ref, "F15_din", B=2, Ns=96, Nq=24, d=256, H=8, L=2, memories=["voxel", "mv", "pc"], heads=["mask"],
+                   spatial=True, structure="parallel", use_self_mask=True, foc=(0, 2),
+                   d_in={"voxel": 128, "mv": 768, "pc": 768})
+    run_model_case(ref, "F15_d768", B=2, Ns=64, Nq=10, d=768, H=12, L=1, memories=["mv", "pc"], heads=["ground"],
+                   spatial=True, structure="parallel")
 
 
 if __name__ == "__main__":

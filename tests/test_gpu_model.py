@@ -17,7 +17,7 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-MODEL_FIXTURES = [f for f in util.fixtures() if not f.startswith(("F3_", "F6_", "F7_", "F8_", "F9_", "F10_", "F11_", "F12_"))]
+MODEL_FIXTURES = util.model_fixtures()
 
 
 def to_dev(dd):

@@ -145,8 +145,8 @@ def test_multi_process_lr_schedule_matches_oracle(num_gpu):
     ddv = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in dd.items()}
     ts = TrainStep(model, lambda out: out["query_embeds"].mean(), lr=1e-3, grad_norm=None, sched="warmup_cosine",
                    warmup_steps=2, total_steps=40, num_gpu=num_gpu)
-    st = T.AdamWState()
     for s in range(9):
         ts.step(ddv)
-        want, _ = T.adamw_step({}, {}, st, lr=1e-3, sched="warmup_cosine", warmup_steps=2, total_steps=40, num_gpu=num_gpu)
+        # == adamw_step(..., num_gpu=num_gpu)'s learning rate for optimizer step s (oracle/train_oracle.py)
+        want = 1e-3 * T.lr_factor("warmup_cosine", s * num_gpu, 2 * num_gpu, 40)
         assert abs(float(ts.last_lr) - want) <= 1e-9 + 1e-6 * want, (s, float(ts.last_lr), want)

@@ -20,6 +20,11 @@ def fixtures(prefix=""):
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
 
 
+def model_fixtures():
+    """Fixtures made by make_golden.run_model_case (whole Query3DUnified forward/backward)."""
+    return [f for f in fixtures() if f.startswith(("F1_", "F2_", "F4_", "F4b_", "F5_", "F15_"))]
+
+
 def load_fixture(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     args = ast.literal_eval(str(z["meta/args"])) if "meta/args" in z else {}
@@ -62,12 +67,13 @@ def model_case(args, device="cpu"):
                                "skip_pred") if k in args}
     kw.setdefault("C", 21)
     d = args["d"]
-    cfg = make_cfg(d=d, H=args["H"], L=args["L"], memories=args["memories"], heads=args["heads"],
+    d_in = args.get("d_in") or {m: d for m in args["memories"]}
+    cfg = make_cfg(d=d, H=args["H"], L=args["L"], memories=args["memories"], heads=args["heads"], d_in=d_in,
                    spatial=args["spatial"], structure=args["structure"], ground_hidden=d // 2 * 3 // 3, **kw)
     model = Query3DUnified(cfg, compute="fp32")
     model.eval()  # the fixtures were generated in eval mode (drop_memories_test applies, dropout off)
     sd = synth.fill_module(model, args["seed"])
-    dd = synth.synth_data_dict(args["B"], args["Ns"], args["Nq"], {m: d for m in args["memories"]},
+    dd = synth.synth_data_dict(args["B"], args["Ns"], args["Nq"], d_in,
                                seed=args["data_seed"], memories=args["memories"],
                                query_valid_min=args.get("query_valid_min"), loc_dim=args.get("dim_loc", 3))
     if args.get("offline_attn"):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Print the measured parity errors of the HIP path (fp32 and bf16 compute) against the golden fixtures /
-the oracle for every model fixture.  Run on the GPU box; the output is committed under profiles/."""
+"""Measured parity of the HIP path (fp32 and bf16 compute modes) against the fp32 oracle for every model fixture and
+at the full BASELINE sizes (c2, c4 with live and with pinned self-masks).  Run on the GPU box; the output is committed
+under profiles/ (parity_rNN.txt, after the per-sublayer table of tools/sublayer_parity.py)."""
 import os
 import sys
 
@@ -17,44 +18,55 @@ def rel(a, b, floor=0.0):
     return float((a[fin] - b[fin]).abs().max() / max(float(b[fin].abs().max()), floor, 1e-6))
 
 
+def one(name, args, compute, dev="cuda"):
+    _cfg, model, sd, dd = util.model_case(args)
+    set_compute(model, compute)
+    model.to(dev)
+    out = model({k: v.to(dev) for k, v in dd.items()})
+    loss = util.synthetic_loss(out, args["heads"], out["query_embeds"])
+    grads = args.get("train_grads", True)
+    if grads:
+        loss.backward()
+    oout, collect, oloss, og = util.run_oracle(args, sd, dd, grads=grads)
+    q = rel(out["query_embeds"], collect[-1])
+    head = rel(out["ground_logits"], oout["ground_logits"]) if "ground" in args["heads"] else float("nan")
+    ml = fl = float("nan")
+    if "mask" in args["heads"]:
+        ml = max(rel(m, r) for m, r in zip(out["predictions_mask"], oout["predictions_mask"]))
+        fl = max(float(((m.detach().float().cpu() < 0) != (r < 0)).float().mean())
+                 for m, r in zip(out["predictions_mask"], oout["predictions_mask"]))
+        head = max(rel(c, r) for c, r in zip(out["predictions_class"], oout["predictions_class"]))
+    le = abs(loss.item() - oloss.item()) / max(1.0, abs(oloss.item()))
+    l2, l2n, cos = float("nan"), "", float("nan")
+    if grads:
+        g = dict(model.named_parameters())
+        # pairwise_loc_fc (the 5 -> H spatial-bias projection) is reported apart: its gradient is a sum of ~1e5 terms
+        # dS_ij / v_ij with v clamped near 1e-6 (transformers.py:226) that cancel to ~1e-3 of their magnitude, so ANY
+        # relative noise eps in the upstream gradient shows as ~1e3 eps there (fp32: 2e-3; bf16 gradients: tens of %)
+        names = [n for n in sorted(og) if "pairwise_loc_fc" not in n]
+        nmax = max(float(og[n].norm()) for n in names)
+        l2, l2n = max((float((g[n].grad.detach().float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * nmax)), n)
+                      for n in names)
+        a = torch.cat([g[n].grad.detach().float().cpu().flatten() for n in names]).double()
+        b = torch.cat([og[n].flatten() for n in names]).double()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        pl = [n for n in og if "pairwise_loc_fc" in n]
+        plw = max((float((g[n].grad.detach().float().cpu() - og[n]).norm() / float(og[n].norm())) for n in pl), default=float("nan"))
+        l2n = f"{l2n}   [pairwise_loc_fc worst relL2 {plw:.2e}]"
+    print(f"{name:22s} {compute:6s} {q:9.2e} {head:9.2e} {ml:10.2e} {fl:10.2e} {le:9.2e} {l2:11.2e} {1 - cos:10.2e}  {l2n}")
+
+
 def main():
-    dev = "cuda"
-    print(f"{'fixture':18s} {'compute':8s} {'vs':16s} {'query':>9s} {'head':>9s} {'mask-logit':>10s} {'flip-rate':>10s} "
-          f"{'loss':>9s} {'worst-grad':>10s}  worst-grad-name")
-    model_fixtures = [f for f in util.fixtures()
-                      if not f.startswith(("F3_", "F6_", "F7_", "F8_", "F9_", "F10_", "F11_", "F12_"))]
-    for name in model_fixtures:
-        z, args = util.load_fixture(name)
-        for compute, emu in (("fp32", None), ("bf16", torch.bfloat16), ("bf16", None)):
-            _cfg, model, sd, dd = util.model_case(args)
-            set_compute(model, compute)
-            model.to(dev)
-            out = model({k: v.to(dev) for k, v in dd.items()})
-            grads = any(k.startswith("grad/") for k in z.files)
-            loss = util.synthetic_loss(out, args["heads"], out["query_embeds"])
-            if grads:
-                loss.backward()
-            oout, collect, oloss, og = util.run_oracle(args, sd, dd, grads=grads, emulate=emu)
-            q = rel(out["query_embeds"], collect[-1])
-            head = rel(out["ground_logits"], oout["ground_logits"]) if "ground" in args["heads"] else float("nan")
-            ml = fl = float("nan")
-            if "mask" in args["heads"]:
-                ml = max(rel(m, r) for m, r in zip(out["predictions_mask"], oout["predictions_mask"]))
-                fl = max(float(((m.detach().float().cpu() < 0) != (r < 0)).float().mean())
-                         for m, r in zip(out["predictions_mask"], oout["predictions_mask"]))
-                head = max(rel(c, r) for c, r in zip(out["predictions_class"], oout["predictions_class"]))
-            le = abs(loss.item() - oloss.item()) / max(1.0, abs(oloss.item()))
-            wg, wn = float("nan"), ""
-            if grads:
-                gmax = max(float(v.abs().max()) for v in og.values())
-                g = dict(model.named_parameters())
-                wg, wn = max((rel(g[n].grad, og[n], floor=1e-2 * gmax), n) for n in og)
-                nmax = max(float(v.norm()) for v in og.values())
-                l2, l2n = max((float((g[n].grad.detach().float().cpu() - og[n]).norm()
-                                     / max(float(og[n].norm()), 1e-2 * nmax)), n) for n in og)
-                wn = f"{wn}  | worst relL2 {l2:.2e} {l2n}"
-            vs = "oracle fp32" if emu is None else "oracle bf16-round"
-            print(f"{name:18s} {compute:8s} {vs:16s} {q:9.2e} {head:9.2e} {ml:10.2e} {fl:10.2e} {le:9.2e} {wg:10.2e}  {wn}")
+    print(f"{'case':22s} {'mode':6s} {'query':>9s} {'head':>9s} {'mask-logit':>10s} {'flip-rate':>10s} {'loss':>9s} "
+          f"{'worst-relL2':>11s} {'1-cos(all)':>10s}  worst-gradient parameter     (all vs the fp32 oracle; max|err|/max|ref|)")
+    for name in util.model_fixtures():
+        _z, args = util.load_fixture(name)
+        for compute in ("fp32", "bf16"):
+            one(name, args, compute)
+    from tests.test_gpu_fullsize import C2, C4, C4_PINNED
+    for name, args in (("FULL c2", C2), ("FULL c4 live masks", C4), ("FULL c4 pinned masks", C4_PINNED)):
+        for compute in ("fp32", "bf16"):
+            one(name, args, compute)
 
 
 if __name__ == "__main__":
