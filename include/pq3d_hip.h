@@ -187,6 +187,10 @@ typedef struct {
 
 int pq3d_attn_fwd(const pq3d_attn_desc* d, void* stream);
 int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
+/* pq3d_attn_bwd picks between two implementations: the all-queries-resident single-pass backward (cross-attention shape:
+ * bf16, d_h 32 / 64, Lq <= 224, Lk >= 128, no additive bias) and the general two-kernel recompute backward.  This
+ * process-wide switch turns the first one off / on (default on) for A/B measurements and tests; returns the old value. */
+int pq3d_attn_resident(int enable);
 
 /* For every (b,i): row_open[b,i] = all_j(mask[b,i,j] != 0)   (query_encoder.py:83) */
 int pq3d_mask_row_all(const uint8_t* mask, uint8_t* row_open, int64_t rows, int64_t Lk, void* stream);

@@ -11,9 +11,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpq3d_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "loss.hip", "pointnet2.hip", "gemm128.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "loss.hip", "pointnet2.hip", "gemm128.hip", "attn_resident.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-Wno-unused-result"]
+# per-file extras.  attn_resident.hip: MFMA results feed the softmax VALU code directly; with the default AGPR form of the
+# MFMAs the compiler shuttles every S / dP tile through v_accvgpr_read / _write (352 extra VALU-slot moves per 4 query
+# pairs); the VGPR form removes them (gfx950 has one unified register file).
+EXTRA = {"attn_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale() -> bool:
@@ -33,7 +37,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src + ".o")
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:

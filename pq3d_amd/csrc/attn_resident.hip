@@ -1,0 +1,388 @@
+// All-queries-resident single-pass attention backward for the decoder's cross-attention shape: FEW queries (N_q <= 224),
+// MANY keys (N_seg in the thousands), small heads (d_h 32 / 64), bf16 operands.
+//
+// The two-kernel recompute backward of attention.hip forms S and dP twice (once per query chunk for dQ, once per key
+// chunk for dK/dV), stages K/V (or Q/dO) tiles through LDS behind a barrier per tile, and re-reads Q, K, V, dO in both
+// kernels (2.6x the algorithmic HBM traffic, MFMA busy < 10 %: profiles/rocprofv3_pmc_attention_r01_c2.txt).  Here one
+// workgroup owns ALL queries of a (scene, head[, key slice]):
+//   * Q and dO of the head (N_q x d_h each, 14 KB at config 2) are loaded ONCE into LDS and stay there, with
+//     delta = rowsum(dO * O) and the log-sum-exp row -- the main loop has no barrier and no LDS staging at all;
+//   * each wave walks 32-key groups with its K / V rows in registers (prefetched one group ahead), forms
+//     S = Q K^T and dP = dO V^T ONCE per (query tile, key tile), and from the same P / dS tiles accumulates
+//       dV^T += dO^T P      dK^T += Q^T dS       (registers: the wave owns its keys -> plain stores, no reduction)
+//       dQ   += dS K                             (fp32 LDS accumulator shared by the 4 waves: ds_add_f32)
+//     -- 5 products for 20 MFMAs per (32 queries x 32 keys), the algorithmic count;
+//   * dS reaches the dQ product through a wave-private [key][query] LDS scratch tile written with one 8-byte store per
+//     key tile and read back with the transposing LDS read, K^T likewise from a wave-private copy of the K tile;
+//   * key groups are dealt round-robin over (slice, wave), so the padded tail of a scene is spread evenly; fully padded
+//     groups cost one mask test.  Key slices (ksplit, a function of N_seg only) leave fp32 dQ partials that the existing
+//     combine kernel sums.
+// Same arithmetic as the two-kernel path (P from the saved log-sum-exp, dS = P (dP - delta) scale, bf16 operands, fp32
+// accumulation); dQ now sums its key contributions in a different (non-deterministic) order.
+#include "attn_common.h"
+
+namespace {
+
+constexpr int RW = 4;                 // waves per workgroup
+constexpr int GK = 32;                // keys per wave iteration (two 16-key MFMA tiles)
+
+template <int DH> struct RT {
+  typedef AT<bf16_t, DH> A;
+  static constexpr int LDR = A::LDR;          // row stride of the resident row-major Q / dO tiles (elements)
+  static constexpr int LDQ = DH + 1;          // row stride of the fp32 dQ accumulator (floats)
+  static constexpr int LDS2 = 16 + 4;         // row stride of the [key][query] dS scratch (elements)
+  static constexpr int KT_ELEMS = GK * A::LDR;
+  static constexpr int SC_ELEMS = 4 * GK * LDS2;   // one scratch tile per query tile of a pair, two pairs in flight
+  static constexpr int MLD = GK + 8;          // row stride of the staged 3-D mask tile [32 queries][32 keys] (bytes)
+};
+
+typedef short v4i16r_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16r_t lds_v4i16r_t;
+// fragment (row r0 + li, k-slots 8 lg .. 8 lg + 7) of an operand stored [k][m] in LDS (gemm.hip's km_frag)
+PQ_DEV u32x4 kmajor_frag(const bf16_t* tile, int ld, int r0, int li, int lg) {
+  const bf16_t* p0 = tile + (8 * lg + (li >> 2)) * ld + r0 + 4 * (li & 3);
+  const v4i16r_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16r_t*)p0);
+  const v4i16r_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16r_t*)(p0 + 4 * ld));
+  const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
+  return (u32x4){lo.x, lo.y, hi.x, hi.y};
+}
+
+PQ_DEV void wave_lds_fence() {   // order this wave's LDS writes before its following LDS reads (other lanes' data)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int DH, int NQP, bool DROP, bool MASK3>
+__global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_attn_desc d) {
+  typedef AT<bf16_t, DH> A;
+  typedef RT<DH> R;
+  constexpr int NQ = NQP * 32;           // resident (padded) query rows
+  constexpr int NS = A::NS, MT = A::MT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* Qs = (bf16_t*)smem;                                  // [NQ][LDR]
+  bf16_t* dOs = Qs + NQ * R::LDR;                              // [NQ][LDR]
+  float* Ls = (float*)(dOs + NQ * R::LDR);                     // [NQ]  log2(e) * logsumexp (+inf past Lq)
+  float* Ds = Ls + NQ;                                         // [NQ]  delta
+  float* dQs = (float*)smem;                                   // [NQ][LDQ] fp32: end-of-kernel sum over the waves, OVER Qs / dOs
+  static_assert(NQ * R::LDQ * 4 <= 2 * NQ * R::LDR * 2, "the dQ reduction buffer must fit over the resident Q / dO tiles");
+  bf16_t* wv = (bf16_t*)(Ds + NQ);                             // per wave: K tile + dS scratch (+ mask tile)
+  constexpr int WV_ELEMS = R::KT_ELEMS + R::SC_ELEMS + (MASK3 ? (32 * R::MLD) / 2 : 0);
+  uint8_t* ros = (uint8_t*)(wv + RW * WV_ELEMS);               // [NQ] row-open flags (MASK3)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int KS = d.ksplit > 1 ? d.ksplit : 1;
+  const int split = blockIdx.x;
+  const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
+  const float sl2 = d.scale * 1.4426950408889634f;
+
+  // ---- resident tiles: Q, dO (zero past Lq), delta = rowsum(dO * O), log-sum-exp
+  {
+    const long qoff = (long)b * d.q_sb + (long)h * d.q_sh, ooff = (long)b * d.o_sb + (long)h * d.o_sh;
+    const long sbase = ((long)b * d.H + h) * d.Lq;
+    constexpr int CPR = A::CPR, TOTAL = NQ * CPR;
+#pragma unroll
+    for (int it = 0; it < (TOTAL + RW * 64 - 1) / (RW * 64); ++it) {
+      const int c = tid + it * RW * 64;
+      const int row = c / CPR, kc = c % CPR;
+      const bool ok = c < TOTAL && row < d.Lq;
+      const int gr = min(row, d.Lq - 1);
+      u32x4 q = *(const u32x4*)((const bf16_t*)d.q + qoff + (long)gr * d.q_sl + kc * 8);
+      u32x4 g = *(const u32x4*)((const bf16_t*)d.dout + ooff + (long)gr * d.o_sl + kc * 8);
+      const u32x4 o = *(const u32x4*)((const bf16_t*)d.o + ooff + (long)gr * d.o_sl + kc * 8);
+      if (!ok) { q = (u32x4){0, 0, 0, 0}; g = (u32x4){0, 0, 0, 0}; }
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s += __uint_as_float(g[j] << 16) * __uint_as_float(o[j] << 16);
+        s += __uint_as_float(g[j] & 0xffff0000u) * __uint_as_float(o[j] & 0xffff0000u);
+      }
+      // the CPR (4 or 8) chunks of a row sit in neighbouring lanes
+#pragma unroll
+      for (int o_ = 1; o_ < CPR; o_ <<= 1) s += __shfl_xor(s, o_, 64);
+      if (c < TOTAL) {
+        *(u32x4*)&Qs[row * R::LDR + kc * 8] = q;
+        *(u32x4*)&dOs[row * R::LDR + kc * 8] = g;
+        if (kc == 0) {
+          Ds[row] = ok ? s : 0.f;
+          Ls[row] = ok ? d.lse[sbase + row] * 1.4426950408889634f : INFINITY;
+          if (ok && split == 0) d.delta[sbase + row] = s;
+          if constexpr (MASK3) ros[row] = (ok && d.row_open) ? d.row_open[(long)bm * d.Lq + row] : 0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  bf16_t* Kt = wv + wave * WV_ELEMS;            // [GK][LDR]  this wave's K tile, row-major
+  bf16_t* sc = Kt + R::KT_ELEMS;                // [2][GK][LDS2] dS scratch, [key][query]
+  uint8_t* mt_ = (uint8_t*)(sc + R::SC_ELEMS);  // [32][MLD] staged 3-D mask bytes of (query pair, key group) (MASK3)
+
+  const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
+  const uint8_t* kpm = d.kpm ? d.kpm + (long)b * d.Lk : nullptr;
+  const int ngroups = (d.Lk + GK - 1) / GK;
+  DropState dst;
+  uint32_t drow0 = 0;
+  if constexpr (DROP) {
+    dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, d.Lk);
+    drow0 = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * d.Lq);
+  }
+
+  // group g of the scene goes to (slice, wave) = ((g / RW) % KS, g % RW): round-robin, the padded tail is spread evenly
+  auto group_of = [&](int it) { return (it * KS + split) * RW + wave; };
+  u32x4 kf[2][NS], vf[2][NS], kfn[2][NS], vfn[2][NS];
+  bool km[2], kmn[2];
+  // 3-D mask: the [32 queries x 32 keys] byte tile of a (query pair, key group) is exactly one 16-byte chunk per lane;
+  // it is requested one pair ahead of its use and parked in a wave-private LDS tile
+  u32x4 mreg = (u32x4){0, 0, 0, 0};
+  auto load_group = [&](int g, u32x4 (&kd)[2][NS], u32x4 (&vd)[2][NS], bool (&md)[2]) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = g * GK + kt * 16 + li;
+      const int ck = min(key, d.Lk - 1);
+      row_frags<bf16_t, DH>(kd[kt], d.k, koff + (long)ck * d.k_sl, lg);
+      row_frags<bf16_t, DH>(vd[kt], d.v, voff + (long)ck * d.v_sl, lg);
+      md[kt] = key < d.Lk ? (kpm ? kpm[key] != 0 : false) : true;
+    }
+  };
+  auto load_mask = [&](int g, int qp) {
+    if constexpr (MASK3) {
+      const int row = min(qp * 32 + (lane >> 1), d.Lq - 1), half = lane & 1;   // chunk: (query row, 16-key half)
+      const long kc = min((long)g * GK + half * 16, (long)d.Lk - 16);
+      mreg = *(const u32x4*)(d.mask + ((long)bm * d.Lq + row) * d.Lk + kc);
+    }
+  };
+
+  // dQ accumulators: C-layout tiles [query 4 lg + r][dh mt * 16 + li] of every query tile, summed over this wave's key
+  // groups in registers and over the 4 waves through LDS once at the end.  (An fp32 LDS accumulator shared by the waves
+  // -- ds_add_f32 per tile -- was measured first: LDS float atomics serialise per lane, ~1400 cycles per instruction,
+  // 189 us instead of 40 us at config 2.)
+  f32x4 accQ[NQP * 2][MT];
+#pragma unroll
+  for (int t = 0; t < NQP * 2; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) accQ[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int it = 0;
+  int g = group_of(0);
+  if (g < ngroups) { load_group(g, kf, vf, km); load_mask(g, 0); }
+  for (; g < ngroups; ++it) {
+    const int gn = group_of(it + 1);
+    // ---- this group's operands into place; next group's loads in flight
+    const bool all_masked = __all(km[0] && km[1]);
+    if (!all_masked) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          *(u32x4*)&Kt[(kt * 16 + li) * R::LDR + s * 32 + lg * 8] = km[kt] ? (u32x4){0, 0, 0, 0} : kf[kt][s];
+    }
+    // A padded key needs no per-score mask test: its K row is ZEROED here (so its scores are 0, P = exp2(-lse) is finite,
+    // and it adds nothing to dQ = dS K), and its dK / dV rows are replaced by zeros at the store.
+    u32x4 kcur[2][NS], vcur[2][NS];
+    bool kmc[2] = {km[0], km[1]};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        kcur[kt][s] = kmc[kt] ? (u32x4){0, 0, 0, 0} : kf[kt][s];
+        vcur[kt][s] = vf[kt][s];
+      }
+    if (gn < ngroups) load_group(gn, kf, vf, km);
+    const int nqp = (d.Lq + 31) / 32;
+    if (all_masked && gn < ngroups) load_mask(gn, 0);
+
+    f32x4 accK[2][MT], accV[2][MT];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { accK[kt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; accV[kt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    if (!all_masked) {
+      wave_lds_fence();
+      u32x4 ktf[MT][GK / 32];     // K as the B operand of dQ = dS K: column dh, k = keys
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) ktf[mt][0] = kmajor_frag(Kt, R::LDR, mt * 16, li, lg);
+#pragma unroll
+      for (int qp = 0; qp < NQP; ++qp) {
+        if (qp >= nqp) break;
+        if constexpr (MASK3) {   // park this pair's mask tile, request the next one (next pair, or pair 0 of the next group)
+          *(u32x4*)&mt_[(lane >> 1) * R::MLD + (lane & 1) * 16] = mreg;
+          if (qp + 1 < nqp) load_mask(g, qp + 1);
+          else if (gn < ngroups) load_mask(gn, 0);
+          wave_lds_fence();
+        }
+        float pt[2][2][4], ds[2][2][4];   // [kt][qt][r]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const int q0 = qp * 32 + qt * 16;
+          u32x4 qa[NS], ga[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            qa[s] = rfrag<bf16_t>(&Qs[(q0 + li) * R::LDR], s, lg);
+            ga[s] = rfrag<bf16_t>(&dOs[(q0 + li) * R::LDR], s, lg);
+          }
+          const f32x4 Lr = *(const f32x4*)&Ls[q0 + 4 * lg], Dr = *(const f32x4*)&Ds[q0 + 4 * lg];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              Mma<bf16_t>::mma(sv, qa[s], kcur[kt][s]);
+              Mma<bf16_t>::mma(dp, ga[s], vcur[kt][s]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ql = q0 + 4 * lg + r;
+              float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sl2, -Lr[r]));   // P from the saved log-sum-exp
+              if constexpr (MASK3) {
+                const bool masked = (!ros[ql]) && (mt_[(qt * 16 + 4 * lg + r) * R::MLD + kt * 16 + li] != 0);
+                p = masked ? 0.f : p;
+              }
+              if constexpr (DROP) {
+                const float kc = drop_keep(dst, drow0 + (uint32_t)min(ql, d.Lq - 1), (uint32_t)min(g * GK + kt * 16 + li, d.Lk - 1)) ? dst.scale : 0.f;
+                pt[kt][qt][r] = p * kc;
+                ds[kt][qt][r] = p * (dp[r] * kc - Dr[r]);
+              } else {
+                pt[kt][qt][r] = p;
+                ds[kt][qt][r] = p * (dp[r] - Dr[r]);     // the 1/sqrt(d_h) factor of dS is applied to dK / dQ at the end
+              }
+            }
+          }
+        }
+        // ---- dV^T += dO^T P, dK^T += Q^T dS (contraction over the pair's 32 queries)
+        u32x4 pf[2][1], dsf[2][1];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { PackP<bf16_t, 2>::run(pt[kt], pf[kt]); PackP<bf16_t, 2>::run(ds[kt], dsf[kt]); }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const u32x4 gT = tfrag_tr(dOs, R::LDR, qp * 32, mt * 16, li, lg);
+          const u32x4 qT = tfrag_tr(Qs, R::LDR, qp * 32, mt * 16, li, lg);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            Mma<bf16_t>::mma(accV[kt][mt], gT, pf[kt][0]);
+            Mma<bf16_t>::mma(accK[kt][mt], qT, dsf[kt][0]);
+          }
+        }
+        // ---- dQ += dS K: dS through the [key][query] scratch (8-byte stores, transposing reads)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          bf16_t* st = sc + ((qp & 1) * 2 + qt) * GK * R::LDS2;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+            *(u32x2*)&st[(kt * 16 + li) * R::LDS2 + 4 * lg] =
+                (u32x2){pack_bf2(ds[kt][qt][0], ds[kt][qt][1]), pack_bf2(ds[kt][qt][2], ds[kt][qt][3])};
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const u32x4 dsA = kmajor_frag(sc + ((qp & 1) * 2 + qt) * GK * R::LDS2, R::LDS2, 0, li, lg);   // row = query li, k = keys
+          const int q0 = qp * 32 + qt * 16;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) Mma<bf16_t>::mma(accQ[qp * 2 + qt][mt], dsA, ktf[mt][0]);
+          (void)q0;
+        }
+      }
+      wave_lds_fence();   // the next group overwrites the K tile / scratch
+    }
+    // ---- dK, dV of this group: C-layout [dh 4 lg + r][key li] -> 4 consecutive channels of one key per lane
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = g * GK + kt * 16 + li;
+      if (key < d.Lk) {
+        const long ko = (long)b * d.k_sb + (long)key * d.k_sl + (long)h * d.k_sh;
+        const long vo = (long)b * d.v_sb + (long)key * d.v_sl + (long)h * d.v_sh;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float ks_ = kmc[kt] ? 0.f : d.scale, vs_ = kmc[kt] ? 0.f : 1.f;   // padded keys: exact zeros
+          *(u32x2*)((bf16_t*)d.dk + ko + mt * 16 + 4 * lg) =
+              (u32x2){pack_bf2(accK[kt][mt][0] * ks_, accK[kt][mt][1] * ks_), pack_bf2(accK[kt][mt][2] * ks_, accK[kt][mt][3] * ks_)};
+          *(u32x2*)((bf16_t*)d.dv + vo + mt * 16 + 4 * lg) =
+              (u32x2){pack_bf2(accV[kt][mt][0] * vs_, accV[kt][mt][1] * vs_), pack_bf2(accV[kt][mt][2] * vs_, accV[kt][mt][3] * vs_)};
+        }
+      }
+    }
+    g = gn;
+  }
+
+  // ---- dQ: sum of the 4 waves' register accumulators through LDS (one wave at a time: no atomics), then out
+  __syncthreads();   // every wave is done with the resident Q / dO tiles: the reduction buffer overlays them
+  for (int w = 0; w < RW; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NQP * 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* p = &dQs[(t * 16 + 4 * lg + r) * R::LDQ + mt * 16 + li];
+            *p = (w == 0 ? 0.f : *p) + accQ[t][mt][r] * d.scale;
+          }
+    }
+    __syncthreads();
+  }
+  const long rows = (long)d.B * d.H * d.Lq;
+  for (int i = tid; i < d.Lq * (DH / 4); i += RW * 64) {
+    const int q = i / (DH / 4), c0 = (i % (DH / 4)) * 4;
+    const float* a = &dQs[q * R::LDQ + c0];
+    if (KS == 1) {
+      const long off = (long)b * d.q_sb + (long)q * d.q_sl + (long)h * d.q_sh + c0;
+      *(u32x2*)((bf16_t*)d.dq + off) = (u32x2){pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+    } else {
+      float* po = d.ws + ((((long)split * d.B + b) * d.H + h) * d.Lq + q) * DH + c0;
+      *(float4*)po = make_float4(a[0], a[1], a[2], a[3]);
+    }
+  }
+  (void)rows;
+}
+
+template <int DH, int NQP> size_t resident_lds(bool mask3) {
+  typedef RT<DH> R;
+  const size_t nq = NQP * 32;
+  size_t b = 2 * nq * R::LDR * 2 + 2 * nq * 4;
+  b += (size_t)RW * (R::KT_ELEMS + R::SC_ELEMS) * 2 + (mask3 ? (size_t)RW * 32 * R::MLD : 0);
+  return b + nq + 16;
+}
+
+template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_attn_desc& d, hipStream_t s) {
+  const int KS = d.ksplit > 1 ? d.ksplit : 1;
+  const size_t lds = resident_lds<DH, NQP>(MASK3);
+  auto kern = attn_bwd_resident_kernel<DH, NQP, DROP, MASK3>;
+  static bool attr_done = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel instantiation
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(KS, d.H, d.B), dim3(RW * 64), lds, s, d);
+}
+
+template <int DH, int NQP> void launch_res_flags(const pq3d_attn_desc& d, hipStream_t s) {
+  const bool dr = d.drop.p > 0.f && d.drop.seed, m3 = d.mask != nullptr;
+  if (dr) { if (m3) launch_res<DH, NQP, true, true>(d, s); else launch_res<DH, NQP, true, false>(d, s); }
+  else { if (m3) launch_res<DH, NQP, false, true>(d, s); else launch_res<DH, NQP, false, false>(d, s); }
+}
+
+template <int DH> bool launch_res_dh(const pq3d_attn_desc& d, hipStream_t s) {
+  const int nqp = (d.Lq + 31) / 32;
+  // more than 128 queries (config 4: 200) would need 112+ accumulator registers per lane for dQ: two-kernel path
+  if (nqp <= 2) launch_res_flags<DH, 2>(d, s);
+  else if (nqp <= 4) launch_res_flags<DH, 4>(d, s);
+  else return false;
+  return true;
+}
+
+}  // namespace
+
+// Runs the all-queries-resident backward when the call has its shape (bf16, d_h 32 / 64, no additive bias, N_q <= 224,
+// enough keys to be worth it); returns false for everything else (attention.hip's two-kernel path).  The caller launches
+// the dQ combine kernel for ksplit > 1 exactly as for the two-kernel path.
+bool pq3d_attn_bwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
+  if (d.ct != PQ3D_BF16 || d.bias || d.dbias) return false;
+  if (d.dh != 32 && d.dh != 64) return false;
+  if (d.Lq > 128 || d.Lk < 128) return false;
+  if (d.mask && ((d.Lk & 15) != 0 || (((uintptr_t)d.mask) & 15) != 0)) return false;
+  if (d.dh == 32) return launch_res_dh<32>(d, s);
+  return launch_res_dh<64>(d, s);
+}

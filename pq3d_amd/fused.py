@@ -210,7 +210,7 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
 def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None, bias=None, mask_bmod=0, bwd=None,
           drop=None, drop_bmod=0):
     d = ops._attn_desc(q, k, v, o, lse, H, ct, zero_attn, 1.0 / math.sqrt(q.shape[-1] // H), kpm, mask, row_open, bias,
-                       drop, drop_bmod)
+                       drop, drop_bmod, bwd=bwd is not None)
     d.mask_bmod = mask_bmod
     B, Lq, dm = q.shape
     Lk = k.shape[1]

@@ -331,7 +331,8 @@ def linear_group(xs, Ws, *, ct: int, out_dtype=torch.float32):
 _ATTN_KSPLIT = int(os.environ.get("PQ3D_ATTN_KSPLIT", "0"))   # experiments only; 0 = built-in rule
 
 
-def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, drop=None, drop_bmod=0) -> L.AttnDesc:
+def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, drop=None, drop_bmod=0,
+               bwd=False) -> L.AttnDesc:
     B, Lq, dm = q.shape
     Lk = k.shape[1]
     d = L.AttnDesc()
@@ -350,6 +351,12 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
     # (forward 70 -> 57 us, step 5.56 -> 5.43 ms); 8 only adds combine traffic.
     nkb = (Lk + 63) // 64
     ks = (_ATTN_KSPLIT or (1 if nkb < 8 else 2 if nkb < 64 else 4)) if bias is None else 1
+    if bwd and not _ATTN_KSPLIT and ks > 1 and ct == BF16 and bias is None and Lq <= 128 and (dm // H) in (32, 64) and \
+            B * H >= 320:
+        # the all-queries-resident backward (attn_resident.hip) runs one workgroup per (scene, head, slice): once the
+        # stacked batch alone fills the chip (config 5: 48 x 8) a second slice only adds dQ partials (85 -> 75 us).
+        # Gradients are summed with atomics downstream anyway, so this may depend on the batch; the forward's may not.
+        ks = 1
     if ks > 1:
         ws = _empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
         d.ksplit, d.ws = ks, L.ptr(ws)
@@ -383,7 +390,7 @@ class _Attention(Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty_like(lse)
         dbias = torch.empty_like(bias) if (bias is not None and ctx.needs_input_grad[3]) else None
-        d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, ctx.drop)
+        d = _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, ctx.drop, bwd=True)
         d.dout, d.dq, d.dk, d.dv, d.delta, d.dbias = map(L.ptr, (do, dq, dk, dv, delta, dbias))
         B, Lq, dm = q.shape
         Lk = k.shape[1]

@@ -709,7 +709,8 @@ def main():
                    spatial=True, structure="parallel", use_self_mask=True, foc=(0, 2),
                    d_in={"voxel": 128, "mv": 768, "pc": 768})
     run_model_case(ref, "F15_d768", B=2, Ns=64, Nq=10, d=768, H=12, L=1, memories=["mv", "pc"], heads=["ground"],
-                   spatial=True, structure="parallel")
+                   spatial=True, structure="parallel", data_seed=4321)   # (seed 1234 puts one FFN pre-activation within
+    # 1e-7 of the ReLU kink: the exact-f32 MFMA sums in another order than torch's CPU GEMM and lands on the other side)
 
 
 if __name__ == "__main__":

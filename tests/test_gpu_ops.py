@@ -383,3 +383,55 @@ def test_upsample_scatter_mean_skips_out_of_range_rows():
     g = torch.zeros(6, 8, device=DEV)
     g[0] = 0.5; g[5] = 0.5; g[2] = 1.0
     assert torch.allclose(src.grad, g, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- resident backward
+def _relL2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+@pytest.mark.parametrize("H,dh", [(8, 32), (2, 64)])
+@pytest.mark.parametrize("Lq,Lk,mode,B", [(100, 1024, "kpm", 3), (100, 1024, "mask3d", 2), (200, 4096, "mask3d", 2),
+                                          (64, 256, "mask3d", 2), (224, 512, "kpm", 2), (7, 160, "kpm", 2),
+                                          (33, 2048, "kpm", 2)])
+def test_attention_backward_resident_path(H, dh, Lq, Lk, mode, B):
+    """The all-queries-resident single-pass backward (attn_resident.hip; cross-attention shape) against an fp64 reference
+    -- relative L2 <= 2e-2 per gradient (bf16 operands) -- and against the general two-kernel backward on the same inputs
+    (same arithmetic: they may differ by bf16 rounding of dS only)."""
+    d = H * dh
+    q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
+    g = torch.Generator().manual_seed(Lq * Lk + H)
+    vl = torch.tensor([Lk] + [max(1, (Lk * (3 + i)) // 7) for i in range(B - 1)])
+    kpm = torch.arange(Lk)[None, :] >= vl[:, None]
+    mask = row_open = None
+    if mode == "mask3d":
+        mask = torch.rand(B, Lq, Lk, generator=g) < 0.6
+        mask[:, 1, :] = True
+        row_open = mask.all(-1)
+        kpm = None
+    todev = lambda t: None if t is None else t.to(DEV)
+    go = rnd(B, Lq, d, seed=7)
+    res = {}
+    lib = L.lib()
+    for resident in (1, 0):
+        old = lib.pq3d_attn_resident(resident)
+        try:
+            qd, kd, vd = (t.to(DEV).bfloat16().requires_grad_(True) for t in (q, k, v))
+            o = ops.attention(qd, kd, vd, H=H, ct=BF16, zero_attn=True, kpm=todev(kpm), mask=todev(mask),
+                              row_open=todev(row_open))
+            o.backward(go.to(DEV).bfloat16())
+            res[resident] = (qd.grad, kd.grad, vd.grad)
+        finally:
+            lib.pq3d_attn_resident(old)
+    qr, kr, vr = (t.bfloat16().double().requires_grad_(True) for t in (q, k, v))
+    orf = attn_ref(qr, kr, vr, H, 1 / math.sqrt(dh), True, kpm, mask, row_open, None)
+    orf.backward(go.bfloat16().double())
+    for name, a, a_old, r in zip(("dq", "dk", "dv"), res[1], res[0], (qr.grad, kr.grad, vr.grad)):
+        assert torch.isfinite(a.float()).all(), name
+        assert _relL2(a, r) <= 2e-2, f"{name}: resident vs fp64 relL2 {_relL2(a, r):.2e}"
+        assert _relL2(a_old, r) <= 2e-2, f"{name}: two-kernel vs fp64 relL2 {_relL2(a_old, r):.2e}"
+        assert _relL2(a, a_old) <= 1e-2, f"{name}: resident vs two-kernel relL2 {_relL2(a, a_old):.2e}"
+    if kpm is not None:   # gradients of padded keys are exactly zero
+        pad = kpm.to(DEV)
+        assert float(res[1][1].float()[pad].abs().max()) == 0.0 and float(res[1][2].float()[pad].abs().max()) == 0.0
