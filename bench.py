@@ -76,7 +76,8 @@ def build(c, compute, device, seed):
 
 
 def loss_fn(out, heads):
-    loss = out["query_embeds"].mean() if "query_embeds" in out else out["query"].mean()
+    from pq3d_amd import ops
+    loss = ops.mean_all(out["query_embeds"] if "query_embeds" in out else out["query"])   # mean(query)
     if "generation" in heads:   # generation_loss: token cross-entropy of the teacher-forced logits
         lg = out["generation_logits"]
         loss = loss + torch.nn.functional.cross_entropy(lg.flatten(0, 1).float(), out["generation_label"].flatten())
@@ -189,6 +190,7 @@ def main():
 
     def fwd_bwd():
         model.zero_grad(set_to_none=True)
+        enc.grad_arena_dirty = False   # one backward per step writes the shared gradient arena (fused.py checks)
         out = model(dict(dd))
         loss_fn(out, c["heads"]).backward()
         reducer.pack()

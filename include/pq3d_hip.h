@@ -187,10 +187,34 @@ typedef struct {
 
 int pq3d_attn_fwd(const pq3d_attn_desc* d, void* stream);
 int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
-/* pq3d_attn_bwd picks between two implementations: the all-queries-resident single-pass backward (cross-attention shape:
- * bf16, d_h 32 / 64, Lq <= 224, Lk >= 128, no additive bias) and the general two-kernel recompute backward.  This
- * process-wide switch turns the first one off / on (default on) for A/B measurements and tests; returns the old value. */
+/* pq3d_attn_fwd / pq3d_attn_bwd pick specialised implementations where the call has their shape, and the general
+ * streaming kernels otherwise:
+ *   bit 0: the all-queries-resident single-pass backward (cross-attention shape: bf16, d_h 32 / 64, Lq <= 128,
+ *          Lk >= 128, no additive bias);
+ *   bit 1: the small-sequence fp32 kernels (self-attention shape: fp32, Lq, Lk <= 128, key padding / additive bias only,
+ *          one workgroup per (scene, head)).
+ * This process-wide switch sets which of them may be used (default 3 = both; for A/B measurements and tests) and returns
+ * the previous value. */
 int pq3d_attn_resident(int enable);
+
+/* Small glue operations of the step, each ONE launch (they replace chains of framework elementwise / cat / reduce kernels
+ * inside the captured step):
+ *   pq3d_mask_not      : dst_g[i] = !src_g[i] for up to PQ3D_MAX_GROUPS byte masks of individual lengths (data_dict's
+ *                        'True = valid' pad masks -> PyTorch's 'True = ignore', query3d_unified.py:113,139,143,148,155)
+ *   pq3d_zero_many     : zero-fill n fp32 buffers (gradient arena, atomics targets)
+ *   pq3d_sum_n         : out = sum_g src_g, fixed order (d query_pos over the layers)
+ *   pq3d_mean_all      : out[0] = mean(x) by one workgroup (deterministic); pq3d_fill_scaled: dst[i] = scalar[0] * c
+ *                        (its gradient) -- the synthetic 'mean(query)' loss of SURVEY 8d
+ *   pq3d_cast_transpose: src_g [rows, cols] fp32 -> out_g bf16 (same layout) and outT_g bf16 with every cols x cols row
+ *                        block transposed (outT[t][k][n] = src[t cols + n][k]): the K/V projection weights once per step
+ *                        for the forward (NT) and the input-gradient (NT on W^T) products */
+int pq3d_mask_not(const uint8_t* const* src, uint8_t* const* dst, const int64_t* counts, int32_t groups, void* stream);
+int pq3d_zero_many(float* const* bufs, const int64_t* counts, int32_t n, void* stream);
+int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_t count, void* stream);
+int pq3d_mean_all(const float* x, int64_t n, float* out, void* stream);
+int pq3d_fill_scaled(float* dst, int64_t n, const float* scalar, float c, void* stream);
+int pq3d_cast_transpose(const float* const* src, void* const* out, void* const* outT, int32_t groups, int32_t rows,
+                        int32_t cols, void* stream);
 
 /* For every (b,i): row_open[b,i] = all_j(mask[b,i,j] != 0)   (query_encoder.py:83) */
 int pq3d_mask_row_all(const uint8_t* mask, uint8_t* row_open, int64_t rows, int64_t Lk, void* stream);

@@ -24,8 +24,15 @@ extern "C" int pq3d_attn_debug_read(long long* out) { return (int)hipMemcpyFromS
 #include "attn_common.h"
 
 bool pq3d_attn_bwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // attn_resident.hip
-static int g_resident = 1;
-extern "C" int pq3d_attn_resident(int enable) { const int old = g_resident; g_resident = enable ? 1 : 0; return old; }
+bool pq3d_attn_small_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);   // attn_small.hip
+static int g_resident = 1, g_small = 1;
+// bit 0: all-queries-resident backward, bit 1: small-sequence fp32 kernels (both on by default)
+extern "C" int pq3d_attn_resident(int enable) {
+  const int old = g_resident | (g_small << 1);
+  g_resident = enable & 1;
+  g_small = (enable >> 1) & 1;
+  return old;
+}
 
 namespace {
 
@@ -809,6 +816,7 @@ extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
   if (int e = check_desc(d)) return e;
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (g_small && pq3d_attn_small_try(d, s, false)) { PQ_LAUNCH_CHECK(); return 0; }
   DISPATCH(launch_fwd)
 }
 
@@ -820,6 +828,7 @@ extern "C" int pq3d_attn_bwd(const pq3d_attn_desc* dp, void* stream) {
   PQ_CHECK_ARG((((uintptr_t)d.dout) & 15) == 0, "pq3d_attn_bwd: dout must be 16-byte aligned");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (g_small && pq3d_attn_small_try(d, s, true)) { PQ_LAUNCH_CHECK(); return 0; }
   DISPATCH(launch_bwd)
 }
 

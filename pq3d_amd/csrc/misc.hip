@@ -364,6 +364,147 @@ int pq3d_zero_launch(const ZeroList& z, hipStream_t s) {
   return 0;
 }
 
+
+// ---- small glue ops that used to be at::native launches inside the captured step (~17 of them) ----------
+namespace {
+struct NotPtrs { const uint8_t* src[PQ3D_MAX_GROUPS]; uint8_t* dst[PQ3D_MAX_GROUPS]; long n[PQ3D_MAX_GROUPS]; };
+// dst_g[i] = !src_g[i] for up to PQ3D_MAX_GROUPS byte masks of different lengths in one launch ('True = valid' pad masks of
+// data_dict -> PyTorch's 'True = ignore', query3d_unified.py:113,139,143,148,155)
+__global__ void mask_not_kernel(const NotPtrs p) {
+  const uint8_t* s = p.src[blockIdx.y];
+  uint8_t* d = p.dst[blockIdx.y];
+  const long n = p.n[blockIdx.y];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = s[i] ? 0 : 1;
+}
+
+struct SumPtrs { const float* src[PQ3D_MAX_GROUPS]; };
+__global__ void sum_n_kernel(const SumPtrs p, int n, float* out, long cnt) {   // out = sum_g src_g (fixed order)
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < cnt; i += (long)gridDim.x * blockDim.x * 4) {
+    float4 a = *(const float4*)(p.src[0] + i);
+    for (int g = 1; g < n; ++g) {
+      const float4 b = *(const float4*)(p.src[g] + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *(float4*)(out + i) = a;
+  }
+}
+
+// mean of all elements by ONE workgroup (deterministic; the tensors this is used on are a few 1e5 elements)
+__global__ __launch_bounds__(1024) void mean_all_kernel(const float* x, long n, float* out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) s += x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    out[0] = t / (float)n;
+  }
+}
+__global__ void fill_scaled_kernel(float* dst, long n, const float* scalar, float c) {   // dst[i] = scalar[0] * c
+  const float v = scalar[0] * c;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+struct CastTPtrs { const float* src[PQ3D_MAX_GROUPS]; bf16_t* out[PQ3D_MAX_GROUPS]; bf16_t* outT[PQ3D_MAX_GROUPS]; };
+// src_g [rows, cols] fp32 -> out_g [rows, cols] bf16 AND outT_g = per (cols x cols) row block transposed:
+// outT[t][k][n] = src[t * cols + n][k]  (rows = T * cols).  32 x 32 tiles through LDS: both writes are coalesced.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const CastTPtrs p, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const float* src = p.src[blockIdx.z];
+  bf16_t* out = p.out[blockIdx.z];
+  bf16_t* outT = p.outT[blockIdx.z];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    const float v = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
+    tile[j][tx] = v;
+    if (r < rows && c < cols) out[(long)r * cols + c] = f2bf(v);
+  }
+  __syncthreads();
+  const int t = r0 / cols, n0 = r0 % cols;   // row block t, rows n0.. of it (cols % 32 == 0: a tile never straddles blocks)
+  for (int j = ty; j < 32; j += 8) {
+    const int k = c0 + j, n = n0 + tx;       // outT[t][k][n] = tile[n - n0][k - c0]
+    if (k < cols && r0 + tx < rows) outT[((long)t * cols + k) * cols + n] = f2bf(tile[tx][j]);
+  }
+}
+}  // namespace
+
+extern "C" int pq3d_mask_not(const uint8_t* const* src, uint8_t* const* dst, const int64_t* counts, int32_t groups, void* stream) {
+  PQ_CHECK_ARG(src && dst && counts && groups >= 1 && groups <= PQ3D_MAX_GROUPS, "pq3d_mask_not: bad args");
+  NotPtrs p;
+  long mx = 0;
+  for (int g = 0; g < groups; ++g) {
+    PQ_CHECK_ARG(src[g] && dst[g] && counts[g] >= 0, "pq3d_mask_not: null pointer / negative count");
+    p.src[g] = src[g]; p.dst[g] = dst[g]; p.n[g] = (long)counts[g];
+    mx = counts[g] > mx ? (long)counts[g] : mx;
+  }
+  if (mx == 0) return 0;
+  hipLaunchKernelGGL(mask_not_kernel, dim3(grid1d(mx, 256, 256), groups), dim3(256), 0, (hipStream_t)stream, p);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_zero_many(float* const* bufs, const int64_t* counts, int32_t n, void* stream) {
+  PQ_CHECK_ARG(bufs && counts && n >= 0, "pq3d_zero_many: bad args");
+  ZeroList z;
+  for (int i = 0; i < n; ++i) {
+    PQ_CHECK_ARG(counts[i] == 0 || bufs[i], "pq3d_zero_many: null buffer");
+    z.add(bufs[i], (long)counts[i]);
+    if (z.full() || i + 1 == n) {
+      if (int e = pq3d_zero_launch(z, (hipStream_t)stream)) return e;
+      z.n = 0;
+    }
+  }
+  return 0;
+}
+
+extern "C" int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_t count, void* stream) {
+  PQ_CHECK_ARG(src && out && n >= 1 && n <= PQ3D_MAX_GROUPS && count >= 0 && (count % 4) == 0, "pq3d_sum_n: bad args (count % 4 == 0)");
+  SumPtrs p;
+  for (int g = 0; g < n; ++g) {
+    PQ_CHECK_ARG(src[g] && ((((uintptr_t)src[g]) & 15) == 0), "pq3d_sum_n: inputs must be 16-byte aligned");
+    p.src[g] = src[g];
+  }
+  PQ_CHECK_ARG((((uintptr_t)out) & 15) == 0, "pq3d_sum_n: out must be 16-byte aligned");
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(sum_n_kernel, dim3(grid1d(count / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream, p, n, out, (long)count);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_mean_all(const float* x, int64_t n, float* out, void* stream) {
+  PQ_CHECK_ARG(x && out && n >= 1, "pq3d_mean_all: bad args");
+  hipLaunchKernelGGL(mean_all_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)n, out);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_fill_scaled(float* dst, int64_t n, const float* scalar, float c, void* stream) {
+  PQ_CHECK_ARG(dst && scalar && n >= 0, "pq3d_fill_scaled: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_scaled_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, dst, (long)n, scalar, c);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_cast_transpose(const float* const* src, void* const* out, void* const* outT, int32_t groups, int32_t rows,
+                                   int32_t cols, void* stream) {
+  PQ_CHECK_ARG(src && out && outT && groups >= 1 && groups <= PQ3D_MAX_GROUPS, "pq3d_cast_transpose: bad args");
+  PQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 32 == 0 && rows % cols == 0, "pq3d_cast_transpose: cols % 32 == 0, rows % cols == 0");
+  CastTPtrs p;
+  for (int g = 0; g < groups; ++g) {
+    PQ_CHECK_ARG(src[g] && out[g] && outT[g], "pq3d_cast_transpose: null pointer");
+    p.src[g] = src[g]; p.out[g] = (bf16_t*)out[g]; p.outT[g] = (bf16_t*)outT[g];
+  }
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3(cols / 32, rows / 32, groups), dim3(256), 0, (hipStream_t)stream, p, rows, cols);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream) {
   PQ_CHECK_ARG(x && out && R >= 0 && N >= 1 && ld >= N, "pq3d_colsum: bad args");
   const void* xs[1] = {x};

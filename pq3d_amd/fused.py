@@ -273,15 +273,22 @@ class _FusedDecoder(Function):
         # bf16 path: the K/V rows of every in_proj_weight are rounded ONCE (one launch) instead of by each of the M/64 row
         # tiles that read them; with both operands in bf16 the projection takes the 128x128-tile kernel (gemm128.hip),
         # whose output is bit-identical to converting in flight
-        wkv = None
+        wkv = wkvT = None
         if kin2[0] is None and ct == BF16 and Ln * M <= MAXG and (2 * d * d) % 8 == 0:
             wkv = torch.empty(Ln, M, 2 * d, d, dtype=ad, device=dev)
             srcs = [ca.multihead_attn.in_proj_weight.detach()[d:] for i in range(Ln) for ca in cas[i]]
             outs = [wkv[i, j] for i in range(Ln) for j in range(M)]
             arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
-            L.check(L.lib().pq3d_add_cast(arr(srcs), arr([None] * len(srcs)), arr(outs), len(srcs), L.BF16, 2 * d * d,
-                                          L.stream()), "pq3d_add_cast")
-        ctx.wkv = wkv
+            if d % 32 == 0 and torch.is_grad_enabled():
+                # the same launch also leaves the transposed blocks [l, m, t][k_in][n_out] the backward's input-gradient
+                # products read (plain NT products on W^T: the 128x128-tile kernel's layout)
+                wkvT = torch.empty(Ln, M, 2, d, d, dtype=ad, device=dev)
+                L.check(L.lib().pq3d_cast_transpose(arr(srcs), arr(outs), arr([wkvT[i, j] for i in range(Ln) for j in range(M)]),
+                                                    len(srcs), 2 * d, d, L.stream()), "pq3d_cast_transpose")
+            else:
+                L.check(L.lib().pq3d_add_cast(arr(srcs), arr([None] * len(srcs)), arr(outs), len(srcs), L.BF16, 2 * d * d,
+                                              L.stream()), "pq3d_add_cast")
+        ctx.wkv, ctx.wkvT = wkv, wkvT
         A, A2, Bw, bs, Cs = [], [], [], [], []
         for i in range(Ln):
             for j, ca in enumerate(cas[i]):
@@ -466,15 +473,24 @@ class _FusedDecoder(Function):
         sizes = [p.numel() for p in params]
         ext = getattr(enc, "grad_arena", None)   # {id(param): (flat, offset, numel)} of a DP reducer's flat buffers
         gv = {}
+        n_app = len(tape)
+        # input gradients of the M-branch cross-attention LayerNorms are accumulated with atomics by the M branch blocks; that
+        # buffer and the gradient arena are zeroed by ONE launch for the whole backward
+        dxr_zero = torch.empty(n_app, B, Nq, d, dtype=torch.float32, device=dev) if M > 1 else None
         if ext is not None and all(id(p) in ext for p in params):
             # gradients go straight into the data-parallel flat buffer (zeroed here): no pack copy afterwards
-            for t in getattr(enc, "grad_arena_buffers", ()):
-                t.zero_()
+            if getattr(enc, "grad_arena_dirty", False):
+                raise RuntimeError("fused decoder: a second backward reached the shared gradient arena before its owner "
+                                   "consumed the first (gradient accumulation over micro-batches is not supported with "
+                                   "grad_arena: call the owner's zero / step between backwards, or remove enc.grad_arena)")
+            enc.grad_arena_dirty = True
+            ops.zero_many(list(getattr(enc, "grad_arena_buffers", ())) + [dxr_zero])
             for p in params:
                 flat, o_, n_ = ext[id(p)]
                 gv[id(p)] = flat[o_:o_ + n_].view(p.shape)
         else:
-            arena = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+            arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            ops.zero_many([arena, dxr_zero])
             off = 0
             for p, n in zip(params, sizes):
                 gv[id(p)] = arena[off:off + n].view(p.shape)
@@ -485,11 +501,7 @@ class _FusedDecoder(Function):
         sb_queue = []   # (W, b, d bias, dW, db) of every spatial self-attention application
         dx = dxf.contiguous().float() if dxf is not None else torch.zeros(B, Nq, d, device=dev)
         dqpos_parts: List[torch.Tensor] = []
-        n_app = len(tape)
         dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=ad, device=dev)
-        # input gradients of the M-branch cross-attention LayerNorms are accumulated with atomics by the M branch blocks:
-        # ONE zero-fill for all layer applications instead of one per LayerNorm backward call
-        dxr_zero = torch.zeros(n_app, B, Nq, d, dtype=torch.float32, device=dev) if M > 1 else None
         dkeys = None  # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
 
         def mh_backward(rec, dc, dm, dx_in):
@@ -673,7 +685,8 @@ class _FusedDecoder(Function):
         # memories then share launches (K-concatenation per memory, several outputs per launch)
         tposed = ctx.wkv is not None and dKV.dtype == torch.bfloat16
         if tposed:
-            wkvT = ctx.wkv.view(Ln, M, 2, d, d).transpose(-1, -2).contiguous()   # [l, m, t][k_in][n_out]
+            wkvT = ctx.wkvT if ctx.wkvT is not None else \
+                ctx.wkv.view(Ln, M, 2, d, d).transpose(-1, -2).contiguous()       # [l, m, t][k_in][n_out]
             Bkv = [wkvT[tape[a]["i"], j, t] for a in range(n_app) for j in range(M) for t in (0, 1)]
             kT = None
             if dkeys is not None:
@@ -762,7 +775,7 @@ class _FusedDecoder(Function):
                 dpos = nxt
         dqpos = None
         if ctx.needs_input_grad[2]:
-            dqpos = torch.stack(dqpos_parts, 0).sum(0) if len(dqpos_parts) > 1 else dqpos_parts[0]
+            dqpos = ops.sum_n(dqpos_parts)
         dwq.flush()
         for i0 in range(0, len(sb_queue), MAXG):
             chunk = sb_queue[i0:i0 + MAXG]

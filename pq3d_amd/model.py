@@ -164,16 +164,23 @@ class Query3DUnified(nn.Module):
         input_dict = {}
         if self.training:
             M.begin_dropout_step(self, data_dict["query_locs"].device)
-        mask = data_dict["query_pad_masks"].logical_not()
-        # the scene-memory pad masks ('True = valid' in data_dict) are inverted in ONE stacked op; the fused executor
-        # then takes the stack as the memories-stacked key-padding mask without another copy
+        # every pad mask ('True = valid' in data_dict) is inverted by ONE launch (ops.mask_not); equal-shape masks come back
+        # as views of one stacked buffer, which the fused executor takes as the memories-stacked key-padding mask
         scene = [m for m in self.inputs if m in ("mv", "pc", "voxel")]
         keys = [m + "_seg_pad_masks" for m in scene] + (["seg_pad_masks"] if hasattr(self, "mask_head") else [])
         inv = {}
-        if len(keys) > 1 and len({(tuple(data_dict[k].shape), data_dict[k].dtype) for k in keys}) == 1:
-            stacked = torch.stack([data_dict[k] for k in keys], 0).logical_not()
-            inv = {k: stacked[j] for j, k in enumerate(keys)}
-            input_dict["_stacked_scene_kpm"] = (stacked[:len(scene)], scene)
+        bool_ok = all(data_dict[k].dtype == torch.bool for k in keys + ["query_pad_masks"])
+        if bool_ok:
+            outs = ops.mask_not([data_dict[k] for k in keys] + [data_dict["query_pad_masks"]])
+            mask = outs[-1]
+            inv = dict(zip(keys, outs[:-1]))
+            if len(scene) > 1 and len({tuple(data_dict[m + "_seg_pad_masks"].shape) for m in scene}) == 1:
+                B_, Ns_ = data_dict[scene[0] + "_seg_pad_masks"].shape
+                stacked = outs[0].new_empty(0).set_(outs[0].untyped_storage(), outs[0].storage_offset(),
+                                                     (len(scene), B_, Ns_), (B_ * Ns_, Ns_, 1))
+                input_dict["_stacked_scene_kpm"] = (stacked, scene)
+        else:
+            mask = data_dict["query_pad_masks"].logical_not()
         query_locs = data_dict["query_locs"][:, :, :self.dim_loc]
         coord_min, coord_max = data_dict["coord_min"], data_dict["coord_max"]
         if self.dim_loc > 3:

@@ -194,6 +194,79 @@ def fourier(xyz: torch.Tensor, cmin: torch.Tensor, cmax: torch.Tensor, gauss_B: 
     return out
 
 
+def _parr(ts):
+    return (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
+
+
+def mask_not(masks: Sequence[torch.Tensor]) -> list:
+    """[~m for m in masks] in ONE launch (bool masks of any shapes): the 'True = valid' -> 'True = ignore' inversions
+    of Query3DUnified.forward (query3d_unified.py:113,139,143,148,155).  Equal-shape masks come back as views of one
+    stacked buffer (what the fused executor takes as the memories-stacked key-padding mask)."""
+    masks = [m.contiguous() for m in masks]
+    total = sum(m.numel() for m in masks)
+    buf = _empty(total, dtype=torch.bool, device=masks[0].device)
+    outs, off = [], 0
+    for m in masks:
+        outs.append(buf[off:off + m.numel()].view(m.shape))
+        off += m.numel()
+    cnt = (C.c_int64 * len(masks))(*[m.numel() for m in masks])
+    for s0 in range(0, len(masks), L.MAXG):
+        e = min(len(masks), s0 + L.MAXG)
+        L.check(L.lib().pq3d_mask_not(_parr(masks[s0:e]), _parr(outs[s0:e]), C.byref(cnt, 8 * s0), e - s0, L.stream()),
+                "pq3d_mask_not")
+    return outs
+
+
+def zero_many(tensors: Sequence[torch.Tensor]) -> None:
+    """Zero-fill several fp32 tensors with one launch (hipMemsetAsync nodes are not replay-safe on this stack: common.h)."""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    if not ts:
+        return
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+    cnt = (C.c_int64 * len(ts))(*[t.numel() for t in ts])
+    L.check(L.lib().pq3d_zero_many(_parr(ts), cnt, len(ts), L.stream()), "pq3d_zero_many")
+
+
+def sum_n(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    """sum of same-shape fp32 tensors in a fixed order, one launch (replaces torch.stack(..).sum(0): cat + reduce)."""
+    parts = [p.contiguous() for p in parts]
+    if len(parts) == 1:
+        return parts[0]
+    out = None
+    step = L.MAXG - 1
+    for s0 in range(0, len(parts), step):
+        chunk = ([out] if out is not None else []) + parts[s0:s0 + step]
+        new = torch.empty_like(parts[0])
+        L.check(L.lib().pq3d_sum_n(_parr(chunk), len(chunk), L.ptr(new), new.numel(), L.stream()), "pq3d_sum_n")
+        out = new
+    return out
+
+
+class _MeanAll(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x.float())
+        out = _empty(1, dtype=torch.float32, device=x.device)
+        L.check(L.lib().pq3d_mean_all(L.ptr(x), x.numel(), L.ptr(out), L.stream()), "pq3d_mean_all")
+        ctx.shape = x.shape
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        n = 1
+        for s_ in ctx.shape:
+            n *= s_
+        dx = _empty(ctx.shape, dtype=torch.float32, device=g.device)
+        gg = _c(g.float().reshape(1))
+        L.check(L.lib().pq3d_fill_scaled(L.ptr(dx), n, L.ptr(gg), 1.0 / n, L.stream()), "pq3d_fill_scaled")
+        return dx
+
+
+def mean_all(x: torch.Tensor) -> torch.Tensor:
+    """x.mean() as one deterministic launch forward, one fill backward (the synthetic 'mean(query)' loss)."""
+    return _MeanAll.apply(x)
+
+
 # ------------------------------------------------------------------------------------------------ linear
 class _Linear(Function):
     @staticmethod

@@ -82,6 +82,9 @@ class TrainStep:
     # -- pieces (each capturable) ---------------------------------------------------------------------------------
     def forward_backward(self, data_dict: dict) -> torch.Tensor:
         self.model.zero_grad(set_to_none=True)
+        enc = getattr(self.model, "unified_encoder", None)
+        if enc is not None:
+            enc.grad_arena_dirty = False      # this step owns the arena: one backward per step (fused.py raises otherwise)
         out = self.model(dict(data_dict))
         loss = self.loss_fn(out)
         loss.backward()

@@ -94,19 +94,22 @@ def test_fp32_encoder_structures(name):
             util.check_against(z, "grad/" + n, p.grad, atol=5e-6, rtol=5e-5, cap=util.MAX_GRAD)
 
 
-@pytest.mark.parametrize("name", ["F1_c1", "F4_c2_slice", "F5_dimloc6", "F2_c1_mask", "F4b_c4_slice"])
-def test_bf16_model_matches_rounding_oracle(name):
-    """bf16 MFMA operands, fp32 accumulate/softmax/LayerNorm, against the oracle run with the SAME operand rounding
-    points (oracle.operand_rounding(bf16)).  Measured (profiles/parity_r1.txt): outputs 2e-3..1.7e-2 of output
-    scale end to end (the two sides still round the softmax probabilities at different points, and ReLU / mask
-    thresholds amplify that through 2-4 layers), self-mask bit flips <= 3e-3, loss <= 6e-4.  Gradients are compared
-    in relative L2 norm per parameter: a flipped ReLU unit changes single rows of a weight gradient by O(1), which
-    a max-norm over 2048 units would report as ~30 %."""
+@pytest.mark.parametrize("name", ["F1_c1", "F4_c2_slice", "F5_dimloc6", "F2_c1_mask", "F4b_c4_slice", "F15_din", "F15_d768"])
+def test_bf16_model_matches_fp32_oracle(name):
+    """'bf16' mode end to end against the fp32 oracle (NOT an oracle with emulated rounding).  What is single-bf16 in
+    this mode is the K/V side of cross-attention (memory rows x weights, K / V / P / O storage): each of those rounding
+    sites alone moves the final query by ~2e-3 of its scale over 4 layers (layer 0 starts from a zero query, so
+    LayerNorm(0 + branch) turns the branch's relative error into the output's), together ~5e-3; everything on the query
+    side is fp32-grade (tests/test_gpu_sublayer_parity.py).  Measured over these fixtures (profiles/parity_r02.txt):
+    outputs 3e-3..1.6e-2, self-mask flips <= 2.6e-3, loss <= 1.7e-3, parameter-gradient vector 1 - cos <= 1.0e-2, worst
+    single parameter 0.16 relative L2 (forward noise crossing ReLU kinks / mask thresholds; the per-op backward error is
+    <= 2e-2, tests/test_gpu_ops.py, tests/test_gpu_sublayer_parity.py).  pairwise_loc_fc is excluded from the gradient
+    comparison: its gradient is a ~1e3:1 cancelling sum (see tools/parity_report.py)."""
     z, args = util.load_fixture(name)
     _cfg, model, sd, dd = util.model_case(args)
     set_compute(model, "bf16")
     out, loss, g = run_hip(model, args, dd)
-    oout, collect, oloss, og = util.run_oracle(args, sd, dd, emulate=torch.bfloat16)
+    oout, collect, oloss, og = util.run_oracle(args, sd, dd)
 
     def rel(a, b):
         a, b = a.detach().float().cpu(), b.detach().float().cpu()
@@ -122,14 +125,18 @@ def test_bf16_model_matches_rounding_oracle(name):
         for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
             assert rel(m, r) < 3e-2
             flips = max(flips, float(((m.detach().float().cpu() < 0) != (r < 0)).float().mean()))
-        assert flips < 1e-2, f"self-mask bit-flip rate vs rounding oracle {flips:.5f}"
+        assert flips < 1e-2, f"self-mask bit-flip rate vs the fp32 oracle {flips:.5f}"
         for c, r in zip(out["predictions_class"], oout["predictions_class"]):
             assert rel(c, r) < 3e-2
     assert abs(loss.item() - oloss.item()) < 3e-3 * max(1.0, abs(oloss.item()))
-    gmax = max(float(v.norm()) for v in og.values())
+    names = [n for n in og if "pairwise_loc_fc" not in n]
+    gmax = max(float(og[n].norm()) for n in names)
     worst = max((float((g[n].detach().float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * gmax)), n)
-                for n in og)
+                for n in names)
     assert worst[0] < 0.3, f"worst gradient (relative L2) {worst}"
+    a = torch.cat([g[n].detach().float().cpu().flatten() for n in sorted(names)]).double()
+    b = torch.cat([og[n].flatten() for n in sorted(names)]).double()
+    assert float((a * b).sum() / (a.norm() * b.norm())) >= 0.98
 
 
 def test_fused_path_is_taken_and_equals_modular_bf16():

@@ -415,7 +415,7 @@ def test_attention_backward_resident_path(H, dh, Lq, Lk, mode, B):
     res = {}
     lib = L.lib()
     for resident in (1, 0):
-        old = lib.pq3d_attn_resident(resident)
+        old = lib.pq3d_attn_resident(2 | resident)
         try:
             qd, kd, vd = (t.to(DEV).bfloat16().requires_grad_(True) for t in (q, k, v))
             o = ops.attention(qd, kd, vd, H=H, ct=BF16, zero_attn=True, kpm=todev(kpm), mask=todev(mask),
@@ -435,3 +435,38 @@ def test_attention_backward_resident_path(H, dh, Lq, Lk, mode, B):
     if kpm is not None:   # gradients of padded keys are exactly zero
         pad = kpm.to(DEV)
         assert float(res[1][1].float()[pad].abs().max()) == 0.0 and float(res[1][2].float()[pad].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("H,dh", [(4, 16), (8, 32), (2, 64)])
+@pytest.mark.parametrize("Lq,Lk,mode", [(100, 100, "bias"), (100, 100, "kpm"), (128, 128, "bias"), (16, 16, "kpm"), (1, 37, "bias"),
+                                        (77, 5, "kpm")])
+def test_attention_small_fp32_kernels(H, dh, Lq, Lk, mode):
+    """The one-workgroup-per-head fp32 kernels (attn_small.hip; the decoder's self-attention) against an fp64 reference and
+    against the general streaming kernels on the same inputs."""
+    B, d = 3, H * dh
+    q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
+    kpm = torch.arange(Lk)[None, :] >= torch.tensor([Lk, max(1, Lk // 2), max(1, Lk - 3)])[:, None]
+    bias = torch.randn(B, H, Lq, Lk, generator=torch.Generator().manual_seed(5)) if mode == "bias" else None
+    go = rnd(B, Lq, d, seed=7)
+    lib = L.lib()
+    res = {}
+    for small in (2, 0):
+        old = lib.pq3d_attn_resident(1 | small)
+        try:
+            qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+            bd = bias.to(DEV).requires_grad_(True) if bias is not None else None
+            o = ops.attention(qd, kd, vd, H=H, ct=F32, kpm=kpm.to(DEV), bias=bd)
+            o.backward(go.to(DEV))
+            res[small] = (o.detach(), qd.grad, kd.grad, vd.grad, bd.grad if bd is not None else None)
+        finally:
+            lib.pq3d_attn_resident(old)
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    br = bias.double().requires_grad_(True) if bias is not None else None
+    orf = attn_ref(qr, kr, vr, H, 1 / math.sqrt(dh), False, kpm, None, None, br)
+    orf.backward(go.double())
+    refs = (orf, qr.grad, kr.grad, vr.grad, br.grad if br is not None else None)
+    for name, a, a_old, r in zip(("o", "dq", "dk", "dv", "dbias"), res[2], res[0], refs):
+        if r is None:
+            continue
+        close(a, r, F32, name + " small-kernel vs fp64", atol=5e-5, rtol=5e-5)
+        close(a, a_old, F32, name + " small-kernel vs streaming", atol=5e-5, rtol=5e-5)
