@@ -203,7 +203,8 @@ int pq3d_attn_resident(int enable);
  *                        'True = valid' pad masks -> PyTorch's 'True = ignore', query3d_unified.py:113,139,143,148,155)
  *   pq3d_zero_many     : zero-fill n fp32 buffers (gradient arena, atomics targets)
  *   pq3d_sum_n         : out = sum_g src_g, fixed order (d query_pos over the layers)
- *   pq3d_mean_all      : out[0] = mean(x) by one workgroup (deterministic); pq3d_fill_scaled: dst[i] = scalar[0] * c
+ *   pq3d_mean_all      : out[0] = mean(x): per-block partial sums + last-arriver combine in block order (deterministic,
+ *                        one launch; ws = counter + partials, self-resetting); pq3d_fill_scaled: dst[i] = scalar[0] * c
  *                        (its gradient) -- the synthetic 'mean(query)' loss of SURVEY 8d
  *   pq3d_cast_transpose: src_g [rows, cols] fp32 -> out_g bf16 (same layout) and outT_g bf16 with every cols x cols row
  *                        block transposed (outT[t][k][n] = src[t cols + n][k]): the K/V projection weights once per step
@@ -211,7 +212,8 @@ int pq3d_attn_resident(int enable);
 int pq3d_mask_not(const uint8_t* const* src, uint8_t* const* dst, const int64_t* counts, int32_t groups, void* stream);
 int pq3d_zero_many(float* const* bufs, const int64_t* counts, int32_t n, void* stream);
 int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_t count, void* stream);
-int pq3d_mean_all(const float* x, int64_t n, float* out, void* stream);
+#define PQ3D_MEAN_MAX_BLOCKS 256   /* ws: fp32[1 + PQ3D_MEAN_MAX_BLOCKS], element 0 (the arrival counter) zero before first use */
+int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, void* stream);
 int pq3d_fill_scaled(float* dst, int64_t n, const float* scalar, float c, void* stream);
 int pq3d_cast_transpose(const float* const* src, void* const* out, void* const* outT, int32_t groups, int32_t rows,
                         int32_t cols, void* stream);

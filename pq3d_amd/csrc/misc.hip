@@ -389,18 +389,35 @@ __global__ void sum_n_kernel(const SumPtrs p, int n, float* out, long cnt) {   /
   }
 }
 
-// mean of all elements by ONE workgroup (deterministic; the tensors this is used on are a few 1e5 elements)
-__global__ __launch_bounds__(1024) void mean_all_kernel(const float* x, long n, float* out) {
-  __shared__ float red[16];
+// mean of all elements, one launch: every block reduces a slice (float4 loads, all in flight), publishes its partial sum,
+// and the block that arrives LAST (device-scope ticket) adds the partials in block order -> deterministic.  ws[0] is the
+// ticket counter (zero before the first use; the last block resets it), ws[1..] the partials.
+__global__ __launch_bounds__(256) void mean_all_kernel(const float* x, long n, float* out, float* ws) {
+  __shared__ float red[4];
+  __shared__ int last;
+  const long n4 = n >> 2;
   float s = 0.f;
-  for (long i = threadIdx.x; i < n; i += 1024) s += x[i];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = ((const float4*)x)[i];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) s += x[(n4 << 2) + threadIdx.x];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < 16; ++w) t += red[w];
-    out[0] = t / (float)n;
+    __hip_atomic_store(&ws[1 + blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add((unsigned*)ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == gridDim.x - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      float tot = 0.f;
+      for (unsigned b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(&ws[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[0] = tot / (float)n;
+      __hip_atomic_store((unsigned*)ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 __global__ void fill_scaled_kernel(float* dst, long n, const float* scalar, float c) {   // dst[i] = scalar[0] * c
@@ -476,9 +493,13 @@ extern "C" int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_
   return 0;
 }
 
-extern "C" int pq3d_mean_all(const float* x, int64_t n, float* out, void* stream) {
-  PQ_CHECK_ARG(x && out && n >= 1, "pq3d_mean_all: bad args");
-  hipLaunchKernelGGL(mean_all_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)n, out);
+extern "C" int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, void* stream) {
+  PQ_CHECK_ARG(x && out && ws && n >= 1, "pq3d_mean_all: bad args");
+  PQ_CHECK_ARG((((uintptr_t)x) & 15) == 0, "pq3d_mean_all: x must be 16-byte aligned");
+  long nb = (n / 4 + 255) / 256;
+  if (nb > PQ3D_MEAN_MAX_BLOCKS) nb = PQ3D_MEAN_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(mean_all_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long)n, out, ws);
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -279,7 +279,7 @@ class _FusedDecoder(Function):
             srcs = [ca.multihead_attn.in_proj_weight.detach()[d:] for i in range(Ln) for ca in cas[i]]
             outs = [wkv[i, j] for i in range(Ln) for j in range(M)]
             arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
-            if d % 32 == 0 and torch.is_grad_enabled():
+            if d % 32 == 0 and any(ctx.needs_input_grad):
                 # the same launch also leaves the transposed blocks [l, m, t][k_in][n_out] the backward's input-gradient
                 # products read (plain NT products on W^T: the 128x128-tile kernel's layout)
                 wkvT = torch.empty(Ln, M, 2, d, d, dtype=ad, device=dev)
@@ -731,7 +731,7 @@ class _FusedDecoder(Function):
                    ldc=d, kconcat=nv)
             for jb, o_ in zip(jobs, outs):
                 dfeats[jb[0]] = o_
-            dpos = Kp.sum(0)
+            dpos = ops.sum_n([Kp[j] for j in range(M)])
             want_dpos = False
         elif tposed and jobs and 0 < per <= MAXG and all(len(jb[1]) == per for jb in jobs):
             cap = max(1, MAXG // per)   # memories per launch

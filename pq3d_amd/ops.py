@@ -242,12 +242,18 @@ def sum_n(parts: Sequence[torch.Tensor]) -> torch.Tensor:
     return out
 
 
+_MEAN_WS = {}
+
+
 class _MeanAll(Function):
     @staticmethod
     def forward(ctx, x):
         x = _c(x.float())
         out = _empty(1, dtype=torch.float32, device=x.device)
-        L.check(L.lib().pq3d_mean_all(L.ptr(x), x.numel(), L.ptr(out), L.stream()), "pq3d_mean_all")
+        ws = _MEAN_WS.get(x.device)
+        if ws is None:     # arrival counter + per-block partials; the kernel leaves the counter at zero again
+            ws = _MEAN_WS[x.device] = torch.zeros(1 + 256, dtype=torch.float32, device=x.device)
+        L.check(L.lib().pq3d_mean_all(L.ptr(x), x.numel(), L.ptr(out), L.ptr(ws), L.stream()), "pq3d_mean_all")
         ctx.shape = x.shape
         return out.view(())
 

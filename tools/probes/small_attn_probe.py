@@ -16,8 +16,11 @@ torch.cuda.synchronize(); e0.record()
 for _ in range(50): fn()
 e1.record(); torch.cuda.synchronize()
 print("fwd us", e0.elapsed_time(e1) / 50 * 1e3)
-buf = (C.c_longlong * 16)()
-lib = C.CDLL(L.LIB_PATH)
-lib.pq3d_small_debug_read(buf)
-t = list(buf)[:6]
-print("stamps (cycles):", [t[i + 1] - t[i] for i in range(5)], "total", t[5] - t[0])
+do = torch.randn_like(o); dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+delta = torch.empty_like(lse); dsb = torch.empty_like(bias)
+bw = lambda: F._attn(q, k, v, o, lse, H, L.F32, False, kpm=kpm, bias=bias, bwd=(do, dq, dk, dv, delta, dsb))
+for _ in range(5): bw()
+torch.cuda.synchronize(); e0.record()
+for _ in range(50): bw()
+e1.record(); torch.cuda.synchronize()
+print("bwd us", e0.elapsed_time(e1) / 50 * 1e3)
