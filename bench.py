@@ -182,11 +182,17 @@ def main():
 
     set_dropout_mode(args.dropout)
     params = [p for p in model.parameters() if p.requires_grad]
-    reducer = FlatGradAllReducer(params)
-    # the fused decoder writes its parameter gradients straight into the reducer's flat buffer (no pack copy)
+    # two gradient buckets in the order they become final: [decoder (+ mask head): complete when the fused backward has
+    # flushed its weight gradients, 93 % of the bytes] and [encoders, heads: complete at the end of backward].  The fused
+    # decoder writes bucket 0 in place (no pack copy) and, in a data-parallel run, starts its all-reduce from inside the
+    # backward (enc.grads_ready) so that it overlaps the key/value input-gradient products and the encoders' backward.
     enc = model.unified_encoder
+    dec_ids = {id(p) for p in enc.parameters()} | ({id(p) for p in model.mask_head.parameters()} if hasattr(model, "mask_head") else set())
+    groups = [[p for p in params if id(p) in dec_ids], [p for p in params if id(p) not in dec_ids]]
+    reducer = FlatGradAllReducer(params, groups=[g for g in groups if g])
     enc.grad_arena = reducer.slots()
-    enc.grad_arena_buffers = reducer.flat
+    enc.grad_arena_buffers = [reducer.flat[0]]
+    overlap = world > 1 and os.environ.get("PQ3D_BENCH_OVERLAP", "1") != "0"
 
     one = torch.ones((), device=dev)
 
@@ -197,36 +203,63 @@ def main():
         loss_fn(out, c["heads"]).backward(gradient=one)   # cached seed gradient: no ones_like fill in the step
         reducer.pack()
 
+    def full_step():
+        """forward + backward with the bucket-0 all-reduce launched from inside the backward, then the rest + join."""
+        fwd_bwd()
+        reducer.finish()
+
     def capture():
-        """3 eager steps on a side stream (allocator + autograd warm-up), then capture one step as a HIP graph."""
+        """3 eager steps on a side stream (allocator + autograd warm-up), then capture one step as a HIP graph.
+        Returns (graph or None, mode).  Data-parallel runs first try to capture the WHOLE step including the RCCL
+        all-reduces (bucket 0 overlapping the tail of the backward on a side stream); if the collective cannot be
+        captured on this stack, forward+backward alone is captured and the all-reduces follow each replay."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(3):
                 fwd_bwd()
+                reducer.finish()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         if args.no_graph:
-            return None
+            return None, "eager" + ("+overlap" if overlap else "")
+        if overlap and backend == "nccl":
+            try:
+                enc.grads_ready = lambda: reducer.launch(0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    full_step()
+                return g, "graph(step+allreduce, bucket 0 overlapped)"
+            except Exception as e:  # noqa: BLE001
+                if rank == 0:
+                    print(f"[bench] capture with the collectives inside failed ({type(e).__name__}: {e}); "
+                          "capturing forward+backward only", file=sys.stderr)
+                torch.cuda.synchronize()
+                reducer._pending, reducer._launched = [], set()
+        enc.grads_ready = None
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fwd_bwd()
-            return g
+            return g, "graph(fwd+bwd) then allreduce"
         except Exception as e:  # noqa: BLE001
             if rank == 0:
                 print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
             torch.cuda.synchronize()
-            return None
+            return None, "eager"
 
-    graph = capture()
+    enc.grads_ready = (lambda: reducer.launch(0)) if overlap else None
+    graph, step_mode = capture()
+    if graph is None and overlap:
+        enc.grads_ready = lambda: reducer.launch(0)
 
     def step():
         if graph is not None:
             graph.replay()
+            if not step_mode.startswith("graph(step"):
+                reducer.finish()
         else:
-            fwd_bwd()
-        reducer.all_reduce()
+            full_step()
 
     def barrier():
         if world > 1:
@@ -258,7 +291,8 @@ def main():
     if rank == 0:
         flops = step_flops(c)
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_TFLOPS
-        # per-kernel attribution: eager profiled pass with HIP events on the launch stream
+        # per-kernel attribution: eager profiled pass with HIP events on the launch stream (rank 0 alone: no collectives)
+        enc.grads_ready = None
         with KernelTimer() as kt:
             for _ in range(args.profile_steps):
                 fwd_bwd()
@@ -316,6 +350,7 @@ def main():
                                    f"parallel cross-attn + spatial self-attn + FFN2048, heads={c['heads']}, "
                                    f"fwd+bwd+grad-pack{'+RCCL all-reduce' if world > 1 else ''}",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
+                       "step_mode": step_mode,
                        "dropout": 0.0 if args.dropout == "off" else "reference train mode (0.1 / heads 0.1, 0.3)",
                        "activation": "relu"},
             "step_algorithmic_gflop": flops / 1e9,
@@ -336,11 +371,30 @@ def main():
             n_e = max(3, args.steps // 5)
             fwd_bwd()
             result["eager_ms_per_step"] = timed_loop(fwd_bwd, n_e)
+            # the drop-in path for a trainer that calls model(data_dict) / loss.backward() itself (reference:
+            # trainer/query3d_trainer.py:30-45): forward and backward as ONE graph replay each behind an autograd node
+            # (pq3d_amd/graphed.py); the loss and the gradient plumbing stay eager
+            try:
+                from pq3d_amd.graphed import GraphedQuery3D
+                for mode in ("direct", "autograd"):
+                    enc.grad_arena = None
+                    gm = GraphedQuery3D(model, dd, mode=mode)
+
+                    def dropin_step():
+                        model.zero_grad(set_to_none=True)
+                        loss_fn(gm(dd), c["heads"]).backward()
+                    for _ in range(3):
+                        dropin_step()
+                    result[f"dropin_graphed_{mode}_ms_per_step"] = timed_loop(dropin_step, max(10, args.steps))
+                    del gm
+            except Exception as e:  # noqa: BLE001
+                result["dropin_graphed_error"] = f"{type(e).__name__}: {e}"[:300]
+            enc.grad_arena, enc.grad_arena_buffers = reducer.slots(), [reducer.flat[0]]
             if args.dropout == "off" and not args.no_dropout_leg:
                 # train-mode dropout as the reference trains (reported separately from the parity-checked
                 # p=0 headline): masks are generated inside the attention / LayerNorm / GEMM-epilogue kernels
                 set_dropout_mode("reference")
-                g2 = capture()
+                g2, _ = capture()
                 run2 = g2.replay if g2 is not None else fwd_bwd
                 for _ in range(args.warmup):
                     run2()

@@ -680,6 +680,24 @@ class _FusedDecoder(Function):
                 GWs += [gw[d:2 * d], gw[2 * d:]]
                 Gbs += [gb[d:2 * d], gb[2 * d:]]
         dwq.add(Akv, Xf, X2, GWs, ct, Gbs)
+        # ---- every parameter gradient of the decoder (+ mask head) is complete after this flush: in a data-parallel step
+        # its all-reduce starts HERE (enc.grads_ready, set by the step owner) and overlaps the key/value input-gradient
+        # products below and the encoders' backward that autograd runs after this function returns
+        dkm_list = {}
+        if dkeys is not None:
+            for j in range(spec.mh_count):
+                mp = list(spec.mh.mask_pred_list)[j]
+                dkm_list[j] = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
+                dwq.add([dkm_list[j]], [ctx.mh_feats[j]], None, [G(mp.k_proj.weight)], ct)
+        dwq.flush()
+        for i0 in range(0, len(sb_queue), MAXG):
+            chunk = sb_queue[i0:i0 + MAXG]
+            arrs = [(C.c_void_p * len(chunk))(*[L.ptr(t[k]) for t in chunk]) for k in range(5)]
+            L.check(L.lib().pq3d_spatial_bias_bwd_grouped(L.ptr(pl), *arrs, len(chunk), B, H, Nq, L.stream()),
+                    "pq3d_spatial_bias_bwd_grouped")
+        ready = getattr(enc, "grads_ready", None)
+        if ready is not None:
+            ready()
         # bf16 path: the input-gradient products read TRANSPOSED bf16 copies of the K/V weights (one copy launch from the
         # forward's pre-cast rows), which turns them into plain NT products -- the 128x128-tile kernel's layout -- and the
         # memories then share launches (K-concatenation per memory, several outputs per launch)
@@ -704,10 +722,8 @@ class _FusedDecoder(Function):
                 if mh_src[j] != u:
                     continue
                 mp = list(spec.mh.mask_pred_list)[j]
-                dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
-                Aj.append(dkm)
+                Aj.append(dkm_list[j])
                 Bj.append(kT[j] if tposed else mp.k_proj.weight.detach())
-                dwq.add([dkm], [ctx.mh_feats[j]], None, [G(mp.k_proj.weight)], ct)
             jobs.append((u, Aj, Bj))
         per = len(jobs[0][1]) if jobs else 0
         want_dpos = pos is not None and ctx.needs_input_grad[4]
@@ -757,12 +773,6 @@ class _FusedDecoder(Function):
                            kconcat=n)
                     out = nxt
                 dfeats[j] = out
-        if dkeys is not None:  # k_proj weight grads for memories whose features need no grad
-            for j in range(spec.mh_count):
-                if not need_feat[mh_src[j]]:
-                    mp = list(spec.mh.mask_pred_list)[j]
-                    dkm = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
-                    dwq.add([dkm], [ctx.mh_feats[j]], None, [G(mp.k_proj.weight)], ct)
         if want_dpos:
             Ak, Bk = Akv[0::2], Bkv[0::2]
             for s in range(0, len(Ak), MAXG):
@@ -776,12 +786,6 @@ class _FusedDecoder(Function):
         dqpos = None
         if ctx.needs_input_grad[2]:
             dqpos = ops.sum_n(dqpos_parts)
-        dwq.flush()
-        for i0 in range(0, len(sb_queue), MAXG):
-            chunk = sb_queue[i0:i0 + MAXG]
-            arrs = [(C.c_void_p * len(chunk))(*[L.ptr(t[k]) for t in chunk]) for k in range(5)]
-            L.check(L.lib().pq3d_spatial_bias_bwd_grouped(L.ptr(pl), *arrs, len(chunk), B, H, Nq, L.stream()),
-                    "pq3d_spatial_bias_bwd_grouped")
         dx0 = dx if ctx.needs_input_grad[1] else None
         pgrads = [gv[id(p)] if p.requires_grad else None for p in params]
         return (None, dx0, dqpos, None, dpos, None, None, None, None, *dfeats, *([None] * M), *pgrads)

@@ -15,23 +15,36 @@ import torch.distributed as dist
 
 
 class FlatGradAllReducer:
+    """``groups``: explicit buckets (lists of parameters) in the order their gradients become final -- bench.py /
+    TrainStep pass [decoder (+ mask head) parameters, everything else]: the fused decoder backward finishes ALL of the
+    first bucket (93 % of the bytes at config 2) before the key/value input gradients and the encoders' backward run, so
+    its all-reduce can be launched early on a side stream (``launch(0)``) and overlaps that tail."""
+
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
-                 keep_order: bool = False):
+                 keep_order: bool = False, groups=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
-        self.buckets: List[List[torch.nn.Parameter]] = [[]]
-        size = 0
-        # default: reverse registration order ~ order gradients become ready; keep_order: the caller's layout (the
-        # flat optimizer wants parameter groups back to back)
-        for p in (self.params if keep_order else reversed(self.params)):
-            nb = p.numel() * 4
-            if size + nb > bucket_bytes and self.buckets[-1]:
-                self.buckets.append([])
-                size = 0
-            self.buckets[-1].append(p)
-            size += nb
-        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device)
-                     for b in self.buckets if b]
+        if groups is not None:
+            self.buckets = [[p for p in g if p.requires_grad] for g in groups]
+            assert sorted(id(p) for b in self.buckets for p in b) == sorted(id(p) for p in self.params), \
+                "groups must partition the parameters"
+        else:
+            self.buckets = [[]]
+            size = 0
+            # default: reverse registration order ~ order gradients become ready; keep_order: the caller's layout (the
+            # flat optimizer wants parameter groups back to back)
+            for p in (self.params if keep_order else reversed(self.params)):
+                nb = p.numel() * 4
+                if size + nb > bucket_bytes and self.buckets[-1]:
+                    self.buckets.append([])
+                    size = 0
+                self.buckets[-1].append(p)
+                size += nb
+        self.buckets = [b for b in self.buckets if b]
+        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device) for b in self.buckets]
+        self._side = None        # side stream of the early launches
+        self._pending = []       # (work handle or None, bucket index)
+        self._launched = set()
 
     def slots(self):
         """{id(param): (flat buffer, element offset, numel)} -- hand this to the fused executor
@@ -46,10 +59,12 @@ class FlatGradAllReducer:
                 off += n
         return out
 
-    def pack(self) -> None:
+    def pack(self, buckets=None) -> None:
         """Copy every .grad into the flat buffers (capturable: fixed addresses, one foreach copy per bucket).
         Gradients that already ARE views of the flat buffer (written in place by the fused executor) are skipped."""
-        for flat, bucket in zip(self.flat, self.buckets):
+        for bi, (flat, bucket) in enumerate(zip(self.flat, self.buckets)):
+            if buckets is not None and bi not in buckets:
+                continue
             views, grads, off = [], [], 0
             for p in bucket:
                 n = p.numel()
@@ -64,14 +79,57 @@ class FlatGradAllReducer:
             if views:
                 torch._foreach_copy_(views, grads)
 
-    def all_reduce(self) -> None:
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
+    # ---- collective -------------------------------------------------------------------------------------------------
+    def _world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _reduce(self, f: torch.Tensor):
+        """mean over ranks, in place.  RCCL ('nccl') averages inside the collective (ReduceOp.AVG: no separate divide
+        launch); gloo (CPU tests, the one-GPU two-rank hook) has no AVG -> SUM, the caller divides."""
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_reduce(f, op=dist.ReduceOp.AVG, group=self.group, async_op=True), False
+        return dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True), True
+
+    def launch(self, bi: int) -> None:
+        """Start the all-reduce of bucket ``bi`` on a side stream that waits for the work queued so far on the current
+        stream; the current stream carries on (the rest of the backward overlaps the transfer).  finish() joins."""
+        if self._world() == 1 or bi in self._launched:
             return
-        handles = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self.flat]
-        for h in handles:
-            h.wait()
-        torch._foreach_div_(self.flat, float(world))
+        cur = torch.cuda.current_stream() if self.flat[bi].is_cuda else None
+        if cur is not None:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                h, div = self._reduce(self.flat[bi])
+        else:
+            h, div = self._reduce(self.flat[bi])
+        self._pending.append((h, bi, div))
+        self._launched.add(bi)
+
+    def finish(self) -> None:
+        """Launch whatever has not been launched, wait for everything, leave the mean in the flat buffers."""
+        if self._world() == 1:
+            return
+        for bi in range(len(self.flat)):
+            self.launch(bi)
+        world = float(self._world())
+        for h, bi, div in self._pending:
+            if self.flat[bi].is_cuda and self._side is not None:
+                with torch.cuda.stream(self._side):
+                    h.wait()
+                    if div:
+                        self.flat[bi].div_(world)
+            else:
+                h.wait()
+                if div:
+                    self.flat[bi].div_(world)
+        if self._side is not None and self.flat[0].is_cuda:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._pending, self._launched = [], set()
+
+    def all_reduce(self) -> None:
+        self.finish()
 
     def unpack_views(self) -> None:
         """Point every .grad at its slice of the reduced flat buffer."""

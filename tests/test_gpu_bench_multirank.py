@@ -36,3 +36,21 @@ def test_bench_two_ranks_one_gpu(config):
     assert r["value"] > 0 and abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
     assert r["grads_identical_across_ranks"] is True
     assert "cpu_baseline" not in r                       # rank-0 / N=1 only
+
+
+def test_bench_two_ranks_rccl():
+    """The real thing where the box has it: two ranks on two GPUs over RCCL (backend 'nccl'), so that the driver's
+    multi-GPU run is not RCCL's first execution of this path.  Exercises graph capture with the collectives inside (or
+    its fallback), ReduceOp.AVG and the early bucket-0 launch.  Skipped on single-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PQ3D_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--headline-only"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 2 and r["grads_identical_across_ranks"] is True and r["value"] > 0

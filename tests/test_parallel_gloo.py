@@ -35,6 +35,21 @@ def _worker(rank, world, port, out):
         assert torch.allclose(p.grad, mean, atol=1e-6), (rank, i)
         assert p.grad.data_ptr() >= red.flat[0].data_ptr() or len(red.flat) > 1   # a view of a flat bucket
     assert len(red.flat) > 1
+    # explicit buckets in readiness order + early launch of the first one (what bench.py does from inside the backward)
+    for p in params:
+        p.grad = None
+    red2 = FlatGradAllReducer(params, groups=[list(lin[2].parameters()), list(lin[0].parameters()) + list(lin[1].parameters()) + [unused]])
+    lin(x).square().mean().backward()
+    local2 = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in params]
+    red2.pack(buckets=[0])
+    red2.launch(0)              # bucket 0 in flight ...
+    red2.pack(buckets=[1])      # ... while the rest is still being packed
+    red2.finish()
+    red2.unpack_views()
+    dist.all_gather_object(gathered, [g.numpy() for g in local2])
+    for i, p in enumerate(params):
+        mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
+        assert torch.allclose(p.grad, mean, atol=1e-6), (rank, i, "groups")
     out.put((rank, float(sum(f.abs().sum() for f in red.flat))))
     dist.barrier()
     dist.destroy_process_group()
