@@ -31,7 +31,7 @@ class Cfg(dict):
 
 
 REGISTRY = {c.__name__: c for c in (M.QueryMaskEncoder, M.QueryEncoder, M.MaskHeadSegLevel, M.GroundHead,
-                                    M.ObjectEncoder, M.T5)}
+                                    M.ObjectEncoder, M.T5, M.PCDMask3DSegLevelEncoder)}
 
 
 def _to_dict(c):
@@ -85,9 +85,9 @@ class Query3DUnified(nn.Module):
         for inp in self.inputs:
             if inp == "prompt":
                 continue  # text encoder out of scope: prompt memory arrives pre-encoded
-            if inp == "voxel" and not self.use_offline_voxel_fts:
-                raise NotImplementedError("online voxel backbone (MinkowskiEngine) is out of scope; "
-                                          "set use_offline_voxel_fts")
+            # voxel without use_offline_voxel_fts: the reference runs its MinkowskiEngine backbone inside the model
+            # (query3d_unified.py:146-152); here the backbone is outside (out of scope) and the voxel encoder is the
+            # post-backbone part (M.PCDMask3DSegLevelEncoder) fed the backbone's per-level features
             enc = build_module_by_name(cfg.model.get(inp + "_encoder"))
             if hasattr(enc, "_drop_base"):   # one dropout-site range per encoder instance
                 enc._drop_base = M.DROP_BASE_OBJ_ENC + (self.inputs.index(inp) << 12)
@@ -141,7 +141,7 @@ class Query3DUnified(nn.Module):
 
     def _encode_scene_memories(self, data_dict):
         """ObjectEncoder projections of all scene memories; same-shape encoders share grouped launches."""
-        names = [m for m in self.inputs if m in ("mv", "pc", "voxel")]
+        names = [m for m in self.inputs if m in ("mv", "pc", "voxel") and not (m == "voxel" and not self.use_offline_voxel_fts)]
         encs = [getattr(self, m + "_encoder") for m in names]
         xs = [data_dict[m + "_seg_fts"] for m in names]
         same = len(names) > 1 and all(isinstance(e, M.ObjectEncoder) and e.use_projection and not hasattr(e, "cls_head")
@@ -166,8 +166,9 @@ class Query3DUnified(nn.Module):
             M.begin_dropout_step(self, data_dict["query_locs"].device)
         # every pad mask ('True = valid' in data_dict) is inverted by ONE launch (ops.mask_not); equal-shape masks come back
         # as views of one stacked buffer, which the fused executor takes as the memories-stacked key-padding mask
-        scene = [m for m in self.inputs if m in ("mv", "pc", "voxel")]
-        keys = [m + "_seg_pad_masks" for m in scene] + (["seg_pad_masks"] if hasattr(self, "mask_head") else [])
+        online_voxel = "voxel" in self.inputs and not self.use_offline_voxel_fts
+        scene = [m for m in self.inputs if m in ("mv", "pc", "voxel") and not (m == "voxel" and online_voxel)]
+        keys = [m + "_seg_pad_masks" for m in scene] + (["seg_pad_masks"] if (hasattr(self, "mask_head") or online_voxel) else [])
         inv = {}
         bool_ok = all(data_dict[k].dtype == torch.bool for k in keys + ["query_pad_masks"])
         if bool_ok:
@@ -201,9 +202,15 @@ class Query3DUnified(nn.Module):
                 feat = enc_out[inp]
                 k = inp + "_seg_pad_masks"
                 mask, pos = inv[k] if k in inv else data_dict[k].logical_not(), fts_pos
-            elif inp == "voxel":
+            elif inp == "voxel" and self.use_offline_voxel_fts:
                 feat = enc_out[inp]
                 mask = inv["voxel_seg_pad_masks"] if "voxel_seg_pad_masks" in inv else data_dict["voxel_seg_pad_masks"].logical_not()
+                pos = fts_pos
+            elif inp == "voxel":
+                # query3d_unified.py:146-152 with the backbone's outputs supplied: multi-scale LIST of segment features
+                feat = self.voxel_encoder(data_dict["voxel_pyramid"], data_dict["voxel2segment"],
+                                          max_seg=data_dict["seg_center"].shape[1])
+                mask = inv["seg_pad_masks"] if "seg_pad_masks" in inv else data_dict["seg_pad_masks"].logical_not()
                 pos = fts_pos
             else:
                 raise NotImplementedError(f"Unknow input type: {inp}")

@@ -796,6 +796,48 @@ class ObjectEncoder(_PostNormBase):
         return obj_embeds
 
 
+class PCDMask3DSegLevelEncoder(_PostNormBase):
+    """modules/vision/pcd_mask3d_encoder.py:114-154 WITHOUT its sparse-convolution backbone (Res16UNet34C on
+    MinkowskiEngine: SURVEY 2 'out of scope').  Everything after the backbone is here, with the reference's parameter
+    names (``feat_proj_list.{i}.{0,1}.{weight,bias}``: a checkpoint's post-backbone weights load; ``backbone.*`` keys are
+    not this module's): for every level in ``hlevels + [4]`` the level's voxel features are up-sampled to full resolution
+    (``pooltr`` x (4 - hlevel), :127-131), mean-pooled per segment (``scatter_mean(..., dim_size=max_seg)``, :149) and
+    projected (Linear + LayerNorm + Dropout, :122-126); the result is the multi-scale LIST the decoder indexes per layer
+    (query_encoder.py:90-91) and whose last entry the mask head matches against (query3d_unified.py:163-165).
+
+    forward(pyramid, point2segment, max_seg): ``pyramid[i] = (feats, parents)`` for level ``hlevels[i]`` -- ``feats[b]``
+    [N_coarse_b, C_level] the backbone's decomposed features of scene b at that level, ``parents[b]`` [N_b] int64 the
+    coarse row of every full-resolution voxel (ops.compose_parents / ops.parents_from_coords; identity for level 4) --
+    which is what the backbone's ``aux`` list + coordinate maps provide.  The up-sampled [N, C] intermediate is never
+    materialised (ops.upsample_scatter_mean).  Third-party semantics (MinkowskiEngine pooling, torch_scatter): parity
+    unpinned by execution, pinned to the oracle's restatement (tests/test_gpu_ops.py)."""
+
+    PLANES = (256, 256, 128, 96, 96)    # Res16UNet34C.PLANES[-5:] (res16unet.py:391)
+
+    def __init__(self, cfg, backbone_kwargs=None, hidden_size=768, hlevels=(0, 1, 2, 3), freeze_backbone=False, dropout=0.1,
+                 sizes=None):
+        super().__init__()
+        self.sizes = tuple(sizes) if sizes is not None else self.PLANES
+        self.hlevels = list(hlevels) + [4]      # 4 is for the last level, always used for mask seg features (:118)
+        self.feat_proj_list = nn.ModuleList([nn.Sequential(nn.Linear(self.sizes[h], hidden_size), nn.LayerNorm(hidden_size),
+                                                           nn.Dropout(dropout)) for h in self.hlevels])
+        self.dropout_p, self._drop_base = float(dropout), DROP_BASE_OBJ_ENC + (7 << 12)
+
+    def forward(self, pyramid, point2segment, max_seg):
+        assert len(pyramid) == len(self.hlevels), "one (features, parents) entry per level in hlevels + [4]"
+        out = []
+        dev = point2segment[0].device
+        ctx = self._head_ctx(dev)
+        for i, ((feats, parents), proj) in enumerate(zip(pyramid, self.feat_proj_list)):
+            pooled = torch.stack([ops.upsample_scatter_mean(f, par, p2s, int(max_seg))
+                                  for f, par, p2s in zip(feats, parents, point2segment)])      # [B, max_seg, C_level]
+            y = linear_ln_forward(proj, pooled, self.ct)
+            if self.dropout_p > 0:
+                y = ops.dropout(y, self._drop(ctx, ops.DROP_ENC_OUT, dev, m=i))
+            out.append(y)
+        return out
+
+
 class PositionEmbeddingCoordsSine(nn.Module):
     """position_embedding.py:46-179, pos_type='fourier', normalize=True (buffer gauss_B [3, d_pos/2])."""
 

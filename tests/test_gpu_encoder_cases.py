@@ -84,3 +84,85 @@ def test_memory_dropout_draws_a_new_mask_per_layer_application():
         idict[m] = [feats[m].cuda(), pad.cuda(), fpos.cuda()]
     enc(idict, M.calc_pairwise_locs(centers.cuda()), None)
     assert seen == list(range(a["L"]))
+
+
+def _pyramid(B=2, S=40, seed=3):
+    """A synthetic 5-level voxel pyramid with the reference's channel widths: coordinates -> stride-2 pooling chains."""
+    from oracle import pq3d_oracle as O
+    from pq3d_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    planes = (256, 256, 128, 96, 96)
+    feats = [[None] * B for _ in range(5)]
+    parents = [[None] * B for _ in range(5)]
+    p2s = []
+    for b in range(B):
+        fine = torch.cat([torch.zeros(900 + 300 * b, 1, dtype=torch.long),
+                          torch.randint(-24, 24, (900 + 300 * b, 3), generator=g)], 1).unique(dim=0)
+        N = fine.shape[0]
+        p2s.append(torch.randint(0, S - 3 * b, (N,), generator=g))
+        maps, cur = [], fine
+        for lvl in range(1, 5):                       # strides 2, 4, 8, 16
+            cc, par = O.pooling_transpose_parents(cur, 2 ** lvl)
+            maps.append(par); cur = cc
+        for h in range(5):                            # backbone level h sits (4 - h) poolings above full resolution
+            npool = 4 - h
+            par = ops.compose_parents(maps[:npool]) if npool else torch.arange(N)
+            n_rows = int(par.max()) + 1
+            feats[h][b] = torch.randn(n_rows, planes[h], generator=g)
+            parents[h][b] = par
+    return [(feats[h], parents[h]) for h in range(5)], p2s
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_pcd_seg_level_encoder_post_backbone_matches_oracle(compute):
+    """PCDMask3DSegLevelEncoder after the backbone (pcd_mask3d_encoder.py:139-154): 5 levels -> 5 projected segment-feature
+    tensors, the multi-scale list of the stage-1 decoder.  State-dict keys as the reference's feat_proj_list."""
+    from oracle import pq3d_oracle as O
+    from pq3d_amd import modules as M
+    from pq3d_amd import synth
+    enc = M.PCDMask3DSegLevelEncoder(None, None, hidden_size=64, hlevels=[0, 1, 2, 3], dropout=0.1)
+    assert sorted(enc.state_dict()) == sorted(f"feat_proj_list.{i}.{j}.{w}" for i in range(5) for j in (0, 1) for w in ("weight", "bias"))
+    sd = synth.fill_module(enc, 2)
+    M.set_compute(enc, compute)
+    enc.to("cuda").eval()
+    pyr, p2s = _pyramid()
+    S = 40
+    ref = O.pcd_seg_level_encoder({k: v.double() for k, v in sd.items()},
+                                  "", [([f.double() for f in fs], ps) for fs, ps in pyr], p2s, S)
+    pyr_d = [([f.cuda().requires_grad_(True) for f in fs], [p.cuda() for p in ps]) for fs, ps in pyr]
+    out = enc(pyr_d, [p.cuda() for p in p2s], S)
+    assert len(out) == 5 and all(o.shape == (2, S, 64) for o in out)
+    tol = 1e-5 if compute == "fp32" else 1e-3     # 'bf16' mode: split-bf16 projection (fp32-grade)
+    for o, r in zip(out, ref):
+        assert float((o.detach().double().cpu() - r).abs().max()) <= tol * float(r.abs().max())
+    sum(o.square().mean() for o in out).backward()
+    assert all(f.grad is not None and torch.isfinite(f.grad).all() for fs, _ in pyr_d for f in fs)
+
+
+def test_model_with_online_voxel_pyramid_takes_the_fused_path():
+    """Query3DUnified with use_offline_voxel_fts = False: the voxel memory is the post-backbone encoder's multi-scale list;
+    the fused executor runs it and agrees with the modular path."""
+    from pq3d_amd import synth
+    from pq3d_amd.model import Cfg, Query3DUnified, make_cfg
+    cfg = make_cfg(d=64, H=4, L=4, memories=["voxel", "mv"], heads=["mask"], use_self_mask=True, num_blocks=2, C=21, foc=(0, 2))
+    cfg.model["use_offline_voxel_fts"] = False
+    cfg.model["voxel_encoder"] = Cfg(name="PCDMask3DSegLevelEncoder", args=Cfg(backbone_kwargs=None, hidden_size=64,
+                                                                               hlevels=[0, 1, 2, 3], dropout=0.1))
+    model = Query3DUnified(cfg, compute="fp32")
+    synth.fill_module(model, 0)
+    model.to("cuda").eval()
+    pyr, p2s = _pyramid()
+    dd = synth.synth_data_dict(2, 40, 9, {"mv": 64, "voxel": 64}, seed=5, memories=["mv"])
+    dd = {k: v.cuda() for k, v in dd.items()}
+    dd["voxel_pyramid"] = [([f.cuda() for f in fs], [p.cuda() for p in ps]) for fs, ps in pyr]
+    dd["voxel2segment"] = [p.cuda() for p in p2s]
+    res = []
+    for fused in (True, False):
+        model.unified_encoder.fused = fused
+        (out, took) = _count_fused(lambda: model(dict(dd)))
+        assert took == fused
+        res.append(out)
+    assert len(res[0]["predictions_mask"]) == 4 * 2 + 1
+    for a, b in zip(res[0]["predictions_mask"], res[1]["predictions_mask"]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b[b > -1e5].abs().max())
+    assert float((res[0]["query_embeds"] - res[1]["query_embeds"]).abs().max()) <= 1e-4
