@@ -77,7 +77,8 @@ def build(c, compute, device, seed):
 
 def loss_fn(out, heads):
     from pq3d_amd import ops
-    loss = ops.mean_all(out["query_embeds"] if "query_embeds" in out else out["query"])   # mean(query)
+    q = out["query_embeds"] if "query_embeds" in out else out["query"]
+    loss = ops.mean_all(q) if q.is_cuda else q.mean()   # mean(query); the CPU-baseline leg has host tensors
     if "generation" in heads:   # generation_loss: token cross-entropy of the teacher-forced logits
         lg = out["generation_logits"]
         loss = loss + torch.nn.functional.cross_entropy(lg.flatten(0, 1).float(), out["generation_label"].flatten())
@@ -127,6 +128,55 @@ def cpu_baseline(c, sd, dd, steps, warmup):
             "host_cpus": ncpu, "threads_tried_ms": {str(k): round(v * 1e3, 1) for k, v in probe.items()},
             "sample": f"{steps} timed fwd+bwd steps (median) of the same {c['B']}-scene batch after {warmup} warm-up, "
                       f"fp32, torch CPU ops, dropout 0, best of the thread counts tried"}
+
+
+def gpu_kernels_of(entry, shape):
+    """GPU kernels behind one (C-ABI entry point, shape key) of the per-kernel table -- used to look the entry's HBM
+    traffic up in the per-kernel PMC file.  Attention: the dispatch rules of attention.hip (small fp32 kernels for
+    Lq, Lk <= 128; the all-queries-resident backward for Lq <= 128 <= Lk; the two-kernel backward otherwise)."""
+    import re
+    m = re.match(r"B(\d+)H(\d+)Lq(\d+)Lk(\d+)dh(\d+)ct(\d+)", shape)
+    if entry in ("pq3d_attn_fwd", "pq3d_attn_bwd") and m:
+        _B, _H, Lq, Lk, _dh, ct = map(int, m.groups())
+        small = ct == 0 and Lq <= 128 and Lk <= 128
+        if entry == "pq3d_attn_fwd":
+            return ["attn_small_fwd_kernel"] if small else ["attn_fwd_kernel", "attn_fwd_combine_kernel"]
+        if small:
+            return ["attn_small_bwd_kernel"]
+        return (["attn_bwd_resident_kernel", "attn_dq_combine_kernel"] if Lq <= 128 <= Lk
+                else ["attn_bwd_dq_kernel", "attn_dq_combine_kernel", "attn_bwd_dkv_kernel"])
+    return {"pq3d_gemm": ["gemm_fast_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel"],
+            "pq3d_add_ln_fwd": ["add_ln_fwd_kernel"], "pq3d_add_ln_bwd": ["add_ln_bwd_kernel"]}.get(entry, [])
+
+
+def pmc_traffic(path, entry, shape, gpu_names):
+    """roofline.traffic (bytes per launch of the entry point) from a committed PMC file: the r02 per-kernel format written
+    by tools/pmc_traffic_json.py, or round 1's per-entry file.  None when the file or the kernels are not in it, or when
+    a kernel name maps to several launch shapes (GEMMs: ambiguous, left null rather than guessed)."""
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    if "kernels" not in doc:
+        e = doc.get(f"{entry}|{shape}")
+        return None if not e else {"traffic": e["hbm_bytes_raw"], "traffic_fetch_x2_corrected": e["hbm_bytes_fetch_x2"],
+                                   "traffic_source": src}
+    if not entry.startswith("pq3d_attn"):
+        return None
+    fetch = write = 0.0
+    found = 0
+    for n in gpu_names:
+        rows = doc["kernels"].get(n, [])
+        if len(rows) > 1:
+            return None
+        if rows:
+            fetch += rows[0]["fetch_kib"] * 1024
+            write += rows[0]["write_kib"] * 1024
+            found += 1
+    if not found or not any(n in doc["kernels"] for n in gpu_names[:1]):
+        return None
+    return {"traffic": fetch + write, "traffic_fetch_x2_corrected": 2 * fetch + write, "traffic_source": src}
 
 
 def main():
@@ -308,18 +358,14 @@ def main():
             ach = top["bytes"] / top["calls"] / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "traffic": None}
-        names = {"pq3d_attn_bwd": ["attn_bwd_dq_kernel", "attn_dq_combine_kernel", "attn_bwd_dkv_kernel"],
-                 "pq3d_attn_fwd": ["attn_fwd_kernel", "attn_fwd_combine_kernel"], "pq3d_gemm": ["gemm_fast_kernel"],
-                 "pq3d_add_ln_fwd": ["add_ln_fwd_kernel"], "pq3d_add_ln_bwd": ["add_ln_bwd_kernel"]}
-        try:  # HBM traffic of this entry point from the committed rocprofv3 --pmc passes (profiles/), per launch
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json"))).get(f"{kname}|{kkey}")
-            if pmc:
-                roof["traffic"] = pmc["hbm_bytes_raw"]
-                roof["traffic_fetch_x2_corrected"] = pmc["hbm_bytes_fetch_x2"]
-                roof["traffic_source"] = "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except (OSError, ValueError):
-            pass
-        roof.update({"kernel": kname, "gpu_kernels": names.get(kname, []), "shape": kkey,
+        gpu_names = gpu_kernels_of(kname, kkey)
+        for tag in (f"r02_{args.config}", "r01"):   # HBM traffic of this entry point from the committed rocprofv3 --pmc passes
+            pmc_file = os.path.join(ROOT, "profiles", f"pmc_traffic_{tag}.json")
+            t = pmc_traffic(pmc_file, kname, kkey, gpu_names)
+            if t is not None:
+                roof.update(t)
+                break
+        roof.update({"kernel": kname, "gpu_kernels": gpu_names, "shape": kkey,
                      "algorithmic_bytes_per_launch": top["bytes"] / top["calls"],
                      "avg_launch_us": per_launch_ms * 1e3,
                      "launches_per_step": top["calls"] / args.profile_steps,

@@ -70,34 +70,6 @@ template <int DH, int SNT> PQ_DEV void load_mat(float* dst, const float* src, lo
   }
 }
 
-// all-lanes max / sum of a wave with DPP quad / row permutes and the lane-half swaps (no LDS-crossbar shuffles)
-PQ_DEV float dpp_xor_f(float v, int which) {
-  const int x = __float_as_int(v);
-  int y;
-  if (which == 0) y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);         // quad_perm [1,0,3,2]
-  else if (which == 1) y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-  else if (which == 2) y = __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);   // row_half_mirror
-  else y = __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true);                   // row_mirror
-  return __int_as_float(y);
-}
-typedef unsigned u32pair_s __attribute__((ext_vector_type(2)));
-PQ_DEV float wave_max_dpp(float v) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v = fmaxf(v, dpp_xor_f(v, k));
-  u32pair_s a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  u32pair_s b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-PQ_DEV float wave_sum_dpp(float v) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v += dpp_xor_f(v, k);
-  u32pair_s a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  u32pair_s b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 template <int DH> PQ_DEV void load_row_regs(float (&r)[DH], const float* p) {
 #pragma unroll
   for (int x = 0; x < DH; x += 4) { const float4 t = *(const float4*)(p + x); r[x] = t.x; r[x + 1] = t.y; r[x + 2] = t.z; r[x + 3] = t.w; }
@@ -149,9 +121,9 @@ __global__ __launch_bounds__(SN<DH>::T) void attn_small_fwd_kernel(const pq3d_at
   // ---- row softmax: one wave per row
   for (int i = wave; i < nr; i += SNT / 64) {
     const float a0 = lane < Lk ? S[i * LS + lane] : -INFINITY, a1 = lane + 64 < Lk ? S[i * LS + lane + 64] : -INFINITY;
-    const float m = wave_max_dpp(fmaxf(a0, a1));
+    const float m = wave_max(fmaxf(a0, a1));
     const float e0 = lane < Lk ? __expf(a0 - m) : 0.f, e1 = lane + 64 < Lk ? __expf(a1 - m) : 0.f;
-    const float l = wave_sum_dpp(e0 + e1);
+    const float l = wave_sum(e0 + e1);
     if (lane < Lk) S[i * LS + lane] = e0;
     if (lane + 64 < Lk) S[i * LS + lane + 64] = e1;
     if (lane == 0) { Li[i] = 1.f / l; d.lse[((long)b * d.H + h) * Lq + r0 + i] = m + logf(l); }

@@ -133,15 +133,33 @@ PQ_DEV float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
-PQ_DEV float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// all-lanes sum / max of a wave with DPP quad / row permutes and the lane-half swaps: no LDS-crossbar shuffles
+// (ds_bpermute: ~6 dependent LDS round trips per reduction, which dominated the one-row-per-wave kernels)
+PQ_DEV float dpp_xor_f(float v, int which) {
+  const int x = __float_as_int(v);
+  int y;
+  if (which == 0) y = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);         // quad_perm [1,0,3,2]
+  else if (which == 1) y = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  else if (which == 2) y = __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  else y = __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true);                   // row_mirror
+  return __int_as_float(y);
 }
+typedef unsigned u32pair_s __attribute__((ext_vector_type(2)));
 PQ_DEV float wave_max(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  for (int k = 0; k < 4; ++k) v = fmaxf(v, dpp_xor_f(v, k));
+  u32pair_s a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u32pair_s b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+PQ_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v += dpp_xor_f(v, k);
+  u32pair_s a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  u32pair_s b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // ---------------------------------------------------------------------------------------------

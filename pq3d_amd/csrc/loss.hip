@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const pq3d_ce_desc d) {
     const float l = mx + logf(se);
     lse[row] = l;
     const long t = target[row];
-    row_loss[row] = t == ignore ? 0.f : l - x[t];
+    // torch's nll_loss device-asserts 0 <= t < C; here an out-of-range label poisons the loss (NaN) instead of reading
+    // out of bounds -- loud at the first .item()/isfinite check, never a silent wrong number
+    row_loss[row] = t == ignore ? 0.f : ((unsigned long)t < (unsigned long)C ? l - x[t] : NAN);
   }
 }
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const pq3d_ce_desc d) {

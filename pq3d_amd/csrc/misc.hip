@@ -390,7 +390,7 @@ __global__ void sum_n_kernel(const SumPtrs p, int n, float* out, long cnt) {   /
 }
 
 // mean of all elements, one launch: every block reduces a slice (float4 loads, all in flight), publishes its partial sum,
-// and the block that arrives LAST (device-scope ticket) adds the partials in block order -> deterministic.  ws[0] is the
+// and the block that arrives LAST (device-scope ticket) adds the partials with a fixed tree -> deterministic.  ws[0] is the
 // ticket counter (zero before the first use; the last block resets it), ws[1..] the partials.
 __global__ __launch_bounds__(256) void mean_all_kernel(const float* x, long n, float* out, float* ws) {
   __shared__ float red[4];
@@ -411,13 +411,19 @@ __global__ __launch_bounds__(256) void mean_all_kernel(const float* x, long n, f
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add((unsigned*)ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last = (t == gridDim.x - 1);
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      float tot = 0.f;
-      for (unsigned b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(&ws[1 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out[0] = tot / (float)n;
-      __hip_atomic_store((unsigned*)ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  }
+  __syncthreads();
+  if (!last) return;
+  // the last block: one partial per thread (gridDim.x <= 256 = blockDim.x), all loads in flight at once, fixed tree
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  float p = threadIdx.x < gridDim.x ? __hip_atomic_load(&ws[1 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  p = wave_sum(p);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+    __hip_atomic_store((unsigned*)ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 __global__ void fill_scaled_kernel(float* dst, long n, const float* scalar, float c) {   // dst[i] = scalar[0] * c

@@ -1,6 +1,9 @@
-// Residual-add + LayerNorm (merged over M branches), forward and backward.  HBM-bound: one wave per row,
-// the row lives in registers (d <= 1024 -> <= 16 values per lane), wave shuffles for the statistics,
-// fp32 math throughout.  Algorithmic bytes per row: (1 + M) reads + 1 write of d elements.
+// Residual-add + LayerNorm (merged over M branches), forward and backward.  HBM-bound: one wave per row at a time,
+// the row lives in registers (d <= 1024 -> <= 16 values per lane), DPP reductions for the statistics, fp32 math
+// throughout.  Algorithmic bytes per row: (1 + M) reads + 1 write of d elements.
+// Column ownership: VEC (d == 64 * PL, PL >= 4, 16-byte aligned operands): lane owns PL CONSECUTIVE columns, every row
+// access is a 16-byte load/store; otherwise lane owns columns lane + 64 j (4-byte accesses, any d).
+// Large R: waves walk rows with a grid stride and keep the NEXT row's loads in flight.
 #include "common.h"
 
 namespace {
@@ -10,139 +13,183 @@ constexpr int WPB = 4;     // waves (rows in flight) per block
 
 struct RowStats { float mean, rstd; };
 
-template <int PL>
+template <int PL, bool VEC> PQ_DEV int colof(int lane, int j) { return VEC ? lane * PL + j : lane + 64 * j; }
+
+template <int PL, bool VEC>
+PQ_DEV void load_row(const void* p, int dt, long base, int lane, int d, float (&v)[PL]) {
+  if constexpr (VEC) {
+    if (dt == PQ3D_F32) {
+      const float4* q = (const float4*)((const float*)p + base + lane * PL);
+#pragma unroll
+      for (int k = 0; k < PL / 4; ++k) { const float4 t = q[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+    } else {
+      const uint2* q = (const uint2*)((const bf16_t*)p + base + lane * PL);
+#pragma unroll
+      for (int k = 0; k < PL / 4; ++k) {
+        const uint2 t = q[k];
+        v[4 * k] = __uint_as_float(t.x << 16); v[4 * k + 1] = __uint_as_float(t.x & 0xffff0000u);
+        v[4 * k + 2] = __uint_as_float(t.y << 16); v[4 * k + 3] = __uint_as_float(t.y & 0xffff0000u);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = c < d ? load_elem(p, dt, base + c) : 0.f;
+    }
+  }
+}
+template <int PL, bool VEC>
+PQ_DEV void store_row(void* p, int dt, long base, int lane, int d, const float (&v)[PL]) {
+  if constexpr (VEC) {
+    if (dt == PQ3D_F32) {
+      float4* q = (float4*)((float*)p + base + lane * PL);
+#pragma unroll
+      for (int k = 0; k < PL / 4; ++k) q[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else {
+      uint2* q = (uint2*)((bf16_t*)p + base + lane * PL);
+#pragma unroll
+      for (int k = 0; k < PL / 4; ++k)
+        q[k] = make_uint2((unsigned)f2bf(v[4 * k]) | ((unsigned)f2bf(v[4 * k + 1]) << 16),
+                          (unsigned)f2bf(v[4 * k + 2]) | ((unsigned)f2bf(v[4 * k + 3]) << 16));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < d) store_elem(p, dt, base + c, v[j]);
+    }
+  }
+}
+
+template <int PL, bool VEC>
 PQ_DEV RowStats row_stats(const float (&v)[PL], int d, int lane, float eps) {
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < PL; ++j) s += (lane + 64 * j < d) ? v[j] : 0.f;
+  for (int j = 0; j < PL; ++j) s += (colof<PL, VEC>(lane, j) < d) ? v[j] : 0.f;
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
   for (int j = 0; j < PL; ++j) {
     const float t = v[j] - mean;
-    q += (lane + 64 * j < d) ? t * t : 0.f;
+    q += (colof<PL, VEC>(lane, j) < d) ? t * t : 0.f;
   }
   const float var = wave_sum(q) / (float)d;
   return {mean, 1.f / sqrtf(var + eps)};
 }
 
-template <int PL>
+template <int PL, bool VEC>
 __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc d) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
-  if (row >= d.R) return;
-  const long base = row * d.d;
-  float xr[PL], y[PL];
-#pragma unroll
-  for (int j = 0; j < PL; ++j) {
-    const int c = lane + 64 * j;
-    xr[j] = (d.x && c < d.d) ? load_elem(d.x, d.dt_x, base + c) : 0.f;
-    y[j] = 0.f;
-  }
-  const long scene = row / d.rows_per_scene, nscene = d.R / d.rows_per_scene;
+  const long wave_id = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+  if (wave_id >= d.R) return;
   // sum_branches: the M inputs are PARTIAL SUMS of one branch (deterministic K-split of the producing GEMM): one
   // LayerNorm of x + dropout(sum_m o_m), statistics / gamma / beta of index 0
   const int mlo = d.independent ? blockIdx.y : 0, mhi = d.independent ? blockIdx.y + 1 : (d.sum_branches ? 1 : d.M);
   const bool drop = drop_on(d.drop);
-  for (int m = mlo; m < mhi; ++m) {
-    float v[PL], ov[PL];
+  const long nscene = d.coef ? d.R / d.rows_per_scene : 1;
+  void* yout = d.independent ? d.ys[blockIdx.y] : d.y;
+  // the next row's residual and first branch are in flight while this row is normalised
+  float nx[PL], no[PL];
+  auto fetch = [&](long row) {
+    const long base = row * d.d;
+    if (d.x) load_row<PL, VEC>(d.x, d.dt_x, base, lane, d.d, nx);
+    else {
 #pragma unroll
-    for (int j = 0; j < PL; ++j) {
-      const int c = lane + 64 * j;
-      ov[j] = c < d.d ? load_elem(d.o[m], d.dt_o, base + c) : 0.f;
+      for (int j = 0; j < PL; ++j) nx[j] = 0.f;
     }
-    if (d.sum_branches) {
-      for (int p = 1; p < d.M; ++p)
+    load_row<PL, VEC>(d.o[mlo], d.dt_o, base, lane, d.d, no);
+  };
+  fetch(wave_id);
+  for (long row = wave_id; row < d.R; row += nwaves) {
+    const long base = row * d.d;
+    float xr[PL], o0[PL], y[PL];
 #pragma unroll
-        for (int j = 0; j < PL; ++j) {
-          const int c = lane + 64 * j;
-          ov[j] += c < d.d ? load_elem(d.o[p], d.dt_o, base + c) : 0.f;
-        }
-      if (d.osum) {   // the summed branch, kept for the backward pass (which then reads one tensor instead of M)
+    for (int j = 0; j < PL; ++j) { xr[j] = nx[j]; o0[j] = no[j]; y[j] = 0.f; }
+    if (row + nwaves < d.R) fetch(row + nwaves);
+    for (int m = mlo; m < mhi; ++m) {
+      float v[PL], ov[PL];
+      if (m == mlo) {
 #pragma unroll
-        for (int j = 0; j < PL; ++j) {
-          const int c = lane + 64 * j;
-          if (c < d.d) d.osum[base + c] = ov[j];
+        for (int j = 0; j < PL; ++j) ov[j] = o0[j];
+      } else load_row<PL, VEC>(d.o[m], d.dt_o, base, lane, d.d, ov);
+      if (d.sum_branches) {
+        for (int p = 1; p < d.M; ++p) {
+          float t[PL];
+          load_row<PL, VEC>(d.o[p], d.dt_o, base, lane, d.d, t);
+#pragma unroll
+          for (int j = 0; j < PL; ++j) ov[j] += t[j];
         }
+        if (d.osum) store_row<PL, VEC>(d.osum, PQ3D_F32, base, lane, d.d, ov);   // kept for the backward pass
+      }
+      if (drop) {   // uniform branch around pure ALU: residual dropout of branch m (site drop.site + m)
+        const DropState ds = drop_init(d.drop, m, d.d);
+#pragma unroll
+        for (int j = 0; j < PL; ++j)
+          ov[j] = drop_keep(ds, (uint32_t)row, (uint32_t)colof<PL, VEC>(lane, j)) ? ov[j] * ds.scale : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < PL; ++j) v[j] = (colof<PL, VEC>(lane, j) < d.d) ? xr[j] + ov[j] : 0.f;
+      const RowStats st = row_stats<PL, VEC>(v, d.d, lane, d.eps);
+      const float w = (d.independent || d.sum_branches) ? 1.f
+                      : (d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M);
+      float gm[PL], bt[PL];
+      load_row<PL, VEC>(d.gamma[m], PQ3D_F32, 0, lane, d.d, gm);
+      load_row<PL, VEC>(d.beta[m], PQ3D_F32, 0, lane, d.d, bt);
+#pragma unroll
+      for (int j = 0; j < PL; ++j) y[j] += w * ((v[j] - st.mean) * st.rstd * gm[j] + bt[j]);
+      if (lane == 0) {
+        d.mean[(long)m * d.R + row] = st.mean;
+        d.rstd[(long)m * d.R + row] = st.rstd;
       }
     }
-    if (drop) {   // uniform branch around pure ALU: residual dropout of branch m (site drop.site + m)
-      const DropState ds = drop_init(d.drop, m, d.d);
-#pragma unroll
-      for (int j = 0; j < PL; ++j) ov[j] = drop_keep(ds, (uint32_t)row, (uint32_t)(lane + 64 * j)) ? ov[j] * ds.scale : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < PL; ++j) v[j] = (lane + 64 * j < d.d) ? xr[j] + ov[j] : 0.f;
-    const RowStats st = row_stats<PL>(v, d.d, lane, d.eps);
-    const float w = (d.independent || d.sum_branches) ? 1.f : (d.coef ? d.coef[m * nscene + scene] : 1.f / (float)d.M);
-#pragma unroll
-    for (int j = 0; j < PL; ++j) {
-      const int c = lane + 64 * j;
-      if (c < d.d) y[j] += w * ((v[j] - st.mean) * st.rstd * d.gamma[m][c] + d.beta[m][c]);
-    }
-    if (lane == 0) {
-      d.mean[(long)m * d.R + row] = st.mean;
-      d.rstd[(long)m * d.R + row] = st.rstd;
-    }
-  }
-  void* yout = d.independent ? d.ys[blockIdx.y] : d.y;
-#pragma unroll
-  for (int j = 0; j < PL; ++j) {
-    const int c = lane + 64 * j;
-    if (c < d.d) store_elem(yout, d.dt_y, base + c, y[j]);
+    store_row<PL, VEC>(yout, d.dt_y, base, lane, d.d, y);
   }
 }
 
-// Backward: each wave walks rows with a grid stride, keeps per-lane partial dgamma/dbeta for its columns in
-// registers for all M branches is too much (M*PL*2) -> loop branches outermost within a row, accumulate the
-// parameter grads of one branch at a time into LDS-free registers by making m the OUTER loop of the kernel
-// (blockIdx.y = m).  dx (sum over branches) is then accumulated with atomics only when M > 1.
-template <int PL>
-__global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc d) {
-  __shared__ float red[2][WPB][64 * PL];
+// Backward: blockIdx.y = branch m; each wave walks rows with a grid stride and keeps the per-lane partial dgamma/dbeta of
+// its columns in registers.  dx (sum over branches) is accumulated with atomics only when M > 1.
+template <int PL, bool VEC, int NW>
+__global__ __launch_bounds__(NW * 64) void add_ln_bwd_kernel(const pq3d_ln_desc d) {
+  __shared__ float red[2][NW][64 * PL];
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.y;
-  const long wave_id = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
-  const long nscene = d.R / d.rows_per_scene;
+  const long wave_id = (long)blockIdx.x * NW + (threadIdx.x >> 6), nwaves = (long)gridDim.x * NW;
+  const long nscene = d.coef ? d.R / d.rows_per_scene : 1;
   float dg[PL], db[PL], gam[PL];
+  load_row<PL, VEC>(d.gamma[m], PQ3D_F32, 0, lane, d.d, gam);
 #pragma unroll
-  for (int j = 0; j < PL; ++j) {
-    const int c = lane + 64 * j;
-    dg[j] = 0.f; db[j] = 0.f;
-    gam[j] = c < d.d ? d.gamma[m][c] : 0.f;
-  }
+  for (int j = 0; j < PL; ++j) { dg[j] = 0.f; db[j] = 0.f; }
   // software-pipelined over rows: the three row loads of the NEXT row are in flight while this row is reduced
   const float* dyp = d.independent ? d.dys[m] : d.dy;
   const bool drop = drop_on(d.drop);
   DropState dst;
   if (drop) dst = drop_init(d.drop, m, d.d);
   float nv[PL], ndy[PL];
-  unsigned nkeep = 0xffffffffu;   // bit j: column lane + 64 j of the fetched row survived the residual dropout
+  unsigned nkeep = 0xffffffffu;   // bit j: column j of the fetched row survived the residual dropout
   auto fetch = [&](long row) {
     const long base = row * d.d;
     float xv[PL], ov[PL];
+    if (d.x) load_row<PL, VEC>(d.x, d.dt_x, base, lane, d.d, xv);
+    else {
 #pragma unroll
-    for (int j = 0; j < PL; ++j) {
-      const int c = lane + 64 * j;
-      if (c < d.d) {
-        xv[j] = d.x ? load_elem(d.x, d.dt_x, base + c) : 0.f;
-        ov[j] = load_elem(d.o[m], d.dt_o, base + c);
-        ndy[j] = dyp[base + c];
-      } else { xv[j] = 0.f; ov[j] = 0.f; ndy[j] = 0.f; }
+      for (int j = 0; j < PL; ++j) xv[j] = 0.f;
     }
+    load_row<PL, VEC>(d.o[m], d.dt_o, base, lane, d.d, ov);
+    load_row<PL, VEC>(dyp, PQ3D_F32, base, lane, d.d, ndy);
     if (d.sum_branches) {
-      for (int p = 1; p < d.M; ++p)
+      for (int p = 1; p < d.M; ++p) {
+        float t[PL];
+        load_row<PL, VEC>(d.o[p], d.dt_o, base, lane, d.d, t);
 #pragma unroll
-        for (int j = 0; j < PL; ++j) {
-          const int c = lane + 64 * j;
-          if (c < d.d) ov[j] += load_elem(d.o[p], d.dt_o, base + c);
-        }
+        for (int j = 0; j < PL; ++j) ov[j] += t[j];
+      }
     }
     if (drop) {
       nkeep = 0;
 #pragma unroll
       for (int j = 0; j < PL; ++j) {
-        const bool k = drop_keep(dst, (uint32_t)row, (uint32_t)(lane + 64 * j));
+        const bool k = drop_keep(dst, (uint32_t)row, (uint32_t)colof<PL, VEC>(lane, j));
         nkeep |= (unsigned)k << j;
         ov[j] = k ? ov[j] * dst.scale : 0.f;
       }
@@ -165,8 +212,7 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
-      const int c = lane + 64 * j;
-      if (c < d.d) {
+      if (colof<PL, VEC>(lane, j) < d.d) {
         const float du = w * dyr[j];
         xh[j] = (v[j] - mean) * rstd;
         dg[j] += du * xh[j];
@@ -178,31 +224,37 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_bwd_kernel(const pq3d_ln_desc
     }
     s1 = wave_sum(s1) / (float)d.d;
     s2 = wave_sum(s2) / (float)d.d;
+    float g[PL], go[PL];
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
-      const int c = lane + 64 * j;
-      if (c < d.d) {
-        const float g = rstd * (dz[j] - s1 - xh[j] * s2);
-        d.d_o[m][base + c] = drop ? (((keep >> j) & 1u) ? g * dst.scale : 0.f) : g;
-        if (d.dx && !d.independent) {
-          if (d.M == 1 || d.sum_branches) d.dx[base + c] = g;
-          else unsafeAtomicAdd(&d.dx[base + c], g);
+      g[j] = rstd * (dz[j] - s1 - xh[j] * s2);
+      go[j] = drop ? (((keep >> j) & 1u) ? g[j] * dst.scale : 0.f) : g[j];
+    }
+    store_row<PL, VEC>(d.d_o[m], PQ3D_F32, base, lane, d.d, go);
+    if (d.dx && !d.independent) {
+      if (d.M == 1 || d.sum_branches) store_row<PL, VEC>(d.dx, PQ3D_F32, base, lane, d.d, g);
+      else {
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+          const int c = colof<PL, VEC>(lane, j);
+          if (c < d.d) unsafeAtomicAdd(&d.dx[base + c], g[j]);
         }
       }
     }
   }
-  // block-level reduction of the parameter-gradient partials, then ONE atomic per column per block
+  // block-level reduction of the parameter-gradient partials (LDS index = column)
   const int wave = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < PL; ++j) {
-    red[0][wave][lane + 64 * j] = dg[j];
-    red[1][wave][lane + 64 * j] = db[j];
+    const int c = colof<PL, VEC>(lane, j);
+    red[0][wave][c] = dg[j];
+    red[1][wave][c] = db[j];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < d.d; c += WPB * 64) {
+  for (int c = threadIdx.x; c < d.d; c += NW * 64) {   // ONE atomic per column per block
     float sg = 0.f, sb = 0.f;
 #pragma unroll
-    for (int w = 0; w < WPB; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; }
+    for (int w = 0; w < NW; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; }
     unsafeAtomicAdd(&d.dgamma[m][c], sg);
     unsafeAtomicAdd(&d.dbeta[m][c], sb);
   }
@@ -227,12 +279,29 @@ int check_ln(const pq3d_ln_desc& d, bool bwd) {
   return 0;
 }
 
-#define LN_DISPATCH(kernel, grid)                                                             \
-  if (d.d <= 64) hipLaunchKernelGGL((kernel<1>), grid, dim3(WPB * 64), 0, s, d);              \
-  else if (d.d <= 128) hipLaunchKernelGGL((kernel<2>), grid, dim3(WPB * 64), 0, s, d);        \
-  else if (d.d <= 256) hipLaunchKernelGGL((kernel<4>), grid, dim3(WPB * 64), 0, s, d);        \
-  else if (d.d <= 512) hipLaunchKernelGGL((kernel<8>), grid, dim3(WPB * 64), 0, s, d);        \
-  else hipLaunchKernelGGL((kernel<16>), grid, dim3(WPB * 64), 0, s, d);
+// VEC: whole rows in 16-byte pieces (d == 64 * PL with PL a multiple of 4, every operand 16-byte aligned)
+bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd) {
+  if (d.d != 256 && d.d != 512 && d.d != 1024) return false;
+  auto al = [](const void* p, int dt) { return ((uintptr_t)p & (dt == PQ3D_F32 ? 15 : 7)) == 0; };
+  bool ok = al(d.x, d.dt_x);
+  const int nm = d.M;
+  for (int m = 0; m < nm; ++m) {
+    const bool first = m == 0 || !d.sum_branches;
+    ok = ok && al(d.o[m], d.dt_o);
+    if (first) ok = ok && al(d.gamma[m], PQ3D_F32) && al(d.beta[m], PQ3D_F32);
+    if (d.independent) ok = ok && (bwd ? al(d.dys[m], PQ3D_F32) : al(d.ys[m], d.dt_y));
+    if (bwd && first) ok = ok && al(d.d_o[m], PQ3D_F32);
+  }
+  if (!d.independent) ok = ok && (bwd ? al(d.dy, PQ3D_F32) && al(d.dx, PQ3D_F32) : al(d.y, d.dt_y));
+  return ok && al(d.osum, PQ3D_F32);
+}
+
+#define LN_DISPATCH(LAUNCH, vec)                                                       \
+  if (d.d <= 64) { LAUNCH(1, false); }                                                 \
+  else if (d.d <= 128) { LAUNCH(2, false); }                                           \
+  else if (d.d <= 256) { if (vec) { LAUNCH(4, true); } else { LAUNCH(4, false); } }    \
+  else if (d.d <= 512) { if (vec) { LAUNCH(8, true); } else { LAUNCH(8, false); } }    \
+  else { if (vec) { LAUNCH(16, true); } else { LAUNCH(16, false); } }
 
 }  // namespace
 
@@ -242,8 +311,15 @@ extern "C" int pq3d_add_ln_fwd(const pq3d_ln_desc* dp, void* stream) {
   if (int e = check_ln(d, false)) return e;
   if (d.R == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)((d.R + WPB - 1) / WPB), d.independent ? d.M : 1);
-  LN_DISPATCH(add_ln_fwd_kernel, grid)
+  // one row per wave up to 4096 rows; beyond that waves walk rows (next row's loads in flight behind the statistics)
+  long nb = (d.R + WPB - 1) / WPB;
+  if (nb > 1024) nb = max(1024L, (d.R + 4 * WPB - 1) / (4 * WPB));
+  if (nb > 4096) nb = 4096;
+  dim3 grid((unsigned)nb, d.independent ? d.M : 1);
+  const bool vec = ln_vec_ok(d, false);
+#define FWD(PLV, V) hipLaunchKernelGGL((add_ln_fwd_kernel<PLV, V>), grid, dim3(WPB * 64), 0, s, d)
+  LN_DISPATCH(FWD, vec)
+#undef FWD
   PQ_LAUNCH_CHECK();
   return 0;
 }
@@ -261,13 +337,23 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
     if (int e = pq3d_zero_launch(z, s)) return e;
   }
   if (d.R == 0) return 0;
-  // two rows per wave (software-pipelined); one atomic per column per block for the parameter gradients
-  const int rpw = d.R >= 4096 ? 4 : 2;   // measured: 2 rows/wave is best for R=800, 4 for R=8192 (atomics)
-  long nb = (d.R + rpw * WPB - 1) / (rpw * WPB);
+  // rows per wave (software-pipelined): 2 for the query-sized calls, more for the big streaming ones (fewer blocks ->
+  // fewer parameter-gradient atomics per column)
+  // big streaming calls: 8 waves per block, 8 rows per wave -- the parameter-gradient atomics (one per column per block,
+  // the 64-byte lines bounce between the XCDs' L2s) set the time, so few fat blocks win: measured at R = 2 x 8192,
+  // blocks x waves: 1024x4 43 us, 512x4 28, 256x4 20, 256x8 16, 128x16 15, 64x16 28; query-sized calls: 4 waves x 2 rows
+  const bool big = d.R >= 4096;
+  const int rpw = big ? 8 : 2, nw = big ? 8 : 4;
+  long nb = (d.R + rpw * nw - 1) / (rpw * nw);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb, d.sum_branches ? 1 : d.M);
-  LN_DISPATCH(add_ln_bwd_kernel, grid)
+  const bool vec = ln_vec_ok(d, true);
+#define BWD8(PLV, V) hipLaunchKernelGGL((add_ln_bwd_kernel<PLV, V, 8>), grid, dim3(512), 0, s, d)
+#define BWD4(PLV, V) hipLaunchKernelGGL((add_ln_bwd_kernel<PLV, V, 4>), grid, dim3(256), 0, s, d)
+  if (big) { LN_DISPATCH(BWD8, vec) } else { LN_DISPATCH(BWD4, vec) }
+#undef BWD8
+#undef BWD4
   PQ_LAUNCH_CHECK();
   return 0;
 }

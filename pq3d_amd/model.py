@@ -270,6 +270,17 @@ class Query3DUnified(nn.Module):
         data_dict["query_embeds"] = query  # extra key (the reference does not expose the final query)
         return data_dict
 
+    def unused_parameters(self):
+        """Parameters that can never receive a gradient: the generation head's T5 ENCODER stack, bypassed through
+        ``encoder_outputs`` (modules/heads/generation_head.py: the decoder cross-attends to the query tokens).  The shared
+        token embedding is used by the decoder and stays.  TrainStep keeps these out of the flat optimizer (torch.optim.AdamW
+        in the reference skips grad-None parameters)."""
+        head = getattr(self, "generation_head", None)
+        if head is None:
+            return []
+        shared = {id(p) for p in head.model.shared.parameters()}
+        return [p for p in head.model.encoder.parameters() if id(p) not in shared]
+
     def get_opt_params(self):
         """model/query3d_unified.py:224-238."""
         def get_lr(c, default_lr):

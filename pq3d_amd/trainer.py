@@ -31,36 +31,7 @@ class TrainStep:
                  grad_norm: Optional[float] = None, sched: str = "warmup_cosine", warmup_steps: int = 0,
                  total_steps: int = 1, sched_gamma: float = 1.0, num_gpu: int = 1, group=None):
         groups = list(opt_groups) if opt_groups is not None else model.get_opt_params()
-        groups = [g for g in groups if len(g["params"])]
-        if len(groups) > L.MAX_OPT_SEGMENTS:   # merge groups with equal (lr, weight_decay), keeping first-seen order
-            merged: Dict[tuple, dict] = {}
-            for g in groups:
-                merged.setdefault((g["lr"], g["weight_decay"]), {"params": [], "lr": g["lr"],
-                                                                  "weight_decay": g["weight_decay"]})["params"] += g["params"]
-            groups = list(merged.values())
-        assert len(groups) <= L.MAX_OPT_SEGMENTS, "too many distinct (lr, weight_decay) parameter groups"
         self.model, self.loss_fn, self.group = model, loss_fn, group
-        params = [p for g in groups for p in g["params"]]
-        assert len({id(p) for p in params}) == len(params), "a parameter appears in two groups"
-        dev = params[0].device
-        self.reducer = FlatGradAllReducer(params, bucket_bytes=1 << 62, group=group, keep_order=True)
-        self.flat_g = self.reducer.flat[0]
-        n = self.flat_g.numel()
-        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.segs = L.OptSegments()
-        self.segs.n = len(groups)
-        off = 0
-        for s, g in enumerate(groups):
-            for p in g["params"]:
-                k = p.numel()
-                self.flat_p[off:off + k].copy_(p.data.reshape(-1))
-                p.data = self.flat_p[off:off + k].view(p.shape)     # parameter storage now lives in the flat buffer
-                off += k
-            self.segs.end[s] = off
-            self.segs.lr_mul[s] = g["lr"] / lr
-            self.segs.weight_decay[s] = g["weight_decay"]
         self.hp = L.AdamWHp()
         self.hp.lr, self.hp.beta1, self.hp.beta2, self.hp.eps = lr, betas[0], betas[1], eps
         self.hp.max_grad_norm = float(grad_norm) if grad_norm else 0.0
@@ -70,11 +41,56 @@ class TrainStep:
         self.hp.warmup_steps = int(warmup_steps) * int(num_gpu)
         self.hp.sched_stride = int(num_gpu)
         self.hp.total_steps, self.hp.sched_gamma = int(total_steps), float(sched_gamma)
-        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.partials = torch.zeros(L.SUMSQ_PARTIALS, dtype=torch.float32, device=dev)
-        self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)   # lr, lr/bc1, 1/sqrt(bc2), clip, |g|, -
+        # torch.optim.AdamW (the reference's optimizer) skips a parameter whose .grad is None: no decay, no moment update;
+        # the flat kernel updates every element of the flat buffer.  So the flat buffer holds only parameters that DO get
+        # gradients: ``model.unused_parameters()`` (the bypassed T5 encoder of the generation head) are left out up front,
+        # and the first step probes the rest (as DDP's find_unused_parameters does, trainer/build.py:66-75): parameters
+        # without a gradient are dropped from the layout before any update (forward_backward).  A parameter used only in
+        # SOME steps keeps being decayed in the steps it is unused -- the remaining, documented divergence.
+        unused = {id(p) for p in (model.unused_parameters() if hasattr(model, "unused_parameters") else ())}
+        self._probed = False
+        self._layout([dict(g, params=[p for p in g["params"] if id(p) not in unused]) for g in groups])
+
+    def _layout(self, groups) -> None:
+        """(Re)build the flat parameter / gradient / moment buffers over ``groups``; parameters keep their values."""
+        lr = self.hp.lr
+        groups = [g for g in groups if len(g["params"])]
+        if len(groups) > L.MAX_OPT_SEGMENTS:   # merge groups with equal (lr, weight_decay), keeping first-seen order
+            merged: Dict[tuple, dict] = {}
+            for g in groups:
+                merged.setdefault((g["lr"], g["weight_decay"]), {"params": [], "lr": g["lr"],
+                                                                  "weight_decay": g["weight_decay"]})["params"] += g["params"]
+            groups = list(merged.values())
+        assert len(groups) <= L.MAX_OPT_SEGMENTS, "too many distinct (lr, weight_decay) parameter groups"
+        self.groups = groups
+        params = [p for g in groups for p in g["params"]]
+        assert len({id(p) for p in params}) == len(params), "a parameter appears in two groups"
+        dev = params[0].device
+        self.reducer = FlatGradAllReducer(params, bucket_bytes=1 << 62, group=self.group, keep_order=True)
+        self.flat_g = self.reducer.flat[0]
+        n = self.flat_g.numel()
+        flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.segs = L.OptSegments()
+        self.segs.n = len(groups)
+        off = 0
+        for s, g in enumerate(groups):
+            for p in g["params"]:
+                k = p.numel()
+                flat_p[off:off + k].copy_(p.data.reshape(-1))
+                p.data = flat_p[off:off + k].view(p.shape)     # parameter storage now lives in the flat buffer
+                off += k
+            self.segs.end[s] = off
+            self.segs.lr_mul[s] = g["lr"] / lr
+            self.segs.weight_decay[s] = g["weight_decay"]
+        self.flat_p = flat_p
+        if not hasattr(self, "step_count"):
+            self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.partials = torch.zeros(L.SUMSQ_PARTIALS, dtype=torch.float32, device=dev)
+            self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)   # lr, lr/bc1, 1/sqrt(bc2), clip, |g|, -
         # the fused decoder writes parameter gradients straight into flat_g (no pack copy)
-        enc = getattr(model, "unified_encoder", None)
+        enc = getattr(self.model, "unified_encoder", None)
         if enc is not None:
             enc.grad_arena = self.reducer.slots()
             enc.grad_arena_buffers = self.reducer.flat
@@ -88,6 +104,18 @@ class TrainStep:
         out = self.model(dict(data_dict))
         loss = self.loss_fn(out)
         loss.backward()
+        if not self._probed and not torch.cuda.is_current_stream_capturing():
+            self._probed = True
+            missing = {id(p) for p in self.reducer.params if p.grad is None}
+            if missing:
+                # first step: parameters this configuration never reaches leave the flat buffer (own storage, never updated --
+                # what torch.optim.AdamW does with grad-None parameters); nothing has been updated yet, so re-laying out and
+                # re-running the step is exact
+                for p in self.reducer.params:
+                    if id(p) in missing:
+                        p.data = p.data.clone()
+                self._layout([dict(g, params=[p for p in g["params"] if id(p) not in missing]) for g in self.groups])
+                return self.forward_backward(data_dict)
         self.reducer.pack()
         return loss.detach()
 

@@ -144,3 +144,16 @@ def test_instseg_loss_wrapper_direct_and_set_match_reference_fixtures():
     total9, _ = InstSegLoss(_loss_cfg("set"))(dd)
     assert abs(total9.item() - float(z9["total"])) <= 2e-5 * abs(float(z9["total"]))
     assert len(dd["indices"]) == len(labels9)
+
+
+def test_cross_entropy_out_of_range_label_poisons_the_loss():
+    """torch device-asserts on a label outside [0, C); the CE kernel must not read out of bounds silently: NaN loss."""
+    from pq3d_amd.losses import cross_entropy_rows
+    x = torch.randn(16, 7, device="cuda")
+    t = torch.randint(0, 7, (16,), device="cuda")
+    assert torch.isfinite(cross_entropy_rows(x, t))
+    for bad in (7, -3, 1 << 40):
+        tb = t.clone(); tb[5] = bad
+        assert torch.isnan(cross_entropy_rows(x, tb))
+    ti = t.clone(); ti[5] = -100
+    assert torch.isfinite(cross_entropy_rows(x, ti))

@@ -150,3 +150,57 @@ def test_multi_process_lr_schedule_matches_oracle(num_gpu):
         # == adamw_step(..., num_gpu=num_gpu)'s learning rate for optimizer step s (oracle/train_oracle.py)
         want = 1e-3 * T.lr_factor("warmup_cosine", s * num_gpu, 2 * num_gpu, 40)
         assert abs(float(ts.last_lr) - want) <= 1e-9 + 1e-6 * want, (s, float(ts.last_lr), want)
+
+
+def test_bypassed_t5_encoder_is_not_touched_by_the_flat_optimizer():
+    """torch.optim.AdamW skips grad-None parameters (no weight decay, no moments).  The generation head's T5 encoder is
+    bypassed (encoder_outputs) and never gets a gradient: TrainStep keeps it out of the flat buffer, so three steps leave
+    it bit-identical while the decoder side moves."""
+    from pq3d_amd import synth
+    from pq3d_amd.model import Query3DUnified, make_cfg
+    _z, a = util.load_fixture("F8_t5_head")
+    model = Query3DUnified(make_cfg(d=64, H=4, L=2, memories=["voxel", "mv"], heads=["generation"], t5=a["hf_config"]),
+                           compute="fp32")
+    synth.fill_module(model, 0)
+    model.to(DEV).train()       # eval mode generates tokens instead of logits
+    unused = model.unused_parameters()
+    assert len(unused) > 0
+    before = [p.detach().clone() for p in unused]
+    proj_before = model.generation_head.input_proj[0].weight.detach().clone()
+    dd = synth.synth_data_dict(2, 64, 10, {"voxel": 64, "mv": 64}, seed=3, memories=["voxel", "mv"])
+    dd["response"] = torch.randint(2, 128, (2, 6))
+    dd = {k: v.to(DEV) for k, v in dd.items()}
+
+    def loss_fn(out):
+        return torch.nn.functional.cross_entropy(out["generation_logits"].flatten(0, 1), out["generation_label"].flatten())
+
+    ts = TrainStep(model, loss_fn, lr=1e-3, grad_norm=1.0, warmup_steps=0, total_steps=10)
+    flat_ids = {id(p) for p in ts.reducer.params}
+    assert not any(id(p) in flat_ids for p in unused)
+    for _ in range(3):
+        ts.step(dd)
+    assert all(p.grad is not None for p in ts.reducer.params)      # the flat buffer holds exactly the parameters in use
+    assert all(torch.equal(p, b) for p, b in zip(unused, before))
+    assert not torch.equal(model.generation_head.input_proj[0].weight, proj_before)
+
+
+def test_first_step_drops_parameters_without_gradient_from_the_flat_buffer():
+    """A head the loss never reaches gets no gradient; torch.optim.AdamW would neither decay nor move it.  The first step
+    re-lays the flat buffer out without it (before any update), and later steps leave it bit-identical."""
+    for name in util.fixtures("F7_"):
+        _z, args = util.load_fixture(name)
+        model, ts, dd = build(args)
+        ids0, n0 = {id(p) for p in ts.reducer.params}, ts.flat_p.numel()
+        ts.forward_backward(dd)                                   # the probing step (no optimizer update yet)
+        kept = {id(p) for p in ts.reducer.params}
+        dropped = [p for p in model.parameters() if id(p) in ids0 and id(p) not in kept]
+        if dropped:
+            break
+    else:
+        pytest.skip("no F7 fixture with an unreached parameter")
+    before = [p.detach().clone() for p in dropped]
+    assert ts.flat_p.numel() == n0 - sum(p.numel() for p in dropped)
+    for _ in range(3):
+        ts.step(dd)
+    assert all(torch.equal(p, b) for p, b in zip(dropped, before))
+    assert all(p.grad is not None for p in ts.reducer.params)

@@ -1,22 +1,32 @@
 #!/bin/bash
-# Regenerates the judged evidence under gpurun_out/ on the GPU box (copy into profiles/ afterwards):
-#   bench JSON (with cpu_baseline), per-entry kernel table, rocprofv3 kernel stats, PMC FETCH/WRITE passes.
-# usage (from the repo root on the GPU box): bash tools/refresh_profiles.sh <tag>
+# Regenerates the judged evidence under gpurun_out/<tag>/ on the GPU box (copy what should be judged into profiles/):
+#   per config: bench JSON (roofline + cpu_baseline), per-entry kernel table, rocprofv3 kernel stats of the replayed
+#   step, the step's dispatch sequence, and HBM traffic per kernel from separate --pmc passes (FETCH_SIZE, WRITE_SIZE).
+# usage (from the repo root on the GPU box): bash tools/refresh_profiles.sh <tag> [configs...]
+# Order matters: the PMC pass of a config runs BEFORE its bench so that bench.py finds profiles/pmc_traffic_<tag>_<cfg>.json
+# (roofline.traffic of the same build).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}; shift
+CONFIGS=${@:-c2 c4 c5}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-if [ "${SKIP_BENCH:-0}" != "1" ]; then
-python $R/bench.py --dump-kernels $OUT/kernel_table_c2.txt > $OUT/bench_c2_1gpu.json 2> $OUT/bench_c2.err
-python $R/bench.py --config c4 --steps 20 --warmup 5 --cpu-steps 0 --dump-kernels $OUT/kernel_table_c4.txt > $OUT/bench_c4_1gpu.json 2> $OUT/bench_c4.err
-fi
-rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats -d /tmp/ks -o s -- python $R/bench.py --steps 20 --warmup 5 --cpu-steps 0 --profile-steps 1 --headline-only > $OUT/bench_under_rocprof.json 2>/dev/null
-python $R/tools/rocprof_summary.py $(find /tmp/ks -name "*.db" | head -1) 26 > $OUT/rocprofv3_kernel_stats_c2.txt
-for cnt in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$cnt
-  rocprofv3 --kernel-trace --pmc $cnt -d /tmp/pmc_$cnt -o p -- python $R/bench.py --no-graph --steps 3 --warmup 1 --cpu-steps 0 --profile-steps 1 --headline-only > /dev/null 2>&1
+for CFG in $CONFIGS; do
+  for cnt in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_$cnt
+    timeout 600 rocprofv3 --kernel-trace --pmc $cnt -d /tmp/pmc_$cnt -o p -- python $R/bench.py --config $CFG --no-graph --steps 3 --warmup 1 --cpu-steps 0 --profile-steps 1 --headline-only > /dev/null 2>&1
+  done
+  F=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
+  python $R/tools/rocprof_pmc_summary.py $F $W > $OUT/rocprofv3_pmc_hbm_traffic_${TAG}_$CFG.txt
+  python $R/tools/pmc_traffic_json.py $F $W > $OUT/pmc_traffic_${TAG}_$CFG.json
+  cp $OUT/pmc_traffic_${TAG}_$CFG.json $R/profiles/pmc_traffic_${TAG}_$CFG.json
+  STEPS=50; [ $CFG != c2 ] && STEPS=20
+  timeout 900 python $R/bench.py --config $CFG --steps $STEPS --warmup 10 --dump-kernels $OUT/kernel_table_${TAG}_fused_$CFG.txt > $OUT/bench_${TAG}_${CFG}_1gpu.json 2> $OUT/bench_$CFG.err
+  rm -rf /tmp/ks
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks -o s -- python $R/bench.py --config $CFG --steps 20 --warmup 5 --cpu-steps 0 --profile-steps 1 --headline-only > $OUT/bench_under_rocprof_$CFG.json 2>/dev/null
+  DB=$(find /tmp/ks -name "*.db" | head -1)
+  python $R/tools/rocprof_summary.py $DB 30 > $OUT/rocprofv3_kernel_stats_${TAG}_fused_graph_$CFG.txt
+  python $R/tools/rocprof_step_sequence.py $DB > $OUT/rocprofv3_step_sequence_${TAG}_$CFG.txt 2>&1
 done
-python $R/tools/rocprof_pmc_summary.py $(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1) > $OUT/rocprofv3_pmc_hbm_traffic_c2.txt
 echo done
