@@ -192,8 +192,10 @@ int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
  *   bit 0: the all-queries-resident single-pass backward (cross-attention shape: bf16, d_h 32 / 64, Lq <= 128,
  *          Lk >= 128, no additive bias);
  *   bit 1: the small-sequence fp32 kernels (self-attention shape: fp32, Lq, Lk <= 128, key padding / additive bias only,
- *          one workgroup per (scene, head)).
- * This process-wide switch sets which of them may be used (default 3 = both; for A/B measurements and tests) and returns
+ *          one workgroup per (scene, head));
+ *   bit 2: the all-keys-resident forward (cross-attention shape: bf16, d_h 32, Lq <= 128, Lk >= 128, key-padding mask
+ *          only, at most 1024 keys per key split: ksplit >= ceil(Lk / 1024)).
+ * This process-wide switch sets which of them may be used (default 7 = all; for A/B measurements and tests) and returns
  * the previous value. */
 int pq3d_attn_resident(int enable);
 

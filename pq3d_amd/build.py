@@ -17,7 +17,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # per-file extras.  attn_resident.hip: MFMA results feed the softmax VALU code directly; with the default AGPR form of the
 # MFMAs the compiler shuttles every S / dP tile through v_accvgpr_read / _write (352 extra VALU-slot moves per 4 query
 # pairs); the VGPR form removes them (gfx950 has one unified register file).
-EXTRA = {"attn_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# attn_resident.hip: MFMA results in VGPRs (no accumulator-register copies around the softmax);  -fno-honor-nans drops the
+# NaN-canonicalising v_max x,x that every fmaxf otherwise costs (32 of ~150 VALU instructions per 64-key block of the
+# forward; the kernels never produce or test NaNs: masked scores are -inf, the running max starts at -1e30)
+EXTRA = {"attn_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"]}
 
 
 def _stale() -> bool:

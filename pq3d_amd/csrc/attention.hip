@@ -24,13 +24,16 @@ extern "C" int pq3d_attn_debug_read(long long* out) { return (int)hipMemcpyFromS
 #include "attn_common.h"
 
 bool pq3d_attn_bwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // attn_resident.hip
+bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // attn_resident.hip
 bool pq3d_attn_small_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);   // attn_small.hip
-static int g_resident = 1, g_small = 1;
-// bit 0: all-queries-resident backward, bit 1: small-sequence fp32 kernels (both on by default)
+static int g_resident = 1, g_small = 1, g_resfwd = 1;
+// bit 0: all-queries-resident backward, bit 1: small-sequence fp32 kernels, bit 2: all-keys-resident forward (all on by
+// default)
 extern "C" int pq3d_attn_resident(int enable) {
-  const int old = g_resident | (g_small << 1);
+  const int old = g_resident | (g_small << 1) | (g_resfwd << 2);
   g_resident = enable & 1;
   g_small = (enable >> 1) & 1;
+  g_resfwd = (enable >> 2) & 1;
   return old;
 }
 
@@ -751,7 +754,8 @@ template <typename CT, int DH, bool DROP, bool MASK3> void launch_fwd_k(const pq
 template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream_t s) {
   const int tiles = (d.Lq + 15) / 16, ks = d.ksplit > 1 ? d.ksplit : 1;
   const bool dr = d.drop.p > 0.f && d.drop.seed, m3 = d.mask != nullptr;
-  if (dr) { if (m3) launch_fwd_k<CT, DH, true, true>(d, s, tiles, ks); else launch_fwd_k<CT, DH, true, false>(d, s, tiles, ks); }
+  if (g_resfwd && pq3d_attn_fwd_resident_try(d, s)) {
+  } else if (dr) { if (m3) launch_fwd_k<CT, DH, true, true>(d, s, tiles, ks); else launch_fwd_k<CT, DH, true, false>(d, s, tiles, ks); }
   else { if (m3) launch_fwd_k<CT, DH, false, true>(d, s, tiles, ks); else launch_fwd_k<CT, DH, false, false>(d, s, tiles, ks); }
   if (ks > 1) {
     const long n = (long)d.B * d.H * d.Lq * (DH / 4);

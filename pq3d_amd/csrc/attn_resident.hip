@@ -373,7 +373,233 @@ template <int DH> bool launch_res_dh(const pq3d_attn_desc& d, hipStream_t s) {
   return true;
 }
 
+// ------------------------------------------------------------------------------------------------ forward
+// All-keys-resident forward for the same shape (N_q <= 128, d_h = 32, bf16, key-padding mask only).  The streaming
+// forward of attention.hip walks 64-key tiles through a two-stage register/LDS pipeline with a workgroup barrier per
+// tile; at 4 KB per tile the loop is bound by one global round trip per tile (24 us for 8 tiles at config 2), not by its
+// 16 MFMAs.  Here the workgroup requests its WHOLE key/value slice (<= 1024 keys: 128 KB) up front -- every 16-byte load
+// in flight at once --, parks it in LDS behind ONE barrier, and then each wave runs the online-softmax loop of its 16
+// queries over all key blocks without any further synchronisation.  1024 keys per workgroup means config 2 needs no key
+// split, so the combine launch goes away as well.  K rows are stored unpadded (64-byte rows: the 64 lanes of a fragment
+// read cover 1 KB exactly once), V rows padded for the transposing reads.  Same arithmetic and rounding points as the
+// streaming kernel (P and V in bf16, fp32 accumulation, exp2-free __expf); only the block order of the online softmax
+// differs with the split count.
+constexpr int FW = 8;            // compute waves = 16-query tiles
+constexpr int FLW = 4;           // loader waves: bring in the second half of the slice while the first is multiplied
+constexpr int FKMAX = 1024;      // keys per workgroup
+constexpr int FK1 = FKMAX / 2;   // keys of stage 1 (loaded by the compute waves themselves)
+constexpr int NB1 = FK1 / KB;
+constexpr int FCH1 = FK1 * 4 / (FW * 64);    // 16-byte chunks of K (and of V) per compute thread, stage 1   (4)
+constexpr int FCH2 = FK1 * 4 / (FLW * 64);   // ... per loader thread, stage 2                              (8)
+
+template <bool DROP>
+__global__ __launch_bounds__((FW + FLW) * 64) void attn_fwd_resident_kernel(const pq3d_attn_desc d) {
+  constexpr int DH = 32;
+  typedef AT<bf16_t, DH> A;
+  constexpr int LDK = DH, LDV = A::LDR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, split = blockIdx.x;
+  const int KS = d.ksplit > 1 ? d.ksplit : 1;
+  const int nkb = (d.Lk + KB - 1) / KB;
+  const int kb_lo = (int)((long)nkb * split / KS), kb_hi = (int)((long)nkb * (split + 1) / KS);
+  const int nb = kb_hi - kb_lo, key_lo = kb_lo * KB, nk = nb * KB;
+  bf16_t* Ks = (bf16_t*)fsm;
+  bf16_t* Vs = Ks + nk * LDK;
+  uint8_t* kpm_s = (uint8_t*)(Vs + nk * LDV);
+  const bool loader = wave >= FW;   // wave-uniform role
+  const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
+  // one 16-byte chunk of a K row and of the same V row: global -> registers (rows past the slice / past Lk: clamped
+  // duplicates, never stored / masked through kpm_s)
+  auto gload = [&](int c, u32x4& kx, u32x4& vx) {
+    c = min(c, nk * 4 - 1);
+    const int gk = min(key_lo + (c >> 2), d.Lk - 1), part = (c & 3) * 8;
+    kx = *(const u32x4*)((const bf16_t*)d.k + koff + (long)gk * d.k_sl + part);
+    vx = *(const u32x4*)((const bf16_t*)d.v + voff + (long)gk * d.v_sl + part);
+  };
+  auto park = [&](int c, const u32x4& kx, const u32x4& vx) {
+    if (c < nk * 4) {
+      *(u32x4*)&Ks[(c >> 2) * LDK + (c & 3) * 8] = kx;
+      *(u32x4*)&Vs[(c >> 2) * LDV + (c & 3) * 8] = vx;
+    }
+  };
+  const int q0 = wave * 16, myq = q0 + li;
+  const bool wave_active = !loader && q0 < d.Lq, qvalid = !loader && myq < d.Lq;
+  u32x4 qf[A::NS];
+  // The load counter is per wave and in-order, and the compiler waits conservatively at loop headers: the waves that
+  // multiply must not have loads in flight.  So the second half of the slice belongs to 4 LOADER waves that only fetch,
+  // park and synchronise; the 8 compute waves fetch the first half (and the mask bytes and their Q fragments).
+  if (!loader) {
+    row_frags<bf16_t, DH>(qf, d.q, (long)b * d.q_sb + (long)min(myq, d.Lq - 1) * d.q_sl + (long)h * d.q_sh, lg);
+    uint8_t kp[FKMAX / (FW * 64)];
+#pragma unroll
+    for (int i = 0; i < FKMAX / (FW * 64); ++i) {
+      const int j = tid + i * FW * 64;
+      kp[i] = (j < nk && key_lo + j < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + key_lo + j] : 0) : 1;
+    }
+    u32x4 kr[FCH1], vr[FCH1];
+#pragma unroll
+    for (int i = 0; i < FCH1; ++i) gload(tid + i * FW * 64, kr[i], vr[i]);
+#pragma unroll
+    for (int i = 0; i < FKMAX / (FW * 64); ++i) {
+      const int j = tid + i * FW * 64;
+      if (j < nk) kpm_s[j] = kp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < FCH1; ++i) park(tid + i * FW * 64, kr[i], vr[i]);
+  }
+  u32x4 kr2[FCH2], vr2[FCH2];
+  const int t2 = tid - FW * 64;
+  if (loader && nb > NB1) {
+#pragma unroll
+    for (int i = 0; i < FCH2; ++i) gload(FK1 * 4 + t2 + i * FLW * 64, kr2[i], vr2[i]);
+  }
+
+  // online softmax in the base-2 domain: x2 = s * (scale * log2 e), p = 2^(x2 - m2) -- one multiply folded into the
+  // scale, v_exp_f32 is a base-2 exponential
+  const float sc2 = d.scale * 1.44269504088896341f;
+  const bool zero0 = d.zero_attn && split == 0;   // the zero key (add_zero_attn) is the initial state of split 0 only
+  float m = zero0 ? 0.f : -1e30f, l = (zero0 && lg == 0) ? 1.f : 0.f;
+  f32x4 acc[A::MT];
+#pragma unroll
+  for (int mt = 0; mt < A::MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  DropState dst;
+  uint32_t drow = 0;
+  if constexpr (DROP) {
+    dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, d.Lk);
+    drow = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * d.Lq + min(myq, d.Lq - 1));
+  }
+  auto block = [&](int t) {
+    const bf16_t* Kt = Ks + t * KB * LDK;
+    const bf16_t* Vt = Vs + t * KB * LDV;
+    uint32_t mw[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) mw[tt] = *(const uint32_t*)&kpm_s[t * KB + tt * 16 + 4 * lg];
+    // a fully padded block contributes nothing (the 4 lane groups together hold all 64 key bytes)
+    if (__all((mw[0] & mw[1] & mw[2] & mw[3]) == 0x01010101u)) return;
+    // every LDS read of the block is issued before the first MFMA (K fragments, then the transposed V fragments that
+    // are only needed after the softmax)
+    u32x4 kf[4], vf[A::MT][2];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) kf[tt] = rfrag<bf16_t>(&Kt[(tt * 16 + li) * LDK], 0, lg);
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) vf[mt][u] = tfrag_tr(Vt, LDV, u * 32, mt * 16, li, lg);
+    f32x4 sc[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      Mma<bf16_t>::mma(sc[tt], kf[tt], qf[0]);
+    }
+    if (!__all((mw[0] | mw[1] | mw[2] | mw[3]) == 0u)) {   // padded keys in the block (the tail only): raw score -> -inf
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[tt][r] = ((mw[tt] >> (8 * r)) & 0xffu) ? -INFINITY : sc[tt][r];
+    }
+    // max over the RAW scores (sc2 > 0 commutes with max), then one fused multiply-subtract + one base-2 exponential
+    // per element
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) mx = fmaxf(fmaxf(mx, fmaxf(sc[tt][0], sc[tt][1])), fmaxf(sc[tt][2], sc[tt][3]));
+    mx = group_max(mx) * sc2;
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float p[4][4];
+    float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[tt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tt][r], sc2, -m_new));
+      rs0 += p[tt][0] + p[tt][1];
+      rs1 += p[tt][2] + p[tt][3];
+    }
+    l = l * alpha + (rs0 + rs1);   // per-lane partial (alpha is uniform over the query's 4 lanes)
+    m = m_new;
+    if constexpr (DROP) {   // the softmax denominator keeps every key; only the value contraction sees the mask
+      const int k0 = key_lo + t * KB;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const uint32_t cp = (uint32_t)(k0 + tt * 16 + 4 * lg) >> 1;
+        const uint32_t w0 = drop_word(dst, drow, cp), w1 = drop_word(dst, drow, cp + 1);
+        p[tt][0] = drop_keep_lo(dst, w0) ? p[tt][0] : 0.f;
+        p[tt][1] = drop_keep_hi(dst, w0) ? p[tt][1] : 0.f;
+        p[tt][2] = drop_keep_lo(dst, w1) ? p[tt][2] : 0.f;
+        p[tt][3] = drop_keep_hi(dst, w1) ? p[tt][3] : 0.f;
+      }
+    }
+    u32x4 pf[2];
+    PackP<bf16_t, 4>::run(p, pf);
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt) {
+      acc[mt] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) Mma<bf16_t>::mma(acc[mt], vf[mt][u], pf[u]);
+    }
+  };
+  // two stages: the first 512 keys are multiplied while the loader waves bring in the rest of the slice
+  __syncthreads();
+  if (wave_active)
+    for (int t = 0; t < min(nb, NB1); ++t) block(t);
+  if (loader && nb > NB1) {
+#pragma unroll
+    for (int i = 0; i < FCH2; ++i) park(FK1 * 4 + t2 + i * FLW * 64, kr2[i], vr2[i]);
+  }
+  __syncthreads();
+  if (wave_active)
+    for (int t = NB1; t < nb; ++t) block(t);
+  l = group_sum(l);
+  if (!qvalid) return;
+  constexpr float LN2 = 0.693147180559945309f;
+  if (KS == 1) {
+    const float inv = (DROP ? dst.scale : 1.f) / l;
+    bf16_t* op = (bf16_t*)d.o + (long)b * d.o_sb + (long)myq * d.o_sl + (long)h * d.o_sh + 4 * lg;
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+      *(u32x2*)(op + mt * 16) = (u32x2){pack_bf2(acc[mt][0] * inv, acc[mt][1] * inv), pack_bf2(acc[mt][2] * inv, acc[mt][3] * inv)};
+    if (lg == 0) d.lse[((long)b * d.H + h) * d.Lq + myq] = m * LN2 + logf(l);
+  } else {   // partial softmax state for attention.hip's combine kernel (same layout as the streaming forward)
+    const long rows = (long)d.B * d.H * d.Lq, ridx = (((long)split * d.B + b) * d.H + h) * d.Lq + myq;
+    float* po = d.ws + ridx * DH;
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+      *(float4*)(po + mt * 16 + 4 * lg) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    if (lg == 0) {
+      d.ws[(long)KS * rows * DH + ridx] = m * LN2;   // natural-log domain, as the combine kernel expects
+      d.ws[(long)KS * rows * (DH + 1) + ridx] = l;
+    }
+  }
+}
+
+template <bool DROP> void launch_fwd_res(const pq3d_attn_desc& d, hipStream_t s, int KS, int nk_max) {
+  const size_t lds = (size_t)nk_max * (32 * 2 + AT<bf16_t, 32>::LDR * 2 + 1) + 16;
+  auto kern = attn_fwd_resident_kernel<DROP>;
+  static size_t attr_lds = 0;   // > 64 KB of dynamic LDS needs the opt-in (raised when a larger slice shows up)
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(KS, d.H, d.B), dim3((FW + FLW) * 64), lds, s, d);
+}
+
 }  // namespace
+
+// Forward twin of the resident backward: bf16, d_h = 32, N_q <= 128, key-padding mask only, at most 1024 keys per
+// (scene, head, split) workgroup.  Returns false otherwise (attention.hip's streaming forward); for ksplit > 1 the caller
+// launches the combine kernel exactly as for the streaming kernel.
+bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
+  if (d.ct != PQ3D_BF16 || d.dt != PQ3D_BF16 || d.bias || d.mask || d.dh != 32) return false;
+  if (d.Lq > 128 || d.Lk < 128) return false;
+  if ((d.q_sl & 7) || (d.k_sl & 7) || (d.v_sl & 7) || (d.o_sl & 3) || (d.q_sb & 7) || (d.k_sb & 7) || (d.v_sb & 7) || (d.o_sb & 3))
+    return false;
+  const int KS = d.ksplit > 1 ? d.ksplit : 1, nkb = (d.Lk + KB - 1) / KB;
+  const int nb_max = (nkb + KS - 1) / KS;   // ceil: the largest slice
+  if (nb_max * KB > FKMAX) return false;
+  if (d.drop.p > 0.f && d.drop.seed) launch_fwd_res<true>(d, s, KS, nb_max * KB);
+  else launch_fwd_res<false>(d, s, KS, nb_max * KB);
+  return true;
+}
 
 // Runs the all-queries-resident backward when the call has its shape (bf16, d_h 32 / 64, no additive bias, N_q <= 224,
 // enough keys to be worth it); returns false for everything else (attention.hip's two-kernel path).  The caller launches

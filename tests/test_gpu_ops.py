@@ -437,6 +437,47 @@ def test_attention_backward_resident_path(H, dh, Lq, Lk, mode, B):
         assert float(res[1][1].float()[pad].abs().max()) == 0.0 and float(res[1][2].float()[pad].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("case", ["c2", "c5_split", "padded_tail", "dropout", "no_zero_key", "short_keys"])
+def test_attention_forward_resident_path(case):
+    """The all-keys-resident forward (attn_resident.hip: the whole key/value slice of a (scene, head) in LDS behind one
+    barrier, no key split up to 1024 keys) against the streaming kernel on the same inputs -- same arithmetic, bf16
+    rounding points and dropout masks, only the block order of the online softmax differs -- and against an fp64
+    reference.  The backward consumes the saved log-sum-exp, so the gradients check that too."""
+    cfg = {"c2": dict(B=6, Lq=100, Lk=1024), "c5_split": dict(B=3, Lq=100, Lk=2048),
+           "padded_tail": dict(B=5, Lq=37, Lk=1000, pad=True), "dropout": dict(B=4, Lq=100, Lk=512, drop=True),
+           "no_zero_key": dict(B=2, Lq=128, Lk=640, zero=False), "short_keys": dict(B=2, Lq=16, Lk=128, pad=True)}[case]
+    B, H, dh, Lq, Lk = cfg["B"], 8, 32, cfg["Lq"], cfg["Lk"]
+    d = H * dh
+    q, k, v, go = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3), rnd(B, Lq, d, seed=7)
+    kpm = None
+    if cfg.get("pad"):
+        kpm = torch.zeros(B, Lk, dtype=torch.bool)
+        for b in range(B):
+            kpm[b, Lk - 1 - (Lk // 8) * b:] = True     # ragged tails
+        kpm[B - 1, :64] = True                         # a fully padded leading block
+    zero = cfg.get("zero", True)
+    drop = ops.make_drop(0.1, 4242, DEV) if cfg.get("drop") else None
+    lib = L.lib()
+    res = {}
+    for mode in (7, 3):
+        old = lib.pq3d_attn_resident(mode)
+        try:
+            qd, kd, vd = (t.to(DEV).bfloat16().requires_grad_(True) for t in (q, k, v))
+            o = ops.attention(qd, kd, vd, H=H, ct=BF16, zero_attn=zero, kpm=None if kpm is None else kpm.to(DEV), drop=drop)
+            o.backward(go.to(DEV).bfloat16())
+            res[mode] = (o.detach(), qd.grad, kd.grad, vd.grad)
+        finally:
+            lib.pq3d_attn_resident(old)
+    for name, a, a_old in zip(("o", "dq", "dk", "dv"), res[7], res[3]):
+        assert torch.isfinite(a.float()).all(), name
+        assert _relL2(a, a_old.double()) <= 1e-2, f"{case} {name}: resident vs streaming relL2 {_relL2(a, a_old.double()):.2e}"
+    if drop is None:
+        qr, kr, vr = (t.bfloat16().double() for t in (q, k, v))
+        orf = attn_ref(qr, kr, vr, H, 1 / math.sqrt(dh), zero, kpm, None, None, None)
+        assert _relL2(res[7][0], orf) <= 1e-2, f"{case}: resident vs fp64 relL2 {_relL2(res[7][0], orf):.2e}"
+        assert _relL2(res[3][0], orf) <= 1e-2
+
+
 @pytest.mark.parametrize("H,dh", [(4, 16), (8, 32), (2, 64)])
 @pytest.mark.parametrize("Lq,Lk,mode", [(100, 100, "bias"), (100, 100, "kpm"), (128, 128, "bias"), (16, 16, "kpm"), (1, 37, "bias"),
                                         (77, 5, "kpm")])
