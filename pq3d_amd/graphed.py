@@ -19,7 +19,7 @@ from typing import Dict, List, Sequence
 import torch
 import torch.nn as nn
 
-OUT_TENSORS = ("query_embeds", "ground_logits", "generation_logits")
+OUT_TENSORS = ("query_embeds", "ground_logits", "generation_logits", "generation_label")   # the label: long, no gradient
 OUT_LISTS = ("predictions_class", "predictions_mask")
 
 
