@@ -444,7 +444,9 @@ def main():
                     for _ in range(3):
                         dropin_step()
                     result[f"dropin_graphed_{mode}_ms_per_step"] = timed_loop(dropin_step, max(10, args.steps))
-                    del gm
+                    del gm, dropin_step
+                    import gc
+                    torch.cuda.synchronize(); gc.collect()   # tear the captured graphs down here, on this thread, device idle
             except Exception as e:  # noqa: BLE001
                 result["dropin_graphed_error"] = f"{type(e).__name__}: {e}"[:300]
             enc.grad_arena, enc.grad_arena_buffers = reducer.slots(), [reducer.flat[0]]

@@ -1,4 +1,4 @@
-// 128x128-tile bf16 GEMMs for the big streaming products of the path (chosen inside pq3d_gemm when both operands are
+// 128-row-tile bf16 GEMMs for the big streaming products of the path (chosen inside pq3d_gemm when both operands are
 // bf16 and the launch still fills the chip):
 //   gemm_nt128_kernel : C_o[m][n] = act( sum_{g in o} sum_k A_g[m][k] B_g[n][k] + bias[n] ) [+ aux],  k contiguous in A and B;
 //                       hoisted K/V projections, their input gradients (K-concatenated over layers, fp32 out, "+ aux"),
@@ -19,28 +19,46 @@ namespace {
 constexpr int TM = 128, TN = 128, TK = 64, LDT = TK + 8;   // padded LDS row: 144 B -> conflict-free 16-byte fragment reads
 constexpr int LDC = TN + 8;                                 // bf16 C staging row
 
-template <bool F32OUT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_nt128_kernel(const pq3d_gemm_desc d) {
-  __shared__ __attribute__((aligned(16))) bf16_t As[TM * LDT];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[TN * LDT];
-  static_assert(sizeof(bf16_t) * TM * LDC <= sizeof(bf16_t) * (TM + TN) * LDT, "C staging must fit in the operand tiles");
+// Operand staging: direct global -> LDS DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), one
+// 1 KB piece per wave instruction = 8 rows of the unpadded [128][64] tile.  The DMA writes lane-linear, so the
+// bank-conflict swizzle lives in the SOURCE address and in the fragment read: 16-byte slot s of row r holds k chunk
+// s ^ ((r >> 1) & 7) -- the 16 lanes of a fragment read (rows r0 .. r0 + 15, one chunk) then hit 16 distinct slots of the
+// 64 banks.  Single LDS buffer, two barriers per k slice: the overlap of loads and MFMAs comes from 4 workgroups per CU
+// (~100 VGPRs, 34 KB of LDS) instead of from staging registers (136 VGPRs, 3 per CU before).
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// Tile shapes (rows x columns per workgroup; 4 waves as 2 x 2):
+//   128 x 128  the streaming products with thousands of tiles (hoisted K/V projection: 3072 at config 2)
+//   128 x 64   launches with < 3 workgroups of 128 x 128 per CU (the K-concatenated input-gradient products: 384 tiles at
+//              config 2): twice the workgroups for the same k loop.  Measured per launch: 30.4 us (128 x 128), 26.5 us
+//              (64 x 128), 27.3 us (128 x 64; kept: the streamed operand A takes 2/3 of each LDS stage)
+template <bool F32OUT, int TMT, int TNT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt128_kernel(const pq3d_gemm_desc d) {
+  constexpr int MI = TMT / 32, NJ = TNT / 32;                // 16 x 16 MFMA tiles per wave: MI x NJ
+  constexpr int LDCT = TNT + 8, LDFT = TNT + 4, HR = TMT / 2;   // bf16 / fp32 C staging rows; rows per fp32 half
+  constexpr int OPB = sizeof(bf16_t) * (TMT + TNT) * TK;
+  constexpr int STB = F32OUT ? (int)sizeof(float) * HR * LDFT : (int)sizeof(bf16_t) * TMT * LDCT;
+  constexpr int SM_BYTES = OPB > STB ? OPB : STB;
+  __shared__ __attribute__((aligned(16))) bf16_t As[SM_BYTES / 2];
+  bf16_t* const Bs = As + TMT * TK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave >> 1) * (TMT / 2), wn = (wave & 1) * (TNT / 2);
   const int kc = d.kconcat > 0 ? d.kconcat : 1;   // kc consecutive groups are concatenated along K into one output
-  const int g = blockIdx.z * kc, m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const int g = blockIdx.z * kc, m0 = blockIdx.x * TMT, n0 = blockIdx.y * TNT;
   const bf16_t* A = (const bf16_t*)d.A[g];
   const bf16_t* B = (const bf16_t*)d.B[g];
   const int nk1 = d.K / TK, nkt = nk1 * kc;
 
-  // staging: thread -> (row = tid / 8 of a 32-row pass, 16-byte chunk = tid % 8 of the 64-wide k slice)
-  const int srow = tid >> 3, sch = (tid & 7) * 8;
-  // 32-bit element offsets (eligibility bounds M * lda and N * ldb below 2^31): 5 registers instead of 16 for pointers
-  int aoff[4];
+  // DMA piece p of this thread: LDS slot (p * 256 + tid) = row slot / 8, position slot % 8 <- k chunk pos ^ swizzle(row)
+  int aoff[MI], boff[NJ];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) aoff[p] = min(m0 + p * 32 + srow, d.M - 1) * (int)d.lda + sch;   // rows past M: clamped
-  const int boff = (n0 + srow) * (int)d.ldb + sch, bstep = 32 * (int)d.ldb;
-  u32x4 ra[4], rb[4];
-  auto gload = [&](int t) {
+  for (int p = 0; p < 4; ++p) {
+    const int slot = p * 256 + tid, row = slot >> 3, c = (slot & 7) ^ ((row >> 1) & 7);
+    if (p < MI) aoff[p] = min(m0 + row, d.M - 1) * (int)d.lda + c * 8;   // rows past M: clamped duplicates (never stored)
+    if (p < NJ) boff[p] = (n0 + row) * (int)d.ldb + c * 8;
+  }
+  auto stage = [&](int t) {
     int kt = t;
     if (kc > 1) {   // uniform: switch to the operands of the group this k-tile belongs to
       const int gi = t / nk1;
@@ -50,36 +68,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      ra[p] = *(const u32x4*)(A + aoff[p] + kt * TK);
-      rb[p] = *(const u32x4*)(B + boff + p * bstep + kt * TK);
+      if (p < MI)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(A + aoff[p] + kt * TK), (lptr_t*)(As + (p * 256 + wave * 64) * 8), 16, 0, 0);
+      if (p < NJ)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(B + boff[p] + kt * TK), (lptr_t*)(Bs + (p * 256 + wave * 64) * 8), 16, 0, 0);
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  gload(0);
+  const int swz = li >> 1;   // (row >> 1) & 7 of this lane's fragment rows (row = 16 * tile + li)
   for (int kt = 0; kt < nkt; ++kt) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *(u32x4*)&As[(p * 32 + srow) * LDT + sch] = ra[p];
-      *(u32x4*)&Bs[(p * 32 + srow) * LDT + sch] = rb[p];
-    }
-    __syncthreads();
-    if (kt + 1 < nkt) gload(kt + 1);   // next k slice in flight behind the MFMAs
+    stage(kt);
+    __syncthreads();   // the compiler drains the DMA queue (vmcnt(0)) before the barrier
 #pragma unroll
     for (int ks = 0; ks < TK / 32; ++ks) {
-      u32x4 af[4], bf[4];
+      u32x4 af[MI], bf[NJ];
+      const int ch = ((ks * 4 + lg) ^ swz) * 8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const u32x4*)&As[(wm + i * 16 + li) * LDT + ks * 32 + lg * 8];
+      for (int i = 0; i < MI; ++i) af[i] = *(const u32x4*)&As[(wm + i * 16 + li) * TK + ch];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *(const u32x4*)&Bs[(wn + j * 16 + li) * LDT + ks * 32 + lg * 8];
+      for (int j = 0; j < NJ; ++j) bf[j] = *(const u32x4*)&Bs[(wn + j * 16 + li) * TK + ch];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Mma<bf16_t>::mma(acc[i][j], af[i], bf[j]);
+        for (int j = 0; j < NJ; ++j) Mma<bf16_t>::mma(acc[i][j], af[i], bf[j]);
     }
     __syncthreads();
   }
@@ -89,57 +105,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const float* bias = (const float*)d.bias[g];
   const bool relu = d.act == PQ3D_ACT_RELU;
   if constexpr (!F32OUT) {
-    bf16_t* Ct = As;   // [TM][LDC] bf16
+    bf16_t* Ct = As;   // [TMT][LDCT] bf16
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int col = wn + j * 16 + li;
       const float bn = bias ? bias[n0 + col] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = acc[i][j][r] * d.alpha + bn;
-          Ct[(wm + i * 16 + 4 * lg + r) * LDC + col] = f2bf(relu ? fmaxf(v, 0.f) : v);
+          Ct[(wm + i * 16 + 4 * lg + r) * LDCT + col] = f2bf(relu ? fmaxf(v, 0.f) : v);
         }
     }
     __syncthreads();
     bf16_t* C = (bf16_t*)d.C[g];
-    const int crow = tid >> 4, cch = (tid & 15) * 8;
+    constexpr int TPR = TNT / 8, RPP = 256 / TPR;   // threads per row (16-byte pieces), rows per pass
+    const int crow = tid / TPR, cch = (tid % TPR) * 8;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int row = p * 16 + crow;
-      if (m0 + row < d.M) *(u32x4*)(C + (long)(m0 + row) * d.ldc + n0 + cch) = *(const u32x4*)&Ct[row * LDC + cch];
+    for (int p = 0; p < TMT / RPP; ++p) {
+      const int row = p * RPP + crow;
+      if (m0 + row < d.M) *(u32x4*)(C + (long)(m0 + row) * d.ldc + n0 + cch) = *(const u32x4*)&Ct[row * LDCT + cch];
     }
   } else {
-    constexpr int LDF = TN + 4;
-    static_assert(sizeof(float) * 64 * LDF <= sizeof(bf16_t) * (TM + TN) * LDT, "fp32 half tile must fit");
-    float* Cf = (float*)As;   // [64][LDF] fp32: the 128 rows leave in two halves
+    float* Cf = (float*)As;   // [HR][LDFT] fp32: the rows leave in two halves (one per pair of waves)
     float* C = (float*)d.C[g];
     const float* aux = d.act_grad == PQ3D_ACT_ADD ? (const float*)d.aux[g] : nullptr;
-    const int crow = tid >> 5, cch = (tid & 31) * 4;
+    constexpr int TPR = TNT / 4, RPP = 256 / TPR;
+    const int crow = tid / TPR, cch = (tid % TPR) * 4;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (wm == h * 64) {   // the two waves that own this half
+      if (wm == h * HR) {   // the two waves that own this half
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           const int col = wn + j * 16 + li;
           const float bn = bias ? bias[n0 + col] : 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float v = acc[i][j][r] * d.alpha + bn;
-              Cf[(i * 16 + 4 * lg + r) * LDF + col] = relu ? fmaxf(v, 0.f) : v;
+              Cf[(i * 16 + 4 * lg + r) * LDFT + col] = relu ? fmaxf(v, 0.f) : v;
             }
         }
       }
       __syncthreads();
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int row = p * 8 + crow;
-        if (m0 + h * 64 + row < d.M) {
-          const long off = (long)(m0 + h * 64 + row) * d.ldc + n0 + cch;
-          float4 v = *(const float4*)&Cf[row * LDF + cch];
+      for (int p = 0; p < HR / RPP; ++p) {
+        const int row = p * RPP + crow;
+        if (m0 + h * HR + row < d.M) {
+          const long off = (long)(m0 + h * HR + row) * d.ldc + n0 + cch;
+          float4 v = *(const float4*)&Cf[row * LDFT + cch];
           if (aux) {   // act_grad == ADD: C = product + aux (gradient accumulation), read as whole 16-byte pieces
             const float4 x = *(const float4*)(aux + off);
             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
@@ -289,8 +305,14 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   const long tiles = (long)((d.M + TM - 1) / TM) * (d.N / TN) * (d.groups / kc);
   const long nkt = (long)(d.K / TK) * kc;
   if (tiles < 512 && !(tiles >= 256 && nkt >= 16)) return false;   // (128 tiles x 48 k-tiles measured equal to the 64x64 tile)
+  if (tiles < 768) {   // fewer than 3 workgroups per CU: 128 x 64 tiles (see the kernel's header)
+    const dim3 grid((d.M + TM - 1) / TM, d.N / 64, d.groups / kc);
+    if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 64>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 64>), grid, dim3(256), 0, s, d);
+    return true;
+  }
   const dim3 grid((d.M + TM - 1) / TM, d.N / TN, d.groups / kc);
-  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL(gemm_nt128_kernel<true>, grid, dim3(256), 0, s, d);
-  else hipLaunchKernelGGL(gemm_nt128_kernel<false>, grid, dim3(256), 0, s, d);
+  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 128>), grid, dim3(256), 0, s, d);
+  else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 128>), grid, dim3(256), 0, s, d);
   return true;
 }
