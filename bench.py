@@ -155,7 +155,7 @@ def gpu_kernels_of(entry, shape):
             return ["attn_small_fwd_kernel"] if small else ["attn_fwd_kernel", "attn_fwd_combine_kernel"]
         if small:
             return ["attn_small_bwd_kernel"]
-        return (["attn_bwd_resident_kernel", "attn_dq_combine_kernel"] if Lq <= 128 <= Lk
+        return (["attn_bwd_resident_kernel", "attn_dq_combine_kernel"] if Lq <= 256 and Lk >= 128
                 else ["attn_bwd_dq_kernel", "attn_dq_combine_kernel", "attn_bwd_dkv_kernel"])
     return {"pq3d_gemm": ["gemm_fast_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel"],
             "pq3d_add_ln_fwd": ["add_ln_fwd_kernel"], "pq3d_add_ln_bwd": ["add_ln_bwd_kernel"]}.get(entry, [])

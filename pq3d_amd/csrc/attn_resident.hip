@@ -53,8 +53,11 @@ PQ_DEV void wave_lds_fence() {   // order this wave's LDS writes before its foll
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The workgroup's resident queries are rows [q_lo, q_lo + nq) of the scene (nq <= 32 NQP).  More than 128 queries (config
+// 4: 200) run as TWO launches over the two halves of the rows; the second one ADDS its dK / dV onto the first one's
+// (acc_kv: read-modify-write of the bf16 rows; each key belongs to exactly one wave of one workgroup per launch).
 template <int DH, int NQP, bool DROP, bool MASK3>
-__global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_attn_desc d) {
+__global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_attn_desc d, int q_lo, int nq, int acc_kv) {
   typedef AT<bf16_t, DH> A;
   typedef RT<DH> R;
   constexpr int NQ = NQP * 32;           // resident (padded) query rows
@@ -81,14 +84,14 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   // ---- resident tiles: Q, dO (zero past Lq), delta = rowsum(dO * O), log-sum-exp
   {
     const long qoff = (long)b * d.q_sb + (long)h * d.q_sh, ooff = (long)b * d.o_sb + (long)h * d.o_sh;
-    const long sbase = ((long)b * d.H + h) * d.Lq;
+    const long sbase = ((long)b * d.H + h) * d.Lq + q_lo;
     constexpr int CPR = A::CPR, TOTAL = NQ * CPR;
 #pragma unroll
     for (int it = 0; it < (TOTAL + RW * 64 - 1) / (RW * 64); ++it) {
       const int c = tid + it * RW * 64;
       const int row = c / CPR, kc = c % CPR;
-      const bool ok = c < TOTAL && row < d.Lq;
-      const int gr = min(row, d.Lq - 1);
+      const bool ok = c < TOTAL && row < nq;
+      const int gr = q_lo + min(row, nq - 1);
       u32x4 q = *(const u32x4*)((const bf16_t*)d.q + qoff + (long)gr * d.q_sl + kc * 8);
       u32x4 g = *(const u32x4*)((const bf16_t*)d.dout + ooff + (long)gr * d.o_sl + kc * 8);
       const u32x4 o = *(const u32x4*)((const bf16_t*)d.o + ooff + (long)gr * d.o_sl + kc * 8);
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
           Ds[row] = ok ? s : 0.f;
           Ls[row] = ok ? d.lse[sbase + row] * 1.4426950408889634f : INFINITY;
           if (ok && split == 0) d.delta[sbase + row] = s;
-          if constexpr (MASK3) ros[row] = (ok && d.row_open) ? d.row_open[(long)bm * d.Lq + row] : 0;
+          if constexpr (MASK3) ros[row] = (ok && d.row_open) ? d.row_open[(long)bm * d.Lq + q_lo + row] : 0;
         }
       }
     }
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   uint32_t drow0 = 0;
   if constexpr (DROP) {
     dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, d.Lk);
-    drow0 = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * d.Lq);
+    drow0 = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * d.Lq + q_lo);
   }
 
   // group g of the scene goes to (slice, wave) = ((g / RW) % KS, g % RW): round-robin, the padded tail is spread evenly
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   };
   auto load_mask = [&](int g, int qp) {
     if constexpr (MASK3) {
-      const int row = min(qp * 32 + (lane >> 1), d.Lq - 1), half = lane & 1;   // chunk: (query row, 16-key half)
+      const int row = q_lo + min(qp * 32 + (lane >> 1), nq - 1), half = lane & 1;   // chunk: (query row, 16-key half)
       const long kc = min((long)g * GK + half * 16, (long)d.Lk - 16);
       mreg = *(const u32x4*)(d.mask + ((long)bm * d.Lq + row) * d.Lk + kc);
     }
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
         vcur[kt][s] = vf[kt][s];
       }
     if (gn < ngroups) load_group(gn, kf, vf, km);
-    const int nqp = (d.Lq + 31) / 32;
+    const int nqp = (nq + 31) / 32;
     if (all_masked && gn < ngroups) load_mask(gn, 0);
 
     f32x4 accK[2][MT], accV[2][MT];
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
                 p = masked ? 0.f : p;
               }
               if constexpr (DROP) {
-                const float kc = drop_keep(dst, drow0 + (uint32_t)min(ql, d.Lq - 1), (uint32_t)min(g * GK + kt * 16 + li, d.Lk - 1)) ? dst.scale : 0.f;
+                const float kc = drop_keep(dst, drow0 + (uint32_t)min(ql, nq - 1), (uint32_t)min(g * GK + kt * 16 + li, d.Lk - 1)) ? dst.scale : 0.f;
                 pt[kt][qt][r] = p * kc;
                 ds[kt][qt][r] = p * (dp[r] * kc - Dr[r]);
               } else {
@@ -297,10 +300,20 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const float ks_ = kmc[kt] ? 0.f : d.scale, vs_ = kmc[kt] ? 0.f : 1.f;   // padded keys: exact zeros
-          *(u32x2*)((bf16_t*)d.dk + ko + mt * 16 + 4 * lg) =
-              (u32x2){pack_bf2(accK[kt][mt][0] * ks_, accK[kt][mt][1] * ks_), pack_bf2(accK[kt][mt][2] * ks_, accK[kt][mt][3] * ks_)};
-          *(u32x2*)((bf16_t*)d.dv + vo + mt * 16 + 4 * lg) =
-              (u32x2){pack_bf2(accV[kt][mt][0] * vs_, accV[kt][mt][1] * vs_), pack_bf2(accV[kt][mt][2] * vs_, accV[kt][mt][3] * vs_)};
+          u32x2* pk = (u32x2*)((bf16_t*)d.dk + ko + mt * 16 + 4 * lg);
+          u32x2* pv = (u32x2*)((bf16_t*)d.dv + vo + mt * 16 + 4 * lg);
+          float ak[4], av[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { ak[r] = accK[kt][mt][r] * ks_; av[r] = accV[kt][mt][r] * vs_; }
+          if (acc_kv) {   // second half of the queries: onto the first launch's rows
+            const u32x2 ok_ = *pk, ov_ = *pv;
+            ak[0] += __uint_as_float(ok_.x << 16); ak[1] += __uint_as_float(ok_.x & 0xffff0000u);
+            ak[2] += __uint_as_float(ok_.y << 16); ak[3] += __uint_as_float(ok_.y & 0xffff0000u);
+            av[0] += __uint_as_float(ov_.x << 16); av[1] += __uint_as_float(ov_.x & 0xffff0000u);
+            av[2] += __uint_as_float(ov_.y << 16); av[3] += __uint_as_float(ov_.y & 0xffff0000u);
+          }
+          *pk = (u32x2){pack_bf2(ak[0], ak[1]), pack_bf2(ak[2], ak[3])};
+          *pv = (u32x2){pack_bf2(av[0], av[1]), pack_bf2(av[2], av[3])};
         }
       }
     }
@@ -324,14 +337,14 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     __syncthreads();
   }
   const long rows = (long)d.B * d.H * d.Lq;
-  for (int i = tid; i < d.Lq * (DH / 4); i += RW * 64) {
+  for (int i = tid; i < nq * (DH / 4); i += RW * 64) {
     const int q = i / (DH / 4), c0 = (i % (DH / 4)) * 4;
     const float* a = &dQs[q * R::LDQ + c0];
     if (KS == 1) {
-      const long off = (long)b * d.q_sb + (long)q * d.q_sl + (long)h * d.q_sh + c0;
+      const long off = (long)b * d.q_sb + (long)(q_lo + q) * d.q_sl + (long)h * d.q_sh + c0;
       *(u32x2*)((bf16_t*)d.dq + off) = (u32x2){pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
     } else {
-      float* po = d.ws + ((((long)split * d.B + b) * d.H + h) * d.Lq + q) * DH + c0;
+      float* po = d.ws + ((((long)split * d.B + b) * d.H + h) * d.Lq + q_lo + q) * DH + c0;
       *(float4*)po = make_float4(a[0], a[1], a[2], a[3]);
     }
   }
@@ -346,7 +359,7 @@ template <int DH, int NQP> size_t resident_lds(bool mask3) {
   return b + nq + 16;
 }
 
-template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_attn_desc& d, hipStream_t s) {
+template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
   const size_t lds = resident_lds<DH, NQP>(MASK3);
   auto kern = attn_bwd_resident_kernel<DH, NQP, DROP, MASK3>;
@@ -355,21 +368,29 @@ template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_att
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(KS, d.H, d.B), dim3(RW * 64), lds, s, d);
+  hipLaunchKernelGGL(kern, dim3(KS, d.H, d.B), dim3(RW * 64), lds, s, d, q_lo, nq, acc);
 }
 
-template <int DH, int NQP> void launch_res_flags(const pq3d_attn_desc& d, hipStream_t s) {
+template <int DH, int NQP> void launch_res_flags(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
   const bool dr = d.drop.p > 0.f && d.drop.seed, m3 = d.mask != nullptr;
-  if (dr) { if (m3) launch_res<DH, NQP, true, true>(d, s); else launch_res<DH, NQP, true, false>(d, s); }
-  else { if (m3) launch_res<DH, NQP, false, true>(d, s); else launch_res<DH, NQP, false, false>(d, s); }
+  if (dr) { if (m3) launch_res<DH, NQP, true, true>(d, s, q_lo, nq, acc); else launch_res<DH, NQP, true, false>(d, s, q_lo, nq, acc); }
+  else { if (m3) launch_res<DH, NQP, false, true>(d, s, q_lo, nq, acc); else launch_res<DH, NQP, false, false>(d, s, q_lo, nq, acc); }
+}
+
+template <int DH> void launch_res_rows(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
+  if (nq <= 64) launch_res_flags<DH, 2>(d, s, q_lo, nq, acc);
+  else launch_res_flags<DH, 4>(d, s, q_lo, nq, acc);
 }
 
 template <int DH> bool launch_res_dh(const pq3d_attn_desc& d, hipStream_t s) {
-  const int nqp = (d.Lq + 31) / 32;
-  // more than 128 queries (config 4: 200) would need 112+ accumulator registers per lane for dQ: two-kernel path
-  if (nqp <= 2) launch_res_flags<DH, 2>(d, s);
-  else if (nqp <= 4) launch_res_flags<DH, 4>(d, s);
-  else return false;
+  // up to 128 resident queries per workgroup (dQ accumulators: 64 registers per lane; 224 resident queries were built
+  // and measured: 256 VGPRs, one wave per SIMD, 200 us = no better than the two-kernel path at config 4).  129 .. 256
+  // queries: two launches over the halves of the rows, the second accumulating dK / dV (config 4: 2 x 100 queries)
+  if (d.Lq <= 128) { launch_res_rows<DH>(d, s, 0, d.Lq, 0); return true; }
+  if (d.Lq > 256) return false;
+  const int h1 = (d.Lq + 1) / 2;
+  launch_res_rows<DH>(d, s, 0, h1, 0);
+  launch_res_rows<DH>(d, s, h1, d.Lq - h1, 1);
   return true;
 }
 
@@ -607,7 +628,7 @@ bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
 bool pq3d_attn_bwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
   if (d.ct != PQ3D_BF16 || d.bias || d.dbias) return false;
   if (d.dh != 32 && d.dh != 64) return false;
-  if (d.Lq > 128 || d.Lk < 128) return false;
+  if (d.Lq > 256 || d.Lk < 128) return false;
   if (d.mask && ((d.Lk & 15) != 0 || (((uintptr_t)d.mask) & 15) != 0)) return false;
   if (d.dh == 32) return launch_res_dh<32>(d, s);
   return launch_res_dh<64>(d, s);
