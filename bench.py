@@ -289,7 +289,8 @@ def main():
             try:
                 enc.grads_ready = lambda: reducer.launch(0)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     full_step()
                 return g, "graph(step+allreduce, bucket 0 overlapped)"
             except Exception as e:  # noqa: BLE001

@@ -431,10 +431,11 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
     nkb = (Lk + 63) // 64
     ks = (_ATTN_KSPLIT or (1 if nkb < 8 else 2 if nkb < 64 else 4)) if bias is None else 1
     if not bwd and not _ATTN_KSPLIT and ct == BF16 and q.dtype == torch.bfloat16 and bias is None and mask is None and \
-            Lq <= 128 <= Lk and dm // H == 32:
+            Lq <= 128 <= Lk and dm // H == 32 and nkb <= 16:
         # the all-keys-resident forward (attn_resident.hip) holds up to 1024 keys per workgroup: config 2 needs no split
-        # (and no combine launch), longer scenes split by 1024 -- a function of the key length only, as above
-        ks = (nkb + 15) // 16
+        # (and no combine launch).  Longer scenes keep the streaming kernel and its split (measured at config 5, 2048 keys:
+        # resident with 2 splits 63-76 us vs streaming 58 us) -- a function of the key length only, as above
+        ks = 1
     if bwd and not _ATTN_KSPLIT and ks > 1 and ct == BF16 and bias is None and Lq <= 128 and (dm // H) in (32, 64) and \
             B * H >= 320:
         # the all-queries-resident backward (attn_resident.hip) runs one workgroup per (scene, head, slice): once the
