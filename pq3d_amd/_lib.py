@@ -12,7 +12,7 @@ F32, BF16, BF16X3 = 0, 1, 2
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "add": 3}
 MAXG = 32
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpq3d_hip.so")
+LIB_PATH = os.environ.get("PQ3D_LIB_PATH") or os.path.join(_HERE, "libpq3d_hip.so")   # override: A/B builds of the kernels
 
 
 class Pq3dError(RuntimeError):

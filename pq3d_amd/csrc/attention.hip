@@ -117,6 +117,7 @@ PQ_DEV void fetch_mask_bias(MaskBias& mb, const pq3d_attn_desc& d, const uint8_t
 // ------------------------------------------------------------------------------------------------ forward
 template <typename CT, int DH, int NW, bool DROP, bool MASK3>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc d) {
+  ATTN_KARG_PIN(d);
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;  // bf16: row-major V + transposing reads; f32: transposed LDS copy
   constexpr int KSZ = KB * A::LDR, VSZ = TRR ? KB * A::LDR : DH * A::LDT;
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
 // merges the `ksplit` partial states of attn_fwd_kernel: one thread per (row, 4-channel group)
 template <int DH>
 __global__ void attn_fwd_combine_kernel(const pq3d_attn_desc d) {
+  ATTN_KARG_PIN(d);
   const long rows = (long)d.B * d.H * d.Lq;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * (DH / 4)) return;
@@ -341,6 +343,8 @@ __global__ void attn_delta_kernel(const pq3d_attn_desc d) {
 // ------------------------------------------------------------------------------------------------ dQ (+ dbias)
 template <typename CT, int DH, int NW, bool DROP, bool MASK3>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_desc d) {
+  ATTN_KARG_PIN(d);
+  ATTN_KARG_PIN_BWD(d);
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
   constexpr int KSZ = KB * A::LDR, TSZ = TRR ? 8 : DH * A::LDT;
@@ -522,6 +526,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
 
 template <int DH>
 __global__ void attn_dq_combine_kernel(const pq3d_attn_desc d) {
+  ATTN_KARG_PIN(d);
+  ATTN_KARG_PIN_BWD(d);
   const long rows = (long)d.B * d.H * d.Lq;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * (DH / 4)) return;
@@ -541,6 +547,8 @@ __global__ void attn_dq_combine_kernel(const pq3d_attn_desc d) {
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <typename CT, int DH, bool DROP, bool MASK3, int NWK>
 __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_desc d) {
+  ATTN_KARG_PIN(d);
+  ATTN_KARG_PIN_BWD(d);
   typedef AT<CT, DH> A;
   constexpr bool TRR = sizeof(CT) == 2;
   constexpr int QSZ = QB * A::LDR, TSZ = TRR ? 8 : DH * A::LDQ;

@@ -58,6 +58,8 @@ PQ_DEV void wave_lds_fence() {   // order this wave's LDS writes before its foll
 // (acc_kv: read-modify-write of the bf16 rows; each key belongs to exactly one wave of one workgroup per launch).
 template <int DH, int NQP, bool DROP, bool MASK3>
 __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_attn_desc d, int q_lo, int nq, int acc_kv) {
+  ATTN_KARG_PIN(d);
+  ATTN_KARG_PIN_BWD(d);
   typedef AT<bf16_t, DH> A;
   typedef RT<DH> R;
   constexpr int NQ = NQP * 32;           // resident (padded) query rows
@@ -415,6 +417,7 @@ constexpr int FCH2 = FK1 * 4 / (FLW * 64);   // ... per loader thread, stage 2  
 
 template <bool DROP>
 __global__ __launch_bounds__((FW + FLW) * 64) void attn_fwd_resident_kernel(const pq3d_attn_desc d) {
+  ATTN_KARG_PIN(d);
   constexpr int DH = 32;
   typedef AT<bf16_t, DH> A;
   constexpr int LDK = DH, LDV = A::LDR;

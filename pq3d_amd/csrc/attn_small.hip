@@ -87,6 +87,7 @@ template <int DH> PQ_DEV float dot_lds(const float* row, const float (&r)[DH]) {
 
 template <int DH>
 __global__ __launch_bounds__(SN<DH>::T) void attn_small_fwd_kernel(const pq3d_attn_desc d) {
+  ATTN_KARG_PIN(d);
   constexpr int SNT = SN<DH>::T;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Lq = d.Lq, Lk = d.Lk, LS = ((Lk + 3) & ~3) + 4;   // float4-readable score rows, bank-shifted
@@ -159,6 +160,8 @@ __global__ __launch_bounds__(SN<DH>::T) void attn_small_fwd_kernel(const pq3d_at
 
 template <int DH>
 __global__ __launch_bounds__(SNB<DH>::T) void attn_small_bwd_kernel(const pq3d_attn_desc d) {
+  ATTN_KARG_PIN(d);
+  ATTN_KARG_PIN_BWD(d);
   constexpr int SNT = SNB<DH>::T;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Lq = d.Lq, Lk = d.Lk, LS = ((Lk + 3) & ~3) + 4;

@@ -133,6 +133,23 @@ PQ_DEV float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+// Kernel-argument prefetch (see gemm_fast_kernel in gemm.hip): one empty asm statement that "uses" every descriptor
+// scalar pins them at the top of the kernel -- one batch of scalar loads instead of one scalar-cache miss per first use.
+#ifdef PQ3D_NO_KARG_PIN   // A/B measurement builds
+#define ATTN_KARG_PIN(d)
+#define ATTN_KARG_PIN_BWD(d)
+#else
+#define ATTN_KARG_PIN(d)                                                                                                     \
+  asm volatile("" ::"s"((d).B), "s"((d).H), "s"((d).Lq), "s"((d).Lk), "s"((d).zero_attn), "s"((d).mask_bmod), "s"((d).scale),    \
+               "s"((d).q_sb), "s"((d).q_sl), "s"((d).q_sh), "s"((d).k_sb), "s"((d).k_sl), "s"((d).k_sh), "s"((d).v_sb),       \
+               "s"((d).v_sl), "s"((d).v_sh), "s"((d).o_sb), "s"((d).o_sl), "s"((d).o_sh), "s"((d).q), "s"((d).k), "s"((d).v),  \
+               "s"((d).o), "s"((d).lse), "s"((d).kpm), "s"((d).mask), "s"((d).row_open), "s"((d).bias), "s"((d).ksplit),        \
+               "s"((d).ws))
+#define ATTN_KARG_PIN_BWD(d)                                                                                                 \
+  asm volatile("" ::"s"((d).dout), "s"((d).dq), "s"((d).dk), "s"((d).dv), "s"((d).delta), "s"((d).dbias), "s"((d).drop.p),      \
+               "s"((d).drop.seed), "s"((d).drop_bmod))
+#endif
+
 // all-lanes sum / max of a wave with DPP quad / row permutes and the lane-half swaps: no LDS-crossbar shuffles
 // (ds_bpermute: ~6 dependent LDS round trips per reduction, which dominated the one-row-per-wave kernels)
 PQ_DEV float dpp_xor_f(float v, int which) {

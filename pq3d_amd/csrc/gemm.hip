@@ -511,11 +511,26 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   static_assert(sizeof(CT) * (BM + BN) * T::LDK >= sizeof(float) * BM * CLD, "C tile must fit in the staging LDS");
   static_assert(!X3 || (!TRA && !TRB && sizeof(CT) == 2 && sizeof(TA) == 4 && sizeof(TB) == 4), "X3: NT, fp32 operands");
   DBG_STAMP(0);
+  // Kernel-argument prefetch.  The descriptor is 2.7 KB of kernarg memory, cold in the scalar cache at every launch; read
+  // on demand (hipcc sinks each scalar load next to its first use, behind the branches that depend on earlier ones) the
+  // prologue was FIVE dependent scalar-cache misses (3.5k cycles before the first operand load was issued, measured with
+  // the stamps above) and the epilogue several more.  Pin every scalar the kernel will use here: one batch of loads.
+#ifndef PQ3D_NO_KARG_PIN
+  asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.batch), "s"(d.splitk), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc),
+               "s"(d.strideA), "s"(d.strideB), "s"(d.strideC), "s"(d.alpha), "s"(d.act), "s"(d.act_grad), "s"(d.dtC),
+               "s"(d.dtC2), "s"(d.dtAux), "s"(d.dtBias), "s"(d.row_fill), "s"(d.row_scale), "s"(d.row_fill_flag),
+               "s"(d.mask_out));
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const BlockCoords b = block_coords<CT>(d);
   if (!b.active) return;
+  // second batch: the per-group pointers of this block's first group (operands now, epilogue operands later)
+#ifndef PQ3D_NO_KARG_PIN
+  asm volatile("" ::"s"(d.A[b.g]), "s"(d.B[b.g]), "s"(d.A2[b.g]), "s"(d.B2[b.g]), "s"(d.bias[b.g]), "s"(d.C[b.g]), "s"(d.C2[b.g]),
+               "s"(d.aux[b.g]), "s"(d.row_mask[b.g]));
+#endif
   const long offA = (long)b.z * d.strideA, offB = (long)b.z * d.strideB;
   const int nk = b.kt1 - b.kt0, nit = nk * b.ng;
 

@@ -35,6 +35,11 @@ typedef __attribute__((address_space(3))) void lptr_t;
 //              (64 x 128), 27.3 us (128 x 64; kept: the streamed operand A takes 2/3 of each LDS stage)
 template <bool F32OUT, int TMT, int TNT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt128_kernel(const pq3d_gemm_desc d) {
+#ifndef PQ3D_NO_KARG_PIN
+  // kernel-argument prefetch (see gemm_fast_kernel): one batch of scalar loads for every descriptor scalar used below
+  asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(d.act),
+               "s"(d.act_grad), "s"(d.groups));
+#endif
   constexpr int MI = TMT / 32, NJ = TNT / 32;                // 16 x 16 MFMA tiles per wave: MI x NJ
   constexpr int LDCT = TNT + 8, LDFT = TNT + 4, HR = TMT / 2;   // bf16 / fp32 C staging rows; rows per fp32 half
   constexpr int OPB = sizeof(bf16_t) * (TMT + TNT) * TK;
@@ -185,6 +190,11 @@ PQ_DEV u32x4 km_frag128(const bf16_t* tile, int r0, int ks, int li, int lg) {
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_tt128_kernel(const pq3d_gemm_desc d,
                                                                                                     const int nsplit) {
+#ifndef PQ3D_NO_KARG_PIN
+  // kernel-argument prefetch (see gemm_fast_kernel): one batch of scalar loads for every descriptor scalar used below
+  asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(d.act),
+               "s"(d.act_grad), "s"(d.groups));
+#endif
   __shared__ __attribute__((aligned(16))) bf16_t As[TK * LDM];
   __shared__ __attribute__((aligned(16))) bf16_t Bs[TK * LDM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;

@@ -80,6 +80,12 @@ PQ_DEV RowStats row_stats(const float (&v)[PL], int d, int lane, float eps) {
 
 template <int PL, bool VEC>
 __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc d) {
+  // kernel-argument prefetch (see gemm_fast_kernel): every descriptor scalar in one batch of scalar loads
+#ifndef PQ3D_NO_KARG_PIN
+  asm volatile("" ::"s"(d.R), "s"(d.d), "s"(d.M), "s"(d.rows_per_scene), "s"(d.dt_x), "s"(d.dt_o), "s"(d.dt_y), "s"(d.eps), "s"(d.x),
+               "s"(d.coef), "s"(d.y), "s"(d.mean), "s"(d.rstd), "s"(d.independent), "s"(d.sum_branches), "s"(d.osum),
+               "s"(d.drop.p), "s"(d.drop.seed), "s"(d.o[0]), "s"(d.gamma[0]), "s"(d.beta[0]));
+#endif
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
   if (wave_id >= d.R) return;
@@ -151,6 +157,14 @@ __global__ __launch_bounds__(WPB * 64) void add_ln_fwd_kernel(const pq3d_ln_desc
 // its columns in registers.  dx (sum over branches) is accumulated with atomics only when M > 1.
 template <int PL, bool VEC, int NW>
 __global__ __launch_bounds__(NW * 64) void add_ln_bwd_kernel(const pq3d_ln_desc d) {
+#ifndef PQ3D_NO_KARG_PIN
+  asm volatile("" ::"s"(d.R), "s"(d.d), "s"(d.M), "s"(d.rows_per_scene), "s"(d.dt_x), "s"(d.dt_o), "s"(d.x), "s"(d.coef), "s"(d.mean),
+               "s"(d.rstd), "s"(d.dy), "s"(d.dx), "s"(d.independent), "s"(d.sum_branches), "s"(d.drop.p), "s"(d.drop.seed));
+#endif
+#ifndef PQ3D_NO_KARG_PIN
+  asm volatile("" ::"s"(d.o[blockIdx.y]), "s"(d.gamma[blockIdx.y]), "s"(d.d_o[blockIdx.y]), "s"(d.dgamma[blockIdx.y]),
+               "s"(d.dbeta[blockIdx.y]));
+#endif
   __shared__ float red[2][NW][64 * PL];
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.y;
