@@ -135,6 +135,49 @@ PQ_DEV float gelu_grad_f(float x) {
 
 // Kernel-argument prefetch (see gemm_fast_kernel in gemm.hip): one empty asm statement that "uses" every descriptor
 // scalar pins them at the top of the kernel -- one batch of scalar loads instead of one scalar-cache miss per first use.
+// ---------------------------------------------------------------------------------------------
+// Kernel-side form of pq3d_gemm_desc.  The public descriptor keeps one 256-byte ARRAY per kind of pointer (A[32],
+// A2[32], ...): the pointers of one group sit in 10 different cache lines, and with the header and the trailing scalars a
+// GEMM workgroup touched 13 lines of cold kernel-argument memory before its first operand load -- ~200 cycles each,
+// 2.6k cycles measured (tools/probes/gemm_x3_timeline.py).  The kernels take this struct instead: every scalar in the
+// first 3 lines, then one 80-byte record per group (2 lines).  Same scalar member names as the public struct, so kernel
+// code reads `d.M`, `d.alpha` unchanged and `d.gp[g].A` for the pointers.  Built on the host by make_kdesc().
+// ---------------------------------------------------------------------------------------------
+struct pq3d_kgroup {
+  const void *A, *A2, *B, *B2, *bias, *aux;
+  void *C, *C2;
+  const uint8_t* row_mask;
+  float* colsum;
+};
+struct pq3d_kdesc {
+  int32_t M, N, K, groups, batch, ct, dtA, dtA2, dtB, dtC, dtC2, dtAux, dtBias, transA, transB, act, act_grad, splitk, kconcat,
+      accumulate, dtB2;
+  float alpha, row_fill;
+  int64_t lda, ldb, ldc, strideA, strideB, strideC;
+  const float* row_scale;
+  const uint8_t* row_fill_flag;
+  uint8_t* mask_out;
+  pq3d_dropout drop;
+  pq3d_kgroup gp[PQ3D_MAX_GROUPS];
+};
+inline pq3d_kdesc make_kdesc(const pq3d_gemm_desc& d) {
+  pq3d_kdesc k;
+  k.M = d.M; k.N = d.N; k.K = d.K; k.groups = d.groups; k.batch = d.batch; k.ct = d.ct; k.dtA = d.dtA; k.dtA2 = d.dtA2;
+  k.dtB = d.dtB; k.dtC = d.dtC; k.dtC2 = d.dtC2; k.dtAux = d.dtAux; k.dtBias = d.dtBias; k.transA = d.transA;
+  k.transB = d.transB; k.act = d.act; k.act_grad = d.act_grad; k.splitk = d.splitk; k.kconcat = d.kconcat;
+  k.accumulate = d.accumulate; k.dtB2 = d.dtB2; k.alpha = d.alpha; k.row_fill = d.row_fill; k.lda = d.lda; k.ldb = d.ldb;
+  k.ldc = d.ldc; k.strideA = d.strideA; k.strideB = d.strideB; k.strideC = d.strideC; k.row_scale = d.row_scale;
+  k.row_fill_flag = d.row_fill_flag; k.mask_out = d.mask_out; k.drop = d.drop;
+  for (int g = 0; g < PQ3D_MAX_GROUPS; ++g) {
+    const bool on = g < d.groups;
+    k.gp[g].A = on ? d.A[g] : nullptr; k.gp[g].A2 = on ? d.A2[g] : nullptr; k.gp[g].B = on ? d.B[g] : nullptr;
+    k.gp[g].B2 = on ? d.B2[g] : nullptr; k.gp[g].bias = on ? d.bias[g] : nullptr; k.gp[g].aux = on ? d.aux[g] : nullptr;
+    k.gp[g].C = on ? d.C[g] : nullptr; k.gp[g].C2 = on ? d.C2[g] : nullptr; k.gp[g].row_mask = on ? d.row_mask[g] : nullptr;
+    k.gp[g].colsum = on ? d.colsum[g] : nullptr;
+  }
+  return k;
+}
+
 #ifdef PQ3D_NO_KARG_PIN   // A/B measurement builds
 #define ATTN_KARG_PIN(d)
 #define ATTN_KARG_PIN_BWD(d)

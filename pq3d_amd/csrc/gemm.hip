@@ -20,8 +20,8 @@ extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol
 #define DBG_STAMP(i)
 #endif
 
-bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s);   // gemm128.hip
-bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, hipStream_t s);   // gemm128.hip
+bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
+bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
 
 namespace {
 
@@ -376,12 +376,26 @@ template <int NV> PQ_DEV void store_vec(void* p, int dt, long idx, bool vec_ok, 
   }
 }
 
-PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* Ct, int g, int z, int m0, int n0, int wm,
-                     int wn, int li, int lg, int tid) {
+// The per-group pointers of a block's (first) group.  load(d, g) reads them from the descriptor's arrays; the fast kernel
+// requests them SPECULATIVELY for group blockIdx.z together with the header scalars (one scalar-cache round trip instead
+// of two dependent ones: the true group index needs splitk / batch / kconcat from the header) and reloads only when the
+// guess was wrong (split-K, batched or K-concatenated launches).
+struct GPtrs {
+  const void *A, *A2, *B, *B2, *bias, *aux;
+  void *C, *C2;
+  const uint8_t* row_mask;
+  PQ_DEV void load(const pq3d_kdesc& d, int g) {
+    const pq3d_kgroup& q = d.gp[g];
+    A = q.A; A2 = q.A2; B = q.B; B2 = q.B2; bias = q.bias; aux = q.aux; C = q.C; C2 = q.C2; row_mask = q.row_mask;
+  }
+};
+
+PQ_DEV void epilogue(const pq3d_kdesc& d, const GPtrs& gp, const f32x4 (&acc)[2][2], float* Ct, int g, int z, int m0, int n0,
+                     int wm, int wn, int li, int lg, int tid) {
   if (d.splitk > 1) {
     // split-K: atomics straight from the C-layout registers -- there the 16 lanes of a group hit 16 CONSECUTIVE
     // addresses per instruction (the row-per-thread layout below would scatter every atomic over 64 cache lines)
-    float* C = (float*)d.C[g] + (long)z * d.strideC;
+    float* C = (float*)gp.C + (long)z * d.strideC;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -410,18 +424,18 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* C
   float v[16];
 #pragma unroll
   for (int j = 0; j < 16; j += 4) { const float4 t = *(const float4*)&Ct[lrow * CLD + lcol + j]; v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w; }
-  void* C = d.C[g];
+  void* C = gp.C;
   const long ci = (long)z * d.strideC + (long)row * d.ldc + col;
   // vector path: full 16-column segment, 16-byte aligned for the widest participant
-  const uintptr_t pbits = (uintptr_t)C | (uintptr_t)d.C2[g] | (uintptr_t)d.aux[g];
+  const uintptr_t pbits = (uintptr_t)C | (uintptr_t)gp.C2 | (uintptr_t)gp.aux;
   const bool vec_ok = nvalid == 16 && (d.ldc % 8 == 0) && (d.strideC % 8 == 0) && (col % 8 == 0) && (pbits & 15) == 0;
-  if (d.bias[g]) {
+  if (gp.bias) {
     float bv[16];
-    load_vec<16>(d.bias[g], d.dtBias, col, nvalid == 16 && (col % 8 == 0) && (((uintptr_t)d.bias[g]) & 15) == 0, nvalid, bv);
+    load_vec<16>(gp.bias, d.dtBias, col, nvalid == 16 && (col % 8 == 0) && (((uintptr_t)gp.bias) & 15) == 0, nvalid, bv);
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] += bv[j];
   }
-  if (d.C2[g]) store_vec<16>(d.C2[g], d.dtC2, ci, vec_ok, nvalid, v);
+  if (gp.C2) store_vec<16>(gp.C2, d.dtC2, ci, vec_ok, nvalid, v);
   if (d.act == PQ3D_ACT_RELU) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -441,7 +455,7 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* C
   }
   if (d.act_grad) {
     float av[16];
-    load_vec<16>(d.aux[g], d.dtAux, ci, vec_ok, nvalid, av);
+    load_vec<16>(gp.aux, d.dtAux, ci, vec_ok, nvalid, av);
     if (d.act_grad == PQ3D_ACT_RELU) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = av[j] > 0.f ? v[j] : 0.f;
@@ -455,9 +469,9 @@ PQ_DEV void epilogue(const pq3d_gemm_desc& d, const f32x4 (&acc)[2][2], float* C
   }
   const long ri = (long)z * d.M + row;
   float rsc = 1.f;
-  if (d.row_mask[g]) rsc = d.row_mask[g][ri] ? 1.f : 0.f;
+  if (gp.row_mask) rsc = gp.row_mask[ri] ? 1.f : 0.f;
   if (d.row_scale) rsc *= d.row_scale[ri];
-  if (d.row_mask[g] || d.row_scale) {
+  if (gp.row_mask || d.row_scale) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] *= rsc;
   }
@@ -478,7 +492,7 @@ struct BlockCoords {
   bool active;
 };
 // grid = (m tiles, n tiles, outputs * batch * splitk): no integer division unless batch > 1 or split-K is used
-template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_gemm_desc& d) {
+template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_kdesc& d) {
   typedef Tile<CT> T;
   BlockCoords b;
   b.ng = d.kconcat > 0 ? d.kconcat : 1;  // groups walked inside the K loop
@@ -500,7 +514,7 @@ template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_gemm_desc& d) 
 }
 
 template <typename CT, typename TA, typename TB, bool TRA, bool TRB, bool HA2, bool HB2, bool X3 = false>
-__global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
+__global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_kdesc d) {
   typedef Tile<CT> T;
   // X3 (split-bf16): hi tiles first, lo tiles behind them -- one contiguous block, so the C tile of the epilogue still
   // overlays the start of the staging LDS
@@ -515,22 +529,22 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   // on demand (hipcc sinks each scalar load next to its first use, behind the branches that depend on earlier ones) the
   // prologue was FIVE dependent scalar-cache misses (3.5k cycles before the first operand load was issued, measured with
   // the stamps above) and the epilogue several more.  Pin every scalar the kernel will use here: one batch of loads.
+  GPtrs gp;
+  const int gspec = min((int)blockIdx.z, PQ3D_MAX_GROUPS - 1);   // the group index of a plain launch (no split / batch / concat)
+  gp.load(d, gspec);
 #ifndef PQ3D_NO_KARG_PIN
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.batch), "s"(d.splitk), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc),
                "s"(d.strideA), "s"(d.strideB), "s"(d.strideC), "s"(d.alpha), "s"(d.act), "s"(d.act_grad), "s"(d.dtC),
                "s"(d.dtC2), "s"(d.dtAux), "s"(d.dtBias), "s"(d.row_fill), "s"(d.row_scale), "s"(d.row_fill_flag),
-               "s"(d.mask_out));
+               "s"(d.mask_out), "s"(gp.A), "s"(gp.A2), "s"(gp.B));
+  asm volatile("" ::"s"(gp.B2), "s"(gp.bias), "s"(gp.aux), "s"(gp.C), "s"(gp.C2), "s"(gp.row_mask));
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const BlockCoords b = block_coords<CT>(d);
   if (!b.active) return;
-  // second batch: the per-group pointers of this block's first group (operands now, epilogue operands later)
-#ifndef PQ3D_NO_KARG_PIN
-  asm volatile("" ::"s"(d.A[b.g]), "s"(d.B[b.g]), "s"(d.A2[b.g]), "s"(d.B2[b.g]), "s"(d.bias[b.g]), "s"(d.C[b.g]), "s"(d.C2[b.g]),
-               "s"(d.aux[b.g]), "s"(d.row_mask[b.g]));
-#endif
+  if (b.g != gspec) gp.load(d, b.g);   // uniform; split-K / batched / K-concatenated launches
   const long offA = (long)b.z * d.strideA, offB = (long)b.z * d.strideB;
   const int nk = b.kt1 - b.kt0, nit = nk * b.ng;
 
@@ -546,22 +560,22 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
   Cursor<CT, TA, TRA, HA2> ca;
   Cursor<CT, TB, TRB, HB2> cb;
   int lg_ = b.g, lk_ = b.kt0, issued = 0;  // next (group, k-tile) to load
-  ca.init(d.A[lg_], d.A2[lg_], offA, d.lda, b.m0, d.M, b.kt0 * T::BKE, tid);
-  cb.init(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
+  ca.init(gp.A, gp.A2, offA, d.lda, b.m0, d.M, b.kt0 * T::BKE, tid);
+  cb.init(gp.B, gp.B2, offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
   auto issue = [&](FastStage<CT, TA, TRA, HA2>& sa, FastStage<CT, TB, TRB, HB2>& sb) {
     sa.load(ca, lk_ * T::BKE, d.K);
     sb.load(cb, lk_ * T::BKE, d.K);
     ++issued;
     if (++lk_ == b.kt1 && issued < nit) {   // next group of a K-concatenated product
       lk_ = b.kt0; ++lg_;
-      ca.init(d.A[lg_], d.A2[lg_], offA, d.lda, b.m0, d.M, b.kt0 * T::BKE, tid);
-      cb.init(d.B[lg_], d.B2[lg_], offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
+      ca.init(d.gp[lg_].A, d.gp[lg_].A2, offA, d.lda, b.m0, d.M, b.kt0 * T::BKE, tid);
+      cb.init(d.gp[lg_].B, d.gp[lg_].B2, offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
     }
   };
   // fused bias gradient (weight-gradient GEMMs): colsum[m] += sum_k A(m,k), taken from the staged A registers by
   // the blocks of the first n-tile column; saves one column-sum launch per linear layer
   float* cs_out = nullptr;
-  if constexpr (TRA) { if (blockIdx.y == 0) cs_out = d.colsum[b.g]; }
+  if constexpr (TRA) { if (blockIdx.y == 0) cs_out = d.gp[b.g].colsum; }
   float bsum = 0.f;
   // thread t sums BKE/4 k-values of row t/4 of the staged A tile (read back from LDS next to the MFMAs)
   auto rowsum = [&]() {
@@ -623,12 +637,12 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_gemm_desc d) {
       }
     }
   }
-  epilogue(d, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
+  epilogue(d, gp, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
   DBG_STAMP(5);
 }
 
 template <typename CT, bool TRA, bool TRB>
-__global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_gemm_desc d) {
+__global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_kdesc d) {
   typedef Tile<CT> T;
   __shared__ __attribute__((aligned(16))) CT As[BM * T::LDK];
   __shared__ __attribute__((aligned(16))) CT Bs[BN * T::LDK];
@@ -650,8 +664,8 @@ __global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_gemm_desc d) {
   SlowStage<CT, TRB> sb;
   int lg_ = b.g, lk_ = b.kt0;
   auto load_next = [&]() {
-    sa.load(d.A[lg_], d.A2[lg_], d.dtA, d.dtA2, offA, d.lda, b.m0, d.M, lk_ * T::BKE, d.K, tid);
-    sb.load(d.B[lg_], d.B2[lg_], d.dtB, d.dtB2, offB, d.ldb, b.n0, d.N, lk_ * T::BKE, d.K, tid);
+    sa.load(d.gp[lg_].A, d.gp[lg_].A2, d.dtA, d.dtA2, offA, d.lda, b.m0, d.M, lk_ * T::BKE, d.K, tid);
+    sb.load(d.gp[lg_].B, d.gp[lg_].B2, d.dtB, d.dtB2, offB, d.ldb, b.n0, d.N, lk_ * T::BKE, d.K, tid);
     if (++lk_ == b.kt1) { lk_ = b.kt0; ++lg_; }
   };
   load_next();
@@ -663,7 +677,9 @@ __global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_gemm_desc d) {
     mma_tile<CT, false, false>(acc, As, Bs, wm, wn, li, lg);
     __syncthreads();
   }
-  epilogue(d, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
+  GPtrs gp;
+  gp.load(d, b.g);
+  epilogue(d, gp, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
 }
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -688,10 +704,10 @@ template <typename CT> bool fast_ok(const pq3d_gemm_desc& d, bool& a2, bool& b2)
   return true;
 }
 
-#define LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(NT), 0, s, d)
+#define LAUNCH(...) hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(NT), 0, s, kd)
 
 template <typename CT, typename TA, typename TB>
-void launch_fast_layout(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s, bool a2, bool b2) {
+void launch_fast_layout(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, dim3 grid, hipStream_t s, bool a2, bool b2) {
   if (!d.transA && !d.transB) {
     if constexpr (sizeof(TA) == 4) { if (a2) { LAUNCH(gemm_fast_kernel<CT, TA, TB, false, false, true, false>); return; } }
     LAUNCH(gemm_fast_kernel<CT, TA, TB, false, false, false, false>);
@@ -703,7 +719,7 @@ void launch_fast_layout(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s, bool 
   }
 }
 
-template <typename CT> void launch_slow(const pq3d_gemm_desc& d, dim3 grid, hipStream_t s) {
+template <typename CT> void launch_slow(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, dim3 grid, hipStream_t s) {
   if (!d.transA && !d.transB) LAUNCH(gemm_slow_kernel<CT, false, false>);
   else if (!d.transA && d.transB) LAUNCH(gemm_slow_kernel<CT, false, true>);
   else if (d.transA && d.transB) LAUNCH(gemm_slow_kernel<CT, true, true>);
@@ -735,6 +751,7 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   PQ_CHECK_ARG(!any_cs || (d.transA && d.transB && kc == 1 && d.batch == 1 && d.splitk > 1),
                "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated split-K GEMM");
   hipStream_t s = (hipStream_t)stream;
+  pq3d_kdesc kd = make_kdesc(d);   // the kernels' compact form of the descriptor (common.h)
   if (d.ct == PQ3D_BF16X3) {
     // split-bf16: C = A.B^T of fp32 operands to fp32-grade accuracy on the bf16 matrix cores (3 MFMAs per product term
     // pair).  Available for the aligned row-major (NT) layout with fp32 A and B; anything else runs the exact-f32 MFMA
@@ -749,9 +766,9 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
       PQ_LAUNCH_CHECK();
       return 0;
     }
-    d.ct = PQ3D_F32;
+    d.ct = kd.ct = PQ3D_F32;
   }
-  if (pq3d_gemm_nt128_try(d, s)) {   // plain big bf16 NT products: 128x128 tiles (gemm128.hip), same bits
+  if (pq3d_gemm_nt128_try(d, kd, s)) {   // plain big bf16 NT products: 128x128 tiles (gemm128.hip), same bits
     PQ_LAUNCH_CHECK();
     return 0;
   }
@@ -771,7 +788,7 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
       }
     }
   }
-  if (pq3d_gemm_tt128_try(d, s)) {   // big bf16 weight-gradient products: 128x128 tiles, own split factor
+  if (pq3d_gemm_tt128_try(d, kd, s)) {   // big bf16 weight-gradient products: 128x128 tiles, own split factor
     PQ_LAUNCH_CHECK();
     return 0;
   }
@@ -780,18 +797,18 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   if (d.ct == PQ3D_BF16) {
     if (fast_ok<bf16_t>(d, a2, b2)) {
       const bool af = d.dtA == PQ3D_F32, bf = d.dtB == PQ3D_F32;
-      if (af && bf) launch_fast_layout<bf16_t, float, float>(d, grid, s, a2, b2);
-      else if (af && !bf) launch_fast_layout<bf16_t, float, bf16_t>(d, grid, s, a2, b2);
-      else if (!af && bf) launch_fast_layout<bf16_t, bf16_t, float>(d, grid, s, a2, b2);
-      else launch_fast_layout<bf16_t, bf16_t, bf16_t>(d, grid, s, a2, b2);
+      if (af && bf) launch_fast_layout<bf16_t, float, float>(d, kd, grid, s, a2, b2);
+      else if (af && !bf) launch_fast_layout<bf16_t, float, bf16_t>(d, kd, grid, s, a2, b2);
+      else if (!af && bf) launch_fast_layout<bf16_t, bf16_t, float>(d, kd, grid, s, a2, b2);
+      else launch_fast_layout<bf16_t, bf16_t, bf16_t>(d, kd, grid, s, a2, b2);
     } else {
       PQ_CHECK_ARG(!any_cs, "pq3d_gemm: colsum needs the aligned fast path");
-      launch_slow<bf16_t>(d, grid, s);
+      launch_slow<bf16_t>(d, kd, grid, s);
     }
   } else {
     if (fast_ok<float>(d, a2, b2) && d.dtA == PQ3D_F32 && d.dtB == PQ3D_F32)
-      launch_fast_layout<float, float, float>(d, grid, s, a2, b2);
-    else { PQ_CHECK_ARG(!any_cs, "pq3d_gemm: colsum needs the aligned fast path"); launch_slow<float>(d, grid, s); }
+      launch_fast_layout<float, float, float>(d, kd, grid, s, a2, b2);
+    else { PQ_CHECK_ARG(!any_cs, "pq3d_gemm: colsum needs the aligned fast path"); launch_slow<float>(d, kd, grid, s); }
   }
   PQ_LAUNCH_CHECK();
   return 0;

@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) void lptr_t;
 //              config 2): twice the workgroups for the same k loop.  Measured per launch: 30.4 us (128 x 128), 26.5 us
 //              (64 x 128), 27.3 us (128 x 64; kept: the streamed operand A takes 2/3 of each LDS stage)
 template <bool F32OUT, int TMT, int TNT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt128_kernel(const pq3d_gemm_desc d) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt128_kernel(const pq3d_kdesc d) {
 #ifndef PQ3D_NO_KARG_PIN
   // kernel-argument prefetch (see gemm_fast_kernel): one batch of scalar loads for every descriptor scalar used below
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(d.act),
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int wm = (wave >> 1) * (TMT / 2), wn = (wave & 1) * (TNT / 2);
   const int kc = d.kconcat > 0 ? d.kconcat : 1;   // kc consecutive groups are concatenated along K into one output
   const int g = blockIdx.z * kc, m0 = blockIdx.x * TMT, n0 = blockIdx.y * TNT;
-  const bf16_t* A = (const bf16_t*)d.A[g];
-  const bf16_t* B = (const bf16_t*)d.B[g];
+  const bf16_t* A = (const bf16_t*)d.gp[g].A;
+  const bf16_t* B = (const bf16_t*)d.gp[g].B;
   const int nk1 = d.K / TK, nkt = nk1 * kc;
 
   // DMA piece p of this thread: LDS slot (p * 256 + tid) = row slot / 8, position slot % 8 <- k chunk pos ^ swizzle(row)
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (kc > 1) {   // uniform: switch to the operands of the group this k-tile belongs to
       const int gi = t / nk1;
       kt = t - gi * nk1;
-      A = (const bf16_t*)d.A[g + gi];
-      B = (const bf16_t*)d.B[g + gi];
+      A = (const bf16_t*)d.gp[g + gi].A;
+      B = (const bf16_t*)d.gp[g + gi].B;
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   // epilogue: + bias, transpose through LDS (the operand tiles are dead: all fragment reads are behind the barrier
   // above) so that every row leaves in whole 16-byte pieces of contiguous columns
-  const float* bias = (const float*)d.bias[g];
+  const float* bias = (const float*)d.gp[g].bias;
   const bool relu = d.act == PQ3D_ACT_RELU;
   if constexpr (!F32OUT) {
     bf16_t* Ct = As;   // [TMT][LDCT] bf16
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     __syncthreads();
-    bf16_t* C = (bf16_t*)d.C[g];
+    bf16_t* C = (bf16_t*)d.gp[g].C;
     constexpr int TPR = TNT / 8, RPP = 256 / TPR;   // threads per row (16-byte pieces), rows per pass
     const int crow = tid / TPR, cch = (tid % TPR) * 8;
 #pragma unroll
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   } else {
     float* Cf = (float*)As;   // [HR][LDFT] fp32: the rows leave in two halves (one per pair of waves)
-    float* C = (float*)d.C[g];
-    const float* aux = d.act_grad == PQ3D_ACT_ADD ? (const float*)d.aux[g] : nullptr;
+    float* C = (float*)d.gp[g].C;
+    const float* aux = d.act_grad == PQ3D_ACT_ADD ? (const float*)d.gp[g].aux : nullptr;
     constexpr int TPR = TNT / 4, RPP = 256 / TPR;
     const int crow = tid / TPR, cch = (tid % TPR) * 4;
 #pragma unroll
@@ -188,7 +188,7 @@ PQ_DEV u32x4 km_frag128(const bf16_t* tile, int r0, int ks, int li, int lg) {
   return (u32x4){lo.x, lo.y, hi.x, hi.y};
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_tt128_kernel(const pq3d_gemm_desc d,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_tt128_kernel(const pq3d_kdesc d,
                                                                                                     const int nsplit) {
 #ifndef PQ3D_NO_KARG_PIN
   // kernel-argument prefetch (see gemm_fast_kernel): one batch of scalar loads for every descriptor scalar used below
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int nkt = d.K / TK, per = (nkt + nsplit - 1) / nsplit;
   const int kt0 = split * per, kt1 = min(nkt, kt0 + per);
   if (kt0 >= kt1) return;
-  const bf16_t* A = (const bf16_t*)d.A[g];
-  const bf16_t* B = (const bf16_t*)d.B[g];
+  const bf16_t* A = (const bf16_t*)d.gp[g].A;
+  const bf16_t* B = (const bf16_t*)d.gp[g].B;
   // staging: thread -> (k row = tid / 16 of a 16-row pass, 16-byte chunk = tid % 16 of the 128-wide m / n slice)
   const int srow = tid >> 4, sch = (tid & 15) * 8;
   const long astep = 16 * d.lda, bstep = 16 * d.ldb;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float* cs_out = blockIdx.y == 0 ? d.colsum[g] : nullptr;   // uniform per block
+  float* cs_out = blockIdx.y == 0 ? d.gp[g].colsum : nullptr;   // uniform per block
   float bsum = 0.f;
 
   gload(kt0);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __syncthreads();
   }
   if (cs_out && tid < TM) unsafeAtomicAdd(&cs_out[m0 + tid], bsum * d.alpha);
-  float* C = (float*)d.C[g];
+  float* C = (float*)d.gp[g].C;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 // Weight-gradient products (split-K launches; C already zeroed by pq3d_gemm unless it accumulates).  The split factor
 // is this kernel's own: ~1.5 workgroups per CU with at least 4 k-tiles each.
-bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
+bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
   if (d.ct != PQ3D_BF16 || d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16 || d.dtC != PQ3D_F32) return false;
   if (!d.transA || !d.transB || d.batch != 1 || d.kconcat > 1 || d.splitk <= 1 || d.act || d.act_grad) return false;
   if (d.M % TM || d.N % TN || d.K % TK || d.K < 8 * TK || d.ldc != d.N) return false;
@@ -287,12 +287,12 @@ bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   if (nsplit > nkt / 4) nsplit = nkt / 4;
   if (nsplit < 1) nsplit = 1;
   if (tiles * nsplit < 256) return false;   // too small to fill the chip: the 64x64 tile spreads it better
-  hipLaunchKernelGGL(gemm_tt128_kernel, dim3(d.M / TM, d.N / TN, d.groups * nsplit), dim3(256), 0, s, d, nsplit);
+  hipLaunchKernelGGL(gemm_tt128_kernel, dim3(d.M / TM, d.N / TN, d.groups * nsplit), dim3(256), 0, s, kd, nsplit);
   return true;
 }
 
 // Eligibility is decided here so that pq3d_gemm stays the single entry point (gemm.hip calls this first).
-bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
+bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
   if (d.ct != PQ3D_BF16 || d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16) return false;
   if (d.dtC != PQ3D_BF16 && d.dtC != PQ3D_F32) return false;
   const int kc = d.kconcat > 0 ? d.kconcat : 1;
@@ -317,12 +317,12 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, hipStream_t s) {
   if (tiles < 512 && !(tiles >= 256 && nkt >= 16)) return false;   // (128 tiles x 48 k-tiles measured equal to the 64x64 tile)
   if (tiles < 768) {   // fewer than 3 workgroups per CU: 128 x 64 tiles (see the kernel's header)
     const dim3 grid((d.M + TM - 1) / TM, d.N / 64, d.groups / kc);
-    if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 64>), grid, dim3(256), 0, s, d);
-    else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 64>), grid, dim3(256), 0, s, d);
+    if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 64>), grid, dim3(256), 0, s, kd);
+    else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 64>), grid, dim3(256), 0, s, kd);
     return true;
   }
   const dim3 grid((d.M + TM - 1) / TM, d.N / TN, d.groups / kc);
-  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 128>), grid, dim3(256), 0, s, d);
-  else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 128>), grid, dim3(256), 0, s, d);
+  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 128>), grid, dim3(256), 0, s, kd);
+  else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 128>), grid, dim3(256), 0, s, kd);
   return true;
 }
