@@ -391,7 +391,7 @@ struct GPtrs {
 };
 
 PQ_DEV void epilogue(const pq3d_kdesc& d, const GPtrs& gp, const f32x4 (&acc)[2][2], float* Ct, int g, int z, int m0, int n0,
-                     int wm, int wn, int li, int lg, int tid) {
+                     int wm, int wn, int li, int lg, int tid, bool bias_done = false) {
   if (d.splitk > 1) {
     // split-K: atomics straight from the C-layout registers -- there the 16 lanes of a group hit 16 CONSECUTIVE
     // addresses per instruction (the row-per-thread layout below would scatter every atomic over 64 cache lines)
@@ -429,7 +429,7 @@ PQ_DEV void epilogue(const pq3d_kdesc& d, const GPtrs& gp, const f32x4 (&acc)[2]
   // vector path: full 16-column segment, 16-byte aligned for the widest participant
   const uintptr_t pbits = (uintptr_t)C | (uintptr_t)gp.C2 | (uintptr_t)gp.aux;
   const bool vec_ok = nvalid == 16 && (d.ldc % 8 == 0) && (d.strideC % 8 == 0) && (col % 8 == 0) && (pbits & 15) == 0;
-  if (gp.bias) {
+  if (gp.bias && !bias_done) {
     float bv[16];
     load_vec<16>(gp.bias, d.dtBias, col, nvalid == 16 && (col % 8 == 0) && (((uintptr_t)gp.bias) & 15) == 0, nvalid, bv);
 #pragma unroll
@@ -591,6 +591,14 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_kdesc d) {
   };
   issue(sa0, sb0);
   if (nit > 1) issue(sa1, sb1);
+  // the bias row in accumulator layout (a lane's 4 rows share its column), requested right behind the first operand
+  // loads and added to the accumulators after the k loop: no dependent global round trip in the epilogue
+  const bool bias_early = gp.bias != nullptr && d.dtBias == PQ3D_F32 && d.alpha == 1.f && d.splitk <= 1;
+  float bcol[2] = {0.f, 0.f};
+  if (bias_early) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bcol[j] = ((const float*)gp.bias)[min(b.n0 + wn + j * 16 + li, d.N - 1)];
+  }
   DBG_STAMP(1);
   auto put = [&](const FastStage<CT, TA, TRA, HA2>& sa, const FastStage<CT, TB, TRB, HB2>& sb) {
     if constexpr (X3) { sa.store_split(As, Al, tid); sb.store_split(Bs, Bl, tid); }
@@ -637,7 +645,15 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_kdesc d) {
       }
     }
   }
-  epilogue(d, gp, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid);
+  if (bias_early) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += bcol[j];
+  }
+  epilogue(d, gp, acc, (float*)As, b.g, b.z, b.m0, b.n0, wm, wn, li, lg, tid, bias_early);
   DBG_STAMP(5);
 }
 
