@@ -269,8 +269,11 @@ struct SlowStage {
   }
 };
 
+// do_cs: also accb[i] += A fragment i x all-ones fragment -- every column of that product is the row sum of the A tile
+// over k (the fused bias gradient of the weight-gradient GEMMs) on the otherwise idle matrix pipe.  (accb by reference,
+// never through a pointer: a pointer to the accumulators sends them to scratch memory.)
 template <typename CT, bool KMA, bool KMB>
-PQ_DEV void mma_tile(f32x4 (&acc)[2][2], const CT* As, const CT* Bs, int wm, int wn, int li, int lg) {
+PQ_DEV void mma_tile(f32x4 (&acc)[2][2], const CT* As, const CT* Bs, int wm, int wn, int li, int lg, f32x4 (&accb)[2], bool do_cs) {
   typedef Tile<CT> T;
 #pragma unroll
   for (int ks = 0; ks < T::BKE / T::KSTEP; ++ks) {
@@ -289,6 +292,12 @@ PQ_DEV void mma_tile(f32x4 (&acc)[2][2], const CT* As, const CT* Bs, int wm, int
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) Mma<CT>::mma(acc[i][j], fa[i], fb[j]);
+    if (do_cs) {   // wave-uniform
+      const uint32_t one = sizeof(CT) == 2 ? 0x3F803F80u : 0x3F800000u;
+      const u32x4 ones = (u32x4){one, one, one, one};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) Mma<CT>::mma(accb[i], fa[i], ones);
+    }
   }
 }
 
@@ -572,23 +581,12 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_kdesc d) {
       cb.init(d.gp[lg_].B, d.gp[lg_].B2, offB, d.ldb, b.n0, d.N, b.kt0 * T::BKE, tid);
     }
   };
-  // fused bias gradient (weight-gradient GEMMs): colsum[m] += sum_k A(m,k), taken from the staged A registers by
-  // the blocks of the first n-tile column; saves one column-sum launch per linear layer
+  // fused bias gradient (weight-gradient GEMMs): colsum[m] += sum_k A(m,k) by the blocks of the first n-tile column, as one
+  // extra MFMA per A fragment against an all-ones fragment (mma_tile); saves one column-sum launch per linear layer
   float* cs_out = nullptr;
   if constexpr (TRA) { if (blockIdx.y == 0) cs_out = d.gp[b.g].colsum; }
-  float bsum = 0.f;
-  // thread t sums BKE/4 k-values of row t/4 of the staged A tile (read back from LDS next to the MFMAs)
-  auto rowsum = [&]() {
-    if constexpr (sizeof(CT) == 2) {   // [k][m] tile: thread = (m = tid % 64, k quarter = tid / 64)
-      const CT* cp = &As[(tid >> 6) * (T::BKE / 4) * T::LDK + (tid & 63)];
-#pragma unroll
-      for (int j = 0; j < T::BKE / 4; ++j) bsum += Cvt<CT>::to(cp[j * T::LDK]);
-    } else {                           // [m][k] tile: thread = (m = tid / 4, k quarter = tid % 4)
-      const CT* rp = &As[(tid >> 2) * T::LDK + (tid & 3) * (T::BKE / 4)];
-#pragma unroll
-      for (int j = 0; j < T::BKE / 4; ++j) bsum += Cvt<CT>::to(rp[j]);
-    }
-  };
+  f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  const bool do_cs = cs_out != nullptr && wn == 0;   // wave-uniform
   issue(sa0, sb0);
   if (nit > 1) issue(sa1, sb1);
   // the bias row in accumulator layout (a lane's 4 rows share its column), requested right behind the first operand
@@ -606,14 +604,13 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_kdesc d) {
   };
   auto mult = [&]() {
     if constexpr (X3) mma_tile_x3(acc, (const bf16_t*)As, (const bf16_t*)Al, (const bf16_t*)Bs, (const bf16_t*)Bl, wm, wn, li, lg);
-    else mma_tile<CT, TRA, TRB>(acc, As, Bs, wm, wn, li, lg);
+    else mma_tile<CT, TRA, TRB>(acc, As, Bs, wm, wn, li, lg, accb, TRA && do_cs);
   };
   for (int it = 0; it < nit; it += 2) {
     put(sa0, sb0);
     if (it == 0) DBG_STAMP(2);
     __syncthreads();
     if (issued < nit) issue(sa0, sb0);
-    if constexpr (TRA) { if (cs_out) rowsum(); }
     mult();
     __syncthreads();
     if (it == 0) DBG_STAMP(3);
@@ -621,28 +618,20 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_kdesc d) {
       put(sa1, sb1);
       __syncthreads();
       if (issued < nit) issue(sa1, sb1);
-      if constexpr (TRA) { if (cs_out) rowsum(); }
-      mult();
+        mult();
       __syncthreads();
     }
   }
   DBG_STAMP(4);
   if constexpr (TRA) {
-    if (cs_out) {   // uniform per block
-      if constexpr (sizeof(CT) == 2) {   // the 4 waves hold the 4 k-quarters of row m = lane: reduce through LDS
-        float* red = (float*)Bs;
-        red[tid] = bsum;
-        __syncthreads();
-        if (tid < 64 && b.m0 + tid < d.M)
-          unsafeAtomicAdd(&cs_out[b.m0 + tid], (red[tid] + red[tid + 64] + red[tid + 128] + red[tid + 192]) * d.alpha);
-        __syncthreads();
-      } else {                           // 4 neighbouring lanes hold the quarters of one row
-        float v = bsum;
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        const int row = b.m0 + (tid >> 2);
-        if ((tid & 3) == 0 && row < d.M) unsafeAtomicAdd(&cs_out[row], v * d.alpha);
-      }
+    if (do_cs && li == 0) {   // C layout: lane (column li, rows 4 lg + r); every column holds the same sums
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = b.m0 + wm + i * 16 + 4 * lg + r;
+          if (row < d.M) unsafeAtomicAdd(&cs_out[row], accb[i][r] * d.alpha);
+        }
     }
   }
   if (bias_early) {
@@ -690,7 +679,7 @@ __global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_kdesc d) {
     sb.store(Bs, tid);
     __syncthreads();
     if (it + 1 < nit) load_next();
-    mma_tile<CT, false, false>(acc, As, Bs, wm, wn, li, lg);
+    { f32x4 nocs[2]; mma_tile<CT, false, false>(acc, As, Bs, wm, wn, li, lg, nocs, false); }
     __syncthreads();
   }
   GPtrs gp;
