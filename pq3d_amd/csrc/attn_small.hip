@@ -74,15 +74,22 @@ template <int DH> PQ_DEV void load_row_regs(float (&r)[DH], const float* p) {
 #pragma unroll
   for (int x = 0; x < DH; x += 4) { const float4 t = *(const float4*)(p + x); r[x] = t.x; r[x + 1] = t.y; r[x + 2] = t.z; r[x + 3] = t.w; }
 }
+// packed fp32 FMAs (v_pk_fma_f32: two lanes of a 64-bit register pair per instruction): 4 independent accumulator pairs,
+// half the VALU instructions of the scalar chain
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+PQ_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 template <int DH> PQ_DEV float dot_lds(const float* row, const float (&r)[DH]) {   // row: LDS, same address for the whole wave
-  float s0 = 0.f, s1 = 0.f;
+  f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f}, a3 = {0.f, 0.f};
 #pragma unroll
   for (int x = 0; x < DH; x += 8) {
     const float4 t = *(const float4*)&row[x], u = *(const float4*)&row[x + 4];
-    s0 = fmaf(t.x, r[x], s0); s0 = fmaf(t.y, r[x + 1], s0); s0 = fmaf(t.z, r[x + 2], s0); s0 = fmaf(t.w, r[x + 3], s0);
-    s1 = fmaf(u.x, r[x + 4], s1); s1 = fmaf(u.y, r[x + 5], s1); s1 = fmaf(u.z, r[x + 6], s1); s1 = fmaf(u.w, r[x + 7], s1);
+    a0 = pk_fma((f32x2){t.x, t.y}, (f32x2){r[x], r[x + 1]}, a0);
+    a1 = pk_fma((f32x2){t.z, t.w}, (f32x2){r[x + 2], r[x + 3]}, a1);
+    a2 = pk_fma((f32x2){u.x, u.y}, (f32x2){r[x + 4], r[x + 5]}, a2);
+    a3 = pk_fma((f32x2){u.z, u.w}, (f32x2){r[x + 6], r[x + 7]}, a3);
   }
-  return s0 + s1;
+  const f32x2 s = (a0 + a1) + (a2 + a3);
+  return s.x + s.y;
 }
 
 template <int DH>
@@ -133,9 +140,9 @@ __global__ __launch_bounds__(SN<DH>::T) void attn_small_fwd_kernel(const pq3d_at
   // ---- O = P V: thread owns channel c and RPT consecutive rows: one V read feeds RPT FMAs, P rows are read as float4
   constexpr int RPT = SR * DH / SNT;     // 1 / 1 / 4
   const int c = tid % DH, i0 = (tid / DH) * RPT;
-  float acc[RPT];
+  f32x2 ac0[RPT], ac1[RPT];   // keys (jj, jj + 1) and (jj + 2, jj + 3): packed FMAs
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
+  for (int r = 0; r < RPT; ++r) { ac0[r] = (f32x2){0.f, 0.f}; ac1[r] = (f32x2){0.f, 0.f}; }
   for (int jj = 0; jj < Lk; jj += 4) {
     float vv[4];
 #pragma unroll
@@ -144,14 +151,14 @@ __global__ __launch_bounds__(SN<DH>::T) void attn_small_fwd_kernel(const pq3d_at
 #pragma unroll
     for (int r = 0; r < RPT; ++r) p[r] = *(const float4*)&S[min(i0 + r, nr - 1) * LS + jj];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = fmaf(p[r].x, vv[0], acc[r]);
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = fmaf(p[r].y, vv[1], acc[r]);
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = fmaf(p[r].z, vv[2], acc[r]);
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = fmaf(p[r].w, vv[3], acc[r]);
+    for (int r = 0; r < RPT; ++r) {
+      ac0[r] = pk_fma((f32x2){p[r].x, p[r].y}, (f32x2){vv[0], vv[1]}, ac0[r]);
+      ac1[r] = pk_fma((f32x2){p[r].z, p[r].w}, (f32x2){vv[2], vv[3]}, ac1[r]);
+    }
   }
+  float acc[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) { const f32x2 t = ac0[r] + ac1[r]; acc[r] = t.x + t.y; }
   float* o = (float*)d.o + (long)b * d.o_sb + (long)h * d.o_sh;
 #pragma unroll
   for (int r = 0; r < RPT; ++r)
@@ -252,9 +259,9 @@ __global__ __launch_bounds__(SNB<DH>::T) void attn_small_bwd_kernel(const pq3d_a
   const int c = tid % DH, i0 = (tid / DH) * RPT;
   // ---- dQ = scale dS K for the slice's rows: thread owns channel c and RPT consecutive rows
   if (nr > 0) {
-    float acc[RPT];
+    f32x2 ac0[RPT], ac1[RPT];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
+    for (int r = 0; r < RPT; ++r) { ac0[r] = (f32x2){0.f, 0.f}; ac1[r] = (f32x2){0.f, 0.f}; }
     for (int jj = 0; jj < Lk; jj += 4) {
       float kk[4];
 #pragma unroll
@@ -263,14 +270,14 @@ __global__ __launch_bounds__(SNB<DH>::T) void attn_small_bwd_kernel(const pq3d_a
 #pragma unroll
       for (int r = 0; r < RPT; ++r) t[r] = *(const float4*)&dSr[min(i0 + r, nr - 1) * LS + jj];
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) acc[r] = fmaf(t[r].x, kk[0], acc[r]);
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) acc[r] = fmaf(t[r].y, kk[1], acc[r]);
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) acc[r] = fmaf(t[r].z, kk[2], acc[r]);
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) acc[r] = fmaf(t[r].w, kk[3], acc[r]);
+      for (int r = 0; r < RPT; ++r) {
+        ac0[r] = pk_fma((f32x2){t[r].x, t[r].y}, (f32x2){kk[0], kk[1]}, ac0[r]);
+        ac1[r] = pk_fma((f32x2){t[r].z, t[r].w}, (f32x2){kk[2], kk[3]}, ac1[r]);
+      }
     }
+    float acc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) { const f32x2 t2 = ac0[r] + ac1[r]; acc[r] = t2.x + t2.y; }
     float* dq = (float*)d.dq + (long)b * d.q_sb + (long)h * d.q_sh;
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
@@ -278,17 +285,17 @@ __global__ __launch_bounds__(SNB<DH>::T) void attn_small_bwd_kernel(const pq3d_a
   }
   // ---- dK = scale dS^T Q, dV = P^T dO for the slice's keys: thread owns channel c and RPT consecutive keys
   if (nk > 0) {
+    f32x2 akv[RPT];   // (dK, dV) accumulator pairs: one packed FMA per (query row, key)
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) akv[r] = (f32x2){0.f, 0.f};
+    for (int i = 0; i < Lq; ++i) {
+      const f32x2 qg = {Qs[i * DH + c], Gs[i * DH + c]};
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) akv[r] = pk_fma((f32x2){dSc[i * LC + i0 + r], Pc[i * LC + i0 + r]}, qg, akv[r]);
+    }
     float ak[RPT], av[RPT];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) { ak[r] = 0.f; av[r] = 0.f; }
-    for (int i = 0; i < Lq; ++i) {
-      const float qv = Qs[i * DH + c], gv = Gs[i * DH + c];
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        ak[r] = fmaf(dSc[i * LC + i0 + r], qv, ak[r]);
-        av[r] = fmaf(Pc[i * LC + i0 + r], gv, av[r]);
-      }
-    }
+    for (int r = 0; r < RPT; ++r) { ak[r] = akv[r].x; av[r] = akv[r].y; }
     float* dk = (float*)d.dk + (long)b * d.k_sb + (long)h * d.k_sh;
     float* dv = (float*)d.dv + (long)b * d.v_sb + (long)h * d.v_sh;
 #pragma unroll
