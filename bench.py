@@ -292,6 +292,8 @@ def main():
                 # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     full_step()
+                g.replay()                      # one checked replay: asynchronous collective errors surface here, inside
+                torch.cuda.synchronize()        # the try, and the run falls back to all-reduces after the replay
                 return g, "graph(step+allreduce, bucket 0 overlapped)"
             except Exception as e:  # noqa: BLE001
                 if rank == 0:
