@@ -322,18 +322,23 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     g = gn;
   }
 
-  // ---- dQ: sum of the 4 waves' register accumulators through LDS (one wave at a time: no atomics), then out
+  // ---- dQ: sum of the 4 waves' register accumulators through LDS (no atomics), then out
   __syncthreads();   // every wave is done with the resident Q / dO tiles: the reduction buffer overlays them
-  for (int w = 0; w < RW; ++w) {
-    if (wave == w) {
+  // two phases instead of four: waves 0 / 1 store into two buffers (dQs over the resident Q / dO tiles, dQs2 over the
+  // per-wave scratch, both dead now), waves 2 / 3 add onto them; the output loop below adds the two buffers
+  float* dQs2 = (float*)wv;
+  static_assert(NQ * R::LDQ * 4 <= RW * WV_ELEMS * 2, "the second dQ buffer must fit over the per-wave scratch");
+  for (int ph = 0; ph < 2; ++ph) {
+    if ((wave >> 1) == ph) {
+      float* dst = (wave & 1) ? dQs2 : dQs;
 #pragma unroll
       for (int t = 0; t < NQP * 2; ++t)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float* p = &dQs[(t * 16 + 4 * lg + r) * R::LDQ + mt * 16 + li];
-            *p = (w == 0 ? 0.f : *p) + accQ[t][mt][r] * d.scale;
+            float* p = &dst[(t * 16 + 4 * lg + r) * R::LDQ + mt * 16 + li];
+            *p = (ph == 0 ? 0.f : *p) + accQ[t][mt][r] * d.scale;
           }
     }
     __syncthreads();
@@ -341,7 +346,9 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   const long rows = (long)d.B * d.H * d.Lq;
   for (int i = tid; i < nq * (DH / 4); i += RW * 64) {
     const int q = i / (DH / 4), c0 = (i % (DH / 4)) * 4;
-    const float* a = &dQs[q * R::LDQ + c0];
+    float a[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) a[x] = dQs[q * R::LDQ + c0 + x] + dQs2[q * R::LDQ + c0 + x];
     if (KS == 1) {
       const long off = (long)b * d.q_sb + (long)(q_lo + q) * d.q_sl + (long)h * d.q_sh + c0;
       *(u32x2*)((bf16_t*)d.dq + off) = (u32x2){pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
