@@ -213,6 +213,10 @@ int pq3d_attn_resident(int enable);
  *                        for the forward (NT) and the input-gradient (NT on W^T) products */
 int pq3d_mask_not(const uint8_t* const* src, uint8_t* const* dst, const int64_t* counts, int32_t groups, void* stream);
 int pq3d_zero_many(float* const* bufs, const int64_t* counts, int32_t n, void* stream);
+/* dst_i[0 .. counts_i) = src_i[..] (fp32) for n (source, destination, length) triples in one launch per 64 triples: the
+ * gradient pack of the data-parallel step (parameter gradients -> their slices of a flat bucket; DDP's bucket copy,
+ * trainer/build.py:66-75). */
+int pq3d_copy_many(const float* const* src, float* const* dst, const int64_t* counts, int32_t n, void* stream);
 int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_t count, void* stream);
 #define PQ3D_MEAN_MAX_BLOCKS 256   /* ws: fp32[1 + PQ3D_MEAN_MAX_BLOCKS], element 0 (the arrival counter) zero before first use */
 int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, void* stream);

@@ -151,6 +151,7 @@ _SIGS = {
     "pq3d_attn_resident": [C.c_int],
     "pq3d_mask_not": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
     "pq3d_zero_many": [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
+    "pq3d_copy_many": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
     "pq3d_sum_n": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p],
     "pq3d_mean_all": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "pq3d_fill_scaled": [C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p],

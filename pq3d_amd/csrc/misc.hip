@@ -485,6 +485,40 @@ extern "C" int pq3d_zero_many(float* const* bufs, const int64_t* counts, int32_t
   return 0;
 }
 
+namespace {
+struct CopyList { int n = 0; const float* src[PQ_ZERO_MAX]; float* dst[PQ_ZERO_MAX]; long count[PQ_ZERO_MAX]; };
+// dst_g[0 .. count_g) = src_g[..] for up to 64 (pointer, pointer, length) triples in one launch: the gradient pack of the
+// data-parallel reducer (parameter gradients -> their slices of the flat bucket), one short copy per parameter
+__global__ __launch_bounds__(256) void copy_many_kernel(const CopyList c) {
+  const float* s = c.src[blockIdx.y];
+  float* d = c.dst[blockIdx.y];
+  const long n = c.count[blockIdx.y];
+  const bool vec = ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0;
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * 1024;
+  for (; i < n; i += stride) {
+    if (vec && i + 3 < n) *(float4*)(d + i) = *(const float4*)(s + i);
+    else for (long j = i; j < min(i + 4, n); ++j) d[j] = s[j];
+  }
+}
+}  // namespace
+
+extern "C" int pq3d_copy_many(const float* const* src, float* const* dst, const int64_t* counts, int32_t n, void* stream) {
+  PQ_CHECK_ARG(src && dst && counts && n >= 0, "pq3d_copy_many: bad args");
+  CopyList c;
+  long mx = 0;
+  for (int i = 0; i < n; ++i) {
+    PQ_CHECK_ARG(counts[i] == 0 || (src[i] && dst[i]), "pq3d_copy_many: null buffer");
+    if (counts[i] > 0) { c.src[c.n] = src[i]; c.dst[c.n] = dst[i]; c.count[c.n] = (long)counts[i]; mx = counts[i] > mx ? (long)counts[i] : mx; ++c.n; }
+    if (c.n == PQ_ZERO_MAX || (i + 1 == n && c.n > 0)) {
+      hipLaunchKernelGGL(copy_many_kernel, dim3(grid1d((mx + 3) / 4, 256, 256), c.n), dim3(256), 0, (hipStream_t)stream, c);
+      PQ_LAUNCH_CHECK();
+      c.n = 0; mx = 0;
+    }
+  }
+  return 0;
+}
+
 extern "C" int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_t count, void* stream) {
   PQ_CHECK_ARG(src && out && n >= 1 && n <= PQ3D_MAX_GROUPS && count >= 0 && (count % 4) == 0, "pq3d_sum_n: bad args (count % 4 == 0)");
   SumPtrs p;

@@ -227,6 +227,18 @@ def zero_many(tensors: Sequence[torch.Tensor]) -> None:
     L.check(L.lib().pq3d_zero_many(_parr(ts), cnt, len(ts), L.stream()), "pq3d_zero_many")
 
 
+def copy_many(dsts: Sequence[torch.Tensor], srcs: Sequence[torch.Tensor]) -> None:
+    """dst_i.copy_(src_i) for many small fp32 tensors in one launch (the gradient pack of parallel.FlatGradAllReducer)."""
+    pairs = [(d_, s_.contiguous()) for d_, s_ in zip(dsts, srcs) if d_.numel()]
+    if not pairs:
+        return
+    assert all(d_.dtype == torch.float32 and s_.dtype == torch.float32 and d_.is_contiguous() and d_.numel() == s_.numel()
+               for d_, s_ in pairs)
+    cnt = (C.c_int64 * len(pairs))(*[d_.numel() for d_, _ in pairs])
+    L.check(L.lib().pq3d_copy_many(_parr([s_ for _, s_ in pairs]), _parr([d_ for d_, _ in pairs]), cnt, len(pairs), L.stream()),
+            "pq3d_copy_many")
+
+
 def sum_n(parts: Sequence[torch.Tensor]) -> torch.Tensor:
     """sum of same-shape fp32 tensors in a fixed order, one launch (replaces torch.stack(..).sum(0): cat + reduce)."""
     parts = [p.contiguous() for p in parts]

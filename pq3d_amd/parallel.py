@@ -77,7 +77,11 @@ class FlatGradAllReducer:
                     v.zero_()
                 off += n
             if views:
-                torch._foreach_copy_(views, grads)
+                if flat.is_cuda and all(g.dtype == torch.float32 for g in grads):
+                    from . import ops           # one launch of our own (torch's multi-tensor copy: 11 us for 60 small tensors)
+                    ops.copy_many(views, grads)
+                else:
+                    torch._foreach_copy_(views, grads)
 
     # ---- collective -------------------------------------------------------------------------------------------------
     def _world(self) -> int:

@@ -511,3 +511,19 @@ def test_attention_small_fp32_kernels(H, dh, Lq, Lk, mode):
             continue
         close(a, r, F32, name + " small-kernel vs fp64", atol=5e-5, rtol=5e-5)
         close(a, a_old, F32, name + " small-kernel vs streaming", atol=5e-5, rtol=5e-5)
+
+
+def test_copy_many_one_launch_pack():
+    """pq3d_copy_many: many small fp32 copies in one launch (the gradient pack of the data-parallel reducer), incl. odd
+    lengths, unaligned slices of a flat buffer and more than 64 pairs (two launches)."""
+    g = torch.Generator().manual_seed(0)
+    sizes = [1, 3, 4, 255, 256, 257, 1000, 65536 + 5] + [7 + i for i in range(70)]
+    srcs = [torch.randn(n, generator=g).to(DEV) for n in sizes]
+    flat = torch.zeros(sum(sizes) + 3, device=DEV)
+    dsts, off = [], 3                      # start at an odd offset: the slices are not 16-byte aligned
+    for n in sizes:
+        dsts.append(flat[off:off + n]); off += n
+    ops.copy_many(dsts, srcs)
+    for d_, s_ in zip(dsts, srcs):
+        assert torch.equal(d_, s_)
+    assert float(flat[:3].abs().sum()) == 0.0
