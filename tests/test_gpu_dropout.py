@@ -225,6 +225,9 @@ def test_fp32_train_mode_matches_oracle_with_same_masks(name, fused):
     _cfg, model, sd, dd = util.model_case(args)
     model.train()
     model.unified_encoder.fused = fused
+    # a known seed word: the masks (and with them which mask logit happens to sit within 1e-6 of zero) must not depend on
+    # how much of torch's CPU generator earlier tests consumed before the device RNG was first created
+    ops.drop_rng(torch.device(DEV)).set_seed(20260929)
     out, loss, g = run_hip(model, args, dd)
     used = set()
     with O.dropout_hook(oracle_hook(model, used)):
@@ -238,7 +241,7 @@ def test_fp32_train_mode_matches_oracle_with_same_masks(name, fused):
     if "mask" in args["heads"] and args.get("use_self_mask"):
         flips = max(float(((m.detach().cpu() < 0) != (r < 0)).float().mean())
                     for m, r in zip(out["predictions_mask"], oout["predictions_mask"]))
-        assert flips < 1e-4
+        assert flips < 5e-4        # fp32 vs fp32: at most a sign or two of logits within ~1e-6 of zero (1 of 4096 = 2.4e-4)
         tol = 2e-5 if flips == 0 else 2e-3
     assert rel(out["query_embeds"], collect[-1]) < tol
     if "ground" in args["heads"]:
