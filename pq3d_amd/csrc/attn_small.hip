@@ -25,8 +25,9 @@ namespace {
 constexpr int SR = 32;
 template <int DH> struct SN { static constexpr int T = DH == 32 ? 1024 : 512; };
 // the backward holds three full [L, d_h] operands plus three score tiles (81 KB at config 2) and two K / V rows per thread
-// in registers: 256 threads measured best (30 us vs 42 us with 1024: the 128-register cap forces the operand rows out)
-template <int DH> struct SNB { static constexpr int T = 256; };
+// in registers: 512 threads measured best once the dot products used packed FMAs (26 us; 256 threads 28 us; 1024 threads
+// 42 us: the 128-register cap forces the operand rows out)
+template <int DH> struct SNB { static constexpr int T = 512; };
 
 // dst[row * LS + col] = src[(r0 + row) * Lk + col] (or 0) for `rows` rows of a [*, Lk] fp32 matrix, as batches of
 // independent loads: a plain "load, store" loop is compiled to one outstanding load at a time (dependent global round trips)
