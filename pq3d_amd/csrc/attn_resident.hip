@@ -23,7 +23,6 @@
 
 namespace {
 
-constexpr int RW = 4;                 // waves per workgroup
 constexpr int GK = 32;                // keys per wave iteration (two 16-key MFMA tiles)
 
 template <int DH> struct RT {
@@ -56,7 +55,7 @@ PQ_DEV void wave_lds_fence() {   // order this wave's LDS writes before its foll
 // The workgroup's resident queries are rows [q_lo, q_lo + nq) of the scene (nq <= 32 NQP).  More than 128 queries (config
 // 4: 200) run as TWO launches over the two halves of the rows; the second one ADDS its dK / dV onto the first one's
 // (acc_kv: read-modify-write of the bf16 rows; each key belongs to exactly one wave of one workgroup per launch).
-template <int DH, int NQP, bool DROP, bool MASK3>
+template <int DH, int NQP, bool DROP, bool MASK3, int RW>
 __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_attn_desc d, int q_lo, int nq, int acc_kv) {
   ATTN_KARG_PIN(d);
   ATTN_KARG_PIN_BWD(d);
@@ -324,13 +323,15 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
 
   // ---- dQ: sum of the 4 waves' register accumulators through LDS (no atomics), then out
   __syncthreads();   // every wave is done with the resident Q / dO tiles: the reduction buffer overlays them
-  // two phases instead of four: waves 0 / 1 store into two buffers (dQs over the resident Q / dO tiles, dQs2 over the
-  // per-wave scratch, both dead now), waves 2 / 3 add onto them; the output loop below adds the two buffers
-  float* dQs2 = (float*)wv;
-  static_assert(NQ * R::LDQ * 4 <= RW * WV_ELEMS * 2, "the second dQ buffer must fit over the per-wave scratch");
+  // two phases: the first half of the waves store into RW / 2 buffers (buffer 0 over the resident Q / dO tiles, the others
+  // over the per-wave scratch, all dead now), the second half add onto them; the output loop below adds the buffers
+  constexpr int NBUF = RW / 2;
+  float* dQx = (float*)wv;   // buffers 1 .. NBUF - 1
+  static_assert((NBUF - 1) * NQ * R::LDQ * 4 <= RW * WV_ELEMS * 2, "the extra dQ buffers must fit over the per-wave scratch");
   for (int ph = 0; ph < 2; ++ph) {
-    if ((wave >> 1) == ph) {
-      float* dst = (wave & 1) ? dQs2 : dQs;
+    if (wave / NBUF == ph) {
+      const int bi = wave % NBUF;
+      float* dst = bi == 0 ? dQs : dQx + (bi - 1) * NQ * R::LDQ;
 #pragma unroll
       for (int t = 0; t < NQP * 2; ++t)
 #pragma unroll
@@ -348,7 +349,11 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     const int q = i / (DH / 4), c0 = (i % (DH / 4)) * 4;
     float a[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) a[x] = dQs[q * R::LDQ + c0 + x] + dQs2[q * R::LDQ + c0 + x];
+    for (int x = 0; x < 4; ++x) {
+      a[x] = dQs[q * R::LDQ + c0 + x];
+#pragma unroll
+      for (int bi = 1; bi < NBUF; ++bi) a[x] += dQx[(bi - 1) * NQ * R::LDQ + q * R::LDQ + c0 + x];
+    }
     if (KS == 1) {
       const long off = (long)b * d.q_sb + (long)(q_lo + q) * d.q_sl + (long)h * d.q_sh + c0;
       *(u32x2*)((bf16_t*)d.dq + off) = (u32x2){pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   (void)rows;
 }
 
-template <int DH, int NQP> size_t resident_lds(bool mask3) {
+template <int DH, int NQP, int RW> size_t resident_lds(bool mask3) {
   typedef RT<DH> R;
   const size_t nq = NQP * 32;
   size_t b = 2 * nq * R::LDR * 2 + 2 * nq * 4;
@@ -368,16 +373,27 @@ template <int DH, int NQP> size_t resident_lds(bool mask3) {
   return b + nq + 16;
 }
 
-template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
+template <int DH, int NQP, bool DROP, bool MASK3, int RW> void launch_res_w(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
-  const size_t lds = resident_lds<DH, NQP>(MASK3);
-  auto kern = attn_bwd_resident_kernel<DH, NQP, DROP, MASK3>;
+  const size_t lds = resident_lds<DH, NQP, RW>(MASK3);
+  auto kern = attn_bwd_resident_kernel<DH, NQP, DROP, MASK3, RW>;
   static bool attr_done = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel instantiation
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(KS, d.H, d.B), dim3(RW * 64), lds, s, d, q_lo, nq, acc);
+}
+
+// 4 waves per workgroup; 8 (two per SIMD: the same latency hiding as two 4-wave workgroups of one (scene, head) on a CU,
+// but Q / dO / O are loaded once and there are no dQ partials to combine) when the launch is not split over the keys and
+// has at most one workgroup per CU -- config 2: 192 (scene, head) pairs
+template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
+  const int KS = d.ksplit > 1 ? d.ksplit : 1;
+  if constexpr (DH == 32) {   // (d_h 64: the four dQ reduction buffers would not fit over the scratch)
+    if (KS == 1 && (long)d.B * d.H <= 256 && d.Lk >= 512) { launch_res_w<DH, NQP, DROP, MASK3, 8>(d, s, q_lo, nq, acc); return; }
+  }
+  launch_res_w<DH, NQP, DROP, MASK3, 4>(d, s, q_lo, nq, acc);
 }
 
 template <int DH, int NQP> void launch_res_flags(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {

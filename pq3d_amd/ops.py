@@ -449,10 +449,12 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
         # resident with 2 splits 63-76 us vs streaming 58 us) -- a function of the key length only, as above
         ks = 1
     if bwd and not _ATTN_KSPLIT and ks > 1 and ct == BF16 and bias is None and Lq <= 128 and (dm // H) in (32, 64) and \
-            B * H >= 320:
+            (B * H >= 320 or (B * H <= 256 and Lk >= 512 and dm // H == 32)):
         # the all-queries-resident backward (attn_resident.hip) runs one workgroup per (scene, head, slice): once the
         # stacked batch alone fills the chip (config 5: 48 x 8) a second slice only adds dQ partials (85 -> 75 us).
         # Gradients are summed with atomics downstream anyway, so this may depend on the batch; the forward's may not.
+        # At most one workgroup per CU (config 2: 24 x 8): the 8-wave variant of the kernel takes all keys of a (scene,
+        # head) -- no dQ partials, no combine launch.
         ks = 1
     if ks > 1:
         ws = _empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
