@@ -387,11 +387,11 @@ template <int DH, int NQP, bool DROP, bool MASK3, int RW> void launch_res_w(cons
 
 // 4 waves per workgroup; 8 (two per SIMD: the same latency hiding as two 4-wave workgroups of one (scene, head) on a CU,
 // but Q / dO / O are loaded once and there are no dQ partials to combine) when the launch is not split over the keys and
-// has at most one workgroup per CU -- config 2: 192 (scene, head) pairs
+// has at most one workgroup per CU -- config 2: 192 (scene, head) pairs unsplit; config 4: 96 pairs x 2 key slices
 template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
   if constexpr (DH == 32) {   // (d_h 64: the four dQ reduction buffers would not fit over the scratch)
-    if (KS == 1 && (long)d.B * d.H <= 256 && d.Lk >= 512) { launch_res_w<DH, NQP, DROP, MASK3, 8>(d, s, q_lo, nq, acc); return; }
+    if ((long)d.B * d.H * KS <= 256 && d.Lk / KS >= 512) { launch_res_w<DH, NQP, DROP, MASK3, 8>(d, s, q_lo, nq, acc); return; }
   }
   launch_res_w<DH, NQP, DROP, MASK3, 4>(d, s, q_lo, nq, acc);
 }

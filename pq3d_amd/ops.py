@@ -456,6 +456,9 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
         # At most one workgroup per CU (config 2: 24 x 8): the 8-wave variant of the kernel takes all keys of a (scene,
         # head) -- no dQ partials, no combine launch.
         ks = 1
+    if bwd and not _ATTN_KSPLIT and ks > 2 and ct == BF16 and bias is None and 128 < Lq <= 256 and dm // H == 32 and \
+            B * H * (ks // 2) <= 256 and Lk // (ks // 2) >= 512:
+        ks //= 2      # the 8-wave resident backward (two query halves, config 4): half the key slices, one workgroup per CU
     if ks > 1:
         ws = _empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
         d.ksplit, d.ws = ks, L.ptr(ws)
