@@ -42,6 +42,11 @@ CONFIGS = {
     # the HIP kernels; the caption body alone is also timed separately ("t5_body")
     "c5": dict(B=16, Ns=2048, Nq=100, d=256, H=8, L=6, memories=["voxel", "mv", "pc"], heads=["generation"],
                use_self_mask=False, Tr=32),
+    # c5p: c5 in the reference's stage-2 SHIPPED decoder configuration (configs/unified_tasks_sceneverse.yaml:113,159-165):
+    # memories [mv, pc, voxel, prompt], structure 'mixed' (parallel scene memories, then a sequential prompt
+    # cross-attention over T = 32 pre-encoded prompt tokens), training-time memory dropout 0.6 -- on the fused executor
+    "c5p": dict(B=16, Ns=2048, Nq=100, d=256, H=8, L=6, memories=["mv", "pc", "voxel", "prompt"], heads=["generation"],
+                use_self_mask=False, Tr=32, structure="mixed", T=32, memory_dropout=0.6),
     "c1": dict(B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=[], use_self_mask=False, spatial=False,
                structure="sequential"),
 }
@@ -49,9 +54,12 @@ CONFIGS = {
 
 def step_flops(c) -> float:
     """SURVEY §8d closed form (multiply-add = 2 FLOP; STEP = 3 x FWD)."""
-    B, Ns, Nq, d, H, L, M = c["B"], c["Ns"], c["Nq"], c["d"], c["H"], c["L"], len(c["memories"])
+    B, Ns, Nq, d, H, L = c["B"], c["Ns"], c["Nq"], c["d"], c["H"], c["L"]
+    M = len([m for m in c["memories"] if m != "prompt"])
     F, C = 2048, 201
     ca = M * (2 * B * d * d * (2 * Nq + 2 * Ns) + 4 * B * Nq * (Ns + 1) * d)
+    if "prompt" in c["memories"]:   # the sequential prompt cross-attention of structure 'mixed' (T prompt tokens)
+        ca += 2 * B * d * d * (2 * Nq + 2 * c["T"]) + 4 * B * Nq * (c["T"] + 1) * d
     sa = 8 * B * Nq * d * d + 4 * B * Nq * Nq * d + (2 * B * Nq * Nq * 5 * H if c.get("spatial", True) else 0)
     ffn = 4 * B * Nq * d * F
     mh = 2 * B * Nq * (d * d + d * C) + M * (2 * B * d * d * (Nq + Ns) + 2 * B * Ns * Nq * d)
@@ -63,12 +71,12 @@ def step_flops(c) -> float:
 def build(c, compute, device, seed):
     cfg = make_cfg(d=c["d"], H=c["H"], L=c["L"], memories=c["memories"], heads=c["heads"],
                    spatial=c.get("spatial", True), structure=c.get("structure", "parallel"),
-                   use_self_mask=c["use_self_mask"], C=201, foc=[0, 2])
+                   use_self_mask=c["use_self_mask"], C=201, foc=[0, 2], memory_dropout=c.get("memory_dropout", 0.0))
     model = Query3DUnified(cfg, compute=compute)
     sd = synth.fill_module(model, 0)
     model.to(device)
     dd = synth.synth_data_dict(c["B"], c["Ns"], c["Nq"], {m: c["d"] for m in c["memories"]}, seed=seed,
-                               memories=c["memories"])
+                               memories=c["memories"], prompt_len=c.get("T", 0), d_model=c["d"])
     if "generation" in c["heads"]:
         g = torch.Generator().manual_seed(seed)
         dd["response"] = torch.randint(2, 32000, (c["B"], c["Tr"]), generator=g)
@@ -244,85 +252,153 @@ def main():
 
     set_dropout_mode(args.dropout)
     params = [p for p in model.parameters() if p.requires_grad]
-    # two gradient buckets in the order they become final: [decoder (+ mask head): complete when the fused backward has
-    # flushed its weight gradients, 93 % of the bytes] and [encoders, heads: complete at the end of backward].  The fused
-    # decoder writes bucket 0 in place (no pack copy) and, in a data-parallel run, starts its all-reduce from inside the
-    # backward (enc.grads_ready) so that it overlaps the key/value input-gradient products and the encoders' backward.
+    # Gradient buckets in the order they become final ("bucketed per decoder layer in reverse execution order"):
+    # [layer L-1, ..., layer 0, mask head, everything else (encoders, heads: complete at the end of backward)].  The fused
+    # decoder writes the decoder buckets in place (no pack copy).  In a data-parallel run it reports readiness from inside
+    # the backward (enc.grads_ready(tag)): with per-layer flushing (enc.grad_bucket_per_layer) tag = layer index as soon as
+    # that layer's gradients are final, and tag = "decoder" when every decoder gradient is -- before the key/value
+    # input-gradient products and the encoders' backward, which the all-reduces then overlap.
     enc = model.unified_encoder
-    dec_ids = {id(p) for p in enc.parameters()} | ({id(p) for p in model.mask_head.parameters()} if hasattr(model, "mask_head") else set())
-    groups = [[p for p in params if id(p) in dec_ids], [p for p in params if id(p) not in dec_ids]]
+    layers = list(enc.unified_encoder)
+    lay_ids = [{id(p) for p in l.parameters()} for l in layers]
+    mh_ids = {id(p) for p in model.mask_head.parameters()} if hasattr(model, "mask_head") else set()
+    dec_ids = set().union(*lay_ids) | mh_ids
+    groups = [[p for p in params if id(p) in lay_ids[i]] for i in reversed(range(len(layers)))]
+    groups += [[p for p in params if id(p) in mh_ids], [p for p in params if id(p) not in dec_ids]]
+    n_layer_buckets = len(layers)
+    keep = [bool(g) for g in groups]
+    bucket_of = [sum(keep[:j]) for j in range(len(groups))]            # index after dropping empty groups
     reducer = FlatGradAllReducer(params, groups=[g for g in groups if g])
+    dec_buckets = [bucket_of[j] for j in range(n_layer_buckets + 1) if keep[j]]
     enc.grad_arena = reducer.slots()
-    enc.grad_arena_buffers = [reducer.flat[0]]
+    enc.grad_arena_buffers = [reducer.flat[b] for b in dec_buckets]
     overlap = world > 1 and os.environ.get("PQ3D_BENCH_OVERLAP", "1") != "0"
+    forced_mode = os.environ.get("PQ3D_BENCH_STEP_MODE", "")   # "", "one_graph", "two_graph", "graph_then_allreduce", "eager"
+
+    def on_ready(tag):
+        """Start the all-reduce of what just became final (side stream; the backward carries on)."""
+        if tag == "decoder":
+            for b in dec_buckets:
+                reducer.launch(b)
+        else:
+            reducer.launch(bucket_of[n_layer_buckets - 1 - int(tag)])
 
     one = torch.ones((), device=dev)
 
     def fwd_bwd():
         model.zero_grad(set_to_none=True)
-        enc.grad_arena_dirty = False   # one backward per step writes the shared gradient arena (fused.py checks)
         out = model(dict(dd))
         loss_fn(out, c["heads"]).backward(gradient=one)   # cached seed gradient: no ones_like fill in the step
         reducer.pack()
 
     def full_step():
-        """forward + backward with the bucket-0 all-reduce launched from inside the backward, then the rest + join."""
+        """forward + backward with the decoder buckets' all-reduces launched from inside the backward, then the rest + join."""
         fwd_bwd()
         reducer.finish()
 
+    class TwoGraphStep:
+        """RCCL-independent overlap: the step as TWO captured graphs split at the point where every decoder gradient is
+        final (enc.grads_ready('decoder'), inside the fused backward).  Graph A = forward + backward through the
+        weight-gradient flush; the decoder buckets' all-reduces are then launched EAGERLY on the side stream and run while
+        graph B = key/value input-gradient products + encoders' backward + pack of the last bucket replays; finish() joins.
+        The capture is split from inside the autograd backward (relaxed capture mode: the backward runs on autograd's
+        device thread), both graphs share one memory pool."""
+
+        def __init__(self):
+            self.ga, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            self.split_seen = False
+            stream = torch.cuda.Stream()
+            stream.wait_stream(torch.cuda.current_stream())
+
+            def split(tag):
+                if tag != "decoder":
+                    return
+                self.split_seen = True
+                self.ga.capture_end()
+                self.gb.capture_begin(pool=self.ga.pool(), capture_error_mode="relaxed")
+            enc.grads_ready, enc.grad_bucket_per_layer = split, False
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            with torch.cuda.stream(stream):
+                self.ga.capture_begin(capture_error_mode="relaxed")
+                try:
+                    fwd_bwd()
+                finally:
+                    (self.gb if self.split_seen else self.ga).capture_end()
+            torch.cuda.current_stream().wait_stream(stream)
+            enc.grads_ready = None
+            if not self.split_seen:
+                raise RuntimeError("the backward never reported 'decoder' readiness (no fused decoder on this configuration)")
+
+        def __call__(self):
+            self.ga.replay()
+            on_ready("decoder")        # eager collectives on the side stream, overlapping graph B
+            self.gb.replay()
+            reducer.finish()
+
     def capture():
-        """3 eager steps on a side stream (allocator + autograd warm-up), then capture one step as a HIP graph.
-        Returns (graph or None, mode).  Data-parallel runs first try to capture the WHOLE step including the RCCL
-        all-reduces (bucket 0 overlapping the tail of the backward on a side stream); if the collective cannot be
-        captured on this stack, forward+backward alone is captured and the all-reduces follow each replay."""
+        """3 eager steps on a side stream (allocator + autograd warm-up), then capture the step.
+        Returns (callable or None, mode).  Data-parallel runs try, in this order: (1) ONE graph with the RCCL all-reduces
+        inside, per-layer buckets launched from inside the backward; (2) TWO graphs split at decoder-gradients-final with
+        the collectives launched eagerly in between (overlap without capturing collectives); (3) forward+backward in one
+        graph, all-reduces after the replay (no overlap); (4) eager."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        enc.grads_ready, enc.grad_bucket_per_layer = (on_ready if overlap else None), overlap
         with torch.cuda.stream(s):
             for _ in range(3):
-                fwd_bwd()
-                reducer.finish()
+                full_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if args.no_graph:
-            return None, "eager" + ("+overlap" if overlap else "")
-        if overlap and backend == "nccl":
+        if args.no_graph or forced_mode == "eager":
+            return None, "eager" + ("+overlap(per-layer buckets)" if overlap else "")
+
+        def note(what, e):
+            if rank == 0:
+                print(f"[bench] {what} failed ({type(e).__name__}: {e})", file=sys.stderr)
+            torch.cuda.synchronize()
+            reducer._pending, reducer._launched = [], set()
+
+        if overlap and backend == "nccl" and forced_mode in ("", "one_graph"):
             try:
-                enc.grads_ready = lambda: reducer.launch(0)
                 g = torch.cuda.CUDAGraph()
                 # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     full_step()
                 g.replay()                      # one checked replay: asynchronous collective errors surface here, inside
-                torch.cuda.synchronize()        # the try, and the run falls back to all-reduces after the replay
-                return g, "graph(step+allreduce, bucket 0 overlapped)"
+                torch.cuda.synchronize()        # the try, and the run falls back
+                return g.replay, f"graph(step+allreduce, {len(dec_buckets)} decoder buckets launched per layer from inside the backward)"
             except Exception as e:  # noqa: BLE001
-                if rank == 0:
-                    print(f"[bench] capture with the collectives inside failed ({type(e).__name__}: {e}); "
-                          "capturing forward+backward only", file=sys.stderr)
+                note("capture with the collectives inside", e)
+        if overlap and forced_mode in ("", "two_graph"):
+            try:
+                tg = TwoGraphStep()
+                tg()
                 torch.cuda.synchronize()
-                reducer._pending, reducer._launched = [], set()
-        enc.grads_ready = None
+                return tg, f"two graphs split at decoder-gradients-final, {len(dec_buckets)} decoder buckets all-reduced eagerly between them (overlapping graph B)"
+            except Exception as e:  # noqa: BLE001
+                note("two-graph capture", e)
+        enc.grads_ready, enc.grad_bucket_per_layer = None, False
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fwd_bwd()
-            return g, "graph(fwd+bwd) then allreduce"
+
+            def run():
+                g.replay()
+                reducer.finish()
+            return (run if world > 1 else g.replay), "graph(fwd+bwd) then allreduce"
         except Exception as e:  # noqa: BLE001
-            if rank == 0:
-                print(f"[bench] HIP graph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            torch.cuda.synchronize()
+            note("HIP graph capture", e)
             return None, "eager"
 
-    enc.grads_ready = (lambda: reducer.launch(0)) if overlap else None
     graph, step_mode = capture()
-    if graph is None and overlap:
-        enc.grads_ready = lambda: reducer.launch(0)
+    if graph is None:
+        enc.grads_ready, enc.grad_bucket_per_layer = (on_ready if overlap else None), overlap
 
     def step():
         if graph is not None:
-            graph.replay()
-            if not step_mode.startswith("graph(step"):
-                reducer.finish()
+            graph()
         else:
             full_step()
 
@@ -357,7 +433,7 @@ def main():
         flops = step_flops(c)
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_TFLOPS
         # per-kernel attribution: eager profiled pass with HIP events on the launch stream (rank 0 alone: no collectives)
-        enc.grads_ready = None
+        enc.grads_ready, enc.grad_bucket_per_layer = None, False
         with KernelTimer() as kt:
             for _ in range(args.profile_steps):
                 fwd_bwd()
@@ -408,7 +484,7 @@ def main():
             "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: B={c['B']} scenes/GPU, N_seg={c['Ns']}, "
                                    f"N_q={c['Nq']}, d={c['d']}, H={c['H']}, L={c['L']}, memories={c['memories']}, "
-                                   f"parallel cross-attn + spatial self-attn + FFN2048, heads={c['heads']}, "
+                                   f"{c.get('structure', 'parallel')} cross-attn + spatial self-attn + FFN2048, heads={c['heads']}, "
                                    f"fwd+bwd+grad-pack{'+RCCL all-reduce' if world > 1 else ''}",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
                        "step_mode": step_mode,
@@ -452,13 +528,13 @@ def main():
                     torch.cuda.synchronize(); gc.collect()   # tear the captured graphs down here, on this thread, device idle
             except Exception as e:  # noqa: BLE001
                 result["dropin_graphed_error"] = f"{type(e).__name__}: {e}"[:300]
-            enc.grad_arena, enc.grad_arena_buffers = reducer.slots(), [reducer.flat[0]]
+            enc.grad_arena, enc.grad_arena_buffers = reducer.slots(), [reducer.flat[b] for b in dec_buckets]
             if args.dropout == "off" and not args.no_dropout_leg:
                 # train-mode dropout as the reference trains (reported separately from the parity-checked
                 # p=0 headline): masks are generated inside the attention / LayerNorm / GEMM-epilogue kernels
                 set_dropout_mode("reference")
                 g2, _ = capture()
-                run2 = g2.replay if g2 is not None else fwd_bwd
+                run2 = g2 if g2 is not None else fwd_bwd
                 for _ in range(args.warmup):
                     run2()
                 ms2 = timed_loop(run2, args.steps)

@@ -129,6 +129,14 @@ typedef struct {
 } pq3d_gemm_desc;
 
 int pq3d_gemm(const pq3d_gemm_desc* d, void* stream);
+/* pq3d_gemm serves the small-M launches of the query side (M = B*N_q rows; batch 1, non-transposed A, fp32 B, bf16 /
+ * split-bf16 compute) with whole-K tiles (csrc/gemm_wk.hip): 32- or 64-row x 64-column tiles on 8 waves, all operand
+ * loads of a 256- (or 128-) wide k chunk in flight at once, chosen so that every workgroup of the launch is resident in
+ * one round -- same MFMA order and epilogue as the 64x64-tile kernel, identical bits.  This process-wide switch sets the
+ * option word (bit 0: on -- the default, environment PQ3D_WK=0 turns them off; bits 4-5: force 32- / 64-row tiles
+ * (1 / 2); bits 6-7: force 128- / 256-wide chunks (1 / 2); bit 8: also take launches that need several rounds) and the
+ * largest M they take (max_m <= 0: keep; default 2048, environment PQ3D_WK_MAX_M).  For A/B measurements and tests. */
+int pq3d_gemm_set_wk(int options, int max_m);
 
 
 /* ------------------------------------------------------------------------------------------------
@@ -189,8 +197,8 @@ int pq3d_attn_fwd(const pq3d_attn_desc* d, void* stream);
 int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
 /* pq3d_attn_fwd / pq3d_attn_bwd pick specialised implementations where the call has their shape, and the general
  * streaming kernels otherwise:
- *   bit 0: the all-queries-resident single-pass backward (cross-attention shape: bf16, d_h 32 / 64, Lq <= 128,
- *          Lk >= 128, no additive bias);
+ *   bit 0: the all-queries-resident single-pass backward (cross-attention shape: bf16, d_h 32 / 64, Lq <= 256
+ *          (129..256 queries: two passes over the query halves), Lk >= 128, no additive bias);
  *   bit 1: the small-sequence fp32 kernels (self-attention shape: fp32, Lq, Lk <= 128, key padding / additive bias only,
  *          one workgroup per (scene, head));
  *   bit 2: the all-keys-resident forward (cross-attention shape: bf16, d_h 32, Lq <= 128, Lk >= 128, key-padding mask
@@ -386,7 +394,8 @@ int pq3d_upsample_scatter_mean_bwd(const float* dout, const int64_t* parent, con
 typedef struct {
   int32_t n;                                 /* groups in use */
   int64_t end[PQ3D_MAX_OPT_SEGMENTS];        /* exclusive end offset (elements) of group s in the flat buffer */
-  float lr_mul[PQ3D_MAX_OPT_SEGMENTS];       /* group lr / hp.lr */
+  float lr_mul[PQ3D_MAX_OPT_SEGMENTS];       /* group lr / hp.lr; < 0: SKIP the segment (p, m, v untouched: a parameter
+                                              * without a gradient this step, as torch.optim.AdamW treats grad None) */
   float weight_decay[PQ3D_MAX_OPT_SEGMENTS];
 } pq3d_opt_segments;
 typedef struct {

@@ -145,6 +145,7 @@ _lib = None
 
 _SIGS = {
     "pq3d_gemm": [C.POINTER(GemmDesc), C.c_void_p],
+    "pq3d_gemm_set_wk": [C.c_int, C.c_int],
     "pq3d_attn_fwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_attn_bwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],

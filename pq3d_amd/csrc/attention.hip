@@ -823,6 +823,7 @@ template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream
 }  // namespace
 
 extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, dp ? dp->q : nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_attn_fwd: null descriptor");
   const pq3d_attn_desc d = *dp;
   if (int e = check_desc(d)) return e;
@@ -833,6 +834,7 @@ extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
 }
 
 extern "C" int pq3d_attn_bwd(const pq3d_attn_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, dp ? dp->q : nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_attn_bwd: null descriptor");
   const pq3d_attn_desc d = *dp;
   if (int e = check_desc(d)) return e;
@@ -845,6 +847,7 @@ extern "C" int pq3d_attn_bwd(const pq3d_attn_desc* dp, void* stream) {
 }
 
 extern "C" int pq3d_mask_row_all(const uint8_t* mask, uint8_t* row_open, int64_t rows, int64_t Lk, void* stream) {
+  PQ_DEVICE_GUARD(stream, mask);
   PQ_CHECK_ARG(mask && row_open && rows >= 0 && Lk >= 0, "pq3d_mask_row_all: bad args");
   if (rows == 0) return 0;
   hipLaunchKernelGGL(mask_row_all_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mask,

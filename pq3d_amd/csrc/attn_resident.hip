@@ -241,6 +241,9 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
             for (int r = 0; r < 4; ++r) {
               const int ql = q0 + 4 * lg + r;
               float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sl2, -Lr[r]));   // P from the saved log-sum-exp
+              // padded key: its K row is zeroed, so the score is 0 and exp2(-lse) can overflow for a strongly negative lse
+              // (no zero key); inf * 0 at the dK / dV store would be NaN -> force the probability itself to 0
+              p = kmc[kt] ? 0.f : p;
               if constexpr (MASK3) {
                 const bool masked = (!ros[ql]) && (mt_[(qt * 16 + 4 * lg + r) * R::MLD + kt * 16 + li] != 0);
                 p = masked ? 0.f : p;
@@ -377,11 +380,8 @@ template <int DH, int NQP, bool DROP, bool MASK3, int RW> void launch_res_w(cons
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
   const size_t lds = resident_lds<DH, NQP, RW>(MASK3);
   auto kern = attn_bwd_resident_kernel<DH, NQP, DROP, MASK3, RW>;
-  static bool attr_done = false;   // > 64 KB of dynamic LDS needs the opt-in once per kernel instantiation
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static std::atomic<unsigned> attr_done{0};   // > 64 KB of dynamic LDS: opt-in once per (kernel instantiation, device)
+  if (pq3d_enable_big_lds(kern, 160 * 1024, attr_done)) { (void)hipGetLastError(); }
   hipLaunchKernelGGL(kern, dim3(KS, d.H, d.B), dim3(RW * 64), lds, s, d, q_lo, nq, acc);
 }
 
@@ -622,11 +622,8 @@ __global__ __launch_bounds__((FW + FLW) * 64) void attn_fwd_resident_kernel(cons
 template <bool DROP> void launch_fwd_res(const pq3d_attn_desc& d, hipStream_t s, int KS, int nk_max) {
   const size_t lds = (size_t)nk_max * (32 * 2 + AT<bf16_t, 32>::LDR * 2 + 1) + 16;
   auto kern = attn_fwd_resident_kernel<DROP>;
-  static size_t attr_lds = 0;   // > 64 KB of dynamic LDS needs the opt-in (raised when a larger slice shows up)
-  if (lds > attr_lds) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_lds = lds;
-  }
+  static std::atomic<unsigned> attr_done{0};   // > 64 KB of dynamic LDS: opt-in once per (kernel, device), to the CU's whole LDS
+  if (pq3d_enable_big_lds(kern, 160 * 1024, attr_done)) { (void)hipGetLastError(); }
   hipLaunchKernelGGL(kern, dim3(KS, d.H, d.B), dim3((FW + FLW) * 64), lds, s, d);
 }
 

@@ -326,13 +326,13 @@ template <int DH> void launch_small(const pq3d_attn_desc& d, hipStream_t s, bool
   const int slices = bwd ? (max(d.Lq, d.Lk) + SR - 1) / SR : (d.Lq + SR - 1) / SR;
   if (bwd) {
     auto kern = attn_small_bwd_kernel<DH>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    static std::atomic<unsigned> done{0};   // per (kernel, device)
+    if (pq3d_enable_big_lds(kern, 160 * 1024, done)) { (void)hipGetLastError(); }
     hipLaunchKernelGGL(kern, dim3(d.H, d.B, slices), dim3(SNB<DH>::T), lds, s, d);
   } else {
     auto kern = attn_small_fwd_kernel<DH>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); done = true; }
+    static std::atomic<unsigned> done{0};   // per (kernel, device)
+    if (pq3d_enable_big_lds(kern, 160 * 1024, done)) { (void)hipGetLastError(); }
     hipLaunchKernelGGL(kern, dim3(d.H, d.B, slices), dim3(SN<DH>::T), lds, s, d);
   }
 }

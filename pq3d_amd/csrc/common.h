@@ -270,6 +270,48 @@ struct ZeroList {
 };
 int pq3d_zero_launch(const ZeroList& z, hipStream_t s);   // returns 0 or a hipError_t (error text set)
 
+// ---------------------------------------------------------------------------------------------
+// Device of a call ("take the device from its inputs").  Every entry point that launches work takes the stream
+// it launches on; the stream's device is made current for the duration of the call and the caller's device restored
+// afterwards (hipSetDevice is per host thread: nothing process-wide changes, PyTorch's autograd thread and the caller's
+// thread do not see each other's setting).  With the NULL stream the device comes from the first device pointer of the
+// call instead.  Single-device processes (the normal one-process-per-GPU deployment with one visible device) skip all of it.
+// ---------------------------------------------------------------------------------------------
+int pq3d_visible_devices();   // api.cpp: cached hipGetDeviceCount
+struct PqDeviceGuard {
+  int prev = -1;
+  PqDeviceGuard(void* stream, const void* ptr) {
+    if (pq3d_visible_devices() <= 1) return;
+    int want = -1, cur = 0;
+    if (stream) {
+      hipDevice_t dv;
+      if (hipStreamGetDevice((hipStream_t)stream, &dv) == hipSuccess) want = (int)dv; else (void)hipGetLastError();
+    } else if (ptr) {
+      hipPointerAttribute_t a;
+      if (hipPointerGetAttributes(&a, ptr) == hipSuccess && a.type == hipMemoryTypeDevice) want = a.device; else (void)hipGetLastError();
+    }
+    if (want < 0 || hipGetDevice(&cur) != hipSuccess || cur == want) return;
+    if (hipSetDevice(want) == hipSuccess) prev = cur;
+  }
+  ~PqDeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  PqDeviceGuard(const PqDeviceGuard&) = delete;
+};
+#define PQ_DEVICE_GUARD(stream, ptr) PqDeviceGuard pq_device_guard_((void*)(stream), (const void*)(ptr))
+
+// > 64 KB of dynamic LDS is a per-DEVICE function attribute: set it once per (kernel, device), race-free.
+#include <atomic>
+template <typename K> inline int pq3d_enable_big_lds(K kern, int bytes, std::atomic<unsigned>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned bit = 1u << (dev & 31);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return 0;
+}
+
 // host-side error plumbing (api.cpp)
 extern "C" void pq3d_set_error(const char* msg);
 #define PQ_CHECK_ARG(cond, msg)      \

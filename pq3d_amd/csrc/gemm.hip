@@ -10,7 +10,7 @@
 //   FAST path  : operands 16-byte aligned, leading dims / K (or M,N for transposed operands) multiples of the
 //                chunk -> unconditional vector loads from clamped addresses + select.
 //   generic    : guarded scalar loads (K = 3 or 5 projections, odd shapes).
-#include "common.h"
+#include "gemm_common.h"
 
 #ifdef PQ3D_DEBUG_TIMING
 __device__ long long pq3d_dbg[16];
@@ -22,6 +22,7 @@ extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol
 
 bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
 bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
+bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err);   // gemm_wk.hip
 
 namespace {
 
@@ -33,35 +34,6 @@ template <typename CT> struct Tile {
   static constexpr int BKE = 128 / (int)sizeof(CT);         // k elements per tile
   static constexpr int LDK = BKE + 16 / (int)sizeof(CT);    // padded LDS row (elements)
   static constexpr int CPR = BKE / EPL;                     // 16-byte chunks per row (= 8)
-};
-
-// ---- raw chunk of EPL source elements -------------------------------------------------------------------
-template <typename TS, int EPL> struct Raw;
-template <> struct Raw<float, 8> {
-  float4 a, b;
-  PQ_DEV void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
-  PQ_DEV void to_float(float* v) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
-};
-template <> struct Raw<float, 4> {
-  float4 a;
-  PQ_DEV void load(const float* p) { a = *(const float4*)p; }
-  PQ_DEV void to_float(float* v) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
-};
-template <> struct Raw<bf16_t, 8> {
-  u32x4 a;
-  PQ_DEV void load(const bf16_t* p) { a = *(const u32x4*)p; }
-  PQ_DEV void to_float(float* v) const {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(a[j] << 16); v[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u); }
-  }
-};
-template <> struct Raw<bf16_t, 4> {
-  u32x2 a;
-  PQ_DEV void load(const bf16_t* p) { a = *(const u32x2*)p; }
-  PQ_DEV void to_float(float* v) const {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { v[2 * j] = __uint_as_float(a[j] << 16); v[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u); }
-  }
 };
 
 // ---- FAST stager: branch-free raw loads, conversion at store time ------------------------------------------
@@ -200,18 +172,6 @@ struct FastStage {
   }
 };
 
-// bf16 fragment (row `r0 + li` of the operand, k-slots 8*lg..8*lg+7 of k-step ks) from a [k][m]-oriented LDS tile via
-// ds_read_b64_tr_b16 (lane (li,lg) pointing at row base + li/4, columns 4*(li%4).. receives tile[base + j][li]).
-typedef short v4i16_t __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4i16_t lds_v4i16_t;
-PQ_DEV u32x4 km_frag(const bf16_t* tile, int ldk, int r0, int ks, int li, int lg) {
-  const bf16_t* p0 = tile + (ks * 32 + 8 * lg + (li >> 2)) * ldk + r0 + 4 * (li & 3);
-  const v4i16_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)p0);
-  const v4i16_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)(p0 + 4 * ldk));
-  const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
-  return (u32x4){lo.x, lo.y, hi.x, hi.y};
-}
-
 // ---- generic stager: guarded scalar loads, runtime dtypes --------------------------------------------------
 template <typename CT, bool TR>
 struct SlowStage {
@@ -337,68 +297,6 @@ PQ_DEV void mma_tile_x3(f32x4 (&acc)[2][2], const bf16_t* Ah, const bf16_t* Al, 
 // branch-wrapped element accesses (which cost 14k cycles -- more than the whole K loop -- in the first version).
 constexpr int CLD = BN + 4;  // padded fp32 row of the transposed C tile
 
-template <int NV> PQ_DEV void load_vec(const void* p, int dt, long idx, bool vec_ok, int nvalid, float* v) {
-  if (dt == PQ3D_F32) {
-    const float* q = (const float*)p + idx;
-    if (vec_ok) {
-#pragma unroll
-      for (int j = 0; j < NV; j += 4) { const float4 t = *(const float4*)(q + j); v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w; }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) v[j] = j < nvalid ? q[j] : 0.f;
-    }
-  } else {
-    const bf16_t* q = (const bf16_t*)p + idx;
-    if (vec_ok) {
-#pragma unroll
-      for (int j = 0; j < NV; j += 8) {
-        const u32x4 t = *(const u32x4*)(q + j);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[j + 2 * k] = __uint_as_float(t[k] << 16); v[j + 2 * k + 1] = __uint_as_float(t[k] & 0xffff0000u); }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) v[j] = j < nvalid ? bf2f(q[j]) : 0.f;
-    }
-  }
-}
-template <int NV> PQ_DEV void store_vec(void* p, int dt, long idx, bool vec_ok, int nvalid, const float* v) {
-  if (dt == PQ3D_F32) {
-    float* q = (float*)p + idx;
-    if (vec_ok) {
-#pragma unroll
-      for (int j = 0; j < NV; j += 4) *(float4*)(q + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) if (j < nvalid) q[j] = v[j];
-    }
-  } else {
-    bf16_t* q = (bf16_t*)p + idx;
-    if (vec_ok) {
-#pragma unroll
-      for (int j = 0; j < NV; j += 8)
-        *(u32x4*)(q + j) = (u32x4){pack_bf2(v[j], v[j + 1]), pack_bf2(v[j + 2], v[j + 3]), pack_bf2(v[j + 4], v[j + 5]), pack_bf2(v[j + 6], v[j + 7])};
-    } else {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) if (j < nvalid) q[j] = f2bf(v[j]);
-    }
-  }
-}
-
-// The per-group pointers of a block's (first) group.  load(d, g) reads them from the descriptor's arrays; the fast kernel
-// requests them SPECULATIVELY for group blockIdx.z together with the header scalars (one scalar-cache round trip instead
-// of two dependent ones: the true group index needs splitk / batch / kconcat from the header) and reloads only when the
-// guess was wrong (split-K, batched or K-concatenated launches).
-struct GPtrs {
-  const void *A, *A2, *B, *B2, *bias, *aux;
-  void *C, *C2;
-  const uint8_t* row_mask;
-  PQ_DEV void load(const pq3d_kdesc& d, int g) {
-    const pq3d_kgroup& q = d.gp[g];
-    A = q.A; A2 = q.A2; B = q.B; B2 = q.B2; bias = q.bias; aux = q.aux; C = q.C; C2 = q.C2; row_mask = q.row_mask;
-  }
-};
-
 PQ_DEV void epilogue(const pq3d_kdesc& d, const GPtrs& gp, const f32x4 (&acc)[2][2], float* Ct, int g, int z, int m0, int n0,
                      int wm, int wn, int li, int lg, int tid, bool bias_done = false) {
   if (d.splitk > 1) {
@@ -429,72 +327,12 @@ PQ_DEV void epilogue(const pq3d_kdesc& d, const GPtrs& gp, const f32x4 (&acc)[2]
   const int lrow = tid >> 2, lcol = (tid & 3) * 16;
   const int row = m0 + lrow, col = n0 + lcol;
   if (row >= d.M || col >= d.N) return;
-  const int nvalid = min(16, d.N - col);
   float v[16];
 #pragma unroll
   for (int j = 0; j < 16; j += 4) { const float4 t = *(const float4*)&Ct[lrow * CLD + lcol + j]; v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w; }
-  void* C = gp.C;
-  const long ci = (long)z * d.strideC + (long)row * d.ldc + col;
-  // vector path: full 16-column segment, 16-byte aligned for the widest participant
-  const uintptr_t pbits = (uintptr_t)C | (uintptr_t)gp.C2 | (uintptr_t)gp.aux;
-  const bool vec_ok = nvalid == 16 && (d.ldc % 8 == 0) && (d.strideC % 8 == 0) && (col % 8 == 0) && (pbits & 15) == 0;
-  if (gp.bias && !bias_done) {
-    float bv[16];
-    load_vec<16>(gp.bias, d.dtBias, col, nvalid == 16 && (col % 8 == 0) && (((uintptr_t)gp.bias) & 15) == 0, nvalid, bv);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] += bv[j];
-  }
-  if (gp.C2) store_vec<16>(gp.C2, d.dtC2, ci, vec_ok, nvalid, v);
-  if (d.act == PQ3D_ACT_RELU) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = fmaxf(v[j], 0.f);
-  } else if (d.act == PQ3D_ACT_GELU) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = gelu_f(v[j]);
-  }
-  if (drop_on(d.drop)) {   // dropout of the activated output; col is a multiple of 16, so pairs never straddle threads
-    const DropState ds = drop_init(d.drop, g, d.N);
-    const uint32_t drow = (uint32_t)((long)z * d.M + row);
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-      const uint32_t w = drop_word(ds, drow, (uint32_t)(col + j) >> 1);
-      v[j] = drop_keep_lo(ds, w) ? v[j] * ds.scale : 0.f;
-      v[j + 1] = drop_keep_hi(ds, w) ? v[j + 1] * ds.scale : 0.f;
-    }
-  }
-  if (d.act_grad) {
-    float av[16];
-    load_vec<16>(gp.aux, d.dtAux, ci, vec_ok, nvalid, av);
-    if (d.act_grad == PQ3D_ACT_RELU) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = av[j] > 0.f ? v[j] : 0.f;
-    } else if (d.act_grad == PQ3D_ACT_GELU) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] *= gelu_grad_f(av[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] += av[j];
-    }
-  }
-  const long ri = (long)z * d.M + row;
-  float rsc = 1.f;
-  if (gp.row_mask) rsc = gp.row_mask[ri] ? 1.f : 0.f;
-  if (d.row_scale) rsc *= d.row_scale[ri];
-  if (gp.row_mask || d.row_scale) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] *= rsc;
-  }
-  if (d.row_fill_flag && d.row_fill_flag[ri]) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = d.row_fill;
-  }
-  store_vec<16>(C, d.dtC, ci, vec_ok, nvalid, v);
-  if (d.mask_out) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (j < nvalid) d.mask_out[((long)z * d.N + col + j) * d.M + row] = (1.f / (1.f + __expf(-v[j])) < 0.5f) ? 1 : 0;
-  }
+  epi_row<16>(d, gp, v, g, z, row, col, bias_done);
 }
+
 
 struct BlockCoords {
   int g, z, m0, n0, kt0, kt1, ng;
@@ -734,6 +572,7 @@ template <typename CT> void launch_slow(const pq3d_gemm_desc& d, const pq3d_kdes
 }  // namespace
 
 extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, dp ? dp->A[0] : nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_gemm: null descriptor");
   pq3d_gemm_desc d = *dp;
   PQ_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K >= 0, "pq3d_gemm: negative dims");
@@ -757,6 +596,13 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
                "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated split-K GEMM");
   hipStream_t s = (hipStream_t)stream;
   pq3d_kdesc kd = make_kdesc(d);   // the kernels' compact form of the descriptor (common.h)
+  int wk_err = 0;
+  // small-M launches (the query side): whole-K tiles, gemm_wk.hip -- same bits, a third of the in-kernel latency
+  if ((d.splitk == 1 || d.accumulate) && pq3d_gemm_wk_try(d, kd, s, &wk_err)) {
+    if (wk_err) return wk_err;
+    PQ_LAUNCH_CHECK();
+    return 0;
+  }
   if (d.ct == PQ3D_BF16X3) {
     // split-bf16: C = A.B^T of fp32 operands to fp32-grade accuracy on the bf16 matrix cores (3 MFMAs per product term
     // pair).  Available for the aligned row-major (NT) layout with fp32 A and B; anything else runs the exact-f32 MFMA
@@ -792,6 +638,11 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
         }
       }
     }
+  }
+  if (d.splitk > 1 && !d.accumulate && pq3d_gemm_wk_try(d, kd, s, &wk_err)) {   // split-K into a freshly zeroed C
+    if (wk_err) return wk_err;
+    PQ_LAUNCH_CHECK();
+    return 0;
   }
   if (pq3d_gemm_tt128_try(d, kd, s)) {   // big bf16 weight-gradient products: 128x128 tiles, own split factor
     PQ_LAUNCH_CHECK();

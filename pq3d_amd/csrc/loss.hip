@@ -277,6 +277,7 @@ static int check_layers(int layers, const char* who) {
 }
 
 extern "C" int pq3d_mask_cost_prep(const pq3d_mask_prep_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_mask_cost_prep: null descriptor");
   const pq3d_mask_prep_desc d = *dp;
   if (int e = check_layers(d.layers, "pq3d_mask_cost_prep: layers must be in [1, PQ3D_MAX_GROUPS]")) return e;
@@ -293,6 +294,7 @@ extern "C" int pq3d_mask_cost_prep(const pq3d_mask_prep_desc* dp, void* stream) 
 extern "C" int32_t pq3d_mask_cost_nsplit(int32_t Ns) { return (Ns + PREP_ROWS - 1) / PREP_ROWS; }
 
 extern "C" int pq3d_match_cost(const pq3d_match_cost_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_match_cost: null descriptor");
   const pq3d_match_cost_desc d = *dp;
   if (int e = check_layers(d.layers, "pq3d_match_cost: layers must be in [1, PQ3D_MAX_GROUPS]")) return e;
@@ -308,6 +310,7 @@ extern "C" int pq3d_match_cost(const pq3d_match_cost_desc* dp, void* stream) {
 }
 
 extern "C" int pq3d_matched_mask_grad(const pq3d_mask_grad_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_matched_mask_grad: null descriptor");
   const pq3d_mask_grad_desc d = *dp;
   if (int e = check_layers(d.layers, "pq3d_matched_mask_grad: layers must be in [1, PQ3D_MAX_GROUPS]")) return e;
@@ -336,6 +339,7 @@ static int check_ce(const pq3d_ce_desc& d, bool bwd) {
   return 0;
 }
 extern "C" int pq3d_cross_entropy_fwd(const pq3d_ce_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_cross_entropy_fwd: null descriptor");
   const pq3d_ce_desc d = *dp;
   if (int e = check_ce(d, false)) return e;
@@ -345,6 +349,7 @@ extern "C" int pq3d_cross_entropy_fwd(const pq3d_ce_desc* dp, void* stream) {
   return 0;
 }
 extern "C" int pq3d_cross_entropy_bwd(const pq3d_ce_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_cross_entropy_bwd: null descriptor");
   const pq3d_ce_desc d = *dp;
   if (int e = check_ce(d, true)) return e;
@@ -356,6 +361,7 @@ extern "C" int pq3d_cross_entropy_bwd(const pq3d_ce_desc* dp, void* stream) {
 
 extern "C" int pq3d_padded_mask_sums(const float* X, const float* T, const uint8_t* P, float* part, int32_t B, int32_t S,
                                      int32_t N, void* stream) {
+  PQ_DEVICE_GUARD(stream, X);
   PQ_CHECK_ARG(X && T && P && part && B >= 0 && S >= 1 && N >= 1, "pq3d_padded_mask_sums: bad args");
   const size_t lds = (size_t)64 * (N + 1) * sizeof(float);
   PQ_CHECK_ARG(lds <= 160 * 1024, "pq3d_padded_mask_sums: N too large for the LDS tile");
@@ -372,6 +378,7 @@ extern "C" int pq3d_padded_mask_sums(const float* X, const float* T, const uint8
 
 extern "C" int pq3d_padded_mask_grad(const float* X, const float* T, const uint8_t* P, const float* sums, const float* gm,
                                      const float* gd, float* dX, int32_t B, int32_t S, int32_t N, void* stream) {
+  PQ_DEVICE_GUARD(stream, X);
   PQ_CHECK_ARG(X && T && P && sums && gm && gd && dX && B >= 0 && S >= 1 && N >= 1, "pq3d_padded_mask_grad: bad args");
   const size_t lds = (size_t)GRAD_ROWS * (N + 1) * sizeof(float);
   PQ_CHECK_ARG(lds <= 64 * 1024, "pq3d_padded_mask_grad: N too large for the LDS tile");

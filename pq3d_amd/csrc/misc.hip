@@ -457,6 +457,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const CastTPtrs p, 
 }  // namespace
 
 extern "C" int pq3d_mask_not(const uint8_t* const* src, uint8_t* const* dst, const int64_t* counts, int32_t groups, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(src && dst && counts && groups >= 1 && groups <= PQ3D_MAX_GROUPS, "pq3d_mask_not: bad args");
   NotPtrs p;
   long mx = 0;
@@ -472,6 +473,7 @@ extern "C" int pq3d_mask_not(const uint8_t* const* src, uint8_t* const* dst, con
 }
 
 extern "C" int pq3d_zero_many(float* const* bufs, const int64_t* counts, int32_t n, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(bufs && counts && n >= 0, "pq3d_zero_many: bad args");
   ZeroList z;
   for (int i = 0; i < n; ++i) {
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(256) void copy_many_kernel(const CopyList c) {
 }  // namespace
 
 extern "C" int pq3d_copy_many(const float* const* src, float* const* dst, const int64_t* counts, int32_t n, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(src && dst && counts && n >= 0, "pq3d_copy_many: bad args");
   CopyList c;
   long mx = 0;
@@ -520,6 +523,7 @@ extern "C" int pq3d_copy_many(const float* const* src, float* const* dst, const 
 }
 
 extern "C" int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_t count, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(src && out && n >= 1 && n <= PQ3D_MAX_GROUPS && count >= 0 && (count % 4) == 0, "pq3d_sum_n: bad args (count % 4 == 0)");
   SumPtrs p;
   for (int g = 0; g < n; ++g) {
@@ -534,6 +538,7 @@ extern "C" int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_
 }
 
 extern "C" int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, void* stream) {
+  PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && out && ws && n >= 1, "pq3d_mean_all: bad args");
   PQ_CHECK_ARG((((uintptr_t)x) & 15) == 0, "pq3d_mean_all: x must be 16-byte aligned");
   long nb = (n / 4 + 255) / 256;
@@ -545,6 +550,7 @@ extern "C" int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, v
 }
 
 extern "C" int pq3d_fill_scaled(float* dst, int64_t n, const float* scalar, float c, void* stream) {
+  PQ_DEVICE_GUARD(stream, dst);
   PQ_CHECK_ARG(dst && scalar && n >= 0, "pq3d_fill_scaled: bad args");
   if (n == 0) return 0;
   hipLaunchKernelGGL(fill_scaled_kernel, dim3(grid1d(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, dst, (long)n, scalar, c);
@@ -554,6 +560,7 @@ extern "C" int pq3d_fill_scaled(float* dst, int64_t n, const float* scalar, floa
 
 extern "C" int pq3d_cast_transpose(const float* const* src, void* const* out, void* const* outT, int32_t groups, int32_t rows,
                                    int32_t cols, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(src && out && outT && groups >= 1 && groups <= PQ3D_MAX_GROUPS, "pq3d_cast_transpose: bad args");
   PQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 32 == 0 && rows % cols == 0, "pq3d_cast_transpose: cols % 32 == 0, rows % cols == 0");
   CastTPtrs p;
@@ -567,6 +574,7 @@ extern "C" int pq3d_cast_transpose(const float* const* src, void* const* out, vo
 }
 
 extern "C" int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream) {
+  PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && out && R >= 0 && N >= 1 && ld >= N, "pq3d_colsum: bad args");
   const void* xs[1] = {x};
   float* outs[1] = {out};
@@ -575,6 +583,7 @@ extern "C" int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int6
 
 extern "C" int pq3d_colsum_grouped(const void* const* x, float* const* out, int32_t groups, int32_t dt, int64_t R,
                                    int64_t N, int64_t ld, int32_t accumulate, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(x && out && groups >= 1 && groups <= PQ3D_MAX_GROUPS && R >= 0 && N >= 1 && ld >= N,
                "pq3d_colsum_grouped: bad args");
   ColsumPtrs cp;
@@ -592,6 +601,7 @@ extern "C" int pq3d_colsum_grouped(const void* const* x, float* const* out, int3
 
 extern "C" int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty, int64_t R, int64_t C,
                                const float* scale, const uint8_t* zero_flag, const uint8_t* keep_mask, void* stream) {
+  PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && y && R >= 0 && C >= 1, "pq3d_scale_rows: bad args");
   if (R == 0) return 0;
   hipLaunchKernelGGL(scale_rows_kernel, dim3(grid1d(R * C)), dim3(256), 0, (hipStream_t)stream, x, dtx, y, dty, (long)R,
@@ -602,6 +612,7 @@ extern "C" int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty,
 
 extern "C" int pq3d_add_cast(const float* const* a, const float* const* b, void* const* out, int32_t groups,
                              int32_t dt_out, int64_t n, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(a && out && groups >= 1 && groups <= PQ3D_MAX_GROUPS && n >= 0, "pq3d_add_cast: bad args");
   PQ_CHECK_ARG((n % 8) == 0, "pq3d_add_cast: n must be a multiple of 8");
   AddCastPtrs p;
@@ -617,6 +628,7 @@ extern "C" int pq3d_add_cast(const float* const* a, const float* const* b, void*
 }
 
 extern "C" int pq3d_bias_add_rows(const float* x, const float* bias, float* out, int64_t R, int64_t N, void* stream) {
+  PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && bias && out && R >= 0 && N >= 4 && (N % 4) == 0, "pq3d_bias_add_rows: bad args (N % 4 == 0)");
   if (R == 0) return 0;
   hipLaunchKernelGGL(bias_add_rows_kernel, dim3(grid1d(R * N / 4)), dim3(256), 0, (hipStream_t)stream, x, bias, out,
@@ -627,6 +639,7 @@ extern "C" int pq3d_bias_add_rows(const float* x, const float* bias, float* out,
 
 extern "C" int pq3d_act_bwd(const void* dy, int32_t dt_dy, const void* saved, int32_t dt_saved, void* dpre,
                             int32_t dt_dpre, int32_t act, int64_t n, void* stream) {
+  PQ_DEVICE_GUARD(stream, dy);
   PQ_CHECK_ARG(dy && saved && dpre && n >= 0, "pq3d_act_bwd: bad args");
   if (n == 0) return 0;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, dy, dt_dy, saved, dt_saved,
@@ -637,6 +650,7 @@ extern "C" int pq3d_act_bwd(const void* dy, int32_t dt_dy, const void* saved, in
 
 extern "C" int pq3d_fill_cols(const float* x, float* y, int64_t R, int64_t C, const int32_t* cols, int32_t ncols,
                               float value, void* stream) {
+  PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && y && R >= 0 && C >= 1 && ncols >= 0 && (ncols == 0 || cols), "pq3d_fill_cols: bad args");
   if (R == 0) return 0;
   hipLaunchKernelGGL(fill_cols_kernel, dim3(grid1d(R * C)), dim3(256), 0, (hipStream_t)stream, x, y, (long)R, (long)C,
@@ -646,6 +660,7 @@ extern "C" int pq3d_fill_cols(const float* x, float* y, int64_t R, int64_t C, co
 }
 
 extern "C" int pq3d_mask_inv_den(const uint8_t* const* masks, int32_t M, int64_t n, float* inv_den, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
   PQ_CHECK_ARG(masks && M >= 1 && M <= PQ3D_MAX_GROUPS && inv_den && n >= 0, "pq3d_mask_inv_den: bad args");
   if (n == 0) return 0;
   MaskPtrs mp;
@@ -658,6 +673,7 @@ extern "C" int pq3d_mask_inv_den(const uint8_t* const* masks, int32_t M, int64_t
 
 extern "C" int pq3d_pairwise_locs(const float* centers, int64_t center_stride, float* out, int32_t B, int32_t L,
                                   float eps, void* stream) {
+  PQ_DEVICE_GUARD(stream, centers);
   PQ_CHECK_ARG(centers && out && B >= 0 && L >= 0 && center_stride >= 3, "pq3d_pairwise_locs: bad args");
   PQ_CHECK_ARG((size_t)L * 3 * sizeof(float) <= 48 * 1024, "pq3d_pairwise_locs: L too large");
   if (B == 0 || L == 0) return 0;
@@ -669,6 +685,7 @@ extern "C" int pq3d_pairwise_locs(const float* centers, int64_t center_stride, f
 
 extern "C" int pq3d_fourier(const float* xyz, int64_t xyz_stride, const float* cmin, const float* cmax,
                             const float* gauss_B, float* out, int32_t B, int32_t N, int32_t half, void* stream) {
+  PQ_DEVICE_GUARD(stream, xyz);
   PQ_CHECK_ARG(xyz && cmin && cmax && gauss_B && out && xyz_stride >= 3 && half >= 1, "pq3d_fourier: bad args");
   if (B == 0 || N == 0) return 0;
   hipLaunchKernelGGL(fourier_kernel, dim3(grid1d((long)B * N * half)), dim3(256), 0, (hipStream_t)stream, xyz,
@@ -680,6 +697,7 @@ extern "C" int pq3d_fourier(const float* xyz, int64_t xyz_stride, const float* c
 extern "C" int pq3d_spatial_bias_fwd_grouped(const float* pl, const float* const* W, const float* const* bw,
                                              float* const* bias, int32_t groups, int32_t B, int32_t H, int32_t L,
                                              void* stream) {
+  PQ_DEVICE_GUARD(stream, pl);
   PQ_CHECK_ARG(pl && W && bw && bias && H >= 1 && groups >= 1 && groups <= PQ3D_MAX_GROUPS,
                "pq3d_spatial_bias_fwd_grouped: bad args");
   SbFwdGroups gr;
@@ -696,11 +714,13 @@ extern "C" int pq3d_spatial_bias_fwd_grouped(const float* pl, const float* const
 
 extern "C" int pq3d_spatial_bias_fwd(const float* pl, const float* W, const float* bw, float* bias, int32_t B,
                                      int32_t H, int32_t L, void* stream) {
+  PQ_DEVICE_GUARD(stream, pl);
   return pq3d_spatial_bias_fwd_grouped(pl, &W, &bw, &bias, 1, B, H, L, stream);
 }
 
 extern "C" int pq3d_spatial_bias_bwd(const float* pl, const float* W, const float* bw, const float* dbias, float* dW,
                                      float* dbw, int32_t B, int32_t H, int32_t L, void* stream) {
+  PQ_DEVICE_GUARD(stream, pl);
   PQ_CHECK_ARG(pl && W && bw && dbias && dW && dbw && H >= 1, "pq3d_spatial_bias_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (int e = memset_async(dW, sizeof(float) * H * 5, s)) return e;
@@ -711,6 +731,7 @@ extern "C" int pq3d_spatial_bias_bwd(const float* pl, const float* W, const floa
 extern "C" int pq3d_spatial_bias_bwd_grouped(const float* pl, const float* const* W, const float* const* bw,
                                              const float* const* dbias, float* const* dW, float* const* dbw,
                                              int32_t groups, int32_t B, int32_t H, int32_t L, void* stream) {
+  PQ_DEVICE_GUARD(stream, pl);
   PQ_CHECK_ARG(pl && W && bw && dbias && dW && dbw && H >= 1 && groups >= 1 && groups <= PQ3D_MAX_GROUPS,
                "pq3d_spatial_bias_bwd_grouped: bad args");
   SbGroups gr;
@@ -733,10 +754,12 @@ extern "C" int pq3d_spatial_bias_bwd_grouped(const float* pl, const float* const
 
 extern "C" int pq3d_spatial_bias_bwd_acc(const float* pl, const float* W, const float* bw, const float* dbias,
                                          float* dW, float* dbw, int32_t B, int32_t H, int32_t L, void* stream) {
+  PQ_DEVICE_GUARD(stream, pl);
   return pq3d_spatial_bias_bwd_grouped(pl, &W, &bw, &dbias, &dW, &dbw, 1, B, H, L, stream);
 }
 
 extern "C" int pq3d_gate_mix_fwd(const float* q, const float* u, const float* g, float* y, int64_t n, void* stream) {
+  PQ_DEVICE_GUARD(stream, q);
   PQ_CHECK_ARG(q && u && g && y && n >= 0, "pq3d_gate_mix_fwd: bad args");
   if (n == 0) return 0;
   hipLaunchKernelGGL(gate_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, q, u, g, y, (long)n);
@@ -745,6 +768,7 @@ extern "C" int pq3d_gate_mix_fwd(const float* q, const float* u, const float* g,
 }
 extern "C" int pq3d_gate_mix_bwd(const float* q, const float* u, const float* g, const float* dy, float* dq, float* du,
                                  float* dg, int64_t n, void* stream) {
+  PQ_DEVICE_GUARD(stream, q);
   PQ_CHECK_ARG(q && u && g && dy && dq && du && dg && n >= 0, "pq3d_gate_mix_bwd: bad args");
   if (n == 0) return 0;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, q, u, g, dy, dq, du, dg,
@@ -755,6 +779,7 @@ extern "C" int pq3d_gate_mix_bwd(const float* q, const float* u, const float* g,
 
 extern "C" int pq3d_scatter_mean_fwd(const float* src, const int64_t* index, float* out, float* count, int64_t N,
                                      int64_t C, int64_t S, void* stream) {
+  PQ_DEVICE_GUARD(stream, src);
   PQ_CHECK_ARG(src && index && out && count && N >= 0 && C >= 1 && S >= 0, "pq3d_scatter_mean_fwd: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (S == 0) return 0;
@@ -769,6 +794,7 @@ extern "C" int pq3d_scatter_mean_fwd(const float* src, const int64_t* index, flo
 }
 extern "C" int pq3d_upsample_scatter_mean_fwd(const float* src, const int64_t* parent, const int64_t* index, float* out,
                                               float* count, int64_t N, int64_t Nc, int64_t C, int64_t S, void* stream) {
+  PQ_DEVICE_GUARD(stream, src);
   PQ_CHECK_ARG(src && parent && index && out && count && N >= 0 && Nc >= 0 && C >= 1 && S >= 0,
                "pq3d_upsample_scatter_mean_fwd: bad args");
   hipStream_t s = (hipStream_t)stream;
@@ -787,6 +813,7 @@ extern "C" int pq3d_upsample_scatter_mean_fwd(const float* src, const int64_t* p
 extern "C" int pq3d_upsample_scatter_mean_bwd(const float* dout, const int64_t* parent, const int64_t* index,
                                               const float* count, float* dsrc, int64_t N, int64_t Nc, int64_t C, int64_t S,
                                               void* stream) {
+  PQ_DEVICE_GUARD(stream, dout);
   PQ_CHECK_ARG(dout && parent && index && count && dsrc && N >= 0 && Nc >= 0 && C >= 1 && S >= 0,
                "pq3d_upsample_scatter_mean_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
@@ -800,6 +827,7 @@ extern "C" int pq3d_upsample_scatter_mean_bwd(const float* dout, const int64_t* 
 }
 extern "C" int pq3d_scatter_mean_bwd(const float* dout, const int64_t* index, const float* count, float* dsrc,
                                      int64_t N, int64_t C, void* stream) {
+  PQ_DEVICE_GUARD(stream, dout);
   PQ_CHECK_ARG(dout && index && count && dsrc && N >= 0 && C >= 1, "pq3d_scatter_mean_bwd: bad args");
   if (N == 0) return 0;
   hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(grid1d(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dout,
@@ -830,6 +858,7 @@ __global__ void dropout_apply_kernel(const void* x, int dtx, void* y, int dty, l
 }  // namespace
 
 extern "C" int pq3d_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, const pq3d_dropout* dr, void* stream) {
+  PQ_DEVICE_GUARD(stream, keep);
   PQ_CHECK_ARG(keep && dr && dr->seed && rows >= 0 && cols >= 1 && dr->p >= 0.f, "pq3d_dropout_mask: bad args");
   PQ_CHECK_DROP(*dr, rows, cols, "pq3d_dropout_mask");
   if (rows == 0) return 0;
@@ -841,6 +870,7 @@ extern "C" int pq3d_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, cons
 
 extern "C" int pq3d_dropout_apply(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
                                   const pq3d_dropout* dr, void* stream) {
+  PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && y && dr && dr->seed && rows >= 0 && cols >= 1 && dr->p > 0.f, "pq3d_dropout_apply: bad args");
   PQ_CHECK_DROP(*dr, rows, cols, "pq3d_dropout_apply");
   if (rows == 0) return 0;
@@ -887,6 +917,7 @@ template <typename E> E pad_as(const void* p) { E v; memcpy(&v, p, sizeof(E)); r
 
 extern "C" int pq3d_pad_sequence(const void* src, const int64_t* offsets, void* out, uint8_t* mask, int32_t B, int64_t L,
                                  int64_t D, int32_t elem_size, const void* pad_value, void* stream) {
+  PQ_DEVICE_GUARD(stream, src);
   PQ_CHECK_ARG(offsets && out && pad_value && B >= 0 && L >= 0 && D >= 1, "pq3d_pad_sequence: bad args");
   PQ_CHECK_ARG(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8, "pq3d_pad_sequence: element size");
   if (B == 0 || L == 0) return 0;
@@ -905,6 +936,7 @@ extern "C" int pq3d_pad_sequence(const void* src, const int64_t* offsets, void* 
 extern "C" int pq3d_pad_sequence_2d(const void* src, const int64_t* offsets, const int32_t* heights, const int32_t* widths,
                                     void* out, uint8_t* mask, int32_t B, int64_t H, int64_t W, int64_t D, int32_t elem_size,
                                     const void* pad_value, void* stream) {
+  PQ_DEVICE_GUARD(stream, src);
   PQ_CHECK_ARG(offsets && heights && widths && out && pad_value && B >= 0 && H >= 0 && W >= 0 && D >= 1,
                "pq3d_pad_sequence_2d: bad args");
   PQ_CHECK_ARG(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8, "pq3d_pad_sequence_2d: element size");
@@ -936,6 +968,7 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int64
 }
 }  // namespace
 extern "C" int pq3d_embedding_fwd(const float* table, const int64_t* ids, float* out, int64_t R, int32_t d, void* stream) {
+  PQ_DEVICE_GUARD(stream, table);
   PQ_CHECK_ARG(table && ids && out && R >= 0 && d >= 1, "pq3d_embedding_fwd: bad args");
   if (R == 0) return 0;
   hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid1d(R * d)), dim3(256), 0, (hipStream_t)stream, table, ids, out, (long)R, d);
@@ -944,6 +977,7 @@ extern "C" int pq3d_embedding_fwd(const float* table, const int64_t* ids, float*
 }
 extern "C" int pq3d_embedding_bwd_acc(const float* dout, const int64_t* ids, float* dtable, int64_t R, int32_t d,
                                       void* stream) {
+  PQ_DEVICE_GUARD(stream, dout);
   PQ_CHECK_ARG(dout && ids && dtable && R >= 0 && d >= 1, "pq3d_embedding_bwd_acc: bad args");
   if (R == 0) return 0;
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid1d(R * d)), dim3(256), 0, (hipStream_t)stream, dout, ids, dtable, (long)R,

@@ -320,6 +320,7 @@ bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd) {
 }  // namespace
 
 extern "C" int pq3d_add_ln_fwd(const pq3d_ln_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, dp ? (dp->x ? dp->x : dp->o[0]) : nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_add_ln_fwd: null descriptor");
   const pq3d_ln_desc d = *dp;
   if (int e = check_ln(d, false)) return e;
@@ -339,6 +340,7 @@ extern "C" int pq3d_add_ln_fwd(const pq3d_ln_desc* dp, void* stream) {
 }
 
 extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, dp ? (dp->x ? dp->x : dp->o[0]) : nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_add_ln_bwd: null descriptor");
   const pq3d_ln_desc d = *dp;
   if (int e = check_ln(d, true)) return e;
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(WPB * 64) void rmsnorm_bwd_kernel(const float* __re
 
 extern "C" int pq3d_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t R, int32_t d, float eps,
                                 void* stream) {
+  PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && w && y && rstd && R >= 0 && d >= 1 && d <= 64 * MAXPL, "pq3d_rmsnorm_fwd: bad args (d <= 1024)");
   if (R == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -460,6 +463,7 @@ extern "C" int pq3d_rmsnorm_fwd(const float* x, const float* w, float* y, float*
 
 extern "C" int pq3d_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw,
                                 int64_t R, int32_t d, int32_t accumulate, void* stream) {
+  PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && w && rstd && dy && dx && dw && R >= 0 && d >= 1 && d <= 64 * MAXPL, "pq3d_rmsnorm_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) {

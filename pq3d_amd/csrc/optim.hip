@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     for (int j = 0; j < 4; ++j) {
       while (sg + 1 < segs.n && e0 + j >= segs.end[sg]) ++sg;
       const float lm = segs.lr_mul[sg], wd = segs.weight_decay[sg];
+      if (lm < 0.f) continue;   // skip segment: a parameter without a gradient this step (torch.optim.AdamW: untouched)
       const float gr = gv[j] * coef;
       const float pp = pv[j] * (1.f - lr * lm * wd);              // param.mul_(1 - lr * weight_decay)
       mv[j] = mv[j] + (gr - mv[j]) * (1.f - beta1);               // exp_avg.lerp_(grad, 1 - beta1)
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }  // namespace
 
 extern "C" int pq3d_sumsq_partials(const float* g, int64_t n, float* partials, void* stream) {
+  PQ_DEVICE_GUARD(stream, g);
   PQ_CHECK_ARG(g && partials && n >= 0, "pq3d_sumsq_partials: bad args");
   PQ_CHECK_ARG((((uintptr_t)g) & 15) == 0, "pq3d_sumsq_partials: g must be 16-byte aligned");
   hipLaunchKernelGGL(sumsq_kernel, dim3(NPART), dim3(256), 0, (hipStream_t)stream, g, (long)n, partials);
@@ -113,6 +115,7 @@ extern "C" int pq3d_sumsq_partials(const float* g, int64_t n, float* partials, v
 
 extern "C" int pq3d_train_scalars(const pq3d_adamw_hp* hp, int64_t* step, const float* partials, float* scalars,
                                   void* stream) {
+  PQ_DEVICE_GUARD(stream, step);
   PQ_CHECK_ARG(hp && step && partials && scalars, "pq3d_train_scalars: null argument");
   PQ_CHECK_ARG(hp->sched >= PQ3D_SCHED_CONSTANT && hp->sched <= PQ3D_SCHED_WARMUP_EXP, "pq3d_train_scalars: bad schedule");
   PQ_CHECK_ARG(hp->sched == PQ3D_SCHED_CONSTANT || hp->total_steps > hp->warmup_steps,
@@ -125,6 +128,7 @@ extern "C" int pq3d_train_scalars(const pq3d_adamw_hp* hp, int64_t* step, const 
 
 extern "C" int pq3d_adamw(float* p, const float* g, float* m, float* v, int64_t n, const pq3d_adamw_hp* hp,
                           const pq3d_opt_segments* segs, const float* scalars, void* stream) {
+  PQ_DEVICE_GUARD(stream, p);
   PQ_CHECK_ARG(p && g && m && v && hp && segs && scalars && n >= 0, "pq3d_adamw: bad args");
   PQ_CHECK_ARG(segs->n >= 1 && segs->n <= PQ3D_MAX_OPT_SEGMENTS && segs->end[segs->n - 1] >= n,
                "pq3d_adamw: segment table must cover [0, n)");

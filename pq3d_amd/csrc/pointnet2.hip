@@ -204,6 +204,7 @@ unsigned blocks_for(long n, int threads, long cap = 1024) {
 }  // namespace
 
 extern "C" int pq3d_furthest_point_sampling(const float* xyz, int32_t* idx, int32_t B, int32_t N, int32_t M, void* stream) {
+  PQ_DEVICE_GUARD(stream, xyz);
   PQ_CHECK_ARG(xyz && idx && B >= 0 && N >= 1 && M >= 0, "pq3d_furthest_point_sampling: bad args");
   PQ_CHECK_ARG(N <= FPS_THREADS * FPS_MAXPT, "pq3d_furthest_point_sampling: at most 8192 points per cloud");
   if (B == 0 || M == 0) return 0;
@@ -219,6 +220,7 @@ extern "C" int pq3d_furthest_point_sampling(const float* xyz, int32_t* idx, int3
 
 extern "C" int pq3d_ball_query(const float* new_xyz, const float* xyz, int32_t* idx, int32_t B, int32_t N, int32_t M,
                                float radius, int32_t nsample, void* stream) {
+  PQ_DEVICE_GUARD(stream, new_xyz);
   PQ_CHECK_ARG(new_xyz && xyz && idx && B >= 0 && N >= 1 && M >= 0 && nsample >= 1, "pq3d_ball_query: bad args");
   if (B == 0 || M == 0) return 0;
   hipLaunchKernelGGL(ball_query_kernel, dim3((M + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, new_xyz, xyz, idx, N, M,
@@ -229,6 +231,7 @@ extern "C" int pq3d_ball_query(const float* new_xyz, const float* xyz, int32_t* 
 
 extern "C" int pq3d_gather_points(const float* points, const int32_t* idx, float* out, int32_t B, int32_t C, int32_t N,
                                   int64_t L, void* stream) {
+  PQ_DEVICE_GUARD(stream, points);
   PQ_CHECK_ARG(points && idx && out && B >= 0 && C >= 1 && N >= 1 && L >= 0, "pq3d_gather_points: bad args");
   if (B == 0 || L == 0) return 0;
   hipLaunchKernelGGL(gather_kernel, dim3(blocks_for(L, 256, 256), (C + CPB - 1) / CPB, B), dim3(256), 0, (hipStream_t)stream,
@@ -239,6 +242,7 @@ extern "C" int pq3d_gather_points(const float* points, const int32_t* idx, float
 
 extern "C" int pq3d_gather_points_grad(const float* grad_out, const int32_t* idx, float* grad_points, int32_t B, int32_t C,
                                        int32_t N, int64_t L, void* stream) {
+  PQ_DEVICE_GUARD(stream, grad_out);
   PQ_CHECK_ARG(grad_out && idx && grad_points && B >= 0 && C >= 1 && N >= 1 && L >= 0, "pq3d_gather_points_grad: bad args");
   if (B == 0) return 0;
   ZeroList z;
@@ -253,6 +257,7 @@ extern "C" int pq3d_gather_points_grad(const float* grad_out, const int32_t* idx
 
 extern "C" int pq3d_three_nn(const float* unknown, const float* known, float* dist2, int32_t* idx, int32_t B, int32_t N,
                              int32_t M, void* stream) {
+  PQ_DEVICE_GUARD(stream, unknown);
   PQ_CHECK_ARG(unknown && known && dist2 && idx && B >= 0 && N >= 0 && M >= 1, "pq3d_three_nn: bad args");
   if (B == 0 || N == 0) return 0;
   hipLaunchKernelGGL(three_nn_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, unknown, known, dist2, idx,
@@ -263,6 +268,7 @@ extern "C" int pq3d_three_nn(const float* unknown, const float* known, float* di
 
 extern "C" int pq3d_three_interpolate(const float* points, const int32_t* idx, const float* weight, float* out, int32_t B,
                                       int32_t C, int32_t M, int32_t N, void* stream) {
+  PQ_DEVICE_GUARD(stream, points);
   PQ_CHECK_ARG(points && idx && weight && out && B >= 0 && C >= 1 && M >= 1 && N >= 0, "pq3d_three_interpolate: bad args");
   if (B == 0 || N == 0) return 0;
   hipLaunchKernelGGL(three_interpolate_kernel, dim3(blocks_for(N, 256, 64), C, B), dim3(256), 0, (hipStream_t)stream, points,
@@ -273,6 +279,7 @@ extern "C" int pq3d_three_interpolate(const float* points, const int32_t* idx, c
 
 extern "C" int pq3d_three_interpolate_grad(const float* grad_out, const int32_t* idx, const float* weight, float* grad_points,
                                            int32_t B, int32_t C, int32_t M, int32_t N, void* stream) {
+  PQ_DEVICE_GUARD(stream, grad_out);
   PQ_CHECK_ARG(grad_out && idx && weight && grad_points && B >= 0 && C >= 1 && M >= 1 && N >= 0,
                "pq3d_three_interpolate_grad: bad args");
   if (B == 0) return 0;
@@ -327,6 +334,7 @@ __global__ void __launch_bounds__(256) group_maxpool_kernel(const void* __restri
 extern "C" int pq3d_group_rows(const float* xyz, const float* new_xyz, const void* feats, int32_t dt_f, int64_t feat_stride,
                                const int32_t* idx, void* out, int32_t dt_o, int32_t B, int32_t N, int32_t C, int32_t np,
                                int32_t ns, int32_t Kp, void* stream) {
+  PQ_DEVICE_GUARD(stream, xyz);
   PQ_CHECK_ARG(xyz && out && B >= 0 && N >= 1 && C >= 0 && np >= 1 && ns >= 1 && Kp >= 3 + C, "pq3d_group_rows: bad args");
   PQ_CHECK_ARG(C == 0 || (feats && feat_stride >= C), "pq3d_group_rows: features missing");
   PQ_CHECK_ARG(idx || ns == N, "pq3d_group_rows: without indices every point is a sample (ns == N)");
@@ -340,6 +348,7 @@ extern "C" int pq3d_group_rows(const float* xyz, const float* new_xyz, const voi
 }
 
 extern "C" int pq3d_group_maxpool(const void* rows, void* out, int32_t dt, int64_t G, int32_t ns, int32_t C, void* stream) {
+  PQ_DEVICE_GUARD(stream, rows);
   PQ_CHECK_ARG(rows && out && G >= 0 && ns >= 1 && C >= 1 && (dt == PQ3D_F32 || dt == PQ3D_BF16), "pq3d_group_maxpool: bad args");
   if (G == 0) return 0;
   hipLaunchKernelGGL(group_maxpool_kernel, dim3(blocks_for((long)G * C, 256, 4096)), dim3(256), 0, (hipStream_t)stream, rows, out,

@@ -119,6 +119,7 @@ class FusedSpec:
         # voxel memory has one source per layer, query_encoder.py:90-91), mh_src[k] = source of mask-head memory k
         # (the LAST scale of a multi-scale memory, query3d_unified.py:163-165)
         self.src, self.mh_src, self.n_src = None, None, len(self.mems)
+        self.prompt = False          # structure 'mixed': a sequential prompt cross-attention follows the parallel scene memories
         self.drop_base = drop_base   # dropout-site base of the encoder when train-mode dropout is active, else None
         self.mh_drop = mh_drop       # mask head's cls_head dropout active
 
@@ -225,10 +226,11 @@ def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None,
 
 
 class _FusedDecoder(Function):
-    """inputs: spec, x0, qpos, qmask, pos, pairwise_locs, seg_pad, offline_mask, coef, M feats, M masks, *params."""
+    """inputs: spec, x0, qpos, qmask, pos, pairwise_locs, seg_pad, offline_mask, coef, prompt, prompt_mask, U feats,
+    M masks, *params."""
 
     @staticmethod
-    def forward(ctx, spec: FusedSpec, x0, qpos, qmask, pos, pl, seg_pad, offline_mask, coef, *rest):
+    def forward(ctx, spec: FusedSpec, x0, qpos, qmask, pos, pl, seg_pad, offline_mask, coef, prompt, prompt_kpm, *rest):
         enc, ct = spec.enc, spec.ct
         ad = ops.act_dtype(ct)
         M, U = len(spec.mems), spec.n_src
@@ -244,6 +246,7 @@ class _FusedDecoder(Function):
         dev = qpos.device
         mem_idx = [layers[0].memories.index(m) for m in spec.mems]
         cas = [[layers[i].cross_attn_list[j] for j in mem_idx] for i in range(Ln)]
+        pcas = [layers[i].memory2ca["prompt"] for i in range(Ln)] if spec.prompt else None
         cq = ops.small_ct(ct)   # query-side GEMMs (M = B*N_q rows): split-bf16 in 'bf16' mode, exact f32 otherwise
         x0, qpos, pos = ops._c(x0), ops._c(qpos), ops._c(pos)
         feats = [ops._c(f) for f in feats]
@@ -301,6 +304,21 @@ class _FusedDecoder(Function):
         for s in range(0, len(A), MAXG):
             L.gemm(M=Rk, N=d, K=d, A=A[s:s + MAXG], A2=A2[s:s + MAXG], B=Bw[s:s + MAXG], bias=bs[s:s + MAXG],
                    Cs=Cs[s:s + MAXG], ct=ct, lda=d, ldb=d, ldc=d)
+        # ---- structure 'mixed' (query_encoder.py:162-165): the prompt memory's K / V of every layer, hoisted like the scene
+        # memories' (the prompt is layer-invariant, pos = None: query3d_unified.py:134-136): one grouped launch
+        PKV = None
+        if spec.prompt:
+            prompt, prompt_kpm = ops._c(prompt), ops._c(prompt_kpm)
+            T = prompt.shape[1]
+            PKV = torch.empty(Ln, 2, B, T, d, dtype=ad, device=dev)
+            Ap, Bp, bp, Cp = [], [], [], []
+            for i in range(Ln):
+                w, b = pcas[i].multihead_attn.in_proj_weight.detach(), pcas[i].multihead_attn.in_proj_bias.detach()
+                Ap += [prompt, prompt]; Bp += [w[d:2 * d], w[2 * d:]]; bp += [b[d:2 * d], b[2 * d:]]
+                Cp += [PKV[i, 0], PKV[i, 1]]
+            for s_ in range(0, len(Ap), MAXG):
+                L.gemm(M=B * T, N=d, K=d, A=Ap[s_:s_ + MAXG], B=Bp[s_:s_ + MAXG], bias=bp[s_:s_ + MAXG], Cs=Cp[s_:s_ + MAXG],
+                       ct=ct, lda=d, ldb=d, ldc=d)
         kpm_all = None
         if not spec.use_self_mask:
             st = spec.stacked_kpm   # [M, B, Ns] already stacked by the model (same memory order): no copy
@@ -383,6 +401,26 @@ class _FusedDecoder(Function):
                                              [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps,
                                              coef[app] if coef is not None else None, Nq, drop=dr_cr)
                 rec.update(q_all=q_all, o_all=o_all, lse=lse, op_all=op_all, mean_c=mean_c, rstd_c=rstd_c, x1=x1)
+                x1s = x1     # input of the self-attention sublayer
+                if spec.prompt:
+                    # -- sequential prompt cross-attention on the parallel block's output (CrossAttentionLayer.forward_post,
+                    # query_encoder.py:288-307: q = x1 + query_pos, k = v = prompt, own LayerNorm): 4 launches
+                    pc = pcas[i]
+                    dr_pa = spec.drop(pc, app, ops.DROP_CA_ATTN, dev, m=4)   # sequential slot 4 + 0 (modules.QueryEncoderLayer)
+                    dr_pr = spec.drop(pc, app, ops.DROP_CA_RES, dev, m=4)
+                    wp, bpq = pc.multihead_attn.in_proj_weight.detach(), pc.multihead_attn.in_proj_bias.detach()
+                    qp = torch.empty(B, Nq, d, dtype=ad, device=dev)
+                    L.gemm(M=R, N=d, K=d, A=[x1], A2=[qpos], B=[wp[:d]], bias=[bpq[:d]], Cs=[qp], ct=cq, lda=d, ldb=d, ldc=d)
+                    o_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
+                    lse_p = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+                    _attn(qp, PKV[i, 0], PKV[i, 1], o_p, lse_p, H, ct, True, kpm=prompt_kpm, drop=dr_pa)
+                    opp = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                    L.gemm(M=R, N=d, K=d, A=[o_p], B=[pc.multihead_attn.out_proj.weight.detach()],
+                           bias=[pc.multihead_attn.out_proj.bias.detach()], Cs=[opp], ct=ct, lda=d, ldb=d, ldc=d)
+                    x1s, mean_p, rstd_p = _ln_fwd(x1, [opp], [pc.norm.weight.detach()], [pc.norm.bias.detach()], pc.norm.eps,
+                                                  None, Nq, drop=dr_pr)
+                    rec.update(qp=qp, o_p=o_p, lse_p=lse_p, opp=opp, mean_p=mean_p, rstd_p=rstd_p, dr_pa=dr_pa, dr_pr=dr_pr)
+                rec["x1s"] = x1s
                 # -- self attention: 5 launches (spatial) / 4
                 sa = layer.self_attn
                 # N_q x N_q scores per scene: projections at fp32 grade, attention core on the exact-f32 MFMA path
@@ -396,7 +434,7 @@ class _FusedDecoder(Function):
                     w, b = sa.self_attn.in_proj_weight.detach(), sa.self_attn.in_proj_bias.detach()
                     Wl, bl = [w[:d], w[d:2 * d], w[2 * d:]], [b[:d], b[d:2 * d], b[2 * d:]]
                     Wo, bo = sa.self_attn.out_proj.weight.detach(), sa.self_attn.out_proj.bias.detach()
-                L.gemm(M=R, N=d, K=d, A=[x1] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=cq,
+                L.gemm(M=R, N=d, K=d, A=[x1s] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=cq,
                        lda=d, ldb=d, ldc=d)
                 sbias = sbias_all[i] if spec.spatial else None   # layer-invariant across blocks: computed once above
                 o_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
@@ -404,7 +442,7 @@ class _FusedDecoder(Function):
                 _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, L.F32, False, kpm=qmask, bias=sbias, drop=dr_sa)
                 f = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=d, K=d, A=[o_s], B=[Wo], bias=[bo], Cs=[f], ct=cq, lda=d, ldb=d, ldc=d)
-                x2, mean_s, rstd_s = _ln_fwd(x1, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
+                x2, mean_s, rstd_s = _ln_fwd(x1s, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
                                              drop=dr_sr)
                 rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
                 # -- FFN: 3 launches
@@ -443,6 +481,7 @@ class _FusedDecoder(Function):
             pmask.append(mlog)
         ctx.spec, ctx.tape, ctx.final_rec = spec, tape, final_rec
         ctx.KV, ctx.keys, ctx.inv_den, ctx.kpm_all = KV, keys, inv_den, kpm_all
+        ctx.PKV, ctx.pcas, ctx.prompt, ctx.pmask = PKV, pcas, prompt if spec.prompt else None, prompt_kpm if spec.prompt else None
         ctx.cas, ctx.n_mh = cas, len(pcls)
         ctx.params = params
         ctx.save_for_backward(x0, qpos, qmask, pos, pl, seg_pad, coef, *feats, *masks)
@@ -477,17 +516,29 @@ class _FusedDecoder(Function):
         # input gradients of the M-branch cross-attention LayerNorms are accumulated with atomics by the M branch blocks; that
         # buffer and the gradient arena are zeroed by ONE launch for the whole backward
         dxr_zero = torch.empty(n_app, B, Nq, d, dtype=torch.float32, device=dev) if M > 1 else None
-        if ext is not None and all(id(p) in ext for p in params):
-            # gradients go straight into the data-parallel flat buffer (zeroed here): no pack copy afterwards
-            if getattr(enc, "grad_arena_dirty", False):
-                raise RuntimeError("fused decoder: a second backward reached the shared gradient arena before its owner "
-                                   "consumed the first (gradient accumulation over micro-batches is not supported with "
-                                   "grad_arena: call the owner's zero / step between backwards, or remove enc.grad_arena)")
-            enc.grad_arena_dirty = True
-            ops.zero_many(list(getattr(enc, "grad_arena_buffers", ())) + [dxr_zero])
+        accumulate = False
+        in_place = ext is not None and all(id(p) in ext for p in params)
+        if in_place:
+            # gradients go straight into the owner's flat buffer (data-parallel bucket / optimizer arena): no pack copy.
             for p in params:
                 flat, o_, n_ = ext[id(p)]
                 gv[id(p)] = flat[o_:o_ + n_].view(p.shape)
+            # torch semantics of a second backward before zero_grad: gradients ACCUMULATE (the reference trains under
+            # accelerator.accumulate, trainer/query3d_trainer.py:35).  Every parameter gradient of this backward is formed
+            # by accumulating launches (split-K atomics, accumulating column sums), so accumulation = not zeroing the arena.
+            # Which case this is is read off the parameters: .grad still aliasing the arena -> the owner has not consumed the
+            # previous micro-batch -> add in place (and hand autograd nothing: .grad already is the arena);
+            # .grad None / foreign everywhere -> fresh step: zero, then hand fresh views to autograd (adopted without a copy).
+            req = [p for p in params if p.requires_grad]
+            alias = [p.grad is not None and p.grad.data_ptr() == gv[id(p)].data_ptr() for p in req]
+            if req and all(alias):
+                accumulate = True
+                ops.zero_many([dxr_zero])
+            elif any(alias):
+                raise RuntimeError("fused decoder backward: some parameters' .grad alias the shared gradient arena and others "
+                                   "do not -- zero ALL gradients (set_to_none=True) or none between micro-batches")
+            else:
+                ops.zero_many(list(getattr(enc, "grad_arena_buffers", ())) + [dxr_zero])
         else:
             arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
             ops.zero_many([arena, dxr_zero])
@@ -502,6 +553,7 @@ class _FusedDecoder(Function):
         dx = dxf.contiguous().float() if dxf is not None else torch.zeros(B, Nq, d, device=dev)
         dqpos_parts: List[torch.Tensor] = []
         dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=ad, device=dev)
+        dPKV = torch.empty(n_app, 2, B, ctx.prompt.shape[1], d, dtype=ad, device=dev) if spec.prompt else None
         dkeys = None  # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
 
         def mh_backward(rec, dc, dm, dx_in):
@@ -560,6 +612,43 @@ class _FusedDecoder(Function):
                 cur = nxt
             return cur
 
+        ready_cb = getattr(enc, "grads_ready", None) if in_place else None   # only when the owner's buffers were written
+        per_layer = bool(getattr(enc, "grad_bucket_per_layer", False)) and ready_cb is not None
+        ready = ready_cb if ready_cb is not None else (lambda tag: None)
+
+        def kv_terms(apps, into_queue):
+            """(dK|dV, W) operand lists of the hoisted K/V projections' backward for the applications `apps`; with
+            into_queue their weight / bias gradient products are queued."""
+            A_, B_, Xf, X2, GWs, Gbs = [], [], [], [], [], []
+            for a_ in apps:
+                i_ = tape[a_]["i"]
+                for j, ca in enumerate(cas[i_]):
+                    w = ca.multihead_attn.in_proj_weight.detach()
+                    gw, gb = G(ca.multihead_attn.in_proj_weight), G(ca.multihead_attn.in_proj_bias)
+                    A_ += [dKV[a_, 0, j], dKV[a_, 1, j]]
+                    B_ += [w[d:2 * d], w[2 * d:]]
+                    Xf += [ctx.kin[src[i_][j]], ctx.vin[src[i_][j]]]
+                    X2 += [ctx.kin2[src[i_][j]], None]
+                    GWs += [gw[d:2 * d], gw[2 * d:]]
+                    Gbs += [gb[d:2 * d], gb[2 * d:]]
+            if into_queue:
+                dwq.add(A_, Xf, X2, GWs, ct, Gbs)
+                if spec.prompt:   # the prompt memory's K / V rows of its cross-attention's in_proj weights
+                    for a_ in apps:
+                        pc_ = ctx.pcas[tape[a_]["i"]]
+                        gw, gb = G(pc_.multihead_attn.in_proj_weight), G(pc_.multihead_attn.in_proj_bias)
+                        dwq.add([dPKV[a_, 0], dPKV[a_, 1]], [ctx.prompt, ctx.prompt], None, [gw[d:2 * d], gw[2 * d:]], ct,
+                                [gb[d:2 * d], gb[2 * d:]])
+            return A_, B_
+
+        def flush_spatial():
+            for i0 in range(0, len(sb_queue), MAXG):
+                chunk = sb_queue[i0:i0 + MAXG]
+                arrs = [(C.c_void_p * len(chunk))(*[L.ptr(t[k]) for t in chunk]) for k in range(5)]
+                L.check(L.lib().pq3d_spatial_bias_bwd_grouped(L.ptr(pl), *arrs, len(chunk), B, H, Nq, L.stream()),
+                        "pq3d_spatial_bias_bwd_grouped")
+            del sb_queue[:]
+
         if ctx.final_rec is not None:
             dx = mh_backward(ctx.final_rec, dcls[-1], dmlog[-1], dx)
 
@@ -602,7 +691,8 @@ class _FusedDecoder(Function):
                 GW = [gw[:d], gw[d:2 * d], gw[2 * d:]]
                 Gb = [gb[:d], gb[d:2 * d], gb[2 * d:]]
                 Wo, GWo, Gbo = sa.self_attn.out_proj.weight.detach(), G(sa.self_attn.out_proj.weight), G(sa.self_attn.out_proj.bias)
-            dx1r, df = _ln_bwd(x1, [rec["f"]], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
+            x1s = rec["x1s"]     # the self-attention sublayer's input (x1, or the prompt cross-attention's output)
+            dx1r, df = _ln_bwd(x1s, [rec["f"]], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
                                rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)],
                                drop=rec["dr_sr"])
             df = df[0]
@@ -626,7 +716,31 @@ class _FusedDecoder(Function):
             L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1]], B=[Wl[0], Wl[1]], Cs=[dx1, None], C2=[gqk, None],
                    aux=[tmpv, None], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=2)
             dqpos_parts.append(gqk)
-            dwq.add([dqkv[0], dqkv[1], dqkv[2]], [x1] * 3, [qpos, qpos, None], GW, ct, Gb)
+            dwq.add([dqkv[0], dqkv[1], dqkv[2]], [x1s] * 3, [qpos, qpos, None], GW, ct, Gb)
+            if spec.prompt:
+                # ---------------- prompt cross-attention backward (sequential, single memory): dx1 is d(x1s) here
+                pc = ctx.pcas[i]
+                wp = pc.multihead_attn.in_proj_weight.detach()
+                gwp, gbp = G(pc.multihead_attn.in_proj_weight), G(pc.multihead_attn.in_proj_bias)
+                dx1pr, dopp = _ln_bwd(x1, [rec["opp"]], [pc.norm.weight.detach()], [pc.norm.bias.detach()], pc.norm.eps, None,
+                                      Nq, rec["mean_p"], rec["rstd_p"], dx1, [G(pc.norm.weight)], [G(pc.norm.bias)],
+                                      drop=rec["dr_pr"])
+                do_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
+                L.gemm(M=R, N=d, K=d, A=[dopp[0]], B=[pc.multihead_attn.out_proj.weight.detach()], Cs=[do_p], ct=ct, lda=d,
+                       ldb=d, ldc=d, transB=True)
+                dwq.add([dopp[0]], [rec["o_p"]], None, [G(pc.multihead_attn.out_proj.weight)], ct,
+                        [G(pc.multihead_attn.out_proj.bias)])
+                dq_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
+                delta_p = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+                _attn(rec["qp"], ctx.PKV[i, 0], ctx.PKV[i, 1], rec["o_p"], rec["lse_p"], H, ct, True, kpm=ctx.pmask,
+                      bwd=(do_p, dq_p, dPKV[a, 0], dPKV[a, 1], delta_p, None), drop=rec["dr_pa"])
+                gq_p = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                dx1n = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                L.gemm(M=R, N=d, K=d, A=[dq_p], B=[wp[:d]], Cs=[dx1n], C2=[gq_p], aux=[dx1pr], act_grad="add", ct=ct, lda=d,
+                       ldb=d, ldc=d, transB=True)
+                dqpos_parts.append(gq_p)
+                dwq.add([dq_p], [x1], [qpos], [gwp[:d]], ct, [gbp[:d]])
+                dx1 = dx1n
             # ---------------- cross-attention backward (M memories per launch)
             cl = cas[i]
             dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
@@ -662,24 +776,22 @@ class _FusedDecoder(Function):
             # ---------------- mask-head call that preceded this layer
             if spec.mh is not None and not spec.skip_pred:
                 dx = mh_backward(rec, dcls[a], dmlog[a], dx)
+            # ---------------- per-layer gradient buckets (data parallel, SURVEY 8e: "bucketed per decoder layer in reverse
+            # execution order"): the first-block application of layer i is the LAST to run backward, so every gradient of
+            # layer i's parameters -- its queued weight-gradient products, the K/V rows of its in_proj weights (from the
+            # dK / dV of all its applications) and its spatial-bias projection -- is complete once they are flushed here;
+            # ready(i) lets the owner start that bucket's all-reduce while the earlier layers still run backward
+            if per_layer and a < Ln:
+                kv_terms(range(i, n_app, Ln), into_queue=True)
+                dwq.flush()
+                flush_spatial()
+                ready(i)
 
         # ---- hoisted K/V projection backward (sum over all applications)
-        need_feat = [ctx.needs_input_grad[9 + u] for u in range(U)]
+        need_feat = [ctx.needs_input_grad[11 + u] for u in range(U)]
         dfeats: List[Optional[torch.Tensor]] = [None] * U
         single = U == M and all(src[i][j] == j for i in range(Ln) for j in range(M)) and mh_src[:M] == list(range(M))[:len(mh_src)]
-        Akv, Bkv, Xf, X2, GWs, Gbs = [], [], [], [], [], []
-        for a in range(n_app):
-            i = tape[a]["i"]
-            for j, ca in enumerate(cas[i]):
-                w = ca.multihead_attn.in_proj_weight.detach()
-                gw, gb = G(ca.multihead_attn.in_proj_weight), G(ca.multihead_attn.in_proj_bias)
-                Akv += [dKV[a, 0, j], dKV[a, 1, j]]
-                Bkv += [w[d:2 * d], w[2 * d:]]
-                Xf += [ctx.kin[src[i][j]], ctx.vin[src[i][j]]]
-                X2 += [ctx.kin2[src[i][j]], None]
-                GWs += [gw[d:2 * d], gw[2 * d:]]
-                Gbs += [gb[d:2 * d], gb[2 * d:]]
-        dwq.add(Akv, Xf, X2, GWs, ct, Gbs)
+        Akv, Bkv = kv_terms(range(n_app), into_queue=not per_layer)
         # ---- every parameter gradient of the decoder (+ mask head) is complete after this flush: in a data-parallel step
         # its all-reduce starts HERE (enc.grads_ready, set by the step owner) and overlaps the key/value input-gradient
         # products below and the encoders' backward that autograd runs after this function returns
@@ -690,14 +802,8 @@ class _FusedDecoder(Function):
                 dkm_list[j] = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
                 dwq.add([dkm_list[j]], [ctx.mh_feats[j]], None, [G(mp.k_proj.weight)], ct)
         dwq.flush()
-        for i0 in range(0, len(sb_queue), MAXG):
-            chunk = sb_queue[i0:i0 + MAXG]
-            arrs = [(C.c_void_p * len(chunk))(*[L.ptr(t[k]) for t in chunk]) for k in range(5)]
-            L.check(L.lib().pq3d_spatial_bias_bwd_grouped(L.ptr(pl), *arrs, len(chunk), B, H, Nq, L.stream()),
-                    "pq3d_spatial_bias_bwd_grouped")
-        ready = getattr(enc, "grads_ready", None)
-        if ready is not None:
-            ready()
+        flush_spatial()
+        ready("decoder")   # every parameter gradient of the decoder (+ mask head) is final
         # bf16 path: the input-gradient products read TRANSPOSED bf16 copies of the K/V weights (one copy launch from the
         # forward's pre-cast rows), which turns them into plain NT products -- the 128x128-tile kernel's layout -- and the
         # memories then share launches (K-concatenation per memory, several outputs per launch)
@@ -787,8 +893,24 @@ class _FusedDecoder(Function):
         if ctx.needs_input_grad[2]:
             dqpos = ops.sum_n(dqpos_parts)
         dx0 = dx if ctx.needs_input_grad[1] else None
-        pgrads = [gv[id(p)] if p.requires_grad else None for p in params]
-        return (None, dx0, dqpos, None, dpos, None, None, None, None, *dfeats, *([None] * M), *pgrads)
+        dprompt = None
+        if spec.prompt and ctx.needs_input_grad[9]:
+            # d prompt = sum over layer applications of dK_p Wk + dV_p Wv: one K-concatenated launch
+            Ap, Bp = [], []
+            for a_ in range(n_app):
+                w = ctx.pcas[tape[a_]["i"]].multihead_attn.in_proj_weight.detach()
+                Ap += [dPKV[a_, 0], dPKV[a_, 1]]
+                Bp += [w[d:2 * d], w[2 * d:]]
+            T = ctx.prompt.shape[1]
+            for s_ in range(0, len(Ap), MAXG):
+                nxt = torch.empty(B, T, d, dtype=torch.float32, device=dev)
+                n = len(Ap[s_:s_ + MAXG])
+                L.gemm(M=B * T, N=d, K=d, A=Ap[s_:s_ + MAXG], B=Bp[s_:s_ + MAXG], Cs=[nxt] + [None] * (n - 1),
+                       aux=([dprompt] + [None] * (n - 1)) if dprompt is not None else None,
+                       act_grad="add" if dprompt is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=n)
+                dprompt = nxt
+        pgrads = [gv[id(p)] if (p.requires_grad and not accumulate) else None for p in params]
+        return (None, dx0, dqpos, None, dpos, None, None, None, None, dprompt, None, *dfeats, *([None] * M), *pgrads)
 
 
 def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_match=None, seg_masks=None,
@@ -798,12 +920,22 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
     mask-head call.  Raises NotImplementedError for configurations it does not cover (callers fall back to the
     modular path)."""
     layer0 = enc.unified_encoder[0]
-    if layer0.structure != "parallel":
-        raise NotImplementedError("fused path covers structure='parallel'")
+    if layer0.structure not in ("parallel", "mixed"):
+        raise NotImplementedError("fused path covers structure='parallel' and 'mixed'")
     training = enc.training
     mems = [m for m in layer0.memories if training or m not in layer0.drop_memories_test]
+    prompt = pmask = None
+    if layer0.structure == "mixed":
+        # query_encoder.py:162-165: parallel over the scene memories, then sequential_ca(query, ['prompt']) -- the literal
+        # list, so the prompt attends even when drop_memories_test names it
+        mems = [m for m in mems if m != "prompt"]
+        if "prompt" not in layer0.memory2ca or "prompt" not in input_dict:
+            raise NotImplementedError("fused path: structure='mixed' needs a prompt memory")
+        prompt, pmask, ppos = input_dict["prompt"][:3]
+        if ppos is not None or pmask.ndim != 2 or isinstance(prompt, (list, tuple)):
+            raise NotImplementedError("fused path: prompt memory with a position tensor / 3-D mask / multi-scale list")
     if not mems or any(m == "prompt" for m in mems):
-        raise NotImplementedError("fused path needs scene memories only")
+        raise NotImplementedError("fused path needs scene memories (a prompt memory only under structure='mixed')")
     x0, qmask, qpos = input_dict["query"][:3]
     feats = [input_dict[m][0] for m in mems]
     masks = [input_dict[m][1] for m in mems]
@@ -875,9 +1007,10 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
             all(masks[j].data_ptr() == st[0][j].data_ptr() for j in range(len(mems))):
         spec.stacked_kpm = st[0]
     spec.src, spec.mh_src, spec.n_src = src, mh_src, len(uniq)
+    spec.prompt = prompt is not None
     params = [p for p in enc.parameters()] + ([p for p in mask_head.parameters()] if mask_head is not None else [])
     outs = _FusedDecoder.apply(spec, x0, qpos, qmask, poss[0], pairwise_locs, seg_masks, offline_attn_masks, coef,
-                               *uniq, *masks, *params)
+                               prompt, pmask, *uniq, *masks, *params)
     query = outs[0]
     n = (len(outs) - 1) // 2
     return query, list(outs[1:1 + n]), list(outs[1 + n:1 + 2 * n])

@@ -2,13 +2,13 @@
 
 The reference trainer (trainer/query3d_trainer.py:30-45, trainer/build.py:66-75) calls ``out = model(data_dict)``,
 builds the loss in Python and runs ``accelerator.backward(loss)`` under DDP -- it cannot replay one captured step.
-Launched eagerly, a step of this package is ~130 dependent kernel launches whose descriptors are marshalled through
-ctypes: host-bound at ~3.5x the device time.  ``GraphedQuery3D`` wraps a ``Query3DUnified`` so that its forward and its
-backward are each ONE HIP-graph replay behind an ordinary autograd node (``torch.cuda.make_graphed_callables``): the
-loss, the optimizer and DDP's gradient hooks stay eager and see ordinary ``.grad`` tensors, the model's ~130 launches
-cost two replays plus the copies of the batch into the static input buffers.
+Launched eagerly, a step of this package is ~100 dependent kernel launches whose descriptors are marshalled through
+ctypes: host-bound at ~4x the device time.  ``GraphedQuery3D`` wraps a ``Query3DUnified`` so that its forward and its
+backward are each ONE HIP-graph replay behind an ordinary autograd node: the loss, the optimizer and DDP's gradient
+hooks stay eager and see ordinary ``.grad`` tensors; the model's launches cost two replays plus the copies of the batch
+into the static input buffers.
 
-Constraints (those of make_graphed_callables): fixed input shapes / dtypes / key set (one wrapper per shape), no
+Constraints (those of any captured graph): fixed input shapes / dtypes / key set (one wrapper per shape), no
 data-dependent host control flow inside the model (true on this path: nothing synchronises), train / eval mode fixed at
 wrap time.  Not usable for greedy generation (host-side token loop) -- eval-mode caption decoding keeps its own graph
 (pq3d_amd/t5.py)."""
@@ -23,17 +23,28 @@ OUT_TENSORS = ("query_embeds", "ground_logits", "generation_logits", "generation
 OUT_LISTS = ("predictions_class", "predictions_mask")
 
 
-class _Flat(nn.Module):
-    """Positional-tensor view of Query3DUnified.forward(data_dict) -> data_dict."""
+def _is_tensor_list(v) -> bool:
+    return isinstance(v, (list, tuple)) and len(v) > 0 and all(torch.is_tensor(t) for t in v)
 
-    def __init__(self, model: nn.Module, in_keys: Sequence[str], const: Dict[str, object]):
+
+class _Flat(nn.Module):
+    """Positional-tensor view of Query3DUnified.forward(data_dict) -> data_dict.  ``specs``: (key, None) for a tensor
+    entry, (key, i) for element i of a list-of-tensors entry (multi-scale voxel pyramids / voxel2segment lists)."""
+
+    def __init__(self, model: nn.Module, specs: Sequence[tuple], const: Dict[str, object]):
         super().__init__()
-        self.model, self.in_keys, self.const = model, list(in_keys), dict(const)
+        self.model, self.specs, self.const = model, list(specs), dict(const)
         self.layout: List[tuple] = []     # filled by the first call: (key, count or None)
 
     def forward(self, *tensors):
         dd = dict(self.const)
-        dd.update(zip(self.in_keys, tensors))
+        for (k, i), t in zip(self.specs, tensors):
+            if i is None:
+                dd[k] = t
+            else:
+                dd.setdefault(k, [])
+                assert len(dd[k]) == i
+                dd[k].append(t)
         out = self.model(dd)
         flat, layout = [], []
         for k in OUT_TENSORS:
@@ -47,26 +58,38 @@ class _Flat(nn.Module):
 
 
 class _Replay(torch.autograd.Function):
-    """One autograd node for the whole model: forward = replay of the captured forward graph, backward = replay of the
-    captured backward graph, which leaves every parameter gradient in the owner's flat buffers."""
+    """One autograd node for the whole model: forward = replay of the captured forward graph, backward = replay of a
+    captured backward graph, which leaves every parameter gradient in the owner's flat buffers.
+    inputs = the batch tensors followed (mode 'autograd') by the parameters."""
 
     @staticmethod
-    def forward(ctx, owner, _anchor, *inputs):
-        # `_anchor` is a 0-d leaf that requires grad: the parameters are not inputs of this node (their gradients are left
-        # in the owner's buffers), so it is what makes autograd call backward() at all
-        ctx.owner = owner
-        owner._copy_in(inputs)
+    def forward(ctx, owner, _anchor, n_in, *inputs):
+        # `_anchor` is a 0-d leaf that requires grad: in 'direct' mode the parameters are not inputs of this node (their
+        # gradients are left in the owner's buffers), so it is what makes autograd call backward() at all
+        ctx.owner, ctx.n_in, ctx.n_par = owner, n_in, len(inputs) - n_in
+        owner._copy_in(inputs[:n_in])
         owner.fwd_graph.replay()
+        owner._fwd_token = ctx.token = object()   # the saved activations of THIS forward live in the graph's static memory
         return tuple(o.detach() for o in owner.static_out)
 
     @staticmethod
     def backward(ctx, *gouts):
         ow = ctx.owner
+        if ctx.token is not ow._fwd_token:
+            raise RuntimeError("GraphedQuery3D: backward of a forward whose saved activations were overwritten by a later "
+                               "forward of the same wrapper (forward and backward are static graphs: run one backward per "
+                               "forward, or wrap the evaluation passes in torch.no_grad())")
         gs = [g if g is not None else z for g, z in zip(gouts, ow.zero_gout)]
         torch._foreach_copy_(ow.static_gout, [gs[i] for i in ow.gout_idx])
-        ow.bwd_graph.replay()
-        ow._publish_grads()
-        return (None, None) + tuple(ow.static_gin)
+        acc = ow._accumulating()
+        ow._bwd_graph(acc).replay()
+        pg = (None,) * ctx.n_par
+        if ow.mode == "direct":
+            ow._publish_grads()
+        elif not acc:
+            # fresh view objects of the flat buffers: AccumulateGrad adopts them without a copy (and runs its hooks: DDP)
+            pg = tuple(ow._grad_view(p) for p in ow._params)
+        return (None, None, None) + tuple(ow.static_gin) + pg
 
 
 class GraphedQuery3D(nn.Module):
@@ -74,26 +97,40 @@ class GraphedQuery3D(nn.Module):
     called (same keys and shapes as the sample).  Parameters are the wrapped model's own (state_dict / optimizer see them
     through ``gm.model``).
 
-    mode='direct' (default): the captured backward writes the parameter gradients straight into two persistent flat fp32
-    buffers (the fused decoder in place, the rest with one multi-tensor copy) and ``.grad`` of every parameter is a view of
-    them -- no per-parameter AccumulateGrad kernels (170 of them at config 2).  ``loss.backward()`` therefore OVERWRITES
-    ``.grad`` (one backward per step; no gradient accumulation) and autograd hooks on the parameters do not fire.
-    mode='autograd': ``torch.cuda.make_graphed_callables`` -- parameter gradients flow through AccumulateGrad as usual
-    (DDP's hooks fire, accumulation works) at the price of one small copy kernel per parameter per step."""
+    Both modes replay the same two captured graphs; the captured backward writes the parameter gradients into two
+    persistent flat fp32 buffers (the fused decoder in place, the rest with one multi-tensor copy).
+    mode='direct' (default): ``.grad`` of every parameter is SET to its view of those buffers after the replay -- no
+    autograd bookkeeping per parameter; autograd hooks on the parameters do not fire.
+    mode='autograd': the parameters are inputs of the autograd node and receive fresh views of the flat buffers as their
+    gradients: AccumulateGrad adopts a view without a copy when ``.grad`` is None and runs its hooks (DDP's bucket hooks
+    fire, ``.grad`` is an ordinary tensor) -- the ~170 host-side AccumulateGrad visits overlap the backward replay on the
+    device (round 2 used torch.cuda.make_graphed_callables here: one copy kernel per parameter per step, 3.5 ms at c2).
+    Gradient accumulation (both modes): a backward that finds the parameters' ``.grad`` still aliasing the flat buffers
+    (no ``zero_grad(set_to_none=True)`` since the last one) replays an ACCUMULATING variant of the backward graph
+    (captured on first use) that adds into the buffers -- torch semantics, the reference trains under
+    accelerator.accumulate (trainer/query3d_trainer.py:35)."""
 
     def __init__(self, model: nn.Module, sample: Dict[str, object], num_warmup_iters: int = 3, mode: str = "direct"):
         super().__init__()
         assert mode in ("direct", "autograd")
+        assert num_warmup_iters >= 1, "GraphedQuery3D needs at least one eager warm-up iteration before capture"
         self.model, self.mode = model, mode
-        self.in_keys = [k for k, v in sample.items() if torch.is_tensor(v)]
-        const = {k: v for k, v in sample.items() if not torch.is_tensor(v)}
-        self._flat = _Flat(model, self.in_keys, const)
-        args = tuple(sample[k].detach().clone().requires_grad_(sample[k].requires_grad) for k in self.in_keys)
+        specs, sample_tensors, const = [], [], {}
+        for k, v in sample.items():
+            if torch.is_tensor(v):
+                specs.append((k, None)); sample_tensors.append(v)
+            elif _is_tensor_list(v):
+                for i, t in enumerate(v):
+                    specs.append((k, i)); sample_tensors.append(t)
+            else:
+                if isinstance(v, (list, tuple, dict)) and any(torch.is_tensor(t) for t in (v.values() if isinstance(v, dict) else v)):
+                    raise ValueError(f"GraphedQuery3D: data_dict[{k!r}] mixes tensors and non-tensors; only tensors and "
+                                     "lists of tensors can be static graph inputs")
+                const[k] = v
+        self.specs, self._const = specs, const
+        self._flat = _Flat(model, specs, const)
+        args = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in sample_tensors)
         self._shapes = [(tuple(a.shape), a.dtype) for a in args]
-        if mode == "autograd":
-            self._graphed = torch.cuda.make_graphed_callables(self._flat, args, num_warmup_iters=num_warmup_iters,
-                                                              allow_unused_input=True)
-            return
         from .parallel import FlatGradAllReducer
         self.static_in = list(args)
         params = [p for p in model.parameters() if p.requires_grad]
@@ -106,27 +143,10 @@ class GraphedQuery3D(nn.Module):
         if enc is not None and groups[0]:
             enc.grad_arena, enc.grad_arena_buffers = self.reducer.slots(), [self.reducer.flat[0]]
         self._params = params
-        gin_idx = [i for i, a in enumerate(args) if a.requires_grad]
-
-        def run_bwd(outs):
-            if enc is not None:
-                enc.grad_arena_dirty = False
-            req = [o for o in outs if o.requires_grad]
-            grads = torch.autograd.grad(req, [args[i] for i in gin_idx] + params, grad_outputs=self.static_gout,
-                                        allow_unused=True)
-            gin, gp = grads[:len(gin_idx)], grads[len(gin_idx):]
-            slots = self.reducer.slots()
-            views, srcs = [], []
-            for p, g in zip(params, gp):
-                flat, off, n = slots[id(p)]
-                v = flat[off:off + n].view_as(p)
-                if g is None:
-                    v.zero_()
-                elif g.data_ptr() != v.data_ptr():
-                    views.append(v); srcs.append(g)
-            if views:
-                torch._foreach_copy_(views, srcs)
-            return gin
+        self._slots = self.reducer.slots()
+        self._args = args
+        self._gin_idx = [i for i, a in enumerate(args) if a.requires_grad]
+        self._fwd_token = None
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -135,23 +155,92 @@ class GraphedQuery3D(nn.Module):
                 outs = self._flat(*args)
                 self.gout_idx = [i for i, o in enumerate(outs) if o.requires_grad]
                 self.static_gout = [torch.zeros_like(outs[i]) for i in self.gout_idx]
-                run_bwd(outs)
+                self._run_bwd(outs, False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.fwd_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.fwd_graph):
             outs = self._flat(*args)
         self.static_out = list(outs)
         self.zero_gout = [torch.zeros_like(o) for o in outs]
-        with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool()):
-            gin = run_bwd(outs)
+        self._bwd = {False: torch.cuda.CUDAGraph(), True: None}
+        with torch.cuda.graph(self._bwd[False], pool=self.fwd_graph.pool()):
+            gin = self._run_bwd(outs, False, retain=True)
         self.static_gin = [None] * len(args)
-        for i, g in zip(gin_idx, gin):
+        for i, g in zip(self._gin_idx, gin):
             self.static_gin[i] = g
+        for p in params:
+            p.grad = None
         self._grad_views = None
         self._anchor = torch.zeros((), device=args[0].device, requires_grad=True)
 
-    # -- direct mode plumbing ------------------------------------------------------------------------------------------
+    # -- backward body (captured twice: fresh / accumulating) ------------------------------------------------------------
+    def _grad_view(self, p):
+        flat, off, n = self._slots[id(p)]
+        return flat[off:off + n].view_as(p)
+
+    def _run_bwd(self, outs, accumulate: bool, retain: bool = False):
+        params = self._params
+        # the fused decoder decides "fresh step or accumulate" from its parameters' .grad (pq3d_amd/fused.py): alias the
+        # flat buffers -> add in place; None -> zero, then write
+        for p in params:
+            p.grad = self._grad_view(p) if accumulate else None
+        req = [o for o in outs if o.requires_grad]
+        grads = torch.autograd.grad(req, [self._args[i] for i in self._gin_idx] + params, grad_outputs=self.static_gout,
+                                    allow_unused=True, retain_graph=retain)
+        gin, gp = grads[:len(self._gin_idx)], grads[len(self._gin_idx):]
+        views, srcs = [], []
+        for p, g in zip(params, gp):
+            v = self._grad_view(p)
+            if g is None:
+                if not accumulate:
+                    # no gradient from autograd: either written in place by the fused executor in accumulate mode (never
+                    # here) or genuinely unused -> zero in a fresh step, untouched when accumulating
+                    v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                views.append(v); srcs.append(g)
+        if views:
+            (torch._foreach_add_ if accumulate else torch._foreach_copy_)(views, srcs)
+        if accumulate and self.static_gin is not None:   # input gradients land in the buffers of the fresh graph
+            dst = [self.static_gin[i] for i in self._gin_idx]
+            if dst:
+                torch._foreach_copy_(dst, list(gin))
+        return gin
+
+    def _accumulating(self) -> bool:
+        """True when every parameter's .grad still aliases its flat-buffer view (no zero_grad since the last backward)."""
+        alias = [p.grad is not None and p.grad.data_ptr() == self._grad_view(p).data_ptr() for p in self._params]
+        if all(alias) and alias:
+            return True
+        if any(alias):
+            raise RuntimeError("GraphedQuery3D: some parameters' .grad alias the flat gradient buffers and others do not -- "
+                               "zero all gradients (set_to_none=True) or none between micro-batches")
+        return False
+
+    def enable_accumulation(self) -> None:
+        """Capture the accumulating variant of the backward graph (done automatically by forward() when it finds the
+        parameters' .grad still aliasing the flat buffers, i.e. on the second micro-batch of a step).  The autograd graph
+        of the captured forward is still alive (retain_graph), its saved tensors are the forward graph's static buffers ->
+        the same backward, adding into the flat buffers."""
+        if self._bwd[True] is not None:
+            return
+        saved = [p.grad for p in self._params]
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.fwd_graph.pool()):
+            self._run_bwd(self.static_out, True, retain=True)
+        for p, gr in zip(self._params, saved):
+            p.grad = gr
+        self._bwd[True] = g
+
+    def _bwd_graph(self, accumulate: bool):
+        if self._bwd[accumulate] is None:
+            raise RuntimeError("GraphedQuery3D: gradient accumulation needs the accumulating backward graph, which is "
+                               "captured by forward() when .grad is still set -- call gm.enable_accumulation() once "
+                               "before training if gradients are re-created between forward and backward")
+        return self._bwd[accumulate]
+
+    # -- plumbing ------------------------------------------------------------------------------------------------------
     def _copy_in(self, inputs):
         by = {}
         for dst, src in zip(self.static_in, inputs):
@@ -159,26 +248,40 @@ class GraphedQuery3D(nn.Module):
                 by.setdefault(dst.dtype, ([], []))
                 by[dst.dtype][0].append(dst); by[dst.dtype][1].append(src)
         for dsts, srcs in by.values():
-            torch._foreach_copy_(dsts, srcs)
+            # the static inputs are saved tensors of the captured forward's autograd graph, which stays alive (the accumulating
+            # backward variant is captured from it later): refreshing their contents must not advance their version counters
+            with torch.autograd._unsafe_preserve_version_counter(tuple(dsts)):
+                torch._foreach_copy_(dsts, srcs)
 
     def _publish_grads(self):
         if self._grad_views is None:
-            slots = self.reducer.slots()
-            self._grad_views = []
-            for p in self._params:
-                flat, off, n = slots[id(p)]
-                self._grad_views.append(flat[off:off + n].view_as(p))
+            self._grad_views = [self._grad_view(p) for p in self._params]
         for p, v in zip(self._params, self._grad_views):
             p.grad = v
 
     def forward(self, data_dict: Dict[str, object]) -> Dict[str, object]:
         args = []
-        for k, (shape, dtype) in zip(self.in_keys, self._shapes):
-            t = data_dict[k]
+        for (k, i), (shape, dtype) in zip(self.specs, self._shapes):
+            t = data_dict[k] if i is None else data_dict[k][i]
             if tuple(t.shape) != shape or t.dtype != dtype:
-                raise ValueError(f"GraphedQuery3D was captured with {k}: {shape} {dtype}, got {tuple(t.shape)} {t.dtype}")
+                raise ValueError(f"GraphedQuery3D was captured with {k}{'' if i is None else [i]}: {shape} {dtype}, "
+                                 f"got {tuple(t.shape)} {t.dtype}")
             args.append(t)
-        flat = self._graphed(*args) if self.mode == "autograd" else _Replay.apply(self, self._anchor, *args)
+        for k, v in self._const.items():   # non-tensor entries were frozen into the graphs as constants: they must not change
+            if k not in data_dict:
+                raise ValueError(f"GraphedQuery3D: data_dict lacks {k!r} (present in the captured sample)")
+            w = data_dict[k]
+            try:
+                same = (w is v) or bool(w == v)
+            except Exception:  # noqa: BLE001  (objects without a usable ==: identity only)
+                same = False
+            if not same:
+                raise ValueError(f"GraphedQuery3D: data_dict[{k!r}] = {w!r} differs from the captured constant {v!r}; "
+                                 "build one wrapper per value")
+        if self._bwd[True] is None and torch.is_grad_enabled() and self._params[0].grad is not None and self._accumulating():
+            self.enable_accumulation()      # second micro-batch of a step: here (caller's thread), not inside backward
+        pars = tuple(self._params) if self.mode == "autograd" else ()
+        flat = _Replay.apply(self, self._anchor, len(args), *args, *pars)
         out = dict(data_dict)
         i = 0
         for k, n in self._flat.layout:

@@ -297,7 +297,7 @@ class Query3DUnified(nn.Module):
 
 def make_cfg(*, d, H, L, memories, heads, d_in=None, spatial=True, structure="parallel", use_self_mask=False,
              num_blocks=1, dim_loc=3, C=201, foc=(), drop_test=(), offline_attn=False, skip_pred=False,
-             activation="relu", ground_hidden=None, t5=None) -> Cfg:
+             activation="relu", ground_hidden=None, t5=None, memory_dropout=0.0) -> Cfg:
     """Config with the reference YAML layout (configs/instseg_sceneverse.yaml:92-155) for synthetic runs."""
     d_in = d_in or {m: d for m in memories}
     model = {"name": "Query3DUnified", "memories": list(memories), "heads": list(heads), "hidden_size": d,
@@ -307,7 +307,8 @@ def make_cfg(*, d, H, L, memories, heads, d_in=None, spatial=True, structure="pa
              "unified_encoder": {"name": "QueryMaskEncoder", "args": {
                  "hidden_size": d, "num_attention_heads": H, "num_layers": L, "spatial_selfattn": spatial,
                  "memories": list(memories), "structure": structure, "use_self_mask": use_self_mask,
-                 "num_blocks": num_blocks, "drop_memories_test": list(drop_test), "activation": activation}},
+                 "num_blocks": num_blocks, "drop_memories_test": list(drop_test), "activation": activation,
+                 "memory_dropout": memory_dropout}},
              "mask_head": {"name": "MaskHeadSegLevel", "args": {"hidden_size": d, "num_targets": C,
                                                                  "memories_for_match": list(memories),
                                                                  "filter_out_classes": list(foc)}},

@@ -65,6 +65,10 @@ class FlatGradAllReducer:
         for bi, (flat, bucket) in enumerate(zip(self.flat, self.buckets)):
             if buckets is not None and bi not in buckets:
                 continue
+            if bi in self._launched:
+                # its all-reduce is already in flight on the side stream (early launch from inside the backward: the
+                # gradients were written in place): packing now would race with / overwrite the reduced data
+                continue
             views, grads, off = [], [], 0
             for p in bucket:
                 n = p.numel()

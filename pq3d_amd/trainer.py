@@ -29,7 +29,8 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, loss_fn: Callable[[dict], torch.Tensor], *,
                  opt_groups: Optional[Sequence[dict]] = None, lr: float = 1e-4, betas=(0.9, 0.98), eps: float = 1e-8,
                  grad_norm: Optional[float] = None, sched: str = "warmup_cosine", warmup_steps: int = 0,
-                 total_steps: int = 1, sched_gamma: float = 1.0, num_gpu: int = 1, group=None):
+                 total_steps: int = 1, sched_gamma: float = 1.0, num_gpu: int = 1, group=None,
+                 unused_parameters=None):
         groups = list(opt_groups) if opt_groups is not None else model.get_opt_params()
         self.model, self.loss_fn, self.group = model, loss_fn, group
         self.hp = L.AdamWHp()
@@ -41,14 +42,19 @@ class TrainStep:
         self.hp.warmup_steps = int(warmup_steps) * int(num_gpu)
         self.hp.sched_stride = int(num_gpu)
         self.hp.total_steps, self.hp.sched_gamma = int(total_steps), float(sched_gamma)
-        # torch.optim.AdamW (the reference's optimizer) skips a parameter whose .grad is None: no decay, no moment update;
-        # the flat kernel updates every element of the flat buffer.  So the flat buffer holds only parameters that DO get
-        # gradients: ``model.unused_parameters()`` (the bypassed T5 encoder of the generation head) are left out up front,
-        # and the first step probes the rest (as DDP's find_unused_parameters does, trainer/build.py:66-75): parameters
-        # without a gradient are dropped from the layout before any update (forward_backward).  A parameter used only in
-        # SOME steps keeps being decayed in the steps it is unused -- the remaining, documented divergence.
+        # torch.optim.AdamW (the reference's optimizer) skips a parameter whose .grad is None: no decay, no moment update.
+        # The flat layout is DETERMINISTIC -- every parameter of the groups except the explicit never-used set
+        # (``model.unused_parameters()``: the bypassed T5 encoder of the generation head, plus the caller's
+        # ``unused_parameters``) -- so ranks, checkpoints and graph captures always agree on it.  A parameter that stays in
+        # the buffer but has no gradient in some step (a head the batch did not reach) is SKIPPED for that step by the
+        # AdamW kernel (a segment with lr_mul < 0: parameter and moments untouched), exactly like torch; see
+        # optimizer_step.  Under data parallelism (world > 1) presence is a per-rank fact, so every parameter of the
+        # layout is updated (zero gradient where a rank had none, averaged like DDP's find_unused_parameters buckets):
+        # a parameter NO rank reaches is then still decayed -- list it in ``unused_parameters`` (documented divergence).
         unused = {id(p) for p in (model.unused_parameters() if hasattr(model, "unused_parameters") else ())}
-        self._probed = False
+        unused |= {id(p) for p in (unused_parameters or ())}
+        self._names = {id(p): n for n, p in model.named_parameters()}
+        self._seg_cache: Dict[frozenset, "L.OptSegments"] = {}
         self._layout([dict(g, params=[p for p in g["params"] if id(p) not in unused]) for g in groups])
 
     def _layout(self, groups) -> None:
@@ -85,6 +91,7 @@ class TrainStep:
             self.segs.lr_mul[s] = g["lr"] / lr
             self.segs.weight_decay[s] = g["weight_decay"]
         self.flat_p = flat_p
+        self._seg_cache = {}
         if not hasattr(self, "step_count"):
             self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
             self.partials = torch.zeros(L.SUMSQ_PARTIALS, dtype=torch.float32, device=dev)
@@ -96,43 +103,81 @@ class TrainStep:
             enc.grad_arena_buffers = self.reducer.flat
 
     # -- pieces (each capturable) ---------------------------------------------------------------------------------
-    def forward_backward(self, data_dict: dict) -> torch.Tensor:
-        self.model.zero_grad(set_to_none=True)
-        enc = getattr(self.model, "unified_encoder", None)
-        if enc is not None:
-            enc.grad_arena_dirty = False      # this step owns the arena: one backward per step (fused.py raises otherwise)
+    def forward_backward(self, data_dict: dict, accumulate: bool = False, loss_scale: float = 1.0) -> torch.Tensor:
+        """One micro-batch: forward, loss, backward, pack.  accumulate=False starts a fresh optimizer step (gradients set
+        to None first); accumulate=True ADDS this micro-batch's gradients to what the previous calls left (the reference
+        trains under accelerator.accumulate, trainer/query3d_trainer.py:35): the fused decoder sees its parameters' .grad
+        still aliasing the flat arena and accumulates in place, everything else accumulates through autograd."""
+        if not accumulate:
+            self.model.zero_grad(set_to_none=True)
         out = self.model(dict(data_dict))
         loss = self.loss_fn(out)
+        if loss_scale != 1.0:
+            loss = loss * loss_scale
         loss.backward()
-        if not self._probed and not torch.cuda.is_current_stream_capturing():
-            self._probed = True
-            missing = {id(p) for p in self.reducer.params if p.grad is None}
-            if missing:
-                # first step: parameters this configuration never reaches leave the flat buffer (own storage, never updated --
-                # what torch.optim.AdamW does with grad-None parameters); nothing has been updated yet, so re-laying out and
-                # re-running the step is exact
-                for p in self.reducer.params:
-                    if id(p) in missing:
-                        p.data = p.data.clone()
-                self._layout([dict(g, params=[p for p in g["params"] if id(p) not in missing]) for g in self.groups])
-                return self.forward_backward(data_dict)
         self.reducer.pack()
         return loss.detach()
 
     def all_reduce(self) -> None:
         self.reducer.all_reduce()     # mean over ranks (DDP semantics); no-op at world size 1
 
+    def _world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _segments(self, missing: frozenset) -> "L.OptSegments":
+        """Segment table of the flat buffer with the parameters in ``missing`` (ids; no gradient this step) marked
+        skip (lr_mul < 0).  Cached per missing set; the empty set is the plain per-group table."""
+        if not missing:
+            return self.segs
+        sg = self._seg_cache.get(missing)
+        if sg is not None:
+            return sg
+        runs, off = [], 0     # [end, lr_mul, weight_decay]
+        for g in self.groups:
+            for p in g["params"]:
+                off += p.numel()
+                key = (-1.0, 0.0) if id(p) in missing else (g["lr"] / self.hp.lr, g["weight_decay"])
+                if runs and (runs[-1][1], runs[-1][2]) == key:
+                    runs[-1][0] = off
+                else:
+                    runs.append([off, key[0], key[1]])
+        if len(runs) > L.MAX_OPT_SEGMENTS:
+            names = [self._names.get(i, "?") for i in list(missing)[:8]]
+            raise RuntimeError(f"TrainStep: {len(missing)} parameters without a gradient split the flat buffer into {len(runs)} "
+                               f"segments (> {L.MAX_OPT_SEGMENTS}); pass the never-used ones as unused_parameters= "
+                               f"(e.g. {names})")
+        sg = L.OptSegments()
+        sg.n = len(runs)
+        for i, (end, lm, wd) in enumerate(runs):
+            sg.end[i], sg.lr_mul[i], sg.weight_decay[i] = end, lm, wd
+        self._seg_cache[missing] = sg
+        return sg
+
     def optimizer_step(self) -> None:
         n, s = self.flat_g.numel(), L.stream()
+        # parameters without a gradient in THIS step (a host-side fact of the autograd graph, also under graph capture):
+        # skipped like torch.optim.AdamW does; their flat gradient is zero (pack), so the clip norm ignores them too
+        missing = frozenset(id(p) for p in self.reducer.params if p.grad is None) if self._world() == 1 else frozenset()
+        segs = self._segments(missing)
         L.check(L.lib().pq3d_sumsq_partials(L.ptr(self.flat_g), n, L.ptr(self.partials), s), "pq3d_sumsq_partials")
         L.check(L.lib().pq3d_train_scalars(C.byref(self.hp), L.ptr(self.step_count), L.ptr(self.partials),
                                            L.ptr(self.scalars), s), "pq3d_train_scalars")
         L.check(L.lib().pq3d_adamw(L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-                                   n, C.byref(self.hp), C.byref(self.segs), L.ptr(self.scalars), s), "pq3d_adamw")
+                                   n, C.byref(self.hp), C.byref(segs), L.ptr(self.scalars), s), "pq3d_adamw")
 
-    def step(self, data_dict: dict) -> torch.Tensor:
-        """One full training step; returns the (detached) loss.  grad norm / lr of the step: ``self.scalars``."""
-        loss = self.forward_backward(data_dict)
+    def step(self, data_dict) -> torch.Tensor:
+        """One full training step; returns the (detached) loss.  grad norm / lr of the step: ``self.scalars``.
+        ``data_dict`` may be a list of micro-batches (gradient accumulation: the losses are scaled by 1/len so that the
+        step equals one step on the concatenated batch for mean-reduced losses, as accelerate does)."""
+        if isinstance(data_dict, (list, tuple)):
+            k = len(data_dict)
+            loss = None
+            for i, mb in enumerate(data_dict):
+                l = self.forward_backward(mb, accumulate=i > 0, loss_scale=1.0 / k)
+                loss = l if loss is None else loss + l
+        else:
+            loss = self.forward_backward(data_dict)
         self.all_reduce()
         self.optimizer_step()
         return loss
@@ -146,8 +191,22 @@ class TrainStep:
     def last_lr(self) -> torch.Tensor:
         return self.scalars[0]
 
+    def layout(self):
+        """[(parameter name, numel)] in flat-buffer order: part of the checkpoint, checked on load."""
+        return [(self._names.get(id(p), f"<unnamed {i}>"), p.numel())
+                for i, p in enumerate(p for g in self.groups for p in g["params"])]
+
     def state_dict(self) -> dict:
-        return {"step": self.step_count.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}
+        return {"step": self.step_count.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "layout": self.layout()}
 
     def load_state_dict(self, sd: dict) -> None:
+        have = self.layout()
+        want = [tuple(x) for x in sd.get("layout", have)]
+        if want != [tuple(x) for x in have]:
+            diff = [a for a, b in zip(want, have) if a != b][:4]
+            raise ValueError(f"TrainStep.load_state_dict: the checkpoint's flat layout ({len(want)} parameters, "
+                             f"{sum(n for _, n in want)} elements) differs from this TrainStep's ({len(have)}, "
+                             f"{sum(n for _, n in have)}); first differences {diff} -- build the TrainStep with the same "
+                             f"parameter groups / unused_parameters")
         self.step_count.copy_(sd["step"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])

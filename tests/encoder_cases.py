@@ -146,3 +146,82 @@ def f14_hip(a, compute, fused, dev="cuda"):
     query, _, _ = enc(input_dict, M.calc_pairwise_locs(centers.to(dev)), None)
     (query * util.loss_weight("query", query.shape).to(dev)).mean().backward()
     return query, {n: p.grad for n, p in enc.named_parameters() if p.grad is not None}
+
+
+# ---------------------------------------------------------------------------------------------- F17 (stage-2 shipped decoder)
+def f17_scene(a):
+    return [m for m in a["memories"] if m != "prompt"]
+
+
+def f17_keep(a):
+    return memory_keep_draws(a["B"], len(f17_scene(a)), a["L"], a["data_seed"]) > a["p"]
+
+
+def f17_inputs(a):
+    from tests.golden.make_golden import stage2_inputs
+    return stage2_inputs(B=a["B"], Ns=a["Ns"], Nq=a["Nq"], d=a["d"], T=a["T"], memories=a["memories"], data_seed=a["data_seed"])
+
+
+def f17_modules(a, compute="fp32"):
+    enc = M.QueryMaskEncoder(None, memories=a["memories"], memory_dropout=a["p"], hidden_size=a["d"],
+                             num_attention_heads=a["H"], num_layers=a["L"], spatial_selfattn=True, structure="mixed",
+                             compute=compute)
+    gh = M.GroundHead(None, input_size=a["d"], hidden_size=a["d"] // 2 * 3, dropout=0.3)
+    M.set_compute(gh, compute)
+    sd = {**{"unified_encoder." + k: v for k, v in synth.fill_module(enc, a["seed"]).items()},
+          **{"ground_head." + k: v for k, v in synth.fill_module(gh, a["seed"] + 1).items()}}
+    return enc, gh, sd
+
+
+def _f17_loss(query, logits, dev="cpu"):
+    gl = torch.where(torch.isfinite(logits), logits, torch.zeros_like(logits))
+    return (query * util.loss_weight("query", query.shape).to(dev)).mean() + (gl * util.loss_weight("ground", gl.shape).to(dev)).mean()
+
+
+def f17_oracle(a, sd):
+    feats, pad, qpos, fpos, centers, prompt, ppad, qvalid = f17_inputs(a)
+    scene = f17_scene(a)
+    keep = f17_keep(a)
+    prompt.requires_grad_(True)
+    feats[scene[0]].requires_grad_(True)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    B, Nq, d = qpos.shape
+    input_dict = {"query": (torch.zeros(B, Nq, d), qvalid.logical_not(), qpos)}
+    for m in scene:
+        input_dict[m] = [feats[m], pad.clone(), fpos]
+    input_dict["prompt"] = [prompt, ppad.clone(), None]
+    query, _, _ = O.query_mask_encoder(sdo, "unified_encoder.", input_dict, O.calc_pairwise_locs(centers), None,
+                                       memories=a["memories"], H=a["H"], num_layers=a["L"], structure="mixed",
+                                       spatial_selfattn=True, training=True, memory_keep=lambda app: keep[app])
+    logits = O.ground_head(sdo, "ground_head.", query, qvalid)
+    loss = _f17_loss(query, logits)
+    loss.backward()
+    g = {k: v.grad for k, v in sdo.items() if v.grad is not None}
+    return query, logits, loss, g, {"prompt": prompt.grad, scene[0]: feats[scene[0]].grad}
+
+
+def f17_hip(a, compute, fused, dev="cuda"):
+    enc, gh, _sd = f17_modules(a, compute)
+    M.set_dropout(enc, 0.0)          # every nn.Dropout-equivalent site off; memory_dropout stays at p
+    enc.to(dev).train(); gh.to(dev).eval()
+    enc.fused = fused
+    keep = f17_keep(a).to(dev)
+    enc.memory_keep_hook = lambda app, B, Mm, device: keep[app]
+    feats, pad, qpos, fpos, centers, prompt, ppad, qvalid = f17_inputs(a)
+    scene = f17_scene(a)
+    pad, qpos, fpos, ppad, qvalid = pad.to(dev), qpos.to(dev), fpos.to(dev), ppad.to(dev), qvalid.to(dev)
+    prompt = prompt.to(dev).requires_grad_(True)
+    fd = {m: feats[m].to(dev) for m in scene}
+    fd[scene[0]].requires_grad_(True)
+    B, Nq, d = qpos.shape
+    input_dict = {"query": (torch.zeros(B, Nq, d, device=dev), qvalid.logical_not(), qpos)}
+    for m in scene:
+        input_dict[m] = [fd[m], pad, fpos]
+    input_dict["prompt"] = [prompt, ppad, None]
+    query, _, _ = enc(input_dict, M.calc_pairwise_locs(centers.to(dev)), None)
+    logits = gh(query, qvalid)
+    loss = _f17_loss(query, logits, dev)
+    loss.backward()
+    g = {"unified_encoder." + n: p.grad for n, p in enc.named_parameters() if p.grad is not None}
+    g.update({"ground_head." + n: p.grad for n, p in gh.named_parameters() if p.grad is not None})
+    return query, logits, loss, g, {"prompt": prompt.grad, scene[0]: fd[scene[0]].grad}

@@ -443,6 +443,84 @@ def run_memory_dropout_case(ref, name, *, B=3, Ns=60, Nq=11, d=64, H=4, L=2, p=0
     save(name, out)
 
 
+def stage2_inputs(*, B, Ns, Nq, d, T, memories, data_seed):
+    """Synthetic inputs of F17 (shared with the tests): scene memories + a pre-encoded prompt memory [B, T, d] with ragged
+    lengths in [T/4, T] (True = padded in `ppad`), positions, centres."""
+    scene = [m for m in memories if m != "prompt"]
+    feats, pad, qpos, fpos, centers = encoder_level_inputs(B=B, Ns=Ns, Nq=Nq, d=d, memories=scene, n_scales=0,
+                                                           data_seed=data_seed)
+    r = np.random.default_rng(data_seed + 1)
+    pl = r.integers(max(1, T // 4), T + 1, size=B); pl[0] = T
+    ppad = torch.from_numpy(np.arange(T)[None, :] >= pl[:, None])
+    prompt = torch.from_numpy(r.standard_normal((B, T, d)).astype(np.float32))
+    prompt[ppad] = 0.0
+    qvalid = torch.from_numpy(np.arange(Nq)[None, :] < r.integers(max(2, Nq // 2), Nq + 1, size=B)[:, None])
+    return feats, pad, qpos, fpos, centers, prompt, ppad, qvalid
+
+
+def run_stage2_case(ref, name, *, B=3, Ns=60, Nq=11, d=64, H=4, L=2, T=32, p=0.6,
+                    memories=("mv", "pc", "voxel", "prompt"), seed=0, data_seed=57):
+    """F17: the stage-2 shipped decoder configuration (configs/unified_tasks_sceneverse.yaml:113,159-165: memories
+    [mv, pc, voxel, prompt], memory_dropout 0.6, structure 'mixed', spatial self-attention) at encoder level, in TRAINING
+    mode with the per-layer [B, 3] keep draws of the parallel part fixed from outside (torch.rand patched; every nn.Dropout /
+    attention dropout at p = 0), followed by the reference's GroundHead (grounding_head.py:44-55, eval-mode dropout) on the
+    final query.  The prompt memory is the pre-encoded [B, T, d] tensor (pos = None, query3d_unified.py:134-136); the CLIP
+    text encoder that produces it in the reference is out of scope."""
+    torch.manual_seed(0)
+    enc = ref.qe.QueryMaskEncoder(None, memories=list(memories), memory_dropout=p, hidden_size=d, num_attention_heads=H,
+                                  num_layers=L, spatial_selfattn=True, structure="mixed")
+    gh = ref.gh.GroundHead(None, input_size=d, hidden_size=d // 2 * 3, dropout=0.3)
+    sd = {**{"unified_encoder." + k: v for k, v in synth.fill_module(enc, seed).items()},
+          **{"ground_head." + k: v for k, v in synth.fill_module(gh, seed + 1).items()}}
+    enc.train(); gh.eval()
+    for mod in enc.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    scene = [m for m in memories if m != "prompt"]
+    feats, pad, qpos, fpos, centers, prompt, ppad, qvalid = stage2_inputs(B=B, Ns=Ns, Nq=Nq, d=d, T=T, memories=memories,
+                                                                          data_seed=data_seed)
+    prompt.requires_grad_(True)
+    feats[scene[0]].requires_grad_(True)
+    input_dict = {"query": (torch.zeros(B, Nq, d), qvalid.logical_not(), qpos)}
+    for m in scene:
+        input_dict[m] = [feats[m], pad.clone(), fpos]
+    input_dict["prompt"] = [prompt, ppad.clone(), None]
+    pl = ref.utils.calc_pairwise_locs(centers, None, pairwise_rel_type="center", spatial_dist_norm=True, spatial_dim=5)
+    draws = memory_keep_draws(B, len(scene), L, data_seed)
+    it = iter(draws)
+    orig = torch.rand
+
+    def fake_rand(*size, **kw):
+        if tuple(size) == (B, len(scene)):
+            return next(it)
+        return orig(*size, **kw)
+    torch.rand = fake_rand
+    try:
+        query, _, _ = enc(input_dict, pl, None)
+    finally:
+        torch.rand = orig
+    assert next(it, None) is None, "the reference did not draw one [B, 3] mask per layer"
+    logits = gh(query, qvalid)
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd)),
+           "meta/args": np.array(repr(dict(B=B, Ns=Ns, Nq=Nq, d=d, H=H, L=L, T=T, p=p, memories=list(memories), seed=seed,
+                                           data_seed=data_seed)))}
+    put(out, "query", query)
+    put(out, "ground_logits", logits)
+    gl = torch.where(torch.isfinite(logits), logits, torch.zeros_like(logits))
+    loss = (query * loss_weight("query", query.shape)).mean() + (gl * loss_weight("ground", gl.shape)).mean()
+    out["loss"] = np.float64(loss.item())
+    loss.backward()
+    for pre, mod in (("unified_encoder.", enc), ("ground_head.", gh)):
+        for n, q in mod.named_parameters():
+            if q.grad is not None:
+                put(out, "grad/" + pre + n, q.grad, MAX_GRAD)
+    put(out, "grad_in/prompt", prompt.grad, MAX_GRAD)
+    put(out, "grad_in/" + scene[0], feats[scene[0]].grad, MAX_GRAD)
+    save(name, out)
+
+
 def run_misc_case(ref, name):
     """F6: calc_pairwise_locs, CoordinateEncoder (Fourier), dim_loc=6 encoders, GroundHead masks."""
     out = {}
@@ -703,6 +781,7 @@ def main():
     run_init_case(ref, "F16_init")
     run_multiscale_case(ref, "F13_multiscale")
     run_memory_dropout_case(ref, "F14_memory_dropout")
+    run_stage2_case(ref, "F17_stage2_mixed_prompt")
     # F15: shipped widths (configs/instseg_sceneverse.yaml:95,121,130,140): d_in 128 (offline voxel) / 768 (mv, pc) != d,
     # and d = 768 with 12 heads (d_h = 64)
     run_model_case(ref, "F15_din", B=2, Ns=96, Nq=24, d=256, H=8, L=2, memories=["voxel", "mv", "pc"], heads=["mask"],

@@ -36,6 +36,11 @@ def test_bench_two_ranks_one_gpu(config):
     assert r["value"] > 0 and abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
     assert r["grads_identical_across_ranks"] is True
     assert "cpu_baseline" not in r                       # rank-0 / N=1 only
+    if config == "c2":
+        # the fused decoder path: collectives cannot be captured with gloo, so the RCCL-independent overlap mode must have
+        # run -- two graphs split at decoder-gradients-final, >= 4 decoder buckets all-reduced in between
+        mode = r["config"]["step_mode"]
+        assert mode.startswith("two graphs") and int(mode.split(",")[1].split()[0]) >= 4, (mode, p.stderr[-1500:])
 
 
 def test_bench_two_ranks_rccl():

@@ -166,3 +166,45 @@ def test_model_with_online_voxel_pyramid_takes_the_fused_path():
     for a, b in zip(res[0]["predictions_mask"], res[1]["predictions_mask"]):
         assert float((a - b).abs().max()) <= 1e-4 * float(b[b > -1e5].abs().max())
     assert float((res[0]["query_embeds"] - res[1]["query_embeds"]).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_stage2_mixed_prompt_matches_reference_fixture(fused, compute):
+    """F17: structure 'mixed' with a prompt memory + memory dropout (the stage-2 shipped configuration,
+    configs/unified_tasks_sceneverse.yaml:113,159-165) on the fused executor and on the modular path, against the fixture
+    made from the reference's QueryMaskEncoder + GroundHead."""
+    z, a = util.load_fixture("F17_stage2_mixed_prompt")
+    (query, logits, loss, g, gin), took = _count_fused(lambda: E.f17_hip(a, compute, fused))
+    assert took == fused
+    tol = dict(atol=1e-5, rtol=1e-5) if compute == "fp32" else dict(atol=5e-3, rtol=5e-3)
+    util.check_against(z, "query", query, **tol)
+    util.check_against(z, "ground_logits", logits, **(tol if compute == "fp32" else dict(atol=1e-2, rtol=1e-2)))
+    if compute == "fp32":
+        assert abs(float(loss) - float(z["loss"])) <= 2e-5 * max(1.0, abs(float(z["loss"])))
+        names = sorted(k[5:-4] for k in z.files if k.startswith("grad/") and k.endswith("/sum"))
+        assert names == sorted(g.keys())
+        for n in names:
+            util.check_against(z, "grad/" + n, g[n], atol=2e-6, rtol=3e-3 if "pairwise_loc_fc" in n else 3e-4, cap=util.MAX_GRAD)
+        for k, v in gin.items():
+            util.check_against(z, "grad_in/" + k, v, atol=2e-6, rtol=3e-4, cap=util.MAX_GRAD)
+    else:
+        # bf16 mode: gradients close to the fp32 reference's in relative L2 (the per-parameter bar of the model-level tests)
+        import numpy as np
+        for k, v in gin.items():
+            ref_l2 = float(z[f"grad_in/{k}/l2"])
+            assert abs(float(v.float().norm()) - ref_l2) <= 5e-2 * ref_l2, k
+
+
+def test_stage2_mixed_prompt_fused_equals_modular_in_fp32():
+    _z, a = util.load_fixture("F17_stage2_mixed_prompt")
+    qf, lf, _, gf, ginf = E.f17_hip(a, "fp32", True)
+    qm, lm, _, gm_, ginm = E.f17_hip(a, "fp32", False)
+    assert float((qf - qm).abs().max()) <= 1e-6 * max(1.0, float(qm.abs().max()))
+    fin = torch.isfinite(lm)
+    assert torch.equal(fin, torch.isfinite(lf)) and float((lf[fin] - lm[fin]).abs().max()) <= 1e-5
+    gmax = max(float(v.norm()) for v in gm_.values())
+    for n in gm_:
+        assert float((gf[n] - gm_[n]).norm()) <= 1e-4 * max(float(gm_[n].norm()), 1e-2 * gmax), n
+    for k in ginm:
+        assert float((ginf[k] - ginm[k]).norm()) <= 1e-4 * float(ginm[k].norm()), k

@@ -43,3 +43,132 @@ def test_graphed_model_matches_eager(name, mode):
     gmax = max(float(v.norm()) for v in g1.values())
     for n in g1:
         assert float((g1[n] - g2[n]).norm()) <= 2e-2 * max(float(g1[n].norm()), 1e-2 * gmax), n
+
+
+def _case(name="F4_c2_slice", compute="fp32"):
+    _z, args = util.load_fixture(name)
+    _cfg, model, _sd, dd = util.model_case(args)
+    set_compute(model, compute)
+    model.to(DEV).train()
+    set_dropout(model, 0.0)
+    ddv = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in dd.items()}
+    _c2, _m2, _sd2, dd2 = util.model_case(dict(args, data_seed=args["data_seed"] + 5))
+    dd2 = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in dd2.items()}
+    return args, model, ddv, dd2
+
+
+@pytest.mark.parametrize("mode", ["direct", "autograd"])
+def test_graphed_gradient_accumulation_equals_sum_of_micro_batches(mode):
+    """Two backward passes without zero_grad ACCUMULATE (torch semantics; the reference trains under
+    accelerator.accumulate, trainer/query3d_trainer.py:35): the accumulating variant of the captured backward adds into the
+    flat buffers.  Equals the sum of the two micro-batches' separately computed gradients to fp32 rounding."""
+    args, model, dda, ddb = _case()
+    gm = GraphedQuery3D(model, dda, mode=mode)
+    loss_of = lambda out: util.synthetic_loss(out, args["heads"], out["query_embeds"])
+    singles = []
+    for d_ in (dda, ddb):
+        model.zero_grad(set_to_none=True)
+        loss_of(gm(d_)).backward()
+        singles.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    model.zero_grad(set_to_none=True)
+    loss_of(gm(dda)).backward()
+    loss_of(gm(ddb)).backward()        # no zero_grad in between -> accumulates
+    gmax = max(float(v.norm()) for v in singles[0].values())
+    for n, p in model.named_parameters():
+        if n not in singles[0]:
+            continue
+        want = singles[0][n] + singles[1][n]
+        assert float((p.grad - want).norm()) <= 2e-4 * max(float(want.norm()), 1e-2 * gmax), n
+    # and a fresh step after zero_grad is again a single micro-batch
+    model.zero_grad(set_to_none=True)
+    loss_of(gm(dda)).backward()
+    for n, p in model.named_parameters():
+        if n in singles[0]:
+            assert float((p.grad - singles[0][n]).norm()) <= 2e-4 * max(float(singles[0][n].norm()), 1e-2 * gmax), n
+
+
+def test_graphed_autograd_mode_runs_parameter_hooks_and_direct_mode_guards_stale_forwards():
+    args, model, dda, ddb = _case()
+    gm = GraphedQuery3D(model, dda, mode="autograd")
+    fired = []
+    p0 = next(p for p in model.unified_encoder.parameters() if p.requires_grad)
+    h = p0.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+    model.zero_grad(set_to_none=True)
+    out = gm(ddb)
+    util.synthetic_loss(out, args["heads"], out["query_embeds"]).backward()
+    h.remove()
+    assert fired, "mode='autograd' must deliver gradients through AccumulateGrad (DDP's hooks live there)"
+    assert p0.grad is not None and p0.grad.data_ptr() == gm._grad_view(p0).data_ptr(), "the view must be adopted without a copy"
+    # a backward whose forward was overwritten by a later forward of the same wrapper raises instead of using stale state
+    out1 = gm(dda)
+    _out2 = gm(ddb)
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        util.synthetic_loss(out1, args["heads"], out1["query_embeds"]).backward()
+    # captured constants must not change silently; shapes are checked
+    bad = dict(ddb)
+    const_keys = [k for k, v in bad.items() if not torch.is_tensor(v)]
+    if const_keys:
+        bad[const_keys[0]] = "something else"
+        with pytest.raises(ValueError, match="differs from the captured constant"):
+            gm(bad)
+    bad = dict(ddb)
+    k0 = next(k for k, v in bad.items() if torch.is_tensor(v) and v.ndim >= 2)
+    bad[k0] = bad[k0][:, :-1]
+    with pytest.raises(ValueError, match="was captured with"):
+        gm(bad)
+
+
+def test_fused_backward_accumulates_into_the_arena_until_gradients_are_reset():
+    """Eager path with a shared gradient arena (TrainStep's / the DP reducer's flat buffer): a second backward before
+    zero_grad adds in place; TrainStep.step([micro-batches]) equals the step on the summed, 1/k-scaled gradients."""
+    from pq3d_amd.parallel import FlatGradAllReducer
+    args, model, dda, ddb = _case()
+    enc = model.unified_encoder
+    params = [p for p in model.parameters() if p.requires_grad]
+    dec = {id(p) for p in enc.parameters()} | ({id(p) for p in model.mask_head.parameters()} if hasattr(model, "mask_head") else set())
+    red = FlatGradAllReducer(params, groups=[[p for p in params if id(p) in dec], [p for p in params if id(p) not in dec]])
+    enc.grad_arena, enc.grad_arena_buffers = red.slots(), [red.flat[0]]
+    loss_of = lambda out: util.synthetic_loss(out, args["heads"], out["query_embeds"])
+    singles = []
+    for d_ in (dda, ddb):
+        model.zero_grad(set_to_none=True)
+        loss_of(model(dict(d_))).backward()
+        singles.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    model.zero_grad(set_to_none=True)
+    loss_of(model(dict(dda))).backward()
+    loss_of(model(dict(ddb))).backward()
+    gmax = max(float(v.norm()) for v in singles[0].values())
+    for n, p in model.named_parameters():
+        if n in singles[0]:
+            want = singles[0][n] + singles[1][n]
+            assert float((p.grad - want).norm()) <= 2e-4 * max(float(want.norm()), 1e-2 * gmax), n
+    enc.grad_arena = None
+
+
+def test_per_layer_gradient_buckets_report_readiness_in_reverse_layer_order_and_change_no_gradient():
+    """Data-parallel mode of the fused backward: with enc.grad_bucket_per_layer the weight-gradient products of
+    a layer (incl. the K/V rows of its in_proj weights and its spatial-bias projection) are flushed when that layer's
+    backward ends and enc.grads_ready(layer) fires -- last layer first -- then 'decoder'.  Same gradients as the single
+    flush at the end (same products, another launch grouping)."""
+    from pq3d_amd.parallel import FlatGradAllReducer
+    args, model, dda, _ddb = _case("F4b_c4_slice")
+    enc = model.unified_encoder
+    params = [p for p in model.parameters() if p.requires_grad]
+    dec = {id(p) for p in enc.parameters()} | {id(p) for p in model.mask_head.parameters()}
+    red = FlatGradAllReducer(params, groups=[[p for p in params if id(p) in dec], [p for p in params if id(p) not in dec]])
+    enc.grad_arena, enc.grad_arena_buffers = red.slots(), [red.flat[0]]
+    loss_of = lambda out: util.synthetic_loss(out, args["heads"], out["query_embeds"])
+    res = []
+    for per_layer in (False, True):
+        tags = []
+        enc.grads_ready, enc.grad_bucket_per_layer = tags.append, per_layer
+        model.zero_grad(set_to_none=True)
+        loss_of(model(dict(dda))).backward()
+        res.append(({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}, tags))
+    enc.grads_ready, enc.grad_bucket_per_layer, enc.grad_arena = None, False, None
+    (g0, t0), (g1, t1) = res
+    L_ = len(enc.unified_encoder)
+    assert t0 == ["decoder"] and t1 == list(range(L_ - 1, -1, -1)) + ["decoder"], (t0, t1)
+    gmax = max(float(v.norm()) for v in g0.values())
+    for n in g0:
+        assert float((g0[n] - g1[n]).norm()) <= 1e-4 * max(float(g0[n].norm()), 1e-2 * gmax), n

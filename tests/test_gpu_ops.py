@@ -527,3 +527,76 @@ def test_copy_many_one_launch_pack():
     for d_, s_ in zip(dsts, srcs):
         assert torch.equal(d_, s_)
     assert float(flat[:3].abs().sum()) == 0.0
+
+
+WK_CASES = [
+    # (M, N, K, groups, kconcat, ct, A dtype, transB, A2, splitk, act, act_grad, C dtype)
+    (800, 256, 256, 3, 0, "x3", "f32", False, True, 1, None, None, "f32"),      # Q / QKV projections (+ query_pos)
+    (800, 256, 256, 1, 0, "x3", "f32", False, False, 1, None, None, "f32"),     # self-attention output projection
+    (800, 2048, 256, 1, 0, "x3", "f32", False, False, 1, "relu", None, "f32"),  # FFN linear1
+    (800, 256, 512, 4, 0, "x3", "f32", False, False, 1, None, None, "f32"),     # FFN linear2, K split over groups
+    (800, 256, 256, 3, 0, "bf16", "bf16", False, False, 1, None, None, "f32"),  # cross-attention output projection
+    (800, 256, 256, 1, 0, "bf16", "f32", True, False, 1, None, "add", "f32"),   # input gradient + residual
+    (800, 256, 256, 3, 3, "bf16", "bf16", True, False, 1, None, "add", "f32"),  # K-concatenated dQ.Wq over memories
+    (800, 256, 256, 3, 0, "bf16", "f32", True, False, 1, None, None, "bf16"),   # d(out-proj input), bf16 out
+    (800, 2048, 256, 1, 0, "bf16", "f32", True, False, 1, None, "relu", "bf16"),  # FFN backward through linear2 + ReLU mask
+    (800, 256, 2048, 1, 0, "bf16", "bf16", True, False, 4, None, "skip_bias", "f32"),  # FFN backward through linear1, split-K
+    (100, 201, 256, 1, 0, "x3", "f32", False, False, 1, None, None, "f32"),     # class head: ragged N
+    (37, 72, 40, 2, 0, "bf16", "f32", True, False, 1, None, None, "f32"),       # ragged everything (K < one chunk)
+    (1600, 512, 520, 2, 2, "x3", "f32", False, False, 1, "gelu", None, "f32"),  # K not a multiple of the chunk, kconcat
+]
+
+
+@pytest.mark.parametrize("case", WK_CASES, ids=[f"M{c[0]}N{c[1]}K{c[2]}g{c[3]}k{c[4]}{c[5]}{'T' if c[7] else 'N'}" for c in WK_CASES])
+def test_gemm_whole_k_tiles_match_64_tile_bit_for_bit(case):
+    """The small-M launches of the query side take the whole-K kernels (gemm_wk.hip).  Same MFMA order, same epilogue ->
+    the same bits as the 64x64-tile pipeline kernel (split-K: atomics, compared to fp32 round-off); also vs torch."""
+    M, N, K, G, kc, ct_, adt, tb, a2, sk, act, ag, cdt = case
+    no_bias = ag == "skip_bias"      # split-K launches add no bias (atomics epilogue)
+    ag = None if no_bias else ag
+    ct = L.BF16X3 if ct_ == "x3" else BF16
+    tdt = lambda n: torch.bfloat16 if n == "bf16" else torch.float32
+    A = [rnd(M, K, seed=g).to(DEV).to(tdt(adt)) for g in range(G)]
+    A2 = [rnd(M, K, seed=50 + g).to(DEV) if (a2 and g != G - 1) else None for g in range(G)] if a2 else None
+    W = [(rnd(K, N, seed=100 + g) * 0.1).to(DEV) if tb else (rnd(N, K, seed=100 + g) * 0.1).to(DEV) for g in range(G)]
+    nout = G // kc if kc else G
+    b = [rnd(N, seed=200 + g).to(DEV) if (not kc or g % kc == 0) else None for g in range(G)] if not (ag or no_bias) else None
+    aux = None
+    if ag:
+        aux = [(rnd(M, N, seed=300 + g).to(DEV).to(tdt(cdt if ag == "relu" else "f32"))) if (not kc or g % kc == 0) else None
+               for g in range(G)]
+    outs = []
+    try:
+        for wk in (1 | (1 << 8), 1 | (1 << 4) | (1 << 6) | (1 << 8), 1 | (2 << 4) | (1 << 6) | (1 << 8), 1 | (2 << 4) | (2 << 6) | (1 << 8), 0):
+            L.lib().pq3d_gemm_set_wk(wk, 0)   # automatic plan, then 32/128, 64/128, 64/256 tiles forced, then the 64x64 kernel
+            C_ = torch.zeros(nout, M, N, dtype=tdt(cdt), device=DEV)
+            Cs = [C_[g // kc] if (kc and g % kc == 0) else (C_[g] if not kc else None) for g in range(G)]
+            L.gemm(M=M, N=N, K=K, A=A, A2=A2, B=W, bias=b, Cs=Cs, aux=aux, ct=ct, lda=K, ldb=N if tb else K, ldc=N, transB=tb,
+                   kconcat=kc, splitk=sk, act=act, act_grad=ag)
+            outs.append(C_)
+    finally:
+        L.lib().pq3d_gemm_set_wk(1, 0)
+    old = outs[-1]
+    for new in outs[:-1]:
+        if sk > 1:
+            assert float((new - old).abs().max()) <= 1e-4 * float(old.abs().max())
+        else:
+            assert torch.equal(new, old), float((new.float() - old.float()).abs().max())
+    new = outs[0]
+    # against torch (first output)
+    rd = lambda t: t.float() if ct_ == "x3" else t.bfloat16().float()
+    acc = torch.zeros(M, N, device=DEV)
+    for g in range(kc or 1):
+        a = A[g].float() + (A2[g] if (A2 is not None and A2[g] is not None) else 0)
+        acc += rd(a) @ (rd(W[g]) if tb else rd(W[g]).T)
+    if b is not None:
+        acc += b[0]
+    if act == "relu":
+        acc = acc.relu()
+    elif act == "gelu":
+        acc = torch.nn.functional.gelu(acc)
+    if ag == "add":
+        acc += aux[0].float()
+    elif ag == "relu":
+        acc = acc * (aux[0].float() > 0)
+    close(new[0].float(), acc, F32 if ct_ == "x3" else BF16, "gemm_wk")

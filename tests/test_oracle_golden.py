@@ -138,3 +138,22 @@ def test_memory_dropout_fixture():
     assert names == sorted(g.keys())
     for n in names:
         util.check_against(z, "grad/" + n, g[n], atol=2e-6, rtol=2e-5, cap=util.MAX_GRAD)
+
+
+def test_stage2_mixed_prompt_fixture():
+    """F17: the stage-2 shipped decoder configuration (memories [mv, pc, voxel, prompt], structure 'mixed', memory_dropout
+    0.6 with the reference's draws fixed from outside, T = 32 prompt tokens, GroundHead on the final query)."""
+    from tests import encoder_cases as E
+    z, a = util.load_fixture("F17_stage2_mixed_prompt")
+    _enc, _gh, sd = E.f17_modules(a)
+    assert abs(synth.state_checksum(sd) - float(z["meta/weights_checksum"])) < 1e-6 * abs(float(z["meta/weights_checksum"]))
+    query, logits, loss, g, gin = E.f17_oracle(a, sd)
+    util.check_against(z, "query", query, **TOL)
+    util.check_against(z, "ground_logits", logits, **TOL)
+    assert abs(float(loss) - float(z["loss"])) <= 1e-6 * max(1.0, abs(float(z["loss"])))
+    names = sorted(k[5:-4] for k in z.files if k.startswith("grad/") and k.endswith("/sum"))
+    assert names == sorted(g.keys())
+    for n in names:
+        util.check_against(z, "grad/" + n, g[n], atol=2e-6, rtol=2e-5, cap=util.MAX_GRAD)
+    for k, v in gin.items():
+        util.check_against(z, "grad_in/" + k, v, atol=2e-6, rtol=2e-5, cap=util.MAX_GRAD)
