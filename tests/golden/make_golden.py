@@ -13,6 +13,7 @@ checksum is stored to detect RNG drift.  Large tensors are stored as a strided s
 """
 from __future__ import annotations
 
+import ast
 import builtins
 import importlib
 import os
@@ -521,6 +522,50 @@ def run_stage2_case(ref, name, *, B=3, Ns=60, Nq=11, d=64, H=4, L=2, T=32, p=0.6
     save(name, out)
 
 
+def run_autocast_case(ref, name, base_name):
+    """F19: the reference's OWN bf16 path -- the trainer runs under accelerate mixed_precision (launch.py:51-52), i.e.
+    torch.autocast(bf16) around the model -- at the shapes of a committed fp32 model case (`base_name`): the same model,
+    weights and data run in fp32 and under CPU bf16 autocast; stored are the autocast run's per-layer queries / outputs
+    (samples) and its error against the fp32 run per layer (max |diff| / max |fp32| and relative L2).  This is the yardstick
+    for the HIP 'bf16' compute mode: tests assert that its error against fp32 stays below the reference's own."""
+    zb = np.load(os.path.join(HERE, base_name + ".npz"), allow_pickle=False)   # the committed base case (its arguments)
+    a = ast.literal_eval(str(zb["meta/args"]))
+    kw = {k: v for k, v in a.items() if k not in ("B", "Ns", "Nq", "d", "H", "L", "memories", "heads", "spatial", "structure",
+                                                  "seed", "data_seed", "query_valid_min")}
+    d_in = dict(kw.pop("d_in", None) or {m: a["d"] for m in a["memories"]})
+    cfg = model_cfg(a["d"], a["H"], a["L"], a["memories"], a["heads"], d_in, spatial=a["spatial"], structure=a["structure"], **kw)
+    torch.manual_seed(0)
+    model = ref.model.Query3DUnified(cfg)
+    sd = synth.fill_module(model, a["seed"])
+    model.eval()
+    dd = synth.synth_data_dict(a["B"], a["Ns"], a["Nq"], d_in, seed=a["data_seed"], memories=a["memories"],
+                               query_valid_min=a.get("query_valid_min"), loc_dim=kw.get("dim_loc", 3))
+    dd["tgt_object_id"] = torch.zeros(a["B"], dtype=torch.long)
+
+    def run(autocast):
+        captured = []
+        hooks = [layer.register_forward_hook(lambda _m, _i, o: captured.append(o.detach().float()))
+                 for layer in model.unified_encoder.unified_encoder]
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            res = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in dd.items()})
+        for h in hooks:
+            h.remove()
+        return captured, res
+    q32, r32 = run(False)
+    q16, r16 = run(True)
+    out = {"meta/weights_checksum": np.float64(synth.state_checksum(sd)), "meta/args": np.array(repr(a)),
+           "meta/base": np.array(base_name)}
+    for i, (x, y) in enumerate(zip(q32, q16)):
+        put(out, f"autocast/layer_query/{i}", y)
+        out[f"err/layer_query/{i}/max_rel"] = np.float64(float((x - y).abs().max() / x.abs().max()))
+        out[f"err/layer_query/{i}/rel_l2"] = np.float64(float((x - y).norm() / x.norm()))
+    if "ground" in a["heads"]:
+        x, y = r32["ground_logits"].float(), r16["ground_logits"].float()
+        fin = torch.isfinite(x)
+        out["err/ground_logits/max_rel"] = np.float64(float((x[fin] - y[fin]).abs().max() / x[fin].abs().max()))
+    save(name, out)
+
+
 def run_misc_case(ref, name):
     """F6: calc_pairwise_locs, CoordinateEncoder (Fourier), dim_loc=6 encoders, GroundHead masks."""
     out = {}
@@ -790,6 +835,9 @@ def main():
     run_model_case(ref, "F15_d768", B=2, Ns=64, Nq=10, d=768, H=12, L=1, memories=["mv", "pc"], heads=["ground"],
                    spatial=True, structure="parallel", data_seed=4321)   # (seed 1234 puts one FFN pre-activation within
     # 1e-7 of the ReLU kink: the exact-f32 MFMA sums in another order than torch's CPU GEMM and lands on the other side)
+    # F19: the reference under its own bf16 autocast at the F4_c2_slice / F15_d768 shapes (yardstick of the bf16 mode)
+    run_autocast_case(ref, "F19_autocast_c2_slice", "F4_c2_slice")
+    run_autocast_case(ref, "F19_autocast_d768", "F15_d768")
 
 
 if __name__ == "__main__":

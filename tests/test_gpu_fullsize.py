@@ -185,9 +185,11 @@ def test_bf16_fullsize_matches_fp32_oracle(args):
     model, sd, dd = build(args, "bf16")
     out, loss = run(model, args, dd)
     oout, collect, oloss, og = util.run_oracle(args, sd, dd)
-    assert rel(out["query_embeds"], collect[-1]) < 1e-2
+    # bars = <= 1.5 x measured (profiles/parity_r0*.txt: c2 query 6.7e-3, head 4.8e-3; c4 pinned 3.7e-3 / 6.5e-3; 1 - cos
+    # 4.5e-3; worst parameter 0.12).  The reference's own bf16 autocast: 2e-2 .. 3e-2 per layer (tests/test_gpu_model.py, F19)
+    assert rel(out["query_embeds"], collect[-1]) < 8e-3
     if "ground" in args["heads"]:
-        assert rel(out["ground_logits"], oout["ground_logits"]) < 1e-2
+        assert rel(out["ground_logits"], oout["ground_logits"]) < 8e-3
     if "mask" in args["heads"]:
         for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
             assert rel(m, r) < 1e-2
@@ -196,10 +198,10 @@ def test_bf16_fullsize_matches_fp32_oracle(args):
     assert abs(loss.item() - oloss.item()) < 1e-3 * max(1.0, abs(oloss.item()))
     g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
     names = sorted(n for n in og if "pairwise_loc_fc" not in n)
-    assert _flat_cos(g, og, names) >= 0.99
+    assert _flat_cos(g, og, names) >= 0.993
     gmax = max(float(og[n].norm()) for n in names)
     worst = max((float((g[n].float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * gmax)), n) for n in names)
-    assert worst[0] < 0.25, f"worst gradient (relative L2) {worst}"
+    assert worst[0] < 0.2, f"worst gradient (relative L2) {worst}"
 
 
 def test_bf16_c4_self_mask_flip_rate():

@@ -117,26 +117,63 @@ def test_bf16_model_matches_fp32_oracle(name):
         assert torch.equal(torch.isfinite(b), torch.isfinite(a))
         return float((a[fin] - b[fin]).abs().max() / max(float(b[fin].abs().max()), 1e-6))
 
-    assert rel(out["query_embeds"], collect[-1]) < 3e-2
+    # bars = <= 1.5 x the largest value measured over these fixtures (profiles/parity_r0*.txt: query 1.5e-2, head logits
+    # 2.1e-2 at d = 768, mask logits 1.6e-2, 1 - cos 4.9e-3, worst parameter 0.12); the reference's OWN bf16 (autocast) is
+    # at 2.3e-2 .. 6.7e-2 on the query at the same shapes (F19 fixtures, test below)
+    assert rel(out["query_embeds"], collect[-1]) < 2e-2
     if "ground" in args["heads"]:
-        assert rel(out["ground_logits"], oout["ground_logits"]) < 3e-2
+        assert rel(out["ground_logits"], oout["ground_logits"]) < 2.5e-2
     if "mask" in args["heads"]:
         flips = 0.0
         for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
-            assert rel(m, r) < 3e-2
+            assert rel(m, r) < 2.5e-2
             flips = max(flips, float(((m.detach().float().cpu() < 0) != (r < 0)).float().mean()))
         assert flips < 1e-2, f"self-mask bit-flip rate vs the fp32 oracle {flips:.5f}"
         for c, r in zip(out["predictions_class"], oout["predictions_class"]):
-            assert rel(c, r) < 3e-2
-    assert abs(loss.item() - oloss.item()) < 3e-3 * max(1.0, abs(oloss.item()))
+            assert rel(c, r) < 2.5e-2
+    assert abs(loss.item() - oloss.item()) < 2e-3 * max(1.0, abs(oloss.item()))
     names = [n for n in og if "pairwise_loc_fc" not in n]
     gmax = max(float(og[n].norm()) for n in names)
     worst = max((float((g[n].detach().float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * gmax)), n)
                 for n in names)
-    assert worst[0] < 0.3, f"worst gradient (relative L2) {worst}"
+    assert worst[0] < 0.2, f"worst gradient (relative L2) {worst}"
     a = torch.cat([g[n].detach().float().cpu().flatten() for n in sorted(names)]).double()
     b = torch.cat([og[n].flatten() for n in sorted(names)]).double()
-    assert float((a * b).sum() / (a.norm() * b.norm())) >= 0.98
+    assert float((a * b).sum() / (a.norm() * b.norm())) >= 0.9925
+
+
+@pytest.mark.parametrize("name", ["F19_autocast_c2_slice", "F19_autocast_d768"])
+def test_bf16_mode_is_closer_to_fp32_than_the_references_own_bf16_autocast(name):
+    """The yardstick north_star's '1e-3 bf16' has to be read against: the REFERENCE itself under its bf16 path
+    (torch.autocast, launch.py:51-52 -> accelerate mixed precision) differs from its fp32 run by 1.8e-2 .. 3.0e-2 of the
+    query scale after EVERY layer at config-2 shapes and 6.7e-2 at d = 768 (fixtures F19, made from the reference on the
+    CPU).  The HIP 'bf16' mode must stay below HALF of the reference's own error at every layer (measured: 4-7x below),
+    in max-norm and in relative L2, on the modular path (per-layer hooks) and on the fused executor (final query)."""
+    z, _ = util.load_fixture(name)
+    base = str(z["meta/base"])
+    _zb, args = util.load_fixture(base)
+    res = {}
+    for fused in (False, True):
+        _cfg, model, sd, dd = util.model_case(args)
+        set_compute(model, "bf16")
+        model.unified_encoder.fused = fused
+        cap = []
+        hooks = [l.register_forward_hook(lambda _m, _i, o: cap.append(o.detach().float().cpu()))
+                 for l in model.unified_encoder.unified_encoder]
+        out, _loss, _g = run_hip(model, args, dd, grads=False)
+        for h in hooks:
+            h.remove()
+        res[fused] = (cap, out["query_embeds"].detach().float().cpu())
+    _oout, collect, _ol, _og = util.run_oracle(args, sd, dd, grads=False)
+    cap, _ = res[False]
+    assert len(cap) == len(collect) == args["L"]
+    for i, (q, r) in enumerate(zip(cap, collect)):
+        mx = float((q - r).abs().max() / r.abs().max())
+        l2 = float((q - r).norm() / r.norm())
+        ref_mx, ref_l2 = float(z[f"err/layer_query/{i}/max_rel"]), float(z[f"err/layer_query/{i}/rel_l2"])
+        assert mx <= 0.5 * ref_mx and l2 <= 0.5 * ref_l2, (i, mx, ref_mx, l2, ref_l2)
+    qf = res[True][1]
+    assert float((qf - collect[-1]).abs().max() / collect[-1].abs().max()) <= 0.5 * float(z[f"err/layer_query/{args['L'] - 1}/max_rel"])
 
 
 def test_fused_path_is_taken_and_equals_modular_bf16():

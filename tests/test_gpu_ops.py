@@ -600,3 +600,44 @@ def test_gemm_whole_k_tiles_match_64_tile_bit_for_bit(case):
     elif ag == "relu":
         acc = acc * (aux[0].float() > 0)
     close(new[0].float(), acc, F32 if ct_ == "x3" else BF16, "gemm_wk")
+
+
+# ---------------------------------------------------------------------------------------------- segment pooling, adversarial
+def test_scatter_mean_adversarial_cases_match_the_published_definition():
+    """pq3d_scatter_mean_* against the oracle's restatement of torch_scatter's published definition on the adversarial
+    inputs of tests/test_oracle_golden.py (unsorted / duplicate ids, empty segments, one segment takes all, dim_size beyond
+    the largest id, single row), forward and backward."""
+    from tests.test_oracle_golden import SCATTER_CASES
+    for name, make in sorted(SCATTER_CASES.items()):
+        src, idx, n = make(np.random.default_rng(0))
+        if len(src) == 0:
+            continue        # an empty scene never reaches the kernel (the collate drops it)
+        src = torch.from_numpy(np.asarray(src, dtype=np.float32))
+        idx = torch.from_numpy(np.asarray(idx, dtype=np.int64))
+        sd = src.to(DEV).requires_grad_(True)
+        out = ops.scatter_mean(sd, idx.to(DEV), n)
+        sr = src.clone().requires_grad_(True)
+        outr = O.scatter_mean(sr, idx, n)
+        close(out, outr, F32, f"scatter_mean [{name}]", atol=1e-6, rtol=1e-6)
+        empty = torch.ones(n, dtype=torch.bool)
+        empty[idx] = False
+        assert float(out.detach().cpu()[empty].abs().sum()) == 0.0, name
+        gy = rnd(n, src.shape[1], seed=3)
+        out.backward(gy.to(DEV)); outr.backward(gy)
+        close(sd.grad, sr.grad, F32, f"scatter_mean grad [{name}]", atol=1e-6, rtol=1e-6)
+
+
+def test_parents_from_coords_negative_and_duplicate_coordinates():
+    """The coordinate map of the stride-2^k pooling pair: floor division for negative coordinates, voxels sharing a coarse
+    cell share the parent, batch items never mix, a missing coarse voxel -> -1 (then skipped by the pooling kernel)."""
+    fine = torch.tensor([[0, -1, -1, -1], [0, -2, -2, -2], [0, 0, 1, 1], [0, 1, 0, 0], [1, 0, 1, 1], [0, 3, 3, 3], [0, -3, 5, 0]])
+    cc, par = O.pooling_transpose_parents(fine, 2)
+    got = ops.parents_from_coords(fine.to(DEV), cc.to(DEV), 2)
+    assert got.cpu().tolist() == par.tolist() == [0, 0, 1, 1, 2, 3, 4]
+    # shuffled coarse rows: the map follows the rows; a removed coarse voxel orphans exactly its children
+    perm = torch.tensor([3, 0, 4, 2, 1])
+    got = ops.parents_from_coords(fine.to(DEV), cc[perm].to(DEV), 2)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(5)
+    assert got.cpu().tolist() == inv[par].tolist()
+    got = ops.parents_from_coords(fine.to(DEV), cc[1:].to(DEV), 2)
+    assert got.cpu().tolist() == [-1, -1, 0, 0, 1, 2, 3]

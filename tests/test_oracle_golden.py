@@ -80,15 +80,60 @@ def test_misc_fixture():
     util.check_against(z, "coord_enc", O.coordinate_encoder(sd, "", locs, cmin, cmax), **TOL)
 
 
-def test_scatter_mean_matches_definition():
-    r = np.random.default_rng(0)
-    src = torch.from_numpy(r.standard_normal((500, 7)).astype(np.float32))
-    idx = torch.from_numpy(r.integers(0, 40, 500))
-    out = O.scatter_mean(src, idx, 48)
-    for s in (0, 5, 39, 47):
-        sel = src[idx == s]
-        exp = sel.mean(0) if len(sel) else torch.zeros(7)
-        assert torch.allclose(out[s], exp, atol=1e-6)
+def _scatter_mean_literal(src, idx, dim_size):
+    """The published torch_scatter definition as a literal per-segment loop (sum, count clamped to >= 1, divide)."""
+    out = torch.zeros(dim_size, *src.shape[1:], dtype=torch.float64)
+    cnt = torch.zeros(dim_size, dtype=torch.float64)
+    for r in range(src.shape[0]):
+        out[int(idx[r])] += src[r].double()
+        cnt[int(idx[r])] += 1
+    cnt[cnt < 1] = 1
+    return (out / cnt.view(-1, *([1] * (src.dim() - 1)))).float()
+
+
+SCATTER_CASES = {
+    "random unsorted ids with gaps": lambda r: (r.standard_normal((500, 7)), r.integers(0, 40, 500), 48),
+    "every second segment empty": lambda r: (r.standard_normal((300, 5)), 2 * r.integers(0, 20, 300), 41),
+    "one segment takes all": lambda r: (r.standard_normal((64, 3)), np.full(64, 9), 12),
+    "ids sorted descending, many duplicates": lambda r: (r.standard_normal((200, 4)), np.sort(r.integers(0, 6, 200))[::-1].copy(), 6),
+    "dim_size far beyond the largest id": lambda r: (r.standard_normal((10, 2)), r.integers(0, 3, 10), 100),
+    "empty source": lambda r: (np.zeros((0, 6)), np.zeros((0,), dtype=np.int64), 5),
+    "single row": lambda r: (r.standard_normal((1, 8)), np.array([3]), 4),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SCATTER_CASES))
+def test_scatter_mean_matches_definition(case):
+    """Row (a)15: torch_scatter is un-vendored (parity unpinned by execution); the oracle restates its published definition
+    and is checked here against a literal loop on adversarial inputs (see O.scatter_mean's docstring for the clauses)."""
+    src, idx, n = SCATTER_CASES[case](np.random.default_rng(0))
+    src, idx = torch.from_numpy(np.asarray(src, dtype=np.float32)), torch.from_numpy(np.asarray(idx, dtype=np.int64))
+    out = O.scatter_mean(src, idx, n)
+    assert out.shape == (n, src.shape[1])
+    assert torch.allclose(out, _scatter_mean_literal(src, idx, n), atol=1e-6)
+    empty = torch.ones(n, dtype=torch.bool)
+    empty[idx] = False
+    assert float(out[empty].abs().sum()) == 0.0      # clause 2: empty segments are exactly zero
+
+
+def test_pooling_transpose_parents_semantics():
+    """Row (f)2: MinkowskiPoolingTranspose(kernel 2, stride 2) coordinate map (MinkowskiEngine not installed: unpinned by
+    execution): floor division also for negative coordinates, one ancestor per fine voxel, duplicates share it, batch items
+    never mix, chained stride-2 maps compose to the stride-2^k map."""
+    fine = torch.tensor([[0, -1, -1, -1], [0, -2, -2, -2], [0, 0, 1, 1], [0, 1, 0, 0], [1, 0, 1, 1], [0, 3, 3, 3], [0, -3, 5, 0]])
+    cc, par = O.pooling_transpose_parents(fine, 2)
+    assert cc.tolist() == [[0, -2, -2, -2], [0, 0, 0, 0], [1, 0, 0, 0], [0, 2, 2, 2], [0, -4, 4, 0]]
+    assert par.tolist() == [0, 0, 1, 1, 2, 3, 4]              # -1 -> -2 (floor), duplicates share, batch 1 is its own cell
+    g = torch.Generator().manual_seed(1)
+    f2 = torch.cat([torch.randint(0, 2, (400, 1), generator=g), torch.randint(-33, 33, (400, 3), generator=g)], 1).unique(dim=0)
+    c1, p1 = O.pooling_transpose_parents(f2, 2)
+    c2, p2 = O.pooling_transpose_parents(c1, 4)
+    c4, p4 = O.pooling_transpose_parents(f2, 4)
+    assert torch.equal(c2[p2[p1]], c4[p4])                    # composition of the chain == the direct stride-4 map
+    feat = torch.arange(c2.shape[0], dtype=torch.float32)[:, None]
+    seg = torch.randint(0, 5, (f2.shape[0],), generator=g)
+    up = feat[p2][p1]                                          # two transposed poolings materialised
+    assert torch.equal(O.multiscale_segment_pool(feat, p2[p1], seg, 7), O.scatter_mean(up, seg, 7))
 
 
 def test_t5_input_proj_against_reference_head():
