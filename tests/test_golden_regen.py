@@ -18,7 +18,9 @@ def test_generator_reproduces_committed_fixtures(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py")], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
-    names = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    # F18 is not made by this generator: it holds outputs of the reference's own GPU kernels (oracle/run_ref_pointnet2.py on an
+    # MI355X box; checked against the oracle by tests/test_pointnet2.py)
+    names = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "F18_pointnet2_ref.npz")
     assert names == sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
     for f in names:
         a, b = np.load(os.path.join(GOLDEN, f)), np.load(os.path.join(tmp_path, f))
