@@ -86,13 +86,20 @@ def build(c, compute, device, seed):
 def loss_fn(out, heads):
     from pq3d_amd import ops
     q = out["query_embeds"] if "query_embeds" in out else out["query"]
-    loss = ops.mean_all(q) if q.is_cuda else q.mean()   # mean(query); the CPU-baseline leg has host tensors
+    if q.is_cuda and "mask" in heads:
+        # mean(query) + sum over prediction layers of mean(clamp(mask_logits, -50)) + mean(class logits of the kept
+        # classes): one launch forward, one backward (ops.mean_many) instead of ~14 framework launches per layer
+        xs = [q] + list(out["predictions_mask"]) + list(out["predictions_class"])
+        modes = ["plain"] + ["clamp_min"] * len(out["predictions_mask"]) + ["finite"] * len(out["predictions_class"])
+        loss = ops.mean_many(xs, modes, clamp_min=-50.0)
+    else:
+        loss = ops.mean_all(q) if q.is_cuda else q.mean()   # the CPU-baseline leg has host tensors
+        if "mask" in heads:
+            for cl, m in zip(out["predictions_class"], out["predictions_mask"]):
+                loss = loss + m.clamp(min=-50.0).mean() + torch.where(torch.isfinite(cl), cl, torch.zeros_like(cl)).mean()
     if "generation" in heads:   # generation_loss: token cross-entropy of the teacher-forced logits
         lg = out["generation_logits"]
         loss = loss + torch.nn.functional.cross_entropy(lg.flatten(0, 1).float(), out["generation_label"].flatten())
-    if "mask" in heads:
-        for cl, m in zip(out["predictions_class"], out["predictions_mask"]):
-            loss = loss + m.clamp(min=-50.0).mean() + torch.where(torch.isfinite(cl), cl, torch.zeros_like(cl)).mean()
     return loss
 
 
@@ -150,53 +157,90 @@ def cpu_baseline(c, sd, dd, steps, warmup, hf_body=None):
                       f"fp32, torch CPU ops, dropout 0, best of the thread counts tried"}
 
 
-def gpu_kernels_of(entry, shape):
-    """GPU kernels behind one (C-ABI entry point, shape key) of the per-kernel table -- used to look the entry's HBM
-    traffic up in the per-kernel PMC file.  Attention: the dispatch rules of attention.hip (small fp32 kernels for
-    Lq, Lk <= 128; the all-queries-resident backward for Lq <= 128 <= Lk; the two-kernel backward otherwise)."""
+FAMILY_KERNELS = {   # GPU kernels behind a C-ABI entry point (rocprofv3 / PMC kernel names, template arguments stripped)
+    "pq3d_gemm": ["gemm_wk_kernel", "gemm_fast_kernel", "gemm_slow_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel"],
+    "pq3d_attn_fwd": ["attn_fwd_resident_kernel", "attn_small_fwd_kernel", "attn_fwd_kernel", "attn_fwd_combine_kernel"],
+    "pq3d_attn_bwd": ["attn_bwd_resident_kernel", "attn_small_bwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
+                      "attn_dq_combine_kernel"],
+    "pq3d_add_ln_fwd": ["add_ln_fwd_kernel"], "pq3d_add_ln_bwd": ["add_ln_bwd_kernel"],
+}
+CALIBRATION_BYTES = 100 << 20   # the PMC calibration launch: copy_many_kernel streams this many bytes in and out (16 B / lane)
+
+
+def committed_profiles(config):
+    """The newest committed evidence of this config under profiles/: (PMC traffic json or None, {kernel: (launches per
+    step, avg us in the replayed graph)} from the rocprofv3 --kernel-trace --stats summary or {}, tag)."""
+    import glob
     import re
-    m = re.match(r"B(\d+)H(\d+)Lq(\d+)Lk(\d+)dh(\d+)ct(\d+)", shape)
-    if entry in ("pq3d_attn_fwd", "pq3d_attn_bwd") and m:
-        _B, _H, Lq, Lk, _dh, ct = map(int, m.groups())
-        small = ct == 0 and Lq <= 128 and Lk <= 128
-        if entry == "pq3d_attn_fwd":
-            return ["attn_small_fwd_kernel"] if small else ["attn_fwd_kernel", "attn_fwd_combine_kernel"]
-        if small:
-            return ["attn_small_bwd_kernel"]
-        return (["attn_bwd_resident_kernel", "attn_dq_combine_kernel"] if Lq <= 256 and Lk >= 128
-                else ["attn_bwd_dq_kernel", "attn_dq_combine_kernel", "attn_bwd_dkv_kernel"])
-    return {"pq3d_gemm": ["gemm_fast_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel"],
-            "pq3d_add_ln_fwd": ["add_ln_fwd_kernel"], "pq3d_add_ln_bwd": ["add_ln_bwd_kernel"]}.get(entry, [])
+    pdir = os.path.join(ROOT, "profiles")
+    tags = sorted({m.group(1) for f in glob.glob(os.path.join(pdir, f"*_{config}*")) for m in [re.search(r"_(r\d\d)_", f)] if m})
+    pmc, stats, tag_used = None, {}, None
+    for tag in reversed(tags):
+        pj = os.path.join(pdir, f"pmc_traffic_{tag}_{config}.json")
+        st = os.path.join(pdir, f"rocprofv3_kernel_stats_{tag}_fused_graph_{config}.txt")
+        if pmc is None and os.path.exists(pj):
+            try:
+                pmc = json.load(open(pj)); pmc["_file"] = f"profiles/{os.path.basename(pj)}"
+            except ValueError:
+                pmc = None
+        if not stats and os.path.exists(st):
+            lines = open(st).read().splitlines()
+            m = re.search(r"(\d+) kernel dispatches.*per step: (\d+) dispatches", lines[0]) if lines else None
+            steps = (int(m.group(1)) / int(m.group(2))) if m else None
+            for ln in lines[2:]:
+                mm = re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+                if mm and steps:
+                    name = re.sub(r"[<(].*$", "", mm.group(1).replace("(anonymous namespace)::", "").replace("void ", ""))
+                    c, tot = stats.get(name, (0.0, 0.0))
+                    stats[name] = (c + int(mm.group(2)) / steps, tot + float(mm.group(3)) * 1e3 / steps)   # launches, us per step
+            stats["_file"] = f"profiles/{os.path.basename(st)}"
+            tag_used = tag
+    return pmc, stats, tag_used
 
 
-def pmc_traffic(path, entry, shape, gpu_names):
-    """roofline.traffic (bytes per launch of the entry point) from a committed PMC file: the r02 per-kernel format written
-    by tools/pmc_traffic_json.py, or round 1's per-entry file.  None when the file or the kernels are not in it, or when
-    a kernel name maps to several launch shapes (GEMMs: ambiguous, left null rather than guessed)."""
-    try:
-        doc = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-    if "kernels" not in doc:
-        e = doc.get(f"{entry}|{shape}")
-        return None if not e else {"traffic": e["hbm_bytes_raw"], "traffic_fetch_x2_corrected": e["hbm_bytes_fetch_x2"],
-                                   "traffic_source": src}
-    if not entry.startswith("pq3d_attn"):
-        return None
-    fetch = write = 0.0
-    found = 0
-    for n in gpu_names:
-        rows = doc["kernels"].get(n, [])
-        if len(rows) > 1:
-            return None
-        if rows:
-            fetch += rows[0]["fetch_kib"] * 1024
-            write += rows[0]["write_kib"] * 1024
-            found += 1
-    if not found or not any(n in doc["kernels"] for n in gpu_names[:1]):
-        return None
-    return {"traffic": fetch + write, "traffic_fetch_x2_corrected": 2 * fetch + write, "traffic_source": src}
+def family_block(entry, v, peak_tflops, steps, pmc, stats):
+    """Roofline entry of one C-ABI entry point (= kernel family): algorithmic FLOPs (or bytes) of all its launches divided
+    by their summed durations (HIP events on the launch stream, eager pass), per-launch averages, and -- from the committed
+    rocprofv3 evidence of the same config -- the family's in-graph time and its HBM traffic per launch."""
+    calls, ms = v["calls"], v["ms"]
+    per_launch_us = ms / calls * 1e3
+    if v["flops"] > 0:
+        ach = v["flops"] / (ms * 1e-3) / 1e12
+        blk = {"bound": "mfma", "achieved": ach, "peak": peak_tflops, "unit": "TFLOP/s", "frac": ach / peak_tflops}
+    else:
+        ach = v["bytes"] / (ms * 1e-3) / 1e9
+        blk = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
+    names = FAMILY_KERNELS.get(entry, [])
+    blk.update({"kernel": entry, "gpu_kernels": names, "launches_per_step": calls / steps, "avg_launch_us": per_launch_us,
+                "ms_per_step": ms / steps, "algorithmic_gflop_per_step": v["flops"] / steps / 1e9,
+                "algorithmic_bytes_per_launch": v["bytes"] / calls, "traffic": None})
+    # in-graph durations of the same kernels (rocprofv3 --kernel-trace --stats of the replayed step, committed)
+    hit = [(n, stats[n]) for n in names if n in stats]
+    if hit:
+        l = sum(c for _n, (c, _t) in hit)
+        t = sum(t for _n, (_c, t) in hit)
+        blk["in_graph"] = {"launches_per_step": round(l, 2), "avg_launch_us": t / max(l, 1e-9), "ms_per_step": t / 1e3,
+                           "frac": (v["flops"] / steps / (t * 1e-6) / 1e12 / peak_tflops) if v["flops"] > 0
+                           else (v["bytes"] / steps / (t * 1e-6) / 1e9 / PEAK_HBM_GBS), "source": stats.get("_file")}
+    # HBM traffic per launch: PMC FETCH_SIZE / WRITE_SIZE sums over the family's kernels / its launches, corrected by the
+    # calibration launch of the same PMC pass (a known 100 MiB streaming copy: raw counter / true bytes)
+    if pmc is not None and "kernels" in pmc:
+        fetch = write = launches = 0.0      # launch-weighted sums over every (kernel, grid) row of the family
+        for n in names:
+            for r in pmc["kernels"].get(n, []):
+                fetch += r["fetch_kib"] * 1024 * r["launches"]
+                write += r["write_kib"] * 1024 * r["launches"]
+                launches += r["launches"]
+        if launches > 0:
+            cal = pmc.get("calibration") or {}
+            cf = 1.0 / cal["fetch_raw_over_true"] if cal.get("fetch_raw_over_true") else 2.0    # guide: x2 for wide reads
+            cw = 1.0 / cal["write_raw_over_true"] if cal.get("write_raw_over_true") else 1.0
+            blk.update({"traffic": (fetch * cf + write * cw) / launches, "traffic_raw_counters": (fetch + write) / launches,
+                        "traffic_correction": {"fetch_x": round(cf, 3), "write_x": round(cw, 3),
+                                               "from": "calibration launch in the same PMC pass" if cal else
+                                               "MI355X_MICROARCH.md HBM section (no calibration in this file)"},
+                        "traffic_source": pmc.get("_file")})
+    return blk
 
 
 def main():
@@ -210,6 +254,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=32, help="timed CPU-baseline steps (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--dump-kernels", default=None, help="write the per-(entry point, shape) timing table here")
+    ap.add_argument("--pmc-calibration", action="store_true",
+                    help="after the profiled pass launch ONE known streaming copy (100 MiB in, 100 MiB out, 16 B / lane): "
+                         "under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE its raw counters calibrate the traffic numbers")
     ap.add_argument("--dropout", default="off", choices=["off", "reference"],
                     help="headline run: 'off' = p=0 (the parity-checked arithmetic); 'reference' = the reference's "
                          "train-mode probabilities (0.1 in the decoder layers and encoders, 0.1/0.3 in the heads)")
@@ -438,30 +485,33 @@ def main():
             for _ in range(args.profile_steps):
                 fwd_bwd()
         summ = kt.summary()
+        if args.pmc_calibration:
+            from pq3d_amd import ops
+            n_cal = CALIBRATION_BYTES // 4
+            csrc, cdst = torch.ones(n_cal, device=dev), torch.empty(n_cal, device=dev)
+            ops.copy_many([cdst], [csrc])
+            torch.cuda.synchronize()
+            del csrc, cdst
+        ps = max(args.profile_steps, 1)
         tot = sum(v["ms"] for v in summ.values())
-        (kname, kkey), top = max(summ.items(), key=lambda kv: kv[1]["ms"])
-        per_launch_ms = top["ms"] / top["calls"]
-        if top["flops"] > 0:
-            ach = top["flops"] / top["calls"] / (per_launch_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "traffic": None}
-        else:
-            ach = top["bytes"] / top["calls"] / (per_launch_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                    "traffic": None}
-        gpu_names = gpu_kernels_of(kname, kkey)
-        for tag in (f"r02_{args.config}", "r01"):   # HBM traffic of this entry point from the committed rocprofv3 --pmc passes
-            pmc_file = os.path.join(ROOT, "profiles", f"pmc_traffic_{tag}.json")
-            t = pmc_traffic(pmc_file, kname, kkey, gpu_names)
-            if t is not None:
-                roof.update(t)
-                break
-        roof.update({"kernel": kname, "gpu_kernels": gpu_names, "shape": kkey,
-                     "algorithmic_bytes_per_launch": top["bytes"] / top["calls"],
-                     "avg_launch_us": per_launch_ms * 1e3,
-                     "launches_per_step": top["calls"] / args.profile_steps,
-                     "share_of_kernel_time": top["ms"] / tot,
-                     "kernel_ms_per_step_eager_events": tot / args.profile_steps})
+        fams = {}
+        for (n, _k), v in summ.items():
+            f = fams.setdefault(n, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
+            for kk in ("ms", "calls", "flops", "bytes"):
+                f[kk] += v[kk]
+        pmc, stats, tag = committed_profiles(args.config)
+        order = sorted(fams, key=lambda n: -fams[n]["ms"])
+        blocks = [family_block(n, fams[n], peak, ps, pmc, stats) for n in order[:3]]
+        for b in blocks:
+            b["share_of_kernel_time"] = fams[b["kernel"]]["ms"] / tot if tot else 0.0
+            mem = sorted(((k, v) for (n, k), v in summ.items() if n == b["kernel"]), key=lambda kv: -kv[1]["ms"])[:6]
+            b["members"] = [{"shape": k, "launches_per_step": v["calls"] / ps, "avg_launch_us": v["ms"] / v["calls"] * 1e3,
+                             "tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "frac": v["flops"] / max(v["ms"], 1e-9) / 1e9 / peak}
+                            for k, v in mem]
+        # the dominant kernel family (largest share of the step's kernel time) is the roofline headline; the next two follow
+        roof = blocks[0] if blocks else {"bound": "mfma", "achieved": 0.0, "peak": peak, "unit": "TFLOP/s", "frac": 0.0, "traffic": None}
+        roof["kernel_ms_per_step_eager_events"] = tot / ps
+        roof["evidence_tag"] = tag
         if args.dump_kernels:
             with open(args.dump_kernels, "w") as f:
                 f.write(f"{'entry point':18s} {'shape':44s} {'calls/step':>10s} {'us/launch':>10s} {'ms/step':>8s} "
@@ -471,11 +521,6 @@ def main():
                     f.write(f"{n:18s} {k:44s} {v['calls'] / args.profile_steps:10.1f} {us:10.1f} "
                             f"{v['ms'] / args.profile_steps:8.3f} {v['flops'] / v['calls'] / us / 1e6:8.2f} "
                             f"{v['bytes'] / v['calls'] / us / 1e3:8.1f}\n")
-        fams = {}
-        for (n, _k), v in summ.items():
-            f = fams.setdefault(n, dict(ms=0.0, calls=0))
-            f["ms"] += v["ms"] / args.profile_steps
-            f["calls"] += v["calls"] / args.profile_steps
         result = {
             "metric": "decoder fwd+bwd scenes/sec at (N_seg=1024,N_q=100,d=256,L=4)" if args.config == "c2"
             else f"decoder fwd+bwd scenes/sec ({args.config})",
@@ -494,7 +539,8 @@ def main():
             "step_roofline_frac": flops * world / (dt / args.steps) / (peak * 1e12 * world),
             **({"grads_identical_across_ranks": grads_identical} if world > 1 else {}),
             "roofline": roof,
-            "kernel_families_ms_per_step": {k: round(v["ms"], 4) for k, v in sorted(fams.items())},
+            "roofline_next": blocks[1:],
+            "kernel_families_ms_per_step": {k: round(v["ms"] / ps, 4) for k, v in sorted(fams.items())},
         }
         if world == 1 and not args.headline_only:
             # the same step launched eagerly (no HIP graph): what a trainer that cannot capture graphs would see

@@ -71,6 +71,22 @@ int pq3d_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, const pq3d_drop
 int pq3d_dropout_apply(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
                        const pq3d_dropout* dr, void* stream);
 
+typedef struct {
+  int32_t M;               /* branches, 1..4; 0 = no LayerNorm prologue */
+  int32_t sum_branches;    /* the M inputs are partial sums of ONE branch */
+  int32_t rows_per_scene;  /* rows per scene (coef indexing) */
+  float eps;
+  const float* x;          /* residual input [R, d] fp32 or NULL */
+  const float* o[4];       /* branches [R, d] fp32 */
+  const float* gamma[4];
+  const float* beta[4];
+  const float* coef;       /* [M, R / rows_per_scene] branch weights or NULL */
+  float* y;                /* [R, d] fp32 out */
+  float* mean;             /* [M, R] out (sum_branches: [1, R]) */
+  float* rstd;
+  float* osum;             /* [R, d] sum of the partial sums (sum_branches) or NULL */
+} pq3d_ln_prologue;
+
 /* ------------------------------------------------------------------------------------------------
  * Grouped / batched GEMM with fused prologue + epilogue (nn.Linear forward and both backward GEMMs,
  * MaskPredictionLayer einsum).  Replaces: F.linear calls inside nn.MultiheadAttention
@@ -126,6 +142,15 @@ typedef struct {
   /* dropout applied to the activated output (site = C viewed as [batch*M, N], site id drop.site + group):
    * FFNLayer's self.dropout(self.activation(self.linear1(x))), query_encoder.py:385.  Not with split-K. */
   pq3d_dropout drop;
+  /* LayerNorm prologue (ln.M > 0): the A operand of EVERY group is y = sum_m w_m LN_m(x + o_m) -- pq3d_add_ln_fwd's
+   * arithmetic (w_m = coef[m, scene] or 1/M; sum_branches: ONE LayerNorm of x + sum_m o_m with gamma/beta 0, osum
+   * receives the sum) over rows of K = d columns -- and A[g] must all point at ln.y.  The small-M whole-K kernels
+   * (csrc/gemm_wk.hip) form y in their prologue from x / o (every workgroup holds complete rows: K = d <= 256) and the
+   * workgroups of the first column tile of group 0 also write y, mean, rstd (and osum) for the backward pass -- the
+   * separate add+LayerNorm launch between two projections disappears (query_encoder.py:303-307 -> :213-227,
+   * :384-388 -> next layer's :288-290); launches those kernels do not take run pq3d_add_ln_fwd first, then the product.
+   * No dropout inside the prologue (train-mode residual dropout keeps the separate launch). */
+  pq3d_ln_prologue ln;
 } pq3d_gemm_desc;
 
 int pq3d_gemm(const pq3d_gemm_desc* d, void* stream);
@@ -157,7 +182,7 @@ int pq3d_gemm_set_wk(int options, int max_m);
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
   int32_t B, H, Lq, Lk, dh;
-  int32_t ct;   /* compute type */
+  int32_t ct;   /* compute type: PQ3D_F32 / PQ3D_BF16 (= storage dtype), or PQ3D_BF16X3 with fp32 storage */
   int32_t dt;   /* storage dtype of q,k,v,o,do,dq,dk,dv */
   int32_t zero_attn;
   int32_t mask_bmod; /* > 0: `mask` / `row_open` are shared by groups of scenes (memories stacked along B) */
@@ -203,7 +228,11 @@ int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
  *          one workgroup per (scene, head));
  *   bit 2: the all-keys-resident forward (cross-attention shape: bf16, d_h 32, Lq <= 128, Lk >= 128, key-padding mask
  *          only, at most 1024 keys per key split: ksplit >= ceil(Lk / 1024)).
- * This process-wide switch sets which of them may be used (default 7 = all; for A/B measurements and tests) and returns
+ *   bit 3: the split-bf16 MFMA self-attention kernels (csrc/attn_sa.hip) for compute type PQ3D_BF16X3 -- fp32 storage,
+ *          fp32-grade arithmetic (hi/lo bf16 operand pairs, 3 MFMAs per product): d_h 32, Lq, Lk <= 240, key padding /
+ *          additive bias only, one workgroup per (scene, head), no atomics.  PQ3D_BF16X3 calls of any other shape run the
+ *          exact-fp32 kernels.
+ * This process-wide switch sets which of them may be used (default 15 = all; for A/B measurements and tests) and returns
  * the previous value. */
 int pq3d_attn_resident(int enable);
 
@@ -228,6 +257,15 @@ int pq3d_copy_many(const float* const* src, float* const* dst, const int64_t* co
 int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_t count, void* stream);
 #define PQ3D_MEAN_MAX_BLOCKS 256   /* ws: fp32[1 + PQ3D_MEAN_MAX_BLOCKS], element 0 (the arrival counter) zero before first use */
 int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, void* stream);
+/* out[0] = sum_g mean(f_g(x_g)) over n <= PQ3D_MAX_GROUPS fp32 tensors of counts[g] elements in ONE deterministic launch
+ * (modes[g]: 0 identity, 1 clamp(min = clamp_min[g]), 2 non-finite elements count as 0), and its gradient
+ * dx_g[i] = gout[0] / counts[g] * f_g'(x_g[i]) in one more -- the synthetic loss of the mask configurations (SURVEY 8d:
+ * sum over prediction layers of mean(clamp(mask_logits, -50)) + mean(class logits, filtered -inf columns dropped)).
+ * ws: fp32[1 + 32 * PQ3D_MAX_GROUPS], element 0 (arrival counter) zero before first use. */
+int pq3d_mean_many(const float* const* x, const int64_t* counts, const int32_t* modes, const float* clamp_min, int32_t n,
+                   float* out, float* ws, void* stream);
+int pq3d_mean_many_bwd(const float* const* x, float* const* dx, const int64_t* counts, const int32_t* modes,
+                       const float* clamp_min, int32_t n, const float* gout, void* stream);
 int pq3d_fill_scaled(float* dst, int64_t n, const float* scalar, float c, void* stream);
 int pq3d_cast_transpose(const float* const* src, void* const* out, void* const* outT, int32_t groups, int32_t rows,
                         int32_t cols, void* stream);

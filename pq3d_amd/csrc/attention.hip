@@ -26,14 +26,16 @@ extern "C" int pq3d_attn_debug_read(long long* out) { return (int)hipMemcpyFromS
 bool pq3d_attn_bwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // attn_resident.hip
 bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // attn_resident.hip
 bool pq3d_attn_small_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);   // attn_small.hip
-static int g_resident = 1, g_small = 1, g_resfwd = 1;
-// bit 0: all-queries-resident backward, bit 1: small-sequence fp32 kernels, bit 2: all-keys-resident forward (all on by
-// default)
+bool pq3d_attn_sa_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);      // attn_sa.hip
+static int g_resident = 1, g_small = 1, g_resfwd = 1, g_sa = 1;
+// bit 0: all-queries-resident backward, bit 1: small-sequence fp32 kernels, bit 2: all-keys-resident forward, bit 3: the
+// split-bf16 MFMA self-attention kernels for compute type PQ3D_BF16X3 (all on by default)
 extern "C" int pq3d_attn_resident(int enable) {
-  const int old = g_resident | (g_small << 1) | (g_resfwd << 2);
+  const int old = g_resident | (g_small << 1) | (g_resfwd << 2) | (g_sa << 3);
   g_resident = enable & 1;
   g_small = (enable >> 1) & 1;
   g_resfwd = (enable >> 2) & 1;
+  g_sa = (enable >> 3) & 1;
   return old;
 }
 
@@ -825,10 +827,15 @@ template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream
 extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
   PQ_DEVICE_GUARD(stream, dp ? dp->q : nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_attn_fwd: null descriptor");
-  const pq3d_attn_desc d = *dp;
+  pq3d_attn_desc d = *dp;
+  // PQ3D_BF16X3: fp32 storage, fp32-GRADE arithmetic -- the split-bf16 MFMA kernels where the call has their shape
+  // (attn_sa.hip: the decoder's self-attention), the exact-fp32 kernels everywhere else
+  const bool x3 = d.ct == PQ3D_BF16X3;
+  if (x3) d.ct = PQ3D_F32;
   if (int e = check_desc(d)) return e;
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (x3 && g_sa && pq3d_attn_sa_try(d, s, false)) { PQ_LAUNCH_CHECK(); return 0; }
   if (g_small && pq3d_attn_small_try(d, s, false)) { PQ_LAUNCH_CHECK(); return 0; }
   DISPATCH(launch_fwd)
 }
@@ -836,12 +843,15 @@ extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
 extern "C" int pq3d_attn_bwd(const pq3d_attn_desc* dp, void* stream) {
   PQ_DEVICE_GUARD(stream, dp ? dp->q : nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_attn_bwd: null descriptor");
-  const pq3d_attn_desc d = *dp;
+  pq3d_attn_desc d = *dp;
+  const bool x3 = d.ct == PQ3D_BF16X3;
+  if (x3) d.ct = PQ3D_F32;
   if (int e = check_desc(d)) return e;
   PQ_CHECK_ARG(d.dout && d.dq && d.dk && d.dv && d.delta, "pq3d_attn_bwd: null dout/dq/dk/dv/delta");
   PQ_CHECK_ARG((((uintptr_t)d.dout) & 15) == 0, "pq3d_attn_bwd: dout must be 16-byte aligned");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (x3 && g_sa && pq3d_attn_sa_try(d, s, true)) { PQ_LAUNCH_CHECK(); return 0; }
   if (g_small && pq3d_attn_small_try(d, s, true)) { PQ_LAUNCH_CHECK(); return 0; }
   DISPATCH(launch_bwd)
 }

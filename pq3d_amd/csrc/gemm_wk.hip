@@ -39,6 +39,7 @@ template <int TM, int KC> struct WkShape {
 template <bool X3, bool TRB, int TM, int KC> constexpr size_t wk_lds_bytes() {
   return (size_t)(X3 ? 2 : 1) * ((size_t)TM * (KC + 8) + (TRB ? (size_t)KC * LDKN : (size_t)TN * (KC + 8))) * sizeof(bf16_t);
 }
+constexpr size_t WK_LN_LDS = 4 * 2 * 256 * sizeof(float);   // LayerNorm prologue: gamma / beta of up to 4 branches, behind the tiles
 
 PQ_DEV void split_hi_lo(const float* v, u32x4& hi, u32x4& lo) {
   hi = pack_frag<bf16_t>(v);
@@ -51,10 +52,26 @@ PQ_DEV void split_hi_lo(const float* v, u32x4& hi, u32x4& lo) {
   lo = pack_frag<bf16_t>(w);
 }
 
-template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int TM, int KC>
+// sum over the 32 lanes of a half wave (the threads that share one operand row at KC = 256; at KC = 128 a row is 16 lanes:
+// `half` = false stops after the 16-lane steps)
+template <bool HALF> PQ_DEV float row_sum(float v) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v += dpp_xor_f(v, k);
+  if constexpr (HALF) {
+    u32pair_s a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  }
+  return v;
+}
+
+// LNM: LayerNorm prologue (pq3d_gemm_desc.ln) with up to LNM branches (0 = none): the A tile is y = sum_m w_m LN_m(x + o_m),
+// formed in registers from x / o for ALL of K (<= 256: one or two chunks) before the first chunk is staged.
+template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int TM, int KC, int LNM = 0>
 __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
   typedef WkShape<TM, KC> S;
   constexpr int LDR = S::LDR, CPR = S::CPR;
+  constexpr int NCK = LNM ? 256 / KC : 1;   // chunks that hold a whole LayerNorm row
+  static_assert(!LNM || (sizeof(TA) == 4 && !TRB), "LayerNorm prologue: fp32 rows, row-major B");
   static_assert(!X3 || (!TRB && sizeof(TA) == 4 && sizeof(TB) == 4), "split-bf16: row-major fp32 operands");
   static_assert(!HA2 || sizeof(TA) == 4, "addend needs an fp32 primary");
   extern __shared__ __attribute__((aligned(16))) unsigned char wk_smem[];
@@ -96,6 +113,8 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
 #pragma unroll
   for (int j = 0; j < S::NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  float yv[LNM ? S::NA : 1][NCK][8];   // LayerNorm prologue: the normalised A rows of this thread, all chunks
+  int ck_put = 0;                      // chunk of the LayerNorm row the next put() stages
   // ---- one register set: the loads of chunk t+1 are issued right after chunk t has been written to LDS
   Raw<TA, 8> ra[S::NA];
   Raw<float, 8> ra2[HA2 ? S::NA : 1];
@@ -114,8 +133,8 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
       const int c = tid + i * WT, row = c / CPR, k = k0 + (c % CPR) * 8;
       oka[i] = k < d.K;
       const long off = (long)min(m0 + row, d.M - 1) * d.lda + (oka[i] ? k : 0);
-      ra[i].load(Ab + off);
-      if constexpr (HA2) ra2[i].load(pA2 ? (const float*)pA2 + off : (const float*)pA + off);
+      if constexpr (!LNM) ra[i].load(Ab + off);
+      if constexpr (HA2) ra2[i].load(pA2 ? (const float*)pA2 + off : (LNM ? d.ln.o[0] + off : (const float*)pA + off));   // no addend: finite filler, scaled by 0
     }
 #pragma unroll
     for (int i = 0; i < S::NB; ++i) {
@@ -147,7 +166,10 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
         *(u32x4*)&Ah[o] = p;
       } else {
         float v[8];
-        ra[i].to_float(v);
+        if constexpr (LNM) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = yv[i][NCK == 1 ? 0 : ck_put][j];
+        } else ra[i].to_float(v);
         if constexpr (HA2) {
           float w[8];
           ra2[i].to_float(w);
@@ -195,7 +217,130 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
     }
   };
 
-  issue();
+  issue();             // B (and A2) of the first chunk go out first; the LayerNorm inputs follow them
+  if constexpr (LNM) {
+    const pq3d_ln_prologue& q = d.ln;
+    const int dd = d.K;                       // LayerNorm width = K (checked on the host)
+    const int nb = q.sum_branches ? 1 : q.M;  // LayerNorms per row
+    const long R = d.M;
+    const bool writer = blockIdx.y == 0 && blockIdx.z == 0;
+    const long nscene = q.coef ? R / q.rows_per_scene : 1;
+    // gamma / beta of every branch go through LDS (one cooperative load now, no dependent global round trip per branch
+    // later); the branch weights of this thread's rows are fetched with the row loads
+    float* const gsm = (float*)(wk_smem + wk_lds_bytes<X3, TRB, TM, KC>());
+    {
+      const int per = dd / 4, tot = nb * 2 * per;     // float4 pieces: [branch][gamma | beta][d / 4]
+      if (tid < tot) {
+        const int m = tid / (2 * per), r_ = tid % (2 * per), isb = r_ / per, c4 = r_ % per;
+        *(float4*)&gsm[(m * 2 + isb) * 256 + c4 * 4] = *(const float4*)((isb ? q.beta[m] : q.gamma[m]) + c4 * 4);
+      }
+    }
+    float wrow[LNM][S::NA];
+#pragma unroll
+    for (int m = 0; m < LNM; ++m)
+#pragma unroll
+      for (int i = 0; i < S::NA; ++i) {
+        const int grow_ = min(m0 + (tid + i * WT) / CPR, d.M - 1);
+        wrow[m][i] = q.sum_branches ? 1.f : (q.coef ? (m < q.M ? q.coef[m * nscene + grow_ / q.rows_per_scene] : 0.f) : 1.f / (float)q.M);
+      }
+    Raw<float, 8> rx[S::NA][NCK], ro[LNM][S::NA][NCK];
+#pragma unroll
+    for (int i = 0; i < S::NA; ++i)
+#pragma unroll
+      for (int ck = 0; ck < NCK; ++ck) {
+        const int c = tid + i * WT, row = c / CPR, k = ck * KC + (c % CPR) * 8;
+        const long off = (long)min(m0 + row, d.M - 1) * dd + (k < dd ? k : 0);
+        if (q.x) rx[i][ck].load(q.x + off);
+#pragma unroll
+        for (int m = 0; m < LNM; ++m)
+          if (m < q.M) ro[m][i][ck].load(q.o[m] + off);
+      }
+    __syncthreads();   // gamma / beta staged
+#pragma unroll
+    for (int i = 0; i < S::NA; ++i) {
+      const int c = tid + i * WT, row = c / CPR, grow = min(m0 + row, d.M - 1);
+      float xr[NCK][8], acc_y[NCK][8];
+#pragma unroll
+      for (int ck = 0; ck < NCK; ++ck) {
+        if (q.x) rx[i][ck].to_float(xr[ck]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { if (!q.x) xr[ck][j] = 0.f; acc_y[ck][j] = 0.f; }
+      }
+#pragma unroll
+      for (int m = 0; m < LNM; ++m) {
+        if (m < nb) {   // uniform
+          float v[NCK][8];
+#pragma unroll
+          for (int ck = 0; ck < NCK; ++ck) {
+            ro[m][i][ck].to_float(v[ck]);
+            if (q.sum_branches) {   // partial sums of one branch: add them in index order (as pq3d_add_ln_fwd)
+#pragma unroll
+              for (int p = 1; p < LNM; ++p)
+                if (p < q.M) {
+                  float t[8];
+                  ro[p][i][ck].to_float(t);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[ck][j] += t[j];
+                }
+              if (q.osum && writer && m0 + row < d.M) {
+                const int k = ck * KC + (c % CPR) * 8;
+                if (k < dd) {
+                  float* po = q.osum + (long)grow * dd + k;
+                  *(float4*)po = make_float4(v[ck][0], v[ck][1], v[ck][2], v[ck][3]);
+                  *(float4*)(po + 4) = make_float4(v[ck][4], v[ck][5], v[ck][6], v[ck][7]);
+                }
+              }
+            }
+          }
+          float s1 = 0.f;
+#pragma unroll
+          for (int ck = 0; ck < NCK; ++ck) {
+            const bool okk = ck * KC + (c % CPR) * 8 < dd;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[ck][j] = okk ? xr[ck][j] + v[ck][j] : 0.f; s1 += v[ck][j]; }
+          }
+          const float mean = row_sum<KC == 256>(s1) / (float)dd;
+          float s2_ = 0.f;
+#pragma unroll
+          for (int ck = 0; ck < NCK; ++ck) {
+            const bool okk = ck * KC + (c % CPR) * 8 < dd;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = v[ck][j] - mean; s2_ += okk ? t * t : 0.f; }
+          }
+          const float rstd = 1.f / sqrtf(row_sum<KC == 256>(s2_) / (float)dd + q.eps);
+          const float w = wrow[m][i];
+#pragma unroll
+          for (int ck = 0; ck < NCK; ++ck) {
+            const int k = ck * KC + (c % CPR) * 8;
+            if (k < dd) {
+              const float* gp_ = &gsm[(m * 2) * 256 + k];
+              const float4 g0 = *(const float4*)gp_, g1 = *(const float4*)(gp_ + 4);
+              const float4 b0 = *(const float4*)(gp_ + 256), b1 = *(const float4*)(gp_ + 260);
+              const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+              const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc_y[ck][j] += w * ((v[ck][j] - mean) * rstd * gm[j] + bt[j]);
+            }
+          }
+          if (writer && (c % CPR) == 0 && m0 + row < d.M) {
+            q.mean[(long)m * R + grow] = mean;
+            q.rstd[(long)m * R + grow] = rstd;
+          }
+        }
+      }
+#pragma unroll
+      for (int ck = 0; ck < NCK; ++ck) {
+        const int k = ck * KC + (c % CPR) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) yv[i][ck][j] = acc_y[ck][j];
+        if (writer && k < dd && m0 + row < d.M) {
+          float* py = q.y + (long)grow * dd + k;
+          *(float4*)py = make_float4(acc_y[ck][0], acc_y[ck][1], acc_y[ck][2], acc_y[ck][3]);
+          *(float4*)(py + 4) = make_float4(acc_y[ck][4], acc_y[ck][5], acc_y[ck][6], acc_y[ck][7]);
+        }
+      }
+    }
+  }
   // the bias row in accumulator layout, requested right behind the first operand loads (no dependent round trip later)
   const bool bias_early = gp.bias != nullptr && d.dtBias == PQ3D_F32 && d.alpha == 1.f && d.splitk <= 1;
   float bcol[S::NJ];
@@ -206,6 +351,7 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
   for (int it = 0; it < nit; ++it) {
     if (it > 0) __syncthreads();   // the previous chunk's fragment reads are done
     put();
+    if constexpr (LNM) ck_put = (ck_put + 1) % NCK;
     __syncthreads();
     const int kspan = min(KC, d.K - kc_cur * KC);
     if (++kc_cur == c1) kc_cur = c0;
@@ -273,10 +419,10 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 std::atomic<int> g_wk_enable{-1};   // -1: read PQ3D_WK from the environment on first use; else the option word (bit 0 = on)
 int g_wk_max_m = 2048;
 
-template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int TM, int KC>
+template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int TM, int KC, int LNM = 0>
 int wk_launch(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
-  auto kern = gemm_wk_kernel<X3, TA, TB, TRB, HA2, TM, KC>;
-  constexpr size_t lds = wk_lds_bytes<X3, TRB, TM, KC>();
+  auto kern = gemm_wk_kernel<X3, TA, TB, TRB, HA2, TM, KC, LNM>;
+  constexpr size_t lds = wk_lds_bytes<X3, TRB, TM, KC>() + (LNM ? WK_LN_LDS : 0);
   static std::atomic<unsigned> attr_done{0};   // per (kernel instantiation, device)
   if (int e = pq3d_enable_big_lds(kern, (int)lds, attr_done)) return e;
   const int kc = d.kconcat > 0 ? d.kconcat : 1;
@@ -293,7 +439,7 @@ struct WkPlan { int tm, kc; };
 size_t wk_lds(bool x3, bool trb, int tm, int kc) {
   return (size_t)(x3 ? 2 : 1) * ((size_t)tm * (kc + 8) + (trb ? (size_t)kc * LDKN : (size_t)TN * (kc + 8))) * 2;
 }
-bool wk_plan(const pq3d_gemm_desc& d, bool x3, int opt, WkPlan* out) {
+bool wk_plan(const pq3d_gemm_desc& d, bool x3, int opt, WkPlan* out, bool tm32_only = false) {
   const int force_tm = (opt >> 4) & 3, force_kc = (opt >> 6) & 3;
   const bool multi_round = (opt >> 8) & 1;
   const int kcn = d.kconcat > 0 ? d.kconcat : 1, sk = d.splitk > 1 ? d.splitk : 1;
@@ -302,9 +448,10 @@ bool wk_plan(const pq3d_gemm_desc& d, bool x3, int opt, WkPlan* out) {
   for (int tm = 32; tm <= 64; tm *= 2)
     for (int kc = 256; kc >= 128; kc /= 2) {
       if (force_tm && tm != (force_tm == 1 ? 32 : 64)) continue;
+      if (tm32_only && tm != 32) continue;
       if (force_kc && kc != (force_kc == 1 ? 128 : 256)) continue;
       const long wgs = (long)((d.M + tm - 1) / tm) * ((d.N + TN - 1) / TN) * (d.groups / kcn) * sk;
-      const size_t lds = wk_lds(x3, d.transB != 0, tm, kc);
+      const size_t lds = wk_lds(x3, d.transB != 0, tm, kc) + (d.ln.M > 0 ? WK_LN_LDS : 0);
       const long per_cu = lds > 80 * 1024 ? 1 : 2;
       const long rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
       if (rounds > 1 && !multi_round) continue;
@@ -316,14 +463,17 @@ bool wk_plan(const pq3d_gemm_desc& d, bool x3, int opt, WkPlan* out) {
   return found;
 }
 
-template <bool X3, typename TA, typename TB, bool TRB, bool HA2>
+template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int LNM = 0>
 int wk_launch_plan(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, WkPlan p) {
   if (p.tm == 32) {
-    if (p.kc == 256) return wk_launch<X3, TA, TB, TRB, HA2, 32, 256>(d, kd, s);
-    return wk_launch<X3, TA, TB, TRB, HA2, 32, 128>(d, kd, s);
+    if (p.kc == 256) return wk_launch<X3, TA, TB, TRB, HA2, 32, 256, LNM>(d, kd, s);
+    return wk_launch<X3, TA, TB, TRB, HA2, 32, 128, LNM>(d, kd, s);
   }
-  if (p.kc == 256) return wk_launch<X3, TA, TB, TRB, HA2, 64, 256>(d, kd, s);
-  return wk_launch<X3, TA, TB, TRB, HA2, 64, 128>(d, kd, s);
+  if constexpr (LNM <= 1) {   // several LayerNorm branches per row: 32-row tiles only (register budget of the prologue)
+    if (p.kc == 256) return wk_launch<X3, TA, TB, TRB, HA2, 64, 256, LNM>(d, kd, s);
+    return wk_launch<X3, TA, TB, TRB, HA2, 64, 128, LNM>(d, kd, s);
+  }
+  return (int)hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -361,10 +511,23 @@ bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t
     if (d.A2[g]) { a2 = true; if (!aligned16(d.A2[g]) || d.dtA2 != PQ3D_F32 || d.dtA != PQ3D_F32) return false; }
   }
   if (a2 && d.transB) return false;
+  const pq3d_ln_prologue& q = d.ln;
+  const bool ln = q.M > 0;
+  if (ln) {   // LayerNorm prologue: split-bf16 forward projections whose rows are whole LayerNorm rows
+    if (!x3 || d.kconcat > 1 || d.K > 256 || d.lda != d.K || q.M > 4 || !q.y || !q.mean || !q.rstd) return false;
+    if ((q.x && !aligned16(q.x)) || !aligned16(q.y) || (q.osum && !aligned16(q.osum))) return false;
+    const int nb = q.sum_branches ? 1 : q.M;
+    for (int m = 0; m < q.M; ++m) if (!q.o[m] || !aligned16(q.o[m])) return false;
+    for (int m = 0; m < nb; ++m) if (!q.gamma[m] || !q.beta[m] || !aligned16(q.gamma[m]) || !aligned16(q.beta[m])) return false;
+    for (int g = 0; g < d.groups; ++g) if (d.A[g] != (const void*)q.y) return false;
+  }
   WkPlan p;
-  if (!wk_plan(d, x3, en, &p)) return false;   // more than one round of workgroups: the 4-wave pipeline kernel is better there
+  if (!wk_plan(d, x3, en, &p, ln && q.M > 1)) return false;   // more than one round of workgroups: the 4-wave pipeline kernel is better there
   int e;
-  if (x3) {
+  if (ln) {
+    if (q.M > 1) e = a2 ? wk_launch_plan<true, float, float, false, true, 4>(d, kd, s, p) : wk_launch_plan<true, float, float, false, false, 4>(d, kd, s, p);
+    else e = a2 ? wk_launch_plan<true, float, float, false, true, 1>(d, kd, s, p) : wk_launch_plan<true, float, float, false, false, 1>(d, kd, s, p);
+  } else if (x3) {
     e = a2 ? wk_launch_plan<true, float, float, false, true>(d, kd, s, p) : wk_launch_plan<true, float, float, false, false>(d, kd, s, p);
   } else if (!d.transB) {
     if (d.dtA == PQ3D_F32) e = a2 ? wk_launch_plan<false, float, float, false, true>(d, kd, s, p) : wk_launch_plan<false, float, float, false, false>(d, kd, s, p);

@@ -431,6 +431,76 @@ __global__ void fill_scaled_kernel(float* dst, long n, const float* scalar, floa
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = v;
 }
 
+
+// ---- sum over up to 32 tensors of mean(f_g(x_g)) in ONE launch, and its gradient in one more: the synthetic loss of the
+// mask configurations (sum over prediction layers of mean(clamp(mask_logits, -50)) + mean(class logits with
+// the filtered -inf columns dropped)) cost ~14 framework launches per prediction layer (isfinite / where / clamp / mean /
+// add forward, fills and masks backward).  f: 0 identity, 1 max(x, c) (clamp(min=c)), 2 x if finite else 0.
+// grid = (MEAN_MANY_BLOCKS, tensors); deterministic: fixed per-block slices, partials combined by the last arriver in
+// (tensor, block) order.  ws[0] = ticket (zero before first use; reset by the last block), ws[1..] partials.
+#define MEAN_MANY_BLOCKS 32
+struct MeanMany { int n; const float* x[PQ3D_MAX_GROUPS]; float* dx[PQ3D_MAX_GROUPS]; long count[PQ3D_MAX_GROUPS]; int mode[PQ3D_MAX_GROUPS]; float cmin[PQ3D_MAX_GROUPS]; };
+PQ_DEV float mean_many_f(float v, int mode, float c) { return mode == 1 ? fmaxf(v, c) : (mode == 2 ? (isfinite(v) ? v : 0.f) : v); }
+__global__ __launch_bounds__(256) void mean_many_kernel(const MeanMany m, float* out, float* ws) {
+  __shared__ float red[4];
+  __shared__ int last;
+  const int g = blockIdx.y;
+  const float* x = m.x[g];
+  const long n = m.count[g], n4 = n >> 2;
+  const int mode = m.mode[g];
+  const float c = m.cmin[g];
+  float s = 0.f;
+  if ((((uintptr_t)x) & 15) == 0) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      const float4 v = ((const float4*)x)[i];
+      s += (mean_many_f(v.x, mode, c) + mean_many_f(v.y, mode, c)) + (mean_many_f(v.z, mode, c) + mean_many_f(v.w, mode, c));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) s += mean_many_f(x[(n4 << 2) + threadIdx.x], mode, c);
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += mean_many_f(x[i], mode, c);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const unsigned total = gridDim.x * gridDim.y;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&ws[1 + g * MEAN_MANY_BLOCKS + blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add((unsigned*)ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (t == total - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // thread t < n tensors: its tensor's partials in block order, then the tensors in index order (wave 0, fixed tree)
+  float p = 0.f;
+  if ((int)threadIdx.x < m.n) {
+    for (int b = 0; b < (int)gridDim.x; ++b)
+      p += __hip_atomic_load(&ws[1 + threadIdx.x * MEAN_MANY_BLOCKS + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p /= (float)m.count[threadIdx.x];
+  }
+  if (threadIdx.x < 64) {
+    p = wave_sum(p);
+    if (threadIdx.x == 0) {
+      out[0] = p;
+      __hip_atomic_store((unsigned*)ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void mean_many_bwd_kernel(const MeanMany m, const float* gout) {
+  const int g = blockIdx.y;
+  const float* x = m.x[g];
+  float* dx = m.dx[g];
+  const long n = m.count[g];
+  const int mode = m.mode[g];
+  const float c = m.cmin[g], sc = gout[0] / (float)n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    dx[i] = mode == 1 ? (v >= c ? sc : 0.f) : (mode == 2 ? (isfinite(v) ? sc : 0.f) : sc);
+  }
+}
+
 struct CastTPtrs { const float* src[PQ3D_MAX_GROUPS]; bf16_t* out[PQ3D_MAX_GROUPS]; bf16_t* outT[PQ3D_MAX_GROUPS]; };
 // src_g [rows, cols] fp32 -> out_g [rows, cols] bf16 AND outT_g = per (cols x cols) row block transposed:
 // outT[t][k][n] = src[t * cols + n][k]  (rows = T * cols).  32 x 32 tiles through LDS: both writes are coalesced.
@@ -545,6 +615,38 @@ extern "C" int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, v
   if (nb > PQ3D_MEAN_MAX_BLOCKS) nb = PQ3D_MEAN_MAX_BLOCKS;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(mean_all_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (long)n, out, ws);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+
+static int mean_many_fill(MeanMany& m, const float* const* x, float* const* dx, const int64_t* counts, const int32_t* modes,
+                          const float* clamp_min, int32_t n) {
+  m.n = n;
+  for (int g = 0; g < n; ++g) {
+    if (!x[g] || counts[g] < 1 || modes[g] < 0 || modes[g] > 2 || (dx && !dx[g])) return 1;
+    m.x[g] = x[g]; m.dx[g] = dx ? dx[g] : nullptr; m.count[g] = (long)counts[g]; m.mode[g] = modes[g];
+    m.cmin[g] = clamp_min ? clamp_min[g] : 0.f;
+  }
+  return 0;
+}
+extern "C" int pq3d_mean_many(const float* const* x, const int64_t* counts, const int32_t* modes, const float* clamp_min,
+                              int32_t n, float* out, float* ws, void* stream) {
+  PQ_DEVICE_GUARD(stream, out);
+  PQ_CHECK_ARG(x && counts && modes && out && ws && n >= 1 && n <= PQ3D_MAX_GROUPS, "pq3d_mean_many: bad args");
+  MeanMany m;
+  PQ_CHECK_ARG(!mean_many_fill(m, x, nullptr, counts, modes, clamp_min, n), "pq3d_mean_many: null tensor / empty / bad mode");
+  hipLaunchKernelGGL(mean_many_kernel, dim3(MEAN_MANY_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, m, out, ws);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pq3d_mean_many_bwd(const float* const* x, float* const* dx, const int64_t* counts, const int32_t* modes,
+                                  const float* clamp_min, int32_t n, const float* gout, void* stream) {
+  PQ_DEVICE_GUARD(stream, gout);
+  PQ_CHECK_ARG(x && dx && counts && modes && gout && n >= 1 && n <= PQ3D_MAX_GROUPS, "pq3d_mean_many_bwd: bad args");
+  MeanMany m;
+  PQ_CHECK_ARG(!mean_many_fill(m, x, dx, counts, modes, clamp_min, n), "pq3d_mean_many_bwd: null tensor / empty / bad mode");
+  hipLaunchKernelGGL(mean_many_bwd_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, m, gout);
   PQ_LAUNCH_CHECK();
   return 0;
 }

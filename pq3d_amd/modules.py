@@ -252,7 +252,7 @@ class SelfAttentionLayer(_PostNormBase):
         q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=ct)
         k = ops.linear(tgt, w[d:2 * d], b[d:2 * d], x2=query_pos, ct=ct)
         v = ops.linear(tgt, w[2 * d:], b[2 * d:], ct=ct)
-        o = ops.attention(q, k, v, H=self.nhead, ct=F32, kpm=tgt_key_padding_mask, mask=attn_mask,
+        o = ops.attention(q, k, v, H=self.nhead, ct=ops.sa_ct(self.ct), kpm=tgt_key_padding_mask, mask=attn_mask,
                           drop=self._drop(ctx, ops.DROP_SA_ATTN, tgt.device))
         o = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, ct=ct)
         return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
@@ -281,7 +281,7 @@ class MultiHeadAttentionSpatial(_PostNormBase):
         kh = ops.linear(k, self.w_ks.weight, self.w_ks.bias, x2=k_pos, ct=ct)
         vh = ops.linear(v, self.w_vs.weight, self.w_vs.bias, ct=ct)
         bias = ops.spatial_bias(pairwise_locs, self.pairwise_loc_fc.weight, self.pairwise_loc_fc.bias)
-        o = ops.attention(qh, kh, vh, H=self.n_head, ct=F32, kpm=key_padding_mask, bias=bias)
+        o = ops.attention(qh, kh, vh, H=self.n_head, ct=ops.sa_ct(self.ct), kpm=key_padding_mask, bias=bias)
         return ops.linear(o, self.fc.weight, self.fc.bias, ct=ct)
 
 

@@ -37,6 +37,12 @@ def small_ct(ct: int) -> int:
     return BF16X3 if ct == BF16 else ct
 
 
+def sa_ct(ct: int) -> int:
+    """Compute type of the decoder's self-attention core (fp32 q / k / v in both modes): 'bf16' mode -> fp32-grade split-bf16
+    MFMA kernels (csrc/attn_sa.hip), 'fp32' mode -> exact fp32."""
+    return BF16X3 if ct == BF16 else F32
+
+
 def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else t.contiguous()
 
@@ -278,6 +284,46 @@ class _MeanAll(Function):
         gg = _c(g.float().reshape(1))
         L.check(L.lib().pq3d_fill_scaled(L.ptr(dx), n, L.ptr(gg), 1.0 / n, L.stream()), "pq3d_fill_scaled")
         return dx
+
+
+class _MeanMany(Function):
+    @staticmethod
+    def forward(ctx, modes, cmins, *xs):
+        xs = [_c(x.float()) for x in xs]
+        dev = xs[0].device
+        n = len(xs)
+        out = _empty(1, dtype=torch.float32, device=dev)
+        key = (dev, "many")
+        ws = _MEAN_WS.get(key)
+        if ws is None:
+            ws = _MEAN_WS[key] = torch.zeros(1 + 32 * L.MAXG, dtype=torch.float32, device=dev)
+        ctx.arr = ((C.c_int64 * n)(*[x.numel() for x in xs]), (C.c_int32 * n)(*modes), (C.c_float * n)(*cmins))
+        L.check(L.lib().pq3d_mean_many(_parr(xs), ctx.arr[0], ctx.arr[1], ctx.arr[2], n, L.ptr(out), L.ptr(ws), L.stream()),
+                "pq3d_mean_many")
+        ctx.save_for_backward(*xs)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        xs = ctx.saved_tensors
+        dxs = [torch.empty_like(x) for x in xs]
+        gg = _c(g.float().reshape(1))
+        L.check(L.lib().pq3d_mean_many_bwd(_parr(xs), _parr(dxs), ctx.arr[0], ctx.arr[1], ctx.arr[2], len(xs), L.ptr(gg),
+                                           L.stream()), "pq3d_mean_many_bwd")
+        return (None, None, *dxs)
+
+
+def mean_many(xs: Sequence[torch.Tensor], modes: Sequence[str], clamp_min: float = 0.0) -> torch.Tensor:
+    """sum_g mean(f_g(x_g)) as ONE launch forward and one backward; modes[g] in {'plain', 'clamp_min', 'finite'}
+    ('clamp_min': x.clamp(min=clamp_min).mean(); 'finite': torch.where(isfinite(x), x, 0).mean()) -- the synthetic loss over
+    the prediction layers without ~14 framework launches per layer."""
+    code = {"plain": 0, "clamp_min": 1, "finite": 2}
+    total = None
+    for s0 in range(0, len(xs), L.MAXG):
+        part = _MeanMany.apply([code[m] for m in modes[s0:s0 + L.MAXG]], [float(clamp_min)] * len(xs[s0:s0 + L.MAXG]),
+                               *xs[s0:s0 + L.MAXG])
+        total = part if total is None else total + part
+    return total
 
 
 def mean_all(x: torch.Tensor) -> torch.Tensor:

@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 for CFG in $CONFIGS; do
   for cnt in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$cnt
-    timeout 600 rocprofv3 --kernel-trace --pmc $cnt -d /tmp/pmc_$cnt -o p -- python $R/bench.py --config $CFG --no-graph --steps 3 --warmup 1 --cpu-steps 0 --profile-steps 1 --headline-only > /dev/null 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $cnt -d /tmp/pmc_$cnt -o p -- python $R/bench.py --config $CFG --no-graph --steps 3 --warmup 1 --cpu-steps 0 --profile-steps 1 --headline-only --pmc-calibration > /dev/null 2>&1
   done
   F=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
   python $R/tools/rocprof_pmc_summary.py $F $W > $OUT/rocprofv3_pmc_hbm_traffic_${TAG}_$CFG.txt
