@@ -25,6 +25,7 @@ extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol
 bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
 bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
 bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err);   // gemm_wk.hip
+bool pq3d_gemm_wktt_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err);   // gemm_wktt.hip
 
 namespace {
 
@@ -663,6 +664,11 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
     return 0;
   }
   if (pq3d_gemm_tt128_try(d, kd, s)) {   // big bf16 weight-gradient products: 128x128 tiles, own split factor
+    PQ_LAUNCH_CHECK();
+    return 0;
+  }
+  if (pq3d_gemm_wktt_try(d, kd, s, &wk_err)) {   // weight gradients over short reductions: 256-row chunks at once (gemm_wktt.hip)
+    if (wk_err) return wk_err;
     PQ_LAUNCH_CHECK();
     return 0;
   }

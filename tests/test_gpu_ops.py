@@ -760,3 +760,30 @@ def test_attention_self_mfma_split_bf16_kernels(Lq, Lk, mode, H):
             continue
         close(a, r, F32, name + " split-bf16 vs fp64", atol=5e-5, rtol=5e-5)
         close(a, a_old, F32, name + " split-bf16 vs exact fp32", atol=5e-5, rtol=5e-5)
+
+
+@pytest.mark.parametrize("R,M,N,G,adt,bdt,b2,cs", [(800, 256, 256, 12, "f32", "f32", True, True), (800, 256, 2048, 4, "f32", "f32", False, True),
+                                                   (800, 2048, 256, 4, "bf16", "f32", False, True), (800, 256, 256, 3, "bf16", "bf16", False, False),
+                                                   (8192, 256, 256, 3, "f32", "f32", False, True), (37, 72, 40, 2, "f32", "bf16", False, True),
+                                                   (8992, 256, 256, 1, "f32", "f32", False, True)])
+def test_gemm_weight_gradient_whole_k_chunks(R, M, N, G, adt, bdt, b2, cs):
+    """dW = g^T (x [+ x2]) (+ fused bias gradient) through the 256-row-chunk kernel (gemm_wktt.hip) against the 64x64-tile
+    pipeline kernel (PQ3D_WKTT=0 is read once per process, so the comparison is against torch in bf16-operand arithmetic
+    and against an exact fp32 product within the bf16 bound), accumulating onto existing contents."""
+    td = lambda n: torch.bfloat16 if n == "bf16" else torch.float32
+    g_ = [rnd(R, M, seed=g).to(DEV).to(td(adt)) for g in range(G)]
+    x_ = [rnd(R, N, seed=50 + g).to(DEV).to(td(bdt)) for g in range(G)]
+    x2 = [rnd(R, N, seed=90 + g).to(DEV) if g % 2 == 0 else None for g in range(G)] if b2 else None
+    base = rnd(G, M, N, seed=7).to(DEV)
+    C_ = base.clone()
+    csum = torch.zeros(G, M, device=DEV) if cs else None
+    L.gemm(M=M, N=N, K=R, A=g_, B=x_, B2=x2, Cs=[C_[g] for g in range(G)], ct=BF16, lda=M, ldb=N, ldc=N, transA=True, transB=True,
+           splitk=4, accumulate=True, colsum=[csum[g] for g in range(G)] if cs else None)
+    for g in range(G):
+        xs = x_[g].float() + (x2[g] if (x2 is not None and x2[g] is not None) else 0)
+        ref = base[g] + g_[g].bfloat16().float().T @ xs.bfloat16().float()
+        err = float((C_[g] - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err <= 2e-5 * (R ** 0.5), (g, err)          # fp32 accumulation order only (operands rounded identically)
+        if cs:
+            rs = g_[g].bfloat16().float().sum(0)
+            assert float((csum[g] - rs).abs().max()) <= 1e-4 * max(1.0, float(rs.abs().max())) * (R ** 0.5) / 10
