@@ -107,10 +107,11 @@ class GraphedQuery3D(nn.Module):
     device (round 2 used torch.cuda.make_graphed_callables here: one copy kernel per parameter per step, 3.5 ms at c2).
     Gradient accumulation (both modes): a backward that finds the parameters' ``.grad`` still aliasing the flat buffers
     (no ``zero_grad(set_to_none=True)`` since the last one) replays an ACCUMULATING variant of the backward graph
-    (captured on first use) that adds into the buffers -- torch semantics, the reference trains under
-    accelerator.accumulate (trainer/query3d_trainer.py:35)."""
+    (captured at construction with ``accumulation=True``) that adds into the buffers -- torch semantics, the reference
+    trains under accelerator.accumulate (trainer/query3d_trainer.py:35)."""
 
-    def __init__(self, model: nn.Module, sample: Dict[str, object], num_warmup_iters: int = 3, mode: str = "direct"):
+    def __init__(self, model: nn.Module, sample: Dict[str, object], num_warmup_iters: int = 3, mode: str = "direct",
+                 accumulation: bool = False):
         super().__init__()
         assert mode in ("direct", "autograd")
         assert num_warmup_iters >= 1, "GraphedQuery3D needs at least one eager warm-up iteration before capture"
@@ -161,14 +162,23 @@ class GraphedQuery3D(nn.Module):
         self.fwd_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.fwd_graph):
             outs = self._flat(*args)
-        self.static_out = list(outs)
         self.zero_gout = [torch.zeros_like(o) for o in outs]
         self._bwd = {False: torch.cuda.CUDAGraph(), True: None}
+        self.static_gin = None
         with torch.cuda.graph(self._bwd[False], pool=self.fwd_graph.pool()):
-            gin = self._run_bwd(outs, False, retain=True)
+            gin = self._run_bwd(outs, False, retain=accumulation)
         self.static_gin = [None] * len(args)
         for i, g in zip(self._gin_idx, gin):
             self.static_gin[i] = g
+        if accumulation:   # the accumulating variant of the backward, from the same (still alive) autograd graph
+            self._bwd[True] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._bwd[True], pool=self.fwd_graph.pool()):
+                self._run_bwd(outs, True, retain=False)
+        # Release the captured forward's autograd graph: its AccumulateGrad nodes were created on the capture stream, and as
+        # long as they live every eager backward of mode 'autograd' finds them (they are per-parameter singletons), sees a
+        # stream mismatch and synchronises once per parameter (3.3 ms instead of 1.6 ms per step at config 2)
+        self.static_out = [o.detach() for o in outs]
+        del outs, gin
         for p in params:
             p.grad = None
         self._grad_views = None
@@ -217,27 +227,12 @@ class GraphedQuery3D(nn.Module):
                                "zero all gradients (set_to_none=True) or none between micro-batches")
         return False
 
-    def enable_accumulation(self) -> None:
-        """Capture the accumulating variant of the backward graph (done automatically by forward() when it finds the
-        parameters' .grad still aliasing the flat buffers, i.e. on the second micro-batch of a step).  The autograd graph
-        of the captured forward is still alive (retain_graph), its saved tensors are the forward graph's static buffers ->
-        the same backward, adding into the flat buffers."""
-        if self._bwd[True] is not None:
-            return
-        saved = [p.grad for p in self._params]
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.fwd_graph.pool()):
-            self._run_bwd(self.static_out, True, retain=True)
-        for p, gr in zip(self._params, saved):
-            p.grad = gr
-        self._bwd[True] = g
-
     def _bwd_graph(self, accumulate: bool):
         if self._bwd[accumulate] is None:
-            raise RuntimeError("GraphedQuery3D: gradient accumulation needs the accumulating backward graph, which is "
-                               "captured by forward() when .grad is still set -- call gm.enable_accumulation() once "
-                               "before training if gradients are re-created between forward and backward")
+            raise RuntimeError("GraphedQuery3D: a backward found the parameters' .grad still set (gradient accumulation over "
+                               "micro-batches) but the wrapper was built without the accumulating backward graph: construct "
+                               "it with GraphedQuery3D(model, sample, accumulation=True), or zero the gradients "
+                               "(set_to_none=True) between backward passes")
         return self._bwd[accumulate]
 
     # -- plumbing ------------------------------------------------------------------------------------------------------
@@ -278,8 +273,6 @@ class GraphedQuery3D(nn.Module):
             if not same:
                 raise ValueError(f"GraphedQuery3D: data_dict[{k!r}] = {w!r} differs from the captured constant {v!r}; "
                                  "build one wrapper per value")
-        if self._bwd[True] is None and torch.is_grad_enabled() and self._params[0].grad is not None and self._accumulating():
-            self.enable_accumulation()      # second micro-batch of a step: here (caller's thread), not inside backward
         pars = tuple(self._params) if self.mode == "autograd" else ()
         flat = _Replay.apply(self, self._anchor, len(args), *args, *pars)
         out = dict(data_dict)

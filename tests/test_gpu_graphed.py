@@ -63,7 +63,7 @@ def test_graphed_gradient_accumulation_equals_sum_of_micro_batches(mode):
     accelerator.accumulate, trainer/query3d_trainer.py:35): the accumulating variant of the captured backward adds into the
     flat buffers.  Equals the sum of the two micro-batches' separately computed gradients to fp32 rounding."""
     args, model, dda, ddb = _case()
-    gm = GraphedQuery3D(model, dda, mode=mode)
+    gm = GraphedQuery3D(model, dda, mode=mode, accumulation=True)
     loss_of = lambda out: util.synthetic_loss(out, args["heads"], out["query_embeds"])
     singles = []
     for d_ in (dda, ddb):

@@ -37,8 +37,8 @@ def main():
     cal = None
     rows = [r for r in out.get("copy_many_kernel", []) if r["fetch_kib"] + r["write_kib"] > 60 * 1024]
     if rows:
-        r = max(rows, key=lambda r: r["write_kib"])
         true_kib = 100 * 1024
+        r = min(rows, key=lambda r: abs(r["write_kib"] - true_kib))     # WRITE_SIZE is exact: the row that wrote 100 MiB
         cal = {"kernel": "copy_many_kernel", "grid": r["grid"], "true_read_kib": true_kib, "true_write_kib": true_kib,
                "fetch_kib_raw": r["fetch_kib"], "write_kib_raw": r["write_kib"],
                "fetch_raw_over_true": round(r["fetch_kib"] / true_kib, 4), "write_raw_over_true": round(r["write_kib"] / true_kib, 4)}

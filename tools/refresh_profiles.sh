@@ -21,12 +21,14 @@ for CFG in $CONFIGS; do
   python $R/tools/rocprof_pmc_summary.py $F $W > $OUT/rocprofv3_pmc_hbm_traffic_${TAG}_$CFG.txt
   python $R/tools/pmc_traffic_json.py $F $W > $OUT/pmc_traffic_${TAG}_$CFG.json
   cp $OUT/pmc_traffic_${TAG}_$CFG.json $R/profiles/pmc_traffic_${TAG}_$CFG.json
-  STEPS=50; [ $CFG != c2 ] && STEPS=20
-  timeout 900 python $R/bench.py --config $CFG --steps $STEPS --warmup 10 --dump-kernels $OUT/kernel_table_${TAG}_fused_$CFG.txt > $OUT/bench_${TAG}_${CFG}_1gpu.json 2> $OUT/bench_$CFG.err
   rm -rf /tmp/ks
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks -o s -- python $R/bench.py --config $CFG --steps 20 --warmup 5 --cpu-steps 0 --profile-steps 1 --headline-only > $OUT/bench_under_rocprof_$CFG.json 2>/dev/null
   DB=$(find /tmp/ks -name "*.db" | head -1)
   python $R/tools/rocprof_summary.py $DB 30 > $OUT/rocprofv3_kernel_stats_${TAG}_fused_graph_$CFG.txt
   python $R/tools/rocprof_step_sequence.py $DB > $OUT/rocprofv3_step_sequence_${TAG}_$CFG.txt 2>&1
+  # the bench reads the in-graph kernel averages of THIS build from profiles/ (roofline.in_graph)
+  cp $OUT/rocprofv3_kernel_stats_${TAG}_fused_graph_$CFG.txt $R/profiles/
+  STEPS=50; [ $CFG != c2 ] && STEPS=20
+  timeout 900 python $R/bench.py --config $CFG --steps $STEPS --warmup 10 --dump-kernels $OUT/kernel_table_${TAG}_fused_$CFG.txt > $OUT/bench_${TAG}_${CFG}_1gpu.json 2> $OUT/bench_$CFG.err
 done
 echo done
