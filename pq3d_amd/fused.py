@@ -85,10 +85,6 @@ def _dw_acc(gs, xs, x2s, outs, ct, bias_outs=None):
         _colsum_acc(gs, bias_outs, R)
 
 
-DW_STREAMS = int(os.environ.get("PQ3D_DW_STREAMS", "1"))   # > 1: weight-gradient buckets of a flush on forked streams
-_DW_SIDE = {}
-
-
 class _DwQueue:
     """Deferred weight-gradient GEMMs.  Every dW = g^T (x [+ x2]) of the backward pass only feeds the gradient arena,
     so they are queued and flushed at the end as a few grouped launches per (shape, dtype) bucket instead of one
@@ -106,26 +102,11 @@ class _DwQueue:
             b[3].append(outs[i]); b[4].append(bias_outs[i] if bias_outs is not None else None)
 
     def flush(self):
-        items = list(self.buckets.items())
+        # (forking the buckets over 3 / 5 streams -- parallel branches of the captured graph -- was measured at config 2:
+        # 1.50 -> 1.80 / 2.17 ms; branch joins cost far more than the overlapped tails save)
+        for key, (g, x, x2, o, bo) in self.buckets.items():
+            _dw_acc(g, x, x2 if any(t is not None for t in x2) else None, o, self.ct, bo if key[5] else None)
         self.buckets = {}
-        ns = min(DW_STREAMS, len(items))
-        if ns <= 1 or not items[0][1][0][0].is_cuda:
-            for key, (g, x, x2, o, bo) in items:
-                _dw_acc(g, x, x2 if any(t is not None for t in x2) else None, o, self.ct, bo if key[5] else None)
-            return
-        # the buckets are independent accumulations into disjoint arena slices: fork them over a few streams (parallel
-        # branches of the captured graph) so that one bucket's tail of workgroups overlaps the next bucket's ramp-up
-        cur = torch.cuda.current_stream()
-        dev = items[0][1][0][0].device
-        pool = _DW_SIDE.setdefault(dev, [torch.cuda.Stream(device=dev) for _ in range(8)])
-        for s_ in pool[:ns - 1]:
-            s_.wait_stream(cur)
-        for i, (key, (g, x, x2, o, bo)) in enumerate(items):
-            st = cur if i % ns == 0 else pool[i % ns - 1]
-            with torch.cuda.stream(st):
-                _dw_acc(g, x, x2 if any(t is not None for t in x2) else None, o, self.ct, bo if key[5] else None)
-        for s_ in pool[:ns - 1]:
-            cur.wait_stream(s_)
 
 
 class FusedSpec:
