@@ -787,3 +787,24 @@ def test_gemm_weight_gradient_whole_k_chunks(R, M, N, G, adt, bdt, b2, cs):
         if cs:
             rs = g_[g].bfloat16().float().sum(0)
             assert float((csum[g] - rs).abs().max()) <= 1e-4 * max(1.0, float(rs.abs().max())) * (R ** 0.5) / 10
+
+
+def test_entry_points_launch_on_the_device_of_their_stream_not_the_current_one():
+    """the library takes the device from its inputs.  With the CURRENT device deliberately set elsewhere, a call
+    on a stream (or, with the NULL stream, on pointers) of another device must run there and leave the caller's current
+    device untouched.  Needs two visible GPUs (skips on the single-GPU test boxes)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs")
+    import ctypes as C_
+    d1 = torch.device("cuda", 1)
+    dst, sc = torch.zeros(1000, device=d1), torch.full((1,), 3.0, device=d1)
+    s1 = torch.cuda.Stream(device=d1)
+    torch.cuda.set_device(0)
+    L.check(L.lib().pq3d_fill_scaled(L.ptr(dst), 1000, L.ptr(sc), 2.0, C_.c_void_p(s1.cuda_stream)), "fill (stream of device 1)")
+    s1.synchronize()
+    assert torch.cuda.current_device() == 0 and float(dst.sum()) == 6000.0
+    dst.zero_()
+    torch.cuda.synchronize(d1)
+    L.check(L.lib().pq3d_fill_scaled(L.ptr(dst), 1000, L.ptr(sc), 1.0, C_.c_void_p(0)), "fill (NULL stream, pointer on device 1)")
+    torch.cuda.synchronize(d1)
+    assert torch.cuda.current_device() == 0 and float(dst.sum()) == 3000.0
