@@ -718,11 +718,15 @@ class _FusedDecoder(Function):
                                drop=rec["dr_fr"])
             dy = dy[0]
             dhp = torch.empty(B, Nq, F_, dtype=ad, device=dev)
-            # inner dropout (ReLU only on this path): the saved h is post-dropout, so [h > 0] already carries the
-            # keep-mask and only the 1/(1-p) factor is left -> alpha
+            # inner dropout.  ReLU: the saved h is post-dropout, so [h > 0] already carries the keep-mask and only the
+            # 1/(1-p) factor is left -> alpha.  GELU (round 3): the epilogue regenerates the forward's mask on the incoming
+            # gradient (same site, same [R, F] indices) before multiplying by gelu'(pre) -- epi_row's order: dropout, then
+            # the activation gradient
+            relu = spec.act != "gelu"
             L.gemm(M=R, N=F_, K=d, A=[dy], B=[ffn.linear2.weight.detach()], Cs=[dhp],
-                   aux=[rec["pre"] if spec.act == "gelu" else rec["h"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
-                   transB=True, alpha=1.0 / (1.0 - rec["dr_fi"].p) if rec["dr_fi"] is not None else 1.0)
+                   aux=[rec["h"] if relu else rec["pre"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
+                   transB=True, alpha=1.0 / (1.0 - rec["dr_fi"].p) if (rec["dr_fi"] is not None and relu) else 1.0,
+                   drop=rec["dr_fi"] if not relu else None)
             dwq.add([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
             dx2 = dx2r   # dx2 = dx2r + dhp W1: split-K accumulated in place onto the residual-branch gradient
             L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], ct=ct, lda=F_, ldb=d, ldc=d,
@@ -1046,8 +1050,6 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
         layers_ = list(enc.unified_encoder)
         ps = [m.dropout_p for l_ in layers_ for m in (list(l_.cross_attn_list) + [l_.self_attn, l_.ffn])]
         if any(p_ > 0.0 for p_ in ps):
-            if layer0.ffn.activation != "relu" and any(l_.ffn.dropout_p > 0.0 for l_ in layers_):
-                raise NotImplementedError("fused path: FFN dropout is implemented for ReLU")
             if any(len({c.dropout_p for c in l_.cross_attn_list}) > 1 for l_ in layers_):
                 raise NotImplementedError("fused path: one dropout probability per layer's cross-attention list")
             drop_base = enc._drop_base

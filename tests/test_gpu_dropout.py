@@ -216,12 +216,13 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "modular"])
-@pytest.mark.parametrize("name", ["F1_c1", "F2_c1_mask", "F4_c2_slice", "F5_dimloc6"])
+@pytest.mark.parametrize("name", ["F1_c1", "F2_c1_mask", "F4_c2_slice", "F5_dimloc6", "F4_c2_slice:gelu"])
 def test_fp32_train_mode_matches_oracle_with_same_masks(name, fused):
     """Whole model in train() mode (dropout 0.1 in the decoder layers, 0.1 / 0.3 in the heads, 0.1 on the encoder
     outputs) against the oracle fed the very same keep-masks: outputs and every parameter gradient."""
+    name, _, act = name.partition(":")
     _z, args = util.load_fixture(name)
-    args = dict(args, drop_test=())
+    args = dict(args, drop_test=(), **({"activation": act} if act else {}))   # ':gelu': north_star's GELU FFN in train mode
     _cfg, model, sd, dd = util.model_case(args)
     model.train()
     model.unified_encoder.fused = fused

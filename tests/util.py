@@ -64,7 +64,7 @@ def loss_weight(name, shape, seed=99):
 def model_case(args, device="cpu"):
     """Rebuild (cfg, our model, synthetic state dict, data_dict) of a `run_model_case` fixture."""
     kw = {k: args[k] for k in ("use_self_mask", "num_blocks", "dim_loc", "C", "foc", "drop_test", "offline_attn",
-                               "skip_pred") if k in args}
+                               "skip_pred", "activation") if k in args}
     kw.setdefault("C", 21)
     d = args["d"]
     d_in = args.get("d_in") or {m: d for m in args["memories"]}
