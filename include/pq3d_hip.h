@@ -255,6 +255,10 @@ int pq3d_zero_many(float* const* bufs, const int64_t* counts, int32_t n, void* s
  * trainer/build.py:66-75). */
 int pq3d_copy_many(const float* const* src, float* const* dst, const int64_t* counts, int32_t n, void* stream);
 int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_t count, void* stream);
+/* two such sums of different lengths in one launch (d query_pos and d pos at the end of the decoder backward, written
+ * into the two halves of one buffer: the coordinate encoder ran on their row concatenation) */
+int pq3d_sum_pair(const float* const* src_a, int32_t na, float* out_a, int64_t count_a, const float* const* src_b,
+                  int32_t nb, float* out_b, int64_t count_b, void* stream);
 #define PQ3D_MEAN_MAX_BLOCKS 256   /* ws: fp32[1 + PQ3D_MEAN_MAX_BLOCKS], element 0 (the arrival counter) zero before first use */
 int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, void* stream);
 /* out[0] = sum_g mean(f_g(x_g)) over n <= PQ3D_MAX_GROUPS fp32 tensors of counts[g] elements in ONE deterministic launch
@@ -315,6 +319,8 @@ typedef struct {
   pq3d_dropout drop;
   int32_t dx_zeroed;   /* backward, M > 1 summed branches: dx (accumulated with atomics by the M branch blocks) was
                           already zeroed by the caller -- one zero-fill for a whole backward pass instead of one per call */
+  const float* dy2;    /* backward, optional: the upstream gradient is (dy + dy2) + dy3 -- the producers' outputs are summed */
+  const float* dy3;    /* here instead of by one more launch (or a dependent "+ aux" chain) in front of this one */
 } pq3d_ln_desc;
 
 int pq3d_add_ln_fwd(const pq3d_ln_desc* d, void* stream);
@@ -365,6 +371,12 @@ int pq3d_pairwise_locs(const float* centers, int64_t center_stride, float* out, 
  * xyz [B,N,*] (row stride xyz_stride) , cmin/cmax [B,3], gauss_B [3,half] -> out [B,N,2*half] = [sin | cos]. */
 int pq3d_fourier(const float* xyz, int64_t xyz_stride, const float* cmin, const float* cmax, const float* gauss_B,
                  float* out, int32_t B, int32_t N, int32_t half, void* stream);
+/* the same for two point sets of the same B scenes (queries [B,Na,*], segments [B,Nb,*]; cmin / cmax / gauss_B shared) in
+ * one launch: out = [B*Na rows of set a | B*Nb rows of set b] x 2*half -- the row-concatenated input of the one
+ * Linear + LayerNorm pass both sets share (query3d_unified.py:117-128 calls the CoordinateEncoder once per set). */
+int pq3d_fourier_pair(const float* xyz_a, int64_t stride_a, int32_t Na, const float* xyz_b, int64_t stride_b, int32_t Nb,
+                      const float* cmin, const float* cmax, const float* gauss_B, float* out, int32_t B, int32_t half,
+                      void* stream);
 
 /* MultiHeadAttentionSpatial 'mul' fusion bias (transformers.py:196-200,226):
  * bias[b,h,i,j] = log(max(relu(W[h,:].pl[b,i,j,:] + bw[h]), 1e-6));  backward accumulates dW [H,5], dbw [H]

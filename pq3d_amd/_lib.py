@@ -144,6 +144,7 @@ class LnDesc(C.Structure):
         ("dbeta", C.c_void_p * MAXG), ("accumulate", C.c_int32), ("independent", C.c_int32),
         ("ys", C.c_void_p * MAXG), ("dys", C.c_void_p * MAXG),
         ("sum_branches", C.c_int32), ("osum", C.c_void_p), ("drop", Dropout), ("dx_zeroed", C.c_int32),
+        ("dy2", C.c_void_p), ("dy3", C.c_void_p),
     ]
 
 
@@ -160,6 +161,7 @@ _SIGS = {
     "pq3d_zero_many": [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
     "pq3d_copy_many": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],
     "pq3d_sum_n": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p],
+    "pq3d_sum_pair": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p],
     "pq3d_mean_all": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
     "pq3d_fill_scaled": [C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p],
     "pq3d_mean_many": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -182,6 +184,8 @@ _SIGS = {
     "pq3d_pairwise_locs": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p],
     "pq3d_fourier": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                      C.c_int32, C.c_void_p],
+    "pq3d_fourier_pair": [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                          C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p],
     "pq3d_spatial_bias_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                               C.c_void_p],
     "pq3d_spatial_bias_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -587,7 +587,7 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   PQ_CHECK_ARG(d.groups % kc == 0, "pq3d_gemm: groups must be a multiple of kconcat");
   for (int g = 0; g < d.groups; ++g) {
     PQ_CHECK_ARG(d.A[g] && d.B[g] && (d.C[g] || (g % kc) != 0), "pq3d_gemm: null A/B/C");
-    PQ_CHECK_ARG(!d.act_grad || d.aux[g] || (g % kc) != 0, "pq3d_gemm: act_grad needs aux");
+    PQ_CHECK_ARG(!d.act_grad || d.act_grad == PQ3D_ACT_ADD || d.aux[g] || (g % kc) != 0, "pq3d_gemm: act_grad needs aux");
   }
   if (d.splitk < 1) d.splitk = 1;
   PQ_CHECK_ARG(!(kc > 1 && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");

@@ -154,7 +154,7 @@ PQ_DEV void epi_row(const pq3d_kdesc& d, const GPtrs& gp, float (&v)[NV], int g,
       v[j + 1] = drop_keep_hi(ds, w) ? v[j + 1] * ds.scale : 0.f;
     }
   }
-  if (d.act_grad) {
+  if (d.act_grad && (gp.aux || d.act_grad != PQ3D_ACT_ADD)) {   // "+ aux" without an aux pointer in this group: no addend
     float av[NV];
     load_vec<NV>(gp.aux, d.dtAux, ci, vec_ok, nvalid, av);
     if (d.act_grad == PQ3D_ACT_RELU) {

@@ -14,14 +14,18 @@
 
 namespace {
 
-constexpr int WT = 512, TM = 64, TN = 64, LDT = 64 + 8;   // [k][64 + 8] bf16 tiles of A and B
+constexpr int WT = 512;
 
-template <typename TA, typename TB, bool HB2, int KC>
+// TT = tile edge (64 or 128: 128-wide tiles halve the operand re-reads from L2, which bound these products at 64 -- each
+// g tile is re-read by every n tile and each x tile by every m tile), KC = reduction rows staged per chunk (256 / 128)
+template <typename TA, typename TB, bool HB2, int KC, int TT>
 __global__ __launch_bounds__(WT) void gemm_wktt_kernel(const pq3d_kdesc d, const int sk) {
+  constexpr int TM = TT, TN = TT, LDT = TT + 8, CPK = TT / 8;   // [k][TT + 8] bf16 tiles of A and B; 8-element chunks per k row
+  constexpr int MI = TT / 64, NJ = TT / 32;                     // 16x16 MFMA blocks per wave: 4 x 2 waves of (16 MI) x (16 NJ)
   extern __shared__ __attribute__((aligned(16))) unsigned char tt_smem[];
   bf16_t* const At = (bf16_t*)tt_smem;        // [KC][LDT]: A(k, m0 + col)
   bf16_t* const Bt = At + KC * LDT;           // [KC][LDT]: B(k, n0 + col)
-  constexpr int NCH = KC * 8 / WT;            // 8-element chunks per operand per thread (4 at KC = 256)
+  constexpr int NCH = KC * CPK / WT;          // 8-element chunks per operand per thread (4)
   const int split = blockIdx.z % sk, g = blockIdx.z / sk;
   const pq3d_kgroup& q = d.gp[min(g, PQ3D_MAX_GROUPS - 1)];
   const TA* A = (const TA*)q.A;
@@ -31,12 +35,18 @@ __global__ __launch_bounds__(WT) void gemm_wktt_kernel(const pq3d_kdesc d, const
   float* cs_out = blockIdx.y == 0 ? q.colsum : nullptr;
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(A), "s"(B), "s"(B2), "s"(C), "s"(cs_out));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int wm = (wave >> 1) * 16, wn = (wave & 1) * 32;   // 4 x 2 waves: 16 rows x 32 columns each
+  const int wm = (wave >> 1) * (16 * MI), wn = (wave & 1) * (16 * NJ);   // 4 x 2 waves
   const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
   const int nck = (d.K + KC - 1) / KC, per = (nck + sk - 1) / sk;
   const int c0 = split * per, c1 = min(nck, c0 + per);
   if (c0 >= c1) return;
-  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}}, accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[MI][NJ], accb[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const bool do_cs = cs_out != nullptr && wn == 0;
   Raw<TA, 8> ra[NCH];
   Raw<TB, 8> rb[NCH];
@@ -47,7 +57,7 @@ __global__ __launch_bounds__(WT) void gemm_wktt_kernel(const pq3d_kdesc d, const
     const int k0 = ck * KC;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * WT, k = k0 + (c >> 3), x = (c & 7) * 8;
+      const int c = tid + i * WT, k = k0 + c / CPK, x = (c % CPK) * 8;
       ok[i] = k < d.K;
       const long ka = ok[i] ? k : 0;
       const long offa = ka * d.lda + min(m0 + x, d.M - 8), offb = ka * d.ldb + min(n0 + x, d.N - 8);
@@ -59,7 +69,7 @@ __global__ __launch_bounds__(WT) void gemm_wktt_kernel(const pq3d_kdesc d, const
   auto put = [&]() {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * WT, o = (c >> 3) * LDT + (c & 7) * 8;
+      const int c = tid + i * WT, o = (c / CPK) * LDT + (c % CPK) * 8;
       u32x4 pa, pb;
       if constexpr (sizeof(TA) == 2) pa = __builtin_bit_cast(u32x4, ra[i]);
       else { float v[8]; ra[i].to_float(v); pa = pack_frag<bf16_t>(v); }
@@ -90,47 +100,75 @@ __global__ __launch_bounds__(WT) void gemm_wktt_kernel(const pq3d_kdesc d, const
 #pragma unroll
     for (int ks = 0; ks < KC / 32; ++ks) {
       if (ks < nks) {   // uniform
-        const u32x4 a = km_frag(At, LDT, wm, ks, li, lg);
+        u32x4 a[MI], bfr[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) Mma<bf16_t>::mma(acc[j], a, km_frag(Bt, LDT, wn + j * 16, ks, li, lg));
+        for (int i = 0; i < MI; ++i) a[i] = km_frag(At, LDT, wm + i * 16, ks, li, lg);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = km_frag(Bt, LDT, wn + j * 16, ks, li, lg);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) Mma<bf16_t>::mma(acc[i][j], a[i], bfr[j]);
         if (do_cs) {
           const u32x4 ones = (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-          Mma<bf16_t>::mma(accb, a, ones);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) Mma<bf16_t>::mma(accb[i], a[i], ones);
         }
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn + j * 16 + li;
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm + lg * 4 + r;
-      if (row < d.M && col < d.N) unsafeAtomicAdd(C + (long)row * d.ldc + col, acc[j][r] * d.alpha);
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + i * 16 + lg * 4 + r;
+        if (row < d.M && col < d.N) unsafeAtomicAdd(C + (long)row * d.ldc + col, acc[i][j][r] * d.alpha);
+      }
     }
-  }
   if (do_cs && li == 0) {   // every column of accb holds the row sums of the A tile over k
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm + lg * 4 + r;
-      if (row < d.M) unsafeAtomicAdd(&cs_out[row], accb[r] * d.alpha);
-    }
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + i * 16 + lg * 4 + r;
+        if (row < d.M) unsafeAtomicAdd(&cs_out[row], accb[i][r] * d.alpha);
+      }
   }
 }
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 std::atomic<int> g_tt_enable{-1};
 
-template <typename TA, typename TB, bool HB2>
-int tt_launch(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int sk) {
-  constexpr int KC = 256;
-  auto kern = gemm_wktt_kernel<TA, TB, HB2, KC>;
-  constexpr size_t lds = 2 * (size_t)KC * LDT * sizeof(bf16_t);
+int g_tt_tile = 0;   // 0: automatic, 64 / 128: forced (PQ3D_WKTT_TILE, A/B measurements)
+
+template <typename TA, typename TB, bool HB2, int KC, int TT>
+int tt_launch_t(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
+  auto kern = gemm_wktt_kernel<TA, TB, HB2, KC, TT>;
+  constexpr size_t lds = 2 * (size_t)KC * (TT + 8) * sizeof(bf16_t);
   static std::atomic<unsigned> done{0};
   if (int e = pq3d_enable_big_lds(kern, (int)lds, done)) return e;
-  const dim3 grid((d.M + TM - 1) / TM, (d.N + TN - 1) / TN, d.groups * sk);
+  // split factor of this kernel: as many KC-row chunks side by side as keep the launch within one round of workgroups
+  // (two ~70 KB workgroups per CU)
+  const long tiles = (long)((d.M + TT - 1) / TT) * ((d.N + TT - 1) / TT) * d.groups;
+  const int nck = (d.K + KC - 1) / KC;
+  int sk = (int)(512 / (tiles > 0 ? tiles : 1));
+  if (sk < 1) sk = 1;
+  if (sk > nck) sk = nck;
+  const dim3 grid((d.M + TT - 1) / TT, (d.N + TT - 1) / TT, d.groups * sk);
   hipLaunchKernelGGL(kern, grid, dim3(WT), lds, s, kd, sk);
   return 0;
+}
+template <typename TA, typename TB, bool HB2>
+int tt_launch(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
+  // 128 x 128 tiles (128 reduction rows per chunk: the same 70 KB of LDS)
+  // -- measured slower on config 2 (flush launches 25-33 us against 15-25: one 178-VGPR workgroup per CU and four times the
+  // atomics per tile outweigh the halved L2 re-reads), so only on request (PQ3D_WKTT_TILE=128)
+  const bool big = g_tt_tile == 128;
+  if (big && d.M >= 128 && d.N >= 128) return tt_launch_t<TA, TB, HB2, 128, 128>(d, kd, s);
+  return tt_launch_t<TA, TB, HB2, 256, 64>(d, kd, s);
 }
 
 }  // namespace
@@ -143,6 +181,7 @@ bool pq3d_gemm_wktt_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream
   if (en < 0) {
     const char* e = getenv("PQ3D_WKTT");
     en = (e && e[0] == '0') ? 0 : 1;
+    if (const char* t = getenv("PQ3D_WKTT_TILE")) g_tt_tile = atoi(t);
     g_tt_enable.store(en);
   }
   if (!en) return false;
@@ -156,20 +195,13 @@ bool pq3d_gemm_wktt_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream
     if (!d.A[g] || !d.B[g] || !d.C[g] || !al16(d.A[g]) || !al16(d.B[g]) || d.A2[g]) return false;
     if (d.B2[g]) { b2 = true; if (!al16(d.B2[g]) || d.dtB2 != PQ3D_F32 || d.dtB != PQ3D_F32) return false; }
   }
-  // split factor of this kernel: as many 256-row chunks side by side as keep the launch within one round of workgroups
-  // (two 74 KB workgroups per CU)
-  const long tiles = (long)((d.M + TM - 1) / TM) * ((d.N + TN - 1) / TN) * d.groups;
-  const int nck = (d.K + 255) / 256;
-  int sk = (int)(512 / (tiles > 0 ? tiles : 1));
-  if (sk < 1) sk = 1;
-  if (sk > nck) sk = nck;
   int e;
   const bool af = d.dtA == PQ3D_F32, bf = d.dtB == PQ3D_F32;
-  if (b2) e = af ? tt_launch<float, float, true>(d, kd, s, sk) : tt_launch<bf16_t, float, true>(d, kd, s, sk);
-  else if (af && bf) e = tt_launch<float, float, false>(d, kd, s, sk);
-  else if (af) e = tt_launch<float, bf16_t, false>(d, kd, s, sk);
-  else if (bf) e = tt_launch<bf16_t, float, false>(d, kd, s, sk);
-  else e = tt_launch<bf16_t, bf16_t, false>(d, kd, s, sk);
+  if (b2) e = af ? tt_launch<float, float, true>(d, kd, s) : tt_launch<bf16_t, float, true>(d, kd, s);
+  else if (af && bf) e = tt_launch<float, float, false>(d, kd, s);
+  else if (af) e = tt_launch<float, bf16_t, false>(d, kd, s);
+  else if (bf) e = tt_launch<bf16_t, float, false>(d, kd, s);
+  else e = tt_launch<bf16_t, bf16_t, false>(d, kd, s);
   if (e) { pq3d_set_error(hipGetErrorString((hipError_t)e)); *err = e; }
   return true;
 }

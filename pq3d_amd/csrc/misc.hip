@@ -166,6 +166,29 @@ __global__ void fourier_kernel(const float* xyz, long xs, const float* cmin, con
   }
 }
 
+// two point sets of the same scenes (queries, segments) in one launch: out = [B * Na rows of set a | B * Nb rows of set b]
+__global__ void fourier_pair_kernel(const float* xa, long sa, int Na, const float* xb, long sb, int Nb, const float* cmin,
+                                    const float* cmax, const float* G, float* out, int B, int half) {
+  const long ra = (long)B * Na, total = (ra + (long)B * Nb) * half;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % half);
+    const long pn = i / half;
+    const bool isa = pn < ra;
+    const long q = isa ? pn : pn - ra;
+    const int b = (int)(q / (isa ? Na : Nb));
+    const float* p = isa ? xa + q * sa : xb + q * sb;
+    float proj = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float t = (p[c] - cmin[b * 3 + c]) / (cmax[b * 3 + c] - cmin[b * 3 + c]);
+      t *= 6.283185307179586f;
+      proj += t * G[c * half + j];
+    }
+    out[pn * 2 * half + j] = sinf(proj);
+    out[pn * 2 * half + half + j] = cosf(proj);
+  }
+}
+
 // ---------------------------------------------------------------- spatial bias
 struct SbFwdGroups {
   const float* W[PQ3D_MAX_GROUPS];
@@ -383,6 +406,24 @@ __global__ void sum_n_kernel(const SumPtrs p, int n, float* out, long cnt) {   /
     float4 a = *(const float4*)(p.src[0] + i);
     for (int g = 1; g < n; ++g) {
       const float4 b = *(const float4*)(p.src[g] + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *(float4*)(out + i) = a;
+  }
+}
+
+// two sums of different lengths in one launch (blockIdx.y selects the job)
+struct SumPair { SumPtrs p[2]; int n[2]; float* out[2]; long cnt[2]; };
+__global__ void sum_pair_kernel(const SumPair q) {
+  const int y = blockIdx.y;
+  const float* const* src = q.p[y].src;
+  const int n = q.n[y];
+  float* out = q.out[y];
+  const long cnt = q.cnt[y];
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < cnt; i += (long)gridDim.x * blockDim.x * 4) {
+    float4 a = *(const float4*)(src[0] + i);
+    for (int g = 1; g < n; ++g) {
+      const float4 b = *(const float4*)(src[g] + i);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     *(float4*)(out + i) = a;
@@ -607,6 +648,30 @@ extern "C" int pq3d_sum_n(const float* const* src, int32_t n, float* out, int64_
   return 0;
 }
 
+extern "C" int pq3d_sum_pair(const float* const* src_a, int32_t na, float* out_a, int64_t count_a, const float* const* src_b,
+                             int32_t nb, float* out_b, int64_t count_b, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
+  PQ_CHECK_ARG(src_a && src_b && out_a && out_b && na >= 1 && nb >= 1 && na <= PQ3D_MAX_GROUPS && nb <= PQ3D_MAX_GROUPS &&
+                   count_a >= 0 && count_b >= 0 && (count_a % 4) == 0 && (count_b % 4) == 0,
+               "pq3d_sum_pair: bad args (counts % 4 == 0)");
+  SumPair q;
+  for (int g = 0; g < na; ++g) {
+    PQ_CHECK_ARG(src_a[g] && ((((uintptr_t)src_a[g]) & 15) == 0), "pq3d_sum_pair: inputs must be 16-byte aligned");
+    q.p[0].src[g] = src_a[g];
+  }
+  for (int g = 0; g < nb; ++g) {
+    PQ_CHECK_ARG(src_b[g] && ((((uintptr_t)src_b[g]) & 15) == 0), "pq3d_sum_pair: inputs must be 16-byte aligned");
+    q.p[1].src[g] = src_b[g];
+  }
+  PQ_CHECK_ARG(((((uintptr_t)out_a) | ((uintptr_t)out_b)) & 15) == 0, "pq3d_sum_pair: outputs must be 16-byte aligned");
+  q.n[0] = na; q.n[1] = nb; q.out[0] = out_a; q.out[1] = out_b; q.cnt[0] = count_a; q.cnt[1] = count_b;
+  const long big = count_a > count_b ? count_a : count_b;
+  if (big == 0) return 0;
+  hipLaunchKernelGGL(sum_pair_kernel, dim3(grid1d(big / 4, 256, 1024), 2), dim3(256), 0, (hipStream_t)stream, q);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, void* stream) {
   PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && out && ws && n >= 1, "pq3d_mean_all: bad args");
@@ -792,6 +857,19 @@ extern "C" int pq3d_fourier(const float* xyz, int64_t xyz_stride, const float* c
   if (B == 0 || N == 0) return 0;
   hipLaunchKernelGGL(fourier_kernel, dim3(grid1d((long)B * N * half)), dim3(256), 0, (hipStream_t)stream, xyz,
                      (long)xyz_stride, cmin, cmax, gauss_B, out, B, N, half);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_fourier_pair(const float* xyz_a, int64_t stride_a, int32_t Na, const float* xyz_b, int64_t stride_b,
+                                 int32_t Nb, const float* cmin, const float* cmax, const float* gauss_B, float* out,
+                                 int32_t B, int32_t half, void* stream) {
+  PQ_DEVICE_GUARD(stream, xyz_a);
+  PQ_CHECK_ARG(xyz_a && xyz_b && cmin && cmax && gauss_B && out && stride_a >= 3 && stride_b >= 3 && half >= 1 && Na >= 0 &&
+                   Nb >= 0, "pq3d_fourier_pair: bad args");
+  if (B == 0 || Na + Nb == 0) return 0;
+  hipLaunchKernelGGL(fourier_pair_kernel, dim3(grid1d((long)B * (Na + Nb) * half)), dim3(256), 0, (hipStream_t)stream, xyz_a,
+                     (long)stride_a, Na, xyz_b, (long)stride_b, Nb, cmin, cmax, gauss_B, out, B, half);
   PQ_LAUNCH_CHECK();
   return 0;
 }

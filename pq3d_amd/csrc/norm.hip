@@ -191,6 +191,17 @@ __global__ __launch_bounds__(NW * 64) void add_ln_bwd_kernel(const pq3d_ln_desc 
     }
     load_row<PL, VEC>(d.o[m], d.dt_o, base, lane, d.d, ov);
     load_row<PL, VEC>(dyp, PQ3D_F32, base, lane, d.d, ndy);
+    if (d.dy2) {   // upstream gradient in up to three addends: (dy + dy2) + dy3
+      float t[PL];
+      load_row<PL, VEC>(d.dy2, PQ3D_F32, base, lane, d.d, t);
+#pragma unroll
+      for (int j = 0; j < PL; ++j) ndy[j] += t[j];
+      if (d.dy3) {
+        load_row<PL, VEC>(d.dy3, PQ3D_F32, base, lane, d.d, t);
+#pragma unroll
+        for (int j = 0; j < PL; ++j) ndy[j] += t[j];
+      }
+    }
     if (d.sum_branches) {
       for (int p = 1; p < d.M; ++p) {
         float t[PL];
@@ -286,6 +297,7 @@ int check_ln(const pq3d_ln_desc& d, bool bwd) {
     PQ_CHECK_ARG(d.o[m] && (!first || (d.gamma[m] && d.beta[m])), "pq3d_add_ln: null o/gamma/beta");
     if (bwd && first) PQ_CHECK_ARG(d.d_o[m] && d.dgamma[m] && d.dbeta[m], "pq3d_add_ln_bwd: null grads");
   }
+  if (bwd) PQ_CHECK_ARG((!d.dy2 && !d.dy3) || (d.dy2 && !d.independent), "pq3d_add_ln_bwd: dy2 / dy3 (dy3 only with dy2; not with independent branches)");
   if (d.independent) {
     for (int m = 0; m < d.M; ++m) PQ_CHECK_ARG(bwd ? d.dys[m] != nullptr : d.ys[m] != nullptr, "pq3d_add_ln: null ys/dys");
   } else if (bwd) PQ_CHECK_ARG(d.dy != nullptr, "pq3d_add_ln_bwd: null dy");
@@ -306,7 +318,7 @@ bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd) {
     if (d.independent) ok = ok && (bwd ? al(d.dys[m], PQ3D_F32) : al(d.ys[m], d.dt_y));
     if (bwd && first) ok = ok && al(d.d_o[m], PQ3D_F32);
   }
-  if (!d.independent) ok = ok && (bwd ? al(d.dy, PQ3D_F32) && al(d.dx, PQ3D_F32) : al(d.y, d.dt_y));
+  if (!d.independent) ok = ok && (bwd ? al(d.dy, PQ3D_F32) && al(d.dx, PQ3D_F32) && al(d.dy2, PQ3D_F32) && al(d.dy3, PQ3D_F32) : al(d.y, d.dt_y));
   return ok && al(d.osum, PQ3D_F32);
 }
 

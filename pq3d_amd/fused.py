@@ -239,6 +239,8 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
     M = len(os_)
     dm = os_[0].shape[-1]
     R = os_[0].numel() // dm
+    dys = list(dy) if isinstance(dy, (list, tuple)) else [dy]   # up to three addends of the upstream gradient, summed in the kernel
+    dy = dys[0]
     dev = dy.device
     d_o = torch.empty(1 if sum_branches else M, *os_[0].shape, dtype=torch.float32, device=dev)
     dx = torch.empty(os_[0].shape, dtype=torch.float32, device=dev) if ((x is not None and want_dx) or dup_dx) else None
@@ -246,6 +248,8 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
     if dx_zeroed is not None and dx is not None:   # a slice of the caller's buffer zeroed once for the whole backward
         dx, d.dx_zeroed = dx_zeroed, 1
     d.dy, d.dx, d.accumulate, d.sum_branches = L.ptr(dy), L.ptr(dx), 1, int(sum_branches)
+    if len(dys) > 1:
+        d.dy2, d.dy3 = L.ptr(dys[1]), L.ptr(dys[2]) if len(dys) > 2 else None
     for m in range(1 if sum_branches else M):
         d.d_o[m], d.dgamma[m], d.dbeta[m] = L.ptr(d_o[m]), L.ptr(dgs[m]), L.ptr(dbs[m])
     nb = (3 * M + 1 + (x is not None)) * R * dm * 4.0
@@ -764,14 +768,14 @@ class _FusedDecoder(Function):
             if spec.spatial:   # deferred: one grouped launch for all layer applications at the end of the backward
                 sb_queue.append((msa.pairwise_loc_fc.weight.detach(), msa.pairwise_loc_fc.bias.detach(), dsb,
                                  G(msa.pairwise_loc_fc.weight), G(msa.pairwise_loc_fc.bias)))
-            tmpv = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)       # dv @ Wv + residual grad
-            L.gemm(M=R, N=d, K=d, A=[dqkv[2]], B=[Wl[2]], Cs=[tmpv], aux=[dx1r], act_grad="add", ct=ct, lda=d, ldb=d,
-                   ldc=d, transB=True)
-            gqk = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)        # pure d(x1 + qpos) from q, k
-            dx1 = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-            L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1]], B=[Wl[0], Wl[1]], Cs=[dx1, None], C2=[gqk, None],
-                   aux=[tmpv, None], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=2)
-            dqpos_parts.append(gqk)
+            # d(x1 + qpos) from q and k, d(x1) from v (+ the residual-branch gradient): three independent products, ONE
+            # launch; their sum is formed by the consumer (the next LayerNorm backward reads three addends) instead of
+            # by a second, dependent "+ aux" launch
+            g3 = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1], dqkv[2]], B=list(Wl), Cs=[g3[0], g3[1], g3[2]],
+                   aux=[None, None, dx1r], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+            dqpos_parts += [g3[0], g3[1]]
+            dx1 = [g3[0], g3[1], g3[2]]
             dwq.add([dqkv[0], dqkv[1], dqkv[2]], [x1s] * 3, [qpos, qpos, None], GW, ct, Gb)
             if spec.prompt:
                 # ---------------- prompt cross-attention backward (sequential, single memory): dx1 is d(x1s) here
@@ -889,6 +893,7 @@ class _FusedDecoder(Function):
             jobs.append((u, Aj, Bj))
         per = len(jobs[0][1]) if jobs else 0
         want_dpos = pos is not None and ctx.needs_input_grad[4]
+        dqpos_done = None
         dpos = None
         nk, nv = n_app, n_app + (1 if dkeys is not None else 0)
         if single and tposed and want_dpos and len(jobs) == M and nk * M <= MAXG and nv * M <= MAXG and \
@@ -909,7 +914,10 @@ class _FusedDecoder(Function):
                    ldc=d, kconcat=nv)
             for jb, o_ in zip(jobs, outs):
                 dfeats[jb[0]] = o_
-            dpos = ops.sum_n([Kp[j] for j in range(M)])
+            if ctx.needs_input_grad[2] and len(dqpos_parts) > 1:   # d query_pos and d pos: one launch, adjacent outputs
+                dqpos_done, dpos = ops.sum_pair(dqpos_parts, [Kp[j] for j in range(M)])
+            else:
+                dpos = ops.sum_n([Kp[j] for j in range(M)])
             want_dpos = False
         elif tposed and jobs and 0 < per <= MAXG and all(len(jb[1]) == per for jb in jobs):
             cap = max(1, MAXG // per)   # memories per launch
@@ -945,8 +953,8 @@ class _FusedDecoder(Function):
                        act_grad="add" if dpos is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=not tposed,
                        kconcat=n)
                 dpos = nxt
-        dqpos = None
-        if ctx.needs_input_grad[2]:
+        dqpos = dqpos_done
+        if ctx.needs_input_grad[2] and dqpos is None:
             dqpos = ops.sum_n(dqpos_parts)
         dx0 = dx if ctx.needs_input_grad[1] else None
         dprompt = None

@@ -132,9 +132,7 @@ class Query3DUnified(nn.Module):
         B, Nq, Ns, d = query_locs.shape[0], query_locs.shape[1], seg_locs.shape[1], self.hidden_size
         if not hasattr(ce, "feat_proj"):
             return ce(query_locs[:, :, :3], [coord_min, coord_max]), ce(seg_locs[:, :, :3], [coord_min, coord_max])
-        buf = torch.empty(B * (Nq + Ns), d, dtype=torch.float32, device=query_locs.device)
-        ops.fourier(query_locs[:, :, :3], coord_min, coord_max, ce.pos_enc.gauss_B, out=buf[:B * Nq].view(B, Nq, d))
-        ops.fourier(seg_locs[:, :, :3], coord_min, coord_max, ce.pos_enc.gauss_B, out=buf[B * Nq:].view(B, Ns, d))
+        buf = ops.fourier_pair(query_locs[:, :, :3], seg_locs[:, :, :3], coord_min, coord_max, ce.pos_enc.gauss_B)
         y = M.linear_ln_forward(ce.feat_proj, buf, self.ct)
         yq, ys = ops.split_rows(y, B * Nq)
         return yq.view(B, Nq, d), ys.view(B, Ns, d)

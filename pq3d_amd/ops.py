@@ -200,6 +200,20 @@ def fourier(xyz: torch.Tensor, cmin: torch.Tensor, cmax: torch.Tensor, gauss_B: 
     return out
 
 
+def fourier_pair(xyz_a: torch.Tensor, xyz_b: torch.Tensor, cmin, cmax, gauss_B) -> torch.Tensor:
+    """fourier() of two point sets of the same scenes in one launch: [B*Na + B*Nb, 2*half], set a's rows first."""
+    def prep(x):
+        assert x.dtype == torch.float32 and x.stride(-1) == 1
+        return x if x.stride(0) == x.shape[1] * x.stride(1) else x.contiguous()
+    xyz_a, xyz_b = prep(xyz_a), prep(xyz_b)
+    B, Na, Nb, half = xyz_a.shape[0], xyz_a.shape[1], xyz_b.shape[1], gauss_B.shape[1]
+    out = _empty(B * (Na + Nb), 2 * half, dtype=torch.float32, device=xyz_a.device)
+    L.check(L.lib().pq3d_fourier_pair(L.ptr(xyz_a), xyz_a.stride(1), Na, L.ptr(xyz_b), xyz_b.stride(1), Nb,
+                                      L.ptr(_c(cmin.float())), L.ptr(_c(cmax.float())), L.ptr(_c(gauss_B)), L.ptr(out), B, half,
+                                      L.stream()), "pq3d_fourier_pair")
+    return out
+
+
 def _parr(ts):
     return (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
 
@@ -258,6 +272,20 @@ def sum_n(parts: Sequence[torch.Tensor]) -> torch.Tensor:
         L.check(L.lib().pq3d_sum_n(_parr(chunk), len(chunk), L.ptr(new), new.numel(), L.stream()), "pq3d_sum_n")
         out = new
     return out
+
+
+def sum_pair(parts_a: Sequence[torch.Tensor], parts_b: Sequence[torch.Tensor]):
+    """(sum_n(parts_a), sum_n(parts_b)) in one launch, the two results ADJACENT in one buffer (a first): a consumer that
+    wants their row concatenation (_SplitRows.backward) finds it already formed."""
+    parts_a, parts_b = [p.contiguous() for p in parts_a], [p.contiguous() for p in parts_b]
+    if len(parts_a) > L.MAXG or len(parts_b) > L.MAXG or parts_a[0].numel() % 4 or parts_b[0].numel() % 4:
+        return sum_n(parts_a), sum_n(parts_b)
+    na, nb = parts_a[0].numel(), parts_b[0].numel()
+    buf = torch.empty(na + nb, dtype=torch.float32, device=parts_a[0].device)
+    oa, ob = buf[:na].view(parts_a[0].shape), buf[na:].view(parts_b[0].shape)
+    L.check(L.lib().pq3d_sum_pair(_parr(parts_a), len(parts_a), L.ptr(oa), na, _parr(parts_b), len(parts_b), L.ptr(ob), nb,
+                                  L.stream()), "pq3d_sum_pair")
+    return oa, ob
 
 
 _MEAN_WS = {}
@@ -944,6 +972,12 @@ class _SplitRows(Function):
         n, (rows, d_) = ctx.n, ctx.shape
         if da is None and db is None:
             return None, None
+        if (da is not None and db is not None and da.is_contiguous() and db.is_contiguous() and da.dtype == db.dtype
+                and da.numel() == n * d_ and db.numel() == (rows - n) * d_
+                and da.untyped_storage().data_ptr() == db.untyped_storage().data_ptr()
+                and da.storage_offset() + da.numel() == db.storage_offset()):
+            # the producer wrote the two gradients side by side in one buffer (ops.sum_pair): already concatenated
+            return torch.as_strided(da, (rows, d_), (d_, 1), da.storage_offset()), None
         da = da.reshape(n, d_) if da is not None else db.new_zeros(n, d_)
         db = db.reshape(rows - n, d_) if db is not None else da.new_zeros(rows - n, d_)
         return torch.cat([da, db], 0), None

@@ -808,3 +808,58 @@ def test_entry_points_launch_on_the_device_of_their_stream_not_the_current_one()
     L.check(L.lib().pq3d_fill_scaled(L.ptr(dst), 1000, L.ptr(sc), 1.0, C_.c_void_p(0)), "fill (NULL stream, pointer on device 1)")
     torch.cuda.synchronize(d1)
     assert torch.cuda.current_device() == 0 and float(dst.sum()) == 3000.0
+
+
+@pytest.mark.gpu
+def test_launch_merges_pair_kernels_and_summed_layernorm_gradient():
+    """fourier_pair == two fourier launches; sum_pair == two sum_n launches with adjacent outputs (and _SplitRows.backward
+    returns their buffer instead of a copy); the LayerNorm backward with the upstream gradient in three addends ==
+    the same call on their sum; a grouped '+ aux' product whose other groups have no aux."""
+    from pq3d_amd import fused
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    B, Na, Nb, half = 3, 40, 77, 128
+    xa, xb = rnd(B, Na, 6), rnd(B, Nb, 3)
+    cmin, cmax, G = rnd(B, 3) - 3, rnd(B, 3) + 3, rnd(3, half)
+    pair = ops.fourier_pair(xa[:, :, :3], xb, cmin, cmax, G)
+    assert torch.equal(pair[:B * Na].view(B, Na, -1), ops.fourier(xa[:, :, :3], cmin, cmax, G))
+    assert torch.equal(pair[B * Na:].view(B, Nb, -1), ops.fourier(xb, cmin, cmax, G))
+    # sum_pair
+    pa, pb = [rnd(B, Na, 256) for _ in range(5)], [rnd(B, Nb, 256) for _ in range(3)]
+    sa, sb = ops.sum_pair(pa, pb)
+    assert torch.equal(sa, ops.sum_n(pa)) and torch.equal(sb, ops.sum_n(pb))
+    y = rnd(B * (Na + Nb), 256).requires_grad_()
+    ya, yb = ops.split_rows(y, B * Na)
+    (gy,) = torch.autograd.grad([ya, yb], [y], [sa.view(B * Na, 256), sb.view(B * Nb, 256)])
+    assert gy.data_ptr() == sa.data_ptr() and torch.equal(gy, torch.cat([sa.view(-1, 256), sb.view(-1, 256)], 0))
+    (gy2,) = torch.autograd.grad(ops.split_rows(y, B * Na), [y], [sa.view(B * Na, 256).clone(), sb.view(B * Nb, 256).clone()])
+    assert torch.equal(gy2, gy)
+    # LayerNorm backward, upstream gradient in three addends (one and four branches)
+    for M in (1, 4):
+        R, d = 800, 256
+        x, os_ = rnd(8, 100, d), [rnd(8, 100, d) for _ in range(M)]
+        gam, bet = [rnd(d) for _ in range(M)], [rnd(d) for _ in range(M)]
+        coef = torch.softmax(rnd(M, 8), 0).contiguous() if M > 1 else None
+        ys = torch.empty(8, 100, d, device=dev)
+        mean, rstd = torch.empty(M, R, device=dev), torch.empty(M, R, device=dev)
+        dd = ops._ln_desc(x, os_, gam, bet, coef, 1e-5, 100, ys, mean, rstd, None)
+        L.check(L.lib().pq3d_add_ln_fwd(C.byref(dd), L.stream()), "fwd")
+        dys = [rnd(8, 100, d) for _ in range(3)]
+        outs = []
+        for dy in (dys, (dys[0] + dys[1]) + dys[2]):
+            dgs, dbs = [torch.zeros(d, device=dev) for _ in range(M)], [torch.zeros(d, device=dev) for _ in range(M)]
+            dx, d_o = fused._ln_bwd(x, os_, gam, bet, 1e-5, coef, 100, mean, rstd, dy, dgs, dbs)
+            outs.append((dx, d_o, torch.stack(dgs), torch.stack(dbs)))
+        for a, b in zip(*outs):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)   # atomics order only (the addends are summed identically)
+    # grouped "+ aux" with an aux pointer in the last group only
+    A = [rnd(800, 256) for _ in range(3)]
+    W = [rnd(256, 256) * 0.05 for _ in range(3)]
+    aux = rnd(800, 256)
+    out = torch.empty(3, 800, 256, device=dev)
+    L.gemm(M=800, N=256, K=256, A=A, B=W, Cs=[out[0], out[1], out[2]], aux=[None, None, aux], act_grad="add", ct=F32, lda=256,
+           ldb=256, ldc=256, transB=True)
+    for i in range(3):
+        ref = A[i].double() @ W[i].double() + (aux.double() if i == 2 else 0)
+        torch.testing.assert_close(out[i].double(), ref, rtol=1e-4, atol=1e-4)
