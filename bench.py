@@ -318,7 +318,7 @@ def main():
     reducer = FlatGradAllReducer(params, groups=[g for g in groups if g])
     dec_buckets = [bucket_of[j] for j in range(n_layer_buckets + 1) if keep[j]]
     enc.grad_arena = reducer.slots()
-    enc.grad_arena_buffers = [reducer.flat[b] for b in dec_buckets]
+    enc.grad_arena_buffers = list(reducer.flat)   # all of them: the encoders' backward writes its slots in place too
     overlap = world > 1 and os.environ.get("PQ3D_BENCH_OVERLAP", "1") != "0"
     forced_mode = os.environ.get("PQ3D_BENCH_STEP_MODE", "")   # "", "one_graph", "two_graph", "graph_then_allreduce", "eager"
 
@@ -574,7 +574,7 @@ def main():
                     torch.cuda.synchronize(); gc.collect()   # tear the captured graphs down here, on this thread, device idle
             except Exception as e:  # noqa: BLE001
                 result["dropin_graphed_error"] = f"{type(e).__name__}: {e}"[:300]
-            enc.grad_arena, enc.grad_arena_buffers = reducer.slots(), [reducer.flat[b] for b in dec_buckets]
+            enc.grad_arena, enc.grad_arena_buffers = reducer.slots(), list(reducer.flat)
             if args.dropout == "off" and not args.no_dropout_leg:
                 # train-mode dropout as the reference trains (reported separately from the parity-checked
                 # p=0 headline): masks are generated inside the attention / LayerNorm / GEMM-epilogue kernels

@@ -587,14 +587,26 @@ class _FusedDecoder(Function):
             # .grad None / foreign everywhere -> fresh step: zero, then hand fresh views to autograd (adopted without a copy).
             req = [p for p in params if p.requires_grad]
             alias = [p.grad is not None and p.grad.data_ptr() == gv[id(p)].data_ptr() for p in req]
+            # parameters outside the decoder (the input encoders) with slots in the buffers zeroed here: offered to the
+            # backward functions that run after this one in the same pass (ops.arena_offer)
+            bufs = list(getattr(enc, "grad_arena_buffers", ()))
+            zeroed, own = {b.data_ptr() for b in bufs}, {id(p) for p in params}
+            offer = {}
+            for i_, q_ in getattr(ext, "params", {}).items():
+                if i_ not in own and q_.requires_grad and ext[i_][0].data_ptr() in zeroed:
+                    fl_, o_, n_ = ext[i_]
+                    offer[q_.data_ptr()] = (q_, fl_, o_, n_)
+            mixed = "fused decoder backward: some parameters' .grad alias the shared gradient arena and others do not -- " \
+                    "zero ALL gradients (set_to_none=True) or none between micro-batches"
             if req and all(alias):
                 accumulate = True
                 ops.zero_many([dxr_zero])
-            elif any(alias):
-                raise RuntimeError("fused decoder backward: some parameters' .grad alias the shared gradient arena and others "
-                                   "do not -- zero ALL gradients (set_to_none=True) or none between micro-batches")
+            elif any(alias) or any(q_.grad is not None and q_.grad.data_ptr() == f_.data_ptr() + 4 * o_ for q_, f_, o_, n_ in offer.values()):
+                raise RuntimeError(mixed)
             else:
-                ops.zero_many(list(getattr(enc, "grad_arena_buffers", ())) + [dxr_zero])
+                ops.zero_many(bufs + [dxr_zero])
+            if offer:
+                ops.arena_offer(offer, "accumulate" if accumulate else "fresh")
         else:
             arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
             ops.zero_many([arena, dxr_zero])

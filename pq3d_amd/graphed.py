@@ -142,7 +142,7 @@ class GraphedQuery3D(nn.Module):
         groups = [[p for p in params if id(p) in dec_ids], [p for p in params if id(p) not in dec_ids]]
         self.reducer = FlatGradAllReducer(params, groups=[g for g in groups if g])   # flat buffers + slot map (+ DP exchange)
         if enc is not None and groups[0]:
-            enc.grad_arena, enc.grad_arena_buffers = self.reducer.slots(), [self.reducer.flat[0]]
+            enc.grad_arena, enc.grad_arena_buffers = self.reducer.slots(), list(self.reducer.flat)
         self._params = params
         self._slots = self.reducer.slots()
         self._args = args

@@ -906,6 +906,7 @@ class _LinearLNGroup(Function):
                       L.stream()), "pq3d_add_ln_fwd")
         ctx.save_for_backward(lin, mean, rstd, *xs, *Ws, *gam, *bet)
         ctx.cfg = (ct, eps, G, need_dx)
+        ctx.pptr = [a.data_ptr() for a in (*Ws, *bs, *gam, *bet)]   # order of the returned parameter gradients
         return tuple(ys[g] for g in range(G))
 
     @staticmethod
@@ -922,10 +923,22 @@ class _LinearLNGroup(Function):
         dys = [(_c(g).float() if g is not None else torch.zeros(lin.shape[1:], device=dev)) for g in dys]
         dlin = _empty(lin.shape, dtype=torch.float32, device=dev)
         # every atomics target of this backward (LayerNorm parameter gradients, split-K weight gradients, bias column
-        # sums) lives in ONE zero-filled buffer: a single fill instead of a zero launch per kernel
-        zb = torch.zeros(G * (3 * N + N * K), dtype=torch.float32, device=dev)
-        dgs = [zb[g * N:(g + 1) * N] for g in range(G)]
-        dbs = [zb[(G + g) * N:(G + g + 1) * N] for g in range(G)]
+        # sums): the parameters' slots of the owner's gradient arena when the decoder's backward offered them for this
+        # pass (zeroed by its one launch: no fill here, no pack copy later), else ONE zero-filled buffer of our own
+        tiles = ((N + 63) // 64) * ((K + 63) // 64)
+        epl = 8 if ct == BF16 else 4
+        fuse = N % epl == 0 and K % epl == 0 and all(x.data_ptr() % 16 == 0 for x in xs)
+        slot, give = arena_take(ctx.pptr) if fuse else (None, False)
+        if slot is not None:
+            dWs, dbl, dgs, dbs = slot[:G], slot[G:2 * G], slot[2 * G:3 * G], slot[3 * G:]
+            dWs = [w.view(N, K) for w in dWs]
+        else:
+            give = True
+            zb = torch.zeros(G * (3 * N + N * K), dtype=torch.float32, device=dev)
+            dgs = [zb[g * N:(g + 1) * N] for g in range(G)]
+            dbs = [zb[(G + g) * N:(G + g + 1) * N] for g in range(G)]
+            dbl = [zb[(2 * G + g) * N:(2 * G + g + 1) * N] for g in range(G)]
+            dWs = [zb[3 * G * N + g * N * K:3 * G * N + (g + 1) * N * K].view(N, K) for g in range(G)]
         d = _ln_desc(None, [lin[g] for g in range(G)], list(gam), list(bet), None, eps, R, None, mean, rstd)
         d.independent = 1
         d.accumulate = 1
@@ -933,11 +946,6 @@ class _LinearLNGroup(Function):
             d.dys[g], d.d_o[g], d.dgamma[g], d.dbeta[g] = L.ptr(dys[g]), L.ptr(dlin[g]), L.ptr(dgs[g]), L.ptr(dbs[g])
         L.check(timed("pq3d_add_ln_bwd", f"R{R}d{N}M{G}i", 0.0, 3.0 * G * R * N * 4, L.lib().pq3d_add_ln_bwd, C.byref(d),
                       L.stream()), "pq3d_add_ln_bwd")
-        dbl = [zb[(2 * G + g) * N:(2 * G + g + 1) * N] for g in range(G)]
-        dWs = [zb[3 * G * N + g * N * K:3 * G * N + (g + 1) * N * K].view(N, K) for g in range(G)]
-        tiles = ((N + 63) // 64) * ((K + 63) // 64)
-        epl = 8 if ct == BF16 else 4
-        fuse = N % epl == 0 and K % epl == 0 and all(x.data_ptr() % 16 == 0 for x in xs)
         L.gemm(M=N, N=K, K=R, A=[dlin[g] for g in range(G)], B=list(xs), Cs=dWs, ct=ct, lda=N, ldb=K, ldc=K, transA=True,
                transB=True, splitk=max(2, _splitk(tiles * G, R, ct)), colsum=dbl if fuse else None, accumulate=True)
         if not fuse:
@@ -948,6 +956,8 @@ class _LinearLNGroup(Function):
             L.gemm(M=R, N=K, K=N, A=[dlin[g] for g in range(G)], B=list(Ws), Cs=[dxb[g] for g in range(G)], ct=ct,
                    lda=N, ldb=K, ldc=K, transB=True)
             dxs = [dxb[g] for g in range(G)]
+        if not give:   # accumulated in place into slots autograd already holds (second micro-batch / second use)
+            return (None, None, None, None, *dxs, *([None] * (4 * G)))
         return (None, None, None, None, *dxs, *dWs, *dbl, *dgs, *dbs)
 
 
@@ -956,6 +966,46 @@ def linear_ln_group(xs, Ws, bs, gammas, betas, *, ct: int, eps: float = 1e-5):
     G = len(xs)
     need_dx = any(x.requires_grad for x in xs)
     return _LinearLNGroup.apply(ct, float(eps), G, need_dx, *xs, *Ws, *bs, *gammas, *betas)
+
+
+# ---- gradient arena offered for one backward pass ----------------------------------------------------------------------
+# The fused decoder's backward zero-fills the owner's flat gradient buffers with its one zero launch and then OFFERS the
+# slots of the parameters outside the decoder (the input encoders) to the backward functions that run after it in the same
+# pass: they accumulate straight into the slots (no zero-fill launch of their own, no pack copy afterwards) and hand
+# autograd views of them.  The offer ends with the pass (engine callback), so a later backward that does not start with
+# the decoder never sees stale zeroing.  mode "fresh": slots were just zeroed, return the views (autograd adopts them);
+# "accumulate": .grad already aliases the slots (second micro-batch), add in place and return None.
+class _Arena:
+    mode = None
+    by_ptr = {}      # parameter data_ptr -> (parameter, flat buffer, element offset, numel) of its slot
+    written = set()  # slots some function of this pass already returned (a second use adds in place, returns None)
+
+
+def arena_offer(views_by_ptr, mode):
+    _Arena.mode, _Arena.by_ptr, _Arena.written = mode, views_by_ptr, set()
+
+    def _end():
+        _Arena.mode, _Arena.by_ptr, _Arena.written = None, {}, set()
+    torch.autograd.Variable._execution_engine.queue_callback(_end)
+
+
+def arena_take(ptrs):
+    """Slot views for the parameters at ``ptrs`` (all of them or None) and whether to return them to autograd."""
+    if _Arena.mode is None or any(q not in _Arena.by_ptr for q in ptrs):
+        return None, False
+    # fresh view objects per call: AccumulateGrad adopts a gradient without a copy only when nobody else references it
+    ent = [(p, fl[o:o + n].view(p.shape)) for p, fl, o, n in (_Arena.by_ptr[q] for q in ptrs)]
+    if _Arena.mode == "fresh":
+        seen = [q in _Arena.written for q in ptrs]
+        if any(seen) and not all(seen):
+            return None, False
+        give = not any(seen)
+    else:   # accumulate: only slots autograd already holds as .grad (anything else still has last step's data in it)
+        if not all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in ent):
+            return None, False
+        give = False
+    _Arena.written.update(ptrs)
+    return [v for _, v in ent], give
 
 
 class _SplitRows(Function):

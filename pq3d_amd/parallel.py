@@ -14,6 +14,16 @@ import torch
 import torch.distributed as dist
 
 
+class GradSlots(dict):
+    """{id(param): (flat buffer, element offset, numel)} plus ``params`` = {id(param): param}: the slot map handed to the
+    fused executor (``encoder.grad_arena``).  ``params`` lets the executor offer the slots of parameters OUTSIDE the decoder
+    (the input encoders) to their own backward functions for the duration of one backward pass (ops.arena_*)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.params = {}
+
+
 class FlatGradAllReducer:
     """``groups``: explicit buckets (lists of parameters) in the order their gradients become final -- bench.py /
     TrainStep pass [decoder (+ mask head) parameters, everything else]: the fused decoder backward finishes ALL of the
@@ -50,12 +60,13 @@ class FlatGradAllReducer:
         """{id(param): (flat buffer, element offset, numel)} -- hand this to the fused executor
         (``encoder.grad_arena``): it then writes parameter gradients straight into the flat buffer (fresh view
         objects per backward, so autograd adopts them without a copy) and pack() skips them."""
-        out = {}
+        out = GradSlots()
         for flat, bucket in zip(self.flat, self.buckets):
             off = 0
             for p in bucket:
                 n = p.numel()
                 out[id(p)] = (flat, off, n)
+                out.params[id(p)] = p
                 off += n
         return out
 

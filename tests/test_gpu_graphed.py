@@ -145,6 +145,56 @@ def test_fused_backward_accumulates_into_the_arena_until_gradients_are_reset():
     enc.grad_arena = None
 
 
+def test_encoder_gradients_written_into_the_offered_arena_slots():
+    """With every flat buffer in enc.grad_arena_buffers the decoder backward zeroes them all in its one launch and offers the
+    input encoders' slots to their backward functions for that pass (ops.arena_offer): those gradients land in the flat
+    buffer (no pack copy), equal the plain path's, accumulate over micro-batches, and the offer ends with the pass."""
+    from pq3d_amd import ops
+    from pq3d_amd.parallel import FlatGradAllReducer
+    args, model, dda, ddb = _case()
+    enc = model.unified_encoder
+    params = [p for p in model.parameters() if p.requires_grad]
+    dec = {id(p) for p in enc.parameters()} | ({id(p) for p in model.mask_head.parameters()} if hasattr(model, "mask_head") else set())
+    loss_of = lambda out: util.synthetic_loss(out, args["heads"], out["query_embeds"])
+    enc.grad_arena = None
+    plain = []
+    for d_ in (dda, ddb):
+        model.zero_grad(set_to_none=True)
+        loss_of(model(dict(d_))).backward()
+        plain.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    red = FlatGradAllReducer(params, groups=[[p for p in params if id(p) in dec], [p for p in params if id(p) not in dec]])
+    slots = red.slots()
+    enc.grad_arena, enc.grad_arena_buffers = slots, list(red.flat)
+    model.zero_grad(set_to_none=True)
+    loss_of(model(dict(dda))).backward()
+    assert ops._Arena.mode is None   # the offer ended with the backward pass
+    in_place = [n for n, p in model.named_parameters() if id(p) not in dec and p.grad is not None
+                and p.grad.data_ptr() == slots[id(p)][0][slots[id(p)][1]:].data_ptr()]
+    assert in_place, "no encoder gradient was written in place"
+    gmax = max(float(v.norm()) for v in plain[0].values())
+    for n, p in model.named_parameters():
+        if n in plain[0]:
+            assert float((p.grad - plain[0][n]).norm()) <= 2e-4 * max(float(plain[0][n].norm()), 1e-2 * gmax), n
+    red.pack()   # the remaining (foreign) gradients are copied; in-place ones are skipped
+    for n, p in model.named_parameters():
+        if n in plain[0]:
+            fl, o, k = slots[id(p)]
+            assert float((fl[o:o + k].view_as(p) - plain[0][n]).norm()) <= 2e-4 * max(float(plain[0][n].norm()), 1e-2 * gmax), n
+    loss_of(model(dict(ddb))).backward()   # second micro-batch: accumulate
+    for n, p in model.named_parameters():
+        if n in plain[0]:
+            want = plain[0][n] + plain[1][n]
+            assert float((p.grad - want).norm()) <= 2e-4 * max(float(want.norm()), 1e-2 * gmax), n
+    # mixed state: an encoder gradient still aliasing its slot while the decoder's were reset
+    for p in params:
+        if id(p) in dec:
+            p.grad = None
+    with pytest.raises(RuntimeError, match="alias the shared gradient arena"):
+        loss_of(model(dict(dda))).backward()
+    model.zero_grad(set_to_none=True)
+    enc.grad_arena = None
+
+
 def test_per_layer_gradient_buckets_report_readiness_in_reverse_layer_order_and_change_no_gradient():
     """Data-parallel mode of the fused backward: with enc.grad_bucket_per_layer the weight-gradient products of
     a layer (incl. the K/V rows of its in_proj weights and its spatial-bias projection) are flushed when that layer's
