@@ -158,9 +158,9 @@ def cpu_baseline(c, sd, dd, steps, warmup, hf_body=None):
 
 
 FAMILY_KERNELS = {   # GPU kernels behind a C-ABI entry point (rocprofv3 / PMC kernel names, template arguments stripped)
-    "pq3d_gemm": ["gemm_wk_kernel", "gemm_fast_kernel", "gemm_slow_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel"],
-    "pq3d_attn_fwd": ["attn_fwd_resident_kernel", "attn_small_fwd_kernel", "attn_fwd_kernel", "attn_fwd_combine_kernel"],
-    "pq3d_attn_bwd": ["attn_bwd_resident_kernel", "attn_small_bwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
+    "pq3d_gemm": ["gemm_wk_kernel", "gemm_fast_kernel", "gemm_slow_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel", "gemm_wktt_kernel"],
+    "pq3d_attn_fwd": ["attn_fwd_resident_kernel", "attn_sa_fwd_kernel", "attn_small_fwd_kernel", "attn_fwd_kernel", "attn_fwd_combine_kernel"],
+    "pq3d_attn_bwd": ["attn_bwd_resident_kernel", "attn_sa_bwd_kernel", "attn_small_bwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
                       "attn_dq_combine_kernel"],
     "pq3d_add_ln_fwd": ["add_ln_fwd_kernel"], "pq3d_add_ln_bwd": ["add_ln_bwd_kernel"],
 }

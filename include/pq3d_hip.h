@@ -180,6 +180,23 @@ int pq3d_gemm_set_wk(int options, int max_m);
  * Backward (pq3d_attn_bwd) recomputes P from lse: needs o, do; writes dq/dk/dv with the strides of q/k/v,
  * `delta` is a [B,H,Lq] fp32 workspace, dbias ([B,H,Lq,Lk] fp32, may be NULL) receives dL/dbias.
  * ------------------------------------------------------------------------------------------------ */
+/* Projection folded into an attention launch (the split-bf16 self-attention kernels only: compute type PQ3D_BF16X3,
+ * d_h = 32, at most 240 queries / keys; any other call with mode != 0 is refused with an error, nothing is launched).
+ *   PQ3D_ATTN_PROJ_DOUT (backward): the out-projection's input gradient is formed in the kernel,
+ *     dO[b, i, h, :] = x[b, i, :] . w[0][:, h*dh : (h+1)*dh]      (x = dL/d(out-proj output) [B, Lq, dm] fp32,
+ *     w[0] = out-proj weight [dm, dm] fp32; bf16 operands, fp32 accumulate -- the arithmetic of the backward products),
+ *     `dout` is ignored: one dependent launch and the [B, Lq, dm] round trip of dO less per layer
+ *     (query_encoder.py:213-227 backward; MultiHeadAttentionSpatial.fc, transformers.py:239). */
+#define PQ3D_ATTN_PROJ_NONE 0
+#define PQ3D_ATTN_PROJ_DOUT 2
+typedef struct {
+  int32_t mode, dm;
+  const float* x;
+  const float* x2;     /* reserved */
+  const float* w[3];
+  const float* b[3];   /* reserved */
+} pq3d_attn_proj;
+
 typedef struct {
   int32_t B, H, Lq, Lk, dh;
   int32_t ct;   /* compute type: PQ3D_F32 / PQ3D_BF16 (= storage dtype), or PQ3D_BF16X3 with fp32 storage */
@@ -216,6 +233,7 @@ typedef struct {
    * b % drop_bmod, so a stacked launch draws exactly the masks the per-memory launches would. */
   pq3d_dropout drop;
   int32_t drop_bmod;
+  pq3d_attn_proj proj;   /* zero-initialised = none */
 } pq3d_attn_desc;
 
 int pq3d_attn_fwd(const pq3d_attn_desc* d, void* stream);

@@ -118,6 +118,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class AttnProj(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("dm", C.c_int32), ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p * 3),
+                ("b", C.c_void_p * 3)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("dh", C.c_int32),
@@ -130,7 +135,7 @@ class AttnDesc(C.Structure):
         ("kpm", C.c_void_p), ("mask", C.c_void_p), ("row_open", C.c_void_p), ("bias", C.c_void_p),
         ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
         ("delta", C.c_void_p), ("dbias", C.c_void_p), ("ksplit", C.c_int32), ("ws", C.c_void_p),
-        ("drop", Dropout), ("drop_bmod", C.c_int32),
+        ("drop", Dropout), ("drop_bmod", C.c_int32), ("proj", AttnProj),
     ]
 
 

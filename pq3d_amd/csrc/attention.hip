@@ -833,6 +833,7 @@ extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
   const bool x3 = d.ct == PQ3D_BF16X3;
   if (x3) d.ct = PQ3D_F32;
   if (int e = check_desc(d)) return e;
+  PQ_CHECK_ARG(d.proj.mode == PQ3D_ATTN_PROJ_NONE, "pq3d_attn_fwd: proj.mode not supported in the forward");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (x3 && g_sa && pq3d_attn_sa_try(d, s, false)) { PQ_LAUNCH_CHECK(); return 0; }
@@ -847,11 +848,18 @@ extern "C" int pq3d_attn_bwd(const pq3d_attn_desc* dp, void* stream) {
   const bool x3 = d.ct == PQ3D_BF16X3;
   if (x3) d.ct = PQ3D_F32;
   if (int e = check_desc(d)) return e;
-  PQ_CHECK_ARG(d.dout && d.dq && d.dk && d.dv && d.delta, "pq3d_attn_bwd: null dout/dq/dk/dv/delta");
+  const bool fold = d.proj.mode == PQ3D_ATTN_PROJ_DOUT;
+  PQ_CHECK_ARG(d.proj.mode == PQ3D_ATTN_PROJ_NONE || fold, "pq3d_attn_bwd: unknown proj.mode");
+  PQ_CHECK_ARG((d.dout || fold) && d.dq && d.dk && d.dv && d.delta, "pq3d_attn_bwd: null dout/dq/dk/dv/delta");
   PQ_CHECK_ARG((((uintptr_t)d.dout) & 15) == 0, "pq3d_attn_bwd: dout must be 16-byte aligned");
+  if (fold) PQ_CHECK_ARG(d.proj.x && d.proj.w[0] && d.proj.dm == d.H * d.dh && (d.proj.dm % 32) == 0 &&
+                             ((((uintptr_t)d.proj.x) | ((uintptr_t)d.proj.w[0])) & 15) == 0,
+                         "pq3d_attn_bwd: proj (DOUT) needs x, w[0] (16-byte aligned) and dm = H * dh, a multiple of 32");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (x3 && g_sa && pq3d_attn_sa_try(d, s, true)) { PQ_LAUNCH_CHECK(); return 0; }
+  PQ_CHECK_ARG(!fold, "pq3d_attn_bwd: proj is served by the split-bf16 self-attention kernels only (PQ3D_BF16X3, d_h = 32, "
+                      "<= 240 tokens, within LDS): not this call -- run the projection as its own pq3d_gemm");
   if (g_small && pq3d_attn_small_try(d, s, true)) { PQ_LAUNCH_CHECK(); return 0; }
   DISPATCH(launch_bwd)
 }

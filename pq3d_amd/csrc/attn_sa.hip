@@ -18,6 +18,7 @@
 //     one writer; S and dP are formed twice (a few hundred MFMAs per wave).
 // zero_attn, 3-D masks and attention dropout stay on the general kernels.
 #include <atomic>
+#include <cstdlib>
 
 #include "attn_common.h"
 #include "gemm_common.h"
@@ -128,15 +129,38 @@ PQ_DEV SaLds carve(unsigned char* sm, int LPq, int LPk, bool bwd) {
   s.dl = s.lse + LPq;
   return s;
 }
-size_t sa_lds_bytes(int Lq, int Lk, bool bwd) {
+size_t sa_lds_bytes(int Lq, int Lk, bool bwd, int dm_fold = 0) {
   const size_t LPq = (Lq + 15) & ~15, LPk = (Lk + 31) & ~31;
-  return ((bwd ? 4 : 2) * LPq + 4 * LPk) * LDH * sizeof(bf16_t) + (LPk + 2 * LPq) * sizeof(float) + 16;
+  return ((bwd ? 4 : 2) * LPq + 4 * LPk + dm_fold) * LDH * sizeof(bf16_t) + (LPk + 2 * LPq) * sizeof(float) + 16;
+}
+
+// fp32 weight slice [rows][DH] (row stride sl) -> single bf16 plane [rows][LDH] (k-major tile of a folded projection)
+PQ_DEV void stage_wslice(bf16_t* dst, const float* src, long sl, int rows, int tid, int nthr) {
+  const int nch = rows * (DH / 8);
+  for (int base = tid; base < nch; base += nthr * 2) {
+    float4 a[2], b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = min(base + u * nthr, nch - 1);
+      const float* p = src + (long)(c / (DH / 8)) * sl + (c % (DH / 8)) * 8;
+      a[u] = *(const float4*)p;
+      b[u] = *(const float4*)(p + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = base + u * nthr;
+      if (c < nch) {
+        const float v[8] = {a[u].x, a[u].y, a[u].z, a[u].w, b[u].x, b[u].y, b[u].z, b[u].w};
+        *(u32x4*)&dst[(c / (DH / 8)) * LDH + (c % (DH / 8)) * 8] = pack_frag<bf16_t>(v);
+      }
+    }
+  }
 }
 
 // 4 consecutive bias values bias[row][c .. c + 3] (c % 4 == 0), 0 beyond the row / matrix
-PQ_DEV void bias4(const float* bias, int row, int c, int Lq, int Lk, bool vec, float* out) {
+PQ_DEV void bias4(const float* bias, int row, int c, int Lq, int Lk, bool vec, float* out, int stride = 0) {
   if (!bias || row >= Lq) { out[0] = out[1] = out[2] = out[3] = 0.f; return; }
-  const float* p = bias + (long)row * Lk + c;
+  const float* p = bias + (long)row * (stride ? stride : Lk) + c;
   if (vec && c + 3 < Lk) { const float4 t = *(const float4*)p; out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w; }
   else {
 #pragma unroll
@@ -144,6 +168,34 @@ PQ_DEV void bias4(const float* bias, int row, int c, int Lq, int Lk, bool vec, f
   }
 }
 
+// Option (PQ3D_SA_BIAS_LDS=1, off by default): the additive bias [Lq][Lk] of the head is copied into LDS by coalesced row
+// loads issued with the operand loads (template BL) and the key loops read it with LDS latency.  Background (in-kernel
+// timeline, tools/probes/sa_timeline.py, config 2): straight from global memory every 32-key step of the backward waits
+// ~0.4 us on its 8 bias values per lane although they are requested one step ahead (1.1 us per step, 0.7 of it
+// arithmetic).  The bias is HBM-cold when the layer's attention runs (written at the start of the step, 100+ launches
+// earlier), so whatever requests it earlier pays the same ~2 us in front of the operand staging instead (loads return in
+// order): requesting 4 steps ahead and this LDS copy both shortened the key loops (phase A 4.6 -> 3.6 us) and lengthened
+// the staging by more (2.4 -> 4.0 us): 17.6 -> 19-21 us per backward launch, 8.9 -> 10.6 forward.  Kept as an option.
+// Row stride: Lk, + 4 floats when Lk % 8 == 0 (16 rows of a 16-byte column read would otherwise share their banks).
+PQ_DEV int bias_lds_stride(int Lk) { return (Lk & 7) == 0 ? Lk + 4 : Lk; }
+PQ_DEV void stage_bias(float* dst, const float* src, int Lq, int Lk, int tid, int nthr) {   // Lk % 4 == 0, src 16-byte aligned
+  const int r4 = Lk >> 2, n4 = Lq * r4, bst = bias_lds_stride(Lk);
+  for (int base = tid; base < n4; base += nthr * 4) {
+    float4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = min(base + u * nthr, n4 - 1);
+      t[u] = *(const float4*)(src + (long)(c / r4) * Lk + (c % r4) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = base + u * nthr;
+      if (c < n4) *(float4*)&dst[(c / r4) * bst + (c % r4) * 4] = t[u];
+    }
+  }
+}
+
+template <bool BL>
 __global__ __launch_bounds__(1024) void attn_sa_fwd_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   extern __shared__ __attribute__((aligned(16))) unsigned char sa_sm[];
@@ -154,6 +206,9 @@ __global__ __launch_bounds__(1024) void attn_sa_fwd_kernel(const pq3d_attn_desc 
   const float* q = (const float*)d.q + (long)b * d.q_sb + (long)h * d.q_sh;
   const float* k = (const float*)d.k + (long)b * d.k_sb + (long)h * d.k_sh;
   const float* v = (const float*)d.v + (long)b * d.v_sb + (long)h * d.v_sh;
+  const float* gbias = d.bias ? d.bias + ((long)b * d.H + h) * Lq * (long)Lk : nullptr;
+  float* const Bs = S.dl + LPq;   // BL: the head's bias tile
+  if constexpr (BL) stage_bias(Bs, gbias, Lq, Lk, tid, nthr);
   stage_planes<2>(S.Qh, S.Ql, q, d.q_sl, Lq, LPq, tid, nthr);
   stage_planes<2>(S.Kh, S.Kl, k, d.k_sl, Lk, LPk, tid, nthr);
   stage_planes<2>(S.Vh, S.Vl, v, d.v_sl, Lk, LPk, tid, nthr);
@@ -162,21 +217,23 @@ __global__ __launch_bounds__(1024) void attn_sa_fwd_kernel(const pq3d_attn_desc 
   const int q0 = wave * 16;
   if (q0 >= LPq) return;
   const int qrow = q0 + li;                       // this lane's query (column of the transposed score tiles)
-  const float* bias = d.bias ? d.bias + ((long)b * d.H + h) * Lq * (long)Lk : nullptr;
-  const bool bvec = (Lk & 3) == 0 && ((((uintptr_t)bias) & 15) == 0);
+  const float* bias;
+  int bst = 0;
+  if constexpr (BL) { bias = Bs; bst = bias_lds_stride(Lk); } else bias = gbias;
+  const bool bvec = BL || ((Lk & 3) == 0 && ((((uintptr_t)bias) & 15) == 0));
   const HL qf = frag_rm(S.Qh, S.Ql, qrow, lg);
   float m_run = -INFINITY, l_run = 0.f;
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};   // O^T: rows d_h 4 lg + r (+16), column = query
   float bn[8];
-  bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn);
-  bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4);
+  bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn, bst);
+  bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4, bst);
   for (int t0 = 0; t0 < LPk; t0 += 32) {
     float bc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bc[j] = bn[j];
     if (t0 + 32 < LPk) {   // next pair's bias in flight during this pair's arithmetic
-      bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn);
-      bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4);
+      bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn, bst);
+      bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4, bst);
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     mma3(s0, frag_rm(S.Kh, S.Kl, t0 + li, lg), qf);
@@ -212,6 +269,16 @@ __global__ __launch_bounds__(1024) void attn_sa_fwd_kernel(const pq3d_attn_desc 
   }
 }
 
+// in-kernel timeline (probe builds only, tools/probes/sa_timeline.py): wave 0 of workgroup (0, 0) stamps the 100 MHz clock
+#ifdef PQ3D_SA_TIMELINE
+#define SA_TL(i) do { if (d.ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ((long long*)d.ws)[i] = wall_clock64(); } while (0)
+#define SA_TLV(i, val) do { float x_ = (val); asm volatile("v_mov_b32 %0, %0" : "+v"(x_)); SA_TL(i); } while (0)   // after `val` exists
+#else
+#define SA_TL(i) do { } while (0)
+#define SA_TLV(i, val) do { } while (0)
+#endif
+
+template <bool BL>
 __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   ATTN_KARG_PIN_BWD(d);
@@ -226,12 +293,103 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
   const float* o = (const float*)d.o + (long)b * d.o_sb + (long)h * d.o_sh;
   const float* g = (const float*)d.dout + (long)b * d.o_sb + (long)h * d.o_sh;
   const long sbase = ((long)b * d.H + h) * Lq;
+  SA_TL(0);
+  // folded out-projection backward (pq3d_attn_proj, DOUT): dO of this head is formed here from the gradient of the
+  // projection's output and the head's 32 columns of the weight (staged k-major as one bf16 plane behind the float arrays)
+  const bool fold = d.proj.mode == PQ3D_ATTN_PROJ_DOUT;
+  bf16_t* const Wt = (bf16_t*)(S.dl + LPq2);
+  float* const Bs = (float*)(Wt + (fold ? d.proj.dm * LDH : 0));   // BL: the head's bias tile (see attn_sa_fwd_kernel)
+  const float* gbias = d.bias ? d.bias + ((long)b * d.H + h) * Lq * (long)Lk : nullptr;
+  // folded projection: the gradient rows of this wave's first query block (dm = 256: all 8 k steps), its O row and lse are
+  // requested before anything waits -- they are back by the time the weight slice is staged
+  float4 xea[8], xeb[8], oe0 = {0.f, 0.f, 0.f, 0.f}, oe1 = {0.f, 0.f, 0.f, 0.f};
+  float lse_e = 0.f;
+  const bool early = fold && d.proj.dm == 256 && wave * 16 < Lq;   // uniform per wave
+  if (early) {
+    const int qr = min(wave * 16 + li, Lq - 1);
+    const float* px = d.proj.x + ((long)b * Lq + qr) * 256 + lg * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { xea[u] = *(const float4*)(px + u * 32); xeb[u] = *(const float4*)(px + u * 32 + 4); }
+    const float* po = o + (long)qr * d.o_sl;
+    oe0 = *(const float4*)(po + 4 * lg);
+    oe1 = *(const float4*)(po + 16 + 4 * lg);
+    lse_e = d.lse[sbase + qr];
+  }
+  if (fold) stage_wslice(Wt, d.proj.w[0] + h * DH, d.proj.dm, d.proj.dm, tid, nthr);
+  if constexpr (BL) stage_bias(Bs, gbias, Lq, Lk, tid, nthr);
   stage_planes<2>(S.Qh, S.Ql, q, d.q_sl, Lq, LPq2, tid, nthr);
-  stage_planes<2>(S.Gh, S.Gl, g, d.o_sl, Lq, LPq2, tid, nthr);
+  if (!fold) stage_planes<2>(S.Gh, S.Gl, g, d.o_sl, Lq, LPq2, tid, nthr);
   stage_planes<2>(S.Kh, S.Kl, k, d.k_sl, Lk, LPk, tid, nthr);
   stage_planes<2>(S.Vh, S.Vl, v, d.v_sl, Lk, LPk, tid, nthr);
   for (int j = tid; j < LPk; j += nthr) S.kb[j] = (j < Lk && !(d.kpm && d.kpm[(long)b * Lk + j])) ? 0.f : -INFINITY;
-  for (int i = tid; i < LPq2; i += nthr) {   // lse and delta = rowsum(dO * O) of every query
+  SA_TL(1);
+  if (fold) {
+    __syncthreads();   // weight slice staged
+    SA_TL(2);
+    const int dm = d.proj.dm, nks = dm >> 5;
+    const float* gx = d.proj.x + (long)b * Lq * dm;
+    for (int rb = wave; rb * 16 < LPq2; rb += nthr >> 6) {
+      // dO^T tile = W_slice^T (A: d_h index x out index, transposing read of the k-major plane) . x^T (B: lane = query,
+      // 8 consecutive out indices straight from the row-major gradient rows): 4 consecutive d_h values per lane and tile
+      const int qrow = rb * 16 + li;
+      const bool ok = qrow < Lq;
+      const float* px = gx + (long)min(qrow, Lq - 1) * dm + lg * 8;
+      f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+      const bool pre = early && rb == wave;   // uniform: the rows are already in registers
+      if (pre) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float xv[8] = {xea[u].x, xea[u].y, xea[u].z, xea[u].w, xeb[u].x, xeb[u].y, xeb[u].z, xeb[u].w};
+          const u32x4 bf = pack_frag<bf16_t>(xv);
+          Mma<bf16_t>::mma(g0, km_frag(Wt, LDH, 0, u, li, lg), bf);
+          Mma<bf16_t>::mma(g1, km_frag(Wt, LDH, 16, u, li, lg), bf);
+        }
+      }
+      for (int ks0 = 0; ks0 < ((!pre && rb * 16 < Lq) ? nks : 0); ks0 += 4) {   // padding blocks: zeros, no loads
+        float4 xa[4], xb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ks = min(ks0 + u, nks - 1);
+          xa[u] = *(const float4*)(px + ks * 32);
+          xb[u] = *(const float4*)(px + ks * 32 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (ks0 + u < nks) {   // uniform
+            const float xv[8] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w, xb[u].x, xb[u].y, xb[u].z, xb[u].w};
+            const u32x4 bf = pack_frag<bf16_t>(xv);
+            Mma<bf16_t>::mma(g0, km_frag(Wt, LDH, 0, ks0 + u, li, lg), bf);
+            Mma<bf16_t>::mma(g1, km_frag(Wt, LDH, 16, ks0 + u, li, lg), bf);
+          }
+        }
+      }
+      float gv[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { gv[j] = ok ? g0[j] : 0.f; gv[4 + j] = ok ? g1[j] : 0.f; }
+      const HL gs = split8(gv);
+      *(u32x2*)&S.Gh[qrow * LDH + 4 * lg] = (u32x2){gs.hi[0], gs.hi[1]};
+      *(u32x2*)&S.Gh[qrow * LDH + 16 + 4 * lg] = (u32x2){gs.hi[2], gs.hi[3]};
+      *(u32x2*)&S.Gl[qrow * LDH + 4 * lg] = (u32x2){gs.lo[0], gs.lo[1]};
+      *(u32x2*)&S.Gl[qrow * LDH + 16 + 4 * lg] = (u32x2){gs.lo[2], gs.lo[3]};
+      float s = 0.f, l = INFINITY;
+      if (ok) {
+        const float* po = o + (long)qrow * d.o_sl;
+        const float4 t0 = pre ? oe0 : *(const float4*)(po + 4 * lg), t1 = pre ? oe1 : *(const float4*)(po + 16 + 4 * lg);
+        s = ((gv[0] * t0.x + gv[1] * t0.y) + (gv[2] * t0.z + gv[3] * t0.w)) + ((gv[4] * t1.x + gv[5] * t1.y) + (gv[6] * t1.z + gv[7] * t1.w));
+      }
+      s = xrow_sum(s);
+      if (lg == 0) {
+        if (ok) {
+          l = pre ? lse_e : d.lse[sbase + qrow];
+          d.delta[sbase + qrow] = s;
+          if (l == -INFINITY) l = INFINITY;
+        }
+        S.dl[qrow] = s;
+        S.lse[qrow] = l;
+      }
+    }
+  }
+  for (int i = tid; i < (fold ? 0 : LPq2); i += nthr) {   // lse and delta = rowsum(dO * O) of every query
     float s = 0.f, l = INFINITY;             // padded queries: lse = +inf -> P = 0
     if (i < Lq) {
 #pragma unroll
@@ -246,10 +404,15 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
     S.dl[i] = s;
     S.lse[i] = l;
   }
+  SA_TL(3);
   __syncthreads();
-  const float* bias = d.bias ? d.bias + ((long)b * d.H + h) * Lq * (long)Lk : nullptr;
+  SA_TL(4);
+  const float* bias;
+  int bst = 0;
+  if constexpr (BL) { bias = Bs; bst = bias_lds_stride(Lk); } else bias = gbias;
   float* dbias = d.dbias ? d.dbias + ((long)b * d.H + h) * Lq * (long)Lk : nullptr;
-  const bool bvec = (Lk & 3) == 0 && ((((uintptr_t)bias) | ((uintptr_t)dbias)) & 15) == 0;
+  const bool bvec = BL || ((Lk & 3) == 0 && ((((uintptr_t)bias)) & 15) == 0);
+  const bool dvec = (Lk & 3) == 0 && ((((uintptr_t)dbias)) & 15) == 0;
   // ---------------- phase A: wave = query block; transposed tiles (lane = query column, 4 keys per tile per lane)
   const int q0 = wave * 16;
   if (q0 < LPq) {
@@ -258,21 +421,23 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
     const float lse = S.lse[qrow], dlt = S.dl[qrow];
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};   // dQ^T
     float bn[8];
-    bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn);
-    bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4);
+    bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn, bst);
+    bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4, bst);
     for (int t0 = 0; t0 < LPk; t0 += 32) {
       float bc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) bc[j] = bn[j];
       if (t0 + 32 < LPk) {
-        bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn);
-        bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4);
+        bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn, bst);
+        bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4, bst);
       }
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+      if (t0 == 0) SA_TLV(8, bc[0] + bc[7]);
       mma3(s0, frag_rm(S.Kh, S.Kl, t0 + li, lg), qf);
       mma3(s1, frag_rm(S.Kh, S.Kl, t0 + 16 + li, lg), qf);
       mma3(p0, frag_rm(S.Vh, S.Vl, t0 + li, lg), gf);           // dP^T = V dO^T
       mma3(p1, frag_rm(S.Vh, S.Vl, t0 + 16 + li, lg), gf);
+      if (t0 == 0) SA_TLV(9, s0[0] + s1[0] + p0[0] + p1[0]);
       const float4 kb0 = *(const float4*)&S.kb[t0 + 4 * lg], kb1 = *(const float4*)&S.kb[t0 + 16 + 4 * lg];
       const float kbv[8] = {kb0.x, kb0.y, kb0.z, kb0.w, kb1.x, kb1.y, kb1.z, kb1.w};
       float ds[8];
@@ -287,16 +452,19 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
         for (int hh = 0; hh < 2; ++hh) {
           const int c = t0 + 16 * hh + 4 * lg;
           float* p = dbias + (long)qrow * Lk + c;
-          if (bvec && c + 3 < Lk) *(float4*)p = make_float4(ds[4 * hh], ds[4 * hh + 1], ds[4 * hh + 2], ds[4 * hh + 3]);
+          if (dvec && c + 3 < Lk) *(float4*)p = make_float4(ds[4 * hh], ds[4 * hh + 1], ds[4 * hh + 2], ds[4 * hh + 3]);
           else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (c + j < Lk) p[j] = ds[4 * hh + j];
           }
         }
       }
+      if (t0 == 0) SA_TLV(10, ds[0] + ds[7]);
       const HL df = split8(ds);
       mma3(a0, frag_tr(S.Kh, S.Kl, t0, t0 + 16, 0, li, lg), df);   // dQ^T += K^T dS^T
       mma3(a1, frag_tr(S.Kh, S.Kl, t0, t0 + 16, 16, li, lg), df);
+      if (t0 == 0) SA_TLV(11, a0[0] + a1[0]);
+      if (t0 == 32) SA_TLV(12, a0[0] + a1[0]);
     }
     if (qrow < Lq) {
       float* dq = (float*)d.dq + (long)b * d.q_sb + (long)h * d.q_sh + (long)qrow * d.q_sl;
@@ -304,6 +472,7 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
       *(float4*)(dq + 16 + 4 * lg) = make_float4(a1[0] * d.scale, a1[1] * d.scale, a1[2] * d.scale, a1[3] * d.scale);
     }
   }
+  SA_TL(5);
   // ---------------- phase B: wave = key block; plain tiles (lane = key column, 4 queries per tile per lane)
   const int k0 = wave * 16;
   if (k0 >= ((Lk + 15) & ~15)) return;
@@ -317,7 +486,7 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int qr = t0 + (j < 4 ? 0 : 16) + 4 * lg + (j & 3);
-      bc[j] = (bias && qr < Lq && krow < Lk) ? bias[(long)qr * Lk + krow] : 0.f;
+      bc[j] = (bias && qr < Lq && krow < Lk) ? bias[(long)qr * (BL ? bst : Lk) + krow] : 0.f;
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
     mma3(s0, frag_rm(S.Qh, S.Ql, t0 + li, lg), kf);             // S = Q K^T
@@ -341,6 +510,7 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
     mma3(dk0, frag_tr(S.Qh, S.Ql, t0, t0 + 16, 0, li, lg), df);   // dK^T += Q^T dS
     mma3(dk1, frag_tr(S.Qh, S.Ql, t0, t0 + 16, 16, li, lg), df);
   }
+  SA_TL(6);
   if (krow < Lk) {
     float* dk = (float*)d.dk + (long)b * d.k_sb + (long)h * d.k_sh + (long)krow * d.k_sl;
     float* dv = (float*)d.dv + (long)b * d.v_sb + (long)h * d.v_sh + (long)krow * d.v_sl;
@@ -349,6 +519,7 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
     *(float4*)(dv + 4 * lg) = make_float4(dv0[0], dv0[1], dv0[2], dv0[3]);
     *(float4*)(dv + 16 + 4 * lg) = make_float4(dv1[0], dv1[1], dv1[2], dv1[3]);
   }
+  SA_TL(7);
 }
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -364,18 +535,25 @@ bool pq3d_attn_sa_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd) {
   // 16-byte row accesses: strides and bases of q / k / v / o (/ their gradients)
   if ((d.q_sl | d.k_sl | d.v_sl | d.o_sl | d.q_sb | d.k_sb | d.v_sb | d.o_sb | d.q_sh | d.k_sh | d.v_sh | d.o_sh) & 3) return false;
   if (!al16(d.q) || !al16(d.k) || !al16(d.v) || !al16(d.o)) return false;
-  if (bwd && !(d.dout && d.dq && d.dk && d.dv && d.delta && al16(d.dout) && al16(d.dq) && al16(d.dk) && al16(d.dv))) return false;
-  const size_t lds = sa_lds_bytes(bwd ? ((d.Lq + 31) & ~31) : d.Lq, d.Lk, bwd);
+  const bool fold = bwd && d.proj.mode == PQ3D_ATTN_PROJ_DOUT;
+  if (bwd && !((d.dout || fold) && d.dq && d.dk && d.dv && d.delta && al16(d.dout) && al16(d.dq) && al16(d.dk) && al16(d.dv))) return false;
+  if (fold && (d.proj.dm != d.H * DH || (d.o_sl & 3))) return false;
+  size_t lds = sa_lds_bytes(bwd ? ((d.Lq + 31) & ~31) : d.Lq, d.Lk, bwd, fold ? d.proj.dm : 0);
   if (lds > 160 * 1024) return false;
+  // the bias tile in LDS when it fits and its rows can be copied in 16-byte pieces
+  const size_t bias_bytes = (size_t)d.Lq * ((d.Lk & 7) == 0 ? d.Lk + 4 : d.Lk) * sizeof(float);
+  static const bool want_bl = [] { const char* e = getenv("PQ3D_SA_BIAS_LDS"); return e && e[0] == '1'; }();
+  const bool bl = want_bl && d.bias && (d.Lk & 3) == 0 && al16(d.bias) && lds + bias_bytes <= 160 * 1024;
+  if (bl) lds += bias_bytes;
   const int blocks = (max(d.Lq, d.Lk) + 15) / 16;
-  if (bwd) {
-    static std::atomic<unsigned> done{0};
-    if (pq3d_enable_big_lds(attn_sa_bwd_kernel, 160 * 1024, done)) { (void)hipGetLastError(); return false; }
-    hipLaunchKernelGGL(attn_sa_bwd_kernel, dim3(d.H, d.B), dim3(blocks * 64), lds, s, d);
-  } else {
-    static std::atomic<unsigned> done{0};
-    if (pq3d_enable_big_lds(attn_sa_fwd_kernel, 160 * 1024, done)) { (void)hipGetLastError(); return false; }
-    hipLaunchKernelGGL(attn_sa_fwd_kernel, dim3(d.H, d.B), dim3(blocks * 64), lds, s, d);
-  }
+#define SA_LAUNCH(KERN)                                                                              \
+  do {                                                                                               \
+    static std::atomic<unsigned> done{0};                                                            \
+    if (pq3d_enable_big_lds(KERN, 160 * 1024, done)) { (void)hipGetLastError(); return false; }      \
+    hipLaunchKernelGGL(KERN, dim3(d.H, d.B), dim3(blocks * 64), lds, s, d);                          \
+  } while (0)
+  if (bwd) { if (bl) SA_LAUNCH(attn_sa_bwd_kernel<true>); else SA_LAUNCH(attn_sa_bwd_kernel<false>); }
+  else { if (bl) SA_LAUNCH(attn_sa_fwd_kernel<true>); else SA_LAUNCH(attn_sa_fwd_kernel<false>); }
+#undef SA_LAUNCH
   return true;
 }

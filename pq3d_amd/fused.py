@@ -259,7 +259,9 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
 
 
 def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None, bias=None, mask_bmod=0, bwd=None,
-          drop=None, drop_bmod=0):
+          drop=None, drop_bmod=0, proj_dout=None):
+    """proj_dout = (g, W): backward only -- dO = g W is formed inside the attention kernel (pq3d_attn_proj, DOUT) and
+    bwd[0] is ignored; the caller checks sa_fold_ok() first."""
     d = ops._attn_desc(q, k, v, o, lse, H, ct, zero_attn, 1.0 / math.sqrt(q.shape[-1] // H), kpm, mask, row_open, bias,
                        drop, drop_bmod, bwd=bwd is not None)
     d.mask_bmod = mask_bmod
@@ -271,8 +273,27 @@ def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None,
                       L.lib().pq3d_attn_fwd, C.byref(d), L.stream()), "pq3d_attn_fwd")
     else:
         d.dout, d.dq, d.dk, d.dv, d.delta, d.dbias = map(L.ptr, bwd)
+        if proj_dout is not None:
+            d.proj.mode, d.proj.dm, d.proj.x = 2, dm, L.ptr(proj_dout[0])
+            d.proj.w[0] = L.ptr(proj_dout[1])
         L.check(timed("pq3d_attn_bwd", key, 8.0 * B * Lq * Lk * dm, (q.numel() * 3 + k.numel() * 4) * q.element_size(),
                       L.lib().pq3d_attn_bwd, C.byref(d), L.stream()), "pq3d_attn_bwd")
+
+
+SA_FOLD = os.environ.get("PQ3D_SA_FOLD", "1") != "0"   # fold the self-attention out-projection backward into the kernel
+
+
+def sa_fold_ok(ct, B, H, L_, dm, drop, df, W) -> bool:
+    """The split-bf16 self-attention backward kernel can form dO itself (attn_sa.hip): its shape limits + 160 KB of LDS."""
+    if not SA_FOLD or ops.sa_ct(ct) != L.BF16X3 or dm != 32 * H or dm % 32 or drop is not None:
+        return False
+    if df.dtype != torch.float32 or W.dtype != torch.float32 or not df.is_contiguous() or not W.is_contiguous():
+        return False
+    if (df.data_ptr() | W.data_ptr()) & 15 or os.environ.get("PQ3D_ATTN_SA", "1") == "0":
+        return False
+    lp2, lpk = (L_ + 31) & ~31, (L_ + 31) & ~31
+    lds = (4 * lp2 + 4 * lpk + dm) * 40 * 2 + (lpk + 2 * lp2) * 4 + 16
+    return L_ <= 240 and lds <= 160 * 1024
 
 
 class _FusedDecoder(Function):
@@ -768,15 +789,19 @@ class _FusedDecoder(Function):
                                rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)],
                                drop=rec["dr_sr"])
             df = df[0]
-            do_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-            L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+            fold = sa_fold_ok(ct, B, H, Nq, d, rec["dr_sa"], df, Wo)
+            do_s = None
+            if not fold:
+                do_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
             dwq.add([df], [rec["o_s"]], None, [GWo], ct, [Gbo])
             qkv = rec["qkv"]
             dqkv = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
             delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
             dsb = torch.empty_like(rec["sbias"]) if spec.spatial else None
             _attn(qkv[0], qkv[1], qkv[2], rec["o_s"], rec["lse_s"], H, ops.sa_ct(ct), False, kpm=qmask, bias=rec["sbias"],
-                  bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb), drop=rec["dr_sa"])
+                  bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb), drop=rec["dr_sa"],
+                  proj_dout=(df, Wo) if fold else None)
             if spec.spatial:   # deferred: one grouped launch for all layer applications at the end of the backward
                 sb_queue.append((msa.pairwise_loc_fc.weight.detach(), msa.pairwise_loc_fc.bias.detach(), dsb,
                                  G(msa.pairwise_loc_fc.weight), G(msa.pairwise_loc_fc.bias)))

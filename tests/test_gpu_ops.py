@@ -863,3 +863,40 @@ def test_launch_merges_pair_kernels_and_summed_layernorm_gradient():
     for i in range(3):
         ref = A[i].double() @ W[i].double() + (aux.double() if i == 2 else 0)
         torch.testing.assert_close(out[i].double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Lq,H,mode", [(100, 8, "bias"), (100, 8, "kpm"), (77, 4, "kpm"), (130, 2, "bias"), (16, 8, "kpm")])
+def test_attention_self_backward_with_folded_out_projection(Lq, H, mode):
+    """pq3d_attn_proj DOUT: dO = g W formed inside the split-bf16 self-attention backward equals the separate
+    single-bf16 product followed by the plain backward call (same arithmetic: bf16 operands, fp32 accumulate)."""
+    from pq3d_amd import fused
+    dh, B = 32, 3
+    d = H * dh
+    q, k, v = (rnd(B, Lq, d, seed=s).to(DEV) for s in (1, 2, 3))
+    kpm = (torch.arange(Lq)[None, :] >= torch.tensor([Lq, max(1, Lq // 2), max(1, Lq - 3)])[:, None]).to(DEV)
+    bias = torch.randn(B, H, Lq, Lq, generator=torch.Generator().manual_seed(5)).to(DEV) if mode == "bias" else None
+    g, W = rnd(B, Lq, d, seed=7).to(DEV), (rnd(d, d, seed=8) * 0.06).to(DEV)
+    o, lse = torch.empty_like(q), torch.empty(B, H, Lq, device=DEV)
+    fused._attn(q, k, v, o, lse, H, L.BF16X3, False, kpm=kpm, bias=bias)
+    assert fused.sa_fold_ok(BF16, B, H, Lq, d, None, g, W)
+    outs = []
+    for fold in (False, True):
+        dqkv = torch.empty(3, B, Lq, d, device=DEV)
+        delta = torch.empty(B, H, Lq, device=DEV)
+        dsb = torch.empty_like(bias) if bias is not None else None
+        do = None
+        if not fold:
+            do = torch.empty(B, Lq, d, device=DEV)
+            L.gemm(M=B * Lq, N=d, K=d, A=[g], B=[W], Cs=[do], ct=BF16, lda=d, ldb=d, ldc=d, transB=True)
+        fused._attn(q, k, v, o, lse, H, L.BF16X3, False, kpm=kpm, bias=bias, bwd=(do, dqkv[0], dqkv[1], dqkv[2], delta, dsb),
+                    proj_dout=(g, W) if fold else None)
+        outs.append((dqkv, delta, dsb))
+    for name, a, b in zip(("dqkv", "delta", "dbias"), outs[1], outs[0]):
+        if a is not None:
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6 * float(b.abs().max()), msg=lambda m: f"{name}: {m}")
+    # a call the split-bf16 kernels do not take is refused, loudly, without a launch
+    dqkv = torch.empty(3, B, Lq, d, device=DEV)
+    with pytest.raises(L.Pq3dError, match="proj"):
+        fused._attn(q, k, v, o, lse, H, F32, False, kpm=kpm, bias=bias,
+                    bwd=(None, dqkv[0], dqkv[1], dqkv[2], torch.empty(B, H, Lq, device=DEV), None), proj_dout=(g, W))
