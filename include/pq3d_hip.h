@@ -180,6 +180,31 @@ int pq3d_gemm_set_wk(int options, int max_m);
  * Backward (pq3d_attn_bwd) recomputes P from lse: needs o, do; writes dq/dk/dv with the strides of q/k/v,
  * `delta` is a [B,H,Lq] fp32 workspace, dbias ([B,H,Lq,Lk] fp32, may be NULL) receives dL/dbias.
  * ------------------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------------------
+ * The decoder's feed-forward sublayer in one launch (FFNLayer, query_encoder.py:371-388):
+ *     h = dropout(act(x W1^T + b1))      [R, F]  (and `pre`, the pre-activation, when the activation is GELU)
+ *     zp[s] = h[:, s*256:(s+1)*256] W2[:, s*256:(s+1)*256]^T  (+ b2 in slice 0)      s = 0 .. F/256 - 1,  [R, d] each
+ * -- the F/256 PARTIAL sums of linear2, to be added in index order by the LayerNorm that follows (pq3d_add_ln_fwd with
+ * sum_branches: y = LN(x + dropout(sum_s zp[s]))).  fp32 tensors, split-bf16 products (PQ3D_BF16X3 arithmetic);
+ * d = 256, F a multiple of 256 (<= 32 slices); every pointer 16-byte aligned.  The inner dropout site is h viewed as
+ * [R, F] (the site pq3d_gemm's epilogue uses for the same tensor, so pq3d_gemm regenerates this mask in the backward).
+ * csrc/ffn.hip.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t R, d, F;
+  int32_t act;              /* PQ3D_ACT_RELU / PQ3D_ACT_GELU */
+  const float* x;           /* [R, d] */
+  const float* w1;          /* [F, d]  linear1.weight */
+  const float* b1;          /* [F] */
+  const float* w2;          /* [d, F]  linear2.weight */
+  const float* b2;          /* [d] or NULL */
+  float* h;                 /* [R, F] out */
+  float* pre;               /* [R, F] out or NULL */
+  float* zp;                /* [F/256, R, d] out */
+  pq3d_dropout drop;        /* inner dropout (p = 0 / seed NULL: off) */
+} pq3d_ffn_desc;
+int pq3d_ffn_fwd(const pq3d_ffn_desc* d, void* stream);
+
 /* Projection folded into an attention launch (the split-bf16 self-attention kernels only: compute type PQ3D_BF16X3,
  * d_h = 32, at most 240 queries / keys; any other call with mode != 0 is refused with an error, nothing is launched).
  *   PQ3D_ATTN_PROJ_DOUT (backward): the out-projection's input gradient is formed in the kernel,

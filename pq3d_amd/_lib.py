@@ -118,6 +118,12 @@ class GemmDesc(C.Structure):
     ]
 
 
+class FfnDesc(C.Structure):
+    _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32), ("act", C.c_int32), ("x", C.c_void_p), ("w1", C.c_void_p),
+                ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("h", C.c_void_p), ("pre", C.c_void_p),
+                ("zp", C.c_void_p), ("drop", Dropout)]
+
+
 class AttnProj(C.Structure):
     _fields_ = [("mode", C.c_int32), ("dm", C.c_int32), ("x", C.c_void_p), ("x2", C.c_void_p), ("w", C.c_void_p * 3),
                 ("b", C.c_void_p * 3)]
@@ -158,6 +164,7 @@ _lib = None
 _SIGS = {
     "pq3d_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "pq3d_gemm_set_wk": [C.c_int, C.c_int],
+    "pq3d_ffn_fwd": [C.POINTER(FfnDesc), C.c_void_p],
     "pq3d_attn_fwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_attn_bwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],

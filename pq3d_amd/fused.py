@@ -280,6 +280,34 @@ def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None,
                       L.lib().pq3d_attn_bwd, C.byref(d), L.stream()), "pq3d_attn_bwd")
 
 
+# the feed-forward sublayer's two products as one launch (csrc/ffn.hip).  Off by default: correct (tests/test_gpu_ops.py) but
+# 34 us against 11 + 13 for the two grouped products at config 2 (same-box A/B, step +35 us) -- see the header of ffn.hip
+FFN_FUSE = os.environ.get("PQ3D_FFN_FUSE", "0") != "0"
+
+
+def ffn_fused_ok(cq, d, F_, x, w1, b1, w2, b2) -> bool:
+    ts = [x, w1, b1, w2] + ([b2] if b2 is not None else [])
+    return (FFN_FUSE and cq == L.BF16X3 and d == 256 and F_ % 256 == 0 and F_ // 256 <= L.MAXG
+            and all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts))
+
+
+def ffn_fwd(x, w1, b1, w2, b2, act, drop, want_pre):
+    """pq3d_ffn_fwd: returns (h [.., F], pre or None, zp [F/256, .., d] partial sums of linear2)."""
+    d = x.shape[-1]
+    R, F_ = x.numel() // d, w1.shape[0]
+    h = torch.empty(*x.shape[:-1], F_, dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(h) if want_pre else None
+    zp = torch.empty(F_ // 256, *x.shape, dtype=torch.float32, device=x.device)
+    q = L.FfnDesc()
+    q.R, q.d, q.F, q.act = R, d, F_, L.ACT[act]
+    q.x, q.w1, q.b1, q.w2, q.b2 = L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2)
+    q.h, q.pre, q.zp = L.ptr(h), L.ptr(pre), L.ptr(zp)
+    L.set_drop(q.drop, drop)
+    L.check(timed("pq3d_ffn_fwd", f"R{R}d{d}F{F_}", 4.0 * R * d * F_, 4.0 * (2 * d * F_ + R * (2 * d + F_)), L.lib().pq3d_ffn_fwd,
+                  C.byref(q), L.stream()), "pq3d_ffn_fwd")
+    return h, pre, zp
+
+
 SA_FOLD = os.environ.get("PQ3D_SA_FOLD", "1") != "0"   # fold the self-attention out-projection backward into the kernel
 
 
@@ -523,22 +551,30 @@ class _FusedDecoder(Function):
                 # -- FFN: 3 launches
                 ffn = layer.ffn
                 F_ = ffn.linear1.out_features
-                h = torch.empty(B, Nq, F_, dtype=ops.act_dtype(cq), device=dev)
-                pre = torch.empty_like(h) if spec.act == "gelu" else None
-                L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
-                       C2=[pre], ct=cq, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi, ln=pend2)
-                # linear2 has K = F = 2048 on only M/64 x d/64 = 52 tiles: a long serial k-loop on a fifth of the chip.  Its K
-                # range is split over KS groups of ONE grouped launch (no atomics: each group owns an output), and the
-                # LayerNorm kernel adds the partial sums (+ residual, + dropout of the summed branch) in a fixed order --
-                # deterministic, so the bit-exact padding-invariance / scene-independence properties hold.
-                KS = 4 if F_ % (4 * 64) == 0 else 1
-                zp = torch.empty(KS, B, Nq, d, dtype=torch.float32, device=dev)
-                Fk = F_ // KS
-                hv, w2 = h.view(R, F_), ffn.linear2.weight.detach()
-                L.gemm(M=R, N=d, K=Fk, A=[hv[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
-                       B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
-                       bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=cq, lda=F_,
-                       ldb=F_, ldc=d)
+                w1_, b1_ = ffn.linear1.weight.detach(), ffn.linear1.bias.detach()
+                w2_, b2_ = ffn.linear2.weight.detach(), ffn.linear2.bias.detach()
+                fused_ffn = pend2 is None and ffn_fused_ok(cq, d, F_, x2, w1_, b1_, w2_, b2_)
+                if fused_ffn:
+                    # -- FFN: 2 launches (both products in one: csrc/ffn.hip; then the LayerNorm over its F/256 partial sums)
+                    h, pre, zp = ffn_fwd(x2, w1_, b1_, w2_, b2_, spec.act, dr_fi, spec.act == "gelu")
+                    KS = F_ // 256
+                else:
+                    h = torch.empty(B, Nq, F_, dtype=ops.act_dtype(cq), device=dev)
+                    pre = torch.empty_like(h) if spec.act == "gelu" else None
+                    L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
+                           C2=[pre], ct=cq, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi, ln=pend2)
+                    # linear2 has K = F = 2048 on only M/64 x d/64 = 52 tiles: a long serial k-loop on a fifth of the chip.  Its K
+                    # range is split over KS groups of ONE grouped launch (no atomics: each group owns an output), and the
+                    # LayerNorm kernel adds the partial sums (+ residual, + dropout of the summed branch) in a fixed order --
+                    # deterministic, so the bit-exact padding-invariance / scene-independence properties hold.
+                    KS = 4 if F_ % (4 * 64) == 0 else 1
+                    zp = torch.empty(KS, B, Nq, d, dtype=torch.float32, device=dev)
+                    Fk = F_ // KS
+                    hv, w2 = h.view(R, F_), ffn.linear2.weight.detach()
+                    L.gemm(M=R, N=d, K=Fk, A=[hv[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
+                           B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
+                           bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=cq, lda=F_,
+                           ldb=F_, ldc=d)
                 z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)   # sum of the partials, kept for the backward
                 x3, mean_f, rstd_f, pend = _ln_defer(x2, [zp[k] for k in range(KS)], [ffn.norm.weight.detach()],
                                                      [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq, drop=dr_fr,
