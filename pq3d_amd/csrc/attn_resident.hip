@@ -55,7 +55,17 @@ PQ_DEV void wave_lds_fence() {   // order this wave's LDS writes before its foll
 // The workgroup's resident queries are rows [q_lo, q_lo + nq) of the scene (nq <= 32 NQP).  More than 128 queries (config
 // 4: 200) run as TWO launches over the two halves of the rows; the second one ADDS its dK / dV onto the first one's
 // (acc_kv: read-modify-write of the bf16 rows; each key belongs to exactly one wave of one workgroup per launch).
-template <int DH, int NQP, bool DROP, bool MASK3, int RW>
+// in-kernel timeline (probe builds only, tools/probes/res_timeline.py): wave 0 of workgroup (0, 0, 0) stamps the 100 MHz clock
+#ifdef PQ3D_RES_TIMELINE
+#define RS_TL(i) do { if (d.ws && d.ksplit <= 1 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ((long long*)d.ws)[i] = wall_clock64(); } while (0)
+#else
+#define RS_TL(i) do { } while (0)
+#endif
+
+// ZA (only without dropout / 3-D mask): the call has the zero key of add_zero_attn, so every log-sum-exp is >= 0 and the
+// probability recomputed for a padded key (score 0: its K row is zeroed) is at most 1 -- it needs no forcing to 0 at all
+// (its dK / dV rows are zeroed at the store, its dQ term multiplies the zero K row).
+template <int DH, int NQP, bool DROP, bool MASK3, int RW, bool ZA = false>
 __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_attn_desc d, int q_lo, int nq, int acc_kv) {
   ATTN_KARG_PIN(d);
   ATTN_KARG_PIN_BWD(d);
@@ -82,6 +92,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
   const float sl2 = d.scale * 1.4426950408889634f;
 
+  RS_TL(0);
   // ---- resident tiles: Q, dO (zero past Lq), delta = rowsum(dO * O), log-sum-exp
   {
     const long qoff = (long)b * d.q_sb + (long)h * d.q_sh, ooff = (long)b * d.o_sb + (long)h * d.o_sh;
@@ -118,7 +129,9 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
       }
     }
   }
+  RS_TL(1);
   __syncthreads();
+  RS_TL(2);
 
   bf16_t* Kt = wv + wave * WV_ELEMS;            // [GK][LDR]  this wave's K tile, row-major
   bf16_t* sc = Kt + R::KT_ELEMS;                // [2][GK][LDS2] dS scratch, [key][query]
@@ -187,6 +200,10 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     // and it adds nothing to dQ = dS K), and its dK / dV rows are replaced by zeros at the store.
     u32x4 kcur[2][NS], vcur[2][NS];
     bool kmc[2] = {km[0], km[1]};
+    // a padded key (lane li of key tile kt) gets its probability forced to 0 without a select per element: its score
+    // accumulator STARTS at -1e30 (its K row is zeroed, so nothing is added), exp2 of that is exactly 0.  (With the score
+    // left at 0, exp2(-lse) could overflow for a strongly negative lse and inf * 0 at the dK / dV store would be NaN.)
+    const float sinit[2] = {(!ZA && !DROP && !MASK3 && km[0]) ? -1e30f : 0.f, (!ZA && !DROP && !MASK3 && km[1]) ? -1e30f : 0.f};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -222,6 +239,13 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           const int q0 = qp * 32 + qt * 16;
+          if (q0 >= nq) {   // uniform: a query tile that is all padding (100 queries: the last of 8) -- P = dS = 0, no arithmetic
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { pt[kt][qt][r] = 0.f; ds[kt][qt][r] = 0.f; }
+            continue;
+          }
           u32x4 qa[NS], ga[NS];
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
@@ -229,14 +253,30 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
             ga[s] = rfrag<bf16_t>(&dOs[(q0 + li) * R::LDR], s, lg);
           }
           const f32x4 Lr = *(const f32x4*)&Ls[q0 + 4 * lg], Dr = *(const f32x4*)&Ds[q0 + 4 * lg];
+          const f32x4 nL = -Lr, nD = -Dr;   // negated once per query tile: the packed forms below then are plain fma / add
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 sv = (f32x4){sinit[kt], sinit[kt], sinit[kt], sinit[kt]}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
               Mma<bf16_t>::mma(sv, qa[s], kcur[kt][s]);
               Mma<bf16_t>::mma(dp, ga[s], vcur[kt][s]);
             }
+            if constexpr (!DROP && !MASK3) {
+              // the softmax recompute is what this kernel spends its time on (in-kernel timeline at config 2: ~4 us per
+              // 32-key group, 700 vector-ALU issue slots against 80 MFMAs): two elements per instruction where the ISA
+              // has packed fp32 forms (fma, subtract, multiply), and the padded-key select only in groups that have one
+              const f32x2 c2 = (f32x2){sl2, sl2};
+              const f32x2 xa = __builtin_elementwise_fma(__builtin_shufflevector(sv, sv, 0, 1), c2, __builtin_shufflevector(nL, nL, 0, 1));
+              const f32x2 xb = __builtin_elementwise_fma(__builtin_shufflevector(sv, sv, 2, 3), c2, __builtin_shufflevector(nL, nL, 2, 3));
+              // P from the saved log-sum-exp; a padded key's score started at -1e30 (sinit), so its probability is exactly 0
+              const f32x2 pa = (f32x2){__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
+              const f32x2 pb = (f32x2){__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
+              const f32x2 da = pa * (__builtin_shufflevector(dp, dp, 0, 1) + __builtin_shufflevector(nD, nD, 0, 1));
+              const f32x2 db = pb * (__builtin_shufflevector(dp, dp, 2, 3) + __builtin_shufflevector(nD, nD, 2, 3));
+              pt[kt][qt][0] = pa.x; pt[kt][qt][1] = pa.y; pt[kt][qt][2] = pb.x; pt[kt][qt][3] = pb.y;
+              ds[kt][qt][0] = da.x; ds[kt][qt][1] = da.y; ds[kt][qt][2] = db.x; ds[kt][qt][3] = db.y;
+            } else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int ql = q0 + 4 * lg + r;
@@ -322,10 +362,13 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
       }
     }
     g = gn;
+    if (it < 5) RS_TL(3 + it);
   }
 
   // ---- dQ: sum of the 4 waves' register accumulators through LDS (no atomics), then out
-  __syncthreads();   // every wave is done with the resident Q / dO tiles: the reduction buffer overlays them
+  RS_TL(8);
+  __syncthreads();
+  RS_TL(9);   // every wave is done with the resident Q / dO tiles: the reduction buffer overlays them
   // two phases: the first half of the waves store into RW / 2 buffers (buffer 0 over the resident Q / dO tiles, the others
   // over the per-wave scratch, all dead now), the second half add onto them; the output loop below adds the buffers
   constexpr int NBUF = RW / 2;
@@ -366,6 +409,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     }
   }
   (void)rows;
+  RS_TL(10);
 }
 
 template <int DH, int NQP, int RW> size_t resident_lds(bool mask3) {
@@ -379,6 +423,15 @@ template <int DH, int NQP, int RW> size_t resident_lds(bool mask3) {
 template <int DH, int NQP, bool DROP, bool MASK3, int RW> void launch_res_w(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
   const size_t lds = resident_lds<DH, NQP, RW>(MASK3);
+  if constexpr (!DROP && !MASK3) {
+    if (d.zero_attn) {
+      auto kz = attn_bwd_resident_kernel<DH, NQP, DROP, MASK3, RW, true>;
+      static std::atomic<unsigned> done_z{0};
+      if (pq3d_enable_big_lds(kz, 160 * 1024, done_z)) { (void)hipGetLastError(); }
+      hipLaunchKernelGGL(kz, dim3(KS, d.H, d.B), dim3(RW * 64), lds, s, d, q_lo, nq, acc);
+      return;
+    }
+  }
   auto kern = attn_bwd_resident_kernel<DH, NQP, DROP, MASK3, RW>;
   static std::atomic<unsigned> attr_done{0};   // > 64 KB of dynamic LDS: opt-in once per (kernel instantiation, device)
   if (pq3d_enable_big_lds(kern, 160 * 1024, attr_done)) { (void)hipGetLastError(); }
