@@ -287,7 +287,7 @@ FFN_FUSE = os.environ.get("PQ3D_FFN_FUSE", "0") != "0"
 
 def ffn_fused_ok(cq, d, F_, x, w1, b1, w2, b2) -> bool:
     ts = [x, w1, b1, w2] + ([b2] if b2 is not None else [])
-    return (FFN_FUSE and cq == L.BF16X3 and d == 256 and F_ % 256 == 0 and F_ // 256 <= L.MAXG
+    return (cq == L.BF16X3 and d == 256 and F_ % 256 == 0 and F_ // 256 <= L.MAXG
             and all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts))
 
 
@@ -553,7 +553,7 @@ class _FusedDecoder(Function):
                 F_ = ffn.linear1.out_features
                 w1_, b1_ = ffn.linear1.weight.detach(), ffn.linear1.bias.detach()
                 w2_, b2_ = ffn.linear2.weight.detach(), ffn.linear2.bias.detach()
-                fused_ffn = pend2 is None and ffn_fused_ok(cq, d, F_, x2, w1_, b1_, w2_, b2_)
+                fused_ffn = FFN_FUSE and pend2 is None and ffn_fused_ok(cq, d, F_, x2, w1_, b1_, w2_, b2_)
                 if fused_ffn:
                     # -- FFN: 2 launches (both products in one: csrc/ffn.hip; then the LayerNorm over its F/256 partial sums)
                     h, pre, zp = ffn_fwd(x2, w1_, b1_, w2_, b2_, spec.act, dr_fi, spec.act == "gelu")

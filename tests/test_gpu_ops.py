@@ -851,8 +851,8 @@ def test_launch_merges_pair_kernels_and_summed_layernorm_gradient():
             dgs, dbs = [torch.zeros(d, device=dev) for _ in range(M)], [torch.zeros(d, device=dev) for _ in range(M)]
             dx, d_o = fused._ln_bwd(x, os_, gam, bet, 1e-5, coef, 100, mean, rstd, dy, dgs, dbs)
             outs.append((dx, d_o, torch.stack(dgs), torch.stack(dbs)))
-        for a, b in zip(*outs):
-            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)   # atomics order only (the addends are summed identically)
+        for a, b in zip(*outs):   # atomics order only (the addends are summed identically): column sums over 800 rows
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
     # grouped "+ aux" with an aux pointer in the last group only
     A = [rnd(800, 256) for _ in range(3)]
     W = [rnd(256, 256) * 0.05 for _ in range(3)]
