@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pq3d_amd import synth  # noqa: E402
+from pq3d_amd import ops, synth  # noqa: E402
 from pq3d_amd.model import Query3DUnified, make_cfg  # noqa: E402
 from pq3d_amd.parallel import FlatGradAllReducer  # noqa: E402
 from pq3d_amd.profiler import KernelTimer  # noqa: E402
@@ -84,7 +84,6 @@ def build(c, compute, device, seed):
 
 
 def loss_fn(out, heads):
-    from pq3d_amd import ops
     q = out["query_embeds"] if "query_embeds" in out else out["query"]
     if q.is_cuda and "mask" in heads:
         # mean(query) + sum over prediction layers of mean(clamp(mask_logits, -50)) + mean(class logits of the kept
@@ -335,7 +334,12 @@ def main():
     def fwd_bwd():
         model.zero_grad(set_to_none=True)
         out = model(dict(dd))
-        loss_fn(out, c["heads"]).backward(gradient=one)   # cached seed gradient: no ones_like fill in the step
+        loss = loss_fn(out, c["heads"])
+        if enc.grad_arena is not None:
+            with ops.grad_arena(enc.grad_arena, enc.grad_arena_buffers):   # every slot offered for the whole pass
+                loss.backward(gradient=one)   # cached seed gradient: no ones_like fill in the step
+        else:
+            loss.backward(gradient=one)
         reducer.pack()
 
     def full_step():
@@ -486,7 +490,6 @@ def main():
                 fwd_bwd()
         summ = kt.summary()
         if args.pmc_calibration:
-            from pq3d_amd import ops
             n_cal = CALIBRATION_BYTES // 4
             csrc, cdst = torch.ones(n_cal, device=dev), torch.empty(n_cal, device=dev)
             ops.copy_many([cdst], [csrc])

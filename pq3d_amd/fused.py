@@ -655,7 +655,15 @@ class _FusedDecoder(Function):
                     offer[q_.data_ptr()] = (q_, fl_, o_, n_)
             mixed = "fused decoder backward: some parameters' .grad alias the shared gradient arena and others do not -- " \
                     "zero ALL gradients (set_to_none=True) or none between micro-batches"
-            if req and all(alias):
+            if ops._Arena.whole_pass and ops._Arena.mode is not None and \
+                    all(p.data_ptr() in ops._Arena.by_ptr for p in req):
+                # the owner opened the arena around the whole pass (ops.grad_arena): already zeroed / accumulating
+                accumulate = ops._Arena.mode == "accumulate"
+                if accumulate and not all(alias):
+                    raise RuntimeError(mixed)
+                offer = {}
+                ops.zero_many([dxr_zero])
+            elif req and all(alias):
                 accumulate = True
                 ops.zero_many([dxr_zero])
             elif any(alias) or any(q_.grad is not None and q_.grad.data_ptr() == f_.data_ptr() + 4 * o_ for q_, f_, o_, n_ in offer.values()):

@@ -19,6 +19,8 @@ from typing import Dict, List, Sequence
 import torch
 import torch.nn as nn
 
+from . import ops
+
 OUT_TENSORS = ("query_embeds", "ground_logits", "generation_logits", "generation_label")   # the label: long, no gradient
 OUT_LISTS = ("predictions_class", "predictions_mask")
 
@@ -196,8 +198,9 @@ class GraphedQuery3D(nn.Module):
         for p in params:
             p.grad = self._grad_view(p) if accumulate else None
         req = [o for o in outs if o.requires_grad]
-        grads = torch.autograd.grad(req, [self._args[i] for i in self._gin_idx] + params, grad_outputs=self.static_gout,
-                                    allow_unused=True, retain_graph=retain)
+        with ops.grad_arena(self._slots, self.reducer.flat):   # every slot offered for the whole pass (zeroed here when fresh)
+            grads = torch.autograd.grad(req, [self._args[i] for i in self._gin_idx] + params, grad_outputs=self.static_gout,
+                                        allow_unused=True, retain_graph=retain)
         gin, gp = grads[:len(self._gin_idx)], grads[len(self._gin_idx):]
         views, srcs = [], []
         for p, g in zip(params, gp):

@@ -375,6 +375,7 @@ class _Linear(Function):
                lda=K, ldb=K, ldc=N, act=act, row_fill_flag=fill_flag, row_fill=fill_value, drop=drop,
                aux=[residual] if residual is not None else None, act_grad="add" if residual is not None else None)
         ctx.has_res = residual is not None
+        ctx.pptr = (w.data_ptr(), b.data_ptr() if b is not None else None)
         ctx.save_for_backward(x, x2, w, pre if act == "gelu" else (y if act == "relu" else None), rm, fill_flag)
         ctx.ct, ctx.act, ctx.has_b, ctx.drop = ct, act, b is not None, drop
         return y
@@ -402,22 +403,36 @@ class _Linear(Function):
             if not ctx.needs_input_grad[0]:
                 dx = None
         want_db = ctx.has_b and ctx.needs_input_grad[2]
+        give_w = True
         if ctx.needs_input_grad[1]:
-            dw = _empty(N, K, dtype=torch.float32, device=x.device)
             tiles = ((N + 63) // 64) * ((K + 63) // 64)
             epl = 8 if ct == BF16 else 4
             # the bias gradient rides on the weight-gradient GEMM when its fast (aligned) path applies
             fuse = want_db and N % epl == 0 and K % epl == 0 and N >= epl and K >= epl and \
                 g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and (x2 is None or x2.dtype == torch.float32) and \
                 (x2 is None or x.dtype == torch.float32)
-            if fuse:
-                db = _empty(N, dtype=torch.float32, device=x.device)
-            L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True,
-                   transB=True, splitk=max(2, _splitk(tiles, R, ct)) if fuse else _splitk(tiles, R, ct),
-                   colsum=[db] if fuse else None)
+            # the owner's gradient arena, when offered for this pass: accumulate straight into the slots (pre-zeroed)
+            slot, give = arena_take([ctx.pptr[0]] + ([ctx.pptr[1]] if fuse else []), [N * K] + ([N] if fuse else []))
+            if slot is not None:
+                dw, give_w = slot[0].view(N, K), give
+                if fuse:
+                    db = slot[1]
+                L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
+                       splitk=max(2, _splitk(tiles, R, ct)), colsum=[db] if fuse else None, accumulate=True)
+            else:
+                dw = _empty(N, K, dtype=torch.float32, device=x.device)
+                if fuse:
+                    db = _empty(N, dtype=torch.float32, device=x.device)
+                L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True,
+                       transB=True, splitk=max(2, _splitk(tiles, R, ct)) if fuse else _splitk(tiles, R, ct),
+                       colsum=[db] if fuse else None)
         if want_db and db is None:
             db = colsum(g.view(R, N))
         dres = dy.contiguous() if (ctx.has_res and ctx.needs_input_grad[11]) else None
+        if not give_w:   # accumulated in place into slots autograd already holds
+            dw = None
+            if db is not None and want_db and fuse:
+                db = None
         return dx, dw, db, dx2, None, None, None, None, None, None, None, dres
 
 
@@ -447,6 +462,7 @@ class _LinearGroup(Function):
         ctx.same_x = all(x.data_ptr() == xs[0].data_ptr() for x in xs)
         ctx.save_for_backward(*xs, *Ws)
         ctx.cfg = (ct, G)
+        ctx.pptr = [w.data_ptr() for w in t[G:2 * G]]
         return tuple(out[g] for g in range(G))
 
     @staticmethod
@@ -477,13 +493,19 @@ class _LinearGroup(Function):
                 dxs[0] = dxb.sum(0)
             else:
                 dxs = [dxb[g] for g in range(G)]
-        dWb = torch.zeros(G, N, K, dtype=torch.float32, device=dev)
+        slot, give = arena_take(ctx.pptr, [N * K] * G)   # the owner's gradient arena, when offered for this pass (pre-zeroed)
+        if slot is not None:
+            dWs = [v.view(N, K) for v in slot]
+        else:
+            give = True
+            dWb = torch.zeros(G, N, K, dtype=torch.float32, device=dev)
+            dWs = [dWb[g] for g in range(G)]
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
         for s in range(0, G, L.MAXG):
             e = min(G, s + L.MAXG)
-            L.gemm(M=N, N=K, K=R, A=gs[s:e], B=list(xs[s:e]), Cs=[dWb[g] for g in range(s, e)], ct=ct, lda=N, ldb=K, ldc=K,
+            L.gemm(M=N, N=K, K=R, A=gs[s:e], B=list(xs[s:e]), Cs=dWs[s:e], ct=ct, lda=N, ldb=K, ldc=K,
                    transA=True, transB=True, splitk=max(2, _splitk(tiles * (e - s), R, ct)), accumulate=True)
-        return (None, None, None, *dxs, *[dWb[g] for g in range(G)])
+        return (None, None, None, *dxs, *(dWs if give else [None] * G))
 
 
 def linear_group(xs, Ws, *, ct: int, out_dtype=torch.float32):
@@ -928,7 +950,7 @@ class _LinearLNGroup(Function):
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
         epl = 8 if ct == BF16 else 4
         fuse = N % epl == 0 and K % epl == 0 and all(x.data_ptr() % 16 == 0 for x in xs)
-        slot, give = arena_take(ctx.pptr) if fuse else (None, False)
+        slot, give = arena_take(ctx.pptr, [N * K] * G + [N] * (3 * G)) if fuse else (None, False)
         if slot is not None:
             dWs, dbl, dgs, dbs = slot[:G], slot[G:2 * G], slot[2 * G:3 * G], slot[3 * G:]
             dWs = [w.view(N, K) for w in dWs]
@@ -979,19 +1001,62 @@ class _Arena:
     mode = None
     by_ptr = {}      # parameter data_ptr -> (parameter, flat buffer, element offset, numel) of its slot
     written = set()  # slots some function of this pass already returned (a second use adds in place, returns None)
+    whole_pass = False   # offered by grad_arena() around the whole backward (the decoder then neither zeroes nor offers)
+
+
+class grad_arena:
+    """``with ops.grad_arena(slots, buffers): loss.backward()`` -- the owner of the flat gradient buffers (a
+    FlatGradAllReducer / TrainStep) offers every parameter's slot for the WHOLE backward pass: one zero launch up front
+    (none when every .grad still aliases its slot: accumulation over micro-batches), then every arena-aware backward function
+    -- the heads that run BEFORE the decoder's backward (the caption body), the decoder, the input encoders after it --
+    accumulates in place.  Without this context the decoder's backward makes the offer itself (arena_offer), which only
+    reaches the functions that run after it."""
+
+    def __init__(self, slots, buffers):
+        self.slots, self.buffers = slots, list(buffers)
+
+    def __enter__(self):
+        if os.environ.get("PQ3D_GRAD_ARENA", "1") == "0":   # A/B switch: the decoder's own offer only
+            return self
+        zeroed = {b.data_ptr() for b in self.buffers}
+        ents = {}
+        for i_, q_ in getattr(self.slots, "params", {}).items():
+            fl_, o_, n_ = self.slots[i_]
+            if q_.requires_grad and fl_.data_ptr() in zeroed:
+                ents[q_.data_ptr()] = (q_, fl_, o_, n_)
+        alias = [q_.grad is not None and q_.grad.data_ptr() == f_.data_ptr() + 4 * o_ for q_, f_, o_, n_ in ents.values()]
+        # a later micro-batch of an accumulating step: the in-place gradients of the previous one are still adopted as .grad
+        # (functions only add into slots whose .grad aliases them; gradients that live in tensors of their own keep
+        # accumulating through autograd and are packed afterwards).  No aliasing .grad anywhere: a fresh step, one zero launch
+        if any(alias):
+            mode = "accumulate"
+        else:
+            mode = "fresh"
+            zero_many(self.buffers)
+        _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass = mode, ents, set(), True
+        return self
+
+    def __exit__(self, *exc):
+        _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass = None, {}, set(), False
+        return False
 
 
 def arena_offer(views_by_ptr, mode):
-    _Arena.mode, _Arena.by_ptr, _Arena.written = mode, views_by_ptr, set()
+    _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass = mode, views_by_ptr, set(), False
 
     def _end():
-        _Arena.mode, _Arena.by_ptr, _Arena.written = None, {}, set()
+        if not _Arena.whole_pass:
+            _Arena.mode, _Arena.by_ptr, _Arena.written = None, {}, set()
     torch.autograd.Variable._execution_engine.queue_callback(_end)
 
 
-def arena_take(ptrs):
-    """Slot views for the parameters at ``ptrs`` (all of them or None) and whether to return them to autograd."""
+def arena_take(ptrs, numels=None):
+    """Slot views for the parameters at ``ptrs`` (all of them or None) and whether to return them to autograd.  ``numels``:
+    the element counts the caller is about to write -- a tensor that only STARTS where a parameter starts (the q rows of a
+    stacked in_proj_weight passed as a slice) is not that parameter."""
     if _Arena.mode is None or any(q not in _Arena.by_ptr for q in ptrs):
+        return None, False
+    if numels is not None and any(_Arena.by_ptr[q][3] != n for q, n in zip(ptrs, numels)):
         return None, False
     # fresh view objects per call: AccumulateGrad adopts a gradient without a copy only when nobody else references it
     ent = [(p, fl[o:o + n].view(p.shape)) for p, fl, o, n in (_Arena.by_ptr[q] for q in ptrs)]
@@ -1048,6 +1113,7 @@ class _RMSNorm(Function):
         rstd = _empty(R, dtype=torch.float32, device=x.device)
         L.check(L.lib().pq3d_rmsnorm_fwd(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(rstd), R, d_, eps, L.stream()), "pq3d_rmsnorm_fwd")
         ctx.save_for_backward(x, w, rstd)
+        ctx.pptr = w.data_ptr()
         return y
 
     @staticmethod
@@ -1055,10 +1121,12 @@ class _RMSNorm(Function):
         x, w, rstd = ctx.saved_tensors
         d_ = x.shape[-1]
         dy = dy.contiguous().float()
-        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        dx = torch.empty_like(x)
+        slot, give = arena_take([ctx.pptr], [w.numel()])   # the owner's gradient arena, when offered for this pass (pre-zeroed)
+        dw = slot[0] if slot is not None else torch.empty_like(w)
         L.check(L.lib().pq3d_rmsnorm_bwd(L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dy), L.ptr(dx), L.ptr(dw), x.numel() // d_, d_,
-                                         0, L.stream()), "pq3d_rmsnorm_bwd")
-        return dx, dw, None
+                                         1 if slot is not None else 0, L.stream()), "pq3d_rmsnorm_bwd")
+        return dx, (dw if (slot is None or give) else None), None
 
 
 def rmsnorm(x, w, eps: float = 1e-6):
@@ -1076,16 +1144,18 @@ class _Embedding(Function):
                 "pq3d_embedding_fwd")
         ctx.save_for_backward(ids)
         ctx.shape = table.shape
+        ctx.pptr = table.data_ptr()
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
-        dt = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        slot, give = arena_take([ctx.pptr], [ctx.shape[0] * ctx.shape[1]])
+        dt = slot[0].view(ctx.shape) if slot is not None else torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
         dout = dout.contiguous().float()
         L.check(L.lib().pq3d_embedding_bwd_acc(L.ptr(dout), L.ptr(ids), L.ptr(dt), ids.numel(), ctx.shape[1], L.stream()),
                 "pq3d_embedding_bwd_acc")
-        return dt, None
+        return (dt if (slot is None or give) else None), None
 
 
 def embedding(table, ids):

@@ -22,6 +22,7 @@ from typing import Callable, Dict, Optional, Sequence
 import torch
 
 from . import _lib as L
+from . import ops
 from .parallel import FlatGradAllReducer
 
 
@@ -114,7 +115,12 @@ class TrainStep:
         loss = self.loss_fn(out)
         if loss_scale != 1.0:
             loss = loss * loss_scale
-        loss.backward()
+        enc = getattr(self.model, "unified_encoder", None)
+        if enc is not None and getattr(enc, "grad_arena", None) is not None:
+            with ops.grad_arena(enc.grad_arena, enc.grad_arena_buffers):   # every slot offered for the whole pass
+                loss.backward()
+        else:
+            loss.backward()
         self.reducer.pack()
         return loss.detach()
 
