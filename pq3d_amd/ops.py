@@ -364,7 +364,7 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value, drop=None, residual=None):
         x, x2, w, fill_flag, residual = _c(x), _c(x2), _c(w), _c(fill_flag), _c(residual)
-        assert residual is None or (act is None and drop is None), "residual add excludes activation / dropout"
+        # epilogue order (gemm_common.h): bias, activation, dropout, then "+ residual": y = residual + dropout(act(x w^T + b))
         K = x.shape[-1]
         R = x.numel() // K
         N = w.shape[0]
@@ -387,10 +387,17 @@ class _Linear(Function):
         N, K = w.shape
         R = x.numel() // K
         g = dy.contiguous()
-        if ctx.drop is not None:   # dropout sits after the activation: undo it first (mask * 1/(1-p))
-            g = _dropout_apply(g, ctx.drop)
-        if ctx.act in ("relu", "gelu"):
+        alpha = 1.0
+        if ctx.drop is not None and ctx.act == "relu" and not ctx.has_b:
+            # the saved output is post-dropout: [y > 0] already carries the keep mask, only the 1/(1-p) factor is left and
+            # rides the two products below as their alpha (no mask-apply launch)
             g = act_bwd(g, saved, ctx.act, act_dtype(ct))
+            alpha = 1.0 / (1.0 - ctx.drop.p)
+        else:
+            if ctx.drop is not None:   # dropout sits after the activation: undo it first (mask * 1/(1-p))
+                g = _dropout_apply(g, ctx.drop)
+            if ctx.act in ("relu", "gelu"):
+                g = act_bwd(g, saved, ctx.act, act_dtype(ct))
         if rm is not None or fill_flag is not None:
             g = scale_rows(g, R, g.dtype, keep_mask=rm, zero_flag=fill_flag)
         dx = dx2 = dw = db = None
@@ -398,7 +405,7 @@ class _Linear(Function):
             dx = _empty(x.shape, dtype=x.dtype, device=x.device)
             # a long reduction over few output tiles (LM head: 512 x 512 outputs, N = 32128) is split over K
             sk = _splitk(((R + 63) // 64) * ((K + 63) // 64), N, ct) if (dx.dtype == torch.float32 and N >= 8192) else 1
-            L.gemm(M=R, N=K, K=N, A=[g], B=[w], Cs=[dx], ct=ct, lda=N, ldb=K, ldc=K, transB=True, splitk=sk)
+            L.gemm(M=R, N=K, K=N, A=[g], B=[w], Cs=[dx], ct=ct, lda=N, ldb=K, ldc=K, transB=True, splitk=sk, alpha=alpha)
             dx2 = dx if (x2 is not None and ctx.needs_input_grad[3]) else None
             if not ctx.needs_input_grad[0]:
                 dx = None
@@ -418,14 +425,14 @@ class _Linear(Function):
                 if fuse:
                     db = slot[1]
                 L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
-                       splitk=max(2, _splitk(tiles, R, ct)), colsum=[db] if fuse else None, accumulate=True)
+                       splitk=max(2, _splitk(tiles, R, ct)), colsum=[db] if fuse else None, accumulate=True, alpha=alpha)
             else:
                 dw = _empty(N, K, dtype=torch.float32, device=x.device)
                 if fuse:
                     db = _empty(N, dtype=torch.float32, device=x.device)
                 L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True,
                        transB=True, splitk=max(2, _splitk(tiles, R, ct)) if fuse else _splitk(tiles, R, ct),
-                       colsum=[db] if fuse else None)
+                       colsum=[db] if fuse else None, alpha=alpha)
         if want_db and db is None:
             db = colsum(g.view(R, N))
         dres = dy.contiguous() if (ctx.has_res and ctx.needs_input_grad[11]) else None

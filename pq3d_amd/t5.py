@@ -69,10 +69,8 @@ def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], 
         return x if d is None else ops.dropout(x, d)
 
     def proj_residual(o, w):
-        """x + dropout(o @ w^T): the residual add rides the GEMM epilogue when dropout is off."""
-        if p_drop <= 0.0:
-            return ops.linear(o, w, None, ct=ct, residual=x)
-        return x + drop(ops.linear(o, w, None, ct=ct))
+        """x + dropout(o @ w^T): dropout and the residual add ride the GEMM epilogue (one launch)."""
+        return ops.linear(o, w, None, ct=ct, residual=x, drop=next_drop())
 
     ids = shift_right(labels, cfg.decoder_start_token_id, cfg.pad_token_id)
     x = drop(ops.embedding(model.shared.weight, ids))
@@ -106,7 +104,7 @@ def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], 
         x = proj_residual(o, A.o.weight)
         # -- feed forward
         h = ops.rmsnorm(x, ff.layer_norm.weight, cfg.layer_norm_epsilon)
-        hid = drop(ops.linear(h, ff.DenseReluDense.wi.weight, None, ct=ct, act="relu", out_dtype=ad))
+        hid = ops.linear(h, ff.DenseReluDense.wi.weight, None, ct=ct, act="relu", out_dtype=ad, drop=next_drop())
         x = proj_residual(hid, ff.DenseReluDense.wo.weight)
     x = drop(ops.rmsnorm(x, dec.final_layer_norm.weight, cfg.layer_norm_epsilon))
     if cfg.tie_word_embeddings:
