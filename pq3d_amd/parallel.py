@@ -73,6 +73,7 @@ class FlatGradAllReducer:
     def pack(self, buckets=None) -> None:
         """Copy every .grad into the flat buffers (capturable: fixed addresses, one foreach copy per bucket).
         Gradients that already ARE views of the flat buffer (written in place by the fused executor) are skipped."""
+        unused = []   # slots of parameters without a gradient this step: zeroed by ONE launch at the end
         for bi, (flat, bucket) in enumerate(zip(self.flat, self.buckets)):
             if buckets is not None and bi not in buckets:
                 continue
@@ -89,7 +90,7 @@ class FlatGradAllReducer:
                         views.append(v)
                         grads.append(p.grad)
                 else:
-                    v.zero_()
+                    unused.append(v)
                 off += n
             if views:
                 if flat.is_cuda and all(g.dtype == torch.float32 for g in grads):
@@ -97,6 +98,14 @@ class FlatGradAllReducer:
                     ops.copy_many(views, grads)
                 else:
                     torch._foreach_copy_(views, grads)
+        if unused:
+            if unused[0].is_cuda:
+                from . import ops           # (an unused sub-module -- the caption model's encoder stack -- is 50 slots)
+                for s0 in range(0, len(unused), 64):
+                    ops.zero_many(unused[s0:s0 + 64])
+            else:
+                for v in unused:
+                    v.zero_()
 
     # ---- collective -------------------------------------------------------------------------------------------------
     def _world(self) -> int:
