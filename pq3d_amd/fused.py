@@ -662,7 +662,8 @@ class _FusedDecoder(Function):
                 if accumulate and not all(alias):
                     raise RuntimeError(mixed)
                 offer = {}
-                ops.zero_many([dxr_zero])
+                if not ops.arena_flush_zero([dxr_zero]):   # first consumer of a fresh pass: arena + own scratch, one launch
+                    ops.zero_many([dxr_zero])
             elif req and all(alias):
                 accumulate = True
                 ops.zero_many([dxr_zero])

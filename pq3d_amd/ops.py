@@ -1009,6 +1009,17 @@ class _Arena:
     by_ptr = {}      # parameter data_ptr -> (parameter, flat buffer, element offset, numel) of its slot
     written = set()  # slots some function of this pass already returned (a second use adds in place, returns None)
     whole_pass = False   # offered by grad_arena() around the whole backward (the decoder then neither zeroes nor offers)
+    pending = None       # fresh whole-pass arena: buffers still to be zeroed -- by the FIRST consumer, together with its own
+
+
+def arena_flush_zero(extra=()) -> bool:
+    """Zero the whole-pass arena's buffers if that is still pending (one launch, ``extra`` buffers of the caller included);
+    False when there was nothing pending (the caller zeroes its own buffers itself)."""
+    if _Arena.pending is None:
+        return False
+    bufs, _Arena.pending = _Arena.pending, None
+    zero_many(list(bufs) + [t for t in extra if t is not None])
+    return True
 
 
 class grad_arena:
@@ -1039,12 +1050,14 @@ class grad_arena:
             mode = "accumulate"
         else:
             mode = "fresh"
-            zero_many(self.buffers)
+            _Arena.pending = list(self.buffers)   # zeroed by the first consumer of the pass (with its own scratch: one launch)
         _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass = mode, ents, set(), True
         return self
 
     def __exit__(self, *exc):
-        _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass = None, {}, set(), False
+        if exc[0] is None:
+            arena_flush_zero()    # nobody consumed it: the owner still expects zeroed buffers
+        _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass, _Arena.pending = None, {}, set(), False, None
         return False
 
 
@@ -1065,6 +1078,7 @@ def arena_take(ptrs, numels=None):
         return None, False
     if numels is not None and any(_Arena.by_ptr[q][3] != n for q, n in zip(ptrs, numels)):
         return None, False
+    arena_flush_zero()
     # fresh view objects per call: AccumulateGrad adopts a gradient without a copy only when nobody else references it
     ent = [(p, fl[o:o + n].view(p.shape)) for p, fl, o, n in (_Arena.by_ptr[q] for q in ptrs)]
     if _Arena.mode == "fresh":
