@@ -222,3 +222,60 @@ def test_per_layer_gradient_buckets_report_readiness_in_reverse_layer_order_and_
     gmax = max(float(v.norm()) for v in g0.values())
     for n in g0:
         assert float((g0[n] - g1[n]).norm()) <= 1e-4 * max(float(g0[n].norm()), 1e-2 * gmax), n
+
+
+def test_whole_pass_gradient_arena_with_modular_functions():
+    """ops.grad_arena around backward(): linear (+ fused bias gradient), grouped linear, RMSNorm and embedding backward write
+    their parameter gradients into the offered slots -- same values as without the arena, a tied weight used twice adds in
+    place once, a second backward before the gradients are reset accumulates, a sliced stacked weight is left alone."""
+    from pq3d_amd import ops
+    from pq3d_amd._lib import BF16, F32
+    from pq3d_amd.parallel import FlatGradAllReducer
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    P = lambda *s: torch.nn.Parameter((torch.randn(*s, generator=g) * 0.1).to(dev))
+    emb, w1, b1, wq, wk, wn, stacked = P(50, 64), P(128, 64), P(128), P(64, 128), P(64, 128), P(128), P(192, 64)
+    params = [emb, w1, b1, wq, wk, wn, stacked]
+    ids = torch.randint(0, 50, (3, 17), generator=g).to(dev)
+
+    def loss_of(scale=1.0):
+        x = ops.embedding(emb, ids)                                   # [3, 17, 64]
+        h = ops.linear(x, w1, b1, ct=F32, act="relu")                 # fused bias gradient
+        h = ops.rmsnorm(h, wn)
+        q, k = ops.linear_group([h, h], [wq, wk], ct=F32)
+        s = ops.linear(q + k, stacked[:64], None, ct=F32)             # the first rows of a stacked weight: NOT that parameter
+        logits = ops.linear(s, emb, None, ct=F32)                     # tied: the embedding table again
+        return (logits.square().mean() + h.mean()) * scale
+
+    def grads():
+        return [p.grad.detach().clone() for p in params]
+
+    for p in params:
+        p.grad = None
+    loss_of().backward()
+    ref1 = grads()
+    loss_of(0.5).backward()
+    ref2 = grads()
+    red = FlatGradAllReducer(params)
+    slots = red.slots()
+    for p in params:
+        p.grad = None
+    with ops.grad_arena(slots, red.flat):
+        loss_of().backward()
+    assert ops._Arena.mode is None and ops._Arena.pending is None
+    in_place = [p.grad.data_ptr() == slots[id(p)][0].data_ptr() + 4 * slots[id(p)][1] for p in params]
+    assert in_place[:6] == [True] * 6 and not in_place[6], in_place
+    for a, b in zip(grads(), ref1):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+    red.pack()
+    for p, b in zip(params, ref1):
+        fl, o, n = slots[id(p)]
+        torch.testing.assert_close(fl[o:o + n].view_as(p), b, rtol=1e-4, atol=1e-6)
+    with ops.grad_arena(slots, red.flat):   # second micro-batch: accumulate (the stacked weight through autograd)
+        loss_of(0.5).backward()
+    for a, b in zip(grads(), ref2):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+    red.pack()
+    for p, b in zip(params, ref2):
+        fl, o, n = slots[id(p)]
+        torch.testing.assert_close(fl[o:o + n].view_as(p), b, rtol=1e-4, atol=1e-6)
