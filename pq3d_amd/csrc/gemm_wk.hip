@@ -121,6 +121,7 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
   Raw<TB, 8> rb[S::NB];
   bool oka[S::NA], okb[S::NB];
   float s2 = 0.f;
+  const bool ua = ((d.lda | d.K) & 7) != 0;   // unaligned A rows (host: fp32 A, transposed B only)
   int gi = g0, ci = c0;   // next (group, chunk) to load
   const void *pA = gp.A, *pA2 = gp.A2, *pB = gp.B;
   auto issue = [&]() {
@@ -133,6 +134,16 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
       const int c = tid + i * WT, row = c / CPR, k = k0 + (c % CPR) * 8;
       oka[i] = k < d.K;
       const long off = (long)min(m0 + row, d.M - 1) * d.lda + (oka[i] ? k : 0);
+      if constexpr (sizeof(TA) == 4 && !HA2 && !LNM && TRB) {
+        if (ua) {   // uniform: rows of an unaligned length (class logits: 201 columns) -- element loads, zeros past K
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = (k + j < d.K) ? ((const float*)Ab)[off + j] : 0.f;
+          ra[i].a = make_float4(t[0], t[1], t[2], t[3]);
+          ra[i].b = make_float4(t[4], t[5], t[6], t[7]);
+          continue;
+        }
+      }
       if constexpr (!LNM) ra[i].load(Ab + off);
       if constexpr (HA2) ra2[i].load(pA2 ? (const float*)pA2 + off : (LNM ? d.ln.o[0] + off : (const float*)pA + off));   // no addend: finite filler, scaled by 0
     }
@@ -497,17 +508,22 @@ bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t
     g_wk_enable.store(en);
   }
   if (!(en & 1)) return false;
-  if (d.transA || d.batch != 1 || d.M > g_wk_max_m || d.M < 1 || d.K < 8 || d.K % 8) return false;
+  // A rows of an unaligned length (K % 8 or lda % 8: the class head's 201 logits as the reduction of its input gradient):
+  // taken with element loads when A is fp32 without an addend and B is the transposed (k-major, aligned) operand
+  const bool ua = ((d.K | d.lda) & 7) != 0;
+  if (d.transA || d.batch != 1 || d.M > g_wk_max_m || d.M < 1 || d.K < 8) return false;
+  if (ua && !(d.transB && d.dtA == PQ3D_F32 && d.ct == PQ3D_BF16 && d.ln.M == 0 && d.splitk <= 1 && d.kconcat <= 1)) return false;
   if (d.ct != PQ3D_BF16 && d.ct != PQ3D_BF16X3) return false;
   const bool x3 = d.ct == PQ3D_BF16X3;
   if (x3 && (d.transB || d.dtA != PQ3D_F32 || d.dtB != PQ3D_F32 || d.splitk > 1)) return false;
   if (d.dtB != PQ3D_F32) return false;   // weights are fp32 parameters on every small-M product of the path
   if (d.transB && (d.N % 8 || d.N < 8)) return false;
-  if (d.lda % 8 || d.ldb % 8) return false;
+  if ((!ua && d.lda % 8) || d.ldb % 8) return false;
   if (d.splitk > 1 && (d.dtC != PQ3D_F32 || d.kconcat > 1)) return false;
   bool a2 = false;
   for (int g = 0; g < d.groups; ++g) {
-    if (!aligned16(d.A[g]) || !aligned16(d.B[g]) || d.B2[g] || d.colsum[g]) return false;
+    if ((!ua && !aligned16(d.A[g])) || (((uintptr_t)d.A[g]) & 3) || !aligned16(d.B[g]) || d.B2[g] || d.colsum[g]) return false;
+    if (ua && d.A2[g]) return false;
     if (d.A2[g]) { a2 = true; if (!aligned16(d.A2[g]) || d.dtA2 != PQ3D_F32 || d.dtA != PQ3D_F32) return false; }
   }
   if (a2 && d.transB) return false;
