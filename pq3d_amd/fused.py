@@ -689,6 +689,7 @@ class _FusedDecoder(Function):
         dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=ad, device=dev)
         dPKV = torch.empty(n_app, 2, B, ctx.prompt.shape[1], d, dtype=ad, device=dev) if spec.prompt else None
         dkeys = None  # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
+        dk_terms = []   # queued (g, q_m) terms of it (one K-concatenated launch at the end)
 
         def mh_backward(rec, dc, dm, dx_in):
             """Backprop one mask-head call; returns dx_in + its contribution to d(query)."""
@@ -723,13 +724,18 @@ class _FusedDecoder(Function):
                 mps = list(mh.mask_pred_list)[:Mm]
                 qm = rec["mh_qm"]
                 g = ops.scale_rows(dm.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=seg_pad)
-                # d keys: g @ q_m (accumulated over calls through the "+ aux" epilogue)
-                newk = torch.empty(Mm, B, Ns, d, dtype=torch.float32, device=dev)
-                L.gemm(M=Ns, N=d, K=Nq, A=[g] * Mm, B=[qm[m] for m in range(Mm)], Cs=[newk[m] for m in range(Mm)],
-                       aux=[dkeys[m] for m in range(Mm)] if dkeys is not None else None,
-                       act_grad="add" if dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
-                       strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
-                dkeys = newk
+                # d keys = sum over the mask-head calls of g_c @ q_m,c: nothing consumes it before the end of the backward, so
+                # the terms are queued and formed by ONE K-concatenated launch there (each call used to re-read and re-write
+                # the [Mm, B, Ns, d] fp32 sum through the "+ aux" epilogue: 100 MB per call at config 4)
+                if Mm * (len(dk_terms) + 1) <= MAXG:
+                    dk_terms.append((g, qm))
+                else:
+                    newk = torch.empty(Mm, B, Ns, d, dtype=torch.float32, device=dev)
+                    L.gemm(M=Ns, N=d, K=Nq, A=[g] * Mm, B=[qm[m] for m in range(Mm)], Cs=[newk[m] for m in range(Mm)],
+                           aux=[dkeys[m] for m in range(Mm)] if dkeys is not None else None,
+                           act_grad="add" if dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
+                           strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
+                    dkeys = newk
                 # [Nq x d] outputs per (memory, scene) over a reduction of Ns segments: few tiles, long K -> split-K into an
                 # fp32 buffer once Ns is large (c4: 192 workgroups x 64 k-tiles otherwise)
                 sk = min(8, Ns // 512) if Ns >= 1024 else 1
@@ -938,6 +944,16 @@ class _FusedDecoder(Function):
         # its all-reduce starts HERE (enc.grads_ready, set by the step owner) and overlaps the key/value input-gradient
         # products below and the encoders' backward that autograd runs after this function returns
         dkm_list = {}
+        if dk_terms:
+            Mm_, nc = spec.mh_count, len(dk_terms)
+            newk = torch.empty(Mm_, B, Ns, d, dtype=torch.float32, device=dev)
+            L.gemm(M=Ns, N=d, K=Nq, A=[t_[0] for m in range(Mm_) for t_ in dk_terms],
+                   B=[t_[1][m] for m in range(Mm_) for t_ in dk_terms],
+                   Cs=[c_ for m in range(Mm_) for c_ in [newk[m]] + [None] * (nc - 1)],
+                   aux=[c_ for m in range(Mm_) for c_ in [dkeys[m]] + [None] * (nc - 1)] if dkeys is not None else None,
+                   act_grad="add" if dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
+                   strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d, kconcat=nc)
+            dkeys, dk_terms = newk, []
         if dkeys is not None:
             for j in range(spec.mh_count):
                 mp = list(spec.mh.mask_pred_list)[j]
