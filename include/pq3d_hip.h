@@ -304,11 +304,12 @@ int pq3d_sum_pair(const float* const* src_a, int32_t na, float* out_a, int64_t c
                   int32_t nb, float* out_b, int64_t count_b, void* stream);
 #define PQ3D_MEAN_MAX_BLOCKS 256   /* ws: fp32[1 + PQ3D_MEAN_MAX_BLOCKS], element 0 (the arrival counter) zero before first use */
 int pq3d_mean_all(const float* x, int64_t n, float* out, float* ws, void* stream);
-/* out[0] = sum_g mean(f_g(x_g)) over n <= PQ3D_MAX_GROUPS fp32 tensors of counts[g] elements in ONE deterministic launch
- * (modes[g]: 0 identity, 1 clamp(min = clamp_min[g]), 2 non-finite elements count as 0), and its gradient
+/* out[0] = sum_g mean(f_g(x_g)) over n <= PQ3D_MAX_GROUPS fp32 tensors of counts[g] elements, deterministic: one launch of per-block
+ * partial sums + a one-block combine launch (an in-kernel last-arriver combine was 4x slower: every block's agent-scope
+ * release fence writes the L2 back) (modes[g]: 0 identity, 1 clamp(min = clamp_min[g]), 2 non-finite elements count as 0), and its gradient
  * dx_g[i] = gout[0] / counts[g] * f_g'(x_g[i]) in one more -- the synthetic loss of the mask configurations (SURVEY 8d:
  * sum over prediction layers of mean(clamp(mask_logits, -50)) + mean(class logits, filtered -inf columns dropped)).
- * ws: fp32[1 + 32 * PQ3D_MAX_GROUPS], element 0 (arrival counter) zero before first use. */
+ * ws: fp32[1 + 130 * PQ3D_MAX_GROUPS] scratch (the partial sums). */
 int pq3d_mean_many(const float* const* x, const int64_t* counts, const int32_t* modes, const float* clamp_min, int32_t n,
                    float* out, float* ws, void* stream);
 int pq3d_mean_many_bwd(const float* const* x, float* const* dx, const int64_t* counts, const int32_t* modes,

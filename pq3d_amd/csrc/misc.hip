@@ -479,7 +479,7 @@ __global__ void fill_scaled_kernel(float* dst, long n, const float* scalar, floa
 // add forward, fills and masks backward).  f: 0 identity, 1 max(x, c) (clamp(min=c)), 2 x if finite else 0.
 // grid = (MEAN_MANY_BLOCKS, tensors); deterministic: fixed per-block slices, partials combined by the last arriver in
 // (tensor, block) order.  ws[0] = ticket (zero before first use; reset by the last block), ws[1..] partials.
-#define MEAN_MANY_BLOCKS 32
+#define MEAN_MANY_BLOCKS 128   /* per tensor (32 with one load in flight per thread streamed config 4's 65 MB at under 1 TB/s) */
 struct MeanMany { int n; const float* x[PQ3D_MAX_GROUPS]; float* dx[PQ3D_MAX_GROUPS]; long count[PQ3D_MAX_GROUPS]; int mode[PQ3D_MAX_GROUPS]; float cmin[PQ3D_MAX_GROUPS]; };
 PQ_DEV float mean_many_f(float v, int mode, float c) { return mode == 1 ? fmaxf(v, c) : (mode == 2 ? (isfinite(v) ? v : 0.f) : v); }
 __global__ __launch_bounds__(256) void mean_many_kernel(const MeanMany m, float* out, float* ws) {
@@ -492,7 +492,17 @@ __global__ __launch_bounds__(256) void mean_many_kernel(const MeanMany m, float*
   const float c = m.cmin[g];
   float s = 0.f;
   if ((((uintptr_t)x) & 15) == 0) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long st = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * st < n4; i += 4 * st) {   // four 16-byte loads in flight per thread; fixed order of additions
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ((const float4*)x)[i + u * st];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        s += (mean_many_f(v[u].x, mode, c) + mean_many_f(v[u].y, mode, c)) + (mean_many_f(v[u].z, mode, c) + mean_many_f(v[u].w, mode, c));
+    }
+    for (; i < n4; i += st) {
       const float4 v = ((const float4*)x)[i];
       s += (mean_many_f(v.x, mode, c) + mean_many_f(v.y, mode, c)) + (mean_many_f(v.z, mode, c) + mean_many_f(v.w, mode, c));
     }
@@ -503,30 +513,29 @@ __global__ __launch_bounds__(256) void mean_many_kernel(const MeanMany m, float*
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  const unsigned total = gridDim.x * gridDim.y;
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&ws[1 + g * MEAN_MANY_BLOCKS + blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add((unsigned*)ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last = (t == total - 1);
+  // partial sums only; a second, one-block launch combines them (mean_many_combine_kernel).  An in-kernel last-arriver
+  // combine (release fence + ticket per block) was measured at ~10 us per 13 MB tensor whatever the block count (1.3 TB/s:
+  // the agent-scope release of every block writes the XCD's L2 back) against one more ~5 us launch here.
+  if (threadIdx.x == 0) ws[1 + 2 * PQ3D_MAX_GROUPS + g * MEAN_MANY_BLOCKS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  (void)out; (void)last;
+}
+// one block: wave w sums the partials of tensors w, w + 4, ... (all requested at once, fixed tree), thread 0 adds the
+// tensors in index order -> deterministic
+__global__ __launch_bounds__(256) void mean_many_combine_kernel(const MeanMany m, float* out, const float* ws, int nblocks) {
+  __shared__ float tsum[PQ3D_MAX_GROUPS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* part = ws + 1 + 2 * PQ3D_MAX_GROUPS;
+  for (int t = wv; t < m.n; t += 4) {
+    float p = 0.f;
+    for (int b = lane; b < nblocks; b += 64) p += part[t * MEAN_MANY_BLOCKS + b];
+    p = wave_sum(p);
+    if (lane == 0) tsum[t] = p / (float)m.count[t];
   }
   __syncthreads();
-  if (!last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // thread t < n tensors: its tensor's partials in block order, then the tensors in index order (wave 0, fixed tree)
-  float p = 0.f;
-  if ((int)threadIdx.x < m.n) {
-    for (int b = 0; b < (int)gridDim.x; ++b)
-      p += __hip_atomic_load(&ws[1 + threadIdx.x * MEAN_MANY_BLOCKS + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    p /= (float)m.count[threadIdx.x];
-  }
-  if (threadIdx.x < 64) {
-    p = wave_sum(p);
-    if (threadIdx.x == 0) {
-      out[0] = p;
-      __hip_atomic_store((unsigned*)ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (threadIdx.x == 0) {
+    float q = 0.f;
+    for (int t = 0; t < m.n; ++t) q += tsum[t];
+    out[0] = q;
   }
 }
 __global__ __launch_bounds__(256) void mean_many_bwd_kernel(const MeanMany m, const float* gout) {
@@ -536,10 +545,20 @@ __global__ __launch_bounds__(256) void mean_many_bwd_kernel(const MeanMany m, co
   const long n = m.count[g];
   const int mode = m.mode[g];
   const float c = m.cmin[g], sc = gout[0] / (float)n;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float v = x[i];
-    dx[i] = mode == 1 ? (v >= c ? sc : 0.f) : (mode == 2 ? (isfinite(v) ? sc : 0.f) : sc);
+  auto f = [&](float v) { return mode == 1 ? (v >= c ? sc : 0.f) : (mode == 2 ? (isfinite(v) ? sc : 0.f) : sc); };
+  long i0 = 0;
+  if (((((uintptr_t)x) | ((uintptr_t)dx)) & 15) == 0) {   // 16-byte pieces, two in flight per thread
+    const long n4 = n >> 2, st = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * st) {
+      const float4 a = ((const float4*)x)[i];
+      const bool two = i + st < n4;
+      const float4 b = two ? ((const float4*)x)[i + st] : a;
+      ((float4*)dx)[i] = make_float4(f(a.x), f(a.y), f(a.z), f(a.w));
+      if (two) ((float4*)dx)[i + st] = make_float4(f(b.x), f(b.y), f(b.z), f(b.w));
+    }
+    i0 = n4 << 2;
   }
+  for (long i = i0 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dx[i] = f(x[i]);
 }
 
 struct CastTPtrs { const float* src[PQ3D_MAX_GROUPS]; bf16_t* out[PQ3D_MAX_GROUPS]; bf16_t* outT[PQ3D_MAX_GROUPS]; };
@@ -702,6 +721,7 @@ extern "C" int pq3d_mean_many(const float* const* x, const int64_t* counts, cons
   MeanMany m;
   PQ_CHECK_ARG(!mean_many_fill(m, x, nullptr, counts, modes, clamp_min, n), "pq3d_mean_many: null tensor / empty / bad mode");
   hipLaunchKernelGGL(mean_many_kernel, dim3(MEAN_MANY_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, m, out, ws);
+  hipLaunchKernelGGL(mean_many_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, m, out, (const float*)ws, MEAN_MANY_BLOCKS);
   PQ_LAUNCH_CHECK();
   return 0;
 }
@@ -711,7 +731,7 @@ extern "C" int pq3d_mean_many_bwd(const float* const* x, float* const* dx, const
   PQ_CHECK_ARG(x && dx && counts && modes && gout && n >= 1 && n <= PQ3D_MAX_GROUPS, "pq3d_mean_many_bwd: bad args");
   MeanMany m;
   PQ_CHECK_ARG(!mean_many_fill(m, x, dx, counts, modes, clamp_min, n), "pq3d_mean_many_bwd: null tensor / empty / bad mode");
-  hipLaunchKernelGGL(mean_many_bwd_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, m, gout);
+  hipLaunchKernelGGL(mean_many_bwd_kernel, dim3(128, n), dim3(256), 0, (hipStream_t)stream, m, gout);
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -324,7 +324,7 @@ class _MeanMany(Function):
         key = (dev, "many")
         ws = _MEAN_WS.get(key)
         if ws is None:
-            ws = _MEAN_WS[key] = torch.zeros(1 + 32 * L.MAXG, dtype=torch.float32, device=dev)
+            ws = _MEAN_WS[key] = torch.zeros(1 + 2 * L.MAXG + 128 * L.MAXG, dtype=torch.float32, device=dev)
         ctx.arr = ((C.c_int64 * n)(*[x.numel() for x in xs]), (C.c_int32 * n)(*modes), (C.c_float * n)(*cmins))
         L.check(L.lib().pq3d_mean_many(_parr(xs), ctx.arr[0], ctx.arr[1], ctx.arr[2], n, L.ptr(out), L.ptr(ws), L.stream()),
                 "pq3d_mean_many")
