@@ -728,7 +728,16 @@ __global__ void mask_row_all_kernel(const uint8_t* mask, uint8_t* row_open, long
   const int lane = threadIdx.x & 63;
   const uint8_t* p = mask + row * Lk;
   int all = 1;
-  for (long j = lane; j < Lk; j += 64) all &= (p[j] != 0);
+  if ((Lk & 15) == 0 && ((((uintptr_t)mask) & 15) == 0)) {   // 16 mask bytes per lane and load (a byte each: 14 us for 10 MB)
+    for (long j = (long)lane * 16; j < Lk; j += 64 * 16) {
+      const uint4 w = *(const uint4*)(p + j);
+      // every byte non-zero <=> no zero byte in the word: (x - 0x01010101) & ~x & 0x80808080 == 0
+      auto nz = [](unsigned x) { return (((x - 0x01010101u) & ~x & 0x80808080u) == 0u); };
+      all &= (nz(w.x) && nz(w.y) && nz(w.z) && nz(w.w)) ? 1 : 0;
+    }
+  } else {
+    for (long j = lane; j < Lk; j += 64) all &= (p[j] != 0);
+  }
   all = __all(all);
   if (lane == 0) row_open[row] = all ? 1 : 0;
 }

@@ -185,6 +185,13 @@ def test_mask_row_all():
     m[1, 4] = True
     m[2, 0] = True
     assert torch.equal(ops.mask_row_all(m.to(DEV)).cpu(), m.all(-1))
+    for Lk in (16, 4096, 1040):   # 16-byte path: rows with a single open key at every position class
+        m = torch.ones(2, 40, Lk, dtype=torch.bool)
+        for r in range(0, 40, 3):
+            m[0, r, (r * 37) % Lk] = False
+        m[1, 5, Lk - 1] = False
+        m[1, 6, 0] = False
+        assert torch.equal(ops.mask_row_all(m.to(DEV)).cpu(), m.all(-1))
 
 
 # ---------------------------------------------------------------------------------------------- layernorm
