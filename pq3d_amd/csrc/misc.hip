@@ -40,6 +40,23 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const ColsumPtrs cp, long 
 __global__ void scale_rows_kernel(const void* x, int dtx, void* y, int dty, long R, long C, const float* scale,
                                   const uint8_t* zero_flag, const uint8_t* keep_mask) {
   const long total = R * C;
+  if (dtx == PQ3D_F32 && (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {   // 8 elements of one row per thread
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < total; i += (long)gridDim.x * blockDim.x * 8) {
+      const long r = i / C;
+      const bool keep = (!zero_flag || !zero_flag[r]) && (!keep_mask || keep_mask[r]);
+      const float sc = keep ? (scale ? scale[r] : 1.f) : 0.f;
+      const float4 a = *(const float4*)((const float*)x + i), b = *(const float4*)((const float*)x + i + 4);
+      // a dropped row is exactly zero (also for non-finite inputs)
+      const float v[8] = {keep ? a.x * sc : 0.f, keep ? a.y * sc : 0.f, keep ? a.z * sc : 0.f, keep ? a.w * sc : 0.f,
+                          keep ? b.x * sc : 0.f, keep ? b.y * sc : 0.f, keep ? b.z * sc : 0.f, keep ? b.w * sc : 0.f};
+      if (dty == PQ3D_BF16) *(u32x4*)((bf16_t*)y + i) = pack_frag<bf16_t>(v);
+      else {
+        *(float4*)((float*)y + i) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)y + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    return;
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / C;
     const bool keep = (!zero_flag || !zero_flag[r]) && (!keep_mask || keep_mask[r]);
