@@ -140,12 +140,21 @@ __global__ void pairwise_locs_kernel(const float* centers, long cs, float* out, 
   const float* c = centers + (long)b * L * cs;
   for (int i = tid; i < L * 3; i += blockDim.x) cen[i] = c[(long)(i / 3) * cs + (i % 3)];
   __syncthreads();
-  float mx = 0.f;
-  for (int p = tid; p < L * L; p += blockDim.x) {
-    const int i = p / L, j = p % L;
-    const float dx = cen[3 * i] - cen[3 * j], dy = cen[3 * i + 1] - cen[3 * j + 1], dz = cen[3 * i + 2] - cen[3 * j + 2];
-    mx = fmaxf(mx, sqrtf(dx * dx + dy * dy + dz * dz + eps));
+  // max over all pairs of sqrt(d2 + eps) = sqrt(max d2 + eps) (sqrtf is monotonic and correctly rounded: the same bits).
+  // Thread t walks row i = t, t + 256, ... against every j: no integer division, the j operands are LDS broadcasts
+  // (one thread per PAIR with p / L, p % L and a square root per pair was 11 us at L = 100, 34 us at L = 200)
+  float m2 = 0.f;
+  // rows x column quarters: thread t takes row t / 4 (+ 64 k) against the columns j = t % 4 (mod 4) -- four times the threads
+  // of a row-per-thread walk at L <= 64 k, the j operands still few distinct LDS addresses per wave
+  for (int i = tid >> 2; i < L; i += blockDim.x >> 2) {
+    const float xi = cen[3 * i], yi = cen[3 * i + 1], zi = cen[3 * i + 2];
+#pragma unroll 4
+    for (int j = tid & 3; j < L; j += 4) {
+      const float dx = xi - cen[3 * j], dy = yi - cen[3 * j + 1], dz = zi - cen[3 * j + 2];
+      m2 = fmaxf(m2, dx * dx + dy * dy + dz * dz + eps);
+    }
   }
+  float mx = L > 0 ? sqrtf(fmaxf(m2, eps)) : 0.f;
   mx = wave_max(mx);
   if ((tid & 63) == 0) red[tid >> 6] = mx;
   __syncthreads();
