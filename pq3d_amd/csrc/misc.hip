@@ -187,8 +187,10 @@ __global__ void fourier_kernel(const float* xyz, long xs, const float* cmin, con
       t *= 6.283185307179586f;
       proj += t * G[c * half + j];
     }
-    out[pn * 2 * half + j] = sinf(proj);
-    out[pn * 2 * half + half + j] = cosf(proj);
+    float sn, cs;
+    sincosf(proj, &sn, &cs);   // one argument reduction for both
+    out[pn * 2 * half + j] = sn;
+    out[pn * 2 * half + half + j] = cs;
   }
 }
 
@@ -210,8 +212,10 @@ __global__ void fourier_pair_kernel(const float* xa, long sa, int Na, const floa
       t *= 6.283185307179586f;
       proj += t * G[c * half + j];
     }
-    out[pn * 2 * half + j] = sinf(proj);
-    out[pn * 2 * half + half + j] = cosf(proj);
+    float sn, cs;
+    sincosf(proj, &sn, &cs);   // one argument reduction for both
+    out[pn * 2 * half + j] = sn;
+    out[pn * 2 * half + half + j] = cs;
   }
 }
 
