@@ -257,6 +257,9 @@ class Query3DUnified(nn.Module):
                     predictions_class, predictions_mask = [], []
                 if getattr(self.unified_encoder, "_fused_final", None) is not None:
                     pred_logits, pred_masks = self.unified_encoder._fused_final  # computed inside the fused executor
+                    # hand-over only: a module attribute would keep this forward's autograd graph (and with it the
+                    # parameters' AccumulateGrad nodes of the stream it ran on) alive until the next forward
+                    self.unified_encoder._fused_final = None
                 else:
                     pred_logits, pred_masks, _ = mask_head_partial(query=query, skip_prediction=False)
                 predictions_class.append(pred_logits)
