@@ -4,6 +4,8 @@
 // Column ownership: VEC (d == 64 * PL, PL >= 4, 16-byte aligned operands): lane owns PL CONSECUTIVE columns, every row
 // access is a 16-byte load/store; otherwise lane owns columns lane + 64 j (4-byte accesses, any d).
 // Large R: waves walk rows with a grid stride and keep the NEXT row's loads in flight.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -371,7 +373,12 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   // the 64-byte lines bounce between the XCDs' L2s) set the time, so few fat blocks win: measured at R = 2 x 8192,
   // blocks x waves: 1024x4 43 us, 512x4 28, 256x4 20, 256x8 16, 128x16 15, 64x16 28; query-sized calls: 4 waves x 2 rows
   const bool big = d.R >= 4096;
-  const int rpw = big ? 8 : 2, nw = big ? 8 : 4;
+  // query-sized calls: ~100 blocks of 4 waves (measured, PQ3D_LN_RPW sweep: R = 800: 2 rows per wave 126 us per step, 4: 130,
+  // 8: 176; R = 1600: 2: 300, 4: 275, 8: 311 -- more rows per wave = fewer contended parameter-gradient atomics, fewer = more
+  // rows in flight)
+  static const int rpw_env = [] { const char* e = getenv("PQ3D_LN_RPW"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
+  const int rpw_small = rpw_env ? rpw_env : (int)((d.R + 399) / 400 < 2 ? 2 : ((d.R + 399) / 400 > 8 ? 8 : (d.R + 399) / 400));
+  const int rpw = big ? 8 : rpw_small, nw = big ? 8 : 4;
   long nb = (d.R + rpw * nw - 1) / (rpw * nw);
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
