@@ -951,3 +951,35 @@ def test_gemm_input_gradient_over_an_unaligned_reduction(M, N, K):
                ct=BF16, lda=K, ldb=N, ldc=N, transB=True)
         ref = g.bfloat16().double() @ w.bfloat16().double() + (aux.double() if with_aux else 0)
         torch.testing.assert_close(out.double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ct", [F32, BF16])
+def test_linear_with_dropout_and_residual_in_the_epilogue_equals_the_separate_ops(ct):
+    """x + dropout(o W^T) and dropout(relu(h W^T)) with the dropout (and the residual add) riding the projection's epilogue
+    (the caption body, pq3d_amd/t5.py) draw the SAME mask as the stand-alone dropout op on the same site and give the same
+    outputs and gradients -- incl. the ReLU case whose backward takes the keep mask from the saved output."""
+    R, K, N, p = 96, 128, 64, 0.3
+    seed = torch.tensor([0x5eed1234], dtype=torch.int64, device=DEV)
+    for act, with_res in ((None, True), ("relu", False), (None, False)):
+        res = {}
+        for fused in (True, False):
+            o = rnd(3, 32, K, seed=1).to(DEV).requires_grad_()
+            w = (rnd(N, K, seed=2) * 0.2).to(DEV).requires_grad_()
+            x = rnd(3, 32, N, seed=3).to(DEV).requires_grad_()
+            d = L.Drop(p, 77, seed)
+            if fused:
+                y = ops.linear(o, w, None, ct=ct, act=act, drop=d, residual=x if with_res else None)
+            else:
+                y = ops.dropout(ops.linear(o, w, None, ct=ct, act=act), d)
+                if with_res:
+                    y = x + y
+            (y * rnd(3, 32, N, seed=4).to(DEV)).sum().backward()
+            res[fused] = (y.detach(), o.grad, w.grad, x.grad if with_res else None)
+        for name, a, b in zip(("y", "do", "dw", "dx"), res[True], res[False]):
+            if a is None:
+                continue
+            assert (a == 0).eq(b == 0).all() or name != "y", "different dropout masks"
+            tol = 1e-5 if ct == F32 else 2e-2
+            torch.testing.assert_close(a, b, rtol=tol, atol=tol * float(b.abs().max()), msg=lambda m: f"{act} {with_res} {name}: {m}")
+    assert R  # (shape constants above are for the reader)
