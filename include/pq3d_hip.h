@@ -664,6 +664,11 @@ int pq3d_group_maxpool(const void* rows, void* out, int32_t dt, int64_t G, int32
 int pq3d_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t R, int32_t d, float eps, void* stream);
 int pq3d_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw, int64_t R,
                      int32_t d, int32_t accumulate, void* stream);
+/* the same with the gradient of the sublayer's residual branch added to dx (x feeds the norm AND the residual add of a
+ * pre-norm sublayer, modeling_t5.py T5LayerSelfAttention / CrossAttention / FF: hidden + dropout(f(norm(hidden)))) -- the
+ * two-way gradient junction without an add launch; dres may be NULL */
+int pq3d_rmsnorm_bwd_res(const float* x, const float* w, const float* rstd, const float* dy, const float* dres, float* dx,
+                         float* dw, int64_t R, int32_t d, int32_t accumulate, void* stream);
 int pq3d_embedding_fwd(const float* table, const int64_t* ids, float* out, int64_t R, int32_t d, void* stream);
 int pq3d_embedding_bwd_acc(const float* dout, const int64_t* ids, float* dtable, int64_t R, int32_t d, void* stream);
 

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(WPB * 64) void rmsnorm_fwd_kernel(const float* __re
 template <int PL>
 __global__ __launch_bounds__(WPB * 64) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ rstd, const float* __restrict__ dy,
-                                                               float* __restrict__ dx, float* __restrict__ dw, long R, int d) {
+                                                               float* __restrict__ dx, float* __restrict__ dw, long R, int d,
+                                                               const float* __restrict__ dres) {
   __shared__ float red[WPB][64 * PL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wave_id = (long)blockIdx.x * WPB + wave, nwaves = (long)gridDim.x * WPB;
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(WPB * 64) void rmsnorm_bwd_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
       const int c = lane + 64 * j;
-      if (c < d) dx[row * d + c] = r * (g[j] - xh[j] * s);
+      if (c < d) dx[row * d + c] = r * (g[j] - xh[j] * s) + (dres ? dres[row * d + c] : 0.f);   // + the residual branch's gradient
     }
   }
 #pragma unroll
@@ -482,6 +483,11 @@ extern "C" int pq3d_rmsnorm_fwd(const float* x, const float* w, float* y, float*
 
 extern "C" int pq3d_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const float* dy, float* dx, float* dw,
                                 int64_t R, int32_t d, int32_t accumulate, void* stream) {
+  return pq3d_rmsnorm_bwd_res(x, w, rstd, dy, nullptr, dx, dw, R, d, accumulate, stream);
+}
+
+extern "C" int pq3d_rmsnorm_bwd_res(const float* x, const float* w, const float* rstd, const float* dy, const float* dres,
+                                    float* dx, float* dw, int64_t R, int32_t d, int32_t accumulate, void* stream) {
   PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && w && rstd && dy && dx && dw && R >= 0 && d >= 1 && d <= 64 * MAXPL, "pq3d_rmsnorm_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
@@ -494,7 +500,7 @@ extern "C" int pq3d_rmsnorm_bwd(const float* x, const float* w, const float* rst
   long nb = (R + 2 * WPB - 1) / (2 * WPB);
   if (nb > 1024) nb = 1024;
   dim3 grid((unsigned)nb);
-  RMS_DISPATCH(rmsnorm_bwd_kernel, grid, x, w, rstd, dy, dx, dw, (long)R, d)
+  RMS_DISPATCH(rmsnorm_bwd_kernel, grid, x, w, rstd, dy, dx, dw, (long)R, d, dres)
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -1125,8 +1125,12 @@ def split_rows(y, n: int):
 
 # ------------------------------------------------------------------------------------------------ T5 body pieces
 class _RMSNorm(Function):
+    """res=True: returns (y, x) -- the second output is x itself, for the sublayer's residual add: the gradients of BOTH uses
+    of x then arrive in this backward and are summed inside its kernel (no add launch at the junction)."""
+
     @staticmethod
-    def forward(ctx, x, w, eps):
+    def forward(ctx, x, w, eps, res=False):
+        ctx.res = bool(res)
         x, w = _c(x).float(), _c(w).float()
         d_ = x.shape[-1]
         R = x.numel() // d_
@@ -1135,24 +1139,33 @@ class _RMSNorm(Function):
         L.check(L.lib().pq3d_rmsnorm_fwd(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(rstd), R, d_, eps, L.stream()), "pq3d_rmsnorm_fwd")
         ctx.save_for_backward(x, w, rstd)
         ctx.pptr = w.data_ptr()
-        return y
+        return (y, x.view_as(x)) if res else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, w, rstd = ctx.saved_tensors
         d_ = x.shape[-1]
+        if dy is None:   # only the pass-through was used
+            return (dres, None, None, None)
         dy = dy.contiguous().float()
+        dres = dres.contiguous().float() if dres is not None else None
         dx = torch.empty_like(x)
         slot, give = arena_take([ctx.pptr], [w.numel()])   # the owner's gradient arena, when offered for this pass (pre-zeroed)
         dw = slot[0] if slot is not None else torch.empty_like(w)
-        L.check(L.lib().pq3d_rmsnorm_bwd(L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dy), L.ptr(dx), L.ptr(dw), x.numel() // d_, d_,
-                                         1 if slot is not None else 0, L.stream()), "pq3d_rmsnorm_bwd")
-        return dx, (dw if (slot is None or give) else None), None
+        L.check(L.lib().pq3d_rmsnorm_bwd_res(L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dy), L.ptr(dres), L.ptr(dx), L.ptr(dw),
+                                             x.numel() // d_, d_, 1 if slot is not None else 0, L.stream()), "pq3d_rmsnorm_bwd_res")
+        return dx, (dw if (slot is None or give) else None), None, None
 
 
 def rmsnorm(x, w, eps: float = 1e-6):
     """T5LayerNorm: x * rsqrt(mean(x^2) + eps) * w (fp32)."""
     return _RMSNorm.apply(x, w, float(eps))
+
+
+def rmsnorm_res(x, w, eps: float = 1e-6):
+    """(rmsnorm(x), x'): x' is x for the residual add of the pre-norm sublayer -- its gradient joins the norm's inside the
+    norm's backward kernel."""
+    return _RMSNorm.apply(x, w, float(eps), True)
 
 
 class _Embedding(Function):

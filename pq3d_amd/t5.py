@@ -14,6 +14,8 @@ import math
 from typing import Dict, Optional, Tuple
 
 import numpy as np
+import os
+
 import torch
 
 from . import ops
@@ -43,6 +45,13 @@ def shift_right(labels: torch.Tensor, start_id: int, pad_id: int) -> torch.Tenso
     """decoder_input_ids = [start, labels[:-1]] with ignored (-100) labels replaced by the pad token."""
     ids = torch.cat([torch.full_like(labels[:, :1], start_id), labels[:, :-1]], 1)
     return torch.where(ids == -100, torch.full_like(ids, pad_id), ids)
+
+
+_RES_JUNCTION = os.environ.get("PQ3D_T5_RES", "1") != "0"   # the residual branch's gradient joins inside the norm's backward kernel
+
+
+def _norm_res(x, w, eps):
+    return ops.rmsnorm_res(x, w, eps) if _RES_JUNCTION else (ops.rmsnorm(x, w, eps), x)
 
 
 def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], labels: torch.Tensor, ct: int,
@@ -90,20 +99,20 @@ def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], 
     for li, blk in enumerate(dec.block):
         sa, ca, ff = blk.layer[0], blk.layer[1], blk.layer[2]
         # -- self attention
-        h = ops.rmsnorm(x, sa.layer_norm.weight, cfg.layer_norm_epsilon)
+        h, x = _norm_res(x, sa.layer_norm.weight, cfg.layer_norm_epsilon)
         A = sa.SelfAttention
         q, k, v = ops.linear_group([h, h, h], [A.q.weight, A.k.weight, A.v.weight], ct=ct, out_dtype=ad)
         o = ops.attention(q, k, v, H=H, ct=ct, scale=1.0, bias=self_bias, drop=next_drop())
         x = proj_residual(o, A.o.weight)
         # -- cross attention to the projected query tokens (no position bias)
-        h = ops.rmsnorm(x, ca.layer_norm.weight, cfg.layer_norm_epsilon)
+        h, x = _norm_res(x, ca.layer_norm.weight, cfg.layer_norm_epsilon)
         A = ca.EncDecAttention
         q = ops.linear(h, A.q.weight, None, ct=ct, out_dtype=ad)
         k, v = xkv[2 * li], xkv[2 * li + 1]
         o = ops.attention(q, k, v, H=H, ct=ct, scale=1.0, kpm=enc_kpm, drop=next_drop())
         x = proj_residual(o, A.o.weight)
         # -- feed forward
-        h = ops.rmsnorm(x, ff.layer_norm.weight, cfg.layer_norm_epsilon)
+        h, x = _norm_res(x, ff.layer_norm.weight, cfg.layer_norm_epsilon)
         hid = ops.linear(h, ff.DenseReluDense.wi.weight, None, ct=ct, act="relu", out_dtype=ad, drop=next_drop())
         x = proj_residual(hid, ff.DenseReluDense.wo.weight)
     x = drop(ops.rmsnorm(x, dec.final_layer_norm.weight, cfg.layer_norm_epsilon))
