@@ -364,7 +364,9 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value, drop=None, residual=None):
         x, x2, w, fill_flag, residual = _c(x), _c(x2), _c(w), _c(fill_flag), _c(residual)
-        # epilogue order (gemm_common.h): bias, activation, dropout, then "+ residual": y = residual + dropout(act(x w^T + b))
+        # epilogue order (gemm_common.h): bias, activation, dropout, then "+ residual": y = residual + dropout(x w^T + b).
+        # No activation together with a residual: the backward reads the activation's mask off the saved OUTPUT.
+        assert residual is None or act is None, "residual add excludes an activation"
         K = x.shape[-1]
         R = x.numel() // K
         N = w.shape[0]
