@@ -1006,6 +1006,9 @@ def linear_ln_group(xs, Ws, bs, gammas, betas, *, ct: int, eps: float = 1e-5):
 # autograd views of them.  The offer ends with the pass (engine callback), so a later backward that does not start with
 # the decoder never sees stale zeroing.  mode "fresh": slots were just zeroed, return the views (autograd adopts them);
 # "accumulate": .grad already aliases the slots (second micro-batch), add in place and return None.
+# Process-global state (the autograd engine runs the backward functions on its own thread, so thread-local would not reach
+# them): ONE backward pass at a time may use an arena -- two models stepping concurrently from different threads must not
+# both be given one.
 class _Arena:
     mode = None
     by_ptr = {}      # parameter data_ptr -> (parameter, flat buffer, element offset, numel) of its slot
