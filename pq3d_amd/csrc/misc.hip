@@ -197,25 +197,35 @@ __global__ void fourier_kernel(const float* xyz, long xs, const float* cmin, con
 // two point sets of the same scenes (queries, segments) in one launch: out = [B * Na rows of set a | B * Nb rows of set b]
 __global__ void fourier_pair_kernel(const float* xa, long sa, int Na, const float* xb, long sb, int Nb, const float* cmin,
                                     const float* cmax, const float* G, float* out, int B, int half) {
-  const long ra = (long)B * Na, total = (ra + (long)B * Nb) * half;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i % half);
-    const long pn = i / half;
+  // one division per THREAD (its row within the block, its column), none per element: threads (row, j) of a block cover
+  // blockDim / half rows (or a column slice of one row when half > blockDim); the per-element 64-bit i / half, i % half and
+  // q / N of a flat index were most of the 12 us this kernel took at config 2
+  const int ra = B * Na, rows = ra + B * Nb;
+  const int tpr = half < (int)blockDim.x ? half : (int)blockDim.x;   // threads per row
+  const int rpb = (int)blockDim.x / tpr;                              // rows per block pass
+  const int rl = (int)threadIdx.x / tpr, j0 = (int)threadIdx.x % tpr;
+  for (int pn = (int)blockIdx.x * rpb + rl; pn < rows; pn += (int)gridDim.x * rpb) {
+    if (rl >= rpb) break;
     const bool isa = pn < ra;
-    const long q = isa ? pn : pn - ra;
-    const int b = (int)(q / (isa ? Na : Nb));
-    const float* p = isa ? xa + q * sa : xb + q * sb;
-    float proj = 0.f;
+    const int q = isa ? pn : pn - ra;
+    const int b = q / (isa ? Na : Nb);
+    const float* p = isa ? xa + (long)q * sa : xb + (long)q * sb;
+    float t[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float t = (p[c] - cmin[b * 3 + c]) / (cmax[b * 3 + c] - cmin[b * 3 + c]);
-      t *= 6.283185307179586f;
-      proj += t * G[c * half + j];
+      t[c] = (p[c] - cmin[b * 3 + c]) / (cmax[b * 3 + c] - cmin[b * 3 + c]);
+      t[c] *= 6.283185307179586f;
     }
-    float sn, cs;
-    sincosf(proj, &sn, &cs);   // one argument reduction for both
-    out[pn * 2 * half + j] = sn;
-    out[pn * 2 * half + half + j] = cs;
+    float* o = out + (long)pn * 2 * half;
+    for (int j = j0; j < half; j += tpr) {
+      float proj = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) proj += t[c] * G[c * half + j];
+      float sn, cs;
+      sincosf(proj, &sn, &cs);   // one argument reduction for both
+      o[j] = sn;
+      o[half + j] = cs;
+    }
   }
 }
 
@@ -935,7 +945,9 @@ extern "C" int pq3d_fourier_pair(const float* xyz_a, int64_t stride_a, int32_t N
   PQ_CHECK_ARG(xyz_a && xyz_b && cmin && cmax && gauss_B && out && stride_a >= 3 && stride_b >= 3 && half >= 1 && Na >= 0 &&
                    Nb >= 0, "pq3d_fourier_pair: bad args");
   if (B == 0 || Na + Nb == 0) return 0;
-  hipLaunchKernelGGL(fourier_pair_kernel, dim3(grid1d((long)B * (Na + Nb) * half)), dim3(256), 0, (hipStream_t)stream, xyz_a,
+  PQ_CHECK_ARG((long)B * (Na + Nb) < (1L << 30), "pq3d_fourier_pair: too many rows");
+  const int rpb_ = half < 256 ? 256 / half : 1;
+  hipLaunchKernelGGL(fourier_pair_kernel, dim3(grid1d(((long)B * (Na + Nb) + rpb_ - 1) / rpb_, 1, 65535)), dim3(256), 0, (hipStream_t)stream, xyz_a,
                      (long)stride_a, Na, xyz_b, (long)stride_b, Nb, cmin, cmax, gauss_B, out, B, half);
   PQ_LAUNCH_CHECK();
   return 0;
