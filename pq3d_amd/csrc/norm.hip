@@ -497,7 +497,10 @@ extern "C" int pq3d_rmsnorm_bwd_res(const float* x, const float* w, const float*
     if (int e = pq3d_zero_launch(z, s)) return e;
   }
   if (R == 0) return 0;
-  long nb = (R + 2 * WPB - 1) / (2 * WPB);
+  // one row per wave (PQ3D_RMS_RPW sweep at config 5, 19 calls of 512 rows x 512: 1 row per wave 194 us per step, 2: 282, 4: 503 --
+  // the rows of a wave are dependent load -> reduce -> store chains; the extra parameter-gradient atomics cost less)
+  static const int rms_rpw = [] { const char* e = getenv("PQ3D_RMS_RPW"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+  long nb = (R + rms_rpw * WPB - 1) / (rms_rpw * WPB);
   if (nb > 1024) nb = 1024;
   dim3 grid((unsigned)nb);
   RMS_DISPATCH(rmsnorm_bwd_kernel, grid, x, w, rstd, dy, dx, dw, (long)R, d, dres)
