@@ -1015,6 +1015,7 @@ class _Arena:
     written = set()  # slots some function of this pass already returned (a second use adds in place, returns None)
     whole_pass = False   # offered by grad_arena() around the whole backward (the decoder then neither zeroes nor offers)
     pending = None       # fresh whole-pass arena: buffers still to be zeroed -- by the FIRST consumer, together with its own
+    zeroed_ptrs = set()  # flat buffers the last fresh pass zero-filled (read by the gradient pack that follows it)
 
 
 def arena_flush_zero(extra=()) -> bool:
@@ -1024,7 +1025,17 @@ def arena_flush_zero(extra=()) -> bool:
         return False
     bufs, _Arena.pending = _Arena.pending, None
     zero_many(list(bufs) + [t for t in extra if t is not None])
+    _Arena.zeroed_ptrs = {b.data_ptr() for b in bufs}
     return True
+
+
+def arena_zeroed_buffers(consume: bool = True) -> set:
+    """data_ptrs of the flat buffers the last fresh whole-pass arena zero-filled: the gradient pack right after that pass need
+    not zero the slots of parameters that received no gradient.  consume: forget them (one pack per pass)."""
+    z = _Arena.zeroed_ptrs
+    if consume:
+        _Arena.zeroed_ptrs = set()
+    return z
 
 
 class grad_arena:
@@ -1039,6 +1050,7 @@ class grad_arena:
         self.slots, self.buffers = slots, list(buffers)
 
     def __enter__(self):
+        _Arena.zeroed_ptrs = set()
         if os.environ.get("PQ3D_GRAD_ARENA", "1") == "0":   # A/B switch: the decoder's own offer only
             return self
         zeroed = {b.data_ptr() for b in self.buffers}

@@ -74,6 +74,10 @@ class FlatGradAllReducer:
         """Copy every .grad into the flat buffers (capturable: fixed addresses, one foreach copy per bucket).
         Gradients that already ARE views of the flat buffer (written in place by the fused executor) are skipped."""
         unused = []   # slots of parameters without a gradient this step: zeroed by ONE launch at the end
+        prezeroed = set()
+        if self.flat and self.flat[0].is_cuda:
+            from . import ops
+            prezeroed = ops.arena_zeroed_buffers()   # buffers a whole-pass gradient arena zero-filled for this very pass
         for bi, (flat, bucket) in enumerate(zip(self.flat, self.buckets)):
             if buckets is not None and bi not in buckets:
                 continue
@@ -89,7 +93,7 @@ class FlatGradAllReducer:
                     if p.grad.data_ptr() != v.data_ptr():
                         views.append(v)
                         grads.append(p.grad)
-                else:
+                elif flat.data_ptr() not in prezeroed:
                     unused.append(v)
                 off += n
             if views:
