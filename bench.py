@@ -268,7 +268,22 @@ def main():
                     help="skip the extra train-mode-dropout timing reported next to the headline (N=1 only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU (the reference launches its own
+        # ranks too: launch.py:62-64, common/launch_utils.py:50-121) -- re-exec under torch.distributed.run on this node
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+                                  *sys.argv[1:]])
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: a line for {args.gpus} GPUs must come from "
+                         f"{args.gpus} ranks (launch with torch.distributed.run --nproc-per-node {args.gpus}, or plain "
+                         f"`python bench.py --gpus {args.gpus}`, which starts them)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback on the product path)"
@@ -540,7 +555,8 @@ def main():
                        "activation": "relu"},
             "step_algorithmic_gflop": flops / 1e9,
             "step_roofline_frac": flops * world / (dt / args.steps) / (peak * 1e12 * world),
-            **({"grads_identical_across_ranks": grads_identical} if world > 1 else {}),
+            **({"grads_identical_across_ranks": grads_identical, "collective_backend": backend,
+                "rccl_ranks": (torch.distributed.get_world_size() if backend == "nccl" else 0)} if world > 1 else {}),
             "roofline": roof,
             "roofline_next": blocks[1:],
             "kernel_families_ms_per_step": {k: round(v["ms"] / ps, 4) for k, v in sorted(fams.items())},

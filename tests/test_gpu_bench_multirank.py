@@ -20,12 +20,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("launcher", ["torchrun", "plain"])
 @pytest.mark.parametrize("config", ["c1", "c2"])
-def test_bench_two_ranks_one_gpu(config):
+def test_bench_two_ranks_one_gpu(config, launcher):
+    """launcher 'torchrun': the driver's N > 1 form; 'plain': `python bench.py --gpus 2` with no launcher -- bench.py starts
+    the ranks itself (a 1-rank process must never print a line for a 2-GPU request)."""
     env = dict(os.environ, PQ3D_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
-           "--config", config, "--headline-only"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--config", config, "--headline-only"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -35,6 +43,7 @@ def test_bench_two_ranks_one_gpu(config):
     assert r["config"]["parallelism"] == "dp2" and r["config"]["global_batch"] % 2 == 0
     assert r["value"] > 0 and abs(r["value"] - r["config"]["global_batch"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
     assert r["grads_identical_across_ranks"] is True
+    assert r["collective_backend"] == "gloo" and r["rccl_ranks"] == 0     # the test hook, not RCCL
     assert "cpu_baseline" not in r                       # rank-0 / N=1 only
     if config == "c2":
         # the fused decoder path: collectives cannot be captured with gloo, so the RCCL-independent overlap mode must have
@@ -58,4 +67,13 @@ def test_bench_two_ranks_rccl():
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
-    assert r["n_gpus"] == 2 and r["grads_identical_across_ranks"] is True and r["value"] > 0
+    assert r["n_gpus"] == 2 and r["grads_identical_across_ranks"] is True and r["value"] > 0 and r["rccl_ranks"] == 2
+
+
+def test_world_size_must_match_the_request():
+    """WORLD_SIZE=1 with --gpus 2 (a launcher that started one rank) must fail instead of printing a 1-GPU line."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
