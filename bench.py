@@ -351,7 +351,7 @@ def main():
         out = model(dict(dd))
         loss = loss_fn(out, c["heads"])
         if enc.grad_arena is not None:
-            with ops.grad_arena(enc.grad_arena, enc.grad_arena_buffers):   # every slot offered for the whole pass
+            with ops.grad_arena(enc.grad_arena, enc.grad_arena_buffers, pack_follows=True):   # every slot offered for the whole pass
                 loss.backward(gradient=one)   # cached seed gradient: no ones_like fill in the step
         else:
             loss.backward(gradient=one)

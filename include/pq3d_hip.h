@@ -71,22 +71,6 @@ int pq3d_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, const pq3d_drop
 int pq3d_dropout_apply(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
                        const pq3d_dropout* dr, void* stream);
 
-typedef struct {
-  int32_t M;               /* branches, 1..4; 0 = no LayerNorm prologue */
-  int32_t sum_branches;    /* the M inputs are partial sums of ONE branch */
-  int32_t rows_per_scene;  /* rows per scene (coef indexing) */
-  float eps;
-  const float* x;          /* residual input [R, d] fp32 or NULL */
-  const float* o[4];       /* branches [R, d] fp32 */
-  const float* gamma[4];
-  const float* beta[4];
-  const float* coef;       /* [M, R / rows_per_scene] branch weights or NULL */
-  float* y;                /* [R, d] fp32 out */
-  float* mean;             /* [M, R] out (sum_branches: [1, R]) */
-  float* rstd;
-  float* osum;             /* [R, d] sum of the partial sums (sum_branches) or NULL */
-} pq3d_ln_prologue;
-
 /* ------------------------------------------------------------------------------------------------
  * Grouped / batched GEMM with fused prologue + epilogue (nn.Linear forward and both backward GEMMs,
  * MaskPredictionLayer einsum).  Replaces: F.linear calls inside nn.MultiheadAttention
@@ -142,15 +126,6 @@ typedef struct {
   /* dropout applied to the activated output (site = C viewed as [batch*M, N], site id drop.site + group):
    * FFNLayer's self.dropout(self.activation(self.linear1(x))), query_encoder.py:385.  Not with split-K. */
   pq3d_dropout drop;
-  /* LayerNorm prologue (ln.M > 0): the A operand of EVERY group is y = sum_m w_m LN_m(x + o_m) -- pq3d_add_ln_fwd's
-   * arithmetic (w_m = coef[m, scene] or 1/M; sum_branches: ONE LayerNorm of x + sum_m o_m with gamma/beta 0, osum
-   * receives the sum) over rows of K = d columns -- and A[g] must all point at ln.y.  The small-M whole-K kernels
-   * (csrc/gemm_wk.hip) form y in their prologue from x / o (every workgroup holds complete rows: K = d <= 256) and the
-   * workgroups of the first column tile of group 0 also write y, mean, rstd (and osum) for the backward pass -- the
-   * separate add+LayerNorm launch between two projections disappears (query_encoder.py:303-307 -> :213-227,
-   * :384-388 -> next layer's :288-290); launches those kernels do not take run pq3d_add_ln_fwd first, then the product.
-   * No dropout inside the prologue (train-mode residual dropout keeps the separate launch). */
-  pq3d_ln_prologue ln;
 } pq3d_gemm_desc;
 
 int pq3d_gemm(const pq3d_gemm_desc* d, void* stream);
@@ -158,9 +133,9 @@ int pq3d_gemm(const pq3d_gemm_desc* d, void* stream);
  * split-bf16 compute) with whole-K tiles (csrc/gemm_wk.hip): 32- or 64-row x 64-column tiles on 8 waves, all operand
  * loads of a 256- (or 128-) wide k chunk in flight at once, chosen so that every workgroup of the launch is resident in
  * one round -- same MFMA order and epilogue as the 64x64-tile kernel, identical bits.  This process-wide switch sets the
- * option word (bit 0: on -- the default, environment PQ3D_WK=0 turns them off; bits 4-5: force 32- / 64-row tiles
+ * option word (bit 0: on -- the default; bits 4-5: force 32- / 64-row tiles
  * (1 / 2); bits 6-7: force 128- / 256-wide chunks (1 / 2); bit 8: also take launches that need several rounds) and the
- * largest M they take (max_m <= 0: keep; default 2048, environment PQ3D_WK_MAX_M).  For A/B measurements and tests. */
+ * largest M they take (max_m <= 0: keep; default 2048).  For A/B measurements and tests. */
 int pq3d_gemm_set_wk(int options, int max_m);
 
 
@@ -180,31 +155,6 @@ int pq3d_gemm_set_wk(int options, int max_m);
  * Backward (pq3d_attn_bwd) recomputes P from lse: needs o, do; writes dq/dk/dv with the strides of q/k/v,
  * `delta` is a [B,H,Lq] fp32 workspace, dbias ([B,H,Lq,Lk] fp32, may be NULL) receives dL/dbias.
  * ------------------------------------------------------------------------------------------------ */
-/* ------------------------------------------------------------------------------------------------
- * The decoder's feed-forward sublayer in one launch (FFNLayer, query_encoder.py:371-388):
- *     h = dropout(act(x W1^T + b1))      [R, F]  (and `pre`, the pre-activation, when the activation is GELU)
- *     zp[s] = h[:, s*256:(s+1)*256] W2[:, s*256:(s+1)*256]^T  (+ b2 in slice 0)      s = 0 .. F/256 - 1,  [R, d] each
- * -- the F/256 PARTIAL sums of linear2, to be added in index order by the LayerNorm that follows (pq3d_add_ln_fwd with
- * sum_branches: y = LN(x + dropout(sum_s zp[s]))).  fp32 tensors, split-bf16 products (PQ3D_BF16X3 arithmetic);
- * d = 256, F a multiple of 256 (<= 32 slices); every pointer 16-byte aligned.  The inner dropout site is h viewed as
- * [R, F] (the site pq3d_gemm's epilogue uses for the same tensor, so pq3d_gemm regenerates this mask in the backward).
- * csrc/ffn.hip.
- * ------------------------------------------------------------------------------------------------ */
-typedef struct {
-  int32_t R, d, F;
-  int32_t act;              /* PQ3D_ACT_RELU / PQ3D_ACT_GELU */
-  const float* x;           /* [R, d] */
-  const float* w1;          /* [F, d]  linear1.weight */
-  const float* b1;          /* [F] */
-  const float* w2;          /* [d, F]  linear2.weight */
-  const float* b2;          /* [d] or NULL */
-  float* h;                 /* [R, F] out */
-  float* pre;               /* [R, F] out or NULL */
-  float* zp;                /* [F/256, R, d] out */
-  pq3d_dropout drop;        /* inner dropout (p = 0 / seed NULL: off) */
-} pq3d_ffn_desc;
-int pq3d_ffn_fwd(const pq3d_ffn_desc* d, void* stream);
-
 /* Projection folded into an attention launch (the split-bf16 self-attention kernels only: compute type PQ3D_BF16X3,
  * d_h = 32, at most 240 queries / keys; any other call with mode != 0 is refused with an error, nothing is launched).
  *   PQ3D_ATTN_PROJ_DOUT (backward): the out-projection's input gradient is formed in the kernel,

@@ -56,7 +56,8 @@ def build(verbose: bool = False) -> str | None:
         os.makedirs(bdir)
         srcs = sorted(glob.glob(work + "/src/*.cpp") + glob.glob(work + "/src/*.cu"))
         load(name=NAME, sources=srcs, extra_include_paths=[os.path.join(work, "include")], build_directory=bdir,
-             verbose=verbose, extra_cflags=["-O2"], extra_cuda_cflags=["-O2"], is_python_module=True)
+             verbose=verbose, extra_cflags=["-O2"], extra_cuda_cflags=["-O2"], is_python_module=False)   # build only: the .so is
+        # imported (= the reference's code executed) nowhere but in oracle/run_ref_pointnet2.py
         shutil.copy2(os.path.join(bdir, NAME + ".so"), target)
     print(f"[oracle/_ref] built {target}")
     return target

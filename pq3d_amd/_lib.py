@@ -93,12 +93,6 @@ class CeDesc(C.Structure):
                 ("scale", C.c_void_p), ("dlogits", C.c_void_p * MAXG)]
 
 
-class LnPrologue(C.Structure):
-    _fields_ = [("M", C.c_int32), ("sum_branches", C.c_int32), ("rows_per_scene", C.c_int32), ("eps", C.c_float),
-                ("x", C.c_void_p), ("o", C.c_void_p * 4), ("gamma", C.c_void_p * 4), ("beta", C.c_void_p * 4),
-                ("coef", C.c_void_p), ("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("osum", C.c_void_p)]
-
-
 class GemmDesc(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32), ("batch", C.c_int32),
@@ -114,14 +108,8 @@ class GemmDesc(C.Structure):
         ("bias", C.c_void_p * MAXG), ("C", C.c_void_p * MAXG), ("C2", C.c_void_p * MAXG),
         ("aux", C.c_void_p * MAXG), ("row_mask", C.c_void_p * MAXG), ("colsum", C.c_void_p * MAXG),
         ("row_scale", C.c_void_p), ("row_fill_flag", C.c_void_p), ("mask_out", C.c_void_p),
-        ("drop", Dropout), ("ln", LnPrologue),
+        ("drop", Dropout),
     ]
-
-
-class FfnDesc(C.Structure):
-    _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32), ("act", C.c_int32), ("x", C.c_void_p), ("w1", C.c_void_p),
-                ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("h", C.c_void_p), ("pre", C.c_void_p),
-                ("zp", C.c_void_p), ("drop", Dropout)]
 
 
 class AttnProj(C.Structure):
@@ -164,7 +152,6 @@ _lib = None
 _SIGS = {
     "pq3d_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "pq3d_gemm_set_wk": [C.c_int, C.c_int],
-    "pq3d_ffn_fwd": [C.POINTER(FfnDesc), C.c_void_p],
     "pq3d_attn_fwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_attn_bwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
@@ -273,8 +260,6 @@ def lib() -> C.CDLL:
             fn.restype = C.c_int
         L.pq3d_last_error.restype = C.c_char_p
         L.pq3d_version.restype = C.c_int
-        if os.environ.get("PQ3D_ATTN_SA") == "0":     # A/B measurements: without the split-bf16 MFMA self-attention kernels
-            L.pq3d_attn_resident(7)
         _lib = L
     return _lib
 
@@ -319,7 +304,7 @@ def _fill(arr, tensors: Optional[Sequence[Optional[torch.Tensor]]]):
 def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C2=None, aux=None, row_mask=None,
          transA=False, transB=False, batch=1, strideA=0, strideB=0, strideC=0, act=None, act_grad=None, splitk=1,
          kconcat=0, accumulate=False, alpha=1.0, row_scale=None, row_fill_flag=None, row_fill=0.0,
-         mask_out=None, colsum=None, drop=None, ln=None) -> None:
+         mask_out=None, colsum=None, drop=None) -> None:
     """kconcat: number of consecutive groups concatenated along K per output (True = all groups)."""
     if kconcat is True:
         kconcat = len(A)
@@ -342,14 +327,6 @@ def gemm(*, M, N, K, A, B, Cs, ct, lda, ldb, ldc, A2=None, B2=None, bias=None, C
     _fill(d.C2, C2); _fill(d.aux, aux); _fill(d.row_mask, row_mask); _fill(d.colsum, colsum)
     d.row_scale, d.row_fill_flag, d.mask_out = ptr(row_scale), ptr(row_fill_flag), ptr(mask_out)
     set_drop(d.drop, drop)
-    if ln is not None:    # LayerNorm prologue (see pq3d_gemm_desc.ln): dict(x, o, gamma, beta, coef, eps, rows_per_scene, y, mean, rstd, sum_branches, osum)
-        q = d.ln
-        q.M, q.sum_branches, q.rows_per_scene, q.eps = len(ln["o"]), int(bool(ln.get("sum_branches"))), int(ln["rows_per_scene"]), float(ln["eps"])
-        q.x, q.coef, q.y, q.mean, q.rstd, q.osum = ptr(ln.get("x")), ptr(ln.get("coef")), ptr(ln["y"]), ptr(ln["mean"]), ptr(ln["rstd"]), ptr(ln.get("osum"))
-        for m_, t_ in enumerate(ln["o"]):
-            q.o[m_] = ptr(t_)
-        for m_, (g_, b_) in enumerate(zip(ln["gamma"], ln["beta"])):
-            q.gamma[m_], q.beta[m_] = ptr(g_), ptr(b_)
     from .profiler import timed
     nb = (M * K * (2 if d.dtA else 4) + N * K * (2 if d.dtB else 4)) * len(A) * batch + \
         M * N * (2 if d.dtC else 4) * (len(A) // max(kconcat, 1)) * batch

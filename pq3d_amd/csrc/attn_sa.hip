@@ -158,9 +158,9 @@ PQ_DEV void stage_wslice(bf16_t* dst, const float* src, long sl, int rows, int t
 }
 
 // 4 consecutive bias values bias[row][c .. c + 3] (c % 4 == 0), 0 beyond the row / matrix
-PQ_DEV void bias4(const float* bias, int row, int c, int Lq, int Lk, bool vec, float* out, int stride = 0) {
+PQ_DEV void bias4(const float* bias, int row, int c, int Lq, int Lk, bool vec, float* out) {
   if (!bias || row >= Lq) { out[0] = out[1] = out[2] = out[3] = 0.f; return; }
-  const float* p = bias + (long)row * (stride ? stride : Lk) + c;
+  const float* p = bias + (long)row * Lk + c;
   if (vec && c + 3 < Lk) { const float4 t = *(const float4*)p; out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w; }
   else {
 #pragma unroll
@@ -168,34 +168,10 @@ PQ_DEV void bias4(const float* bias, int row, int c, int Lq, int Lk, bool vec, f
   }
 }
 
-// Option (PQ3D_SA_BIAS_LDS=1, off by default): the additive bias [Lq][Lk] of the head is copied into LDS by coalesced row
-// loads issued with the operand loads (template BL) and the key loops read it with LDS latency.  Background (in-kernel
-// timeline, tools/probes/sa_timeline.py, config 2): straight from global memory every 32-key step of the backward waits
-// ~0.4 us on its 8 bias values per lane although they are requested one step ahead (1.1 us per step, 0.7 of it
-// arithmetic).  The bias is HBM-cold when the layer's attention runs (written at the start of the step, 100+ launches
-// earlier), so whatever requests it earlier pays the same ~2 us in front of the operand staging instead (loads return in
-// order): requesting 4 steps ahead and this LDS copy both shortened the key loops (phase A 4.6 -> 3.6 us) and lengthened
-// the staging by more (2.4 -> 4.0 us): 17.6 -> 19-21 us per backward launch, 8.9 -> 10.6 forward.  Kept as an option.
-// Row stride: Lk, + 4 floats when Lk % 8 == 0 (16 rows of a 16-byte column read would otherwise share their banks).
-PQ_DEV int bias_lds_stride(int Lk) { return (Lk & 7) == 0 ? Lk + 4 : Lk; }
-PQ_DEV void stage_bias(float* dst, const float* src, int Lq, int Lk, int tid, int nthr) {   // Lk % 4 == 0, src 16-byte aligned
-  const int r4 = Lk >> 2, n4 = Lq * r4, bst = bias_lds_stride(Lk);
-  for (int base = tid; base < n4; base += nthr * 4) {
-    float4 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = min(base + u * nthr, n4 - 1);
-      t[u] = *(const float4*)(src + (long)(c / r4) * Lk + (c % r4) * 4);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = base + u * nthr;
-      if (c < n4) *(float4*)&dst[(c / r4) * bst + (c % r4) * 4] = t[u];
-    }
-  }
-}
-
-template <bool BL>
+// (Measured and removed, round 3: the head's additive bias copied into LDS with the operand loads, or requested 4 steps ahead.
+// The bias is HBM-cold when the layer's attention runs -- written at the start of the step, 100+ launches earlier -- so
+// whatever requests it earlier pays the same ~2 us in front of the operand staging instead: key loops 4.6 -> 3.6 us, staging
+// 2.4 -> 4.0 us, 17.6 -> 19-21 us per backward launch.  tools/probes/sa_timeline.py)
 __global__ __launch_bounds__(1024) void attn_sa_fwd_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   extern __shared__ __attribute__((aligned(16))) unsigned char sa_sm[];
@@ -207,8 +183,6 @@ __global__ __launch_bounds__(1024) void attn_sa_fwd_kernel(const pq3d_attn_desc 
   const float* k = (const float*)d.k + (long)b * d.k_sb + (long)h * d.k_sh;
   const float* v = (const float*)d.v + (long)b * d.v_sb + (long)h * d.v_sh;
   const float* gbias = d.bias ? d.bias + ((long)b * d.H + h) * Lq * (long)Lk : nullptr;
-  float* const Bs = S.dl + LPq;   // BL: the head's bias tile
-  if constexpr (BL) stage_bias(Bs, gbias, Lq, Lk, tid, nthr);
   stage_planes<2>(S.Qh, S.Ql, q, d.q_sl, Lq, LPq, tid, nthr);
   stage_planes<2>(S.Kh, S.Kl, k, d.k_sl, Lk, LPk, tid, nthr);
   stage_planes<2>(S.Vh, S.Vl, v, d.v_sl, Lk, LPk, tid, nthr);
@@ -217,23 +191,21 @@ __global__ __launch_bounds__(1024) void attn_sa_fwd_kernel(const pq3d_attn_desc 
   const int q0 = wave * 16;
   if (q0 >= LPq) return;
   const int qrow = q0 + li;                       // this lane's query (column of the transposed score tiles)
-  const float* bias;
-  int bst = 0;
-  if constexpr (BL) { bias = Bs; bst = bias_lds_stride(Lk); } else bias = gbias;
-  const bool bvec = BL || ((Lk & 3) == 0 && ((((uintptr_t)bias) & 15) == 0));
+  const float* bias = gbias;
+  const bool bvec = (Lk & 3) == 0 && ((((uintptr_t)bias) & 15) == 0);
   const HL qf = frag_rm(S.Qh, S.Ql, qrow, lg);
   float m_run = -INFINITY, l_run = 0.f;
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};   // O^T: rows d_h 4 lg + r (+16), column = query
   float bn[8];
-  bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn, bst);
-  bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4, bst);
+  bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn);
+  bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4);
   for (int t0 = 0; t0 < LPk; t0 += 32) {
     float bc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bc[j] = bn[j];
     if (t0 + 32 < LPk) {   // next pair's bias in flight during this pair's arithmetic
-      bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn, bst);
-      bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4, bst);
+      bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn);
+      bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4);
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     mma3(s0, frag_rm(S.Kh, S.Kl, t0 + li, lg), qf);
@@ -278,7 +250,6 @@ __global__ __launch_bounds__(1024) void attn_sa_fwd_kernel(const pq3d_attn_desc 
 #define SA_TLV(i, val) do { } while (0)
 #endif
 
-template <bool BL>
 __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   ATTN_KARG_PIN_BWD(d);
@@ -298,7 +269,6 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
   // projection's output and the head's 32 columns of the weight (staged k-major as one bf16 plane behind the float arrays)
   const bool fold = d.proj.mode == PQ3D_ATTN_PROJ_DOUT;
   bf16_t* const Wt = (bf16_t*)(S.dl + LPq2);
-  float* const Bs = (float*)(Wt + (fold ? d.proj.dm * LDH : 0));   // BL: the head's bias tile (see attn_sa_fwd_kernel)
   const float* gbias = d.bias ? d.bias + ((long)b * d.H + h) * Lq * (long)Lk : nullptr;
   // folded projection: the gradient rows of this wave's first query block (dm = 256: all 8 k steps), its O row and lse are
   // requested before anything waits -- they are back by the time the weight slice is staged
@@ -316,7 +286,6 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
     lse_e = d.lse[sbase + qr];
   }
   if (fold) stage_wslice(Wt, d.proj.w[0] + h * DH, d.proj.dm, d.proj.dm, tid, nthr);
-  if constexpr (BL) stage_bias(Bs, gbias, Lq, Lk, tid, nthr);
   stage_planes<2>(S.Qh, S.Ql, q, d.q_sl, Lq, LPq2, tid, nthr);
   if (!fold) stage_planes<2>(S.Gh, S.Gl, g, d.o_sl, Lq, LPq2, tid, nthr);
   stage_planes<2>(S.Kh, S.Kl, k, d.k_sl, Lk, LPk, tid, nthr);
@@ -407,11 +376,9 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
   SA_TL(3);
   __syncthreads();
   SA_TL(4);
-  const float* bias;
-  int bst = 0;
-  if constexpr (BL) { bias = Bs; bst = bias_lds_stride(Lk); } else bias = gbias;
+  const float* bias = gbias;
   float* dbias = d.dbias ? d.dbias + ((long)b * d.H + h) * Lq * (long)Lk : nullptr;
-  const bool bvec = BL || ((Lk & 3) == 0 && ((((uintptr_t)bias)) & 15) == 0);
+  const bool bvec = (Lk & 3) == 0 && ((((uintptr_t)bias)) & 15) == 0;
   const bool dvec = (Lk & 3) == 0 && ((((uintptr_t)dbias)) & 15) == 0;
   // ---------------- phase A: wave = query block; transposed tiles (lane = query column, 4 keys per tile per lane)
   const int q0 = wave * 16;
@@ -421,15 +388,15 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
     const float lse = S.lse[qrow], dlt = S.dl[qrow];
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};   // dQ^T
     float bn[8];
-    bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn, bst);
-    bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4, bst);
+    bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn);
+    bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4);
     for (int t0 = 0; t0 < LPk; t0 += 32) {
       float bc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) bc[j] = bn[j];
       if (t0 + 32 < LPk) {
-        bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn, bst);
-        bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4, bst);
+        bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn);
+        bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4);
       }
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
       if (t0 == 0) SA_TLV(8, bc[0] + bc[7]);
@@ -486,7 +453,7 @@ __global__ __launch_bounds__(1024) void attn_sa_bwd_kernel(const pq3d_attn_desc 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int qr = t0 + (j < 4 ? 0 : 16) + 4 * lg + (j & 3);
-      bc[j] = (bias && qr < Lq && krow < Lk) ? bias[(long)qr * (BL ? bst : Lk) + krow] : 0.f;
+      bc[j] = (bias && qr < Lq && krow < Lk) ? bias[(long)qr * Lk + krow] : 0.f;
     }
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
     mma3(s0, frag_rm(S.Qh, S.Ql, t0 + li, lg), kf);             // S = Q K^T
@@ -540,11 +507,6 @@ bool pq3d_attn_sa_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd) {
   if (fold && (d.proj.dm != d.H * DH || (d.o_sl & 3))) return false;
   size_t lds = sa_lds_bytes(bwd ? ((d.Lq + 31) & ~31) : d.Lq, d.Lk, bwd, fold ? d.proj.dm : 0);
   if (lds > 160 * 1024) return false;
-  // the bias tile in LDS when it fits and its rows can be copied in 16-byte pieces
-  const size_t bias_bytes = (size_t)d.Lq * ((d.Lk & 7) == 0 ? d.Lk + 4 : d.Lk) * sizeof(float);
-  static const bool want_bl = [] { const char* e = getenv("PQ3D_SA_BIAS_LDS"); return e && e[0] == '1'; }();
-  const bool bl = want_bl && d.bias && (d.Lk & 3) == 0 && al16(d.bias) && lds + bias_bytes <= 160 * 1024;
-  if (bl) lds += bias_bytes;
   const int blocks = (max(d.Lq, d.Lk) + 15) / 16;
 #define SA_LAUNCH(KERN)                                                                              \
   do {                                                                                               \
@@ -552,8 +514,7 @@ bool pq3d_attn_sa_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd) {
     if (pq3d_enable_big_lds(KERN, 160 * 1024, done)) { (void)hipGetLastError(); return false; }      \
     hipLaunchKernelGGL(KERN, dim3(d.H, d.B), dim3(blocks * 64), lds, s, d);                          \
   } while (0)
-  if (bwd) { if (bl) SA_LAUNCH(attn_sa_bwd_kernel<true>); else SA_LAUNCH(attn_sa_bwd_kernel<false>); }
-  else { if (bl) SA_LAUNCH(attn_sa_fwd_kernel<true>); else SA_LAUNCH(attn_sa_fwd_kernel<false>); }
+  if (bwd) SA_LAUNCH(attn_sa_bwd_kernel); else SA_LAUNCH(attn_sa_fwd_kernel);
 #undef SA_LAUNCH
   return true;
 }

@@ -158,7 +158,6 @@ struct pq3d_kdesc {
   const uint8_t* row_fill_flag;
   uint8_t* mask_out;
   pq3d_dropout drop;
-  pq3d_ln_prologue ln;
   pq3d_kgroup gp[PQ3D_MAX_GROUPS];
 };
 inline pq3d_kdesc make_kdesc(const pq3d_gemm_desc& d) {
@@ -168,7 +167,7 @@ inline pq3d_kdesc make_kdesc(const pq3d_gemm_desc& d) {
   k.transB = d.transB; k.act = d.act; k.act_grad = d.act_grad; k.splitk = d.splitk; k.kconcat = d.kconcat;
   k.accumulate = d.accumulate; k.dtB2 = d.dtB2; k.alpha = d.alpha; k.row_fill = d.row_fill; k.lda = d.lda; k.ldb = d.ldb;
   k.ldc = d.ldc; k.strideA = d.strideA; k.strideB = d.strideB; k.strideC = d.strideC; k.row_scale = d.row_scale;
-  k.row_fill_flag = d.row_fill_flag; k.mask_out = d.mask_out; k.drop = d.drop; k.ln = d.ln;
+  k.row_fill_flag = d.row_fill_flag; k.mask_out = d.mask_out; k.drop = d.drop;
   for (int g = 0; g < PQ3D_MAX_GROUPS; ++g) {
     const bool on = g < d.groups;
     k.gp[g].A = on ? d.A[g] : nullptr; k.gp[g].A2 = on ? d.A2[g] : nullptr; k.gp[g].B = on ? d.B[g] : nullptr;

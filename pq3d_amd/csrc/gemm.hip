@@ -600,27 +600,11 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   pq3d_kdesc kd = make_kdesc(d);   // the kernels' compact form of the descriptor (common.h)
   int wk_err = 0;
-  if (d.ln.M > 0) {
-    PQ_CHECK_ARG(d.ln.M <= 4 && d.ln.y && d.ln.mean && d.ln.rstd && d.batch == 1 && !d.transA, "pq3d_gemm: bad LayerNorm prologue");
-    for (int g = 0; g < d.groups; ++g) PQ_CHECK_ARG(d.A[g] == (const void*)d.ln.y && d.dtA == PQ3D_F32, "pq3d_gemm: with a LayerNorm prologue every A must be ln.y (fp32)");
-  }
   // small-M launches (the query side): whole-K tiles, gemm_wk.hip -- same bits, a third of the in-kernel latency
   if ((d.splitk == 1 || d.accumulate) && pq3d_gemm_wk_try(d, kd, s, &wk_err)) {
     if (wk_err) return wk_err;
     PQ_LAUNCH_CHECK();
     return 0;
-  }
-  if (d.ln.M > 0) {
-    // not a launch the whole-K kernels fuse the LayerNorm into: run it as its own launch (pq3d_add_ln_fwd), then the product
-    pq3d_ln_desc l;
-    memset(&l, 0, sizeof(l));
-    l.R = d.M; l.d = d.K; l.M = d.ln.M; l.rows_per_scene = d.ln.rows_per_scene > 0 ? d.ln.rows_per_scene : d.M;
-    l.dt_x = l.dt_o = l.dt_y = PQ3D_F32; l.eps = d.ln.eps;
-    l.x = d.ln.x; l.coef = d.ln.coef; l.y = d.ln.y; l.mean = d.ln.mean; l.rstd = d.ln.rstd;
-    l.sum_branches = d.ln.sum_branches; l.osum = d.ln.osum;
-    for (int m = 0; m < d.ln.M; ++m) { l.o[m] = d.ln.o[m]; l.gamma[m] = d.ln.gamma[m]; l.beta[m] = d.ln.beta[m]; }
-    if (int e = pq3d_add_ln_fwd(&l, stream)) return e;
-    d.ln.M = 0; kd.ln.M = 0;
   }
   if (d.ct == PQ3D_BF16X3) {
     // split-bf16: C = A.B^T of fp32 operands to fp32-grade accuracy on the bf16 matrix cores (3 MFMAs per product term

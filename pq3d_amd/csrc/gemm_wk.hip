@@ -39,7 +39,6 @@ template <int TM, int KC> struct WkShape {
 template <bool X3, bool TRB, int TM, int KC> constexpr size_t wk_lds_bytes() {
   return (size_t)(X3 ? 2 : 1) * ((size_t)TM * (KC + 8) + (TRB ? (size_t)KC * LDKN : (size_t)TN * (KC + 8))) * sizeof(bf16_t);
 }
-constexpr size_t WK_LN_LDS = 4 * 2 * 256 * sizeof(float);   // LayerNorm prologue: gamma / beta of up to 4 branches, behind the tiles
 
 PQ_DEV void split_hi_lo(const float* v, u32x4& hi, u32x4& lo) {
   hi = pack_frag<bf16_t>(v);
@@ -52,26 +51,10 @@ PQ_DEV void split_hi_lo(const float* v, u32x4& hi, u32x4& lo) {
   lo = pack_frag<bf16_t>(w);
 }
 
-// sum over the 32 lanes of a half wave (the threads that share one operand row at KC = 256; at KC = 128 a row is 16 lanes:
-// `half` = false stops after the 16-lane steps)
-template <bool HALF> PQ_DEV float row_sum(float v) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v += dpp_xor_f(v, k);
-  if constexpr (HALF) {
-    u32pair_s a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  }
-  return v;
-}
-
-// LNM: LayerNorm prologue (pq3d_gemm_desc.ln) with up to LNM branches (0 = none): the A tile is y = sum_m w_m LN_m(x + o_m),
-// formed in registers from x / o for ALL of K (<= 256: one or two chunks) before the first chunk is staged.
-template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int TM, int KC, int LNM = 0>
+template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int TM, int KC>
 __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
   typedef WkShape<TM, KC> S;
   constexpr int LDR = S::LDR, CPR = S::CPR;
-  constexpr int NCK = LNM ? 256 / KC : 1;   // chunks that hold a whole LayerNorm row
-  static_assert(!LNM || (sizeof(TA) == 4 && !TRB), "LayerNorm prologue: fp32 rows, row-major B");
   static_assert(!X3 || (!TRB && sizeof(TA) == 4 && sizeof(TB) == 4), "split-bf16: row-major fp32 operands");
   static_assert(!HA2 || sizeof(TA) == 4, "addend needs an fp32 primary");
   extern __shared__ __attribute__((aligned(16))) unsigned char wk_smem[];
@@ -113,8 +96,6 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
 #pragma unroll
   for (int j = 0; j < S::NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float yv[LNM ? S::NA : 1][NCK][8];   // LayerNorm prologue: the normalised A rows of this thread, all chunks
-  int ck_put = 0;                      // chunk of the LayerNorm row the next put() stages
   // ---- one register set: the loads of chunk t+1 are issued right after chunk t has been written to LDS
   Raw<TA, 8> ra[S::NA];
   Raw<float, 8> ra2[HA2 ? S::NA : 1];
@@ -134,7 +115,7 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
       const int c = tid + i * WT, row = c / CPR, k = k0 + (c % CPR) * 8;
       oka[i] = k < d.K;
       const long off = (long)min(m0 + row, d.M - 1) * d.lda + (oka[i] ? k : 0);
-      if constexpr (sizeof(TA) == 4 && !HA2 && !LNM && TRB) {
+      if constexpr (sizeof(TA) == 4 && !HA2 && TRB) {
         if (ua) {   // uniform: rows of an unaligned length (class logits: 201 columns) -- element loads, zeros past K
           float t[8];
 #pragma unroll
@@ -144,8 +125,8 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
           continue;
         }
       }
-      if constexpr (!LNM) ra[i].load(Ab + off);
-      if constexpr (HA2) ra2[i].load(pA2 ? (const float*)pA2 + off : (LNM ? d.ln.o[0] + off : (const float*)pA + off));   // no addend: finite filler, scaled by 0
+      ra[i].load(Ab + off);
+      if constexpr (HA2) ra2[i].load(pA2 ? (const float*)pA2 + off : (const float*)pA + off);   // no addend: finite filler, scaled by 0
     }
 #pragma unroll
     for (int i = 0; i < S::NB; ++i) {
@@ -177,10 +158,7 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
         *(u32x4*)&Ah[o] = p;
       } else {
         float v[8];
-        if constexpr (LNM) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = yv[i][NCK == 1 ? 0 : ck_put][j];
-        } else ra[i].to_float(v);
+        ra[i].to_float(v);
         if constexpr (HA2) {
           float w[8];
           ra2[i].to_float(w);
@@ -228,130 +206,7 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
     }
   };
 
-  issue();             // B (and A2) of the first chunk go out first; the LayerNorm inputs follow them
-  if constexpr (LNM) {
-    const pq3d_ln_prologue& q = d.ln;
-    const int dd = d.K;                       // LayerNorm width = K (checked on the host)
-    const int nb = q.sum_branches ? 1 : q.M;  // LayerNorms per row
-    const long R = d.M;
-    const bool writer = blockIdx.y == 0 && blockIdx.z == 0;
-    const long nscene = q.coef ? R / q.rows_per_scene : 1;
-    // gamma / beta of every branch go through LDS (one cooperative load now, no dependent global round trip per branch
-    // later); the branch weights of this thread's rows are fetched with the row loads
-    float* const gsm = (float*)(wk_smem + wk_lds_bytes<X3, TRB, TM, KC>());
-    {
-      const int per = dd / 4, tot = nb * 2 * per;     // float4 pieces: [branch][gamma | beta][d / 4]
-      if (tid < tot) {
-        const int m = tid / (2 * per), r_ = tid % (2 * per), isb = r_ / per, c4 = r_ % per;
-        *(float4*)&gsm[(m * 2 + isb) * 256 + c4 * 4] = *(const float4*)((isb ? q.beta[m] : q.gamma[m]) + c4 * 4);
-      }
-    }
-    float wrow[LNM][S::NA];
-#pragma unroll
-    for (int m = 0; m < LNM; ++m)
-#pragma unroll
-      for (int i = 0; i < S::NA; ++i) {
-        const int grow_ = min(m0 + (tid + i * WT) / CPR, d.M - 1);
-        wrow[m][i] = q.sum_branches ? 1.f : (q.coef ? (m < q.M ? q.coef[m * nscene + grow_ / q.rows_per_scene] : 0.f) : 1.f / (float)q.M);
-      }
-    Raw<float, 8> rx[S::NA][NCK], ro[LNM][S::NA][NCK];
-#pragma unroll
-    for (int i = 0; i < S::NA; ++i)
-#pragma unroll
-      for (int ck = 0; ck < NCK; ++ck) {
-        const int c = tid + i * WT, row = c / CPR, k = ck * KC + (c % CPR) * 8;
-        const long off = (long)min(m0 + row, d.M - 1) * dd + (k < dd ? k : 0);
-        if (q.x) rx[i][ck].load(q.x + off);
-#pragma unroll
-        for (int m = 0; m < LNM; ++m)
-          if (m < q.M) ro[m][i][ck].load(q.o[m] + off);
-      }
-    __syncthreads();   // gamma / beta staged
-#pragma unroll
-    for (int i = 0; i < S::NA; ++i) {
-      const int c = tid + i * WT, row = c / CPR, grow = min(m0 + row, d.M - 1);
-      float xr[NCK][8], acc_y[NCK][8];
-#pragma unroll
-      for (int ck = 0; ck < NCK; ++ck) {
-        if (q.x) rx[i][ck].to_float(xr[ck]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { if (!q.x) xr[ck][j] = 0.f; acc_y[ck][j] = 0.f; }
-      }
-#pragma unroll
-      for (int m = 0; m < LNM; ++m) {
-        if (m < nb) {   // uniform
-          float v[NCK][8];
-#pragma unroll
-          for (int ck = 0; ck < NCK; ++ck) {
-            ro[m][i][ck].to_float(v[ck]);
-            if (q.sum_branches) {   // partial sums of one branch: add them in index order (as pq3d_add_ln_fwd)
-#pragma unroll
-              for (int p = 1; p < LNM; ++p)
-                if (p < q.M) {
-                  float t[8];
-                  ro[p][i][ck].to_float(t);
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) v[ck][j] += t[j];
-                }
-              if (q.osum && writer && m0 + row < d.M) {
-                const int k = ck * KC + (c % CPR) * 8;
-                if (k < dd) {
-                  float* po = q.osum + (long)grow * dd + k;
-                  *(float4*)po = make_float4(v[ck][0], v[ck][1], v[ck][2], v[ck][3]);
-                  *(float4*)(po + 4) = make_float4(v[ck][4], v[ck][5], v[ck][6], v[ck][7]);
-                }
-              }
-            }
-          }
-          float s1 = 0.f;
-#pragma unroll
-          for (int ck = 0; ck < NCK; ++ck) {
-            const bool okk = ck * KC + (c % CPR) * 8 < dd;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { v[ck][j] = okk ? xr[ck][j] + v[ck][j] : 0.f; s1 += v[ck][j]; }
-          }
-          const float mean = row_sum<KC == 256>(s1) / (float)dd;
-          float s2_ = 0.f;
-#pragma unroll
-          for (int ck = 0; ck < NCK; ++ck) {
-            const bool okk = ck * KC + (c % CPR) * 8 < dd;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float t = v[ck][j] - mean; s2_ += okk ? t * t : 0.f; }
-          }
-          const float rstd = 1.f / sqrtf(row_sum<KC == 256>(s2_) / (float)dd + q.eps);
-          const float w = wrow[m][i];
-#pragma unroll
-          for (int ck = 0; ck < NCK; ++ck) {
-            const int k = ck * KC + (c % CPR) * 8;
-            if (k < dd) {
-              const float* gp_ = &gsm[(m * 2) * 256 + k];
-              const float4 g0 = *(const float4*)gp_, g1 = *(const float4*)(gp_ + 4);
-              const float4 b0 = *(const float4*)(gp_ + 256), b1 = *(const float4*)(gp_ + 260);
-              const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-              const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-              for (int j = 0; j < 8; ++j) acc_y[ck][j] += w * ((v[ck][j] - mean) * rstd * gm[j] + bt[j]);
-            }
-          }
-          if (writer && (c % CPR) == 0 && m0 + row < d.M) {
-            q.mean[(long)m * R + grow] = mean;
-            q.rstd[(long)m * R + grow] = rstd;
-          }
-        }
-      }
-#pragma unroll
-      for (int ck = 0; ck < NCK; ++ck) {
-        const int k = ck * KC + (c % CPR) * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) yv[i][ck][j] = acc_y[ck][j];
-        if (writer && k < dd && m0 + row < d.M) {
-          float* py = q.y + (long)grow * dd + k;
-          *(float4*)py = make_float4(acc_y[ck][0], acc_y[ck][1], acc_y[ck][2], acc_y[ck][3]);
-          *(float4*)(py + 4) = make_float4(acc_y[ck][4], acc_y[ck][5], acc_y[ck][6], acc_y[ck][7]);
-        }
-      }
-    }
-  }
+  issue();
   // the bias row in accumulator layout, requested right behind the first operand loads (no dependent round trip later)
   const bool bias_early = gp.bias != nullptr && d.dtBias == PQ3D_F32 && d.alpha == 1.f && d.splitk <= 1;
   float bcol[S::NJ];
@@ -362,7 +217,6 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
   for (int it = 0; it < nit; ++it) {
     if (it > 0) __syncthreads();   // the previous chunk's fragment reads are done
     put();
-    if constexpr (LNM) ck_put = (ck_put + 1) % NCK;
     __syncthreads();
     const int kspan = min(KC, d.K - kc_cur * KC);
     if (++kc_cur == c1) kc_cur = c0;
@@ -427,13 +281,13 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-std::atomic<int> g_wk_enable{-1};   // -1: read PQ3D_WK from the environment on first use; else the option word (bit 0 = on)
+std::atomic<int> g_wk_enable{1};   // the option word of pq3d_gemm_set_wk (bit 0 = on)
 int g_wk_max_m = 2048;
 
-template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int TM, int KC, int LNM = 0>
+template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int TM, int KC>
 int wk_launch(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
-  auto kern = gemm_wk_kernel<X3, TA, TB, TRB, HA2, TM, KC, LNM>;
-  constexpr size_t lds = wk_lds_bytes<X3, TRB, TM, KC>() + (LNM ? WK_LN_LDS : 0);
+  auto kern = gemm_wk_kernel<X3, TA, TB, TRB, HA2, TM, KC>;
+  constexpr size_t lds = wk_lds_bytes<X3, TRB, TM, KC>();
   static std::atomic<unsigned> attr_done{0};   // per (kernel instantiation, device)
   if (int e = pq3d_enable_big_lds(kern, (int)lds, attr_done)) return e;
   const int kc = d.kconcat > 0 ? d.kconcat : 1;
@@ -450,7 +304,7 @@ struct WkPlan { int tm, kc; };
 size_t wk_lds(bool x3, bool trb, int tm, int kc) {
   return (size_t)(x3 ? 2 : 1) * ((size_t)tm * (kc + 8) + (trb ? (size_t)kc * LDKN : (size_t)TN * (kc + 8))) * 2;
 }
-bool wk_plan(const pq3d_gemm_desc& d, bool x3, int opt, WkPlan* out, bool tm32_only = false) {
+bool wk_plan(const pq3d_gemm_desc& d, bool x3, int opt, WkPlan* out) {
   const int force_tm = (opt >> 4) & 3, force_kc = (opt >> 6) & 3;
   const bool multi_round = (opt >> 8) & 1;
   const int kcn = d.kconcat > 0 ? d.kconcat : 1, sk = d.splitk > 1 ? d.splitk : 1;
@@ -459,10 +313,9 @@ bool wk_plan(const pq3d_gemm_desc& d, bool x3, int opt, WkPlan* out, bool tm32_o
   for (int tm = 32; tm <= 64; tm *= 2)
     for (int kc = 256; kc >= 128; kc /= 2) {
       if (force_tm && tm != (force_tm == 1 ? 32 : 64)) continue;
-      if (tm32_only && tm != 32) continue;
       if (force_kc && kc != (force_kc == 1 ? 128 : 256)) continue;
       const long wgs = (long)((d.M + tm - 1) / tm) * ((d.N + TN - 1) / TN) * (d.groups / kcn) * sk;
-      const size_t lds = wk_lds(x3, d.transB != 0, tm, kc) + (d.ln.M > 0 ? WK_LN_LDS : 0);
+      const size_t lds = wk_lds(x3, d.transB != 0, tm, kc);
       const long per_cu = lds > 80 * 1024 ? 1 : 2;
       const long rounds = (wgs + 256 * per_cu - 1) / (256 * per_cu);
       if (rounds > 1 && !multi_round) continue;
@@ -474,17 +327,14 @@ bool wk_plan(const pq3d_gemm_desc& d, bool x3, int opt, WkPlan* out, bool tm32_o
   return found;
 }
 
-template <bool X3, typename TA, typename TB, bool TRB, bool HA2, int LNM = 0>
+template <bool X3, typename TA, typename TB, bool TRB, bool HA2>
 int wk_launch_plan(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, WkPlan p) {
   if (p.tm == 32) {
-    if (p.kc == 256) return wk_launch<X3, TA, TB, TRB, HA2, 32, 256, LNM>(d, kd, s);
-    return wk_launch<X3, TA, TB, TRB, HA2, 32, 128, LNM>(d, kd, s);
+    if (p.kc == 256) return wk_launch<X3, TA, TB, TRB, HA2, 32, 256>(d, kd, s);
+    return wk_launch<X3, TA, TB, TRB, HA2, 32, 128>(d, kd, s);
   }
-  if constexpr (LNM <= 1) {   // several LayerNorm branches per row: 32-row tiles only (register budget of the prologue)
-    if (p.kc == 256) return wk_launch<X3, TA, TB, TRB, HA2, 64, 256, LNM>(d, kd, s);
-    return wk_launch<X3, TA, TB, TRB, HA2, 64, 128, LNM>(d, kd, s);
-  }
-  return (int)hipErrorInvalidValue;
+  if (p.kc == 256) return wk_launch<X3, TA, TB, TRB, HA2, 64, 256>(d, kd, s);
+  return wk_launch<X3, TA, TB, TRB, HA2, 64, 128>(d, kd, s);
 }
 
 }  // namespace
@@ -499,20 +349,13 @@ extern "C" int pq3d_gemm_set_wk(int options, int max_m) {
 // call is outside its domain.
 bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err) {
   *err = 0;
-  int en = g_wk_enable.load();
-  if (en < 0) {
-    const char* e = getenv("PQ3D_WK");
-    en = e ? atoi(e) : 1;
-    if (en < 0) en = 0;
-    if (const char* m = getenv("PQ3D_WK_MAX_M")) { const int v = atoi(m); if (v > 0) g_wk_max_m = v; }
-    g_wk_enable.store(en);
-  }
+  const int en = g_wk_enable.load();
   if (!(en & 1)) return false;
   // A rows of an unaligned length (K % 8 or lda % 8: the class head's 201 logits as the reduction of its input gradient):
   // taken with element loads when A is fp32 without an addend and B is the transposed (k-major, aligned) operand
   const bool ua = ((d.K | d.lda) & 7) != 0;
   if (d.transA || d.batch != 1 || d.M > g_wk_max_m || d.M < 1 || d.K < 8) return false;
-  if (ua && !(d.transB && d.dtA == PQ3D_F32 && d.ct == PQ3D_BF16 && d.ln.M == 0 && d.splitk <= 1 && d.kconcat <= 1)) return false;
+  if (ua && !(d.transB && d.dtA == PQ3D_F32 && d.ct == PQ3D_BF16 && d.splitk <= 1 && d.kconcat <= 1)) return false;
   if (d.ct != PQ3D_BF16 && d.ct != PQ3D_BF16X3) return false;
   const bool x3 = d.ct == PQ3D_BF16X3;
   if (x3 && (d.transB || d.dtA != PQ3D_F32 || d.dtB != PQ3D_F32 || d.splitk > 1)) return false;
@@ -520,6 +363,11 @@ bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t
   if (d.transB && (d.N % 8 || d.N < 8)) return false;
   if ((!ua && d.lda % 8) || d.ldb % 8) return false;
   if (d.splitk > 1 && (d.dtC != PQ3D_F32 || d.kconcat > 1)) return false;
+  if (d.splitk > 1) {   // the split-K branch adds alpha * acc with atomics and has no epilogue: refuse anything that needs one
+    if (d.act || d.act_grad || d.row_scale || d.row_fill_flag || d.mask_out || (d.drop.p > 0.f && d.drop.seed)) return false;
+    for (int g = 0; g < d.groups; ++g)
+      if (d.bias[g] || d.aux[g] || d.C2[g] || d.row_mask[g]) return false;
+  }
   bool a2 = false;
   for (int g = 0; g < d.groups; ++g) {
     if ((!ua && !aligned16(d.A[g])) || (((uintptr_t)d.A[g]) & 3) || !aligned16(d.B[g]) || d.B2[g] || d.colsum[g]) return false;
@@ -527,23 +375,10 @@ bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t
     if (d.A2[g]) { a2 = true; if (!aligned16(d.A2[g]) || d.dtA2 != PQ3D_F32 || d.dtA != PQ3D_F32) return false; }
   }
   if (a2 && d.transB) return false;
-  const pq3d_ln_prologue& q = d.ln;
-  const bool ln = q.M > 0;
-  if (ln) {   // LayerNorm prologue: split-bf16 forward projections whose rows are whole LayerNorm rows
-    if (!x3 || d.kconcat > 1 || d.K > 256 || d.lda != d.K || q.M > 4 || !q.y || !q.mean || !q.rstd) return false;
-    if ((q.x && !aligned16(q.x)) || !aligned16(q.y) || (q.osum && !aligned16(q.osum))) return false;
-    const int nb = q.sum_branches ? 1 : q.M;
-    for (int m = 0; m < q.M; ++m) if (!q.o[m] || !aligned16(q.o[m])) return false;
-    for (int m = 0; m < nb; ++m) if (!q.gamma[m] || !q.beta[m] || !aligned16(q.gamma[m]) || !aligned16(q.beta[m])) return false;
-    for (int g = 0; g < d.groups; ++g) if (d.A[g] != (const void*)q.y) return false;
-  }
   WkPlan p;
-  if (!wk_plan(d, x3, en, &p, ln && q.M > 1)) return false;   // more than one round of workgroups: the 4-wave pipeline kernel is better there
+  if (!wk_plan(d, x3, en, &p)) return false;   // more than one round of workgroups: the 4-wave pipeline kernel is better there
   int e;
-  if (ln) {
-    if (q.M > 1) e = a2 ? wk_launch_plan<true, float, float, false, true, 4>(d, kd, s, p) : wk_launch_plan<true, float, float, false, false, 4>(d, kd, s, p);
-    else e = a2 ? wk_launch_plan<true, float, float, false, true, 1>(d, kd, s, p) : wk_launch_plan<true, float, float, false, false, 1>(d, kd, s, p);
-  } else if (x3) {
+  if (x3) {
     e = a2 ? wk_launch_plan<true, float, float, false, true>(d, kd, s, p) : wk_launch_plan<true, float, float, false, false>(d, kd, s, p);
   } else if (!d.transB) {
     if (d.dtA == PQ3D_F32) e = a2 ? wk_launch_plan<false, float, float, false, true>(d, kd, s, p) : wk_launch_plan<false, float, float, false, false>(d, kd, s, p);

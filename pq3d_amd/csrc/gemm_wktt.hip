@@ -140,9 +140,6 @@ __global__ __launch_bounds__(WT) void gemm_wktt_kernel(const pq3d_kdesc d, const
 }
 
 bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-std::atomic<int> g_tt_enable{-1};
-
-int g_tt_tile = 0;   // 0: automatic, 64 / 128: forced (PQ3D_WKTT_TILE, A/B measurements)
 
 template <typename TA, typename TB, bool HB2, int KC, int TT>
 int tt_launch_t(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
@@ -163,11 +160,9 @@ int tt_launch_t(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
 }
 template <typename TA, typename TB, bool HB2>
 int tt_launch(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
-  // 128 x 128 tiles (128 reduction rows per chunk: the same 70 KB of LDS)
-  // -- measured slower on config 2 (flush launches 25-33 us against 15-25: one 178-VGPR workgroup per CU and four times the
-  // atomics per tile outweigh the halved L2 re-reads), so only on request (PQ3D_WKTT_TILE=128)
-  const bool big = g_tt_tile == 128;
-  if (big && d.M >= 128 && d.N >= 128) return tt_launch_t<TA, TB, HB2, 128, 128>(d, kd, s);
+  // 64 x 64 tiles, 256 reduction rows per chunk.  (128 x 128 tiles over 128-row chunks -- the same 70 KB of LDS, half the
+  // operand re-reads from L2 -- were measured slower at config 2: flush launches 25-33 us against 15-25, one 178-VGPR
+  // workgroup per CU and four times the atomics per tile; the instantiation is not built any more)
   return tt_launch_t<TA, TB, HB2, 256, 64>(d, kd, s);
 }
 
@@ -177,17 +172,13 @@ int tt_launch(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
 // outside its domain.  The caller has zero-filled C (or accumulates on purpose).
 bool pq3d_gemm_wktt_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err) {
   *err = 0;
-  int en = g_tt_enable.load();
-  if (en < 0) {
-    const char* e = getenv("PQ3D_WKTT");
-    en = (e && e[0] == '0') ? 0 : 1;
-    if (const char* t = getenv("PQ3D_WKTT_TILE")) g_tt_tile = atoi(t);
-    g_tt_enable.store(en);
-  }
-  if (!en) return false;
   if (!(d.transA && d.transB) || d.ct != PQ3D_BF16 || d.batch != 1 || d.kconcat > 1 || d.splitk < 2 || d.dtC != PQ3D_F32) return false;
   if (d.M < 8 || d.N < 8 || d.M % 8 || d.N % 8 || d.lda % 8 || d.ldb % 8 || d.K < 1) return false;
   if (d.ldc != d.N) return false;
+  // this kernel has no epilogue beyond alpha and the fused column sums: anything else belongs to the pipeline kernel
+  if (d.act || d.act_grad || d.row_scale || d.row_fill_flag || d.mask_out || (d.drop.p > 0.f && d.drop.seed)) return false;
+  for (int g = 0; g < d.groups; ++g)
+    if (d.bias[g] || d.aux[g] || d.C2[g] || d.row_mask[g]) return false;
   // long reductions over bf16 x bf16 operands (the K/V projections' weight gradients) belong to the 128x128-tile kernel
   if (d.dtA == PQ3D_BF16 && d.dtB == PQ3D_BF16 && d.K >= 2048) return false;
   bool b2 = false;

@@ -373,11 +373,10 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   // the 64-byte lines bounce between the XCDs' L2s) set the time, so few fat blocks win: measured at R = 2 x 8192,
   // blocks x waves: 1024x4 43 us, 512x4 28, 256x4 20, 256x8 16, 128x16 15, 64x16 28; query-sized calls: 4 waves x 2 rows
   const bool big = d.R >= 4096;
-  // query-sized calls: ~100 blocks of 4 waves (measured, PQ3D_LN_RPW sweep: R = 800: 2 rows per wave 126 us per step, 4: 130,
+  // query-sized calls: ~100 blocks of 4 waves (measured, rows-per-wave sweep: R = 800: 2 rows per wave 126 us per step, 4: 130,
   // 8: 176; R = 1600: 2: 300, 4: 275, 8: 311 -- more rows per wave = fewer contended parameter-gradient atomics, fewer = more
   // rows in flight)
-  static const int rpw_env = [] { const char* e = getenv("PQ3D_LN_RPW"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 0; }();
-  const int rpw_small = rpw_env ? rpw_env : (int)((d.R + 399) / 400 < 2 ? 2 : ((d.R + 399) / 400 > 8 ? 8 : (d.R + 399) / 400));
+  const int rpw_small = (int)((d.R + 399) / 400 < 2 ? 2 : ((d.R + 399) / 400 > 8 ? 8 : (d.R + 399) / 400));
   const int rpw = big ? 8 : rpw_small, nw = big ? 8 : 4;
   long nb = (d.R + rpw * nw - 1) / (rpw * nw);
   if (nb > 1024) nb = 1024;
@@ -497,9 +496,9 @@ extern "C" int pq3d_rmsnorm_bwd_res(const float* x, const float* w, const float*
     if (int e = pq3d_zero_launch(z, s)) return e;
   }
   if (R == 0) return 0;
-  // one row per wave (PQ3D_RMS_RPW sweep at config 5, 19 calls of 512 rows x 512: 1 row per wave 194 us per step, 2: 282, 4: 503 --
+  // one row per wave (rows-per-wave sweep at config 5, 19 calls of 512 rows x 512: 1 row per wave 194 us per step, 2: 282, 4: 503 --
   // the rows of a wave are dependent load -> reduce -> store chains; the extra parameter-gradient atomics cost less)
-  static const int rms_rpw = [] { const char* e = getenv("PQ3D_RMS_RPW"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 8 ? v : 1; }();
+  constexpr int rms_rpw = 1;
   long nb = (R + rms_rpw * WPB - 1) / (rms_rpw * WPB);
   if (nb > 1024) nb = 1024;
   dim3 grid((unsigned)nb);

@@ -18,7 +18,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -133,9 +132,8 @@ class FusedSpec:
         return ops.make_drop(module.dropout_p, ops.drop_site(self.drop_base, app, kind, m), device)
 
 
-def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call, ln=None):
-    """One MaskHeadSegLevel call (number `call` of this forward) on the fused path; returns (cls, mlog, amask).
-    ``ln``: pending LayerNorm that produces x (see _ln_defer), consumed by the call's first projection."""
+def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
+    """One MaskHeadSegLevel call (number `call` of this forward) on the fused path; returns (cls, mlog, amask)."""
     mh = spec.mh
     ct = ops.small_ct(spec.ct)     # query-side GEMMs: split-bf16 in 'bf16' mode (fp32 operands and outputs)
     ad = ops.act_dtype(ct)
@@ -144,7 +142,7 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call, ln=None):
     c0, c2, c4 = mh.cls_head[0], mh.cls_head[2], mh.cls_head[4]
     h1 = torch.empty(B, Nq, c0.out_features, dtype=torch.float32, device=x.device)
     L.gemm(M=R, N=c0.out_features, K=d, A=[x], B=[c0.weight.detach()], bias=[c0.bias.detach()], Cs=[h1], ct=ct,
-           lda=d, ldb=d, ldc=c0.out_features, act="relu", ln=ln)
+           lda=d, ldb=d, ldc=c0.out_features, act="relu")
     h2, mean, rstd = _ln_fwd(None, [h1], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq)
     hdrop = None
     if spec.mh_drop:   # nn.Dropout between LayerNorm and the classifier (utils.py:23), site (mask-head base, call)
@@ -188,48 +186,6 @@ def _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, out_dtype=torch.fl
     L.check(timed("pq3d_add_ln_fwd", f"R{R}d{dm}M{M}", 0.0, nb, L.lib().pq3d_add_ln_fwd, C.byref(d), L.stream()),
             "pq3d_add_ln_fwd")
     return y, mean, rstd
-
-
-# Fold add+LayerNorm launches into the next projection's prologue (pq3d_gemm_desc.ln).  OFF by default: measured on MI355X at
-# config 2 (tools/ab_env.sh PQ3D_LN_FUSE, round 3) the folded launches cost MORE than the pair they replace -- every
-# workgroup of the consumer recomputes the LayerNorm of its rows (12x redundantly for the 3-group Q/K/V projection, 32x for
-# the FFN's first layer) as a serial phase in front of its MFMAs: Q/K/V 9.0 + LayerNorm 6.0 us -> 22.4 us folded, FFN linear1
-# 11.2 + 4.8 -> 16.7, next-layer Q projection 9.0 + 5.4 -> 19.0; step 1.54 -> 1.59 ms at 126 -> 115 dispatches.
-LN_FUSE = os.environ.get("PQ3D_LN_FUSE", "0") != "0"
-
-
-def _ln_defer(x, os_, gammas, betas, eps, coef, rows_per_scene, drop=None, sum_branches=False, osum=None):
-    """add+LayerNorm whose result is first consumed as the A operand of a small-M projection: returns
-    (y, mean, rstd, pending).  `pending` is the LayerNorm-prologue argument of that projection (L.gemm(..., ln=pending):
-    the whole-K kernel forms y from x / o in its prologue and writes y / mean / rstd for the backward; pq3d_gemm itself
-    falls back to the separate launch where that kernel does not apply) -- or None when the LayerNorm was launched here
-    (residual dropout, bf16 inputs, wide rows, fusion switched off)."""
-    M = len(os_)
-    dm = os_[0].shape[-1]
-    ok = LN_FUSE and drop is None and M <= 4 and dm <= 256 and dm % 8 == 0 and (x is None or x.dtype == torch.float32) \
-        and all(o.dtype == torch.float32 for o in os_)
-    if not ok:
-        y, mean, rstd = _ln_fwd(x, os_, gammas, betas, eps, coef, rows_per_scene, drop=drop, sum_branches=sum_branches,
-                                osum=osum)
-        return y, mean, rstd, None
-    R = os_[0].numel() // dm
-    y = torch.empty(os_[0].shape, dtype=torch.float32, device=os_[0].device)
-    mean = torch.empty(M, R, dtype=torch.float32, device=y.device)
-    rstd = torch.empty_like(mean)
-    pending = dict(x=x, o=list(os_), gamma=list(gammas), beta=list(betas), coef=coef, eps=eps,
-                   rows_per_scene=rows_per_scene, y=y, mean=mean, rstd=rstd, sum_branches=sum_branches, osum=osum)
-    return y, mean, rstd, pending
-
-
-def _ln_flush(pending):
-    """Launch a deferred LayerNorm that found no projection to ride on (the decoder's last layer without a mask head)."""
-    if pending is None:
-        return
-    q = pending
-    d = ops._ln_desc(q["x"], q["o"], q["gamma"], q["beta"], q["coef"], q["eps"], q["rows_per_scene"], q["y"], q["mean"],
-                     q["rstd"], None)
-    d.sum_branches, d.osum = int(q["sum_branches"]), L.ptr(q["osum"])
-    L.check(L.lib().pq3d_add_ln_fwd(C.byref(d), L.stream()), "pq3d_add_ln_fwd")
 
 
 def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dgs, dbs, want_dx=True, dup_dx=False,
@@ -280,44 +236,13 @@ def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None,
                       L.lib().pq3d_attn_bwd, C.byref(d), L.stream()), "pq3d_attn_bwd")
 
 
-# the feed-forward sublayer's two products as one launch (csrc/ffn.hip).  Off by default: correct (tests/test_gpu_ops.py) but
-# 34 us against 11 + 13 for the two grouped products at config 2 (same-box A/B, step +35 us) -- see the header of ffn.hip
-FFN_FUSE = os.environ.get("PQ3D_FFN_FUSE", "0") != "0"
-
-
-def ffn_fused_ok(cq, d, F_, x, w1, b1, w2, b2) -> bool:
-    ts = [x, w1, b1, w2] + ([b2] if b2 is not None else [])
-    return (cq == L.BF16X3 and d == 256 and F_ % 256 == 0 and F_ // 256 <= L.MAXG
-            and all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts))
-
-
-def ffn_fwd(x, w1, b1, w2, b2, act, drop, want_pre):
-    """pq3d_ffn_fwd: returns (h [.., F], pre or None, zp [F/256, .., d] partial sums of linear2)."""
-    d = x.shape[-1]
-    R, F_ = x.numel() // d, w1.shape[0]
-    h = torch.empty(*x.shape[:-1], F_, dtype=torch.float32, device=x.device)
-    pre = torch.empty_like(h) if want_pre else None
-    zp = torch.empty(F_ // 256, *x.shape, dtype=torch.float32, device=x.device)
-    q = L.FfnDesc()
-    q.R, q.d, q.F, q.act = R, d, F_, L.ACT[act]
-    q.x, q.w1, q.b1, q.w2, q.b2 = L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2)
-    q.h, q.pre, q.zp = L.ptr(h), L.ptr(pre), L.ptr(zp)
-    L.set_drop(q.drop, drop)
-    L.check(timed("pq3d_ffn_fwd", f"R{R}d{d}F{F_}", 4.0 * R * d * F_, 4.0 * (2 * d * F_ + R * (2 * d + F_)), L.lib().pq3d_ffn_fwd,
-                  C.byref(q), L.stream()), "pq3d_ffn_fwd")
-    return h, pre, zp
-
-
-SA_FOLD = os.environ.get("PQ3D_SA_FOLD", "1") != "0"   # fold the self-attention out-projection backward into the kernel
-
-
 def sa_fold_ok(ct, B, H, L_, dm, drop, df, W) -> bool:
     """The split-bf16 self-attention backward kernel can form dO itself (attn_sa.hip): its shape limits + 160 KB of LDS."""
-    if not SA_FOLD or ops.sa_ct(ct) != L.BF16X3 or dm != 32 * H or dm % 32 or drop is not None:
+    if ops.sa_ct(ct) != L.BF16X3 or dm != 32 * H or dm % 32 or drop is not None:
         return False
     if df.dtype != torch.float32 or W.dtype != torch.float32 or not df.is_contiguous() or not W.is_contiguous():
         return False
-    if (df.data_ptr() | W.data_ptr()) & 15 or os.environ.get("PQ3D_ATTN_SA", "1") == "0":
+    if (df.data_ptr() | W.data_ptr()) & 15:
         return False
     lp2, lpk = (L_ + 31) & ~31, (L_ + 31) & ~31
     lds = (4 * lp2 + 4 * lpk + dm) * 40 * 2 + (lpk + 2 * lp2) * 4 + 16
@@ -452,7 +377,6 @@ class _FusedDecoder(Function):
         tape: List[dict] = []
         pcls, pmask = [], []
         x = x0
-        pend = None     # LayerNorm that produces x but has not been launched: rides on the first projection that reads x
         attn_mask = row_open = None
         for blk in range(spec.num_blocks):
             for i, layer in enumerate(layers):
@@ -468,8 +392,7 @@ class _FusedDecoder(Function):
                 dr_fr = spec.drop(layer.ffn, app, ops.DROP_FFN_RES, dev)
                 rec.update(dr_ca=dr_ca, dr_cr=dr_cr, dr_sa=dr_sa, dr_sr=dr_sr, dr_fi=dr_fi, dr_fr=dr_fr)
                 if spec.mh is not None and not spec.skip_pred:
-                    cls, mlog, amask = _mh_forward(spec, x, keys, inv_den, seg_pad, rec, app, ln=pend)
-                    pend = None
+                    cls, mlog, amask = _mh_forward(spec, x, keys, inv_den, seg_pad, rec, app)
                     pcls.append(cls)
                     pmask.append(mlog)
                     attn_mask = offline_mask if spec.offline else amask
@@ -483,8 +406,7 @@ class _FusedDecoder(Function):
                 ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cas[i]]
                 bsl = [ca.multihead_attn.in_proj_bias.detach() for ca in cas[i]]
                 L.gemm(M=R, N=d, K=d, A=[x] * M, A2=[qpos] * M, B=[w[:d] for w in ws], bias=[b[:d] for b in bsl],
-                       Cs=[q_all[m] for m in range(M)], ct=cq, lda=d, ldb=d, ldc=d, ln=pend)
-                pend = None
+                       Cs=[q_all[m] for m in range(M)], ct=cq, lda=d, ldb=d, ldc=d)
                 o_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
                 lse = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
                 if spec.use_self_mask:
@@ -499,9 +421,9 @@ class _FusedDecoder(Function):
                        B=[ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
                        bias=[ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]],
                        Cs=[op_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
-                x1, mean_c, rstd_c, pend1 = _ln_defer(x, [op_all[m] for m in range(M)], [ca.norm.weight.detach() for ca in cas[i]],
-                                                      [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps,
-                                                      coef[app] if coef is not None else None, Nq, drop=dr_cr)
+                x1, mean_c, rstd_c = _ln_fwd(x, [op_all[m] for m in range(M)], [ca.norm.weight.detach() for ca in cas[i]],
+                                             [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps,
+                                             coef[app] if coef is not None else None, Nq, drop=dr_cr)
                 rec.update(q_all=q_all, o_all=o_all, lse=lse, op_all=op_all, mean_c=mean_c, rstd_c=rstd_c, x1=x1)
                 x1s = x1     # input of the self-attention sublayer
                 if spec.prompt:
@@ -512,16 +434,15 @@ class _FusedDecoder(Function):
                     dr_pr = spec.drop(pc, app, ops.DROP_CA_RES, dev, m=4)
                     wp, bpq = pc.multihead_attn.in_proj_weight.detach(), pc.multihead_attn.in_proj_bias.detach()
                     qp = torch.empty(B, Nq, d, dtype=ad, device=dev)
-                    L.gemm(M=R, N=d, K=d, A=[x1], A2=[qpos], B=[wp[:d]], bias=[bpq[:d]], Cs=[qp], ct=cq, lda=d, ldb=d, ldc=d,
-                           ln=pend1)
+                    L.gemm(M=R, N=d, K=d, A=[x1], A2=[qpos], B=[wp[:d]], bias=[bpq[:d]], Cs=[qp], ct=cq, lda=d, ldb=d, ldc=d)
                     o_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
                     lse_p = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
                     _attn(qp, PKV[i, 0], PKV[i, 1], o_p, lse_p, H, ct, True, kpm=prompt_kpm, drop=dr_pa)
                     opp = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                     L.gemm(M=R, N=d, K=d, A=[o_p], B=[pc.multihead_attn.out_proj.weight.detach()],
                            bias=[pc.multihead_attn.out_proj.bias.detach()], Cs=[opp], ct=ct, lda=d, ldb=d, ldc=d)
-                    x1s, mean_p, rstd_p, pend1 = _ln_defer(x1, [opp], [pc.norm.weight.detach()], [pc.norm.bias.detach()],
-                                                           pc.norm.eps, None, Nq, drop=dr_pr)
+                    x1s, mean_p, rstd_p = _ln_fwd(x1, [opp], [pc.norm.weight.detach()], [pc.norm.bias.detach()], pc.norm.eps,
+                                                  None, Nq, drop=dr_pr)
                     rec.update(qp=qp, o_p=o_p, lse_p=lse_p, opp=opp, mean_p=mean_p, rstd_p=rstd_p, dr_pa=dr_pa, dr_pr=dr_pr)
                 rec["x1s"] = x1s
                 # -- self attention: 5 launches (spatial) / 4
@@ -538,60 +459,49 @@ class _FusedDecoder(Function):
                     Wl, bl = [w[:d], w[d:2 * d], w[2 * d:]], [b[:d], b[d:2 * d], b[2 * d:]]
                     Wo, bo = sa.self_attn.out_proj.weight.detach(), sa.self_attn.out_proj.bias.detach()
                 L.gemm(M=R, N=d, K=d, A=[x1s] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=cq,
-                       lda=d, ldb=d, ldc=d, ln=pend1)
+                       lda=d, ldb=d, ldc=d)
                 sbias = sbias_all[i] if spec.spatial else None   # layer-invariant across blocks: computed once above
                 o_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 lse_s = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
                 _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ops.sa_ct(ct), False, kpm=qmask, bias=sbias, drop=dr_sa)
                 f = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 L.gemm(M=R, N=d, K=d, A=[o_s], B=[Wo], bias=[bo], Cs=[f], ct=cq, lda=d, ldb=d, ldc=d)
-                x2, mean_s, rstd_s, pend2 = _ln_defer(x1s, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps,
-                                                      None, Nq, drop=dr_sr)
+                x2, mean_s, rstd_s = _ln_fwd(x1s, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
+                                             drop=dr_sr)
                 rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
                 # -- FFN: 3 launches
                 ffn = layer.ffn
                 F_ = ffn.linear1.out_features
-                w1_, b1_ = ffn.linear1.weight.detach(), ffn.linear1.bias.detach()
-                w2_, b2_ = ffn.linear2.weight.detach(), ffn.linear2.bias.detach()
-                fused_ffn = FFN_FUSE and pend2 is None and ffn_fused_ok(cq, d, F_, x2, w1_, b1_, w2_, b2_)
-                if fused_ffn:
-                    # -- FFN: 2 launches (both products in one: csrc/ffn.hip; then the LayerNorm over its F/256 partial sums)
-                    h, pre, zp = ffn_fwd(x2, w1_, b1_, w2_, b2_, spec.act, dr_fi, spec.act == "gelu")
-                    KS = F_ // 256
-                else:
-                    h = torch.empty(B, Nq, F_, dtype=ops.act_dtype(cq), device=dev)
-                    pre = torch.empty_like(h) if spec.act == "gelu" else None
-                    L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
-                           C2=[pre], ct=cq, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi, ln=pend2)
-                    # linear2 has K = F = 2048 on only M/64 x d/64 = 52 tiles: a long serial k-loop on a fifth of the chip.  Its K
-                    # range is split over KS groups of ONE grouped launch (no atomics: each group owns an output), and the
-                    # LayerNorm kernel adds the partial sums (+ residual, + dropout of the summed branch) in a fixed order --
-                    # deterministic, so the bit-exact padding-invariance / scene-independence properties hold.
-                    KS = 4 if F_ % (4 * 64) == 0 else 1
-                    zp = torch.empty(KS, B, Nq, d, dtype=torch.float32, device=dev)
-                    Fk = F_ // KS
-                    hv, w2 = h.view(R, F_), ffn.linear2.weight.detach()
-                    L.gemm(M=R, N=d, K=Fk, A=[hv[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
-                           B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
-                           bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=cq, lda=F_,
-                           ldb=F_, ldc=d)
+                h = torch.empty(B, Nq, F_, dtype=ops.act_dtype(cq), device=dev)
+                pre = torch.empty_like(h) if spec.act == "gelu" else None
+                L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
+                       C2=[pre], ct=cq, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi)
+                # linear2 has K = F = 2048 on only M/64 x d/64 = 52 tiles: a long serial k-loop on a fifth of the chip.  Its K
+                # range is split over KS groups of ONE grouped launch (no atomics: each group owns an output), and the
+                # LayerNorm kernel adds the partial sums (+ residual, + dropout of the summed branch) in a fixed order --
+                # deterministic, so the bit-exact padding-invariance / scene-independence properties hold.
+                KS = 4 if F_ % (4 * 64) == 0 else 1
+                zp = torch.empty(KS, B, Nq, d, dtype=torch.float32, device=dev)
+                Fk = F_ // KS
+                hv, w2 = h.view(R, F_), ffn.linear2.weight.detach()
+                L.gemm(M=R, N=d, K=Fk, A=[hv[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
+                       B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
+                       bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=cq, lda=F_,
+                       ldb=F_, ldc=d)
                 z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)   # sum of the partials, kept for the backward
-                x3, mean_f, rstd_f, pend = _ln_defer(x2, [zp[k] for k in range(KS)], [ffn.norm.weight.detach()],
-                                                     [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq, drop=dr_fr,
-                                                     sum_branches=True, osum=z)
+                x3, mean_f, rstd_f = _ln_fwd(x2, [zp[k] for k in range(KS)], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()],
+                                             ffn.norm.eps, None, Nq, drop=dr_fr, sum_branches=True, osum=z)
                 rec.update(h=h, pre=pre, z=z, mean_f=mean_f, rstd_f=rstd_f)
                 tape.append(rec)
                 x = x3
         final_rec = None
         if spec.mh is not None:
             final_rec = {"x_in": x}
-            cls, mlog, _ = _mh_forward(spec, x, keys, inv_den, seg_pad, final_rec, spec.num_blocks * Ln, ln=pend)
-            pend = None
+            cls, mlog, _ = _mh_forward(spec, x, keys, inv_den, seg_pad, final_rec, spec.num_blocks * Ln)
             if spec.skip_pred:
                 pcls, pmask = [], []
             pcls.append(cls)
             pmask.append(mlog)
-        _ln_flush(pend)    # the last layer's output without a mask head behind it
         ctx.spec, ctx.tape, ctx.final_rec = spec, tape, final_rec
         ctx.KV, ctx.keys, ctx.inv_den, ctx.kpm_all = KV, keys, inv_den, kpm_all
         ctx.PKV, ctx.pcas, ctx.prompt, ctx.pmask = PKV, pcas, prompt if spec.prompt else None, prompt_kpm if spec.prompt else None

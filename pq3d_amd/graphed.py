@@ -84,13 +84,21 @@ class _Replay(torch.autograd.Function):
         gs = [g if g is not None else z for g, z in zip(gouts, ow.zero_gout)]
         torch._foreach_copy_(ow.static_gout, [gs[i] for i in ow.gout_idx])
         acc = ow._accumulating()
-        ow._bwd_graph(acc).replay()
         pg = (None,) * ctx.n_par
         if ow.mode == "direct":
+            ow._bwd_graph(acc).replay()
             ow._publish_grads()
         elif not acc:
-            # fresh view objects of the flat buffers: AccumulateGrad adopts them without a copy (and runs its hooks: DDP)
-            pg = tuple(ow._grad_view(p) for p in ow._params)
+            ow._bwd_graph(False).replay()
+            # fresh view objects of the flat buffers: AccumulateGrad adopts them without a copy (and runs its hooks: DDP);
+            # parameters the captured batch never reached get None, as from an eager backward
+            pg = tuple(None if id(p) in ow._unused else ow._grad_view(p) for p in ow._params)
+        else:
+            # accumulating micro-batch in 'autograd' mode: this micro-batch's gradients are formed FRESH in a second set of
+            # flat buffers and handed to autograd, whose AccumulateGrad adds them onto .grad (= the views of the first set)
+            # and runs its hooks -- DDP's bucket hooks fire on the last micro-batch of a no_sync window
+            ow._bwd_graph("delta").replay()
+            pg = tuple(None if id(p) in ow._unused else ow._grad_view(p, delta=True) for p in ow._params)
         return (None, None, None) + tuple(ow.static_gin) + pg
 
 
@@ -107,10 +115,13 @@ class GraphedQuery3D(nn.Module):
     gradients: AccumulateGrad adopts a view without a copy when ``.grad`` is None and runs its hooks (DDP's bucket hooks
     fire, ``.grad`` is an ordinary tensor) -- the ~170 host-side AccumulateGrad visits overlap the backward replay on the
     device (round 2 used torch.cuda.make_graphed_callables here: one copy kernel per parameter per step, 3.5 ms at c2).
-    Gradient accumulation (both modes): a backward that finds the parameters' ``.grad`` still aliasing the flat buffers
-    (no ``zero_grad(set_to_none=True)`` since the last one) replays an ACCUMULATING variant of the backward graph
-    (captured at construction with ``accumulation=True``) that adds into the buffers -- torch semantics, the reference
-    trains under accelerator.accumulate (trainer/query3d_trainer.py:35)."""
+    Gradient accumulation (both modes; construct with ``accumulation=True``): a backward that finds the parameters'
+    ``.grad`` still aliasing the flat buffers (no ``zero_grad(set_to_none=True)`` since the last one) accumulates -- torch
+    semantics, the reference trains under accelerator.accumulate (trainer/query3d_trainer.py:35).  'direct' replays a
+    variant of the backward graph that ADDS into the buffers; 'autograd' replays a variant that forms the micro-batch's
+    gradients in a second set of buffers and returns those, so AccumulateGrad does the addition and its hooks (DDP) run on
+    every micro-batch.  Parameters the captured batch never reaches (a bypassed sub-module) keep ``.grad = None`` in both
+    modes, as after an eager backward (torch.optim.AdamW skips them)."""
 
     def __init__(self, model: nn.Module, sample: Dict[str, object], num_warmup_iters: int = 3, mode: str = "direct",
                  accumulation: bool = False):
@@ -147,6 +158,11 @@ class GraphedQuery3D(nn.Module):
             enc.grad_arena, enc.grad_arena_buffers = self.reducer.slots(), list(self.reducer.flat)
         self._params = params
         self._slots = self.reducer.slots()
+        self._unused = set()      # ids of parameters without a gradient in the captured backward
+        self._delta = None        # second set of flat buffers + slot map ('autograd' mode with accumulation)
+        if mode == "autograd" and accumulation:
+            self._delta = FlatGradAllReducer(params, groups=[g for g in groups if g])
+            self._slots_delta = self._delta.slots()
         self._args = args
         self._gin_idx = [i for i, a in enumerate(args) if a.requires_grad]
         self._fwd_token = None
@@ -165,17 +181,27 @@ class GraphedQuery3D(nn.Module):
         with torch.cuda.graph(self.fwd_graph):
             outs = self._flat(*args)
         self.zero_gout = [torch.zeros_like(o) for o in outs]
-        self._bwd = {False: torch.cuda.CUDAGraph(), True: None}
+        self._bwd = {False: torch.cuda.CUDAGraph(), True: None, "delta": None}
         self.static_gin = None
         with torch.cuda.graph(self._bwd[False], pool=self.fwd_graph.pool()):
-            gin = self._run_bwd(outs, False, retain=accumulation)
+            gin = self._run_bwd(outs, False, retain=accumulation, record_unused=True)
         self.static_gin = [None] * len(args)
         for i, g in zip(self._gin_idx, gin):
             self.static_gin[i] = g
-        if accumulation:   # the accumulating variant of the backward, from the same (still alive) autograd graph
+        if accumulation and mode == "direct":   # the accumulating variant, from the same (still alive) autograd graph
             self._bwd[True] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._bwd[True], pool=self.fwd_graph.pool()):
                 self._run_bwd(outs, True, retain=False)
+        elif accumulation:                      # 'autograd': the same backward, fresh, into the second set of buffers
+            self._bwd["delta"] = torch.cuda.CUDAGraph()
+            if enc is not None and groups[0]:
+                enc.grad_arena, enc.grad_arena_buffers = self._slots_delta, list(self._delta.flat)
+            try:
+                with torch.cuda.graph(self._bwd["delta"], pool=self.fwd_graph.pool()):
+                    self._run_bwd(outs, False, retain=False, delta=True)
+            finally:
+                if enc is not None and groups[0]:
+                    enc.grad_arena, enc.grad_arena_buffers = self._slots, list(self.reducer.flat)
         # Release the captured forward's autograd graph: its AccumulateGrad nodes were created on the capture stream, and as
         # long as they live every eager backward of mode 'autograd' finds them (they are per-parameter singletons), sees a
         # stream mismatch and synchronises once per parameter (3.3 ms instead of 1.6 ms per step at config 2)
@@ -187,34 +213,38 @@ class GraphedQuery3D(nn.Module):
         self._anchor = torch.zeros((), device=args[0].device, requires_grad=True)
 
     # -- backward body (captured twice: fresh / accumulating) ------------------------------------------------------------
-    def _grad_view(self, p):
-        flat, off, n = self._slots[id(p)]
+    def _grad_view(self, p, delta: bool = False):
+        flat, off, n = (self._slots_delta if delta else self._slots)[id(p)]
         return flat[off:off + n].view_as(p)
 
-    def _run_bwd(self, outs, accumulate: bool, retain: bool = False):
+    def _run_bwd(self, outs, accumulate: bool, retain: bool = False, record_unused: bool = False, delta: bool = False):
+        """delta: write (fresh) into the second set of flat buffers; the input gradients still land in the first graph's."""
         params = self._params
+        slots, flats = (self._slots_delta, self._delta.flat) if delta else (self._slots, self.reducer.flat)
         # the fused decoder decides "fresh step or accumulate" from its parameters' .grad (pq3d_amd/fused.py): alias the
         # flat buffers -> add in place; None -> zero, then write
         for p in params:
             p.grad = self._grad_view(p) if accumulate else None
         req = [o for o in outs if o.requires_grad]
-        with ops.grad_arena(self._slots, self.reducer.flat):   # every slot offered for the whole pass (zeroed here when fresh)
+        with ops.grad_arena(slots, flats):   # every slot offered for the whole pass (zeroed here when fresh)
             grads = torch.autograd.grad(req, [self._args[i] for i in self._gin_idx] + params, grad_outputs=self.static_gout,
                                         allow_unused=True, retain_graph=retain)
         gin, gp = grads[:len(self._gin_idx)], grads[len(self._gin_idx):]
         views, srcs = [], []
         for p, g in zip(params, gp):
-            v = self._grad_view(p)
+            v = self._grad_view(p, delta)
             if g is None:
                 if not accumulate:
                     # no gradient from autograd: either written in place by the fused executor in accumulate mode (never
                     # here) or genuinely unused -> zero in a fresh step, untouched when accumulating
                     v.zero_()
+                    if record_unused:
+                        self._unused.add(id(p))
             elif g.data_ptr() != v.data_ptr():
                 views.append(v); srcs.append(g)
         if views:
             (torch._foreach_add_ if accumulate else torch._foreach_copy_)(views, srcs)
-        if accumulate and self.static_gin is not None:   # input gradients land in the buffers of the fresh graph
+        if (accumulate or delta) and self.static_gin is not None:   # input gradients land in the buffers of the fresh graph
             dst = [self.static_gin[i] for i in self._gin_idx]
             if dst:
                 torch._foreach_copy_(dst, list(gin))
@@ -222,7 +252,8 @@ class GraphedQuery3D(nn.Module):
 
     def _accumulating(self) -> bool:
         """True when every parameter's .grad still aliases its flat-buffer view (no zero_grad since the last backward)."""
-        alias = [p.grad is not None and p.grad.data_ptr() == self._grad_view(p).data_ptr() for p in self._params]
+        alias = [p.grad is not None and p.grad.data_ptr() == self._grad_view(p).data_ptr() for p in self._params
+                 if id(p) not in self._unused]
         if all(alias) and alias:
             return True
         if any(alias):
@@ -230,7 +261,7 @@ class GraphedQuery3D(nn.Module):
                                "zero all gradients (set_to_none=True) or none between micro-batches")
         return False
 
-    def _bwd_graph(self, accumulate: bool):
+    def _bwd_graph(self, accumulate):
         if self._bwd[accumulate] is None:
             raise RuntimeError("GraphedQuery3D: a backward found the parameters' .grad still set (gradient accumulation over "
                                "micro-batches) but the wrapper was built without the accumulating backward graph: construct "
@@ -253,7 +284,7 @@ class GraphedQuery3D(nn.Module):
 
     def _publish_grads(self):
         if self._grad_views is None:
-            self._grad_views = [self._grad_view(p) for p in self._params]
+            self._grad_views = [None if id(p) in self._unused else self._grad_view(p) for p in self._params]
         for p, v in zip(self._params, self._grad_views):
             p.grad = v
 

@@ -524,9 +524,6 @@ def linear_group(xs, Ws, *, ct: int, out_dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-_ATTN_KSPLIT = int(os.environ.get("PQ3D_ATTN_KSPLIT", "0"))   # experiments only; 0 = built-in rule
-
-
 def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, drop=None, drop_bmod=0,
                bwd=False) -> L.AttnDesc:
     B, Lq, dm = q.shape
@@ -546,14 +543,14 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
     # (tools/probes/attn_bench.py + bench.py): c2 (16 key blocks) and c5 (32) are fastest with 2 splits, c4 (64) with 4
     # (forward 70 -> 57 us, step 5.56 -> 5.43 ms); 8 only adds combine traffic.
     nkb = (Lk + 63) // 64
-    ks = (_ATTN_KSPLIT or (1 if nkb < 8 else 2 if nkb < 64 else 4)) if bias is None else 1
-    if not bwd and not _ATTN_KSPLIT and ct == BF16 and q.dtype == torch.bfloat16 and bias is None and mask is None and \
+    ks = (1 if nkb < 8 else 2 if nkb < 64 else 4) if bias is None else 1
+    if not bwd and ct == BF16 and q.dtype == torch.bfloat16 and bias is None and mask is None and \
             Lq <= 128 <= Lk and dm // H == 32 and nkb <= 16:
         # the all-keys-resident forward (attn_resident.hip) holds up to 1024 keys per workgroup: config 2 needs no split
         # (and no combine launch).  Longer scenes keep the streaming kernel and its split (measured at config 5, 2048 keys:
         # resident with 2 splits 63-76 us vs streaming 58 us) -- a function of the key length only, as above
         ks = 1
-    if bwd and not _ATTN_KSPLIT and ks > 1 and ct == BF16 and bias is None and Lq <= 128 and (dm // H) in (32, 64) and \
+    if bwd and ks > 1 and ct == BF16 and bias is None and Lq <= 128 and (dm // H) in (32, 64) and \
             (B * H >= 320 or (B * H <= 256 and Lk >= 512 and dm // H == 32)):
         # the all-queries-resident backward (attn_resident.hip) runs one workgroup per (scene, head, slice): once the
         # stacked batch alone fills the chip (config 5: 48 x 8) a second slice only adds dQ partials (85 -> 75 us).
@@ -561,7 +558,7 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
         # At most one workgroup per CU (config 2: 24 x 8): the 8-wave variant of the kernel takes all keys of a (scene,
         # head) -- no dQ partials, no combine launch.
         ks = 1
-    if bwd and not _ATTN_KSPLIT and ks > 2 and ct == BF16 and bias is None and 128 < Lq <= 256 and dm // H == 32 and \
+    if bwd and ks > 2 and ct == BF16 and bias is None and 128 < Lq <= 256 and dm // H == 32 and \
             B * H * (ks // 2) <= 256 and Lk // (ks // 2) >= 512:
         ks //= 2      # the 8-wave resident backward (two query halves, config 4): half the key slices, one workgroup per CU
     if ks > 1:
@@ -1013,6 +1010,7 @@ class _Arena:
     mode = None
     by_ptr = {}      # parameter data_ptr -> (parameter, flat buffer, element offset, numel) of its slot
     written = set()  # slots some function of this pass already returned (a second use adds in place, returns None)
+    multi = set()    # slots that took such an in-place second use in a FRESH pass: verified when the pass ends (arena_verify)
     whole_pass = False   # offered by grad_arena() around the whole backward (the decoder then neither zeroes nor offers)
     pending = None       # fresh whole-pass arena: buffers still to be zeroed -- by the FIRST consumer, together with its own
     zeroed_ptrs = set()  # flat buffers the last fresh pass zero-filled (read by the gradient pack that follows it)
@@ -1038,6 +1036,28 @@ def arena_zeroed_buffers(consume: bool = True) -> set:
     return z
 
 
+def arena_verify() -> None:
+    """A fresh pass hands the FIRST arena-aware use of a parameter a view of its slot and lets later arena-aware uses (a tied
+    weight) add into the slot in place.  That is only correct while autograd keeps that view as the gradient: a gradient
+    for the same parameter from a function that is NOT arena-aware makes autograd sum out of place, .grad becomes a tensor
+    of its own and the later in-place additions are lost.  Autograd gives no guarantee here, so the hand-out is CHECKED
+    when the pass ends: every slot that took an in-place second use must still be what .grad aliases."""
+    bad = []
+    for q in _Arena.multi:
+        ent = _Arena.by_ptr.get(q)
+        if ent is None:
+            continue
+        p_, fl_, o_, _n = ent
+        if p_.grad is None or p_.grad.data_ptr() != fl_.data_ptr() + 4 * o_:
+            bad.append(tuple(p_.shape))
+    _Arena.multi = set()
+    if bad:
+        raise RuntimeError(f"gradient arena: {len(bad)} parameter(s) (shapes {bad[:4]}) received gradients both in place "
+                           "through their arena slot (a tied weight's second use) and through a function that does not use "
+                           "the arena; autograd summed them out of place and the in-place part is lost -- run this backward "
+                           "without ops.grad_arena / enc.grad_arena, or route every use of the parameter through pq3d_amd.ops")
+
+
 class grad_arena:
     """``with ops.grad_arena(slots, buffers): loss.backward()`` -- the owner of the flat gradient buffers (a
     FlatGradAllReducer / TrainStep) offers every parameter's slot for the WHOLE backward pass: one zero launch up front
@@ -1046,13 +1066,13 @@ class grad_arena:
     accumulates in place.  Without this context the decoder's backward makes the offer itself (arena_offer), which only
     reaches the functions that run after it."""
 
-    def __init__(self, slots, buffers):
-        self.slots, self.buffers = slots, list(buffers)
+    def __init__(self, slots, buffers, pack_follows: bool = False):
+        # pack_follows: the owner calls FlatGradAllReducer.pack() on these buffers right after the pass; only then is the
+        # "already zero-filled" note (arena_zeroed_buffers) kept past the end of the context
+        self.slots, self.buffers, self.pack_follows = slots, list(buffers), pack_follows
 
     def __enter__(self):
-        _Arena.zeroed_ptrs = set()
-        if os.environ.get("PQ3D_GRAD_ARENA", "1") == "0":   # A/B switch: the decoder's own offer only
-            return self
+        _Arena.zeroed_ptrs, _Arena.multi = set(), set()
         zeroed = {b.data_ptr() for b in self.buffers}
         ents = {}
         for i_, q_ in getattr(self.slots, "params", {}).items():
@@ -1072,9 +1092,15 @@ class grad_arena:
         return self
 
     def __exit__(self, *exc):
-        if exc[0] is None:
-            arena_flush_zero()    # nobody consumed it: the owner still expects zeroed buffers
-        _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass, _Arena.pending = None, {}, set(), False, None
+        try:
+            if exc[0] is None:
+                arena_flush_zero()    # nobody consumed it: the owner still expects zeroed buffers
+                arena_verify()
+        finally:
+            _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass, _Arena.pending = None, {}, set(), False, None
+            _Arena.multi = set()
+            if not self.pack_follows:
+                _Arena.zeroed_ptrs = set()
         return False
 
 
@@ -1083,7 +1109,10 @@ def arena_offer(views_by_ptr, mode):
 
     def _end():
         if not _Arena.whole_pass:
-            _Arena.mode, _Arena.by_ptr, _Arena.written = None, {}, set()
+            try:
+                arena_verify()
+            finally:
+                _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.multi = None, {}, set(), set()
     torch.autograd.Variable._execution_engine.queue_callback(_end)
 
 
@@ -1103,6 +1132,8 @@ def arena_take(ptrs, numels=None):
         if any(seen) and not all(seen):
             return None, False
         give = not any(seen)
+        if not give:
+            _Arena.multi.update(ptrs)
     else:   # accumulate: only slots autograd already holds as .grad (anything else still has last step's data in it)
         if not all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in ent):
             return None, False

@@ -47,11 +47,9 @@ def shift_right(labels: torch.Tensor, start_id: int, pad_id: int) -> torch.Tenso
     return torch.where(ids == -100, torch.full_like(ids, pad_id), ids)
 
 
-_RES_JUNCTION = os.environ.get("PQ3D_T5_RES", "1") != "0"   # the residual branch's gradient joins inside the norm's backward kernel
-
-
 def _norm_res(x, w, eps):
-    return ops.rmsnorm_res(x, w, eps) if _RES_JUNCTION else (ops.rmsnorm(x, w, eps), x)
+    """T5LayerNorm whose backward also takes the residual branch's gradient (pq3d_rmsnorm_bwd_res: no add launch)."""
+    return ops.rmsnorm_res(x, w, eps)
 
 
 def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], labels: torch.Tensor, ct: int,

@@ -52,6 +52,10 @@ class TrainStep:
         # optimizer_step.  Under data parallelism (world > 1) presence is a per-rank fact, so every parameter of the
         # layout is updated (zero gradient where a rank had none, averaged like DDP's find_unused_parameters buckets):
         # a parameter NO rank reaches is then still decayed -- list it in ``unused_parameters`` (documented divergence).
+        # Second documented divergence: the bias corrections use the ONE global step count, torch.optim.AdamW a per-parameter
+        # count that only advances when the parameter has a gradient -- a head that is skipped in some steps gets
+        # 1 - beta^t with the global t instead of its own (identical as soon as every parameter is reached every step, which
+        # is the case for the reference's stage-1 / stage-2 trainers; tests/test_gpu_trainer.py pins that case).
         unused = {id(p) for p in (model.unused_parameters() if hasattr(model, "unused_parameters") else ())}
         unused |= {id(p) for p in (unused_parameters or ())}
         self._names = {id(p): n for n, p in model.named_parameters()}
@@ -117,7 +121,7 @@ class TrainStep:
             loss = loss * loss_scale
         enc = getattr(self.model, "unified_encoder", None)
         if enc is not None and getattr(enc, "grad_arena", None) is not None:
-            with ops.grad_arena(enc.grad_arena, enc.grad_arena_buffers):   # every slot offered for the whole pass
+            with ops.grad_arena(enc.grad_arena, enc.grad_arena_buffers, pack_follows=True):   # every slot offered for the whole pass
                 loss.backward()
         else:
             loss.backward()
@@ -208,6 +212,12 @@ class TrainStep:
 
     def load_state_dict(self, sd: dict) -> None:
         have = self.layout()
+        if "layout" not in sd:
+            # a checkpoint of the former (probed) layout: the buffers cannot be matched to parameters by position
+            if sd["exp_avg"].numel() != self.exp_avg.numel():
+                raise ValueError(f"TrainStep.load_state_dict: checkpoint without a 'layout' entry holds {sd['exp_avg'].numel()} "
+                                 f"moment elements, this TrainStep {self.exp_avg.numel()}: rebuild it with the parameter set it "
+                                 "was saved with (older checkpoints covered only the parameters that received gradients)")
         want = [tuple(x) for x in sd.get("layout", have)]
         if want != [tuple(x) for x in have]:
             diff = [a for a, b in zip(want, have) if a != b][:4]

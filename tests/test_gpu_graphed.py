@@ -118,6 +118,69 @@ def test_graphed_autograd_mode_runs_parameter_hooks_and_direct_mode_guards_stale
         gm(bad)
 
 
+def test_autograd_mode_accumulation_fires_hooks_on_every_micro_batch():
+    """under no_sync-style accumulation DDP reduces on the LAST micro-batch, from its AccumulateGrad hooks -- an
+    accumulating replay that hands autograd nothing would never trigger them.  The 'autograd' mode forms every micro-batch's
+    gradients in a second set of buffers and returns them: hooks run on each backward, .grad keeps aliasing the first set."""
+    args, model, dda, ddb = _case()
+    gm = GraphedQuery3D(model, dda, mode="autograd", accumulation=True)
+    fired = []
+    ps = [p for p in model.parameters() if p.requires_grad and id(p) not in gm._unused]
+    hs = [p.register_post_accumulate_grad_hook(lambda p_: fired.append(id(p_))) for p in ps]
+    loss_of = lambda out: util.synthetic_loss(out, args["heads"], out["query_embeds"])
+    model.zero_grad(set_to_none=True)
+    loss_of(gm(dda)).backward()
+    n1 = len(fired)
+    loss_of(gm(ddb)).backward()
+    for h in hs:
+        h.remove()
+    assert n1 == len(ps) and len(fired) == 2 * len(ps), "every parameter's hook must run on both micro-batches"
+    for p in ps:
+        assert p.grad.data_ptr() == gm._grad_view(p).data_ptr()
+
+
+def test_parameters_the_batch_never_reaches_keep_grad_none():
+    """A parameter without a gradient in the captured backward gets None (not a zero-filled view): an eager
+    torch.optim.AdamW then skips it, as it does after the reference's eager backward."""
+    args, model, dda, _ddb = _case()
+    extra = torch.nn.Parameter(torch.ones(4, device=DEV))      # registered, never used by forward
+    model.register_parameter("never_used", extra)
+    for mode in ("direct", "autograd"):
+        gm = GraphedQuery3D(model, dda, mode=mode)
+        model.zero_grad(set_to_none=True)
+        out = gm(dda)
+        util.synthetic_loss(out, args["heads"], out["query_embeds"]).backward()
+        assert extra.grad is None, mode
+        assert all(p.grad is not None for n, p in model.named_parameters() if n != "never_used" and id(p) not in gm._unused)
+        model.unified_encoder.grad_arena = None
+
+
+def test_arena_refuses_a_tied_weight_that_also_gets_a_gradient_outside_the_arena():
+    """a fresh arena pass lets a parameter's second arena-aware use add into the slot in place; if a function that
+    does not use the arena also produces a gradient for it, autograd sums out of place and the in-place part would be lost
+    silently -- the pass must end with an error instead."""
+    from pq3d_amd import ops
+    from pq3d_amd._lib import F32
+    from pq3d_amd.parallel import FlatGradAllReducer
+    w = torch.nn.Parameter(torch.randn(16, 16, device=DEV) * 0.1)
+    red = FlatGradAllReducer([w])
+    x = torch.randn(8, 16, device=DEV)
+    # tied use through arena-aware functions only: fine, gradient = both uses
+    y = ops.linear(ops.linear(x, w, None, ct=F32), w, None, ct=F32).sum()
+    with ops.grad_arena(red.slots(), red.flat):
+        y.backward()
+    g_tied = w.grad.detach().clone()
+    w.grad = None
+    y = ops.linear(ops.linear(x, w, None, ct=F32), w, None, ct=F32).sum()
+    y.backward()
+    torch.testing.assert_close(g_tied, w.grad, rtol=1e-5, atol=1e-6)
+    w.grad = None
+    z = ops.linear(ops.linear(x, w, None, ct=F32), w, None, ct=F32).sum() + (w * w).sum()
+    with pytest.raises(RuntimeError, match="gradient arena"):
+        with ops.grad_arena(red.slots(), red.flat):
+            z.backward()
+
+
 def test_fused_backward_accumulates_into_the_arena_until_gradients_are_reset():
     """Eager path with a shared gradient arena (TrainStep's / the DP reducer's flat buffer): a second backward before
     zero_grad adds in place; TrainStep.step([micro-batches]) equals the step on the summed, 1/k-scaled gradients."""
