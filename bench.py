@@ -49,13 +49,28 @@ CONFIGS = {
                 use_self_mask=False, Tr=32, structure="mixed", T=32, memory_dropout=0.6),
     "c1": dict(B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=[], use_self_mask=False, spatial=False,
                structure="sequential"),
+    # s1 / s2: the decoder sizes the reference SHIPS, on synthetic inputs of the shipped shapes.
+    # s1 = stage 1, configs/instseg_sceneverse.yaml:57,95,140-146: per-GPU batch 4, hidden 768, 12 heads (d_h = 64), 4 layers
+    #      re-traversed by num_blocks = 3 (12 layer applications, 13 mask-head calls over the 3 memories, 201 targets), 3-D
+    #      self-masks, 120 queries (:44); 2048 segments per scene (the segment count is data-dependent; ScanNet scenes have
+    #      1-3 k); ObjectEncoder inputs 768-d
+    "s1": dict(B=4, Ns=2048, Nq=120, d=768, H=12, L=4, num_blocks=3, memories=["voxel", "mv", "pc"], heads=["mask"],
+               use_self_mask=True),
+    # s2 = stage 2, configs/unified_tasks_sceneverse.yaml:62,85,113,120,159-171: per-GPU batch 128 scenes of <= 80 objects
+    #      (queries AND memory rows are the objects), memories [mv, pc, voxel, prompt], structure 'mixed' with T = 32 prompt
+    #      tokens, memory dropout 0.6, 6-D locations, offline voxel features 128-d, ground head (hidden 384)
+    "s2": dict(B=128, Ns=80, Nq=80, d=768, H=12, L=4, memories=["mv", "pc", "voxel", "prompt"], heads=["ground"],
+               use_self_mask=False, structure="mixed", T=32, memory_dropout=0.6, dim_loc=6, ground_hidden=384,
+               d_in={"mv": 768, "pc": 768, "voxel": 128}),
 }
 
 
 def step_flops(c) -> float:
     """SURVEY §8d closed form (multiply-add = 2 FLOP; STEP = 3 x FWD)."""
     B, Ns, Nq, d, H, L = c["B"], c["Ns"], c["Nq"], c["d"], c["H"], c["L"]
-    M = len([m for m in c["memories"] if m != "prompt"])
+    nb = c.get("num_blocks", 1)
+    mems = [m for m in c["memories"] if m != "prompt"]
+    M = len(mems)
     F, C = 2048, 201
     ca = M * (2 * B * d * d * (2 * Nq + 2 * Ns) + 4 * B * Nq * (Ns + 1) * d)
     if "prompt" in c["memories"]:   # the sequential prompt cross-attention of structure 'mixed' (T prompt tokens)
@@ -63,20 +78,23 @@ def step_flops(c) -> float:
     sa = 8 * B * Nq * d * d + 4 * B * Nq * Nq * d + (2 * B * Nq * Nq * 5 * H if c.get("spatial", True) else 0)
     ffn = 4 * B * Nq * d * F
     mh = 2 * B * Nq * (d * d + d * C) + M * (2 * B * d * d * (Nq + Ns) + 2 * B * Ns * Nq * d)
-    enc = M * 2 * B * Ns * d * d + 2 * B * (Nq + Ns) * d * d + 2 * B * (Nq + Ns) * 3 * (d // 2)
-    calls = (L + 1) if "mask" in c["heads"] else 0
-    return 3.0 * (L * (ca + sa + ffn) + calls * mh + enc)
+    d_in = c.get("d_in", {})
+    enc = sum(2 * B * Ns * d_in.get(m, d) * d for m in mems) + 2 * B * (Nq + Ns) * d * d + 2 * B * (Nq + Ns) * 3 * (d // 2)
+    calls = (L * nb + 1) if "mask" in c["heads"] else 0
+    return 3.0 * (L * nb * (ca + sa + ffn) + calls * mh + enc)
 
 
 def build(c, compute, device, seed):
-    cfg = make_cfg(d=c["d"], H=c["H"], L=c["L"], memories=c["memories"], heads=c["heads"],
+    d_in = {m: c.get("d_in", {}).get(m, c["d"]) for m in c["memories"]}
+    cfg = make_cfg(d=c["d"], H=c["H"], L=c["L"], memories=c["memories"], heads=c["heads"], d_in=d_in,
                    spatial=c.get("spatial", True), structure=c.get("structure", "parallel"),
-                   use_self_mask=c["use_self_mask"], C=201, foc=[0, 2], memory_dropout=c.get("memory_dropout", 0.0))
+                   use_self_mask=c["use_self_mask"], C=201, foc=[0, 2], memory_dropout=c.get("memory_dropout", 0.0),
+                   num_blocks=c.get("num_blocks", 1), dim_loc=c.get("dim_loc", 3), ground_hidden=c.get("ground_hidden"))
     model = Query3DUnified(cfg, compute=compute)
     sd = synth.fill_module(model, 0)
     model.to(device)
-    dd = synth.synth_data_dict(c["B"], c["Ns"], c["Nq"], {m: c["d"] for m in c["memories"]}, seed=seed,
-                               memories=c["memories"], prompt_len=c.get("T", 0), d_model=c["d"])
+    dd = synth.synth_data_dict(c["B"], c["Ns"], c["Nq"], d_in, seed=seed, memories=c["memories"], prompt_len=c.get("T", 0),
+                               d_model=c["d"], loc_dim=c.get("dim_loc", 3))
     if "generation" in c["heads"]:
         g = torch.Generator().manual_seed(seed)
         dd["response"] = torch.randint(2, 32000, (c["B"], c["Tr"]), generator=g)
@@ -110,7 +128,8 @@ def cpu_baseline(c, sd, dd, steps, warmup, hf_body=None):
     from oracle import pq3d_oracle as O  # CPU baseline leg only
     ocfg = dict(memories=c["memories"], heads=c["heads"], hidden_size=c["d"], num_heads=c["H"], num_layers=c["L"],
                 structure=c.get("structure", "parallel"), spatial_selfattn=c.get("spatial", True),
-                use_self_mask=c["use_self_mask"], filter_out_classes=[0, 2])
+                use_self_mask=c["use_self_mask"], filter_out_classes=[0, 2], num_blocks=c.get("num_blocks", 1),
+                dim_loc=c.get("dim_loc", 3))
     sdo = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.endswith("gauss_B") and
                                        not k.startswith("generation_head.model.")) for k, v in sd.items()}
 

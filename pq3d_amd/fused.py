@@ -74,6 +74,7 @@ def _dw_acc(gs, xs, x2s, outs, ct, bias_outs=None):
     epl = 8 if ct == BF16 else 4
     fusable = bias_outs is not None and N % epl == 0 and K % epl == 0 and N >= epl and K >= epl and \
         all(t.data_ptr() % 16 == 0 for t in list(gs) + list(xs))
+    gs, xs, x2s = ops.dw_operands(gs, xs, x2s, N, K, R, ct)   # long reductions: bf16 operands once, 128 x 128 tiles
     for i in range(0, len(gs), MAXG):
         g_, x_, o_ = gs[i:i + MAXG], xs[i:i + MAXG], outs[i:i + MAXG]
         x2_ = x2s[i:i + MAXG] if x2s is not None else None

@@ -422,17 +422,18 @@ class _Linear(Function):
                 (x2 is None or x.dtype == torch.float32)
             # the owner's gradient arena, when offered for this pass: accumulate straight into the slots (pre-zeroed)
             slot, give = arena_take([ctx.pptr[0]] + ([ctx.pptr[1]] if fuse else []), [N * K] + ([N] if fuse else []))
+            ga, xa, x2a = dw_operands([g], [x], [x2], N, K, R, ct)   # long reductions: bf16 operands, 128 x 128 tiles
             if slot is not None:
                 dw, give_w = slot[0].view(N, K), give
                 if fuse:
                     db = slot[1]
-                L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
+                L.gemm(M=N, N=K, K=R, A=ga, B=xa, B2=x2a, Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
                        splitk=max(2, _splitk(tiles, R, ct)), colsum=[db] if fuse else None, accumulate=True, alpha=alpha)
             else:
                 dw = _empty(N, K, dtype=torch.float32, device=x.device)
                 if fuse:
                     db = _empty(N, dtype=torch.float32, device=x.device)
-                L.gemm(M=N, N=K, K=R, A=[g], B=[x], B2=[x2], Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True,
+                L.gemm(M=N, N=K, K=R, A=ga, B=xa, B2=x2a, Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True,
                        transB=True, splitk=max(2, _splitk(tiles, R, ct)) if fuse else _splitk(tiles, R, ct),
                        colsum=[db] if fuse else None, alpha=alpha)
         if want_db and db is None:
@@ -443,6 +444,46 @@ class _Linear(Function):
             if db is not None and want_db and fuse:
                 db = None
         return dx, dw, db, dx2, None, None, None, None, None, None, None, dres
+
+
+def dw_operands(gs, xs, x2s, N: int, K: int, R: int, ct: int):
+    """Operands of weight-gradient products dW[N, K] += g^T (x [+ x2]) over a LONG reduction (R >= 2048 rows: the encoders'
+    B * N_seg rows, every projection of the stage-2 shipped shape with its 128 x 80 object rows): fp32 operands are rounded to
+    bf16 ONCE by one launch per operand shape -- the rounding the GEMM staging applies anyway, (x + x2) summed in fp32 first
+    -- so that the product takes the 128 x 128-tile bf16 kernel (gemm_tt128_kernel: half the operand re-reads of the 64 x 64
+    tile, 2 B per element instead of 4; config s2: 155 -> ~490 TFLOP/s on these launches).  Returns (gs, xs, x2s)."""
+    if ct != BF16 or R < 2048 or R % 64 or N % 128 or K % 128:
+        return gs, xs, x2s
+    x2s = list(x2s) if x2s is not None else [None] * len(xs)
+    if all(t.dtype == torch.bfloat16 for t in list(gs) + list(xs)) and all(t is None for t in x2s):
+        return gs, xs, None
+    if any(t.dtype != torch.float32 for t in x2s if t is not None) or \
+            any(t.dtype == torch.bfloat16 and t2 is not None for t, t2 in zip(xs, x2s)):
+        return gs, xs, (x2s if any(t is not None for t in x2s) else None)
+    cache, jobs = {}, {}
+
+    def conv(t, t2):
+        if t.dtype == torch.bfloat16:
+            return t
+        key = (t.data_ptr(), t2.data_ptr() if t2 is not None else 0, t.numel())
+        o = cache.get(key)
+        if o is None:
+            if t.numel() % 8 or t.data_ptr() % 16 or (t2 is not None and t2.data_ptr() % 16) or not t.is_contiguous():
+                return None
+            o = cache[key] = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+            jobs.setdefault(t.numel(), []).append((t, t2, o))
+        return o
+    g2 = [conv(t, None) for t in gs]
+    x2 = [conv(t, t2) for t, t2 in zip(xs, x2s)]
+    if any(t is None for t in g2 + x2):
+        return gs, xs, (x2s if any(t is not None for t in x2s) else None)
+    arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
+    for n, lst in jobs.items():
+        for s0 in range(0, len(lst), L.MAXG):
+            ch = lst[s0:s0 + L.MAXG]
+            L.check(L.lib().pq3d_add_cast(arr([a for a, _, _ in ch]), arr([b for _, b, _ in ch]), arr([o for _, _, o in ch]),
+                                          len(ch), L.BF16, n, L.stream()), "pq3d_add_cast")
+    return g2, x2, None
 
 
 def linear(x, w, b=None, *, ct: int, x2=None, act: Optional[str] = None, out_dtype=torch.float32, row_mask=None,
@@ -510,9 +551,10 @@ class _LinearGroup(Function):
             dWb = torch.zeros(G, N, K, dtype=torch.float32, device=dev)
             dWs = [dWb[g] for g in range(G)]
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
+        gs, xs_, _ = dw_operands(list(gs), list(xs), None, N, K, R, ct)
         for s in range(0, G, L.MAXG):
             e = min(G, s + L.MAXG)
-            L.gemm(M=N, N=K, K=R, A=gs[s:e], B=list(xs[s:e]), Cs=dWs[s:e], ct=ct, lda=N, ldb=K, ldc=K,
+            L.gemm(M=N, N=K, K=R, A=gs[s:e], B=list(xs_[s:e]), Cs=dWs[s:e], ct=ct, lda=N, ldb=K, ldc=K,
                    transA=True, transB=True, splitk=max(2, _splitk(tiles * (e - s), R, ct)), accumulate=True)
         return (None, None, None, *dxs, *(dWs if give else [None] * G))
 
@@ -974,7 +1016,8 @@ class _LinearLNGroup(Function):
             d.dys[g], d.d_o[g], d.dgamma[g], d.dbeta[g] = L.ptr(dys[g]), L.ptr(dlin[g]), L.ptr(dgs[g]), L.ptr(dbs[g])
         L.check(timed("pq3d_add_ln_bwd", f"R{R}d{N}M{G}i", 0.0, 3.0 * G * R * N * 4, L.lib().pq3d_add_ln_bwd, C.byref(d),
                       L.stream()), "pq3d_add_ln_bwd")
-        L.gemm(M=N, N=K, K=R, A=[dlin[g] for g in range(G)], B=list(xs), Cs=dWs, ct=ct, lda=N, ldb=K, ldc=K, transA=True,
+        ga_, xa_, _ = dw_operands([dlin[g] for g in range(G)], list(xs), None, N, K, R, ct)
+        L.gemm(M=N, N=K, K=R, A=ga_, B=xa_, Cs=dWs, ct=ct, lda=N, ldb=K, ldc=K, transA=True,
                transB=True, splitk=max(2, _splitk(tiles * G, R, ct)), colsum=dbl if fuse else None, accumulate=True)
         if not fuse:
             dbl = [colsum(dlin[g].view(R, N)) for g in range(G)]
