@@ -669,13 +669,17 @@ def test_mean_many_matches_torch_forward_and_backward():
     assert float(l2) == float(la)
 
 
-@pytest.mark.parametrize("Lq,Lk,mode,H", [(100, 100, "bias", 8), (100, 100, "kpm", 8), (200, 200, "bias", 8), (240, 240, "kpm", 2),
-                                          (16, 16, "kpm", 4), (1, 37, "bias", 4), (77, 5, "kpm", 4), (130, 97, "bias", 3)])
-def test_attention_self_mfma_split_bf16_kernels(Lq, Lk, mode, H):
+@pytest.mark.parametrize("Lq,Lk,mode,H,dh", [(100, 100, "bias", 8, 32), (100, 100, "kpm", 8, 32), (200, 200, "bias", 8, 32),
+                                             (240, 240, "kpm", 2, 32), (16, 16, "kpm", 4, 32), (1, 37, "bias", 4, 32),
+                                             (77, 5, "kpm", 4, 32), (130, 97, "bias", 3, 32),
+                                             (120, 120, "bias", 12, 64), (80, 80, "bias", 12, 64), (128, 128, "kpm", 3, 64),
+                                             (1, 37, "bias", 2, 64), (77, 5, "kpm", 2, 64), (97, 128, "bias", 2, 64)])
+def test_attention_self_mfma_split_bf16_kernels(Lq, Lk, mode, H, dh):
     """Compute type BF16X3 (fp32 storage, split-bf16 MFMA arithmetic; csrc/attn_sa.hip: the decoder's self-attention at
-    d_h = 32) against an fp64 reference and against the exact-fp32 kernels on the same inputs: outputs, lse-dependent
-    gradients of q / k / v and the bias gradient, incl. padded keys, ragged sizes and a query count above 128."""
-    dh, B = 32, 3
+    d_h = 32 and at d_h = 64, the shipped decoders' head width) against an fp64 reference and against the exact-fp32 kernels
+    on the same inputs: outputs, lse-dependent gradients of q / k / v and the bias gradient, incl. padded keys, ragged sizes
+    and a query count above 128."""
+    B = 3
     d = H * dh
     q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
     kpm = torch.arange(Lk)[None, :] >= torch.tensor([Lk, max(1, Lk // 2), max(1, Lk - 3)])[:, None]
