@@ -194,6 +194,12 @@ def committed_profiles(config):
     tags = sorted({m.group(1) for f in glob.glob(os.path.join(pdir, f"*_{config}*")) for m in [re.search(r"_(r\d\d)_", f)] if m})
     pmc, stats, tag_used = None, {}, None
     for tag in reversed(tags):
+        mj = os.path.join(pdir, f"pmc_mfma_{tag}_{config}.json")
+        if "_mfma" not in stats and os.path.exists(mj):
+            try:
+                stats["_mfma"] = json.load(open(mj)); stats["_mfma"]["_file"] = f"profiles/{os.path.basename(mj)}"
+            except ValueError:
+                pass
         pj = os.path.join(pdir, f"pmc_traffic_{tag}_{config}.json")
         st = os.path.join(pdir, f"rocprofv3_kernel_stats_{tag}_fused_graph_{config}.txt")
         if pmc is None and os.path.exists(pj):
@@ -201,47 +207,54 @@ def committed_profiles(config):
                 pmc = json.load(open(pj)); pmc["_file"] = f"profiles/{os.path.basename(pj)}"
             except ValueError:
                 pmc = None
-        if not stats and os.path.exists(st):
+        if "_file" not in stats and os.path.exists(st):
             lines = open(st).read().splitlines()
-            m = re.search(r"(\d+) kernel dispatches.*per step: (\d+) dispatches", lines[0]) if lines else None
-            steps = (int(m.group(1)) / int(m.group(2))) if m else None
+            # steps of the trace = calls of a once-per-step kernel (tools/rocprof_summary.py writes it into the header);
+            # older files: the most common call count of the table
+            m = re.search(r"steps (\d+)", lines[0]) if lines else None
+            steps = float(m.group(1)) if m else None
+            if steps is None:
+                import collections
+                cc = collections.Counter(int(mm.group(2)) for ln in lines[2:]
+                                         for mm in [re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s", ln)] if mm and int(mm.group(2)) >= 3)
+                steps = float(cc.most_common(1)[0][0]) if cc else None
             for ln in lines[2:]:
                 mm = re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
                 if mm and steps:
                     name = re.sub(r"[<(].*$", "", mm.group(1).replace("(anonymous namespace)::", "").replace("void ", ""))
                     c, tot = stats.get(name, (0.0, 0.0))
                     stats[name] = (c + int(mm.group(2)) / steps, tot + float(mm.group(3)) * 1e3 / steps)   # launches, us per step
-            stats["_file"] = f"profiles/{os.path.basename(st)}"
+            stats["_file"], stats["_steps"] = f"profiles/{os.path.basename(st)}", steps
             tag_used = tag
     return pmc, stats, tag_used
 
 
 def family_block(entry, v, peak_tflops, steps, pmc, stats):
-    """Roofline entry of one C-ABI entry point (= kernel family): algorithmic FLOPs (or bytes) of all its launches divided
-    by their summed durations (HIP events on the launch stream, eager pass), per-launch averages, and -- from the committed
-    rocprofv3 evidence of the same config -- the family's in-graph time and its HBM traffic per launch."""
+    """Roofline entry of one C-ABI entry point (= kernel family).  BOTH roofs are reported:
+      frac_mfma = algorithmic FLOPs of the family's launches / their time / the dense MFMA peak of the compute dtype,
+      frac_hbm  = measured memory-side traffic (PMC FETCH_SIZE / WRITE_SIZE, corrected by the calibration launch of the same
+                  pass; includes Infinity-Cache hits = an upper bound on HBM bytes) / the same time / 8 TB/s -- or the
+                  algorithmic bytes when no PMC file of this config is committed,
+    `bound` = the larger one and `frac` / `achieved` / `peak` / `unit` are that roof's.  Time = the family's kernels in the
+    REPLAYED graph (committed rocprofv3 --kernel-trace --stats summary of the same build, per step = totals / calls of a
+    once-per-step kernel) when profiles/ holds one, else the HIP-event time of this run's eager profiled pass; `timing`
+    says which.  `mfma_busy`: SQ_VALU_MFMA_BUSY_CYCLES of the family per step / (in-graph time x 2.4 GHz x 1024 SIMDs)."""
     calls, ms = v["calls"], v["ms"]
-    per_launch_us = ms / calls * 1e3
-    if v["flops"] > 0:
-        ach = v["flops"] / (ms * 1e-3) / 1e12
-        blk = {"bound": "mfma", "achieved": ach, "peak": peak_tflops, "unit": "TFLOP/s", "frac": ach / peak_tflops}
-    else:
-        ach = v["bytes"] / (ms * 1e-3) / 1e9
-        blk = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
     names = FAMILY_KERNELS.get(entry, [])
-    blk.update({"kernel": entry, "gpu_kernels": names, "launches_per_step": calls / steps, "avg_launch_us": per_launch_us,
-                "ms_per_step": ms / steps, "algorithmic_gflop_per_step": v["flops"] / steps / 1e9,
-                "algorithmic_bytes_per_launch": v["bytes"] / calls, "traffic": None})
-    # in-graph durations of the same kernels (rocprofv3 --kernel-trace --stats of the replayed step, committed)
+    blk = {"kernel": entry, "gpu_kernels": names, "launches_per_step": calls / steps, "avg_launch_us": ms / calls * 1e3,
+           "ms_per_step_eager_events": ms / steps, "algorithmic_gflop_per_step": v["flops"] / steps / 1e9,
+           "algorithmic_bytes_per_launch": v["bytes"] / calls, "traffic": None}
+    t_us, timing, l_graph = ms / steps * 1e3, "HIP events on the launch stream, eager profiled pass of this run", calls / steps
     hit = [(n, stats[n]) for n in names if n in stats]
     if hit:
-        l = sum(c for _n, (c, _t) in hit)
-        t = sum(t for _n, (_c, t) in hit)
-        blk["in_graph"] = {"launches_per_step": round(l, 2), "avg_launch_us": t / max(l, 1e-9), "ms_per_step": t / 1e3,
-                           "frac": (v["flops"] / steps / (t * 1e-6) / 1e12 / peak_tflops) if v["flops"] > 0
-                           else (v["bytes"] / steps / (t * 1e-6) / 1e9 / PEAK_HBM_GBS), "source": stats.get("_file")}
-    # HBM traffic per launch: PMC FETCH_SIZE / WRITE_SIZE sums over the family's kernels / its launches, corrected by the
-    # calibration launch of the same PMC pass (a known 100 MiB streaming copy: raw counter / true bytes)
+        l_graph = sum(c for _n, (c, _t) in hit)
+        t_us = sum(t for _n, (_c, t) in hit)
+        timing = f"in-graph kernel durations, {stats.get('_file')} ({stats.get('_steps'):.0f} steps)"
+        blk["in_graph"] = {"launches_per_step": round(l_graph, 2), "avg_launch_us": t_us / max(l_graph, 1e-9),
+                           "ms_per_step": t_us / 1e3, "source": stats.get("_file")}
+    blk["timing"] = timing
+    # HBM-side traffic per launch: PMC sums over the family's kernels / its launches, calibrated
+    traffic_step = None
     if pmc is not None and "kernels" in pmc:
         fetch = write = launches = 0.0      # launch-weighted sums over every (kernel, grid) row of the family
         for n in names:
@@ -253,11 +266,34 @@ def family_block(entry, v, peak_tflops, steps, pmc, stats):
             cal = pmc.get("calibration") or {}
             cf = 1.0 / cal["fetch_raw_over_true"] if cal.get("fetch_raw_over_true") else 2.0    # guide: x2 for wide reads
             cw = 1.0 / cal["write_raw_over_true"] if cal.get("write_raw_over_true") else 1.0
-            blk.update({"traffic": (fetch * cf + write * cw) / launches, "traffic_raw_counters": (fetch + write) / launches,
+            per_launch = (fetch * cf + write * cw) / launches
+            traffic_step = per_launch * l_graph
+            blk.update({"traffic": per_launch, "traffic_raw_counters": (fetch + write) / launches,
                         "traffic_correction": {"fetch_x": round(cf, 3), "write_x": round(cw, 3),
                                                "from": "calibration launch in the same PMC pass" if cal else
                                                "MI355X_MICROARCH.md HBM section (no calibration in this file)"},
                         "traffic_source": pmc.get("_file")})
+    bytes_step = traffic_step if traffic_step is not None else v["bytes"] / steps
+    tf = v["flops"] / steps / (t_us * 1e-6) / 1e12
+    gbs = bytes_step / (t_us * 1e-6) / 1e9
+    blk["frac_mfma"], blk["frac_hbm"] = tf / peak_tflops, gbs / PEAK_HBM_GBS
+    blk["hbm_bytes_basis"] = "measured traffic (PMC, calibrated)" if traffic_step is not None else "algorithmic bytes (no PMC file)"
+    if blk["frac_mfma"] >= blk["frac_hbm"]:
+        blk.update({"bound": "mfma", "achieved": tf, "peak": peak_tflops, "unit": "TFLOP/s", "frac": blk["frac_mfma"]})
+    else:
+        blk.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": blk["frac_hbm"]})
+    mf = stats.get("_mfma")
+    if mf is not None:
+        cyc = launches = 0.0
+        for n in names:
+            for r in mf["kernels"].get(n, []):
+                cyc += r["mfma_busy_cycles"] * r["launches"]
+                launches += r["launches"]
+        if launches > 0:
+            per_step = cyc / launches * l_graph
+            blk["mfma_busy"] = per_step / (t_us * 1e-6 * mf.get("clock_ghz", 2.4) * 1e9 * mf.get("simds", 1024))
+            blk["mfma_busy_cycles_per_step"] = per_step
+            blk["mfma_busy_source"] = mf.get("_file")
     return blk
 
 

@@ -176,6 +176,37 @@ def test_bf16_mode_is_closer_to_fp32_than_the_references_own_bf16_autocast(name)
     assert float((qf - collect[-1]).abs().max() / collect[-1].abs().max()) <= 0.5 * float(z[f"err/layer_query/{args['L'] - 1}/max_rel"])
 
 
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", ["F19_autocast_c2_slice", "F19_autocast_d768"])
+def test_bf16_gradients_are_closer_to_fp32_than_the_references_own_bf16_autocast(name, fused):
+    """The same yardstick for the BACKWARD (VERDICT r3 item 6 i): the reference under its own bf16 autocast differentiates
+    the model-case loss with a per-parameter gradient error against its fp32 run of 20 % (median, relative L2; cosine of the
+    whole gradient vector 0.96 - 0.97) and 26 - 85 % on `pairwise_loc_fc`, the ~1e3 : 1 cancelling sum the bf16 gradient
+    checks used to leave out (F19, err/grad/*).  The HIP 'bf16' mode is asserted below 0.75 x the reference's own error for
+    EVERY parameter -- `pairwise_loc_fc` included (measured: worst ratio 0.52, the K/V-side biases; the forward is 4-7x below)
+    -- and at a quarter of its cosine defect."""
+    z, _ = util.load_fixture(name)
+    _zb, args = util.load_fixture(str(z["meta/base"]))
+    _cfg, model, sd, dd = util.model_case(args)
+    set_compute(model, "bf16")
+    model.unified_encoder.fused = fused
+    _out, _loss, g = run_hip(model, args, dd, grads=True)
+    _oout, _collect, _ol, og = util.run_oracle(args, sd, dd)
+    assert sorted(g) == sorted(og)
+    gmax = max(float(v.norm()) for v in og.values())
+    worst = []
+    for n in og:
+        mine = float((g[n].float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * gmax))
+        ref = float(z[f"err/grad/{n}/rel_l2"])
+        worst.append((mine / max(ref, 1e-3), n, mine, ref))
+        assert mine <= max(0.75 * ref, 2e-3), (n, mine, ref)
+    names = sorted(og)
+    va = torch.cat([g[n].float().cpu().flatten() for n in names]).double()
+    vb = torch.cat([og[n].flatten() for n in names]).double()
+    cos = float((va * vb).sum() / (va.norm() * vb.norm()))
+    assert 1.0 - cos <= 0.25 * (1.0 - float(z["err/grad_cos"])), (cos, float(z["err/grad_cos"]), max(worst)[:2])
+
+
 def test_fused_path_is_taken_and_equals_modular_bf16():
     """The fused executor must actually run for the parallel structure and agree with the modular path in bf16
     (same kernels, same rounding points; only atomics order differs)."""

@@ -21,10 +21,16 @@ for CFG in $CONFIGS; do
   python $R/tools/rocprof_pmc_summary.py $F $W > $OUT/rocprofv3_pmc_hbm_traffic_${TAG}_$CFG.txt
   python $R/tools/pmc_traffic_json.py $F $W > $OUT/pmc_traffic_${TAG}_$CFG.json
   cp $OUT/pmc_traffic_${TAG}_$CFG.json $R/profiles/pmc_traffic_${TAG}_$CFG.json
+  # MFMA utilisation (north_star: "MFMA utilisation reported"): its own counter pass
+  rm -rf /tmp/pmc_mfma
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d /tmp/pmc_mfma -o p -- python $R/bench.py --config $CFG --no-graph --steps 3 --warmup 1 --cpu-steps 0 --profile-steps 1 --headline-only > /dev/null 2>&1
+  MF=$(find /tmp/pmc_mfma -name "*.db" | head -1)
+  python $R/tools/pmc_mfma_json.py $MF > $OUT/pmc_mfma_${TAG}_$CFG.json && cp $OUT/pmc_mfma_${TAG}_$CFG.json $R/profiles/
   rm -rf /tmp/ks
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks -o s -- python $R/bench.py --config $CFG --steps 20 --warmup 5 --cpu-steps 0 --profile-steps 1 --headline-only > $OUT/bench_under_rocprof_$CFG.json 2>/dev/null
   DB=$(find /tmp/ks -name "*.db" | head -1)
-  python $R/tools/rocprof_summary.py $DB 30 > $OUT/rocprofv3_kernel_stats_${TAG}_fused_graph_$CFG.txt
+  # steps in this trace: 3 eager warm-up steps + 5 warm-up replays + 20 timed replays + 1 eager profiled step
+  python $R/tools/rocprof_summary.py $DB 29 > $OUT/rocprofv3_kernel_stats_${TAG}_fused_graph_$CFG.txt
   python $R/tools/rocprof_step_sequence.py $DB > $OUT/rocprofv3_step_sequence_${TAG}_$CFG.txt 2>&1
   # the bench reads the in-graph kernel averages of THIS build from profiles/ (roofline.in_graph)
   cp $OUT/rocprofv3_kernel_stats_${TAG}_fused_graph_$CFG.txt $R/profiles/
