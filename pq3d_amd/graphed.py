@@ -226,10 +226,12 @@ class GraphedQuery3D(nn.Module):
         for p in params:
             p.grad = self._grad_view(p) if accumulate else None
         req = [o for o in outs if o.requires_grad]
-        with ops.grad_arena(slots, flats):   # every slot offered for the whole pass (zeroed here when fresh)
+        with ops.grad_arena(slots, flats) as arena:   # every slot offered for the whole pass (zeroed here when fresh)
             grads = torch.autograd.grad(req, [self._args[i] for i in self._gin_idx] + params, grad_outputs=self.static_gout,
                                         allow_unused=True, retain_graph=retain)
         gin, gp = grads[:len(self._gin_idx)], grads[len(self._gin_idx):]
+        if not accumulate:
+            arena.verify_returned(params, gp)   # tied weights: the returned gradient must still be the slot (ops.arena_verify)
         views, srcs = [], []
         for p, g in zip(params, gp):
             v = self._grad_view(p, delta)

@@ -452,7 +452,10 @@ def dw_operands(gs, xs, x2s, N: int, K: int, R: int, ct: int):
     bf16 ONCE by one launch per operand shape -- the rounding the GEMM staging applies anyway, (x + x2) summed in fp32 first
     -- so that the product takes the 128 x 128-tile bf16 kernel (gemm_tt128_kernel: half the operand re-reads of the 64 x 64
     tile, 2 B per element instead of 4; config s2: 155 -> ~490 TFLOP/s on these launches).  Returns (gs, xs, x2s)."""
-    if ct != BF16 or R < 2048 or R % 64 or N % 128 or K % 128:
+    # ... when the launch has enough 128 x 128 output tiles to fill the chip without a deep split-K (config 2's input
+    # encoders: 3 groups of [256, 256] over 8192 rows = 12 tiles -- 14 us of rounding + 33 us against 29 us on the 64 x 64
+    # chunk kernel, measured; config s2: 16-24 groups of [768, 768] = 576+ tiles)
+    if ct != BF16 or R < 2048 or R % 64 or N % 128 or K % 128 or (N // 128) * (K // 128) * len(gs) < 64:
         return gs, xs, x2s
     x2s = list(x2s) if x2s is not None else [None] * len(xs)
     if all(t.dtype == torch.bfloat16 for t in list(gs) + list(xs)) and all(t is None for t in x2s):
@@ -1079,19 +1082,24 @@ def arena_zeroed_buffers(consume: bool = True) -> set:
     return z
 
 
-def arena_verify() -> None:
+def arena_verify(returned=None) -> None:
     """A fresh pass hands the FIRST arena-aware use of a parameter a view of its slot and lets later arena-aware uses (a tied
     weight) add into the slot in place.  That is only correct while autograd keeps that view as the gradient: a gradient
     for the same parameter from a function that is NOT arena-aware makes autograd sum out of place, .grad becomes a tensor
     of its own and the later in-place additions are lost.  Autograd gives no guarantee here, so the hand-out is CHECKED
-    when the pass ends: every slot that took an in-place second use must still be what .grad aliases."""
+    when the pass ends: every slot that took an in-place second use must still be what .grad aliases.  ``returned``:
+    {parameter data_ptr: gradient torch.autograd.grad() returned} for callers that do not go through .backward()
+    (GraphedQuery3D): checked instead of .grad."""
     bad = []
     for q in _Arena.multi:
         ent = _Arena.by_ptr.get(q)
         if ent is None:
             continue
         p_, fl_, o_, _n = ent
-        if p_.grad is None or p_.grad.data_ptr() != fl_.data_ptr() + 4 * o_:
+        g_ = returned.get(q, None) if returned is not None else p_.grad
+        if returned is None and g_ is None:
+            continue      # torch.autograd.grad(): .grad is not written -- the caller verifies what it got back (returned=...)
+        if g_ is None or g_.data_ptr() != fl_.data_ptr() + 4 * o_:
             bad.append(tuple(p_.shape))
     _Arena.multi = set()
     if bad:
@@ -1114,6 +1122,15 @@ class grad_arena:
         # "already zero-filled" note (arena_zeroed_buffers) kept past the end of the context
         self.slots, self.buffers, self.pack_follows = slots, list(buffers), pack_follows
 
+    def verify_returned(self, params, grads) -> None:
+        """For torch.autograd.grad() callers, after the context: the gradients returned for tied parameters that took an
+        in-place second use must alias their slots."""
+        _Arena.multi, _Arena.by_ptr = set(self.multi), dict(self.by_ptr)
+        try:
+            arena_verify({p.data_ptr(): g for p, g in zip(params, grads)})
+        finally:
+            _Arena.multi, _Arena.by_ptr = set(), {}
+
     def __enter__(self):
         _Arena.zeroed_ptrs, _Arena.multi = set(), set()
         zeroed = {b.data_ptr() for b in self.buffers}
@@ -1135,6 +1152,7 @@ class grad_arena:
         return self
 
     def __exit__(self, *exc):
+        self.multi, self.by_ptr = set(_Arena.multi), dict(_Arena.by_ptr)
         try:
             if exc[0] is None:
                 arena_flush_zero()    # nobody consumed it: the owner still expects zeroed buffers

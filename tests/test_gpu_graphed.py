@@ -13,7 +13,7 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("mode", ["direct", "autograd"])
-@pytest.mark.parametrize("name", ["F4_c2_slice", "F4b_c4_slice"])
+@pytest.mark.parametrize("name", ["F4_c2_slice", "F4b_c4_slice", "F5_dimloc6"])   # dimloc6: a Linear used twice (tied slot use)
 def test_graphed_model_matches_eager(name, mode):
     _z, args = util.load_fixture(name)
     _cfg, model, sd, dd = util.model_case(args)

@@ -35,6 +35,8 @@ for CFG in $CONFIGS; do
   # the bench reads the in-graph kernel averages of THIS build from profiles/ (roofline.in_graph)
   cp $OUT/rocprofv3_kernel_stats_${TAG}_fused_graph_$CFG.txt $R/profiles/
   STEPS=50; [ $CFG != c2 ] && STEPS=20
-  timeout 900 python $R/bench.py --config $CFG --steps $STEPS --warmup 10 --dump-kernels $OUT/kernel_table_${TAG}_fused_$CFG.txt > $OUT/bench_${TAG}_${CFG}_1gpu.json 2> $OUT/bench_$CFG.err
+  CPUS=32; case $CFG in s1|s2) CPUS=3;; esac     # the shipped-size oracle step takes ~10 s on the host: a 3-step sample
+  timeout 1500 python $R/bench.py --config $CFG --steps $STEPS --warmup 10 --cpu-steps $CPUS --dump-kernels $OUT/kernel_table_${TAG}_fused_$CFG.txt > $OUT/bench_${TAG}_${CFG}_1gpu.json 2> $OUT/bench_$CFG.err
+  cp $OUT/bench_${TAG}_${CFG}_1gpu.json $OUT/kernel_table_${TAG}_fused_$CFG.txt $OUT/rocprofv3_step_sequence_${TAG}_$CFG.txt $OUT/rocprofv3_pmc_hbm_traffic_${TAG}_$CFG.txt $R/profiles/ 2>/dev/null
 done
 echo done
