@@ -278,7 +278,7 @@ int pq3d_mask_row_all(const uint8_t* mask, uint8_t* row_open, int64_t rows, int6
  * x may be NULL (plain LN of o_m: nn.Sequential(Linear, LayerNorm) encoders, get_mlp_head's LN eps=1e-12).
  * mean/rstd ([M,R] fp32) are saved for backward.  Backward: dx = sum_m d(x+o_m), d_o[m], dgamma[m], dbeta[m]
  * (dgamma/dbeta are zeroed by the call and accumulated with atomics).  One 64-lane wave per row, row kept in
- * registers (d <= 1024), two-pass statistics in fp32.
+ * registers (d <= 2048), two-pass statistics in fp32.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
   int32_t R, d, M, rows_per_scene;

@@ -1,5 +1,5 @@
 // Residual-add + LayerNorm (merged over M branches), forward and backward.  HBM-bound: one wave per row at a time,
-// the row lives in registers (d <= 1024 -> <= 16 values per lane), DPP reductions for the statistics, fp32 math
+// the row lives in registers (d <= 2048 -> <= 32 values per lane), DPP reductions for the statistics, fp32 math
 // throughout.  Algorithmic bytes per row: (1 + M) reads + 1 write of d elements.
 // Column ownership: VEC (d == 64 * PL, PL >= 4, 16-byte aligned operands): lane owns PL CONSECUTIVE columns, every row
 // access is a 16-byte load/store; otherwise lane owns columns lane + 64 j (4-byte accesses, any d).
@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int MAXPL = 16;  // values per lane -> d <= 1024
+constexpr int MAXPL = 32;  // values per lane -> d <= 2048 (round 4: 1152-wide MLP heads of a 768-wide decoder ran into 1024)
 constexpr int WPB = 4;     // waves (rows in flight) per block
 
 struct RowStats { float mean, rstd; };
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void add_ln_bwd_kernel(const pq3d_ln_desc 
 }
 
 int check_ln(const pq3d_ln_desc& d, bool bwd) {
-  PQ_CHECK_ARG(d.R >= 0 && d.d >= 1 && d.d <= 64 * MAXPL, "pq3d_add_ln: d must be in [1,1024]");
+  PQ_CHECK_ARG(d.R >= 0 && d.d >= 1 && d.d <= 64 * MAXPL, "pq3d_add_ln: d must be in [1,2048]");
   PQ_CHECK_ARG(d.M >= 1 && d.M <= PQ3D_MAX_GROUPS, "pq3d_add_ln: M out of range");
   PQ_CHECK_ARG(d.rows_per_scene >= 1 && (d.R % d.rows_per_scene) == 0, "pq3d_add_ln: R % rows_per_scene != 0");
   PQ_CHECK_ARG(d.mean && d.rstd, "pq3d_add_ln: null mean/rstd");
@@ -309,7 +309,9 @@ int check_ln(const pq3d_ln_desc& d, bool bwd) {
 
 // VEC: whole rows in 16-byte pieces (d == 64 * PL with PL a multiple of 4, every operand 16-byte aligned)
 bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd) {
-  if (d.d != 256 && d.d != 512 && d.d != 1024) return false;
+  // 64 * PL with PL in {4, 8, 16, 32}.  (d = 768 as 12-piece vector rows was tried in round 4: the 3-branch backward at
+  // R = 10240 went from ~0.1 ms to 0.92 ms per launch -- left on the 4-byte path, 3.2 TB/s on the single-branch calls)
+  if (d.d != 256 && d.d != 512 && d.d != 1024 && d.d != 2048) return false;
   auto al = [](const void* p, int dt) { return ((uintptr_t)p & (dt == PQ3D_F32 ? 15 : 7)) == 0; };
   bool ok = al(d.x, d.dt_x);
   const int nm = d.M;
@@ -329,7 +331,8 @@ bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd) {
   else if (d.d <= 128) { LAUNCH(2, false); }                                           \
   else if (d.d <= 256) { if (vec) { LAUNCH(4, true); } else { LAUNCH(4, false); } }    \
   else if (d.d <= 512) { if (vec) { LAUNCH(8, true); } else { LAUNCH(8, false); } }    \
-  else { if (vec) { LAUNCH(16, true); } else { LAUNCH(16, false); } }
+  else if (d.d <= 1024) { if (vec) { LAUNCH(16, true); } else { LAUNCH(16, false); } } \
+  else { if (vec) { LAUNCH(32, true); } else { LAUNCH(32, false); } }
 
 }  // namespace
 
@@ -466,12 +469,13 @@ __global__ __launch_bounds__(WPB * 64) void rmsnorm_bwd_kernel(const float* __re
   else if (d <= 128) hipLaunchKernelGGL((kernel<2>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);          \
   else if (d <= 256) hipLaunchKernelGGL((kernel<4>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);          \
   else if (d <= 512) hipLaunchKernelGGL((kernel<8>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);          \
-  else hipLaunchKernelGGL((kernel<16>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);
+  else if (d <= 1024) hipLaunchKernelGGL((kernel<16>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);       \
+  else hipLaunchKernelGGL((kernel<32>), grid, dim3(WPB * 64), 0, s, __VA_ARGS__);
 
 extern "C" int pq3d_rmsnorm_fwd(const float* x, const float* w, float* y, float* rstd, int64_t R, int32_t d, float eps,
                                 void* stream) {
   PQ_DEVICE_GUARD(stream, x);
-  PQ_CHECK_ARG(x && w && y && rstd && R >= 0 && d >= 1 && d <= 64 * MAXPL, "pq3d_rmsnorm_fwd: bad args (d <= 1024)");
+  PQ_CHECK_ARG(x && w && y && rstd && R >= 0 && d >= 1 && d <= 64 * MAXPL, "pq3d_rmsnorm_fwd: bad args (d <= 2048)");
   if (R == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((R + WPB - 1) / WPB));

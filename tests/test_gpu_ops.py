@@ -195,7 +195,7 @@ def test_mask_row_all():
 
 
 # ---------------------------------------------------------------------------------------------- layernorm
-@pytest.mark.parametrize("d", [64, 256, 768, 100])
+@pytest.mark.parametrize("d", [64, 256, 768, 100, 1024, 1152, 2048])   # > 1024: 32 values per lane
 @pytest.mark.parametrize("M,with_x,with_coef", [(1, True, False), (3, True, False), (2, False, True), (3, True, True)])
 def test_add_layernorm(d, M, with_x, with_coef):
     B, Lq = 3, 11
