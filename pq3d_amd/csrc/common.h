@@ -151,7 +151,7 @@ struct pq3d_kgroup {
 };
 struct pq3d_kdesc {
   int32_t M, N, K, groups, batch, ct, dtA, dtA2, dtB, dtC, dtC2, dtAux, dtBias, transA, transB, act, act_grad, splitk, kconcat,
-      accumulate, dtB2;
+      accumulate, dtB2, xcd_order;
   float alpha, row_fill;
   int64_t lda, ldb, ldc, strideA, strideB, strideC;
   const float* row_scale;
@@ -167,7 +167,7 @@ inline pq3d_kdesc make_kdesc(const pq3d_gemm_desc& d) {
   k.transB = d.transB; k.act = d.act; k.act_grad = d.act_grad; k.splitk = d.splitk; k.kconcat = d.kconcat;
   k.accumulate = d.accumulate; k.dtB2 = d.dtB2; k.alpha = d.alpha; k.row_fill = d.row_fill; k.lda = d.lda; k.ldb = d.ldb;
   k.ldc = d.ldc; k.strideA = d.strideA; k.strideB = d.strideB; k.strideC = d.strideC; k.row_scale = d.row_scale;
-  k.row_fill_flag = d.row_fill_flag; k.mask_out = d.mask_out; k.drop = d.drop;
+  k.row_fill_flag = d.row_fill_flag; k.mask_out = d.mask_out; k.drop = d.drop; k.xcd_order = 0;
   for (int g = 0; g < PQ3D_MAX_GROUPS; ++g) {
     const bool on = g < d.groups;
     k.gp[g].A = on ? d.A[g] : nullptr; k.gp[g].A2 = on ? d.A2[g] : nullptr; k.gp[g].B = on ? d.B[g] : nullptr;
@@ -176,6 +176,79 @@ inline pq3d_kdesc make_kdesc(const pq3d_gemm_desc& d) {
     k.gp[g].colsum = on ? d.colsum[g] : nullptr;
   }
   return k;
+}
+
+// ---- XCD-aware tile order (big launches) ---------------------------------------------------------------------------
+// The dispatcher deals the workgroups of a grid to the 8 XCDs round-robin in linear-id order (x fastest), and every XCD has
+// its own 4 MB L2.  In hardware order the workgroups that share an operand tile (the n-tiles of one 64-row slab of A; the
+// 36 output tiles of one k-split of a weight gradient) land on 8 different L2s or run far apart in time, so a launch with
+// more workgroups than the chip holds at once re-fetches the shared operand once per sharer: measured (rocprofv3 FETCH_SIZE,
+// shipped stage-2 shape) 6-12 x the algorithmic bytes, 6 TB/s of fabric traffic for a 320 TFLOP/s weight-gradient GEMM.
+// With xcd_order the workgroups ONE XCD receives (linear ids = xcd mod 8, in dispatch order) walk a contiguous range of
+// logical tiles, ordered: blocks of `zrun` z-planes slowest, then SUPER-ROWS of `sr` x-tiles; inside a super-row x
+// fastest, then the virtual column index (y, z inside the block).
+//   sr    1 when operand B of one z-plane fits an L2 comfortably (<= 2.5 MB: a 768 x 768 fp32 weight): plain
+//         column-fastest order, A and B are both fetched once per XCD (measured at M = 10240, N = K = 768, 3 planes:
+//         1123 MB in hardware order, 491 MB with sr = 8, 274 MB with sr = 1).  8 otherwise: the ~150 workgroups an XCD
+//         has in flight cover 8 row tiles x ~19 column tiles that stream k in step -- each A slab is fetched once, each
+//         B slab once per super-row (FFN up-projection, B = 6.3 MB: 442 MB hardware order, 854 MB with sr = 1, 162 MB
+//         with sr = 8).
+//   zrun  consecutive z-planes (groups) that read the SAME row operand (the hoisted K/V projections: one memory, 8
+//         weight matrices; their weight gradients) are walked as extra columns of one plane, so the shared slab is
+//         fetched once per run instead of once per group.
+// Host side: xcd_order_for() turns it on for launches of >= PQ3D_XCD_MIN workgroups (smaller launches are co-resident
+// as a whole; the index arithmetic would only add latency there).
+#ifndef PQ3D_XCD_MIN
+#define PQ3D_XCD_MIN 1024   // measured: 512 / 1024 / 2048 within noise of each other at c2 and c5, 1024 best at c4 (-2.2 %), s1, s2
+#endif
+struct TileIdx { int x, y, z; };
+#ifdef __HIPCC__
+// xcd_order: 0 = hardware order, else sr | zrun << 8
+PQ_DEV TileIdx tile_index(const int xcd_order) {
+  TileIdx t = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  if (!xcd_order) return t;   // uniform
+  const int sr = xcd_order & 255, zr = xcd_order >> 8;
+  const int gx = gridDim.x, gy = gridDim.y, gyv = gy * zr, total = gx * gy * (int)gridDim.z;
+  const int id = t.x + gx * (t.y + gy * t.z), xcd = id & 7, per = total >> 3, rem = total & 7;
+  int l = xcd * per + min(xcd, rem) + (id >> 3);   // XCD j owns logical tiles [j * per + min(j, rem), ...): rem XCDs hold one more
+  const int zb = l / (gx * gyv);
+  l -= zb * gx * gyv;
+  const int s = l / (sr * gyv), in = l - s * sr * gyv, rows = min(sr, gx - s * sr);   // the last super-row may be short
+  const int yv = in / rows;
+  t.x = s * sr + (in - yv * rows);
+  const int zi = yv / gy;
+  t.y = yv - zi * gy;
+  t.z = zb * zr + zi;
+  return t;
+}
+#endif
+// workgroups: of the launch; b_plane_bytes: operand B of one z-plane; zrun: z-planes per run sharing operand A (must divide the z extent)
+inline int xcd_order_for(long workgroups, long b_plane_bytes, int zrun) {
+#ifdef PQ3D_XCD_OFF   // A/B measurement builds (tools/build_variant.py)
+  return 0;
+#else
+  if (workgroups < PQ3D_XCD_MIN) return 0;
+  const int sr = b_plane_bytes * (zrun > 1 ? zrun : 1) <= (5L << 19) ? 1 : 8;
+  return sr | ((zrun > 1 ? zrun : 1) << 8);
+#endif
+}
+// Planes per run that share the row operand of a plain grouped launch (one z-plane per group): A and its addend A2.
+inline int uniform_run(const void* const* p, int n);
+inline int shared_a_run(const pq3d_gemm_desc& d) {
+  if (d.kconcat > 1 || d.batch > 1 || d.splitk > 1 || d.groups <= 1) return 1;
+  const int r = uniform_run(d.A, d.groups);
+  return (r > 1 && uniform_run(d.A2, d.groups) % r == 0) ? r : 1;
+}
+// Longest run length r (dividing n) such that every block of r consecutive pointers is one pointer.
+inline int uniform_run(const void* const* p, int n) {
+  if (n <= 1) return 1;
+  int r = 1;
+  while (r < n && p[r] == p[0]) ++r;
+  if (n % r) return 1;
+  for (int b = 0; b < n; b += r)
+    for (int i = 1; i < r; ++i)
+      if (p[b + i] != p[b]) return 1;
+  return r;
 }
 
 #ifdef PQ3D_NO_KARG_PIN   // A/B measurement builds

@@ -342,16 +342,16 @@ struct BlockCoords {
   bool active;
 };
 // grid = (m tiles, n tiles, outputs * batch * splitk): no integer division unless batch > 1 or split-K is used
-template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_kdesc& d) {
+template <typename CT> PQ_DEV BlockCoords block_coords(const pq3d_kdesc& d, const TileIdx& ti) {
   typedef Tile<CT> T;
   BlockCoords b;
   b.ng = d.kconcat > 0 ? d.kconcat : 1;  // groups walked inside the K loop
-  int zz = blockIdx.z, split = 0;
+  int zz = ti.z, split = 0;
   if (d.splitk > 1) { split = zz % d.splitk; zz /= d.splitk; }
   if (d.batch > 1) { b.z = zz % d.batch; zz /= d.batch; } else b.z = 0;
   b.g = zz * b.ng;
-  b.m0 = blockIdx.x * BM;
-  b.n0 = blockIdx.y * BN;
+  b.m0 = ti.x * BM;
+  b.n0 = ti.y * BN;
   const int nkt = (d.K + T::BKE - 1) / T::BKE;
   b.kt0 = 0; b.kt1 = nkt; b.active = true;
   if (d.splitk > 1) {
@@ -380,19 +380,20 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_kdesc d) {
   // prologue was FIVE dependent scalar-cache misses (3.5k cycles before the first operand load was issued, measured with
   // the stamps above) and the epilogue several more.  Pin every scalar the kernel will use here: one batch of loads.
   GPtrs gp;
-  const int gspec = min((int)blockIdx.z, PQ3D_MAX_GROUPS - 1);   // the group index of a plain launch (no split / batch / concat)
+  const TileIdx ti = tile_index(d.xcd_order);   // hardware order, or the XCD-aware order of a big launch (common.h)
+  const int gspec = min(ti.z, PQ3D_MAX_GROUPS - 1);   // the group index of a plain launch (no split / batch / concat)
   gp.load(d, gspec);
 #ifndef PQ3D_NO_KARG_PIN
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.batch), "s"(d.splitk), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc),
                "s"(d.strideA), "s"(d.strideB), "s"(d.strideC), "s"(d.alpha), "s"(d.act), "s"(d.act_grad), "s"(d.dtC),
                "s"(d.dtC2), "s"(d.dtAux), "s"(d.dtBias), "s"(d.row_fill), "s"(d.row_scale), "s"(d.row_fill_flag),
-               "s"(d.mask_out), "s"(gp.A), "s"(gp.A2), "s"(gp.B));
+               "s"(d.mask_out), "s"(gp.A), "s"(gp.A2), "s"(gp.B), "s"(d.xcd_order));
   asm volatile("" ::"s"(gp.B2), "s"(gp.bias), "s"(gp.aux), "s"(gp.C), "s"(gp.C2), "s"(gp.row_mask));
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  const BlockCoords b = block_coords<CT>(d);
+  const BlockCoords b = block_coords<CT>(d, ti);
   if (!b.active) return;
   if (b.g != gspec) gp.load(d, b.g);   // uniform; split-K / batched / K-concatenated launches
   const long offA = (long)b.z * d.strideA, offB = (long)b.z * d.strideB;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(NT) void gemm_fast_kernel(const pq3d_kdesc d) {
   // fused bias gradient (weight-gradient GEMMs): colsum[m] += sum_k A(m,k) by the blocks of the first n-tile column, as one
   // extra MFMA per A fragment against an all-ones fragment (mma_tile); saves one column-sum launch per linear layer
   float* cs_out = nullptr;
-  if constexpr (TRA) { if (blockIdx.y == 0) cs_out = d.gp[b.g].colsum; }
+  if constexpr (TRA) { if (ti.y == 0) cs_out = d.gp[b.g].colsum; }
   f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
   const bool do_cs = cs_out != nullptr && wn == 0;   // wave-uniform
   issue(sa0, sb0);
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(NT) void gemm_slow_kernel(const pq3d_kdesc d) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  const BlockCoords b = block_coords<CT>(d);
+  const BlockCoords b = block_coords<CT>(d, tile_index(0));
   if (!b.active) return;
   const long offA = (long)b.z * d.strideA, offB = (long)b.z * d.strideB;
   const int nk = b.kt1 - b.kt0, nit = nk * b.ng;
@@ -615,6 +616,7 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
                     fast_ok<bf16_t>(d, a2, b2);
     if (ok) {
       dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (d.groups / kc) * d.batch);
+      kd.xcd_order = xcd_order_for((long)grid.x * grid.y * grid.z, (long)d.N * d.K * 4 * kc, shared_a_run(d));
       if (a2) LAUNCH(gemm_fast_kernel<bf16_t, float, float, false, false, true, false, true>);
       else LAUNCH(gemm_fast_kernel<bf16_t, float, float, false, false, false, false, true>);
       PQ_LAUNCH_CHECK();
@@ -657,6 +659,9 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
     return 0;
   }
   dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (d.groups / kc) * d.batch * d.splitk);
+  // XCD-aware tile order (common.h; read by the fast kernels only).  Weight-gradient layouts (transA): super-rows of 8.
+  kd.xcd_order = xcd_order_for((long)grid.x * grid.y * grid.z,
+                               d.transA ? (1L << 40) : (long)d.N * d.K * (d.dtB == PQ3D_F32 ? 4 : 2) * kc, shared_a_run(d));
   bool a2 = false, b2 = false;
   if (d.ct == PQ3D_BF16) {
     if (fast_ok<bf16_t>(d, a2, b2)) {

@@ -12,6 +12,8 @@
 // (one accumulator per output, 32-wide MFMA steps in sequence) is gemm.hip's, so the NT kernel produces the same bits.
 // K % 64 == 0, N % 128 == 0 (M % 128 == 0 for TT).  Bound: L2 -> LDS traffic / HBM write of C; algorithmic bytes per
 // group: (M + N) * K * 2 + M * N * {2, 4}.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #ifndef PQ3D_NO_KARG_PIN
   // kernel-argument prefetch (see gemm_fast_kernel): one batch of scalar loads for every descriptor scalar used below
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(d.act),
-               "s"(d.act_grad), "s"(d.groups));
+               "s"(d.act_grad), "s"(d.groups), "s"(d.xcd_order));
 #endif
   constexpr int MI = TMT / 32, NJ = TNT / 32;                // 16 x 16 MFMA tiles per wave: MI x NJ
   constexpr int LDCT = TNT + 8, LDFT = TNT + 4, HR = TMT / 2;   // bf16 / fp32 C staging rows; rows per fp32 half
@@ -50,7 +52,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * (TMT / 2), wn = (wave & 1) * (TNT / 2);
   const int kc = d.kconcat > 0 ? d.kconcat : 1;   // kc consecutive groups are concatenated along K into one output
-  const int g = blockIdx.z * kc, m0 = blockIdx.x * TMT, n0 = blockIdx.y * TNT;
+  const TileIdx ti = tile_index(d.xcd_order);   // hardware order, or the XCD-aware order of a big launch (common.h)
+  const int g = ti.z * kc, m0 = ti.x * TMT, n0 = ti.y * TNT;
   const bf16_t* A = (const bf16_t*)d.gp[g].A;
   const bf16_t* B = (const bf16_t*)d.gp[g].B;
   const int nk1 = d.K / TK, nkt = nk1 * kc;
@@ -193,13 +196,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #ifndef PQ3D_NO_KARG_PIN
   // kernel-argument prefetch (see gemm_fast_kernel): one batch of scalar loads for every descriptor scalar used below
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(d.act),
-               "s"(d.act_grad), "s"(d.groups));
+               "s"(d.act_grad), "s"(d.groups), "s"(d.xcd_order));
 #endif
   __shared__ __attribute__((aligned(16))) bf16_t As[TK * LDM];
   __shared__ __attribute__((aligned(16))) bf16_t Bs[TK * LDM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int split = blockIdx.z % nsplit, g = blockIdx.z / nsplit, m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const TileIdx ti = tile_index(d.xcd_order);   // XCD-aware: the M/128 x N/128 tiles of one (group, k-split) share an L2
+  const int split = ti.z % nsplit, g = ti.z / nsplit, m0 = ti.x * TM, n0 = ti.y * TN;
   const int nkt = d.K / TK, per = (nkt + nsplit - 1) / nsplit;
   const int kt0 = split * per, kt1 = min(nkt, kt0 + per);
   if (kt0 >= kt1) return;
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float* cs_out = blockIdx.y == 0 ? d.gp[g].colsum : nullptr;   // uniform per block
+  float* cs_out = ti.y == 0 ? d.gp[g].colsum : nullptr;   // uniform per block
   // fused bias gradient colsum[m] = sum_k A[k][m]: one extra MFMA per A fragment against an all-ones B fragment (every
   // column of the result holds the column sums; the matrix pipe is idle 85 % of the time here) instead of 64 scalar LDS
   // reads per k slice on two of the four waves -- those waves set the pace of half the workgroups
@@ -299,7 +303,17 @@ bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStrea
   if (nsplit > nkt / 4) nsplit = nkt / 4;
   if (nsplit < 1) nsplit = 1;
   if (tiles * nsplit < 256) return false;   // too small to fill the chip: the 64x64 tile spreads it better
-  hipLaunchKernelGGL(gemm_tt128_kernel, dim3(d.M / TM, d.N / TN, d.groups * nsplit), dim3(256), 0, s, kd, nsplit);
+  pq3d_kdesc k = kd;
+  // the (M/128) x (N/128) tiles of one (group, k-split) read the same 2 operand slabs: on one L2 whenever there are enough
+  // of them to matter, co-resident or not (hardware order deals them to 8 L2s -- 5.7 x the bytes at 6 x 6 tiles)
+  // The (M/128) x (N/128) tiles of one (group, k-split) read the same 2 operand slabs: on one L2 whenever there are enough of
+  // them to matter, co-resident or not (hardware order deals them to 8 L2s: 5.7 x the bytes at 6 x 6 tiles, measured 3507 ->
+  // 1912 MB per launch at the shipped stage-2 shape).  2 x 2 tiles (config 2) stay in hardware order, which by the
+  // arithmetic of x + 2 y + 4 z mod 8 already keeps one memory's 8 groups of a tile position on one L2 (158 MB; 250 MB
+  // when walked in XCD order with the groups as runs -- measured, rejected).
+  const long per_plane = (long)(d.M / TM) * (d.N / TN);
+  k.xcd_order = xcd_order_for(per_plane >= 9 ? PQ3D_XCD_MIN : 0, 1L << 40, 1);
+  hipLaunchKernelGGL(gemm_tt128_kernel, dim3(d.M / TM, d.N / TN, d.groups * nsplit), dim3(256), 0, s, k, nsplit);
   return true;
 }
 
@@ -327,14 +341,26 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStrea
   const long tiles = (long)((d.M + TM - 1) / TM) * (d.N / TN) * (d.groups / kc);
   const long nkt = (long)(d.K / TK) * kc;
   if (tiles < 512 && !(tiles >= 256 && nkt >= 16)) return false;   // (128 tiles x 48 k-tiles measured equal to the 64x64 tile)
+  pq3d_kdesc k = kd;
+  // Groups that read one row operand (one memory's tokens against the K / V weights of every layer) become one run of
+  // z-planes (common.h): the group order of a plain launch carries no meaning, so sort by the A pointer first.
+  int run = 1;
+  if (kc == 1 && d.groups > 1) {
+    std::stable_sort(k.gp, k.gp + d.groups, [](const pq3d_kgroup& a, const pq3d_kgroup& b) { return (uintptr_t)a.A < (uintptr_t)b.A; });
+    const void* ap[PQ3D_MAX_GROUPS];
+    for (int g = 0; g < d.groups; ++g) ap[g] = k.gp[g].A;
+    run = uniform_run(ap, d.groups);
+  }
   if (tiles < 768) {   // fewer than 3 workgroups per CU: 128 x 64 tiles (see the kernel's header)
     const dim3 grid((d.M + TM - 1) / TM, d.N / 64, d.groups / kc);
-    if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 64>), grid, dim3(256), 0, s, kd);
-    else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 64>), grid, dim3(256), 0, s, kd);
+    k.xcd_order = xcd_order_for(2 * tiles, (long)d.N * d.K * 2 * kc, run);
+    if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 64>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 64>), grid, dim3(256), 0, s, k);
     return true;
   }
   const dim3 grid((d.M + TM - 1) / TM, d.N / TN, d.groups / kc);
-  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 128>), grid, dim3(256), 0, s, kd);
-  else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 128>), grid, dim3(256), 0, s, kd);
+  k.xcd_order = xcd_order_for(tiles, (long)d.N * d.K * 2 * kc, run);
+  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 128>), grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 128>), grid, dim3(256), 0, s, k);
   return true;
 }

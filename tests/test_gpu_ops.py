@@ -889,3 +889,59 @@ def test_linear_with_dropout_and_residual_in_the_epilogue_equals_the_separate_op
             tol = 1e-5 if ct == F32 else 2e-2
             torch.testing.assert_close(a, b, rtol=tol, atol=tol * float(b.abs().max()), msg=lambda m: f"{act} {with_res} {name}: {m}")
     assert R  # (shape constants above are for the reader)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["x3_nt", "f32_nt", "bf16_nn_dx", "nt128", "tt128"])
+def test_gemm_xcd_aware_tile_order_of_big_launches(kind):
+    """Launches of >= 2048 workgroups (and 128-tile weight gradients with >= 9 tiles per k-split) walk their tiles in the
+    XCD-aware order (csrc/common.h tile_index: every XCD gets a contiguous run of logical tiles, sharers adjacent).  The
+    order is a permutation of the tiles: every output element must be written exactly once, also when the workgroup count
+    is not a multiple of 8 and the last row tile is ragged.  Compared with float64 products of the same operands."""
+    if kind in ("x3_nt", "f32_nt"):
+        M, N, K, G = 10300, 768, 96, 3      # 161 x 12 x 3 = 5796 workgroups (= 4 mod 8), ragged last row tile
+        A = [rnd(M, K, seed=0).to(DEV)] * G if kind == "x3_nt" else [rnd(M, K, seed=g).to(DEV) for g in range(G)]   # q / k / v of one input
+        W = [(rnd(N, K, seed=10 + g) * 0.1).to(DEV) for g in range(G)]
+        b = [rnd(N, seed=20 + g).to(DEV) for g in range(G)]
+        C = torch.full((G, M, N), 7.0, device=DEV)
+        L.gemm(M=M, N=N, K=K, A=A, B=W, bias=b, Cs=[C[g] for g in range(G)], ct=L.BF16X3 if kind == "x3_nt" else F32,
+               lda=K, ldb=K, ldc=N)
+        for g in range(G):
+            ref = (A[g].double() @ W[g].double().T + b[g].double())
+            assert float((C[g].double() - ref).abs().max()) / float(ref.abs().max()) < (1e-5 if kind == "x3_nt" else 3e-6), g
+    elif kind == "bf16_nn_dx":
+        M, N, K, G = 10300, 768, 128, 3     # dX = dY W (B not transposed in memory: transB)
+        dY = [rnd(M, K, seed=g).to(DEV) for g in range(G)]
+        W = [(rnd(K, N, seed=10 + g) * 0.1).to(DEV) for g in range(G)]
+        C = torch.full((G, M, N), 7.0, device=DEV)
+        L.gemm(M=M, N=N, K=K, A=dY, B=W, Cs=[C[g] for g in range(G)], ct=BF16, lda=K, ldb=N, ldc=N, transB=True)
+        for g in range(G):
+            ref = dY[g].bfloat16().double() @ W[g].bfloat16().double()
+            assert float((C[g].double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5, g
+    elif kind == "nt128":
+        M, N, K, G = 8200, 768, 128, 6      # 65 x 6 x 6 = 2340 tiles of 128 x 128 (= 4 mod 8)
+        A2 = [rnd(M, K, seed=g).to(DEV).bfloat16() for g in range(2)]
+        A = [A2[g % 2] for g in range(G)]       # 3 groups per row operand, interleaved: sorted into runs, each walked as one plane
+        W = [(rnd(N, K, seed=100 + g) * 0.1).to(DEV) for g in range(G)]
+        b = [rnd(N, seed=200 + g).to(DEV) for g in range(G)]
+        C_new = torch.zeros(G, M, N, dtype=torch.bfloat16, device=DEV)
+        C_old = torch.zeros_like(C_new)
+        L.gemm(M=M, N=N, K=K, A=A, B=[w.bfloat16() for w in W], bias=b, Cs=[C_new[g] for g in range(G)], ct=BF16, lda=K, ldb=K, ldc=N)
+        L.gemm(M=M, N=N, K=K, A=A, B=W, bias=b, Cs=[C_old[g] for g in range(G)], ct=BF16, lda=K, ldb=K, ldc=N)   # 64 x 64 tiles
+        assert torch.equal(C_new, C_old)
+        for g in (0, G - 1):
+            close(C_new[g].float(), A[g].float() @ W[g].bfloat16().float().T + b[g], BF16, "gemm128 xcd order")
+    else:
+        R, M, N, G = 4096, 768, 768, 4      # 6 x 6 tiles per (group, k-split); pairs of groups share the column operand
+        gs = [rnd(R, M, seed=g).to(DEV).bfloat16() for g in range(G)]
+        x2 = [rnd(R, N, seed=50 + g).to(DEV).bfloat16() for g in range(2)]
+        xs = [x2[g // 2] for g in range(G)]
+        dW = torch.full((G, M, N), 123.0, device=DEV)
+        cb = torch.full((G, M), -5.0, device=DEV)
+        L.gemm(M=M, N=N, K=R, A=gs, B=xs, Cs=[dW[g] for g in range(G)], ct=BF16, lda=M, ldb=N, ldc=N, transA=True, transB=True,
+               splitk=2, colsum=[cb[g] for g in range(G)])
+        for g in range(G):
+            ref = gs[g].double().T @ xs[g].double()
+            assert float((dW[g].double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5, g
+            refb = gs[g].double().sum(0)
+            assert float((cb[g].double() - refb).abs().max()) / float(refb.abs().max()) < 2e-5
