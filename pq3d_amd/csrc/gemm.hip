@@ -24,6 +24,7 @@ extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol
 
 bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
 bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
+bool pq3d_gemm_x3_128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, bool a2);   // gemm_x3.hip
 bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err);   // gemm_wk.hip
 bool pq3d_gemm_wktt_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err);   // gemm_wktt.hip
 
@@ -615,6 +616,10 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
     const bool ok = !d.transA && !d.transB && d.dtA == PQ3D_F32 && d.dtB == PQ3D_F32 && d.splitk == 1 && !any_cs &&
                     fast_ok<bf16_t>(d, a2, b2);
     if (ok) {
+      if (pq3d_gemm_x3_128_try(d, kd, s, a2)) {   // big-M launches: 128 x 128 tiles (gemm_x3.hip), same bits
+        PQ_LAUNCH_CHECK();
+        return 0;
+      }
       dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN, (d.groups / kc) * d.batch);
       kd.xcd_order = xcd_order_for((long)grid.x * grid.y * grid.z, (long)d.N * d.K * 4 * kc, shared_a_run(d));
       if (a2) LAUNCH(gemm_fast_kernel<bf16_t, float, float, false, false, true, false, true>);

@@ -945,3 +945,38 @@ def test_gemm_xcd_aware_tile_order_of_big_launches(kind):
             assert float((dW[g].double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5, g
             refb = gs[g].double().sum(0)
             assert float((cb[g].double() - refb).abs().max()) / float(refb.abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("a2,act,shared", [(False, None, True), (True, None, False), (False, "gelu", False), (True, "relu", True)])
+def test_gemm_split_bf16_128_tile_matches_the_64_tile_kernels_bit_for_bit(a2, act, shared):
+    """Split-bf16 NT products with >= 512 tiles of 128 x 128 take gemm_x3.hip (the shipped stage-2 decoder's projections and
+    FFN at M = 10240): same hi / lo split, same k order, same three-term order per accumulator as the 64 x 64 and whole-K
+    kernels -> identical bits to the same product launched in 1024-row pieces (which stay on those kernels); also against
+    float64.  Ragged last row tile, optional addend (x + pos), bias, activation, second (pre-activation) output."""
+    M, N, K, G = 10300, 768, 256, 3
+    A = [rnd(M, K, seed=0).to(DEV)] * G if shared else [rnd(M, K, seed=g).to(DEV) for g in range(G)]
+    P = [rnd(M, K, seed=30).to(DEV)] * G if a2 else None
+    W = [(rnd(N, K, seed=10 + g) * 0.1).to(DEV) for g in range(G)]
+    b = [rnd(N, seed=20 + g).to(DEV) for g in range(G)]
+    C = torch.full((G, M, N), 7.0, device=DEV)
+    C2 = torch.full((G, M, N), 7.0, device=DEV) if act else None
+    Cp = torch.full((G, M, N), 7.0, device=DEV)
+    Cp2 = torch.full((G, M, N), 7.0, device=DEV) if act else None
+    L.gemm(M=M, N=N, K=K, A=A, A2=P, B=W, bias=b, Cs=[C[g] for g in range(G)], C2=[C2[g] for g in range(G)] if act else None,
+           ct=L.BF16X3, lda=K, ldb=K, ldc=N, act=act)
+    for r0 in range(0, M, 1024):
+        r1 = min(M, r0 + 1024)
+        L.gemm(M=r1 - r0, N=N, K=K, A=[a[r0:r1] for a in A], A2=[p[r0:r1] for p in P] if a2 else None, B=W, bias=b,
+               Cs=[Cp[g, r0:r1] for g in range(G)], C2=[Cp2[g, r0:r1] for g in range(G)] if act else None, ct=L.BF16X3,
+               lda=K, ldb=K, ldc=N, act=act)
+    assert torch.equal(C, Cp)
+    if act:
+        assert torch.equal(C2, Cp2)
+    for g in range(G):
+        x = A[g].double() + (P[g].double() if a2 else 0)
+        pre = x @ W[g].double().T + b[g].double()
+        ref = pre if act is None else (torch.relu(pre) if act == "relu" else torch.nn.functional.gelu(pre))
+        assert float((C[g].double() - ref).abs().max()) / float(ref.abs().max()) < 1e-5, g
+        if act:
+            assert float((C2[g].double() - pre).abs().max()) / float(pre.abs().max()) < 1e-5, g
