@@ -24,7 +24,7 @@ extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol
 
 bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
 bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
-bool pq3d_gemm_x3_128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, bool a2);   // gemm_x3.hip
+bool pq3d_gemm_cv128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm_cv128.hip
 bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err);   // gemm_wk.hip
 bool pq3d_gemm_wktt_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err);   // gemm_wktt.hip
 
@@ -616,7 +616,7 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
     const bool ok = !d.transA && !d.transB && d.dtA == PQ3D_F32 && d.dtB == PQ3D_F32 && d.splitk == 1 && !any_cs &&
                     fast_ok<bf16_t>(d, a2, b2);
     if (ok) {
-      if (pq3d_gemm_x3_128_try(d, kd, s, a2)) {   // big-M launches: 128 x 128 tiles (gemm_x3.hip), same bits
+      if (pq3d_gemm_cv128_try(d, kd, s)) {   // big-M launches: 128 x 128 tiles (gemm_cv128.hip), same bits
         PQ_LAUNCH_CHECK();
         return 0;
       }
@@ -630,6 +630,10 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
     d.ct = kd.ct = PQ3D_F32;
   }
   if (pq3d_gemm_nt128_try(d, kd, s)) {   // plain big bf16 NT products: 128x128 tiles (gemm128.hip), same bits
+    PQ_LAUNCH_CHECK();
+    return 0;
+  }
+  if (!any_cs && pq3d_gemm_cv128_try(d, kd, s)) {   // big products with fp32-stored operands: 128x128 tiles (gemm_cv128.hip)
     PQ_LAUNCH_CHECK();
     return 0;
   }

@@ -950,7 +950,7 @@ def test_gemm_xcd_aware_tile_order_of_big_launches(kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("a2,act,shared", [(False, None, True), (True, None, False), (False, "gelu", False), (True, "relu", True)])
 def test_gemm_split_bf16_128_tile_matches_the_64_tile_kernels_bit_for_bit(a2, act, shared):
-    """Split-bf16 NT products with >= 512 tiles of 128 x 128 take gemm_x3.hip (the shipped stage-2 decoder's projections and
+    """Split-bf16 NT products with >= 512 tiles of 128 x 128 take gemm_cv128.hip (the shipped stage-2 decoder's projections and
     FFN at M = 10240): same hi / lo split, same k order, same three-term order per accumulator as the 64 x 64 and whole-K
     kernels -> identical bits to the same product launched in 1024-row pieces (which stay on those kernels); also against
     float64.  Ragged last row tile, optional addend (x + pos), bias, activation, second (pre-activation) output."""
@@ -980,3 +980,82 @@ def test_gemm_split_bf16_128_tile_matches_the_64_tile_kernels_bit_for_bit(a2, ac
         assert float((C[g].double() - ref).abs().max()) / float(ref.abs().max()) < 1e-5, g
         if act:
             assert float((C2[g].double() - pre).abs().max()) / float(pre.abs().max()) < 1e-5, g
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["nt_f32", "nn_f32_gelu_grad", "nn_bf16_add_c2", "nn_kconcat", "nt_bf16_relu"])
+def test_gemm_converting_128_tile_matches_the_64_tile_kernels_bit_for_bit(kind):
+    """bf16-compute products with fp32-stored operands and >= 256 / 512 tiles of 128 x 128 take gemm_cv128.hip (input
+    gradients dX = dY W and the K-concatenated sums of the shipped stage-2 decoder at M = 10240): same rounding points and
+    k order as the 64 x 64 kernels -> identical bits to the same product launched in 1024-row pieces, with the fused
+    epilogue options the decoder's backward uses (activation gradient, "+ aux", second output, dropout-free)."""
+    M, N, K = 10300, 768, 768
+    nn = kind.startswith("nn")
+    G = 3
+    kc = 3 if kind == "nn_kconcat" else 0
+    adt = torch.bfloat16 if "bf16" in kind else torch.float32
+    A = [rnd(M, K, seed=g).to(DEV).to(adt) for g in range(G)]
+    W = [(rnd(K, N, seed=10 + g) * 0.1).to(DEV) for g in range(G)] if nn else [(rnd(N, K, seed=10 + g) * 0.1).to(DEV) for g in range(G)]
+    outs = 1 if kc else G
+    aux = [rnd(M, N, seed=40 + o).to(DEV) for o in range(outs)] if kind != "nt_f32" else None
+    bias = [rnd(N, seed=20 + g).to(DEV) for g in range(G)] if not nn else None
+    kw = dict(ct=BF16, lda=K, ldb=N if nn else K, ldc=N, transB=nn, kconcat=kc)
+    if kind == "nn_f32_gelu_grad":
+        kw.update(act_grad="gelu")
+    elif kind in ("nn_bf16_add_c2", "nn_kconcat"):
+        kw.update(act_grad="add")
+    elif kind == "nt_bf16_relu":
+        kw.update(act="relu")
+        aux = None
+    pad = lambda ts: [t for o in range(outs) for t in [ts[o]] + [None] * (kc - 1)] if kc else ts
+
+    def run(r0, r1, C, C2):
+        L.gemm(M=r1 - r0, N=N, K=K, A=[a[r0:r1] for a in A], B=W, bias=bias,
+               Cs=pad([C[o, r0:r1] for o in range(outs)]), C2=pad([C2[o, r0:r1] for o in range(outs)]) if C2 is not None else None,
+               aux=pad([x[r0:r1] for x in aux]) if aux is not None else None, **kw)
+    C = torch.full((outs, M, N), 7.0, device=DEV)
+    Cp = torch.full((outs, M, N), 7.0, device=DEV)
+    C2 = torch.full((outs, M, N), 7.0, device=DEV) if kind == "nn_bf16_add_c2" else None
+    Cp2 = torch.full((outs, M, N), 7.0, device=DEV) if C2 is not None else None
+    run(0, M, C, C2)
+    for r0 in range(0, M, 1024):
+        run(r0, min(M, r0 + 1024), Cp, Cp2)
+    assert torch.equal(C, Cp)
+    if C2 is not None:
+        assert torch.equal(C2, Cp2)
+    for o in range(outs):
+        gs = range(o * kc, (o + 1) * kc) if kc else [o]
+        pre = sum(A[g].bfloat16().double() @ (W[g].bfloat16().double() if nn else W[g].bfloat16().double().T) for g in gs)
+        if bias is not None:
+            pre = pre + bias[o].double()
+        if C2 is not None:
+            assert float((C2[o].double() - pre).abs().max()) / float(pre.abs().max()) < 2e-5
+        if kind == "nn_f32_gelu_grad":
+            x = aux[o].double()
+            ref = pre * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-x * x / 2) / (2 * torch.pi) ** 0.5)
+        elif kw.get("act_grad") == "add":
+            ref = pre + aux[o].double()
+        elif kw.get("act") == "relu":
+            ref = torch.relu(pre)
+        else:
+            ref = pre
+        assert float((C[o].double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5, o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("acc", [False, True])
+def test_gemm_split_k_request_on_a_big_launch_is_one_deterministic_pass(acc):
+    """A split-K input-gradient product with enough 128 x 128 tiles (the FFN's dx += dh W1 at M = 10240) is served by
+    gemm_cv128.hip as one pass -- C = / += product through the epilogue, no atomics: two runs give identical bits."""
+    M, N, K = 10240, 768, 2048
+    A = rnd(M, K, seed=1).to(DEV)
+    W = (rnd(K, N, seed=2) * 0.05).to(DEV)
+    base = rnd(M, N, seed=3).to(DEV)
+    outs = []
+    for _ in range(2):
+        C = base.clone() if acc else torch.full((M, N), 9.0, device=DEV)
+        L.gemm(M=M, N=N, K=K, A=[A], B=[W], Cs=[C], ct=BF16, lda=K, ldb=N, ldc=N, transB=True, splitk=4, accumulate=acc)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    ref = A.bfloat16().double() @ W.bfloat16().double() + (base.double() if acc else 0)
+    assert float((outs[0].double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5
