@@ -606,6 +606,10 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
     if bwd and ks > 2 and ct == BF16 and bias is None and 128 < Lq <= 256 and dm // H == 32 and \
             B * H * (ks // 2) <= 256 and Lk // (ks // 2) >= 512:
         ks //= 2      # the 8-wave resident backward (two query halves, config 4): half the key slices, one workgroup per CU
+    if bwd and ct == BF16 and bias is None and Lq <= 128 and dm // H == 64 and nkb >= 16 and B * H * ks < 512:
+        # d_h = 64 resident backward (4 waves per workgroup, the shipped stage-1 decoder: 12 x 12 (scene, head) pairs,
+        # 2048 keys): at least two workgroups per CU -- measured 2 / 4 / 8 / 16 slices: 15.12 / 14.82 / 14.97 / 15.45 ms
+        ks = min(8, -(-512 // (B * H)))
     if ks > 1:
         ws = _empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
         d.ksplit, d.ws = ks, L.ptr(ws)
