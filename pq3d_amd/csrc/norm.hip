@@ -1,8 +1,12 @@
 // Residual-add + LayerNorm (merged over M branches), forward and backward.  HBM-bound: one wave per row at a time,
 // the row lives in registers (d <= 2048 -> <= 32 values per lane), DPP reductions for the statistics, fp32 math
 // throughout.  Algorithmic bytes per row: (1 + M) reads + 1 write of d elements.
-// Column ownership: VEC (d == 64 * PL, PL >= 4, 16-byte aligned operands): lane owns PL CONSECUTIVE columns, every row
-// access is a 16-byte load/store; otherwise lane owns columns lane + 64 j (4-byte accesses, any d).
+// Column ownership: VEC (d == 64 * PL, PL a multiple of 4, 16-byte aligned operands): lane owns PL / 4 pieces of 4
+// consecutive columns, piece k at columns 256 k + 4 lane -- every row access is a 16-byte load/store and every wave
+// instruction covers 1 KB of consecutive bytes (round 4; before, a lane owned PL CONSECUTIVE columns: for PL > 4 the
+// 16-byte pieces of one instruction sat PL * 4 bytes apart -- 3 x the cache lines per instruction at d = 768, and the
+// 3-branch backward's dx atomics scattered the same way: 0.92 ms per launch at R = 10240); otherwise lane owns columns
+// lane + 64 j (4-byte accesses, any d).
 // Large R: waves walk rows with a grid stride and keep the NEXT row's loads in flight.
 #include <cstdlib>
 
@@ -15,20 +19,20 @@ constexpr int WPB = 4;     // waves (rows in flight) per block
 
 struct RowStats { float mean, rstd; };
 
-template <int PL, bool VEC> PQ_DEV int colof(int lane, int j) { return VEC ? lane * PL + j : lane + 64 * j; }
+template <int PL, bool VEC> PQ_DEV int colof(int lane, int j) { return VEC ? (j >> 2) * 256 + lane * 4 + (j & 3) : lane + 64 * j; }
 
 template <int PL, bool VEC>
 PQ_DEV void load_row(const void* p, int dt, long base, int lane, int d, float (&v)[PL]) {
   if constexpr (VEC) {
     if (dt == PQ3D_F32) {
-      const float4* q = (const float4*)((const float*)p + base + lane * PL);
+      const float4* q = (const float4*)((const float*)p + base + lane * 4);
 #pragma unroll
-      for (int k = 0; k < PL / 4; ++k) { const float4 t = q[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+      for (int k = 0; k < PL / 4; ++k) { const float4 t = q[64 * k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
     } else {
-      const uint2* q = (const uint2*)((const bf16_t*)p + base + lane * PL);
+      const uint2* q = (const uint2*)((const bf16_t*)p + base + lane * 4);
 #pragma unroll
       for (int k = 0; k < PL / 4; ++k) {
-        const uint2 t = q[k];
+        const uint2 t = q[64 * k];
         v[4 * k] = __uint_as_float(t.x << 16); v[4 * k + 1] = __uint_as_float(t.x & 0xffff0000u);
         v[4 * k + 2] = __uint_as_float(t.y << 16); v[4 * k + 3] = __uint_as_float(t.y & 0xffff0000u);
       }
@@ -45,14 +49,14 @@ template <int PL, bool VEC>
 PQ_DEV void store_row(void* p, int dt, long base, int lane, int d, const float (&v)[PL]) {
   if constexpr (VEC) {
     if (dt == PQ3D_F32) {
-      float4* q = (float4*)((float*)p + base + lane * PL);
+      float4* q = (float4*)((float*)p + base + lane * 4);
 #pragma unroll
-      for (int k = 0; k < PL / 4; ++k) q[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+      for (int k = 0; k < PL / 4; ++k) q[64 * k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
     } else {
-      uint2* q = (uint2*)((bf16_t*)p + base + lane * PL);
+      uint2* q = (uint2*)((bf16_t*)p + base + lane * 4);
 #pragma unroll
       for (int k = 0; k < PL / 4; ++k)
-        q[k] = make_uint2((unsigned)f2bf(v[4 * k]) | ((unsigned)f2bf(v[4 * k + 1]) << 16),
+        q[64 * k] = make_uint2((unsigned)f2bf(v[4 * k]) | ((unsigned)f2bf(v[4 * k + 1]) << 16),
                           (unsigned)f2bf(v[4 * k + 2]) | ((unsigned)f2bf(v[4 * k + 3]) << 16));
     }
   } else {
@@ -309,9 +313,12 @@ int check_ln(const pq3d_ln_desc& d, bool bwd) {
 
 // VEC: whole rows in 16-byte pieces (d == 64 * PL with PL a multiple of 4, every operand 16-byte aligned)
 bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd) {
-  // 64 * PL with PL in {4, 8, 16, 32}.  (d = 768 as 12-piece vector rows was tried in round 4: the 3-branch backward at
-  // R = 10240 went from ~0.1 ms to 0.92 ms per launch -- left on the 4-byte path, 3.2 TB/s on the single-branch calls)
-  if (d.d != 256 && d.d != 512 && d.d != 1024 && d.d != 2048) return false;
+  // 64 * PL with PL in {4, 8, 12, 16, 32}
+  if (d.d != 256 && d.d != 512 && d.d != 768 && d.d != 1024 && d.d != 2048) return false;
+  // the merged-branch backward sums dx with one atomic per element: a lane's 4-column pieces make every atomic instruction
+  // touch 64 addresses 16 bytes apart (4 x the cache lines of the lane + 64 j layout).  Fine at d = 256 (measured, config
+  // 2), 0.32 ms instead of 0.1 ms per launch at d = 768, R = 10240: wide rows keep the 4-byte layout there.
+  if (bwd && d.d > 256 && d.M > 1 && d.dx && !d.independent && !d.sum_branches) return false;
   auto al = [](const void* p, int dt) { return ((uintptr_t)p & (dt == PQ3D_F32 ? 15 : 7)) == 0; };
   bool ok = al(d.x, d.dt_x);
   const int nm = d.M;
@@ -331,6 +338,7 @@ bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd) {
   else if (d.d <= 128) { LAUNCH(2, false); }                                           \
   else if (d.d <= 256) { if (vec) { LAUNCH(4, true); } else { LAUNCH(4, false); } }    \
   else if (d.d <= 512) { if (vec) { LAUNCH(8, true); } else { LAUNCH(8, false); } }    \
+  else if (d.d == 768 && vec) { LAUNCH(12, true); }                                     \
   else if (d.d <= 1024) { if (vec) { LAUNCH(16, true); } else { LAUNCH(16, false); } } \
   else { if (vec) { LAUNCH(32, true); } else { LAUNCH(32, false); } }
 
