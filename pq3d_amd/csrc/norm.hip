@@ -291,6 +291,113 @@ __global__ __launch_bounds__(NW * 64) void add_ln_bwd_kernel(const pq3d_ln_desc 
   }
 }
 
+// Merged-branch backward for the big streaming calls (the cross-attention sublayer of a large batch: M = 3 memories, R in the
+// thousands): ONE wave handles a row for all MB branches -- x and the upstream gradient are read once, dx = sum_m g_m is
+// formed in registers and stored once.  The one-branch-per-block kernel above sums dx with one atomic per element per
+// branch onto a zero-filled buffer (R d x (4 + 3 x 8) bytes of extra traffic; 106 us per launch at R = 10240, d = 768).
+// Same arithmetic per (row, branch); the parameter-gradient partials are reduced per branch as above.
+template <int PL, bool VEC, int NW, int MB>
+__global__ __launch_bounds__(NW * 64) void add_ln_bwd_merged_kernel(const pq3d_ln_desc d) {
+  __shared__ float red[2][NW][64 * PL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long wave_id = (long)blockIdx.x * NW + wave, nwaves = (long)gridDim.x * NW;
+  const long nscene = d.coef ? d.R / d.rows_per_scene : 1;
+  float dg[MB][PL], db[MB][PL];   // (gamma is re-read per row: L1-resident, and 2 MB PL accumulators already fill the budget)
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+#pragma unroll
+    for (int j = 0; j < PL; ++j) { dg[m][j] = 0.f; db[m][j] = 0.f; }
+  }
+  const bool drop = drop_on(d.drop);
+  for (long row = wave_id; row < d.R; row += nwaves) {
+    const long base = row * d.d;
+    float xv[PL], dyr[PL], gsum[PL];
+    if (d.x) load_row<PL, VEC>(d.x, d.dt_x, base, lane, d.d, xv);
+    else {
+#pragma unroll
+      for (int j = 0; j < PL; ++j) xv[j] = 0.f;
+    }
+    load_row<PL, VEC>(d.dy, PQ3D_F32, base, lane, d.d, dyr);
+    if (d.dy2) {   // upstream gradient in up to three addends: (dy + dy2) + dy3
+      float t[PL];
+      load_row<PL, VEC>(d.dy2, PQ3D_F32, base, lane, d.d, t);
+#pragma unroll
+      for (int j = 0; j < PL; ++j) dyr[j] += t[j];
+      if (d.dy3) {
+        load_row<PL, VEC>(d.dy3, PQ3D_F32, base, lane, d.d, t);
+#pragma unroll
+        for (int j = 0; j < PL; ++j) dyr[j] += t[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PL; ++j) gsum[j] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      float ov[PL], gam[PL];
+      load_row<PL, VEC>(d.o[m], d.dt_o, base, lane, d.d, ov);
+      load_row<PL, VEC>(d.gamma[m], PQ3D_F32, 0, lane, d.d, gam);
+      unsigned keep = 0xffffffffu;
+      DropState dst;
+      if (drop) {
+        dst = drop_init(d.drop, m, d.d);
+        keep = 0;
+#pragma unroll
+        for (int j = 0; j < PL; ++j) {
+          const bool k = drop_keep(dst, (uint32_t)row, (uint32_t)colof<PL, VEC>(lane, j));
+          keep |= (unsigned)k << j;
+          ov[j] = k ? ov[j] * dst.scale : 0.f;
+        }
+      }
+      const float mean = d.mean[(long)m * d.R + row], rstd = d.rstd[(long)m * d.R + row];
+      const float w = d.coef ? d.coef[m * nscene + row / d.rows_per_scene] : 1.f / (float)d.M;
+      float xh[PL], dz[PL];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < PL; ++j) {
+        if (colof<PL, VEC>(lane, j) < d.d) {
+          const float du = w * dyr[j];
+          xh[j] = ((xv[j] + ov[j]) - mean) * rstd;
+          dg[m][j] += du * xh[j];
+          db[m][j] += du;
+          dz[j] = du * gam[j];
+          s1 += dz[j];
+          s2 += dz[j] * xh[j];
+        } else { xh[j] = 0.f; dz[j] = 0.f; }
+      }
+      s1 = wave_sum(s1) / (float)d.d;
+      s2 = wave_sum(s2) / (float)d.d;
+      float go[PL];
+#pragma unroll
+      for (int j = 0; j < PL; ++j) {
+        const float g = rstd * (dz[j] - s1 - xh[j] * s2);
+        gsum[j] += g;
+        go[j] = drop ? (((keep >> j) & 1u) ? g * dst.scale : 0.f) : g;
+      }
+      store_row<PL, VEC>(d.d_o[m], PQ3D_F32, base, lane, d.d, go);
+    }
+    store_row<PL, VEC>(d.dx, PQ3D_F32, base, lane, d.d, gsum);
+  }
+  // block-level reduction of the parameter-gradient partials, one branch after the other (LDS index = column)
+#pragma unroll
+  for (int m = 0; m < MB; ++m) {
+#pragma unroll
+    for (int j = 0; j < PL; ++j) {
+      const int c = colof<PL, VEC>(lane, j);
+      red[0][wave][c] = dg[m][j];
+      red[1][wave][c] = db[m][j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.d; c += NW * 64) {   // ONE atomic per column per block
+      float sg = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; }
+      unsafeAtomicAdd(&d.dgamma[m][c], sg);
+      unsafeAtomicAdd(&d.dbeta[m][c], sb);
+    }
+    __syncthreads();
+  }
+}
+
 int check_ln(const pq3d_ln_desc& d, bool bwd) {
   PQ_CHECK_ARG(d.R >= 0 && d.d >= 1 && d.d <= 64 * MAXPL, "pq3d_add_ln: d must be in [1,2048]");
   PQ_CHECK_ARG(d.M >= 1 && d.M <= PQ3D_MAX_GROUPS, "pq3d_add_ln: M out of range");
@@ -312,13 +419,13 @@ int check_ln(const pq3d_ln_desc& d, bool bwd) {
 }
 
 // VEC: whole rows in 16-byte pieces (d == 64 * PL with PL a multiple of 4, every operand 16-byte aligned)
-bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd) {
+bool ln_vec_ok(const pq3d_ln_desc& d, bool bwd, bool no_dx_atomics = false) {
   // 64 * PL with PL in {4, 8, 12, 16, 32}
   if (d.d != 256 && d.d != 512 && d.d != 768 && d.d != 1024 && d.d != 2048) return false;
   // the merged-branch backward sums dx with one atomic per element: a lane's 4-column pieces make every atomic instruction
   // touch 64 addresses 16 bytes apart (4 x the cache lines of the lane + 64 j layout).  Fine at d = 256 (measured, config
   // 2), 0.32 ms instead of 0.1 ms per launch at d = 768, R = 10240: wide rows keep the 4-byte layout there.
-  if (bwd && d.d > 256 && d.M > 1 && d.dx && !d.independent && !d.sum_branches) return false;
+  if (bwd && !no_dx_atomics && d.d > 256 && d.M > 1 && d.dx && !d.independent && !d.sum_branches) return false;
   auto al = [](const void* p, int dt) { return ((uintptr_t)p & (dt == PQ3D_F32 ? 15 : 7)) == 0; };
   bool ok = al(d.x, d.dt_x);
   const int nm = d.M;
@@ -370,11 +477,14 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   const pq3d_ln_desc d = *dp;
   if (int e = check_ln(d, true)) return e;
   hipStream_t s = (hipStream_t)stream;
+  // big 3-branch merged calls (one dx for all branches): the all-branches-per-wave kernel, no dx atomics, no dx zero-fill
+  const bool merged = d.R >= 4096 && d.M == 3 && d.dx && !d.independent && !d.sum_branches &&
+                      (d.d <= 512 || (d.d == 768 && ln_vec_ok(d, true, true)));   // wider rows would spill the 6 d / 64 accumulators
   {   // zero the atomics targets in one launch (not hipMemsetAsync: see common.h ZeroList)
     ZeroList z;
     for (int m = 0; m < (d.sum_branches ? 1 : d.M) && !d.accumulate; ++m) { z.add(d.dgamma[m], d.d); z.add(d.dbeta[m], d.d); }
     if (z.full()) { if (int e = pq3d_zero_launch(z, s)) return e; z.n = 0; }
-    if (d.R > 0 && d.dx && d.M > 1 && !d.independent && !d.sum_branches && !d.dx_zeroed) z.add(d.dx, (long)d.R * d.d);
+    if (d.R > 0 && d.dx && d.M > 1 && !d.independent && !d.sum_branches && !d.dx_zeroed && !merged) z.add(d.dx, (long)d.R * d.d);
     if (int e = pq3d_zero_launch(z, s)) return e;
   }
   if (d.R == 0) return 0;
@@ -393,6 +503,19 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   dim3 grid((unsigned)nb, d.sum_branches ? 1 : d.M);
+  if (merged) {
+    grid.y = 1;
+    const bool vecm = ln_vec_ok(d, true, true);
+#define BWDM(PLV, V) hipLaunchKernelGGL((add_ln_bwd_merged_kernel<PLV, V, 8, 3>), grid, dim3(512), 0, s, d)
+    if (d.d <= 64) { BWDM(1, false); }
+    else if (d.d <= 128) { BWDM(2, false); }
+    else if (d.d <= 256) { if (vecm) { BWDM(4, true); } else { BWDM(4, false); } }
+    else if (d.d <= 512) { if (vecm) { BWDM(8, true); } else { BWDM(8, false); } }
+    else { BWDM(12, true); }
+#undef BWDM
+    PQ_LAUNCH_CHECK();
+    return 0;
+  }
   const bool vec = ln_vec_ok(d, true);
 #define BWD8(PLV, V) hipLaunchKernelGGL((add_ln_bwd_kernel<PLV, V, 8>), grid, dim3(512), 0, s, d)
 #define BWD4(PLV, V) hipLaunchKernelGGL((add_ln_bwd_kernel<PLV, V, 4>), grid, dim3(256), 0, s, d)

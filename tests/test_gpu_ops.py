@@ -224,6 +224,35 @@ def test_add_layernorm(d, M, with_x, with_coef):
         close(a.grad, r.grad, F32, "grad", atol=5e-5, rtol=5e-5)
 
 
+@pytest.mark.parametrize("d", [256, 512, 768, 100])
+@pytest.mark.parametrize("with_coef", [False, True])
+def test_add_layernorm_big_three_branch_backward_without_dx_atomics(d, with_coef):
+    """R >= 4096 rows, 3 merged branches (the cross-attention sublayer of a large batch): the backward runs every branch of a
+    row in one wave and stores dx once (norm.hip add_ln_bwd_merged_kernel) -- checked against float64 autograd of the same
+    expression, incl. per-scene branch weights."""
+    B, Lq, M = 41, 100, 3     # 4100 rows
+    x = rnd(B, Lq, d)
+    os_ = [rnd(B, Lq, d, seed=5 + m) for m in range(M)]
+    gam = [rnd(d, seed=20 + m).abs() + 0.5 for m in range(M)]
+    bet = [rnd(d, seed=30 + m) for m in range(M)]
+    coef = torch.rand(M, B) + 0.1 if with_coef else None
+    leaves = [t.to(DEV).requires_grad_(True) for t in [x] + os_ + gam + bet]
+    y = ops.add_layernorm(leaves[0], leaves[1:1 + M], leaves[1 + M:1 + 2 * M], leaves[1 + 2 * M:], eps=1e-5,
+                          coef=coef.to(DEV) if with_coef else None)
+    refl = [t.clone().double().requires_grad_(True) for t in [x] + os_ + gam + bet]
+    yr = 0
+    for m in range(M):
+        w = coef[m].double()[:, None, None] if with_coef else 1.0 / M
+        yr = yr + w * O.layer_norm(refl[0] + refl[1 + m], refl[1 + M + m], refl[1 + 2 * M + m])
+    close(y, yr, F32, "y")
+    gy = rnd(B, Lq, d, seed=77)
+    y.backward(gy.to(DEV))
+    yr.backward(gy.double())
+    for i, (a, r) in enumerate(zip(leaves, refl)):
+        err = float((a.grad.double().cpu() - r.grad).abs().max()) / float(r.grad.abs().max())
+        assert err < 2e-5, (i, err)
+
+
 # ---------------------------------------------------------------------------------------------- misc
 def test_pairwise_locs_and_fourier_and_spatial_bias():
     c = torch.rand(2, 23, 3, generator=torch.Generator().manual_seed(11)) * 4
