@@ -477,8 +477,12 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   const pq3d_ln_desc d = *dp;
   if (int e = check_ln(d, true)) return e;
   hipStream_t s = (hipStream_t)stream;
-  // big 3-branch merged calls (one dx for all branches): the all-branches-per-wave kernel, no dx atomics, no dx zero-fill
-  const bool merged = d.R >= 4096 && d.M == 3 && d.dx && !d.independent && !d.sum_branches &&
+  // 3-branch merged calls (one dx for all branches): the all-branches-per-wave kernel, no dx atomics, no dx zero-fill
+  // (config 2: 1.4136 -> 1.3965 ms per step, config 5: 6.77 -> 6.71; interleaved runs on one box)
+#ifndef PQ3D_LN_MERGED_MIN_R
+#define PQ3D_LN_MERGED_MIN_R 512
+#endif
+  const bool merged = d.R >= PQ3D_LN_MERGED_MIN_R && d.M == 3 && d.dx && !d.independent && !d.sum_branches &&
                       (d.d <= 512 || (d.d == 768 && ln_vec_ok(d, true, true)));   // wider rows would spill the 6 d / 64 accumulators
   {   // zero the atomics targets in one launch (not hipMemsetAsync: see common.h ZeroList)
     ZeroList z;
@@ -506,6 +510,8 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   if (merged) {
     grid.y = 1;
     const bool vecm = ln_vec_ok(d, true, true);
+    // 8 waves per block also for the query-sized calls (one row per wave at R = 800): measured at config 2, same box, 4
+    // waves x 2 rows 1.4155 ms per step (= the atomics kernel), 8 waves 1.409
 #define BWDM(PLV, V) hipLaunchKernelGGL((add_ln_bwd_merged_kernel<PLV, V, 8, 3>), grid, dim3(512), 0, s, d)
     if (d.d <= 64) { BWDM(1, false); }
     else if (d.d <= 128) { BWDM(2, false); }
