@@ -176,7 +176,8 @@ def cpu_baseline(c, sd, dd, steps, warmup, hf_body=None):
 
 
 FAMILY_KERNELS = {   # GPU kernels behind a C-ABI entry point (rocprofv3 / PMC kernel names, template arguments stripped)
-    "pq3d_gemm": ["gemm_wk_kernel", "gemm_fast_kernel", "gemm_slow_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel", "gemm_wktt_kernel"],
+    "pq3d_gemm": ["gemm_wk_kernel", "gemm_fast_kernel", "gemm_slow_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel", "gemm_wktt_kernel",
+                  "gemm_cv128_kernel"],
     "pq3d_attn_fwd": ["attn_fwd_resident_kernel", "attn_sa_fwd_kernel", "attn_small_fwd_kernel", "attn_fwd_kernel", "attn_fwd_combine_kernel"],
     "pq3d_attn_bwd": ["attn_bwd_resident_kernel", "attn_sa_bwd_kernel", "attn_small_bwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
                       "attn_dq_combine_kernel"],
@@ -572,7 +573,8 @@ def main():
             f = fams.setdefault(n, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
             for kk in ("ms", "calls", "flops", "bytes"):
                 f[kk] += v[kk]
-        pmc, stats, tag = committed_profiles(args.config)
+        # the committed rocprofv3 / PMC evidence is of the bf16 build of this config: the fp32 compute type has no in-graph leg
+        pmc, stats, tag = committed_profiles(args.config) if args.compute == "bf16" else (None, {}, None)
         order = sorted(fams, key=lambda n: -fams[n]["ms"])
         blocks = [family_block(n, fams[n], peak, ps, pmc, stats) for n in order[:3]]
         for b in blocks:

@@ -169,7 +169,7 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
     L.gemm(M=Ns, N=Nq, K=d, A=list(keys), B=[qm[m] for m in range(Mm)], Cs=[mlog] + [None] * (Mm - 1), ct=ct, lda=d,
            ldb=d, ldc=Nq, batch=B, strideA=Ns * d, strideB=Nq * d, strideC=Ns * Nq, kconcat=Mm, row_scale=inv_den,
            row_fill_flag=seg_pad, row_fill=-1e6, mask_out=amask)
-    rec.update(mh_x=x, mh_h1=h1, mh_h2=h2, mh_mean=mean, mh_rstd=rstd, mh_qm=qm, mh_drop=hdrop)
+    rec.update(mh_x=x.detach(), mh_h1=h1, mh_h2=h2, mh_mean=mean, mh_rstd=rstd, mh_qm=qm, mh_drop=hdrop)
     return cls, mlog, amask
 
 
@@ -497,7 +497,11 @@ class _FusedDecoder(Function):
                 x = x3
         final_rec = None
         if spec.mh is not None:
-            final_rec = {"x_in": x}
+            # detached aliases: x is also RETURNED, i.e. it becomes a tensor whose grad_fn is this ctx -- kept here as the same
+            # object it would close a reference cycle (ctx -> rec -> x -> grad_fn = ctx) that only Python's cycle collector
+            # frees: the saved activations of every step would outlive it, and under GraphedQuery3D the captured forward's
+            # autograd graph did (round 4: its capture-stream AccumulateGrad nodes cost config 4's 'autograd' mode 2 ms per step)
+            final_rec = {"x_in": x.detach()}
             cls, mlog, _ = _mh_forward(spec, x, keys, inv_den, seg_pad, final_rec, spec.num_blocks * Ln)
             if spec.skip_pred:
                 pcls, pmask = [], []

@@ -204,11 +204,17 @@ class GraphedQuery3D(nn.Module):
                     enc.grad_arena, enc.grad_arena_buffers = self._slots, list(self.reducer.flat)
         # Release the captured forward's autograd graph: its AccumulateGrad nodes were created on the capture stream, and as
         # long as they live every eager backward of mode 'autograd' finds them (they are per-parameter singletons), sees a
-        # stream mismatch and synchronises once per parameter (3.3 ms instead of 1.6 ms per step at config 2)
+        # stream mismatch and pays one hipEventRecord + hipStreamWaitEvent pair per parameter on the capture stream, behind
+        # which the step's stream then stalls (config 2: 3.3 instead of 1.6 ms per step; config 4: 5.89 instead of 3.75 ms).
+        # `del` alone is not enough: with a mask head the captured graph sits in a reference cycle (found in round 4 with
+        # rocprofv3 --hip-runtime-trace, tools/probes/dropin_hiptrace2.sh: 175 waits per step on
+        # torch.cuda.graph.default_capture_stream) and survives until Python's cycle collector happens to run.
         self.static_out = [o.detach() for o in outs]
         del outs, gin
         for p in params:
             p.grad = None
+        import gc
+        gc.collect()
         self._grad_views = None
         self._anchor = torch.zeros((), device=args[0].device, requires_grad=True)
 
