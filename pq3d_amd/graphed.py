@@ -92,13 +92,13 @@ class _Replay(torch.autograd.Function):
             ow._bwd_graph(False).replay()
             # fresh view objects of the flat buffers: AccumulateGrad adopts them without a copy (and runs its hooks: DDP);
             # parameters the captured batch never reached get None, as from an eager backward
-            pg = tuple(None if id(p) in ow._unused else ow._grad_view(p) for p in ow._params)
+            pg = ow._fresh_grad_views()
         else:
             # accumulating micro-batch in 'autograd' mode: this micro-batch's gradients are formed FRESH in a second set of
             # flat buffers and handed to autograd, whose AccumulateGrad adds them onto .grad (= the views of the first set)
             # and runs its hooks -- DDP's bucket hooks fire on the last micro-batch of a no_sync window
             ow._bwd_graph("delta").replay()
-            pg = tuple(None if id(p) in ow._unused else ow._grad_view(p, delta=True) for p in ow._params)
+            pg = ow._fresh_grad_views(delta=True)
         return (None, None, None) + tuple(ow.static_gin) + pg
 
 
@@ -223,6 +223,26 @@ class GraphedQuery3D(nn.Module):
         flat, off, n = (self._slots_delta if delta else self._slots)[id(p)]
         return flat[off:off + n].view_as(p)
 
+    def _fresh_grad_views(self, delta: bool = False):
+        """One NEW view object per parameter (None for the unreached ones), in parameter order: what mode 'autograd' hands to
+        AccumulateGrad, which adopts a gradient without a copy only if nobody else holds the object.  One as_strided call each
+        from cached (buffer, shape, strides, offset) -- the slice + view_as pair and the dictionary look-ups were 0.3-0.5 ms
+        of host time per step at 160 parameters, and the step of config 2 is host-bound in this mode on a slow host."""
+        key = "_view_meta_delta" if delta else "_view_meta"
+        meta = getattr(self, key, None)
+        if meta is None:
+            slots = self._slots_delta if delta else self._slots
+            meta = []
+            for p in self._params:
+                if id(p) in self._unused:
+                    meta.append(None)
+                else:
+                    flat, off, n = slots[id(p)]
+                    meta.append((flat, tuple(p.shape), tuple(torch.empty(p.shape, device="meta").stride()), off))
+            setattr(self, key, meta)
+        ast = torch.as_strided
+        return tuple(None if m is None else ast(m[0], m[1], m[2], m[3]) for m in meta)
+
     def _run_bwd(self, outs, accumulate: bool, retain: bool = False, record_unused: bool = False, delta: bool = False):
         """delta: write (fresh) into the second set of flat buffers; the input gradients still land in the first graph's."""
         params = self._params
@@ -260,8 +280,10 @@ class GraphedQuery3D(nn.Module):
 
     def _accumulating(self) -> bool:
         """True when every parameter's .grad still aliases its flat-buffer view (no zero_grad since the last backward)."""
-        alias = [p.grad is not None and p.grad.data_ptr() == self._grad_view(p).data_ptr() for p in self._params
-                 if id(p) not in self._unused]
+        ptrs = getattr(self, "_view_ptrs", None)
+        if ptrs is None:   # (parameter, address of its slot): cached -- a view per parameter per step was 0.3 ms of host time
+            ptrs = self._view_ptrs = [(p, self._grad_view(p).data_ptr()) for p in self._params if id(p) not in self._unused]
+        alias = [p.grad is not None and p.grad.data_ptr() == a for p, a in ptrs]
         if all(alias) and alias:
             return True
         if any(alias):
