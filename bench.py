@@ -350,9 +350,19 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # PQ3D_BENCH_FORCE_DIST=1 (test hook): run the data-parallel step flow with ONE rank -- a real RCCL communicator of
+    # size 1, every bucket's all-reduce issued (side stream, ReduceOp.AVG) and, in the default step mode, captured inside
+    # the HIP graph.  A one-GPU box cannot run two RCCL ranks; this is how the 'nccl' branch executes on hardware at all.
+    dist_on = world > 1 or os.environ.get("PQ3D_BENCH_FORCE_DIST", "0") == "1"
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -389,7 +399,8 @@ def main():
     dec_buckets = [bucket_of[j] for j in range(n_layer_buckets + 1) if keep[j]]
     enc.grad_arena = reducer.slots()
     enc.grad_arena_buffers = list(reducer.flat)   # all of them: the encoders' backward writes its slots in place too
-    overlap = world > 1 and os.environ.get("PQ3D_BENCH_OVERLAP", "1") != "0"
+    reducer.force_collectives = dist_on and world == 1
+    overlap = dist_on and os.environ.get("PQ3D_BENCH_OVERLAP", "1") != "0"
     forced_mode = os.environ.get("PQ3D_BENCH_STEP_MODE", "")   # "", "one_graph", "two_graph", "graph_then_allreduce", "eager"
 
     def on_ready(tag):
@@ -429,6 +440,7 @@ def main():
         def __init__(self):
             self.ga, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             self.split_seen = False
+            self.ev = torch.cuda.Event()
             stream = torch.cuda.Stream()
             stream.wait_stream(torch.cuda.current_stream())
 
@@ -454,16 +466,22 @@ def main():
 
         def __call__(self):
             self.ga.replay()
-            on_ready("decoder")        # eager collectives on the side stream, overlapping graph B
-            self.gb.replay()
+            self.ev.record()           # every decoder gradient is final here
+            self.gb.replay()           # enqueued BEFORE the collectives: the device goes from A straight into B while the
+            for b in dec_buckets:      # host is still issuing the all-reduces (side stream, behind the event only)
+                reducer.launch(b, after=self.ev)
             reducer.finish()
 
     def capture():
         """3 eager steps on a side stream (allocator + autograd warm-up), then capture the step.
-        Returns (callable or None, mode).  Data-parallel runs try, in this order: (1) ONE graph with the RCCL all-reduces
-        inside, per-layer buckets launched from inside the backward; (2) TWO graphs split at decoder-gradients-final with
-        the collectives launched eagerly in between (overlap without capturing collectives); (3) forward+backward in one
-        graph, all-reduces after the replay (no overlap); (4) eager."""
+        Returns (callable or None, mode).  Data-parallel runs use, in this order: (1) only on request
+        (PQ3D_BENCH_STEP_MODE=one_graph) ONE graph with the RCCL all-reduces inside, on the capturing stream at the point
+        each layer's bucket becomes final -- no host work per step, but no overlap either (branches of one graph do not run
+        concurrently on this runtime), and capturing them on a forked side stream crashes hipStreamEndCapture
+        (tools/probes/rccl_capture_probe.py); (2) DEFAULT: TWO graphs split at decoder-gradients-final with the collectives
+        launched eagerly in between on a side stream, overlapping graph B (validated over RCCL with a one-rank communicator
+        on an MI355X and over gloo with two ranks); (3) forward+backward in one graph, all-reduces after the replay (no
+        overlap); (4) eager."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         enc.grads_ready, enc.grad_bucket_per_layer = (on_ready if overlap else None), overlap
@@ -481,7 +499,7 @@ def main():
             torch.cuda.synchronize()
             reducer._pending, reducer._launched = [], set()
 
-        if overlap and backend == "nccl" and forced_mode in ("", "one_graph"):
+        if overlap and backend == "nccl" and forced_mode == "one_graph":
             try:
                 g = torch.cuda.CUDAGraph()
                 # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
@@ -489,7 +507,7 @@ def main():
                     full_step()
                 g.replay()                      # one checked replay: asynchronous collective errors surface here, inside
                 torch.cuda.synchronize()        # the try, and the run falls back
-                return g.replay, f"graph(step+allreduce, {len(dec_buckets)} decoder buckets launched per layer from inside the backward)"
+                return g.replay, f"graph(step+allreduce, {len(dec_buckets)} decoder buckets all-reduced in-stream per layer from inside the backward)"
             except Exception as e:  # noqa: BLE001
                 note("capture with the collectives inside", e)
         if overlap and forced_mode in ("", "two_graph"):
@@ -509,7 +527,7 @@ def main():
             def run():
                 g.replay()
                 reducer.finish()
-            return (run if world > 1 else g.replay), "graph(fwd+bwd) then allreduce"
+            return (run if dist_on else g.replay), "graph(fwd+bwd) then allreduce"
         except Exception as e:  # noqa: BLE001
             note("HIP graph capture", e)
             return None, "eager"
@@ -525,7 +543,7 @@ def main():
             full_step()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
@@ -536,14 +554,14 @@ def main():
         step()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     value = c["B"] * world * args.steps / dt
     grads_identical = None
-    if world > 1:   # after the all-reduce every rank must hold the same (mean) gradient: fingerprint min == max over ranks
+    if dist_on:   # after the all-reduce every rank must hold the same (mean) gradient: fingerprint min == max over ranks
         fp = torch.stack([torch.stack([f.double().sum(), f.double().abs().sum()]) for f in reducer.flat]).flatten()
         lo, hi = fp.clone(), fp.clone()
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
@@ -605,7 +623,7 @@ def main():
             "config": {"workload": f"BASELINE config {args.config}: B={c['B']} scenes/GPU, N_seg={c['Ns']}, "
                                    f"N_q={c['Nq']}, d={c['d']}, H={c['H']}, L={c['L']}, memories={c['memories']}, "
                                    f"{c.get('structure', 'parallel')} cross-attn + spatial self-attn + FFN2048, heads={c['heads']}, "
-                                   f"fwd+bwd+grad-pack{'+RCCL all-reduce' if world > 1 else ''}",
+                                   f"fwd+bwd+grad-pack{'+RCCL all-reduce' if dist_on else ''}",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
                        "step_mode": step_mode,
                        "dropout": 0.0 if args.dropout == "off" else "reference train mode (0.1 / heads 0.1, 0.3)",
@@ -613,7 +631,7 @@ def main():
             "step_algorithmic_gflop": flops / 1e9,
             "step_roofline_frac": flops * world / (dt / args.steps) / (peak * 1e12 * world),
             **({"grads_identical_across_ranks": grads_identical, "collective_backend": backend,
-                "rccl_ranks": (torch.distributed.get_world_size() if backend == "nccl" else 0)} if world > 1 else {}),
+                "rccl_ranks": (torch.distributed.get_world_size() if backend == "nccl" else 0)} if dist_on else {}),
             "roofline": roof,
             "roofline_next": blocks[1:],
             "kernel_families_ms_per_step": {k: round(v["ms"] / ps, 4) for k, v in sorted(fams.items())},
@@ -721,7 +739,7 @@ def main():
                 result["cpu_baseline"]["sample"] += "; caption body = stock HF T5 on the CPU (third-party, as the reference calls it)"
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
         print(json.dumps(result))
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -55,6 +55,9 @@ class FlatGradAllReducer:
         self._side = None        # side stream of the early launches
         self._pending = []       # (work handle or None, bucket index)
         self._launched = set()
+        # single-rank probe (bench.py PQ3D_BENCH_FORCE_DIST=1): issue the collectives even with ONE rank, so that the RCCL
+        # code path (ReduceOp.AVG, side stream, capture inside a HIP graph) executes on a one-GPU box
+        self.force_collectives = False
 
     def slots(self):
         """{id(param): (flat buffer, element offset, numel)} -- hand this to the fused executor
@@ -115,6 +118,9 @@ class FlatGradAllReducer:
     def _world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
+    def _active(self) -> bool:
+        return self._world() > 1 or (self.force_collectives and dist.is_initialized())
+
     def _reduce(self, f: torch.Tensor):
         """mean over ranks, in place.  RCCL ('nccl') averages inside the collective (ReduceOp.AVG: no separate divide
         launch); gloo (CPU tests, the one-GPU two-rank hook) has no AVG -> SUM, the caller divides."""
@@ -122,16 +128,34 @@ class FlatGradAllReducer:
             return dist.all_reduce(f, op=dist.ReduceOp.AVG, group=self.group, async_op=True), False
         return dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True), True
 
-    def launch(self, bi: int) -> None:
+    def launch(self, bi: int, after=None) -> None:
         """Start the all-reduce of bucket ``bi`` on a side stream that waits for the work queued so far on the current
-        stream; the current stream carries on (the rest of the backward overlaps the transfer).  finish() joins."""
-        if self._world() == 1 or bi in self._launched:
+        stream -- or, with ``after`` (an event recorded on the current stream when the bucket became final), only for
+        that point: work queued behind it then overlaps the transfer even though it was enqueued first.  The current
+        stream carries on (the rest of the backward overlaps the transfer).  finish() joins."""
+        if not self._active() or bi in self._launched:
             return
         cur = torch.cuda.current_stream() if self.flat[bi].is_cuda else None
+        if cur is not None and torch.cuda.is_current_stream_capturing():
+            # Inside a HIP-graph capture the collective stays ON the capturing stream (a synchronous op: RCCL's internal
+            # stream forks from and rejoins this one).  Forking a side stream first -- cur -> side -> RCCL's stream -> side
+            # -> cur -- makes hipStreamEndCapture SEGFAULT on this stack (torch 2.10 / ROCm 7.2, found with a one-rank
+            # communicator on an MI355X: tools/probes/rccl_capture_probe.py); branches of one graph do not run
+            # concurrently on this runtime anyway (DESIGN section 3), so nothing is lost.
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_reduce(self.flat[bi], op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group)
+                self.flat[bi].div_(float(self._world()))
+            self._launched.add(bi)
+            return
         if cur is not None:
             if self._side is None:
                 self._side = torch.cuda.Stream()
-            self._side.wait_stream(cur)
+            if after is not None:
+                self._side.wait_event(after)
+            else:
+                self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
                 h, div = self._reduce(self.flat[bi])
         else:
@@ -141,7 +165,7 @@ class FlatGradAllReducer:
 
     def finish(self) -> None:
         """Launch whatever has not been launched, wait for everything, leave the mean in the flat buffers."""
-        if self._world() == 1:
+        if not self._active():
             return
         for bi in range(len(self.flat)):
             self.launch(bi)
@@ -156,7 +180,9 @@ class FlatGradAllReducer:
                 h.wait()
                 if div:
                     self.flat[bi].div_(world)
-        if self._side is not None and self.flat[0].is_cuda:
+        if self._side is not None and self.flat[0].is_cuda and self._pending:
+            # (nothing is pending on the side stream when the collectives ran in-stream inside a capture: no join, which a
+            # capturing stream could not take from a stream outside the capture anyway)
             torch.cuda.current_stream().wait_stream(self._side)
         self._pending, self._launched = [], set()
 

@@ -52,6 +52,30 @@ def test_bench_two_ranks_one_gpu(config, launcher):
         assert mode.startswith("two graphs") and int(mode.split(",")[1].split()[0]) >= 4, (mode, p.stderr[-1500:])
 
 
+@pytest.mark.parametrize("mode", ["", "one_graph", "graph_then_allreduce", "eager"])
+def test_bench_one_rank_rccl(mode):
+    """RCCL on the box we have: a communicator of ONE rank (PQ3D_BENCH_FORCE_DIST=1) runs the whole data-parallel step
+    flow over backend 'nccl' -- the default (two graphs, the decoder buckets' ReduceOp.AVG all-reduces launched eagerly on
+    the side stream between them), the collectives captured INSIDE one HIP graph (on request; on the capturing stream: a
+    forked side stream crashes hipStreamEndCapture on this stack, tools/probes/rccl_capture_probe.py), and both
+    fallbacks.  A mean over one rank is the identity, so the gradients must come out finite and non-zero, and the step
+    mode must be the requested one."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PQ3D_BENCH_FORCE_DIST="1", PQ3D_BENCH_STEP_MODE=mode)
+    for k in ("PQ3D_BENCH_BACKEND", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--headline-only"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["collective_backend"] == "nccl"
+    assert r["grads_identical_across_ranks"] is True and r["value"] > 0
+    sm = r["config"]["step_mode"]
+    want = {"": "two graphs", "one_graph": "graph(step+allreduce", "graph_then_allreduce": "graph(fwd+bwd) then allreduce",
+            "eager": "eager"}[mode]
+    assert sm.startswith(want), (sm, p.stderr[-2000:])
+
+
 def test_bench_two_ranks_rccl():
     """The real thing where the box has it: two ranks on two GPUs over RCCL (backend 'nccl'), so that the driver's
     multi-GPU run is not RCCL's first execution of this path.  Exercises graph capture with the collectives inside (or
