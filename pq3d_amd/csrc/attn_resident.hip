@@ -76,8 +76,8 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* Qs = (bf16_t*)smem;                                  // [NQ][LDR]
   bf16_t* dOs = Qs + NQ * R::LDR;                              // [NQ][LDR]
-  float* Ls = (float*)(dOs + NQ * R::LDR);                     // [NQ]  log2(e) * logsumexp (+inf past Lq)
-  float* Ds = Ls + NQ;                                         // [NQ]  delta
+  float* Ls = (float*)(dOs + NQ * R::LDR);                     // [NQ]  -log2(e) * logsumexp (-inf past Lq)
+  float* Ds = Ls + NQ;                                         // [NQ]  -delta
   float* dQs = (float*)smem;                                   // [NQ][LDQ] fp32: end-of-kernel sum over the waves, OVER Qs / dOs
   static_assert(NQ * R::LDQ * 4 <= 2 * NQ * R::LDR * 2, "the dQ reduction buffer must fit over the resident Q / dO tiles");
   bf16_t* wv = (bf16_t*)(Ds + NQ);                             // per wave: K tile + dS scratch (+ mask tile)
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
         *(u32x4*)&Qs[row * R::LDR + kc * 8] = q;
         *(u32x4*)&dOs[row * R::LDR + kc * 8] = g;
         if (kc == 0) {
-          Ds[row] = ok ? s : 0.f;
-          Ls[row] = ok ? d.lse[sbase + row] * 1.4426950408889634f : INFINITY;
+          Ds[row] = ok ? -s : 0.f;     // both rows are kept NEGATED: the loop adds them (accumulator start, fma addend)
+          Ls[row] = ok ? d.lse[sbase + row] * -1.4426950408889634f : -INFINITY;
           if (ok && split == 0) d.delta[sbase + row] = s;
           if constexpr (MASK3) ros[row] = (ok && d.row_open) ? d.row_open[(long)bm * d.Lq + q_lo + row] : 0;
         }
@@ -138,6 +138,9 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   uint8_t* mt_ = (uint8_t*)(sc + R::SC_ELEMS);  // [32][MLD] staged 3-D mask bytes of (query pair, key group) (MASK3)
 
   const long koff = (long)b * d.k_sb + (long)h * d.k_sh, voff = (long)b * d.v_sb + (long)h * d.v_sh;
+  const bf16_t* const kbase = (const bf16_t*)d.k + koff;
+  const bf16_t* const vbase = (const bf16_t*)d.v + voff;
+  const int k_sl32 = (int)d.k_sl, v_sl32 = (int)d.v_sl;
   const uint8_t* kpm = d.kpm ? d.kpm + (long)b * d.Lk : nullptr;
   const int ngroups = (d.Lk + GK - 1) / GK;
   DropState dst;
@@ -159,8 +162,10 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     for (int kt = 0; kt < 2; ++kt) {
       const int key = g * GK + kt * 16 + li;
       const int ck = min(key, d.Lk - 1);
-      row_frags<bf16_t, DH>(kd[kt], d.k, koff + (long)ck * d.k_sl, lg);
-      row_frags<bf16_t, DH>(vd[kt], d.v, voff + (long)ck * d.v_sl, lg);
+      // (32-bit products: a scene's K / V rows span < 2^31 elements -- checked on the host; the 64-bit multiplies were 50
+      // vector-ALU instructions per group)
+      row_frags<bf16_t, DH>(kd[kt], kbase, (long)(ck * k_sl32), lg);
+      row_frags<bf16_t, DH>(vd[kt], vbase, (long)(ck * v_sl32), lg);
       md[kt] = key < d.Lk ? (kpm ? kpm[key] != 0 : false) : true;
     }
   };
@@ -252,11 +257,12 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
             qa[s] = rfrag<bf16_t>(&Qs[(q0 + li) * R::LDR], s, lg);
             ga[s] = rfrag<bf16_t>(&dOs[(q0 + li) * R::LDR], s, lg);
           }
-          const f32x4 Lr = *(const f32x4*)&Ls[q0 + 4 * lg], Dr = *(const f32x4*)&Ds[q0 + 4 * lg];
-          const f32x4 nL = -Lr, nD = -Dr;   // negated once per query tile: the packed forms below then are plain fma / add
+          const f32x4 nL = *(const f32x4*)&Ls[q0 + 4 * lg], nD = *(const f32x4*)&Ds[q0 + 4 * lg];   // -lse log2(e), -delta
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            f32x4 sv = (f32x4){sinit[kt], sinit[kt], sinit[kt], sinit[kt]}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // without dropout the dP accumulator STARTS at -delta (the first MFMA takes the negated delta fragment as its C
+            // operand): dP - delta costs no instruction at all (it was 64 v_sub_f32 per 32-key group)
+            f32x4 sv = (f32x4){sinit[kt], sinit[kt], sinit[kt], sinit[kt]}, dp = DROP ? (f32x4){0.f, 0.f, 0.f, 0.f} : nD;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
               Mma<bf16_t>::mma(sv, qa[s], kcur[kt][s]);
@@ -272,15 +278,15 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
               // P from the saved log-sum-exp; a padded key's score started at -1e30 (sinit), so its probability is exactly 0
               const f32x2 pa = (f32x2){__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
               const f32x2 pb = (f32x2){__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
-              const f32x2 da = pa * (__builtin_shufflevector(dp, dp, 0, 1) + __builtin_shufflevector(nD, nD, 0, 1));
-              const f32x2 db = pb * (__builtin_shufflevector(dp, dp, 2, 3) + __builtin_shufflevector(nD, nD, 2, 3));
+              const f32x2 da = pa * __builtin_shufflevector(dp, dp, 0, 1);   // dp already holds dP - delta
+              const f32x2 db = pb * __builtin_shufflevector(dp, dp, 2, 3);
               pt[kt][qt][0] = pa.x; pt[kt][qt][1] = pa.y; pt[kt][qt][2] = pb.x; pt[kt][qt][3] = pb.y;
               ds[kt][qt][0] = da.x; ds[kt][qt][1] = da.y; ds[kt][qt][2] = db.x; ds[kt][qt][3] = db.y;
             } else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int ql = q0 + 4 * lg + r;
-              float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sl2, -Lr[r]));   // P from the saved log-sum-exp
+              float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], sl2, nL[r]));   // P from the saved log-sum-exp
               // padded key: its K row is zeroed, so the score is 0 and exp2(-lse) can overflow for a strongly negative lse
               // (no zero key); inf * 0 at the dK / dV store would be NaN -> force the probability itself to 0
               p = kmc[kt] ? 0.f : p;
@@ -291,10 +297,10 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
               if constexpr (DROP) {
                 const float kc = drop_keep(dst, drow0 + (uint32_t)min(ql, nq - 1), (uint32_t)min(g * GK + kt * 16 + li, d.Lk - 1)) ? dst.scale : 0.f;
                 pt[kt][qt][r] = p * kc;
-                ds[kt][qt][r] = p * (dp[r] * kc - Dr[r]);
+                ds[kt][qt][r] = p * (dp[r] * kc + nD[r]);
               } else {
                 pt[kt][qt][r] = p;
-                ds[kt][qt][r] = p * (dp[r] - Dr[r]);     // the 1/sqrt(d_h) factor of dS is applied to dK / dQ at the end
+                ds[kt][qt][r] = p * dp[r];     // dp = dP - delta (accumulator start); 1/sqrt(d_h) is applied to dK / dQ at the end
               }
             }
           }
@@ -339,8 +345,8 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     for (int kt = 0; kt < 2; ++kt) {
       const int key = g * GK + kt * 16 + li;
       if (key < d.Lk) {
-        const long ko = (long)b * d.k_sb + (long)key * d.k_sl + (long)h * d.k_sh;
-        const long vo = (long)b * d.v_sb + (long)key * d.v_sl + (long)h * d.v_sh;
+        const long ko = koff + (long)(key * k_sl32);
+        const long vo = voff + (long)(key * v_sl32);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const float ks_ = kmc[kt] ? 0.f : d.scale, vs_ = kmc[kt] ? 0.f : 1.f;   // padded keys: exact zeros
@@ -456,8 +462,11 @@ template <int DH, int NQP> void launch_res_flags(const pq3d_attn_desc& d, hipStr
 }
 
 template <int DH> void launch_res_rows(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
-  if (nq <= 64) launch_res_flags<DH, 2>(d, s, q_lo, nq, acc);
-  else launch_res_flags<DH, 4>(d, s, q_lo, nq, acc);
+  if (nq <= 64) { launch_res_flags<DH, 2>(d, s, q_lo, nq, acc); return; }
+#ifdef PQ3D_RES_NQP3   // probe builds: 65 .. 96 resident queries on 3 query pairs (the shipped stage-2 shape: 80 objects)
+  if (nq <= 96) { launch_res_flags<DH, 3>(d, s, q_lo, nq, acc); return; }
+#endif
+  launch_res_flags<DH, 4>(d, s, q_lo, nq, acc);
 }
 
 template <int DH> bool launch_res_dh(const pq3d_attn_desc& d, hipStream_t s) {
@@ -707,7 +716,13 @@ bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
 bool pq3d_attn_bwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
   if (d.ct != PQ3D_BF16 || d.bias || d.dbias) return false;
   if (d.dh != 32 && d.dh != 64) return false;
-  if (d.Lq > 256 || d.Lk < 128) return false;
+#ifndef PQ3D_RES_MIN_LK
+#define PQ3D_RES_MIN_LK 128
+#endif
+  // d_h = 64 from 64 keys on: the shipped stage-2 cross-attention (80 objects per memory) is 342 -> 262 us per call here
+  // against the two-kernel path (tools/probes/attn_s2_probe.py); at 32 keys (prompt tokens) the two-kernel path wins
+  if (d.Lq > 256 || d.Lk < (d.dh == 64 ? (PQ3D_RES_MIN_LK < 64 ? PQ3D_RES_MIN_LK : 64) : PQ3D_RES_MIN_LK)) return false;
+  if ((long)d.Lk * d.k_sl >= (1L << 31) || (long)d.Lk * d.v_sl >= (1L << 31)) return false;   // 32-bit row offsets inside a scene
   if (d.mask && ((d.Lk & 15) != 0 || (((uintptr_t)d.mask) & 15) != 0)) return false;
   if (d.dh == 32) return launch_res_dh<32>(d, s);
   return launch_res_dh<64>(d, s);

@@ -221,7 +221,39 @@ PQ_DEV TileIdx tile_index(const int xcd_order) {
   t.z = zb * zr + zi;
   return t;
 }
+// Per-plane variant for the SMALL launches (gemm_wk / gemm_wktt: every workgroup resident at once, <= a few hundred per
+// z-plane): z stays blockIdx.z (the speculative per-group pointer load of those kernels stays right), and inside the plane
+// the workgroups one XCD receives (same linear id mod 8) take a contiguous range of the plane's tiles -- y fastest
+// (order 1: an XCD owns whole row tiles, the A slab is fetched by one L2) or x fastest (order 255: whole column tiles, the
+// B slab).  In hardware order the m-tiles of one weight slab sit on 8 different L2s and every L2 fetches every slab:
+// measured 42 MB per FFN down-projection launch at config 2 for 8.5 MB of operands (profiles/pmc_traffic_r04_c2.json).
+PQ_DEV TileIdx tile_index_plane(const int order) {
+  TileIdx t = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  if (!order) return t;   // uniform
+  const int gx = gridDim.x, gy = gridDim.y, ps = gx * gy;
+  const int id = t.x + gx * t.y, r = id & 7, per = ps >> 3, rem = ps & 7;
+  const int l = r * per + min(r, rem) + (id >> 3);
+  if ((order & 255) == 1) { t.x = l / gy; t.y = l - t.x * gy; }
+  else { t.y = l / gx; t.x = l - t.y * gx; }
+  return t;
+}
 #endif
+// Order of tile_index_plane() that gives one XCD the smaller operand footprint; a_tile / b_tile: bytes of the operand slab
+// of one row tile / one column tile.  0 (hardware order) for planes of fewer than 16 tiles.
+inline int plane_xcd_order(int gx, int gy, long a_tile, long b_tile) {
+#ifdef PQ3D_XCD_PLANE_OFF   // A/B measurement builds (tools/build_variant.py)
+  return 0;
+#else
+  const int ps = gx * gy;
+  if (ps < 16) return 0;
+  const int T = (ps + 7) / 8;
+  const long rows_y = (T + gy - 1) / gy + (T % gy ? 1 : 0), cols_y = T < gy ? T : gy;
+  const long fy = (rows_y < gx ? rows_y : gx) * a_tile + cols_y * b_tile;
+  const long cols_x = (T + gx - 1) / gx + (T % gx ? 1 : 0), rows_x = T < gx ? T : gx;
+  const long fx = rows_x * a_tile + (cols_x < gy ? cols_x : gy) * b_tile;
+  return (fy <= fx ? 1 : 255) | (1 << 8);
+#endif
+}
 // workgroups: of the launch; b_plane_bytes: operand B of one z-plane; zrun: z-planes per run sharing operand A (must divide the z extent)
 inline int xcd_order_for(long workgroups, long b_plane_bytes, int zrun) {
 #ifdef PQ3D_XCD_OFF   // A/B measurement builds (tools/build_variant.py)

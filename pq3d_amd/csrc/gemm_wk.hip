@@ -67,11 +67,11 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
 
   // kernel-argument prefetch (see gemm_fast_kernel): every scalar the kernel uses in one batch of scalar loads
   GPtrs gp;
-  const int gspec = min((int)blockIdx.z, PQ3D_MAX_GROUPS - 1);
+  const int gspec = min((int)blockIdx.z, PQ3D_MAX_GROUPS - 1);   // z is never remapped (tile_index_plane)
   gp.load(d, gspec);
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.splitk), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc),
                "s"(d.strideC), "s"(d.alpha), "s"(d.act), "s"(d.act_grad), "s"(d.dtC), "s"(d.dtC2), "s"(d.dtAux), "s"(d.dtBias),
-               "s"(d.row_fill), "s"(d.row_scale), "s"(d.row_fill_flag), "s"(d.mask_out), "s"(gp.A), "s"(gp.A2), "s"(gp.B));
+               "s"(d.row_fill), "s"(d.row_scale), "s"(d.row_fill_flag), "s"(d.mask_out), "s"(gp.A), "s"(gp.A2), "s"(gp.B), "s"(d.xcd_order));
   asm volatile("" ::"s"(gp.bias), "s"(gp.aux), "s"(gp.C), "s"(gp.C2), "s"(gp.row_mask));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(WT) void gemm_wk_kernel(const pq3d_kdesc d) {
   int zz = blockIdx.z, split = 0;
   if (d.splitk > 1) { split = zz % d.splitk; zz /= d.splitk; }
   const int g0 = zz * ng;
-  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const TileIdx ti = tile_index_plane(d.xcd_order);   // the tiles one XCD receives are neighbours in its plane (common.h)
+  const int m0 = ti.x * TM, n0 = ti.y * TN;
   const int nck = (d.K + KC - 1) / KC;
   int c0 = 0, c1 = nck;
   if (d.splitk > 1) {
@@ -292,7 +293,14 @@ int wk_launch(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
   if (int e = pq3d_enable_big_lds(kern, (int)lds, attr_done)) return e;
   const int kc = d.kconcat > 0 ? d.kconcat : 1;
   const dim3 grid((d.M + TM - 1) / TM, (d.N + TN - 1) / TN, (d.groups / kc) * (d.splitk > 1 ? d.splitk : 1));
-  hipLaunchKernelGGL(kern, grid, dim3(WT), lds, s, kd);
+  if (g_wk_enable.load() & (1 << 9)) {   // A/B switch of the probes: hardware tile order
+    hipLaunchKernelGGL(kern, grid, dim3(WT), lds, s, kd);
+    return 0;
+  }
+  pq3d_kdesc k2 = kd;
+  const long kl = (long)d.K * kc / (d.splitk > 1 ? d.splitk : 1);   // reduction length one workgroup walks
+  k2.xcd_order = plane_xcd_order((int)grid.x, (int)grid.y, (long)TM * kl * (long)(sizeof(TA) + (HA2 ? 4 : 0)), (long)TN * kl * (long)sizeof(TB));
+  hipLaunchKernelGGL(kern, grid, dim3(WT), lds, s, k2);
   return 0;
 }
 

@@ -21,7 +21,7 @@ SHAPES = [  # name, M, N, K, groups, kconcat, ct, A dtype, transB, A2, splitk, a
     ("enc    M8992 x3", 8992, 256, 256, 1, 0, X3, "f32", False, False, 1, None, "f32"),
     ("objenc M8192g3x3", 8192, 256, 256, 3, 0, X3, "f32", False, False, 1, None, "f32"),
 ]
-OPTS = [("old 64x64", 0), ("auto", 1), ("32/256", 1 | (1 << 4) | (2 << 6) | (1 << 8)), ("64/256", 1 | (2 << 4) | (2 << 6) | (1 << 8)),
+OPTS = [("old 64x64", 0), ("auto", 1), ("auto hw-order", 1 | (1 << 9)), ("32/256", 1 | (1 << 4) | (2 << 6) | (1 << 8)), ("64/256", 1 | (2 << 4) | (2 << 6) | (1 << 8)),
         ("32/128", 1 | (1 << 4) | (1 << 6) | (1 << 8)), ("64/128", 1 | (2 << 4) | (1 << 6) | (1 << 8))]
 td = lambda n: torch.bfloat16 if n == "bf16" else torch.float32
 
@@ -60,13 +60,13 @@ def run(shape, opt, reps=40):
 
 
 if __name__ == "__main__":
-    print(f"{'shape':18s}" + "".join(f"{n:>11s}" for n, _ in OPTS))
+    print(f"{'shape':18s}" + "".join(f"{n:>14s}" for n, _ in OPTS))
     for sh in SHAPES:
         row = []
         for n, o in OPTS:
             try:
-                row.append(f"{run(sh, o):11.2f}")
+                row.append(f"{run(sh, o):14.2f}")
             except Exception as e:  # noqa
-                row.append(f"{'err':>11s}")
+                row.append(f"{'err':>14s}")
         print(f"{sh[0]:18s}" + "".join(row), flush=True)
     L.lib().pq3d_gemm_set_wk(1, 2048)
