@@ -225,7 +225,10 @@ int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
  *          fp32-grade arithmetic (hi/lo bf16 operand pairs, 3 MFMAs per product): d_h 32, Lq, Lk <= 240, key padding /
  *          additive bias only, one workgroup per (scene, head), no atomics.  PQ3D_BF16X3 calls of any other shape run the
  *          exact-fp32 kernels.
- * This process-wide switch sets which of them may be used (default 15 = all; for A/B measurements and tests) and returns
+ *   bit 4: the small bf16 cross-attention kernels (csrc/attn_ca.hip): bf16 storage and compute, d_h 32 / 64, at most 128
+ *          queries AND 128 keys per (scene, head), key padding / zero key only -- the shipped stage-2 decoder's attention
+ *          over <= 80 objects per memory and its prompt tokens; one workgroup per (scene, head), no atomics.
+ * This process-wide switch sets which of them may be used (default 31 = all; for A/B measurements and tests) and returns
  * the previous value. */
 int pq3d_attn_resident(int enable);
 

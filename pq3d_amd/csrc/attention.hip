@@ -27,15 +27,18 @@ bool pq3d_attn_bwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // at
 bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // attn_resident.hip
 bool pq3d_attn_small_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);   // attn_small.hip
 bool pq3d_attn_sa_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);      // attn_sa.hip
-static int g_resident = 1, g_small = 1, g_resfwd = 1, g_sa = 1;
+bool pq3d_attn_ca_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);      // attn_ca.hip
+static int g_resident = 1, g_small = 1, g_resfwd = 1, g_sa = 1, g_ca = 1;
 // bit 0: all-queries-resident backward, bit 1: small-sequence fp32 kernels, bit 2: all-keys-resident forward, bit 3: the
-// split-bf16 MFMA self-attention kernels for compute type PQ3D_BF16X3 (all on by default)
+// split-bf16 MFMA self-attention kernels for compute type PQ3D_BF16X3, bit 4: the small bf16 cross-attention kernels
+// (all on by default)
 extern "C" int pq3d_attn_resident(int enable) {
-  const int old = g_resident | (g_small << 1) | (g_resfwd << 2) | (g_sa << 3);
+  const int old = g_resident | (g_small << 1) | (g_resfwd << 2) | (g_sa << 3) | (g_ca << 4);
   g_resident = enable & 1;
   g_small = (enable >> 1) & 1;
   g_resfwd = (enable >> 2) & 1;
   g_sa = (enable >> 3) & 1;
+  g_ca = (enable >> 4) & 1;
   return old;
 }
 
@@ -773,7 +776,8 @@ template <typename CT, int DH, bool DROP, bool MASK3> void launch_fwd_k(const pq
 template <typename CT, int DH> int launch_fwd(const pq3d_attn_desc& d, hipStream_t s) {
   const int tiles = (d.Lq + 15) / 16, ks = d.ksplit > 1 ? d.ksplit : 1;
   const bool dr = d.drop.p > 0.f && d.drop.seed, m3 = d.mask != nullptr;
-  if (g_resfwd && pq3d_attn_fwd_resident_try(d, s)) {
+  if (g_ca && pq3d_attn_ca_try(d, s, false)) {   // few queries AND few keys, bf16: one workgroup per (scene, head)
+  } else if (g_resfwd && pq3d_attn_fwd_resident_try(d, s)) {
   } else if (dr) { if (m3) launch_fwd_k<CT, DH, true, true>(d, s, tiles, ks); else launch_fwd_k<CT, DH, true, false>(d, s, tiles, ks); }
   else { if (m3) launch_fwd_k<CT, DH, false, true>(d, s, tiles, ks); else launch_fwd_k<CT, DH, false, false>(d, s, tiles, ks); }
   if (ks > 1) {
@@ -803,6 +807,7 @@ template <typename CT, int DH> int launch_bwd(const pq3d_attn_desc& d, hipStream
   const int tiles = (d.Lq + 15) / 16;   // the dQ kernel also produces delta = rowsum(dO * O) for the dK/dV kernel
   const int ks = d.ksplit > 1 ? d.ksplit : 1;
   if constexpr (sizeof(CT) == 2 && (DH == 32 || DH == 64)) {
+    if (g_ca && pq3d_attn_ca_try(d, s, true)) { PQ_LAUNCH_CHECK(); return 0; }   // few queries AND few keys (attn_ca.hip)
     // cross-attention shape (few queries, many keys): single-pass backward with all queries resident (attn_resident.hip)
     if (g_resident && pq3d_attn_bwd_resident_try(d, s)) {
       if (ks > 1) {

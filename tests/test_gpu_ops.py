@@ -423,6 +423,53 @@ def test_upsample_scatter_mean_skips_out_of_range_rows():
     assert torch.allclose(src.grad, g, atol=1e-6)
 
 
+# ---------------------------------------------------------------------------------------------- small bf16 cross-attention
+@pytest.mark.parametrize("za", [True, False])
+@pytest.mark.parametrize("B,Lq,Lk,H,dh", [(6, 80, 80, 12, 64), (4, 80, 32, 12, 64), (5, 100, 32, 8, 32), (3, 17, 5, 2, 32),
+                                          (2, 128, 128, 4, 64), (3, 1, 128, 2, 32), (2, 33, 97, 2, 64)])
+def test_attention_small_cross_kernels(B, Lq, Lk, H, dh, za):
+    """attn_ca.hip (bf16, at most 128 queries and 128 keys per (scene, head): the shipped stage-2 decoder's cross-attention
+    over <= 80 objects, prompt tokens) against an fp64 reference of the same bf16 inputs -- output and every gradient
+    within the bf16 bars of the general kernels -- and against the general kernels on the same inputs; a scene's result
+    does not depend on the amount of key padding behind it (bit-identical)."""
+    d = H * dh
+    q, k, v = rnd(B, Lq, d, seed=11), rnd(B, Lk, d, seed=12), rnd(B, Lk, d, seed=13)
+    vl = torch.tensor([Lk] + [max(1, (Lk * (3 + i)) // 7) for i in range(B - 1)])
+    kpm = torch.arange(Lk)[None, :] >= vl[:, None]
+    go = rnd(B, Lq, d, seed=17)
+    lib = L.lib()
+    res = {}
+    for ca in (1, 0):
+        old = lib.pq3d_attn_resident((16 if ca else 0) | 15)
+        try:
+            qd, kd, vd = (t.to(DEV).bfloat16().requires_grad_(True) for t in (q, k, v))
+            o = ops.attention(qd, kd, vd, H=H, ct=BF16, zero_attn=za, kpm=kpm.to(DEV))
+            o.backward(go.to(DEV).bfloat16())
+            res[ca] = (o.detach(), qd.grad, kd.grad, vd.grad)
+        finally:
+            lib.pq3d_attn_resident(old)
+    qr, kr, vr = (t.bfloat16().double().requires_grad_(True) for t in (q, k, v))
+    orf = attn_ref(qr, kr, vr, H, 1 / math.sqrt(dh), za, kpm, None, None, None)
+    orf.backward(go.bfloat16().double())
+    for name, a, a_old, r in zip(("o", "dq", "dk", "dv"), res[1], res[0], (orf, qr.grad, kr.grad, vr.grad)):
+        assert torch.isfinite(a.float()).all(), name
+        assert _relL2(a, r) <= 2e-2, f"{name}: small cross-attention vs fp64 relL2 {_relL2(a, r):.2e}"
+        assert _relL2(a, a_old) <= 2e-2, f"{name}: small cross-attention vs general kernels relL2 {_relL2(a, a_old):.2e}"
+    # padded keys behind a scene: exact zeros in dK / dV, and the scene's results do not change with their number
+    for bi in range(1, B):
+        n = int(vl[bi])
+        assert float(res[1][2][bi, n:].float().abs().max() if n < Lk else 0.0) == 0.0
+        assert float(res[1][3][bi, n:].float().abs().max() if n < Lk else 0.0) == 0.0
+    if Lk >= 48:
+        Ls = Lk - 16     # scene 1 alone with fewer padded keys behind it (its valid keys fit: vl[1] <= 4/7 Lk)
+        assert int(vl[1]) <= Ls
+        qd, kd, vd = (t[1:2].to(DEV).bfloat16().requires_grad_(True) for t in (q, k[:, :Ls].contiguous(), v[:, :Ls].contiguous()))
+        o2 = ops.attention(qd, kd, vd, H=H, ct=BF16, zero_attn=za, kpm=kpm[1:2, :Ls].to(DEV))
+        o2.backward(go[1:2].to(DEV).bfloat16())
+        assert torch.equal(o2.detach(), res[1][0][1:2]) and torch.equal(qd.grad, res[1][1][1:2])
+        assert torch.equal(kd.grad, res[1][2][1:2, :Ls]) and torch.equal(vd.grad, res[1][3][1:2, :Ls])
+
+
 # ---------------------------------------------------------------------------------------------- resident backward
 def _relL2(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()

@@ -29,18 +29,20 @@ def case(name, B, Lq, Lk, H, d):
     kw = dict(kpm=(torch.arange(Lk)[None] >= vl[:, None]).to(dev))
     fwd = lambda: F._attn(q, k, v, o, lse, H, L.BF16, True, **kw)
     fwd()
-    res = []
-    for mode in (0, 1):
+    res, tf = [], []
+    for mode in (0, 1, 31):          # general two-kernel path | all-queries-resident backward | small cross-attention kernels
         lib.pq3d_attn_resident(mode)
+        tf.append(timeit(fwd))
         dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
         bwd = lambda: F._attn(q, k, v, o, lse, H, L.BF16, True, bwd=(do, dq, dk, dv, delta, None), **kw)
         t = timeit(bwd)
         res.append((t, dq.float().clone(), dk.float().clone(), dv.float().clone()))
-    lib.pq3d_attn_resident(1)
-    errs = [float((res[0][i] - res[1][i]).abs().max() / res[0][i].abs().max()) for i in (1, 2, 3)]
-    print(f"{name:34s} fwd {timeit(fwd):7.1f} us | bwd two-kernel {res[0][0]:7.1f} | resident {res[1][0]:7.1f} us | rel diff dq dk dv {errs[0]:.1e} {errs[1]:.1e} {errs[2]:.1e}", flush=True)
+    lib.pq3d_attn_resident(31)
+    errs = [float((res[0][i] - res[2][i]).abs().max() / res[0][i].abs().max()) for i in (1, 2, 3)]
+    print(f"{name:34s} fwd general {tf[0]:7.1f} | small {tf[2]:7.1f} us || bwd two-kernel {res[0][0]:7.1f} | resident {res[1][0]:7.1f} | small {res[2][0]:7.1f} us | rel diff dq dk dv {errs[0]:.1e} {errs[1]:.1e} {errs[2]:.1e}", flush=True)
 
 
 case("s2 cross B384 Lq80 Lk80 H12 dh64", 384, 80, 80, 12, 768)
 case("s2 prompt B128 Lq80 Lk32 H12 dh64", 128, 80, 32, 12, 768)
 case("c5p prompt B16 Lq100 Lk32 H8 dh32", 16, 100, 32, 8, 256)
+case("c5 caption x-attn B16 Lq32 Lk100 H8 dh64", 16, 32, 100, 8, 512)
