@@ -27,12 +27,19 @@ PQ_DEV void mmak(f32x4& acc, const bf16_t* pl, int row, int lg, const u32x4* b) 
 }
 // transposed fragment (A operand, m = d_h index c0 + li, k = tokens): slots 0..3 = tokens t0 + 4 lg + 0..3, slots 4..7 =
 // tokens t1 + 4 lg + 0..3 -- the token order in which two 16-token C tiles sit in a lane's registers
-PQ_DEV u32x4 frag_tr(const bf16_t* plane, int t0, int t1, int c0, int li, int lg) {
+// has2 (wave-uniform): the second tile exists -- the planes hold whole 16-row tiles, not whole pairs (80 tokens = 5 tiles: 46 KB
+// instead of 55 KB for the four planes of the shipped stage-2 shape, three workgroups per CU instead of two); an absent
+// tile reads as zeros
+PQ_DEV u32x4 frag_tr(const bf16_t* plane, int t0, int t1, int c0, int li, int lg, bool has2) {
   const bf16_t* p0 = plane + (t0 + 4 * lg + (li >> 2)) * LDH + c0 + 4 * (li & 3);
-  const bf16_t* p1 = plane + (t1 + 4 * lg + (li >> 2)) * LDH + c0 + 4 * (li & 3);
   const v4i16_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)p0);
-  const v4i16_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)p1);
-  const u32x2 x = __builtin_bit_cast(u32x2, a), y = __builtin_bit_cast(u32x2, b);
+  const u32x2 x = __builtin_bit_cast(u32x2, a);
+  u32x2 y = (u32x2){0, 0};
+  if (has2) {
+    const bf16_t* p1 = plane + (t1 + 4 * lg + (li >> 2)) * LDH + c0 + 4 * (li & 3);
+    const v4i16_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_t*)p1);
+    y = __builtin_bit_cast(u32x2, b);
+  }
   return (u32x4){x.x, x.y, y.x, y.y};
 }
 
@@ -58,41 +65,42 @@ struct CaLds {
   bf16_t *Q, *K, *V, *G;
   float *kb, *lse, *dl;   // additive key term (0 / -inf) [LPk]; lse, delta [LPq]
 };
-PQ_DEV CaLds carve(unsigned char* sm, int LPq, int LPk, bool bwd) {
+// planes: TQ / TK rows (whole 16-row tiles); float rows: LPq / LPk entries (whole pairs of tiles)
+PQ_DEV CaLds carve(unsigned char* sm, int TQ, int TK, int LPq, int LPk, bool bwd) {
   CaLds s;
   bf16_t* p = (bf16_t*)sm;
-  s.Q = p; p += LPq * LDH;
-  s.K = p; p += LPk * LDH;
-  s.V = p; p += LPk * LDH;
+  s.Q = p; p += TQ * LDH;
+  s.K = p; p += TK * LDH;
+  s.V = p; p += TK * LDH;
   s.G = nullptr;
-  if (bwd) { s.G = p; p += LPq * LDH; }
+  if (bwd) { s.G = p; p += TQ * LDH; }
   s.kb = (float*)p;
   s.lse = s.kb + LPk;
   s.dl = s.lse + LPq;
   return s;
 }
 size_t ca_lds_bytes(int Lq, int Lk, bool bwd) {
-  const size_t LPq = (Lq + 31) & ~31, LPk = (Lk + 31) & ~31;
-  return ((bwd ? 2 : 1) * LPq + 2 * LPk) * LDH * sizeof(bf16_t) + (LPk + 2 * LPq) * sizeof(float) + 16;
+  const size_t TQ = (Lq + 15) & ~15, TK = (Lk + 15) & ~15, LPq = (Lq + 31) & ~31, LPk = (Lk + 31) & ~31;
+  return ((bwd ? 2 : 1) * TQ + 2 * TK) * LDH * sizeof(bf16_t) + (LPk + 2 * LPq) * sizeof(float) + 16;
 }
 
 __global__ __launch_bounds__(CA_MAXT) void attn_ca_fwd_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   extern __shared__ __attribute__((aligned(16))) unsigned char ca_sm[];
-  const int Lq = d.Lq, Lk = d.Lk, LPq = (Lq + 31) & ~31, LPk = (Lk + 31) & ~31;
-  const CaLds S = carve(ca_sm, LPq, LPk, false);
+  const int Lq = d.Lq, Lk = d.Lk, LPq = (Lq + 31) & ~31, LPk = (Lk + 31) & ~31, TQ = (Lq + 15) & ~15, TK = (Lk + 15) & ~15;
+  const CaLds S = carve(ca_sm, TQ, TK, LPq, LPk, false);
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.y, h = blockIdx.x;
   const bf16_t* q = (const bf16_t*)d.q + (long)b * d.q_sb + (long)h * d.q_sh;
   const bf16_t* k = (const bf16_t*)d.k + (long)b * d.k_sb + (long)h * d.k_sh;
   const bf16_t* v = (const bf16_t*)d.v + (long)b * d.v_sb + (long)h * d.v_sh;
-  stage_rows<2>(S.Q, q, d.q_sl, Lq, LPq, tid, nthr);
-  stage_rows<2>(S.K, k, d.k_sl, Lk, LPk, tid, nthr);
-  stage_rows<2>(S.V, v, d.v_sl, Lk, LPk, tid, nthr);
+  stage_rows<2>(S.Q, q, d.q_sl, Lq, TQ, tid, nthr);
+  stage_rows<2>(S.K, k, d.k_sl, Lk, TK, tid, nthr);
+  stage_rows<2>(S.V, v, d.v_sl, Lk, TK, tid, nthr);
   for (int j = tid; j < LPk; j += nthr) S.kb[j] = (j < Lk && !(d.kpm && d.kpm[(long)b * Lk + j])) ? 0.f : -INFINITY;
   __syncthreads();
   const int q0 = wave * 16;
-  if (q0 >= ((Lq + 15) & ~15)) return;
+  if (q0 >= TQ) return;
   const int qrow = q0 + li;                       // this lane's query (column of the transposed score tiles)
   u32x4 qf[KS];
 #pragma unroll
@@ -103,9 +111,10 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_fwd_kernel(const pq3d_attn_de
 #pragma unroll
   for (int t = 0; t < OT; ++t) ot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int t0 = 0; t0 < LPk; t0 += 32) {
+    const bool has2 = t0 + 16 < TK;               // uniform: the pair's second key tile exists (else: -inf through kb)
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     mmak(s0, S.K, t0 + li, lg, qf);               // S^T = K Q^T: lane = query column, 4 consecutive keys per tile
-    mmak(s1, S.K, t0 + 16 + li, lg, qf);
+    if (has2) mmak(s1, S.K, t0 + 16 + li, lg, qf);
     const float4 kb0 = *(const float4*)&S.kb[t0 + 4 * lg], kb1 = *(const float4*)&S.kb[t0 + 16 + 4 * lg];
     const float kbv[8] = {kb0.x, kb0.y, kb0.z, kb0.w, kb1.x, kb1.y, kb1.z, kb1.w};
     float sv[8], mx = -INFINITY;
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_fwd_kernel(const pq3d_attn_de
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
       ot[t] *= alpha;
-      Mma<bf16_t>::mma(ot[t], frag_tr(S.V, t0, t0 + 16, 16 * t, li, lg), pf);   // O^T += V^T P^T
+      Mma<bf16_t>::mma(ot[t], frag_tr(S.V, t0, t0 + 16, 16 * t, li, lg, has2), pf);   // O^T += V^T P^T
     }
   }
   if (qrow < Lq) {
@@ -143,8 +152,8 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
   ATTN_KARG_PIN(d);
   ATTN_KARG_PIN_BWD(d);
   extern __shared__ __attribute__((aligned(16))) unsigned char ca_sm[];
-  const int Lq = d.Lq, Lk = d.Lk, LPq = (Lq + 31) & ~31, LPk = (Lk + 31) & ~31;   // whole PAIRS of 16-row tiles on both sides
-  const CaLds S = carve(ca_sm, LPq, LPk, true);
+  const int Lq = d.Lq, Lk = d.Lk, LPq = (Lq + 31) & ~31, LPk = (Lk + 31) & ~31, TQ = (Lq + 15) & ~15, TK = (Lk + 15) & ~15;
+  const CaLds S = carve(ca_sm, TQ, TK, LPq, LPk, true);
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.y, h = blockIdx.x;
   const bf16_t* q = (const bf16_t*)d.q + (long)b * d.q_sb + (long)h * d.q_sh;
@@ -181,15 +190,15 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
       }
     }
   }
-  stage_rows<2>(S.Q, q, d.q_sl, Lq, LPq, tid, nthr);
-  stage_rows<2>(S.G, g, d.o_sl, Lq, LPq, tid, nthr);
-  stage_rows<2>(S.K, k, d.k_sl, Lk, LPk, tid, nthr);
-  stage_rows<2>(S.V, v, d.v_sl, Lk, LPk, tid, nthr);
+  stage_rows<2>(S.Q, q, d.q_sl, Lq, TQ, tid, nthr);
+  stage_rows<2>(S.G, g, d.o_sl, Lq, TQ, tid, nthr);
+  stage_rows<2>(S.K, k, d.k_sl, Lk, TK, tid, nthr);
+  stage_rows<2>(S.V, v, d.v_sl, Lk, TK, tid, nthr);
   for (int j = tid; j < LPk; j += nthr) S.kb[j] = (j < Lk && !(d.kpm && d.kpm[(long)b * Lk + j])) ? 0.f : -INFINITY;
   __syncthreads();
   // ---------------- phase A: wave = query block; transposed tiles (lane = query column, 4 keys per tile per lane)
   const int q0 = wave * 16;
-  if (q0 < ((Lq + 15) & ~15)) {
+  if (q0 < TQ) {
     const int qrow = q0 + li;
     u32x4 qf[KS], gf[KS];
 #pragma unroll
@@ -199,12 +208,15 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
 #pragma unroll
     for (int t = 0; t < OT; ++t) at[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int t0 = 0; t0 < LPk; t0 += 32) {
+      const bool has2 = t0 + 16 < TK;                 // uniform: the pair's second key tile exists (else P = 0 through kb)
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
       f32x4 p0 = {ndl, ndl, ndl, ndl}, p1 = p0;       // dP - delta: the accumulators start at -delta
       mmak(s0, S.K, t0 + li, lg, qf);
-      mmak(s1, S.K, t0 + 16 + li, lg, qf);
       mmak(p0, S.V, t0 + li, lg, gf);                 // dP^T = V dO^T
-      mmak(p1, S.V, t0 + 16 + li, lg, gf);
+      if (has2) {
+        mmak(s1, S.K, t0 + 16 + li, lg, qf);
+        mmak(p1, S.V, t0 + 16 + li, lg, gf);
+      }
       const float4 kb0 = *(const float4*)&S.kb[t0 + 4 * lg], kb1 = *(const float4*)&S.kb[t0 + 16 + 4 * lg];
       const float kbv[8] = {kb0.x, kb0.y, kb0.z, kb0.w, kb1.x, kb1.y, kb1.z, kb1.w};
       float ds[8];
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
       }
       const u32x4 df = pack_frag<bf16_t>(ds);
 #pragma unroll
-      for (int t = 0; t < OT; ++t) Mma<bf16_t>::mma(at[t], frag_tr(S.K, t0, t0 + 16, 16 * t, li, lg), df);   // dQ^T += K^T dS^T
+      for (int t = 0; t < OT; ++t) Mma<bf16_t>::mma(at[t], frag_tr(S.K, t0, t0 + 16, 16 * t, li, lg, has2), df);   // dQ^T += K^T dS^T
     }
     if (qrow < Lq) {
       bf16_t* dq = (bf16_t*)d.dq + (long)b * d.q_sb + (long)h * d.q_sh + (long)qrow * d.q_sl;
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
   }
   // ---------------- phase B: wave = key block; plain tiles (lane = key column, 4 queries per tile per lane)
   const int k0 = wave * 16;
-  if (k0 >= ((Lk + 15) & ~15)) return;
+  if (k0 >= TK) return;
   const int krow = k0 + li;
   u32x4 kf[KS], vf[KS];
 #pragma unroll
@@ -242,10 +254,13 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
     const float4 e0 = *(const float4*)&S.dl[t0 + 4 * lg], e1 = *(const float4*)&S.dl[t0 + 16 + 4 * lg];
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 p0 = {-e0.x, -e0.y, -e0.z, -e0.w}, p1 = {-e1.x, -e1.y, -e1.z, -e1.w};   // dP - delta
+    const bool has2 = t0 + 16 < TQ;             // uniform: the pair's second query tile exists (else lse = +inf: P = 0)
     mmak(s0, S.Q, t0 + li, lg, kf);             // S = Q K^T
-    mmak(s1, S.Q, t0 + 16 + li, lg, kf);
     mmak(p0, S.G, t0 + li, lg, vf);             // dP = dO V^T
-    mmak(p1, S.G, t0 + 16 + li, lg, vf);
+    if (has2) {
+      mmak(s1, S.Q, t0 + 16 + li, lg, kf);
+      mmak(p1, S.G, t0 + 16 + li, lg, vf);
+    }
     const float ls[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
     float p[8], ds[8];
 #pragma unroll
@@ -257,8 +272,8 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
     const u32x4 pf = pack_frag<bf16_t>(p), df = pack_frag<bf16_t>(ds);
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
-      Mma<bf16_t>::mma(dvt[t], frag_tr(S.G, t0, t0 + 16, 16 * t, li, lg), pf);   // dV^T += dO^T P
-      Mma<bf16_t>::mma(dkt[t], frag_tr(S.Q, t0, t0 + 16, 16 * t, li, lg), df);   // dK^T += Q^T dS
+      Mma<bf16_t>::mma(dvt[t], frag_tr(S.G, t0, t0 + 16, 16 * t, li, lg, has2), pf);   // dV^T += dO^T P
+      Mma<bf16_t>::mma(dkt[t], frag_tr(S.Q, t0, t0 + 16, 16 * t, li, lg, has2), df);   // dK^T += Q^T dS
     }
   }
   if (krow < Lk) {
