@@ -13,8 +13,8 @@
 //             dQ^T += K^T dS^T; phase B (wave = key block) the same tiles in the S orientation for dV^T += dO^T P and
 //             dK^T += Q^T dS.  S and dP are formed twice (a few dozen MFMAs per wave); every output has one writer.
 // Same rounding points as the general bf16 kernels (P and dS rounded to bf16 for the second products, fp32 accumulate,
-// fp32 softmax); key padding through an additive 0 / -inf row; 3-D masks, attention dropout, additive bias and key splits
-// stay on the general kernels.  The launch is bound by HBM: 82 KB of operands and results per (scene, head) at 80 x 80 x 64.
+// fp32 softmax); key padding through an additive 0 / -inf row; attention dropout from the counter-based generator (the
+// masks of the general kernels: same site rows / columns); 3-D masks, additive bias and key splits stay on the general kernels.  The launch is bound by HBM: 82 KB of operands and results per (scene, head) at 80 x 80 x 64.
 #include <atomic>
 #include <cstdlib>
 
@@ -44,7 +44,8 @@ bool ca_al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // false when the call is not of that shape (the general / resident kernels run instead).
 bool pq3d_attn_ca_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd) {
   if (d.ct != PQ3D_BF16 || d.dt != PQ3D_BF16 || (d.dh != 32 && d.dh != 64)) return false;
-  if (d.mask || d.bias || d.dbias || (d.drop.p > 0.f && d.drop.seed) || d.ksplit > 1 || d.proj.mode != PQ3D_ATTN_PROJ_NONE) return false;
+  if (d.mask || d.bias || d.dbias || d.ksplit > 1 || d.proj.mode != PQ3D_ATTN_PROJ_NONE) return false;
+  const bool dr = d.drop.p > 0.f && d.drop.seed;
   if (d.Lq < 1 || d.Lk < 1 || d.Lq > 128 || d.Lk > 128) return false;
   // 16-byte row accesses: strides and bases of q / k / v / o (/ their gradients)
   if ((d.q_sl | d.k_sl | d.v_sl | d.o_sl | d.q_sb | d.k_sb | d.v_sb | d.o_sb | d.q_sh | d.k_sh | d.v_sh | d.o_sh) & 7) return false;
@@ -58,8 +59,13 @@ bool pq3d_attn_ca_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd) {
     if (pq3d_enable_big_lds(KERN, 160 * 1024, done)) { (void)hipGetLastError(); return false; }      \
     hipLaunchKernelGGL(KERN, dim3(d.H, d.B), dim3(blocks * 64), lds, s, d);                          \
   } while (0)
-  if (d.dh == 32) { if (bwd) CA_LAUNCH(ca32::attn_ca_bwd_kernel); else CA_LAUNCH(ca32::attn_ca_fwd_kernel); }
-  else { if (bwd) CA_LAUNCH(ca64::attn_ca_bwd_kernel); else CA_LAUNCH(ca64::attn_ca_fwd_kernel); }
+  if (d.dh == 32) {
+    if (bwd) { if (dr) CA_LAUNCH(ca32::attn_ca_bwd_kernel<true>); else CA_LAUNCH(ca32::attn_ca_bwd_kernel<false>); }
+    else { if (dr) CA_LAUNCH(ca32::attn_ca_fwd_kernel<true>); else CA_LAUNCH(ca32::attn_ca_fwd_kernel<false>); }
+  } else {
+    if (bwd) { if (dr) CA_LAUNCH(ca64::attn_ca_bwd_kernel<true>); else CA_LAUNCH(ca64::attn_ca_bwd_kernel<false>); }
+    else { if (dr) CA_LAUNCH(ca64::attn_ca_fwd_kernel<true>); else CA_LAUNCH(ca64::attn_ca_fwd_kernel<false>); }
+  }
 #undef CA_LAUNCH
   return true;
 }

@@ -84,6 +84,21 @@ size_t ca_lds_bytes(int Lq, int Lk, bool bwd) {
   return ((bwd ? 2 : 1) * TQ + 2 * TK) * LDH * sizeof(bf16_t) + (LPk + 2 * LPq) * sizeof(float) + 16;
 }
 
+// keep factors (0 / 1) of the 8 probabilities a lane holds for one row of the dropout site and the key columns c0 .. c0 + 3,
+// c0 + 16 .. c0 + 19 (c0 % 4 == 0: two hash words per 4 columns)
+PQ_DEV void drop_keep8(const DropState& dst, uint32_t row, int c0, float* kf) {
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const uint32_t cp = (uint32_t)(c0 + 16 * hh) >> 1;
+    const uint32_t w0 = drop_word(dst, row, cp), w1 = drop_word(dst, row, cp + 1);
+    kf[4 * hh + 0] = drop_keep_lo(dst, w0) ? 1.f : 0.f;
+    kf[4 * hh + 1] = drop_keep_hi(dst, w0) ? 1.f : 0.f;
+    kf[4 * hh + 2] = drop_keep_lo(dst, w1) ? 1.f : 0.f;
+    kf[4 * hh + 3] = drop_keep_hi(dst, w1) ? 1.f : 0.f;
+  }
+}
+
+template <bool DROP>
 __global__ __launch_bounds__(CA_MAXT) void attn_ca_fwd_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   extern __shared__ __attribute__((aligned(16))) unsigned char ca_sm[];
@@ -107,6 +122,12 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_fwd_kernel(const pq3d_attn_de
   for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_rm(S.Q, qrow, lg, ks);
   // the zero key of add_zero_attn (logit exactly 0, value 0) is the initial state of the online softmax
   float m_run = d.zero_attn ? 0.f : -INFINITY, l_run = d.zero_attn ? 1.f : 0.f;
+  DropState dst;
+  uint32_t drow = 0;
+  if constexpr (DROP) {   // attention-probability dropout: the site is the matrix [B H Lq, Lk] (pq3d_hip.h)
+    dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, Lk);
+    drow = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * Lq + min(qrow, Lq - 1));
+  }
   f32x4 ot[OT];   // O^T: tile t = rows d_h 16 t + 4 lg + r, column = query
 #pragma unroll
   for (int t = 0; t < OT; ++t) ot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -131,6 +152,12 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_fwd_kernel(const pq3d_attn_de
     for (int j = 0; j < 8; ++j) { p[j] = __expf(sv[j] - m_use); ps += p[j]; }
     l_run = l_run * alpha + xrow_sum(ps);
     m_run = m_new;
+    if constexpr (DROP) {   // the softmax denominator keeps every key; only the value contraction sees the mask
+      float kf[8];
+      drop_keep8(dst, drow, t0 + 4 * lg, kf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] *= kf[j];
+    }
     const u32x4 pf = pack_frag<bf16_t>(p);
 #pragma unroll
     for (int t = 0; t < OT; ++t) {
@@ -139,7 +166,7 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_fwd_kernel(const pq3d_attn_de
     }
   }
   if (qrow < Lq) {
-    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    const float inv = l_run > 0.f ? (DROP ? dst.scale : 1.f) / l_run : 0.f;
     bf16_t* o = (bf16_t*)d.o + (long)b * d.o_sb + (long)h * d.o_sh + (long)qrow * d.o_sl;
 #pragma unroll
     for (int t = 0; t < OT; ++t)
@@ -148,6 +175,7 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_fwd_kernel(const pq3d_attn_de
   }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   ATTN_KARG_PIN_BWD(d);
@@ -196,6 +224,12 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
   stage_rows<2>(S.V, v, d.v_sl, Lk, TK, tid, nthr);
   for (int j = tid; j < LPk; j += nthr) S.kb[j] = (j < Lk && !(d.kpm && d.kpm[(long)b * Lk + j])) ? 0.f : -INFINITY;
   __syncthreads();
+  DropState dst;
+  uint32_t drow0 = 0;     // site row of query 0 of this (scene, head)
+  if constexpr (DROP) {
+    dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, Lk);
+    drow0 = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * Lq);
+  }
   // ---------------- phase A: wave = query block; transposed tiles (lane = query column, 4 keys per tile per lane)
   const int q0 = wave * 16;
   if (q0 < TQ) {
@@ -210,7 +244,8 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
     for (int t0 = 0; t0 < LPk; t0 += 32) {
       const bool has2 = t0 + 16 < TK;                 // uniform: the pair's second key tile exists (else P = 0 through kb)
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 p0 = {ndl, ndl, ndl, ndl}, p1 = p0;       // dP - delta: the accumulators start at -delta
+      const float pin = DROP ? 0.f : ndl;             // dP - delta: without dropout the accumulators start at -delta
+      f32x4 p0 = {pin, pin, pin, pin}, p1 = p0;
       mmak(s0, S.K, t0 + li, lg, qf);
       mmak(p0, S.V, t0 + li, lg, gf);                 // dP^T = V dO^T
       if (has2) {
@@ -219,12 +254,15 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
       }
       const float4 kb0 = *(const float4*)&S.kb[t0 + 4 * lg], kb1 = *(const float4*)&S.kb[t0 + 16 + 4 * lg];
       const float kbv[8] = {kb0.x, kb0.y, kb0.z, kb0.w, kb1.x, kb1.y, kb1.z, kb1.w};
-      float ds[8];
+      float ds[8], kf[8];
+      if constexpr (DROP) drop_keep8(dst, drow0 + (uint32_t)min(qrow, Lq - 1), t0 + 4 * lg, kf);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float sv = (j < 4 ? s0[j] : s1[j - 4]) * d.scale + kbv[j];
         const float p = __expf(sv - lse);                        // masked / padded: exp(-inf) = 0
-        ds[j] = p * (j < 4 ? p0[j] : p1[j - 4]);
+        const float dp = j < 4 ? p0[j] : p1[j - 4];
+        if constexpr (DROP) ds[j] = p * (dp * (kf[j] * dst.scale) + ndl);   // dS = P (dP keep / (1 - p) - delta)
+        else ds[j] = p * dp;
       }
       const u32x4 df = pack_frag<bf16_t>(ds);
 #pragma unroll
@@ -254,6 +292,7 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
     const float4 e0 = *(const float4*)&S.dl[t0 + 4 * lg], e1 = *(const float4*)&S.dl[t0 + 16 + 4 * lg];
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 p0 = {-e0.x, -e0.y, -e0.z, -e0.w}, p1 = {-e1.x, -e1.y, -e1.z, -e1.w};   // dP - delta
+    if constexpr (DROP) { p0 = (f32x4){0.f, 0.f, 0.f, 0.f}; p1 = p0; }
     const bool has2 = t0 + 16 < TQ;             // uniform: the pair's second query tile exists (else lse = +inf: P = 0)
     mmak(s0, S.Q, t0 + li, lg, kf);             // S = Q K^T
     mmak(p0, S.G, t0 + li, lg, vf);             // dP = dO V^T
@@ -262,12 +301,21 @@ __global__ __launch_bounds__(CA_MAXT) void attn_ca_bwd_kernel(const pq3d_attn_de
       mmak(p1, S.G, t0 + 16 + li, lg, vf);
     }
     const float ls[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    const float dl[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
     float p[8], ds[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float sv = (j < 4 ? s0[j] : s1[j - 4]) * d.scale + kbias;
+      const float dp = j < 4 ? p0[j] : p1[j - 4];
       p[j] = __expf(sv - ls[j]);
-      ds[j] = p[j] * (j < 4 ? p0[j] : p1[j - 4]);
+      if constexpr (DROP) {
+        const int qr = min(t0 + (j < 4 ? 0 : 16) + 4 * lg + (j & 3), Lq - 1);
+        const float kc = drop_keep(dst, drow0 + (uint32_t)qr, (uint32_t)min(krow, Lk - 1)) ? dst.scale : 0.f;
+        ds[j] = p[j] * (dp * kc - dl[j]);
+        p[j] *= kc;                               // dV sees the dropped, rescaled probabilities
+      } else {
+        ds[j] = p[j] * dp;
+      }
     }
     const u32x4 pf = pack_frag<bf16_t>(p), df = pack_frag<bf16_t>(ds);
 #pragma unroll

@@ -115,6 +115,42 @@ def test_attention_dropout_fp32(Lq, Lk, zero):
     assert (o0 - o).abs().max().item() > 1e-3
 
 
+@pytest.mark.parametrize("B,Lq,Lk,H,dh,zero", [(6, 80, 80, 12, 64, True), (4, 80, 32, 12, 64, True), (3, 100, 32, 8, 32, False),
+                                                (2, 17, 5, 2, 32, True)])
+def test_attention_dropout_small_cross_bf16(B, Lq, Lk, H, dh, zero):
+    """attn_ca.hip with the probability dropout fused in: the masks of the general kernels (same site rows / columns) --
+    against torch on the same bf16 inputs with the generator's keep mask, and against the general kernels."""
+    torch.manual_seed(Lq * 100 + Lk)
+    d, p = H * dh, 0.2
+    seed = seed_tensor(123)
+    q, k, v = (torch.randn(B, L_, d, device=DEV).bfloat16() for L_ in (Lq, Lk, Lk))
+    kpm = torch.zeros(B, Lk, dtype=torch.bool, device=DEV)
+    kpm[1, max(1, Lk // 2):] = True
+    g = torch.randn(B, Lq, d, device=DEV).bfloat16()
+    lib = L.lib()
+    res = {}
+    for ca in (1, 0):
+        old = lib.pq3d_attn_resident((16 if ca else 0) | 15)
+        try:
+            qd, kd, vd = (t.clone().requires_grad_(True) for t in (q, k, v))
+            o = ops.attention(qd, kd, vd, H=H, ct=L.BF16, zero_attn=zero, kpm=kpm, drop=L.Drop(p, 21, seed))
+            o.backward(g)
+            res[ca] = (o.detach().float(), qd.grad.float(), kd.grad.float(), vd.grad.float())
+        finally:
+            lib.pq3d_attn_resident(old)
+    keep = keep_of(p, 21, seed, (B * H * Lq, Lk))
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = torch_attention(qr, kr, vr, H, kpm, zero, keep.double(), p)
+    ref.backward(g.double())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+    for n, a, a_old, r in zip(("o", "dq", "dk", "dv"), res[1], res[0], (ref, qr.grad, kr.grad, vr.grad)):
+        assert torch.isfinite(a).all(), n
+        assert rel(a, r) <= 2e-2, f"{n}: vs torch relL2 {rel(a, r):.2e}"
+        assert rel(a, a_old) <= 2e-2, f"{n}: vs general kernels relL2 {rel(a, a_old):.2e}"
+    o0 = ops.attention(q, k, v, H=H, ct=L.BF16, zero_attn=zero, kpm=kpm)
+    assert (o0.float() - res[1][0]).abs().max().item() > 1e-3     # p > 0 really changes the result
+
+
 def test_attention_dropout_stacked_equals_separate_bf16():
     """drop_bmod: memories stacked along the batch draw the masks of the per-memory launches (fused == modular)."""
     from pq3d_amd import fused as F
