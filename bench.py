@@ -521,7 +521,10 @@ def main():
         enc.grads_ready, enc.grad_bucket_per_layer = None, False
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # with a process group alive its watchdog thread polls events of earlier collectives (hipEventQuery): under the
+            # default 'global' capture mode that aborts the process ("operation not permitted when stream is capturing",
+            # seen once in four runs of the one-rank RCCL test) -- captures next to RCCL are thread-local / relaxed
+            with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if dist_on else {})):
                 fwd_bwd()
 
             def run():
@@ -636,7 +639,7 @@ def main():
             "roofline_next": blocks[1:],
             "kernel_families_ms_per_step": {k: round(v["ms"] / ps, 4) for k, v in sorted(fams.items())},
         }
-        if world == 1 and not args.headline_only:
+        if world == 1 and not dist_on and not args.headline_only:
             # the same step launched eagerly (no HIP graph): what a trainer that cannot capture graphs would see
             def timed_loop(fn, n):
                 torch.cuda.synchronize()
@@ -715,7 +718,7 @@ def main():
                     "optimizer": "AdamW(betas=(0.9,0.98), wd 0.01) + clip_grad_norm_(80) + warmup_cosine, 3 kernels on "
                                  "one flat fp32 buffer", "params": int(ts.flat_p.numel()),
                     "finite": bool(torch.isfinite(ts.flat_p).all())}
-        if world == 1 and "generation" in c["heads"] and not args.headline_only:
+        if world == 1 and not dist_on and "generation" in c["heads"] and not args.headline_only:
             # the third-party body alone (fwd + bwd of the head on a detached query), eager
             gh = model.generation_head
             qd = torch.randn(c["B"], c["Nq"], c["d"], device=dev, requires_grad=True)
@@ -729,7 +732,7 @@ def main():
                                  "impl": "T5-small decoder (random init, HF parameter layout) restated on the HIP kernels "
                                          "(pq3d_amd/t5.py) + input_proj; teacher-forced, T_r = %d" % c["Tr"],
                                  "params": sum(p.numel() for p in gh.parameters())}
-        if world == 1 and args.cpu_steps > 0:
+        if world == 1 and not dist_on and args.cpu_steps > 0:
             hf_body = None
             if "generation" in c["heads"]:
                 import copy
