@@ -360,6 +360,56 @@ def mean_all(x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ linear
+# ---- deferred weight gradients of a whole-pass gradient arena ------------------------------------------------------------
+# Inside ``with ops.grad_arena(...)`` every dW = g^T (x [+ x2]) of an arena-aware linear layer only feeds its slot of the flat
+# gradient buffer, so nothing waits for it: the products are queued per (shape, dtype) bucket and launched as a few GROUPED
+# split-K launches when the pass ends (grad_arena.__exit__) instead of one launch per layer -- the caption body's 46 launches of
+# [512 x 512] / [2048 x 512] products over 512 rows at config 5 are latency chains of ~15 us each.  The decoder's own backward
+# has done the same for its layers since round 1 (fused._DwQueue); this is the same idea for everything that goes through
+# ops.linear / ops.linear_group around it.
+class _DwDeferred:
+    buckets = {}     # (N, K, R, g dtype, x dtype, has x2, has bias, ct) -> lists
+
+
+_DW_DEFER = True    # module switch for A/B measurements (tools/probes/bench_nodefer.py)
+
+
+def _dw_can_defer(g, x, x2, N, K) -> bool:
+    if not _DW_DEFER or not _Arena.whole_pass or _Arena.mode is None:
+        return False
+    return not ((x2 is not None and (x2.dtype != torch.float32 or x.dtype != torch.float32)) or N % 8 or K % 8 or
+                g.data_ptr() % 16 or x.data_ptr() % 16 or (x2 is not None and x2.data_ptr() % 16) or
+                not g.is_contiguous() or not x.is_contiguous())
+
+
+def _dw_defer(g, x, x2, dw, db, N, K, R, ct) -> bool:
+    """Queue dw[N, K] += g^T (x [+ x2]) (and db[N] += column sums of g); False when the pass has no whole-pass arena."""
+    if not _dw_can_defer(g, x, x2, N, K):
+        return False
+    key = (N, K, R, g.dtype, x.dtype, x2 is not None, db is not None, ct)
+    b = _DwDeferred.buckets.setdefault(key, ([], [], [], [], []))
+    # the queue keeps its OWN view objects of the slots: AccumulateGrad adopts the returned gradient without a copy only when
+    # nobody else references that tensor object (arena_take) -- a second reference would turn .grad into a clone of zeros
+    b[0].append(g); b[1].append(x); b[2].append(x2); b[3].append(dw.view(N, K)); b[4].append(db.view(-1) if db is not None else None)
+    return True
+
+
+def dw_deferred_flush(run: bool = True) -> None:
+    buckets, _DwDeferred.buckets = _DwDeferred.buckets, {}
+    if not run:
+        return
+    for (N, K, R, _gd, _xd, has2, hasb, ct), (gs, xs, x2s, dws, dbs) in buckets.items():
+        tiles = ((N + 63) // 64) * ((K + 63) // 64)
+        ga, xa, x2a = dw_operands(gs, xs, x2s if has2 else None, N, K, R, ct)
+        for i in range(0, len(ga), L.MAXG):
+            n = len(ga[i:i + L.MAXG])
+            nkt = max(1, R // (64 if ct == BF16 else 32))
+            sk = max(1, min(nkt // 2 if nkt >= 2 else 1, max(1, 768 // max(tiles * n, 1)), 64))
+            L.gemm(M=N, N=K, K=R, A=ga[i:i + L.MAXG], B=xa[i:i + L.MAXG], B2=x2a[i:i + L.MAXG] if x2a is not None else None,
+                   Cs=dws[i:i + L.MAXG], ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True, splitk=max(2, sk),
+                   accumulate=True, colsum=dbs[i:i + L.MAXG] if hasb else None)
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value, drop=None, residual=None):
@@ -422,14 +472,16 @@ class _Linear(Function):
                 (x2 is None or x.dtype == torch.float32)
             # the owner's gradient arena, when offered for this pass: accumulate straight into the slots (pre-zeroed)
             slot, give = arena_take([ctx.pptr[0]] + ([ctx.pptr[1]] if fuse else []), [N * K] + ([N] if fuse else []))
-            ga, xa, x2a = dw_operands([g], [x], [x2], N, K, R, ct)   # long reductions: bf16 operands, 128 x 128 tiles
             if slot is not None:
                 dw, give_w = slot[0].view(N, K), give
                 if fuse:
                     db = slot[1]
-                L.gemm(M=N, N=K, K=R, A=ga, B=xa, B2=x2a, Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
-                       splitk=max(2, _splitk(tiles, R, ct)), colsum=[db] if fuse else None, accumulate=True, alpha=alpha)
+                if not (alpha == 1.0 and _dw_defer(g, x, x2, dw, db if fuse else None, N, K, R, ct)):   # else: queued until the pass ends
+                    ga, xa, x2a = dw_operands([g], [x], [x2], N, K, R, ct)   # long reductions: bf16 operands, 128 x 128 tiles
+                    L.gemm(M=N, N=K, K=R, A=ga, B=xa, B2=x2a, Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
+                           splitk=max(2, _splitk(tiles, R, ct)), colsum=[db] if fuse else None, accumulate=True, alpha=alpha)
             else:
+                ga, xa, x2a = dw_operands([g], [x], [x2], N, K, R, ct)   # long reductions: bf16 operands, 128 x 128 tiles
                 dw = _empty(N, K, dtype=torch.float32, device=x.device)
                 if fuse:
                     db = _empty(N, dtype=torch.float32, device=x.device)
@@ -554,6 +606,10 @@ class _LinearGroup(Function):
             dWb = torch.zeros(G, N, K, dtype=torch.float32, device=dev)
             dWs = [dWb[g] for g in range(G)]
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
+        if slot is not None and all(_dw_can_defer(gs[g], xs[g], None, N, K) for g in range(G)):
+            for g in range(G):
+                _dw_defer(gs[g], xs[g], None, dWs[g], None, N, K, R, ct)
+            return (None, None, None, *dxs, *(dWs if give else [None] * G))   # queued until the pass ends
         gs, xs_, _ = dw_operands(list(gs), list(xs), None, N, K, R, ct)
         for s in range(0, G, L.MAXG):
             e = min(G, s + L.MAXG)
@@ -1158,6 +1214,7 @@ class grad_arena:
     def __exit__(self, *exc):
         self.multi, self.by_ptr = set(_Arena.multi), dict(_Arena.by_ptr)
         try:
+            dw_deferred_flush(run=exc[0] is None)   # the queued weight-gradient products of the pass: a few grouped launches
             if exc[0] is None:
                 arena_flush_zero()    # nobody consumed it: the owner still expects zeroed buffers
                 arena_verify()
