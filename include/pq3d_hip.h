@@ -228,7 +228,8 @@ int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
  *   bit 4: the small bf16 cross-attention kernels (csrc/attn_ca.hip): bf16 storage and compute, d_h 32 / 64, at most 128
  *          queries AND 128 keys per (scene, head), key padding / zero key only -- the shipped stage-2 decoder's attention
  *          over <= 80 objects per memory and its prompt tokens; one workgroup per (scene, head), no atomics.
- * This process-wide switch sets which of them may be used (default 31 = all; for A/B measurements and tests) and returns
+ *   bit 5: the all-keys-resident forward also for key-split calls (a longer scene as slices of <= 1024 keys; config 5).
+ * This process-wide switch sets which of them may be used (default 63 = all; for A/B measurements and tests) and returns
  * the previous value. */
 int pq3d_attn_resident(int enable);
 

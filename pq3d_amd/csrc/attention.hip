@@ -28,17 +28,19 @@ bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // at
 bool pq3d_attn_small_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);   // attn_small.hip
 bool pq3d_attn_sa_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);      // attn_sa.hip
 bool pq3d_attn_ca_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);      // attn_ca.hip
-static int g_resident = 1, g_small = 1, g_resfwd = 1, g_sa = 1, g_ca = 1;
+static int g_resident = 1, g_small = 1, g_resfwd = 1, g_sa = 1, g_ca = 1, g_resfwd_split = 1;
+bool pq3d_resfwd_split_allowed() { return g_resfwd_split != 0; }
 // bit 0: all-queries-resident backward, bit 1: small-sequence fp32 kernels, bit 2: all-keys-resident forward, bit 3: the
 // split-bf16 MFMA self-attention kernels for compute type PQ3D_BF16X3, bit 4: the small bf16 cross-attention kernels
-// (all on by default)
+// bit 5: the all-keys-resident forward also for key-split calls (slices of <= 1024 keys of a longer scene) (all on by default)
 extern "C" int pq3d_attn_resident(int enable) {
-  const int old = g_resident | (g_small << 1) | (g_resfwd << 2) | (g_sa << 3) | (g_ca << 4);
+  const int old = g_resident | (g_small << 1) | (g_resfwd << 2) | (g_sa << 3) | (g_ca << 4) | (g_resfwd_split << 5);
   g_resident = enable & 1;
   g_small = (enable >> 1) & 1;
   g_resfwd = (enable >> 2) & 1;
   g_sa = (enable >> 3) & 1;
   g_ca = (enable >> 4) & 1;
+  g_resfwd_split = (enable >> 5) & 1;   // the all-keys-resident forward also for key-split calls of > 1024 keys
   return old;
 }
 

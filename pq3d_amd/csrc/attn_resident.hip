@@ -694,6 +694,7 @@ template <bool DROP> void launch_fwd_res(const pq3d_attn_desc& d, hipStream_t s,
 // Forward twin of the resident backward: bf16, d_h = 32, N_q <= 128, key-padding mask only, at most 1024 keys per
 // (scene, head, split) workgroup.  Returns false otherwise (attention.hip's streaming forward); for ksplit > 1 the caller
 // launches the combine kernel exactly as for the streaming kernel.
+bool pq3d_resfwd_split_allowed();   // attention.hip: pq3d_attn_resident bit 5
 bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
   if (d.ct != PQ3D_BF16 || d.dt != PQ3D_BF16 || d.bias || d.mask || d.dh != 32) return false;
   if (d.Lq > 128 || d.Lk < 128) return false;
@@ -702,9 +703,10 @@ bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
   const int KS = d.ksplit > 1 ? d.ksplit : 1, nkb = (d.Lk + KB - 1) / KB;
   const int nb_max = (nkb + KS - 1) / KS;   // ceil: the largest slice
   if (nb_max * KB > FKMAX) return false;
-  // with a key split the streaming kernel is as fast or faster (config 5, 2048 keys: 58 us vs 63-76 us): its workgroups
-  // overlap across splits, this one's slice loads do not; explicit splits of <= 1024 keys still run here (tests)
-  if (KS > 1 && d.Lk > FKMAX) return false;
+  // key-split calls of longer scenes (config 5: 2048 keys as two slices of 1024): measured in isolation in round 2 the streaming
+  // kernel was as fast (58 us against 63-76 us); in the step it is 75 + 6 us against this kernel, and the step says 6.535 ->
+  // 6.463 ms with the slices here (tools/probes/ab_resfwd_split.sh) -- on by default since round 4, switch: pq3d_attn_resident bit 5
+  if (KS > 1 && d.Lk > FKMAX && !pq3d_resfwd_split_allowed()) return false;
   if (d.drop.p > 0.f && d.drop.seed) launch_fwd_res<true>(d, s, KS, nb_max * KB);
   else launch_fwd_res<false>(d, s, KS, nb_max * KB);
   return true;

@@ -37,7 +37,7 @@ def case(name, B, Lq, Lk, H, d):
         bwd = lambda: F._attn(q, k, v, o, lse, H, L.BF16, True, bwd=(do, dq, dk, dv, delta, None), **kw)
         t = timeit(bwd)
         res.append((t, dq.float().clone(), dk.float().clone(), dv.float().clone()))
-    lib.pq3d_attn_resident(31)
+    lib.pq3d_attn_resident(63)
     errs = [float((res[0][i] - res[2][i]).abs().max() / res[0][i].abs().max()) for i in (1, 2, 3)]
     print(f"{name:34s} fwd general {tf[0]:7.1f} | small {tf[2]:7.1f} us || bwd two-kernel {res[0][0]:7.1f} | resident {res[1][0]:7.1f} | small {res[2][0]:7.1f} us | rel diff dq dk dv {errs[0]:.1e} {errs[1]:.1e} {errs[2]:.1e}", flush=True)
 
