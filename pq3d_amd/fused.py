@@ -669,7 +669,14 @@ class _FusedDecoder(Function):
 
         ready_cb = getattr(enc, "grads_ready", None) if in_place else None   # only when the owner's buffers were written
         per_layer = bool(getattr(enc, "grad_bucket_per_layer", False)) and ready_cb is not None
-        ready = ready_cb if ready_cb is not None else (lambda tag: None)
+        if ready_cb is not None:
+            def ready(tag):
+                # weight gradients queued by ops.linear layers that ran backward BEFORE the decoder (heads; ops._DwDeferred)
+                # must be in their slots before an owner is told that a bucket is final
+                ops.dw_deferred_flush()
+                ready_cb(tag)
+        else:
+            ready = lambda tag: None
 
         def kv_terms(apps, into_queue):
             """(dK|dV, W) operand lists of the hoisted K/V projections' backward for the applications `apps`; with
