@@ -630,6 +630,9 @@ def main():
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
                        "step_mode": step_mode,
                        "dropout": 0.0 if args.dropout == "off" else "reference train mode (0.1 / heads 0.1, 0.3)",
+                       # the caption body keeps the HF config's dropout_rate under model.train() in BOTH dropout settings
+                       # (pq3d_amd/t5.py: the reference never overrides it) -- extra work inside the timed step, stated here
+                       **({"caption_body_dropout": "0.1 (T5 config dropout_rate, live: model.train())"} if "generation" in c["heads"] else {}),
                        "activation": "relu"},
             "step_algorithmic_gflop": flops / 1e9,
             "step_roofline_frac": flops * world / (dt / args.steps) / (peak * 1e12 * world),
