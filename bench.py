@@ -390,13 +390,19 @@ def main():
     lay_ids = [{id(p) for p in l.parameters()} for l in layers]
     mh_ids = {id(p) for p in model.mask_head.parameters()} if hasattr(model, "mask_head") else set()
     dec_ids = set().union(*lay_ids) | mh_ids
+    # (An own, early bucket for the output heads behind the decoder -- they run backward FIRST, config 5: 200 MB -- was tried
+    # and checked with the per-bucket fingerprints of the JSON: the grounding head's bucket came out all zeros and the caption
+    # body's 1 % short, because pack() skips buckets in flight and not every head gradient is written in place through the
+    # arena.  tools/probes/heads_early_check.sh at commit "early heads bucket")
+    head_ids = set()
     groups = [[p for p in params if id(p) in lay_ids[i]] for i in reversed(range(len(layers)))]
-    groups += [[p for p in params if id(p) in mh_ids], [p for p in params if id(p) not in dec_ids]]
+    groups += [[p for p in params if id(p) in mh_ids], [p for p in params if id(p) in head_ids],
+               [p for p in params if id(p) not in dec_ids and id(p) not in head_ids]]
     n_layer_buckets = len(layers)
     keep = [bool(g) for g in groups]
     bucket_of = [sum(keep[:j]) for j in range(len(groups))]            # index after dropping empty groups
     reducer = FlatGradAllReducer(params, groups=[g for g in groups if g])
-    dec_buckets = [bucket_of[j] for j in range(n_layer_buckets + 1) if keep[j]]
+    dec_buckets = [bucket_of[j] for j in range(n_layer_buckets + 2) if keep[j]]   # layers, mask head, (early) heads
     enc.grad_arena = reducer.slots()
     enc.grad_arena_buffers = list(reducer.flat)   # all of them: the encoders' backward writes its slots in place too
     reducer.force_collectives = dist_on and world == 1
@@ -570,6 +576,7 @@ def main():
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
         grads_identical = bool(torch.equal(lo, hi)) and bool(torch.isfinite(fp).all()) and bool((fp[1::2] > 0).all())
+        grad_fingerprint = [[float(fp[2 * i]), float(fp[2 * i + 1])] for i in range(len(reducer.flat))]
 
     result = None
     if rank == 0:
@@ -636,7 +643,8 @@ def main():
                        "activation": "relu"},
             "step_algorithmic_gflop": flops / 1e9,
             "step_roofline_frac": flops * world / (dt / args.steps) / (peak * 1e12 * world),
-            **({"grads_identical_across_ranks": grads_identical, "collective_backend": backend,
+            **({"grads_identical_across_ranks": grads_identical, "grad_fingerprint_per_bucket": grad_fingerprint,
+                "collective_backend": backend,
                 "rccl_ranks": (torch.distributed.get_world_size() if backend == "nccl" else 0)} if dist_on else {}),
             "roofline": roof,
             "roofline_next": blocks[1:],
