@@ -7,7 +7,8 @@ namespace {
 
 // ---------------------------------------------------------------- colsum
 // grid ceil(N/64); block 1024 = 16 row-lanes x 64 columns; each thread strides over rows with 4 independent loads in
-// flight, then a 16-way LDS tree.  No atomics, no memset: deterministic.
+// flight, then a 16-way LDS tree.  No atomics, no memset: deterministic -- except for long ACCUMULATING reductions (R >= 2048
+// rows into a running output: bias gradients into the gradient arena), which run as row slices that add atomically.
 struct ColsumPtrs { const void* x[PQ3D_MAX_GROUPS]; float* out[PQ3D_MAX_GROUPS]; };
 template <typename T>
 __global__ __launch_bounds__(1024) void colsum_kernel(const ColsumPtrs cp, long R, long N, long ld, int accumulate) {
@@ -17,6 +18,12 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const ColsumPtrs cp, long 
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const long col = (long)blockIdx.x * 64 + cx;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // row slices (gridDim.z > 1; accumulating calls only): a [10240, 768] gradient is 12 column blocks -- a handful of
+  // workgroups walking 10240 rows each (55 us at the shipped stage-2 shape); the slices add their partial sums atomically
+  const long rchunk = gridDim.z > 1 ? (((R + gridDim.z - 1) / gridDim.z + 15) & ~15L) : R;
+  const long r_lo = (long)blockIdx.z * rchunk;
+  x += r_lo * ld;
+  R = max(0L, min(R - r_lo, rchunk));
   if (col < N) {
     long r = ry;
     for (; r + 48 < R; r += 64) {
@@ -32,7 +39,8 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const ColsumPtrs cp, long 
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += part[k][cx];
-    out[col] = accumulate ? out[col] + t : t;
+    if (gridDim.z > 1) unsafeAtomicAdd(&out[col], t);
+    else out[col] = accumulate ? out[col] + t : t;
   }
 }
 
@@ -837,6 +845,12 @@ extern "C" int pq3d_colsum_grouped(const void* const* x, float* const* out, int3
   }
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((N + 63) / 64), groups);
+  if (accumulate && R >= 2048) {   // long columns into an accumulating (pre-zeroed / running) output: row slices, ~2 workgroups per CU
+    const long blocks = (long)grid.x * grid.y;
+    long nz = 512 / (blocks > 0 ? blocks : 1);
+    if (nz > R / 512) nz = R / 512;
+    if (nz > 1) grid.z = (unsigned)nz;
+  }
   if (dt == PQ3D_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(1024), 0, s, cp, (long)R, (long)N, (long)ld, accumulate);
   else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(1024), 0, s, cp, (long)R, (long)N, (long)ld, accumulate);
   PQ_LAUNCH_CHECK();

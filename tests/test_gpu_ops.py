@@ -423,6 +423,19 @@ def test_upsample_scatter_mean_skips_out_of_range_rows():
     assert torch.allclose(src.grad, g, atol=1e-6)
 
 
+def test_colsum_accumulate_long_reduction_row_slices():
+    """Bias gradients into the arena: long accumulating column sums run as row slices with atomic adds (misc.hip)."""
+    from pq3d_amd import fused as F
+    for R, N, G, dt in ((10240, 768, 3, torch.float32), (4099, 200, 2, torch.float32), (8192, 256, 4, torch.bfloat16), (600, 64, 2, torch.float32)):
+        xs = [rnd(R, N, seed=90 + g).to(DEV).to(dt) for g in range(G)]
+        base = [rnd(N, seed=190 + g).to(DEV) for g in range(G)]
+        outs = [b.clone() for b in base]
+        F._colsum_acc(xs, outs, R)
+        for x, b, o in zip(xs, base, outs):
+            ref = b.double() + x.double().sum(0)
+            assert float((o.double() - ref).abs().max()) <= 2e-3 * max(1.0, float(ref.abs().max())) * (8 if dt == torch.bfloat16 else 1) * 1e-1 + 1e-3
+
+
 # ---------------------------------------------------------------------------------------------- small bf16 cross-attention
 @pytest.mark.parametrize("za", [True, False])
 @pytest.mark.parametrize("B,Lq,Lk,H,dh", [(6, 80, 80, 12, 64), (4, 80, 32, 12, 64), (5, 100, 32, 8, 32), (3, 17, 5, 2, 32),
