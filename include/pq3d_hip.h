@@ -401,23 +401,39 @@ int pq3d_gate_mix_fwd(const float* q, const float* u, const float* g, float* y, 
 int pq3d_gate_mix_bwd(const float* q, const float* u, const float* g, const float* dy, float* dq, float* du,
                       float* dg, int64_t n, void* stream);
 
-/* Segment pooling torch_scatter.scatter_mean(src, index, dim=0, dim_size=S) (pcd_mask3d_encoder.py:149):
- * src [N,C] fp32, index int64 [N] -> out [S,C] fp32; count [S] fp32 workspace/output (number of voxels per
- * segment).  Backward: dsrc[v,:] = dout[index[v],:] / max(count,1). */
-int pq3d_scatter_mean_fwd(const float* src, const int64_t* index, float* out, float* count, int64_t N, int64_t C,
-                          int64_t S, void* stream);
-int pq3d_scatter_mean_bwd(const float* dout, const int64_t* index, const float* count, float* dsrc, int64_t N,
-                          int64_t C, void* stream);
-/* Multi-scale segment pooling (PCDMask3DSegLevelEncoder.forward, pcd_mask3d_encoder.py:133-152): the reference
- * up-samples a coarse level to full resolution with (4 - hlevel) MinkowskiPoolingTranspose(kernel 2, stride 2) calls --
- * every fine voxel receives the feature of its one coarse ancestor -- and then scatter_means over point2segment.  Here
- * the up-sampling is the index composition parent[v] (fine voxel -> row of the coarse level): out[s,:] =
- * mean_{v: index[v]==s} src[parent[v],:]; src [Nc,C] fp32.  Backward scatter-adds dout[index[v]]/count into a zeroed
- * dsrc [Nc,C].  Rows with an out-of-range segment or parent are skipped. */
-int pq3d_upsample_scatter_mean_fwd(const float* src, const int64_t* parent, const int64_t* index, float* out, float* count,
-                                   int64_t N, int64_t Nc, int64_t C, int64_t S, void* stream);
-int pq3d_upsample_scatter_mean_bwd(const float* dout, const int64_t* parent, const int64_t* index, const float* count,
-                                   float* dsrc, int64_t N, int64_t Nc, int64_t C, int64_t S, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Segment pooling: torch_scatter.scatter_mean(feat, point2segment, dim=0, dim_size=max_seg)
+ * (modules/vision/pcd_mask3d_encoder.py:149; on coordinates data/datasets/sceneverse_instseg.py:183,186), the
+ * MinkowskiPoolingTranspose up-sampling in front of it (pcd_mask3d_encoder.py:127-131,147) as an index composition, and the
+ * inverse gathers mask[voxel2segment] (evaluator/instseg_eval.py:101,272-281).  Bandwidth kernels: no atomics, no zero
+ * fill, every result bit-identical run to run (pq3d_amd/csrc/segment.hip).
+ *
+ * pq3d_segment_plan sorts the voxel -> segment ids of a batch ONCE (stable: ascending voxel id inside a segment; ids outside
+ * [0, S) are dropped) into the caller's plan buffer of pq3d_segment_plan_bytes(N, S) bytes (16-byte aligned device memory;
+ * opaque: sorted voxel order, per-segment offsets, work items).  The plan serves every reduction over that grouping: the 5
+ * feature levels of a batch and, keyed by the coarse parent instead, the gradient of an up-sampled level.
+ *
+ * pq3d_segment_reduce: out[s,:] = sum or mean over the voxels v of segment s of  w(v) * src[row(v),:]   (out [S,C] fp32,
+ *   every row written, empty segments zero), with row(v) = v (gather NULL: src has a row per voxel, torch_scatter's
+ *   scatter_mean) or gather[v] (src [Nsrc,C] = a COARSE level, gather = the composed fine -> coarse row index: the
+ *   up-sampled [N,C] intermediate of the reference never exists); rows outside [0, Nsrc) contribute nothing and are not
+ *   counted.  w(v) = row_scale[row(v)] or 1 (NULL).  count (optional, [S] fp32) receives the number of rows summed; mean
+ *   divides by max(count, 1).  ws: pq3d_segment_ws_bytes(N, S, C) bytes of scratch (partial rows of segments longer than one
+ *   128-voxel piece), 16-byte aligned.
+ *   Gradient of the up-sampled mean w.r.t. the coarse level = the same call with the plan of `parent`, src = dout [S,C],
+ *   gather = index, row_scale = 1 / max(count, 1) per segment, mean = 0.
+ *
+ * pq3d_segment_gather: out[v,:] = table[index[v],:] (* 1 / max(count[index[v]], 1) when count is given) for v < N, zero rows
+ *   for ids outside [0, S): the gradient of the plain segment mean (table = dout) and the evaluator's voxel <- segment
+ *   gathers.  16-byte vector rows when C % 4 == 0 and the pointers are 16-byte aligned, scalar rows otherwise. */
+int64_t pq3d_segment_plan_bytes(int64_t N, int64_t S);
+int64_t pq3d_segment_ws_bytes(int64_t N, int64_t S, int64_t C);
+int pq3d_segment_plan(const int64_t* index, int64_t N, int64_t S, void* plan, int64_t plan_bytes, void* stream);
+int pq3d_segment_reduce(const float* src, int64_t Nsrc, const int64_t* gather, const float* row_scale, const void* plan,
+                        int64_t N, int64_t S, int64_t C, int32_t mean, float* out, float* count, void* ws, int64_t ws_bytes,
+                        void* stream);
+int pq3d_segment_gather(const float* table, const int64_t* index, const float* count, float* out, int64_t N, int64_t S,
+                        int64_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer side of the training step around the path: what Query3DTrainer.backward does after

@@ -196,13 +196,12 @@ _SIGS = {
     "pq3d_spatial_bias_bwd_grouped": [C.c_void_p] + [C.POINTER(C.c_void_p)] * 5 + [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "pq3d_gate_mix_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "pq3d_gate_mix_bwd": [C.c_void_p] * 7 + [C.c_int64, C.c_void_p],
-    "pq3d_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                              C.c_void_p],
-    "pq3d_scatter_mean_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
-    "pq3d_upsample_scatter_mean_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
-                                       C.c_int64, C.c_int64, C.c_void_p],
-    "pq3d_upsample_scatter_mean_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
-                                       C.c_int64, C.c_int64, C.c_void_p],
+    "pq3d_segment_plan_bytes": [C.c_int64, C.c_int64],
+    "pq3d_segment_ws_bytes": [C.c_int64, C.c_int64, C.c_int64],
+    "pq3d_segment_plan": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+    "pq3d_segment_reduce": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "pq3d_segment_gather": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_sumsq_partials": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "pq3d_train_scalars": [C.POINTER(AdamWHp), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "pq3d_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(AdamWHp), C.POINTER(OptSegments),
@@ -243,6 +242,7 @@ _SIGS = {
     "pq3d_dropout_apply": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout),
                            C.c_void_p],
 }
+_RET64 = {"pq3d_segment_plan_bytes", "pq3d_segment_ws_bytes"}   # size queries: bytes (or -1), not a status code
 EXPORTS = sorted(list(_SIGS) + ["pq3d_last_error", "pq3d_version"])
 
 
@@ -257,7 +257,7 @@ def lib() -> C.CDLL:
         for name, args in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name in _RET64 else C.c_int
         L.pq3d_last_error.restype = C.c_char_p
         L.pq3d_version.restype = C.c_int
         _lib = L

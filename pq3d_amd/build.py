@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpq3d_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "loss.hip", "pointnet2.hip", "gemm128.hip", "attn_resident.hip", "attn_small.hip", "gemm_wk.hip", "attn_sa.hip", "gemm_wktt.hip", "gemm_cv128.hip", "attn_ca.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "loss.hip", "pointnet2.hip", "gemm128.hip", "attn_resident.hip", "attn_small.hip", "gemm_wk.hip", "attn_sa.hip", "gemm_wktt.hip", "gemm_cv128.hip", "attn_ca.hip", "segment.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-Wno-unused-result"]
 # per-file extras.  attn_resident.hip: MFMA results feed the softmax VALU code directly; with the default AGPR form of the
@@ -33,6 +33,16 @@ def _stale() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+def _obj_stale(src: str, obj: str) -> bool:
+    """An object is rebuilt when its own source, any header under csrc/ or the public header is newer than it."""
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, src), os.path.join(HERE, "..", "include", "pq3d_hip.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
@@ -42,9 +52,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src + ".o")
+        objs.append(obj)
+        if not force and not _obj_stale(src, obj):
+            continue
         cmd = [hipcc, *FLAGS, *EXTRA.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -53,7 +65,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(out.decode())
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     if verbose:
-        print(f"built {LIB}")
+        print(f"built {LIB} ({len(procs)} of {len(SOURCES)} objects recompiled)")
     return LIB
 
 

@@ -362,56 +362,7 @@ __global__ void gate_bwd_kernel(const float* q, const float* u, const float* g, 
   }
 }
 
-// ---------------------------------------------------------------- scatter mean (segment pooling)
-// One thread per (voxel, 4-channel group): coalesced reads of src rows, atomics into the (L2-resident) segment
-// table.  Algorithmic bytes per scene: N*C*4 (src) + N*8 (index) + S*C*4 (out).
-__global__ void scatter_add_kernel(const float* src, const int64_t* index, float* out, float* count, long N, long C,
-                                   long S) {
-  const long total = N * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long v = i / C, c = i % C;
-    const long s = index[v];
-    if (s < 0 || s >= S) continue;
-    unsafeAtomicAdd(&out[s * C + c], src[i]);
-    if (c == 0) unsafeAtomicAdd(&count[s], 1.f);
-  }
-}
-// Multi-scale variant (pcd_mask3d_encoder.py:133-152): the coarse-level feature of a fine voxel is read through the
-// composed parent index instead of materialising the up-sampled [N_fine, C] tensor of the repeated pooling transposes.
-__global__ void upsample_scatter_add_kernel(const float* src, const int64_t* parent, const int64_t* index, float* out,
-                                            float* count, long N, long Nc, long C, long S) {
-  const long total = N * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long v = i / C, c = i % C;
-    const long s = index[v], p = parent[v];
-    if (s < 0 || s >= S || p < 0 || p >= Nc) continue;
-    unsafeAtomicAdd(&out[s * C + c], src[p * C + c]);
-    if (c == 0) unsafeAtomicAdd(&count[s], 1.f);
-  }
-}
-__global__ void upsample_scatter_mean_bwd_kernel(const float* dout, const int64_t* parent, const int64_t* index,
-                                                 const float* count, float* dsrc, long N, long Nc, long C, long S) {
-  const long total = N * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long v = i / C, c = i % C;
-    const long s = index[v], p = parent[v];
-    if (s < 0 || s >= S || p < 0 || p >= Nc) continue;
-    unsafeAtomicAdd(&dsrc[p * C + c], dout[s * C + c] / fmaxf(count[s], 1.f));
-  }
-}
-__global__ void scatter_div_kernel(float* out, const float* count, long S, long C) {
-  const long total = S * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-    out[i] /= fmaxf(count[i / C], 1.f);
-}
-__global__ void scatter_mean_bwd_kernel(const float* dout, const int64_t* index, const float* count, float* dsrc,
-                                        long N, long C) {
-  const long total = N * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long v = i / C, c = i % C, s = index[v];
-    dsrc[i] = dout[s * C + c] / fmaxf(count[s], 1.f);
-  }
-}
+// (segment pooling: segment.hip)
 
 inline unsigned grid1d(long total, int block = 256, long cap = 4096) {
   long g = (total + block - 1) / block;
@@ -1046,65 +997,6 @@ extern "C" int pq3d_gate_mix_bwd(const float* q, const float* u, const float* g,
   if (n == 0) return 0;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, q, u, g, dy, dq, du, dg,
                      (long)n);
-  PQ_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int pq3d_scatter_mean_fwd(const float* src, const int64_t* index, float* out, float* count, int64_t N,
-                                     int64_t C, int64_t S, void* stream) {
-  PQ_DEVICE_GUARD(stream, src);
-  PQ_CHECK_ARG(src && index && out && count && N >= 0 && C >= 1 && S >= 0, "pq3d_scatter_mean_fwd: bad args");
-  hipStream_t s = (hipStream_t)stream;
-  if (S == 0) return 0;
-  if (int e = memset_async(out, sizeof(float) * S * C, s)) return e;
-  if (int e = memset_async(count, sizeof(float) * S, s)) return e;
-  if (N > 0)
-    hipLaunchKernelGGL(scatter_add_kernel, dim3(grid1d(N * C, 256, 8192)), dim3(256), 0, s, src, index, out, count,
-                       (long)N, (long)C, (long)S);
-  hipLaunchKernelGGL(scatter_div_kernel, dim3(grid1d(S * C)), dim3(256), 0, s, out, count, (long)S, (long)C);
-  PQ_LAUNCH_CHECK();
-  return 0;
-}
-extern "C" int pq3d_upsample_scatter_mean_fwd(const float* src, const int64_t* parent, const int64_t* index, float* out,
-                                              float* count, int64_t N, int64_t Nc, int64_t C, int64_t S, void* stream) {
-  PQ_DEVICE_GUARD(stream, src);
-  PQ_CHECK_ARG(src && parent && index && out && count && N >= 0 && Nc >= 0 && C >= 1 && S >= 0,
-               "pq3d_upsample_scatter_mean_fwd: bad args");
-  hipStream_t s = (hipStream_t)stream;
-  if (S == 0) return 0;
-  ZeroList z;
-  z.add(out, (long)S * C);
-  z.add(count, (long)S);
-  if (int e = pq3d_zero_launch(z, s)) return e;
-  if (N > 0)
-    hipLaunchKernelGGL(upsample_scatter_add_kernel, dim3(grid1d(N * C, 256, 8192)), dim3(256), 0, s, src, parent, index, out,
-                       count, (long)N, (long)Nc, (long)C, (long)S);
-  hipLaunchKernelGGL(scatter_div_kernel, dim3(grid1d(S * C)), dim3(256), 0, s, out, count, (long)S, (long)C);
-  PQ_LAUNCH_CHECK();
-  return 0;
-}
-extern "C" int pq3d_upsample_scatter_mean_bwd(const float* dout, const int64_t* parent, const int64_t* index,
-                                              const float* count, float* dsrc, int64_t N, int64_t Nc, int64_t C, int64_t S,
-                                              void* stream) {
-  PQ_DEVICE_GUARD(stream, dout);
-  PQ_CHECK_ARG(dout && parent && index && count && dsrc && N >= 0 && Nc >= 0 && C >= 1 && S >= 0,
-               "pq3d_upsample_scatter_mean_bwd: bad args");
-  hipStream_t s = (hipStream_t)stream;
-  if (Nc == 0) return 0;
-  if (int e = memset_async(dsrc, sizeof(float) * Nc * C, s)) return e;
-  if (N > 0)
-    hipLaunchKernelGGL(upsample_scatter_mean_bwd_kernel, dim3(grid1d(N * C, 256, 8192)), dim3(256), 0, s, dout, parent, index,
-                       count, dsrc, (long)N, (long)Nc, (long)C, (long)S);
-  PQ_LAUNCH_CHECK();
-  return 0;
-}
-extern "C" int pq3d_scatter_mean_bwd(const float* dout, const int64_t* index, const float* count, float* dsrc,
-                                     int64_t N, int64_t C, void* stream) {
-  PQ_DEVICE_GUARD(stream, dout);
-  PQ_CHECK_ARG(dout && index && count && dsrc && N >= 0 && C >= 1, "pq3d_scatter_mean_bwd: bad args");
-  if (N == 0) return 0;
-  hipLaunchKernelGGL(scatter_mean_bwd_kernel, dim3(grid1d(N * C, 256, 8192)), dim3(256), 0, (hipStream_t)stream, dout,
-                     index, count, dsrc, (long)N, (long)C);
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,584 @@
+// Segment pooling (voxel -> segment mean), its gathers and its gradients as BANDWIDTH kernels for gfx950.
+//
+// Reference: torch_scatter.scatter_mean(feat, point2segment, dim=0, dim_size=max_seg) per scene and level
+// (modules/vision/pcd_mask3d_encoder.py:149; the same op on coordinates data/datasets/sceneverse_instseg.py:183,186), the
+// up-sampling in front of it (pcd_mask3d_encoder.py:127-131,147) and the inverse gathers mask[voxel2segment]
+// (evaluator/instseg_eval.py:101,272-281).
+//
+// Design (SURVEY 7 step 7 / VERDICT r4 item 2): the voxel -> segment ids of a batch are sorted ONCE
+// (pq3d_segment_plan: stable LSD radix sort of 32-bit keys, 8 bits per pass, ids out of range sorted behind everything) into
+//   perm[]      voxels ordered by segment, ascending voxel id inside a segment (stable -> one fixed summation order),
+//   seg_off[]   CSR offsets per segment,
+//   pieces[]    work items {first row, end row, segment, partial slot}: a segment of n voxels is cut into ceil(n / 128)
+//               pieces so that one giant segment (a floor) does not serialise on one wave,
+// and every reduction over that grouping (5 feature levels forward, the coarse levels' gradients) then runs as
+//   segment_reduce_kernel : ONE WAVE PER PIECE, 16-byte row loads (a 256-channel fp32 row = one 1-KB wave instruction, narrower
+//                           rows share the instruction: 2 rows of 128 / 96 channels), 8 row loads in flight per lane,
+//                           register accumulation, one store per segment row -- no atomics, no zero fill, bit-identical run to
+//                           run; segments longer than one piece leave per-piece partial rows that
+//   segment_combine_kernel  sums in piece order (one workgroup per long segment).
+// The inverse direction (gradient of the plain mean, evaluator gathers) is segment_gather_kernel: one 16-byte-vector row copy
+// per voxel from the (cache-resident) segment table, streaming stores.
+// Algorithmic bytes per level: N*C*4 (rows) + N*8 (ids) + S*C*4 (result).
+#include "common.h"
+
+namespace {
+
+constexpr int SEG_P = 128;        // rows per piece (two 64-row index blocks)
+constexpr int SORT_ROUNDS = 8;    // a sort tile = 256 threads x 8 rounds
+constexpr int SORT_TILE = 256 * SORT_ROUNDS;
+
+// ---- plan buffer layout (int32 units; every section starts on a 64-byte boundary) -----------------------------------
+struct PlanLayout {
+  long meta, seg_off, perm, pieces, longs, keys_a, keys_b, perm_b, tile_hist, dig_tot, total;
+  long n_tiles, max_pieces, max_long, max_slots;
+};
+inline long up16(long x) { return (x + 15) & ~15L; }
+inline PlanLayout plan_layout(long N, long S) {
+  PlanLayout L;
+  L.n_tiles = (N + SORT_TILE - 1) / SORT_TILE;
+  if (L.n_tiles < 1) L.n_tiles = 1;
+  L.max_pieces = S + N / SEG_P + 1;           // sum over segments of max(1, ceil(n / P))
+  L.max_long = N / (SEG_P + 1) + 1;           // segments with more than P voxels
+  L.max_slots = N / SEG_P + L.max_long + 1;   // their pieces
+  long o = 0;
+  L.meta = o; o += 16;
+  L.seg_off = o; o += up16(S + 1);
+  L.perm = o; o += up16(N);
+  L.pieces = o; o += up16(4 * L.max_pieces);
+  L.longs = o; o += up16(2 * L.max_long);
+  L.keys_a = o; o += up16(N);
+  L.keys_b = o; o += up16(N);
+  L.perm_b = o; o += up16(N);
+  L.tile_hist = o; o += up16(256 * L.n_tiles);
+  L.dig_tot = o; o += 256;
+  L.total = o;
+  return L;
+}
+
+// ---- block-wide exclusive scan helpers (plan kernels only; not on the bandwidth path) -------------------------------
+PQ_DEV int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int u = __shfl_up(v, d);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+// exclusive prefix of v over the block's threads (<= 1024 threads); *total = block sum.  `sm` holds >= 17 ints.
+PQ_DEV int block_excl_scan(int v, int* sm, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int inc = wave_incl_scan(v);
+  __syncthreads();
+  if (lane == 63) sm[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int i = 0; i < nw; ++i) { const int t = sm[i]; sm[i] = s; s += t; }
+    sm[16] = s;
+  }
+  __syncthreads();
+  *total = sm[16];
+  return inc - v + sm[w];
+}
+
+// ---- sort pass 1/3: keys (first pass: from the int64 ids) and per-tile digit histograms -----------------------------
+template <bool FROM_INDEX>
+__global__ __launch_bounds__(256) void seg_hist_kernel(const int64_t* __restrict__ index, const int* __restrict__ keys_in,
+                                                       int* __restrict__ keys_out, int* __restrict__ tile_hist, long N,
+                                                       long S, int shift, long n_tiles) {
+  __shared__ int hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const long t0 = (long)blockIdx.x * SORT_TILE;
+#pragma unroll
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const long i = t0 + r * 256 + threadIdx.x;
+    if (i < N) {
+      int key;
+      if (FROM_INDEX) {
+        const int64_t s = index[i];
+        key = (s < 0 || s >= S) ? (int)S : (int)s;
+        keys_out[i] = key;
+      } else {
+        key = keys_in[i];
+      }
+      atomicAdd(&hist[(key >> shift) & 255], 1);   // LDS integer atomics: order-independent result
+    }
+  }
+  __syncthreads();
+  tile_hist[(long)threadIdx.x * n_tiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// ---- sort pass 2/3: exclusive scan of every digit's row of tile counts (one workgroup per digit) --------------------
+__global__ __launch_bounds__(256) void seg_scan_rows_kernel(int* __restrict__ tile_hist, int* __restrict__ dig_tot,
+                                                            long n_tiles) {
+  __shared__ int sm[17];
+  int* row = tile_hist + (long)blockIdx.x * n_tiles;
+  int carry = 0;
+  for (long c0 = 0; c0 < n_tiles; c0 += 256) {
+    const long i = c0 + threadIdx.x;
+    const int v = i < n_tiles ? row[i] : 0;
+    int tot;
+    const int ex = block_excl_scan(v, sm, &tot);
+    if (i < n_tiles) row[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) dig_tot[blockIdx.x] = carry;
+}
+
+// ---- sort pass 3/3: stable scatter of one tile ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seg_scatter_kernel(const int* __restrict__ keys_in, const int* __restrict__ perm_in,
+                                                          int* __restrict__ keys_out, int* __restrict__ perm_out,
+                                                          const int* __restrict__ tile_hist, const int* __restrict__ dig_tot,
+                                                          long N, int shift, long n_tiles) {
+  __shared__ int sm[17];
+  __shared__ int base[256];        // next free output slot of every digit for this tile
+  __shared__ int wcnt[4][256];
+  __shared__ int wbase[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  {
+    int tot;
+    const int ex = block_excl_scan(dig_tot[tid], sm, &tot);
+    base[tid] = ex + tile_hist[(long)tid * n_tiles + blockIdx.x];
+  }
+  const long t0 = (long)blockIdx.x * SORT_TILE;
+  for (int r = 0; r < SORT_ROUNDS; ++r) {
+    const long i = t0 + r * 256 + tid;
+    const bool valid = i < N;
+    const int key = valid ? keys_in[i] : 0;
+    const int pv = valid ? (perm_in ? perm_in[i] : (int)i) : 0;
+    const int dg = (key >> shift) & 255;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wcnt[k][tid] = 0;
+    // lanes of this wave holding the same digit (8 ballots), rank of this lane among them
+    unsigned long long m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (dg >> b) & 1;
+      const unsigned long long bal = __ballot(valid && bit);
+      m &= bit ? bal : ~bal;
+    }
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (valid && rank == 0) wcnt[w][dg] = __popcll(m);
+    __syncthreads();
+    {
+      int s = base[tid];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { wbase[k][tid] = s; s += wcnt[k][tid]; }
+      base[tid] = s;
+    }
+    __syncthreads();
+    if (valid) {
+      const int pos = wbase[w][dg] + rank;
+      keys_out[pos] = key;
+      perm_out[pos] = pv;
+    }
+  }
+}
+
+// ---- CSR offsets from the sorted keys: seg_off[s] = first sorted position with key >= s; seg_off[S] = valid rows ----
+__global__ void seg_offsets_kernel(const int* __restrict__ keys, int* __restrict__ seg_off, int* __restrict__ meta, long N,
+                                   long S) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > N) return;
+  const long prev = i == 0 ? -1 : keys[i - 1];
+  const long cur = i == N ? S : keys[i];
+  for (long s = prev + 1; s <= cur; ++s) seg_off[s] = (int)i;
+  (void)meta;   // meta[0] (valid rows) = seg_off[S] is written by the pieces kernel
+}
+
+// ---- work items: one piece per <= 128 sorted rows of a segment (an empty segment has one empty piece: it writes zeros) ---
+__global__ __launch_bounds__(1024) void seg_pieces_kernel(const int* __restrict__ seg_off, int4* __restrict__ pieces,
+                                                          int2* __restrict__ longs, int* __restrict__ meta, long S) {
+  __shared__ int sm[17];
+  int cp = 0, cs = 0, cl = 0;   // running pieces, partial slots, long segments
+  for (long c0 = 0; c0 < S; c0 += 1024) {
+    const long s = c0 + threadIdx.x;
+    int b = 0, n = 0;
+    if (s < S) { b = seg_off[s]; n = seg_off[s + 1] - b; }
+    const int np = s < S ? max(1, (n + SEG_P - 1) / SEG_P) : 0;
+    const int lg = np > 1;
+    int tp, ts, tl;
+    const int ep = block_excl_scan(np, sm, &tp);
+    const int es = block_excl_scan(lg ? np : 0, sm, &ts);
+    const int el = block_excl_scan(lg, sm, &tl);
+    if (s < S) {
+      for (int k = 0; k < np; ++k) {
+        const int r0 = b + k * SEG_P;
+        pieces[cp + ep + k] = make_int4(r0, min(r0 + SEG_P, b + n), (int)s, lg ? cs + es + k : -1);
+      }
+      if (lg) longs[cl + el] = make_int2((int)s, cs + es);
+    }
+    cp += tp; cs += ts; cl += tl;
+  }
+  if (threadIdx.x == 0) { meta[0] = seg_off[S]; meta[1] = cp; meta[2] = cl; meta[3] = cs; }
+}
+
+// ---- the reduction ---------------------------------------------------------------------------------------------------
+// Lanes of a wave: LPR = 1 << lpr_log2 lanes cover one row (VEC floats each, KCH chunks per lane), 64 / LPR rows share one
+// wave instruction.  Rows of a piece come from perm[] (loaded 64 at a time, one per lane, handed out with ds_bpermute);
+// the row actually read is perm[r] itself or gather[perm[r]] (multi-scale: the coarse ancestor); rows outside [0, Nsrc)
+// are skipped and do not count.  row_scale (optional, indexed by the row read) weighs a row (gradient path: 1 / count).
+template <int VEC> struct RowVec;
+template <> struct RowVec<4> {
+  typedef f32x4 T;
+  static PQ_DEV T ld(const float* p, bool stream) {
+    return stream ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p;
+  }
+  static PQ_DEV void st(float* p, T v) { *(f32x4*)p = v; }
+  static PQ_DEV void st_stream(float* p, T v) { __builtin_nontemporal_store(v, (f32x4*)p); }
+  static PQ_DEV T zero() { return T{0.f, 0.f, 0.f, 0.f}; }
+};
+template <> struct RowVec<1> {
+  typedef float T;
+  static PQ_DEV T ld(const float* p, bool stream) { return stream ? __builtin_nontemporal_load(p) : *p; }
+  static PQ_DEV void st(float* p, T v) { *p = v; }
+  static PQ_DEV void st_stream(float* p, T v) { __builtin_nontemporal_store(v, p); }
+  static PQ_DEV T zero() { return 0.f; }
+};
+template <int VEC> PQ_DEV typename RowVec<VEC>::T vshfl_xor(typename RowVec<VEC>::T v, int m);
+template <> PQ_DEV f32x4 vshfl_xor<4>(f32x4 v, int m) {
+  f32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = __shfl_xor(v[j], m);
+  return r;
+}
+template <> PQ_DEV float vshfl_xor<1>(float v, int m) { return __shfl_xor(v, m); }
+
+template <int VEC, int KCH>
+__global__ __launch_bounds__(256) void segment_reduce_kernel(
+    const float* __restrict__ src, const int64_t* __restrict__ gather, const float* __restrict__ row_scale,
+    const int* __restrict__ meta, const int* __restrict__ perm, const int4* __restrict__ pieces, float* __restrict__ out,
+    float* __restrict__ count, float* __restrict__ part, float* __restrict__ part_cnt, long Nsrc, int C, int lpr_log2,
+    int mean) {
+  typedef RowVec<VEC> RV;
+  typedef typename RV::T V;
+  constexpr int U = KCH >= 4 ? 2 : (KCH == 2 ? 4 : 8);   // row loads in flight per lane x KCH chunks = 8 vectors
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= meta[1]) return;
+  const int4 pc = pieces[wave];
+  const int lane = threadIdx.x & 63;
+  const int LPR = 1 << lpr_log2, RPI = 64 >> lpr_log2;
+  const int sub = lane >> lpr_log2, cl = lane & (LPR - 1);
+  const int colw = LPR * VEC;                                   // columns one chunk round covers
+  const int col0 = blockIdx.y * (colw * KCH) + cl * VEC;
+  const bool stream = gather == nullptr;                        // plain rows are read exactly once
+
+  // the (<= 2) index blocks of this piece: row read by lane `lane` of each block, its weight
+  int rowv[2];
+  float scv[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int r = pc.x + b * 64 + lane;
+    int row = -1;
+    if (r < pc.y) {
+      const int v = perm[r];
+      if (gather) {
+        const int64_t g = gather[v];
+        row = (g < 0 || g >= Nsrc) ? -1 : (int)g;
+      } else {
+        row = v < Nsrc ? v : -1;
+      }
+    }
+    rowv[b] = row;
+    scv[b] = (row >= 0 && row_scale) ? row_scale[row] : 1.f;
+  }
+
+  V acc[KCH];
+#pragma unroll
+  for (int k = 0; k < KCH; ++k) acc[k] = RV::zero();
+  float cnt = 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int nrows = min(64, pc.y - (pc.x + b * 64));
+    if (nrows <= 0) break;
+    for (int it0 = 0; it0 * RPI < nrows; it0 += U) {
+      int rw[U];
+      float sc[U];
+      V x[U][KCH];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = (it0 + u) * RPI + sub;          // <= 63 + ... masked below
+        rw[u] = __shfl(rowv[b], j & 63);
+        sc[u] = __shfl(scv[b], j & 63);
+        if (j >= nrows) rw[u] = -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float* p = src + (long)(rw[u] < 0 ? 0 : rw[u]) * C + col0;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+          x[u][k] = (rw[u] >= 0 && col0 + k * colw < C) ? RV::ld(p + k * colw, stream) : RV::zero();
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) acc[k] += x[u][k] * sc[u];
+        cnt += rw[u] >= 0 ? 1.f : 0.f;
+      }
+    }
+  }
+  // rows that shared an instruction: fixed-order tree over the lane bits above the row width
+  for (int m = LPR; m < 64; m <<= 1) {
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) acc[k] += vshfl_xor<VEC>(acc[k], m);
+    cnt += __shfl_xor(cnt, m);
+  }
+  if (sub != 0) return;
+  if (pc.w < 0) {
+    const float s = mean ? 1.f / fmaxf(cnt, 1.f) : 1.f;
+    float* o = out + (long)pc.z * C + col0;
+#pragma unroll
+    for (int k = 0; k < KCH; ++k)
+      if (col0 + k * colw < C) RV::st(o + k * colw, acc[k] * s);
+    if (count && lane == 0 && blockIdx.y == 0) count[pc.z] = cnt;
+  } else {
+    float* o = part + (long)pc.w * C + col0;
+#pragma unroll
+    for (int k = 0; k < KCH; ++k)
+      if (col0 + k * colw < C) RV::st(o + k * colw, acc[k]);
+    if (lane == 0 && blockIdx.y == 0) part_cnt[pc.w] = cnt;
+  }
+}
+
+// long segments: partial rows summed in piece order.  One workgroup per long segment: thread t owns vector column
+// t % CV of partials k = t / CV (mod 256 / CV); the <= 256 / CV partial sums are then added in k order.
+template <int VEC>
+__global__ __launch_bounds__(256) void segment_combine_kernel(const int* __restrict__ meta, const int* __restrict__ seg_off,
+                                                              const int2* __restrict__ longs, const float* __restrict__ part,
+                                                              const float* __restrict__ part_cnt, float* __restrict__ out,
+                                                              float* __restrict__ count, int C, int mean) {
+  typedef RowVec<VEC> RV;
+  typedef typename RV::T V;
+  extern __shared__ __align__(16) float red[];          // [256][VEC]
+  if ((int)blockIdx.x >= meta[2]) return;
+  const int2 lg = longs[blockIdx.x];
+  const int n = seg_off[lg.x + 1] - seg_off[lg.x];
+  const int np = (n + SEG_P - 1) / SEG_P;
+  const int nvec = (C + VEC - 1) / VEC;
+  __shared__ float cnt_s;
+  if (threadIdx.x < 64) {                 // counts are small integers in fp32: any order is exact
+    float c = 0.f;
+    for (int k = threadIdx.x; k < np; k += 64) c += part_cnt[lg.y + k];
+    c = wave_sum(c);
+    if (threadIdx.x == 0) cnt_s = c;
+  }
+  __syncthreads();
+  const float cnt = cnt_s;
+  const float s = mean ? 1.f / fmaxf(cnt, 1.f) : 1.f;
+  for (int c0 = 0; c0 < nvec; c0 += 256) {
+    const int CV = min(256, nvec - c0);               // vector columns of this round
+    int cvp = 1;
+    while (cvp < CV) cvp <<= 1;                       // threads per partial row (power of two <= 256)
+    const int KP = 256 / cvp;                         // partial rows in flight
+    const int cv = threadIdx.x & (cvp - 1), kk = threadIdx.x / cvp;
+    V a = RV::zero();
+    if (cv < CV)
+      for (int k = kk; k < np; k += KP) a += RV::ld(part + (long)(lg.y + k) * C + (long)(c0 + cv) * VEC, false);
+    __syncthreads();
+    RV::st(red + threadIdx.x * VEC, a);
+    __syncthreads();
+    if (kk == 0 && cv < CV) {
+      V t = RV::zero();
+      for (int k = 0; k < KP; ++k) t += RV::ld(red + (k * cvp + cv) * VEC, false);
+      RV::st(out + (long)lg.x * C + (long)(c0 + cv) * VEC, t * s);
+    }
+  }
+  if (count && threadIdx.x == 0) count[lg.x] = cnt;
+}
+
+// out[v,:] = table[index[v],:] (* 1 / max(count[index[v]], 1)); rows with an id outside [0, S) are zero.
+template <int VEC, int KCH>
+__global__ __launch_bounds__(256) void segment_gather_kernel(const float* __restrict__ table, const int64_t* __restrict__ index,
+                                                             const float* __restrict__ count, float* __restrict__ out, long N,
+                                                             long S, int C, int lpr_log2) {
+  typedef RowVec<VEC> RV;
+  typedef typename RV::T V;
+  constexpr int U = KCH >= 4 ? 2 : (KCH == 2 ? 4 : 8);
+  const long blk = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (blk >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int LPR = 1 << lpr_log2, RPI = 64 >> lpr_log2;
+  const int sub = lane >> lpr_log2, cl = lane & (LPR - 1);
+  const int colw = LPR * VEC;
+  const int col0 = blockIdx.y * (colw * KCH) + cl * VEC;
+  int rowv = -1;
+  float scv = 1.f;
+  if (blk + lane < N) {
+    const int64_t s = index[blk + lane];
+    if (s >= 0 && s < S) {
+      rowv = (int)s;
+      if (count) scv = 1.f / fmaxf(count[s], 1.f);
+    }
+  }
+  const int nrows = (int)min((long)64, N - blk);
+  for (int it0 = 0; it0 * RPI < nrows; it0 += U) {
+    int rw[U];
+    float sc[U];
+    bool live[U];
+    V x[U][KCH];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = (it0 + u) * RPI + sub;
+      rw[u] = __shfl(rowv, j & 63);
+      sc[u] = __shfl(scv, j & 63);
+      live[u] = j < nrows;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* p = table + (long)(rw[u] < 0 ? 0 : rw[u]) * C + col0;
+#pragma unroll
+      for (int k = 0; k < KCH; ++k)
+        x[u][k] = (live[u] && rw[u] >= 0 && col0 + k * colw < C) ? RV::ld(p + k * colw, false) : RV::zero();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+      float* o = out + (blk + (it0 + u) * RPI + sub) * C + col0;
+#pragma unroll
+      for (int k = 0; k < KCH; ++k)
+        if (col0 + k * colw < C) RV::st_stream(o + k * colw, x[u][k] * sc[u]);
+    }
+  }
+}
+
+struct RowGeom { int vec, kch, lpr_log2, ycols; };
+inline RowGeom row_geom(int64_t C, const void* a, const void* b) {
+  RowGeom g;
+  const bool v4 = (C % 4 == 0) && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
+  g.vec = v4 ? 4 : 1;
+  const long chunks = (C + g.vec - 1) / g.vec;
+  int lg = 0;
+  while ((1L << lg) < chunks && lg < 6) ++lg;
+  g.lpr_log2 = lg;
+  const long per = (chunks + (1L << lg) - 1) >> lg;      // chunks per lane
+  g.kch = per >= 3 ? 4 : (int)per;
+  const long colw = (1L << lg) * g.vec * g.kch;
+  g.ycols = (int)((C + colw - 1) / colw);
+  return g;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------- C ABI
+extern "C" int64_t pq3d_segment_plan_bytes(int64_t N, int64_t S) {
+  if (N < 0 || S < 0) return -1;
+  return plan_layout(N, S).total * 4;
+}
+extern "C" int64_t pq3d_segment_ws_bytes(int64_t N, int64_t S, int64_t C) {
+  if (N < 0 || S < 0 || C < 1) return -1;
+  const PlanLayout L = plan_layout(N, S);
+  return (L.max_slots * (C + 1) + 16) * 4;
+}
+
+extern "C" int pq3d_segment_plan(const int64_t* index, int64_t N, int64_t S, void* plan, int64_t plan_bytes, void* stream) {
+  PQ_DEVICE_GUARD(stream, plan);
+  PQ_CHECK_ARG(plan && (index || N == 0) && N >= 0 && S >= 0, "pq3d_segment_plan: bad args");
+  PQ_CHECK_ARG(N < (1LL << 31) - 65536 && S < (1LL << 31) - 65536, "pq3d_segment_plan: N and S must fit 31 bits");
+  const PlanLayout L = plan_layout(N, S);
+  PQ_CHECK_ARG(plan_bytes >= L.total * 4, "pq3d_segment_plan: plan buffer smaller than pq3d_segment_plan_bytes(N, S)");
+  PQ_CHECK_ARG((((uintptr_t)plan) & 15) == 0, "pq3d_segment_plan: plan buffer must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  int* P = (int*)plan;
+  int *keys_a = P + L.keys_a, *keys_b = P + L.keys_b, *perm = P + L.perm, *perm_b = P + L.perm_b;
+  int *th = P + L.tile_hist, *dt = P + L.dig_tot;
+  int bits = 1;
+  while ((1LL << bits) <= S) ++bits;                 // keys 0 .. S (S = the out-of-range sentinel)
+  const int passes = (bits + 7) / 8;
+  const unsigned tiles = (unsigned)L.n_tiles;
+  const int* sorted_keys = keys_a;
+  if (N > 0) {
+    // pass p reads (kin, pin) and writes (kout, pout); the LAST pass must land in `perm`
+    const int* kin = keys_a;
+    const int* pin = nullptr;
+    for (int p = 0; p < passes; ++p) {
+      const int shift = 8 * p;
+      int* kout = (kin == keys_a) ? keys_b : keys_a;
+      int* pout = ((passes - 1 - p) % 2 == 0) ? perm : perm_b;
+      if (p == 0)
+        hipLaunchKernelGGL(seg_hist_kernel<true>, dim3(tiles), dim3(256), 0, s, index, (const int*)nullptr, keys_a, th, (long)N,
+                           (long)S, shift, (long)L.n_tiles);
+      else
+        hipLaunchKernelGGL(seg_hist_kernel<false>, dim3(tiles), dim3(256), 0, s, (const int64_t*)nullptr, kin, (int*)nullptr, th,
+                           (long)N, (long)S, shift, (long)L.n_tiles);
+      hipLaunchKernelGGL(seg_scan_rows_kernel, dim3(256), dim3(256), 0, s, th, dt, (long)L.n_tiles);
+      hipLaunchKernelGGL(seg_scatter_kernel, dim3(tiles), dim3(256), 0, s, kin, pin, kout, pout, (const int*)th, (const int*)dt,
+                         (long)N, shift, (long)L.n_tiles);
+      kin = kout; pin = pout;
+      sorted_keys = kout;
+    }
+  }
+  hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, s, sorted_keys, P + L.seg_off,
+                     P + L.meta, (long)N, (long)S);
+  hipLaunchKernelGGL(seg_pieces_kernel, dim3(1), dim3(1024), 0, s, (const int*)(P + L.seg_off), (int4*)(P + L.pieces),
+                     (int2*)(P + L.longs), P + L.meta, (long)S);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int VEC, int KCH>
+static void launch_reduce(const float* src, const int64_t* gather, const float* row_scale, const int* P, const PlanLayout& L,
+                          float* out, float* count, float* part, float* part_cnt, int64_t Nsrc, int64_t C, const RowGeom& g,
+                          int mean, hipStream_t s) {
+  const unsigned blocks = (unsigned)((L.max_pieces + 3) / 4);
+  hipLaunchKernelGGL((segment_reduce_kernel<VEC, KCH>), dim3(blocks, g.ycols), dim3(256), 0, s, src, gather, row_scale,
+                     P + L.meta, P + L.perm, (const int4*)(P + L.pieces), out, count, part, part_cnt, (long)Nsrc, (int)C,
+                     g.lpr_log2, mean);
+}
+
+extern "C" int pq3d_segment_reduce(const float* src, int64_t Nsrc, const int64_t* gather, const float* row_scale,
+                                   const void* plan, int64_t N, int64_t S, int64_t C, int32_t mean, float* out, float* count,
+                                   void* ws, int64_t ws_bytes, void* stream) {
+  PQ_DEVICE_GUARD(stream, plan);
+  PQ_CHECK_ARG(plan && out && (src || Nsrc == 0) && N >= 0 && S >= 0 && C >= 1 && Nsrc >= 0 && C < (1 << 24),
+               "pq3d_segment_reduce: bad args");
+  PQ_CHECK_ARG(gather || Nsrc >= N, "pq3d_segment_reduce: without a gather index src needs a row per voxel");
+  if (S == 0) return 0;
+  const PlanLayout L = plan_layout(N, S);
+  PQ_CHECK_ARG(ws && ws_bytes >= (L.max_slots * (C + 1) + 16) * 4,
+               "pq3d_segment_reduce: workspace smaller than pq3d_segment_ws_bytes(N, S, C)");
+  PQ_CHECK_ARG((((uintptr_t)ws) & 15) == 0, "pq3d_segment_reduce: workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int* P = (const int*)plan;
+  float* part = (float*)ws;
+  float* part_cnt = part + ((L.max_slots * C + 3) & ~3L);
+  const RowGeom g = row_geom(C, src, out);
+  const bool v4 = g.vec == 4 && (C % 4 == 0);
+#define PQ_SEG_REDUCE(V, K) launch_reduce<V, K>(src, gather, row_scale, P, L, out, count, part, part_cnt, Nsrc, C, g, mean, s)
+  if (v4) { if (g.kch == 1) PQ_SEG_REDUCE(4, 1); else if (g.kch == 2) PQ_SEG_REDUCE(4, 2); else PQ_SEG_REDUCE(4, 4); }
+  else    { if (g.kch == 1) PQ_SEG_REDUCE(1, 1); else if (g.kch == 2) PQ_SEG_REDUCE(1, 2); else PQ_SEG_REDUCE(1, 4); }
+#undef PQ_SEG_REDUCE
+  const unsigned nlong = (unsigned)L.max_long;
+  if (N > SEG_P) {   // a segment longer than one piece can exist
+    if (v4)
+      hipLaunchKernelGGL(segment_combine_kernel<4>, dim3(nlong), dim3(256), 256 * 4 * sizeof(float), s, P + L.meta, P + L.seg_off,
+                         (const int2*)(P + L.longs), (const float*)part, (const float*)part_cnt, out, count, (int)C, mean);
+    else
+      hipLaunchKernelGGL(segment_combine_kernel<1>, dim3(nlong), dim3(256), 256 * sizeof(float), s, P + L.meta, P + L.seg_off,
+                         (const int2*)(P + L.longs), (const float*)part, (const float*)part_cnt, out, count, (int)C, mean);
+  }
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_segment_gather(const float* table, const int64_t* index, const float* count, float* out, int64_t N,
+                                   int64_t S, int64_t C, void* stream) {
+  PQ_DEVICE_GUARD(stream, out);
+  PQ_CHECK_ARG((table || S == 0) && (index || N == 0) && (out || N == 0) && N >= 0 && S >= 0 && C >= 1 && C < (1 << 24),
+               "pq3d_segment_gather: bad args");
+  if (N == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const RowGeom g = row_geom(C, table, out);
+  const unsigned blocks = (unsigned)((N + 255) / 256);
+#define PQ_SEG_GATHER(V, K)                                                                                                   \
+  hipLaunchKernelGGL((segment_gather_kernel<V, K>), dim3(blocks, g.ycols), dim3(256), 0, s, table, index, count, out, (long)N, \
+                     (long)S, (int)C, g.lpr_log2)
+  if (g.vec == 4) { if (g.kch == 1) PQ_SEG_GATHER(4, 1); else if (g.kch == 2) PQ_SEG_GATHER(4, 2); else PQ_SEG_GATHER(4, 4); }
+  else            { if (g.kch == 1) PQ_SEG_GATHER(1, 1); else if (g.kch == 2) PQ_SEG_GATHER(1, 2); else PQ_SEG_GATHER(1, 4); }
+#undef PQ_SEG_GATHER
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

@@ -828,9 +828,11 @@ class PCDMask3DSegLevelEncoder(_PostNormBase):
         out = []
         dev = point2segment[0].device
         ctx = self._head_ctx(dev)
+        # the voxel -> segment ids are sorted once per scene; all 5 levels (and their gradients) reduce over that grouping
+        plans = [ops.SegmentPlan(p2s, int(max_seg)) for p2s in point2segment]
         for i, ((feats, parents), proj) in enumerate(zip(pyramid, self.feat_proj_list)):
-            pooled = torch.stack([ops.upsample_scatter_mean(f, par, p2s, int(max_seg))
-                                  for f, par, p2s in zip(feats, parents, point2segment)])      # [B, max_seg, C_level]
+            pooled = torch.stack([ops.upsample_scatter_mean(f, par, p2s, int(max_seg), plan=pl)
+                                  for f, par, p2s, pl in zip(feats, parents, point2segment, plans)])   # [B, max_seg, C_level]
             y = linear_ln_forward(proj, pooled, self.ct)
             if self.dropout_p > 0:
                 y = ops.dropout(y, self._drop(ctx, ops.DROP_ENC_OUT, dev, m=i))

@@ -369,6 +369,10 @@ def mean_all(x: torch.Tensor) -> torch.Tensor:
 # ops.linear / ops.linear_group around it.
 class _DwDeferred:
     buckets = {}     # (N, K, R, g dtype, x dtype, has x2, has bias, ct) -> lists
+    nbytes = 0       # operand bytes the queue keeps alive; above _DW_DEFER_CAP the queue is flushed on the spot
+
+
+_DW_DEFER_CAP = 256 << 20   # the deferral exists for the latency-bound small-R products; big operands are not held for long
 
 
 _DW_DEFER = True    # module switch for A/B measurements (tools/probes/bench_nodefer.py)
@@ -382,20 +386,37 @@ def _dw_can_defer(g, x, x2, N, K) -> bool:
                 not g.is_contiguous() or not x.is_contiguous())
 
 
-def _dw_defer(g, x, x2, dw, db, N, K, R, ct) -> bool:
-    """Queue dw[N, K] += g^T (x [+ x2]) (and db[N] += column sums of g); False when the pass has no whole-pass arena."""
-    if not _dw_can_defer(g, x, x2, N, K):
+def _param_has_hooks(q) -> bool:
+    ent = _Arena.by_ptr.get(q)
+    if ent is None:
         return False
+    p_ = ent[0]
+    return bool(getattr(p_, "_backward_hooks", None)) or bool(getattr(p_, "_post_accumulate_grad_hooks", None))
+
+
+def _dw_defer(g, x, x2, dw, db, N, K, R, ct, pptrs=()) -> bool:
+    """Queue dw[N, K] += g^T (x [+ x2]) (and db[N] += column sums of g); False when the pass has no whole-pass arena.
+    A parameter with gradient hooks (a post-accumulate-grad hook, an eager DDP bucket hook) is never deferred: its hook
+    would read the slot before the queued product has run."""
+    if not _dw_can_defer(g, x, x2, N, K) or any(_param_has_hooks(q) for q in pptrs if q is not None):
+        return False
+    _DwDeferred.nbytes += g.numel() * g.element_size() + x.numel() * x.element_size() + \
+        (x2.numel() * x2.element_size() if x2 is not None else 0)
     key = (N, K, R, g.dtype, x.dtype, x2 is not None, db is not None, ct)
     b = _DwDeferred.buckets.setdefault(key, ([], [], [], [], []))
     # the queue keeps its OWN view objects of the slots: AccumulateGrad adopts the returned gradient without a copy only when
     # nobody else references that tensor object (arena_take) -- a second reference would turn .grad into a clone of zeros
     b[0].append(g); b[1].append(x); b[2].append(x2); b[3].append(dw.view(N, K)); b[4].append(db.view(-1) if db is not None else None)
+    if _DwDeferred.nbytes > _DW_DEFER_CAP:
+        dw_deferred_flush()
     return True
 
 
 def dw_deferred_flush(run: bool = True) -> None:
-    buckets, _DwDeferred.buckets = _DwDeferred.buckets, {}
+    """Launch (run=False: drop) the queued weight-gradient products.  Called when the pass ends (grad_arena.__exit__), from
+    the fused decoder's readiness reports, from FlatGradAllReducer.launch() / pack() -- no reader of a slot gets ahead of the
+    queue -- and when the queue holds more than _DW_DEFER_CAP bytes of operands."""
+    buckets, _DwDeferred.buckets, _DwDeferred.nbytes = _DwDeferred.buckets, {}, 0
     if not run:
         return
     for (N, K, R, _gd, _xd, has2, hasb, ct), (gs, xs, x2s, dws, dbs) in buckets.items():
@@ -476,7 +497,7 @@ class _Linear(Function):
                 dw, give_w = slot[0].view(N, K), give
                 if fuse:
                     db = slot[1]
-                if not (alpha == 1.0 and _dw_defer(g, x, x2, dw, db if fuse else None, N, K, R, ct)):   # else: queued until the pass ends
+                if not (alpha == 1.0 and _dw_defer(g, x, x2, dw, db if fuse else None, N, K, R, ct, pptrs=ctx.pptr)):   # else: queued until the pass ends
                     ga, xa, x2a = dw_operands([g], [x], [x2], N, K, R, ct)   # long reductions: bf16 operands, 128 x 128 tiles
                     L.gemm(M=N, N=K, K=R, A=ga, B=xa, B2=x2a, Cs=[dw], ct=ct, lda=N, ldb=K, ldc=K, transA=True, transB=True,
                            splitk=max(2, _splitk(tiles, R, ct)), colsum=[db] if fuse else None, accumulate=True, alpha=alpha)
@@ -606,7 +627,8 @@ class _LinearGroup(Function):
             dWb = torch.zeros(G, N, K, dtype=torch.float32, device=dev)
             dWs = [dWb[g] for g in range(G)]
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
-        if slot is not None and all(_dw_can_defer(gs[g], xs[g], None, N, K) for g in range(G)):
+        if slot is not None and all(_dw_can_defer(gs[g], xs[g], None, N, K) for g in range(G)) and \
+                not any(_param_has_hooks(q) for q in ctx.pptr):
             for g in range(G):
                 _dw_defer(gs[g], xs[g], None, dWs[g], None, N, K, R, ct)
             return (None, None, None, *dxs, *(dWs if give else [None] * G))   # queued until the pass ends
@@ -919,70 +941,120 @@ def fill_cols(x, cols: torch.Tensor, value: float):
     return _FillCols.apply(x, cols, float(value))
 
 
+class SegmentPlan:
+    """The voxel -> segment grouping of a batch, sorted ONCE on the device (pq3d_segment_plan): serves every reduction over
+    it -- the 5 feature levels of PCDMask3DSegLevelEncoder (pcd_mask3d_encoder.py:142-150) forward, and through
+    ``child(parent)`` (the grouping of the fine voxels by their coarse ancestor) the gradient of an up-sampled level.
+    ``index`` [N] int64 (ids outside [0, dim_size) are dropped), batched scenes = ids offset by b * max_seg."""
+
+    def __init__(self, index: torch.Tensor, dim_size: int):
+        assert index.dtype == torch.int64 and index.dim() == 1
+        self.index, self.N, self.S = _c(index), int(index.numel()), int(dim_size)
+        nbytes = int(L.lib().pq3d_segment_plan_bytes(self.N, self.S))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=index.device)
+        L.check(L.lib().pq3d_segment_plan(L.ptr(self.index), self.N, self.S, L.ptr(self.buf), nbytes, L.stream()),
+                "pq3d_segment_plan")
+        self._ws = {}
+        self._children = {}
+
+    def ws(self, C_: int) -> torch.Tensor:
+        if C_ not in self._ws:
+            self._ws[C_] = torch.empty(int(L.lib().pq3d_segment_ws_bytes(self.N, self.S, C_)), dtype=torch.uint8,
+                                       device=self.buf.device)
+        return self._ws[C_]
+
+    def child(self, parent: torch.Tensor, n_coarse: int) -> "SegmentPlan":
+        """Plan of the same voxels grouped by ``parent`` (rows of a coarse level); cached per parent tensor."""
+        key = (parent.data_ptr(), int(n_coarse))
+        if key not in self._children:
+            self._children[key] = (SegmentPlan(parent, n_coarse), parent)    # keeps `parent` alive: the key is its address
+        return self._children[key][0]
+
+    def reduce(self, src, gather, row_scale, C_, mean, want_count=True):
+        out = _empty(self.S, C_, dtype=torch.float32, device=src.device)
+        count = _empty(self.S, dtype=torch.float32, device=src.device) if want_count else None
+        ws = self.ws(C_)
+        # algorithmic bytes (SURVEY 8d row 15): N*C*4 (one row per voxel, as if the up-sampled level were read) + N*8 (ids) +
+        # S*C*4 (result)
+        nb = self.N * C_ * 4.0 + self.N * 8.0 + self.S * C_ * 4.0
+        L.check(timed("pq3d_segment_reduce", f"N{self.N}S{self.S}C{C_}{'g' if gather is not None else ''}", 0.0, nb,
+                      L.lib().pq3d_segment_reduce, L.ptr(src), src.shape[0], L.ptr(gather), L.ptr(row_scale), L.ptr(self.buf),
+                      self.N, self.S, C_, int(mean), L.ptr(out), L.ptr(count), L.ptr(ws), ws.numel(), L.stream()),
+                "pq3d_segment_reduce")
+        return out, count
+
+
+def segment_gather(table: torch.Tensor, index: torch.Tensor, count: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[v,:] = table[index[v],:] (/ max(count[index[v]], 1)): the evaluator's mask[voxel2segment]
+    (evaluator/instseg_eval.py:101,272-281) and the gradient of the segment mean; ids outside the table give zero rows.
+    No autograd (an inference / backward helper)."""
+    assert table.dtype == torch.float32 and index.dtype == torch.int64 and table.dim() == 2 and index.dim() == 1
+    table, index = _c(table), _c(index)
+    out = _empty(index.numel(), table.shape[1], dtype=torch.float32, device=table.device)
+    N, S, C_ = index.numel(), table.shape[0], table.shape[1]
+    L.check(timed("pq3d_segment_gather", f"N{N}S{S}C{C_}", 0.0, N * C_ * 4.0 + N * 8.0 + S * C_ * 4.0,
+                  L.lib().pq3d_segment_gather, L.ptr(table), L.ptr(index), L.ptr(count), L.ptr(out), N, S, C_, L.stream()),
+            "pq3d_segment_gather")
+    return out
+
+
 class _ScatterMean(Function):
     @staticmethod
-    def forward(ctx, src, index, dim_size):
-        src, index = _c(src), _c(index)
-        N, C_ = src.shape
-        out = _empty(dim_size, C_, dtype=torch.float32, device=src.device)
-        count = _empty(dim_size, dtype=torch.float32, device=src.device)
-        L.check(L.lib().pq3d_scatter_mean_fwd(L.ptr(src), L.ptr(index), L.ptr(out), L.ptr(count), N, C_, dim_size,
-                                              L.stream()), "pq3d_scatter_mean_fwd")
-        ctx.save_for_backward(index, count)
+    def forward(ctx, src, plan):
+        src = _c(src)
+        out, count = plan.reduce(src, None, None, src.shape[1], True)
+        ctx.plan, ctx.count = plan, count
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        index, count = ctx.saved_tensors
-        dout = dout.contiguous()
-        N, C_ = index.numel(), dout.shape[1]
-        dsrc = _empty(N, C_, dtype=torch.float32, device=dout.device)
-        L.check(L.lib().pq3d_scatter_mean_bwd(L.ptr(dout), L.ptr(index), L.ptr(count), L.ptr(dsrc), N, C_,
-                                              L.stream()), "pq3d_scatter_mean_bwd")
-        return dsrc, None, None
+        plan = ctx.plan
+        return segment_gather(dout.contiguous(), plan.index, ctx.count), None
 
 
-def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
+def scatter_mean(src: torch.Tensor, index: torch.Tensor, dim_size: int, plan: Optional[SegmentPlan] = None) -> torch.Tensor:
     """torch_scatter.scatter_mean(src, index, dim=0, dim_size) for [N,C] fp32 voxel features
-    (pcd_mask3d_encoder.py:149)."""
+    (pcd_mask3d_encoder.py:149).  ``plan``: a SegmentPlan of (index, dim_size) built once per batch and shared by every
+    level; built here when absent."""
     assert src.dtype == torch.float32 and index.dtype == torch.int64 and src.dim() == 2
-    return _ScatterMean.apply(src, index, int(dim_size))
+    assert src.shape[0] == index.numel()
+    if plan is None:
+        plan = SegmentPlan(index, int(dim_size))
+    assert plan.N == index.numel() and plan.S == int(dim_size)
+    return _ScatterMean.apply(src, plan)
 
 
 class _UpsampleScatterMean(Function):
     @staticmethod
-    def forward(ctx, src, parent, index, dim_size):
-        src, parent, index = _c(src), _c(parent), _c(index)
-        Nc, C_ = src.shape
-        N = index.numel()
-        out = _empty(dim_size, C_, dtype=torch.float32, device=src.device)
-        count = _empty(dim_size, dtype=torch.float32, device=src.device)
-        L.check(L.lib().pq3d_upsample_scatter_mean_fwd(L.ptr(src), L.ptr(parent), L.ptr(index), L.ptr(out), L.ptr(count), N,
-                                                       Nc, C_, dim_size, L.stream()), "pq3d_upsample_scatter_mean_fwd")
-        ctx.save_for_backward(parent, index, count)
-        ctx.nc = Nc
+    def forward(ctx, src, parent, plan):
+        src, parent = _c(src), _c(parent)
+        out, count = plan.reduce(src, parent, None, src.shape[1], True)
+        ctx.plan, ctx.parent, ctx.count, ctx.nc = plan, parent, count, src.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        parent, index, count = ctx.saved_tensors
-        dout = dout.contiguous()
-        C_ = dout.shape[1]
-        dsrc = _empty(ctx.nc, C_, dtype=torch.float32, device=dout.device)
-        L.check(L.lib().pq3d_upsample_scatter_mean_bwd(L.ptr(dout), L.ptr(parent), L.ptr(index), L.ptr(count), L.ptr(dsrc),
-                                                       index.numel(), ctx.nc, C_, dout.shape[0], L.stream()),
-                "pq3d_upsample_scatter_mean_bwd")
-        return dsrc, None, None, None
+        # dsrc[p,:] = sum over the fine voxels v below coarse row p of dout[index[v],:] / count[index[v]]: the same
+        # reduction, grouped by the parent instead of the segment (no atomics: deterministic gradients)
+        plan, dout = ctx.plan, dout.contiguous()
+        pplan = plan.child(ctx.parent, ctx.nc)
+        inv = torch.reciprocal(ctx.count.clamp(min=1.0))
+        dsrc, _ = pplan.reduce(dout, plan.index, inv, dout.shape[1], False, want_count=False)
+        return dsrc, None, None
 
 
-def upsample_scatter_mean(src: torch.Tensor, parent: torch.Tensor, index: torch.Tensor, dim_size: int) -> torch.Tensor:
+def upsample_scatter_mean(src: torch.Tensor, parent: torch.Tensor, index: torch.Tensor, dim_size: int,
+                          plan: Optional[SegmentPlan] = None) -> torch.Tensor:
     """scatter_mean(upsample(src), index): ``src`` [Nc, C] are the features of a COARSE voxel level, ``parent`` [N] the
     coarse row of every full-resolution voxel (the composition of the stride-2 pooling maps, see
     ``compose_parents`` / ``parents_from_coords``), ``index`` [N] its segment (pcd_mask3d_encoder.py:133-152 without
-    the up-sampled intermediate)."""
+    the up-sampled intermediate).  Voxels whose parent or segment is out of range contribute nothing and are not counted."""
     assert src.dtype == torch.float32 and parent.dtype == torch.int64 and index.dtype == torch.int64 and src.dim() == 2
     assert parent.numel() == index.numel()
-    return _UpsampleScatterMean.apply(src, parent, index, int(dim_size))
+    if plan is None:
+        plan = SegmentPlan(index, int(dim_size))
+    assert plan.N == index.numel() and plan.S == int(dim_size)
+    return _UpsampleScatterMean.apply(src, parent, plan)
 
 
 def compose_parents(maps) -> torch.Tensor:
@@ -1175,7 +1247,12 @@ class grad_arena:
     (none when every .grad still aliases its slot: accumulation over micro-batches), then every arena-aware backward function
     -- the heads that run BEFORE the decoder's backward (the caption body), the decoder, the input encoders after it --
     accumulates in place.  Without this context the decoder's backward makes the offer itself (arena_offer), which only
-    reaches the functions that run after it."""
+    reaches the functions that run after it.
+
+    .grad IS NOT FINAL UNTIL THE CONTEXT EXITS: weight gradients of arena-aware linear layers are queued (_DwDeferred) and
+    launched grouped at __exit__ (earlier only at the fused decoder's readiness reports, FlatGradAllReducer.launch() /
+    pack(), or when the queue exceeds _DW_DEFER_CAP); a reader of p.grad inside the pass sees zeros or partial sums.
+    Parameters with gradient hooks registered are excluded from the deferral for that reason."""
 
     def __init__(self, slots, buffers, pack_follows: bool = False):
         # pack_follows: the owner calls FlatGradAllReducer.pack() on these buffers right after the pass; only then is the

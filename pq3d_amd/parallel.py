@@ -80,6 +80,7 @@ class FlatGradAllReducer:
         prezeroed = set()
         if self.flat and self.flat[0].is_cuda:
             from . import ops
+            ops.dw_deferred_flush()   # no reader of the slots gets ahead of queued weight-gradient products (ops._DwDeferred)
             prezeroed = ops.arena_zeroed_buffers()   # buffers a whole-pass gradient arena zero-filled for this very pass
         for bi, (flat, bucket) in enumerate(zip(self.flat, self.buckets)):
             if buckets is not None and bi not in buckets:
@@ -135,6 +136,9 @@ class FlatGradAllReducer:
         stream carries on (the rest of the backward overlaps the transfer).  finish() joins."""
         if not self._active() or bi in self._launched:
             return
+        if self.flat[bi].is_cuda:
+            from . import ops
+            ops.dw_deferred_flush()   # weight gradients still queued for this pass (ops._DwDeferred) land before the bucket leaves
         cur = torch.cuda.current_stream() if self.flat[bi].is_cuda else None
         if cur is not None and torch.cuda.is_current_stream_capturing():
             # Inside a HIP-graph capture the collective stays ON the capturing stream (a synchronous op: RCCL's internal
