@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["pool"],
                     help="c2 = the BASELINE metric's configuration (default); pool = segment pooling alone (bench_pool.py)")
     ap.add_argument("--pool-nvox", type=int, default=250_000, help="--config pool: voxels per scene")
+    ap.add_argument("--pool-pmc", action="store_true", help="--config pool: only the headline launches (counter passes)")
     ap.add_argument("--pool-segments", type=int, default=4096, help="--config pool: segments per scene (max_seg)")
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")

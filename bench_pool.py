@@ -64,6 +64,21 @@ def _ev_time(fn, iters, warm=3):
 def run(args, dev, world, rank, barrier, dist_on):
     from pq3d_amd import ops
     B, n_vox, max_seg = 4, int(args.pool_nvox), int(args.pool_segments)
+    if getattr(args, "pool_pmc", False):
+        # counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/pool_profile.sh): ONLY the headline launch -- plain
+        # scatter_mean forward at N = 4 x 250000, C = 256 -- and its gradient's gather, 5 times each, plus the calibration copy
+        n_, s_ = B * 250_000, B * max_seg
+        ids_ = synth_ids(B, 250_000, max_seg, 7).to(dev)
+        pl = ops.SegmentPlan(ids_, s_)
+        x, dy, cnt = torch.randn(n_, 256, device=dev), torch.randn(s_, 256, device=dev), torch.ones(s_, device=dev)
+        for _ in range(5):
+            pl.reduce(x, None, None, 256, True)
+            ops.segment_gather(dy, ids_, cnt)
+        n_cal = (100 << 20) // 4
+        csrc, cdst = torch.ones(n_cal, device=dev), torch.empty(n_cal, device=dev)
+        ops.copy_many([cdst], [csrc])
+        torch.cuda.synchronize()
+        return {"pool_pmc": True}
     N, S = B * n_vox, B * max_seg
     idx = synth_ids(B, n_vox, max_seg, 1234 + rank).to(dev)
     parents, n_coarse = synth_parents(B, n_vox, 1234 + rank)
@@ -162,15 +177,24 @@ def run(args, dev, world, rank, barrier, dist_on):
                         "bit_identical_run_to_run": None}
             del x, dy
     roof["bit_identical_run_to_run"] = bitexact
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_r05_pool.json")
-    if os.path.exists(pmc):
+    # measured memory-side traffic of that very launch: committed rocprofv3 --pmc passes (tools/pool_profile.sh), corrected by
+    # the calibration copy of the same pass as MI355X_MICROARCH.md's HBM section prescribes
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_r*_pool.json")))
+    if pmcs:
         try:
-            pj = json.load(open(pmc))
-            roof["traffic"] = pj.get("segment_reduce_traffic_bytes_per_launch")
-            roof["traffic_source"] = "profiles/pmc_traffic_r05_pool.json"
-            if roof["traffic"]:
+            pj = json.load(open(pmcs[-1]))
+            rows = pj["kernels"].get("segment_reduce_kernel", [])
+            cal = pj.get("calibration") or {}
+            cf = 1.0 / cal["fetch_raw_over_true"] if cal.get("fetch_raw_over_true") else 2.0
+            cw = 1.0 / cal["write_raw_over_true"] if cal.get("write_raw_over_true") else 1.0
+            if rows:
+                r0 = max(rows, key=lambda r: r["launches"])
+                roof["traffic"] = (r0["fetch_kib"] * cf + r0["write_kib"] * cw) * 1024
                 roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
-        except ValueError:
+                roof["traffic_source"] = "profiles/" + os.path.basename(pmcs[-1])
+                roof["traffic_correction"] = {"fetch_x": round(cf, 3), "write_x": round(cw, 3)}
+        except (ValueError, KeyError):
             pass
     step_bytes = sum(2 * alg_bytes(N, S, c) for c in LEVEL_C)
     result = {

@@ -417,11 +417,11 @@ int pq3d_gate_mix_bwd(const float* q, const float* u, const float* g, const floa
  *   every row written, empty segments zero), with row(v) = v (gather NULL: src has a row per voxel, torch_scatter's
  *   scatter_mean) or gather[v] (src [Nsrc,C] = a COARSE level, gather = the composed fine -> coarse row index: the
  *   up-sampled [N,C] intermediate of the reference never exists); rows outside [0, Nsrc) contribute nothing and are not
- *   counted.  w(v) = row_scale[row(v)] or 1 (NULL).  count (optional, [S] fp32) receives the number of rows summed; mean
+ *   counted.  w(v) = 1 / max(row_div[row(v)], 1) or 1 (NULL).  count (optional, [S] fp32) receives the number of rows summed; mean
  *   divides by max(count, 1).  ws: pq3d_segment_ws_bytes(N, S, C) bytes of scratch (partial rows of segments longer than one
  *   128-voxel piece), 16-byte aligned.
  *   Gradient of the up-sampled mean w.r.t. the coarse level = the same call with the plan of `parent`, src = dout [S,C],
- *   gather = index, row_scale = 1 / max(count, 1) per segment, mean = 0.
+ *   gather = index, row_div = count (per segment), mean = 0.
  *
  * pq3d_segment_gather: out[v,:] = table[index[v],:] (* 1 / max(count[index[v]], 1) when count is given) for v < N, zero rows
  *   for ids outside [0, S): the gradient of the plain segment mean (table = dout) and the evaluator's voxel <- segment
@@ -429,7 +429,7 @@ int pq3d_gate_mix_bwd(const float* q, const float* u, const float* g, const floa
 int64_t pq3d_segment_plan_bytes(int64_t N, int64_t S);
 int64_t pq3d_segment_ws_bytes(int64_t N, int64_t S, int64_t C);
 int pq3d_segment_plan(const int64_t* index, int64_t N, int64_t S, void* plan, int64_t plan_bytes, void* stream);
-int pq3d_segment_reduce(const float* src, int64_t Nsrc, const int64_t* gather, const float* row_scale, const void* plan,
+int pq3d_segment_reduce(const float* src, int64_t Nsrc, const int64_t* gather, const float* row_div, const void* plan,
                         int64_t N, int64_t S, int64_t C, int32_t mean, float* out, float* count, void* ws, int64_t ws_bytes,
                         void* stream);
 int pq3d_segment_gather(const float* table, const int64_t* index, const float* count, float* out, int64_t N, int64_t S,

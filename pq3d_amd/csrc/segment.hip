@@ -30,7 +30,7 @@ constexpr int SORT_TILE = 256 * SORT_ROUNDS;
 
 // ---- plan buffer layout (int32 units; every section starts on a 64-byte boundary) -----------------------------------
 struct PlanLayout {
-  long meta, seg_off, perm, pieces, longs, keys_a, keys_b, perm_b, tile_hist, dig_tot, total;
+  long meta, seg_off, perm, pieces, longs, keys_a, keys_b, perm_b, tile_hist, dig_tot, bsum, total;
   long n_tiles, max_pieces, max_long, max_slots;
 };
 inline long up16(long x) { return (x + 15) & ~15L; }
@@ -52,6 +52,7 @@ inline PlanLayout plan_layout(long N, long S) {
   L.perm_b = o; o += up16(N);
   L.tile_hist = o; o += up16(256 * L.n_tiles);
   L.dig_tot = o; o += 256;
+  L.bsum = o; o += up16(3 * ((S + 1023) / 1024 + 1));
   L.total = o;
   return L;
 }
@@ -191,37 +192,89 @@ __global__ void seg_offsets_kernel(const int* __restrict__ keys, int* __restrict
 }
 
 // ---- work items: one piece per <= 128 sorted rows of a segment (an empty segment has one empty piece: it writes zeros) ---
-__global__ __launch_bounds__(1024) void seg_pieces_kernel(const int* __restrict__ seg_off, int4* __restrict__ pieces,
-                                                          int2* __restrict__ longs, int* __restrict__ meta, long S) {
+// Three short launches (a single-workgroup version took 160-570 us: one thread wrote every piece of a giant segment and the
+// scans of a 250 000-row parent grouping ran on one CU): per-1024-segment block sums, a scan of the block sums, then the
+// pieces -- every thread its segment's first piece, the further pieces of long segments written by the whole workgroup.
+PQ_DEV void seg_piece_counts(const int* __restrict__ seg_off, long s, long S, int& b, int& n, int& np, int& lg) {
+  b = 0; n = 0;
+  if (s < S) { b = seg_off[s]; n = seg_off[s + 1] - b; }
+  np = s < S ? max(1, (n + SEG_P - 1) / SEG_P) : 0;
+  lg = np > 1;
+}
+__global__ __launch_bounds__(1024) void seg_piece_sums_kernel(const int* __restrict__ seg_off, int* __restrict__ bsum, long S) {
   __shared__ int sm[17];
-  int cp = 0, cs = 0, cl = 0;   // running pieces, partial slots, long segments
-  for (long c0 = 0; c0 < S; c0 += 1024) {
-    const long s = c0 + threadIdx.x;
-    int b = 0, n = 0;
-    if (s < S) { b = seg_off[s]; n = seg_off[s + 1] - b; }
-    const int np = s < S ? max(1, (n + SEG_P - 1) / SEG_P) : 0;
-    const int lg = np > 1;
-    int tp, ts, tl;
-    const int ep = block_excl_scan(np, sm, &tp);
-    const int es = block_excl_scan(lg ? np : 0, sm, &ts);
-    const int el = block_excl_scan(lg, sm, &tl);
-    if (s < S) {
-      for (int k = 0; k < np; ++k) {
-        const int r0 = b + k * SEG_P;
-        pieces[cp + ep + k] = make_int4(r0, min(r0 + SEG_P, b + n), (int)s, lg ? cs + es + k : -1);
-      }
-      if (lg) longs[cl + el] = make_int2((int)s, cs + es);
+  int b, n, np, lg, tp, ts, tl;
+  seg_piece_counts(seg_off, (long)blockIdx.x * 1024 + threadIdx.x, S, b, n, np, lg);
+  block_excl_scan(np, sm, &tp);
+  block_excl_scan(lg ? np : 0, sm, &ts);
+  block_excl_scan(lg, sm, &tl);
+  if (threadIdx.x == 0) { bsum[3 * blockIdx.x] = tp; bsum[3 * blockIdx.x + 1] = ts; bsum[3 * blockIdx.x + 2] = tl; }
+}
+__global__ __launch_bounds__(1024) void seg_piece_blockscan_kernel(int* __restrict__ bsum, const int* __restrict__ seg_off,
+                                                                   int* __restrict__ meta, long nb, long S) {
+  __shared__ int sm[17];
+  int c[3] = {0, 0, 0};
+  for (long c0 = 0; c0 < nb; c0 += 1024) {
+    const long i = c0 + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int v = i < nb ? bsum[3 * i + q] : 0;
+      int tot;
+      const int ex = block_excl_scan(v, sm, &tot);
+      if (i < nb) bsum[3 * i + q] = c[q] + ex;
+      c[q] += tot;
     }
-    cp += tp; cs += ts; cl += tl;
   }
-  if (threadIdx.x == 0) { meta[0] = seg_off[S]; meta[1] = cp; meta[2] = cl; meta[3] = cs; }
+  if (threadIdx.x == 0) { meta[0] = seg_off[S]; meta[1] = c[0]; meta[2] = c[2]; meta[3] = c[1]; }
+}
+__global__ __launch_bounds__(1024) void seg_pieces_kernel(const int* __restrict__ seg_off, const int* __restrict__ bsum,
+                                                          int4* __restrict__ pieces, int2* __restrict__ longs, long S) {
+  __shared__ int sm[17];
+  __shared__ int4 lq[1024];     // long segments of this block: {first row, rows, first piece, first slot}
+  __shared__ int lseg[1024];
+  __shared__ int nlq;
+  if (threadIdx.x == 0) nlq = 0;
+  const long s = (long)blockIdx.x * 1024 + threadIdx.x;
+  int b, n, np, lg, tp, ts, tl;
+  seg_piece_counts(seg_off, s, S, b, n, np, lg);
+  const int ep = bsum[3 * blockIdx.x] + block_excl_scan(np, sm, &tp);
+  const int es = bsum[3 * blockIdx.x + 1] + block_excl_scan(lg ? np : 0, sm, &ts);
+  const int el = bsum[3 * blockIdx.x + 2] + block_excl_scan(lg, sm, &tl);
+  constexpr int OWN = 8;        // pieces a thread writes itself; only longer segments go to the workgroup's list
+  if (s < S) {
+    if (!lg) {
+      pieces[ep] = make_int4(b, b + n, (int)s, -1);
+    } else {
+      longs[el] = make_int2((int)s, es);
+      for (int k = 0; k < min(np, OWN); ++k) {
+        const int r0 = b + k * SEG_P;
+        pieces[ep + k] = make_int4(r0, min(r0 + SEG_P, b + n), (int)s, es + k);
+      }
+      if (np > OWN) {
+        const int q = atomicAdd(&nlq, 1);     // order inside the block's list is irrelevant: every entry is self-contained
+        lq[q] = make_int4(b, n, ep, es);
+        lseg[q] = (int)s;
+      }
+    }
+  }
+  __syncthreads();
+  const int nl = nlq;
+  for (int q = 0; q < nl; ++q) {
+    const int4 e = lq[q];
+    const int cnt = (e.y + SEG_P - 1) / SEG_P;
+    for (int k = OWN + threadIdx.x; k < cnt; k += 1024) {
+      const int r0 = e.x + k * SEG_P;
+      pieces[e.z + k] = make_int4(r0, min(r0 + SEG_P, e.x + e.y), lseg[q], e.w + k);
+    }
+  }
 }
 
 // ---- the reduction ---------------------------------------------------------------------------------------------------
 // Lanes of a wave: LPR = 1 << lpr_log2 lanes cover one row (VEC floats each, KCH chunks per lane), 64 / LPR rows share one
 // wave instruction.  Rows of a piece come from perm[] (loaded 64 at a time, one per lane, handed out with ds_bpermute);
 // the row actually read is perm[r] itself or gather[perm[r]] (multi-scale: the coarse ancestor); rows outside [0, Nsrc)
-// are skipped and do not count.  row_scale (optional, indexed by the row read) weighs a row (gradient path: 1 / count).
+// are skipped and do not count.  row_div (optional, indexed by the row read) weighs a row by 1 / max(row_div, 1) (gradient
+// path: the per-segment voxel counts).
 template <int VEC> struct RowVec;
 template <> struct RowVec<4> {
   typedef f32x4 T;
@@ -250,7 +303,7 @@ template <> PQ_DEV float vshfl_xor<1>(float v, int m) { return __shfl_xor(v, m);
 
 template <int VEC, int KCH>
 __global__ __launch_bounds__(256) void segment_reduce_kernel(
-    const float* __restrict__ src, const int64_t* __restrict__ gather, const float* __restrict__ row_scale,
+    const float* __restrict__ src, const int64_t* __restrict__ gather, const float* __restrict__ row_div,
     const int* __restrict__ meta, const int* __restrict__ perm, const int4* __restrict__ pieces, float* __restrict__ out,
     float* __restrict__ count, float* __restrict__ part, float* __restrict__ part_cnt, long Nsrc, int C, int lpr_log2,
     int mean) {
@@ -284,7 +337,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
       }
     }
     rowv[b] = row;
-    scv[b] = (row >= 0 && row_scale) ? row_scale[row] : 1.f;
+    scv[b] = (row >= 0 && row_div) ? 1.f / fmaxf(row_div[row], 1.f) : 1.f;
   }
 
   V acc[KCH];
@@ -329,11 +382,11 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
   }
   if (sub != 0) return;
   if (pc.w < 0) {
-    const float s = mean ? 1.f / fmaxf(cnt, 1.f) : 1.f;
+    const float dv = mean ? fmaxf(cnt, 1.f) : 1.f;   // a true division, as torch_scatter's out.true_divide_(count)
     float* o = out + (long)pc.z * C + col0;
 #pragma unroll
     for (int k = 0; k < KCH; ++k)
-      if (col0 + k * colw < C) RV::st(o + k * colw, acc[k] * s);
+      if (col0 + k * colw < C) RV::st(o + k * colw, acc[k] / dv);
     if (count && lane == 0 && blockIdx.y == 0) count[pc.z] = cnt;
   } else {
     float* o = part + (long)pc.w * C + col0;
@@ -354,8 +407,10 @@ __global__ __launch_bounds__(256) void segment_combine_kernel(const int* __restr
   typedef RowVec<VEC> RV;
   typedef typename RV::T V;
   extern __shared__ __align__(16) float red[];          // [256][VEC]
-  if ((int)blockIdx.x >= meta[2]) return;
-  const int2 lg = longs[blockIdx.x];
+  const int nlong = meta[2];
+  for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
+  __syncthreads();
+  const int2 lg = longs[li];
   const int n = seg_off[lg.x + 1] - seg_off[lg.x];
   const int np = (n + SEG_P - 1) / SEG_P;
   const int nvec = (C + VEC - 1) / VEC;
@@ -368,7 +423,7 @@ __global__ __launch_bounds__(256) void segment_combine_kernel(const int* __restr
   }
   __syncthreads();
   const float cnt = cnt_s;
-  const float s = mean ? 1.f / fmaxf(cnt, 1.f) : 1.f;
+  const float dv = mean ? fmaxf(cnt, 1.f) : 1.f;
   for (int c0 = 0; c0 < nvec; c0 += 256) {
     const int CV = min(256, nvec - c0);               // vector columns of this round
     int cvp = 1;
@@ -384,10 +439,11 @@ __global__ __launch_bounds__(256) void segment_combine_kernel(const int* __restr
     if (kk == 0 && cv < CV) {
       V t = RV::zero();
       for (int k = 0; k < KP; ++k) t += RV::ld(red + (k * cvp + cv) * VEC, false);
-      RV::st(out + (long)lg.x * C + (long)(c0 + cv) * VEC, t * s);
+      RV::st(out + (long)lg.x * C + (long)(c0 + cv) * VEC, t / dv);
     }
   }
   if (count && threadIdx.x == 0) count[lg.x] = cnt;
+  }
 }
 
 // out[v,:] = table[index[v],:] (* 1 / max(count[index[v]], 1)); rows with an id outside [0, S) are zero.
@@ -513,27 +569,33 @@ extern "C" int pq3d_segment_plan(const int64_t* index, int64_t N, int64_t S, voi
   }
   hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, s, sorted_keys, P + L.seg_off,
                      P + L.meta, (long)N, (long)S);
-  hipLaunchKernelGGL(seg_pieces_kernel, dim3(1), dim3(1024), 0, s, (const int*)(P + L.seg_off), (int4*)(P + L.pieces),
-                     (int2*)(P + L.longs), P + L.meta, (long)S);
+  const long nb = (S + 1023) / 1024;
+  if (nb > 0)
+    hipLaunchKernelGGL(seg_piece_sums_kernel, dim3((unsigned)nb), dim3(1024), 0, s, (const int*)(P + L.seg_off), P + L.bsum, (long)S);
+  hipLaunchKernelGGL(seg_piece_blockscan_kernel, dim3(1), dim3(1024), 0, s, P + L.bsum, (const int*)(P + L.seg_off), P + L.meta, nb,
+                     (long)S);
+  if (nb > 0)
+    hipLaunchKernelGGL(seg_pieces_kernel, dim3((unsigned)nb), dim3(1024), 0, s, (const int*)(P + L.seg_off), (const int*)(P + L.bsum),
+                       (int4*)(P + L.pieces), (int2*)(P + L.longs), (long)S);
   PQ_LAUNCH_CHECK();
   return 0;
 }
 
 template <int VEC, int KCH>
-static void launch_reduce(const float* src, const int64_t* gather, const float* row_scale, const int* P, const PlanLayout& L,
+static void launch_reduce(const float* src, const int64_t* gather, const float* row_div, const int* P, const PlanLayout& L,
                           float* out, float* count, float* part, float* part_cnt, int64_t Nsrc, int64_t C, const RowGeom& g,
                           int mean, hipStream_t s) {
   const unsigned blocks = (unsigned)((L.max_pieces + 3) / 4);
-  hipLaunchKernelGGL((segment_reduce_kernel<VEC, KCH>), dim3(blocks, g.ycols), dim3(256), 0, s, src, gather, row_scale,
+  hipLaunchKernelGGL((segment_reduce_kernel<VEC, KCH>), dim3(blocks, g.ycols), dim3(256), 0, s, src, gather, row_div,
                      P + L.meta, P + L.perm, (const int4*)(P + L.pieces), out, count, part, part_cnt, (long)Nsrc, (int)C,
                      g.lpr_log2, mean);
 }
 
-extern "C" int pq3d_segment_reduce(const float* src, int64_t Nsrc, const int64_t* gather, const float* row_scale,
+extern "C" int pq3d_segment_reduce(const float* src, int64_t Nsrc, const int64_t* gather, const float* row_div,
                                    const void* plan, int64_t N, int64_t S, int64_t C, int32_t mean, float* out, float* count,
                                    void* ws, int64_t ws_bytes, void* stream) {
   PQ_DEVICE_GUARD(stream, plan);
-  PQ_CHECK_ARG(plan && out && (src || Nsrc == 0) && N >= 0 && S >= 0 && C >= 1 && Nsrc >= 0 && C < (1 << 24),
+  PQ_CHECK_ARG(plan && (out || S == 0) && (src || Nsrc == 0) && N >= 0 && S >= 0 && C >= 1 && Nsrc >= 0 && C < (1 << 24),
                "pq3d_segment_reduce: bad args");
   PQ_CHECK_ARG(gather || Nsrc >= N, "pq3d_segment_reduce: without a gather index src needs a row per voxel");
   if (S == 0) return 0;
@@ -547,11 +609,11 @@ extern "C" int pq3d_segment_reduce(const float* src, int64_t Nsrc, const int64_t
   float* part_cnt = part + ((L.max_slots * C + 3) & ~3L);
   const RowGeom g = row_geom(C, src, out);
   const bool v4 = g.vec == 4 && (C % 4 == 0);
-#define PQ_SEG_REDUCE(V, K) launch_reduce<V, K>(src, gather, row_scale, P, L, out, count, part, part_cnt, Nsrc, C, g, mean, s)
+#define PQ_SEG_REDUCE(V, K) launch_reduce<V, K>(src, gather, row_div, P, L, out, count, part, part_cnt, Nsrc, C, g, mean, s)
   if (v4) { if (g.kch == 1) PQ_SEG_REDUCE(4, 1); else if (g.kch == 2) PQ_SEG_REDUCE(4, 2); else PQ_SEG_REDUCE(4, 4); }
   else    { if (g.kch == 1) PQ_SEG_REDUCE(1, 1); else if (g.kch == 2) PQ_SEG_REDUCE(1, 2); else PQ_SEG_REDUCE(1, 4); }
 #undef PQ_SEG_REDUCE
-  const unsigned nlong = (unsigned)L.max_long;
+  const unsigned nlong = (unsigned)(L.max_long < 2048 ? L.max_long : 2048);   // block-stride loop over the long segments
   if (N > SEG_P) {   // a segment longer than one piece can exist
     if (v4)
       hipLaunchKernelGGL(segment_combine_kernel<4>, dim3(nlong), dim3(256), 256 * 4 * sizeof(float), s, P + L.meta, P + L.seg_off,

@@ -970,7 +970,7 @@ class SegmentPlan:
             self._children[key] = (SegmentPlan(parent, n_coarse), parent)    # keeps `parent` alive: the key is its address
         return self._children[key][0]
 
-    def reduce(self, src, gather, row_scale, C_, mean, want_count=True):
+    def reduce(self, src, gather, row_div, C_, mean, want_count=True):
         out = _empty(self.S, C_, dtype=torch.float32, device=src.device)
         count = _empty(self.S, dtype=torch.float32, device=src.device) if want_count else None
         ws = self.ws(C_)
@@ -978,7 +978,7 @@ class SegmentPlan:
         # S*C*4 (result)
         nb = self.N * C_ * 4.0 + self.N * 8.0 + self.S * C_ * 4.0
         L.check(timed("pq3d_segment_reduce", f"N{self.N}S{self.S}C{C_}{'g' if gather is not None else ''}", 0.0, nb,
-                      L.lib().pq3d_segment_reduce, L.ptr(src), src.shape[0], L.ptr(gather), L.ptr(row_scale), L.ptr(self.buf),
+                      L.lib().pq3d_segment_reduce, L.ptr(src), src.shape[0], L.ptr(gather), L.ptr(row_div), L.ptr(self.buf),
                       self.N, self.S, C_, int(mean), L.ptr(out), L.ptr(count), L.ptr(ws), ws.numel(), L.stream()),
                 "pq3d_segment_reduce")
         return out, count
@@ -1038,8 +1038,7 @@ class _UpsampleScatterMean(Function):
         # reduction, grouped by the parent instead of the segment (no atomics: deterministic gradients)
         plan, dout = ctx.plan, dout.contiguous()
         pplan = plan.child(ctx.parent, ctx.nc)
-        inv = torch.reciprocal(ctx.count.clamp(min=1.0))
-        dsrc, _ = pplan.reduce(dout, plan.index, inv, dout.shape[1], False, want_count=False)
+        dsrc, _ = pplan.reduce(dout, plan.index, ctx.count, dout.shape[1], False, want_count=False)
         return dsrc, None, None
 
 
