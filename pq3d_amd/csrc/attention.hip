@@ -137,9 +137,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const pq3d_attn_desc 
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
-  const int split = blockIdx.x % KS, qchunk = blockIdx.x / KS;
+  const WgXyz wg = attn_wg_xyz(KS);
+  const int b = wg.b, h = wg.h;
+  const int split = wg.x % KS, qchunk = wg.x / KS;
   const int q0 = (qchunk * NW + wave) * 16;
   const int myq = q0 + li;
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
@@ -365,9 +366,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const pq3d_attn_de
   constexpr int nthreads = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
-  const int split = blockIdx.x % KS, qchunk = blockIdx.x / KS;
+  const WgXyz wg = attn_wg_xyz(KS);
+  const int b = wg.b, h = wg.h;
+  const int split = wg.x % KS, qchunk = wg.x / KS;
   const int q0 = (qchunk * NW + wave) * 16;
   const int myq = q0 + li;
   const bool wave_active = q0 < d.Lq, qvalid = myq < d.Lq;
@@ -570,8 +572,9 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   constexpr int nthreads = NWK * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int key = (blockIdx.x * NWK + wave) * 16 + li;
+  const WgXyz wg = attn_wg_xyz((int)gridDim.x);
+  const int b = wg.b, h = wg.h;
+  const int key = (wg.x * NWK + wave) * 16 + li;
   const bool kvalid = key < d.Lk;
 
   if (A::DHK > DH) {
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(NWK * 64) void attn_bwd_dkv_kernel(const pq3d_attn_
   // bytes global -> register -> LDS with the Q / dO tiles (prefetched 2-3 tiles ahead) instead of 8 dependent 1-byte
   // loads per lane inside the compute stage
   u32x2 mk_r[MASK3 ? 2 : 1];
-  const int key0 = blockIdx.x * NWK * 16;
+  const int key0 = wg.x * NWK * 16;
   const bool mvec = MASK3 && (d.Lk & 7) == 0 && d.Lk >= 8 && ((((uintptr_t)d.mask) & 7) == 0);
   auto load = [&](int t, auto set) {
     constexpr int S = decltype(set)::value;

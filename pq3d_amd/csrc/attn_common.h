@@ -5,6 +5,47 @@
 
 namespace {
 
+// ---- XCD-aware workgroup coordinates of a (X, H, B) attention grid ---------------------------------------------------------
+// Heads are packed in the last dimension of Q / K / V (h * d_h + c): at d_h = 32 a bf16 key row of one head
+// is a 64-byte slice at a 512-byte stride, i.e. HALF of a 128-byte line whose other half belongs to the neighbouring head; a
+// 3-D self-mask tile is read by all H heads of its scene.  The dispatcher deals workgroups to the 8 XCDs round-robin in
+// linear-id order (x fastest, then y = head): with the plain blockIdx mapping the H heads of a scene run on H DIFFERENT
+// XCDs (id = x + X * (h + H * b): for X = 1, H = 8 head h is always on XCD h), each with its own L2, and every K / V line is
+// fetched from memory twice (measured, rocprofv3 FETCH_SIZE calibrated: 53 MB per forward launch at config 2 for 25 MB of
+// K + V, 212 MB for 101 MB at config 5), every mask tile 8 times.
+// Here the workgroups ONE XCD receives in consecutive dispatch rounds (ids i, i + 8, i + 16, ...) are the members of ONE
+// group = the workgroups that read the same K / V lines: every head -- and every query chunk -- of one (key slice, scene).
+// They run at the same time on the same L2 and stream the same lines in step, so all but the first reader of a line hit (or
+// merge with its miss).  `xinner` = how many DISTINCT key slices the x dimension enumerates in its low part (x = xo * xinner
+// + xi: the streaming kernels' x = qchunk * KS + split -> xinner = KS; the resident kernels' x = split and the dK / dV kernel's
+// x = key chunk -> xinner = gridDim.x).  The last partial block of 8 groups keeps the plain logical order.  Pure placement:
+// every workgroup still owns exactly one (x, h, b); results do not depend on it.
+#ifndef PQ3D_ATTN_XCD
+#define PQ3D_ATTN_XCD 1
+#endif
+struct WgXyz { int x, h, b; };
+PQ_DEV WgXyz attn_wg_xyz(int xinner) {
+#if PQ3D_ATTN_XCD
+  const unsigned X = gridDim.x, H = gridDim.y, B = gridDim.z, XI = (unsigned)xinner, XO = X / XI;
+  const unsigned id = blockIdx.x + X * (blockIdx.y + H * blockIdx.z);
+  const unsigned G = XO * H;                       // members of a group: (xo, h)
+  const unsigned blk = 8u * G, T = (X * H * B / blk) * blk;
+  unsigned unit, m;                                // unit = (xi, b), xi fastest
+  if (id < T) {
+    const unsigned xcd = id & 7u, j = id >> 3;
+    unit = (j / G) * 8u + xcd;
+    m = j % G;
+  } else {                                         // tail: members fastest, then units
+    unit = id / G;
+    m = id % G;
+  }
+  return WgXyz{(int)((m / H) * XI + unit % XI), (int)(m % H), (int)(unit / XI)};
+#else
+  (void)xinner;
+  return WgXyz{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+#endif
+}
+
 constexpr int KB = 64;  // keys per main-loop iteration (fwd, dQ)
 constexpr int QB = 32;  // queries per main-loop iteration (dK/dV)
 // dK/dV: 16 keys per wave; 4 waves (64 keys) per workgroup for short key sequences, 8 (128 keys) for long ones

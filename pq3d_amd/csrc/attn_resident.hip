@@ -86,9 +86,10 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const WgXyz wg = attn_wg_xyz((int)gridDim.x);
+  const int b = wg.b, h = wg.h;
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
-  const int split = blockIdx.x;
+  const int split = wg.x;
   const int bm = d.mask_bmod > 0 ? b % d.mask_bmod : b;
   const float sl2 = d.scale * 1.4426950408889634f;
 
@@ -508,7 +509,8 @@ __global__ __launch_bounds__((FW + FLW) * 64) void attn_fwd_resident_kernel(cons
   constexpr int LDK = DH, LDV = A::LDR;
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, split = blockIdx.x;
+  const WgXyz wg = attn_wg_xyz((int)gridDim.x);
+  const int b = wg.b, h = wg.h, split = wg.x;
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
   const int nkb = (d.Lk + KB - 1) / KB;
   const int kb_lo = (int)((long)nkb * split / KS), kb_hi = (int)((long)nkb * (split + 1) / KS);
