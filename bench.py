@@ -116,7 +116,11 @@ def loss_fn(out, heads):
                 loss = loss + m.clamp(min=-50.0).mean() + torch.where(torch.isfinite(cl), cl, torch.zeros_like(cl)).mean()
     if "generation" in heads:   # generation_loss: token cross-entropy of the teacher-forced logits
         lg = out["generation_logits"]
-        loss = loss + torch.nn.functional.cross_entropy(lg.flatten(0, 1).float(), out["generation_label"].flatten())
+        if lg.is_cuda:   # the 32128-way token cross-entropy on the path's own kernels (one workgroup per row)
+            from pq3d_amd.losses import cross_entropy_rows
+            loss = cross_entropy_rows(lg, out["generation_label"], add=loss)
+        else:
+            loss = loss + torch.nn.functional.cross_entropy(lg.flatten(0, 1).float(), out["generation_label"].flatten())
     return loss
 
 
@@ -785,8 +789,8 @@ def main():
             qd = torch.randn(c["B"], c["Nq"], c["d"], device=dev, requires_grad=True)
 
             def head_only():
-                lg = gh(qd, dd["query_pad_masks"], dd["response"])
-                torch.nn.functional.cross_entropy(lg.flatten(0, 1).float(), dd["response"].flatten()).backward()
+                from pq3d_amd.losses import cross_entropy_rows
+                cross_entropy_rows(gh(qd, dd["query_pad_masks"], dd["response"]), dd["response"]).backward()
             for _ in range(3):
                 head_only()
             result["t5_body"] = {"ms_per_step_eager": timed_loop(head_only, max(3, args.steps // 5)),

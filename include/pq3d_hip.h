@@ -70,6 +70,10 @@ int pq3d_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, const pq3d_drop
  * (get_mlp_head, utils.py:23; ObjectEncoder, object_encoder.py:72-73). */
 int pq3d_dropout_apply(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
                        const pq3d_dropout* dr, void* stream);
+/* the same times a constant: y = alpha * dropout(x) (the caption decoder's "dropout(final norm) * d_model^-0.5" in front of
+ * the tied LM head, one launch instead of two in either direction) */
+int pq3d_dropout_apply_scaled(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
+                              const pq3d_dropout* dr, float alpha, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Grouped / batched GEMM with fused prologue + epilogue (nn.Linear forward and both backward GEMMs,
@@ -546,12 +550,20 @@ typedef struct {
   float* lse;                            /* [layers, R] written by forward, read by backward */
   const float* scale;                    /* [layers] (backward) */
   float* dlogits[PQ3D_MAX_GROUPS];       /* [R, C] per layer (backward) */
+  const float* scale_mul;                /* optional [layers] (backward): a second device-side factor of scale -- the
+                                            1 / kept-row count pq3d_cross_entropy_mean leaves, so that neither it nor the
+                                            upstream gradient ever visits the host */
 } pq3d_ce_desc;
 int pq3d_mask_cost_prep(const pq3d_mask_prep_desc* d, void* stream);
 int32_t pq3d_mask_cost_nsplit(int32_t Ns);
 int pq3d_match_cost(const pq3d_match_cost_desc* d, void* stream);
 int pq3d_matched_mask_grad(const pq3d_mask_grad_desc* d, void* stream);
 int pq3d_cross_entropy_fwd(const pq3d_ce_desc* d, void* stream);
+/* loss[layer] = sum_r row_loss / kept rows (F.cross_entropy reduction='mean' with ignore_index) [+ addend[layer]: the other
+ * terms of a total loss, so that "loss = loss + ce" costs no launch], inv_count[layer] = 1 / kept rows; one launch, fixed
+ * summation order.  Rows of >= 1024 classes (the caption head's 32128-way LM head,
+ * generation_head.py:24-27) take one workgroup per row in both directions. */
+int pq3d_cross_entropy_mean(const pq3d_ce_desc* d, float* loss, float* inv_count, const float* addend, void* stream);
 int pq3d_cross_entropy_bwd(const pq3d_ce_desc* d, void* stream);
 
 /* Padded mask losses without matching: batch_mask_loss / batch_dice_loss (optim/loss/instseg_loss.py:54-85), used by
@@ -639,8 +651,29 @@ int pq3d_rmsnorm_bwd(const float* x, const float* w, const float* rstd, const fl
  * two-way gradient junction without an add launch; dres may be NULL */
 int pq3d_rmsnorm_bwd_res(const float* x, const float* w, const float* rstd, const float* dy, const float* dres, float* dx,
                          float* dw, int64_t R, int32_t d, int32_t accumulate, void* stream);
+/* ... and with a second output dxm = dropout_mask(drop) * dx / (1 - p) over the [R, d] site `drop`: the gradient the
+ * PRECEDING sublayer's output projection needs (hidden = residual + dropout(o W^T)), written by this kernel instead of by a
+ * dropout launch of its own (18 launches per caption-body backward at config 5).  drop / dxm may be NULL. */
+int pq3d_rmsnorm_bwd_res_drop(const float* x, const float* w, const float* rstd, const float* dy, const float* dres, float* dx,
+                              float* dw, int64_t R, int32_t d, int32_t accumulate, const pq3d_dropout* drop, float* dxm,
+                              void* stream);
 int pq3d_embedding_fwd(const float* table, const int64_t* ids, float* out, int64_t R, int32_t d, void* stream);
 int pq3d_embedding_bwd_acc(const float* dout, const int64_t* ids, float* dtable, int64_t R, int32_t d, void* stream);
+/* token embedding with the embedding dropout of the T5 stack fused in (out = dropout(table[ids]) over the [R, d] site), and
+ * its gradient (dtable += scatter of dropout(dout)) */
+int pq3d_embedding_drop_fwd(const float* table, const int64_t* ids, float* out, int64_t R, int32_t d, const pq3d_dropout* dr,
+                            void* stream);
+int pq3d_embedding_drop_bwd_acc(const float* dout, const int64_t* ids, float* dtable, int64_t R, int32_t d,
+                                const pq3d_dropout* dr, void* stream);
+/* One launch for what the HF model does with framework elementwise ops before its first layer (pq3d_amd/csrc/t5glue.hip):
+ * ids [B,T] = shift_right(labels) ([start, labels[:-1]], -100 -> pad); bias [B,H,T,T] = rel[buckets[q,k], h] with -inf for
+ * k > q (relative-position bias + causal mask, rel [NB,H] = relative_attention_bias.weight, buckets [T,T] int64); kpm [B,N]
+ * = !enc_valid (NULL: skipped).  pq3d_t5_bias_bwd: drel[nb,h] (+)= sum_b sum_{(q,k) causal, bucket nb} dbias[b,h,q,k]. */
+int pq3d_t5_prep(const int64_t* labels, int64_t start_id, int64_t pad_id, const float* rel, const int64_t* buckets,
+                 const uint8_t* enc_valid, int64_t* ids, float* bias, uint8_t* kpm, int32_t B, int32_t T, int32_t H, int64_t N,
+                 void* stream);
+int pq3d_t5_bias_bwd(const float* dbias, const int64_t* buckets, float* drel, int32_t B, int32_t T, int32_t H, int32_t NB,
+                     int32_t accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -90,7 +90,7 @@ class MaskGradDesc(C.Structure):
 class CeDesc(C.Structure):
     _fields_ = [("layers", C.c_int32), ("C", C.c_int32), ("R", C.c_int64), ("ignore_index", C.c_int64),
                 ("logits", C.c_void_p * MAXG), ("target", C.c_void_p), ("row_loss", C.c_void_p), ("lse", C.c_void_p),
-                ("scale", C.c_void_p), ("dlogits", C.c_void_p * MAXG)]
+                ("scale", C.c_void_p), ("dlogits", C.c_void_p * MAXG), ("scale_mul", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -212,6 +212,7 @@ _SIGS = {
     "pq3d_matched_mask_grad": [C.POINTER(MaskGradDesc), C.c_void_p],
     "pq3d_cross_entropy_fwd": [C.POINTER(CeDesc), C.c_void_p],
     "pq3d_cross_entropy_bwd": [C.POINTER(CeDesc), C.c_void_p],
+    "pq3d_cross_entropy_mean": [C.POINTER(CeDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "pq3d_padded_mask_sums": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     "pq3d_padded_mask_grad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                               C.c_int32, C.c_int32, C.c_void_p],
@@ -241,6 +242,14 @@ _SIGS = {
     "pq3d_dropout_mask": [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(Dropout), C.c_void_p],
     "pq3d_dropout_apply": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout),
                            C.c_void_p],
+    "pq3d_dropout_apply_scaled": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.POINTER(Dropout),
+                                  C.c_float, C.c_void_p],
+    "pq3d_rmsnorm_bwd_res_drop": [C.c_void_p] * 7 + [C.c_int64, C.c_int32, C.c_int32, C.POINTER(Dropout), C.c_void_p, C.c_void_p],
+    "pq3d_embedding_drop_fwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(Dropout), C.c_void_p],
+    "pq3d_embedding_drop_bwd_acc": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(Dropout), C.c_void_p],
+    "pq3d_t5_prep": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                     C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p],
+    "pq3d_t5_bias_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
 }
 _RET64 = {"pq3d_segment_plan_bytes", "pq3d_segment_ws_bytes"}   # size queries: bytes (or -1), not a status code
 EXPORTS = sorted(list(_SIGS) + ["pq3d_last_error", "pq3d_version"])

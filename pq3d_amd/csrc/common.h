@@ -221,8 +221,7 @@ PQ_DEV TileIdx tile_index(const int xcd_order) {
   t.z = zb * zr + zi;
   return t;
 }
-// Per-plane variant for the SMALL launches (gemm_wk / gemm_wktt: every workgroup resident at once, <= a few hundred per
-// z-plane): z stays blockIdx.z (the speculative per-group pointer load of those kernels stays right), and inside the plane
+// Per-plane variant for the SMALL launches (gemm_wk, gemm_wktt: <= a few hundred workgroups per z-plane, usually all resident at once): z stays blockIdx.z (the speculative per-group pointer load of those kernels stays right), and inside the plane
 // the workgroups one XCD receives (same linear id mod 8) take a contiguous range of the plane's tiles -- y fastest
 // (order 1: an XCD owns whole row tiles, the A slab is fetched by one L2) or x fastest (order 255: whole column tiles, the
 // B slab).  In hardware order the m-tiles of one weight slab sit on 8 different L2s and every L2 fetches every slab:

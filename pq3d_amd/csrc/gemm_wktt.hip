@@ -32,11 +32,15 @@ __global__ __launch_bounds__(WT) void gemm_wktt_kernel(const pq3d_kdesc d, const
   const TB* B = (const TB*)q.B;
   const float* B2 = (const float*)q.B2;
   float* C = (float*)q.C;
-  float* cs_out = blockIdx.y == 0 ? q.colsum : nullptr;
+  // the tiles one XCD receives are neighbours in the (m, n) plane (common.h tile_index_plane): in hardware order the n-tiles
+  // of one m-tile sit gridDim.x ids apart -- on other XCDs, much later -- and every one of them fetches the g slab again
+  // (caption LM head, dW [32128 x 512] over 512 rows: 8 n-tiles, 535-643 MB fetched per launch for 66 MB of g)
+  const TileIdx ti = tile_index_plane(d.xcd_order);
+  float* cs_out = ti.y == 0 ? q.colsum : nullptr;
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(A), "s"(B), "s"(B2), "s"(C), "s"(cs_out));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * (16 * MI), wn = (wave & 1) * (16 * NJ);   // 4 x 2 waves
-  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const int m0 = ti.x * TM, n0 = ti.y * TN;
   const int nck = (d.K + KC - 1) / KC, per = (nck + sk - 1) / sk;
   const int c0 = split * per, c1 = min(nck, c0 + per);
   if (c0 >= c1) return;
@@ -155,7 +159,10 @@ int tt_launch_t(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s) {
   if (sk < 1) sk = 1;
   if (sk > nck) sk = nck;
   const dim3 grid((d.M + TT - 1) / TT, (d.N + TT - 1) / TT, d.groups * sk);
-  hipLaunchKernelGGL(kern, grid, dim3(WT), lds, s, kd, sk);
+  pq3d_kdesc k2 = kd;
+  const long kl = ((long)(nck + sk - 1) / sk) * KC;   // reduction rows of one workgroup
+  k2.xcd_order = plane_xcd_order((int)grid.x, (int)grid.y, (long)TT * kl * (long)sizeof(TA), (long)TT * kl * (long)(sizeof(TB) + (HB2 ? 4 : 0)));
+  hipLaunchKernelGGL(kern, grid, dim3(WT), lds, s, k2, sk);
   return 0;
 }
 template <typename TA, typename TB, bool HB2>

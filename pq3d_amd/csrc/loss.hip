@@ -261,11 +261,103 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const pq3d_ce_desc d) {
   if (row >= R) return;
   const int lane = threadIdx.x & 63;
   const long t = target[row];
-  const float sc = t == ignore ? 0.f : d.scale[layer];
+  const float sc = t == ignore ? 0.f : d.scale[layer] * (d.scale_mul ? d.scale_mul[layer] : 1.f);
   const float l = lse[row];
   for (int c = lane; c < C; c += 64) {
     const float x = logits[row * C + c];
     dlogits[row * C + c] = sc == 0.f ? 0.f : sc * (expf(x - l) - (c == t ? 1.f : 0.f));
+  }
+}
+
+
+// ---- wide rows (the caption head's 32128-way LM head, generation_head.py:24-27 + generation_loss): ONE WORKGROUP per row,
+// 16-byte loads, a single pass with an online (max, sum) per thread.  A 512 x 32128 fp32 logit matrix is 66 MB: the forward
+// reads it once, the backward reads it once and writes the gradient once (streaming stores).
+PQ_DEV void ce_online(float& m, float& s, float v) {
+  const float mn = fmaxf(m, v);
+  s = s * __expf(m - mn) + __expf(v - mn);
+  m = mn;
+}
+__global__ __launch_bounds__(256) void ce_fwd_wide_kernel(const pq3d_ce_desc d) {
+  __shared__ float sm[4], ss[4];
+  const long R = d.R, ignore = d.ignore_index, row = blockIdx.x;
+  const int C = d.C, layer = blockIdx.y, tid = threadIdx.x;
+  const float* __restrict__ x = d.logits[layer] + row * C;
+  float m = -INFINITY, s = 0.f;
+  const int head = (int)(((16 - ((uintptr_t)x & 15)) & 15) >> 2);          // floats before the first 16-byte boundary
+  const int h = head < C ? head : C, nv = (C - h) >> 2;
+  if (tid < h) ce_online(m, s, x[tid]);
+  const f32x4* x4 = (const f32x4*)(x + h);
+  for (int i = tid; i < nv; i += 256) {
+    const f32x4 v = __builtin_nontemporal_load(x4 + i);
+    const float mv = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), mn = fmaxf(m, mv);
+    s = s * __expf(m - mn) + ((__expf(v[0] - mn) + __expf(v[1] - mn)) + (__expf(v[2] - mn) + __expf(v[3] - mn)));
+    m = mn;
+  }
+  for (int c = h + 4 * nv + tid; c < C; c += 256) ce_online(m, s, x[c]);
+  const float wm = wave_max(m);
+  s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - wm));
+  if ((tid & 63) == 0) { sm[tid >> 6] = wm; ss[tid >> 6] = s; }
+  __syncthreads();
+  if (tid == 0) {
+    const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float S = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) S += sm[w] == -INFINITY ? 0.f : ss[w] * __expf(sm[w] - M);
+    const float l = M + logf(S);
+    d.lse[(long)layer * R + row] = l;
+    const long t = d.target[(long)layer * R + row];
+    d.row_loss[(long)layer * R + row] = t == ignore ? 0.f : ((unsigned long)t < (unsigned long)C ? l - x[t] : NAN);
+  }
+}
+__global__ __launch_bounds__(256) void ce_bwd_wide_kernel(const pq3d_ce_desc d) {
+  const long R = d.R, ignore = d.ignore_index, row = blockIdx.x;
+  const int C = d.C, layer = blockIdx.y, tid = threadIdx.x;
+  const float* __restrict__ x = d.logits[layer] + row * C;
+  float* __restrict__ dl = d.dlogits[layer] + row * C;
+  const long t = d.target[(long)layer * R + row];
+  const float sc = t == ignore ? 0.f : d.scale[layer] * (d.scale_mul ? d.scale_mul[layer] : 1.f);
+  const float l = d.lse[(long)layer * R + row];
+  const int head = (int)(((16 - ((uintptr_t)x & 15)) & 15) >> 2);
+  const int h = head < C ? head : C, nv = (C - h) >> 2;
+  const bool al = (((uintptr_t)(dl + h)) & 15) == 0;
+  auto one = [&](int c) { dl[c] = sc == 0.f ? 0.f : sc * (__expf(x[c] - l) - (c == t ? 1.f : 0.f)); };
+  if (tid < h) one(tid);
+  if (al) {
+    const f32x4* x4 = (const f32x4*)(x + h);
+    f32x4* d4 = (f32x4*)(dl + h);
+    for (int i = tid; i < nv; i += 256) {
+      const f32x4 v = __builtin_nontemporal_load(x4 + i);
+      f32x4 g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = sc == 0.f ? 0.f : sc * (__expf(v[j] - l) - ((long)(h + 4 * i + j) == t ? 1.f : 0.f));
+      __builtin_nontemporal_store(g, d4 + i);
+    }
+  } else {
+    for (int c = h + tid; c < h + 4 * nv; c += 256) one(c);
+  }
+  for (int c = h + 4 * nv + tid; c < C; c += 256) one(c);
+}
+// mean over the kept rows: loss[layer] = sum(row_loss) / max(kept, 1) ... F.cross_entropy's 'mean' divides by the kept count
+// (0 kept rows -> nan there; here 0 / 0 -> nan as well), inv_count[layer] = 1 / kept for the backward.  One block per layer,
+// fixed summation order.
+__global__ __launch_bounds__(256) void ce_mean_kernel(const pq3d_ce_desc d, float* __restrict__ loss, float* __restrict__ inv_count,
+                                                      const float* __restrict__ addend) {
+  __shared__ float ps[4], pc[4];
+  const long R = d.R, ignore = d.ignore_index;
+  const int layer = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f, c = 0.f;
+  for (long r = tid; r < R; r += 256) {
+    s += d.row_loss[(long)layer * R + r];
+    c += d.target[(long)layer * R + r] == ignore ? 0.f : 1.f;
+  }
+  s = wave_sum(s); c = wave_sum(c);
+  if ((tid & 63) == 0) { ps[tid >> 6] = s; pc[tid >> 6] = c; }
+  __syncthreads();
+  if (tid == 0) {
+    const float S = (ps[0] + ps[1]) + (ps[2] + ps[3]), Cn = (pc[0] + pc[1]) + (pc[2] + pc[3]);
+    loss[layer] = S / Cn + (addend ? addend[layer] : 0.f);
+    inv_count[layer] = 1.f / Cn;
   }
 }
 
@@ -344,7 +436,18 @@ extern "C" int pq3d_cross_entropy_fwd(const pq3d_ce_desc* dp, void* stream) {
   const pq3d_ce_desc d = *dp;
   if (int e = check_ce(d, false)) return e;
   if (d.R == 0) return 0;
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)((d.R + 3) / 4), d.layers), dim3(256), 0, (hipStream_t)stream, d);
+  if (d.C >= 1024) hipLaunchKernelGGL(ce_fwd_wide_kernel, dim3((unsigned)d.R, d.layers), dim3(256), 0, (hipStream_t)stream, d);
+  else hipLaunchKernelGGL(ce_fwd_kernel, dim3((unsigned)((d.R + 3) / 4), d.layers), dim3(256), 0, (hipStream_t)stream, d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pq3d_cross_entropy_mean(const pq3d_ce_desc* dp, float* loss, float* inv_count, const float* addend, void* stream) {
+  PQ_DEVICE_GUARD(stream, loss);
+  PQ_CHECK_ARG(dp != nullptr && loss && inv_count, "pq3d_cross_entropy_mean: null argument");
+  const pq3d_ce_desc d = *dp;
+  if (int e = check_layers(d.layers, "pq3d_cross_entropy_mean: layers must be in [1, PQ3D_MAX_GROUPS]")) return e;
+  PQ_CHECK_ARG(d.target && d.row_loss && d.R >= 0, "pq3d_cross_entropy_mean: bad args");
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(d.layers), dim3(256), 0, (hipStream_t)stream, d, loss, inv_count, addend);
   PQ_LAUNCH_CHECK();
   return 0;
 }
@@ -354,7 +457,8 @@ extern "C" int pq3d_cross_entropy_bwd(const pq3d_ce_desc* dp, void* stream) {
   const pq3d_ce_desc d = *dp;
   if (int e = check_ce(d, true)) return e;
   if (d.R == 0) return 0;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((d.R + 3) / 4), d.layers), dim3(256), 0, (hipStream_t)stream, d);
+  if (d.C >= 1024) hipLaunchKernelGGL(ce_bwd_wide_kernel, dim3((unsigned)d.R, d.layers), dim3(256), 0, (hipStream_t)stream, d);
+  else hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((d.R + 3) / 4), d.layers), dim3(256), 0, (hipStream_t)stream, d);
   PQ_LAUNCH_CHECK();
   return 0;
 }

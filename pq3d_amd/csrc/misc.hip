@@ -1009,8 +1009,10 @@ __global__ void dropout_mask_kernel(uint8_t* keep, long rows, long cols, const p
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     keep[i] = drop_keep(s, (uint32_t)(i / cols), (uint32_t)(i % cols)) ? 1 : 0;
 }
-__global__ void dropout_apply_kernel(const void* x, int dtx, void* y, int dty, long rows, long cols, const pq3d_dropout dr) {
-  const DropState s = drop_init(dr, 0, cols);
+__global__ void dropout_apply_kernel(const void* x, int dtx, void* y, int dty, long rows, long cols, const pq3d_dropout dr,
+                                     const float alpha) {
+  DropState s = drop_init(dr, 0, cols);
+  s.scale *= alpha;
   const long half = (cols + 1) >> 1, n = rows * half;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long r = i / half, j = i % half;
@@ -1035,12 +1037,16 @@ extern "C" int pq3d_dropout_mask(uint8_t* keep, int64_t rows, int64_t cols, cons
 
 extern "C" int pq3d_dropout_apply(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
                                   const pq3d_dropout* dr, void* stream) {
+  return pq3d_dropout_apply_scaled(x, dt_x, y, dt_y, rows, cols, dr, 1.f, stream);
+}
+extern "C" int pq3d_dropout_apply_scaled(const void* x, int32_t dt_x, void* y, int32_t dt_y, int64_t rows, int64_t cols,
+                                         const pq3d_dropout* dr, float alpha, void* stream) {
   PQ_DEVICE_GUARD(stream, x);
   PQ_CHECK_ARG(x && y && dr && dr->seed && rows >= 0 && cols >= 1 && dr->p > 0.f, "pq3d_dropout_apply: bad args");
   PQ_CHECK_DROP(*dr, rows, cols, "pq3d_dropout_apply");
   if (rows == 0) return 0;
   hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid1d(rows * ((cols + 1) / 2), 256, 8192)), dim3(256), 0,
-                     (hipStream_t)stream, x, dt_x, y, dt_y, (long)rows, (long)cols, *dr);
+                     (hipStream_t)stream, x, dt_x, y, dt_y, (long)rows, (long)cols, *dr, alpha);
   PQ_LAUNCH_CHECK();
   return 0;
 }

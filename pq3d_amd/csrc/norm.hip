@@ -563,8 +563,14 @@ template <int PL>
 __global__ __launch_bounds__(WPB * 64) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ rstd, const float* __restrict__ dy,
                                                                float* __restrict__ dx, float* __restrict__ dw, long R, int d,
-                                                               const float* __restrict__ dres) {
+                                                               const float* __restrict__ dres, const pq3d_dropout dr,
+                                                               float* __restrict__ dxm) {
   __shared__ float red[WPB][64 * PL];
+  // dxm (optional): a second copy of dx with the dropout mask (x 1/(1-p)) of site `dr` over [R, d] applied -- the gradient
+  // the PRECEDING sublayer's output projection needs (x = residual + dropout(o W^T): its dropout's backward), written here
+  // instead of by a launch of its own
+  DropState dst;
+  if (dxm) dst = drop_init(dr, 0, d);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long wave_id = (long)blockIdx.x * WPB + wave, nwaves = (long)gridDim.x * WPB;
   float acc[PL], wv[PL];
@@ -586,7 +592,11 @@ __global__ __launch_bounds__(WPB * 64) void rmsnorm_bwd_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < PL; ++j) {
       const int c = lane + 64 * j;
-      if (c < d) dx[row * d + c] = r * (g[j] - xh[j] * s) + (dres ? dres[row * d + c] : 0.f);   // + the residual branch's gradient
+      if (c < d) {
+        const float v = r * (g[j] - xh[j] * s) + (dres ? dres[row * d + c] : 0.f);   // + the residual branch's gradient
+        dx[row * d + c] = v;
+        if (dxm) dxm[row * d + c] = drop_keep(dst, (uint32_t)row, (uint32_t)c) ? v * dst.scale : 0.f;
+      }
     }
   }
 #pragma unroll
@@ -628,7 +638,18 @@ extern "C" int pq3d_rmsnorm_bwd(const float* x, const float* w, const float* rst
 
 extern "C" int pq3d_rmsnorm_bwd_res(const float* x, const float* w, const float* rstd, const float* dy, const float* dres,
                                     float* dx, float* dw, int64_t R, int32_t d, int32_t accumulate, void* stream) {
+  return pq3d_rmsnorm_bwd_res_drop(x, w, rstd, dy, dres, dx, dw, R, d, accumulate, nullptr, nullptr, stream);
+}
+
+extern "C" int pq3d_rmsnorm_bwd_res_drop(const float* x, const float* w, const float* rstd, const float* dy, const float* dres,
+                                         float* dx, float* dw, int64_t R, int32_t d, int32_t accumulate, const pq3d_dropout* drop,
+                                         float* dxm, void* stream) {
   PQ_DEVICE_GUARD(stream, x);
+  PQ_CHECK_ARG(!dxm || (drop && drop->seed && drop->p > 0.f), "pq3d_rmsnorm_bwd_res_drop: dxm needs a dropout site");
+  if (dxm) PQ_CHECK_DROP(*drop, R, d, "pq3d_rmsnorm_bwd_res_drop");
+  pq3d_dropout dr_v;
+  dr_v.p = 0.f; dr_v.site = 0; dr_v.seed = nullptr;
+  if (dxm) dr_v = *drop;
   PQ_CHECK_ARG(x && w && rstd && dy && dx && dw && R >= 0 && d >= 1 && d <= 64 * MAXPL, "pq3d_rmsnorm_bwd: bad args");
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) {
@@ -643,7 +664,7 @@ extern "C" int pq3d_rmsnorm_bwd_res(const float* x, const float* w, const float*
   long nb = (R + rms_rpw * WPB - 1) / (rms_rpw * WPB);
   if (nb > 1024) nb = 1024;
   dim3 grid((unsigned)nb);
-  RMS_DISPATCH(rmsnorm_bwd_kernel, grid, x, w, rstd, dy, dx, dw, (long)R, d, dres)
+  RMS_DISPATCH(rmsnorm_bwd_kernel, grid, x, w, rstd, dy, dx, dw, (long)R, d, dres, dr_v, dxm)
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -11,7 +11,7 @@ gradient launch and two cross-entropy launches.  No CPU fallback for the device 
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -299,38 +299,51 @@ def batch_dice_loss(logits, targets, padding_mask):
     return padded_mask_losses(_segments_first(logits), targets, padding_mask)[1]
 
 
-def cross_entropy_rows(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
-    """F.cross_entropy(logits.view(-1, C), labels.view(-1), ignore_index) through the CE kernels (mean over kept rows)."""
-    return _RowCE.apply(logits, labels, ignore_index)
+def cross_entropy_rows(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100,
+                       add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.cross_entropy(logits.view(-1, C), labels.view(-1), ignore_index) through the CE kernels (mean over kept rows).
+    ``add``: a 0-dim fp32 device tensor (the other terms of a total loss) added inside the mean launch -- "total = other + ce"
+    without an elementwise launch; its gradient is the upstream gradient."""
+    return _RowCE.apply(logits, labels, ignore_index, add)
 
 
 class _RowCE(Function):
+    """Forward: per-row loss + log-sum-exp (one launch), then the mean over the kept rows and 1 / kept (one launch).  Backward:
+    one launch; the upstream gradient and 1 / kept stay on the device (scale, scale_mul).  No framework kernels."""
+
     @staticmethod
-    def forward(ctx, logits, labels, ignore_index):
+    def forward(ctx, logits, labels, ignore_index, add=None):
+        assert add is None or (add.numel() == 1 and add.dtype == torch.float32 and add.is_cuda)
         x = logits.contiguous().float().view(-1, logits.shape[-1])
         t = labels.contiguous().view(-1).long()
         R, Ccls = x.shape
-        row_loss = torch.empty(R, dtype=torch.float32, device=x.device)
-        lse = torch.empty_like(row_loss)
+        buf = torch.empty(2 * R + 2, dtype=torch.float32, device=x.device)      # row_loss | lse | loss | 1 / kept
+        row_loss, lse, loss, inv = buf[:R], buf[R:2 * R], buf[2 * R:2 * R + 1], buf[2 * R + 1:]
         ce = L.CeDesc()
         ce.layers, ce.C, ce.R, ce.ignore_index = 1, Ccls, R, ignore_index
         ce.logits[0], ce.target, ce.row_loss, ce.lse = L.ptr(x), L.ptr(t), L.ptr(row_loss), L.ptr(lse)
         L.check(L.lib().pq3d_cross_entropy_fwd(C.byref(ce), L.stream()), "pq3d_cross_entropy_fwd")
-        cnt = (t != ignore_index).sum().float()
-        ctx.save_for_backward(x, t, lse, cnt)
+        L.check(L.lib().pq3d_cross_entropy_mean(C.byref(ce), L.ptr(loss), L.ptr(inv), L.ptr(add), L.stream()),
+                "pq3d_cross_entropy_mean")
+        ctx.has_add = add is not None
+        ctx.save_for_backward(x, t, lse, inv)
         ctx.ignore_index, ctx.shape, ctx.dtype = ignore_index, logits.shape, logits.dtype
-        return row_loss.sum() / cnt
+        return loss.view(())
 
     @staticmethod
     def backward(ctx, g):
-        x, t, lse, cnt = ctx.saved_tensors
+        x, t, lse, inv = ctx.saved_tensors
         dl = torch.empty_like(x)
-        scale = (g / cnt).reshape(1).float().contiguous()
+        scale = g.reshape(1)
+        if scale.dtype != torch.float32 or not scale.is_contiguous():
+            scale = scale.float().contiguous()
         ce = L.CeDesc()
         ce.layers, ce.C, ce.R, ce.ignore_index = 1, x.shape[1], x.shape[0], ctx.ignore_index
         ce.logits[0], ce.dlogits[0], ce.target, ce.lse, ce.scale = L.ptr(x), L.ptr(dl), L.ptr(t), L.ptr(lse), L.ptr(scale)
+        ce.scale_mul = L.ptr(inv)
         L.check(L.lib().pq3d_cross_entropy_bwd(C.byref(ce), L.stream()), "pq3d_cross_entropy_bwd")
-        return dl.view(ctx.shape).to(ctx.dtype), None, None
+        dl = dl.view(ctx.shape)
+        return (dl if ctx.dtype == torch.float32 else dl.to(ctx.dtype)), None, None, (g if ctx.has_add else None)
 
 
 class DirectCriterion(nn.Module):

@@ -109,30 +109,32 @@ def dropout_mask(rows: int, cols: int, drop: L.Drop) -> torch.Tensor:
     return keep
 
 
-def _dropout_apply(x: torch.Tensor, drop: L.Drop, out_dtype=None) -> torch.Tensor:
+def _dropout_apply(x: torch.Tensor, drop: L.Drop, out_dtype=None, alpha: float = 1.0) -> torch.Tensor:
     x = x.contiguous()
     y = _empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     cols = x.shape[-1]
     dc = drop.c()
-    L.check(L.lib().pq3d_dropout_apply(L.ptr(x), L.dt_of(x), L.ptr(y), L.dt_of(y), x.numel() // cols, cols, C.byref(dc),
-                                       L.stream()), "pq3d_dropout_apply")
+    L.check(L.lib().pq3d_dropout_apply_scaled(L.ptr(x), L.dt_of(x), L.ptr(y), L.dt_of(y), x.numel() // cols, cols, C.byref(dc),
+                                              float(alpha), L.stream()), "pq3d_dropout_apply")
     return y
 
 
 class _Dropout(Function):
     @staticmethod
-    def forward(ctx, x, drop):
-        ctx.drop = drop
-        return _dropout_apply(x, drop)
+    def forward(ctx, x, drop, alpha=1.0):
+        ctx.drop, ctx.alpha = drop, alpha
+        return _dropout_apply(x, drop, alpha=alpha)
 
     @staticmethod
     def backward(ctx, dy):
-        return _dropout_apply(dy, ctx.drop), None
+        return _dropout_apply(dy, ctx.drop, alpha=ctx.alpha), None, None
 
 
-def dropout(x: torch.Tensor, drop: Optional[L.Drop]) -> torch.Tensor:
-    """nn.Dropout over the last dim as the site's column axis (site = x viewed as [rows, x.shape[-1]])."""
-    return x if drop is None else _Dropout.apply(x, drop)
+def dropout(x: torch.Tensor, drop: Optional[L.Drop], alpha: float = 1.0) -> torch.Tensor:
+    """alpha * nn.Dropout(x) over the last dim as the site's column axis (site = x viewed as [rows, x.shape[-1]])."""
+    if drop is None:
+        return x if alpha == 1.0 else x * alpha
+    return _Dropout.apply(x, drop, float(alpha))
 
 
 # ------------------------------------------------------------------------------------------------ small kernels
@@ -433,7 +435,8 @@ def dw_deferred_flush(run: bool = True) -> None:
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value, drop=None, residual=None):
+    def forward(ctx, x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, fill_value, drop=None, residual=None, masked_grad=None):
+        ctx.masked_grad = masked_grad
         x, x2, w, fill_flag, residual = _c(x), _c(x2), _c(w), _c(fill_flag), _c(residual)
         # epilogue order (gemm_common.h): bias, activation, dropout, then "+ residual": y = residual + dropout(x w^T + b).
         # No activation together with a residual: the backward reads the activation's mask off the saved OUTPUT.
@@ -468,7 +471,13 @@ class _Linear(Function):
             alpha = 1.0 / (1.0 - ctx.drop.p)
         else:
             if ctx.drop is not None:   # dropout sits after the activation: undo it first (mask * 1/(1-p))
-                g = _dropout_apply(g, ctx.drop)
+                mg = ctx.masked_grad
+                if mg is not None and mg.get("of") is not None and mg["of"].data_ptr() == g.data_ptr() and \
+                        mg["of"].shape == g.shape and mg["g"].dtype == g.dtype:
+                    g = mg.pop("g")        # written by the consuming norm's backward kernel (pq3d_rmsnorm_bwd_res_drop)
+                    mg.pop("of")
+                else:
+                    g = _dropout_apply(g, ctx.drop)
             if ctx.act in ("relu", "gelu"):
                 g = act_bwd(g, saved, ctx.act, act_dtype(ct))
         if rm is not None or fill_flag is not None:
@@ -516,7 +525,7 @@ class _Linear(Function):
             dw = None
             if db is not None and want_db and fuse:
                 db = None
-        return dx, dw, db, dx2, None, None, None, None, None, None, None, dres
+        return dx, dw, db, dx2, None, None, None, None, None, None, None, dres, None
 
 
 def dw_operands(gs, xs, x2s, N: int, K: int, R: int, ct: int):
@@ -563,11 +572,14 @@ def dw_operands(gs, xs, x2s, N: int, K: int, R: int, ct: int):
 
 
 def linear(x, w, b=None, *, ct: int, x2=None, act: Optional[str] = None, out_dtype=torch.float32, row_mask=None,
-           fill_flag=None, fill_value=0.0, drop: Optional[L.Drop] = None, residual=None):
+           fill_flag=None, fill_value=0.0, drop: Optional[L.Drop] = None, residual=None, masked_grad: Optional[dict] = None):
     """y = act((x + x2) @ w.T + b); rows where row_mask == False are zeroed; rows where fill_flag == True are
     set to fill_value (masked_fill of whole rows); residual (same shape as y) is added in the GEMM epilogue.
-    (F.linear call sites, see include/pq3d_hip.h)"""
-    return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value), drop, residual)
+    (F.linear call sites, see include/pq3d_hip.h)
+    masked_grad: a hand-over slot shared with the rmsnorm that consumes y (``rmsnorm(..., grad_drop=(drop, slot))``): that
+    norm's backward kernel also writes dropout_mask * dy / (1 - p), which this layer's backward then takes instead of
+    launching a dropout of its own (checked by address: anything else falls back to the launch)."""
+    return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value), drop, residual, masked_grad)
 
 
 class _LinearGroup(Function):
@@ -1372,11 +1384,13 @@ def split_rows(y, n: int):
 # ------------------------------------------------------------------------------------------------ T5 body pieces
 class _RMSNorm(Function):
     """res=True: returns (y, x) -- the second output is x itself, for the sublayer's residual add: the gradients of BOTH uses
-    of x then arrive in this backward and are summed inside its kernel (no add launch at the junction)."""
+    of x then arrive in this backward and are summed inside its kernel (no add launch at the junction).
+    grad_drop = (drop site, slot dict): the backward kernel also writes dropout_mask(site) * dx / (1 - p) into slot["g"]
+    (slot["of"] = dx) for the projection that produced x (ops.linear(..., drop=site, masked_grad=slot))."""
 
     @staticmethod
-    def forward(ctx, x, w, eps, res=False):
-        ctx.res = bool(res)
+    def forward(ctx, x, w, eps, res=False, grad_drop=None):
+        ctx.res, ctx.grad_drop = bool(res), grad_drop
         x, w = _c(x).float(), _c(w).float()
         d_ = x.shape[-1]
         R = x.numel() // d_
@@ -1392,38 +1406,51 @@ class _RMSNorm(Function):
         x, w, rstd = ctx.saved_tensors
         d_ = x.shape[-1]
         if dy is None:   # only the pass-through was used
-            return (dres, None, None, None)
+            return (dres, None, None, None, None)
         dy = dy.contiguous().float()
         dres = dres.contiguous().float() if dres is not None else None
         dx = torch.empty_like(x)
         slot, give = arena_take([ctx.pptr], [w.numel()])   # the owner's gradient arena, when offered for this pass (pre-zeroed)
         dw = slot[0] if slot is not None else torch.empty_like(w)
-        L.check(L.lib().pq3d_rmsnorm_bwd_res(L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dy), L.ptr(dres), L.ptr(dx), L.ptr(dw),
-                                             x.numel() // d_, d_, 1 if slot is not None else 0, L.stream()), "pq3d_rmsnorm_bwd_res")
-        return dx, (dw if (slot is None or give) else None), None, None
+        gd = ctx.grad_drop
+        dxm, dc = None, None
+        if gd is not None and gd[0] is not None and gd[0].p > 0.0:
+            dxm, dc = torch.empty_like(x), gd[0].c()
+        L.check(L.lib().pq3d_rmsnorm_bwd_res_drop(L.ptr(x), L.ptr(w), L.ptr(rstd), L.ptr(dy), L.ptr(dres), L.ptr(dx), L.ptr(dw),
+                                                  x.numel() // d_, d_, 1 if slot is not None else 0,
+                                                  C.byref(dc) if dc is not None else None, L.ptr(dxm), L.stream()),
+                "pq3d_rmsnorm_bwd_res_drop")
+        if dxm is not None:
+            gd[1]["g"], gd[1]["of"] = dxm, dx
+        return dx, (dw if (slot is None or give) else None), None, None, None
 
 
-def rmsnorm(x, w, eps: float = 1e-6):
+def rmsnorm(x, w, eps: float = 1e-6, grad_drop=None):
     """T5LayerNorm: x * rsqrt(mean(x^2) + eps) * w (fp32)."""
-    return _RMSNorm.apply(x, w, float(eps))
+    return _RMSNorm.apply(x, w, float(eps), False, grad_drop)
 
 
-def rmsnorm_res(x, w, eps: float = 1e-6):
+def rmsnorm_res(x, w, eps: float = 1e-6, grad_drop=None):
     """(rmsnorm(x), x'): x' is x for the residual add of the pre-norm sublayer -- its gradient joins the norm's inside the
     norm's backward kernel."""
-    return _RMSNorm.apply(x, w, float(eps), True)
+    return _RMSNorm.apply(x, w, float(eps), True, grad_drop)
 
 
 class _Embedding(Function):
     @staticmethod
-    def forward(ctx, table, ids):
+    def forward(ctx, table, ids, drop=None):
         table, ids = _c(table).float(), _c(ids).long()
         d_ = table.shape[1]
         out = _empty(*ids.shape, d_, dtype=torch.float32, device=table.device)
-        L.check(L.lib().pq3d_embedding_fwd(L.ptr(table), L.ptr(ids), L.ptr(out), ids.numel(), d_, L.stream()),
-                "pq3d_embedding_fwd")
+        if drop is not None:
+            dc = drop.c()
+            L.check(L.lib().pq3d_embedding_drop_fwd(L.ptr(table), L.ptr(ids), L.ptr(out), ids.numel(), d_, C.byref(dc), L.stream()),
+                    "pq3d_embedding_drop_fwd")
+        else:
+            L.check(L.lib().pq3d_embedding_fwd(L.ptr(table), L.ptr(ids), L.ptr(out), ids.numel(), d_, L.stream()),
+                    "pq3d_embedding_fwd")
         ctx.save_for_backward(ids)
-        ctx.shape = table.shape
+        ctx.shape, ctx.drop = table.shape, drop
         ctx.pptr = table.data_ptr()
         return out
 
@@ -1433,10 +1460,62 @@ class _Embedding(Function):
         slot, give = arena_take([ctx.pptr], [ctx.shape[0] * ctx.shape[1]])
         dt = slot[0].view(ctx.shape) if slot is not None else torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
         dout = dout.contiguous().float()
-        L.check(L.lib().pq3d_embedding_bwd_acc(L.ptr(dout), L.ptr(ids), L.ptr(dt), ids.numel(), ctx.shape[1], L.stream()),
-                "pq3d_embedding_bwd_acc")
-        return (dt if (slot is None or give) else None), None
+        if ctx.drop is not None:
+            dc = ctx.drop.c()
+            L.check(L.lib().pq3d_embedding_drop_bwd_acc(L.ptr(dout), L.ptr(ids), L.ptr(dt), ids.numel(), ctx.shape[1], C.byref(dc),
+                                                        L.stream()), "pq3d_embedding_drop_bwd_acc")
+        else:
+            L.check(L.lib().pq3d_embedding_bwd_acc(L.ptr(dout), L.ptr(ids), L.ptr(dt), ids.numel(), ctx.shape[1], L.stream()),
+                    "pq3d_embedding_bwd_acc")
+        return (dt if (slot is None or give) else None), None, None
 
 
-def embedding(table, ids):
-    return _Embedding.apply(table, ids)
+class _T5Prep(Function):
+    """decoder_input_ids, the [B, H, T, T] self-attention bias (relative-position bias + causal -inf) and the encoder tokens'
+    key-padding bytes in ONE launch (pq3d_t5_prep); backward: the bias table's gradient in one more (pq3d_t5_bias_bwd)."""
+
+    @staticmethod
+    def forward(ctx, rel, labels, buckets, enc_valid, start_id, pad_id, H):
+        rel, labels, buckets = _c(rel).float(), _c(labels).long(), _c(buckets).long()
+        B, T = labels.shape
+        dev = rel.device
+        ids = _empty(B, T, dtype=torch.int64, device=dev)
+        bias = _empty(B, H, T, T, dtype=torch.float32, device=dev)
+        kpm, ev, N = None, None, 0
+        if enc_valid is not None:
+            ev = _c(enc_valid)
+            assert ev.dtype == torch.bool and ev.shape[0] == B
+            N = ev.shape[1]
+            kpm = _empty(B, N, dtype=torch.bool, device=dev)
+        L.check(L.lib().pq3d_t5_prep(L.ptr(labels), int(start_id), int(pad_id), L.ptr(rel), L.ptr(buckets), L.ptr(ev), L.ptr(ids),
+                                     L.ptr(bias), L.ptr(kpm), B, T, H, N, L.stream()), "pq3d_t5_prep")
+        ctx.save_for_backward(buckets)
+        ctx.cfg = (B, T, H, rel.shape[0])
+        ctx.pptr = rel.data_ptr()
+        ctx.mark_non_differentiable(ids)
+        if kpm is not None:
+            ctx.mark_non_differentiable(kpm)
+            return ids, bias, kpm
+        return ids, bias
+
+    @staticmethod
+    def backward(ctx, _dids, dbias, _dkpm=None):
+        (buckets,) = ctx.saved_tensors
+        B, T, H, NB = ctx.cfg
+        slot, give = arena_take([ctx.pptr], [NB * H])
+        drel = slot[0].view(NB, H) if slot is not None else _empty(NB, H, dtype=torch.float32, device=dbias.device)
+        dbias = dbias.contiguous().float()
+        L.check(L.lib().pq3d_t5_bias_bwd(L.ptr(dbias), L.ptr(buckets), L.ptr(drel), B, T, H, NB, 1 if slot is not None else 0,
+                                         L.stream()), "pq3d_t5_bias_bwd")
+        return (drel if (slot is None or give) else None), None, None, None, None, None, None
+
+
+def t5_prep(rel, labels, buckets, enc_valid, start_id: int, pad_id: int, H: int):
+    """(decoder_input_ids [B,T], self-attention bias [B,H,T,T], encoder key-padding bytes [B,N] or None): see _T5Prep."""
+    out = _T5Prep.apply(rel, labels, buckets, enc_valid, int(start_id), int(pad_id), int(H))
+    return (out[0], out[1], out[2]) if enc_valid is not None else (out[0], out[1], None)
+
+
+def embedding(table, ids, drop: Optional[L.Drop] = None):
+    """table[ids] (nn.Embedding), optionally with the dropout of site ``drop`` over the [ids.numel(), d] rows fused in."""
+    return _Embedding.apply(table, ids, drop if (drop is not None and drop.p > 0.0) else None)

@@ -47,11 +47,6 @@ def shift_right(labels: torch.Tensor, start_id: int, pad_id: int) -> torch.Tenso
     return torch.where(ids == -100, torch.full_like(ids, pad_id), ids)
 
 
-def _norm_res(x, w, eps):
-    """T5LayerNorm whose backward also takes the residual branch's gradient (pq3d_rmsnorm_bwd_res: no add launch)."""
-    return ops.rmsnorm_res(x, w, eps)
-
-
 def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], labels: torch.Tensor, ct: int,
                    training: bool = False, drop_epoch_owner=None) -> torch.Tensor:
     """Teacher-forced logits [B, T, vocab] of the HF T5 model's decoder attending to ``enc`` [B, N, d_model]
@@ -71,23 +66,34 @@ def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], 
         site[0] += 1
         return ops.make_drop(p_drop, DROP_BASE_T5 + site[0], dev)
 
-    def drop(x):
-        d = next_drop()
-        return x if d is None else ops.dropout(x, d)
+    handover = [None]   # (drop site, slot) of the last proj_residual: the norm that consumes its output writes the masked gradient
 
     def proj_residual(o, w):
-        """x + dropout(o @ w^T): dropout and the residual add ride the GEMM epilogue (one launch)."""
-        return ops.linear(o, w, None, ct=ct, residual=x, drop=next_drop())
+        """x + dropout(o @ w^T): dropout and the residual add ride the GEMM epilogue (one launch); in the backward the
+        dropout's mask is applied by the NEXT norm's backward kernel (ops.rmsnorm grad_drop) instead of a launch of its own."""
+        d = next_drop()
+        slot = {} if d is not None else None
+        handover[0] = (d, slot) if d is not None else None
+        return ops.linear(o, w, None, ct=ct, residual=x, drop=d, masked_grad=slot)
 
-    ids = shift_right(labels, cfg.decoder_start_token_id, cfg.pad_token_id)
-    x = drop(ops.embedding(model.shared.weight, ids))
-    # relative-position + causal bias, shared by all layers (the table lives in block 0)
+    def norm_res(x_, w_):
+        gd, handover[0] = handover[0], None
+        return ops.rmsnorm_res(x_, w_, cfg.layer_norm_epsilon, grad_drop=gd)
+
+    T5_TT_MAX = 114 * 114   # pq3d_t5_bias_bwd keeps the [T, T] sums in LDS
     rel = dec.block[0].layer[0].SelfAttention.relative_attention_bias.weight           # [num_buckets, H]
     buckets = relative_buckets(T, cfg.relative_attention_num_buckets, getattr(cfg, "relative_attention_max_distance", 128), dev)
-    pos_bias = ops.embedding(rel, buckets).permute(2, 0, 1)                              # [H, T, T]
-    causal = torch.ones(T, T, dtype=torch.bool, device=dev).triu(1)
-    self_bias = pos_bias.masked_fill(causal, float("-inf")).unsqueeze(0).expand(B, H, T, T).contiguous()
-    enc_kpm = enc_valid.logical_not().contiguous() if enc_valid is not None else None
+    if T * T <= T5_TT_MAX and rel.shape[0] <= 256 and (enc_valid is None or enc_valid.dtype == torch.bool):
+        # shift_right, relative-position + causal bias (shared by all layers; the table lives in block 0) and the encoder's
+        # key-padding bytes: one launch (was ~12 framework launches forward, ~8 backward)
+        ids, self_bias, enc_kpm = ops.t5_prep(rel, labels, buckets, enc_valid, cfg.decoder_start_token_id, cfg.pad_token_id, H)
+    else:
+        ids = shift_right(labels, cfg.decoder_start_token_id, cfg.pad_token_id)
+        pos_bias = ops.embedding(rel, buckets).permute(2, 0, 1)                              # [H, T, T]
+        causal = torch.ones(T, T, dtype=torch.bool, device=dev).triu(1)
+        self_bias = pos_bias.masked_fill(causal, float("-inf")).unsqueeze(0).expand(B, H, T, T).contiguous()
+        enc_kpm = enc_valid.logical_not().contiguous() if enc_valid is not None else None
+    x = ops.embedding(model.shared.weight, ids, drop=next_drop())
     ad = ops.act_dtype(ct)
     # cross-attention K/V projections of ALL layers read the same encoder tokens: one grouped launch (and one
     # K-concatenated input-gradient product, one grouped weight-gradient product in the backward)
@@ -97,25 +103,26 @@ def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], 
     for li, blk in enumerate(dec.block):
         sa, ca, ff = blk.layer[0], blk.layer[1], blk.layer[2]
         # -- self attention
-        h, x = _norm_res(x, sa.layer_norm.weight, cfg.layer_norm_epsilon)
+        h, x = norm_res(x, sa.layer_norm.weight)
         A = sa.SelfAttention
         q, k, v = ops.linear_group([h, h, h], [A.q.weight, A.k.weight, A.v.weight], ct=ct, out_dtype=ad)
         o = ops.attention(q, k, v, H=H, ct=ct, scale=1.0, bias=self_bias, drop=next_drop())
         x = proj_residual(o, A.o.weight)
         # -- cross attention to the projected query tokens (no position bias)
-        h, x = _norm_res(x, ca.layer_norm.weight, cfg.layer_norm_epsilon)
+        h, x = norm_res(x, ca.layer_norm.weight)
         A = ca.EncDecAttention
         q = ops.linear(h, A.q.weight, None, ct=ct, out_dtype=ad)
         k, v = xkv[2 * li], xkv[2 * li + 1]
         o = ops.attention(q, k, v, H=H, ct=ct, scale=1.0, kpm=enc_kpm, drop=next_drop())
         x = proj_residual(o, A.o.weight)
         # -- feed forward
-        h, x = _norm_res(x, ff.layer_norm.weight, cfg.layer_norm_epsilon)
+        h, x = norm_res(x, ff.layer_norm.weight)
         hid = ops.linear(h, ff.DenseReluDense.wi.weight, None, ct=ct, act="relu", out_dtype=ad, drop=next_drop())
         x = proj_residual(hid, ff.DenseReluDense.wo.weight)
-    x = drop(ops.rmsnorm(x, dec.final_layer_norm.weight, cfg.layer_norm_epsilon))
-    if cfg.tie_word_embeddings:
-        x = x * (dm ** -0.5)
+    gd, handover[0] = handover[0], None
+    x = ops.rmsnorm(x, dec.final_layer_norm.weight, cfg.layer_norm_epsilon, grad_drop=gd)
+    # final dropout and the tied-embedding scale d_model^-0.5 in one launch (either direction)
+    x = ops.dropout(x, next_drop(), alpha=(dm ** -0.5) if cfg.tie_word_embeddings else 1.0)
     return ops.linear(x, model.lm_head.weight, None, ct=ct)
 
 

@@ -157,3 +157,31 @@ def test_cross_entropy_out_of_range_label_poisons_the_loss():
         assert torch.isnan(cross_entropy_rows(x, tb))
     ti = t.clone(); ti[5] = -100
     assert torch.isfinite(cross_entropy_rows(x, ti))
+
+
+@pytest.mark.parametrize("R,Cls", [(512, 32128), (37, 1031), (64, 2048), (16, 201), (5, 1024)])
+def test_cross_entropy_rows_matches_torch_narrow_and_wide_rows(R, Cls):
+    """F.cross_entropy (mean over kept rows, ignore_index) forward and backward: the wave-per-row kernels (class logits) and
+    the workgroup-per-row kernels of wide rows (>= 1024 classes: the caption head's 32128-way LM head; 1031 = rows that do
+    not start on 16-byte boundaries), the mean + 1 / kept on the device, an addend folded into the mean launch."""
+    from pq3d_amd.losses import cross_entropy_rows
+    g = torch.Generator().manual_seed(R + Cls)
+    x = (torch.randn(R, Cls, generator=g) * 3).to("cuda").requires_grad_(True)
+    t = torch.randint(0, Cls, (R,), generator=g)
+    t[::5] = -100
+    t = t.to("cuda")
+    xr = x.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t)
+    add = torch.full((), 0.75, device="cuda", requires_grad=True)
+    out = cross_entropy_rows(x, t, add=add)
+    assert abs(float(out) - 0.75 - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    w = torch.tensor(1.7, device="cuda")
+    (out * w).backward()
+    (ref * 1.7).backward()
+    assert float(add.grad) == pytest.approx(1.7)
+    err = float((x.grad.double() - xr.grad).abs().max())
+    assert err <= 2e-6 * float(xr.grad.abs().max()) + 1e-9, err
+    assert float(x.grad[::5].abs().max()) == 0.0     # ignored rows: exact zeros
+    # plain call (no addend) on a 3-D logits tensor, as the caption head hands it over
+    out2 = cross_entropy_rows(x.detach().view(1, R, Cls), t.view(1, R))
+    assert abs(float(out2) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
