@@ -41,17 +41,32 @@ __global__ __launch_bounds__(256) void t5_bias_bwd_kernel(const float* __restric
   for (int p = tid; p < TT; p += 256) {
     const int q = p / T, k = p % T;
     float s = 0.f;
-    if (k <= q)
-      for (int b = 0; b < B; ++b) s += dbias[(((long)b * H + h) * T + q) * T + k];
+    if (k <= q) {
+      const float* src = dbias + ((long)h * T + q) * T + k;
+      const long sb = (long)H * T * T;
+      for (int b0 = 0; b0 < B; b0 += 8) {       // 8 independent loads in flight (one per scene), summed in scene order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = b0 + u < B ? src[(long)(b0 + u) * sb] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+    }
     S[p] = s;
     bk[p] = (uint8_t)buckets[p];
   }
   __syncthreads();
-  for (int nb = tid; nb < NB; nb += 256) {
+  // 8 lanes per bucket: lane j sums the pairs p = j, j + 8, ..., then a fixed 3-step tree over the 8 partial sums
+  for (int nb0 = 0; nb0 < NB; nb0 += 32) {
+    const int nb = nb0 + (tid >> 3), j = tid & 7;
     float a = 0.f;
-    for (int p = 0; p < TT; ++p) a += bk[p] == nb ? S[p] : 0.f;
-    float* o = drel + (long)nb * H + h;
-    *o = accumulate ? *o + a : a;
+    if (nb < NB)
+      for (int p = j; p < TT; p += 8) a += bk[p] == nb ? S[p] : 0.f;
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+    if (nb < NB && j == 0) {
+      float* o = drel + (long)nb * H + h;
+      *o = accumulate ? *o + a : a;
+    }
   }
 }
 

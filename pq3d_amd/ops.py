@@ -1476,6 +1476,7 @@ class _T5Prep(Function):
 
     @staticmethod
     def forward(ctx, rel, labels, buckets, enc_valid, start_id, pad_id, H):
+        ctx.set_materialize_grads(False)    # no zero-filled gradients for the integer / boolean outputs
         rel, labels, buckets = _c(rel).float(), _c(labels).long(), _c(buckets).long()
         B, T = labels.shape
         dev = rel.device
@@ -1502,6 +1503,8 @@ class _T5Prep(Function):
     def backward(ctx, _dids, dbias, _dkpm=None):
         (buckets,) = ctx.saved_tensors
         B, T, H, NB = ctx.cfg
+        if dbias is None:
+            return (None,) * 7
         slot, give = arena_take([ctx.pptr], [NB * H])
         drel = slot[0].view(NB, H) if slot is not None else _empty(NB, H, dtype=torch.float32, device=dbias.device)
         dbias = dbias.contiguous().float()
