@@ -333,8 +333,13 @@ int pq3d_add_ln_bwd(const pq3d_ln_desc* d, void* stream);
  * ------------------------------------------------------------------------------------------------ */
 /* out[n] = sum_r x[r*ld + n]  (bias gradients). */
 int pq3d_colsum(const void* x, int32_t dt, int64_t R, int64_t N, int64_t ld, float* out, void* stream);
-/* Grouped form: out_g[n] (+)= sum_r x_g[r*ld + n] for g < groups (host arrays of device pointers);
- * accumulate != 0 adds onto out_g (one writer per element: no atomics needed). */
+/* Grouped form: out_g[n] (+)= sum_r x_g[r*ld + n] for g < groups (host arrays of device pointers).
+ * accumulate == 0: every out_g[n] is WRITTEN by exactly one workgroup, fixed summation order (deterministic).
+ * accumulate == 1: added onto out_g, which must hold valid numbers (a pre-zeroed or running gradient slot).  Up to 2047 rows
+ *   one writer per element; from 2048 rows on the rows are cut into slices that add with fp32 atomics (bias gradients of the
+ *   10 240-row shipped shapes: 12-36 workgroups walking every row otherwise) -- the sum is then order-dependent in the last
+ *   bit.  accumulate == 2: as 1 but ALWAYS one writer per element (bit-reproducible; what fingerprint / bit-exactness tests
+ *   and a deterministic training mode ask for). */
 int pq3d_colsum_grouped(const void* const* x, float* const* out, int32_t groups, int32_t dt, int64_t R, int64_t N,
                         int64_t ld, int32_t accumulate, void* stream);
 

@@ -208,6 +208,7 @@ PQ_DEV TileIdx tile_index(const int xcd_order) {
   TileIdx t = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
   if (!xcd_order) return t;   // uniform
   const int sr = xcd_order & 255, zr = xcd_order >> 8;
+  if (zr < 1 || (int)gridDim.z % zr) return t;   // a run length that does not divide the z extent would map tiles out of range
   const int gx = gridDim.x, gy = gridDim.y, gyv = gy * zr, total = gx * gy * (int)gridDim.z;
   const int id = t.x + gx * (t.y + gy * t.z), xcd = id & 7, per = total >> 3, rem = total & 7;
   int l = xcd * per + min(xcd, rem) + (id >> 3);   // XCD j owns logical tiles [j * per + min(j, rem), ...): rem XCDs hold one more
@@ -259,6 +260,7 @@ inline int xcd_order_for(long workgroups, long b_plane_bytes, int zrun) {
   return 0;
 #else
   if (workgroups < PQ3D_XCD_MIN) return 0;
+  if (zrun > 0xFFFFFF) zrun = 1;   // packed as sr | zrun << 8 (the kernel also refuses a run that does not divide gridDim.z)
   const int sr = b_plane_bytes * (zrun > 1 ? zrun : 1) <= (5L << 19) ? 1 : 8;
   return sr | ((zrun > 1 ? zrun : 1) << 8);
 #endif

@@ -796,7 +796,7 @@ extern "C" int pq3d_colsum_grouped(const void* const* x, float* const* out, int3
   }
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)((N + 63) / 64), groups);
-  if (accumulate && R >= 2048) {   // long columns into an accumulating (pre-zeroed / running) output: row slices, ~2 workgroups per CU
+  if (accumulate == 1 && R >= 2048) {   // (accumulate == 2: the deterministic single-slice form at every row count) long columns into an accumulating (pre-zeroed / running) output: row slices, ~2 workgroups per CU
     const long blocks = (long)grid.x * grid.y;
     long nz = 512 / (blocks > 0 ? blocks : 1);
     if (nz > R / 512) nz = R / 512;

@@ -497,7 +497,9 @@ extern "C" int pq3d_add_ln_bwd(const pq3d_ln_desc* dp, void* stream) {
   // big streaming calls: 8 waves per block, 8 rows per wave -- the parameter-gradient atomics (one per column per block,
   // the 64-byte lines bounce between the XCDs' L2s) set the time, so few fat blocks win: measured at R = 2 x 8192,
   // blocks x waves: 1024x4 43 us, 512x4 28, 256x4 20, 256x8 16, 128x16 15, 64x16 28; query-sized calls: 4 waves x 2 rows
-  const bool big = d.R >= 4096;
+  // (rows wider than 1024 keep the 4-wave kernel at every row count: with 32 values per lane the 8-wave kernel's reduction
+  // buffer would be 128 KB of static LDS -- one block per CU and outside the 64 KB every other kernel stays within)
+  const bool big = d.R >= 4096 && (merged || d.d <= 1024);
   // query-sized calls: ~100 blocks of 4 waves (measured, rows-per-wave sweep: R = 800: 2 rows per wave 126 us per step, 4: 130,
   // 8: 176; R = 1600: 2: 300, 4: 275, 8: 311 -- more rows per wave = fewer contended parameter-gradient atomics, fewer = more
   // rows in flight)

@@ -56,7 +56,8 @@ def _colsum_acc(xs: Sequence[torch.Tensor], outs: Sequence[torch.Tensor], rows: 
     for xc, oc in batches:
         xa = (C.c_void_p * len(xc))(*[L.ptr(t) for t in xc])
         oa = (C.c_void_p * len(oc))(*[L.ptr(t) for t in oc])
-        L.check(L.lib().pq3d_colsum_grouped(xa, oa, len(xc), L.dt_of(xc[0]), rows, N, N, 1, L.stream()),
+        # accumulate = 2: the one-writer (bit-reproducible) form at every row count; 1 lets long columns add row slices atomically
+        L.check(L.lib().pq3d_colsum_grouped(xa, oa, len(xc), L.dt_of(xc[0]), rows, N, N, 2 if ops.DETERMINISTIC else 1, L.stream()),
                 "pq3d_colsum_grouped")
 
 

@@ -107,6 +107,13 @@ class GraphedQuery3D(nn.Module):
     called (same keys and shapes as the sample).  Parameters are the wrapped model's own (state_dict / optimizer see them
     through ``gm.model``).
 
+    UNREACHED PARAMETERS ARE FIXED AT CAPTURE TIME: a parameter the captured sample batch's loss does not reach keeps
+    ``.grad = None`` on every replay (both modes; under DDP's hook-driven 'autograd' mode this needs
+    ``find_unused_parameters=True``).  A later batch that WOULD reach such a parameter (data-dependent head routing, a prompt
+    type absent from the sample) replays the captured graph all the same -- its gradient for that parameter is not computed.
+    Capture on a batch that exercises every branch the run will use, or rebuild the wrapper when the routing changes;
+    ``unreached_parameter_names()`` lists what the capture left out so a caller can assert on it.
+
     Both modes replay the same two captured graphs; the captured backward writes the parameter gradients into two
     persistent flat fp32 buffers (the fused decoder in place, the rest with one multi-tensor copy).
     mode='direct' (default): ``.grad`` of every parameter is SET to its view of those buffers after the replay -- no
@@ -277,6 +284,12 @@ class GraphedQuery3D(nn.Module):
             if dst:
                 torch._foreach_copy_(dst, list(gin))
         return gin
+
+    def unreached_parameter_names(self):
+        """Names of the parameters the captured sample batch's loss did not reach: their ``.grad`` stays None on every
+        replay, whatever later batches contain (see the class docstring)."""
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        return sorted(names.get(i, "<unnamed>") for i in self._unused)
 
     def _accumulating(self) -> bool:
         """True when every parameter's .grad still aliases its flat-buffer view (no zero_grad since the last backward)."""

@@ -16,6 +16,10 @@ from ._lib import BF16, BF16X3, F32
 from .profiler import timed
 
 _empty = torch.empty
+# PQ3D_DETERMINISTIC=1: reductions that have an order-independent form take it (today: bias-gradient column sums of long
+# accumulating calls, include/pq3d_hip.h pq3d_colsum_grouped accumulate == 2).  Split-K weight gradients and the LayerNorm
+# parameter gradients still add with fp32 atomics.
+DETERMINISTIC = os.environ.get("PQ3D_DETERMINISTIC", "0") == "1"
 
 
 def act_dtype(ct: int) -> torch.dtype:

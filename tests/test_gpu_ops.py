@@ -254,6 +254,26 @@ def test_add_layernorm_three_branch_backward_without_dx_atomics(d, with_coef, B)
         assert err < 2e-5, (i, err)
 
 
+@pytest.mark.parametrize("d", [1152, 2048, 1024])
+def test_add_layernorm_wide_rows_many_rows(d):
+    """R >= 4096 rows of more than 1024 columns (32 values per lane): the backward must stay on the 4-wave kernel (64 KB of
+    LDS); 1024 columns take the 8-wave kernel.  Checked against float64 autograd."""
+    R = 4100
+    x, o = rnd(R, d), rnd(R, d, seed=5)
+    gam, bet = rnd(d, seed=20).abs() + 0.5, rnd(d, seed=30)
+    leaves = [t.to(DEV).requires_grad_(True) for t in (x, o, gam, bet)]
+    y = ops.add_layernorm(leaves[0], [leaves[1]], [leaves[2]], [leaves[3]], eps=1e-5)
+    refl = [t.clone().double().requires_grad_(True) for t in (x, o, gam, bet)]
+    yr = O.layer_norm(refl[0] + refl[1], refl[2], refl[3])
+    close(y, yr, F32, "y")
+    gy = rnd(R, d, seed=77)
+    y.backward(gy.to(DEV))
+    yr.backward(gy.double())
+    for i, (a, r) in enumerate(zip(leaves, refl)):
+        err = float((a.grad.double().cpu() - r.grad).abs().max()) / float(r.grad.abs().max())
+        assert err < 5e-5, (i, err)
+
+
 # ---------------------------------------------------------------------------------------------- misc
 def test_pairwise_locs_and_fourier_and_spatial_bias():
     c = torch.rand(2, 23, 3, generator=torch.Generator().manual_seed(11)) * 4

@@ -188,16 +188,27 @@ def test_parameters_without_gradient_stay_in_the_layout_and_are_skipped_per_step
     """A head the loss never reaches gets no gradient; torch.optim.AdamW neither decays nor moves it.  The flat layout is
     deterministic (no first-step probe: ranks / checkpoints / captures agree on it); the AdamW launch marks such parameters'
     segments 'skip' for the step, so they and their moments stay bit-identical while everything else moves."""
-    for name in util.fixtures("F7_"):
-        _z, args = util.load_fixture(name)
-        model, ts, dd = build(args)
-        n0, lay0 = ts.flat_p.numel(), ts.layout()
-        ts.forward_backward(dd)
-        missing = [p for p in ts.reducer.params if p.grad is None]
-        if missing:
-            break
-    else:
-        pytest.skip("no F7 fixture with an unreached parameter")
+    from pq3d_amd import synth
+    from pq3d_amd.model import Query3DUnified, make_cfg
+    # a grounding head next to the mask head, and a loss that only reads the mask head's outputs: the grounding head's MLP is
+    # in the layout (get_opt_params lists it, query3d_unified.py:224-238) but its parameters never see a gradient
+    model = Query3DUnified(make_cfg(d=64, H=4, L=2, memories=["voxel", "mv"], heads=["mask", "ground"], use_self_mask=True,
+                                    C=21, foc=(0, 2)), compute="fp32")
+    synth.fill_module(model, 0)
+    model.to(DEV).eval()
+    dd = synth.synth_data_dict(2, 48, 10, {"voxel": 64, "mv": 64}, seed=3, memories=["voxel", "mv"])
+    dd["tgt_object_id"] = torch.zeros(2, dtype=torch.long)
+    dd = {k: v.to(DEV) for k, v in dd.items()}
+
+    def loss_fn(out):
+        return out["query_embeds"].square().mean() + sum(m.clamp(min=-50.0).mean() for m in out["predictions_mask"])
+
+    ts = TrainStep(model, loss_fn, lr=1e-3, grad_norm=5.0, warmup_steps=0, total_steps=10)
+    n0, lay0 = ts.flat_p.numel(), ts.layout()
+    ts.forward_backward(dd)
+    missing = [p for p in ts.reducer.params if p.grad is None]
+    ground = {id(p) for p in model.ground_head.parameters()}
+    assert missing and all(id(p) in ground for p in missing) and len(missing) == len(ground)
     before = [p.detach().clone() for p in missing]
     moved0 = [p.detach().clone() for p in ts.reducer.params if p.grad is not None][:4]
     for _ in range(3):
