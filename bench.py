@@ -422,19 +422,39 @@ def main():
     lay_ids = [{id(p) for p in l.parameters()} for l in layers]
     mh_ids = {id(p) for p in model.mask_head.parameters()} if hasattr(model, "mask_head") else set()
     dec_ids = set().union(*lay_ids) | mh_ids
-    # (An own, early bucket for the output heads behind the decoder -- they run backward FIRST, config 5: 200 MB -- was tried
-    # and checked with the per-bucket fingerprints of the JSON: the grounding head's bucket came out all zeros and the caption
-    # body's 1 % short, because pack() skips buckets in flight and not every head gradient is written in place through the
-    # arena.  tools/probes/heads_early_check.sh at commit "early heads bucket")
+    # Bucket layout (PQ3D_BENCH_BUCKETS):
+    #   coalesced (default): [output heads] [decoder layers + mask head] [everything else] -- at most 3 collectives per step.
+    #     With one-rank RCCL the per-layer layout cost 0.23 ms per step of pure launch / stream-join overhead at config 2 (1.646
+    #     vs 1.416 ms, profiles/rccl_one_rank_modes_r04.txt) for an overlap window of ~0.3 ms: a few large messages beat many
+    #     small ones on point-to-point xGMI as well.
+    #   per_layer: [heads] [layer L-1] ... [layer 0] [mask head] [everything else], launched from inside the backward as each
+    #     layer's gradients become final (one_graph / eager modes: the only way to overlap there).
+    # The heads' bucket (they run backward FIRST, query3d_unified.py:193-218; config 5: the caption body's 240 MB) is launched
+    # when the fused decoder's backward starts (enc.grads_ready('heads')) and reduces under the whole decoder backward.  That is
+    # only correct when every head parameter's gradient is written IN PLACE through the arena before that point (round 4: it
+    # was not -- grounding head all zeros, caption body 1 % short); FlatGradAllReducer.launch() flushes the deferred weight
+    # gradients first, tools/probes/heads_arena_probe.py checks the precondition per configuration and the per-bucket
+    # fingerprints in the JSON verify every run.  PQ3D_BENCH_EARLY_HEADS=0 puts the heads back into the last bucket.
+    bucket_mode = os.environ.get("PQ3D_BENCH_BUCKETS", "coalesced")
+    side_stream = os.environ.get("PQ3D_BENCH_SIDE_STREAM", "0") == "1"   # replayed pieces: collectives through a side stream
+    early_heads = os.environ.get("PQ3D_BENCH_EARLY_HEADS", "1") != "0"
     head_ids = set()
-    groups = [[p for p in params if id(p) in lay_ids[i]] for i in reversed(range(len(layers)))]
-    groups += [[p for p in params if id(p) in mh_ids], [p for p in params if id(p) in head_ids],
-               [p for p in params if id(p) not in dec_ids and id(p) not in head_ids]]
-    n_layer_buckets = len(layers)
+    if early_heads:
+        for hn in ("generation_head", "ground_head"):
+            if hasattr(model, hn):
+                head_ids |= {id(p) for p in getattr(model, hn).parameters() if p.requires_grad}
+    P = lambda ids: [p for p in params if id(p) in ids]
+    if bucket_mode == "per_layer":
+        layer_groups = [P(lay_ids[i]) for i in reversed(range(len(layers)))] + [P(mh_ids)]
+    else:
+        layer_groups = [P(dec_ids)]
+    groups = [P(head_ids)] + layer_groups + [[p for p in params if id(p) not in dec_ids and id(p) not in head_ids]]
     keep = [bool(g) for g in groups]
     bucket_of = [sum(keep[:j]) for j in range(len(groups))]            # index after dropping empty groups
     reducer = FlatGradAllReducer(params, groups=[g for g in groups if g])
-    dec_buckets = [bucket_of[j] for j in range(n_layer_buckets + 2) if keep[j]]   # layers, mask head, (early) heads
+    heads_bucket = bucket_of[0] if keep[0] else None
+    dec_buckets = [bucket_of[j] for j in range(1, 1 + len(layer_groups)) if keep[j]]
+    n_layer_buckets = len(layers) if bucket_mode == "per_layer" else 0
     enc.grad_arena = reducer.slots()
     enc.grad_arena_buffers = list(reducer.flat)   # all of them: the encoders' backward writes its slots in place too
     reducer.force_collectives = dist_on and world == 1
@@ -443,11 +463,14 @@ def main():
 
     def on_ready(tag):
         """Start the all-reduce of what just became final (side stream; the backward carries on)."""
-        if tag == "decoder":
+        if tag == "heads":
+            if heads_bucket is not None:
+                reducer.launch(heads_bucket)
+        elif tag == "decoder":
             for b in dec_buckets:
                 reducer.launch(b)
-        else:
-            reducer.launch(bucket_of[n_layer_buckets - 1 - int(tag)])
+        elif n_layer_buckets:
+            reducer.launch(bucket_of[1 + n_layer_buckets - 1 - int(tag)])
 
     one = torch.ones((), device=dev)
 
@@ -467,48 +490,63 @@ def main():
         fwd_bwd()
         reducer.finish()
 
-    class TwoGraphStep:
-        """RCCL-independent overlap: the step as TWO captured graphs split at the point where every decoder gradient is
-        final (enc.grads_ready('decoder'), inside the fused backward).  Graph A = forward + backward through the
-        weight-gradient flush; the decoder buckets' all-reduces are then launched EAGERLY on the side stream and run while
-        graph B = key/value input-gradient products + encoders' backward + pack of the last bucket replays; finish() joins.
-        The capture is split from inside the autograd backward (relaxed capture mode: the backward runs on autograd's
-        device thread), both graphs share one memory pool."""
+    class SplitGraphStep:
+        """RCCL-independent overlap: the step as SEVERAL captured graphs split where a bucket becomes final -- at the start of
+        the fused decoder's backward (enc.grads_ready('heads'): the output heads' gradients; only with an early heads bucket)
+        and where every decoder gradient is final (enc.grads_ready('decoder')).  After each piece the finished buckets'
+        all-reduces are launched EAGERLY on the side stream and run while the next piece replays (heads: under the whole
+        decoder backward; decoder: under the key/value input-gradient products + the encoders' backward + the pack of the last
+        bucket); finish() joins.  The capture is split from inside the autograd backward (relaxed capture mode: the backward
+        runs on autograd's device thread), all graphs share one memory pool."""
 
         def __init__(self):
-            self.ga, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            self.split_seen = False
-            self.ev = torch.cuda.Event()
+            self.tags = (["heads"] if heads_bucket is not None else []) + ["decoder"]
+            self.graphs, self.seen = [torch.cuda.CUDAGraph()], []
             stream = torch.cuda.Stream()
             stream.wait_stream(torch.cuda.current_stream())
 
             def split(tag):
-                if tag != "decoder":
+                if tag not in self.tags or tag in self.seen:
                     return
-                self.split_seen = True
-                self.ga.capture_end()
-                self.gb.capture_begin(pool=self.ga.pool(), capture_error_mode="relaxed")
+                self.seen.append(tag)
+                self.graphs[-1].capture_end()
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin(pool=self.graphs[0].pool(), capture_error_mode="relaxed")
+                self.graphs.append(g)
             enc.grads_ready, enc.grad_bucket_per_layer = split, False
             import gc
             gc.collect(); torch.cuda.empty_cache()
             with torch.cuda.stream(stream):
-                self.ga.capture_begin(capture_error_mode="relaxed")
+                self.graphs[0].capture_begin(capture_error_mode="relaxed")
                 try:
                     fwd_bwd()
                 finally:
-                    (self.gb if self.split_seen else self.ga).capture_end()
+                    self.graphs[-1].capture_end()
             torch.cuda.current_stream().wait_stream(stream)
             enc.grads_ready = None
-            if not self.split_seen:
+            if "decoder" not in self.seen:
                 raise RuntimeError("the backward never reported 'decoder' readiness (no fused decoder on this configuration)")
+            self.evs = [torch.cuda.Event() for _ in self.seen]
+            self.buckets = [([heads_bucket] if t == "heads" else list(dec_buckets)) for t in self.seen]
 
         def __call__(self):
-            self.ga.replay()
-            self.ev.record()           # every decoder gradient is final here
-            self.gb.replay()           # enqueued BEFORE the collectives: the device goes from A straight into B while the
-            for b in dec_buckets:      # host is still issuing the all-reduces (side stream, behind the event only)
-                reducer.launch(b, after=self.ev)
-            reducer.finish()
+            self.graphs[0].replay()
+            if side_stream:
+                for k, bs in enumerate(self.buckets):
+                    self.evs[k].record()           # the buckets of piece k are final here
+                    self.graphs[k + 1].replay()    # enqueued BEFORE the collectives: the device goes straight into the next piece
+                    for b in bs:                   # while the host is still issuing the all-reduces (side stream, behind the event)
+                        reducer.launch(b, after=self.evs[k])
+                reducer.finish()
+            else:
+                # default: no side stream -- each collective is issued from the current stream's position between two pieces
+                # (the backend's communication stream picks up there), the next piece is enqueued behind the CALL, not behind
+                # the transfer, and everything is joined once at the end: 2 stream hops per bucket instead of 4
+                for k, bs in enumerate(self.buckets):
+                    for b in bs:
+                        reducer.launch(b, side=False)
+                    self.graphs[k + 1].replay()
+                reducer.finish(side=False)
 
     def capture():
         """3 eager steps on a side stream (allocator + autograd warm-up), then capture the step.
@@ -522,7 +560,7 @@ def main():
         overlap); (4) eager."""
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        enc.grads_ready, enc.grad_bucket_per_layer = (on_ready if overlap else None), overlap
+        enc.grads_ready, enc.grad_bucket_per_layer = (on_ready if overlap else None), overlap and bucket_mode == "per_layer"
         with torch.cuda.stream(s):
             for _ in range(3):
                 full_step()
@@ -545,15 +583,17 @@ def main():
                     full_step()
                 g.replay()                      # one checked replay: asynchronous collective errors surface here, inside
                 torch.cuda.synchronize()        # the try, and the run falls back
-                return g.replay, f"graph(step+allreduce, {len(dec_buckets)} decoder buckets all-reduced in-stream per layer from inside the backward)"
+                return g.replay, f"graph(step+allreduce, {len(dec_buckets)} decoder bucket(s) all-reduced in-stream from inside the backward, buckets={bucket_mode})"
             except Exception as e:  # noqa: BLE001
                 note("capture with the collectives inside", e)
         if overlap and forced_mode in ("", "two_graph"):
             try:
-                tg = TwoGraphStep()
+                tg = SplitGraphStep()
                 tg()
                 torch.cuda.synchronize()
-                return tg, f"two graphs split at decoder-gradients-final, {len(dec_buckets)} decoder buckets all-reduced eagerly between them (overlapping graph B)"
+                return tg, (f"{len(tg.graphs)} graphs split at {' / '.join(tg.seen)}-gradients-final, "
+                            f"{sum(len(b) for b in tg.buckets)} bucket(s) all-reduced eagerly between them (overlapping the next piece), "
+                            f"buckets={bucket_mode}")
             except Exception as e:  # noqa: BLE001
                 note("two-graph capture", e)
         enc.grads_ready, enc.grad_bucket_per_layer = None, False
@@ -567,7 +607,7 @@ def main():
 
             def run():
                 g.replay()
-                reducer.finish()
+                reducer.finish(side=side_stream)
             return (run if dist_on else g.replay), "graph(fwd+bwd) then allreduce"
         except Exception as e:  # noqa: BLE001
             note("HIP graph capture", e)
@@ -575,7 +615,7 @@ def main():
 
     graph, step_mode = capture()
     if graph is None:
-        enc.grads_ready, enc.grad_bucket_per_layer = (on_ready if overlap else None), overlap
+        enc.grads_ready, enc.grad_bucket_per_layer = (on_ready if overlap else None), overlap and bucket_mode == "per_layer"
 
     def step():
         if graph is not None:

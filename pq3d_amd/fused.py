@@ -678,6 +678,10 @@ class _FusedDecoder(Function):
                 ready_cb(tag)
         else:
             ready = lambda tag: None
+        # the output heads consume the decoder's outputs, so their backward has run when this one starts (the reference:
+        # query3d_unified.py:193-218): whatever they wrote into their arena slots is final now -- an owner may start that
+        # bucket's all-reduce under the whole decoder backward (config 5: the caption body's 240 MB)
+        ready("heads")
 
         def kv_terms(apps, into_queue):
             """(dK|dV, W) operand lists of the hoisted K/V projections' backward for the applications `apps`; with

@@ -129,11 +129,15 @@ class FlatGradAllReducer:
             return dist.all_reduce(f, op=dist.ReduceOp.AVG, group=self.group, async_op=True), False
         return dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True), True
 
-    def launch(self, bi: int, after=None) -> None:
+    def launch(self, bi: int, after=None, side: bool = True) -> None:
         """Start the all-reduce of bucket ``bi`` on a side stream that waits for the work queued so far on the current
         stream -- or, with ``after`` (an event recorded on the current stream when the bucket became final), only for
         that point: work queued behind it then overlaps the transfer even though it was enqueued first.  The current
-        stream carries on (the rest of the backward overlaps the transfer).  finish() joins."""
+        stream carries on (the rest of the backward overlaps the transfer).  finish() joins.
+        side=False: no side stream -- the collective is issued from the CURRENT stream's position (the backend's own
+        communication stream picks up there) and only joined in finish(); work enqueued on the current stream AFTER this
+        call overlaps it.  Two stream hops per bucket instead of four (each hop is a barrier packet + signal wait on this
+        runtime): what a graph-replayed step uses between its pieces."""
         if not self._active() or bi in self._launched:
             return
         if self.flat[bi].is_cuda:
@@ -153,7 +157,8 @@ class FlatGradAllReducer:
                 self.flat[bi].div_(float(self._world()))
             self._launched.add(bi)
             return
-        if cur is not None:
+        on_side = cur is not None and side
+        if on_side:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             if after is not None:
@@ -164,18 +169,20 @@ class FlatGradAllReducer:
                 h, div = self._reduce(self.flat[bi])
         else:
             h, div = self._reduce(self.flat[bi])
-        self._pending.append((h, bi, div))
+        self._pending.append((h, bi, div, on_side))
         self._launched.add(bi)
 
-    def finish(self) -> None:
+    def finish(self, side: bool = True) -> None:
         """Launch whatever has not been launched, wait for everything, leave the mean in the flat buffers."""
         if not self._active():
             return
         for bi in range(len(self.flat)):
-            self.launch(bi)
+            self.launch(bi, side=side)
         world = float(self._world())
-        for h, bi, div in self._pending:
-            if self.flat[bi].is_cuda and self._side is not None:
+        any_side = False
+        for h, bi, div, on_side in self._pending:
+            if self.flat[bi].is_cuda and on_side:
+                any_side = True
                 with torch.cuda.stream(self._side):
                     h.wait()
                     if div:
@@ -184,7 +191,7 @@ class FlatGradAllReducer:
                 h.wait()
                 if div:
                     self.flat[bi].div_(world)
-        if self._side is not None and self.flat[0].is_cuda and self._pending:
+        if self._side is not None and self.flat[0].is_cuda and self._pending and any_side:
             # (nothing is pending on the side stream when the collectives ran in-stream inside a capture: no join, which a
             # capturing stream could not take from a stream outside the capture anyway)
             torch.cuda.current_stream().wait_stream(self._side)
