@@ -213,8 +213,17 @@ typedef struct {
   pq3d_dropout drop;
   int32_t drop_bmod;
   pq3d_attn_proj proj;   /* zero-initialised = none */
+  /* optional bit form of `mask` with `row_open` folded in (pq3d_mask_pack): [B or mask_bmod, Lq, ceil(Lk / 32)] words, bit j
+   * of word w of a row = key 32 w + j is masked for that query (an open row is all zero).  1/8 of the mask bytes and no
+   * per-element byte loads: the all-queries-resident backward uses it when present (config 4: 8 launches per step whose
+   * 3-D mask handling was +60 % of their time); `mask` / `row_open` must still be set (the other kernels read them). */
+  const uint32_t* mask_bits;
 } pq3d_attn_desc;
 
+/* row_open[r] = every byte of mask row r is non-zero (query_encoder.py:83: such rows attend everywhere) and, when bits != NULL,
+ * bits[r, w] = the row's mask as bits (bit j of word w = mask[r, 32 w + j] != 0; all zero for an open row; keys past Lk: 0).
+ * One pass over the mask bytes; mask [rows, Lk] uint8, bits [rows, ceil(Lk / 32)] uint32. */
+int pq3d_mask_pack(const uint8_t* mask, uint8_t* row_open, uint32_t* bits, int64_t rows, int64_t Lk, void* stream);
 int pq3d_attn_fwd(const pq3d_attn_desc* d, void* stream);
 int pq3d_attn_bwd(const pq3d_attn_desc* d, void* stream);
 /* pq3d_attn_fwd / pq3d_attn_bwd pick specialised implementations where the call has their shape, and the general

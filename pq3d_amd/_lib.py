@@ -129,7 +129,7 @@ class AttnDesc(C.Structure):
         ("kpm", C.c_void_p), ("mask", C.c_void_p), ("row_open", C.c_void_p), ("bias", C.c_void_p),
         ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
         ("delta", C.c_void_p), ("dbias", C.c_void_p), ("ksplit", C.c_int32), ("ws", C.c_void_p),
-        ("drop", Dropout), ("drop_bmod", C.c_int32), ("proj", AttnProj),
+        ("drop", Dropout), ("drop_bmod", C.c_int32), ("proj", AttnProj), ("mask_bits", C.c_void_p),
     ]
 
 
@@ -154,6 +154,7 @@ _SIGS = {
     "pq3d_gemm_set_wk": [C.c_int, C.c_int],
     "pq3d_attn_fwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_attn_bwd": [C.POINTER(AttnDesc), C.c_void_p],
+    "pq3d_mask_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_attn_resident": [C.c_int],
     "pq3d_mask_not": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p],

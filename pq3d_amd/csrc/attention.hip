@@ -82,7 +82,17 @@ struct MaskBias {
 // The 3-D mask words of one key block for this lane's query (4 x 4 key bytes).  Issued by the pipeline's load stage two
 // to three tiles ahead of their use: as dependent loads inside the compute stage they cost +38 % (forward) / +63 %
 // (backward) at config-4 shapes (tools/probes/attn_mask_cost_probe.py).  Caller guarantees d.mask != nullptr.
+// With d.mask_bits (pq3d_mask_pack: bit words, open rows cleared) the 64 keys of a block are TWO words of the query's row
+// instead of 16 bytes per lane: w[0], w[1] = the words, w[2] = w[3] = 0; fetch_mask_bias expands this lane's 4 bits per tile.
 PQ_DEV void load_mask_words(uint32_t (&w)[4], const pq3d_attn_desc& d, int bm, int myq, int k0, int lg) {
+  if (d.mask_bits) {   // uniform
+    const int W = (d.Lk + 31) >> 5;
+    const uint32_t* br = d.mask_bits + ((long)bm * d.Lq + min(myq, d.Lq - 1)) * W + (k0 >> 5);
+    w[0] = br[0];
+    w[1] = (k0 >> 5) + 1 < W ? br[1] : 0u;
+    w[2] = 0; w[3] = 0;
+    return;
+  }
   const uint8_t* mr = d.mask + ((long)bm * d.Lq + min(myq, d.Lq - 1)) * d.Lk;
   const bool vec = (d.Lk & 3) == 0 && ((((uintptr_t)d.mask) & 3) == 0);
 #pragma unroll
@@ -104,8 +114,17 @@ PQ_DEV void fetch_mask_bias(MaskBias& mb, const pq3d_attn_desc& d, const uint8_t
   for (int t = 0; t < 4; ++t) mb.mw[t] = *(const uint32_t*)&kpm_s[t * 16 + 4 * lg];
   if constexpr (MASK3) {
     const bool use = qvalid && !ro;
+    if (d.mask_bits) {   // uniform: bits 16 t' + 4 lg + r of word t / 2 -> byte flags r of mw[t]
 #pragma unroll
-    for (int t = 0; t < 4; ++t) mb.mw[t] |= use ? mwords[t] : 0u;   // keys >= Lk are already masked through kpm_s
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t nib = (mwords[t >> 1] >> ((t & 1) * 16 + 4 * lg)) & 0xFu;
+        const uint32_t by = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+        mb.mw[t] |= use ? by : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mb.mw[t] |= use ? mwords[t] : 0u;   // keys >= Lk are already masked through kpm_s
+    }
   }
   if (d.bias) {
     const float* br = d.bias + (((long)b * d.H + h) * d.Lq + min(myq, d.Lq - 1)) * d.Lk;
@@ -750,6 +769,50 @@ __global__ void mask_row_all_kernel(const uint8_t* mask, uint8_t* row_open, long
   if (lane == 0) row_open[row] = all ? 1 : 0;
 }
 
+// mask bytes -> row_open flag + bit words (row_open folded in): one wave per row, two passes over the row (the second one
+// hits the cache): pass 1 = is every byte non-zero, pass 2 = 32 bytes -> one word per lane step
+__global__ void mask_pack_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ row_open, uint32_t* __restrict__ bits,
+                                 long rows, long Lk) {
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const uint8_t* p = mask + row * Lk;
+  const bool vec = (Lk & 15) == 0 && ((((uintptr_t)mask) & 15) == 0);
+  auto nz = [](unsigned x) { return (((x - 0x01010101u) & ~x & 0x80808080u) == 0u); };
+  int all = 1;
+  if (vec) {
+    for (long j = (long)lane * 16; j < Lk; j += 64 * 16) {
+      const uint4 w = *(const uint4*)(p + j);
+      all &= (nz(w.x) && nz(w.y) && nz(w.z) && nz(w.w)) ? 1 : 0;
+    }
+  } else {
+    for (long j = lane; j < Lk; j += 64) all &= (p[j] != 0);
+  }
+  all = __all(all);
+  if (lane == 0) row_open[row] = all ? 1 : 0;
+  if (!bits) return;
+  const long W = (Lk + 31) >> 5;
+  // bit j of a word = byte j != 0: (b | b >> 1 | ... ) folded per byte with a multiply-gather of the 4 low bits of each dword
+  auto pack4 = [](unsigned x) {   // 4 bytes -> 4 bits (bit i = byte i != 0)
+    x |= x >> 4; x |= x >> 2; x |= x >> 1; x &= 0x01010101u;
+    return ((x * 0x01020408u) >> 24) & 0xFu;   // bytes 0..3 -> bits 0..3
+  };
+  for (long w = lane; w < W; w += 64) {
+    unsigned word = 0;
+    const long k0 = w * 32;
+    if (!all) {
+      if (vec && k0 + 32 <= Lk) {
+        const uint4 a = *(const uint4*)(p + k0), b = *(const uint4*)(p + k0 + 16);
+        word = pack4(a.x) | (pack4(a.y) << 4) | (pack4(a.z) << 8) | (pack4(a.w) << 12) | (pack4(b.x) << 16) | (pack4(b.y) << 20) |
+               (pack4(b.z) << 24) | (pack4(b.w) << 28);
+      } else {
+        for (int j = 0; j < 32 && k0 + j < Lk; ++j) word |= (p[k0 + j] != 0 ? 1u : 0u) << j;
+      }
+    }
+    bits[row * W + w] = word;
+  }
+}
+
 int check_desc(const pq3d_attn_desc& d) {
   PQ_CHECK_ARG(d.B >= 0 && d.H >= 1 && d.Lq >= 0 && d.Lk >= 0, "pq3d_attn: bad sizes");
   PQ_CHECK_ARG(d.dh == 16 || d.dh == 32 || d.dh == 64, "pq3d_attn: head dim must be 16, 32 or 64");
@@ -881,6 +944,16 @@ extern "C" int pq3d_attn_bwd(const pq3d_attn_desc* dp, void* stream) {
                       "<= 240 tokens, within LDS): not this call -- run the projection as its own pq3d_gemm");
   if (g_small && pq3d_attn_small_try(d, s, true)) { PQ_LAUNCH_CHECK(); return 0; }
   DISPATCH(launch_bwd)
+}
+
+extern "C" int pq3d_mask_pack(const uint8_t* mask, uint8_t* row_open, uint32_t* bits, int64_t rows, int64_t Lk, void* stream) {
+  PQ_DEVICE_GUARD(stream, mask);
+  PQ_CHECK_ARG(mask && row_open && rows >= 0 && Lk >= 0, "pq3d_mask_pack: bad args");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, mask, row_open, bits,
+                     (long)rows, (long)Lk);
+  PQ_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int pq3d_mask_row_all(const uint8_t* mask, uint8_t* row_open, int64_t rows, int64_t Lk, void* stream) {

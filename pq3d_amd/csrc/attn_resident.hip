@@ -65,7 +65,10 @@ PQ_DEV void wave_lds_fence() {   // order this wave's LDS writes before its foll
 // ZA (only without dropout / 3-D mask): the call has the zero key of add_zero_attn, so every log-sum-exp is >= 0 and the
 // probability recomputed for a padded key (score 0: its K row is zeroed) is at most 1 -- it needs no forcing to 0 at all
 // (its dK / dV rows are zeroed at the store, its dQ term multiplies the zero K row).
-template <int DH, int NQP, bool DROP, bool MASK3, int RW, bool ZA = false>
+// MASK3: 0 = no 3-D mask, 1 = mask BYTES [B,Lq,Lk] + row_open flags (staged per (query pair, key group) through a wave-private
+// LDS tile), 2 = mask BITS with row_open folded in (pq3d_mask_pack: one 32-bit word per query and 32-key group = exactly this
+// kernel's key group; 32 lanes fetch the pair's 32 words, ds_bpermute hands every lane its 4 query rows' words)
+template <int DH, int NQP, bool DROP, int MASK3, int RW, bool ZA = false>
 __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_attn_desc d, int q_lo, int nq, int acc_kv) {
   ATTN_KARG_PIN(d);
   ATTN_KARG_PIN_BWD(d);
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   float* dQs = (float*)smem;                                   // [NQ][LDQ] fp32: end-of-kernel sum over the waves, OVER Qs / dOs
   static_assert(NQ * R::LDQ * 4 <= 2 * NQ * R::LDR * 2, "the dQ reduction buffer must fit over the resident Q / dO tiles");
   bf16_t* wv = (bf16_t*)(Ds + NQ);                             // per wave: K tile + dS scratch (+ mask tile)
-  constexpr int WV_ELEMS = R::KT_ELEMS + R::SC_ELEMS + (MASK3 ? (32 * R::MLD) / 2 : 0);
+  constexpr int WV_ELEMS = R::KT_ELEMS + R::SC_ELEMS + (MASK3 == 1 ? (32 * R::MLD) / 2 : 0);
   uint8_t* ros = (uint8_t*)(wv + RW * WV_ELEMS);               // [NQ] row-open flags (MASK3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
           Ds[row] = ok ? -s : 0.f;     // both rows are kept NEGATED: the loop adds them (accumulator start, fma addend)
           Ls[row] = ok ? d.lse[sbase + row] * -1.4426950408889634f : -INFINITY;
           if (ok && split == 0) d.delta[sbase + row] = s;
-          if constexpr (MASK3) ros[row] = (ok && d.row_open) ? d.row_open[(long)bm * d.Lq + q_lo + row] : 0;
+          if constexpr (MASK3 == 1) ros[row] = (ok && d.row_open) ? d.row_open[(long)bm * d.Lq + q_lo + row] : 0;
         }
       }
     }
@@ -158,6 +161,8 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   // 3-D mask: the [32 queries x 32 keys] byte tile of a (query pair, key group) is exactly one 16-byte chunk per lane;
   // it is requested one pair ahead of its use and parked in a wave-private LDS tile
   u32x4 mreg = (u32x4){0, 0, 0, 0};
+  uint32_t wreg = 0;                          // MASK3 == 2: the mask word of query (lane & 31) of the requested pair
+  const int mwords = (d.Lk + 31) >> 5;
   auto load_group = [&](int g, u32x4 (&kd)[2][NS], u32x4 (&vd)[2][NS], bool (&md)[2]) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -171,7 +176,11 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     }
   };
   auto load_mask = [&](int g, int qp) {
-    if constexpr (MASK3) {
+    if constexpr (MASK3 == 2) {
+      const int row = q_lo + min(qp * 32 + (lane & 31), nq - 1);
+      wreg = d.mask_bits[((long)bm * d.Lq + row) * mwords + g];
+    }
+    if constexpr (MASK3 == 1) {
       const int row = q_lo + min(qp * 32 + (lane >> 1), nq - 1), half = lane & 1;   // chunk: (query row, 16-key half)
       const long kc = min((long)g * GK + half * 16, (long)d.Lk - 16);
       mreg = *(const u32x4*)(d.mask + ((long)bm * d.Lq + row) * d.Lk + kc);
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
     // a padded key (lane li of key tile kt) gets its probability forced to 0 without a select per element: its score
     // accumulator STARTS at -1e30 (its K row is zeroed, so nothing is added), exp2 of that is exactly 0.  (With the score
     // left at 0, exp2(-lse) could overflow for a strongly negative lse and inf * 0 at the dK / dV store would be NaN.)
-    const float sinit[2] = {(!ZA && !DROP && !MASK3 && km[0]) ? -1e30f : 0.f, (!ZA && !DROP && !MASK3 && km[1]) ? -1e30f : 0.f};
+    const float sinit[2] = {(!ZA && !DROP && km[0]) ? -1e30f : 0.f, (!ZA && !DROP && km[1]) ? -1e30f : 0.f};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -235,11 +244,21 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
 #pragma unroll
       for (int qp = 0; qp < NQP; ++qp) {
         if (qp >= nqp) break;
-        if constexpr (MASK3) {   // park this pair's mask tile, request the next one (next pair, or pair 0 of the next group)
+        if constexpr (MASK3 == 1) {   // park this pair's mask tile, request the next one (next pair, or pair 0 of the next group)
           *(u32x4*)&mt_[(lane >> 1) * R::MLD + (lane & 1) * 16] = mreg;
           if (qp + 1 < nqp) load_mask(g, qp + 1);
           else if (gn < ngroups) load_mask(gn, 0);
           wave_lds_fence();
+        }
+        uint32_t wq[2][4];            // MASK3 == 2: mask words of this lane's query rows (4 lg + r of both query tiles)
+        if constexpr (MASK3 == 2) {
+          const uint32_t wcur = wreg;
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wq[qt][r] = (uint32_t)__shfl((int)wcur, qt * 16 + 4 * lg + r);
+          if (qp + 1 < nqp) load_mask(g, qp + 1);
+          else if (gn < ngroups) load_mask(gn, 0);
         }
         float pt[2][2][4], ds[2][2][4];   // [kt][qt][r]
 #pragma unroll
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
               Mma<bf16_t>::mma(sv, qa[s], kcur[kt][s]);
               Mma<bf16_t>::mma(dp, ga[s], vcur[kt][s]);
             }
-            if constexpr (!DROP && !MASK3) {
+            if constexpr (!DROP) {
               // the softmax recompute is what this kernel spends its time on (in-kernel timeline at config 2: ~4 us per
               // 32-key group, 700 vector-ALU issue slots against 80 MFMAs): two elements per instruction where the ISA
               // has packed fp32 forms (fma, subtract, multiply), and the padded-key select only in groups that have one
@@ -277,8 +296,17 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
               const f32x2 xa = __builtin_elementwise_fma(__builtin_shufflevector(sv, sv, 0, 1), c2, __builtin_shufflevector(nL, nL, 0, 1));
               const f32x2 xb = __builtin_elementwise_fma(__builtin_shufflevector(sv, sv, 2, 3), c2, __builtin_shufflevector(nL, nL, 2, 3));
               // P from the saved log-sum-exp; a padded key's score started at -1e30 (sinit), so its probability is exactly 0
-              const f32x2 pa = (f32x2){__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
-              const f32x2 pb = (f32x2){__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
+              f32x2 pa = (f32x2){__builtin_amdgcn_exp2f(xa.x), __builtin_amdgcn_exp2f(xa.y)};
+              f32x2 pb = (f32x2){__builtin_amdgcn_exp2f(xb.x), __builtin_amdgcn_exp2f(xb.y)};
+              if constexpr (MASK3 != 0) {    // masked (query, key) pairs: probability exactly 0
+                bool mk[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  if constexpr (MASK3 == 2) mk[r] = (wq[qt][r] >> (kt * 16 + li)) & 1u;
+                  else mk[r] = (!ros[q0 + 4 * lg + r]) && (mt_[(qt * 16 + 4 * lg + r) * R::MLD + kt * 16 + li] != 0);
+                }
+                pa.x = mk[0] ? 0.f : pa.x; pa.y = mk[1] ? 0.f : pa.y; pb.x = mk[2] ? 0.f : pb.x; pb.y = mk[3] ? 0.f : pb.y;
+              }
               const f32x2 da = pa * __builtin_shufflevector(dp, dp, 0, 1);   // dp already holds dP - delta
               const f32x2 db = pb * __builtin_shufflevector(dp, dp, 2, 3);
               pt[kt][qt][0] = pa.x; pt[kt][qt][1] = pa.y; pt[kt][qt][2] = pb.x; pt[kt][qt][3] = pb.y;
@@ -291,10 +319,11 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
               // padded key: its K row is zeroed, so the score is 0 and exp2(-lse) can overflow for a strongly negative lse
               // (no zero key); inf * 0 at the dK / dV store would be NaN -> force the probability itself to 0
               p = kmc[kt] ? 0.f : p;
-              if constexpr (MASK3) {
+              if constexpr (MASK3 == 1) {
                 const bool masked = (!ros[ql]) && (mt_[(qt * 16 + 4 * lg + r) * R::MLD + kt * 16 + li] != 0);
                 p = masked ? 0.f : p;
               }
+              if constexpr (MASK3 == 2) p = ((wq[qt][r] >> (kt * 16 + li)) & 1u) ? 0.f : p;
               if constexpr (DROP) {
                 const float kc = drop_keep(dst, drow0 + (uint32_t)min(ql, nq - 1), (uint32_t)min(g * GK + kt * 16 + li, d.Lk - 1)) ? dst.scale : 0.f;
                 pt[kt][qt][r] = p * kc;
@@ -419,7 +448,7 @@ __global__ __launch_bounds__(RW * 64) void attn_bwd_resident_kernel(const pq3d_a
   RS_TL(10);
 }
 
-template <int DH, int NQP, int RW> size_t resident_lds(bool mask3) {
+template <int DH, int NQP, int RW> size_t resident_lds(bool mask3) {   // mask3: the BYTE form (a staged tile per wave)
   typedef RT<DH> R;
   const size_t nq = NQP * 32;
   size_t b = 2 * nq * R::LDR * 2 + 2 * nq * 4;
@@ -427,9 +456,9 @@ template <int DH, int NQP, int RW> size_t resident_lds(bool mask3) {
   return b + nq + 16;
 }
 
-template <int DH, int NQP, bool DROP, bool MASK3, int RW> void launch_res_w(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
+template <int DH, int NQP, bool DROP, int MASK3, int RW> void launch_res_w(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
-  const size_t lds = resident_lds<DH, NQP, RW>(MASK3);
+  const size_t lds = resident_lds<DH, NQP, RW>(MASK3 == 1);
   if constexpr (!DROP && !MASK3) {
     if (d.zero_attn) {
       auto kz = attn_bwd_resident_kernel<DH, NQP, DROP, MASK3, RW, true>;
@@ -448,7 +477,7 @@ template <int DH, int NQP, bool DROP, bool MASK3, int RW> void launch_res_w(cons
 // 4 waves per workgroup; 8 (two per SIMD: the same latency hiding as two 4-wave workgroups of one (scene, head) on a CU,
 // but Q / dO / O are loaded once and there are no dQ partials to combine) when the launch is not split over the keys and
 // has at most one workgroup per CU -- config 2: 192 (scene, head) pairs unsplit; config 4: 96 pairs x 2 key slices
-template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
+template <int DH, int NQP, bool DROP, int MASK3> void launch_res(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
   const int KS = d.ksplit > 1 ? d.ksplit : 1;
   if constexpr (DH == 32) {   // (d_h 64: the four dQ reduction buffers would not fit over the scratch)
     if ((long)d.B * d.H * KS <= 256 && d.Lk / KS >= 512) { launch_res_w<DH, NQP, DROP, MASK3, 8>(d, s, q_lo, nq, acc); return; }
@@ -457,9 +486,17 @@ template <int DH, int NQP, bool DROP, bool MASK3> void launch_res(const pq3d_att
 }
 
 template <int DH, int NQP> void launch_res_flags(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {
-  const bool dr = d.drop.p > 0.f && d.drop.seed, m3 = d.mask != nullptr;
-  if (dr) { if (m3) launch_res<DH, NQP, true, true>(d, s, q_lo, nq, acc); else launch_res<DH, NQP, true, false>(d, s, q_lo, nq, acc); }
-  else { if (m3) launch_res<DH, NQP, false, true>(d, s, q_lo, nq, acc); else launch_res<DH, NQP, false, false>(d, s, q_lo, nq, acc); }
+  const bool dr = d.drop.p > 0.f && d.drop.seed;
+  const int m3 = d.mask != nullptr ? (d.mask_bits != nullptr ? 2 : 1) : 0;
+  if (dr) {
+    if (m3 == 2) launch_res<DH, NQP, true, 2>(d, s, q_lo, nq, acc);
+    else if (m3 == 1) launch_res<DH, NQP, true, 1>(d, s, q_lo, nq, acc);
+    else launch_res<DH, NQP, true, 0>(d, s, q_lo, nq, acc);
+  } else {
+    if (m3 == 2) launch_res<DH, NQP, false, 2>(d, s, q_lo, nq, acc);
+    else if (m3 == 1) launch_res<DH, NQP, false, 1>(d, s, q_lo, nq, acc);
+    else launch_res<DH, NQP, false, 0>(d, s, q_lo, nq, acc);
+  }
 }
 
 template <int DH> void launch_res_rows(const pq3d_attn_desc& d, hipStream_t s, int q_lo, int nq, int acc) {

@@ -217,11 +217,11 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
 
 
 def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None, bias=None, mask_bmod=0, bwd=None,
-          drop=None, drop_bmod=0, proj_dout=None):
+          drop=None, drop_bmod=0, proj_dout=None, mask_bits=None):
     """proj_dout = (g, W): backward only -- dO = g W is formed inside the attention kernel (pq3d_attn_proj, DOUT) and
     bwd[0] is ignored; the caller checks sa_fold_ok() first."""
     d = ops._attn_desc(q, k, v, o, lse, H, ct, zero_attn, 1.0 / math.sqrt(q.shape[-1] // H), kpm, mask, row_open, bias,
-                       drop, drop_bmod, bwd=bwd is not None)
+                       drop, drop_bmod, bwd=bwd is not None, mask_bits=mask_bits)
     d.mask_bmod = mask_bmod
     B, Lq, dm = q.shape
     Lk = k.shape[1]
@@ -400,9 +400,15 @@ class _FusedDecoder(Function):
                     attn_mask = offline_mask if spec.offline else amask
                 elif spec.offline:
                     attn_mask = offline_mask
+                mask_bits = None
                 if spec.use_self_mask:
-                    row_open = ops.mask_row_all(attn_mask)
-                rec["attn_mask"], rec["row_open"] = attn_mask, row_open
+                    # row-open flags AND the mask as bit words (open rows cleared) from one pass over the bytes: the
+                    # resident backward reads 1/8 of the mask and no byte tiles (attn_resident.hip MASK3 == 2)
+                    if ct == BF16:
+                        row_open, mask_bits = ops.mask_pack(attn_mask)
+                    else:
+                        row_open = ops.mask_row_all(attn_mask)
+                rec["attn_mask"], rec["row_open"], rec["mask_bits"] = attn_mask, row_open, mask_bits
                 # -- cross attention over the M memories: 4 launches
                 q_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
                 ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cas[i]]
@@ -414,7 +420,7 @@ class _FusedDecoder(Function):
                 if spec.use_self_mask:
                     _attn(q_all.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
                           o_all.view(M * B, Nq, d), lse, H, ct, True, mask=attn_mask, row_open=row_open, mask_bmod=B,
-                          drop=dr_ca, drop_bmod=B)
+                          drop=dr_ca, drop_bmod=B, mask_bits=mask_bits)
                 else:
                     _attn(q_all.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
                           o_all.view(M * B, Nq, d), lse, H, ct, True, kpm=kpm_all, drop=dr_ca, drop_bmod=B)
@@ -831,7 +837,7 @@ class _FusedDecoder(Function):
                     [G(ca.multihead_attn.out_proj.bias) for ca in cl])
             dq_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
             delta_c = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
-            mb = dict(mask=rec["attn_mask"], row_open=rec["row_open"], mask_bmod=B) if spec.use_self_mask \
+            mb = dict(mask=rec["attn_mask"], row_open=rec["row_open"], mask_bmod=B, mask_bits=rec.get("mask_bits")) if spec.use_self_mask \
                 else dict(kpm=ctx.kpm_all)
             _attn(rec["q_all"].view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
                   rec["o_all"].view(M * B, Nq, d), rec["lse"], H, ct, True,

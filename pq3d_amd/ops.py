@@ -172,6 +172,17 @@ def mask_row_all(mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def mask_pack(mask: torch.Tensor):
+    """[B,Lq,Lk] bool -> (row_open [B,Lq] bool as mask_row_all, bits [B,Lq,ceil(Lk/32)] int32: the mask as bit words with the
+    open rows cleared) in one pass (pq3d_mask_pack); the resident attention backward reads the bits instead of the bytes."""
+    mask = mask.contiguous()
+    Lk = mask.shape[-1]
+    out = _empty(mask.shape[:-1], dtype=torch.bool, device=mask.device)
+    bits = _empty(*mask.shape[:-1], (Lk + 31) // 32, dtype=torch.int32, device=mask.device)
+    L.check(L.lib().pq3d_mask_pack(L.ptr(mask), L.ptr(out), L.ptr(bits), out.numel(), Lk, L.stream()), "pq3d_mask_pack")
+    return out, bits
+
+
 def mask_inv_den(masks: Sequence[torch.Tensor]) -> torch.Tensor:
     masks = [m.contiguous() for m in masks]
     arr = (C.c_void_p * len(masks))(*[L.ptr(m) for m in masks])
@@ -664,7 +675,7 @@ def linear_group(xs, Ws, *, ct: int, out_dtype=torch.float32):
 
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bias, drop=None, drop_bmod=0,
-               bwd=False) -> L.AttnDesc:
+               bwd=False, mask_bits=None) -> L.AttnDesc:
     B, Lq, dm = q.shape
     Lk = k.shape[1]
     d = L.AttnDesc()
@@ -675,6 +686,7 @@ def _attn_desc(q, k, v, o, lse, H, ct, zero_attn, scale, kpm, mask, row_open, bi
         setattr(d, name + "_sb", t.stride(0)); setattr(d, name + "_sl", t.stride(1)); setattr(d, name + "_sh", dm // H)
     d.q, d.k, d.v, d.o, d.lse = L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse)
     d.kpm, d.mask, d.row_open, d.bias = L.ptr(kpm), L.ptr(mask), L.ptr(row_open), L.ptr(bias)
+    d.mask_bits = L.ptr(mask_bits) if mask is not None else None
     L.set_drop(d.drop, drop)
     d.drop_bmod = drop_bmod
     # key split (not with dbias).  The factor depends on the key length ONLY, never on the batch: a scene's result

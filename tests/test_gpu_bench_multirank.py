@@ -47,9 +47,9 @@ def test_bench_two_ranks_one_gpu(config, launcher):
     assert "cpu_baseline" not in r                       # rank-0 / N=1 only
     if config == "c2":
         # the fused decoder path: collectives cannot be captured with gloo, so the RCCL-independent overlap mode must have
-        # run -- two graphs split at decoder-gradients-final, >= 4 decoder buckets all-reduced in between
+        # run -- graphs split at decoder-gradients-final, the coalesced decoder bucket all-reduced in between
         mode = r["config"]["step_mode"]
-        assert mode.startswith("two graphs") and int(mode.split(",")[1].split()[0]) >= 4, (mode, p.stderr[-1500:])
+        assert mode.startswith("2 graphs split at decoder") and "buckets=coalesced" in mode, (mode, p.stderr[-1500:])
 
 
 @pytest.mark.parametrize("mode", ["", "one_graph", "graph_then_allreduce", "eager"])
@@ -71,9 +71,28 @@ def test_bench_one_rank_rccl(mode):
     assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["collective_backend"] == "nccl"
     assert r["grads_identical_across_ranks"] is True and r["value"] > 0
     sm = r["config"]["step_mode"]
-    want = {"": "two graphs", "one_graph": "graph(step+allreduce", "graph_then_allreduce": "graph(fwd+bwd) then allreduce",
+    want = {"": "2 graphs split", "one_graph": "graph(step+allreduce", "graph_then_allreduce": "graph(fwd+bwd) then allreduce",
             "eager": "eager"}[mode]
     assert sm.startswith(want), (sm, p.stderr[-2000:])
+
+
+@pytest.mark.parametrize("buckets", ["coalesced", "per_layer"])
+def test_bench_one_rank_rccl_caption_config_splits_at_the_heads(buckets):
+    """Config 5 (caption head) over a one-rank RCCL communicator: the heads' bucket is launched when the decoder backward
+    starts (a 3-piece graph split: heads / decoder / rest) in both bucket layouts; gradients finite, non-zero in every bucket."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PQ3D_BENCH_FORCE_DIST="1", PQ3D_BENCH_BUCKETS=buckets)
+    for k in ("PQ3D_BENCH_BACKEND", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "PQ3D_BENCH_STEP_MODE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--headline-only",
+           "--config", "c5", "--cpu-steps", "0"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["rccl_ranks"] == 1 and r["grads_identical_across_ranks"] is True
+    sm = r["config"]["step_mode"]
+    assert sm.startswith("3 graphs split at heads / decoder") and f"buckets={buckets}" in sm, (sm, p.stderr[-2000:])
+    assert all(fp[1] > 0 for fp in r["grad_fingerprint_per_bucket"])
 
 
 def test_bench_two_ranks_rccl():

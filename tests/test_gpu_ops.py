@@ -1169,3 +1169,57 @@ def test_gemm_split_k_request_on_a_big_launch_is_one_deterministic_pass(acc):
     assert torch.equal(outs[0], outs[1])
     ref = A.bfloat16().double() @ W.bfloat16().double() + (base.double() if acc else 0)
     assert float((outs[0].double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------- 3-D mask as bits
+@pytest.mark.parametrize("Lk", [4096, 1056, 100])
+def test_mask_pack_matches_row_all_and_bytes(Lk):
+    g = torch.Generator().manual_seed(Lk)
+    m = torch.rand(3, 37, Lk, generator=g) < 0.5
+    m[1, 4] = True                      # an all-masked row: opened (bits cleared)
+    m[2, 9] = False
+    ro, bits = ops.mask_pack(m.to(DEV))
+    assert torch.equal(ro.cpu(), m.all(-1))
+    W = (Lk + 31) // 32
+    mm = m & ~m.all(-1, keepdim=True)
+    pad = torch.zeros(3, 37, W * 32, dtype=torch.bool)
+    pad[..., :Lk] = mm
+    want = (pad.view(3, 37, W, 32).long() << torch.arange(32)).sum(-1)
+    want = torch.where(want >= 2 ** 31, want - 2 ** 32, want).int()
+    assert torch.equal(bits.cpu(), want)
+
+
+@pytest.mark.parametrize("B,Lq,Lk", [(6, 200, 4096), (3, 100, 1024), (3, 57, 544)])
+def test_resident_backward_mask_bits_equal_mask_bytes(B, Lq, Lk):
+    """The all-queries-resident cross-attention backward with the 3-D self-mask as bit words (pq3d_mask_pack, row_open folded
+    in) gives the very gradients of the byte-mask path (memories stacked along the batch share the mask: mask_bmod)."""
+    from pq3d_amd import fused as F
+    H, d = 8, 256
+    g = torch.Generator().manual_seed(B + Lq)
+    q = torch.randn(B, Lq, d, generator=g).to(DEV).bfloat16()
+    k = torch.randn(B, Lk, d, generator=g).to(DEV).bfloat16()
+    v = torch.randn(B, Lk, d, generator=g).to(DEV).bfloat16()
+    nb = B // 3
+    m = (torch.rand(nb, Lq, Lk, generator=g) < 0.6)
+    m[0, 3] = True
+    m = m.to(DEV)
+    ro, bits = ops.mask_pack(m)
+    o = torch.empty_like(q); lse = torch.empty(B, H, Lq, device=DEV)
+    F._attn(q, k, v, o, lse, H, L.BF16, True, mask=m, row_open=ro, mask_bmod=nb)
+    o2, lse2 = torch.empty_like(o), torch.empty_like(lse)      # the streaming forward reads the same bits: identical outputs
+    F._attn(q, k, v, o2, lse2, H, L.BF16, True, mask=m, row_open=ro, mask_bmod=nb, mask_bits=bits)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    do = torch.randn(B, Lq, d, generator=g).to(DEV).bfloat16()
+    res = []
+    for mb in (None, bits):
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        delta = torch.empty_like(lse)
+        F._attn(q, k, v, o, lse, H, L.BF16, True, mask=m, row_open=ro, mask_bmod=nb, mask_bits=mb,
+                bwd=(do, dq, dk, dv, delta, None))
+        res.append((dq, dk, dv))
+    for a, b_, name in zip(res[0], res[1], ("dq", "dk", "dv")):
+        if name == "dq":     # summed over the waves in a fixed order, over key slices by the combine kernel: deterministic too
+            assert float((a.float() - b_.float()).abs().max()) <= 1e-2 * float(a.float().abs().max()), name
+        else:
+            assert torch.equal(a, b_), name
+    assert float(res[1][0].float().abs().max()) > 0 and torch.isfinite(res[1][1].float()).all()

@@ -30,7 +30,11 @@ def case(name, B, Lq, Lk, mask3=False):
         nb = B // 3
         m = torch.rand(nb, Lq, Lk, device=dev) < 0.5
         kw["mask"] = m
-        kw["row_open"] = torch.zeros(nb, Lq, dtype=torch.bool, device=dev)
+        import os
+        if os.environ.get("PROBE_BITS", "1") == "1":
+            kw["row_open"], kw["mask_bits"] = ops.mask_pack(m)
+        else:
+            kw["row_open"] = ops.mask_row_all(m)
         kw["mask_bmod"] = nb
     else:
         m = torch.zeros(B, Lk, dtype=torch.bool, device=dev)
