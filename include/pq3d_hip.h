@@ -143,6 +143,28 @@ int pq3d_gemm(const pq3d_gemm_desc* d, void* stream);
 int pq3d_gemm_set_wk(int options, int max_m);
 
 
+/* A heterogeneous batch of short-reduction weight-gradient products in ONE launch (pq3d_amd/csrc/gemm_ttmulti.hip): for every
+ * problem p < n (n <= PQ3D_TT_MAX_PROBLEMS)
+ *     C[M, N] (fp32, ld = N) += A[K, M]^T (B[K, N] + B2[K, N]),      colsum[M] += column sums of A   (NULL: skipped)
+ * -- the dW = g^T (x [+ x2]) (and bias gradient) of every nn.Linear of a backward pass over K = B * N_q query rows, whatever
+ * their shapes and operand dtypes (f32 / bf16 per operand; B2 fp32, only with an fp32 B), instead of one pq3d_gemm launch per
+ * (shape, dtype) bucket.  Operands are rounded to bf16 once, fp32 accumulation, fp32 atomics into C / colsum, which must hold
+ * valid numbers (zeroed or running gradient slots).  M, N, lda, ldb multiples of 8; A, B, B2 16-byte aligned. */
+#define PQ3D_TT_MAX_PROBLEMS 56
+typedef struct {
+  int32_t M, N, K, dtA, dtB;
+  int64_t lda, ldb;
+  const void* A;
+  const void* B;
+  const float* B2;
+  float* C;
+  float* colsum;
+} pq3d_tt_problem;
+int pq3d_gemm_tt_multi(const pq3d_tt_problem* probs, int32_t n, void* stream);
+/* process-wide switch for A/B measurements: 0 = every problem on the 64 x 64 tile (default 1: problems with M % 256 == 0 and
+ * N % 128 == 0 take 256 x 128 tiles, which read their operands 2.5-3x less often from L2) */
+int pq3d_gemm_tt_multi_wide(int32_t on);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused masked multi-head attention (flash-style online softmax, never materialises [B*H,Lq,Lk]).
  * Replaces the need_weights branch of F.multi_head_attention_forward as driven by CrossAttentionLayer

@@ -87,6 +87,15 @@ class MaskGradDesc(C.Structure):
                 ("g", C.c_void_p), ("dX", C.c_void_p * MAXG)]
 
 
+TT_MAX_PROBLEMS = 56
+
+
+class TtProblem(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("dtA", C.c_int32), ("dtB", C.c_int32),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("A", C.c_void_p), ("B", C.c_void_p), ("B2", C.c_void_p),
+                ("C", C.c_void_p), ("colsum", C.c_void_p)]
+
+
 class CeDesc(C.Structure):
     _fields_ = [("layers", C.c_int32), ("C", C.c_int32), ("R", C.c_int64), ("ignore_index", C.c_int64),
                 ("logits", C.c_void_p * MAXG), ("target", C.c_void_p), ("row_loss", C.c_void_p), ("lse", C.c_void_p),
@@ -154,6 +163,8 @@ _SIGS = {
     "pq3d_gemm_set_wk": [C.c_int, C.c_int],
     "pq3d_attn_fwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_attn_bwd": [C.POINTER(AttnDesc), C.c_void_p],
+    "pq3d_gemm_tt_multi": [C.POINTER(TtProblem), C.c_int32, C.c_void_p],
+    "pq3d_gemm_tt_multi_wide": [C.c_int32],
     "pq3d_mask_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_attn_resident": [C.c_int],

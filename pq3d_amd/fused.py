@@ -105,7 +105,16 @@ class _DwQueue:
     def flush(self):
         # (forking the buckets over 3 / 5 streams -- parallel branches of the captured graph -- was measured at config 2:
         # 1.50 -> 1.80 / 2.17 ms; branch joins cost far more than the overlapped tails save)
+        multi, rest = [], {}
         for key, (g, x, x2, o, bo) in self.buckets.items():
+            N, K, R = key[0], key[1], key[2]
+            if self.ct == BF16 and all(ops.tt_multi_ok(g[i], x[i], x2[i], o[i], bo[i], N, K, R) for i in range(len(g))):
+                multi += list(zip(g, x, x2, o, bo))
+            else:
+                rest[key] = (g, x, x2, o, bo)
+        if multi:   # every short-reduction weight / bias gradient of the flush: ONE launch (csrc/gemm_ttmulti.hip)
+            ops.tt_multi(multi)
+        for key, (g, x, x2, o, bo) in rest.items():
             _dw_acc(g, x, x2 if any(t is not None for t in x2) else None, o, self.ct, bo if key[5] else None)
         self.buckets = {}
 

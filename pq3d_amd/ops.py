@@ -429,6 +429,42 @@ def _dw_defer(g, x, x2, dw, db, N, K, R, ct, pptrs=()) -> bool:
     return True
 
 
+_TT_MULTI = os.environ.get("PQ3D_TT_MULTI", "1") != "0"   # A/B switch (tools/probes): one launch for a whole flush
+
+
+def tt_multi_ok(g, x, x2, dw, db, N: int, K: int, R: int) -> bool:
+    """Can dW[N, K] += g^T (x [+ x2]) (+ db[N] += colsum g) join the one-launch flush (pq3d_gemm_tt_multi)?  Short reductions
+    only: long ones (R >= 2048: the encoders' B * N_seg rows) belong to the 128 x 128-tile bf16 kernel (dw_operands)."""
+    if not _TT_MULTI or R >= 2048 or R < 1 or N % 8 or K % 8 or N < 8 or K < 8:
+        return False
+    for t in (g, x):
+        if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous() or t.data_ptr() % 16:
+            return False
+    if x2 is not None and (x2.dtype != torch.float32 or x.dtype != torch.float32 or not x2.is_contiguous() or x2.data_ptr() % 16):
+        return False
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or (db is not None and (db.dtype != torch.float32 or not db.is_contiguous())):
+        return False
+    return g.numel() == R * N and x.numel() == R * K
+
+
+def tt_multi(problems) -> None:
+    """problems: [(g [R,N], x [R,K], x2 or None, dw [N,K], db [N] or None)] -- every weight (and bias) gradient of a flush in
+    ONE launch per 56 problems (csrc/gemm_ttmulti.hip) instead of one launch per (shape, dtype) bucket."""
+    for s0 in range(0, len(problems), L.TT_MAX_PROBLEMS):
+        ch = problems[s0:s0 + L.TT_MAX_PROBLEMS]
+        arr = (L.TtProblem * len(ch))()
+        fl = 0.0
+        for q, (g, x, x2, dw, db) in zip(arr, ch):
+            N, K = dw.shape[-2], dw.shape[-1]
+            R = g.numel() // N
+            q.M, q.N, q.K, q.lda, q.ldb = N, K, R, N, K
+            q.dtA, q.dtB = L.dt_of(g), L.dt_of(x)
+            q.A, q.B, q.B2, q.C, q.colsum = L.ptr(g), L.ptr(x), L.ptr(x2), L.ptr(dw), L.ptr(db)
+            fl += 2.0 * N * K * R
+        L.check(timed("pq3d_gemm", f"ttmulti{len(ch)}", fl, 0.0, L.lib().pq3d_gemm_tt_multi, arr, len(ch), L.stream()),
+                "pq3d_gemm_tt_multi")
+
+
 def dw_deferred_flush(run: bool = True) -> None:
     """Launch (run=False: drop) the queued weight-gradient products.  Called when the pass ends (grad_arena.__exit__), from
     the fused decoder's readiness reports, from FlatGradAllReducer.launch() / pack() -- no reader of a slot gets ahead of the
@@ -436,7 +472,16 @@ def dw_deferred_flush(run: bool = True) -> None:
     buckets, _DwDeferred.buckets, _DwDeferred.nbytes = _DwDeferred.buckets, {}, 0
     if not run:
         return
-    for (N, K, R, _gd, _xd, has2, hasb, ct), (gs, xs, x2s, dws, dbs) in buckets.items():
+    multi, rest = [], {}
+    for key, (gs, xs, x2s, dws, dbs) in buckets.items():
+        N, K, R, ct = key[0], key[1], key[2], key[7]
+        if ct == BF16 and all(tt_multi_ok(g, x, x2, dw, db, N, K, R) for g, x, x2, dw, db in zip(gs, xs, x2s, dws, dbs)):
+            multi += list(zip(gs, xs, x2s, dws, dbs))
+        else:
+            rest[key] = (gs, xs, x2s, dws, dbs)
+    if multi:
+        tt_multi(multi)
+    for (N, K, R, _gd, _xd, has2, hasb, ct), (gs, xs, x2s, dws, dbs) in rest.items():
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
         ga, xa, x2a = dw_operands(gs, xs, x2s if has2 else None, N, K, R, ct)
         for i in range(0, len(ga), L.MAXG):

@@ -281,7 +281,7 @@ def test_per_layer_gradient_buckets_report_readiness_in_reverse_layer_order_and_
     enc.grads_ready, enc.grad_bucket_per_layer, enc.grad_arena = None, False, None
     (g0, t0), (g1, t1) = res
     L_ = len(enc.unified_encoder)
-    assert t0 == ["decoder"] and t1 == list(range(L_ - 1, -1, -1)) + ["decoder"], (t0, t1)
+    assert t0 == ["heads", "decoder"] and t1 == ["heads"] + list(range(L_ - 1, -1, -1)) + ["decoder"], (t0, t1)   # "heads": the decoder backward starts (output heads final)
     gmax = max(float(v.norm()) for v in g0.values())
     for n in g0:
         assert float((g0[n] - g1[n]).norm()) <= 1e-4 * max(float(g0[n].norm()), 1e-2 * gmax), n

@@ -94,6 +94,12 @@ def test_fp32_encoder_structures(name):
             util.check_against(z, "grad/" + n, p.grad, atol=5e-6, rtol=5e-5, cap=util.MAX_GRAD)
 
 
+# (query, head logits, mask logits) = 1.5 x the value measured for the fixture on an MI355X (profiles/parity_r04.txt)
+BF16_BARS = {"F1_c1": (6.3e-3, 8.1e-3, 1.0), "F4_c2_slice": (7.0e-3, 7.5e-3, 1.0), "F5_dimloc6": (8.1e-3, 8.4e-3, 1.0),
+             "F2_c1_mask": (4.4e-3, 1.41e-2, 7.2e-3), "F4b_c4_slice": (1.73e-2, 1.62e-2, 1.58e-2),
+             "F15_din": (2.27e-2, 2.42e-2, 2.42e-2), "F15_d768": (1.73e-2, 3.05e-2, 1.0)}
+
+
 @pytest.mark.parametrize("name", ["F1_c1", "F4_c2_slice", "F5_dimloc6", "F2_c1_mask", "F4b_c4_slice", "F15_din", "F15_d768"])
 def test_bf16_model_matches_fp32_oracle(name):
     """'bf16' mode end to end against the fp32 oracle (NOT an oracle with emulated rounding).  What is single-bf16 in
@@ -117,20 +123,22 @@ def test_bf16_model_matches_fp32_oracle(name):
         assert torch.equal(torch.isfinite(b), torch.isfinite(a))
         return float((a[fin] - b[fin]).abs().max() / max(float(b[fin].abs().max()), 1e-6))
 
-    # bars = <= 1.5 x the largest value measured over these fixtures (profiles/parity_r0*.txt: query 1.5e-2, head logits
-    # 2.1e-2 at d = 768, mask logits 1.6e-2, 1 - cos 4.9e-3, worst parameter 0.12); the reference's OWN bf16 (autocast) is
-    # at 2.3e-2 .. 6.7e-2 on the query at the same shapes (F19 fixtures, test below)
-    assert rel(out["query_embeds"], collect[-1]) < 2e-2
+    # bars PER FIXTURE = 1.5 x what this fixture measured (profiles/parity_r04.txt, columns query / head / mask-logit; the
+    # reference's OWN bf16 (autocast) is at 2.3e-2 .. 6.7e-2 on the query at the same shapes: F19 fixtures, test below).
+    # Which rounding site costs what, and why fp32 K / V storage alone ('bf16_kv32') would not reach 2e-3 either:
+    # tests/rounding_sites_report.py (profiles/rounding_sites_r05.txt).
+    q_bar, h_bar, m_bar = BF16_BARS[name]
+    assert rel(out["query_embeds"], collect[-1]) < q_bar
     if "ground" in args["heads"]:
-        assert rel(out["ground_logits"], oout["ground_logits"]) < 2.5e-2
+        assert rel(out["ground_logits"], oout["ground_logits"]) < h_bar
     if "mask" in args["heads"]:
         flips = 0.0
         for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
-            assert rel(m, r) < 2.5e-2
+            assert rel(m, r) < m_bar
             flips = max(flips, float(((m.detach().float().cpu() < 0) != (r < 0)).float().mean()))
-        assert flips < 1e-2, f"self-mask bit-flip rate vs the fp32 oracle {flips:.5f}"
+        assert flips < 5e-3, f"self-mask bit-flip rate vs the fp32 oracle {flips:.5f}"
         for c, r in zip(out["predictions_class"], oout["predictions_class"]):
-            assert rel(c, r) < 2.5e-2
+            assert rel(c, r) < h_bar
     assert abs(loss.item() - oloss.item()) < 2e-3 * max(1.0, abs(oloss.item()))
     names = [n for n in og if "pairwise_loc_fc" not in n]
     gmax = max(float(og[n].norm()) for n in names)

@@ -1223,3 +1223,40 @@ def test_resident_backward_mask_bits_equal_mask_bytes(B, Lq, Lk):
         else:
             assert torch.equal(a, b_), name
     assert float(res[1][0].float().abs().max()) > 0 and torch.isfinite(res[1][1].float()).all()
+
+
+def test_gemm_tt_multi_heterogeneous_weight_gradients_in_one_launch():
+    """pq3d_gemm_tt_multi: weight (+ bias) gradients of different shapes and operand dtypes in one launch -- against fp64 on the
+    bf16-rounded operands, accumulating onto running slots, duplicated outputs (a weight shared by two layer applications)."""
+    g = torch.Generator().manual_seed(3)
+    R = 800
+    specs = [(256, 256, torch.float32, torch.float32, True, True), (2048, 256, torch.float32, torch.float32, False, True),
+             (256, 2048, torch.float32, torch.bfloat16, False, True), (256, 256, torch.bfloat16, torch.float32, True, False),
+             (200, 264, torch.float32, torch.float32, False, True), (8, 8, torch.bfloat16, torch.bfloat16, False, False)]
+    probs, refs = [], []
+    for N, K, dg, dx, has2, hasb in specs:
+        gt = torch.randn(R, N, generator=g).to(DEV).to(dg)
+        xt = torch.randn(R, K, generator=g).to(DEV).to(dx)
+        x2 = torch.randn(R, K, generator=g).to(DEV) if has2 else None
+        dw = torch.randn(N, K, generator=g).to(DEV)
+        db = torch.randn(N, generator=g).to(DEV) if hasb else None
+        gb = gt.float().bfloat16().double()
+        xb = (xt.float() + (x2 if has2 else 0)).bfloat16().double()
+        refs.append((dw.double() + gb.t() @ xb, (db.double() + gb.sum(0)) if hasb else None))
+        probs.append((gt, xt, x2, dw, db))
+    # the first weight once more (shared across num_blocks): its slot takes both contributions
+    gt, xt, x2, dw, db = probs[0]
+    probs.append((gt, xt, x2, dw, db))
+    gb = gt.float().bfloat16().double(); xb = (xt + x2).bfloat16().double()
+    refs[0] = (refs[0][0] + gb.t() @ xb, refs[0][1] + gb.sum(0))
+    assert all(ops.tt_multi_ok(*p, p[3].shape[0], p[3].shape[1], R) for p in probs)
+    ops.tt_multi(probs)
+    for (gt, xt, x2, dw, db), (rw, rb) in zip(probs[:len(specs)], refs):
+        assert float((dw.double() - rw).abs().max()) <= 2e-4 * float(rw.abs().max()), dw.shape
+        if db is not None:
+            assert float((db.double() - rb).abs().max()) <= 2e-4 * float(rb.abs().max())
+    # not eligible: a long reduction, an odd width
+    assert not ops.tt_multi_ok(torch.zeros(4096, 256, device=DEV), torch.zeros(4096, 256, device=DEV), None,
+                               torch.zeros(256, 256, device=DEV), None, 256, 256, 4096)
+    assert not ops.tt_multi_ok(torch.zeros(100, 12, device=DEV), torch.zeros(100, 20, device=DEV), None,
+                               torch.zeros(12, 20, device=DEV), None, 12, 20, 100)

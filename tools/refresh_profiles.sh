@@ -13,6 +13,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for CFG in $CONFIGS; do
+ if [ -z "${SKIP_PMC:-}" ]; then     # SKIP_PMC=1: only the kernel stats + bench legs (the committed counter files stay)
   for cnt in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$cnt
     timeout 600 rocprofv3 --kernel-trace --pmc $cnt -d /tmp/pmc_$cnt -o p -- python $R/bench.py --config $CFG --no-graph --steps 3 --warmup 1 --cpu-steps 0 --profile-steps 1 --headline-only --pmc-calibration > /dev/null 2>&1
@@ -26,8 +27,9 @@ for CFG in $CONFIGS; do
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d /tmp/pmc_mfma -o p -- python $R/bench.py --config $CFG --no-graph --steps 3 --warmup 1 --cpu-steps 0 --profile-steps 1 --headline-only > /dev/null 2>&1
   MF=$(find /tmp/pmc_mfma -name "*.db" | head -1)
   python $R/tools/pmc_mfma_json.py $MF > $OUT/pmc_mfma_${TAG}_$CFG.json && cp $OUT/pmc_mfma_${TAG}_$CFG.json $R/profiles/
+ fi
   rm -rf /tmp/ks
-  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks -o s -- python $R/bench.py --config $CFG --steps 20 --warmup 5 --cpu-steps 0 --profile-steps 1 --headline-only > $OUT/bench_under_rocprof_$CFG.json 2>/dev/null
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks -o s -- python $R/bench.py --config $CFG --steps 20 --warmup 5 --cpu-steps 0 --profile-steps 1 --headline-only --min-time 0 > $OUT/bench_under_rocprof_$CFG.json 2>/dev/null
   DB=$(find /tmp/ks -name "*.db" | head -1)
   # steps in this trace: 3 eager warm-up steps + 5 warm-up replays + 20 timed replays + 1 eager profiled step
   python $R/tools/rocprof_summary.py $DB 29 > $OUT/rocprofv3_kernel_stats_${TAG}_fused_graph_$CFG.txt
