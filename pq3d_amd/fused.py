@@ -108,7 +108,8 @@ class _DwQueue:
         multi, rest = [], {}
         for key, (g, x, x2, o, bo) in self.buckets.items():
             N, K, R = key[0], key[1], key[2]
-            if self.ct == BF16 and all(ops.tt_multi_ok(g[i], x[i], x2[i], o[i], bo[i], N, K, R) for i in range(len(g))):
+            if self.ct == BF16 and not ops.dw_long_path(N, K, R, len(g), self.ct) and \
+                    all(ops.tt_multi_ok(g[i], x[i], x2[i], o[i], bo[i], N, K, R) for i in range(len(g))):
                 multi += list(zip(g, x, x2, o, bo))
             else:
                 rest[key] = (g, x, x2, o, bo)

@@ -430,12 +430,21 @@ def _dw_defer(g, x, x2, dw, db, N, K, R, ct, pptrs=()) -> bool:
 
 
 _TT_MULTI = os.environ.get("PQ3D_TT_MULTI", "1") != "0"   # A/B switch (tools/probes): one launch for a whole flush
+# ... also for long reductions over few tiles (the encoders' [256 x 256] over 8192 rows)?  Measured slower (k-slices x 256 x 128
+# tiles = 3x the atomics of the 64 x 64 split: c4 +1.0 %, c2 +0.2 .. 1.7 % on the same box): off
+_TT_LONG = os.environ.get("PQ3D_TT_MULTI_LONG", "0") != "0"
+
+
+def dw_long_path(N: int, K: int, R: int, count: int, ct: int) -> bool:
+    """dw_operands' condition: a LONG reduction with enough 128 x 128 output tiles to fill the chip -> operands rounded to bf16
+    once, then the 128 x 128-tile bf16 kernel (gemm_tt128).  Everything else is pq3d_gemm_tt_multi's."""
+    return ct == BF16 and R >= 2048 and R % 64 == 0 and N % 128 == 0 and K % 128 == 0 and (N // 128) * (K // 128) * count >= 64
 
 
 def tt_multi_ok(g, x, x2, dw, db, N: int, K: int, R: int) -> bool:
-    """Can dW[N, K] += g^T (x [+ x2]) (+ db[N] += colsum g) join the one-launch flush (pq3d_gemm_tt_multi)?  Short reductions
-    only: long ones (R >= 2048: the encoders' B * N_seg rows) belong to the 128 x 128-tile bf16 kernel (dw_operands)."""
-    if not _TT_MULTI or R >= 2048 or R < 1 or N % 8 or K % 8 or N < 8 or K < 8:
+    """Can dW[N, K] += g^T (x [+ x2]) (+ db[N] += colsum g) join the one-launch flush (pq3d_gemm_tt_multi)?  (Callers keep long
+    reductions over many tiles -- dw_long_path -- on the 128 x 128-tile bf16 kernel.)"""
+    if not _TT_MULTI or (R >= 2048 and not _TT_LONG) or R < 1 or N % 8 or K % 8 or N < 8 or K < 8 or R * max(N, K) >= (1 << 31):
         return False
     for t in (g, x):
         if t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous() or t.data_ptr() % 16:
@@ -475,7 +484,8 @@ def dw_deferred_flush(run: bool = True) -> None:
     multi, rest = [], {}
     for key, (gs, xs, x2s, dws, dbs) in buckets.items():
         N, K, R, ct = key[0], key[1], key[2], key[7]
-        if ct == BF16 and all(tt_multi_ok(g, x, x2, dw, db, N, K, R) for g, x, x2, dw, db in zip(gs, xs, x2s, dws, dbs)):
+        if ct == BF16 and not dw_long_path(N, K, R, len(gs), ct) and \
+                all(tt_multi_ok(g, x, x2, dw, db, N, K, R) for g, x, x2, dw, db in zip(gs, xs, x2s, dws, dbs)):
             multi += list(zip(gs, xs, x2s, dws, dbs))
         else:
             rest[key] = (gs, xs, x2s, dws, dbs)
@@ -1223,9 +1233,14 @@ class _LinearLNGroup(Function):
             d.dys[g], d.d_o[g], d.dgamma[g], d.dbeta[g] = L.ptr(dys[g]), L.ptr(dlin[g]), L.ptr(dgs[g]), L.ptr(dbs[g])
         L.check(timed("pq3d_add_ln_bwd", f"R{R}d{N}M{G}i", 0.0, 3.0 * G * R * N * 4, L.lib().pq3d_add_ln_bwd, C.byref(d),
                       L.stream()), "pq3d_add_ln_bwd")
-        ga_, xa_, _ = dw_operands([dlin[g] for g in range(G)], list(xs), None, N, K, R, ct)
-        L.gemm(M=N, N=K, K=R, A=ga_, B=xa_, Cs=dWs, ct=ct, lda=N, ldb=K, ldc=K, transA=True,
-               transB=True, splitk=max(2, _splitk(tiles * G, R, ct)), colsum=dbl if fuse else None, accumulate=True)
+        if fuse and ct == BF16 and not dw_long_path(N, K, R, G, ct) and \
+                all(tt_multi_ok(dlin[g], xs[g], None, dWs[g], dbl[g], N, K, R) for g in range(G)):
+            # few output tiles over a long reduction (config 2: 3 encoders of [256 x 256] over 8192 rows): wide tiles + k-slices
+            tt_multi([(dlin[g], xs[g], None, dWs[g], dbl[g]) for g in range(G)])
+        else:
+            ga_, xa_, _ = dw_operands([dlin[g] for g in range(G)], list(xs), None, N, K, R, ct)
+            L.gemm(M=N, N=K, K=R, A=ga_, B=xa_, Cs=dWs, ct=ct, lda=N, ldb=K, ldc=K, transA=True,
+                   transB=True, splitk=max(2, _splitk(tiles * G, R, ct)), colsum=dbl if fuse else None, accumulate=True)
         if not fuse:
             dbl = [colsum(dlin[g].view(R, N)) for g in range(G)]
         dxs = [None] * G

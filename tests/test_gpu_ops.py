@@ -1255,8 +1255,7 @@ def test_gemm_tt_multi_heterogeneous_weight_gradients_in_one_launch():
         assert float((dw.double() - rw).abs().max()) <= 2e-4 * float(rw.abs().max()), dw.shape
         if db is not None:
             assert float((db.double() - rb).abs().max()) <= 2e-4 * float(rb.abs().max())
-    # not eligible: a long reduction, an odd width
-    assert not ops.tt_multi_ok(torch.zeros(4096, 256, device=DEV), torch.zeros(4096, 256, device=DEV), None,
-                               torch.zeros(256, 256, device=DEV), None, 256, 256, 4096)
+    # not eligible: an odd width; long reductions over many tiles stay on the 128 x 128-tile kernel
+    assert ops.dw_long_path(768, 768, 10240, 16, BF16) and not ops.dw_long_path(256, 256, 8192, 3, BF16)
     assert not ops.tt_multi_ok(torch.zeros(100, 12, device=DEV), torch.zeros(100, 20, device=DEV), None,
                                torch.zeros(12, 20, device=DEV), None, 12, 20, 100)
