@@ -113,8 +113,10 @@ class _DwQueue:
                 multi += list(zip(g, x, x2, o, bo))
             else:
                 rest[key] = (g, x, x2, o, bo)
-        if multi:   # every short-reduction weight / bias gradient of the flush: ONE launch (csrc/gemm_ttmulti.hip)
-            ops.tt_multi(multi)
+        if multi and ops.tt_multi_pays(multi):   # every short-reduction weight / bias gradient of the flush: ONE launch
+            ops.tt_multi(multi)                  # (csrc/gemm_ttmulti.hip)
+        else:
+            rest = self.buckets
         for key, (g, x, x2, o, bo) in rest.items():
             _dw_acc(g, x, x2 if any(t is not None for t in x2) else None, o, self.ct, bo if key[5] else None)
         self.buckets = {}

@@ -823,9 +823,25 @@ class PCDMask3DSegLevelEncoder(_PostNormBase):
                                                            nn.Dropout(dropout)) for h in self.hlevels])
         self.dropout_p, self._drop_base = float(dropout), DROP_BASE_OBJ_ENC + (7 << 12)
 
-    def forward(self, pyramid, point2segment, max_seg):
+    def forward(self, pyramid, point2segment, max_seg, batch_size=None):
+        """Two input forms.  LIST form (the reference's decomposed features): ``pyramid[i] = ([feats_b], [parents_b])``,
+        ``point2segment = [ids_b]``.  BATCHED form (what a sparse tensor's ``.F`` already is): ``pyramid[i] = (feats [sum N_c, C],
+        parents [sum N] -> rows of the concatenated coarse level)``, ``point2segment`` ONE int64 tensor [sum N] with scene b's
+        ids offset by ``b * max_seg`` and ``batch_size`` given: one sort for the whole batch, one launch per level."""
         assert len(pyramid) == len(self.hlevels), "one (features, parents) entry per level in hlevels + [4]"
         out = []
+        if torch.is_tensor(point2segment):
+            assert batch_size is not None, "the batched form needs batch_size (ids are offset by b * max_seg)"
+            dev = point2segment.device
+            ctx = self._head_ctx(dev)
+            plan = ops.SegmentPlan(point2segment, int(batch_size) * int(max_seg))
+            for i, ((feats, parents), proj) in enumerate(zip(pyramid, self.feat_proj_list)):
+                pooled = ops.upsample_scatter_mean(feats, parents, point2segment, plan.S, plan=plan)
+                y = linear_ln_forward(proj, pooled.view(int(batch_size), int(max_seg), -1), self.ct)
+                if self.dropout_p > 0:
+                    y = ops.dropout(y, self._drop(ctx, ops.DROP_ENC_OUT, dev, m=i))
+                out.append(y)
+            return out
         dev = point2segment[0].device
         ctx = self._head_ctx(dev)
         # the voxel -> segment ids are sorted once per scene; all 5 levels (and their gradients) reduce over that grouping

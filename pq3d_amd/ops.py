@@ -456,6 +456,16 @@ def tt_multi_ok(g, x, x2, dw, db, N: int, K: int, R: int) -> bool:
     return g.numel() == R * N and x.numel() == R * K
 
 
+def tt_multi_pays(problems) -> bool:
+    """The one-launch flush wins through its 256 x 128 tiles (2.5-3x fewer operand re-reads from L2) while those fit about one
+    round of workgroups (<= 400 wide tiles: the decoder's flush at configs 2 / 4 / 5); a flush WITHOUT such a launch -- the
+    caption body's ~660 wide tiles over 512 rows, which the library sends back to 64 x 64 tiles -- is faster as one
+    gemm_wktt launch per (shape, dtype) bucket (config 5, same box: 6.21 vs 6.27 ms per step)."""
+    wt = sum((dw.shape[-2] // 256) * (dw.shape[-1] // 128) for _g, _x, _x2, dw, _db in problems
+             if dw.shape[-2] % 256 == 0 and dw.shape[-1] % 128 == 0)
+    return 0 < wt <= 400
+
+
 def tt_multi(problems) -> None:
     """problems: [(g [R,N], x [R,K], x2 or None, dw [N,K], db [N] or None)] -- every weight (and bias) gradient of a flush in
     ONE launch per 56 problems (csrc/gemm_ttmulti.hip) instead of one launch per (shape, dtype) bucket."""
@@ -489,8 +499,10 @@ def dw_deferred_flush(run: bool = True) -> None:
             multi += list(zip(gs, xs, x2s, dws, dbs))
         else:
             rest[key] = (gs, xs, x2s, dws, dbs)
-    if multi:
+    if multi and tt_multi_pays(multi):
         tt_multi(multi)
+    else:
+        rest = buckets
     for (N, K, R, _gd, _xd, has2, hasb, ct), (gs, xs, x2s, dws, dbs) in rest.items():
         tiles = ((N + 63) // 64) * ((K + 63) // 64)
         ga, xa, x2a = dw_operands(gs, xs, x2s if has2 else None, N, K, R, ct)
@@ -1271,14 +1283,30 @@ def linear_ln_group(xs, Ws, bs, gammas, betas, *, ct: int, eps: float = 1e-5):
 # Process-global state (the autograd engine runs the backward functions on its own thread, so thread-local would not reach
 # them): ONE backward pass at a time may use an arena -- two models stepping concurrently from different threads must not
 # both be given one.
-class _Arena:
-    mode = None
-    by_ptr = {}      # parameter data_ptr -> (parameter, flat buffer, element offset, numel) of its slot
-    written = set()  # slots some function of this pass already returned (a second use adds in place, returns None)
-    multi = set()    # slots that took such an in-place second use in a FRESH pass: verified when the pass ends (arena_verify)
-    whole_pass = False   # offered by grad_arena() around the whole backward (the decoder then neither zeroes nor offers)
-    pending = None       # fresh whole-pass arena: buffers still to be zeroed -- by the FIRST consumer, together with its own
-    zeroed_ptrs = set()  # flat buffers the last fresh pass zero-filled (read by the gradient pack that follows it)
+class _ArenaState:
+    """The gradient arena of the backward pass in flight, as ONE object with three transitions -- begin() (a whole-pass
+    grad_arena context or the decoder's offer), end() (the pass is over: everything per-pass is dropped) and the accessors
+    below -- instead of loose class attributes that every call site had to clear by hand."""
+
+    def __init__(self):
+        self.zeroed_ptrs = set()   # flat buffers the last fresh pass zero-filled (read by the gradient pack that follows it)
+        self.end()
+
+    def begin(self, mode, by_ptr, whole_pass, pending=None):
+        self.mode = mode                 # None | "fresh" | "accumulate"
+        self.by_ptr = by_ptr             # parameter data_ptr -> (parameter, flat buffer, element offset, numel) of its slot
+        self.written = set()             # slots some function of this pass already returned (a second use adds in place)
+        self.whole_pass = whole_pass     # offered by grad_arena() around the whole backward (the decoder then neither zeroes nor offers)
+        self.pending = pending           # fresh whole-pass arena: buffers still to be zeroed -- by the FIRST consumer
+
+    def end(self, keep_zeroed: bool = True):
+        self.mode, self.by_ptr, self.written, self.whole_pass, self.pending = None, {}, set(), False, None
+        self.multi = set()               # slots that took an in-place second use in a FRESH pass: verified when the pass ends
+        if not keep_zeroed:
+            self.zeroed_ptrs = set()
+
+
+_Arena = _ArenaState()
 
 
 def arena_flush_zero(extra=()) -> bool:
@@ -1353,7 +1381,7 @@ class grad_arena:
         try:
             arena_verify({p.data_ptr(): g for p, g in zip(params, grads)})
         finally:
-            _Arena.multi, _Arena.by_ptr = set(), {}
+            _Arena.end()
 
     def __enter__(self):
         _Arena.zeroed_ptrs, _Arena.multi = set(), set()
@@ -1367,12 +1395,9 @@ class grad_arena:
         # a later micro-batch of an accumulating step: the in-place gradients of the previous one are still adopted as .grad
         # (functions only add into slots whose .grad aliases them; gradients that live in tensors of their own keep
         # accumulating through autograd and are packed afterwards).  No aliasing .grad anywhere: a fresh step, one zero launch
-        if any(alias):
-            mode = "accumulate"
-        else:
-            mode = "fresh"
-            _Arena.pending = list(self.buffers)   # zeroed by the first consumer of the pass (with its own scratch: one launch)
-        _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass = mode, ents, set(), True
+        mode = "accumulate" if any(alias) else "fresh"
+        # fresh: the buffers are zeroed by the first consumer of the pass (with its own scratch: one launch)
+        _Arena.begin(mode, ents, True, pending=list(self.buffers) if mode == "fresh" else None)
         return self
 
     def __exit__(self, *exc):
@@ -1383,22 +1408,19 @@ class grad_arena:
                 arena_flush_zero()    # nobody consumed it: the owner still expects zeroed buffers
                 arena_verify()
         finally:
-            _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass, _Arena.pending = None, {}, set(), False, None
-            _Arena.multi = set()
-            if not self.pack_follows:
-                _Arena.zeroed_ptrs = set()
+            _Arena.end(keep_zeroed=self.pack_follows)
         return False
 
 
 def arena_offer(views_by_ptr, mode):
-    _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.whole_pass = mode, views_by_ptr, set(), False
+    _Arena.begin(mode, views_by_ptr, False)
 
     def _end():
         if not _Arena.whole_pass:
             try:
                 arena_verify()
             finally:
-                _Arena.mode, _Arena.by_ptr, _Arena.written, _Arena.multi = None, {}, set(), set()
+                _Arena.end()
     torch.autograd.Variable._execution_engine.queue_callback(_end)
 
 

@@ -139,6 +139,30 @@ def test_pcd_seg_level_encoder_post_backbone_matches_oracle(compute):
     assert all(f.grad is not None and torch.isfinite(f.grad).all() for fs, _ in pyr_d for f in fs)
 
 
+def test_pcd_seg_level_encoder_batched_form_equals_list_form():
+    """One plan + one launch per level for the whole batch (concatenated features, ids offset by b * max_seg, parents
+    indexing the concatenated coarse level) gives the list form's outputs bit for bit (same summation order per segment)."""
+    from pq3d_amd import modules as M
+    from pq3d_amd import synth
+    enc = M.PCDMask3DSegLevelEncoder(None, None, hidden_size=64, hlevels=[0, 1, 2, 3], dropout=0.0)
+    synth.fill_module(enc, 2)
+    enc.to("cuda").eval()
+    pyr, p2s = _pyramid()
+    S = 40
+    pyr_d = [([f.cuda() for f in fs], [p.cuda() for p in ps]) for fs, ps in pyr]
+    ref = enc(pyr_d, [p.cuda() for p in p2s], S)
+    ids = torch.cat([p.cuda() + b * S for b, p in enumerate(p2s)])
+    pyr_b = []
+    for fs, ps in pyr_d:
+        offs = [0]
+        for f in fs:
+            offs.append(offs[-1] + f.shape[0])
+        pyr_b.append((torch.cat(fs), torch.cat([torch.where(p >= 0, p + o, p) for p, o in zip(ps, offs)])))
+    out = enc(pyr_b, ids, S, batch_size=len(p2s))
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+
+
 def test_model_with_online_voxel_pyramid_takes_the_fused_path():
     """Query3DUnified with use_offline_voxel_fts = False: the voxel memory is the post-backbone encoder's multi-scale list;
     the fused executor runs it and agrees with the modular path."""
