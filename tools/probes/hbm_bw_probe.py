@@ -12,3 +12,7 @@ for mb in (100, 400, 1600):
     us = t(lambda: a.zero_()); print(f"{mb} MB fill : {us:7.1f} us  {mb * 1.048576 / us * 1e3 / 1e3:.2f} TB/s written")
     us = t(lambda: a.copy_(b)); print(f"{mb} MB copy : {us:7.1f} us  {2 * mb * 1.048576 / us * 1e3 / 1e3:.2f} TB/s moved")
     us = t(lambda: a.sum()); print(f"{mb} MB read : {us:7.1f} us  {mb * 1.048576 / us * 1e3 / 1e3:.2f} TB/s read")
+# write-only streams of non-zero data (a GEMM epilogue's pattern), 537 MB = the hoisted K/V tensor of config 5
+n = 537 * 1000 * 1000 // 2
+a = torch.empty(n, dtype=torch.bfloat16, device=dev)
+us = t(lambda: a.fill_(1.25)); print(f"537 MB fill(1.25): {us:7.1f} us  {537 / us:.2f} TB/s written")
