@@ -263,6 +263,564 @@ def sa_fold_ok(ct, B, H, L_, dm, drop, df, W) -> bool:
     return L_ <= 240 and lds <= 160 * 1024
 
 
+class _DecoderBackward:
+    """One backward pass of the fused decoder: the state every sublayer step shares (saved tensors, sizes, the gradient
+    arena, the deferred weight-gradient queue, the K/V gradient buffers) and one method per step, run in reverse order of the
+    forward: mask head -> FFN -> self-attention -> (prompt cross-attention) -> cross-attention over the scene memories, per
+    layer application; then the hoisted K/V projections' backward.  `_FusedDecoder.backward` is `_DecoderBackward(...).run()`."""
+
+    def __init__(self, ctx, dxf, dheads):
+        self.ctx, self.dxf = ctx, dxf
+        self.spec, self.tape = spec, _ = ctx.spec, ctx.tape
+        self.enc, self.ct = enc, ct = spec.enc, spec.ct
+        self.ad = ops.act_dtype(ct)
+        self.M, self.U, self.src, self.mh_src = M, U, _, _ = ctx.M, ctx.U, ctx.src, ctx.mh_src
+        sv = ctx.saved_tensors
+        self.x0, self.qpos, self.qmask, self.pos, self.pl, self.seg_pad, self.coef = sv[:7]
+        self.feats, self.masks = list(sv[7:7 + U]), list(sv[7 + U:7 + U + M])
+        self.params = ctx.params
+        self.layers = list(enc.unified_encoder)
+        self.Ln, self.H = len(self.layers), enc.num_heads
+        self.B, self.Nq, self.d = B, Nq, d = self.qpos.shape
+        self.Ns = Ns = self.feats[0].shape[1]
+        self.R, self.Rk = B * Nq, B * Ns
+        self.dev = dev = self.qpos.device
+        self.cas, self.KV = ctx.cas, ctx.KV
+        self.n_mh = n_mh = ctx.n_mh
+        self.dcls, self.dmlog = list(dheads[:n_mh]), list(dheads[n_mh:2 * n_mh])
+        self.n_app = n_app = len(self.tape)
+        self._open_arena()   # self.gv (parameter -> gradient view), self.accumulate, self.in_place, self.dxr_zero
+        self.dwq = _DwQueue(ct)
+        self.sb_queue = []   # (W, b, d bias, dW, db) of every spatial self-attention application
+        self.dqpos_parts: List[torch.Tensor] = []
+        self.dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=self.ad, device=dev)
+        self.dPKV = torch.empty(n_app, 2, B, ctx.prompt.shape[1], d, dtype=self.ad, device=dev) if spec.prompt else None
+        self.dkeys = None    # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
+        self.dk_terms = []   # queued (g, q_m) terms of it (one K-concatenated launch at the end)
+        ready_cb = getattr(enc, "grads_ready", None) if self.in_place else None   # only when the owner's buffers were written
+        self.per_layer = bool(getattr(enc, "grad_bucket_per_layer", False)) and ready_cb is not None
+        if ready_cb is not None:
+            def ready(tag):
+                # weight gradients queued by ops.linear layers that ran backward BEFORE the decoder (heads; ops._DwDeferred)
+                # must be in their slots before an owner is told that a bucket is final
+                ops.dw_deferred_flush()
+                ready_cb(tag)
+        else:
+            ready = lambda tag: None
+        self.ready = ready
+        # the output heads consume the decoder's outputs, so their backward has run when this one starts (the reference:
+        # query3d_unified.py:193-218): whatever they wrote into their arena slots is final now -- an owner may start that
+        # bucket's all-reduce under the whole decoder backward (config 5: the caption body's 240 MB)
+        ready("heads")
+
+    def _open_arena(self):
+        """Gradient arena: every parameter gradient of the decoder is a view of a flat zeroed fp32 buffer (the data-parallel
+        reducer's / optimizer's, or one of this pass); decides fresh vs accumulating pass."""
+        tape, enc, M, params, B, Nq, d = self.tape, self.enc, self.M, self.params, self.B, self.Nq, self.d
+        dev, = self.dev,
+        # ---- gradient arena: one flat zeroed fp32 buffer, every parameter gradient is a view of it
+        sizes = [p.numel() for p in params]
+        ext = getattr(enc, "grad_arena", None)   # {id(param): (flat, offset, numel)} of a DP reducer's flat buffers
+        gv = {}
+        n_app = len(tape)
+        # input gradients of the M-branch cross-attention LayerNorms are accumulated with atomics by the M branch blocks; that
+        # buffer and the gradient arena are zeroed by ONE launch for the whole backward
+        dxr_zero = torch.empty(n_app, B, Nq, d, dtype=torch.float32, device=dev) if M > 1 else None
+        accumulate = False
+        in_place = ext is not None and all(id(p) in ext for p in params)
+        if in_place:
+            # gradients go straight into the owner's flat buffer (data-parallel bucket / optimizer arena): no pack copy.
+            for p in params:
+                flat, o_, n_ = ext[id(p)]
+                gv[id(p)] = flat[o_:o_ + n_].view(p.shape)
+            # torch semantics of a second backward before zero_grad: gradients ACCUMULATE (the reference trains under
+            # accelerator.accumulate, trainer/query3d_trainer.py:35).  Every parameter gradient of this backward is formed
+            # by accumulating launches (split-K atomics, accumulating column sums), so accumulation = not zeroing the arena.
+            # Which case this is is read off the parameters: .grad still aliasing the arena -> the owner has not consumed the
+            # previous micro-batch -> add in place (and hand autograd nothing: .grad already is the arena);
+            # .grad None / foreign everywhere -> fresh step: zero, then hand fresh views to autograd (adopted without a copy).
+            req = [p for p in params if p.requires_grad]
+            alias = [p.grad is not None and p.grad.data_ptr() == gv[id(p)].data_ptr() for p in req]
+            # parameters outside the decoder (the input encoders) with slots in the buffers zeroed here: offered to the
+            # backward functions that run after this one in the same pass (ops.arena_offer)
+            bufs = list(getattr(enc, "grad_arena_buffers", ()))
+            zeroed, own = {b.data_ptr() for b in bufs}, {id(p) for p in params}
+            offer = {}
+            for i_, q_ in getattr(ext, "params", {}).items():
+                if i_ not in own and q_.requires_grad and ext[i_][0].data_ptr() in zeroed:
+                    fl_, o_, n_ = ext[i_]
+                    offer[q_.data_ptr()] = (q_, fl_, o_, n_)
+            mixed = "fused decoder backward: some parameters' .grad alias the shared gradient arena and others do not -- " \
+                    "zero ALL gradients (set_to_none=True) or none between micro-batches"
+            if ops._Arena.whole_pass and ops._Arena.mode is not None and \
+                    all(p.data_ptr() in ops._Arena.by_ptr for p in req):
+                # the owner opened the arena around the whole pass (ops.grad_arena): already zeroed / accumulating
+                accumulate = ops._Arena.mode == "accumulate"
+                if accumulate and not all(alias):
+                    raise RuntimeError(mixed)
+                offer = {}
+                if not ops.arena_flush_zero([dxr_zero]):   # first consumer of a fresh pass: arena + own scratch, one launch
+                    ops.zero_many([dxr_zero])
+            elif req and all(alias):
+                accumulate = True
+                ops.zero_many([dxr_zero])
+            elif any(alias) or any(q_.grad is not None and q_.grad.data_ptr() == f_.data_ptr() + 4 * o_ for q_, f_, o_, n_ in offer.values()):
+                raise RuntimeError(mixed)
+            else:
+                ops.zero_many(bufs + [dxr_zero])
+            if offer:
+                ops.arena_offer(offer, "accumulate" if accumulate else "fresh")
+        else:
+            arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            ops.zero_many([arena, dxr_zero])
+            off = 0
+            for p, n in zip(params, sizes):
+                gv[id(p)] = arena[off:off + n].view(p.shape)
+                off += n
+        self.gv, self.dxr_zero, self.accumulate, self.in_place = gv, dxr_zero, accumulate, in_place
+
+    def G(self, p):
+        return self.gv[id(p)]
+
+    def mask_head(self, rec, dc, dm, dx_in):
+        """Backprop one mask-head call; returns dx_in + its contribution to d(query)."""
+        ctx, spec, ct, ad, M, seg_pad, B = self.ctx, self.spec, self.ct, self.ad, self.M, self.seg_pad, self.B
+        Nq, d, Ns, R, dev, G, dwq = self.Nq, self.d, self.Ns, self.R, self.dev, self.G, self.dwq
+        mh = spec.mh
+        c0, c2, c4 = mh.cls_head[0], mh.cls_head[2], mh.cls_head[4]
+        x_in = rec["mh_x"]
+        Hd, C_ = c0.out_features, c4.out_features
+        cur = dx_in
+        if dc is not None:
+            dcl = dc.contiguous()
+            if mh._foc_cols.numel():
+                t = torch.empty_like(dcl)
+                L.check(L.lib().pq3d_fill_cols(L.ptr(dcl), L.ptr(t), R, C_, L.ptr(mh._foc_cols),
+                                               mh._foc_cols.numel(), 0.0, L.stream()), "pq3d_fill_cols")
+                dcl = t
+            dh2 = torch.empty(B, Nq, Hd, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=Hd, K=C_, A=[dcl], B=[c4.weight.detach()], Cs=[dh2], ct=ct, lda=C_, ldb=Hd, ldc=Hd, transB=True)
+            dwq.add([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct, [G(c4.bias)])
+            if rec.get("mh_drop") is not None:
+                dh2 = ops._dropout_apply(dh2, rec["mh_drop"])
+            _, dh1 = _ln_bwd(None, [rec["mh_h1"]], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq,
+                             rec["mh_mean"], rec["mh_rstd"], dh2, [G(c2.weight)], [G(c2.bias)])
+            dpre = ops.act_bwd(dh1[0], rec["mh_h1"], "relu", ad)
+            nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=Hd, A=[dpre], B=[c0.weight.detach()], Cs=[nxt], aux=[cur], act_grad="add", ct=ct,
+                   lda=Hd, ldb=d, ldc=d, transB=True)
+            dwq.add([dpre], [x_in], None, [G(c0.weight)], ct, [G(c0.bias)])
+            cur = nxt
+        if dm is not None:
+            Mm = spec.mh_count
+            mps = list(mh.mask_pred_list)[:Mm]
+            qm = rec["mh_qm"]
+            g = ops.scale_rows(dm.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=seg_pad)
+            # d keys = sum over the mask-head calls of g_c @ q_m,c: nothing consumes it before the end of the backward, so
+            # the terms are queued and formed by ONE K-concatenated launch there (each call used to re-read and re-write
+            # the [Mm, B, Ns, d] fp32 sum through the "+ aux" epilogue: 100 MB per call at config 4)
+            if Mm * (len(self.dk_terms) + 1) <= MAXG:
+                self.dk_terms.append((g, qm))
+            else:
+                newk = torch.empty(Mm, B, Ns, d, dtype=torch.float32, device=dev)
+                L.gemm(M=Ns, N=d, K=Nq, A=[g] * Mm, B=[qm[m] for m in range(Mm)], Cs=[newk[m] for m in range(Mm)],
+                       aux=[self.dkeys[m] for m in range(Mm)] if self.dkeys is not None else None,
+                       act_grad="add" if self.dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
+                       strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
+                self.dkeys = newk
+            # [Nq x d] outputs per (memory, scene) over a reduction of Ns segments: few tiles, long K -> split-K into an
+            # fp32 buffer once Ns is large (c4: 192 workgroups x 64 k-tiles otherwise)
+            sk = min(8, Ns // 512) if Ns >= 1024 else 1
+            dqm = torch.empty(Mm, B, Nq, d, dtype=torch.float32 if sk > 1 else ad, device=dev)
+            L.gemm(M=Nq, N=d, K=Ns, A=[g] * Mm, B=list(ctx.keys), Cs=[dqm[m] for m in range(Mm)], ct=ct, lda=Nq,
+                   ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d,
+                   splitk=sk)
+            nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[dqm[m] for m in range(Mm)], B=[mp.q_proj.weight.detach() for mp in mps],
+                   Cs=[nxt] + [None] * (Mm - 1), aux=[cur] + [None] * (Mm - 1), act_grad="add", ct=ct, lda=d, ldb=d,
+                   ldc=d, transB=True, kconcat=Mm)
+            dwq.add([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct,
+                    [G(mp.q_proj.bias) for mp in mps])
+            cur = nxt
+        return cur
+
+    def kv_terms(self, apps, into_queue):
+        """(dK|dV, W) operand lists of the hoisted K/V projections' backward for the applications `apps`; with
+        into_queue their weight / bias gradient products are queued."""
+        ctx, spec, tape, ct, src, d, cas = self.ctx, self.spec, self.tape, self.ct, self.src, self.d, self.cas
+        G, dwq, dKV, dPKV = self.G, self.dwq, self.dKV, self.dPKV
+        A_, B_, Xf, X2, GWs, Gbs = [], [], [], [], [], []
+        for a_ in apps:
+            i_ = tape[a_]["i"]
+            for j, ca in enumerate(cas[i_]):
+                w = ca.multihead_attn.in_proj_weight.detach()
+                gw, gb = G(ca.multihead_attn.in_proj_weight), G(ca.multihead_attn.in_proj_bias)
+                A_ += [dKV[a_, 0, j], dKV[a_, 1, j]]
+                B_ += [w[d:2 * d], w[2 * d:]]
+                Xf += [ctx.kin[src[i_][j]], ctx.vin[src[i_][j]]]
+                X2 += [ctx.kin2[src[i_][j]], None]
+                GWs += [gw[d:2 * d], gw[2 * d:]]
+                Gbs += [gb[d:2 * d], gb[2 * d:]]
+        if into_queue:
+            dwq.add(A_, Xf, X2, GWs, ct, Gbs)
+            if spec.prompt:   # the prompt memory's K / V rows of its cross-attention's in_proj weights
+                for a_ in apps:
+                    pc_ = ctx.pcas[tape[a_]["i"]]
+                    gw, gb = G(pc_.multihead_attn.in_proj_weight), G(pc_.multihead_attn.in_proj_bias)
+                    dwq.add([dPKV[a_, 0], dPKV[a_, 1]], [ctx.prompt, ctx.prompt], None, [gw[d:2 * d], gw[2 * d:]], ct,
+                            [gb[d:2 * d], gb[2 * d:]])
+        return A_, B_
+
+    def flush_spatial(self):
+        pl, H, B, Nq, sb_queue = self.pl, self.H, self.B, self.Nq, self.sb_queue
+        for i0 in range(0, len(sb_queue), MAXG):
+            chunk = sb_queue[i0:i0 + MAXG]
+            arrs = [(C.c_void_p * len(chunk))(*[L.ptr(t[k]) for t in chunk]) for k in range(5)]
+            L.check(L.lib().pq3d_spatial_bias_bwd_grouped(L.ptr(pl), *arrs, len(chunk), B, H, Nq, L.stream()),
+                    "pq3d_spatial_bias_bwd_grouped")
+        del sb_queue[:]
+
+    def ffn(self, rec, layer, dx):
+        """FFN sublayer: returns d(x2), the gradient of the sublayer's input (residual + linear1 path)."""
+        spec, ct, ad, M, B, Nq, d = self.spec, self.ct, self.ad, self.M, self.B, self.Nq, self.d
+        R, dev, accumulate, G, dwq = self.R, self.dev, self.accumulate, self.G, self.dwq
+        x2 = rec["x2"]
+        # ---------------- FFN backward
+        ffn = layer.ffn
+        F_ = ffn.linear1.out_features
+        # dx2r = residual-branch gradient, dy = (dropout-masked) gradient of the linear2 output (sum of the partials)
+        dx2r, dy = _ln_bwd(x2, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq,
+                           rec["mean_f"][:1], rec["rstd_f"][:1], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
+                           drop=rec["dr_fr"])
+        dy = dy[0]
+        dhp = torch.empty(B, Nq, F_, dtype=ad, device=dev)
+        # inner dropout.  ReLU: the saved h is post-dropout, so [h > 0] already carries the keep-mask and only the
+        # 1/(1-p) factor is left -> alpha.  GELU (round 3): the epilogue regenerates the forward's mask on the incoming
+        # gradient (same site, same [R, F] indices) before multiplying by gelu'(pre) -- epi_row's order: dropout, then
+        # the activation gradient
+        relu = spec.act != "gelu"
+        L.gemm(M=R, N=F_, K=d, A=[dy], B=[ffn.linear2.weight.detach()], Cs=[dhp],
+               aux=[rec["h"] if relu else rec["pre"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
+               transB=True, alpha=1.0 / (1.0 - rec["dr_fi"].p) if (rec["dr_fi"] is not None and relu) else 1.0,
+               drop=rec["dr_fi"] if not relu else None)
+        dwq.add([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
+        dx2 = dx2r   # dx2 = dx2r + dhp W1: split-K accumulated in place onto the residual-branch gradient
+        L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], ct=ct, lda=F_, ldb=d, ldc=d,
+               transB=True, splitk=4, accumulate=True)
+        dwq.add([dhp], [x2], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
+        return dx2
+
+    def self_attn(self, rec, layer, dx2):
+        """Self-attention sublayer: returns the three addends of d(x1s) (from q, from k, from v + residual)."""
+        spec, ct, M, qpos, qmask, H, B = self.spec, self.ct, self.M, self.qpos, self.qmask, self.H, self.B
+        Nq, d, R, dev, G, dwq, sb_queue = self.Nq, self.d, self.R, self.dev, self.G, self.dwq, self.sb_queue
+        dqpos_parts, = self.dqpos_parts,
+        # ---------------- self-attention backward
+        sa = layer.self_attn
+        if spec.spatial:
+            msa = sa.self_attn
+            Wl = [msa.w_qs.weight, msa.w_ks.weight, msa.w_vs.weight]
+            GW = [G(w) for w in Wl]
+            Gb = [G(msa.w_qs.bias), G(msa.w_ks.bias), G(msa.w_vs.bias)]
+            Wl = [w.detach() for w in Wl]
+            Wo, GWo, Gbo = msa.fc.weight.detach(), G(msa.fc.weight), G(msa.fc.bias)
+        else:
+            w, gw, gb = sa.self_attn.in_proj_weight.detach(), G(sa.self_attn.in_proj_weight), G(sa.self_attn.in_proj_bias)
+            Wl = [w[:d], w[d:2 * d], w[2 * d:]]
+            GW = [gw[:d], gw[d:2 * d], gw[2 * d:]]
+            Gb = [gb[:d], gb[d:2 * d], gb[2 * d:]]
+            Wo, GWo, Gbo = sa.self_attn.out_proj.weight.detach(), G(sa.self_attn.out_proj.weight), G(sa.self_attn.out_proj.bias)
+        x1s = rec["x1s"]     # the self-attention sublayer's input (x1, or the prompt cross-attention's output)
+        dx1r, df = _ln_bwd(x1s, [rec["f"]], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
+                           rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)],
+                           drop=rec["dr_sr"])
+        df = df[0]
+        fold = sa_fold_ok(ct, B, H, Nq, d, rec["dr_sa"], df, Wo)
+        do_s = None
+        if not fold:
+            do_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+        dwq.add([df], [rec["o_s"]], None, [GWo], ct, [Gbo])
+        qkv = rec["qkv"]
+        dqkv = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
+        delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+        dsb = torch.empty_like(rec["sbias"]) if spec.spatial else None
+        _attn(qkv[0], qkv[1], qkv[2], rec["o_s"], rec["lse_s"], H, ops.sa_ct(ct), False, kpm=qmask, bias=rec["sbias"],
+              bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb), drop=rec["dr_sa"],
+              proj_dout=(df, Wo) if fold else None)
+        if spec.spatial:   # deferred: one grouped launch for all layer applications at the end of the backward
+            sb_queue.append((msa.pairwise_loc_fc.weight.detach(), msa.pairwise_loc_fc.bias.detach(), dsb,
+                             G(msa.pairwise_loc_fc.weight), G(msa.pairwise_loc_fc.bias)))
+        # d(x1 + qpos) from q and k, d(x1) from v (+ the residual-branch gradient): three independent products, ONE
+        # launch; their sum is formed by the consumer (the next LayerNorm backward reads three addends) instead of
+        # by a second, dependent "+ aux" launch
+        g3 = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
+        L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1], dqkv[2]], B=list(Wl), Cs=[g3[0], g3[1], g3[2]],
+               aux=[None, None, dx1r], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+        dqpos_parts += [g3[0], g3[1]]
+        dx1 = [g3[0], g3[1], g3[2]]
+        dwq.add([dqkv[0], dqkv[1], dqkv[2]], [x1s] * 3, [qpos, qpos, None], GW, ct, Gb)
+        return dx1
+
+    def prompt_cross_attn(self, a, rec, dx1):
+        """structure 'mixed': the prompt memory's sequential cross-attention; dx1 is d(x1s), returns d(x1)."""
+        ctx, ct, ad, M, qpos, H, B = self.ctx, self.ct, self.ad, self.M, self.qpos, self.H, self.B
+        Nq, d, R, dev, G, dwq, dqpos_parts = self.Nq, self.d, self.R, self.dev, self.G, self.dwq, self.dqpos_parts
+        dPKV, = self.dPKV,
+        i, x1 = rec["i"], rec["x1"]
+        # ---------------- prompt cross-attention backward (sequential, single memory): dx1 is d(x1s) here
+        pc = ctx.pcas[i]
+        wp = pc.multihead_attn.in_proj_weight.detach()
+        gwp, gbp = G(pc.multihead_attn.in_proj_weight), G(pc.multihead_attn.in_proj_bias)
+        dx1pr, dopp = _ln_bwd(x1, [rec["opp"]], [pc.norm.weight.detach()], [pc.norm.bias.detach()], pc.norm.eps, None,
+                              Nq, rec["mean_p"], rec["rstd_p"], dx1, [G(pc.norm.weight)], [G(pc.norm.bias)],
+                              drop=rec["dr_pr"])
+        do_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
+        L.gemm(M=R, N=d, K=d, A=[dopp[0]], B=[pc.multihead_attn.out_proj.weight.detach()], Cs=[do_p], ct=ct, lda=d,
+               ldb=d, ldc=d, transB=True)
+        dwq.add([dopp[0]], [rec["o_p"]], None, [G(pc.multihead_attn.out_proj.weight)], ct,
+                [G(pc.multihead_attn.out_proj.bias)])
+        dq_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
+        delta_p = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
+        _attn(rec["qp"], ctx.PKV[i, 0], ctx.PKV[i, 1], rec["o_p"], rec["lse_p"], H, ct, True, kpm=ctx.pmask,
+              bwd=(do_p, dq_p, dPKV[a, 0], dPKV[a, 1], delta_p, None), drop=rec["dr_pa"])
+        gq_p = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+        dx1n = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+        L.gemm(M=R, N=d, K=d, A=[dq_p], B=[wp[:d]], Cs=[dx1n], C2=[gq_p], aux=[dx1pr], act_grad="add", ct=ct, lda=d,
+               ldb=d, ldc=d, transB=True)
+        dqpos_parts.append(gq_p)
+        dwq.add([dq_p], [x1], [qpos], [gwp[:d]], ct, [gbp[:d]])
+        dx1 = dx1n
+        return dx1
+
+    def cross_attn(self, a, rec, dx1):
+        """Cross-attention over the M scene memories (one launch each for out-projection, attention, query projection):
+        returns d(x_in) of the layer application; dK / dV of the application go to self.dKV[a]."""
+        ctx, spec, ct, ad, M, qpos, coef = self.ctx, self.spec, self.ct, self.ad, self.M, self.qpos, self.coef
+        H, B, Nq, d, Ns, R, dev = self.H, self.B, self.Nq, self.d, self.Ns, self.R, self.dev
+        cas, KV, dxr_zero, G, dwq, dqpos_parts = self.cas, self.KV, self.dxr_zero, self.G, self.dwq, self.dqpos_parts
+        dKV, = self.dKV,
+        i, x_in = rec["i"], rec["x_in"]
+        # ---------------- cross-attention backward (M memories per launch)
+        cl = cas[i]
+        dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
+                           [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef[a] if coef is not None else None,
+                           Nq, rec["mean_c"], rec["rstd_c"],
+                           dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl], drop=rec["dr_cr"],
+                           dx_zeroed=dxr_zero[a] if dxr_zero is not None else None)
+        do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+        L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
+               Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+        dwq.add([dop[m] for m in range(M)], [rec["o_all"][m] for m in range(M)], None,
+                [G(ca.multihead_attn.out_proj.weight) for ca in cl], ct,
+                [G(ca.multihead_attn.out_proj.bias) for ca in cl])
+        dq_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+        delta_c = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
+        mb = dict(mask=rec["attn_mask"], row_open=rec["row_open"], mask_bmod=B, mask_bits=rec.get("mask_bits")) if spec.use_self_mask \
+            else dict(kpm=ctx.kpm_all)
+        _attn(rec["q_all"].view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
+              rec["o_all"].view(M * B, Nq, d), rec["lse"], H, ct, True,
+              bwd=(do_all.view(M * B, Nq, d), dq_all.view(M * B, Nq, d), dKV[a, 0].view(M * B, Ns, d),
+                   dKV[a, 1].view(M * B, Ns, d), delta_c, None), drop=rec["dr_ca"], drop_bmod=B, **mb)
+        ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cl]
+        gq = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+        dxn = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+        L.gemm(M=R, N=d, K=d, A=[dq_all[m] for m in range(M)], B=[w[:d] for w in ws], Cs=[dxn] + [None] * (M - 1),
+               C2=[gq] + [None] * (M - 1), aux=[dxr] + [None] * (M - 1), act_grad="add", ct=ct, lda=d, ldb=d, ldc=d,
+               transB=True, kconcat=M)
+        dqpos_parts.append(gq)
+        dwq.add([dq_all[m] for m in range(M)], [x_in] * M, [qpos] * M,
+                [G(ca.multihead_attn.in_proj_weight)[:d] for ca in cl], ct,
+                [G(ca.multihead_attn.in_proj_bias)[:d] for ca in cl])
+        dx = dxn
+        return dx
+
+    def layer(self, a, dx):
+        """One layer application in reverse: FFN, self-attention, (prompt) cross-attention, the mask-head call in front of it."""
+        spec, layers, Ln, dcls, dmlog, n_app, dwq = self.spec, self.layers, self.Ln, self.dcls, self.dmlog, self.n_app, self.dwq
+        ready, per_layer = self.ready, self.per_layer
+        rec = self.tape[a]
+        i = rec["i"]
+        layer = self.layers[i]
+        dx2 = self.ffn(rec, layer, dx)
+        dx1 = self.self_attn(rec, layer, dx2)
+        if self.spec.prompt:
+            dx1 = self.prompt_cross_attn(a, rec, dx1)
+        dx = self.cross_attn(a, rec, dx1)
+        # ---------------- mask-head call that preceded this layer
+        if spec.mh is not None and not spec.skip_pred:
+            dx = self.mask_head(rec, dcls[a], dmlog[a], dx)
+        # ---------------- per-layer gradient buckets (data parallel, SURVEY 8e: "bucketed per decoder layer in reverse
+        # execution order"): the first-block application of layer i is the LAST to run backward, so every gradient of
+        # layer i's parameters -- its queued weight-gradient products, the K/V rows of its in_proj weights (from the
+        # dK / dV of all its applications) and its spatial-bias projection -- is complete once they are flushed here;
+        # ready(i) lets the owner start that bucket's all-reduce while the earlier layers still run backward
+        if per_layer and a < Ln:
+            self.kv_terms(range(i, n_app, Ln), into_queue=True)
+            dwq.flush()
+            self.flush_spatial()
+            ready(i)
+        return dx
+
+    def run(self):
+        ctx, B, Nq, d, dev, dcls, dmlog = self.ctx, self.B, self.Nq, self.d, self.dev, self.dcls, self.dmlog
+        n_app, = self.n_app,
+        dxf = self.dxf
+        dx = dxf.contiguous().float() if dxf is not None else torch.zeros(B, Nq, d, device=dev)
+        if ctx.final_rec is not None:
+            dx = self.mask_head(ctx.final_rec, dcls[-1], dmlog[-1], dx)
+        for a in range(n_app - 1, -1, -1):
+            dx = self.layer(a, dx)
+        return self.inputs(dx)
+
+    def inputs(self, dx):
+        """After the last layer: the deferred weight-gradient flush, then the input gradients -- the hoisted K/V projections'
+        backward (sum over all layer applications per source tensor), d pos, d query_pos, d prompt."""
+        ctx, spec, tape, enc, ct, ad, M = self.ctx, self.spec, self.tape, self.enc, self.ct, self.ad, self.M
+        U, src, mh_src, pos, params, Ln, B = self.U, self.src, self.mh_src, self.pos, self.params, self.Ln, self.B
+        Nq, d, Ns, Rk, dev, gv, n_app = self.Nq, self.d, self.Ns, self.Rk, self.dev, self.gv, self.n_app
+        accumulate, G, dwq, dqpos_parts, dKV, dPKV, ready = self.accumulate, self.G, self.dwq, self.dqpos_parts, self.dKV, self.dPKV, self.ready
+        per_layer, = self.per_layer,
+        # ---- hoisted K/V projection backward (sum over all applications)
+        need_feat = [ctx.needs_input_grad[11 + u] for u in range(U)]
+        dfeats: List[Optional[torch.Tensor]] = [None] * U
+        single = U == M and all(src[i][j] == j for i in range(Ln) for j in range(M)) and mh_src[:M] == list(range(M))[:len(mh_src)]
+        Akv, Bkv = self.kv_terms(range(n_app), into_queue=not per_layer)
+        # ---- every parameter gradient of the decoder (+ mask head) is complete after this flush: in a data-parallel step
+        # its all-reduce starts HERE (enc.grads_ready, set by the step owner) and overlaps the key/value input-gradient
+        # products below and the encoders' backward that autograd runs after this function returns
+        dkm_list = {}
+        if self.dk_terms:
+            Mm_, nc = spec.mh_count, len(self.dk_terms)
+            newk = torch.empty(Mm_, B, Ns, d, dtype=torch.float32, device=dev)
+            L.gemm(M=Ns, N=d, K=Nq, A=[t_[0] for m in range(Mm_) for t_ in self.dk_terms],
+                   B=[t_[1][m] for m in range(Mm_) for t_ in self.dk_terms],
+                   Cs=[c_ for m in range(Mm_) for c_ in [newk[m]] + [None] * (nc - 1)],
+                   aux=[c_ for m in range(Mm_) for c_ in [self.dkeys[m]] + [None] * (nc - 1)] if self.dkeys is not None else None,
+                   act_grad="add" if self.dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
+                   strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d, kconcat=nc)
+            self.dkeys, self.dk_terms = newk, []
+        if self.dkeys is not None:
+            for j in range(spec.mh_count):
+                mp = list(spec.mh.mask_pred_list)[j]
+                dkm_list[j] = ops.scale_rows(self.dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
+                dwq.add([dkm_list[j]], [ctx.mh_feats[j]], None, [G(mp.k_proj.weight)], ct)
+        dwq.flush()
+        self.flush_spatial()
+        ready("decoder")   # every parameter gradient of the decoder (+ mask head) is final
+        # bf16 path: the input-gradient products read TRANSPOSED bf16 copies of the K/V weights (one copy launch from the
+        # forward's pre-cast rows), which turns them into plain NT products -- the 128x128-tile kernel's layout -- and the
+        # memories then share launches (K-concatenation per memory, several outputs per launch)
+        tposed = ctx.wkv is not None and dKV.dtype == torch.bfloat16
+        if tposed:
+            wkvT = ctx.wkvT if ctx.wkvT is not None else \
+                ctx.wkv.view(Ln, M, 2, d, d).transpose(-1, -2).contiguous()       # [l, m, t][k_in][n_out]
+            Bkv = [wkvT[tape[a]["i"], j, t] for a in range(n_app) for j in range(M) for t in (0, 1)]
+            kT = None
+            if self.dkeys is not None:
+                kT = torch.stack([mp.k_proj.weight.detach() for mp in list(spec.mh.mask_pred_list)[:spec.mh_count]]) \
+                    .transpose(1, 2).contiguous().to(ad)
+        # d source_u = sum over the (application, memory) pairs that read it of (dK Wk + dV Wv) [+ mask-head key path]
+        jobs = []
+        for u in range(U):
+            if not need_feat[u]:
+                continue
+            pairs = [(a, j) for a in range(n_app) for j in range(M) if src[tape[a]["i"]][j] == u]
+            Aj = [Akv[2 * (a * M + j) + t] for a, j in pairs for t in (0, 1)]
+            Bj = [Bkv[2 * (a * M + j) + t] for a, j in pairs for t in (0, 1)]
+            for j in range(spec.mh_count if self.dkeys is not None else 0):
+                if mh_src[j] != u:
+                    continue
+                mp = list(spec.mh.mask_pred_list)[j]
+                Aj.append(dkm_list[j])
+                Bj.append(kT[j] if tposed else mp.k_proj.weight.detach())
+            jobs.append((u, Aj, Bj))
+        per = len(jobs[0][1]) if jobs else 0
+        want_dpos = pos is not None and ctx.needs_input_grad[4]
+        dqpos_done = None
+        dpos = None
+        nk, nv = n_app, n_app + (1 if self.dkeys is not None else 0)
+        if single and tposed and want_dpos and len(jobs) == M and nk * M <= MAXG and nv * M <= MAXG and \
+                (self.dkeys is None or spec.mh_count == M):
+            # the position embedding enters every memory's KEY input, so d pos = sum_m (K part of d feat_m): form the K
+            # parts once (one launch, M outputs), add them into the V parts through the "+ aux" epilogue (second launch)
+            # and sum them for d pos -- instead of a third product over all (layer, memory) key terms
+            Kp = torch.empty(M, B, Ns, d, dtype=torch.float32, device=dev)
+            L.gemm(M=Rk, N=d, K=d, A=[jb[1][2 * a] for jb in jobs for a in range(n_app)],
+                   B=[jb[2][2 * a] for jb in jobs for a in range(n_app)],
+                   Cs=[c_ for j in range(M) for c_ in [Kp[j]] + [None] * (nk - 1)], ct=ct, lda=d, ldb=d, ldc=d, kconcat=nk)
+            outs = [torch.empty(B, Ns, d, dtype=torch.float32, device=dev) for _ in range(M)]
+            vA = [[jb[1][2 * a + 1] for a in range(n_app)] + jb[1][2 * n_app:] for jb in jobs]
+            vB = [[jb[2][2 * a + 1] for a in range(n_app)] + jb[2][2 * n_app:] for jb in jobs]
+            L.gemm(M=Rk, N=d, K=d, A=[t_ for l_ in vA for t_ in l_], B=[t_ for l_ in vB for t_ in l_],
+                   Cs=[c_ for o_ in outs for c_ in [o_] + [None] * (nv - 1)],
+                   aux=[c_ for j in range(M) for c_ in [Kp[j]] + [None] * (nv - 1)], act_grad="add", ct=ct, lda=d, ldb=d,
+                   ldc=d, kconcat=nv)
+            for jb, o_ in zip(jobs, outs):
+                dfeats[jb[0]] = o_
+            if ctx.needs_input_grad[2] and len(dqpos_parts) > 1:   # d query_pos and d pos: one launch, adjacent outputs
+                dqpos_done, dpos = ops.sum_pair(dqpos_parts, [Kp[j] for j in range(M)])
+            else:
+                dpos = ops.sum_n([Kp[j] for j in range(M)])
+            want_dpos = False
+        elif tposed and jobs and 0 < per <= MAXG and all(len(jb[1]) == per for jb in jobs):
+            cap = max(1, MAXG // per)   # memories per launch
+            for c0 in range(0, len(jobs), cap):
+                chunk = jobs[c0:c0 + cap]
+                outs = [torch.empty(B, Ns, d, dtype=torch.float32, device=dev) for _ in chunk]
+                L.gemm(M=Rk, N=d, K=d, A=[t_ for jb in chunk for t_ in jb[1]], B=[t_ for jb in chunk for t_ in jb[2]],
+                       Cs=[c_ for o_ in outs for c_ in [o_] + [None] * (per - 1)], ct=ct, lda=d, ldb=d, ldc=d,
+                       kconcat=per)
+                for jb, o_ in zip(chunk, outs):
+                    dfeats[jb[0]] = o_
+        else:
+            for j, Aj, Bj in jobs:
+                out = None
+                if not Aj:   # a source no layer reads (e.g. a surplus scale): zero gradient
+                    out = torch.zeros(B, Ns, d, dtype=torch.float32, device=dev)
+                for s in range(0, len(Aj), MAXG):
+                    nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
+                    n = len(Aj[s:s + MAXG])
+                    L.gemm(M=Rk, N=d, K=d, A=Aj[s:s + MAXG], B=Bj[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
+                           aux=([out] + [None] * (n - 1)) if out is not None else None,
+                           act_grad="add" if out is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=not tposed,
+                           kconcat=n)
+                    out = nxt
+                dfeats[j] = out
+        if want_dpos:
+            Ak, Bk = Akv[0::2], Bkv[0::2]
+            for s in range(0, len(Ak), MAXG):
+                nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
+                n = len(Ak[s:s + MAXG])
+                L.gemm(M=Rk, N=d, K=d, A=Ak[s:s + MAXG], B=Bk[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
+                       aux=([dpos] + [None] * (n - 1)) if dpos is not None else None,
+                       act_grad="add" if dpos is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=not tposed,
+                       kconcat=n)
+                dpos = nxt
+        dqpos = dqpos_done
+        if ctx.needs_input_grad[2] and dqpos is None:
+            dqpos = ops.sum_n(dqpos_parts)
+        dx0 = dx if ctx.needs_input_grad[1] else None
+        dprompt = None
+        if spec.prompt and ctx.needs_input_grad[9]:
+            # d prompt = sum over layer applications of dK_p Wk + dV_p Wv: one K-concatenated launch
+            Ap, Bp = [], []
+            for a_ in range(n_app):
+                w = ctx.pcas[tape[a_]["i"]].multihead_attn.in_proj_weight.detach()
+                Ap += [dPKV[a_, 0], dPKV[a_, 1]]
+                Bp += [w[d:2 * d], w[2 * d:]]
+            T = ctx.prompt.shape[1]
+            for s_ in range(0, len(Ap), MAXG):
+                nxt = torch.empty(B, T, d, dtype=torch.float32, device=dev)
+                n = len(Ap[s_:s_ + MAXG])
+                L.gemm(M=B * T, N=d, K=d, A=Ap[s_:s_ + MAXG], B=Bp[s_:s_ + MAXG], Cs=[nxt] + [None] * (n - 1),
+                       aux=([dprompt] + [None] * (n - 1)) if dprompt is not None else None,
+                       act_grad="add" if dprompt is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=n)
+                dprompt = nxt
+        pgrads = [gv[id(p)] if (p.requires_grad and not accumulate) else None for p in params]
+        return (None, dx0, dqpos, None, dpos, None, None, None, None, dprompt, None, *dfeats, *([None] * M), *pgrads)
+
+
 class _FusedDecoder(Function):
     """inputs: spec, x0, qpos, qmask, pos, pairwise_locs, seg_pad, offline_mask, coef, prompt, prompt_mask, U feats,
     M masks, *params."""
@@ -537,487 +1095,7 @@ class _FusedDecoder(Function):
 
     @staticmethod
     def backward(ctx, dxf, *dheads):
-        spec, tape = ctx.spec, ctx.tape
-        enc, ct = spec.enc, spec.ct
-        ad = ops.act_dtype(ct)
-        M, U, src, mh_src = ctx.M, ctx.U, ctx.src, ctx.mh_src
-        sv = ctx.saved_tensors
-        x0, qpos, qmask, pos, pl, seg_pad, coef = sv[:7]
-        feats, masks = list(sv[7:7 + U]), list(sv[7 + U:7 + U + M])
-        params = ctx.params
-        layers = list(enc.unified_encoder)
-        Ln, H = len(layers), enc.num_heads
-        B, Nq, d = qpos.shape
-        Ns = feats[0].shape[1]
-        R, Rk = B * Nq, B * Ns
-        dev = qpos.device
-        cas, KV = ctx.cas, ctx.KV
-        n_mh = ctx.n_mh
-        dcls, dmlog = list(dheads[:n_mh]), list(dheads[n_mh:2 * n_mh])
-
-        # ---- gradient arena: one flat zeroed fp32 buffer, every parameter gradient is a view of it
-        sizes = [p.numel() for p in params]
-        ext = getattr(enc, "grad_arena", None)   # {id(param): (flat, offset, numel)} of a DP reducer's flat buffers
-        gv = {}
-        n_app = len(tape)
-        # input gradients of the M-branch cross-attention LayerNorms are accumulated with atomics by the M branch blocks; that
-        # buffer and the gradient arena are zeroed by ONE launch for the whole backward
-        dxr_zero = torch.empty(n_app, B, Nq, d, dtype=torch.float32, device=dev) if M > 1 else None
-        accumulate = False
-        in_place = ext is not None and all(id(p) in ext for p in params)
-        if in_place:
-            # gradients go straight into the owner's flat buffer (data-parallel bucket / optimizer arena): no pack copy.
-            for p in params:
-                flat, o_, n_ = ext[id(p)]
-                gv[id(p)] = flat[o_:o_ + n_].view(p.shape)
-            # torch semantics of a second backward before zero_grad: gradients ACCUMULATE (the reference trains under
-            # accelerator.accumulate, trainer/query3d_trainer.py:35).  Every parameter gradient of this backward is formed
-            # by accumulating launches (split-K atomics, accumulating column sums), so accumulation = not zeroing the arena.
-            # Which case this is is read off the parameters: .grad still aliasing the arena -> the owner has not consumed the
-            # previous micro-batch -> add in place (and hand autograd nothing: .grad already is the arena);
-            # .grad None / foreign everywhere -> fresh step: zero, then hand fresh views to autograd (adopted without a copy).
-            req = [p for p in params if p.requires_grad]
-            alias = [p.grad is not None and p.grad.data_ptr() == gv[id(p)].data_ptr() for p in req]
-            # parameters outside the decoder (the input encoders) with slots in the buffers zeroed here: offered to the
-            # backward functions that run after this one in the same pass (ops.arena_offer)
-            bufs = list(getattr(enc, "grad_arena_buffers", ()))
-            zeroed, own = {b.data_ptr() for b in bufs}, {id(p) for p in params}
-            offer = {}
-            for i_, q_ in getattr(ext, "params", {}).items():
-                if i_ not in own and q_.requires_grad and ext[i_][0].data_ptr() in zeroed:
-                    fl_, o_, n_ = ext[i_]
-                    offer[q_.data_ptr()] = (q_, fl_, o_, n_)
-            mixed = "fused decoder backward: some parameters' .grad alias the shared gradient arena and others do not -- " \
-                    "zero ALL gradients (set_to_none=True) or none between micro-batches"
-            if ops._Arena.whole_pass and ops._Arena.mode is not None and \
-                    all(p.data_ptr() in ops._Arena.by_ptr for p in req):
-                # the owner opened the arena around the whole pass (ops.grad_arena): already zeroed / accumulating
-                accumulate = ops._Arena.mode == "accumulate"
-                if accumulate and not all(alias):
-                    raise RuntimeError(mixed)
-                offer = {}
-                if not ops.arena_flush_zero([dxr_zero]):   # first consumer of a fresh pass: arena + own scratch, one launch
-                    ops.zero_many([dxr_zero])
-            elif req and all(alias):
-                accumulate = True
-                ops.zero_many([dxr_zero])
-            elif any(alias) or any(q_.grad is not None and q_.grad.data_ptr() == f_.data_ptr() + 4 * o_ for q_, f_, o_, n_ in offer.values()):
-                raise RuntimeError(mixed)
-            else:
-                ops.zero_many(bufs + [dxr_zero])
-            if offer:
-                ops.arena_offer(offer, "accumulate" if accumulate else "fresh")
-        else:
-            arena = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-            ops.zero_many([arena, dxr_zero])
-            off = 0
-            for p, n in zip(params, sizes):
-                gv[id(p)] = arena[off:off + n].view(p.shape)
-                off += n
-        G = lambda p: gv[id(p)]
-
-        dwq = _DwQueue(ct)
-        sb_queue = []   # (W, b, d bias, dW, db) of every spatial self-attention application
-        dx = dxf.contiguous().float() if dxf is not None else torch.zeros(B, Nq, d, device=dev)
-        dqpos_parts: List[torch.Tensor] = []
-        dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=ad, device=dev)
-        dPKV = torch.empty(n_app, 2, B, ctx.prompt.shape[1], d, dtype=ad, device=dev) if spec.prompt else None
-        dkeys = None  # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
-        dk_terms = []   # queued (g, q_m) terms of it (one K-concatenated launch at the end)
-
-        def mh_backward(rec, dc, dm, dx_in):
-            """Backprop one mask-head call; returns dx_in + its contribution to d(query)."""
-            nonlocal dkeys
-            mh = spec.mh
-            c0, c2, c4 = mh.cls_head[0], mh.cls_head[2], mh.cls_head[4]
-            x_in = rec["mh_x"]
-            Hd, C_ = c0.out_features, c4.out_features
-            cur = dx_in
-            if dc is not None:
-                dcl = dc.contiguous()
-                if mh._foc_cols.numel():
-                    t = torch.empty_like(dcl)
-                    L.check(L.lib().pq3d_fill_cols(L.ptr(dcl), L.ptr(t), R, C_, L.ptr(mh._foc_cols),
-                                                   mh._foc_cols.numel(), 0.0, L.stream()), "pq3d_fill_cols")
-                    dcl = t
-                dh2 = torch.empty(B, Nq, Hd, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=Hd, K=C_, A=[dcl], B=[c4.weight.detach()], Cs=[dh2], ct=ct, lda=C_, ldb=Hd, ldc=Hd, transB=True)
-                dwq.add([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct, [G(c4.bias)])
-                if rec.get("mh_drop") is not None:
-                    dh2 = ops._dropout_apply(dh2, rec["mh_drop"])
-                _, dh1 = _ln_bwd(None, [rec["mh_h1"]], [c2.weight.detach()], [c2.bias.detach()], c2.eps, None, Nq,
-                                 rec["mh_mean"], rec["mh_rstd"], dh2, [G(c2.weight)], [G(c2.bias)])
-                dpre = ops.act_bwd(dh1[0], rec["mh_h1"], "relu", ad)
-                nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=Hd, A=[dpre], B=[c0.weight.detach()], Cs=[nxt], aux=[cur], act_grad="add", ct=ct,
-                       lda=Hd, ldb=d, ldc=d, transB=True)
-                dwq.add([dpre], [x_in], None, [G(c0.weight)], ct, [G(c0.bias)])
-                cur = nxt
-            if dm is not None:
-                Mm = spec.mh_count
-                mps = list(mh.mask_pred_list)[:Mm]
-                qm = rec["mh_qm"]
-                g = ops.scale_rows(dm.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=seg_pad)
-                # d keys = sum over the mask-head calls of g_c @ q_m,c: nothing consumes it before the end of the backward, so
-                # the terms are queued and formed by ONE K-concatenated launch there (each call used to re-read and re-write
-                # the [Mm, B, Ns, d] fp32 sum through the "+ aux" epilogue: 100 MB per call at config 4)
-                if Mm * (len(dk_terms) + 1) <= MAXG:
-                    dk_terms.append((g, qm))
-                else:
-                    newk = torch.empty(Mm, B, Ns, d, dtype=torch.float32, device=dev)
-                    L.gemm(M=Ns, N=d, K=Nq, A=[g] * Mm, B=[qm[m] for m in range(Mm)], Cs=[newk[m] for m in range(Mm)],
-                           aux=[dkeys[m] for m in range(Mm)] if dkeys is not None else None,
-                           act_grad="add" if dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
-                           strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
-                    dkeys = newk
-                # [Nq x d] outputs per (memory, scene) over a reduction of Ns segments: few tiles, long K -> split-K into an
-                # fp32 buffer once Ns is large (c4: 192 workgroups x 64 k-tiles otherwise)
-                sk = min(8, Ns // 512) if Ns >= 1024 else 1
-                dqm = torch.empty(Mm, B, Nq, d, dtype=torch.float32 if sk > 1 else ad, device=dev)
-                L.gemm(M=Nq, N=d, K=Ns, A=[g] * Mm, B=list(ctx.keys), Cs=[dqm[m] for m in range(Mm)], ct=ct, lda=Nq,
-                       ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d,
-                       splitk=sk)
-                nxt = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=d, A=[dqm[m] for m in range(Mm)], B=[mp.q_proj.weight.detach() for mp in mps],
-                       Cs=[nxt] + [None] * (Mm - 1), aux=[cur] + [None] * (Mm - 1), act_grad="add", ct=ct, lda=d, ldb=d,
-                       ldc=d, transB=True, kconcat=Mm)
-                dwq.add([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct,
-                        [G(mp.q_proj.bias) for mp in mps])
-                cur = nxt
-            return cur
-
-        ready_cb = getattr(enc, "grads_ready", None) if in_place else None   # only when the owner's buffers were written
-        per_layer = bool(getattr(enc, "grad_bucket_per_layer", False)) and ready_cb is not None
-        if ready_cb is not None:
-            def ready(tag):
-                # weight gradients queued by ops.linear layers that ran backward BEFORE the decoder (heads; ops._DwDeferred)
-                # must be in their slots before an owner is told that a bucket is final
-                ops.dw_deferred_flush()
-                ready_cb(tag)
-        else:
-            ready = lambda tag: None
-        # the output heads consume the decoder's outputs, so their backward has run when this one starts (the reference:
-        # query3d_unified.py:193-218): whatever they wrote into their arena slots is final now -- an owner may start that
-        # bucket's all-reduce under the whole decoder backward (config 5: the caption body's 240 MB)
-        ready("heads")
-
-        def kv_terms(apps, into_queue):
-            """(dK|dV, W) operand lists of the hoisted K/V projections' backward for the applications `apps`; with
-            into_queue their weight / bias gradient products are queued."""
-            A_, B_, Xf, X2, GWs, Gbs = [], [], [], [], [], []
-            for a_ in apps:
-                i_ = tape[a_]["i"]
-                for j, ca in enumerate(cas[i_]):
-                    w = ca.multihead_attn.in_proj_weight.detach()
-                    gw, gb = G(ca.multihead_attn.in_proj_weight), G(ca.multihead_attn.in_proj_bias)
-                    A_ += [dKV[a_, 0, j], dKV[a_, 1, j]]
-                    B_ += [w[d:2 * d], w[2 * d:]]
-                    Xf += [ctx.kin[src[i_][j]], ctx.vin[src[i_][j]]]
-                    X2 += [ctx.kin2[src[i_][j]], None]
-                    GWs += [gw[d:2 * d], gw[2 * d:]]
-                    Gbs += [gb[d:2 * d], gb[2 * d:]]
-            if into_queue:
-                dwq.add(A_, Xf, X2, GWs, ct, Gbs)
-                if spec.prompt:   # the prompt memory's K / V rows of its cross-attention's in_proj weights
-                    for a_ in apps:
-                        pc_ = ctx.pcas[tape[a_]["i"]]
-                        gw, gb = G(pc_.multihead_attn.in_proj_weight), G(pc_.multihead_attn.in_proj_bias)
-                        dwq.add([dPKV[a_, 0], dPKV[a_, 1]], [ctx.prompt, ctx.prompt], None, [gw[d:2 * d], gw[2 * d:]], ct,
-                                [gb[d:2 * d], gb[2 * d:]])
-            return A_, B_
-
-        def flush_spatial():
-            for i0 in range(0, len(sb_queue), MAXG):
-                chunk = sb_queue[i0:i0 + MAXG]
-                arrs = [(C.c_void_p * len(chunk))(*[L.ptr(t[k]) for t in chunk]) for k in range(5)]
-                L.check(L.lib().pq3d_spatial_bias_bwd_grouped(L.ptr(pl), *arrs, len(chunk), B, H, Nq, L.stream()),
-                        "pq3d_spatial_bias_bwd_grouped")
-            del sb_queue[:]
-
-        if ctx.final_rec is not None:
-            dx = mh_backward(ctx.final_rec, dcls[-1], dmlog[-1], dx)
-
-        for a in range(n_app - 1, -1, -1):
-            rec = tape[a]
-            i = rec["i"]
-            layer = layers[i]
-            x_in, x1, x2 = rec["x_in"], rec["x1"], rec["x2"]
-            # ---------------- FFN backward
-            ffn = layer.ffn
-            F_ = ffn.linear1.out_features
-            # dx2r = residual-branch gradient, dy = (dropout-masked) gradient of the linear2 output (sum of the partials)
-            dx2r, dy = _ln_bwd(x2, [rec["z"]], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()], ffn.norm.eps, None, Nq,
-                               rec["mean_f"][:1], rec["rstd_f"][:1], dx, [G(ffn.norm.weight)], [G(ffn.norm.bias)],
-                               drop=rec["dr_fr"])
-            dy = dy[0]
-            dhp = torch.empty(B, Nq, F_, dtype=ad, device=dev)
-            # inner dropout.  ReLU: the saved h is post-dropout, so [h > 0] already carries the keep-mask and only the
-            # 1/(1-p) factor is left -> alpha.  GELU (round 3): the epilogue regenerates the forward's mask on the incoming
-            # gradient (same site, same [R, F] indices) before multiplying by gelu'(pre) -- epi_row's order: dropout, then
-            # the activation gradient
-            relu = spec.act != "gelu"
-            L.gemm(M=R, N=F_, K=d, A=[dy], B=[ffn.linear2.weight.detach()], Cs=[dhp],
-                   aux=[rec["h"] if relu else rec["pre"]], act_grad=spec.act, ct=ct, lda=d, ldb=F_, ldc=F_,
-                   transB=True, alpha=1.0 / (1.0 - rec["dr_fi"].p) if (rec["dr_fi"] is not None and relu) else 1.0,
-                   drop=rec["dr_fi"] if not relu else None)
-            dwq.add([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
-            dx2 = dx2r   # dx2 = dx2r + dhp W1: split-K accumulated in place onto the residual-branch gradient
-            L.gemm(M=R, N=d, K=F_, A=[dhp], B=[ffn.linear1.weight.detach()], Cs=[dx2], ct=ct, lda=F_, ldb=d, ldc=d,
-                   transB=True, splitk=4, accumulate=True)
-            dwq.add([dhp], [x2], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
-            # ---------------- self-attention backward
-            sa = layer.self_attn
-            if spec.spatial:
-                msa = sa.self_attn
-                Wl = [msa.w_qs.weight, msa.w_ks.weight, msa.w_vs.weight]
-                GW = [G(w) for w in Wl]
-                Gb = [G(msa.w_qs.bias), G(msa.w_ks.bias), G(msa.w_vs.bias)]
-                Wl = [w.detach() for w in Wl]
-                Wo, GWo, Gbo = msa.fc.weight.detach(), G(msa.fc.weight), G(msa.fc.bias)
-            else:
-                w, gw, gb = sa.self_attn.in_proj_weight.detach(), G(sa.self_attn.in_proj_weight), G(sa.self_attn.in_proj_bias)
-                Wl = [w[:d], w[d:2 * d], w[2 * d:]]
-                GW = [gw[:d], gw[d:2 * d], gw[2 * d:]]
-                Gb = [gb[:d], gb[d:2 * d], gb[2 * d:]]
-                Wo, GWo, Gbo = sa.self_attn.out_proj.weight.detach(), G(sa.self_attn.out_proj.weight), G(sa.self_attn.out_proj.bias)
-            x1s = rec["x1s"]     # the self-attention sublayer's input (x1, or the prompt cross-attention's output)
-            dx1r, df = _ln_bwd(x1s, [rec["f"]], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
-                               rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)],
-                               drop=rec["dr_sr"])
-            df = df[0]
-            fold = sa_fold_ok(ct, B, H, Nq, d, rec["dr_sa"], df, Wo)
-            do_s = None
-            if not fold:
-                do_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=d, A=[df], B=[Wo], Cs=[do_s], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
-            dwq.add([df], [rec["o_s"]], None, [GWo], ct, [Gbo])
-            qkv = rec["qkv"]
-            dqkv = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
-            delta = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
-            dsb = torch.empty_like(rec["sbias"]) if spec.spatial else None
-            _attn(qkv[0], qkv[1], qkv[2], rec["o_s"], rec["lse_s"], H, ops.sa_ct(ct), False, kpm=qmask, bias=rec["sbias"],
-                  bwd=(do_s, dqkv[0], dqkv[1], dqkv[2], delta, dsb), drop=rec["dr_sa"],
-                  proj_dout=(df, Wo) if fold else None)
-            if spec.spatial:   # deferred: one grouped launch for all layer applications at the end of the backward
-                sb_queue.append((msa.pairwise_loc_fc.weight.detach(), msa.pairwise_loc_fc.bias.detach(), dsb,
-                                 G(msa.pairwise_loc_fc.weight), G(msa.pairwise_loc_fc.bias)))
-            # d(x1 + qpos) from q and k, d(x1) from v (+ the residual-branch gradient): three independent products, ONE
-            # launch; their sum is formed by the consumer (the next LayerNorm backward reads three addends) instead of
-            # by a second, dependent "+ aux" launch
-            g3 = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
-            L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1], dqkv[2]], B=list(Wl), Cs=[g3[0], g3[1], g3[2]],
-                   aux=[None, None, dx1r], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True)
-            dqpos_parts += [g3[0], g3[1]]
-            dx1 = [g3[0], g3[1], g3[2]]
-            dwq.add([dqkv[0], dqkv[1], dqkv[2]], [x1s] * 3, [qpos, qpos, None], GW, ct, Gb)
-            if spec.prompt:
-                # ---------------- prompt cross-attention backward (sequential, single memory): dx1 is d(x1s) here
-                pc = ctx.pcas[i]
-                wp = pc.multihead_attn.in_proj_weight.detach()
-                gwp, gbp = G(pc.multihead_attn.in_proj_weight), G(pc.multihead_attn.in_proj_bias)
-                dx1pr, dopp = _ln_bwd(x1, [rec["opp"]], [pc.norm.weight.detach()], [pc.norm.bias.detach()], pc.norm.eps, None,
-                                      Nq, rec["mean_p"], rec["rstd_p"], dx1, [G(pc.norm.weight)], [G(pc.norm.bias)],
-                                      drop=rec["dr_pr"])
-                do_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
-                L.gemm(M=R, N=d, K=d, A=[dopp[0]], B=[pc.multihead_attn.out_proj.weight.detach()], Cs=[do_p], ct=ct, lda=d,
-                       ldb=d, ldc=d, transB=True)
-                dwq.add([dopp[0]], [rec["o_p"]], None, [G(pc.multihead_attn.out_proj.weight)], ct,
-                        [G(pc.multihead_attn.out_proj.bias)])
-                dq_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
-                delta_p = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
-                _attn(rec["qp"], ctx.PKV[i, 0], ctx.PKV[i, 1], rec["o_p"], rec["lse_p"], H, ct, True, kpm=ctx.pmask,
-                      bwd=(do_p, dq_p, dPKV[a, 0], dPKV[a, 1], delta_p, None), drop=rec["dr_pa"])
-                gq_p = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                dx1n = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=d, A=[dq_p], B=[wp[:d]], Cs=[dx1n], C2=[gq_p], aux=[dx1pr], act_grad="add", ct=ct, lda=d,
-                       ldb=d, ldc=d, transB=True)
-                dqpos_parts.append(gq_p)
-                dwq.add([dq_p], [x1], [qpos], [gwp[:d]], ct, [gbp[:d]])
-                dx1 = dx1n
-            # ---------------- cross-attention backward (M memories per launch)
-            cl = cas[i]
-            dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
-                               [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef[a] if coef is not None else None,
-                               Nq, rec["mean_c"], rec["rstd_c"],
-                               dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl], drop=rec["dr_cr"],
-                               dx_zeroed=dxr_zero[a] if dxr_zero is not None else None)
-            do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
-            L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
-                   Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
-            dwq.add([dop[m] for m in range(M)], [rec["o_all"][m] for m in range(M)], None,
-                    [G(ca.multihead_attn.out_proj.weight) for ca in cl], ct,
-                    [G(ca.multihead_attn.out_proj.bias) for ca in cl])
-            dq_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
-            delta_c = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
-            mb = dict(mask=rec["attn_mask"], row_open=rec["row_open"], mask_bmod=B, mask_bits=rec.get("mask_bits")) if spec.use_self_mask \
-                else dict(kpm=ctx.kpm_all)
-            _attn(rec["q_all"].view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
-                  rec["o_all"].view(M * B, Nq, d), rec["lse"], H, ct, True,
-                  bwd=(do_all.view(M * B, Nq, d), dq_all.view(M * B, Nq, d), dKV[a, 0].view(M * B, Ns, d),
-                       dKV[a, 1].view(M * B, Ns, d), delta_c, None), drop=rec["dr_ca"], drop_bmod=B, **mb)
-            ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cl]
-            gq = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-            dxn = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-            L.gemm(M=R, N=d, K=d, A=[dq_all[m] for m in range(M)], B=[w[:d] for w in ws], Cs=[dxn] + [None] * (M - 1),
-                   C2=[gq] + [None] * (M - 1), aux=[dxr] + [None] * (M - 1), act_grad="add", ct=ct, lda=d, ldb=d, ldc=d,
-                   transB=True, kconcat=M)
-            dqpos_parts.append(gq)
-            dwq.add([dq_all[m] for m in range(M)], [x_in] * M, [qpos] * M,
-                    [G(ca.multihead_attn.in_proj_weight)[:d] for ca in cl], ct,
-                    [G(ca.multihead_attn.in_proj_bias)[:d] for ca in cl])
-            dx = dxn
-            # ---------------- mask-head call that preceded this layer
-            if spec.mh is not None and not spec.skip_pred:
-                dx = mh_backward(rec, dcls[a], dmlog[a], dx)
-            # ---------------- per-layer gradient buckets (data parallel, SURVEY 8e: "bucketed per decoder layer in reverse
-            # execution order"): the first-block application of layer i is the LAST to run backward, so every gradient of
-            # layer i's parameters -- its queued weight-gradient products, the K/V rows of its in_proj weights (from the
-            # dK / dV of all its applications) and its spatial-bias projection -- is complete once they are flushed here;
-            # ready(i) lets the owner start that bucket's all-reduce while the earlier layers still run backward
-            if per_layer and a < Ln:
-                kv_terms(range(i, n_app, Ln), into_queue=True)
-                dwq.flush()
-                flush_spatial()
-                ready(i)
-
-        # ---- hoisted K/V projection backward (sum over all applications)
-        need_feat = [ctx.needs_input_grad[11 + u] for u in range(U)]
-        dfeats: List[Optional[torch.Tensor]] = [None] * U
-        single = U == M and all(src[i][j] == j for i in range(Ln) for j in range(M)) and mh_src[:M] == list(range(M))[:len(mh_src)]
-        Akv, Bkv = kv_terms(range(n_app), into_queue=not per_layer)
-        # ---- every parameter gradient of the decoder (+ mask head) is complete after this flush: in a data-parallel step
-        # its all-reduce starts HERE (enc.grads_ready, set by the step owner) and overlaps the key/value input-gradient
-        # products below and the encoders' backward that autograd runs after this function returns
-        dkm_list = {}
-        if dk_terms:
-            Mm_, nc = spec.mh_count, len(dk_terms)
-            newk = torch.empty(Mm_, B, Ns, d, dtype=torch.float32, device=dev)
-            L.gemm(M=Ns, N=d, K=Nq, A=[t_[0] for m in range(Mm_) for t_ in dk_terms],
-                   B=[t_[1][m] for m in range(Mm_) for t_ in dk_terms],
-                   Cs=[c_ for m in range(Mm_) for c_ in [newk[m]] + [None] * (nc - 1)],
-                   aux=[c_ for m in range(Mm_) for c_ in [dkeys[m]] + [None] * (nc - 1)] if dkeys is not None else None,
-                   act_grad="add" if dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
-                   strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d, kconcat=nc)
-            dkeys, dk_terms = newk, []
-        if dkeys is not None:
-            for j in range(spec.mh_count):
-                mp = list(spec.mh.mask_pred_list)[j]
-                dkm_list[j] = ops.scale_rows(dkeys[j], Rk, ad, keep_mask=ctx.mh_valid[j])
-                dwq.add([dkm_list[j]], [ctx.mh_feats[j]], None, [G(mp.k_proj.weight)], ct)
-        dwq.flush()
-        flush_spatial()
-        ready("decoder")   # every parameter gradient of the decoder (+ mask head) is final
-        # bf16 path: the input-gradient products read TRANSPOSED bf16 copies of the K/V weights (one copy launch from the
-        # forward's pre-cast rows), which turns them into plain NT products -- the 128x128-tile kernel's layout -- and the
-        # memories then share launches (K-concatenation per memory, several outputs per launch)
-        tposed = ctx.wkv is not None and dKV.dtype == torch.bfloat16
-        if tposed:
-            wkvT = ctx.wkvT if ctx.wkvT is not None else \
-                ctx.wkv.view(Ln, M, 2, d, d).transpose(-1, -2).contiguous()       # [l, m, t][k_in][n_out]
-            Bkv = [wkvT[tape[a]["i"], j, t] for a in range(n_app) for j in range(M) for t in (0, 1)]
-            kT = None
-            if dkeys is not None:
-                kT = torch.stack([mp.k_proj.weight.detach() for mp in list(spec.mh.mask_pred_list)[:spec.mh_count]]) \
-                    .transpose(1, 2).contiguous().to(ad)
-        # d source_u = sum over the (application, memory) pairs that read it of (dK Wk + dV Wv) [+ mask-head key path]
-        jobs = []
-        for u in range(U):
-            if not need_feat[u]:
-                continue
-            pairs = [(a, j) for a in range(n_app) for j in range(M) if src[tape[a]["i"]][j] == u]
-            Aj = [Akv[2 * (a * M + j) + t] for a, j in pairs for t in (0, 1)]
-            Bj = [Bkv[2 * (a * M + j) + t] for a, j in pairs for t in (0, 1)]
-            for j in range(spec.mh_count if dkeys is not None else 0):
-                if mh_src[j] != u:
-                    continue
-                mp = list(spec.mh.mask_pred_list)[j]
-                Aj.append(dkm_list[j])
-                Bj.append(kT[j] if tposed else mp.k_proj.weight.detach())
-            jobs.append((u, Aj, Bj))
-        per = len(jobs[0][1]) if jobs else 0
-        want_dpos = pos is not None and ctx.needs_input_grad[4]
-        dqpos_done = None
-        dpos = None
-        nk, nv = n_app, n_app + (1 if dkeys is not None else 0)
-        if single and tposed and want_dpos and len(jobs) == M and nk * M <= MAXG and nv * M <= MAXG and \
-                (dkeys is None or spec.mh_count == M):
-            # the position embedding enters every memory's KEY input, so d pos = sum_m (K part of d feat_m): form the K
-            # parts once (one launch, M outputs), add them into the V parts through the "+ aux" epilogue (second launch)
-            # and sum them for d pos -- instead of a third product over all (layer, memory) key terms
-            Kp = torch.empty(M, B, Ns, d, dtype=torch.float32, device=dev)
-            L.gemm(M=Rk, N=d, K=d, A=[jb[1][2 * a] for jb in jobs for a in range(n_app)],
-                   B=[jb[2][2 * a] for jb in jobs for a in range(n_app)],
-                   Cs=[c_ for j in range(M) for c_ in [Kp[j]] + [None] * (nk - 1)], ct=ct, lda=d, ldb=d, ldc=d, kconcat=nk)
-            outs = [torch.empty(B, Ns, d, dtype=torch.float32, device=dev) for _ in range(M)]
-            vA = [[jb[1][2 * a + 1] for a in range(n_app)] + jb[1][2 * n_app:] for jb in jobs]
-            vB = [[jb[2][2 * a + 1] for a in range(n_app)] + jb[2][2 * n_app:] for jb in jobs]
-            L.gemm(M=Rk, N=d, K=d, A=[t_ for l_ in vA for t_ in l_], B=[t_ for l_ in vB for t_ in l_],
-                   Cs=[c_ for o_ in outs for c_ in [o_] + [None] * (nv - 1)],
-                   aux=[c_ for j in range(M) for c_ in [Kp[j]] + [None] * (nv - 1)], act_grad="add", ct=ct, lda=d, ldb=d,
-                   ldc=d, kconcat=nv)
-            for jb, o_ in zip(jobs, outs):
-                dfeats[jb[0]] = o_
-            if ctx.needs_input_grad[2] and len(dqpos_parts) > 1:   # d query_pos and d pos: one launch, adjacent outputs
-                dqpos_done, dpos = ops.sum_pair(dqpos_parts, [Kp[j] for j in range(M)])
-            else:
-                dpos = ops.sum_n([Kp[j] for j in range(M)])
-            want_dpos = False
-        elif tposed and jobs and 0 < per <= MAXG and all(len(jb[1]) == per for jb in jobs):
-            cap = max(1, MAXG // per)   # memories per launch
-            for c0 in range(0, len(jobs), cap):
-                chunk = jobs[c0:c0 + cap]
-                outs = [torch.empty(B, Ns, d, dtype=torch.float32, device=dev) for _ in chunk]
-                L.gemm(M=Rk, N=d, K=d, A=[t_ for jb in chunk for t_ in jb[1]], B=[t_ for jb in chunk for t_ in jb[2]],
-                       Cs=[c_ for o_ in outs for c_ in [o_] + [None] * (per - 1)], ct=ct, lda=d, ldb=d, ldc=d,
-                       kconcat=per)
-                for jb, o_ in zip(chunk, outs):
-                    dfeats[jb[0]] = o_
-        else:
-            for j, Aj, Bj in jobs:
-                out = None
-                if not Aj:   # a source no layer reads (e.g. a surplus scale): zero gradient
-                    out = torch.zeros(B, Ns, d, dtype=torch.float32, device=dev)
-                for s in range(0, len(Aj), MAXG):
-                    nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
-                    n = len(Aj[s:s + MAXG])
-                    L.gemm(M=Rk, N=d, K=d, A=Aj[s:s + MAXG], B=Bj[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
-                           aux=([out] + [None] * (n - 1)) if out is not None else None,
-                           act_grad="add" if out is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=not tposed,
-                           kconcat=n)
-                    out = nxt
-                dfeats[j] = out
-        if want_dpos:
-            Ak, Bk = Akv[0::2], Bkv[0::2]
-            for s in range(0, len(Ak), MAXG):
-                nxt = torch.empty(B, Ns, d, dtype=torch.float32, device=dev)
-                n = len(Ak[s:s + MAXG])
-                L.gemm(M=Rk, N=d, K=d, A=Ak[s:s + MAXG], B=Bk[s:s + MAXG], Cs=[nxt] + [None] * (n - 1),
-                       aux=([dpos] + [None] * (n - 1)) if dpos is not None else None,
-                       act_grad="add" if dpos is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=not tposed,
-                       kconcat=n)
-                dpos = nxt
-        dqpos = dqpos_done
-        if ctx.needs_input_grad[2] and dqpos is None:
-            dqpos = ops.sum_n(dqpos_parts)
-        dx0 = dx if ctx.needs_input_grad[1] else None
-        dprompt = None
-        if spec.prompt and ctx.needs_input_grad[9]:
-            # d prompt = sum over layer applications of dK_p Wk + dV_p Wv: one K-concatenated launch
-            Ap, Bp = [], []
-            for a_ in range(n_app):
-                w = ctx.pcas[tape[a_]["i"]].multihead_attn.in_proj_weight.detach()
-                Ap += [dPKV[a_, 0], dPKV[a_, 1]]
-                Bp += [w[d:2 * d], w[2 * d:]]
-            T = ctx.prompt.shape[1]
-            for s_ in range(0, len(Ap), MAXG):
-                nxt = torch.empty(B, T, d, dtype=torch.float32, device=dev)
-                n = len(Ap[s_:s_ + MAXG])
-                L.gemm(M=B * T, N=d, K=d, A=Ap[s_:s_ + MAXG], B=Bp[s_:s_ + MAXG], Cs=[nxt] + [None] * (n - 1),
-                       aux=([dprompt] + [None] * (n - 1)) if dprompt is not None else None,
-                       act_grad="add" if dprompt is not None else None, ct=ct, lda=d, ldb=d, ldc=d, transB=True, kconcat=n)
-                dprompt = nxt
-        pgrads = [gv[id(p)] if (p.requires_grad and not accumulate) else None for p in params]
-        return (None, dx0, dqpos, None, dpos, None, None, None, None, dprompt, None, *dfeats, *([None] * M), *pgrads)
+        return _DecoderBackward(ctx, dxf, dheads).run()
 
 
 def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_match=None, seg_masks=None,
