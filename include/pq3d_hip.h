@@ -360,6 +360,46 @@ int pq3d_add_ln_fwd(const pq3d_ln_desc* d, void* stream);
 int pq3d_add_ln_bwd(const pq3d_ln_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The row-local tail of a decoder layer's forward in ONE launch (bf16 mode's split-bf16 query side, ReLU, no dropout):
+ *     f = o_s Wo^T + bo;  x2 = LN1(x1s + f);  h = relu(x2 W1^T + b1);  zp_k = h_k W2_k^T (+ b2, k = 0; K split in 4);
+ *     z = ((zp_0 + zp_1) + zp_2) + zp_3;  x3 = LN2(x2 + z)
+ * = self-attention out-projection + post-norm and FFNLayer (query_encoder.py:224-225, 384-388), bit for bit what
+ * pq3d_gemm / pq3d_add_ln_fwd produce in five launches.  A group of 8 workgroups on one XCD owns a 32-row tile for all
+ * five steps and hands rows over through that XCD's L2 (csrc/chain_ffn.hip).  R <= 1024 rows, d = 256, F = 2048.
+ * flags: >= ceil(R / 32) * 128 uint32 words, zeroed ONCE when allocated, never touched by the caller afterwards, not
+ * shared between call sites that can be in flight together.  err (optional): set to 1 if a hand-off wait gave up.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t R, d, F;
+  float eps1, eps2;
+  const float* o_s;             /* [R, d] self-attention output */
+  const float* Wo;              /* [d, d] */
+  const float* bo;              /* [d] */
+  const float* x1s;             /* [R, d] residual of the first LayerNorm */
+  const float* g1;
+  const float* be1;
+  float* f;                     /* [R, d] out: out-projection (saved for the backward) */
+  float* x2;                    /* [R, d] out */
+  float* mean1;                 /* [R] out */
+  float* rstd1;                 /* [R] out */
+  const float* W1;              /* [F, d] */
+  const float* b1;              /* [F] */
+  float* h;                     /* [R, F] out */
+  const float* W2;              /* [d, F] */
+  const float* b2;              /* [d] */
+  float* zp;                    /* [4, R, d] out: partial sums of linear2 */
+  float* z;                     /* [R, d] out: their sum */
+  const float* g2;
+  const float* be2;
+  float* x3;                    /* [R, d] out */
+  float* mean2;                 /* [R] out */
+  float* rstd2;                 /* [R] out */
+  uint32_t* flags;
+  int32_t* err;
+} pq3d_chain_ffn_desc;
+int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Small memory-bound kernels.
  * ------------------------------------------------------------------------------------------------ */
 /* out[n] = sum_r x[r*ld + n]  (bias gradients). */

@@ -156,6 +156,12 @@ class LnDesc(C.Structure):
     ]
 
 
+class ChainFfnDesc(C.Structure):
+    _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32), ("eps1", C.c_float), ("eps2", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("o_s", "Wo", "bo", "x1s", "g1", "be1", "f", "x2", "mean1", "rstd1", "W1", "b1", "h", "W2",
+                                          "b2", "zp", "z", "g2", "be2", "x3", "mean2", "rstd2", "flags", "err")]
+
+
 _lib = None
 
 _SIGS = {
@@ -165,6 +171,7 @@ _SIGS = {
     "pq3d_attn_bwd": [C.POINTER(AttnDesc), C.c_void_p],
     "pq3d_gemm_tt_multi": [C.POINTER(TtProblem), C.c_int32, C.c_void_p],
     "pq3d_gemm_tt_multi_wide": [C.c_int32],
+    "pq3d_chain_ffn_fwd": [C.POINTER(ChainFfnDesc), C.c_void_p],
     "pq3d_mask_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_attn_resident": [C.c_int],

@@ -1,0 +1,431 @@
+// One launch for the row-local tail of a decoder layer's forward (reference: QueryEncoderLayer's self-attention output
+// projection + post-norm, then FFNLayer -- query_encoder.py:224-225, 384-388):
+//     f  = o_s Wo^T + bo                x2 = LN1(x1s + f)
+//     h  = relu(x2 W1^T + b1)           zp_k = h[:, k-th quarter] W2[:, k-th quarter]^T (+ b2 for k = 0)
+//     z  = ((zp_0 + zp_1) + zp_2) + zp_3        x3 = LN2(x2 + z)
+// Until round 5 these were five dependent launches (gemm_wk, add_ln_fwd, gemm_wk, gemm_wk, add_ln_fwd: 41.6 us per layer at
+// config 2, 4.7 us of launch-to-launch floor each).  Every step is ROW-LOCAL: a 32-row tile never needs another tile's rows.
+// So a group of 8 workgroups owns a row tile for all five steps, and the group sits on ONE XCD (workgroup id % 8 is the XCD):
+// its members hand rows to each other through the XCD's L2 -- stores (write-through L1), s_waitcnt vmcnt(0), one flag word
+// per member, L1-bypassing (sc1) loads on the consumer side -- at 1.9 us per hand-off (tools/probes/xcd_barrier_probe.hip:
+// 0 stale reads in 1000 rounds x 256 workgroups; an agent-scope acquire fence instead of sc1 loads costs 9 us, a release
+// with L2 write-back is only needed ACROSS XCDs).  No cross-XCD traffic, no atomics.
+//
+// Arithmetic is the five kernels' own, instruction for instruction: split-bf16 products (hi/lo planes, MFMA order lo*hi, hi*lo,
+// hi*hi per 32-wide k-step, k ascending, one accumulator per output), bias added to the accumulator, ReLU, two-pass LayerNorm
+// statistics with the same wave reductions, the four partial sums of linear2 added in index order -- tests/test_gpu_chain.py
+// compares every output bit for bit with the five-launch path.
+// Residency: at most 32 workgroups per XCD (one per CU: 110 KB of LDS each), all resident at once; a hand-off wait that
+// runs out of patience sets *err and goes on (wrong numbers, never a hung GPU).
+#include <atomic>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CT = 512;                     // threads per workgroup (8 waves)
+constexpr int TM = 32, TN = 64, KC = 256;   // tile rows / columns, k elements staged at once (= gemm_wk's 32 x 64 x 256 plan)
+constexpr int LDR = KC + 8, CLD = TN + 4;
+constexpr int G = 8;                        // workgroups per row tile
+constexpr int D = 256;                      // model width (LayerNorm rows: 4 values per lane)
+// steps 3 / 4 (the FFN products): a member owns 256 (linear1) / 128 (linear2) output columns of its row tile, every wave
+// 4 / 2 independent 16 x 16 accumulators, the weights staged in k slabs of 64 / 128 (one 16-dword RawB load each)
+constexpr int K3 = 64, LD3 = K3 + 8, N3 = 256;      // linear1: [256 columns][64 k] slab, x2 staged whole ([32][264])
+constexpr int K4 = 128, LD4 = K4 + 8, N4 = 128;     // linear2: [128 columns][128 k] slab + [32][128 k] slab of h
+constexpr int CL3 = N3 + 4, CL4 = N4 + 4;
+constexpr size_t LDS_S1 = (size_t)2 * (TM + TN) * LDR * 2 + (size_t)TM * CLD * 4;
+constexpr size_t LDS_S3 = (size_t)2 * TM * LDR * 2 + (size_t)2 * N3 * LD3 * 2 + (size_t)TM * CL3 * 4;
+constexpr size_t LDS_S4 = (size_t)2 * TM * LD4 * 2 + (size_t)2 * N4 * LD4 * 2 + (size_t)TM * CL4 * 4;
+constexpr size_t CHAIN_LDS = LDS_S3 > LDS_S1 ? (LDS_S3 > LDS_S4 ? LDS_S3 : LDS_S4) : (LDS_S1 > LDS_S4 ? LDS_S1 : LDS_S4);
+static_assert(CHAIN_LDS <= 160 * 1024, "LDS");
+constexpr int SPIN_LIMIT = 1 << 20;
+
+typedef __attribute__((address_space(3))) unsigned char lds_b_t;
+
+struct Ctx {
+  bf16_t *Ah, *Al, *Bh, *Bl;
+  float* Ct;
+  int tid, lane, wave, li, lg, wm, wn;
+};
+
+PQ_DEV void split_hi_lo(const float* v, u32x4& hi, u32x4& lo) {
+  hi = pack_frag<bf16_t>(v);
+  float w[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    w[2 * j] = v[2 * j] - __uint_as_float(hi[j] << 16);
+    w[2 * j + 1] = v[2 * j + 1] - __uint_as_float(hi[j] & 0xffff0000u);
+  }
+  lo = pack_frag<bf16_t>(w);
+}
+
+// 8 consecutive floats; SC1: L1-bypassing (data written by another CU of this XCD during this launch)
+template <bool SC1> PQ_DEV void load8(const float* base, long off, float (&v)[8]) {
+  if constexpr (SC1) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, 16);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4) + 16, 0, 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = __uint_as_float(a[j]); v[4 + j] = __uint_as_float(b[j]); }
+  } else {
+    const float4 a = *(const float4*)(base + off), b = *(const float4*)(base + off + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+template <bool SC1> PQ_DEV void load4(const float* base, long off, float (&v)[4]) {
+  if constexpr (SC1) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(a[j]);
+  } else {
+    const float4 a = *(const float4*)(base + off);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  }
+}
+
+// ---- operand staging: [rows][256 k] fp32 -> hi / lo bf16 planes in LDS (gemm_wk's put())
+struct RawA { float v[2][8]; };   // 32 rows x 32 chunks = 1024 chunks / 512 threads
+struct RawB { float v[4][8]; };   // 64 rows x 32 chunks = 2048 chunks
+template <bool SC1> PQ_DEV void issue_a(const Ctx& c, RawA& r, const float* A, int lda, int m0, int R, int k0) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = c.tid + i * CT, row = ch >> 5, k = k0 + (ch & 31) * 8;
+    load8<SC1>(A, (long)min(m0 + row, R - 1) * lda + k, r.v[i]);
+  }
+}
+PQ_DEV void put_a(const Ctx& c, const RawA& r) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = c.tid + i * CT, o = (ch >> 5) * LDR + (ch & 31) * 8;
+    u32x4 hi, lo;
+    split_hi_lo(r.v[i], hi, lo);
+    *(u32x4*)&c.Ah[o] = hi;
+    *(u32x4*)&c.Al[o] = lo;
+  }
+}
+PQ_DEV void issue_b(const Ctx& c, RawB& r, const float* W, int ldb, int n0, int k0) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = c.tid + i * CT, row = ch >> 5, k = k0 + (ch & 31) * 8;
+    load8<false>(W, (long)(n0 + row) * ldb + k, r.v[i]);
+  }
+}
+PQ_DEV void put_b(const Ctx& c, const RawB& r) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = c.tid + i * CT, o = (ch >> 5) * LDR + (ch & 31) * 8;
+    u32x4 hi, lo;
+    split_hi_lo(r.v[i], hi, lo);
+    *(u32x4*)&c.Bh[o] = hi;
+    *(u32x4*)&c.Bl[o] = lo;
+  }
+}
+// 8 k-steps of one staged chunk into this wave's 16 x 16 accumulator (gemm_wk's loop at NJ = 1)
+PQ_DEV void mma_chunk(const Ctx& c, f32x4& acc) {
+#pragma unroll
+  for (int ks = 0; ks < KC / 32; ++ks) {
+    const int oa = (c.wm + c.li) * LDR + ks * 32 + c.lg * 8, ob = (c.wn + c.li) * LDR + ks * 32 + c.lg * 8;
+    const u32x4 ah = *(const u32x4*)&c.Ah[oa], al = *(const u32x4*)&c.Al[oa];
+    const u32x4 bh = *(const u32x4*)&c.Bh[ob], bl = *(const u32x4*)&c.Bl[ob];
+    Mma<bf16_t>::mma(acc, al, bh);
+    Mma<bf16_t>::mma(acc, ah, bl);
+    Mma<bf16_t>::mma(acc, ah, bh);
+  }
+}
+// (acc + bias) [relu] -> C, rows leave in 16-byte pieces through the transposed LDS tile (gemm_wk's epilogue at alpha = 1)
+PQ_DEV void store_tile(const Ctx& c, const f32x4& acc, const float* bias, int n0, bool relu, float* C, int ldc, int m0, int R) {
+  const float bcol = bias ? bias[n0 + c.wn + c.li] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c.Ct[(c.wm + c.lg * 4 + r) * CLD + c.wn + c.li] = (acc[r] + bcol) * 1.f;
+  __syncthreads();
+  const int lrow = c.tid >> 4, lcol = (c.tid & 15) * 4, row = m0 + lrow;
+  float4 t = *(const float4*)&c.Ct[lrow * CLD + lcol];
+  if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+  if (row < R) *(float4*)(C + (long)row * ldc + n0 + lcol) = t;
+  __syncthreads();   // the next tile reuses Ct (and the B planes)
+}
+
+// ---- hand-off inside the group: publish `target`, wait until every member has
+PQ_DEV void handoff(const Ctx& c, unsigned* mine, unsigned* group, unsigned target, int* err) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through L1: acknowledged stores are in the XCD's L2
+  __syncthreads();
+  if (c.wave == 0) {
+    if (c.lane == 0) __hip_atomic_store(mine, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+    int spins = 0;
+    do {
+      const unsigned v = c.lane < G ? __hip_atomic_load(group + c.lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+      ok = (int)(v - target) >= 0;
+    } while (!__all((int)ok) && ++spins < SPIN_LIMIT);
+    if (!__all((int)ok) && c.lane == 0 && err) *err = 1;
+  }
+  __syncthreads();
+}
+
+// ---- LayerNorm rows (norm.hip's add_ln_fwd at d = 256: lane owns columns 4 lane .. 4 lane + 3)
+struct RowStats { float mean, rstd; };
+PQ_DEV RowStats row_stats4(const float (&v)[4], float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s += v[j];
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float t = v[j] - mean; q += t * t; }
+  const float var = wave_sum(q) / (float)D;
+  return {mean, 1.f / sqrtf(var + eps)};
+}
+// y = LN(x + (o_0 + ... + o_{nsum-1})); the sum is kept in osum when given
+template <bool SC1X>
+PQ_DEV void ln_row(const Ctx& c, long row, const float* x, const float* const* o, int nsum, long ostride, const float* gamma,
+                   const float* beta, float eps, float* osum, float* y, float* mean, float* rstd) {
+  const long base = row * D + c.lane * 4;
+  float xr[4], ov[4], v[4], gm[4], bt[4], out[4];
+  load4<SC1X>(x, base, xr);
+  load4<true>(o[0], base, ov);
+  for (int p = 1; p < nsum; ++p) {
+    float t[4];
+    load4<true>(o[0] + p * ostride, base, t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ov[j] += t[j];
+  }
+  if (osum) *(float4*)(osum + base) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = xr[j] + ov[j];
+  const RowStats st = row_stats4(v, eps);
+  load4<false>(gamma, c.lane * 4, gm);
+  load4<false>(beta, c.lane * 4, bt);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { out[j] = 0.f; out[j] += 1.f * ((v[j] - st.mean) * st.rstd * gm[j] + bt[j]); }
+  if (c.lane == 0) { mean[row] = st.mean; rstd[row] = st.rstd; }
+  *(float4*)(y + base) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// in-kernel timeline (probe builds only, tools/probes/chain_timeline.py): thread 0 of workgroup 0 stamps the 100 MHz clock
+#ifdef PQ3D_CHAIN_TL
+#define CH_TL(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) ((long long*)d.err)[i] = wall_clock64(); } while (0)
+#else
+#define CH_TL(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
+  Ctx c;
+  c.Ah = (bf16_t*)ch_smem;
+  c.Al = c.Ah + TM * LDR;
+  c.Bh = c.Al + TM * LDR;
+  c.Bl = c.Bh + TN * LDR;
+  c.Ct = (float*)(c.Bl + TN * LDR);
+  c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.li = c.lane & 15; c.lg = c.lane >> 4;
+  c.wm = (c.wave >> 2) * 16; c.wn = (c.wave & 3) * 16;
+  // group = row tile; its 8 members share id % 8 (= the XCD)
+  const int id = (int)blockIdx.x, xcd = id & 7, q = id >> 3, slot = q >> 3, j = q & 7;
+  const int rt = slot * 8 + xcd, m0 = rt * TM;
+  const int R = d.R, F = d.F;
+  if (m0 >= R) return;
+  unsigned* const group = d.flags + (long)rt * G * 16;
+  unsigned* const mine = group + j * 16;
+  const unsigned v0 = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // equal for the whole group at launch
+
+  CH_TL(0);
+  // Weights do not depend on the chain: the eight slabs a member needs (4 k slabs of its 256 W1 rows, 4 of its 128 W2 rows)
+  // are requested ahead of their use through a ring of three register sets -- the first three before anything else, so they
+  // travel under the out-projection, the first LayerNorm and two hand-offs.
+  const int Fq = F / 4;
+  const int kq = j >> 1, nh = (j & 1) * N4;      // step 4: this member's quarter of linear2's reduction, its half of the columns
+  RawB ring[3];
+  auto issue_w = [&](int l, RawB& r) {            // load l of this member's weight sequence: 2048 (l < 4) / 2048 chunks of 8 floats
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = c.tid + i * CT;
+      if (l < 4) load8<false>(d.W1, (long)(j * N3 + (ch >> 3)) * D + l * K3 + (ch & 7) * 8, r.v[i]);
+      else load8<false>(d.W2, (long)(nh + (ch >> 4)) * F + kq * Fq + (l - 4) * K4 + (ch & 15) * 8, r.v[i]);
+    }
+  };
+  // ---- 1. out-projection: members 0..3 take the four 64-column tiles
+  {
+    RawA ra; RawB rbo;
+    if (j < 4) {
+      issue_a<false>(c, ra, d.o_s, D, m0, R, 0);
+      issue_b(c, rbo, d.Wo, D, j * TN, 0);
+    }
+    issue_w(0, ring[0]); issue_w(1, ring[1]); issue_w(2, ring[2]);
+    if (j < 4) {
+      put_a(c, ra); put_b(c, rbo);
+      __syncthreads();
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mma_chunk(c, acc);
+      store_tile(c, acc, d.bo, j * TN, false, d.f, D, m0, R);
+    }
+  }
+  CH_TL(1);
+  handoff(c, mine, group, v0 + 1, d.err);
+  CH_TL(2);
+  // ---- 2. x2 = LN1(x1s + f): 32 rows over 8 members x 4 waves
+  const long lrow = m0 + 4 * j + c.wave;
+  {
+    const float* o1[1] = {d.f};
+    if (c.wave < 4 && lrow < R) ln_row<false>(c, lrow, d.x1s, o1, 1, 0, d.g1, d.be1, d.eps1, nullptr, d.x2, d.mean1, d.rstd1);
+  }
+  CH_TL(3);
+  handoff(c, mine, group, v0 + 2, d.err);
+  CH_TL(4);
+  const int wr = (c.wave >> 2) * 16;              // steps 3 / 4: this wave's 16 rows
+  // ---- 3. h = relu(x2 W1^T + b1): member j owns columns [256 j, 256 j + 256); wave = 16 rows x 64 columns (4 accumulators)
+  {
+    bf16_t* const Bh3 = c.Al + TM * LDR;          // [256][LD3] x 2 planes behind the whole-K planes of x2
+    bf16_t* const Bl3 = Bh3 + N3 * LD3;
+    float* const Ct3 = (float*)(Bl3 + N3 * LD3);  // [32][CL3]
+    const int wc = (c.wave & 3) * 64;
+    RawA ra;
+    issue_a<true>(c, ra, d.x2, D, m0, R, 0);
+    put_a(c, ra);
+    f32x4 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l > 0) __syncthreads();                 // the previous slab's fragment reads are done
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = c.tid + i * CT, o = (ch >> 3) * LD3 + (ch & 7) * 8;
+        u32x4 hi, lo;
+        split_hi_lo(ring[l % 3].v[i], hi, lo);
+        *(u32x4*)&Bh3[o] = hi;
+        *(u32x4*)&Bl3[o] = lo;
+      }
+      __syncthreads();
+      issue_w(l + 3, ring[l % 3]);                // three loads ahead (runs into W2's slabs)
+#pragma unroll
+      for (int ks = 0; ks < K3 / 32; ++ks) {
+        const int oa = (wr + c.li) * LDR + l * K3 + ks * 32 + c.lg * 8;
+        const u32x4 ah = *(const u32x4*)&c.Ah[oa], al = *(const u32x4*)&c.Al[oa];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int ob = (wc + nb * 16 + c.li) * LD3 + ks * 32 + c.lg * 8;
+          const u32x4 bh = *(const u32x4*)&Bh3[ob], bl = *(const u32x4*)&Bl3[ob];
+          Mma<bf16_t>::mma(acc[nb], al, bh);
+          Mma<bf16_t>::mma(acc[nb], ah, bl);
+          Mma<bf16_t>::mma(acc[nb], ah, bh);
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const float bcol = d.b1[j * N3 + wc + nb * 16 + c.li];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ct3[(wr + c.lg * 4 + r) * CL3 + wc + nb * 16 + c.li] = (acc[nb][r] + bcol) * 1.f;
+    }
+    __syncthreads();
+    const int orow = c.tid >> 4, row = m0 + orow;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int col = qd * 64 + (c.tid & 15) * 4;
+      float4 t = *(const float4*)&Ct3[orow * CL3 + col];
+      t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+      if (row < R) *(float4*)(d.h + (long)row * F + j * N3 + col) = t;
+    }
+  }
+  CH_TL(5);
+  handoff(c, mine, group, v0 + 3, d.err);
+  CH_TL(6);
+  // ---- 4. zp_k = h[:, quarter k] W2[:, quarter k]^T (+ b2 at k = 0): member j owns quarter j / 2 and columns [128 (j & 1), + 128);
+  // wave = 16 rows x 32 columns (2 accumulators), k slabs of 128
+  {
+    bf16_t* const Ah4 = (bf16_t*)ch_smem;         // [32][LD4] x 2 planes
+    bf16_t* const Al4 = Ah4 + TM * LD4;
+    bf16_t* const Bh4 = Al4 + TM * LD4;           // [128][LD4] x 2 planes
+    bf16_t* const Bl4 = Bh4 + N4 * LD4;
+    float* const Ct4 = (float*)(Bl4 + N4 * LD4);  // [32][CL4]
+    const int wc = (c.wave & 3) * 32;
+    float av[8];
+    auto issue_h = [&](int l) {                   // [32 rows][128 k] of h: 512 chunks, one per thread
+      load8<true>(d.h, (long)min(m0 + (c.tid >> 4), R - 1) * F + kq * Fq + l * K4 + (c.tid & 15) * 8, av);
+    };
+    issue_h(0);
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                              // step 3's reads of the LDS this step overlays are done
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l > 0) __syncthreads();
+      {
+        u32x4 hi, lo;
+        split_hi_lo(av, hi, lo);
+        const int o = (c.tid >> 4) * LD4 + (c.tid & 15) * 8;
+        *(u32x4*)&Ah4[o] = hi;
+        *(u32x4*)&Al4[o] = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = c.tid + i * CT, o = (ch >> 4) * LD4 + (ch & 15) * 8;
+        u32x4 hi, lo;
+        split_hi_lo(ring[(4 + l) % 3].v[i], hi, lo);
+        *(u32x4*)&Bh4[o] = hi;
+        *(u32x4*)&Bl4[o] = lo;
+      }
+      __syncthreads();
+      if (l + 1 < 4) issue_h(l + 1);
+      if (4 + l + 3 < 8) issue_w(4 + l + 3, ring[(4 + l) % 3]);
+#pragma unroll
+      for (int ks = 0; ks < K4 / 32; ++ks) {
+        const int oa = (wr + c.li) * LD4 + ks * 32 + c.lg * 8;
+        const u32x4 ah = *(const u32x4*)&Ah4[oa], al = *(const u32x4*)&Al4[oa];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int ob = (wc + nb * 16 + c.li) * LD4 + ks * 32 + c.lg * 8;
+          const u32x4 bh = *(const u32x4*)&Bh4[ob], bl = *(const u32x4*)&Bl4[ob];
+          Mma<bf16_t>::mma(acc[nb], al, bh);
+          Mma<bf16_t>::mma(acc[nb], ah, bl);
+          Mma<bf16_t>::mma(acc[nb], ah, bh);
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float bcol = kq == 0 ? d.b2[nh + wc + nb * 16 + c.li] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ct4[(wr + c.lg * 4 + r) * CL4 + wc + nb * 16 + c.li] = (acc[nb][r] + bcol) * 1.f;
+    }
+    __syncthreads();
+    const int orow = c.tid >> 4, row = m0 + orow;
+    float* const zq = d.zp + (long)kq * R * D;
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd) {
+      const int col = qd * 64 + (c.tid & 15) * 4;
+      const float4 t = *(const float4*)&Ct4[orow * CL4 + col];
+      if (row < R) *(float4*)(zq + (long)row * D + nh + col) = t;
+    }
+  }
+  CH_TL(7);
+  handoff(c, mine, group, v0 + 4, d.err);
+  CH_TL(8);
+  // ---- 5. z = sum of the partials, x3 = LN2(x2 + z)
+  {
+    const float* o2[1] = {d.zp};
+    if (c.wave < 4 && lrow < R) ln_row<true>(c, lrow, d.x2, o2, 4, (long)R * D, d.g2, d.be2, d.eps2, d.z, d.x3, d.mean2, d.rstd2);
+  }
+  CH_TL(9);
+}
+
+}  // namespace
+
+extern "C" int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, dp ? dp->o_s : nullptr);
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_chain_ffn_fwd: null descriptor");
+  const pq3d_chain_ffn_desc d = *dp;
+  PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.F == 2048, "pq3d_chain_ffn_fwd: d = 256, F = 2048");
+  const int row_tiles = (d.R + TM - 1) / TM, slots = (row_tiles + 7) / 8;
+  PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_ffn_fwd: more than 1024 rows (the groups would not all be resident)");
+  PQ_CHECK_ARG(d.o_s && d.Wo && d.bo && d.x1s && d.g1 && d.be1 && d.f && d.x2 && d.mean1 && d.rstd1 && d.W1 && d.b1 && d.h && d.W2 && d.b2 &&
+               d.zp && d.z && d.g2 && d.be2 && d.x3 && d.mean2 && d.rstd2 && d.flags, "pq3d_chain_ffn_fwd: null pointer");
+  const void* al[] = {d.o_s, d.Wo, d.x1s, d.g1, d.be1, d.f, d.x2, d.W1, d.h, d.W2, d.zp, d.z, d.g2, d.be2, d.x3};
+  for (const void* p : al) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_chain_ffn_fwd: operands must be 16-byte aligned");
+  PQ_CHECK_ARG((long)d.R * d.F * 4 < 0x7ffffff0L, "pq3d_chain_ffn_fwd: hidden activations too large");
+  static std::atomic<unsigned> done{0};
+  if (int e = pq3d_enable_big_lds(chain_ffn_fwd_kernel, (int)CHAIN_LDS, done)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
+  hipLaunchKernelGGL(chain_ffn_fwd_kernel, dim3((unsigned)(8 * G * slots)), dim3(CT), CHAIN_LDS, (hipStream_t)stream, d);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

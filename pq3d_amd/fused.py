@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -84,6 +85,16 @@ def _dw_acc(gs, xs, x2s, outs, ct, bias_outs=None):
                colsum=bias_outs[i:i + MAXG] if fusable else None)
     if bias_outs is not None and not fusable:
         _colsum_acc(gs, bias_outs, R)
+
+
+# one-launch row-local chain (csrc/chain_ffn.hip) for the forward's out-projection + LayerNorm + FFN + LayerNorm; PQ3D_CHAIN=0 or
+# fused.set_chain(False) keeps the five launches (same bits: A/B measurements, tests)
+_CHAIN = os.environ.get("PQ3D_CHAIN", "1") != "0"
+
+
+def set_chain(on: bool) -> None:
+    global _CHAIN
+    _CHAIN = bool(on)
 
 
 class _DwQueue:
@@ -1042,33 +1053,50 @@ class _FusedDecoder(Function):
                 o_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 lse_s = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
                 _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ops.sa_ct(ct), False, kpm=qmask, bias=sbias, drop=dr_sa)
-                f = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=d, A=[o_s], B=[Wo], bias=[bo], Cs=[f], ct=cq, lda=d, ldb=d, ldc=d)
-                x2, mean_s, rstd_s = _ln_fwd(x1s, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
-                                             drop=dr_sr)
-                rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
-                # -- FFN: 3 launches
                 ffn = layer.ffn
                 F_ = ffn.linear1.out_features
-                h = torch.empty(B, Nq, F_, dtype=ops.act_dtype(cq), device=dev)
-                pre = torch.empty_like(h) if spec.act == "gelu" else None
-                L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
-                       C2=[pre], ct=cq, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi)
-                # linear2 has K = F = 2048 on only M/64 x d/64 = 52 tiles: a long serial k-loop on a fifth of the chip.  Its K
-                # range is split over KS groups of ONE grouped launch (no atomics: each group owns an output), and the
-                # LayerNorm kernel adds the partial sums (+ residual, + dropout of the summed branch) in a fixed order --
-                # deterministic, so the bit-exact padding-invariance / scene-independence properties hold.
-                KS = 4 if F_ % (4 * 64) == 0 else 1
-                zp = torch.empty(KS, B, Nq, d, dtype=torch.float32, device=dev)
-                Fk = F_ // KS
-                hv, w2 = h.view(R, F_), ffn.linear2.weight.detach()
-                L.gemm(M=R, N=d, K=Fk, A=[hv[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
-                       B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
-                       bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=cq, lda=F_,
-                       ldb=F_, ldc=d)
-                z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)   # sum of the partials, kept for the backward
-                x3, mean_f, rstd_f = _ln_fwd(x2, [zp[k] for k in range(KS)], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()],
-                                             ffn.norm.eps, None, Nq, drop=dr_fr, sum_branches=True, osum=z)
+                chain = _CHAIN and cq == L.BF16X3 and spec.act == "relu" and dr_sr is None and dr_fi is None and dr_fr is None and \
+                    ops.chain_ffn_ok(R, d, F_) and sa.norm.weight.shape[0] == d
+                if chain:
+                    # the row-local tail of the layer in ONE launch (csrc/chain_ffn.hip: out-projection, post-norm, FFN, post-norm;
+                    # 8 workgroups per 32-row tile handing rows over inside one XCD) -- the five launches' bits
+                    flags = getattr(enc, "_chain_flags", None)
+                    if flags is None or flags.device != dev or flags.numel() < ((R + 31) // 32) * 128:
+                        flags = enc._chain_flags = ops.chain_flags(max(R, 1024), dev)
+                    f, x2, mean_s, rstd_s, h, _zp, z, x3, mean_f, rstd_f = ops.chain_ffn_fwd(
+                        o_s, Wo, bo, x1s, sa.norm.weight.detach(), sa.norm.bias.detach(), sa.norm.eps,
+                        ffn.linear1.weight.detach(), ffn.linear1.bias.detach(), ffn.linear2.weight.detach(), ffn.linear2.bias.detach(),
+                        ffn.norm.weight.detach(), ffn.norm.bias.detach(), ffn.norm.eps, flags)
+                    pre = None
+                    rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
+                else:
+                    f = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+                    L.gemm(M=R, N=d, K=d, A=[o_s], B=[Wo], bias=[bo], Cs=[f], ct=cq, lda=d, ldb=d, ldc=d)
+                    x2, mean_s, rstd_s = _ln_fwd(x1s, [f], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
+                                                 drop=dr_sr)
+                    rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
+                    # -- FFN: 3 launches
+                    ffn = layer.ffn
+                    F_ = ffn.linear1.out_features
+                    h = torch.empty(B, Nq, F_, dtype=ops.act_dtype(cq), device=dev)
+                    pre = torch.empty_like(h) if spec.act == "gelu" else None
+                    L.gemm(M=R, N=F_, K=d, A=[x2], B=[ffn.linear1.weight.detach()], bias=[ffn.linear1.bias.detach()], Cs=[h],
+                           C2=[pre], ct=cq, lda=d, ldb=d, ldc=F_, act=spec.act, drop=dr_fi)
+                    # linear2 has K = F = 2048 on only M/64 x d/64 = 52 tiles: a long serial k-loop on a fifth of the chip.  Its K
+                    # range is split over KS groups of ONE grouped launch (no atomics: each group owns an output), and the
+                    # LayerNorm kernel adds the partial sums (+ residual, + dropout of the summed branch) in a fixed order --
+                    # deterministic, so the bit-exact padding-invariance / scene-independence properties hold.
+                    KS = 4 if F_ % (4 * 64) == 0 else 1
+                    zp = torch.empty(KS, B, Nq, d, dtype=torch.float32, device=dev)
+                    Fk = F_ // KS
+                    hv, w2 = h.view(R, F_), ffn.linear2.weight.detach()
+                    L.gemm(M=R, N=d, K=Fk, A=[hv[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
+                           B=[w2[:, k * Fk:(k + 1) * Fk] for k in range(KS)],
+                           bias=[ffn.linear2.bias.detach()] + [None] * (KS - 1), Cs=[zp[k] for k in range(KS)], ct=cq, lda=F_,
+                           ldb=F_, ldc=d)
+                    z = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)   # sum of the partials, kept for the backward
+                    x3, mean_f, rstd_f = _ln_fwd(x2, [zp[k] for k in range(KS)], [ffn.norm.weight.detach()], [ffn.norm.bias.detach()],
+                                                 ffn.norm.eps, None, Nq, drop=dr_fr, sum_branches=True, osum=z)
                 rec.update(h=h, pre=pre, z=z, mean_f=mean_f, rstd_f=rstd_f)
                 tape.append(rec)
                 x = x3

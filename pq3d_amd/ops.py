@@ -1620,3 +1620,50 @@ def t5_prep(rel, labels, buckets, enc_valid, start_id: int, pad_id: int, H: int)
 def embedding(table, ids, drop: Optional[L.Drop] = None):
     """table[ids] (nn.Embedding), optionally with the dropout of site ``drop`` over the [ids.numel(), d] rows fused in."""
     return _Embedding.apply(table, ids, drop if (drop is not None and drop.p > 0.0) else None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Row-local chain of a decoder layer's forward in one launch (csrc/chain_ffn.hip): self-attention out-projection + post-norm
+# + FFN + post-norm.  Same bits as the five launches it replaces (tests/test_gpu_chain.py).
+def chain_flags(R: int, device) -> torch.Tensor:
+    """Hand-off words of one call site (zeroed once; the kernel keeps them consistent from launch to launch)."""
+    return torch.zeros(((R + 31) // 32) * 8 * 16, dtype=torch.int32, device=device)
+
+
+_CHAIN_ERR = {}
+
+
+def chain_ffn_ok(R: int, d: int, F_: int) -> bool:
+    return d == 256 and F_ == 2048 and 1 <= R <= 1024
+
+
+def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2, flags):
+    """Returns (f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2); every tensor fp32, rows = o_s.numel() // 256."""
+    d = o_s.shape[-1]
+    R, F_ = o_s.numel() // d, W1.shape[0]
+    dev = o_s.device
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    f, x2, x3, z = e(o_s.shape), e(o_s.shape), e(o_s.shape), e(o_s.shape)
+    h, zp = e(*o_s.shape[:-1], F_), e(4, *o_s.shape)
+    mean1, rstd1, mean2, rstd2 = e(1, R), e(1, R), e(1, R), e(1, R)
+    err = _CHAIN_ERR.get(dev)
+    if err is None:
+        err = _CHAIN_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    c = L.ChainFfnDesc()
+    c.R, c.d, c.F, c.eps1, c.eps2 = R, d, F_, eps1, eps2
+    for n, t in (("o_s", o_s), ("Wo", Wo), ("bo", bo), ("x1s", x1s), ("g1", g1), ("be1", be1), ("f", f), ("x2", x2), ("mean1", mean1),
+                 ("rstd1", rstd1), ("W1", W1), ("b1", b1), ("h", h), ("W2", W2), ("b2", b2), ("zp", zp), ("z", z), ("g2", g2),
+                 ("be2", be2), ("x3", x3), ("mean2", mean2), ("rstd2", rstd2), ("flags", flags), ("err", err)):
+        assert t.is_contiguous() and (n in ("flags", "err") or t.dtype == torch.float32), n
+        setattr(c, n, L.ptr(t))
+    from .profiler import timed
+    fl = 2.0 * R * d * (d + 2 * F_)
+    nb = 4.0 * (R * d * 9 + 2 * R * F_ + d * d + 2 * d * F_)
+    L.check(timed("pq3d_chain_ffn_fwd", f"R{R}d{d}F{F_}", fl, nb, L.lib().pq3d_chain_ffn_fwd, C.byref(c), L.stream()), "pq3d_chain_ffn_fwd")
+    return f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2
+
+
+def chain_error(device) -> bool:
+    """True if a hand-off wait of any chain launch on `device` gave up (synchronises)."""
+    err = _CHAIN_ERR.get(device)
+    return bool(err is not None and int(err.item()) != 0)

@@ -50,6 +50,8 @@ int main(void) {
          offsetof(pq3d_attn_desc, dbias));
   printf("%zu %zu %zu %zu\n", sizeof(pq3d_ln_desc), offsetof(pq3d_ln_desc, eps), offsetof(pq3d_ln_desc, x),
          offsetof(pq3d_ln_desc, dbeta));
+  printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_ffn_desc), offsetof(pq3d_chain_ffn_desc, eps2), offsetof(pq3d_chain_ffn_desc, o_s),
+         offsetof(pq3d_chain_ffn_desc, err));
   return 0;
 }''')
     exe = tmp_path / "layout"
@@ -59,6 +61,8 @@ int main(void) {
     assert rows[0] == [ctypes.sizeof(G), G.alpha.offset, G.A.offset, G.mask_out.offset]
     assert rows[1] == [ctypes.sizeof(A), A.scale.offset, A.q.offset, A.dbias.offset]
     assert rows[2] == [ctypes.sizeof(Ln), Ln.eps.offset, Ln.x.offset, Ln.dbeta.offset]
+    Ch = _lib.ChainFfnDesc
+    assert rows[3] == [ctypes.sizeof(Ch), Ch.eps2.offset, Ch.o_s.offset, Ch.err.offset]
 
 
 def test_argument_errors_are_reported(lib):
