@@ -365,7 +365,7 @@ int pq3d_add_ln_bwd(const pq3d_ln_desc* d, void* stream);
  *     z = ((zp_0 + zp_1) + zp_2) + zp_3;  x3 = LN2(x2 + z)
  * = self-attention out-projection + post-norm and FFNLayer (query_encoder.py:224-225, 384-388), bit for bit what
  * pq3d_gemm / pq3d_add_ln_fwd produce in five launches.  A group of 8 workgroups on one XCD owns a 32-row tile for all
- * five steps and hands rows over through that XCD's L2 (csrc/chain_ffn.hip).  R <= 1024 rows, d = 256, F = 2048.
+ * five steps and hands rows over through that XCD's L2 (csrc/chain_ffn.hip).  R <= 2048 rows, d = 256, F = 2048.
  * flags: >= ceil(R / 32) * 128 uint32 words, zeroed ONCE when allocated, never touched by the caller afterwards, not
  * shared between call sites that can be in flight together.  err (optional): set to 1 if a hand-off wait gave up.
  * ------------------------------------------------------------------------------------------------ */

@@ -33,11 +33,17 @@ constexpr int D = 256;                      // model width (LayerNorm rows: 4 va
 constexpr int K3 = 64, LD3 = K3 + 8, N3 = 256;      // linear1: [256 columns][64 k] slab, x2 staged whole ([32][264])
 constexpr int K4 = 128, LD4 = K4 + 8, N4 = 128;     // linear2: [128 columns][128 k] slab + [32][128 k] slab of h
 constexpr int CL3 = N3 + 4, CL4 = N4 + 4;
-constexpr size_t LDS_S1 = (size_t)2 * (TM + TN) * LDR * 2 + (size_t)TM * CLD * 4;
-constexpr size_t LDS_S3 = (size_t)2 * TM * LDR * 2 + (size_t)2 * N3 * LD3 * 2 + (size_t)TM * CL3 * 4;
-constexpr size_t LDS_S4 = (size_t)2 * TM * LD4 * 2 + (size_t)2 * N4 * LD4 * 2 + (size_t)TM * CL4 * 4;
-constexpr size_t CHAIN_LDS = LDS_S3 > LDS_S1 ? (LDS_S3 > LDS_S4 ? LDS_S3 : LDS_S4) : (LDS_S1 > LDS_S4 ? LDS_S1 : LDS_S4);
-static_assert(CHAIN_LDS <= 160 * 1024, "LDS");
+// LDS (bytes) of the widest step at NRT row tiles per group: x2 planes of all row tiles + one W1 slab (the fp32 output tile
+// overlays the slab once its last fragments are read)
+constexpr size_t chain_lds(int nrt) {
+  const size_t s1 = (size_t)2 * (TM + TN) * LDR * 2 + (size_t)TM * CLD * 4;
+  const size_t s3a = (size_t)2 * N3 * LD3 * 2, s3c = (size_t)TM * CL3 * 4;
+  const size_t s3 = (size_t)nrt * 2 * TM * LDR * 2 + (s3a > s3c ? s3a : s3c);
+  const size_t s4b = (size_t)2 * N4 * LD4 * 2, s4c = (size_t)TM * CL4 * 4;
+  const size_t s4 = (size_t)nrt * 2 * TM * LD4 * 2 + (s4b > s4c ? s4b : s4c);
+  return s1 > s3 ? (s1 > s4 ? s1 : s4) : (s3 > s4 ? s3 : s4);
+}
+static_assert(chain_lds(2) <= 160 * 1024, "LDS");
 constexpr int SPIN_LIMIT = 1 << 20;
 
 typedef __attribute__((address_space(3))) unsigned char lds_b_t;
@@ -209,6 +215,8 @@ PQ_DEV void ln_row(const Ctx& c, long row, const float* x, const float* const* o
 #define CH_TL(i) do { } while (0)
 #endif
 
+// NRT: 32-row tiles per group (1: up to 1024 rows; 2: up to 2048 -- a member converts each weight slab once for both tiles)
+template <int NRT>
 __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_desc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
   Ctx c;
@@ -219,12 +227,13 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
   c.Ct = (float*)(c.Bl + TN * LDR);
   c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.li = c.lane & 15; c.lg = c.lane >> 4;
   c.wm = (c.wave >> 2) * 16; c.wn = (c.wave & 3) * 16;
-  // group = row tile; its 8 members share id % 8 (= the XCD)
+  // group = NRT consecutive row tiles; its 8 members share id % 8 (= the XCD)
+  constexpr int GR = TM * NRT;                    // rows per group
   const int id = (int)blockIdx.x, xcd = id & 7, q = id >> 3, slot = q >> 3, j = q & 7;
-  const int rt = slot * 8 + xcd, m0 = rt * TM;
+  const int grp = slot * 8 + xcd, m0 = grp * GR;
   const int R = d.R, F = d.F;
   if (m0 >= R) return;
-  unsigned* const group = d.flags + (long)rt * G * 16;
+  unsigned* const group = d.flags + (long)grp * G * 16;
   unsigned* const mine = group + j * 16;
   const unsigned v0 = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // equal for the whole group at launch
 
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
   const int Fq = F / 4;
   const int kq = j >> 1, nh = (j & 1) * N4;      // step 4: this member's quarter of linear2's reduction, its half of the columns
   RawB ring[3];
-  auto issue_w = [&](int l, RawB& r) {            // load l of this member's weight sequence: 2048 (l < 4) / 2048 chunks of 8 floats
+  auto issue_w = [&](int l, RawB& r) {            // load l of this member's weight sequence: 2048 chunks of 8 floats each
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ch = c.tid + i * CT;
@@ -243,47 +252,63 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
       else load8<false>(d.W2, (long)(nh + (ch >> 4)) * F + kq * Fq + (l - 4) * K4 + (ch & 15) * 8, r.v[i]);
     }
   };
-  // ---- 1. out-projection: members 0..3 take the four 64-column tiles
+  // ---- 1. out-projection: 4 NRT (row tile, 64-column tile) units, one per member
   {
     RawA ra; RawB rbo;
-    if (j < 4) {
-      issue_a<false>(c, ra, d.o_s, D, m0, R, 0);
-      issue_b(c, rbo, d.Wo, D, j * TN, 0);
+    const bool on = j < 4 * NRT && m0 + (j >> 2) * TM < R;
+    const int mt = m0 + (j >> 2) * TM;
+    if (on) {
+      issue_a<false>(c, ra, d.o_s, D, mt, R, 0);
+      issue_b(c, rbo, d.Wo, D, (j & 3) * TN, 0);
     }
     issue_w(0, ring[0]); issue_w(1, ring[1]); issue_w(2, ring[2]);
-    if (j < 4) {
+    if (on) {
       put_a(c, ra); put_b(c, rbo);
       __syncthreads();
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       mma_chunk(c, acc);
-      store_tile(c, acc, d.bo, j * TN, false, d.f, D, m0, R);
+      store_tile(c, acc, d.bo, (j & 3) * TN, false, d.f, D, mt, R);
     }
   }
   CH_TL(1);
   handoff(c, mine, group, v0 + 1, d.err);
   CH_TL(2);
-  // ---- 2. x2 = LN1(x1s + f): 32 rows over 8 members x 4 waves
-  const long lrow = m0 + 4 * j + c.wave;
+  // ---- 2. x2 = LN1(x1s + f): 32 NRT rows over 8 members x 4 NRT waves
+  const long lrow = m0 + 4 * NRT * j + c.wave;
+  const bool lnw = c.wave < 4 * NRT && lrow < R;
   {
     const float* o1[1] = {d.f};
-    if (c.wave < 4 && lrow < R) ln_row<false>(c, lrow, d.x1s, o1, 1, 0, d.g1, d.be1, d.eps1, nullptr, d.x2, d.mean1, d.rstd1);
+    if (lnw) ln_row<false>(c, lrow, d.x1s, o1, 1, 0, d.g1, d.be1, d.eps1, nullptr, d.x2, d.mean1, d.rstd1);
   }
   CH_TL(3);
   handoff(c, mine, group, v0 + 2, d.err);
   CH_TL(4);
-  const int wr = (c.wave >> 2) * 16;              // steps 3 / 4: this wave's 16 rows
-  // ---- 3. h = relu(x2 W1^T + b1): member j owns columns [256 j, 256 j + 256); wave = 16 rows x 64 columns (4 accumulators)
+  const int wr = (c.wave >> 2) * 16;              // steps 3 / 4: this wave's 16 rows of every row tile
+  // ---- 3. h = relu(x2 W1^T + b1): member j owns columns [256 j, 256 j + 256); wave = 16 rows x 64 columns per row tile
   {
-    bf16_t* const Bh3 = c.Al + TM * LDR;          // [256][LD3] x 2 planes behind the whole-K planes of x2
+    bf16_t* const Ah3 = (bf16_t*)ch_smem;         // [NRT][2 planes][32][LDR]: x2, whole K
+    bf16_t* const Bh3 = Ah3 + NRT * 2 * TM * LDR; // [256][LD3] x 2 planes: one k slab of W1
     bf16_t* const Bl3 = Bh3 + N3 * LD3;
-    float* const Ct3 = (float*)(Bl3 + N3 * LD3);  // [32][CL3]
+    float* const Ct3 = (float*)Bh3;               // [32][CL3], over the slab once it is dead
     const int wc = (c.wave & 3) * 64;
-    RawA ra;
-    issue_a<true>(c, ra, d.x2, D, m0, R, 0);
-    put_a(c, ra);
-    f32x4 acc[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NRT; ++t) {
+      RawA ra;
+      issue_a<true>(c, ra, d.x2, D, m0 + t * TM, R, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = c.tid + i * CT, o = (ch >> 5) * LDR + (ch & 31) * 8;
+        u32x4 hi, lo;
+        split_hi_lo(ra.v[i], hi, lo);
+        *(u32x4*)&Ah3[(t * 2) * TM * LDR + o] = hi;
+        *(u32x4*)&Ah3[(t * 2 + 1) * TM * LDR + o] = lo;
+      }
+    }
+    f32x4 acc[NRT][4];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[t][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       if (l > 0) __syncthreads();                 // the previous slab's fragment reads are done
@@ -299,63 +324,79 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
       issue_w(l + 3, ring[l % 3]);                // three loads ahead (runs into W2's slabs)
 #pragma unroll
       for (int ks = 0; ks < K3 / 32; ++ks) {
-        const int oa = (wr + c.li) * LDR + l * K3 + ks * 32 + c.lg * 8;
-        const u32x4 ah = *(const u32x4*)&c.Ah[oa], al = *(const u32x4*)&c.Al[oa];
+        u32x4 bh[4], bl[4];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           const int ob = (wc + nb * 16 + c.li) * LD3 + ks * 32 + c.lg * 8;
-          const u32x4 bh = *(const u32x4*)&Bh3[ob], bl = *(const u32x4*)&Bl3[ob];
-          Mma<bf16_t>::mma(acc[nb], al, bh);
-          Mma<bf16_t>::mma(acc[nb], ah, bl);
-          Mma<bf16_t>::mma(acc[nb], ah, bh);
+          bh[nb] = *(const u32x4*)&Bh3[ob];
+          bl[nb] = *(const u32x4*)&Bl3[ob];
+        }
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+          const int oa = (wr + c.li) * LDR + l * K3 + ks * 32 + c.lg * 8;
+          const u32x4 ah = *(const u32x4*)&Ah3[(t * 2) * TM * LDR + oa], al = *(const u32x4*)&Ah3[(t * 2 + 1) * TM * LDR + oa];
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            Mma<bf16_t>::mma(acc[t][nb], al, bh[nb]);
+            Mma<bf16_t>::mma(acc[t][nb], ah, bl[nb]);
+            Mma<bf16_t>::mma(acc[t][nb], ah, bh[nb]);
+          }
         }
       }
     }
+    float bcol[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const float bcol = d.b1[j * N3 + wc + nb * 16 + c.li];
+    for (int nb = 0; nb < 4; ++nb) bcol[nb] = d.b1[j * N3 + wc + nb * 16 + c.li];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Ct3[(wr + c.lg * 4 + r) * CL3 + wc + nb * 16 + c.li] = (acc[nb][r] + bcol) * 1.f;
-    }
-    __syncthreads();
-    const int orow = c.tid >> 4, row = m0 + orow;
+    for (int t = 0; t < NRT; ++t) {
+      __syncthreads();                            // the slab's last reads / the previous row tile's output reads are done
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-      const int col = qd * 64 + (c.tid & 15) * 4;
-      float4 t = *(const float4*)&Ct3[orow * CL3 + col];
-      t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
-      if (row < R) *(float4*)(d.h + (long)row * F + j * N3 + col) = t;
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct3[(wr + c.lg * 4 + r) * CL3 + wc + nb * 16 + c.li] = (acc[t][nb][r] + bcol[nb]) * 1.f;
+      __syncthreads();
+      const int orow = c.tid >> 4, row = m0 + t * TM + orow;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int col = qd * 64 + (c.tid & 15) * 4;
+        float4 v = *(const float4*)&Ct3[orow * CL3 + col];
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (row < R) *(float4*)(d.h + (long)row * F + j * N3 + col) = v;
+      }
     }
   }
   CH_TL(5);
   handoff(c, mine, group, v0 + 3, d.err);
   CH_TL(6);
   // ---- 4. zp_k = h[:, quarter k] W2[:, quarter k]^T (+ b2 at k = 0): member j owns quarter j / 2 and columns [128 (j & 1), + 128);
-  // wave = 16 rows x 32 columns (2 accumulators), k slabs of 128
+  // wave = 16 rows x 32 columns per row tile (2 accumulators), k slabs of 128
   {
-    bf16_t* const Ah4 = (bf16_t*)ch_smem;         // [32][LD4] x 2 planes
-    bf16_t* const Al4 = Ah4 + TM * LD4;
-    bf16_t* const Bh4 = Al4 + TM * LD4;           // [128][LD4] x 2 planes
+    bf16_t* const Ah4 = (bf16_t*)ch_smem;         // [NRT][2 planes][32][LD4]: one k slab of h
+    bf16_t* const Bh4 = Ah4 + NRT * 2 * TM * LD4; // [128][LD4] x 2 planes: one k slab of W2
     bf16_t* const Bl4 = Bh4 + N4 * LD4;
-    float* const Ct4 = (float*)(Bl4 + N4 * LD4);  // [32][CL4]
+    float* const Ct4 = (float*)Bh4;               // [32][CL4], over the slab once it is dead
     const int wc = (c.wave & 3) * 32;
-    float av[8];
-    auto issue_h = [&](int l) {                   // [32 rows][128 k] of h: 512 chunks, one per thread
-      load8<true>(d.h, (long)min(m0 + (c.tid >> 4), R - 1) * F + kq * Fq + l * K4 + (c.tid & 15) * 8, av);
+    float av[NRT][8];
+    auto issue_h = [&](int l) {                   // [32 NRT rows][128 k] of h: 512 NRT chunks, NRT per thread
+#pragma unroll
+      for (int t = 0; t < NRT; ++t)
+        load8<true>(d.h, (long)min(m0 + t * TM + (c.tid >> 4), R - 1) * F + kq * Fq + l * K4 + (c.tid & 15) * 8, av[t]);
     };
     issue_h(0);
-    f32x4 acc[2];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NRT][2];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     __syncthreads();                              // step 3's reads of the LDS this step overlays are done
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       if (l > 0) __syncthreads();
-      {
+#pragma unroll
+      for (int t = 0; t < NRT; ++t) {
         u32x4 hi, lo;
-        split_hi_lo(av, hi, lo);
+        split_hi_lo(av[t], hi, lo);
         const int o = (c.tid >> 4) * LD4 + (c.tid & 15) * 8;
-        *(u32x4*)&Ah4[o] = hi;
-        *(u32x4*)&Al4[o] = lo;
+        *(u32x4*)&Ah4[(t * 2) * TM * LD4 + o] = hi;
+        *(u32x4*)&Ah4[(t * 2 + 1) * TM * LD4 + o] = lo;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -370,32 +411,45 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
       if (4 + l + 3 < 8) issue_w(4 + l + 3, ring[(4 + l) % 3]);
 #pragma unroll
       for (int ks = 0; ks < K4 / 32; ++ks) {
-        const int oa = (wr + c.li) * LD4 + ks * 32 + c.lg * 8;
-        const u32x4 ah = *(const u32x4*)&Ah4[oa], al = *(const u32x4*)&Al4[oa];
+        u32x4 bh[2], bl[2];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
           const int ob = (wc + nb * 16 + c.li) * LD4 + ks * 32 + c.lg * 8;
-          const u32x4 bh = *(const u32x4*)&Bh4[ob], bl = *(const u32x4*)&Bl4[ob];
-          Mma<bf16_t>::mma(acc[nb], al, bh);
-          Mma<bf16_t>::mma(acc[nb], ah, bl);
-          Mma<bf16_t>::mma(acc[nb], ah, bh);
+          bh[nb] = *(const u32x4*)&Bh4[ob];
+          bl[nb] = *(const u32x4*)&Bl4[ob];
+        }
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+          const int oa = (wr + c.li) * LD4 + ks * 32 + c.lg * 8;
+          const u32x4 ah = *(const u32x4*)&Ah4[(t * 2) * TM * LD4 + oa], al = *(const u32x4*)&Ah4[(t * 2 + 1) * TM * LD4 + oa];
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            Mma<bf16_t>::mma(acc[t][nb], al, bh[nb]);
+            Mma<bf16_t>::mma(acc[t][nb], ah, bl[nb]);
+            Mma<bf16_t>::mma(acc[t][nb], ah, bh[nb]);
+          }
         }
       }
     }
+    float bcol[2];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const float bcol = kq == 0 ? d.b2[nh + wc + nb * 16 + c.li] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ct4[(wr + c.lg * 4 + r) * CL4 + wc + nb * 16 + c.li] = (acc[nb][r] + bcol) * 1.f;
-    }
-    __syncthreads();
-    const int orow = c.tid >> 4, row = m0 + orow;
+    for (int nb = 0; nb < 2; ++nb) bcol[nb] = kq == 0 ? d.b2[nh + wc + nb * 16 + c.li] : 0.f;
     float* const zq = d.zp + (long)kq * R * D;
 #pragma unroll
-    for (int qd = 0; qd < 2; ++qd) {
-      const int col = qd * 64 + (c.tid & 15) * 4;
-      const float4 t = *(const float4*)&Ct4[orow * CL4 + col];
-      if (row < R) *(float4*)(zq + (long)row * D + nh + col) = t;
+    for (int t = 0; t < NRT; ++t) {
+      __syncthreads();
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct4[(wr + c.lg * 4 + r) * CL4 + wc + nb * 16 + c.li] = (acc[t][nb][r] + bcol[nb]) * 1.f;
+      __syncthreads();
+      const int orow = c.tid >> 4, row = m0 + t * TM + orow;
+#pragma unroll
+      for (int qd = 0; qd < 2; ++qd) {
+        const int col = qd * 64 + (c.tid & 15) * 4;
+        const float4 v = *(const float4*)&Ct4[orow * CL4 + col];
+        if (row < R) *(float4*)(zq + (long)row * D + nh + col) = v;
+      }
     }
   }
   CH_TL(7);
@@ -404,7 +458,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
   // ---- 5. z = sum of the partials, x3 = LN2(x2 + z)
   {
     const float* o2[1] = {d.zp};
-    if (c.wave < 4 && lrow < R) ln_row<true>(c, lrow, d.x2, o2, 4, (long)R * D, d.g2, d.be2, d.eps2, d.z, d.x3, d.mean2, d.rstd2);
+    if (lnw) ln_row<true>(c, lrow, d.x2, o2, 4, (long)R * D, d.g2, d.be2, d.eps2, d.z, d.x3, d.mean2, d.rstd2);
   }
   CH_TL(9);
 }
@@ -416,16 +470,24 @@ extern "C" int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* dp, void* stream) {
   PQ_CHECK_ARG(dp != nullptr, "pq3d_chain_ffn_fwd: null descriptor");
   const pq3d_chain_ffn_desc d = *dp;
   PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.F == 2048, "pq3d_chain_ffn_fwd: d = 256, F = 2048");
-  const int row_tiles = (d.R + TM - 1) / TM, slots = (row_tiles + 7) / 8;
-  PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_ffn_fwd: more than 1024 rows (the groups would not all be resident)");
+  const int row_tiles = (d.R + TM - 1) / TM;
+  const int nrt = row_tiles * G <= 256 ? 1 : 2;   // all groups resident: 8 workgroups per group, one per CU
+  const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
+  PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_ffn_fwd: more than 2048 rows (the groups would not all be resident)");
   PQ_CHECK_ARG(d.o_s && d.Wo && d.bo && d.x1s && d.g1 && d.be1 && d.f && d.x2 && d.mean1 && d.rstd1 && d.W1 && d.b1 && d.h && d.W2 && d.b2 &&
                d.zp && d.z && d.g2 && d.be2 && d.x3 && d.mean2 && d.rstd2 && d.flags, "pq3d_chain_ffn_fwd: null pointer");
   const void* al[] = {d.o_s, d.Wo, d.x1s, d.g1, d.be1, d.f, d.x2, d.W1, d.h, d.W2, d.zp, d.z, d.g2, d.be2, d.x3};
   for (const void* p : al) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_chain_ffn_fwd: operands must be 16-byte aligned");
   PQ_CHECK_ARG((long)d.R * d.F * 4 < 0x7ffffff0L, "pq3d_chain_ffn_fwd: hidden activations too large");
-  static std::atomic<unsigned> done{0};
-  if (int e = pq3d_enable_big_lds(chain_ffn_fwd_kernel, (int)CHAIN_LDS, done)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
-  hipLaunchKernelGGL(chain_ffn_fwd_kernel, dim3((unsigned)(8 * G * slots)), dim3(CT), CHAIN_LDS, (hipStream_t)stream, d);
+  static std::atomic<unsigned> done1{0}, done2{0};
+  const dim3 grid((unsigned)(8 * G * slots));
+  if (nrt == 1) {
+    if (int e = pq3d_enable_big_lds(chain_ffn_fwd_kernel<1>, (int)chain_lds(1), done1)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
+    hipLaunchKernelGGL(chain_ffn_fwd_kernel<1>, grid, dim3(CT), chain_lds(1), (hipStream_t)stream, d);
+  } else {
+    if (int e = pq3d_enable_big_lds(chain_ffn_fwd_kernel<2>, (int)chain_lds(2), done2)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
+    hipLaunchKernelGGL(chain_ffn_fwd_kernel<2>, grid, dim3(CT), chain_lds(2), (hipStream_t)stream, d);
+  }
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -1062,7 +1062,7 @@ class _FusedDecoder(Function):
                     # 8 workgroups per 32-row tile handing rows over inside one XCD) -- the five launches' bits
                     flags = getattr(enc, "_chain_flags", None)
                     if flags is None or flags.device != dev or flags.numel() < ((R + 31) // 32) * 128:
-                        flags = enc._chain_flags = ops.chain_flags(max(R, 1024), dev)
+                        flags = enc._chain_flags = ops.chain_flags(max(R, 2048), dev)
                     f, x2, mean_s, rstd_s, h, _zp, z, x3, mean_f, rstd_f = ops.chain_ffn_fwd(
                         o_s, Wo, bo, x1s, sa.norm.weight.detach(), sa.norm.bias.detach(), sa.norm.eps,
                         ffn.linear1.weight.detach(), ffn.linear1.bias.detach(), ffn.linear2.weight.detach(), ffn.linear2.bias.detach(),

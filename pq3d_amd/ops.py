@@ -1627,14 +1627,14 @@ def embedding(table, ids, drop: Optional[L.Drop] = None):
 # + FFN + post-norm.  Same bits as the five launches it replaces (tests/test_gpu_chain.py).
 def chain_flags(R: int, device) -> torch.Tensor:
     """Hand-off words of one call site (zeroed once; the kernel keeps them consistent from launch to launch)."""
-    return torch.zeros(((R + 31) // 32) * 8 * 16, dtype=torch.int32, device=device)
+    return torch.zeros(max((R + 31) // 32, 64) * 8 * 16, dtype=torch.int32, device=device)
 
 
 _CHAIN_ERR = {}
 
 
 def chain_ffn_ok(R: int, d: int, F_: int) -> bool:
-    return d == 256 and F_ == 2048 and 1 <= R <= 1024
+    return d == 256 and F_ == 2048 and 1 <= R <= 2048
 
 
 def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2, flags):

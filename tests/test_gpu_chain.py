@@ -28,7 +28,7 @@ def _five_launches(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps
     return f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2
 
 
-@pytest.mark.parametrize("B,Nq,F_", [(8, 100, 2048), (4, 200, 2048), (3, 37, 2048), (1, 1, 2048), (10, 100, 2048)])
+@pytest.mark.parametrize("B,Nq,F_", [(8, 100, 2048), (4, 200, 2048), (3, 37, 2048), (1, 1, 2048), (10, 100, 2048), (16, 100, 2048), (9, 200, 2048), (1, 2048, 2048), (1, 1025, 2048)])
 def test_chain_equals_five_launches(B, Nq, F_):
     from pq3d_amd import ops
     dev = torch.device("cuda")
@@ -51,7 +51,7 @@ def test_chain_equals_five_launches(B, Nq, F_):
 
 def test_chain_refuses_what_it_cannot_hold():
     from pq3d_amd import _lib as L, ops
-    assert not ops.chain_ffn_ok(1025, 256, 2048) and not ops.chain_ffn_ok(800, 512, 2048) and ops.chain_ffn_ok(800, 256, 2048) and not ops.chain_ffn_ok(800, 256, 1024)
+    assert not ops.chain_ffn_ok(2049, 256, 2048) and not ops.chain_ffn_ok(800, 512, 2048) and ops.chain_ffn_ok(800, 256, 2048) and not ops.chain_ffn_ok(800, 256, 1024)
     c = L.ChainFfnDesc()
-    c.R, c.d, c.F = 2000, 256, 2048
+    c.R, c.d, c.F = 4000, 256, 2048
     assert L.lib().pq3d_chain_ffn_fwd(L.C.byref(c), None) == -1

@@ -8,7 +8,7 @@ from pq3d_amd import ops
 from test_gpu_chain import _five_launches
 
 dev = torch.device("cuda")
-for B, Nq in ((8, 100), (4, 200)):
+for B, Nq in ((8, 100), (16, 100)):
     g = torch.Generator().manual_seed(0)
     r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
     d, F_ = 256, 2048
