@@ -396,8 +396,43 @@ typedef struct {
   float* rstd2;                 /* [R] out */
   uint32_t* flags;
   int32_t* err;
+  /* optional sixth step: the NEXT layer application's cross-attention query projections q_m = (x3 + qpos) Wq_m^T + bq_m, m < nq <= 3
+   * (split-bf16, bf16 output: what pq3d_gemm writes for it) -- one launch less per layer; nq = 0: none */
+  int32_t nq;
+  const float* qpos;            /* [R, d] */
+  const float* Wq[3];           /* [d, d] */
+  const float* bq[3];
+  void* qout[3];                /* [R, d] bf16 out */
 } pq3d_chain_ffn_desc;
 int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* d, void* stream);
+
+/* The row-local steps between a layer's cross-attention and its self-attention in ONE launch (csrc/chain_ca.hip; bf16 mode, no
+ * residual dropout): op_m = o_m Wo_m^T + bo_m (m < M <= 3, o_m bf16), x1 = sum_m c_m LN_m(x + op_m) (c_m = coef[m][row /
+ * rows_per_scene] or 1 / M), q = (x1 + qpos) Wq^T + bq, k = (x1 + qpos) Wk^T + bk, v = x1 Wv^T + bv -- bit for bit what pq3d_gemm,
+ * pq3d_add_ln_fwd, pq3d_gemm produce (CrossAttentionLayer out_proj + post-norm, query_encoder.py:145-152, 304-305; self-attention
+ * projections, transformers.py:190-193).  R <= 2048 rows, d = 256.  flags / err: as for pq3d_chain_ffn_fwd (own words per site). */
+typedef struct {
+  int32_t R, d, M, rows_per_scene;
+  float eps;
+  const void* o[3];             /* [R, d] bf16 attention outputs */
+  const float* Wo[3];           /* [d, d] */
+  const float* bo[3];
+  const float* x;               /* [R, d] residual */
+  const float* gamma[3];
+  const float* beta[3];
+  const float* coef;            /* [M, R / rows_per_scene] or NULL */
+  float* op[3];                 /* [R, d] out */
+  float* x1;                    /* [R, d] out */
+  float* mean;                  /* [M, R] out */
+  float* rstd;                  /* [M, R] out */
+  const float* qpos;            /* [R, d] */
+  const float* Wqkv[3];         /* [d, d] each: q, k, v */
+  const float* bqkv[3];
+  float* qkv[3];                /* [R, d] out each */
+  uint32_t* flags;
+  int32_t* err;
+} pq3d_chain_ca_desc;
+int pq3d_chain_ca_fwd(const pq3d_chain_ca_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Small memory-bound kernels.

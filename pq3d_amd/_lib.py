@@ -159,7 +159,16 @@ class LnDesc(C.Structure):
 class ChainFfnDesc(C.Structure):
     _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32), ("eps1", C.c_float), ("eps2", C.c_float)] + \
                [(n, C.c_void_p) for n in ("o_s", "Wo", "bo", "x1s", "g1", "be1", "f", "x2", "mean1", "rstd1", "W1", "b1", "h", "W2",
-                                          "b2", "zp", "z", "g2", "be2", "x3", "mean2", "rstd2", "flags", "err")]
+                                          "b2", "zp", "z", "g2", "be2", "x3", "mean2", "rstd2", "flags", "err")] + \
+               [("nq", C.c_int32), ("qpos", C.c_void_p), ("Wq", C.c_void_p * 3), ("bq", C.c_void_p * 3), ("qout", C.c_void_p * 3)]
+
+
+class ChainCaDesc(C.Structure):
+    _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("M", C.c_int32), ("rows_per_scene", C.c_int32), ("eps", C.c_float),
+                ("o", C.c_void_p * 3), ("Wo", C.c_void_p * 3), ("bo", C.c_void_p * 3), ("x", C.c_void_p), ("gamma", C.c_void_p * 3),
+                ("beta", C.c_void_p * 3), ("coef", C.c_void_p), ("op", C.c_void_p * 3), ("x1", C.c_void_p), ("mean", C.c_void_p),
+                ("rstd", C.c_void_p), ("qpos", C.c_void_p), ("Wqkv", C.c_void_p * 3), ("bqkv", C.c_void_p * 3), ("qkv", C.c_void_p * 3),
+                ("flags", C.c_void_p), ("err", C.c_void_p)]
 
 
 _lib = None
@@ -172,6 +181,7 @@ _SIGS = {
     "pq3d_gemm_tt_multi": [C.POINTER(TtProblem), C.c_int32, C.c_void_p],
     "pq3d_gemm_tt_multi_wide": [C.c_int32],
     "pq3d_chain_ffn_fwd": [C.POINTER(ChainFfnDesc), C.c_void_p],
+    "pq3d_chain_ca_fwd": [C.POINTER(ChainCaDesc), C.c_void_p],
     "pq3d_mask_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_attn_resident": [C.c_int],

@@ -19,15 +19,10 @@
 // runs out of patience sets *err and goes on (wrong numbers, never a hung GPU).
 #include <atomic>
 
-#include "common.h"
+#include "chain_common.h"
 
 namespace {
 
-constexpr int CT = 512;                     // threads per workgroup (8 waves)
-constexpr int TM = 32, TN = 64, KC = 256;   // tile rows / columns, k elements staged at once (= gemm_wk's 32 x 64 x 256 plan)
-constexpr int LDR = KC + 8, CLD = TN + 4;
-constexpr int G = 8;                        // workgroups per row tile
-constexpr int D = 256;                      // model width (LayerNorm rows: 4 values per lane)
 // steps 3 / 4 (the FFN products): a member owns 256 (linear1) / 128 (linear2) output columns of its row tile, every wave
 // 4 / 2 independent 16 x 16 accumulators, the weights staged in k slabs of 64 / 128 (one 16-dword RawB load each)
 constexpr int K3 = 64, LD3 = K3 + 8, N3 = 256;      // linear1: [256 columns][64 k] slab, x2 staged whole ([32][264])
@@ -41,179 +36,11 @@ constexpr size_t chain_lds(int nrt) {
   const size_t s3 = (size_t)nrt * 2 * TM * LDR * 2 + (s3a > s3c ? s3a : s3c);
   const size_t s4b = (size_t)2 * N4 * LD4 * 2, s4c = (size_t)TM * CL4 * 4;
   const size_t s4 = (size_t)nrt * 2 * TM * LD4 * 2 + (s4b > s4c ? s4b : s4c);
-  return s1 > s3 ? (s1 > s4 ? s1 : s4) : (s3 > s4 ? s3 : s4);
+  const size_t s6 = nrt == 1 ? proj_lds<1>(true) : proj_lds<2>(true);
+  const size_t m = s1 > s3 ? (s1 > s4 ? s1 : s4) : (s3 > s4 ? s3 : s4);
+  return m > s6 ? m : s6;
 }
 static_assert(chain_lds(2) <= 160 * 1024, "LDS");
-constexpr int SPIN_LIMIT = 1 << 20;
-
-typedef __attribute__((address_space(3))) unsigned char lds_b_t;
-
-struct Ctx {
-  bf16_t *Ah, *Al, *Bh, *Bl;
-  float* Ct;
-  int tid, lane, wave, li, lg, wm, wn;
-};
-
-PQ_DEV void split_hi_lo(const float* v, u32x4& hi, u32x4& lo) {
-  hi = pack_frag<bf16_t>(v);
-  float w[8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    w[2 * j] = v[2 * j] - __uint_as_float(hi[j] << 16);
-    w[2 * j + 1] = v[2 * j + 1] - __uint_as_float(hi[j] & 0xffff0000u);
-  }
-  lo = pack_frag<bf16_t>(w);
-}
-
-// 8 consecutive floats; SC1: L1-bypassing (data written by another CU of this XCD during this launch)
-template <bool SC1> PQ_DEV void load8(const float* base, long off, float (&v)[8]) {
-  if constexpr (SC1) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
-    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, 16);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4) + 16, 0, 16);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = __uint_as_float(a[j]); v[4 + j] = __uint_as_float(b[j]); }
-  } else {
-    const float4 a = *(const float4*)(base + off), b = *(const float4*)(base + off + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  }
-}
-template <bool SC1> PQ_DEV void load4(const float* base, long off, float (&v)[4]) {
-  if constexpr (SC1) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
-    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 4), 0, 16);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(a[j]);
-  } else {
-    const float4 a = *(const float4*)(base + off);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-  }
-}
-
-// ---- operand staging: [rows][256 k] fp32 -> hi / lo bf16 planes in LDS (gemm_wk's put())
-struct RawA { float v[2][8]; };   // 32 rows x 32 chunks = 1024 chunks / 512 threads
-struct RawB { float v[4][8]; };   // 64 rows x 32 chunks = 2048 chunks
-template <bool SC1> PQ_DEV void issue_a(const Ctx& c, RawA& r, const float* A, int lda, int m0, int R, int k0) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ch = c.tid + i * CT, row = ch >> 5, k = k0 + (ch & 31) * 8;
-    load8<SC1>(A, (long)min(m0 + row, R - 1) * lda + k, r.v[i]);
-  }
-}
-PQ_DEV void put_a(const Ctx& c, const RawA& r) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ch = c.tid + i * CT, o = (ch >> 5) * LDR + (ch & 31) * 8;
-    u32x4 hi, lo;
-    split_hi_lo(r.v[i], hi, lo);
-    *(u32x4*)&c.Ah[o] = hi;
-    *(u32x4*)&c.Al[o] = lo;
-  }
-}
-PQ_DEV void issue_b(const Ctx& c, RawB& r, const float* W, int ldb, int n0, int k0) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ch = c.tid + i * CT, row = ch >> 5, k = k0 + (ch & 31) * 8;
-    load8<false>(W, (long)(n0 + row) * ldb + k, r.v[i]);
-  }
-}
-PQ_DEV void put_b(const Ctx& c, const RawB& r) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ch = c.tid + i * CT, o = (ch >> 5) * LDR + (ch & 31) * 8;
-    u32x4 hi, lo;
-    split_hi_lo(r.v[i], hi, lo);
-    *(u32x4*)&c.Bh[o] = hi;
-    *(u32x4*)&c.Bl[o] = lo;
-  }
-}
-// 8 k-steps of one staged chunk into this wave's 16 x 16 accumulator (gemm_wk's loop at NJ = 1)
-PQ_DEV void mma_chunk(const Ctx& c, f32x4& acc) {
-#pragma unroll
-  for (int ks = 0; ks < KC / 32; ++ks) {
-    const int oa = (c.wm + c.li) * LDR + ks * 32 + c.lg * 8, ob = (c.wn + c.li) * LDR + ks * 32 + c.lg * 8;
-    const u32x4 ah = *(const u32x4*)&c.Ah[oa], al = *(const u32x4*)&c.Al[oa];
-    const u32x4 bh = *(const u32x4*)&c.Bh[ob], bl = *(const u32x4*)&c.Bl[ob];
-    Mma<bf16_t>::mma(acc, al, bh);
-    Mma<bf16_t>::mma(acc, ah, bl);
-    Mma<bf16_t>::mma(acc, ah, bh);
-  }
-}
-// (acc + bias) [relu] -> C, rows leave in 16-byte pieces through the transposed LDS tile (gemm_wk's epilogue at alpha = 1)
-PQ_DEV void store_tile(const Ctx& c, const f32x4& acc, const float* bias, int n0, bool relu, float* C, int ldc, int m0, int R) {
-  const float bcol = bias ? bias[n0 + c.wn + c.li] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) c.Ct[(c.wm + c.lg * 4 + r) * CLD + c.wn + c.li] = (acc[r] + bcol) * 1.f;
-  __syncthreads();
-  const int lrow = c.tid >> 4, lcol = (c.tid & 15) * 4, row = m0 + lrow;
-  float4 t = *(const float4*)&c.Ct[lrow * CLD + lcol];
-  if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-  if (row < R) *(float4*)(C + (long)row * ldc + n0 + lcol) = t;
-  __syncthreads();   // the next tile reuses Ct (and the B planes)
-}
-
-// ---- hand-off inside the group: publish `target`, wait until every member has
-PQ_DEV void handoff(const Ctx& c, unsigned* mine, unsigned* group, unsigned target, int* err) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through L1: acknowledged stores are in the XCD's L2
-  __syncthreads();
-  if (c.wave == 0) {
-    if (c.lane == 0) __hip_atomic_store(mine, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool ok = true;
-    int spins = 0;
-    do {
-      const unsigned v = c.lane < G ? __hip_atomic_load(group + c.lane * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-      ok = (int)(v - target) >= 0;
-    } while (!__all((int)ok) && ++spins < SPIN_LIMIT);
-    if (!__all((int)ok) && c.lane == 0 && err) *err = 1;
-  }
-  __syncthreads();
-}
-
-// ---- LayerNorm rows (norm.hip's add_ln_fwd at d = 256: lane owns columns 4 lane .. 4 lane + 3)
-struct RowStats { float mean, rstd; };
-PQ_DEV RowStats row_stats4(const float (&v)[4], float eps) {
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) s += v[j];
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const float t = v[j] - mean; q += t * t; }
-  const float var = wave_sum(q) / (float)D;
-  return {mean, 1.f / sqrtf(var + eps)};
-}
-// y = LN(x + (o_0 + ... + o_{nsum-1})); the sum is kept in osum when given
-template <bool SC1X>
-PQ_DEV void ln_row(const Ctx& c, long row, const float* x, const float* const* o, int nsum, long ostride, const float* gamma,
-                   const float* beta, float eps, float* osum, float* y, float* mean, float* rstd) {
-  const long base = row * D + c.lane * 4;
-  float xr[4], ov[4], v[4], gm[4], bt[4], out[4];
-  load4<SC1X>(x, base, xr);
-  load4<true>(o[0], base, ov);
-  for (int p = 1; p < nsum; ++p) {
-    float t[4];
-    load4<true>(o[0] + p * ostride, base, t);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ov[j] += t[j];
-  }
-  if (osum) *(float4*)(osum + base) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = xr[j] + ov[j];
-  const RowStats st = row_stats4(v, eps);
-  load4<false>(gamma, c.lane * 4, gm);
-  load4<false>(beta, c.lane * 4, bt);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { out[j] = 0.f; out[j] += 1.f * ((v[j] - st.mean) * st.rstd * gm[j] + bt[j]); }
-  if (c.lane == 0) { mean[row] = st.mean; rstd[row] = st.rstd; }
-  *(float4*)(y + base) = make_float4(out[0], out[1], out[2], out[3]);
-}
-
-// in-kernel timeline (probe builds only, tools/probes/chain_timeline.py): thread 0 of workgroup 0 stamps the 100 MHz clock
-#ifdef PQ3D_CHAIN_TL
-#define CH_TL(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) ((long long*)d.err)[i] = wall_clock64(); } while (0)
-#else
-#define CH_TL(i) do { } while (0)
-#endif
 
 // NRT: 32-row tiles per group (1: up to 1024 rows; 2: up to 2048 -- a member converts each weight slab once for both tiles)
 template <int NRT>
@@ -452,6 +279,9 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
       }
     }
   }
+  // step 6's weights (the ring is free now) travel under the last hand-offs and the second LayerNorm
+  RawB wq[2];
+  if (d.nq > 0) proj_issue_w(c, j, d.nq, d.Wq, wq);
   CH_TL(7);
   handoff(c, mine, group, v0 + 4, d.err);
   CH_TL(8);
@@ -461,6 +291,14 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
     if (lnw) ln_row<true>(c, lrow, d.x2, o2, 4, (long)R * D, d.g2, d.be2, d.eps2, d.z, d.x3, d.mean2, d.rstd2);
   }
   CH_TL(9);
+  // ---- 6. (optional) the next layer application's cross-attention query projections from x3 + qpos
+  if (d.nq > 0) {   // uniform
+    handoff(c, mine, group, v0 + 5, d.err);
+    const void* A[3] = {d.x3, d.x3, d.x3};
+    const float* A2[3] = {d.qpos, d.qpos, d.qpos};
+    bf16_t* out[3] = {(bf16_t*)d.qout[0], (bf16_t*)d.qout[1], (bf16_t*)d.qout[2]};
+    proj_3x256<NRT, true, true, bf16_t>(c, ch_smem, j, d.nq, m0, R, A, A2, d.Wq, d.bq, out, wq, true);
+  }
 }
 
 }  // namespace
@@ -479,6 +317,10 @@ extern "C" int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* dp, void* stream) {
   const void* al[] = {d.o_s, d.Wo, d.x1s, d.g1, d.be1, d.f, d.x2, d.W1, d.h, d.W2, d.zp, d.z, d.g2, d.be2, d.x3};
   for (const void* p : al) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_chain_ffn_fwd: operands must be 16-byte aligned");
   PQ_CHECK_ARG((long)d.R * d.F * 4 < 0x7ffffff0L, "pq3d_chain_ffn_fwd: hidden activations too large");
+  PQ_CHECK_ARG(d.nq >= 0 && d.nq <= 3 && (d.nq == 0 || (d.qpos && (((uintptr_t)d.qpos) & 15) == 0)), "pq3d_chain_ffn_fwd: 0..3 query projections");
+  for (int m = 0; m < d.nq; ++m)
+    PQ_CHECK_ARG(d.Wq[m] && d.bq[m] && d.qout[m] && ((((uintptr_t)d.Wq[m]) | ((uintptr_t)d.qout[m])) & 15) == 0,
+                 "pq3d_chain_ffn_fwd: query-projection operands (non-null, 16-byte aligned)");
   static std::atomic<unsigned> done1{0}, done2{0};
   const dim3 grid((unsigned)(8 * G * slots));
   if (nrt == 1) {

@@ -961,6 +961,7 @@ class _FusedDecoder(Function):
         pcls, pmask = [], []
         x = x0
         attn_mask = row_open = None
+        q_next = None   # the next application's cross-attention queries when the chain launch of this one formed them
         for blk in range(spec.num_blocks):
             for i, layer in enumerate(layers):
                 app = blk * Ln + i
@@ -991,11 +992,14 @@ class _FusedDecoder(Function):
                         row_open = ops.mask_row_all(attn_mask)
                 rec["attn_mask"], rec["row_open"], rec["mask_bits"] = attn_mask, row_open, mask_bits
                 # -- cross attention over the M memories: 4 launches
-                q_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
-                ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cas[i]]
-                bsl = [ca.multihead_attn.in_proj_bias.detach() for ca in cas[i]]
-                L.gemm(M=R, N=d, K=d, A=[x] * M, A2=[qpos] * M, B=[w[:d] for w in ws], bias=[b[:d] for b in bsl],
-                       Cs=[q_all[m] for m in range(M)], ct=cq, lda=d, ldb=d, ldc=d)
+                if q_next is not None:   # formed by the previous layer application's chain launch (csrc/chain_ffn.hip, step 6)
+                    q_all, q_next = q_next, None
+                else:
+                    q_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+                    ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cas[i]]
+                    bsl = [ca.multihead_attn.in_proj_bias.detach() for ca in cas[i]]
+                    L.gemm(M=R, N=d, K=d, A=[x] * M, A2=[qpos] * M, B=[w[:d] for w in ws], bias=[b[:d] for b in bsl],
+                           Cs=[q_all[m] for m in range(M)], ct=cq, lda=d, ldb=d, ldc=d)
                 o_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
                 lse = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
                 if spec.use_self_mask:
@@ -1005,14 +1009,39 @@ class _FusedDecoder(Function):
                 else:
                     _attn(q_all.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
                           o_all.view(M * B, Nq, d), lse, H, ct, True, kpm=kpm_all, drop=dr_ca, drop_bmod=B)
-                op_all = torch.empty(M, B, Nq, d, dtype=torch.float32, device=dev)
-                L.gemm(M=R, N=d, K=d, A=[o_all[m] for m in range(M)],
-                       B=[ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
-                       bias=[ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]],
-                       Cs=[op_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
-                x1, mean_c, rstd_c = _ln_fwd(x, [op_all[m] for m in range(M)], [ca.norm.weight.detach() for ca in cas[i]],
-                                             [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps,
-                                             coef[app] if coef is not None else None, Nq, drop=dr_cr)
+                sa = layer.self_attn
+                if spec.spatial:
+                    msa = sa.self_attn
+                    Wl = [msa.w_qs.weight.detach(), msa.w_ks.weight.detach(), msa.w_vs.weight.detach()]
+                    bl = [msa.w_qs.bias.detach(), msa.w_ks.bias.detach(), msa.w_vs.bias.detach()]
+                    Wo, bo = msa.fc.weight.detach(), msa.fc.bias.detach()
+                else:
+                    w, b = sa.self_attn.in_proj_weight.detach(), sa.self_attn.in_proj_bias.detach()
+                    Wl, bl = [w[:d], w[d:2 * d], w[2 * d:]], [b[:d], b[d:2 * d], b[2 * d:]]
+                    Wo, bo = sa.self_attn.out_proj.weight.detach(), sa.self_attn.out_proj.bias.detach()
+                # out-projections + merged post-norm + the self-attention's q / k / v projections: ONE launch when the shapes allow
+                # (csrc/chain_ca.hip: same bits as the three launches below)
+                chain_ca = _CHAIN and ct == BF16 and cq == L.BF16X3 and not spec.prompt and dr_cr is None and \
+                    ops.chain_ca_ok(R, d, M) and o_all.dtype == torch.bfloat16
+                qkv = None
+                if chain_ca:
+                    flags = getattr(enc, "_chain_flags_ca", None)
+                    if flags is None or flags.device != dev:
+                        flags = enc._chain_flags_ca = ops.chain_flags(2048, dev)
+                    op_all, x1, mean_c, rstd_c, qkv = ops.chain_ca_fwd(
+                        o_all, [ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
+                        [ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]], x, [ca.norm.weight.detach() for ca in cas[i]],
+                        [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps, coef[app] if coef is not None else None, Nq, qpos,
+                        [t_.contiguous() for t_ in Wl], [t_.contiguous() for t_ in bl], flags)
+                else:
+                    op_all = torch.empty(M, B, Nq, d, dtype=torch.float32, device=dev)
+                    L.gemm(M=R, N=d, K=d, A=[o_all[m] for m in range(M)],
+                           B=[ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
+                           bias=[ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]],
+                           Cs=[op_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
+                    x1, mean_c, rstd_c = _ln_fwd(x, [op_all[m] for m in range(M)], [ca.norm.weight.detach() for ca in cas[i]],
+                                                 [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps,
+                                                 coef[app] if coef is not None else None, Nq, drop=dr_cr)
                 rec.update(q_all=q_all, o_all=o_all, lse=lse, op_all=op_all, mean_c=mean_c, rstd_c=rstd_c, x1=x1)
                 x1s = x1     # input of the self-attention sublayer
                 if spec.prompt:
@@ -1035,20 +1064,11 @@ class _FusedDecoder(Function):
                     rec.update(qp=qp, o_p=o_p, lse_p=lse_p, opp=opp, mean_p=mean_p, rstd_p=rstd_p, dr_pa=dr_pa, dr_pr=dr_pr)
                 rec["x1s"] = x1s
                 # -- self attention: 5 launches (spatial) / 4
-                sa = layer.self_attn
                 # N_q x N_q scores per scene: projections at fp32 grade, attention core on the exact-f32 MFMA path
-                qkv = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
-                if spec.spatial:
-                    msa = sa.self_attn
-                    Wl = [msa.w_qs.weight.detach(), msa.w_ks.weight.detach(), msa.w_vs.weight.detach()]
-                    bl = [msa.w_qs.bias.detach(), msa.w_ks.bias.detach(), msa.w_vs.bias.detach()]
-                    Wo, bo = msa.fc.weight.detach(), msa.fc.bias.detach()
-                else:
-                    w, b = sa.self_attn.in_proj_weight.detach(), sa.self_attn.in_proj_bias.detach()
-                    Wl, bl = [w[:d], w[d:2 * d], w[2 * d:]], [b[:d], b[d:2 * d], b[2 * d:]]
-                    Wo, bo = sa.self_attn.out_proj.weight.detach(), sa.self_attn.out_proj.bias.detach()
-                L.gemm(M=R, N=d, K=d, A=[x1s] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=cq,
-                       lda=d, ldb=d, ldc=d)
+                if qkv is None:
+                    qkv = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
+                    L.gemm(M=R, N=d, K=d, A=[x1s] * 3, A2=[qpos, qpos, None], B=Wl, bias=bl, Cs=[qkv[0], qkv[1], qkv[2]], ct=cq,
+                           lda=d, ldb=d, ldc=d)
                 sbias = sbias_all[i] if spec.spatial else None   # layer-invariant across blocks: computed once above
                 o_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 lse_s = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
@@ -1063,10 +1083,19 @@ class _FusedDecoder(Function):
                     flags = getattr(enc, "_chain_flags", None)
                     if flags is None or flags.device != dev or flags.numel() < ((R + 31) // 32) * 128:
                         flags = enc._chain_flags = ops.chain_flags(max(R, 2048), dev)
-                    f, x2, mean_s, rstd_s, h, _zp, z, x3, mean_f, rstd_f = ops.chain_ffn_fwd(
+                    # ... and the NEXT application's cross-attention query projections (they read this application's output): the
+                    # mask head in front of the next layer reads x3, not the queries, so nothing else moves
+                    nextq = None
+                    if app + 1 < spec.num_blocks * Ln and M <= 3 and ad == torch.bfloat16:
+                        cn = cas[(i + 1) % Ln]
+                        nextq = (qpos, [ca.multihead_attn.in_proj_weight.detach()[:d] for ca in cn],
+                                 [ca.multihead_attn.in_proj_bias.detach()[:d] for ca in cn])
+                    outs = ops.chain_ffn_fwd(
                         o_s, Wo, bo, x1s, sa.norm.weight.detach(), sa.norm.bias.detach(), sa.norm.eps,
                         ffn.linear1.weight.detach(), ffn.linear1.bias.detach(), ffn.linear2.weight.detach(), ffn.linear2.bias.detach(),
-                        ffn.norm.weight.detach(), ffn.norm.bias.detach(), ffn.norm.eps, flags)
+                        ffn.norm.weight.detach(), ffn.norm.bias.detach(), ffn.norm.eps, flags, nextq=nextq)
+                    f, x2, mean_s, rstd_s, h, _zp, z, x3, mean_f, rstd_f = outs[:10]
+                    q_next = outs[10] if nextq is not None else None
                     pre = None
                     rec.update(qkv=qkv, sbias=sbias, o_s=o_s, lse_s=lse_s, f=f, mean_s=mean_s, rstd_s=rstd_s, x2=x2)
                 else:

@@ -1637,8 +1637,9 @@ def chain_ffn_ok(R: int, d: int, F_: int) -> bool:
     return d == 256 and F_ == 2048 and 1 <= R <= 2048
 
 
-def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2, flags):
-    """Returns (f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2); every tensor fp32, rows = o_s.numel() // 256."""
+def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2, flags, nextq=None):
+    """Returns (f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2[, q_next]); every tensor fp32, rows = o_s.numel() // 256.
+    nextq = (qpos, [Wq_m], [bq_m]): also q_next[m] = (x3 + qpos) Wq_m^T + bq_m as bf16 (the next layer's cross-attention queries)."""
     d = o_s.shape[-1]
     R, F_ = o_s.numel() // d, W1.shape[0]
     dev = o_s.device
@@ -1656,11 +1657,56 @@ def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2
                  ("be2", be2), ("x3", x3), ("mean2", mean2), ("rstd2", rstd2), ("flags", flags), ("err", err)):
         assert t.is_contiguous() and (n in ("flags", "err") or t.dtype == torch.float32), n
         setattr(c, n, L.ptr(t))
+    qn = None
+    if nextq is not None:
+        qpos, Wqs, bqs = nextq
+        qn = torch.empty(len(Wqs), *o_s.shape, dtype=torch.bfloat16, device=dev)
+        assert qpos.is_contiguous() and qpos.dtype == torch.float32 and len(Wqs) <= 3
+        c.nq, c.qpos = len(Wqs), L.ptr(qpos)
+        for m, (w_, b_) in enumerate(zip(Wqs, bqs)):
+            assert w_.is_contiguous() and b_.is_contiguous() and w_.dtype == torch.float32
+            c.Wq[m], c.bq[m], c.qout[m] = L.ptr(w_), L.ptr(b_), L.ptr(qn[m])
     from .profiler import timed
     fl = 2.0 * R * d * (d + 2 * F_)
     nb = 4.0 * (R * d * 9 + 2 * R * F_ + d * d + 2 * d * F_)
     L.check(timed("pq3d_chain_ffn_fwd", f"R{R}d{d}F{F_}", fl, nb, L.lib().pq3d_chain_ffn_fwd, C.byref(c), L.stream()), "pq3d_chain_ffn_fwd")
-    return f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2
+    return (f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2) + ((qn,) if qn is not None else ())
+
+
+def chain_ca_ok(R: int, d: int, M: int) -> bool:
+    return d == 256 and 1 <= M <= 3 and 1 <= R <= 2048
+
+
+def chain_ca_fwd(o_all, Wos, bos, x, gammas, betas, eps, coef, rows_per_scene, qpos, Wqkv, bqkv, flags):
+    """o_all [M, ..., d] bf16 -> (op_all [M, ..., d], x1, mean [M, R], rstd [M, R], qkv [3, ..., d]); everything else fp32."""
+    M, d = o_all.shape[0], o_all.shape[-1]
+    R = x.numel() // d
+    dev = x.device
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    op_all, x1, qkv = e(M, *x.shape), e(x.shape), e(3, *x.shape)
+    mean, rstd = e(M, R), e(M, R)
+    err = _CHAIN_ERR.get(dev)
+    if err is None:
+        err = _CHAIN_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    c = L.ChainCaDesc()
+    c.R, c.d, c.M, c.rows_per_scene, c.eps = R, d, M, rows_per_scene, eps
+    assert o_all.dtype == torch.bfloat16 and o_all.is_contiguous() and x.is_contiguous() and qpos.is_contiguous()
+    assert x.dtype == torch.float32 and qpos.dtype == torch.float32
+    for m in range(M):
+        for n, t in (("o", o_all[m]), ("Wo", Wos[m]), ("bo", bos[m]), ("gamma", gammas[m]), ("beta", betas[m]), ("op", op_all[m])):
+            assert t.is_contiguous() and (n == "o" or t.dtype == torch.float32), n
+            getattr(c, n)[m] = L.ptr(t)
+    for g in range(3):
+        for n, t in (("Wqkv", Wqkv[g]), ("bqkv", bqkv[g]), ("qkv", qkv[g])):
+            assert t.is_contiguous() and t.dtype == torch.float32, n
+            getattr(c, n)[g] = L.ptr(t)
+    if coef is not None:
+        assert coef.is_contiguous() and coef.dtype == torch.float32
+    c.x, c.coef, c.x1, c.mean, c.rstd, c.qpos, c.flags, c.err = map(L.ptr, (x, coef, x1, mean, rstd, qpos, flags, err))
+    fl = 2.0 * R * d * d * (M + 3)
+    nb = 4.0 * (R * d * (2 * M + 6) + (M + 3) * d * d) + 2.0 * M * R * d
+    L.check(timed("pq3d_chain_ca_fwd", f"R{R}d{d}M{M}", fl, nb, L.lib().pq3d_chain_ca_fwd, C.byref(c), L.stream()), "pq3d_chain_ca_fwd")
+    return op_all, x1, mean, rstd, qkv
 
 
 def chain_error(device) -> bool:

@@ -52,6 +52,8 @@ int main(void) {
          offsetof(pq3d_ln_desc, dbeta));
   printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_ffn_desc), offsetof(pq3d_chain_ffn_desc, eps2), offsetof(pq3d_chain_ffn_desc, o_s),
          offsetof(pq3d_chain_ffn_desc, err));
+  printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_ca_desc), offsetof(pq3d_chain_ca_desc, eps), offsetof(pq3d_chain_ca_desc, o),
+         offsetof(pq3d_chain_ca_desc, err));
   return 0;
 }''')
     exe = tmp_path / "layout"
@@ -63,6 +65,8 @@ int main(void) {
     assert rows[2] == [ctypes.sizeof(Ln), Ln.eps.offset, Ln.x.offset, Ln.dbeta.offset]
     Ch = _lib.ChainFfnDesc
     assert rows[3] == [ctypes.sizeof(Ch), Ch.eps2.offset, Ch.o_s.offset, Ch.err.offset]
+    Ca = _lib.ChainCaDesc
+    assert rows[4] == [ctypes.sizeof(Ca), Ca.eps.offset, Ca.o.offset, Ca.err.offset]
 
 
 def test_argument_errors_are_reported(lib):

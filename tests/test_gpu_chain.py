@@ -55,3 +55,67 @@ def test_chain_refuses_what_it_cannot_hold():
     c = L.ChainFfnDesc()
     c.R, c.d, c.F = 4000, 256, 2048
     assert L.lib().pq3d_chain_ffn_fwd(L.C.byref(c), None) == -1
+
+
+def _three_launches(o_all, Wos, bos, x, gammas, betas, eps, coef, rps, qpos, Wqkv, bqkv):
+    from pq3d_amd import _lib as L, fused
+    M, d = o_all.shape[0], o_all.shape[-1]
+    R = x.numel() // d
+    dev = x.device
+    op_all = torch.empty(M, *x.shape, dtype=torch.float32, device=dev)
+    L.gemm(M=R, N=d, K=d, A=[o_all[m] for m in range(M)], B=list(Wos), bias=list(bos), Cs=[op_all[m] for m in range(M)], ct=L.BF16,
+           lda=d, ldb=d, ldc=d)
+    x1, mean, rstd = fused._ln_fwd(x, [op_all[m] for m in range(M)], list(gammas), list(betas), eps, coef, rps)
+    qkv = torch.empty(3, *x.shape, dtype=torch.float32, device=dev)
+    L.gemm(M=R, N=d, K=d, A=[x1] * 3, A2=[qpos, qpos, None], B=list(Wqkv), bias=list(bqkv), Cs=[qkv[0], qkv[1], qkv[2]], ct=L.BF16X3,
+           lda=d, ldb=d, ldc=d)
+    return op_all, x1, mean, rstd, qkv
+
+
+@pytest.mark.parametrize("B,Nq,M,with_coef", [(8, 100, 3, False), (8, 100, 3, True), (4, 200, 3, False), (16, 100, 3, True), (3, 37, 2, False),
+                                               (1, 1, 1, False), (1, 2048, 3, False)])
+def test_chain_ca_equals_three_launches(B, Nq, M, with_coef):
+    from pq3d_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 1000 + Nq + M)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    d = 256
+    coef = None
+    if with_coef:
+        coef = torch.rand(M, B, generator=g).to(dev)
+        coef = (coef / coef.sum(0, keepdim=True)).contiguous()
+    args = (r(M, B, Nq, d).bfloat16(), [r(d, d, sc=0.06) for _ in range(M)], [r(d, sc=0.1) for _ in range(M)], r(B, Nq, d),
+            [1 + r(d, sc=0.1) for _ in range(M)], [r(d, sc=0.1) for _ in range(M)], 1e-5, coef, Nq, r(B, Nq, d),
+            [r(d, d, sc=0.06) for _ in range(3)], [r(d, sc=0.1) for _ in range(3)])
+    ref = _three_launches(*args)
+    flags = ops.chain_flags(B * Nq, dev)
+    for rep in range(3):
+        out = ops.chain_ca_fwd(*args, flags)
+        torch.cuda.synchronize()
+        assert not ops.chain_error(dev)
+        for n, a, b in zip(("op", "x1", "mean", "rstd", "qkv"), out, ref):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (n, rep, (a - b).abs().max().item())
+
+
+def test_chain_ffn_with_next_query_projection():
+    """Sixth step of the FFN chain: the next layer's cross-attention queries, bf16, equal to the grouped launch's."""
+    from pq3d_amd import _lib as L, ops
+    dev = torch.device("cuda")
+    for B, Nq, M in ((8, 100, 3), (16, 100, 3), (2, 50, 1)):
+        g = torch.Generator().manual_seed(7 + B)
+        r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+        d, F_ = 256, 2048
+        args = (r(B, Nq, d), r(d, d, sc=0.06), r(d, sc=0.1), r(B, Nq, d), 1 + r(d, sc=0.1), r(d, sc=0.1), 1e-5,
+                r(F_, d, sc=0.06), r(F_, sc=0.1), r(d, F_, sc=0.03), r(d, sc=0.1), 1 + r(d, sc=0.1), r(d, sc=0.1), 1e-5)
+        qpos, Wq, bq = r(B, Nq, d), [r(d, d, sc=0.06) for _ in range(M)], [r(d, sc=0.1) for _ in range(M)]
+        ref = _five_launches(*args)
+        x3 = ref[7]
+        qref = torch.empty(M, B, Nq, d, dtype=torch.bfloat16, device=dev)
+        L.gemm(M=B * Nq, N=d, K=d, A=[x3] * M, A2=[qpos] * M, B=Wq, bias=bq, Cs=[qref[m] for m in range(M)], ct=L.BF16X3, lda=d, ldb=d, ldc=d)
+        flags = ops.chain_flags(B * Nq, dev)
+        for rep in range(3):
+            out = ops.chain_ffn_fwd(*args, flags, nextq=(qpos, Wq, bq))
+            torch.cuda.synchronize()
+            assert not ops.chain_error(dev)
+            assert torch.equal(out[7].view(torch.int32), x3.view(torch.int32))
+            assert torch.equal(out[10].view(torch.int16), qref.view(torch.int16)), (B, rep)
