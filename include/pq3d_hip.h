@@ -434,6 +434,42 @@ typedef struct {
 } pq3d_chain_ca_desc;
 int pq3d_chain_ca_fwd(const pq3d_chain_ca_desc* d, void* stream);
 
+/* The row-local head of a decoder layer's BACKWARD in one launch (csrc/chain_ffn_bwd.hip; bf16 mode, ReLU, no dropout):
+ *     g2 = LN2'(x2 + z; dx);  dhp = [h > 0] (g2 W2) (bf16);  p_k = dhp_k W1_k (K = F in 4 partial sums);
+ *     g1 = LN1'(x1s + f; g2 + p_0 + p_1 + p_2 + p_3)
+ * = pq3d_add_ln_bwd, pq3d_gemm (transB, act_grad relu), pq3d_gemm (transB, split-K), pq3d_add_ln_bwd of FFNLayer and the
+ * self-attention post-norm (query_encoder.py:384-388, 224-225).  dy (= g2: d z and the residual branch), dhp and df (= g1: d f and
+ * the residual branch) are left in memory for the weight-gradient products; d gamma / d beta are ACCUMULATED (atomics) onto
+ * dg2 / db2 / dg1 / db1.  R <= 2048, d = 256, F = 2048.  part: [4, R, d] fp32 workspace.  flags / err: as for pq3d_chain_ffn_fwd. */
+typedef struct {
+  int32_t R, d, F;
+  const float* dx;              /* [R, d] upstream gradient */
+  const float* x2;              /* [R, d] */
+  const float* z;               /* [R, d] */
+  const float* g2;              /* LN2 gamma */
+  const float* mean2;           /* [R] */
+  const float* rstd2;
+  float* dg2;                   /* [d] accumulated */
+  float* db2;
+  float* dy;                    /* [R, d] out: g2 */
+  const float* W2;              /* [d, F] */
+  const float* h;               /* [R, F] forward hidden (post-ReLU) */
+  void* dhp;                    /* [R, F] bf16 out */
+  const float* W1;              /* [F, d] */
+  float* part;                  /* [4, R, d] workspace */
+  const float* x1s;             /* [R, d] */
+  const float* f;               /* [R, d] */
+  const float* g1;              /* LN1 gamma */
+  const float* mean1;
+  const float* rstd1;
+  float* dg1;
+  float* db1;
+  float* df;                    /* [R, d] out: g1 */
+  uint32_t* flags;
+  int32_t* err;
+} pq3d_chain_ffn_bwd_desc;
+int pq3d_chain_ffn_bwd(const pq3d_chain_ffn_bwd_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small memory-bound kernels.
  * ------------------------------------------------------------------------------------------------ */

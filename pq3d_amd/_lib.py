@@ -171,6 +171,12 @@ class ChainCaDesc(C.Structure):
                 ("flags", C.c_void_p), ("err", C.c_void_p)]
 
 
+class ChainFfnBwdDesc(C.Structure):
+    _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("dx", "x2", "z", "g2", "mean2", "rstd2", "dg2", "db2", "dy", "W2", "h", "dhp", "W1", "part", "x1s",
+                                          "f", "g1", "mean1", "rstd1", "dg1", "db1", "df", "flags", "err")]
+
+
 _lib = None
 
 _SIGS = {
@@ -182,6 +188,7 @@ _SIGS = {
     "pq3d_gemm_tt_multi_wide": [C.c_int32],
     "pq3d_chain_ffn_fwd": [C.POINTER(ChainFfnDesc), C.c_void_p],
     "pq3d_chain_ca_fwd": [C.POINTER(ChainCaDesc), C.c_void_p],
+    "pq3d_chain_ffn_bwd": [C.POINTER(ChainFfnBwdDesc), C.c_void_p],
     "pq3d_mask_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_attn_resident": [C.c_int],

@@ -1709,6 +1709,32 @@ def chain_ca_fwd(o_all, Wos, bos, x, gammas, betas, eps, coef, rows_per_scene, q
     return op_all, x1, mean, rstd, qkv
 
 
+def chain_ffn_bwd(dx, x2, z, g2, mean2, rstd2, dg2, db2, W2, h, W1, x1s, f, g1, mean1, rstd1, dg1, db1, flags):
+    """Backward of the FFN sublayer + the self-attention post-norm in one launch.  Returns (dy, dhp, df): dy = d z (= the
+    residual-branch gradient of LN2), dhp = d(linear1 output) as bf16, df = d f (= the residual-branch gradient of LN1).
+    dg2 / db2 / dg1 / db1 (arena views) are accumulated onto."""
+    d = dx.shape[-1]
+    R, F_ = dx.numel() // d, W1.shape[0]
+    dev = dx.device
+    dy, df = torch.empty_like(dx), torch.empty_like(dx)
+    dhp = torch.empty(*dx.shape[:-1], F_, dtype=torch.bfloat16, device=dev)
+    part = torch.empty(4, R, d, dtype=torch.float32, device=dev)
+    err = _CHAIN_ERR.get(dev)
+    if err is None:
+        err = _CHAIN_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    c = L.ChainFfnBwdDesc()
+    c.R, c.d, c.F = R, d, F_
+    for n, t in (("dx", dx), ("x2", x2), ("z", z), ("g2", g2), ("mean2", mean2), ("rstd2", rstd2), ("dg2", dg2), ("db2", db2), ("dy", dy),
+                 ("W2", W2), ("h", h), ("dhp", dhp), ("W1", W1), ("part", part), ("x1s", x1s), ("f", f), ("g1", g1), ("mean1", mean1),
+                 ("rstd1", rstd1), ("dg1", dg1), ("db1", db1), ("df", df), ("flags", flags), ("err", err)):
+        assert t.is_contiguous() and (n in ("flags", "err", "dhp") or t.dtype == torch.float32), n
+        setattr(c, n, L.ptr(t))
+    fl = 2.0 * R * d * 2 * F_
+    nb = 4.0 * (R * d * 12 + R * F_ + 2 * d * F_) + 2.0 * 2 * R * F_
+    L.check(timed("pq3d_chain_ffn_bwd", f"R{R}d{d}F{F_}", fl, nb, L.lib().pq3d_chain_ffn_bwd, C.byref(c), L.stream()), "pq3d_chain_ffn_bwd")
+    return dy, dhp, df
+
+
 def chain_error(device) -> bool:
     """True if a hand-off wait of any chain launch on `device` gave up (synchronises)."""
     err = _CHAIN_ERR.get(device)

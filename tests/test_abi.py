@@ -54,6 +54,8 @@ int main(void) {
          offsetof(pq3d_chain_ffn_desc, err));
   printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_ca_desc), offsetof(pq3d_chain_ca_desc, eps), offsetof(pq3d_chain_ca_desc, o),
          offsetof(pq3d_chain_ca_desc, err));
+  printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_ffn_bwd_desc), offsetof(pq3d_chain_ffn_bwd_desc, F), offsetof(pq3d_chain_ffn_bwd_desc, dx),
+         offsetof(pq3d_chain_ffn_bwd_desc, err));
   return 0;
 }''')
     exe = tmp_path / "layout"
@@ -67,6 +69,8 @@ int main(void) {
     assert rows[3] == [ctypes.sizeof(Ch), Ch.eps2.offset, Ch.o_s.offset, Ch.err.offset]
     Ca = _lib.ChainCaDesc
     assert rows[4] == [ctypes.sizeof(Ca), Ca.eps.offset, Ca.o.offset, Ca.err.offset]
+    Cb = _lib.ChainFfnBwdDesc
+    assert rows[5] == [ctypes.sizeof(Cb), Cb.F.offset, Cb.dx.offset, Cb.err.offset]
 
 
 def test_argument_errors_are_reported(lib):

@@ -119,3 +119,43 @@ def test_chain_ffn_with_next_query_projection():
             assert not ops.chain_error(dev)
             assert torch.equal(out[7].view(torch.int32), x3.view(torch.int32))
             assert torch.equal(out[10].view(torch.int16), qref.view(torch.int16)), (B, rep)
+
+
+@pytest.mark.parametrize("B,Nq", [(8, 100), (16, 100), (3, 37), (1, 1)])
+def test_chain_ffn_bwd_against_separate_launches(B, Nq):
+    """Backward chain: g2 and dhp bit for bit; g1 and the LayerNorm parameter gradients to fp32 summation-order accuracy (the
+    separate launches add linear1's four k slices with atomics, the chain in a fixed order)."""
+    from pq3d_amd import _lib as L, fused, ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11 + B)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    d, F_ = 256, 2048
+    R = B * Nq
+    fwd = (r(B, Nq, d), r(d, d, sc=0.06), r(d, sc=0.1), r(B, Nq, d), 1 + r(d, sc=0.1), r(d, sc=0.1), 1e-5,
+           r(F_, d, sc=0.06), r(F_, sc=0.1), r(d, F_, sc=0.03), r(d, sc=0.1), 1 + r(d, sc=0.1), r(d, sc=0.1), 1e-5)
+    f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2 = _five_launches(*fwd)
+    x1s, g1, W1, W2, g2 = fwd[3], fwd[4], fwd[7], fwd[9], fwd[11]
+    dx = r(B, Nq, d)
+    # separate launches (what _DecoderBackward.ffn / .self_attn issue)
+    dg2r, db2r, dg1r, db1r = (torch.zeros(d, device=dev) for _ in range(4))
+    dx2r, dyl = fused._ln_bwd(x2, [z], [g2], [fwd[12]], 1e-5, None, Nq, mean2[:1], rstd2[:1], dx, [dg2r], [db2r])
+    dy_ref = dyl[0]
+    dhp_ref = torch.empty(B, Nq, F_, dtype=torch.bfloat16, device=dev)
+    L.gemm(M=R, N=F_, K=d, A=[dy_ref], B=[W2], Cs=[dhp_ref], aux=[h], act_grad="relu", ct=L.BF16, lda=d, ldb=F_, ldc=F_, transB=True)
+    dx2 = dx2r.clone()
+    L.gemm(M=R, N=d, K=F_, A=[dhp_ref], B=[W1], Cs=[dx2], ct=L.BF16, lda=F_, ldb=d, ldc=d, transB=True, splitk=4, accumulate=True)
+    dx1r, dfl = fused._ln_bwd(x1s, [f], [g1], [fwd[5]], 1e-5, None, Nq, mean1, rstd1, dx2, [dg1r], [db1r])
+    flags = ops.chain_flags(R, dev)
+    for rep in range(3):
+        dg2, db2, dg1, db1 = (torch.zeros(d, device=dev) for _ in range(4))
+        dy, dhp, df = ops.chain_ffn_bwd(dx, x2, z, g2, mean2[:1].contiguous(), rstd2[:1].contiguous(), dg2, db2, W2, h, W1, x1s, f, g1,
+                                        mean1, rstd1, dg1, db1, flags)
+        torch.cuda.synchronize()
+        assert not ops.chain_error(dev)
+        assert torch.equal(dy.view(torch.int32), dy_ref.view(torch.int32))
+        assert torch.equal(dy.view(torch.int32), dx2r.view(torch.int32))
+        assert torch.equal(dhp.view(torch.int16), dhp_ref.view(torch.int16))
+        sc = dfl[0].abs().max().item()
+        assert (df - dfl[0]).abs().max().item() <= 2e-5 * sc and (df - dx1r).abs().max().item() <= 2e-5 * sc
+        for a, b in ((dg2, dg2r), (db2, db2r), (dg1, dg1r), (db1, db1r)):
+            assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1.0), rep
