@@ -521,7 +521,30 @@ class _DecoderBackward:
         dwq.add([dhp], [x2], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
         return dx2
 
-    def self_attn(self, rec, layer, dx2):
+    def ffn_chain_ok(self, rec, layer, dx) -> bool:
+        """The FFN backward + the self-attention post-norm backward can run as ONE launch (csrc/chain_ffn_bwd.hip)."""
+        ffn = layer.ffn
+        return (_CHAIN and self.ct == BF16 and self.ad == torch.bfloat16 and self.spec.act == "relu" and isinstance(dx, torch.Tensor)
+                and rec["dr_fr"] is None and rec["dr_fi"] is None and rec["dr_sr"] is None and rec["h"].dtype == torch.float32
+                and ops.chain_ffn_ok(self.R, self.d, ffn.linear1.out_features))
+
+    def ffn_chain(self, rec, layer, dx):
+        """FFN sublayer + the self-attention post-norm in one launch: returns (dx1r, df), both the same gradient (no dropout);
+        queues the two weight-gradient products of the FFN exactly as ffn() does."""
+        ct, G, dwq, enc, dev = self.ct, self.G, self.dwq, self.enc, self.dev
+        ffn, sa = layer.ffn, layer.self_attn
+        flags = getattr(enc, "_chain_flags_bwd", None)
+        if flags is None or flags.device != dev:
+            flags = enc._chain_flags_bwd = ops.chain_flags(2048, dev)
+        dy, dhp, df = ops.chain_ffn_bwd(
+            dx.contiguous(), rec["x2"], rec["z"], ffn.norm.weight.detach(), rec["mean_f"][:1], rec["rstd_f"][:1], G(ffn.norm.weight),
+            G(ffn.norm.bias), ffn.linear2.weight.detach(), rec["h"], ffn.linear1.weight.detach(), rec["x1s"], rec["f"],
+            sa.norm.weight.detach(), rec["mean_s"], rec["rstd_s"], G(sa.norm.weight), G(sa.norm.bias), flags)
+        dwq.add([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
+        dwq.add([dhp], [rec["x2"]], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
+        return df, df
+
+    def self_attn(self, rec, layer, dx2, pre=None):
         """Self-attention sublayer: returns the three addends of d(x1s) (from q, from k, from v + residual)."""
         spec, ct, M, qpos, qmask, H, B = self.spec, self.ct, self.M, self.qpos, self.qmask, self.H, self.B
         Nq, d, R, dev, G, dwq, sb_queue = self.Nq, self.d, self.R, self.dev, self.G, self.dwq, self.sb_queue
@@ -542,10 +565,13 @@ class _DecoderBackward:
             Gb = [gb[:d], gb[d:2 * d], gb[2 * d:]]
             Wo, GWo, Gbo = sa.self_attn.out_proj.weight.detach(), G(sa.self_attn.out_proj.weight), G(sa.self_attn.out_proj.bias)
         x1s = rec["x1s"]     # the self-attention sublayer's input (x1, or the prompt cross-attention's output)
-        dx1r, df = _ln_bwd(x1s, [rec["f"]], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
-                           rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)],
-                           drop=rec["dr_sr"])
-        df = df[0]
+        if pre is not None:   # formed by the chain launch (ffn_chain)
+            dx1r, df = pre
+        else:
+            dx1r, df = _ln_bwd(x1s, [rec["f"]], [sa.norm.weight.detach()], [sa.norm.bias.detach()], sa.norm.eps, None, Nq,
+                               rec["mean_s"], rec["rstd_s"], dx2, [G(sa.norm.weight)], [G(sa.norm.bias)],
+                               drop=rec["dr_sr"])
+            df = df[0]
         fold = sa_fold_ok(ct, B, H, Nq, d, rec["dr_sa"], df, Wo)
         do_s = None
         if not fold:
@@ -653,8 +679,11 @@ class _DecoderBackward:
         rec = self.tape[a]
         i = rec["i"]
         layer = self.layers[i]
-        dx2 = self.ffn(rec, layer, dx)
-        dx1 = self.self_attn(rec, layer, dx2)
+        if self.ffn_chain_ok(rec, layer, dx):
+            dx1 = self.self_attn(rec, layer, None, pre=self.ffn_chain(rec, layer, dx))
+        else:
+            dx2 = self.ffn(rec, layer, dx)
+            dx1 = self.self_attn(rec, layer, dx2)
         if self.spec.prompt:
             dx1 = self.prompt_cross_attn(a, rec, dx1)
         dx = self.cross_attn(a, rec, dx1)
