@@ -470,6 +470,33 @@ typedef struct {
 } pq3d_chain_ffn_bwd_desc;
 int pq3d_chain_ffn_bwd(const pq3d_chain_ffn_bwd_desc* d, void* stream);
 
+/* The row-local steps between a layer's self-attention backward and its cross-attention backward in one launch
+ * (csrc/chain_sa_bwd.hip; bf16 mode, no residual dropout, no prompt memory): g3 = [dq Wq, dk Wk, dv Wv + aux2]; for m < M <= 3:
+ * dop_m = LN_m'(x + op_m; c_m ((g3_0 + g3_1) + g3_2)), dxr = sum_m dop_m, d gamma_m / d beta_m accumulated; do_m = dop_m Wo_m (bf16)
+ * = pq3d_gemm (transB, "+ aux"), pq3d_add_ln_bwd (merged), pq3d_gemm (transB) -- the same bits at M = 3.  R <= 2048, d = 256. */
+typedef struct {
+  int32_t R, d, M, rows_per_scene;
+  const float* dqkv[3];         /* [R, d] gradients of q, k, v */
+  const float* Wl[3];           /* [d, d] Wq, Wk, Wv */
+  const float* aux2;            /* [R, d] added to the v part */
+  float* g3[3];                 /* [R, d] out */
+  const float* x;               /* [R, d] layer input (residual of the merged LayerNorm) */
+  const float* op[3];           /* [R, d] forward out-projections */
+  const float* gamma[3];
+  const float* mean;            /* [M, R] */
+  const float* rstd;
+  const float* coef;            /* [M, R / rows_per_scene] or NULL (1 / M) */
+  float* dop[3];                /* [R, d] out */
+  float* dxr;                   /* [R, d] out */
+  float* dgamma[3];             /* [d] accumulated */
+  float* dbeta[3];
+  const float* Wo[3];           /* [d, d] */
+  void* do_all[3];              /* [R, d] bf16 out */
+  uint32_t* flags;
+  int32_t* err;
+} pq3d_chain_sa_bwd_desc;
+int pq3d_chain_sa_bwd(const pq3d_chain_sa_bwd_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small memory-bound kernels.
  * ------------------------------------------------------------------------------------------------ */

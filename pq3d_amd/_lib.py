@@ -177,6 +177,14 @@ class ChainFfnBwdDesc(C.Structure):
                                           "f", "g1", "mean1", "rstd1", "dg1", "db1", "df", "flags", "err")]
 
 
+class ChainSaBwdDesc(C.Structure):
+    _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("M", C.c_int32), ("rows_per_scene", C.c_int32),
+                ("dqkv", C.c_void_p * 3), ("Wl", C.c_void_p * 3), ("aux2", C.c_void_p), ("g3", C.c_void_p * 3), ("x", C.c_void_p),
+                ("op", C.c_void_p * 3), ("gamma", C.c_void_p * 3), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("coef", C.c_void_p),
+                ("dop", C.c_void_p * 3), ("dxr", C.c_void_p), ("dgamma", C.c_void_p * 3), ("dbeta", C.c_void_p * 3),
+                ("Wo", C.c_void_p * 3), ("do_all", C.c_void_p * 3), ("flags", C.c_void_p), ("err", C.c_void_p)]
+
+
 _lib = None
 
 _SIGS = {
@@ -189,6 +197,7 @@ _SIGS = {
     "pq3d_chain_ffn_fwd": [C.POINTER(ChainFfnDesc), C.c_void_p],
     "pq3d_chain_ca_fwd": [C.POINTER(ChainCaDesc), C.c_void_p],
     "pq3d_chain_ffn_bwd": [C.POINTER(ChainFfnBwdDesc), C.c_void_p],
+    "pq3d_chain_sa_bwd": [C.POINTER(ChainSaBwdDesc), C.c_void_p],
     "pq3d_mask_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_mask_row_all": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_attn_resident": [C.c_int],

@@ -310,6 +310,103 @@ PQ_DEV void proj_3x256(const Ctx& c, unsigned char* smem, int j, int ng, int m0,
   }
 }
 
+// ---- the backward's analogue of proj_3x256: out_g = A_g W_g (+ aux_g) with W_g [256 k][256 n] row-major (input gradients dX = dY W;
+// pq3d_gemm's transB layout), single-bf16 operands.  Member j < 2 ng owns group j / 2 and columns [128 (j & 1), + 128); the weight
+// in two [128 k][128 n] slabs read through the transposing LDS load; wave = 16 rows x 32 columns per row tile.
+constexpr int TPK = 128, TPN = 128, TPLD = TPN + 8, TPCL = TPN + 4;
+template <int NRT> constexpr size_t tproj_lds() {
+  const size_t b = (size_t)TPK * TPLD * 2, ct = (size_t)TM * TPCL * 4;
+  return (size_t)NRT * TM * LDR * 2 + (b > ct ? b : ct);
+}
+PQ_DEV void tproj_issue_w(const Ctx& c, int j, int ng, const float* const* W, RawB (&wb)[2]) {
+  if (j >= 2 * ng) return;
+  const int g = j >> 1, n0 = (j & 1) * TPN;
+#pragma unroll
+  for (int l = 0; l < 2; ++l)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = c.tid + i * CT;   // [128 k][16 chunks of 8 n]
+      load8<false>(W[g], (long)(l * TPK + (ch >> 4)) * D + n0 + (ch & 15) * 8, wb[l].v[i]);
+    }
+}
+PQ_DEV u32x4 tp_km_frag(const bf16_t* tile, int ldk, int r0, int ks, int li, int lg) {   // gemm_common.h's km_frag
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4s_t lds_v4s_t;
+  const bf16_t* p0 = tile + (ks * 32 + 8 * lg + (li >> 2)) * ldk + r0 + 4 * (li & 3);
+  const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)p0);
+  const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t*)(p0 + 4 * ldk));
+  const u32x2 lo = __builtin_bit_cast(u32x2, a), hi = __builtin_bit_cast(u32x2, b);
+  return (u32x4){lo.x, lo.y, hi.x, hi.y};
+}
+template <int NRT, bool SC1A, typename TO>
+PQ_DEV void tproj_3x256(const Ctx& c, unsigned char* smem, int j, int ng, int m0, int R, const float* const* A, const float* const* aux,
+                        TO* const* out, RawB (&wb)[2]) {
+  if (j >= 2 * ng) return;   // (uniform: the whole workgroup)
+  const int g = j >> 1, n0 = (j & 1) * TPN;
+  bf16_t* const Ap = (bf16_t*)smem;                       // [NRT][32][LDR]: A as bf16, whole K
+  bf16_t* const Bp = Ap + NRT * TM * LDR;                 // [128 k][TPLD]: one k slab of W
+  float* const Ct = (float*)Bp;
+  const int wr = (c.wave >> 2) * 16, wc = (c.wave & 3) * 32;
+#pragma unroll
+  for (int t = 0; t < NRT; ++t) {
+    RawA ra;
+    issue_a<SC1A>(c, ra, A[g], D, m0 + t * TM, R, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = c.tid + i * CT;
+      *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] = pack_frag<bf16_t>(ra.v[i]);
+    }
+  }
+  f32x4 acc[NRT][2];
+#pragma unroll
+  for (int t = 0; t < NRT; ++t) { acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    if (l > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = c.tid + i * CT;
+      *(u32x4*)&Bp[(ch >> 4) * TPLD + (ch & 15) * 8] = pack_frag<bf16_t>(wb[l].v[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < TPK / 32; ++ks) {
+      u32x4 bh[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) bh[nb] = tp_km_frag(Bp, TPLD, wc + nb * 16, ks, c.li, c.lg);
+#pragma unroll
+      for (int t = 0; t < NRT; ++t) {
+        const u32x4 ah = *(const u32x4*)&Ap[t * TM * LDR + (wr + c.li) * LDR + l * TPK + ks * 32 + c.lg * 8];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) Mma<bf16_t>::mma(acc[t][nb], ah, bh[nb]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NRT; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ct[(wr + c.lg * 4 + r) * TPCL + wc + nb * 16 + c.li] = (acc[t][nb][r] + 0.f) * 1.f;
+    __syncthreads();
+    const int orow = c.tid >> 4, row = m0 + t * TM + orow;
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd) {
+      const int col = qd * 64 + (c.tid & 15) * 4;
+      float4 v = *(const float4*)&Ct[orow * TPCL + col];
+      if (row < R) {
+        if (aux && aux[g]) {
+          const float4 a = *(const float4*)(aux[g] + (long)row * D + n0 + col);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if constexpr (sizeof(TO) == 4) *(float4*)((float*)out[g] + (long)row * D + n0 + col) = v;
+        else *(u32x2*)((bf16_t*)out[g] + (long)row * D + n0 + col) = (u32x2){pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};
+      }
+    }
+  }
+}
+
 // in-kernel timeline (probe builds only, tools/probes/chain_timeline.py): thread 0 of workgroup 0 stamps the 100 MHz clock
 #ifdef PQ3D_CHAIN_TL
 #define CH_TL(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) ((long long*)d.err)[i] = wall_clock64(); } while (0)

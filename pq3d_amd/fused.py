@@ -521,6 +521,11 @@ class _DecoderBackward:
         dwq.add([dhp], [x2], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
         return dx2
 
+    def sa_chain_ok(self, rec) -> bool:
+        """q / k / v input gradients + merged LayerNorm backward + cross-attention d O as one launch (csrc/chain_sa_bwd.hip)."""
+        return (_CHAIN and self.ct == BF16 and self.ad == torch.bfloat16 and not self.spec.prompt and rec["dr_cr"] is None
+                and ops.chain_ca_ok(self.R, self.d, self.M) and rec["op_all"].dtype == torch.float32)
+
     def ffn_chain_ok(self, rec, layer, dx) -> bool:
         """The FFN backward + the self-attention post-norm backward can run as ONE launch (csrc/chain_ffn_bwd.hip)."""
         ffn = layer.ffn
@@ -591,9 +596,25 @@ class _DecoderBackward:
         # d(x1 + qpos) from q and k, d(x1) from v (+ the residual-branch gradient): three independent products, ONE
         # launch; their sum is formed by the consumer (the next LayerNorm backward reads three addends) instead of
         # by a second, dependent "+ aux" launch
-        g3 = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
-        L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1], dqkv[2]], B=list(Wl), Cs=[g3[0], g3[1], g3[2]],
-               aux=[None, None, dx1r], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+        self._sa_chain = None
+        if self.sa_chain_ok(rec):
+            # these products, the merged cross-attention post-norm backward and the cross-attention d O in ONE launch
+            # (csrc/chain_sa_bwd.hip); cross_attn() picks the results up
+            cl = self.cas[rec["i"]]
+            enc = self.enc
+            flags = getattr(enc, "_chain_flags_sab", None)
+            if flags is None or flags.device != dev:
+                flags = enc._chain_flags_sab = ops.chain_flags(2048, dev)
+            a_ = self._cur_app
+            g3, dop, dxr, do_all = ops.chain_sa_bwd(
+                dqkv, [w_.contiguous() for w_ in Wl], dx1r, rec["x_in"], rec["op_all"], [ca.norm.weight.detach() for ca in cl],
+                rec["mean_c"], rec["rstd_c"], self.coef[a_] if self.coef is not None else None, Nq, [G(ca.norm.weight) for ca in cl],
+                [G(ca.norm.bias) for ca in cl], [ca.multihead_attn.out_proj.weight.detach() for ca in cl], flags)
+            self._sa_chain = (dxr, dop, do_all)
+        else:
+            g3 = torch.empty(3, B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1], dqkv[2]], B=list(Wl), Cs=[g3[0], g3[1], g3[2]],
+                   aux=[None, None, dx1r], act_grad="add", ct=ct, lda=d, ldb=d, ldc=d, transB=True)
         dqpos_parts += [g3[0], g3[1]]
         dx1 = [g3[0], g3[1], g3[2]]
         dwq.add([dqkv[0], dqkv[1], dqkv[2]], [x1s] * 3, [qpos, qpos, None], GW, ct, Gb)
@@ -640,14 +661,19 @@ class _DecoderBackward:
         i, x_in = rec["i"], rec["x_in"]
         # ---------------- cross-attention backward (M memories per launch)
         cl = cas[i]
-        dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
-                           [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef[a] if coef is not None else None,
-                           Nq, rec["mean_c"], rec["rstd_c"],
-                           dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl], drop=rec["dr_cr"],
-                           dx_zeroed=dxr_zero[a] if dxr_zero is not None else None)
-        do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
-        L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
-               Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
+        pre = getattr(self, "_sa_chain", None)
+        self._sa_chain = None
+        if pre is not None:   # formed by self_attn()'s chain launch
+            dxr, dop, do_all = pre
+        else:
+            dxr, dop = _ln_bwd(x_in, [rec["op_all"][m] for m in range(M)], [ca.norm.weight.detach() for ca in cl],
+                               [ca.norm.bias.detach() for ca in cl], cl[0].norm.eps, coef[a] if coef is not None else None,
+                               Nq, rec["mean_c"], rec["rstd_c"],
+                               dx1, [G(ca.norm.weight) for ca in cl], [G(ca.norm.bias) for ca in cl], drop=rec["dr_cr"],
+                               dx_zeroed=dxr_zero[a] if dxr_zero is not None else None)
+            do_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=[ca.multihead_attn.out_proj.weight.detach() for ca in cl],
+                   Cs=[do_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d, transB=True)
         dwq.add([dop[m] for m in range(M)], [rec["o_all"][m] for m in range(M)], None,
                 [G(ca.multihead_attn.out_proj.weight) for ca in cl], ct,
                 [G(ca.multihead_attn.out_proj.bias) for ca in cl])
@@ -679,6 +705,7 @@ class _DecoderBackward:
         rec = self.tape[a]
         i = rec["i"]
         layer = self.layers[i]
+        self._cur_app = a
         if self.ffn_chain_ok(rec, layer, dx):
             dx1 = self.self_attn(rec, layer, None, pre=self.ffn_chain(rec, layer, dx))
         else:

@@ -1735,6 +1735,40 @@ def chain_ffn_bwd(dx, x2, z, g2, mean2, rstd2, dg2, db2, W2, h, W1, x1s, f, g1, 
     return dy, dhp, df
 
 
+def chain_sa_bwd(dqkv, Wl, aux2, x, op_all, gammas, mean, rstd, coef, rows_per_scene, dgammas, dbetas, Wos, flags):
+    """dqkv [3, ..., d] fp32 -> (g3 [3, ..., d], dop [M, ..., d], dxr, do_all [M, ..., d] bf16); d gamma / d beta accumulated."""
+    d = x.shape[-1]
+    R, M = x.numel() // d, op_all.shape[0]
+    dev = x.device
+    g3 = torch.empty(3, *x.shape, dtype=torch.float32, device=dev)
+    dop = torch.empty(M, *x.shape, dtype=torch.float32, device=dev)
+    dxr = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    do_all = torch.empty(M, *x.shape, dtype=torch.bfloat16, device=dev)
+    err = _CHAIN_ERR.get(dev)
+    if err is None:
+        err = _CHAIN_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    c = L.ChainSaBwdDesc()
+    c.R, c.d, c.M, c.rows_per_scene = R, d, M, rows_per_scene
+    for g in range(3):
+        for n, t in (("dqkv", dqkv[g]), ("Wl", Wl[g]), ("g3", g3[g])):
+            assert t.is_contiguous() and t.dtype == torch.float32, n
+            getattr(c, n)[g] = L.ptr(t)
+    for m in range(M):
+        for n, t in (("op", op_all[m]), ("gamma", gammas[m]), ("dop", dop[m]), ("dgamma", dgammas[m]), ("dbeta", dbetas[m]), ("Wo", Wos[m]),
+                     ("do_all", do_all[m])):
+            assert t.is_contiguous() and (n == "do_all" or t.dtype == torch.float32), n
+            getattr(c, n)[m] = L.ptr(t)
+    for t in (aux2, x, mean, rstd):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    if coef is not None:
+        assert coef.is_contiguous() and coef.dtype == torch.float32
+    c.aux2, c.x, c.mean, c.rstd, c.coef, c.dxr, c.flags, c.err = map(L.ptr, (aux2, x, mean, rstd, coef, dxr, flags, err))
+    fl = 2.0 * R * d * d * (3 + M)
+    nb = 4.0 * (R * d * (8 + 3 * M) + (3 + M) * d * d) + 2.0 * M * R * d
+    L.check(timed("pq3d_chain_sa_bwd", f"R{R}d{d}M{M}", fl, nb, L.lib().pq3d_chain_sa_bwd, C.byref(c), L.stream()), "pq3d_chain_sa_bwd")
+    return g3, dop, dxr, do_all
+
+
 def chain_error(device) -> bool:
     """True if a hand-off wait of any chain launch on `device` gave up (synchronises)."""
     err = _CHAIN_ERR.get(device)

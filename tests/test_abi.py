@@ -56,6 +56,8 @@ int main(void) {
          offsetof(pq3d_chain_ca_desc, err));
   printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_ffn_bwd_desc), offsetof(pq3d_chain_ffn_bwd_desc, F), offsetof(pq3d_chain_ffn_bwd_desc, dx),
          offsetof(pq3d_chain_ffn_bwd_desc, err));
+  printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_sa_bwd_desc), offsetof(pq3d_chain_sa_bwd_desc, dqkv), offsetof(pq3d_chain_sa_bwd_desc, coef),
+         offsetof(pq3d_chain_sa_bwd_desc, err));
   return 0;
 }''')
     exe = tmp_path / "layout"
@@ -71,6 +73,8 @@ int main(void) {
     assert rows[4] == [ctypes.sizeof(Ca), Ca.eps.offset, Ca.o.offset, Ca.err.offset]
     Cb = _lib.ChainFfnBwdDesc
     assert rows[5] == [ctypes.sizeof(Cb), Cb.F.offset, Cb.dx.offset, Cb.err.offset]
+    Cs = _lib.ChainSaBwdDesc
+    assert rows[6] == [ctypes.sizeof(Cs), Cs.dqkv.offset, Cs.coef.offset, Cs.err.offset]
 
 
 def test_argument_errors_are_reported(lib):

@@ -159,3 +159,51 @@ def test_chain_ffn_bwd_against_separate_launches(B, Nq):
         assert (df - dfl[0]).abs().max().item() <= 2e-5 * sc and (df - dx1r).abs().max().item() <= 2e-5 * sc
         for a, b in ((dg2, dg2r), (db2, db2r), (dg1, dg1r), (db1, db1r)):
             assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1.0), rep
+
+
+@pytest.mark.parametrize("B,Nq,M,with_coef", [(8, 100, 3, False), (8, 100, 3, True), (16, 100, 3, False), (3, 37, 2, False), (1, 1, 1, False)])
+def test_chain_sa_bwd_against_separate_launches(B, Nq, M, with_coef):
+    from pq3d_amd import _lib as L, fused, ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 100 + Nq + M)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    d, R = 256, B * Nq
+    coef = None
+    if with_coef:
+        coef = torch.rand(M, B, generator=g).to(dev)
+        coef = (coef / coef.sum(0, keepdim=True)).contiguous()
+    x, qpos = r(B, Nq, d), r(B, Nq, d)
+    o_all = r(M, B, Nq, d).bfloat16()
+    Wos, bos = [r(d, d, sc=0.06) for _ in range(M)], [r(d, sc=0.1) for _ in range(M)]
+    gam, bet = [1 + r(d, sc=0.1) for _ in range(M)], [r(d, sc=0.1) for _ in range(M)]
+    Wl, bl = [r(d, d, sc=0.06) for _ in range(3)], [r(d, sc=0.1) for _ in range(3)]
+    op_all, x1, mean, rstd, qkv = _three_launches(o_all, Wos, bos, x, gam, bet, 1e-5, coef, Nq, qpos, Wl, bl)
+    dqkv, dx1r = r(3, B, Nq, d), r(B, Nq, d)
+    # separate launches
+    g3r = torch.empty(3, B, Nq, d, device=dev)
+    L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1], dqkv[2]], B=list(Wl), Cs=[g3r[0], g3r[1], g3r[2]], aux=[None, None, dx1r], act_grad="add",
+           ct=L.BF16, lda=d, ldb=d, ldc=d, transB=True)
+    dgr, dbr = [torch.zeros(d, device=dev) for _ in range(M)], [torch.zeros(d, device=dev) for _ in range(M)]
+    dxz = torch.zeros(B, Nq, d, device=dev)
+    dxr_ref, dop_ref = fused._ln_bwd(x, [op_all[m] for m in range(M)], gam, bet, 1e-5, coef, Nq, mean, rstd, [g3r[0], g3r[1], g3r[2]],
+                                     dgr, dbr, dx_zeroed=dxz if M > 1 else None)
+    do_ref = torch.empty(M, B, Nq, d, dtype=torch.bfloat16, device=dev)
+    L.gemm(M=R, N=d, K=d, A=[dop_ref[m] for m in range(M)], B=list(Wos), Cs=[do_ref[m] for m in range(M)], ct=L.BF16, lda=d, ldb=d, ldc=d,
+           transB=True)
+    flags = ops.chain_flags(R, dev)
+    exact = M == 3 and R >= 512   # the merged kernel (one row order); otherwise the reference sums dx with atomics
+    for rep in range(3):
+        dg, db = [torch.zeros(d, device=dev) for _ in range(M)], [torch.zeros(d, device=dev) for _ in range(M)]
+        g3, dop, dxr, do_all = ops.chain_sa_bwd(dqkv, Wl, dx1r, x, op_all, gam, mean, rstd, coef, Nq, dg, db, Wos, flags)
+        torch.cuda.synchronize()
+        assert not ops.chain_error(dev)
+        assert torch.equal(g3.view(torch.int32), g3r.view(torch.int32))
+        assert torch.equal(dop.view(torch.int32), dop_ref.view(torch.int32))
+        assert torch.equal(do_all.view(torch.int16), do_ref.view(torch.int16))
+        if exact:
+            assert torch.equal(dxr.view(torch.int32), dxr_ref.view(torch.int32))
+        else:
+            assert (dxr - dxr_ref).abs().max().item() <= 1e-5 * max(dxr_ref.abs().max().item(), 1e-6)
+        for m in range(M):
+            assert (dg[m] - dgr[m]).abs().max().item() <= 1e-4 * max(dgr[m].abs().max().item(), 1.0)
+            assert (db[m] - dbr[m]).abs().max().item() <= 1e-4 * max(dbr[m].abs().max().item(), 1.0)
