@@ -23,6 +23,11 @@ struct Ctx {
 };
 
 PQ_DEV void split_hi_lo(const float* v, u32x4& hi, u32x4& lo) {
+#ifdef PQ3D_CHAIN_NOSPLIT   // timing probe only (wrong numbers): what the conversion costs
+  hi = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  lo = (u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+  return;
+#endif
   hi = pack_frag<bf16_t>(v);
   float w[8];
 #pragma unroll

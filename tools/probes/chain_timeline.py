@@ -17,7 +17,7 @@ for _ in range(200):
     ops.chain_ffn_fwd(*args, flags)
 torch.cuda.synchronize()
 t = ops._CHAIN_ERR[dev].view(torch.int64).cpu().tolist()[:10]
-names = ["out-projection tile", "hand-off 1", "LayerNorm 1", "hand-off 2", "FFN1 (4 tiles)", "hand-off 3", "FFN2 (2 units x 2 chunks)", "hand-off 4", "LayerNorm 2"]
+names = ["out-projection tile", "hand-off 1", "LayerNorm 1", "hand-off 2", "linear1 (4 k slabs)", "hand-off 3", "linear2 (4 k slabs)", "hand-off 4", "LayerNorm 2"]
 for n, a, b in zip(names, t[:-1], t[1:]):
     print(f"  {n:28s} {(b - a) * 0.01:6.2f} us")
 print(f"  total in-kernel {(t[9] - t[0]) * 0.01:.2f} us")
