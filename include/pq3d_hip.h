@@ -467,6 +467,7 @@ typedef struct {
   float* df;                    /* [R, d] out: g1 */
   uint32_t* flags;
   int32_t* err;
+  float* lnws;                  /* >= 32 * 8 * 1024 floats of scratch (the groups' LayerNorm parameter-gradient partials) */
 } pq3d_chain_ffn_bwd_desc;
 int pq3d_chain_ffn_bwd(const pq3d_chain_ffn_bwd_desc* d, void* stream);
 
@@ -494,6 +495,7 @@ typedef struct {
   void* do_all[3];              /* [R, d] bf16 out */
   uint32_t* flags;
   int32_t* err;
+  float* lnws;                  /* >= 32 * 8 * 1536 floats of scratch */
 } pq3d_chain_sa_bwd_desc;
 int pq3d_chain_sa_bwd(const pq3d_chain_sa_bwd_desc* d, void* stream);
 

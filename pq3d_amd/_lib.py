@@ -174,7 +174,7 @@ class ChainCaDesc(C.Structure):
 class ChainFfnBwdDesc(C.Structure):
     _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("dx", "x2", "z", "g2", "mean2", "rstd2", "dg2", "db2", "dy", "W2", "h", "dhp", "W1", "part", "x1s",
-                                          "f", "g1", "mean1", "rstd1", "dg1", "db1", "df", "flags", "err")]
+                                          "f", "g1", "mean1", "rstd1", "dg1", "db1", "df", "flags", "err", "lnws")]
 
 
 class ChainSaBwdDesc(C.Structure):
@@ -182,7 +182,7 @@ class ChainSaBwdDesc(C.Structure):
                 ("dqkv", C.c_void_p * 3), ("Wl", C.c_void_p * 3), ("aux2", C.c_void_p), ("g3", C.c_void_p * 3), ("x", C.c_void_p),
                 ("op", C.c_void_p * 3), ("gamma", C.c_void_p * 3), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("coef", C.c_void_p),
                 ("dop", C.c_void_p * 3), ("dxr", C.c_void_p), ("dgamma", C.c_void_p * 3), ("dbeta", C.c_void_p * 3),
-                ("Wo", C.c_void_p * 3), ("do_all", C.c_void_p * 3), ("flags", C.c_void_p), ("err", C.c_void_p)]
+                ("Wo", C.c_void_p * 3), ("do_all", C.c_void_p * 3), ("flags", C.c_void_p), ("err", C.c_void_p), ("lnws", C.c_void_p)]
 
 
 _lib = None

@@ -412,6 +412,41 @@ PQ_DEV void tproj_3x256(const Ctx& c, unsigned char* smem, int j, int ng, int m0
   }
 }
 
+// ---- LayerNorm parameter gradients of a group: every member leaves its column sums ([2][256] floats per LayerNorm) in the
+// group's scratch; behind the next hand-off member j adds up columns [32 j, 32 j + 32) of all 8 members and issues the atomics --
+// 512 per group and LayerNorm instead of 512 per WORKGROUP (all of them on the same 512 addresses: measured 5.3 us of a 25.5 us
+// backward chain at config 2)
+PQ_DEV void ln_partials_store(const Ctx& c, float* red, const float (&dg)[4], const float (&db)[4], float* slot) {   // slot: [512] of this member
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    red[c.wave * D + c.lane * 4 + k] = dg[k];
+    red[8 * D + c.wave * D + c.lane * 4 + k] = db[k];
+  }
+  __syncthreads();
+  {
+    const int col = c.tid & (D - 1), kind = c.tid >> 8;   // 512 threads: gamma columns, then beta columns
+    float sv = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sv += red[kind * 8 * D + w * D + col];
+    slot[kind * D + col] = sv;
+  }
+  __syncthreads();
+}
+// group: [8 members][stride floats]; off: this LayerNorm's [512] inside a member's record
+PQ_DEV void ln_partials_reduce(const Ctx& c, int j, const float* group, int stride, int off, float* dgamma, float* dbeta) {
+  if (c.tid < 64) {
+    const int col = 32 * j + (c.tid & 31), kind = c.tid >> 5;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)group, 0, 0x7ffffff0, 0x00020000);
+    float sv = 0.f;
+#pragma unroll
+    for (int m = 0; m < G; ++m)
+      sv += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (m * stride + off + kind * D + col) * 4, 0, 16));
+#ifndef PQ3D_CHAIN_NOATOM   // (timing probe: what the parameter-gradient atomics cost)
+    unsafeAtomicAdd(kind ? &dbeta[col] : &dgamma[col], sv);
+#endif
+  }
+}
+
 // in-kernel timeline (probe builds only, tools/probes/chain_timeline.py): thread 0 of workgroup 0 stamps the 100 MHz clock
 #ifdef PQ3D_CHAIN_TL
 #define CH_TL(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) ((long long*)d.err)[i] = wall_clock64(); } while (0)

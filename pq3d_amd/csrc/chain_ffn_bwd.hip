@@ -51,24 +51,6 @@ PQ_DEV void ln_bwd_row(const float (&v)[4], const float (&dyr)[4], const float (
 #pragma unroll
   for (int j = 0; j < 4; ++j) g[j] = rstd * (dz[j] - s1 - xh[j] * s2);
 }
-// the workgroup's parameter-gradient partials -> one atomic per column (red: [2][8][256] floats of LDS)
-PQ_DEV void ln_param_grads(const Ctx& c, float* red, const float (&dg)[4], const float (&db)[4], float* dgamma, float* dbeta) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    red[c.wave * D + c.lane * 4 + j] = dg[j];
-    red[8 * D + c.wave * D + c.lane * 4 + j] = db[j];
-  }
-  __syncthreads();
-  if (c.tid < D) {
-    float sg = 0.f, sb = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) { sg += red[w * D + c.tid]; sb += red[8 * D + w * D + c.tid]; }
-    unsafeAtomicAdd(&dgamma[c.tid], sg);
-    unsafeAtomicAdd(&dbeta[c.tid], sb);
-  }
-  __syncthreads();
-}
-
 template <int NRT>
 __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_bwd_desc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
@@ -84,6 +66,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
   unsigned* const group = d.flags + (long)grp * G * 16;
   unsigned* const mine = group + j * 16;
   const unsigned v0 = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* const lnws = d.lnws + (long)grp * G * 1024;   // [8 members][2 LayerNorms][gamma 256 | beta 256]
   const long lrow = m0 + 4 * NRT * j + c.wave;
   const bool lnw = c.wave < 4 * NRT && lrow < R;
   const long lbase = lrow * D + c.lane * 4;
@@ -114,9 +97,10 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
       ln_bwd_row(v, dyr, gam, d.mean2[lrow], d.rstd2[lrow], g, dg, db);
       *(float4*)(d.dy + lbase) = make_float4(g[0], g[1], g[2], g[3]);
     }
-    ln_param_grads(c, (float*)ch_smem, dg, db, d.dg2, d.db2);
+    ln_partials_store(c, (float*)ch_smem, dg, db, lnws + j * 1024);
   }
   handoff(c, mine, group, v0 + 1, d.err);
+  ln_partials_reduce(c, j, lnws, 1024, 0, d.dg2, d.db2);   // LayerNorm 2's parameter gradients: 64 atomics per member
   // ---- 2. dhp = [h > 0] (g2 W2): member j owns hidden columns [256 j, + 256); wave = 16 rows x 64 columns per row tile
   {
     bf16_t* const Ap = (bf16_t*)ch_smem;                 // [NRT][32][LDR]: g2 as bf16, whole K = 256
@@ -275,9 +259,10 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
       ln_bwd_row(v, dyr, gam, d.mean1[lrow], d.rstd1[lrow], g, dg, db);
       *(float4*)(d.df + lbase) = make_float4(g[0], g[1], g[2], g[3]);
     }
-    ln_param_grads(c, (float*)ch_smem, dg, db, d.dg1, d.db1);
+    ln_partials_store(c, (float*)ch_smem, dg, db, lnws + j * 1024 + 512);
   }
-  handoff(c, mine, group, v0 + 4, d.err);   // (keeps the members' flag words in step)
+  handoff(c, mine, group, v0 + 4, d.err);
+  ln_partials_reduce(c, j, lnws, 1024, 512, d.dg1, d.db1);
 }
 
 }  // namespace
@@ -292,7 +277,7 @@ extern "C" int pq3d_chain_ffn_bwd(const pq3d_chain_ffn_bwd_desc* dp, void* strea
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_ffn_bwd: more than 2048 rows (the groups would not all be resident)");
   const void* ps[] = {d.dx, d.x2, d.z, d.g2, d.mean2, d.rstd2, d.dg2, d.db2, d.dy, d.W2, d.h, d.dhp, d.W1, d.part, d.x1s, d.f, d.g1, d.mean1,
-                      d.rstd1, d.dg1, d.db1, d.df, d.flags};
+                      d.rstd1, d.dg1, d.db1, d.df, d.flags, d.lnws};
   for (const void* p : ps) PQ_CHECK_ARG(p != nullptr, "pq3d_chain_ffn_bwd: null pointer");
   const void* al[] = {d.dx, d.x2, d.z, d.g2, d.dy, d.W2, d.h, d.dhp, d.W1, d.part, d.x1s, d.f, d.g1, d.df};
   for (const void* p : al) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_chain_ffn_bwd: operands must be 16-byte aligned");

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(CT) void chain_sa_bwd_kernel(const pq3d_chain_sa_bw
   unsigned* const group = d.flags + (long)grp * G * 16;
   unsigned* const mine = group + j * 16;
   const unsigned v0 = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* const lnws = d.lnws + (long)grp * G * 1536;   // [8 members][3 branches][gamma 256 | beta 256]
 
   RawB w1[2], w3[2];
   tproj_issue_w(c, j, 3, d.Wl, w1);
@@ -91,29 +92,13 @@ __global__ __launch_bounds__(CT) void chain_sa_bwd_kernel(const pq3d_chain_sa_bw
       }
       *(float4*)(d.dxr + base) = make_float4(gsum[0], gsum[1], gsum[2], gsum[3]);
     }
-    // parameter gradients: one branch after the other through LDS, one atomic per column and workgroup
-    float* const red = (float*)ch_smem;   // [2][8][256]
+    // parameter gradients: the member's column sums of every branch into the group's scratch (reduced behind the hand-off)
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      if (m < M) {   // uniform
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          red[c.wave * D + c.lane * 4 + k] = dg[m][k];
-          red[8 * D + c.wave * D + c.lane * 4 + k] = db[m][k];
-        }
-        __syncthreads();
-        if (c.tid < D) {
-          float sg = 0.f, sb = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) { sg += red[w * D + c.tid]; sb += red[8 * D + w * D + c.tid]; }
-          unsafeAtomicAdd(&d.dgamma[m][c.tid], sg);
-          unsafeAtomicAdd(&d.dbeta[m][c.tid], sb);
-        }
-        __syncthreads();
-      }
-    }
+    for (int m = 0; m < 3; ++m)
+      if (m < M) ln_partials_store(c, (float*)ch_smem, dg[m], db[m], lnws + j * 1536 + m * 512);   // uniform
   }
   handoff(c, mine, group, v0 + 2, d.err);
+  for (int m = 0; m < M; ++m) ln_partials_reduce(c, j, lnws, 1536, m * 512, d.dgamma[m], d.dbeta[m]);
   // ---- 3. d O of the cross-attention: do_m = dop_m Wo_m (bf16)
   {
     bf16_t* out[3] = {(bf16_t*)d.do_all[0], (bf16_t*)d.do_all[1], (bf16_t*)d.do_all[2]};
@@ -135,7 +120,7 @@ extern "C" int pq3d_chain_sa_bwd(const pq3d_chain_sa_bwd_desc* dp, void* stream)
   const int nrt = row_tiles * G <= 256 ? 1 : 2;
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_sa_bwd: more than 2048 rows (the groups would not all be resident)");
-  PQ_CHECK_ARG(d.x && d.aux2 && d.mean && d.rstd && d.dxr && d.flags && ((((uintptr_t)d.x) | ((uintptr_t)d.aux2) | ((uintptr_t)d.dxr)) & 15) == 0,
+  PQ_CHECK_ARG(d.x && d.aux2 && d.mean && d.rstd && d.dxr && d.flags && d.lnws && ((((uintptr_t)d.x) | ((uintptr_t)d.aux2) | ((uintptr_t)d.dxr)) & 15) == 0,
                "pq3d_chain_sa_bwd: null / unaligned pointer");
   for (int g = 0; g < 3; ++g)
     PQ_CHECK_ARG(d.dqkv[g] && d.Wl[g] && d.g3[g] && ((((uintptr_t)d.dqkv[g]) | ((uintptr_t)d.Wl[g]) | ((uintptr_t)d.g3[g])) & 15) == 0,

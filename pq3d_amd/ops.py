@@ -1631,6 +1631,15 @@ def chain_flags(R: int, device) -> torch.Tensor:
 
 
 _CHAIN_ERR = {}
+_CHAIN_WS = {}
+
+
+def _chain_ws(dev) -> torch.Tensor:
+    """Scratch of the backward chains (the groups' LayerNorm parameter-gradient partials): written and read inside one launch."""
+    w = _CHAIN_WS.get(dev)
+    if w is None:
+        w = _CHAIN_WS[dev] = torch.empty(32 * 8 * 1536, dtype=torch.float32, device=dev)
+    return w
 
 
 def chain_ffn_ok(R: int, d: int, F_: int) -> bool:
@@ -1726,7 +1735,7 @@ def chain_ffn_bwd(dx, x2, z, g2, mean2, rstd2, dg2, db2, W2, h, W1, x1s, f, g1, 
     c.R, c.d, c.F = R, d, F_
     for n, t in (("dx", dx), ("x2", x2), ("z", z), ("g2", g2), ("mean2", mean2), ("rstd2", rstd2), ("dg2", dg2), ("db2", db2), ("dy", dy),
                  ("W2", W2), ("h", h), ("dhp", dhp), ("W1", W1), ("part", part), ("x1s", x1s), ("f", f), ("g1", g1), ("mean1", mean1),
-                 ("rstd1", rstd1), ("dg1", dg1), ("db1", db1), ("df", df), ("flags", flags), ("err", err)):
+                 ("rstd1", rstd1), ("dg1", dg1), ("db1", db1), ("df", df), ("flags", flags), ("err", err), ("lnws", _chain_ws(dev))):
         assert t.is_contiguous() and (n in ("flags", "err", "dhp") or t.dtype == torch.float32), n
         setattr(c, n, L.ptr(t))
     fl = 2.0 * R * d * 2 * F_
@@ -1763,6 +1772,7 @@ def chain_sa_bwd(dqkv, Wl, aux2, x, op_all, gammas, mean, rstd, coef, rows_per_s
     if coef is not None:
         assert coef.is_contiguous() and coef.dtype == torch.float32
     c.aux2, c.x, c.mean, c.rstd, c.coef, c.dxr, c.flags, c.err = map(L.ptr, (aux2, x, mean, rstd, coef, dxr, flags, err))
+    c.lnws = L.ptr(_chain_ws(dev))
     fl = 2.0 * R * d * d * (3 + M)
     nb = 4.0 * (R * d * (8 + 3 * M) + (3 + M) * d * d) + 2.0 * M * R * d
     L.check(timed("pq3d_chain_sa_bwd", f"R{R}d{d}M{M}", fl, nb, L.lib().pq3d_chain_sa_bwd, C.byref(c), L.stream()), "pq3d_chain_sa_bwd")

@@ -62,4 +62,60 @@ for B, Nq in ((8, 100), (16, 100)):
             torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 400 * 1e3
     print(f"R = {B * Nq}: three launches {res['three launches']:.2f} us, chain_ca {res['chain_ca']:.2f} us")
+    # ---- backward chains against their separate launches
+    from pq3d_amd import _lib as L, fused
+    f_, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2 = _five_launches(*args)
+    x1s, g1, W1, W2, g2 = args[3], args[4], args[7], args[9], args[11]
+    dx = r(B, Nq, d)
+    R = B * Nq
+    zs = lambda: torch.zeros(d, device=dev)
+    acc = [zs() for _ in range(4)]
+    fl3 = ops.chain_flags(R, dev)
+    m2, r2 = mean2[:1].contiguous(), rstd2[:1].contiguous()
+    def sep_ffn_bwd():
+        dx2r, dyl = fused._ln_bwd(x2, [z], [g2], [args[12]], 1e-5, None, Nq, m2, r2, dx, [acc[0]], [acc[1]])
+        dhp = torch.empty(B, Nq, F_, dtype=torch.bfloat16, device=dev)
+        L.gemm(M=R, N=F_, K=d, A=[dyl[0]], B=[W2], Cs=[dhp], aux=[h], act_grad="relu", ct=L.BF16, lda=d, ldb=F_, ldc=F_, transB=True)
+        L.gemm(M=R, N=d, K=F_, A=[dhp], B=[W1], Cs=[dx2r], ct=L.BF16, lda=F_, ldb=d, ldc=d, transB=True, splitk=4, accumulate=True)
+        return fused._ln_bwd(x1s, [f_], [g1], [args[5]], 1e-5, None, Nq, mean1, rstd1, dx2r, [acc[2]], [acc[3]])
+    def chain_ffn_bwd():
+        return ops.chain_ffn_bwd(dx, x2, z, g2, m2, r2, acc[0], acc[1], W2, h, W1, x1s, f_, g1, mean1, rstd1, acc[2], acc[3], fl3)
+    op_all, x1, meanc, rstdc, qkv = _three_launches(*a2)
+    dqkv, dx1r = r(3, B, Nq, d), r(B, Nq, d)
+    dgs, dbs = [zs() for _ in range(M)], [zs() for _ in range(M)]
+    dxz = torch.zeros(B, Nq, d, device=dev)
+    fl4 = ops.chain_flags(R, dev)
+    def sep_sa_bwd():
+        g3 = torch.empty(3, B, Nq, d, device=dev)
+        L.gemm(M=R, N=d, K=d, A=[dqkv[0], dqkv[1], dqkv[2]], B=list(a2[10]), Cs=[g3[0], g3[1], g3[2]], aux=[None, None, dx1r], act_grad="add",
+               ct=L.BF16, lda=d, ldb=d, ldc=d, transB=True)
+        dxr, dop = fused._ln_bwd(a2[3], [op_all[m] for m in range(M)], a2[4], a2[5], 1e-5, None, Nq, meanc, rstdc, [g3[0], g3[1], g3[2]], dgs, dbs,
+                                 dx_zeroed=dxz)
+        do = torch.empty(M, B, Nq, d, dtype=torch.bfloat16, device=dev)
+        L.gemm(M=R, N=d, K=d, A=[dop[m] for m in range(M)], B=list(a2[1]), Cs=[do[m] for m in range(M)], ct=L.BF16, lda=d, ldb=d, ldc=d, transB=True)
+        return do
+    def chain_sa_bwd():
+        return ops.chain_sa_bwd(dqkv, a2[10], dx1r, a2[3], op_all, a2[4], meanc, rstdc, None, Nq, dgs, dbs, a2[1], fl4)
+    for name, fn in (("sep_ffn_bwd", sep_ffn_bwd), ("chain_ffn_bwd", chain_ffn_bwd), ("sep_sa_bwd", sep_sa_bwd), ("chain_sa_bwd", chain_sa_bwd)):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                for _ in range(20):
+                    keep = fn()
+            for _ in range(5):
+                gr.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / 400 * 1e3
+    print(f"R = {B * Nq}: backward FFN group: four launches {res['sep_ffn_bwd']:.2f} us, chain {res['chain_ffn_bwd']:.2f} us; "
+          f"q/k/v + merged LN + dO group: three launches {res['sep_sa_bwd']:.2f} us, chain {res['chain_sa_bwd']:.2f} us")
     print(f"R = {B * Nq}: five launches {res['five launches']:.2f} us, chain {res['chain']:.2f} us per layer tail; hand-off timeouts: {ops.chain_error(dev)}")
