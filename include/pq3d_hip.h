@@ -468,6 +468,15 @@ typedef struct {
   uint32_t* flags;
   int32_t* err;
   float* lnws;                  /* >= 32 * 8 * 1024 floats of scratch (the groups' LayerNorm parameter-gradient partials) */
+  /* optional step 0 (nq > 0; dx is then ignored): the upstream gradient is formed here, dxo = sum_{m < nq} dq_m Wq_m + dxr and
+   * gq = the same sum without dxr -- pq3d_gemm (transB, kconcat = nq, C2, "+ aux") of the cross-attention query projections of
+   * the layer application that ran backward just before (its d query_pos term and this layer's input gradient) */
+  int32_t nq;
+  const void* dq[3];            /* [R, d] bf16 */
+  const float* Wq[3];           /* [d, d] */
+  const float* dxr;             /* [R, d] */
+  float* gq;                    /* [R, d] out */
+  float* dxo;                   /* [R, d] out */
 } pq3d_chain_ffn_bwd_desc;
 int pq3d_chain_ffn_bwd(const pq3d_chain_ffn_bwd_desc* d, void* stream);
 

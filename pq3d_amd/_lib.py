@@ -174,7 +174,8 @@ class ChainCaDesc(C.Structure):
 class ChainFfnBwdDesc(C.Structure):
     _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("dx", "x2", "z", "g2", "mean2", "rstd2", "dg2", "db2", "dy", "W2", "h", "dhp", "W1", "part", "x1s",
-                                          "f", "g1", "mean1", "rstd1", "dg1", "db1", "df", "flags", "err", "lnws")]
+                                          "f", "g1", "mean1", "rstd1", "dg1", "db1", "df", "flags", "err", "lnws")] + \
+               [("nq", C.c_int32), ("dq", C.c_void_p * 3), ("Wq", C.c_void_p * 3), ("dxr", C.c_void_p), ("gq", C.c_void_p), ("dxo", C.c_void_p)]
 
 
 class ChainSaBwdDesc(C.Structure):

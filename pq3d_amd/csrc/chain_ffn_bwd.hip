@@ -20,13 +20,16 @@ namespace {
 constexpr int B2K = 64, B2N = 256, B2LD = B2N + 8;     // step 2: [64 k][256 n] slab of W2 (k = model dim, n = hidden dim)
 constexpr int B3K = 128, B3N = 128, B3LD = B3N + 8;    // step 3: [128 k][128 n] slab of W1 (k = hidden dim, n = model dim)
 constexpr int A3LD = B3K + 8;
+constexpr int S0N = 32, S0LD = S0N + 8;                // step 0: [256 k][32 n] slab of a query-projection weight
 constexpr size_t bwd_lds(int nrt) {
   const size_t s2b = (size_t)B2K * B2LD * 2, s2c = (size_t)TM * (B2N + 4) * 4;
   const size_t s2 = (size_t)nrt * TM * LDR * 2 + (s2b > s2c ? s2b : s2c);
   const size_t s3b = (size_t)B3K * B3LD * 2, s3c = (size_t)TM * (B3N + 4) * 4;
   const size_t s3 = (size_t)nrt * TM * A3LD * 2 + (s3b > s3c ? s3b : s3c);
   const size_t sl = (size_t)2 * 8 * D * 4;   // LayerNorm parameter-gradient partials [2][8 waves][256]
-  const size_t m = s2 > s3 ? s2 : s3;
+  const size_t s0 = (size_t)nrt * TM * LDR * 2 + (size_t)D * S0LD * 2 + (size_t)TM * 36 * 4;   // step 0
+  size_t m = s2 > s3 ? s2 : s3;
+  m = m > s0 ? m : s0;
   return m > sl ? m : sl;
 }
 
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
   unsigned* const group = d.flags + (long)grp * G * 16;
   unsigned* const mine = group + j * 16;
   const unsigned v0 = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned vs = v0;   // hand-off targets: strictly increasing, the same sequence in every member
   float* const lnws = d.lnws + (long)grp * G * 1024;   // [8 members][2 LayerNorms][gamma 256 | beta 256]
   const long lrow = m0 + 4 * NRT * j + c.wave;
   const bool lnw = c.wave < 4 * NRT && lrow < R;
@@ -83,6 +87,69 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
   };
   issue_w2(0, ring[0]); issue_w2(1, ring[1]);
 
+  // ---- 0. (optional) the upstream gradient itself: dx = sum_m dq_m Wq_m + dxr, the input gradient of the cross-attention query
+  // projections of the layer application that ran backward just before this one (pq3d_gemm: transB, kconcat = nq, C2 = the sum
+  // without the addend).  Member j owns columns [32 j, + 32); waves 0..3 = 2 row halves x 2 column blocks, one accumulator
+  // per row tile over all nq x 256 reduction steps (the separate launch's order).
+  if (d.nq > 0) {   // uniform
+    bf16_t* const Ap = (bf16_t*)ch_smem;                 // [NRT][32][LDR]: dq_m (bf16)
+    bf16_t* const Bp = Ap + NRT * TM * LDR;              // [256 k][S0LD]: Wq_m[:, 32 j .. + 32)
+    float* const Ct = (float*)(Bp + D * S0LD);           // [32][36]
+    const int wr0 = (c.wave >> 1) * 16, wc0 = (c.wave & 1) * 16;   // waves 0..3
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < d.nq; ++m) {
+      if (m > 0) __syncthreads();
+      const bf16_t* A = (const bf16_t*)d.dq[m];
+#pragma unroll
+      for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ch = c.tid + i * CT;
+          *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] =
+              *(const u32x4*)(A + (long)min(m0 + t * TM + (ch >> 5), R - 1) * D + (ch & 31) * 8);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {                      // 256 k x 4 chunks of 8 columns
+        const int ch = c.tid + i * CT;
+        float v[8];
+        load8<false>(d.Wq[m], (long)(ch >> 2) * D + j * S0N + (ch & 3) * 8, v);
+        *(u32x4*)&Bp[(ch >> 2) * S0LD + (ch & 3) * 8] = pack_frag<bf16_t>(v);
+      }
+      __syncthreads();
+      if (c.wave < 4) {
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+          const u32x4 bh = km_frag(Bp, S0LD, wc0, ks, c.li, c.lg);
+#pragma unroll
+          for (int t = 0; t < NRT; ++t)
+            Mma<bf16_t>::mma(acc[t], *(const u32x4*)&Ap[t * TM * LDR + (wr0 + c.li) * LDR + ks * 32 + c.lg * 8], bh);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+      __syncthreads();
+      if (c.wave < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[(wr0 + c.lg * 4 + r) * 36 + wc0 + c.li] = (acc[t][r] + 0.f) * 1.f;
+      }
+      __syncthreads();
+      if (c.tid < 256) {                                 // 32 rows x 8 pieces of 4 columns
+        const int orow = c.tid >> 3, col = (c.tid & 7) * 4, row = m0 + t * TM + orow;
+        if (row < R) {
+          float4 v = *(const float4*)&Ct[orow * 36 + col];
+          const long o = (long)row * D + j * S0N + col;
+          *(float4*)(d.gq + o) = v;
+          const float4 a = *(const float4*)(d.dxr + o);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          *(float4*)(d.dxo + o) = v;
+        }
+      }
+    }
+    handoff(c, mine, group, ++vs, d.err);
+  }
   // ---- 1. g2 = LN2'(x2 + z; dx)
   {
     float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
@@ -90,7 +157,8 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
       float xv[4], ov[4], v[4], dyr[4], gam[4], g[4];
       load4<false>(d.x2, lbase, xv);
       load4<false>(d.z, lbase, ov);
-      load4<false>(d.dx, lbase, dyr);
+      if (d.nq > 0) load4<true>(d.dxo, lbase, dyr);
+      else load4<false>(d.dx, lbase, dyr);
       load4<false>(d.g2, c.lane * 4, gam);
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = xv[k] + ov[k];
@@ -99,7 +167,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
     }
     ln_partials_store(c, (float*)ch_smem, dg, db, lnws + j * 1024);
   }
-  handoff(c, mine, group, v0 + 1, d.err);
+  handoff(c, mine, group, ++vs, d.err);
   ln_partials_reduce(c, j, lnws, 1024, 0, d.dg2, d.db2);   // LayerNorm 2's parameter gradients: 64 atomics per member
   // ---- 2. dhp = [h > 0] (g2 W2): member j owns hidden columns [256 j, + 256); wave = 16 rows x 64 columns per row tile
   {
@@ -176,7 +244,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
     }
   };
   issue_w1(0, ring[0]); issue_w1(1, ring[1]);
-  handoff(c, mine, group, v0 + 2, d.err);
+  handoff(c, mine, group, ++vs, d.err);
   // ---- 3. p_k = dhp[:, quarter k] W1[quarter k, :]: member j owns quarter j / 2 and model columns [128 (j & 1), + 128)
   {
     bf16_t* const Ap = (bf16_t*)ch_smem;                 // [NRT][32][A3LD]: one k slab of dhp
@@ -238,7 +306,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
       }
     }
   }
-  handoff(c, mine, group, v0 + 3, d.err);
+  handoff(c, mine, group, ++vs, d.err);
   // ---- 4. g1 = LN1'(x1s + f; g2 + p_0 + p_1 + p_2 + p_3)
   {
     float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
@@ -261,14 +329,14 @@ __global__ __launch_bounds__(CT) void chain_ffn_bwd_kernel(const pq3d_chain_ffn_
     }
     ln_partials_store(c, (float*)ch_smem, dg, db, lnws + j * 1024 + 512);
   }
-  handoff(c, mine, group, v0 + 4, d.err);
+  handoff(c, mine, group, ++vs, d.err);
   ln_partials_reduce(c, j, lnws, 1024, 512, d.dg1, d.db1);
 }
 
 }  // namespace
 
 extern "C" int pq3d_chain_ffn_bwd(const pq3d_chain_ffn_bwd_desc* dp, void* stream) {
-  PQ_DEVICE_GUARD(stream, dp ? dp->dx : nullptr);
+  PQ_DEVICE_GUARD(stream, dp ? dp->x2 : nullptr);
   PQ_CHECK_ARG(dp != nullptr, "pq3d_chain_ffn_bwd: null descriptor");
   const pq3d_chain_ffn_bwd_desc d = *dp;
   PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.F == 2048, "pq3d_chain_ffn_bwd: d = 256, F = 2048");
@@ -276,12 +344,19 @@ extern "C" int pq3d_chain_ffn_bwd(const pq3d_chain_ffn_bwd_desc* dp, void* strea
   const int nrt = row_tiles * G <= 256 ? 1 : 2;
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_ffn_bwd: more than 2048 rows (the groups would not all be resident)");
-  const void* ps[] = {d.dx, d.x2, d.z, d.g2, d.mean2, d.rstd2, d.dg2, d.db2, d.dy, d.W2, d.h, d.dhp, d.W1, d.part, d.x1s, d.f, d.g1, d.mean1,
+  const void* ps[] = {d.nq > 0 ? (const void*)d.dxo : (const void*)d.dx, d.x2, d.z, d.g2, d.mean2, d.rstd2, d.dg2, d.db2, d.dy, d.W2, d.h, d.dhp, d.W1, d.part, d.x1s, d.f, d.g1, d.mean1,
                       d.rstd1, d.dg1, d.db1, d.df, d.flags, d.lnws};
   for (const void* p : ps) PQ_CHECK_ARG(p != nullptr, "pq3d_chain_ffn_bwd: null pointer");
-  const void* al[] = {d.dx, d.x2, d.z, d.g2, d.dy, d.W2, d.h, d.dhp, d.W1, d.part, d.x1s, d.f, d.g1, d.df};
+  const void* al[] = {d.nq > 0 ? (const void*)d.dxo : (const void*)d.dx, d.x2, d.z, d.g2, d.dy, d.W2, d.h, d.dhp, d.W1, d.part, d.x1s, d.f, d.g1, d.df};
   for (const void* p : al) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_chain_ffn_bwd: operands must be 16-byte aligned");
   PQ_CHECK_ARG((long)d.R * d.F * 4 < 0x7ffffff0L, "pq3d_chain_ffn_bwd: hidden activations too large");
+  PQ_CHECK_ARG(d.nq >= 0 && d.nq <= 3, "pq3d_chain_ffn_bwd: 0..3 query-projection terms");
+  if (d.nq > 0) {
+    PQ_CHECK_ARG(d.dxr && d.gq && d.dxo && ((((uintptr_t)d.dxr) | ((uintptr_t)d.gq) | ((uintptr_t)d.dxo)) & 15) == 0,
+                 "pq3d_chain_ffn_bwd: step 0 needs dxr, gq, dxo (16-byte aligned)");
+    for (int m = 0; m < d.nq; ++m)
+      PQ_CHECK_ARG(d.dq[m] && d.Wq[m] && ((((uintptr_t)d.dq[m]) | ((uintptr_t)d.Wq[m])) & 15) == 0, "pq3d_chain_ffn_bwd: dq / Wq (non-null, aligned)");
+  }
   static std::atomic<unsigned> done1{0}, done2{0};
   const dim3 grid((unsigned)(8 * G * slots));
   if (nrt == 1) {

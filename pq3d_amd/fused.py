@@ -274,6 +274,15 @@ def sa_fold_ok(ct, B, H, L_, dm, drop, df, W) -> bool:
     return L_ <= 240 and lds <= 160 * 1024
 
 
+class _PendingDx:
+    """Upstream gradient of a layer application that the NEXT backward chain launch forms itself (csrc/chain_ffn_bwd.hip, step 0):
+    sum_m dq_m Wq_m + dxr."""
+    __slots__ = ("dq_all", "Wqs", "dxr", "gq")
+
+    def __init__(self, dq_all, Wqs, dxr, gq):
+        self.dq_all, self.Wqs, self.dxr, self.gq = dq_all, Wqs, dxr, gq
+
+
 class _DecoderBackward:
     """One backward pass of the fused decoder: the state every sublayer step shares (saved tensors, sizes, the gradient
     arena, the deferred weight-gradient queue, the K/V gradient buffers) and one method per step, run in reverse order of the
@@ -529,7 +538,7 @@ class _DecoderBackward:
     def ffn_chain_ok(self, rec, layer, dx) -> bool:
         """The FFN backward + the self-attention post-norm backward can run as ONE launch (csrc/chain_ffn_bwd.hip)."""
         ffn = layer.ffn
-        return (_CHAIN and self.ct == BF16 and self.ad == torch.bfloat16 and self.spec.act == "relu" and isinstance(dx, torch.Tensor)
+        return (_CHAIN and self.ct == BF16 and self.ad == torch.bfloat16 and self.spec.act == "relu" and isinstance(dx, (torch.Tensor, _PendingDx))
                 and rec["dr_fr"] is None and rec["dr_fi"] is None and rec["dr_sr"] is None and rec["h"].dtype == torch.float32
                 and ops.chain_ffn_ok(self.R, self.d, ffn.linear1.out_features))
 
@@ -541,10 +550,11 @@ class _DecoderBackward:
         flags = getattr(enc, "_chain_flags_bwd", None)
         if flags is None or flags.device != dev:
             flags = enc._chain_flags_bwd = ops.chain_flags(2048, dev)
+        prev = (dx.dq_all, dx.Wqs, dx.dxr, dx.gq) if isinstance(dx, _PendingDx) else None
         dy, dhp, df = ops.chain_ffn_bwd(
-            dx.contiguous(), rec["x2"], rec["z"], ffn.norm.weight.detach(), rec["mean_f"][:1], rec["rstd_f"][:1], G(ffn.norm.weight),
+            None if prev is not None else dx.contiguous(), rec["x2"], rec["z"], ffn.norm.weight.detach(), rec["mean_f"][:1], rec["rstd_f"][:1], G(ffn.norm.weight),
             G(ffn.norm.bias), ffn.linear2.weight.detach(), rec["h"], ffn.linear1.weight.detach(), rec["x1s"], rec["f"],
-            sa.norm.weight.detach(), rec["mean_s"], rec["rstd_s"], G(sa.norm.weight), G(sa.norm.bias), flags)
+            sa.norm.weight.detach(), rec["mean_s"], rec["rstd_s"], G(sa.norm.weight), G(sa.norm.bias), flags, prev=prev)[:3]
         dwq.add([dy], [rec["h"]], None, [G(ffn.linear2.weight)], ct, [G(ffn.linear2.bias)])
         dwq.add([dhp], [rec["x2"]], None, [G(ffn.linear1.weight)], ct, [G(ffn.linear1.bias)])
         return df, df
@@ -687,10 +697,17 @@ class _DecoderBackward:
                    dKV[a, 1].view(M * B, Ns, d), delta_c, None), drop=rec["dr_ca"], drop_bmod=B, **mb)
         ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cl]
         gq = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-        dxn = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
-        L.gemm(M=R, N=d, K=d, A=[dq_all[m] for m in range(M)], B=[w[:d] for w in ws], Cs=[dxn] + [None] * (M - 1),
-               C2=[gq] + [None] * (M - 1), aux=[dxr] + [None] * (M - 1), act_grad="add", ct=ct, lda=d, ldb=d, ldc=d,
-               transB=True, kconcat=M)
+        # the input gradient of the query projections feeds the FFN backward of the application in front of this one: when that
+        # one runs as a chain launch (and no mask-head call sits in between) the launch forms it itself (step 0)
+        fold = a > 0 and (spec.mh is None or spec.skip_pred) and M <= 3 and dq_all.dtype == torch.bfloat16 and \
+            self.ffn_chain_ok(self.tape[a - 1], self.layers[self.tape[a - 1]["i"]], dxr)
+        if fold:
+            dxn = _PendingDx(dq_all, [w[:d] for w in ws], dxr, gq)
+        else:
+            dxn = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
+            L.gemm(M=R, N=d, K=d, A=[dq_all[m] for m in range(M)], B=[w[:d] for w in ws], Cs=[dxn] + [None] * (M - 1),
+                   C2=[gq] + [None] * (M - 1), aux=[dxr] + [None] * (M - 1), act_grad="add", ct=ct, lda=d, ldb=d, ldc=d,
+                   transB=True, kconcat=M)
         dqpos_parts.append(gq)
         dwq.add([dq_all[m] for m in range(M)], [x_in] * M, [qpos] * M,
                 [G(ca.multihead_attn.in_proj_weight)[:d] for ca in cl], ct,

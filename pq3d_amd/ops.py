@@ -1718,15 +1718,23 @@ def chain_ca_fwd(o_all, Wos, bos, x, gammas, betas, eps, coef, rows_per_scene, q
     return op_all, x1, mean, rstd, qkv
 
 
-def chain_ffn_bwd(dx, x2, z, g2, mean2, rstd2, dg2, db2, W2, h, W1, x1s, f, g1, mean1, rstd1, dg1, db1, flags):
+def chain_ffn_bwd(dx, x2, z, g2, mean2, rstd2, dg2, db2, W2, h, W1, x1s, f, g1, mean1, rstd1, dg1, db1, flags, prev=None):
     """Backward of the FFN sublayer + the self-attention post-norm in one launch.  Returns (dy, dhp, df): dy = d z (= the
     residual-branch gradient of LN2), dhp = d(linear1 output) as bf16, df = d f (= the residual-branch gradient of LN1).
-    dg2 / db2 / dg1 / db1 (arena views) are accumulated onto."""
-    d = dx.shape[-1]
-    R, F_ = dx.numel() // d, W1.shape[0]
-    dev = dx.device
-    dy, df = torch.empty_like(dx), torch.empty_like(dx)
-    dhp = torch.empty(*dx.shape[:-1], F_, dtype=torch.bfloat16, device=dev)
+    dg2 / db2 / dg1 / db1 (arena views) are accumulated onto.
+    prev = (dq_all [M, ..., d] bf16, [Wq_m], dxr, gq): dx is None and the upstream gradient sum_m dq_m Wq_m + dxr is formed in the
+    launch (gq receives the sum without dxr); a fourth result, that upstream gradient, is returned."""
+    like = dx if dx is not None else x2
+    d = like.shape[-1]
+    R, F_ = like.numel() // d, W1.shape[0]
+    dev = like.device
+    dy, df = torch.empty_like(like), torch.empty_like(like)
+    dhp = torch.empty(*like.shape[:-1], F_, dtype=torch.bfloat16, device=dev)
+    dxo = None
+    if prev is not None:
+        dq_all, Wqs, dxr, gq = prev
+        dxo = torch.empty_like(like)
+        dx = dxo   # (pointer only: not read by the kernel)
     part = torch.empty(4, R, d, dtype=torch.float32, device=dev)
     err = _CHAIN_ERR.get(dev)
     if err is None:
@@ -1738,10 +1746,16 @@ def chain_ffn_bwd(dx, x2, z, g2, mean2, rstd2, dg2, db2, W2, h, W1, x1s, f, g1, 
                  ("rstd1", rstd1), ("dg1", dg1), ("db1", db1), ("df", df), ("flags", flags), ("err", err), ("lnws", _chain_ws(dev))):
         assert t.is_contiguous() and (n in ("flags", "err", "dhp") or t.dtype == torch.float32), n
         setattr(c, n, L.ptr(t))
+    if prev is not None:
+        assert dq_all.dtype == torch.bfloat16 and dq_all.is_contiguous() and dxr.is_contiguous() and gq.is_contiguous() and len(Wqs) <= 3
+        c.nq, c.dxr, c.gq, c.dxo = len(Wqs), L.ptr(dxr), L.ptr(gq), L.ptr(dxo)
+        for m, w_ in enumerate(Wqs):
+            assert w_.is_contiguous() and w_.dtype == torch.float32
+            c.dq[m], c.Wq[m] = L.ptr(dq_all[m]), L.ptr(w_)
     fl = 2.0 * R * d * 2 * F_
     nb = 4.0 * (R * d * 12 + R * F_ + 2 * d * F_) + 2.0 * 2 * R * F_
     L.check(timed("pq3d_chain_ffn_bwd", f"R{R}d{d}F{F_}", fl, nb, L.lib().pq3d_chain_ffn_bwd, C.byref(c), L.stream()), "pq3d_chain_ffn_bwd")
-    return dy, dhp, df
+    return (dy, dhp, df) if prev is None else (dy, dhp, df, dxo)
 
 
 def chain_sa_bwd(dqkv, Wl, aux2, x, op_all, gammas, mean, rstd, coef, rows_per_scene, dgammas, dbetas, Wos, flags):

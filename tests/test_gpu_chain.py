@@ -207,3 +207,38 @@ def test_chain_sa_bwd_against_separate_launches(B, Nq, M, with_coef):
         for m in range(M):
             assert (dg[m] - dgr[m]).abs().max().item() <= 1e-4 * max(dgr[m].abs().max().item(), 1.0)
             assert (db[m] - dbr[m]).abs().max().item() <= 1e-4 * max(dbr[m].abs().max().item(), 1.0)
+
+
+def test_chain_ffn_bwd_forms_its_upstream_gradient():
+    """Step 0 of the backward chain: dx = sum_m dq_m Wq_m + dxr and the sum without dxr, the grouped launch's bits; the rest of
+    the chain on that dx as before."""
+    from pq3d_amd import _lib as L, fused, ops
+    dev = torch.device("cuda")
+    for B, Nq, M in ((8, 100, 3), (16, 100, 3), (2, 33, 1)):
+        g = torch.Generator().manual_seed(5 + B)
+        r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+        d, F_, R = 256, 2048, B * Nq
+        fwd = (r(B, Nq, d), r(d, d, sc=0.06), r(d, sc=0.1), r(B, Nq, d), 1 + r(d, sc=0.1), r(d, sc=0.1), 1e-5,
+               r(F_, d, sc=0.06), r(F_, sc=0.1), r(d, F_, sc=0.03), r(d, sc=0.1), 1 + r(d, sc=0.1), r(d, sc=0.1), 1e-5)
+        f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2 = _five_launches(*fwd)
+        x1s, g1, W1, W2, g2 = fwd[3], fwd[4], fwd[7], fwd[9], fwd[11]
+        dq_all, Wq, dxr = r(M, B, Nq, d).bfloat16(), [r(d, d, sc=0.06) for _ in range(M)], r(B, Nq, d)
+        gq_ref, dx_ref = torch.empty(B, Nq, d, device=dev), torch.empty(B, Nq, d, device=dev)
+        L.gemm(M=R, N=d, K=d, A=[dq_all[m] for m in range(M)], B=Wq, Cs=[dx_ref] + [None] * (M - 1), C2=[gq_ref] + [None] * (M - 1),
+               aux=[dxr] + [None] * (M - 1), act_grad="add", ct=L.BF16, lda=d, ldb=d, ldc=d, transB=True, kconcat=M)
+        m2, r2 = mean2[:1].contiguous(), rstd2[:1].contiguous()
+        z4 = lambda: [torch.zeros(d, device=dev) for _ in range(4)]
+        flags = ops.chain_flags(R, dev)
+        a0 = z4()
+        dy0, dhp0, df0 = ops.chain_ffn_bwd(dx_ref, x2, z, g2, m2, r2, a0[0], a0[1], W2, h, W1, x1s, f, g1, mean1, rstd1, a0[2], a0[3], flags)
+        for rep in range(3):
+            a1 = z4()
+            gq = torch.empty(B, Nq, d, device=dev)
+            dy, dhp, df, dxo = ops.chain_ffn_bwd(None, x2, z, g2, m2, r2, a1[0], a1[1], W2, h, W1, x1s, f, g1, mean1, rstd1, a1[2], a1[3],
+                                                 flags, prev=(dq_all, Wq, dxr, gq))
+            torch.cuda.synchronize()
+            assert not ops.chain_error(dev)
+            assert torch.equal(gq.view(torch.int32), gq_ref.view(torch.int32))
+            assert torch.equal(dxo.view(torch.int32), dx_ref.view(torch.int32))
+            assert torch.equal(dy.view(torch.int32), dy0.view(torch.int32)) and torch.equal(dhp.view(torch.int16), dhp0.view(torch.int16))
+            assert torch.equal(df.view(torch.int32), df0.view(torch.int32))
