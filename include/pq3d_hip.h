@@ -434,6 +434,35 @@ typedef struct {
 } pq3d_chain_ca_desc;
 int pq3d_chain_ca_fwd(const pq3d_chain_ca_desc* d, void* stream);
 
+/* The row-local part of one MaskHeadSegLevel call in ONE launch (csrc/chain_mh.hip; bf16 mode, no head dropout):
+ * h1 = relu(x W0^T + b0), qm_m = x Wq_m^T + bq_m (m < Mm <= 3), h2 = LN(h1), cls = h2 W4^T + b4 with the columns flagged in
+ * colfill set to `fill` -- bit for bit what pq3d_gemm, pq3d_add_ln_fwd, pq3d_gemm, pq3d_fill_cols, pq3d_gemm produce (class MLP
+ * of get_mlp_head, utils.py:17-26, called at mask_head.py:36; MaskPredictionLayer's query projection, mask_head.py:57-60).
+ * R <= 2048 rows, d = hidden = 256, C <= 256 classes.  flags / err: as for pq3d_chain_ffn_fwd (own words per site). */
+typedef struct {
+  int32_t R, d, Mm, C;
+  float eps, fill;
+  const float* x;               /* [R, d] queries */
+  const float* W0;              /* [d, d] */
+  const float* b0;
+  const float* gamma;
+  const float* beta;
+  const float* W4;              /* [C, d] */
+  const float* b4;              /* [C] or NULL */
+  const int32_t* colfill;       /* [C] (non-zero: filled column) or NULL */
+  const float* Wq[3];           /* [d, d] */
+  const float* bq[3];
+  float* h1;                    /* [R, d] out */
+  float* h2;                    /* [R, d] out */
+  float* mean;                  /* [R] out */
+  float* rstd;                  /* [R] out */
+  float* cls;                   /* [R, C] out */
+  float* qm[3];                 /* [R, d] out */
+  uint32_t* flags;
+  int32_t* err;
+} pq3d_chain_mh_desc;
+int pq3d_chain_mh_fwd(const pq3d_chain_mh_desc* d, void* stream);
+
 /* The row-local head of a decoder layer's BACKWARD in one launch (csrc/chain_ffn_bwd.hip; bf16 mode, ReLU, no dropout):
  *     g2 = LN2'(x2 + z; dx);  dhp = [h > 0] (g2 W2) (bf16);  p_k = dhp_k W1_k (K = F in 4 partial sums);
  *     g1 = LN1'(x1s + f; g2 + p_0 + p_1 + p_2 + p_3)

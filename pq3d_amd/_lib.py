@@ -171,6 +171,14 @@ class ChainCaDesc(C.Structure):
                 ("flags", C.c_void_p), ("err", C.c_void_p)]
 
 
+class ChainMhDesc(C.Structure):
+    _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("Mm", C.c_int32), ("C", C.c_int32), ("eps", C.c_float), ("fill", C.c_float)] + \
+               [(n, C.c_void_p) for n in ("x", "W0", "b0", "gamma", "beta", "W4", "b4", "colfill")] + \
+               [("Wq", C.c_void_p * 3), ("bq", C.c_void_p * 3)] + \
+               [(n, C.c_void_p) for n in ("h1", "h2", "mean", "rstd", "cls")] + \
+               [("qm", C.c_void_p * 3), ("flags", C.c_void_p), ("err", C.c_void_p)]
+
+
 class ChainFfnBwdDesc(C.Structure):
     _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("dx", "x2", "z", "g2", "mean2", "rstd2", "dg2", "db2", "dy", "W2", "h", "dhp", "W1", "part", "x1s",
@@ -197,6 +205,7 @@ _SIGS = {
     "pq3d_gemm_tt_multi_wide": [C.c_int32],
     "pq3d_chain_ffn_fwd": [C.POINTER(ChainFfnDesc), C.c_void_p],
     "pq3d_chain_ca_fwd": [C.POINTER(ChainCaDesc), C.c_void_p],
+    "pq3d_chain_mh_fwd": [C.POINTER(ChainMhDesc), C.c_void_p],
     "pq3d_chain_ffn_bwd": [C.POINTER(ChainFfnBwdDesc), C.c_void_p],
     "pq3d_chain_sa_bwd": [C.POINTER(ChainSaBwdDesc), C.c_void_p],
     "pq3d_mask_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],

@@ -206,7 +206,8 @@ PQ_DEV void proj_issue_w(const Ctx& c, int j, int ng, const float* const* W, Raw
 }
 template <int NRT, bool X3, bool SC1A, typename TO>
 PQ_DEV void proj_3x256(const Ctx& c, unsigned char* smem, int j, int ng, int m0, int R, const void* const* A, const float* const* A2,
-                       const float* const* W, const float* const* bias, TO* const* out, RawB (&wb)[2], bool preloaded) {
+                       const float* const* W, const float* const* bias, TO* const* out, RawB (&wb)[2], bool preloaded,
+                       int relu_mask = 0) {   // relu_mask: bit g set -> max(., 0) on group g's outputs
   if (j >= 2 * ng) return;   // (uniform: the whole workgroup)
   constexpr int PL = X3 ? 2 : 1;
   const int g = j >> 1, n0 = (j & 1) * PN;
@@ -306,7 +307,8 @@ PQ_DEV void proj_3x256(const Ctx& c, unsigned char* smem, int j, int ng, int m0,
 #pragma unroll
     for (int qd = 0; qd < 2; ++qd) {
       const int col = qd * 64 + (c.tid & 15) * 4;
-      const float4 v = *(const float4*)&Ct[orow * PCL + col];
+      float4 v = *(const float4*)&Ct[orow * PCL + col];
+      if ((relu_mask >> g) & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if (row < R) {
         if constexpr (sizeof(TO) == 4) *(float4*)((float*)out[g] + (long)row * D + n0 + col) = v;
         else *(u32x2*)((bf16_t*)out[g] + (long)row * D + n0 + col) = (u32x2){pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)};

@@ -1,0 +1,186 @@
+// One launch for the row-local part of a MaskHeadSegLevel call (reference: mask_head.py:24-44 -- the class MLP of
+// get_mlp_head, utils.py:17-26: Linear + ReLU + LayerNorm + Dropout + Linear; and the query side of every MaskPredictionLayer,
+// mask_head.py:57-60):
+//     h1   = relu(x W0^T + b0)                  qm_m = x Wq_m^T + bq_m   (m < Mm <= 3)
+//     h2   = LN(h1)
+//     cls  = h2 W4^T + b4, focus columns filled with -inf (the reference's logits[..., cols] = -inf)
+// -- five dependent launches before (gemm_wk, add_ln_fwd, gemm_wk, fill_cols, gemm_wk: 29 us per call at config 4, which runs
+// the head after every decoder block).  Same construction as chain_ffn.hip / chain_ca.hip: a group of 8 workgroups on one XCD
+// owns NRT 32-row tiles through all steps, rows cross between members through that XCD's L2 (flags + sc1 loads).  Arithmetic is
+// the separate kernels' own (split-bf16 products, k ascending, bias on the accumulator): tests/test_gpu_chain.py, bit for bit.
+// The query -> segment mask-logit product itself (all segments of a scene per query) is not row-local and stays pq3d_gemm's.
+#include <atomic>
+
+#include "chain_common.h"
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int CN = 32, CCL = CN + 4;   // class-logit step: a member owns 32 classes
+template <int NRT> constexpr size_t mh_lds() {
+  const size_t s1 = proj_lds<NRT>(true);
+  const size_t s3 = (size_t)NRT * 2 * TM * LDR * 2 + (size_t)2 * CN * LDR * 2 + (size_t)TM * CCL * 4;
+  return s1 > s3 ? s1 : s3;
+}
+static_assert(mh_lds<2>() <= 160 * 1024, "LDS");
+
+template <int NRT>
+__global__ __launch_bounds__(CT) void chain_mh_fwd_kernel(const pq3d_chain_mh_desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
+  Ctx c;
+  c.Ah = (bf16_t*)ch_smem;
+  c.Al = c.Ah + TM * LDR;
+  c.Bh = c.Al + TM * LDR;
+  c.Bl = c.Bh + TN * LDR;
+  c.Ct = (float*)(c.Bl + TN * LDR);
+  c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.li = c.lane & 15; c.lg = c.lane >> 4;
+  c.wm = (c.wave >> 2) * 16; c.wn = (c.wave & 3) * 16;
+  constexpr int GR = TM * NRT;
+  const int id = (int)blockIdx.x, xcd = id & 7, q = id >> 3, slot = q >> 3, j = q & 7;
+  const int grp = slot * 8 + xcd, m0 = grp * GR;
+  const int R = d.R, Mm = d.Mm, Cn = d.C;
+  if (m0 >= R) return;
+  unsigned* const group = d.flags + (long)grp * G * 16;
+  unsigned* const mine = group + j * 16;
+  const unsigned v0 = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // step 3's weight slab travels under steps 1 and 2: classes [32 j, + 32) x 256 k (rows beyond the last class: clamped, unused)
+  const int n3 = j * CN;
+  const bool on3 = n3 < Cn;
+  RawA w4;
+  if (on3) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = c.tid + i * CT;
+      load8<false>(d.W4, (long)min(n3 + (ch >> 5), Cn - 1) * D + (ch & 31) * 8, w4.v[i]);
+    }
+  }
+  // ---- 1. h1 = relu(x W0^T + b0), qm_m = x Wq_m^T + bq_m: member j < 2 (1 + Mm) owns product j / 2, half of its columns
+  {
+    const void* A[4] = {d.x, d.x, d.x, d.x};
+    const float* W[4] = {d.W0, d.Wq[0], d.Wq[1], d.Wq[2]};
+    const float* bias[4] = {d.b0, d.bq[0], d.bq[1], d.bq[2]};
+    float* out[4] = {d.h1, d.qm[0], d.qm[1], d.qm[2]};
+    RawB w1[2];
+    proj_3x256<NRT, true, false, float>(c, ch_smem, j, 1 + Mm, m0, R, A, nullptr, W, bias, out, w1, false, 1);
+  }
+  handoff(c, mine, group, v0 + 1, d.err);
+  // ---- 2. h2 = LN(h1) (no residual: add_ln_fwd's x = NULL): 32 NRT rows over 8 members x 4 NRT waves
+  {
+    const long row = m0 + 4 * NRT * j + c.wave;
+    if (c.wave < 4 * NRT && row < R) {
+      const long base = row * D + c.lane * 4;
+      float ov[4], v[4], gm[4], bt[4], y[4];
+      load4<true>(d.h1, base, ov);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = 0.f + ov[k];
+      const RowStats st = row_stats4(v, d.eps);
+      load4<false>(d.gamma, c.lane * 4, gm);
+      load4<false>(d.beta, c.lane * 4, bt);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { y[k] = 0.f; y[k] += 1.f * ((v[k] - st.mean) * st.rstd * gm[k] + bt[k]); }
+      if (c.lane == 0) { d.mean[row] = st.mean; d.rstd[row] = st.rstd; }
+      *(float4*)(d.h2 + base) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+  }
+  handoff(c, mine, group, v0 + 2, d.err);
+  // ---- 3. cls = h2 W4^T + b4 (+ the column fill): member j owns classes [32 j, + 32); waves 0..3 = 2 row halves x 2 class blocks
+  if (on3) {   // uniform
+    bf16_t* const Ap = (bf16_t*)ch_smem;                  // [NRT][2 planes][32][LDR]: h2, whole K
+    bf16_t* const Bp = Ap + NRT * 2 * TM * LDR;           // [2 planes][32][LDR]: this member's classes
+    float* const Ct = (float*)(Bp + 2 * CN * LDR);        // [32][CCL]
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+      RawA ra;
+      issue_a<true>(c, ra, d.h2, D, m0 + t * TM, R, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = c.tid + i * CT, o = (ch >> 5) * LDR + (ch & 31) * 8;
+        u32x4 hi, lo;
+        split_hi_lo(ra.v[i], hi, lo);
+        *(u32x4*)&Ap[(t * 2) * TM * LDR + o] = hi;
+        *(u32x4*)&Ap[(t * 2 + 1) * TM * LDR + o] = lo;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = c.tid + i * CT, o = (ch >> 5) * LDR + (ch & 31) * 8;
+      u32x4 hi, lo;
+      split_hi_lo(w4.v[i], hi, lo);
+      *(u32x4*)&Bp[o] = hi;
+      *(u32x4*)&Bp[CN * LDR + o] = lo;
+    }
+    __syncthreads();
+    const int wr0 = (c.wave >> 1) * 16, wc0 = (c.wave & 1) * 16;   // waves 0..3
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c.wave < 4) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 32; ++ks) {
+        const int ob = (wc0 + c.li) * LDR + ks * 32 + c.lg * 8, oa = (wr0 + c.li) * LDR + ks * 32 + c.lg * 8;
+        const u32x4 bh = *(const u32x4*)&Bp[ob], bl = *(const u32x4*)&Bp[CN * LDR + ob];
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+          const u32x4 ah = *(const u32x4*)&Ap[(t * 2) * TM * LDR + oa], al = *(const u32x4*)&Ap[(t * 2 + 1) * TM * LDR + oa];
+          Mma<bf16_t>::mma(acc[t], al, bh);
+          Mma<bf16_t>::mma(acc[t], ah, bl);
+          Mma<bf16_t>::mma(acc[t], ah, bh);
+        }
+      }
+    }
+    const int bc = n3 + wc0 + c.li;
+    const float bcol = (c.wave < 4 && bc < Cn && d.b4) ? d.b4[bc] : 0.f;
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+      if (t > 0) __syncthreads();
+      if (c.wave < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[(wr0 + c.lg * 4 + r) * CCL + wc0 + c.li] = (acc[t][r] + bcol) * 1.f;
+      }
+      __syncthreads();
+      const int orow = c.tid >> 4, row = m0 + t * TM + orow;   // 32 rows x 16 pairs of classes
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int cl = (c.tid & 15) * 2 + e, col = n3 + cl;
+        if (row < R && col < Cn) {
+          float v = Ct[orow * CCL + cl];
+          if (d.colfill && d.colfill[col]) v = d.fill;
+          d.cls[(long)row * Cn + col] = v;
+        }
+      }
+    }
+  }
+  handoff(c, mine, group, v0 + 3, d.err);   // (the flags advance by the same amount in every member)
+}
+
+template <int NRT>
+int launch_fwd(const pq3d_chain_mh_desc& d, int slots, hipStream_t s, std::atomic<unsigned>& done) {
+  if (int e = pq3d_enable_big_lds(chain_mh_fwd_kernel<NRT>, (int)mh_lds<NRT>(), done)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
+  hipLaunchKernelGGL(chain_mh_fwd_kernel<NRT>, dim3((unsigned)(8 * G * slots)), dim3(CT), mh_lds<NRT>(), s, d);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pq3d_chain_mh_fwd(const pq3d_chain_mh_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, dp ? dp->x : nullptr);
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_chain_mh_fwd: null descriptor");
+  const pq3d_chain_mh_desc d = *dp;
+  PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.Mm >= 0 && d.Mm <= 3 && d.C >= 1 && d.C <= 256, "pq3d_chain_mh_fwd: d = 256, 0..3 memories, 1..256 classes");
+  const int row_tiles = (d.R + TM - 1) / TM;
+  const int nrt = row_tiles * G <= 256 ? 1 : 2;
+  const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
+  PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_mh_fwd: more than 2048 rows (the groups would not all be resident)");
+  PQ_CHECK_ARG(d.x && d.W0 && d.b0 && d.gamma && d.beta && d.W4 && d.h1 && d.h2 && d.mean && d.rstd && d.cls && d.flags,
+               "pq3d_chain_mh_fwd: null pointer");
+  PQ_CHECK_ARG(((((uintptr_t)d.x) | ((uintptr_t)d.W0) | ((uintptr_t)d.gamma) | ((uintptr_t)d.beta) | ((uintptr_t)d.W4) |
+                 ((uintptr_t)d.h1) | ((uintptr_t)d.h2)) & 15) == 0, "pq3d_chain_mh_fwd: operands must be 16-byte aligned");
+  for (int m = 0; m < d.Mm; ++m)
+    PQ_CHECK_ARG(d.Wq[m] && d.bq[m] && d.qm[m] && ((((uintptr_t)d.Wq[m]) | ((uintptr_t)d.qm[m])) & 15) == 0,
+                 "pq3d_chain_mh_fwd: per-memory operands (non-null, 16-byte aligned)");
+  static std::atomic<unsigned> done1{0}, done2{0};
+  if (int e = nrt == 1 ? launch_fwd<1>(d, slots, (hipStream_t)stream, done1) : launch_fwd<2>(d, slots, (hipStream_t)stream, done2)) return e;
+  PQ_LAUNCH_CHECK();
+  return 0;
+}

@@ -165,6 +165,27 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
     B, Nq, d = x.shape
     R = B * Nq
     c0, c2, c4 = mh.cls_head[0], mh.cls_head[2], mh.cls_head[4]
+    Mm = len(keys)
+    mps = list(mh.mask_pred_list)[:Mm]
+    Ns = keys[0].shape[1]
+    if _CHAIN and ct == L.BF16X3 and not spec.mh_drop and x.dtype == torch.float32 and x.is_contiguous() and \
+            ops.chain_mh_ok(d, c0.out_features, c4.out_features, Mm, R) and c4.bias is not None:
+        # the row-local part (class MLP + the mask predictions' query projections) in one launch (csrc/chain_mh.hip)
+        flags = getattr(mh, "_chain_flags", None)
+        if flags is None or flags.device != x.device:
+            flags = mh._chain_flags = ops.chain_flags(2048, x.device)
+        colfill = mh._foc_flags if mh._foc_cols.numel() else None
+        h1, h2, mean, rstd, cls, qm = ops.chain_mh_fwd(
+            x, c0.weight.detach(), c0.bias.detach(), c2.weight.detach(), c2.bias.detach(), c2.eps, c4.weight.detach(),
+            c4.bias.detach(), colfill, float("-inf"), [mp.q_proj.weight.detach() for mp in mps],
+            [mp.q_proj.bias.detach() for mp in mps], flags)
+        mlog = torch.empty(B, Ns, Nq, dtype=torch.float32, device=x.device)
+        amask = torch.empty(B, Nq, Ns, dtype=torch.bool, device=x.device)
+        L.gemm(M=Ns, N=Nq, K=d, A=list(keys), B=[qm[m] for m in range(Mm)], Cs=[mlog] + [None] * (Mm - 1), ct=ct, lda=d,
+               ldb=d, ldc=Nq, batch=B, strideA=Ns * d, strideB=Nq * d, strideC=Ns * Nq, kconcat=Mm, row_scale=inv_den,
+               row_fill_flag=seg_pad, row_fill=-1e6, mask_out=amask)
+        rec.update(mh_x=x.detach(), mh_h1=h1, mh_h2=h2, mh_mean=mean, mh_rstd=rstd, mh_qm=qm, mh_drop=None)
+        return cls, mlog, amask
     h1 = torch.empty(B, Nq, c0.out_features, dtype=torch.float32, device=x.device)
     L.gemm(M=R, N=c0.out_features, K=d, A=[x], B=[c0.weight.detach()], bias=[c0.bias.detach()], Cs=[h1], ct=ct,
            lda=d, ldb=d, ldc=c0.out_features, act="relu")
@@ -182,12 +203,9 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
         cls = torch.empty_like(cls_raw)
         L.check(L.lib().pq3d_fill_cols(L.ptr(cls_raw), L.ptr(cls), R, C_, L.ptr(mh._foc_cols), mh._foc_cols.numel(),
                                        float("-inf"), L.stream()), "pq3d_fill_cols")
-    Mm = len(keys)
-    mps = list(mh.mask_pred_list)[:Mm]
     qm = torch.empty(Mm, B, Nq, d, dtype=ad, device=x.device)
     L.gemm(M=R, N=d, K=d, A=[x] * Mm, B=[mp.q_proj.weight.detach() for mp in mps],
            bias=[mp.q_proj.bias.detach() for mp in mps], Cs=[qm[m] for m in range(Mm)], ct=ct, lda=d, ldb=d, ldc=d)
-    Ns = keys[0].shape[1]
     mlog = torch.empty(B, Ns, Nq, dtype=torch.float32, device=x.device)
     amask = torch.empty(B, Nq, Ns, dtype=torch.bool, device=x.device)
     L.gemm(M=Ns, N=Nq, K=d, A=list(keys), B=[qm[m] for m in range(Mm)], Cs=[mlog] + [None] * (Mm - 1), ct=ct, lda=d,

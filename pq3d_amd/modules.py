@@ -623,6 +623,9 @@ class MaskHeadSegLevel(_PostNormBase):
         # reference quirk: filter_out_classes=None makes x[..., None] = -inf overwrite every logit (mask_head.py:28)
         foc = list(range(num_targets)) if filter_out_classes is None else list(filter_out_classes)
         self.register_buffer("_foc_cols", torch.tensor(foc, dtype=torch.int32), persistent=False)
+        flags = torch.zeros(num_targets, dtype=torch.int32)
+        flags[[c for c in foc if 0 <= c < num_targets]] = 1          # the same set as per-column flags (csrc/chain_mh.hip)
+        self.register_buffer("_foc_flags", flags, persistent=False)
 
     def project_keys(self, seg_fts_for_match):
         """k_proj of every matching memory (rows of padded segments zeroed) + the masked-mean denominators.

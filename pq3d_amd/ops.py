@@ -1718,6 +1718,39 @@ def chain_ca_fwd(o_all, Wos, bos, x, gammas, betas, eps, coef, rows_per_scene, q
     return op_all, x1, mean, rstd, qkv
 
 
+def chain_mh_ok(d: int, hidden: int, C_: int, Mm: int, R: int) -> bool:
+    return d == 256 and hidden == 256 and 1 <= C_ <= 256 and 0 <= Mm <= 3 and 1 <= R <= 2048
+
+
+def chain_mh_fwd(x, W0, b0, gamma, beta, eps, W4, b4, colfill, fill, Wqs, bqs, flags):
+    """Row-local part of a mask-head call in one launch: returns (h1, h2, mean [1, R], rstd [1, R], cls [..., C], qm [Mm, ..., d]);
+    everything fp32.  colfill: int32 [C] column flags (non-zero -> `fill`) or None."""
+    d = x.shape[-1]
+    R, C_, Mm = x.numel() // d, W4.shape[0], len(Wqs)
+    dev = x.device
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    h1, h2, cls, qm = e(x.shape), e(x.shape), e(*x.shape[:-1], C_), e(Mm, *x.shape)
+    mean, rstd = e(1, R), e(1, R)
+    err = _CHAIN_ERR.get(dev)
+    if err is None:
+        err = _CHAIN_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    c = L.ChainMhDesc()
+    c.R, c.d, c.Mm, c.C, c.eps, c.fill = R, d, Mm, C_, eps, fill
+    for n, t in (("x", x), ("W0", W0), ("b0", b0), ("gamma", gamma), ("beta", beta), ("W4", W4), ("b4", b4)):
+        assert t.is_contiguous() and t.dtype == torch.float32, n
+    assert colfill is None or (colfill.dtype == torch.int32 and colfill.numel() == C_ and colfill.is_contiguous())
+    for m in range(Mm):
+        for n, t in (("Wq", Wqs[m]), ("bq", bqs[m]), ("qm", qm[m])):
+            assert t.is_contiguous() and t.dtype == torch.float32, n
+            getattr(c, n)[m] = L.ptr(t)
+    c.x, c.W0, c.b0, c.gamma, c.beta, c.W4, c.b4, c.colfill = map(L.ptr, (x, W0, b0, gamma, beta, W4, b4, colfill))
+    c.h1, c.h2, c.mean, c.rstd, c.cls, c.flags, c.err = map(L.ptr, (h1, h2, mean, rstd, cls, flags, err))
+    fl = 2.0 * R * d * (d * (1 + Mm) + C_)
+    nb = 4.0 * (R * d * (3 + Mm) + R * C_ + (1 + Mm) * d * d + C_ * d)
+    L.check(timed("pq3d_chain_mh_fwd", f"R{R}d{d}M{Mm}C{C_}", fl, nb, L.lib().pq3d_chain_mh_fwd, C.byref(c), L.stream()), "pq3d_chain_mh_fwd")
+    return h1, h2, mean, rstd, cls, qm
+
+
 def chain_ffn_bwd(dx, x2, z, g2, mean2, rstd2, dg2, db2, W2, h, W1, x1s, f, g1, mean1, rstd1, dg1, db1, flags, prev=None):
     """Backward of the FFN sublayer + the self-attention post-norm in one launch.  Returns (dy, dhp, df): dy = d z (= the
     residual-branch gradient of LN2), dhp = d(linear1 output) as bf16, df = d f (= the residual-branch gradient of LN1).

@@ -58,6 +58,8 @@ int main(void) {
          offsetof(pq3d_chain_ffn_bwd_desc, err));
   printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_sa_bwd_desc), offsetof(pq3d_chain_sa_bwd_desc, dqkv), offsetof(pq3d_chain_sa_bwd_desc, coef),
          offsetof(pq3d_chain_sa_bwd_desc, err));
+  printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_mh_desc), offsetof(pq3d_chain_mh_desc, fill), offsetof(pq3d_chain_mh_desc, Wq),
+         offsetof(pq3d_chain_mh_desc, err));
   return 0;
 }''')
     exe = tmp_path / "layout"
@@ -75,6 +77,8 @@ int main(void) {
     assert rows[5] == [ctypes.sizeof(Cb), Cb.F.offset, Cb.dx.offset, Cb.err.offset]
     Cs = _lib.ChainSaBwdDesc
     assert rows[6] == [ctypes.sizeof(Cs), Cs.dqkv.offset, Cs.coef.offset, Cs.err.offset]
+    Cm = _lib.ChainMhDesc
+    assert rows[7] == [ctypes.sizeof(Cm), Cm.fill.offset, Cm.Wq.offset, Cm.err.offset]
 
 
 def test_argument_errors_are_reported(lib):

@@ -242,3 +242,52 @@ def test_chain_ffn_bwd_forms_its_upstream_gradient():
             assert torch.equal(dxo.view(torch.int32), dx_ref.view(torch.int32))
             assert torch.equal(dy.view(torch.int32), dy0.view(torch.int32)) and torch.equal(dhp.view(torch.int16), dhp0.view(torch.int16))
             assert torch.equal(df.view(torch.int32), df0.view(torch.int32))
+
+
+def _mh_five_launches(x, W0, b0, gamma, beta, eps, W4, b4, cols, Wqs, bqs):
+    """The mask head's row-local part as fused._mh_forward launches it without the chain."""
+    from pq3d_amd import _lib as L, fused
+    d = x.shape[-1]
+    R, C_, Mm = x.numel() // d, W4.shape[0], len(Wqs)
+    dev = x.device
+    h1 = torch.empty_like(x)
+    L.gemm(M=R, N=d, K=d, A=[x], B=[W0], bias=[b0], Cs=[h1], ct=L.BF16X3, lda=d, ldb=d, ldc=d, act="relu")
+    h2, mean, rstd = fused._ln_fwd(None, [h1], [gamma], [beta], eps, None, x.shape[-2])
+    cls_raw = torch.empty(*x.shape[:-1], C_, dtype=torch.float32, device=dev)
+    L.gemm(M=R, N=C_, K=d, A=[h2], B=[W4], bias=[b4], Cs=[cls_raw], ct=L.BF16X3, lda=d, ldb=d, ldc=C_)
+    cls = cls_raw
+    if cols is not None:
+        cls = torch.empty_like(cls_raw)
+        L.check(L.lib().pq3d_fill_cols(L.ptr(cls_raw), L.ptr(cls), R, C_, L.ptr(cols), cols.numel(), float("-inf"), L.stream()), "fill")
+    qm = torch.empty(Mm, *x.shape, dtype=torch.float32, device=dev)
+    if Mm:
+        L.gemm(M=R, N=d, K=d, A=[x] * Mm, B=list(Wqs), bias=list(bqs), Cs=[qm[m] for m in range(Mm)], ct=L.BF16X3, lda=d, ldb=d, ldc=d)
+    return h1, h2, mean, rstd, cls, qm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Nq,C_,Mm,fill", [(4, 200, 201, 3, True), (8, 100, 201, 3, False), (3, 37, 19, 1, True), (1, 1, 1, 0, False),
+                                             (1, 2048, 256, 3, True), (9, 200, 607 - 400, 2, True), (16, 100, 32, 3, False)])
+def test_chain_mh_equals_five_launches(B, Nq, C_, Mm, fill):
+    from pq3d_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 1000 + Nq + C_)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    d = 256
+    cols = flags_c = None
+    if fill:
+        pick = sorted({0, C_ - 1, C_ // 2})
+        cols = torch.tensor(pick, dtype=torch.int32, device=dev)
+        flags_c = torch.zeros(C_, dtype=torch.int32, device=dev)
+        flags_c[cols.long()] = 1
+    x, W0, b0, gamma, beta = r(B, Nq, d), r(d, d, sc=0.06), r(d, sc=0.1), 1 + r(d, sc=0.1), r(d, sc=0.1)
+    W4, b4 = r(C_, d, sc=0.06), r(C_, sc=0.1)
+    Wqs, bqs = [r(d, d, sc=0.06) for _ in range(Mm)], [r(d, sc=0.1) for _ in range(Mm)]
+    ref = _mh_five_launches(x, W0, b0, gamma, beta, 1e-5, W4, b4, cols, Wqs, bqs)
+    flags = ops.chain_flags(B * Nq, dev)
+    for rep in range(3):
+        out = ops.chain_mh_fwd(x, W0, b0, gamma, beta, 1e-5, W4, b4, flags_c, float("-inf"), Wqs, bqs, flags)
+        torch.cuda.synchronize()
+        assert not ops.chain_error(dev)
+        for n, a, b in zip(("h1", "h2", "mean", "rstd", "cls", "qm"), out, ref):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (n, rep)
