@@ -463,6 +463,37 @@ typedef struct {
 } pq3d_chain_mh_desc;
 int pq3d_chain_mh_fwd(const pq3d_chain_mh_desc* d, void* stream);
 
+/* Backward of the same part in ONE launch (csrc/chain_mh.hip): dcl = dc with the flagged columns zeroed, dh2 = dcl W4,
+ * dh1 = LN'(h1; dh2) (dgamma / dbeta accumulated), dpre = [h1 > 0] dh1 (bf16), out = sum_m dq_m Wq_m + (dpre W0 + cur) -- what
+ * pq3d_fill_cols, pq3d_gemm, pq3d_add_ln_bwd, pq3d_act_bwd, pq3d_gemm, pq3d_gemm produce (single-bf16 products, fp32
+ * accumulation; the LayerNorm parameter gradients to summation order).  dq_m: the query-side gradient of the mask logits
+ * (fp32 when dq_f32, else bf16); the weight gradients themselves stay with the caller (they read dcl, dpre, dq_m).
+ * lnws: scratch of 32 * 8 * 512 floats. */
+typedef struct {
+  int32_t R, d, Mm, C, dq_f32;
+  const float* dc;              /* [R, C] gradient of the class logits */
+  const int32_t* colfill;       /* [C] or NULL */
+  float* dcl;                   /* [R, C] out (NULL allowed without colfill: dcl = dc) */
+  const float* W4;              /* [C, d] */
+  const float* h1;              /* [R, d] */
+  const float* mean;            /* [R] */
+  const float* rstd;            /* [R] */
+  const float* gamma;
+  float* dgamma;                /* accumulated */
+  float* dbeta;                 /* accumulated */
+  float* dh2;                   /* [R, d] out (scratch of the launch) */
+  void* dpre;                   /* [R, d] bf16 out */
+  const float* W0;              /* [d, d] */
+  const float* cur;             /* [R, d] gradient arriving at the queries from elsewhere */
+  const void* dq[3];            /* [R, d] */
+  const float* Wq[3];           /* [d, d] */
+  float* out;                   /* [R, d] out */
+  uint32_t* flags;
+  int32_t* err;
+  float* lnws;
+} pq3d_chain_mh_bwd_desc;
+int pq3d_chain_mh_bwd(const pq3d_chain_mh_bwd_desc* d, void* stream);
+
 /* The row-local head of a decoder layer's BACKWARD in one launch (csrc/chain_ffn_bwd.hip; bf16 mode, ReLU, no dropout):
  *     g2 = LN2'(x2 + z; dx);  dhp = [h > 0] (g2 W2) (bf16);  p_k = dhp_k W1_k (K = F in 4 partial sums);
  *     g1 = LN1'(x1s + f; g2 + p_0 + p_1 + p_2 + p_3)

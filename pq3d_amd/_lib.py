@@ -179,6 +179,14 @@ class ChainMhDesc(C.Structure):
                [("qm", C.c_void_p * 3), ("flags", C.c_void_p), ("err", C.c_void_p)]
 
 
+class ChainMhBwdDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("R", "d", "Mm", "C", "dq_f32")] + \
+               [(n, C.c_void_p) for n in ("dc", "colfill", "dcl", "W4", "h1", "mean", "rstd", "gamma", "dgamma", "dbeta", "dh2", "dpre",
+                                          "W0", "cur")] + \
+               [("dq", C.c_void_p * 3), ("Wq", C.c_void_p * 3), ("out", C.c_void_p), ("flags", C.c_void_p), ("err", C.c_void_p),
+                ("lnws", C.c_void_p)]
+
+
 class ChainFfnBwdDesc(C.Structure):
     _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("dx", "x2", "z", "g2", "mean2", "rstd2", "dg2", "db2", "dy", "W2", "h", "dhp", "W1", "part", "x1s",
@@ -206,6 +214,7 @@ _SIGS = {
     "pq3d_chain_ffn_fwd": [C.POINTER(ChainFfnDesc), C.c_void_p],
     "pq3d_chain_ca_fwd": [C.POINTER(ChainCaDesc), C.c_void_p],
     "pq3d_chain_mh_fwd": [C.POINTER(ChainMhDesc), C.c_void_p],
+    "pq3d_chain_mh_bwd": [C.POINTER(ChainMhBwdDesc), C.c_void_p],
     "pq3d_chain_ffn_bwd": [C.POINTER(ChainFfnBwdDesc), C.c_void_p],
     "pq3d_chain_sa_bwd": [C.POINTER(ChainSaBwdDesc), C.c_void_p],
     "pq3d_mask_pack": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],

@@ -161,6 +161,242 @@ int launch_fwd(const pq3d_chain_mh_desc& d, int slots, hipStream_t s, std::atomi
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward of the same part (autograd of the class MLP and of the query projections' input, as fused.py's mask_head() launches
+// it without the chain: fill_cols, gemm_wk, add_ln_bwd, act_bwd, gemm_wk, gemm_wk -- 43 us per call at config 4):
+//     dcl  = dc with the focus columns zeroed                      (operand of the queued weight gradient of W4)
+//     dh2  = dcl W4                                                (single-bf16 product, K = C classes)
+//     dh1  = LN'(h1; dh2)   (d gamma, d beta accumulated)          dpre = [h1 > 0] dh1  (bf16: operand of W0's weight gradient)
+//     t    = dpre W0 + cur                                         out = sum_m dqm_m Wq_m + t
+// Products as pq3d_gemm's transB form (weights [k][n] row-major, read through the transposing LDS load): member j owns 32 output
+// columns, waves 0..3 = 2 row halves x 2 column blocks, one accumulator per row tile and product.
+constexpr int S0N = 32, S0LD = S0N + 8;
+template <int NRT> constexpr size_t mhb_lds() {
+  const size_t s = (size_t)NRT * TM * LDR * 2 + (size_t)D * S0LD * 2 + (size_t)TM * 36 * 4;
+  const size_t sl = (size_t)2 * 8 * D * 4;
+  return s > sl ? s : sl;
+}
+
+PQ_DEV void ln_bwd_row(const float (&v)[4], const float (&dyr)[4], const float (&gam)[4], float mean, float rstd, float (&g)[4],
+                       float (&dg)[4], float (&db)[4]) {   // norm.hip's add_ln_bwd at M = 1, no dropout
+  float xh[4], dz[4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float du = 1.f * dyr[j];
+    xh[j] = (v[j] - mean) * rstd;
+    dg[j] += du * xh[j];
+    db[j] += du;
+    dz[j] = du * gam[j];
+    s1 += dz[j];
+    s2 += dz[j] * xh[j];
+  }
+  s1 = wave_sum(s1) / (float)D;
+  s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] = rstd * (dz[j] - s1 - xh[j] * s2);
+}
+
+template <int NRT>
+__global__ __launch_bounds__(CT) void chain_mh_bwd_kernel(const pq3d_chain_mh_bwd_desc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
+  Ctx c;
+  c.Ah = (bf16_t*)ch_smem; c.Al = c.Ah; c.Bh = c.Ah; c.Bl = c.Ah; c.Ct = (float*)ch_smem;
+  c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = c.tid >> 6; c.li = c.lane & 15; c.lg = c.lane >> 4;
+  c.wm = (c.wave >> 2) * 16; c.wn = (c.wave & 3) * 16;
+  constexpr int GR = TM * NRT;
+  const int id = (int)blockIdx.x, xcd = id & 7, q = id >> 3, slot = q >> 3, j = q & 7;
+  const int grp = slot * 8 + xcd, m0 = grp * GR;
+  const int R = d.R, Cn = d.C, Mm = d.Mm;
+  if (m0 >= R) return;
+  unsigned* const group = d.flags + (long)grp * G * 16;
+  unsigned* const mine = group + j * 16;
+  unsigned vs = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* const lnws = d.lnws + (long)grp * G * 512;   // [8 members][gamma 256 | beta 256]
+
+  bf16_t* const Ap = (bf16_t*)ch_smem;                 // [NRT][32][LDR]: the left operand (bf16), whole K <= 256
+  bf16_t* const Bp = Ap + NRT * TM * LDR;              // [256 k][S0LD]: columns [32 j, + 32) of a weight
+  float* const Ct = (float*)(Bp + D * S0LD);           // [32][36]
+  const int wr0 = (c.wave >> 1) * 16, wc0 = (c.wave & 1) * 16;   // waves 0..3
+  // one weight slab [256 k][32 n] (k rows beyond kmax: zero): 1024 chunks of 8 floats, 2 per thread
+  auto issue_wslab = [&](const float* W, int kmax, RawA& r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = c.tid + i * CT, k = ch >> 2;
+      if (k < kmax) load8<false>(W, (long)k * D + j * S0N + (ch & 3) * 8, r.v[i]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[i][e] = 0.f;
+      }
+    }
+  };
+  auto put_wslab = [&](const RawA& r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = c.tid + i * CT;
+      *(u32x4*)&Bp[(ch >> 2) * S0LD + (ch & 3) * 8] = pack_frag<bf16_t>(r.v[i]);
+    }
+  };
+  auto mma_slab = [&](f32x4 (&acc)[NRT], int nks) {
+    if (c.wave < 4) {
+      for (int ks = 0; ks < nks; ++ks) {
+        const u32x4 bh = km_frag(Bp, S0LD, wc0, ks, c.li, c.lg);
+#pragma unroll
+        for (int t = 0; t < NRT; ++t)
+          Mma<bf16_t>::mma(acc[t], *(const u32x4*)&Ap[t * TM * LDR + (wr0 + c.li) * LDR + ks * 32 + c.lg * 8], bh);
+      }
+    }
+  };
+  RawA w4s, w0s;
+  issue_wslab(d.W4, Cn, w4s);
+  issue_wslab(d.W0, D, w0s);   // step 3's first weight travels under steps 1 and 2
+
+  // ---- 1. dh2 = dcl W4 (dcl = dc, focus columns zeroed): K = C classes, zero-padded to a multiple of 32
+  {
+    const int nks = (Cn + 31) >> 5;
+#pragma unroll
+    for (int t = 0; t < NRT; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ch = c.tid + i * CT, lr = ch >> 5, cc = ch & 31, row = m0 + t * TM + lr, rr = min(row, R - 1);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int col = cc * 8 + e;
+          float x = 0.f;
+          if (col < Cn) {
+            x = d.dc[(long)rr * Cn + col];
+            if (d.colfill && d.colfill[col]) x = 0.f;
+            if (d.dcl && (cc & 7) == j && row < R) d.dcl[(long)row * Cn + col] = x;
+          }
+          v[e] = x;
+        }
+        *(u32x4*)&Ap[t * TM * LDR + lr * LDR + cc * 8] = pack_frag<bf16_t>(v);
+      }
+    put_wslab(w4s);
+    __syncthreads();
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mma_slab(acc, nks);
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+      if (t > 0) __syncthreads();
+      if (c.wave < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[(wr0 + c.lg * 4 + r) * 36 + wc0 + c.li] = (acc[t][r] + 0.f) * 1.f;
+      }
+      __syncthreads();
+      if (c.tid < 256) {                                 // 32 rows x 8 pieces of 4 columns
+        const int orow = c.tid >> 3, col = (c.tid & 7) * 4, row = m0 + t * TM + orow;
+        if (row < R) *(float4*)(d.dh2 + (long)row * D + j * S0N + col) = *(const float4*)&Ct[orow * 36 + col];
+      }
+    }
+  }
+  handoff(c, mine, group, ++vs, d.err);
+  // ---- 2. dh1 = LN'(h1; dh2), dpre = [h1 > 0] dh1 (bf16): 32 NRT rows over 8 members x 4 NRT waves
+  {
+    const long lrow = m0 + 4 * NRT * j + c.wave;
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c.wave < 4 * NRT && lrow < R) {
+      const long lbase = lrow * D + c.lane * 4;
+      float ov[4], v[4], dyr[4], gam[4], g[4];
+      load4<false>(d.h1, lbase, ov);
+      load4<true>(d.dh2, lbase, dyr);
+      load4<false>(d.gamma, c.lane * 4, gam);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = 0.f + ov[k];
+      ln_bwd_row(v, dyr, gam, d.mean[lrow], d.rstd[lrow], g, dg, db);
+      *(u32x2*)((bf16_t*)d.dpre + lbase) = (u32x2){pack_bf2(ov[0] > 0.f ? g[0] : 0.f, ov[1] > 0.f ? g[1] : 0.f),
+                                                   pack_bf2(ov[2] > 0.f ? g[2] : 0.f, ov[3] > 0.f ? g[3] : 0.f)};
+    }
+    ln_partials_store(c, (float*)ch_smem, dg, db, lnws + j * 512);
+  }
+  handoff(c, mine, group, ++vs, d.err);
+  ln_partials_reduce(c, j, lnws, 512, 0, d.dgamma, d.dbeta);   // the LayerNorm's parameter gradients: 64 atomics per member
+  // ---- 3. out = sum_m dqm_m Wq_m + (dpre W0 + cur)
+  {
+    f32x4 acc1[NRT], acc2[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) { acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.dpre, 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+      for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ch = c.tid + i * CT;
+          *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] = __builtin_amdgcn_raw_buffer_load_b128(
+              rs, (int)(((long)min(m0 + t * TM + (ch >> 5), R - 1) * D + (ch & 31) * 8) * 2), 0, 16);
+        }
+      put_wslab(w0s);
+      __syncthreads();
+      mma_slab(acc1, D / 32);
+    }
+    for (int m = 0; m < Mm; ++m) {
+      __syncthreads();
+      RawA wq;
+      issue_wslab(d.Wq[m], D, wq);
+#pragma unroll
+      for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ch = c.tid + i * CT;
+          const long o = (long)min(m0 + t * TM + (ch >> 5), R - 1) * D + (ch & 31) * 8;
+          u32x4 a;
+          if (d.dq_f32) {
+            float v[8];
+            load8<false>((const float*)d.dq[m], o, v);
+            a = pack_frag<bf16_t>(v);
+          } else a = *(const u32x4*)((const bf16_t*)d.dq[m] + o);
+          *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] = a;
+        }
+      put_wslab(wq);
+      __syncthreads();
+      mma_slab(acc2, D / 32);
+    }
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+      const int orow = (c.tid & 255) >> 3, col = (c.tid & 7) * 4, row = m0 + t * TM + orow;
+      const long o = (long)row * D + j * S0N + col;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
+      if (c.wave < 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[(wr0 + c.lg * 4 + r) * 36 + wc0 + c.li] = (acc1[t][r] + 0.f) * 1.f;
+      }
+      __syncthreads();
+      if (c.tid < 256 && row < R) {
+        v = *(const float4*)&Ct[orow * 36 + col];
+        const float4 a = *(const float4*)(d.cur + o);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      if (Mm > 0) {   // uniform
+        __syncthreads();
+        if (c.wave < 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ct[(wr0 + c.lg * 4 + r) * 36 + wc0 + c.li] = (acc2[t][r] + 0.f) * 1.f;
+        }
+        __syncthreads();
+        if (c.tid < 256 && row < R) {
+          const float4 w = *(const float4*)&Ct[orow * 36 + col];
+          v.x = w.x + v.x; v.y = w.y + v.y; v.z = w.z + v.z; v.w = w.w + v.w;
+        }
+      }
+      if (c.tid < 256 && row < R) *(float4*)(d.out + o) = v;
+    }
+  }
+  handoff(c, mine, group, ++vs, d.err);   // (the flags advance by the same amount in every member)
+}
+
+template <int NRT>
+int launch_bwd(const pq3d_chain_mh_bwd_desc& d, int slots, hipStream_t s, std::atomic<unsigned>& done) {
+  if (int e = pq3d_enable_big_lds(chain_mh_bwd_kernel<NRT>, (int)mhb_lds<NRT>(), done)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
+  hipLaunchKernelGGL(chain_mh_bwd_kernel<NRT>, dim3((unsigned)(8 * G * slots)), dim3(CT), mhb_lds<NRT>(), s, d);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int pq3d_chain_mh_fwd(const pq3d_chain_mh_desc* dp, void* stream) {
@@ -181,6 +417,28 @@ extern "C" int pq3d_chain_mh_fwd(const pq3d_chain_mh_desc* dp, void* stream) {
                  "pq3d_chain_mh_fwd: per-memory operands (non-null, 16-byte aligned)");
   static std::atomic<unsigned> done1{0}, done2{0};
   if (int e = nrt == 1 ? launch_fwd<1>(d, slots, (hipStream_t)stream, done1) : launch_fwd<2>(d, slots, (hipStream_t)stream, done2)) return e;
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_chain_mh_bwd(const pq3d_chain_mh_bwd_desc* dp, void* stream) {
+  PQ_DEVICE_GUARD(stream, dp ? dp->dc : nullptr);
+  PQ_CHECK_ARG(dp != nullptr, "pq3d_chain_mh_bwd: null descriptor");
+  const pq3d_chain_mh_bwd_desc d = *dp;
+  PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.Mm >= 0 && d.Mm <= 3 && d.C >= 1 && d.C <= 256, "pq3d_chain_mh_bwd: d = 256, 0..3 memories, 1..256 classes");
+  const int row_tiles = (d.R + TM - 1) / TM;
+  const int nrt = row_tiles * G <= 256 ? 1 : 2;
+  const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
+  PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_mh_bwd: more than 2048 rows (the groups would not all be resident)");
+  const void* ps[] = {d.dc, d.W4, d.h1, d.mean, d.rstd, d.gamma, d.dgamma, d.dbeta, d.dh2, d.dpre, d.W0, d.cur, d.out, d.flags, d.lnws};
+  for (const void* p : ps) PQ_CHECK_ARG(p != nullptr, "pq3d_chain_mh_bwd: null pointer");
+  const void* al[] = {d.W4, d.h1, d.gamma, d.dh2, d.dpre, d.W0, d.cur, d.out};
+  for (const void* p : al) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_chain_mh_bwd: operands must be 16-byte aligned");
+  PQ_CHECK_ARG(!d.colfill || d.dcl, "pq3d_chain_mh_bwd: a column fill needs the dcl output");
+  for (int m = 0; m < d.Mm; ++m)
+    PQ_CHECK_ARG(d.dq[m] && d.Wq[m] && ((((uintptr_t)d.dq[m]) | ((uintptr_t)d.Wq[m])) & 15) == 0, "pq3d_chain_mh_bwd: dq / Wq (non-null, aligned)");
+  static std::atomic<unsigned> done1{0}, done2{0};
+  if (int e = nrt == 1 ? launch_bwd<1>(d, slots, (hipStream_t)stream, done1) : launch_bwd<2>(d, slots, (hipStream_t)stream, done2)) return e;
   PQ_LAUNCH_CHECK();
   return 0;
 }

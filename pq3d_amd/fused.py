@@ -429,6 +429,10 @@ class _DecoderBackward:
         x_in = rec["mh_x"]
         Hd, C_ = c0.out_features, c4.out_features
         cur = dx_in
+        if dc is not None and dm is not None and _CHAIN and ct == BF16 and ad == torch.bfloat16 and rec.get("mh_drop") is None and \
+                ops.chain_mh_ok(d, Hd, C_, spec.mh_count, R) and rec["mh_h1"].dtype == torch.float32 and \
+                isinstance(cur, torch.Tensor) and cur.dtype == torch.float32 and cur.is_contiguous():
+            return self.mask_head_chain(rec, dc, dm, cur)
         if dc is not None:
             dcl = dc.contiguous()
             if mh._foc_cols.numel():
@@ -481,6 +485,45 @@ class _DecoderBackward:
                     [G(mp.q_proj.bias) for mp in mps])
             cur = nxt
         return cur
+
+    def mask_head_chain(self, rec, dc, dm, cur):
+        """mask_head() with the row-local steps in one launch (csrc/chain_mh.hip): the mask logits' query-side gradient first
+        (not row-local: a reduction over the scene's segments), then class-MLP backward + both input-gradient products."""
+        ctx, spec, ct, ad, seg_pad, B = self.ctx, self.spec, self.ct, self.ad, self.seg_pad, self.B
+        Nq, d, Ns, dev, G, dwq = self.Nq, self.d, self.Ns, self.dev, self.G, self.dwq
+        mh = spec.mh
+        c0, c2, c4 = mh.cls_head[0], mh.cls_head[2], mh.cls_head[4]
+        x_in = rec["mh_x"]
+        Mm = spec.mh_count
+        mps = list(mh.mask_pred_list)[:Mm]
+        qm = rec["mh_qm"]
+        g = ops.scale_rows(dm.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=seg_pad)
+        if Mm * (len(self.dk_terms) + 1) <= MAXG:
+            self.dk_terms.append((g, qm))
+        else:
+            newk = torch.empty(Mm, B, Ns, d, dtype=torch.float32, device=dev)
+            L.gemm(M=Ns, N=d, K=Nq, A=[g] * Mm, B=[qm[m] for m in range(Mm)], Cs=[newk[m] for m in range(Mm)],
+                   aux=[self.dkeys[m] for m in range(Mm)] if self.dkeys is not None else None,
+                   act_grad="add" if self.dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
+                   strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
+            self.dkeys = newk
+        sk = min(8, Ns // 512) if Ns >= 1024 else 1
+        dqm = torch.empty(Mm, B, Nq, d, dtype=torch.float32 if sk > 1 else ad, device=dev)
+        L.gemm(M=Nq, N=d, K=Ns, A=[g] * Mm, B=list(ctx.keys), Cs=[dqm[m] for m in range(Mm)], ct=ct, lda=Nq,
+               ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d,
+               splitk=sk)
+        flags = getattr(mh, "_chain_flags_bwd", None)
+        if flags is None or flags.device != dev:
+            flags = mh._chain_flags_bwd = ops.chain_flags(2048, dev)
+        dcl, dpre, out = ops.chain_mh_bwd(
+            dc.contiguous(), mh._foc_flags if mh._foc_cols.numel() else None, c4.weight.detach(), rec["mh_h1"], rec["mh_mean"],
+            rec["mh_rstd"], c2.weight.detach(), G(c2.weight), G(c2.bias), c0.weight.detach(), cur,
+            [dqm[m] for m in range(Mm)], [mp.q_proj.weight.detach() for mp in mps], flags)
+        dwq.add([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct, [G(c4.bias)])
+        dwq.add([dpre], [x_in], None, [G(c0.weight)], ct, [G(c0.bias)])
+        dwq.add([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct,
+                [G(mp.q_proj.bias) for mp in mps])
+        return out
 
     def kv_terms(self, apps, into_queue):
         """(dK|dV, W) operand lists of the hoisted K/V projections' backward for the applications `apps`; with

@@ -1751,6 +1751,39 @@ def chain_mh_fwd(x, W0, b0, gamma, beta, eps, W4, b4, colfill, fill, Wqs, bqs, f
     return h1, h2, mean, rstd, cls, qm
 
 
+def chain_mh_bwd(dc, colfill, W4, h1, mean, rstd, gamma, dgamma, dbeta, W0, cur, dqs, Wqs, flags):
+    """Backward of chain_mh_fwd's part in one launch.  dc [..., C] fp32; dqs: the Mm query-side gradients of the mask logits
+    ([..., d] each, all fp32 or all bf16).  Returns (dcl, dpre bf16, out): dcl = dc with the flagged columns zeroed (dc itself
+    without flags), dpre = d(linear 0 output), out = sum_m dq_m Wq_m + (dpre W0 + cur).  dgamma / dbeta are accumulated onto."""
+    d = h1.shape[-1]
+    R, C_, Mm = h1.numel() // d, W4.shape[0], len(dqs)
+    dev = h1.device
+    dcl = torch.empty_like(dc) if colfill is not None else None
+    dh2, out = torch.empty_like(h1), torch.empty_like(h1)
+    dpre = torch.empty(h1.shape, dtype=torch.bfloat16, device=dev)
+    err = _CHAIN_ERR.get(dev)
+    if err is None:
+        err = _CHAIN_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    c = L.ChainMhBwdDesc()
+    c.R, c.d, c.Mm, c.C = R, d, Mm, C_
+    c.dq_f32 = int(Mm > 0 and dqs[0].dtype == torch.float32)
+    for n, t in (("dc", dc), ("W4", W4), ("h1", h1), ("mean", mean), ("rstd", rstd), ("gamma", gamma), ("dgamma", dgamma),
+                 ("dbeta", dbeta), ("W0", W0), ("cur", cur)):
+        assert t.is_contiguous() and t.dtype == torch.float32, n
+    assert colfill is None or (colfill.dtype == torch.int32 and colfill.numel() == C_ and colfill.is_contiguous())
+    for m in range(Mm):
+        assert dqs[m].is_contiguous() and dqs[m].dtype == dqs[0].dtype and dqs[m].dtype in (torch.float32, torch.bfloat16)
+        assert Wqs[m].is_contiguous() and Wqs[m].dtype == torch.float32
+        c.dq[m], c.Wq[m] = L.ptr(dqs[m]), L.ptr(Wqs[m])
+    c.dc, c.colfill, c.dcl, c.W4, c.h1, c.mean, c.rstd, c.gamma, c.dgamma, c.dbeta = map(
+        L.ptr, (dc, colfill, dcl, W4, h1, mean, rstd, gamma, dgamma, dbeta))
+    c.dh2, c.dpre, c.W0, c.cur, c.out, c.flags, c.err, c.lnws = map(L.ptr, (dh2, dpre, W0, cur, out, flags, err, _chain_ws(dev)))
+    fl = 2.0 * R * d * (C_ + d * (1 + Mm))
+    nb = 4.0 * (R * C_ * 2 + R * d * (5 + Mm) + C_ * d + (1 + Mm) * d * d) + 2.0 * R * d
+    L.check(timed("pq3d_chain_mh_bwd", f"R{R}d{d}M{Mm}C{C_}", fl, nb, L.lib().pq3d_chain_mh_bwd, C.byref(c), L.stream()), "pq3d_chain_mh_bwd")
+    return (dcl if dcl is not None else dc), dpre, out
+
+
 def chain_ffn_bwd(dx, x2, z, g2, mean2, rstd2, dg2, db2, W2, h, W1, x1s, f, g1, mean1, rstd1, dg1, db1, flags, prev=None):
     """Backward of the FFN sublayer + the self-attention post-norm in one launch.  Returns (dy, dhp, df): dy = d z (= the
     residual-branch gradient of LN2), dhp = d(linear1 output) as bf16, df = d f (= the residual-branch gradient of LN1).

@@ -60,6 +60,8 @@ int main(void) {
          offsetof(pq3d_chain_sa_bwd_desc, err));
   printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_mh_desc), offsetof(pq3d_chain_mh_desc, fill), offsetof(pq3d_chain_mh_desc, Wq),
          offsetof(pq3d_chain_mh_desc, err));
+  printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_mh_bwd_desc), offsetof(pq3d_chain_mh_bwd_desc, dc), offsetof(pq3d_chain_mh_bwd_desc, dq),
+         offsetof(pq3d_chain_mh_bwd_desc, lnws));
   return 0;
 }''')
     exe = tmp_path / "layout"
@@ -79,6 +81,8 @@ int main(void) {
     assert rows[6] == [ctypes.sizeof(Cs), Cs.dqkv.offset, Cs.coef.offset, Cs.err.offset]
     Cm = _lib.ChainMhDesc
     assert rows[7] == [ctypes.sizeof(Cm), Cm.fill.offset, Cm.Wq.offset, Cm.err.offset]
+    Cn = _lib.ChainMhBwdDesc
+    assert rows[8] == [ctypes.sizeof(Cn), Cn.dc.offset, Cn.dq.offset, Cn.lnws.offset]
 
 
 def test_argument_errors_are_reported(lib):

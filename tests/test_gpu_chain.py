@@ -291,3 +291,63 @@ def test_chain_mh_equals_five_launches(B, Nq, C_, Mm, fill):
         assert not ops.chain_error(dev)
         for n, a, b in zip(("h1", "h2", "mean", "rstd", "cls", "qm"), out, ref):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (n, rep)
+
+
+def _mh_bwd_six_launches(dc, cols, W4, h1, mean, rstd, gamma, dg, db, W0, cur, dqs, Wqs):
+    """The mask head's row-local backward as fused._DecoderBackward.mask_head launches it without the chain."""
+    from pq3d_amd import _lib as L, fused, ops
+    d = h1.shape[-1]
+    R, C_, Mm = h1.numel() // d, W4.shape[0], len(dqs)
+    dev = h1.device
+    dcl = dc
+    if cols is not None:
+        dcl = torch.empty_like(dc)
+        L.check(L.lib().pq3d_fill_cols(L.ptr(dc), L.ptr(dcl), R, C_, L.ptr(cols), cols.numel(), 0.0, L.stream()), "fill")
+    dh2 = torch.empty_like(h1)
+    L.gemm(M=R, N=d, K=C_, A=[dcl], B=[W4], Cs=[dh2], ct=L.BF16, lda=C_, ldb=d, ldc=d, transB=True)
+    _, dh1 = fused._ln_bwd(None, [h1], [gamma], [torch.zeros_like(gamma)], 1e-5, None, h1.shape[-2], mean, rstd, dh2, [dg], [db])
+    dpre = ops.act_bwd(dh1[0], h1, "relu", torch.bfloat16)
+    nxt = torch.empty_like(h1)
+    L.gemm(M=R, N=d, K=d, A=[dpre], B=[W0], Cs=[nxt], aux=[cur], act_grad="add", ct=L.BF16, lda=d, ldb=d, ldc=d, transB=True)
+    out = nxt
+    if Mm:
+        out = torch.empty_like(h1)
+        L.gemm(M=R, N=d, K=d, A=list(dqs), B=list(Wqs), Cs=[out] + [None] * (Mm - 1), aux=[nxt] + [None] * (Mm - 1), act_grad="add",
+               ct=L.BF16, lda=d, ldb=d, ldc=d, transB=True, kconcat=Mm)
+    return dcl, dpre, out
+
+
+@pytest.mark.parametrize("B,Nq,C_,Mm,fill,f32", [(4, 200, 201, 3, True, True), (8, 100, 201, 3, False, False), (3, 37, 19, 1, True, True),
+                                                 (1, 1, 1, 0, False, True), (1, 2048, 256, 3, True, False), (9, 200, 207, 2, True, True),
+                                                 (16, 100, 32, 3, False, True)])
+def test_chain_mh_bwd_against_separate_launches(B, Nq, C_, Mm, fill, f32):
+    from pq3d_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 1000 + Nq + C_ + 7)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    d = 256
+    cols = flags_c = None
+    if fill:
+        pick = sorted({0, C_ - 1, C_ // 2})
+        cols = torch.tensor(pick, dtype=torch.int32, device=dev)
+        flags_c = torch.zeros(C_, dtype=torch.int32, device=dev)
+        flags_c[cols.long()] = 1
+    h1 = torch.relu(r(B, Nq, d))
+    mean, rstd = h1.mean(-1).reshape(1, -1).contiguous(), (1.0 / (h1.var(-1, unbiased=False) + 1e-5).sqrt()).reshape(1, -1).contiguous()
+    dc, W4, gamma, W0, cur = r(B, Nq, C_), r(C_, d, sc=0.06), 1 + r(d, sc=0.1), r(d, d, sc=0.06), r(B, Nq, d)
+    dqs = [r(B, Nq, d) if f32 else r(B, Nq, d).bfloat16() for _ in range(Mm)]
+    Wqs = [r(d, d, sc=0.06) for _ in range(Mm)]
+    dg0, db0 = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    ref = _mh_bwd_six_launches(dc, cols, W4, h1, mean, rstd, gamma, dg0, db0, W0, cur, dqs, Wqs)
+    flags = ops.chain_flags(B * Nq, dev)
+    for rep in range(3):
+        dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+        out = ops.chain_mh_bwd(dc, flags_c, W4, h1, mean, rstd, gamma, dg, db, W0, cur, dqs, Wqs, flags)
+        torch.cuda.synchronize()
+        assert not ops.chain_error(dev)
+        for n, a, b in zip(("dcl", "dpre", "out"), out, ref):
+            assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32),
+                               b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32)), (n, rep, (a.float() - b.float()).abs().max().item())
+        # parameter gradients: the same terms in another summation order
+        for n, a, b in (("dgamma", dg, dg0), ("dbeta", db, db0)):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max()))), (n, (a - b).abs().max().item())
