@@ -491,6 +491,13 @@ typedef struct {
   uint32_t* flags;
   int32_t* err;
   float* lnws;
+  /* optional: cur = sum_m dqc_m Wqc_m + dxr formed in the launch (m < nq <= 3, dqc_m bf16; gq receives the sum without dxr) --
+   * the input gradient of the cross-attention query projections that pq3d_gemm (kconcat, C2) forms otherwise; nq = 0: cur is read */
+  int32_t nq;
+  const void* dqc[3];           /* [R, d] bf16 */
+  const float* Wqc[3];          /* [d, d] */
+  const float* dxr;             /* [R, d] */
+  float* gq;                    /* [R, d] out */
 } pq3d_chain_mh_bwd_desc;
 int pq3d_chain_mh_bwd(const pq3d_chain_mh_bwd_desc* d, void* stream);
 

@@ -184,7 +184,8 @@ class ChainMhBwdDesc(C.Structure):
                [(n, C.c_void_p) for n in ("dc", "colfill", "dcl", "W4", "h1", "mean", "rstd", "gamma", "dgamma", "dbeta", "dh2", "dpre",
                                           "W0", "cur")] + \
                [("dq", C.c_void_p * 3), ("Wq", C.c_void_p * 3), ("out", C.c_void_p), ("flags", C.c_void_p), ("err", C.c_void_p),
-                ("lnws", C.c_void_p)]
+                ("lnws", C.c_void_p), ("nq", C.c_int32), ("dqc", C.c_void_p * 3), ("Wqc", C.c_void_p * 3), ("dxr", C.c_void_p),
+                ("gq", C.c_void_p)]
 
 
 class ChainFfnBwdDesc(C.Structure):

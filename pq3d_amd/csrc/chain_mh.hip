@@ -169,6 +169,8 @@ int launch_fwd(const pq3d_chain_mh_desc& d, int slots, hipStream_t s, std::atomi
 //     dh2  = dcl W4                                                (single-bf16 product, K = C classes)
 //     dh1  = LN'(h1; dh2)   (d gamma, d beta accumulated)          dpre = [h1 > 0] dh1  (bf16: operand of W0's weight gradient)
 //     t    = dpre W0 + cur                                         out = sum_m dqm_m Wq_m + t
+//     (optionally cur itself = sum_m dqc_m Wqc_m + dxr: the query-projection input gradient of the cross-attention that ran
+//      backward just before -- one more launch, pq3d_gemm with kconcat + C2)
 // Products as pq3d_gemm's transB form (weights [k][n] row-major, read through the transposing LDS load): member j owns 32 output
 // columns, waves 0..3 = 2 row halves x 2 column blocks, one accumulator per row tile and product.
 constexpr int S0N = 32, S0LD = S0N + 8;
@@ -317,9 +319,11 @@ __global__ __launch_bounds__(CT) void chain_mh_bwd_kernel(const pq3d_chain_mh_bw
   ln_partials_reduce(c, j, lnws, 512, 0, d.dgamma, d.dbeta);   // the LayerNorm's parameter gradients: 64 atomics per member
   // ---- 3. out = sum_m dqm_m Wq_m + (dpre W0 + cur)
   {
-    f32x4 acc1[NRT], acc2[NRT];
+    f32x4 acc0[NRT], acc1[NRT], acc2[NRT];
 #pragma unroll
-    for (int t = 0; t < NRT; ++t) { acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < NRT; ++t) {
+      acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     {
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.dpre, 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
@@ -356,11 +360,43 @@ __global__ __launch_bounds__(CT) void chain_mh_bwd_kernel(const pq3d_chain_mh_bw
       __syncthreads();
       mma_slab(acc2, D / 32);
     }
+    // (optional) cur itself: the input gradient of the following layer application's cross-attention query projections,
+    // cur = sum_m dqc_m Wqc_m + dxr (gq = the sum without dxr) -- the member owns the same 32 columns of it, no hand-off needed
+    for (int m = 0; m < d.nq; ++m) {
+      __syncthreads();
+      RawA wq;
+      issue_wslab(d.Wqc[m], D, wq);
+#pragma unroll
+      for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int ch = c.tid + i * CT;
+          *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] =
+              *(const u32x4*)((const bf16_t*)d.dqc[m] + (long)min(m0 + t * TM + (ch >> 5), R - 1) * D + (ch & 31) * 8);
+        }
+      put_wslab(wq);
+      __syncthreads();
+      mma_slab(acc0, D / 32);
+    }
 #pragma unroll
     for (int t = 0; t < NRT; ++t) {
       const int orow = (c.tid & 255) >> 3, col = (c.tid & 7) * 4, row = m0 + t * TM + orow;
       const long o = (long)row * D + j * S0N + col;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), cur4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d.nq > 0) {   // uniform
+        __syncthreads();
+        if (c.wave < 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ct[(wr0 + c.lg * 4 + r) * 36 + wc0 + c.li] = (acc0[t][r] + 0.f) * 1.f;
+        }
+        __syncthreads();
+        if (c.tid < 256 && row < R) {
+          cur4 = *(const float4*)&Ct[orow * 36 + col];
+          *(float4*)(d.gq + o) = cur4;
+          const float4 a = *(const float4*)(d.dxr + o);
+          cur4.x += a.x; cur4.y += a.y; cur4.z += a.z; cur4.w += a.w;
+        }
+      } else if (c.tid < 256 && row < R) cur4 = *(const float4*)(d.cur + o);
       __syncthreads();
       if (c.wave < 4) {
 #pragma unroll
@@ -369,8 +405,7 @@ __global__ __launch_bounds__(CT) void chain_mh_bwd_kernel(const pq3d_chain_mh_bw
       __syncthreads();
       if (c.tid < 256 && row < R) {
         v = *(const float4*)&Ct[orow * 36 + col];
-        const float4 a = *(const float4*)(d.cur + o);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        v.x += cur4.x; v.y += cur4.y; v.z += cur4.z; v.w += cur4.w;
       }
       if (Mm > 0) {   // uniform
         __syncthreads();
@@ -430,9 +465,15 @@ extern "C" int pq3d_chain_mh_bwd(const pq3d_chain_mh_bwd_desc* dp, void* stream)
   const int nrt = row_tiles * G <= 256 ? 1 : 2;
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_mh_bwd: more than 2048 rows (the groups would not all be resident)");
-  const void* ps[] = {d.dc, d.W4, d.h1, d.mean, d.rstd, d.gamma, d.dgamma, d.dbeta, d.dh2, d.dpre, d.W0, d.cur, d.out, d.flags, d.lnws};
+  const void* ps[] = {d.dc, d.W4, d.h1, d.mean, d.rstd, d.gamma, d.dgamma, d.dbeta, d.dh2, d.dpre, d.W0, d.out, d.flags, d.lnws};
   for (const void* p : ps) PQ_CHECK_ARG(p != nullptr, "pq3d_chain_mh_bwd: null pointer");
-  const void* al[] = {d.W4, d.h1, d.gamma, d.dh2, d.dpre, d.W0, d.cur, d.out};
+  PQ_CHECK_ARG(d.nq >= 0 && d.nq <= 3, "pq3d_chain_mh_bwd: 0..3 query-projection terms");
+  if (d.nq > 0) {
+    PQ_CHECK_ARG(d.dxr && d.gq && ((((uintptr_t)d.dxr) | ((uintptr_t)d.gq)) & 15) == 0, "pq3d_chain_mh_bwd: dxr, gq (non-null, 16-byte aligned)");
+    for (int m = 0; m < d.nq; ++m)
+      PQ_CHECK_ARG(d.dqc[m] && d.Wqc[m] && ((((uintptr_t)d.dqc[m]) | ((uintptr_t)d.Wqc[m])) & 15) == 0, "pq3d_chain_mh_bwd: dqc / Wqc (non-null, aligned)");
+  } else PQ_CHECK_ARG(d.cur && (((uintptr_t)d.cur) & 15) == 0, "pq3d_chain_mh_bwd: cur (non-null, 16-byte aligned)");
+  const void* al[] = {d.W4, d.h1, d.gamma, d.dh2, d.dpre, d.W0, d.out};
   for (const void* p : al) PQ_CHECK_ARG((((uintptr_t)p) & 15) == 0, "pq3d_chain_mh_bwd: operands must be 16-byte aligned");
   PQ_CHECK_ARG(!d.colfill || d.dcl, "pq3d_chain_mh_bwd: a column fill needs the dcl output");
   for (int m = 0; m < d.Mm; ++m)

@@ -45,21 +45,33 @@ def _gemm_groups(n_per_call_limit, **kw):
 def _colsum_acc(xs: Sequence[torch.Tensor], outs: Sequence[torch.Tensor], rows: int) -> None:
     """outs[g] += column sums of xs[g] viewed as [rows, N] (bias gradients into the arena)."""
     N = xs[0].numel() // rows
-    # a launch adds with one (non-atomic) writer per output element: outputs must be unique within a launch
-    # (shared weights across num_blocks put the same bias slice in several groups) -> greedy batching
-    batches, cur, seen = [], ([], []), set()
+    # operands of one output that lie back to back in memory (the mask head's calls write slices of one buffer) are one taller
+    # operand: (first tensor, output, number of row blocks)
+    merged = []
     for xt, ot in zip(xs, outs):
-        if ot.data_ptr() in seen or len(cur[0]) == MAXG:
-            batches.append(cur)
-            cur, seen = ([], []), set()
-        cur[0].append(xt); cur[1].append(ot); seen.add(ot.data_ptr())
-    batches.append(cur)
-    for xc, oc in batches:
-        xa = (C.c_void_p * len(xc))(*[L.ptr(t) for t in xc])
-        oa = (C.c_void_p * len(oc))(*[L.ptr(t) for t in oc])
-        # accumulate = 2: the one-writer (bit-reproducible) form at every row count; 1 lets long columns add row slices atomically
-        L.check(L.lib().pq3d_colsum_grouped(xa, oa, len(xc), L.dt_of(xc[0]), rows, N, N, 2 if ops.DETERMINISTIC else 1, L.stream()),
-                "pq3d_colsum_grouped")
+        if merged and merged[-1][1].data_ptr() == ot.data_ptr() and xt.dtype == merged[-1][0].dtype and \
+                xt.data_ptr() == merged[-1][0].data_ptr() + merged[-1][2] * rows * N * xt.element_size():
+            merged[-1][2] += 1
+        else:
+            merged.append([xt, ot, 1])
+    for nblk in sorted({m_[2] for m_ in merged}):
+        # a launch adds with one (non-atomic) writer per output element: outputs must be unique within a launch
+        # (shared weights across num_blocks put the same bias slice in several groups) -> greedy batching
+        batches, cur, seen = [], ([], []), set()
+        for xt, ot, nb_ in merged:
+            if nb_ != nblk:
+                continue
+            if ot.data_ptr() in seen or len(cur[0]) == MAXG:
+                batches.append(cur)
+                cur, seen = ([], []), set()
+            cur[0].append(xt); cur[1].append(ot); seen.add(ot.data_ptr())
+        batches.append(cur)
+        for xc, oc in batches:
+            xa = (C.c_void_p * len(xc))(*[L.ptr(t) for t in xc])
+            oa = (C.c_void_p * len(oc))(*[L.ptr(t) for t in oc])
+            # accumulate = 2: the one-writer (bit-reproducible) form at every row count; 1 lets long columns add row slices atomically
+            L.check(L.lib().pq3d_colsum_grouped(xa, oa, len(xc), L.dt_of(xc[0]), rows * nblk, N, N, 2 if ops.DETERMINISTIC else 1,
+                                                L.stream()), "pq3d_colsum_grouped")
 
 
 def _splitk(tiles: int, k: int, ct: int, groups: int) -> int:
@@ -333,6 +345,7 @@ class _DecoderBackward:
         self.dqpos_parts: List[torch.Tensor] = []
         self.dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=self.ad, device=dev)
         self.dPKV = torch.empty(n_app, 2, B, ctx.prompt.shape[1], d, dtype=self.ad, device=dev) if spec.prompt else None
+        self._mh_calls, self._mh_dqm, self._mh_dcl = 0, None, None   # mask_head_chain(): per-pass buffers shared by its calls
         self.dkeys = None    # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
         self.dk_terms = []   # queued (g, q_m) terms of it (one K-concatenated launch at the end)
         ready_cb = getattr(enc, "grads_ready", None) if self.in_place else None   # only when the owner's buffers were written
@@ -429,10 +442,9 @@ class _DecoderBackward:
         x_in = rec["mh_x"]
         Hd, C_ = c0.out_features, c4.out_features
         cur = dx_in
-        if dc is not None and dm is not None and _CHAIN and ct == BF16 and ad == torch.bfloat16 and rec.get("mh_drop") is None and \
-                ops.chain_mh_ok(d, Hd, C_, spec.mh_count, R) and rec["mh_h1"].dtype == torch.float32 and \
-                isinstance(cur, torch.Tensor) and cur.dtype == torch.float32 and cur.is_contiguous():
+        if self.mask_head_chain_ok(rec, dc, dm, cur):
             return self.mask_head_chain(rec, dc, dm, cur)
+        assert not isinstance(cur, _PendingDx)
         if dc is not None:
             dcl = dc.contiguous()
             if mh._foc_cols.numel():
@@ -486,6 +498,16 @@ class _DecoderBackward:
             cur = nxt
         return cur
 
+    def mask_head_chain_ok(self, rec, dc, dm, cur) -> bool:
+        mh = self.spec.mh
+        c0, c4 = mh.cls_head[0], mh.cls_head[4]
+        if isinstance(cur, _PendingDx):
+            cur = cur.dxr
+        return (dc is not None and dm is not None and _CHAIN and self.ct == BF16 and self.ad == torch.bfloat16 and
+                rec.get("mh_drop") is None and ops.chain_mh_ok(self.d, c0.out_features, c4.out_features, self.spec.mh_count, self.R)
+                and rec["mh_h1"].dtype == torch.float32 and isinstance(cur, torch.Tensor) and cur.dtype == torch.float32
+                and cur.is_contiguous())
+
     def mask_head_chain(self, rec, dc, dm, cur):
         """mask_head() with the row-local steps in one launch (csrc/chain_mh.hip): the mask logits' query-side gradient first
         (not row-local: a reduction over the scene's segments), then class-MLP backward + both input-gradient products."""
@@ -508,17 +530,32 @@ class _DecoderBackward:
                    strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
             self.dkeys = newk
         sk = min(8, Ns // 512) if Ns >= 1024 else 1
-        dqm = torch.empty(Mm, B, Nq, d, dtype=torch.float32 if sk > 1 else ad, device=dev)
+        call = self._mh_calls
+        self._mh_calls += 1
+        if sk > 1:
+            # split-K partial sums are added into the output: the outputs of ALL mask-head calls of the pass are one buffer zeroed
+            # by one launch (each call used to zero its own: 5 launches at config 4)
+            if self._mh_dqm is None:
+                self._mh_dqm = torch.empty(self.n_mh, Mm, B, Nq, d, dtype=torch.float32, device=dev)
+                ops.zero_many([self._mh_dqm])
+            dqm = self._mh_dqm[call]
+        else:
+            dqm = torch.empty(Mm, B, Nq, d, dtype=ad, device=dev)
         L.gemm(M=Nq, N=d, K=Ns, A=[g] * Mm, B=list(ctx.keys), Cs=[dqm[m] for m in range(Mm)], ct=ct, lda=Nq,
                ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d,
-               splitk=sk)
+               splitk=sk, accumulate=sk > 1)
+        if self._mh_dcl is None and mh._foc_cols.numel():   # adjacent rows call after call: their column sums (the bias
+            self._mh_dcl = torch.empty(self.n_mh, B, Nq, c4.out_features, dtype=torch.float32, device=dev)   # gradient) in one launch
         flags = getattr(mh, "_chain_flags_bwd", None)
         if flags is None or flags.device != dev:
             flags = mh._chain_flags_bwd = ops.chain_flags(2048, dev)
         dcl, dpre, out = ops.chain_mh_bwd(
             dc.contiguous(), mh._foc_flags if mh._foc_cols.numel() else None, c4.weight.detach(), rec["mh_h1"], rec["mh_mean"],
-            rec["mh_rstd"], c2.weight.detach(), G(c2.weight), G(c2.bias), c0.weight.detach(), cur,
-            [dqm[m] for m in range(Mm)], [mp.q_proj.weight.detach() for mp in mps], flags)
+            rec["mh_rstd"], c2.weight.detach(), G(c2.weight), G(c2.bias), c0.weight.detach(),
+            None if isinstance(cur, _PendingDx) else cur,
+            [dqm[m] for m in range(Mm)], [mp.q_proj.weight.detach() for mp in mps], flags,
+            dcl_out=self._mh_dcl[call] if self._mh_dcl is not None else None,
+            prev=(cur.dq_all, cur.Wqs, cur.dxr, cur.gq) if isinstance(cur, _PendingDx) else None)
         dwq.add([dcl], [rec["mh_h2"]], None, [G(c4.weight)], ct, [G(c4.bias)])
         dwq.add([dpre], [x_in], None, [G(c0.weight)], ct, [G(c0.bias)])
         dwq.add([dqm[m] for m in range(Mm)], [x_in] * Mm, None, [G(mp.q_proj.weight) for mp in mps], ct,
@@ -760,8 +797,11 @@ class _DecoderBackward:
         gq = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
         # the input gradient of the query projections feeds the FFN backward of the application in front of this one: when that
         # one runs as a chain launch (and no mask-head call sits in between) the launch forms it itself (step 0)
-        fold = a > 0 and (spec.mh is None or spec.skip_pred) and M <= 3 and dq_all.dtype == torch.bfloat16 and \
-            self.ffn_chain_ok(self.tape[a - 1], self.layers[self.tape[a - 1]["i"]], dxr)
+        if spec.mh is None or spec.skip_pred:
+            fold = a > 0 and M <= 3 and dq_all.dtype == torch.bfloat16 and \
+                self.ffn_chain_ok(self.tape[a - 1], self.layers[self.tape[a - 1]["i"]], dxr)
+        else:   # a mask-head call sits in front of this application: its chain launch forms the sum (csrc/chain_mh.hip)
+            fold = M <= 3 and dq_all.dtype == torch.bfloat16 and self.mask_head_chain_ok(rec, self.dcls[a], self.dmlog[a], dxr)
         if fold:
             dxn = _PendingDx(dq_all, [w[:d] for w in ws], dxr, gq)
         else:

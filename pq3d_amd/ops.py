@@ -1751,14 +1751,17 @@ def chain_mh_fwd(x, W0, b0, gamma, beta, eps, W4, b4, colfill, fill, Wqs, bqs, f
     return h1, h2, mean, rstd, cls, qm
 
 
-def chain_mh_bwd(dc, colfill, W4, h1, mean, rstd, gamma, dgamma, dbeta, W0, cur, dqs, Wqs, flags):
+def chain_mh_bwd(dc, colfill, W4, h1, mean, rstd, gamma, dgamma, dbeta, W0, cur, dqs, Wqs, flags, dcl_out=None, prev=None):
     """Backward of chain_mh_fwd's part in one launch.  dc [..., C] fp32; dqs: the Mm query-side gradients of the mask logits
     ([..., d] each, all fp32 or all bf16).  Returns (dcl, dpre bf16, out): dcl = dc with the flagged columns zeroed (dc itself
-    without flags), dpre = d(linear 0 output), out = sum_m dq_m Wq_m + (dpre W0 + cur).  dgamma / dbeta are accumulated onto."""
+    without flags), dpre = d(linear 0 output), out = sum_m dq_m Wq_m + (dpre W0 + cur).  dgamma / dbeta are accumulated onto.
+    prev = (dq_all [M, ..., d] bf16, [Wq_m], dxr, gq): cur is None and cur = sum_m dq_all_m Wq_m + dxr is formed in the launch (gq
+    receives the sum without dxr)."""
     d = h1.shape[-1]
     R, C_, Mm = h1.numel() // d, W4.shape[0], len(dqs)
     dev = h1.device
-    dcl = torch.empty_like(dc) if colfill is not None else None
+    dcl = (dcl_out if dcl_out is not None else torch.empty_like(dc)) if colfill is not None else None
+    assert dcl is None or (dcl.is_contiguous() and dcl.dtype == torch.float32 and dcl.shape == dc.shape)
     dh2, out = torch.empty_like(h1), torch.empty_like(h1)
     dpre = torch.empty(h1.shape, dtype=torch.bfloat16, device=dev)
     err = _CHAIN_ERR.get(dev)
@@ -1767,6 +1770,16 @@ def chain_mh_bwd(dc, colfill, W4, h1, mean, rstd, gamma, dgamma, dbeta, W0, cur,
     c = L.ChainMhBwdDesc()
     c.R, c.d, c.Mm, c.C = R, d, Mm, C_
     c.dq_f32 = int(Mm > 0 and dqs[0].dtype == torch.float32)
+    if prev is not None:
+        dq_all, Wqc, dxr, gq = prev
+        assert cur is None and dq_all.dtype == torch.bfloat16 and dq_all.is_contiguous() and 1 <= dq_all.shape[0] <= 3
+        c.nq = dq_all.shape[0]
+        for m in range(c.nq):
+            assert Wqc[m].is_contiguous() and Wqc[m].dtype == torch.float32
+            c.dqc[m], c.Wqc[m] = L.ptr(dq_all[m]), L.ptr(Wqc[m])
+        cur = dxr
+        c.dxr, c.gq = L.ptr(dxr), L.ptr(gq)
+        assert gq.is_contiguous() and gq.dtype == torch.float32
     for n, t in (("dc", dc), ("W4", W4), ("h1", h1), ("mean", mean), ("rstd", rstd), ("gamma", gamma), ("dgamma", dgamma),
                  ("dbeta", dbeta), ("W0", W0), ("cur", cur)):
         assert t.is_contiguous() and t.dtype == torch.float32, n
@@ -1777,7 +1790,8 @@ def chain_mh_bwd(dc, colfill, W4, h1, mean, rstd, gamma, dgamma, dbeta, W0, cur,
         c.dq[m], c.Wq[m] = L.ptr(dqs[m]), L.ptr(Wqs[m])
     c.dc, c.colfill, c.dcl, c.W4, c.h1, c.mean, c.rstd, c.gamma, c.dgamma, c.dbeta = map(
         L.ptr, (dc, colfill, dcl, W4, h1, mean, rstd, gamma, dgamma, dbeta))
-    c.dh2, c.dpre, c.W0, c.cur, c.out, c.flags, c.err, c.lnws = map(L.ptr, (dh2, dpre, W0, cur, out, flags, err, _chain_ws(dev)))
+    c.dh2, c.dpre, c.W0, c.cur, c.out, c.flags, c.err, c.lnws = map(
+        L.ptr, (dh2, dpre, W0, cur if prev is None else None, out, flags, err, _chain_ws(dev)))
     fl = 2.0 * R * d * (C_ + d * (1 + Mm))
     nb = 4.0 * (R * C_ * 2 + R * d * (5 + Mm) + C_ * d + (1 + Mm) * d * d) + 2.0 * R * d
     L.check(timed("pq3d_chain_mh_bwd", f"R{R}d{d}M{Mm}C{C_}", fl, nb, L.lib().pq3d_chain_mh_bwd, C.byref(c), L.stream()), "pq3d_chain_mh_bwd")

@@ -61,7 +61,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_mh_desc), offsetof(pq3d_chain_mh_desc, fill), offsetof(pq3d_chain_mh_desc, Wq),
          offsetof(pq3d_chain_mh_desc, err));
   printf("%zu %zu %zu %zu\n", sizeof(pq3d_chain_mh_bwd_desc), offsetof(pq3d_chain_mh_bwd_desc, dc), offsetof(pq3d_chain_mh_bwd_desc, dq),
-         offsetof(pq3d_chain_mh_bwd_desc, lnws));
+         offsetof(pq3d_chain_mh_bwd_desc, gq));
   return 0;
 }''')
     exe = tmp_path / "layout"
@@ -82,7 +82,7 @@ int main(void) {
     Cm = _lib.ChainMhDesc
     assert rows[7] == [ctypes.sizeof(Cm), Cm.fill.offset, Cm.Wq.offset, Cm.err.offset]
     Cn = _lib.ChainMhBwdDesc
-    assert rows[8] == [ctypes.sizeof(Cn), Cn.dc.offset, Cn.dq.offset, Cn.lnws.offset]
+    assert rows[8] == [ctypes.sizeof(Cn), Cn.dc.offset, Cn.dq.offset, Cn.gq.offset]
 
 
 def test_argument_errors_are_reported(lib):

@@ -351,3 +351,35 @@ def test_chain_mh_bwd_against_separate_launches(B, Nq, C_, Mm, fill, f32):
         # parameter gradients: the same terms in another summation order
         for n, a, b in (("dgamma", dg, dg0), ("dbeta", db, db0)):
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(b.abs().max()))), (n, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("B,Nq,M", [(4, 200, 3), (3, 37, 2), (16, 100, 1)])
+def test_chain_mh_bwd_forms_its_upstream_gradient(B, Nq, M):
+    """prev = (dq_all, Wq, dxr, gq): cur = sum_m dq_m Wq_m + dxr formed inside the launch, bit for bit pq3d_gemm's (kconcat, C2)."""
+    from pq3d_amd import _lib as L, ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 77 + Nq + M)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    d, C_, Mm = 256, 201, 3
+    R = B * Nq
+    flags_c = torch.zeros(C_, dtype=torch.int32, device=dev)
+    flags_c[5] = 1
+    h1 = torch.relu(r(B, Nq, d))
+    mean, rstd = h1.mean(-1).reshape(1, -1).contiguous(), (1.0 / (h1.var(-1, unbiased=False) + 1e-5).sqrt()).reshape(1, -1).contiguous()
+    dc, W4, gamma, W0 = r(B, Nq, C_), r(C_, d, sc=0.06), 1 + r(d, sc=0.1), r(d, d, sc=0.06)
+    dqs, Wqs = [r(B, Nq, d) for _ in range(Mm)], [r(d, d, sc=0.06) for _ in range(Mm)]
+    dq_all, Wqc, dxr = r(M, B, Nq, d).bfloat16(), [r(d, d, sc=0.06) for _ in range(M)], r(B, Nq, d)
+    cur, gq0 = torch.empty_like(dxr), torch.empty_like(dxr)
+    L.gemm(M=R, N=d, K=d, A=[dq_all[m] for m in range(M)], B=Wqc, Cs=[cur] + [None] * (M - 1), C2=[gq0] + [None] * (M - 1),
+           aux=[dxr] + [None] * (M - 1), act_grad="add", ct=L.BF16, lda=d, ldb=d, ldc=d, transB=True, kconcat=M)
+    flags = ops.chain_flags(R, dev)
+    z = lambda: torch.zeros(d, device=dev)
+    ref = ops.chain_mh_bwd(dc, flags_c, W4, h1, mean, rstd, gamma, z(), z(), W0, cur, dqs, Wqs, flags)
+    for rep in range(2):
+        gq = torch.empty_like(dxr)
+        out = ops.chain_mh_bwd(dc, flags_c, W4, h1, mean, rstd, gamma, z(), z(), W0, None, dqs, Wqs, flags, prev=(dq_all, Wqc, dxr, gq))
+        torch.cuda.synchronize()
+        assert not ops.chain_error(dev)
+        assert torch.equal(gq.view(torch.int32), gq0.view(torch.int32))
+        assert torch.equal(out[2].view(torch.int32), ref[2].view(torch.int32)), (out[2] - ref[2]).abs().max().item()
+        assert torch.equal(out[1].view(torch.int16), ref[1].view(torch.int16))
