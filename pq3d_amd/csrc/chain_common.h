@@ -3,6 +3,8 @@
 // word per member; consumers poll the flags and read the rows with L1-bypassing sc1 loads).  See chain_ffn.hip for the design
 // notes and the measurements.  The GEMM pieces are gemm_wk.hip's 32 x 64 x 256 plan, instruction for instruction.
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -447,6 +449,14 @@ PQ_DEV void ln_partials_reduce(const Ctx& c, int j, const float* group, int stri
     unsafeAtomicAdd(kind ? &dbeta[col] : &dgamma[col], sv);
 #endif
   }
+}
+
+// Row tiles per group: 1 while all groups are resident at once (8 workgroups per group, at most one workgroup per CU), else 2.
+// PQ3D_CHAIN_NRT=2 forces two (a tuning switch for measurements: half as many groups, each weight slab converted once for 64 rows).
+inline int chain_nrt(int row_tiles) {
+  static const int forced = [] { const char* e = getenv("PQ3D_CHAIN_NRT"); return e ? atoi(e) : 0; }();
+  if (forced == 2) return 2;
+  return row_tiles * G <= 256 ? 1 : 2;
 }
 
 // in-kernel timeline (probe builds only, tools/probes/chain_timeline.py): thread 0 of workgroup 0 stamps the 100 MHz clock

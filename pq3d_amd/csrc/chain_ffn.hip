@@ -309,7 +309,7 @@ extern "C" int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* dp, void* stream) {
   const pq3d_chain_ffn_desc d = *dp;
   PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.F == 2048, "pq3d_chain_ffn_fwd: d = 256, F = 2048");
   const int row_tiles = (d.R + TM - 1) / TM;
-  const int nrt = row_tiles * G <= 256 ? 1 : 2;   // all groups resident: 8 workgroups per group, one per CU
+  const int nrt = chain_nrt(row_tiles);
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_ffn_fwd: more than 2048 rows (the groups would not all be resident)");
   PQ_CHECK_ARG(d.o_s && d.Wo && d.bo && d.x1s && d.g1 && d.be1 && d.f && d.x2 && d.mean1 && d.rstd1 && d.W1 && d.b1 && d.h && d.W2 && d.b2 &&

@@ -341,7 +341,7 @@ extern "C" int pq3d_chain_ffn_bwd(const pq3d_chain_ffn_bwd_desc* dp, void* strea
   const pq3d_chain_ffn_bwd_desc d = *dp;
   PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.F == 2048, "pq3d_chain_ffn_bwd: d = 256, F = 2048");
   const int row_tiles = (d.R + TM - 1) / TM;
-  const int nrt = row_tiles * G <= 256 ? 1 : 2;
+  const int nrt = chain_nrt(row_tiles);
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_ffn_bwd: more than 2048 rows (the groups would not all be resident)");
   const void* ps[] = {d.nq > 0 ? (const void*)d.dxo : (const void*)d.dx, d.x2, d.z, d.g2, d.mean2, d.rstd2, d.dg2, d.db2, d.dy, d.W2, d.h, d.dhp, d.W1, d.part, d.x1s, d.f, d.g1, d.mean1,

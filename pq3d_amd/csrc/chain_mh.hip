@@ -440,7 +440,7 @@ extern "C" int pq3d_chain_mh_fwd(const pq3d_chain_mh_desc* dp, void* stream) {
   const pq3d_chain_mh_desc d = *dp;
   PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.Mm >= 0 && d.Mm <= 3 && d.C >= 1 && d.C <= 256, "pq3d_chain_mh_fwd: d = 256, 0..3 memories, 1..256 classes");
   const int row_tiles = (d.R + TM - 1) / TM;
-  const int nrt = row_tiles * G <= 256 ? 1 : 2;
+  const int nrt = chain_nrt(row_tiles);
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_mh_fwd: more than 2048 rows (the groups would not all be resident)");
   PQ_CHECK_ARG(d.x && d.W0 && d.b0 && d.gamma && d.beta && d.W4 && d.h1 && d.h2 && d.mean && d.rstd && d.cls && d.flags,
@@ -462,7 +462,7 @@ extern "C" int pq3d_chain_mh_bwd(const pq3d_chain_mh_bwd_desc* dp, void* stream)
   const pq3d_chain_mh_bwd_desc d = *dp;
   PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.Mm >= 0 && d.Mm <= 3 && d.C >= 1 && d.C <= 256, "pq3d_chain_mh_bwd: d = 256, 0..3 memories, 1..256 classes");
   const int row_tiles = (d.R + TM - 1) / TM;
-  const int nrt = row_tiles * G <= 256 ? 1 : 2;
+  const int nrt = chain_nrt(row_tiles);
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_mh_bwd: more than 2048 rows (the groups would not all be resident)");
   const void* ps[] = {d.dc, d.W4, d.h1, d.mean, d.rstd, d.gamma, d.dgamma, d.dbeta, d.dh2, d.dpre, d.W0, d.out, d.flags, d.lnws};

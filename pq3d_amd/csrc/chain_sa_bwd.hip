@@ -117,7 +117,7 @@ extern "C" int pq3d_chain_sa_bwd(const pq3d_chain_sa_bwd_desc* dp, void* stream)
   PQ_CHECK_ARG(d.R >= 1 && d.d == D && d.M >= 1 && d.M <= 3, "pq3d_chain_sa_bwd: d = 256, 1..3 memories");
   PQ_CHECK_ARG(!d.coef || (d.rows_per_scene >= 1 && d.R % d.rows_per_scene == 0), "pq3d_chain_sa_bwd: rows_per_scene must divide R");
   const int row_tiles = (d.R + TM - 1) / TM;
-  const int nrt = row_tiles * G <= 256 ? 1 : 2;
+  const int nrt = chain_nrt(row_tiles);
   const int groups = (row_tiles + nrt - 1) / nrt, slots = (groups + 7) / 8;
   PQ_CHECK_ARG(slots * G <= 32, "pq3d_chain_sa_bwd: more than 2048 rows (the groups would not all be resident)");
   PQ_CHECK_ARG(d.x && d.aux2 && d.mean && d.rstd && d.dxr && d.flags && d.lnws && ((((uintptr_t)d.x) | ((uintptr_t)d.aux2) | ((uintptr_t)d.dxr)) & 15) == 0,

@@ -119,3 +119,53 @@ for B, Nq in ((8, 100), (16, 100)):
     print(f"R = {B * Nq}: backward FFN group: four launches {res['sep_ffn_bwd']:.2f} us, chain {res['chain_ffn_bwd']:.2f} us; "
           f"q/k/v + merged LN + dO group: three launches {res['sep_sa_bwd']:.2f} us, chain {res['chain_sa_bwd']:.2f} us")
     print(f"R = {B * Nq}: five launches {res['five launches']:.2f} us, chain {res['chain']:.2f} us per layer tail; hand-off timeouts: {ops.chain_error(dev)}")
+
+# ---- the mask head's chains (csrc/chain_mh.hip) against their separate launches, config 4's shape
+from test_gpu_chain import _mh_five_launches, _mh_bwd_six_launches
+
+
+def _time(fn):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            for _ in range(20):
+                keep = fn()
+        for _ in range(5):
+            gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 400 * 1e3
+
+
+for B, Nq in ((4, 200), (8, 100)):
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    d, C_, Mm = 256, 201, 3
+    cols = torch.tensor([0, 7], dtype=torch.int32, device=dev)
+    cf = torch.zeros(C_, dtype=torch.int32, device=dev)
+    cf[cols.long()] = 1
+    x, W0, b0, gamma, beta = r(B, Nq, d), r(d, d, sc=0.06), r(d, sc=0.1), 1 + r(d, sc=0.1), r(d, sc=0.1)
+    W4, b4 = r(C_, d, sc=0.06), r(C_, sc=0.1)
+    Wqs, bqs = [r(d, d, sc=0.06) for _ in range(Mm)], [r(d, sc=0.1) for _ in range(Mm)]
+    fl = ops.chain_flags(B * Nq, dev)
+    t_sep = _time(lambda: _mh_five_launches(x, W0, b0, gamma, beta, 1e-5, W4, b4, cols, Wqs, bqs))
+    t_ch = _time(lambda: ops.chain_mh_fwd(x, W0, b0, gamma, beta, 1e-5, W4, b4, cf, float("-inf"), Wqs, bqs, fl))
+    h1, h2, mean, rstd, cls, qm = ops.chain_mh_fwd(x, W0, b0, gamma, beta, 1e-5, W4, b4, cf, float("-inf"), Wqs, bqs, fl)
+    dc, cur, dqs = r(B, Nq, C_), r(B, Nq, d), [r(B, Nq, d) for _ in range(Mm)]
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    fb = ops.chain_flags(B * Nq, dev)
+    t_sepb = _time(lambda: _mh_bwd_six_launches(dc, cols, W4, h1, mean, rstd, gamma, dg, db, W0, cur, dqs, Wqs))
+    t_chb = _time(lambda: ops.chain_mh_bwd(dc, cf, W4, h1, mean, rstd, gamma, dg, db, W0, cur, dqs, Wqs, fb))
+    dq_all, Wqc, dxr, gq = r(3, B, Nq, d).bfloat16(), [r(d, d, sc=0.06) for _ in range(3)], r(B, Nq, d), torch.empty(B, Nq, d, device=dev)
+    t_chb0 = _time(lambda: ops.chain_mh_bwd(dc, cf, W4, h1, mean, rstd, gamma, dg, db, W0, None, dqs, Wqs, fb, prev=(dq_all, Wqc, dxr, gq)))
+    print(f"R = {B * Nq}: mask head forward: five launches {t_sep:.2f} us, chain {t_ch:.2f} us; backward: six launches {t_sepb:.2f} us, "
+          f"chain {t_chb:.2f} us, chain incl. the cross-attention query gradient {t_chb0:.2f} us; hand-off timeouts: {ops.chain_error(dev)}")
