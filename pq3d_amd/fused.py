@@ -903,8 +903,16 @@ class _DecoderBackward:
             Bkv = [wkvT[tape[a]["i"], j, t] for a in range(n_app) for j in range(M) for t in (0, 1)]
             kT = None
             if self.dkeys is not None:
-                kT = torch.stack([mp.k_proj.weight.detach() for mp in list(spec.mh.mask_pred_list)[:spec.mh_count]]) \
-                    .transpose(1, 2).contiguous().to(ad)
+                # transposed bf16 copies of the mask-head key projections: one launch (pq3d_cast_transpose; rows = cols = d)
+                kws = [mp.k_proj.weight.detach() for mp in list(spec.mh.mask_pred_list)[:spec.mh_count]]
+                if d % 32 == 0 and ad == torch.bfloat16 and len(kws) <= MAXG and all(w_.is_contiguous() and w_.shape == (d, d) for w_ in kws):
+                    kT, kS = torch.empty(2, len(kws), d, d, dtype=ad, device=dev)
+                    arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
+                    L.check(L.lib().pq3d_cast_transpose(arr(kws), arr([kS[m_] for m_ in range(len(kws))]),
+                                                        arr([kT[m_] for m_ in range(len(kws))]), len(kws), d, d, L.stream()),
+                            "pq3d_cast_transpose")
+                else:
+                    kT = torch.stack(kws).transpose(1, 2).contiguous().to(ad)
         # d source_u = sum over the (application, memory) pairs that read it of (dK Wk + dV Wv) [+ mask-head key path]
         jobs = []
         for u in range(U):
@@ -1109,7 +1117,7 @@ class _FusedDecoder(Function):
         keys = inv_den = None
         if spec.mh is not None:
             mps = list(spec.mh.mask_pred_list)[:spec.mh_count]
-            valid = [m.logical_not() for m in masks[:spec.mh_count]]
+            valid = ops.mask_not(masks[:spec.mh_count])   # one launch
             cq = ops.small_ct(ct)   # fp32-grade keys (split-bf16): see MaskHeadSegLevel.project_keys
             keys_buf = torch.empty(spec.mh_count, B, Ns, d, dtype=ops.act_dtype(cq), device=dev)
             L.gemm(M=Rk, N=d, K=d, A=mh_feats[:spec.mh_count], B=[mp.k_proj.weight.detach() for mp in mps],
