@@ -383,3 +383,52 @@ def test_chain_mh_bwd_forms_its_upstream_gradient(B, Nq, M):
         assert torch.equal(gq.view(torch.int32), gq0.view(torch.int32))
         assert torch.equal(out[2].view(torch.int32), ref[2].view(torch.int32)), (out[2] - ref[2]).abs().max().item()
         assert torch.equal(out[1].view(torch.int16), ref[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("case", ["mask_head", "plain"])
+def test_model_step_is_the_same_with_and_without_chains(case):
+    """End to end: one forward + backward of the whole model in 'bf16' mode with the chain launches on and off (fused.set_chain)
+    -- every output tensor bit for bit (the chains' arithmetic is the separate launches'), every parameter gradient to the
+    summation order of the reductions the backward chains do in a fixed order instead of with atomics (see below)."""
+    from tests import util
+    from pq3d_amd import fused, ops
+    from pq3d_amd.modules import set_compute
+    dev = torch.device("cuda")
+    if case == "mask_head":   # config 4's structure at a reduced segment count (mask head in front of every layer, 3-D self-masks)
+        args = dict(B=4, Ns=512, Nq=200, d=256, H=8, L=2, memories=["voxel", "mv", "pc"], heads=["mask"], spatial=True,
+                    structure="parallel", use_self_mask=True, C=201, foc=(0, 2), seed=0, data_seed=1234)
+    else:                     # config 2's structure
+        args = dict(B=8, Ns=256, Nq=100, d=256, H=8, L=2, memories=["voxel", "mv", "pc"], heads=[], spatial=True,
+                    structure="parallel", seed=0, data_seed=1234)
+    _cfg, model, _sd, dd = util.model_case(args)
+    set_compute(model, "bf16")
+    model.unified_encoder.fused = True
+    model.to(dev)
+    ddv = {k: v.to(dev) for k, v in dd.items()}
+    res = {}
+    try:
+        for on in (True, False):
+            fused.set_chain(on)
+            model.zero_grad()
+            out = model(dict(ddv))
+            util.synthetic_loss(out, args["heads"], out["query_embeds"]).backward()
+            torch.cuda.synchronize()
+            assert not ops.chain_error(dev)
+            outs = [out["query_embeds"]] + list(out.get("predictions_mask", [])) + list(out.get("predictions_class", []))
+            res[on] = ([t.detach().clone() for t in outs], {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        fused.set_chain(True)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert sorted(res[True][1]) == sorted(res[False][1])
+    # Gradients: the backward's products take bf16 operands, so a last-bit difference of an fp32 gradient tensor (summation order:
+    # the unchained path's split-K atomics are not even the same from run to run, 1-2e-3 on the far parameters) flips operand
+    # roundings further down and grows stage by stage towards one bf16 ulp (tools/probes/chain_e2e_diff.py: 2e-7 at the last
+    # layer's norms -> 2e-5 -> 4e-4 -> 3e-3 at the input encoders; chains on vs on: 3e-7 everywhere, chains off vs off: 2e-3).
+    # So: tight where the difference is born (last layer's FFN / self-attention norm), bf16-rounding level everywhere else.
+    gmax = max(float(v.norm()) for v in res[False][1].values())
+    last = f"unified_encoder.unified_encoder.{args['L'] - 1}."
+    for n, g0 in res[False][1].items():
+        err = float((res[True][1][n] - g0).norm() / max(float(g0.norm()), 1e-3 * gmax))
+        tight = n.startswith(last + "ffn.") or n.startswith(last + "self_attn.norm")
+        assert err < (2e-5 if tight else 1e-2), (n, err)
