@@ -569,6 +569,8 @@ class _Linear(Function):
             dx = _empty(x.shape, dtype=x.dtype, device=x.device)
             # a long reduction over few output tiles (LM head: 512 x 512 outputs, N = 32128) is split over K
             sk = _splitk(((R + 63) // 64) * ((K + 63) // 64), N, ct) if (dx.dtype == torch.float32 and N >= 8192) else 1
+            if sk > 1:   # these shapes run on gemm_wk's 64 x 256 tiles: one round of workgroups over the chip (c5's LM head: 8 -> 16
+                sk = max(sk, min(64, 256 // max(1, ((R + 63) // 64) * ((K + 255) // 256))))   # slices, 107 -> 81 us)
             L.gemm(M=R, N=K, K=N, A=[g], B=[w], Cs=[dx], ct=ct, lda=N, ldb=K, ldc=K, transB=True, splitk=sk, alpha=alpha)
             dx2 = dx if (x2 is not None and ctx.needs_input_grad[3]) else None
             if not ctx.needs_input_grad[0]:
