@@ -324,59 +324,49 @@ __global__ __launch_bounds__(CT) void chain_mh_bwd_kernel(const pq3d_chain_mh_bw
     for (int t = 0; t < NRT; ++t) {
       acc0[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.dpre, 0, 0x7ffffff0, 0x00020000);
+    // The 1 + Mm + nq products run back to back on the same LDS tiles; the operands of product p + 1 are requested (registers)
+    // before product p's MFMAs, so their latency hides behind them.  Order: dpre W0 (acc1), dqm_m Wq_m (acc2), then -- optional --
+    // cur itself: the input gradient of the following layer application's cross-attention query projections, dqc_m Wqc_m (acc0:
+    // cur = acc0 + dxr, gq = acc0; the member owns the same 32 columns of it, no hand-off needed).
+    struct Opnd { RawA w; float af[NRT][2][8]; u32x4 ab[NRT][2]; };
+    const int P = 1 + Mm + d.nq;
+    auto issue_p = [&](int p, Opnd& o) {
+      if (p > 0) issue_wslab(p <= Mm ? d.Wq[p - 1] : d.Wqc[p - 1 - Mm], D, o.w);   // (product 0's weight travels since the kernel's start)
+      const bool f32 = p >= 1 && p <= Mm && d.dq_f32;
+      const void* A = p == 0 ? (const void*)d.dpre : p <= Mm ? d.dq[p - 1] : d.dqc[p - 1 - Mm];
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
       for (int t = 0; t < NRT; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int ch = c.tid + i * CT;
-          *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] = __builtin_amdgcn_raw_buffer_load_b128(
-              rs, (int)(((long)min(m0 + t * TM + (ch >> 5), R - 1) * D + (ch & 31) * 8) * 2), 0, 16);
+          const long off = (long)min(m0 + t * TM + (ch >> 5), R - 1) * D + (ch & 31) * 8;
+          if (f32) load8<false>((const float*)A, off, o.af[t][i]);
+          else if (p == 0) o.ab[t][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off * 2), 0, 16);   // written in this launch: sc1
+          else o.ab[t][i] = *(const u32x4*)((const bf16_t*)A + off);
         }
-      put_wslab(w0s);
-      __syncthreads();
-      mma_slab(acc1, D / 32);
-    }
-    for (int m = 0; m < Mm; ++m) {
-      __syncthreads();
-      RawA wq;
-      issue_wslab(d.Wq[m], D, wq);
+    };
+    auto put_p = [&](int p, const Opnd& o) {
+      const bool f32 = p >= 1 && p <= Mm && d.dq_f32;
 #pragma unroll
       for (int t = 0; t < NRT; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int ch = c.tid + i * CT;
-          const long o = (long)min(m0 + t * TM + (ch >> 5), R - 1) * D + (ch & 31) * 8;
-          u32x4 a;
-          if (d.dq_f32) {
-            float v[8];
-            load8<false>((const float*)d.dq[m], o, v);
-            a = pack_frag<bf16_t>(v);
-          } else a = *(const u32x4*)((const bf16_t*)d.dq[m] + o);
-          *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] = a;
+          *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] = f32 ? pack_frag<bf16_t>(o.af[t][i]) : o.ab[t][i];
         }
-      put_wslab(wq);
+      put_wslab(p == 0 ? w0s : o.w);
+    };
+    Opnd op;
+    issue_p(0, op);
+    for (int p = 0; p < P; ++p) {
+      if (p > 0) __syncthreads();   // the previous product's fragments are read
+      put_p(p, op);
       __syncthreads();
-      mma_slab(acc2, D / 32);
-    }
-    // (optional) cur itself: the input gradient of the following layer application's cross-attention query projections,
-    // cur = sum_m dqc_m Wqc_m + dxr (gq = the sum without dxr) -- the member owns the same 32 columns of it, no hand-off needed
-    for (int m = 0; m < d.nq; ++m) {
-      __syncthreads();
-      RawA wq;
-      issue_wslab(d.Wqc[m], D, wq);
-#pragma unroll
-      for (int t = 0; t < NRT; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int ch = c.tid + i * CT;
-          *(u32x4*)&Ap[t * TM * LDR + (ch >> 5) * LDR + (ch & 31) * 8] =
-              *(const u32x4*)((const bf16_t*)d.dqc[m] + (long)min(m0 + t * TM + (ch >> 5), R - 1) * D + (ch & 31) * 8);
-        }
-      put_wslab(wq);
-      __syncthreads();
-      mma_slab(acc0, D / 32);
+      if (p + 1 < P) issue_p(p + 1, op);
+      if (p == 0) mma_slab(acc1, D / 32);
+      else if (p <= Mm) mma_slab(acc2, D / 32);
+      else mma_slab(acc0, D / 32);
     }
 #pragma unroll
     for (int t = 0; t < NRT; ++t) {
