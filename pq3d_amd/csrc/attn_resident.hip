@@ -19,6 +19,8 @@
 //     combine kernel sums.
 // Same arithmetic as the two-kernel path (P from the saved log-sum-exp, dS = P (dP - delta) scale, bf16 operands, fp32
 // accumulation); dQ now sums its key contributions in a different (non-deterministic) order.
+#include <cstdlib>
+
 #include "attn_common.h"
 
 namespace {
@@ -538,7 +540,7 @@ constexpr int NB1 = FK1 / KB;
 constexpr int FCH1 = FK1 * 4 / (FW * 64);    // 16-byte chunks of K (and of V) per compute thread, stage 1   (4)
 constexpr int FCH2 = FK1 * 4 / (FLW * 64);   // ... per loader thread, stage 2                              (8)
 
-template <bool DROP>
+template <bool DROP, bool TWO>
 __global__ __launch_bounds__((FW + FLW) * 64) void attn_fwd_resident_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   constexpr int DH = 32;
@@ -617,7 +619,7 @@ __global__ __launch_bounds__((FW + FLW) * 64) void attn_fwd_resident_kernel(cons
     dst = drop_init(d.drop, d.drop_bmod > 0 ? b / d.drop_bmod : 0, d.Lk);
     drow = (uint32_t)(((long)(d.drop_bmod > 0 ? b % d.drop_bmod : b) * d.H + h) * d.Lq + min(myq, d.Lq - 1));
   }
-  auto block = [&](int t) {
+  auto block = [&](int t) __attribute__((always_inline)) {
     const bf16_t* Kt = Ks + t * KB * LDK;
     const bf16_t* Vt = Vs + t * KB * LDV;
     uint32_t mw[4];
@@ -686,17 +688,74 @@ __global__ __launch_bounds__((FW + FLW) * 64) void attn_fwd_resident_kernel(cons
       for (int u = 0; u < 2; ++u) Mma<bf16_t>::mma(acc[mt], vf[mt][u], pf[u]);
     }
   };
+  // Two unpadded blocks as ONE online-softmax step (128 keys): a block is a single dependent chain (MFMA -> max -> cross-lane
+  // max -> exp -> pack -> MFMA) and a SIMD holds 3 waves, so twice the independent work per chain step hides more of its latency
+  // (8 back-to-back score MFMAs, 32 independent exponentials per lane).  Blocks with padded keys (the tail) take block().
+  auto block2 = [&](int t) __attribute__((always_inline)) {
+    const bf16_t* Kt = Ks + t * KB * LDK;
+    const bf16_t* Vt = Vs + t * KB * LDV;
+    uint32_t any = 0;
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) any |= *(const uint32_t*)&kpm_s[t * KB + tt * 16 + 4 * lg];
+    if (!__all(any == 0u)) { block(t); block(t + 1); return; }
+    f32x4 sc[8];
+    {
+      u32x4 kf[8];
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) kf[tt] = rfrag<bf16_t>(&Kt[(tt * 16 + li) * LDK], 0, lg);
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        Mma<bf16_t>::mma(sc[tt], kf[tt], qf[0]);
+      }
+    }
+    u32x4 vf[A::MT][4];
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vf[mt][u] = tfrag_tr(Vt + (u >> 1) * KB * LDV, LDV, (u & 1) * 32, mt * 16, li, lg);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) mx = fmaxf(fmaxf(mx, fmaxf(sc[tt][0], sc[tt][1])), fmaxf(sc[tt][2], sc[tt][3]));
+    mx = group_max(mx) * sc2;
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    float p[8][4];
+    float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[tt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tt][r], sc2, -m_new));
+      rs0 += p[tt][0] + p[tt][1];
+      rs1 += p[tt][2] + p[tt][3];
+    }
+    l = l * alpha + (rs0 + rs1);
+    m = m_new;
+    u32x4 pf[4];
+    PackP<bf16_t, 8>::run(p, pf);
+#pragma unroll
+    for (int mt = 0; mt < A::MT; ++mt) {
+      acc[mt] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Mma<bf16_t>::mma(acc[mt], vf[mt][u], pf[u]);
+    }
+  };
+  auto run_blocks = [&](int t0, int t1) __attribute__((always_inline)) {
+    int t = t0;
+    if constexpr (TWO) {
+      for (; t + 1 < t1; t += 2) block2(t);
+    }
+    for (; t < t1; ++t) block(t);
+  };
   // two stages: the first 512 keys are multiplied while the loader waves bring in the rest of the slice
   __syncthreads();
-  if (wave_active)
-    for (int t = 0; t < min(nb, NB1); ++t) block(t);
+  if (wave_active) run_blocks(0, min(nb, NB1));
   if (loader && nb > NB1) {
 #pragma unroll
     for (int i = 0; i < FCH2; ++i) park(FK1 * 4 + t2 + i * FLW * 64, kr2[i], vr2[i]);
   }
   __syncthreads();
-  if (wave_active)
-    for (int t = NB1; t < nb; ++t) block(t);
+  if (wave_active) run_blocks(NB1, nb);
   l = group_sum(l);
   if (!qvalid) return;
   constexpr float LN2 = 0.693147180559945309f;
@@ -720,9 +779,9 @@ __global__ __launch_bounds__((FW + FLW) * 64) void attn_fwd_resident_kernel(cons
   }
 }
 
-template <bool DROP> void launch_fwd_res(const pq3d_attn_desc& d, hipStream_t s, int KS, int nk_max) {
+template <bool DROP, bool TWO> void launch_fwd_res(const pq3d_attn_desc& d, hipStream_t s, int KS, int nk_max) {
   const size_t lds = (size_t)nk_max * (32 * 2 + AT<bf16_t, 32>::LDR * 2 + 1) + 16;
-  auto kern = attn_fwd_resident_kernel<DROP>;
+  auto kern = attn_fwd_resident_kernel<DROP, TWO>;
   static std::atomic<unsigned> attr_done{0};   // > 64 KB of dynamic LDS: opt-in once per (kernel, device), to the CU's whole LDS
   if (pq3d_enable_big_lds(kern, 160 * 1024, attr_done)) { (void)hipGetLastError(); }
   hipLaunchKernelGGL(kern, dim3(KS, d.H, d.B), dim3((FW + FLW) * 64), lds, s, d);
@@ -746,8 +805,11 @@ bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s) {
   // kernel was as fast (58 us against 63-76 us); in the step it is 75 + 6 us against this kernel, and the step says 6.535 ->
   // 6.463 ms with the slices here (tools/probes/ab_resfwd_split.sh) -- on by default since round 4, switch: pq3d_attn_resident bit 5
   if (KS > 1 && d.Lk > FKMAX && !pq3d_resfwd_split_allowed()) return false;
-  if (d.drop.p > 0.f && d.drop.seed) launch_fwd_res<true>(d, s, KS, nb_max * KB);
-  else launch_fwd_res<false>(d, s, KS, nb_max * KB);
+  // PQ3D_RESFWD_ONE=1: one 64-key block per online-softmax step (the form before round 5's two-block step; A/B measurements)
+  static const bool one = [] { const char* e = getenv("PQ3D_RESFWD_ONE"); return e && atoi(e) != 0; }();
+  if (d.drop.p > 0.f && d.drop.seed) launch_fwd_res<true, false>(d, s, KS, nb_max * KB);
+  else if (one) launch_fwd_res<false, false>(d, s, KS, nb_max * KB);
+  else launch_fwd_res<false, true>(d, s, KS, nb_max * KB);
   return true;
 }
 
