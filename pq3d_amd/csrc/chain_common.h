@@ -25,11 +25,6 @@ struct Ctx {
 };
 
 PQ_DEV void split_hi_lo(const float* v, u32x4& hi, u32x4& lo) {
-#ifdef PQ3D_CHAIN_NOSPLIT   // timing probe only (wrong numbers): what the conversion costs
-  hi = (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-  lo = (u32x4){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
-  return;
-#endif
   hi = pack_frag<bf16_t>(v);
   float w[8];
 #pragma unroll
@@ -445,9 +440,7 @@ PQ_DEV void ln_partials_reduce(const Ctx& c, int j, const float* group, int stri
 #pragma unroll
     for (int m = 0; m < G; ++m)
       sv += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (m * stride + off + kind * D + col) * 4, 0, 16));
-#ifndef PQ3D_CHAIN_NOATOM   // (timing probe: what the parameter-gradient atomics cost)
     unsafeAtomicAdd(kind ? &dbeta[col] : &dgamma[col], sv);
-#endif
   }
 }
 
