@@ -445,11 +445,13 @@ PQ_DEV void ln_partials_reduce(const Ctx& c, int j, const float* group, int stri
 }
 
 // Row tiles per group: 1 while all groups are resident at once (8 workgroups per group, at most one workgroup per CU), else 2.
+// The limit leaves 32 of the 256 CUs free: a collective of another stream (RCCL: one workgroup per channel) may hold CUs for the whole
+// launch, and a group whose member cannot become resident would make the others spin to the limit.
 // PQ3D_CHAIN_NRT=2 forces two (a tuning switch for measurements: half as many groups, each weight slab converted once for 64 rows).
 inline int chain_nrt(int row_tiles) {
   static const int forced = [] { const char* e = getenv("PQ3D_CHAIN_NRT"); return e ? atoi(e) : 0; }();
   if (forced == 2) return 2;
-  return row_tiles * G <= 256 ? 1 : 2;
+  return row_tiles * G <= 224 ? 1 : 2;
 }
 
 // in-kernel timeline (probe builds only, tools/probes/chain_timeline.py): thread 0 of workgroup 0 stamps the 100 MHz clock
