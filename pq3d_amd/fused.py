@@ -345,7 +345,7 @@ class _DecoderBackward:
         self.dqpos_parts: List[torch.Tensor] = []
         self.dKV = torch.empty(n_app, 2, M, B, Ns, d, dtype=self.ad, device=dev)
         self.dPKV = torch.empty(n_app, 2, B, ctx.prompt.shape[1], d, dtype=self.ad, device=dev) if spec.prompt else None
-        self._mh_calls, self._mh_dqm, self._mh_dcl = 0, None, None   # mask_head_chain(): per-pass buffers shared by its calls
+        self._mh_calls, self._mh_pre, self._mh_dcl = 0, None, None   # mask_head_chain(): per-pass buffers shared by its calls
         self.dkeys = None    # accumulated gradient of the mask-head key projections [Mm,B,Ns,d] fp32->ad
         self.dk_terms = []   # queued (g, q_m) terms of it (one K-concatenated launch at the end)
         ready_cb = getattr(enc, "grads_ready", None) if self.in_place else None   # only when the owner's buffers were written
@@ -508,6 +508,39 @@ class _DecoderBackward:
                 and rec["mh_h1"].dtype == torch.float32 and isinstance(cur, torch.Tensor) and cur.dtype == torch.float32
                 and cur.is_contiguous())
 
+    def _mh_logit_grads(self):
+        """{id(rec): (g, dqm)} of every mask-head call of the pass: the query-side gradient of the mask logits, dqm_c =
+        g_c^T keys, depends on the loss' gradient of that call's logits and on the keys only -- not on anything the backward
+        pass computes -- so the products of ALL calls are formed by ONE launch when the first call runs backward (config 4: 5
+        launches of 31-34 us -> one of ~105; their split-K outputs are one buffer zeroed by one launch)."""
+        if self._mh_pre is not None:
+            return self._mh_pre
+        ctx, spec, ct, ad, B, Nq, d, Ns, dev = self.ctx, self.spec, self.ct, self.ad, self.B, self.Nq, self.d, self.Ns, self.dev
+        Mm = spec.mh_count
+        calls = []
+        if ctx.final_rec is not None:
+            calls.append((ctx.final_rec, self.dcls[-1], self.dmlog[-1]))
+        if spec.mh is not None and not spec.skip_pred:
+            calls += [(self.tape[a], self.dcls[a], self.dmlog[a]) for a in range(self.n_app - 1, -1, -1)]
+        calls = [(r_, dm_) for r_, dc_, dm_ in calls if self.mask_head_chain_ok(r_, dc_, dm_, self.qpos)]   # (qpos: any fp32 rows)
+        self._mh_pre = {}
+        per = max(1, MAXG // max(Mm, 1))
+        if not calls or Mm < 1:
+            return self._mh_pre
+        sk = min(8, Ns // 512) if Ns >= 1024 else 1
+        buf = torch.empty(len(calls), Mm, B, Nq, d, dtype=torch.float32 if sk > 1 else ad, device=dev)
+        if sk > 1:
+            ops.zero_many([buf])   # split-K partial sums are added into the outputs
+        gs = [ops.scale_rows(dm_.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=self.seg_pad) for _r, dm_ in calls]
+        for c0_ in range(0, len(calls), per):
+            idx = range(c0_, min(c0_ + per, len(calls)))
+            L.gemm(M=Nq, N=d, K=Ns, A=[gs[c_] for c_ in idx for _m in range(Mm)], B=list(ctx.keys) * len(idx),
+                   Cs=[buf[c_, m] for c_ in idx for m in range(Mm)], ct=ct, lda=Nq, ldb=d, ldc=d, transA=True, transB=True, batch=B,
+                   strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d, splitk=sk, accumulate=sk > 1)
+        for c_, (r_, _dm) in enumerate(calls):
+            self._mh_pre[id(r_)] = (gs[c_], buf[c_])
+        return self._mh_pre
+
     def mask_head_chain(self, rec, dc, dm, cur):
         """mask_head() with the row-local steps in one launch (csrc/chain_mh.hip): the mask logits' query-side gradient first
         (not row-local: a reduction over the scene's segments), then class-MLP backward + both input-gradient products."""
@@ -519,7 +552,8 @@ class _DecoderBackward:
         Mm = spec.mh_count
         mps = list(mh.mask_pred_list)[:Mm]
         qm = rec["mh_qm"]
-        g = ops.scale_rows(dm.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=seg_pad)
+        pre = self._mh_logit_grads().get(id(rec))
+        g = pre[0] if pre is not None else ops.scale_rows(dm.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=seg_pad)
         if Mm * (len(self.dk_terms) + 1) <= MAXG:
             self.dk_terms.append((g, qm))
         else:
@@ -529,21 +563,16 @@ class _DecoderBackward:
                    act_grad="add" if self.dkeys is not None else None, ct=ct, lda=Nq, ldb=d, ldc=d, transB=True, batch=B,
                    strideA=Ns * Nq, strideB=Nq * d, strideC=Ns * d)
             self.dkeys = newk
-        sk = min(8, Ns // 512) if Ns >= 1024 else 1
         call = self._mh_calls
         self._mh_calls += 1
-        if sk > 1:
-            # split-K partial sums are added into the output: the outputs of ALL mask-head calls of the pass are one buffer zeroed
-            # by one launch (each call used to zero its own: 5 launches at config 4)
-            if self._mh_dqm is None:
-                self._mh_dqm = torch.empty(self.n_mh, Mm, B, Nq, d, dtype=torch.float32, device=dev)
-                ops.zero_many([self._mh_dqm])
-            dqm = self._mh_dqm[call]
+        if pre is not None:
+            dqm = pre[1]
         else:
-            dqm = torch.empty(Mm, B, Nq, d, dtype=ad, device=dev)
-        L.gemm(M=Nq, N=d, K=Ns, A=[g] * Mm, B=list(ctx.keys), Cs=[dqm[m] for m in range(Mm)], ct=ct, lda=Nq,
-               ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d,
-               splitk=sk, accumulate=sk > 1)
+            sk = min(8, Ns // 512) if Ns >= 1024 else 1
+            dqm = torch.empty(Mm, B, Nq, d, dtype=torch.float32 if sk > 1 else ad, device=dev)
+            L.gemm(M=Nq, N=d, K=Ns, A=[g] * Mm, B=list(ctx.keys), Cs=[dqm[m] for m in range(Mm)], ct=ct, lda=Nq,
+                   ldb=d, ldc=d, transA=True, transB=True, batch=B, strideA=Ns * Nq, strideB=Ns * d, strideC=Nq * d,
+                   splitk=sk)
         if self._mh_dcl is None and mh._foc_cols.numel():   # adjacent rows call after call: their column sums (the bias
             self._mh_dcl = torch.empty(self.n_mh, B, Nq, c4.out_features, dtype=torch.float32, device=dev)   # gradient) in one launch
         flags = getattr(mh, "_chain_flags_bwd", None)
