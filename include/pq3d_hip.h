@@ -594,6 +594,9 @@ int pq3d_colsum_grouped(const void* const* x, float* const* out, int32_t groups,
  * scale NULL -> 1.  (backward of mask_head.py:35-38 and of row-masked projections) */
 int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty, int64_t R, int64_t C, const float* scale,
                     const uint8_t* zero_flag, const uint8_t* keep_mask, void* stream);
+/* the same for `groups` <= PQ3D_MAX_GROUPS fp32 tensors of one shape sharing scale / flags (C % 8 == 0, 16-byte aligned): one launch */
+int pq3d_scale_rows_grouped(const float* const* x, void* const* y, int32_t groups, int32_t dty, int64_t R, int64_t C,
+                            const float* scale, const uint8_t* zero_flag, const uint8_t* keep_mask, void* stream);
 
 /* Grouped elementwise add + cast: out_g[i] = (dt_out)(a_g[i] + b_g[i]) for g < groups (b_g may be NULL); fp32 inputs.
  * Used once per forward to materialise the layer-invariant bf16 MFMA operands (feat + pos) and (feat) of every scene

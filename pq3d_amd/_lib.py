@@ -238,6 +238,8 @@ _SIGS = {
                             C.c_int64, C.c_int32, C.c_void_p],
     "pq3d_scale_rows": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                         C.c_void_p, C.c_void_p],
+    "pq3d_scale_rows_grouped": [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p],
     "pq3d_add_cast": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                       C.c_int64, C.c_void_p],
     "pq3d_bias_add_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],

@@ -819,6 +819,48 @@ extern "C" int pq3d_scale_rows(const void* x, int32_t dtx, void* y, int32_t dty,
   return 0;
 }
 
+namespace {
+struct ScaleRowsPtrs { const void* x[PQ3D_MAX_GROUPS]; void* y[PQ3D_MAX_GROUPS]; };
+// scale_rows_kernel's fast path for several same-shape tensors that share the row scales / flags (blockIdx.y = tensor): the
+// mask-logit gradients of all prediction layers of a pass
+__global__ void scale_rows_grouped_kernel(const ScaleRowsPtrs p, int dty, long R, long C, const float* scale, const uint8_t* zero_flag,
+                                          const uint8_t* keep_mask) {
+  const float* x = (const float*)p.x[blockIdx.y];
+  void* y = p.y[blockIdx.y];
+  const long total = R * C;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < total; i += (long)gridDim.x * blockDim.x * 8) {
+    const long r = i / C;
+    const bool keep = (!zero_flag || !zero_flag[r]) && (!keep_mask || keep_mask[r]);
+    const float sc = keep ? (scale ? scale[r] : 1.f) : 0.f;
+    const float4 a = *(const float4*)(x + i), b = *(const float4*)(x + i + 4);
+    const float v[8] = {keep ? a.x * sc : 0.f, keep ? a.y * sc : 0.f, keep ? a.z * sc : 0.f, keep ? a.w * sc : 0.f,
+                        keep ? b.x * sc : 0.f, keep ? b.y * sc : 0.f, keep ? b.z * sc : 0.f, keep ? b.w * sc : 0.f};
+    if (dty == PQ3D_BF16) *(u32x4*)((bf16_t*)y + i) = pack_frag<bf16_t>(v);
+    else {
+      *(float4*)((float*)y + i) = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)((float*)y + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int pq3d_scale_rows_grouped(const float* const* x, void* const* y, int32_t groups, int32_t dty, int64_t R, int64_t C,
+                                       const float* scale, const uint8_t* zero_flag, const uint8_t* keep_mask, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
+  PQ_CHECK_ARG(x && y && groups >= 1 && groups <= PQ3D_MAX_GROUPS && R >= 0 && C >= 8 && (C & 7) == 0 &&
+               (dty == PQ3D_F32 || dty == PQ3D_BF16), "pq3d_scale_rows_grouped: 1..32 fp32 tensors, C % 8 == 0");
+  if (R == 0) return 0;
+  ScaleRowsPtrs p;
+  for (int g = 0; g < groups; ++g) {
+    PQ_CHECK_ARG(x[g] && y[g] && ((((uintptr_t)x[g]) | ((uintptr_t)y[g])) & 15) == 0, "pq3d_scale_rows_grouped: tensors must be 16-byte aligned");
+    p.x[g] = x[g]; p.y[g] = y[g];
+  }
+  hipLaunchKernelGGL(scale_rows_grouped_kernel, dim3(grid1d(R * C / 8, 256, 1024), groups), dim3(256), 0, (hipStream_t)stream, p, dty,
+                     (long)R, (long)C, scale, zero_flag, keep_mask);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pq3d_add_cast(const float* const* a, const float* const* b, void* const* out, int32_t groups,
                              int32_t dt_out, int64_t n, void* stream) {
   PQ_DEVICE_GUARD(stream, nullptr);

@@ -531,7 +531,7 @@ class _DecoderBackward:
         buf = torch.empty(len(calls), Mm, B, Nq, d, dtype=torch.float32 if sk > 1 else ad, device=dev)
         if sk > 1:
             ops.zero_many([buf])   # split-K partial sums are added into the outputs
-        gs = [ops.scale_rows(dm_.contiguous(), B * Ns, ad, scale=ctx.inv_den, zero_flag=self.seg_pad) for _r, dm_ in calls]
+        gs = ops.scale_rows_many([dm_ for _r, dm_ in calls], B * Ns, ad, scale=ctx.inv_den, zero_flag=self.seg_pad)   # one launch
         for c0_ in range(0, len(calls), per):
             idx = range(c0_, min(c0_ + per, len(calls)))
             L.gemm(M=Nq, N=d, K=Ns, A=[gs[c_] for c_ in idx for _m in range(Mm)], B=list(ctx.keys) * len(idx),

@@ -156,6 +156,22 @@ def scale_rows(x: torch.Tensor, rows: int, out_dtype: torch.dtype, scale=None, z
     return y
 
 
+def scale_rows_many(xs, rows: int, out_dtype: torch.dtype, scale=None, zero_flag=None, keep_mask=None) -> list:
+    """[scale_rows(x, ...) for x in xs] for same-shape fp32 tensors sharing the scales / flags: one launch per 32 tensors."""
+    xs = [x.contiguous() for x in xs]
+    C_ = xs[0].numel() // max(rows, 1)
+    if len(xs) < 2 or C_ % 8 or any(x.dtype != torch.float32 or x.shape != xs[0].shape or x.data_ptr() % 16 for x in xs):
+        return [scale_rows(x, rows, out_dtype, scale, zero_flag, keep_mask) for x in xs]
+    ys = _empty((len(xs),) + tuple(xs[0].shape), dtype=out_dtype, device=xs[0].device)
+    for s0 in range(0, len(xs), L.MAXG):
+        ch = range(s0, min(s0 + L.MAXG, len(xs)))
+        xa = (C.c_void_p * len(ch))(*[L.ptr(xs[i]) for i in ch])
+        ya = (C.c_void_p * len(ch))(*[L.ptr(ys[i]) for i in ch])
+        L.check(L.lib().pq3d_scale_rows_grouped(xa, ya, len(ch), L.dt_of(ys), rows, C_, L.ptr(scale), L.ptr(zero_flag), L.ptr(keep_mask),
+                                                L.stream()), "pq3d_scale_rows_grouped")
+    return [ys[i] for i in range(len(xs))]
+
+
 def act_bwd(dy: torch.Tensor, saved: torch.Tensor, act: str, out_dtype: torch.dtype) -> torch.Tensor:
     out = _empty(dy.shape, dtype=out_dtype, device=dy.device)
     L.check(L.lib().pq3d_act_bwd(L.ptr(dy), L.dt_of(dy), L.ptr(saved), L.dt_of(saved), L.ptr(out), L.dt_of(out),

@@ -1259,3 +1259,23 @@ def test_gemm_tt_multi_heterogeneous_weight_gradients_in_one_launch():
     assert ops.dw_long_path(768, 768, 10240, 16, BF16) and not ops.dw_long_path(256, 256, 8192, 3, BF16)
     assert not ops.tt_multi_ok(torch.zeros(100, 12, device=DEV), torch.zeros(100, 20, device=DEV), None,
                                torch.zeros(12, 20, device=DEV), None, 12, 20, 100)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_scale_rows_many_equals_per_tensor(out_dtype):
+    """pq3d_scale_rows_grouped: several same-shape tensors sharing scales / flags in one launch -- the same bits as one launch each."""
+    from pq3d_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    R, C_ = 4 * 333, 200
+    xs = [torch.randn(4, 333, C_, generator=g).to(dev) for _ in range(5)]
+    xs[1][0, 5, 3] = float("nan")
+    scale = torch.rand(R, generator=g).to(dev)
+    zf = (torch.rand(R, generator=g) < 0.2).to(dev)
+    zf[5] = True   # the row with the NaN is dropped: exactly zero
+    ref = [ops.scale_rows(x, R, out_dtype, scale=scale, zero_flag=zf) for x in xs]
+    out = ops.scale_rows_many(xs, R, out_dtype, scale=scale, zero_flag=zf)
+    it = torch.int16 if out_dtype == torch.bfloat16 else torch.int32
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape and torch.equal(a.view(it), b.view(it))
