@@ -47,6 +47,12 @@ def set_dropout(module: nn.Module, p: float) -> nn.Module:
             m.dropout_p = float(p)
         if hasattr(m, "cls_dropout_p"):
             m.cls_dropout_p = float(p)
+        if hasattr(m, "cls_head") and isinstance(m.cls_head, nn.Sequential):
+            # the nn.Dropout inside get_mlp_head's Sequential mirrors the rate the kernels apply (dropout_p / cls_dropout_p): kept in
+            # step, so that a model with every rate at zero does not advance the dropout RNG (two launches per step) for nothing
+            for sub in m.cls_head:
+                if isinstance(sub, nn.Dropout):
+                    sub.p = float(p)
     return module
 
 
@@ -59,8 +65,12 @@ def begin_dropout_step(owner: nn.Module, device, extra: Sequence[nn.Module] = ()
     cache = owner.__dict__.get("_pq3d_drop_cache")
     if cache is None or cache[0] != len(extra):
         tree = list(owner.modules())
+        # the nn.Dropout inside a head's get_mlp_head Sequential is a placeholder (state_dict / module-tree parity with the
+        # reference): the rate that is APPLIED there is the head's dropout_p / cls_dropout_p, already looked at through `mods`
+        mirrored = {id(sub) for m in tree + list(extra) if isinstance(m, _PostNormBase) and isinstance(getattr(m, "cls_head", None), nn.Sequential)
+                    for sub in m.cls_head if isinstance(sub, nn.Dropout)}
         cache = (len(extra), [m for m in tree + list(extra) if isinstance(m, _PostNormBase)],
-                 [m for m in tree if isinstance(m, nn.Dropout)])
+                 [m for m in tree if isinstance(m, nn.Dropout) and id(m) not in mirrored])
         owner.__dict__["_pq3d_drop_cache"] = cache
     mods, nn_drops = cache[1], cache[2]
     # nothing draws from the generator when every rate is zero: skip the (device-side) epoch advance then
