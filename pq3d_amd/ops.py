@@ -1635,6 +1635,34 @@ def t5_prep(rel, labels, buckets, enc_valid, start_id: int, pad_id: int, H: int)
     return (out[0], out[1], out[2]) if enc_valid is not None else (out[0], out[1], None)
 
 
+class _Fanout(Function):
+    """n aliases of one tensor whose gradients are summed by ONE launch (pq3d_sum_n, fixed order) instead of autograd's n - 1
+    pairwise adds: a tensor read by every layer of a stack (T5's shared self-attention position bias)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1 or any(g.dtype != torch.float32 or g.shape != gs[0].shape for g in gs):
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None
+        return sum_n(gs), None
+
+
+def fanout(x: torch.Tensor, n: int):
+    """[x] * n for a tensor that n consumers read; with a gradient, their n gradients are summed in one launch."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return [x] * n
+    return list(_Fanout.apply(x, n))
+
+
 def embedding(table, ids, drop: Optional[L.Drop] = None):
     """table[ids] (nn.Embedding), optionally with the dropout of site ``drop`` over the [ids.numel(), d] rows fused in."""
     return _Embedding.apply(table, ids, drop if (drop is not None and drop.p > 0.0) else None)

@@ -100,13 +100,14 @@ def decoder_logits(model, enc: torch.Tensor, enc_valid: Optional[torch.Tensor], 
     xkv = ops.linear_group([enc] * (2 * len(dec.block)),
                            [w_.weight for blk in dec.block for w_ in (blk.layer[1].EncDecAttention.k,
                                                                        blk.layer[1].EncDecAttention.v)], ct=ct, out_dtype=ad)
+    self_biases = ops.fanout(self_bias, len(dec.block))   # every block reads the shared position bias: one gradient sum
     for li, blk in enumerate(dec.block):
         sa, ca, ff = blk.layer[0], blk.layer[1], blk.layer[2]
         # -- self attention
         h, x = norm_res(x, sa.layer_norm.weight)
         A = sa.SelfAttention
         q, k, v = ops.linear_group([h, h, h], [A.q.weight, A.k.weight, A.v.weight], ct=ct, out_dtype=ad)
-        o = ops.attention(q, k, v, H=H, ct=ct, scale=1.0, bias=self_bias, drop=next_drop())
+        o = ops.attention(q, k, v, H=H, ct=ct, scale=1.0, bias=self_biases[li], drop=next_drop())
         x = proj_residual(o, A.o.weight)
         # -- cross attention to the projected query tokens (no position bias)
         h, x = norm_res(x, ca.layer_norm.weight)
