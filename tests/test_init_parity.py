@@ -70,3 +70,28 @@ def test_init_statistics_and_identical_copies():
         if k.startswith("mask_pred_list.0."):
             for j in range(1, 3):
                 assert torch.equal(v, msd[k.replace("mask_pred_list.0.", f"mask_pred_list.{j}.")]), k
+
+
+def test_zero_rate_model_does_not_advance_the_dropout_rng():
+    """Host logic (no kernels): the nn.Dropout inside a head's class MLP (kept for module-tree parity with utils.py:17-26) is a
+    placeholder -- the applied rate is the head's dropout_p.  With every applied rate at zero a training forward must not advance
+    the device RNG (two launches per step otherwise); with a non-zero rate it must."""
+    import torch
+    from pq3d_amd import modules as M, ops
+    head = M.MaskHeadSegLevel(None, 32, 7, memories_for_match=["voxel"], dropout=0.1)
+    head.train()
+    dev = torch.device("cpu")
+    rng = ops.drop_rng(dev)
+    M.begin_dropout_step(head, dev)          # rate 0.1: a fresh epoch for this call
+    e0 = rng.epoch
+    head.__dict__.pop("_pq3d_drop_cache", None)
+    head.dropout_p = 0.0                      # what bench.py / set_dropout do; cls_head[3].p stays 0.1
+    M.begin_dropout_step(head, dev)
+    M.begin_dropout_step(head, dev)
+    assert rng.epoch == e0
+    head.dropout_p = 0.1
+    head._drop_epoch = rng.epoch              # (a second call within the same epoch)
+    M.begin_dropout_step(head, dev)
+    assert rng.epoch == e0 + 1
+    M.set_dropout(head, 0.0)
+    assert all(sub.p == 0.0 for sub in head.cls_head if isinstance(sub, torch.nn.Dropout))
