@@ -39,6 +39,9 @@ extern "C" {
 
 #define PQ3D_MAX_GROUPS 32
 #define PQ3D_ACT_ADD 3 /* act_grad mode: C = acc + aux (fused residual / gradient accumulation) */
+#define PQ3D_ACT_PLANES 4 /* act_grad mode: v = act(alpha acc + bias) leaves as two bf16 planes, C = bf16(v), C2 = bf16(v - C)
+                             (operand form of the split-bf16 attention, compute mode 'bf16x3'); plain bf16 NT products on the
+                             128-row-tile kernel only (gemm128.hip): any other call is refused */
 
 const char* pq3d_last_error(void);
 int pq3d_version(void);
@@ -240,6 +243,17 @@ typedef struct {
    * per-element byte loads: the all-queries-resident backward uses it when present (config 4: 8 launches per step whose
    * 3-D mask handling was +60 % of their time); `mask` / `row_open` must still be set (the other kernels read them). */
   const uint32_t* mask_bits;
+  /* split-bf16 cross-attention FORWARD (compute mode 'bf16x3', csrc/attn_x3.hip): ct = PQ3D_BF16X3, q and o fp32 (dt = PQ3D_F32),
+   * the keys / values as bf16 hi / lo PLANES (k, v = hi planes, k_lo, v_lo = residual planes with the same strides; written by
+   * pq3d_gemm's PQ3D_ACT_PLANES epilogue).  Scores and the value contraction are 3 bf16 MFMAs per term pair (q, P split in
+   * registers): fp32-grade results at bf16 MFMA rate, K / V bytes = an fp32 tensor's.  q_bf / o_bf (optional, strides of q / o):
+   * bf16 copies of q and of the output for the (single-bf16) backward, which then reads exactly a 'bf16'-mode forward's tensors.
+   * Shape: d_h = 32, Lq <= 128 (<= 256 with a 3-D mask as bit words: two query halves), key padding / zero key / mask_bits,
+   * at most 1024 keys per key split (ksplit >= ceil(Lk / 1024)); any other call with k_lo set is refused. */
+  const void* k_lo;
+  const void* v_lo;
+  void* q_bf;
+  void* o_bf;
 } pq3d_attn_desc;
 
 /* row_open[r] = every byte of mask row r is non-zero (query_encoder.py:83: such rows attend everywhere) and, when bits != NULL,
@@ -402,7 +416,8 @@ typedef struct {
   const float* qpos;            /* [R, d] */
   const float* Wq[3];           /* [d, d] */
   const float* bq[3];
-  void* qout[3];                /* [R, d] bf16 out */
+  void* qout[3];                /* [R, d] out: bf16, or fp32 when qout_f32 != 0 */
+  int32_t qout_f32;
 } pq3d_chain_ffn_desc;
 int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* d, void* stream);
 
@@ -414,7 +429,7 @@ int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* d, void* stream);
 typedef struct {
   int32_t R, d, M, rows_per_scene;
   float eps;
-  const void* o[3];             /* [R, d] bf16 attention outputs */
+  const void* o[3];             /* [R, d] bf16 attention outputs (fp32 with o_f32) */
   const float* Wo[3];           /* [d, d] */
   const float* bo[3];
   const float* x;               /* [R, d] residual */
@@ -431,6 +446,7 @@ typedef struct {
   float* qkv[3];                /* [R, d] out each */
   uint32_t* flags;
   int32_t* err;
+  int32_t o_f32;                /* != 0: o[] are fp32 and the out-projections split-bf16 products (compute mode 'bf16x3') */
 } pq3d_chain_ca_desc;
 int pq3d_chain_ca_fwd(const pq3d_chain_ca_desc* d, void* stream);
 
@@ -603,6 +619,13 @@ int pq3d_scale_rows_grouped(const float* const* x, void* const* y, int32_t group
  * memory, so the hoisted K/V projection GEMMs read 2 B instead of 8 B per element. */
 int pq3d_add_cast(const float* const* a, const float* const* b, void* const* out, int32_t groups, int32_t dt_out,
                   int64_t n, void* stream);
+
+/* Operand planes of the split-bf16 products (compute mode 'bf16x3'): for g < groups, v = a_g[i] + b_g[i] (b_g may be NULL),
+ * hi_g[i] = bf16(v) (round to nearest even), lo_g[i] = bf16(v - hi_g[i]); hi_g may be NULL (only the residual plane is written).
+ * counts[g] elements (multiples of 8), 16-byte aligned pointers.  Written once per step for tensors that many launches read as
+ * MFMA operands (the memories' tokens, the K / V rows of in_proj_weight: query_encoder.py:288-307's key / value projections). */
+int pq3d_split_planes(const float* const* a, const float* const* b, void* const* hi, void* const* lo, const int64_t* counts,
+                      int32_t groups, void* stream);
 
 /* out[r,:] = x[r,:] + bias[:]  (fp32): seeds the output of a split-K GEMM with residual + bias so that
  * LayerNorm(x + h W2^T + b2) (query_encoder.py:385-387) needs no separate epilogue pass. */

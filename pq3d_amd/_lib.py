@@ -9,7 +9,7 @@ from typing import Optional, Sequence
 import torch
 
 F32, BF16, BF16X3 = 0, 1, 2
-ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "add": 3}
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2, "add": 3, "planes": 4}
 MAXG = 32
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PQ3D_LIB_PATH") or os.path.join(_HERE, "libpq3d_hip.so")   # override: A/B builds of the kernels
@@ -139,6 +139,7 @@ class AttnDesc(C.Structure):
         ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
         ("delta", C.c_void_p), ("dbias", C.c_void_p), ("ksplit", C.c_int32), ("ws", C.c_void_p),
         ("drop", Dropout), ("drop_bmod", C.c_int32), ("proj", AttnProj), ("mask_bits", C.c_void_p),
+        ("k_lo", C.c_void_p), ("v_lo", C.c_void_p), ("q_bf", C.c_void_p), ("o_bf", C.c_void_p),
     ]
 
 
@@ -160,7 +161,8 @@ class ChainFfnDesc(C.Structure):
     _fields_ = [("R", C.c_int32), ("d", C.c_int32), ("F", C.c_int32), ("eps1", C.c_float), ("eps2", C.c_float)] + \
                [(n, C.c_void_p) for n in ("o_s", "Wo", "bo", "x1s", "g1", "be1", "f", "x2", "mean1", "rstd1", "W1", "b1", "h", "W2",
                                           "b2", "zp", "z", "g2", "be2", "x3", "mean2", "rstd2", "flags", "err")] + \
-               [("nq", C.c_int32), ("qpos", C.c_void_p), ("Wq", C.c_void_p * 3), ("bq", C.c_void_p * 3), ("qout", C.c_void_p * 3)]
+               [("nq", C.c_int32), ("qpos", C.c_void_p), ("Wq", C.c_void_p * 3), ("bq", C.c_void_p * 3), ("qout", C.c_void_p * 3),
+                ("qout_f32", C.c_int32)]
 
 
 class ChainCaDesc(C.Structure):
@@ -168,7 +170,7 @@ class ChainCaDesc(C.Structure):
                 ("o", C.c_void_p * 3), ("Wo", C.c_void_p * 3), ("bo", C.c_void_p * 3), ("x", C.c_void_p), ("gamma", C.c_void_p * 3),
                 ("beta", C.c_void_p * 3), ("coef", C.c_void_p), ("op", C.c_void_p * 3), ("x1", C.c_void_p), ("mean", C.c_void_p),
                 ("rstd", C.c_void_p), ("qpos", C.c_void_p), ("Wqkv", C.c_void_p * 3), ("bqkv", C.c_void_p * 3), ("qkv", C.c_void_p * 3),
-                ("flags", C.c_void_p), ("err", C.c_void_p)]
+                ("flags", C.c_void_p), ("err", C.c_void_p), ("o_f32", C.c_int32)]
 
 
 class ChainMhDesc(C.Structure):
@@ -242,6 +244,8 @@ _SIGS = {
                                 C.c_void_p],
     "pq3d_add_cast": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                       C.c_int64, C.c_void_p],
+    "pq3d_split_planes": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_int64), C.c_int32, C.c_void_p],
     "pq3d_bias_add_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     "pq3d_act_bwd": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                      C.c_void_p],

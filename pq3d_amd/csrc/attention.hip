@@ -25,6 +25,7 @@ extern "C" int pq3d_attn_debug_read(long long* out) { return (int)hipMemcpyFromS
 
 bool pq3d_attn_bwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // attn_resident.hip
 bool pq3d_attn_fwd_resident_try(const pq3d_attn_desc& d, hipStream_t s);   // attn_resident.hip
+int pq3d_attn_fwd_x3(const pq3d_attn_desc& d, hipStream_t s);               // attn_x3.hip
 bool pq3d_attn_small_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);   // attn_small.hip
 bool pq3d_attn_sa_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);      // attn_sa.hip
 bool pq3d_attn_ca_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd);      // attn_ca.hip
@@ -334,6 +335,8 @@ __global__ void attn_fwd_combine_kernel(const pq3d_attn_desc d) {
   const long ooff = (long)b * d.o_sb + (long)q * d.o_sl + (long)h * d.o_sh + c0;
   store_elem(d.o, d.dt, ooff, o.x * inv); store_elem(d.o, d.dt, ooff + 1, o.y * inv);
   store_elem(d.o, d.dt, ooff + 2, o.z * inv); store_elem(d.o, d.dt, ooff + 3, o.w * inv);
+  if (d.o_bf)   // split-bf16 forward (attn_x3.hip): the bf16 copy of the output the backward reads
+    *(u32x2*)((bf16_t*)d.o_bf + ooff) = (u32x2){pack_bf2(o.x * inv, o.y * inv), pack_bf2(o.z * inv, o.w * inv)};
   if (c0 == 0) d.lse[row] = M + logf(Lsum);
 }
 
@@ -918,6 +921,16 @@ extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
   PQ_CHECK_ARG(d.proj.mode == PQ3D_ATTN_PROJ_NONE, "pq3d_attn_fwd: proj.mode not supported in the forward");
   if (d.B == 0 || d.Lq == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (d.k_lo || d.v_lo) {   // keys / values as bf16 hi / lo planes: the split-bf16 cross-attention forward (attn_x3.hip) or nothing
+    PQ_CHECK_ARG(x3, "pq3d_attn_fwd: k_lo / v_lo need compute type PQ3D_BF16X3");
+    if (int e = pq3d_attn_fwd_x3(d, s)) return e;
+    if (d.ksplit > 1) {
+      const long n = (long)d.B * d.H * d.Lq * (32 / 4);
+      hipLaunchKernelGGL((attn_fwd_combine_kernel<32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+    }
+    PQ_LAUNCH_CHECK();
+    return 0;
+  }
   if (x3 && g_sa && pq3d_attn_sa_try(d, s, false)) { PQ_LAUNCH_CHECK(); return 0; }
   if (g_small && pq3d_attn_small_try(d, s, false)) { PQ_LAUNCH_CHECK(); return 0; }
   DISPATCH(launch_fwd)

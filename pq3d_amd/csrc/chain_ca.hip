@@ -15,7 +15,9 @@ namespace {
 
 
 
-template <int NRT>
+// OX3: the attention outputs arrive in fp32 and the out-projections are split-bf16 products (compute mode 'bf16x3'; the LDS of
+// step 3 covers it)
+template <int NRT, bool OX3>
 __global__ __launch_bounds__(CT) void chain_ca_fwd_kernel(const pq3d_chain_ca_desc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
   Ctx c;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(CT) void chain_ca_fwd_kernel(const pq3d_chain_ca_de
     RawB w1[2];
     proj_issue_w(c, j, M, d.Wo, w1);
     proj_issue_w(c, j, 3, d.Wqkv, wq);   // step 3's weights travel under steps 1 and 2
-    proj_3x256<NRT, false, false, float>(c, ch_smem, j, M, m0, R, A, nullptr, d.Wo, d.bo, d.op, w1, true);
+    proj_3x256<NRT, OX3, false, float>(c, ch_smem, j, M, m0, R, A, nullptr, d.Wo, d.bo, d.op, w1, true);
   }
   handoff(c, mine, group, v0 + 1, d.err);
   // ---- 2. x1 = sum_m c_m LN_m(x + op_m): 32 NRT rows over 8 members x 4 NRT waves
@@ -101,15 +103,17 @@ extern "C" int pq3d_chain_ca_fwd(const pq3d_chain_ca_desc* dp, void* stream) {
     PQ_CHECK_ARG(d.Wqkv[g] && d.bqkv[g] && d.qkv[g] && ((((uintptr_t)d.Wqkv[g]) | ((uintptr_t)d.qkv[g])) & 15) == 0,
                  "pq3d_chain_ca_fwd: q / k / v operands (non-null, 16-byte aligned)");
   PQ_CHECK_ARG(((((uintptr_t)d.x) | ((uintptr_t)d.x1) | ((uintptr_t)d.qpos)) & 15) == 0, "pq3d_chain_ca_fwd: operands must be 16-byte aligned");
-  static std::atomic<unsigned> done1{0}, done2{0};
+  static std::atomic<unsigned> done[4] = {{0}, {0}, {0}, {0}};
   const dim3 grid((unsigned)(8 * G * slots));
-  if (nrt == 1) {
-    if (int e = pq3d_enable_big_lds(chain_ca_fwd_kernel<1>, (int)proj_lds<1>(true), done1)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
-    hipLaunchKernelGGL(chain_ca_fwd_kernel<1>, grid, dim3(CT), proj_lds<1>(true), (hipStream_t)stream, d);
-  } else {
-    if (int e = pq3d_enable_big_lds(chain_ca_fwd_kernel<2>, (int)proj_lds<2>(true), done2)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
-    hipLaunchKernelGGL(chain_ca_fwd_kernel<2>, grid, dim3(CT), proj_lds<2>(true), (hipStream_t)stream, d);
-  }
+  auto go = [&](auto kern, size_t lds, std::atomic<unsigned>& dn) -> int {
+    if (int e = pq3d_enable_big_lds(kern, (int)lds, dn)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
+    hipLaunchKernelGGL(kern, grid, dim3(CT), lds, (hipStream_t)stream, d);
+    return 0;
+  };
+  int e = 0;
+  if (nrt == 1) e = d.o_f32 ? go(chain_ca_fwd_kernel<1, true>, proj_lds<1>(true), done[0]) : go(chain_ca_fwd_kernel<1, false>, proj_lds<1>(true), done[1]);
+  else e = d.o_f32 ? go(chain_ca_fwd_kernel<2, true>, proj_lds<2>(true), done[2]) : go(chain_ca_fwd_kernel<2, false>, proj_lds<2>(true), done[3]);
+  if (e) return e;
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -296,8 +296,13 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
     handoff(c, mine, group, v0 + 5, d.err);
     const void* A[3] = {d.x3, d.x3, d.x3};
     const float* A2[3] = {d.qpos, d.qpos, d.qpos};
-    bf16_t* out[3] = {(bf16_t*)d.qout[0], (bf16_t*)d.qout[1], (bf16_t*)d.qout[2]};
-    proj_3x256<NRT, true, true, bf16_t>(c, ch_smem, j, d.nq, m0, R, A, A2, d.Wq, d.bq, out, wq, true);
+    if (d.qout_f32) {   // uniform: fp32 queries (compute mode 'bf16x3': the split-bf16 cross-attention splits them itself)
+      float* out[3] = {(float*)d.qout[0], (float*)d.qout[1], (float*)d.qout[2]};
+      proj_3x256<NRT, true, true, float>(c, ch_smem, j, d.nq, m0, R, A, A2, d.Wq, d.bq, out, wq, true);
+    } else {
+      bf16_t* out[3] = {(bf16_t*)d.qout[0], (bf16_t*)d.qout[1], (bf16_t*)d.qout[2]};
+      proj_3x256<NRT, true, true, bf16_t>(c, ch_smem, j, d.nq, m0, R, A, A2, d.Wq, d.bq, out, wq, true);
+    }
   }
 }
 

@@ -589,7 +589,8 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
   PQ_CHECK_ARG(d.groups % kc == 0, "pq3d_gemm: groups must be a multiple of kconcat");
   for (int g = 0; g < d.groups; ++g) {
     PQ_CHECK_ARG(d.A[g] && d.B[g] && (d.C[g] || (g % kc) != 0), "pq3d_gemm: null A/B/C");
-    PQ_CHECK_ARG(!d.act_grad || d.act_grad == PQ3D_ACT_ADD || d.aux[g] || (g % kc) != 0, "pq3d_gemm: act_grad needs aux");
+    PQ_CHECK_ARG(!d.act_grad || d.act_grad == PQ3D_ACT_ADD || d.act_grad == PQ3D_ACT_PLANES || d.aux[g] || (g % kc) != 0,
+                 "pq3d_gemm: act_grad needs aux");
   }
   if (d.splitk < 1) d.splitk = 1;
   PQ_CHECK_ARG(!(kc > 1 && d.splitk > 1), "pq3d_gemm: kconcat and split-K are exclusive");
@@ -601,6 +602,13 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
                "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated split-K GEMM");
   hipStream_t s = (hipStream_t)stream;
   pq3d_kdesc kd = make_kdesc(d);   // the kernels' compact form of the descriptor (common.h)
+  if (d.act_grad == PQ3D_ACT_PLANES) {   // bf16 hi / lo planes of the result: the 128-row-tile kernel's epilogue only
+    PQ_CHECK_ARG(d.splitk == 1 && pq3d_gemm_nt128_try(d, kd, s),
+                 "pq3d_gemm: PQ3D_ACT_PLANES needs a plain bf16 NT product of the 128-row-tile kernel's shape (M >= 128, N % 128 == "
+                 "0, K % 64 == 0, >= 256 tiles, bf16 C and C2)");
+    PQ_LAUNCH_CHECK();
+    return 0;
+  }
   int wk_err = 0;
   // small-M launches (the query side): whole-K tiles, gemm_wk.hip -- same bits, a third of the in-kernel latency
   if ((d.splitk == 1 || d.accumulate) && pq3d_gemm_wk_try(d, kd, s, &wk_err)) {

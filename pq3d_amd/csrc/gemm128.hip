@@ -35,8 +35,11 @@ typedef __attribute__((address_space(3))) void lptr_t;
 //   128 x 64   launches with < 3 workgroups of 128 x 128 per CU (the K-concatenated input-gradient products: 384 tiles at
 //              config 2): twice the workgroups for the same k loop.  Measured per launch: 30.4 us (128 x 128), 26.5 us
 //              (64 x 128), 27.3 us (128 x 64; kept: the streamed operand A takes 2/3 of each LDS stage)
-template <bool F32OUT, int TMT, int TNT>
+// OUT: 0 = bf16 C, 1 = fp32 C (+ aux), 2 = bf16 hi / lo PLANES of the fp32 result (C = bf16(v), C2 = bf16(v - C): the K / V tensors
+// of compute mode 'bf16x3', whose split-bf16 product arrives here as 3 K-concatenated bf16 groups hi.hi + lo.hi + hi.lo)
+template <int OUT, int TMT, int TNT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nt128_kernel(const pq3d_kdesc d) {
+  constexpr bool F32OUT = OUT == 1;
 #ifndef PQ3D_NO_KARG_PIN
   // kernel-argument prefetch (see gemm_fast_kernel): one batch of scalar loads for every descriptor scalar used below
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.kconcat), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(d.act),
@@ -122,8 +125,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[i][j][r] * d.alpha + bn;
-          Ct[(wm + i * 16 + 4 * lg + r) * LDCT + col] = f2bf(relu ? fmaxf(v, 0.f) : v);
+          float v = acc[i][j][r] * d.alpha + bn;
+          v = relu ? fmaxf(v, 0.f) : v;
+          const bf16_t hi = f2bf(v);
+          Ct[(wm + i * 16 + 4 * lg + r) * LDCT + col] = hi;
+          if constexpr (OUT == 2) acc[i][j][r] = v - bf2f(hi);   // the residual, rounded and stored by the second pass
         }
     }
     __syncthreads();
@@ -134,6 +140,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int p = 0; p < TMT / RPP; ++p) {
       const int row = p * RPP + crow;
       if (m0 + row < d.M) *(u32x4*)(C + (long)(m0 + row) * d.ldc + n0 + cch) = *(const u32x4*)&Ct[row * LDCT + cch];
+    }
+    if constexpr (OUT == 2) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = wn + j * 16 + li;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ct[(wm + i * 16 + 4 * lg + r) * LDCT + col] = f2bf(acc[i][j][r]);
+      }
+      __syncthreads();
+      bf16_t* C2 = (bf16_t*)d.gp[g].C2;
+#pragma unroll
+      for (int p = 0; p < TMT / RPP; ++p) {
+        const int row = p * RPP + crow;
+        if (m0 + row < d.M) *(u32x4*)(C2 + (long)(m0 + row) * d.ldc + n0 + cch) = *(const u32x4*)&Ct[row * LDCT + cch];
+      }
     }
   } else {
     float* Cf = (float*)As;   // [HR][LDFT] fp32: the rows leave in two halves (one per pair of waves)
@@ -324,13 +348,16 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStrea
   const int kc = d.kconcat > 0 ? d.kconcat : 1;
   if (d.transA || d.transB || d.batch != 1 || d.splitk > 1 || (d.act != PQ3D_ACT_NONE && d.act != PQ3D_ACT_RELU)) return false;
   const bool add = d.act_grad == PQ3D_ACT_ADD;   // "+ aux" epilogue: fp32 output and fp32 aux only
-  if (d.act_grad && !(add && d.dtC == PQ3D_F32 && d.dtAux == PQ3D_F32 && d.act == PQ3D_ACT_NONE)) return false;
+  const bool planes = d.act_grad == PQ3D_ACT_PLANES;   // bf16 hi / lo planes of the result: C and C2 both bf16
+  if (planes && !(d.dtC == PQ3D_BF16 && d.dtC2 == PQ3D_BF16)) return false;
+  if (d.act_grad && !planes && !(add && d.dtC == PQ3D_F32 && d.dtAux == PQ3D_F32 && d.act == PQ3D_ACT_NONE)) return false;
   if (d.M < TM || d.N % TN || d.K % TK || d.K < TK) return false;
   if (d.lda % 8 || d.ldb % 8 || d.ldc % 8) return false;
   if ((long)d.M * d.lda >= (1L << 31) || (long)d.N * d.ldb >= (1L << 31)) return false;
   if (d.row_scale || d.row_fill_flag || d.mask_out || (d.drop.p > 0.f && d.drop.seed)) return false;
   for (int g = 0; g < d.groups; ++g) {
-    if (d.A2[g] || d.B2[g] || d.C2[g] || d.row_mask[g] || d.colsum[g]) return false;
+    if (d.A2[g] || d.B2[g] || d.row_mask[g] || d.colsum[g]) return false;
+    if (planes ? ((g % kc) == 0 && (!d.C2[g] || (((uintptr_t)d.C2[g]) & 15))) : d.C2[g] != nullptr) return false;
     if (d.aux[g] && !(add && (g % kc) == 0 && (((uintptr_t)d.aux[g]) & 15) == 0)) return false;
     if (add && (g % kc) == 0 && !d.aux[g]) return false;
     if (d.bias[g] && d.dtBias != PQ3D_F32) return false;
@@ -340,7 +367,7 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStrea
   // worth it only when the launch still fills the chip: >= 2 workgroups per CU, or >= 1 per CU with a long K loop
   const long tiles = (long)((d.M + TM - 1) / TM) * (d.N / TN) * (d.groups / kc);
   const long nkt = (long)(d.K / TK) * kc;
-  if (tiles < 512 && !(tiles >= 256 && nkt >= 16)) return false;   // (128 tiles x 48 k-tiles measured equal to the 64x64 tile)
+  if (!planes && tiles < 512 && !(tiles >= 256 && nkt >= 16)) return false;   // (the plane epilogue exists only here: any size)   // (128 tiles x 48 k-tiles measured equal to the 64x64 tile)
   pq3d_kdesc k = kd;
   // Groups that read one row operand (one memory's tokens against the K / V weights of every layer) become one run of
   // z-planes (common.h): the group order of a plain launch carries no meaning, so sort by the A pointer first.
@@ -354,13 +381,15 @@ bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStrea
   if (tiles < 768) {   // fewer than 3 workgroups per CU: 128 x 64 tiles (see the kernel's header)
     const dim3 grid((d.M + TM - 1) / TM, d.N / 64, d.groups / kc);
     k.xcd_order = xcd_order_for(2 * tiles, (long)d.N * d.K * 2 * kc, run);
-    if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 64>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 64>), grid, dim3(256), 0, s, k);
+    if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<1, 128, 64>), grid, dim3(256), 0, s, k);
+    else if (planes) hipLaunchKernelGGL((gemm_nt128_kernel<2, 128, 64>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((gemm_nt128_kernel<0, 128, 64>), grid, dim3(256), 0, s, k);
     return true;
   }
   const dim3 grid((d.M + TM - 1) / TM, d.N / TN, d.groups / kc);
   k.xcd_order = xcd_order_for(tiles, (long)d.N * d.K * 2 * kc, run);
-  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<true, 128, 128>), grid, dim3(256), 0, s, k);
-  else hipLaunchKernelGGL((gemm_nt128_kernel<false, 128, 128>), grid, dim3(256), 0, s, k);
+  if (d.dtC == PQ3D_F32) hipLaunchKernelGGL((gemm_nt128_kernel<1, 128, 128>), grid, dim3(256), 0, s, k);
+  else if (planes) hipLaunchKernelGGL((gemm_nt128_kernel<2, 128, 128>), grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((gemm_nt128_kernel<0, 128, 128>), grid, dim3(256), 0, s, k);
   return true;
 }

@@ -100,6 +100,36 @@ __global__ void add_cast_kernel(const AddCastPtrs p, int dt_out, long n) {
   }
 }
 
+// hi / lo bf16 planes of (a + b): hi = bf16(v) (round to nearest even), lo = bf16(v - hi) -- the operand form of the split-bf16
+// products whose operands are reused by many launches (compute mode 'bf16x3': the memories' tokens and the K / V weights);
+// groups of individual lengths, hi may be NULL for a group (its hi plane already exists)
+struct SplitPtrs { const float* a[PQ3D_MAX_GROUPS]; const float* b[PQ3D_MAX_GROUPS]; void* hi[PQ3D_MAX_GROUPS]; void* lo[PQ3D_MAX_GROUPS];
+                   long n[PQ3D_MAX_GROUPS]; };
+__global__ void split_planes_kernel(const SplitPtrs p) {
+  const int g = blockIdx.y;
+  const float* a = p.a[g];
+  const float* b = p.b[g];
+  bf16_t* hi = (bf16_t*)p.hi[g];
+  bf16_t* lo = (bf16_t*)p.lo[g];
+  const long n = p.n[g];
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long)gridDim.x * blockDim.x * 8) {
+    const float4 a0 = *(const float4*)(a + i), a1 = *(const float4*)(a + i + 4);
+    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    if (b) {
+      const float4 b0 = *(const float4*)(b + i), b1 = *(const float4*)(b + i + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    u32x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h[j] = pack_bf2(v[2 * j], v[2 * j + 1]);
+      l[j] = pack_bf2(v[2 * j] - __uint_as_float(h[j] << 16), v[2 * j + 1] - __uint_as_float(h[j] & 0xffff0000u));
+    }
+    if (hi) *(u32x4*)(hi + i) = h;
+    *(u32x4*)(lo + i) = l;
+  }
+}
+
 __global__ void bias_add_rows_kernel(const float* x, const float* bias, float* out, long R, long N) {
   const long n4 = N / 4, total = R * n4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -874,6 +904,25 @@ extern "C" int pq3d_add_cast(const float* const* a, const float* const* b, void*
   if (n == 0) return 0;
   hipLaunchKernelGGL(add_cast_kernel, dim3(grid1d(n / 8, 256, 1024), groups), dim3(256), 0, (hipStream_t)stream, p,
                      dt_out, (long)n);
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_split_planes(const float* const* a, const float* const* b, void* const* hi, void* const* lo,
+                                 const int64_t* counts, int32_t groups, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
+  PQ_CHECK_ARG(a && lo && counts && groups >= 1 && groups <= PQ3D_MAX_GROUPS, "pq3d_split_planes: bad args");
+  SplitPtrs p;
+  long nmax = 0;
+  for (int g = 0; g < groups; ++g) {
+    PQ_CHECK_ARG(a[g] && lo[g] && counts[g] >= 0 && (counts[g] % 8) == 0, "pq3d_split_planes: null pointer / count not a multiple of 8");
+    PQ_CHECK_ARG(((((uintptr_t)a[g]) | ((uintptr_t)lo[g]) | ((uintptr_t)(hi ? hi[g] : nullptr)) | ((uintptr_t)(b ? b[g] : nullptr))) & 15) == 0,
+                 "pq3d_split_planes: operands must be 16-byte aligned");
+    p.a[g] = a[g]; p.b[g] = b ? b[g] : nullptr; p.hi[g] = hi ? hi[g] : nullptr; p.lo[g] = lo[g]; p.n[g] = (long)counts[g];
+    nmax = counts[g] > nmax ? (long)counts[g] : nmax;
+  }
+  if (nmax == 0) return 0;
+  hipLaunchKernelGGL(split_planes_kernel, dim3(grid1d(nmax / 8, 256, 1024), groups), dim3(256), 0, (hipStream_t)stream, p);
   PQ_LAUNCH_CHECK();
   return 0;
 }

@@ -159,6 +159,7 @@ class FusedSpec:
         # (the LAST scale of a multi-scale memory, query3d_unified.py:163-165)
         self.src, self.mh_src, self.n_src = None, None, len(self.mems)
         self.prompt = False          # structure 'mixed': a sequential prompt cross-attention follows the parallel scene memories
+        self.kv3 = False             # compute mode 'bf16x3': split-bf16 key/value side (set by fused_decoder)
         self.drop_base = drop_base   # dropout-site base of the encoder when train-mode dropout is active, else None
         self.mh_drop = mh_drop       # mask head's cls_head dropout active
 
@@ -269,15 +270,30 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
     return dx, d_o
 
 
+def kv3_ks(Lk: int) -> int:
+    """Key splits of the split-bf16 cross-attention forward (csrc/attn_x3.hip: at most 1024 keys per workgroup) -- a function of the
+    key length only, like every forward split factor (a scene's result must not depend on how scenes are batched)."""
+    return max(1, -(-((Lk + 63) // 64) // 16))
+
+
 def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None, bias=None, mask_bmod=0, bwd=None,
-          drop=None, drop_bmod=0, proj_dout=None, mask_bits=None):
+          drop=None, drop_bmod=0, proj_dout=None, mask_bits=None, planes=None):
     """proj_dout = (g, W): backward only -- dO = g W is formed inside the attention kernel (pq3d_attn_proj, DOUT) and
-    bwd[0] is ignored; the caller checks sa_fold_ok() first."""
+    bwd[0] is ignored; the caller checks sa_fold_ok() first.
+    planes = (k_lo, v_lo, q_bf, o_bf): forward only, compute mode 'bf16x3' -- q / o fp32, k / v the hi planes (csrc/attn_x3.hip)."""
     d = ops._attn_desc(q, k, v, o, lse, H, ct, zero_attn, 1.0 / math.sqrt(q.shape[-1] // H), kpm, mask, row_open, bias,
                        drop, drop_bmod, bwd=bwd is not None, mask_bits=mask_bits)
     d.mask_bmod = mask_bmod
     B, Lq, dm = q.shape
     Lk = k.shape[1]
+    if planes is not None:
+        assert bwd is None and ct == L.BF16X3 and q.dtype == torch.float32 and k.dtype == torch.bfloat16
+        d.k_lo, d.v_lo, d.q_bf, d.o_bf = map(L.ptr, planes)
+        ks = kv3_ks(Lk)
+        d.ksplit, d.ws, d._ws_keepalive = 1, None, None
+        if ks > 1:
+            d._ws_keepalive = torch.empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
+            d.ksplit, d.ws = ks, L.ptr(d._ws_keepalive)
     key = f"B{B}H{H}Lq{Lq}Lk{Lk}dh{dm // H}ct{ct}"
     if bwd is None:
         L.check(timed("pq3d_attn_fwd", key, 4.0 * B * Lq * Lk * dm, (q.numel() * 2 + k.numel() * 2) * q.element_size(),
@@ -1074,6 +1090,8 @@ class _FusedDecoder(Function):
 
         # ---- layer-invariant MFMA operands, rounded once: kin_m = (feat_m + pos), vin_m = feat_m in the activation
         # dtype (bf16 path: the 2*L*M hoisted GEMMs and their weight-gradient GEMM then read 2 B/element, not 8)
+        kv3 = spec.kv3   # compute mode 'bf16x3': split-bf16 key/value side (hi + lo bf16 planes), see fused_decoder()
+        kvin_lo = None
         if ct == BF16 and (B * Ns * d) % 8 == 0 and 2 * U <= MAXG:
             kvin = torch.empty(2, U, B, Ns, d, dtype=ad, device=dev)
             srcs = [feats[u] for u in range(U)] * 2
@@ -1082,8 +1100,12 @@ class _FusedDecoder(Function):
             if pos is None:
                 adds = [None] * (2 * U)
             arr = lambda ts: (C.c_void_p * len(ts))(*[L.ptr(t) for t in ts])
-            L.check(L.lib().pq3d_add_cast(arr(srcs), arr(adds), arr(outs), 2 * U, L.BF16, B * Ns * d, L.stream()),
-                    "pq3d_add_cast")
+            if kv3:   # both planes of (feat + pos) and feat in one launch; the K / V weights' residual planes join it below
+                kvin_lo = torch.empty(2, U, B, Ns, d, dtype=ad, device=dev)
+                f_srcs, f_adds, f_outs = srcs, adds, outs
+            else:
+                L.check(L.lib().pq3d_add_cast(arr(srcs), arr(adds), arr(outs), 2 * U, L.BF16, B * Ns * d, L.stream()),
+                        "pq3d_add_cast")
             kin, vin, kin2 = [kvin[0, u] for u in range(U)], [kvin[1, u] for u in range(U)], [None] * U
         else:
             kin, vin, kin2 = feats, feats, [pos] * U
@@ -1110,18 +1132,48 @@ class _FusedDecoder(Function):
                 L.check(L.lib().pq3d_add_cast(arr(srcs), arr([None] * len(srcs)), arr(outs), len(srcs), L.BF16, 2 * d * d,
                                               L.stream()), "pq3d_add_cast")
         ctx.wkv, ctx.wkvT = wkv, wkvT
-        A, A2, Bw, bs, Cs = [], [], [], [], []
-        for i in range(Ln):
-            for j, ca in enumerate(cas[i]):
-                w, b = ca.multihead_attn.in_proj_weight.detach(), ca.multihead_attn.in_proj_bias.detach()
-                A += [kin[src[i][j]], vin[src[i][j]]]
-                A2 += [kin2[src[i][j]], None]
-                Bw += [w[d:2 * d], w[2 * d:]] if wkv is None else [wkv[i, j, :d], wkv[i, j, d:]]
-                bs += [b[d:2 * d], b[2 * d:]]
-                Cs += [KV[i, 0, j], KV[i, 1, j]]
-        for s in range(0, len(A), MAXG):
-            L.gemm(M=Rk, N=d, K=d, A=A[s:s + MAXG], A2=A2[s:s + MAXG], B=Bw[s:s + MAXG], bias=bs[s:s + MAXG],
-                   Cs=Cs[s:s + MAXG], ct=ct, lda=d, ldb=d, ldc=d)
+        KV_lo = None
+        if kv3:
+            # split-bf16 projection as THREE K-concatenated bf16 groups per output on the 128-row-tile kernel (lo.hi + hi.lo + hi.hi,
+            # small terms first), its fp32 result leaving as hi / lo bf16 planes (PQ3D_ACT_PLANES): KV = exactly the 'bf16'-mode
+            # tensor the backward reads, KV_lo the residual the forward's split-bf16 attention adds (csrc/attn_x3.hip)
+            assert wkv is not None and kvin_lo is not None
+            wkv_lo = torch.empty_like(wkv)
+            ops.split_planes(f_srcs + [ca.multihead_attn.in_proj_weight.detach()[d:] for i in range(Ln) for ca in cas[i]],
+                             f_adds + [None] * (Ln * M), f_outs + [None] * (Ln * M),
+                             [kvin_lo[0, u] for u in range(U)] + [kvin_lo[1, u] for u in range(U)] +
+                             [wkv_lo[i, j] for i in range(Ln) for j in range(M)])
+            KV_lo = torch.empty_like(KV)
+            A, Bw, bs, Cs, C2 = [], [], [], [], []
+            for i in range(Ln):
+                for j, ca in enumerate(cas[i]):
+                    b = ca.multihead_attn.in_proj_bias.detach()
+                    u = src[i][j]
+                    for t in (0, 1):
+                        a_hi, a_lo = kvin[t, u], kvin_lo[t, u]
+                        w_hi, w_lo = wkv[i, j, t * d:(t + 1) * d], wkv_lo[i, j, t * d:(t + 1) * d]
+                        A += [a_lo, a_hi, a_hi]
+                        Bw += [w_hi, w_lo, w_hi]
+                        bs += [b[(1 + t) * d:(2 + t) * d], None, None]
+                        Cs += [KV[i, t, j], None, None]
+                        C2 += [KV_lo[i, t, j], None, None]
+            per = (MAXG // 3) * 3
+            for s in range(0, len(A), per):
+                L.gemm(M=Rk, N=d, K=d, A=A[s:s + per], B=Bw[s:s + per], bias=bs[s:s + per], Cs=Cs[s:s + per], C2=C2[s:s + per],
+                       ct=ct, lda=d, ldb=d, ldc=d, kconcat=3, act_grad="planes")
+        else:
+            A, A2, Bw, bs, Cs = [], [], [], [], []
+            for i in range(Ln):
+                for j, ca in enumerate(cas[i]):
+                    w, b = ca.multihead_attn.in_proj_weight.detach(), ca.multihead_attn.in_proj_bias.detach()
+                    A += [kin[src[i][j]], vin[src[i][j]]]
+                    A2 += [kin2[src[i][j]], None]
+                    Bw += [w[d:2 * d], w[2 * d:]] if wkv is None else [wkv[i, j, :d], wkv[i, j, d:]]
+                    bs += [b[d:2 * d], b[2 * d:]]
+                    Cs += [KV[i, 0, j], KV[i, 1, j]]
+            for s in range(0, len(A), MAXG):
+                L.gemm(M=Rk, N=d, K=d, A=A[s:s + MAXG], A2=A2[s:s + MAXG], B=Bw[s:s + MAXG], bias=bs[s:s + MAXG],
+                       Cs=Cs[s:s + MAXG], ct=ct, lda=d, ldb=d, ldc=d)
         # ---- structure 'mixed' (query_encoder.py:162-165): the prompt memory's K / V of every layer, hoisted like the scene
         # memories' (the prompt is layer-invariant, pos = None: query3d_unified.py:134-136): one grouped launch
         PKV = None
@@ -1206,14 +1258,25 @@ class _FusedDecoder(Function):
                 if q_next is not None:   # formed by the previous layer application's chain launch (csrc/chain_ffn.hip, step 6)
                     q_all, q_next = q_next, None
                 else:
-                    q_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+                    q_all = torch.empty(M, B, Nq, d, dtype=torch.float32 if kv3 else ad, device=dev)
                     ws = [ca.multihead_attn.in_proj_weight.detach() for ca in cas[i]]
                     bsl = [ca.multihead_attn.in_proj_bias.detach() for ca in cas[i]]
                     L.gemm(M=R, N=d, K=d, A=[x] * M, A2=[qpos] * M, B=[w[:d] for w in ws], bias=[b[:d] for b in bsl],
                            Cs=[q_all[m] for m in range(M)], ct=cq, lda=d, ldb=d, ldc=d)
                 o_all = torch.empty(M, B, Nq, d, dtype=ad, device=dev)
                 lse = torch.empty(M * B, H, Nq, dtype=torch.float32, device=dev)
-                if spec.use_self_mask:
+                o_f32 = None
+                if kv3:
+                    # split-bf16 cross-attention (csrc/attn_x3.hip): fp32 q in, fp32 o out (-> the split-bf16 out-projection); the
+                    # bf16 copies it leaves of q and o are what the (single-bf16) backward reads -- a 'bf16'-mode tape
+                    q_f32, q_all = q_all, torch.empty(M, B, Nq, d, dtype=ad, device=dev)
+                    o_f32 = torch.empty(M, B, Nq, d, dtype=torch.float32, device=dev)
+                    mkw = dict(mask=attn_mask, row_open=row_open, mask_bmod=B, mask_bits=mask_bits) if spec.use_self_mask \
+                        else dict(kpm=kpm_all)
+                    _attn(q_f32.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
+                          o_f32.view(M * B, Nq, d), lse, H, L.BF16X3, True, drop=dr_ca, drop_bmod=B,
+                          planes=(KV_lo[i, 0], KV_lo[i, 1], q_all, o_all), **mkw)
+                elif spec.use_self_mask:
                     _attn(q_all.view(M * B, Nq, d), KV[i, 0].view(M * B, Ns, d), KV[i, 1].view(M * B, Ns, d),
                           o_all.view(M * B, Nq, d), lse, H, ct, True, mask=attn_mask, row_open=row_open, mask_bmod=B,
                           drop=dr_ca, drop_bmod=B, mask_bits=mask_bits)
@@ -1240,16 +1303,16 @@ class _FusedDecoder(Function):
                     if flags is None or flags.device != dev:
                         flags = enc._chain_flags_ca = ops.chain_flags(2048, dev)
                     op_all, x1, mean_c, rstd_c, qkv = ops.chain_ca_fwd(
-                        o_all, [ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
+                        o_f32 if kv3 else o_all, [ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
                         [ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]], x, [ca.norm.weight.detach() for ca in cas[i]],
                         [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps, coef[app] if coef is not None else None, Nq, qpos,
                         [t_.contiguous() for t_ in Wl], [t_.contiguous() for t_ in bl], flags)
                 else:
                     op_all = torch.empty(M, B, Nq, d, dtype=torch.float32, device=dev)
-                    L.gemm(M=R, N=d, K=d, A=[o_all[m] for m in range(M)],
+                    L.gemm(M=R, N=d, K=d, A=[(o_f32 if kv3 else o_all)[m] for m in range(M)],
                            B=[ca.multihead_attn.out_proj.weight.detach() for ca in cas[i]],
                            bias=[ca.multihead_attn.out_proj.bias.detach() for ca in cas[i]],
-                           Cs=[op_all[m] for m in range(M)], ct=ct, lda=d, ldb=d, ldc=d)
+                           Cs=[op_all[m] for m in range(M)], ct=cq if kv3 else ct, lda=d, ldb=d, ldc=d)
                     x1, mean_c, rstd_c = _ln_fwd(x, [op_all[m] for m in range(M)], [ca.norm.weight.detach() for ca in cas[i]],
                                                  [ca.norm.bias.detach() for ca in cas[i]], cas[i][0].norm.eps,
                                                  coef[app] if coef is not None else None, Nq, drop=dr_cr)
@@ -1304,7 +1367,8 @@ class _FusedDecoder(Function):
                     outs = ops.chain_ffn_fwd(
                         o_s, Wo, bo, x1s, sa.norm.weight.detach(), sa.norm.bias.detach(), sa.norm.eps,
                         ffn.linear1.weight.detach(), ffn.linear1.bias.detach(), ffn.linear2.weight.detach(), ffn.linear2.bias.detach(),
-                        ffn.norm.weight.detach(), ffn.norm.bias.detach(), ffn.norm.eps, flags, nextq=nextq)
+                        ffn.norm.weight.detach(), ffn.norm.bias.detach(), ffn.norm.eps, flags, nextq=nextq,
+                        q_dtype=torch.float32 if kv3 else torch.bfloat16)
                     f, x2, mean_s, rstd_s, h, _zp, z, x3, mean_f, rstd_f = outs[:10]
                     q_next = outs[10] if nextq is not None else None
                     pre = None
@@ -1441,7 +1505,16 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
         coef = torch.stack([memory_keep_coef(B_, len(mems), layer0.memory_dropout, x0.device,
                                              hook(a, B_, len(mems), x0.device) if hook is not None else None)
                             for a in range(n_app)]).contiguous()
-    ct = L.BF16 if layer0.compute == "bf16" else L.F32
+    ct = L.BF16 if layer0.compute in ("bf16", "bf16x3") else L.F32
+    # compute mode 'bf16x3': the split-bf16 key/value side where its kernels cover the shape (128-row-tile plane GEMM: d % 128 == 0;
+    # csrc/attn_x3.hip: d_h = 32, <= 256 queries; scene memories only), the exact-f32 kernels otherwise -- same accuracy contract
+    kv3 = False
+    if layer0.compute == "bf16x3":
+        B_, Ns_, d_ = uniq[0].shape
+        kv3 = (d_ % 128 == 0 and d_ == 32 * enc.num_heads and x0.shape[1] <= 256 and B_ * Ns_ >= 128 and 2 * len(uniq) <= MAXG and
+               len(mems) * Ln_ <= MAXG and prompt is None and all(f.dtype == torch.float32 for f in uniq))
+        if not kv3:
+            ct = L.F32
     drop_base, mh_drop = None, False
     if training:   # the caller (QueryMaskEncoder.forward) has opened the RNG epoch (modules.begin_dropout_step)
         layers_ = list(enc.unified_encoder)
@@ -1458,6 +1531,7 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
             all(masks[j].data_ptr() == st[0][j].data_ptr() for j in range(len(mems))):
         spec.stacked_kpm = st[0]
     spec.src, spec.mh_src, spec.n_src = src, mh_src, len(uniq)
+    spec.kv3 = kv3
     spec.prompt = prompt is not None
     params = [p for p in enc.parameters()] + ([p for p in mask_head.parameters()] if mask_head is not None else [])
     outs = _FusedDecoder.apply(spec, x0, qpos, qmask, poss[0], pairwise_locs, seg_masks, offline_attn_masks, coef,

@@ -4,7 +4,8 @@ forward contracts and state_dict keys, computing through the HIP k
 nn.Linear / nn.LayerNorm / nn.Sequential instances below are *parameter containers* only (they give the
 reference's state_dict key names and let DDP / optimisers see ordinary leaf Parameters); their forward() is
 never called.  ``compute`` selects the MFMA path: 'bf16' (bf16 operands, fp32 accumulate / softmax / LayerNorm /
-residual stream) or 'fp32' (exact-f32 MFMA everywhere).
+residual stream), 'bf16x3' (the same with a split-bf16, fp32-grade key/value side: see ``CT``) or 'fp32' (exact-f32 MFMA
+everywhere).
 
 Dropout: in train mode every nn.Dropout / MultiheadAttention(dropout=p) site of the reference is applied INSIDE the
 kernels (attention probabilities, residual branches before add+LayerNorm, FFN hidden) from a counter-based generator
@@ -24,7 +25,11 @@ import torch.nn as nn
 from . import ops
 from ._lib import BF16, F32
 
-CT = {"bf16": BF16, "fp32": F32}
+# 'bf16x3' = 'bf16' with the KEY/VALUE side of the decoder's cross-attention (hoisted K/V projections, scores, value contraction,
+# out-projection: the only single-bf16 forward products of 'bf16') carried as hi + lo bf16 pairs, 3 MFMAs per product -- fp32-grade
+# forward (north_star's 1e-3 end to end), single-bf16 backward.  Everything else is identical to 'bf16', hence the same table entry;
+# the fused executor (fused.fused_decoder) and CrossAttentionLayer.branch look at the mode string itself.
+CT = {"bf16": BF16, "fp32": F32, "bf16x3": BF16}
 # dropout-site bases of the module roles (a second instance of a role in one model may be given its own
 # ``_drop_base``; instances sharing a base draw identical masks for identical shapes)
 DROP_BASE_ENCODER, DROP_BASE_MASK_HEAD, DROP_BASE_GROUND_HEAD, DROP_BASE_OBJ_ENC, DROP_BASE_LAYER = \
@@ -32,7 +37,7 @@ DROP_BASE_ENCODER, DROP_BASE_MASK_HEAD, DROP_BASE_GROUND_HEAD, DROP_BASE_OBJ_ENC
 
 
 def set_compute(module: nn.Module, compute: str) -> nn.Module:
-    """Select 'bf16' or 'fp32' MFMA path for every pq3d module below ``module``."""
+    """Select the 'bf16', 'bf16x3' or 'fp32' MFMA path for every pq3d module below ``module``."""
     assert compute in CT
     for m in module.modules():
         if hasattr(m, "compute"):
@@ -221,6 +226,10 @@ class CrossAttentionLayer(_PostNormBase):
                row_open=None, _drop=None, _m=0) -> torch.Tensor:
         """out_proj(MHA(tgt+query_pos, memory+pos, memory)) -- the pre-residual branch output, fp32."""
         ct, d = self.ct, tgt.shape[-1]
+        if self.compute == "bf16x3":
+            # modular path (structures the fused executor does not cover): the key/value side on the exact-f32 kernels, forward and
+            # backward -- the mode's accuracy contract without its split-bf16 kernels (those live in the fused executor)
+            ct = F32
         w, b = self.multihead_attn.in_proj_weight, self.multihead_attn.in_proj_bias
         ad = ops.act_dtype(ct)
         # the query projection (B*N_q rows) is formed at fp32 grade (split-bf16) and rounded once to the attention

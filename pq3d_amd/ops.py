@@ -142,6 +142,18 @@ def dropout(x: torch.Tensor, drop: Optional[L.Drop], alpha: float = 1.0) -> torc
 
 
 # ------------------------------------------------------------------------------------------------ small kernels
+def split_planes(srcs, adds, his, los) -> None:
+    """bf16 hi / lo planes of fp32 tensors (+ an optional addend): his[g] = bf16(v), los[g] = bf16(v - his[g]); his[g] may be None.
+    The operand form of the split-bf16 key/value side (compute mode 'bf16x3')."""
+    for i in range(0, len(srcs), L.MAXG):
+        sl = slice(i, i + L.MAXG)
+        n = len(srcs[sl])
+        arr = lambda ts: (C.c_void_p * n)(*[L.ptr(t) for t in ts])
+        cnt = (C.c_int64 * n)(*[t.numel() for t in srcs[sl]])
+        L.check(L.lib().pq3d_split_planes(arr(srcs[sl]), arr(adds[sl]), arr(his[sl]), arr(los[sl]), cnt, n, L.stream()),
+                "pq3d_split_planes")
+
+
 def colsum(x2d: torch.Tensor) -> torch.Tensor:
     R, N = x2d.shape
     out = _empty(N, dtype=torch.float32, device=x2d.device)
@@ -1692,9 +1704,10 @@ def chain_ffn_ok(R: int, d: int, F_: int) -> bool:
     return d == 256 and F_ == 2048 and 1 <= R <= 2048
 
 
-def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2, flags, nextq=None):
+def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2, flags, nextq=None, q_dtype=torch.bfloat16):
     """Returns (f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2[, q_next]); every tensor fp32, rows = o_s.numel() // 256.
-    nextq = (qpos, [Wq_m], [bq_m]): also q_next[m] = (x3 + qpos) Wq_m^T + bq_m as bf16 (the next layer's cross-attention queries)."""
+    nextq = (qpos, [Wq_m], [bq_m]): also q_next[m] = (x3 + qpos) Wq_m^T + bq_m as bf16 (the next layer's cross-attention queries;
+    q_dtype = torch.float32 for compute mode 'bf16x3')."""
     d = o_s.shape[-1]
     R, F_ = o_s.numel() // d, W1.shape[0]
     dev = o_s.device
@@ -1715,9 +1728,9 @@ def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2
     qn = None
     if nextq is not None:
         qpos, Wqs, bqs = nextq
-        qn = torch.empty(len(Wqs), *o_s.shape, dtype=torch.bfloat16, device=dev)
+        qn = torch.empty(len(Wqs), *o_s.shape, dtype=q_dtype, device=dev)
         assert qpos.is_contiguous() and qpos.dtype == torch.float32 and len(Wqs) <= 3
-        c.nq, c.qpos = len(Wqs), L.ptr(qpos)
+        c.nq, c.qpos, c.qout_f32 = len(Wqs), L.ptr(qpos), int(q_dtype == torch.float32)
         for m, (w_, b_) in enumerate(zip(Wqs, bqs)):
             assert w_.is_contiguous() and b_.is_contiguous() and w_.dtype == torch.float32
             c.Wq[m], c.bq[m], c.qout[m] = L.ptr(w_), L.ptr(b_), L.ptr(qn[m])
@@ -1733,7 +1746,8 @@ def chain_ca_ok(R: int, d: int, M: int) -> bool:
 
 
 def chain_ca_fwd(o_all, Wos, bos, x, gammas, betas, eps, coef, rows_per_scene, qpos, Wqkv, bqkv, flags):
-    """o_all [M, ..., d] bf16 -> (op_all [M, ..., d], x1, mean [M, R], rstd [M, R], qkv [3, ..., d]); everything else fp32."""
+    """o_all [M, ..., d] bf16 (fp32: split-bf16 out-projections, compute mode 'bf16x3') -> (op_all [M, ..., d], x1, mean [M, R],
+    rstd [M, R], qkv [3, ..., d]); everything else fp32."""
     M, d = o_all.shape[0], o_all.shape[-1]
     R = x.numel() // d
     dev = x.device
@@ -1745,7 +1759,8 @@ def chain_ca_fwd(o_all, Wos, bos, x, gammas, betas, eps, coef, rows_per_scene, q
         err = _CHAIN_ERR[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
     c = L.ChainCaDesc()
     c.R, c.d, c.M, c.rows_per_scene, c.eps = R, d, M, rows_per_scene, eps
-    assert o_all.dtype == torch.bfloat16 and o_all.is_contiguous() and x.is_contiguous() and qpos.is_contiguous()
+    assert o_all.dtype in (torch.bfloat16, torch.float32) and o_all.is_contiguous() and x.is_contiguous() and qpos.is_contiguous()
+    c.o_f32 = int(o_all.dtype == torch.float32)
     assert x.dtype == torch.float32 and qpos.dtype == torch.float32
     for m in range(M):
         for n, t in (("o", o_all[m]), ("Wo", Wos[m]), ("bo", bos[m]), ("gamma", gammas[m]), ("beta", betas[m]), ("op", op_all[m])):

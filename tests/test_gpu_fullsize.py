@@ -204,6 +204,35 @@ def test_bf16_fullsize_matches_fp32_oracle(args):
     assert worst[0] < 0.2, f"worst gradient (relative L2) {worst}"
 
 
+@pytest.mark.parametrize("args", [C2, dict(C2, heads=[]), C4_PINNED], ids=["c2", "c2-bench-heads", "c4-pinned-masks"])
+def test_bf16x3_fullsize_meets_north_star_tolerance(args):
+    """Compute mode 'bf16x3' (split-bf16 key/value side: hi + lo bf16 planes of K / V, q, P and O, 3 MFMAs per product; single-bf16
+    backward) at BASELINE's full sizes against the fp32 oracle: north_star's 1e-3 END TO END on every output (not 1.5 x measured:
+    measured ~3e-5), every parameter gradient within 2e-2 relative L2 (floor 1e-2 of the largest gradient norm; measured
+    ~1.3e-2, the single-bf16 backward products of the query side -- tools/probes/x3_grad_emul.py).  'c2-bench-heads' is the
+    configuration bench.py times (no output head)."""
+    model, sd, dd = build(args, "bf16x3")
+    out, loss = run(model, args, dd)
+    assert model.unified_encoder.fused
+    oout, collect, oloss, og = util.run_oracle(args, sd, dd)
+    assert rel(out["query_embeds"], collect[-1]) < 1e-3
+    if "ground" in args["heads"]:
+        assert rel(out["ground_logits"], oout["ground_logits"]) < 1e-3
+    if "mask" in args["heads"]:
+        for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
+            assert rel(m, r) < 1e-3
+        for c, r in zip(out["predictions_class"], oout["predictions_class"]):
+            assert rel(c, r) < 1e-3
+    assert abs(loss.item() - oloss.item()) < 1e-3 * max(1.0, abs(oloss.item()))
+    g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert sorted(g) == sorted(og)
+    names = sorted(n for n in og if "pairwise_loc_fc" not in n)
+    assert _flat_cos(g, og, names) >= 0.9999
+    gmax = max(float(og[n].norm()) for n in names)
+    worst = max((float((g[n].float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * gmax)), n) for n in names)
+    assert worst[0] < 2e-2, f"worst gradient (relative L2) {worst}"
+
+
 def test_bf16_c4_self_mask_flip_rate():
     """Live (un-pinned) self-masks in 'bf16' mode: the thresholded mask logits are fp32-grade given the query (split-bf16
     mask head), so bits only flip where the query's own ~1e-3 error moves a logit across 0."""

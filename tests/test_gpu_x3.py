@@ -1,0 +1,215 @@
+"""GPU: the split-bf16 key/value side of compute mode 'bf16x3' (north_star: outputs within 1e-3 at bf16-class speed).
+
+Kernels: pq3d_split_planes (hi / lo bf16 planes), pq3d_gemm's PQ3D_ACT_PLANES epilogue on three K-concatenated bf16 groups
+(csrc/gemm128.hip), the split-bf16 cross-attention forward (csrc/attn_x3.hip), the fp32-input variants of the two forward
+chains.  References: float64 torch restatements of the reference arithmetic (nn.MultiheadAttention with add_zero_attn,
+query_encoder.py:268-307); model level: the fp32 oracle (tests/test_gpu_fullsize.py holds the full-size cases)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from pq3d_amd import _lib as L
+from pq3d_amd import fused, ops
+from pq3d_amd.modules import set_compute
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def planes(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+def test_split_planes_is_exact_and_fp32_grade():
+    a, b = rnd(3, 1000, 64, seed=1), rnd(1000, 64, seed=2)
+    ad, bd = a.to(DEV), b.to(DEV)
+    hi = torch.empty(3, 1000, 64, dtype=torch.bfloat16, device=DEV)
+    lo = torch.empty_like(hi)
+    lo2 = torch.empty_like(hi[0])
+    ops.split_planes([ad[0], ad[1], ad[2], ad[0]], [bd, None, bd, None], [hi[0], hi[1], hi[2], None], [lo[0], lo[1], lo[2], lo2])
+    for g, add in enumerate((b, None, b)):
+        v = a[g] + add if add is not None else a[g]
+        rh, rl = planes(v)
+        assert torch.equal(hi[g].cpu(), rh) and torch.equal(lo[g].cpu(), rl)
+        assert float((hi[g].float().cpu() + lo[g].float().cpu() - v).abs().max()) <= 2.0 ** -16 * float(v.abs().max())
+    assert torch.equal(lo2.cpu(), planes(a[0])[1])   # hi = NULL: only the residual plane
+
+
+@pytest.mark.parametrize("M,N,K,outs", [(8192, 256, 256, 3), (130, 256, 256, 1), (1024, 768, 768, 2), (300, 128, 64, 10)])
+def test_plane_gemm_matches_float64(M, N, K, outs):
+    """C (hi) + C2 (lo) of the three-term K-concatenated product = the fp32 product to 2^-16 of its scale; C alone = its bf16 rounding."""
+    xs = [rnd(M, K, seed=10 + o) for o in range(outs)]
+    ws = [rnd(N, K, seed=20 + o, scale=K ** -0.5) for o in range(outs)]
+    bs = [rnd(N, seed=30 + o) for o in range(outs)]
+    A, B, bias, Cs, C2 = [], [], [], [], []
+    his, los = [], []
+    for o in range(outs):
+        xh, xl = (t.to(DEV) for t in planes(xs[o]))
+        wh, wl = (t.to(DEV) for t in planes(ws[o]))
+        hi = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        lo = torch.empty_like(hi)
+        his.append(hi); los.append(lo)
+        A += [xl, xh, xh]; B += [wh, wl, wh]; bias += [bs[o].to(DEV), None, None]; Cs += [hi, None, None]; C2 += [lo, None, None]
+    L.gemm(M=M, N=N, K=K, A=A, B=B, bias=bias, Cs=Cs, C2=C2, ct=L.BF16, lda=K, ldb=K, ldc=N, kconcat=3, act_grad="planes")
+    for o in range(outs):
+        ref = xs[o].double() @ ws[o].double().t() + bs[o].double()
+        got = his[o].float().cpu().double() + los[o].float().cpu().double()
+        s = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 3e-5 * s, (o, float((got - ref).abs().max()) / s)
+        # the hi plane is the bf16 rounding of the fp32-grade result (what a 'bf16'-mode consumer reads)
+        assert float((his[o].float().cpu().double() - ref).abs().max()) <= 2.0 ** -8 * s
+
+
+def test_plane_gemm_refuses_other_layouts():
+    x = torch.zeros(256, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(100, 64, dtype=torch.bfloat16, device=DEV)   # N % 128 != 0
+    hi = torch.empty(256, 100, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.Pq3dError):
+        L.gemm(M=256, N=100, K=64, A=[x], B=[w], Cs=[hi], C2=[torch.empty_like(hi)], ct=L.BF16, lda=64, ldb=64, ldc=100,
+               act_grad="planes")
+
+
+def attn_ref(q, k, v, H, kpm=None, mask=None, keep=None):
+    """float64: softmax(q k^T / sqrt(d_h) + masks, + the zero key) v; mask rows that are fully masked attend everywhere
+    (query_encoder.py:83); keep = dropout keep mask on the probabilities (scaled by the caller)."""
+    B, Lq, d = q.shape
+    dh = d // H
+    sp = lambda t: t.view(B, -1, H, dh).permute(0, 2, 1, 3)
+    qh, kh, vh = sp(q), sp(k), sp(v)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dh)
+    if mask is not None:
+        m = mask.clone()
+        m[m.all(-1)] = False
+        s = s.masked_fill(m[:, None], float("-inf"))
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    s = torch.cat([s, s.new_zeros(B, H, Lq, 1)], -1)
+    p = torch.softmax(s, -1)[..., :-1]
+    if keep is not None:
+        p = p * keep
+    o = p @ vh
+    lse = torch.logsumexp(s, -1)
+    return o.permute(0, 2, 1, 3).reshape(B, Lq, d), lse
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,mode", [(3, 8, 100, 1024, "kpm"), (2, 8, 100, 1000, "kpm"), (2, 4, 16, 130, "kpm"), (2, 8, 128, 2048, "kpm"),
+                                            (2, 8, 200, 4096, "mask"), (2, 8, 200, 1111, "mask"), (2, 2, 7, 64, "none"),
+                                            (2, 8, 100, 3000, "kpm"), (1, 8, 256, 512, "mask"), (2, 8, 129, 600, "kpm")])
+def test_attn_x3_forward_matches_float64(B, H, Lq, Lk, mode):
+    d = 32 * H
+    q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
+    g = torch.Generator().manual_seed(Lq * Lk + H)
+    kpm = mask = None
+    if mode == "kpm":
+        kpm = torch.arange(Lk)[None, :] >= torch.tensor([Lk, max(1, Lk // 2), 1][:B])[:, None]
+    if mode == "mask":
+        mask = torch.rand(B, Lq, Lk, generator=g) < 0.6
+        mask[:, 1, :] = True      # a fully masked row: attends everywhere
+        mask[0, 3, 64:] = True    # a row that attends to the first block only
+    kh, kl = (t.to(DEV) for t in planes(k))
+    vh, vl = (t.to(DEV) for t in planes(v))
+    qd = q.to(DEV)
+    o = torch.empty(B, Lq, d, dtype=torch.float32, device=DEV)
+    o_bf = torch.empty(B, Lq, d, dtype=torch.bfloat16, device=DEV)
+    q_bf = torch.empty_like(o_bf)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
+    kw = {}
+    if mask is not None:
+        md = mask.to(DEV)
+        row_open, bits = ops.mask_pack(md)
+        kw = dict(mask=md, row_open=row_open, mask_bits=bits)
+    elif kpm is not None:
+        kw = dict(kpm=kpm.to(DEV))
+    fused._attn(qd, kh, vh, o, lse, H, L.BF16X3, True, planes=(kl, vl, q_bf, o_bf), **kw)
+    # reference on the operands the kernel sees: k, v = hi + lo planes (2^-17-exact to the fp32 tensors)
+    kk = (kh.float() + kl.float()).cpu().double()
+    vv = (vh.float() + vl.float()).cpu().double()
+    oref, lref = attn_ref(q.double(), kk, vv, H, kpm, mask)
+    s = float(oref.abs().max())
+    assert float((o.cpu().double() - oref).abs().max()) <= 2e-5 * s, float((o.cpu().double() - oref).abs().max()) / s
+    assert float((lse.cpu().double() - lref).abs().max()) <= 2e-5 * max(1.0, float(lref.abs().max()))
+    assert torch.equal(o_bf.cpu(), o.cpu().to(torch.bfloat16))
+    assert torch.equal(q_bf.cpu(), q.to(torch.bfloat16))
+
+
+def test_attn_x3_forward_dropout_uses_the_shared_generator():
+    B, H, Lq, Lk = 2, 8, 100, 1024
+    d = 32 * H
+    q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
+    kh, kl = (t.to(DEV) for t in planes(k))
+    vh, vl = (t.to(DEV) for t in planes(v))
+    drop = ops.make_drop(0.25, ops.drop_site(1 << 20, 0, ops.DROP_CA_ATTN), torch.device(DEV))
+    keep = ops.dropout_mask(B * H * Lq, Lk, drop).view(B, H, Lq, Lk).cpu().double() / 0.75
+    o = torch.empty(B, Lq, d, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=DEV)
+    fused._attn(q.to(DEV), kh, vh, o, lse, H, L.BF16X3, True, planes=(kl, vl, None, None), drop=drop)
+    kk = (kh.float() + kl.float()).cpu().double()
+    vv = (vh.float() + vl.float()).cpu().double()
+    oref, _ = attn_ref(q.double(), kk, vv, H, keep=keep)
+    assert float((o.cpu().double() - oref).abs().max()) <= 2e-5 * float(oref.abs().max())
+
+
+def test_attn_planes_refused_outside_the_kernels_shape():
+    B, H, Lq, Lk = 1, 4, 300, 128   # > 256 queries
+    d = 32 * H
+    z = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=DEV)
+    with pytest.raises(L.Pq3dError):
+        fused._attn(z(B, Lq, d, dt=torch.float32), z(B, Lk, d), z(B, Lk, d), z(B, Lq, d, dt=torch.float32),
+                    z(B, H, Lq, dt=torch.float32), H, L.BF16X3, True, planes=(z(B, Lk, d), z(B, Lk, d), None, None))
+
+
+# ---------------------------------------------------------------------------------------------------- model level (fixture sizes)
+SMALL = [
+    dict(B=2, Ns=256, Nq=40, d=256, H=8, L=2, memories=["voxel", "mv", "pc"], heads=["ground"], spatial=True, structure="parallel",
+         seed=0, data_seed=7),
+    dict(B=2, Ns=320, Nq=136, d=256, H=8, L=2, memories=["voxel", "mv", "pc"], heads=["mask"], spatial=True, structure="parallel",
+         use_self_mask=True, C=21, foc=(0, 2), offline_attn=True, seed=0, data_seed=8),
+]
+
+
+@pytest.mark.parametrize("args", SMALL, ids=["kpm", "pinned-self-mask"])
+def test_bf16x3_model_is_fp32_grade_and_backward_is_the_bf16_modes(args):
+    """Forward within 1e-3 of the fp32 oracle end to end (measured ~2e-5); every gradient within 2e-2 (relative L2 against
+    max(|g|, 1e-2 max|g|): the single-bf16 backward); the fused executor takes the split-bf16 path (spec.kv3)."""
+    _cfg, model, sd, dd = util.model_case(args)
+    set_compute(model, "bf16x3")
+    model.to(DEV)
+    out = model({k: v.to(DEV) for k, v in dd.items()})
+    loss = util.synthetic_loss(out, args["heads"], out["query_embeds"])
+    loss.backward()
+    oout, collect, oloss, og = util.run_oracle(args, sd, dd)
+    q, qo = out["query_embeds"].detach().float().cpu(), collect[-1].detach()
+    assert float((q - qo).abs().max()) < 1e-3 * float(qo.abs().max())
+    if "mask" in args["heads"]:
+        for m, r in zip(out["predictions_mask"], oout["predictions_mask"]):
+            m, r = m.detach().float().cpu(), r.detach()
+            fin = torch.isfinite(r) & (r > -1e5)
+            assert float((m[fin] - r[fin]).abs().max()) < 1e-3 * float(r[fin].abs().max())
+    g = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    names = sorted(n for n in og if "pairwise_loc_fc" not in n)
+    gmax = max(float(og[n].norm()) for n in names)
+    worst = max((float((g[n].float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * gmax)), n) for n in names)
+    assert worst[0] < 2e-2, f"worst gradient (relative L2) {worst}"
+
+
+def test_bf16x3_falls_back_to_fp32_kernels_outside_the_split_kernels_shape():
+    """d_h = 16 is not covered by csrc/attn_x3.hip: the mode then runs the exact-f32 kernels -- same accuracy contract."""
+    args = dict(B=2, Ns=128, Nq=16, d=64, H=4, L=1, memories=["voxel"], heads=[], spatial=False, structure="parallel", seed=0,
+                data_seed=3)
+    _cfg, model, sd, dd = util.model_case(args)
+    set_compute(model, "bf16x3")
+    model.to(DEV)
+    with torch.no_grad():
+        q = model({k: v.to(DEV) for k, v in dd.items()})["query_embeds"].float().cpu()
+    _o, collect, _l, _g = util.run_oracle(args, sd, dd, grads=False)
+    assert float((q - collect[-1]).abs().max()) < 2e-5 * float(collect[-1].abs().max())
