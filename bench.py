@@ -661,6 +661,14 @@ def main():
     dt = sdts[len(sdts) // 2] if len(sdts) % 2 else 0.5 * (sdts[len(sdts) // 2 - 1] + sdts[len(sdts) // 2])
     ms = dt / args.steps * 1e3
     value = c["B"] * world * args.steps / dt
+    # the one-launch chains' error word (csrc/chain_common.h: a hand-off that ran past its bound sets it and the launch goes on with
+    # stale rows): read ONCE behind the timed region on every rank; set anywhere -> "chain_error": true in the line and exit code 3
+    from pq3d_amd import ops as _ops
+    chain_err = bool(_ops.chain_error(dev))
+    if dist_on:
+        ce = torch.tensor([int(chain_err)], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(ce, op=torch.distributed.ReduceOp.MAX)
+        chain_err = bool(int(ce.item()))
     grads_identical = None
     if dist_on:   # after the all-reduce every rank must hold the same (mean) gradient: fingerprint min == max over ranks
         fp = torch.stack([torch.stack([f.double().sum(), f.double().abs().sum()]) for f in reducer.flat]).flatten()
@@ -898,10 +906,14 @@ def main():
             if hf_body is not None:
                 result["cpu_baseline"]["sample"] += "; caption body = stock HF T5 on the CPU (third-party, as the reference calls it)"
             result["speedup_vs_cpu_baseline"] = value / result["cpu_baseline"]["value"]
+        result["chain_error"] = chain_err or bool(_ops.chain_error(dev))   # (the side legs above replay chain launches too)
         print(json.dumps(result))
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if chain_err or bool(_ops.chain_error(dev)):
+        print("[bench] a row-local chain launch timed out in a hand-off: the run is INVALID (see ops.chain_check)", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -420,6 +420,16 @@ typedef struct {
   int32_t qout_f32;
 } pq3d_chain_ffn_desc;
 int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* d, void* stream);
+/* Device gate of every pq3d_chain_* entry point: 1 if the current device of `stream` is the one their in-launch hand-offs are valid
+ * on -- gfx950, 256 CUs, 160 KB of LDS per workgroup, and (probe != 0: one 256-workgroup launch + a synchronous copy, cached per
+ * device; do not call with probe != 0 while the stream is capturing) the measured placement rule "workgroup id % 8 == XCC_ID" for
+ * all 256 workgroups -- else 0: the caller must use the separate launches (same bits).  The err word of a chain descriptor reports
+ * a hand-off that gave up at run time (a member that never became resident: CU-masked queue, a long-running neighbour kernel). */
+int pq3d_chain_device_ok(int32_t probe, void* stream);
+/* Test support (tests/test_gpu_chain.py): `workgroups` one-wave workgroups that each hold `lds_bytes` of a CU's LDS and spin for
+ * `microseconds` on `stream` -- a stand-in for a collective of another stream (RCCL: one workgroup per channel) that keeps CUs busy
+ * beside a chain launch (trainer/build.py:66-75: DDP's all-reduce overlaps the backward). */
+int pq3d_test_occupy_cus(int32_t workgroups, int32_t lds_bytes, int64_t microseconds, void* stream);
 
 /* The row-local steps between a layer's cross-attention and its self-attention in ONE launch (csrc/chain_ca.hip; bf16 mode, no
  * residual dropout): op_m = o_m Wo_m^T + bo_m (m < M <= 3, o_m bf16), x1 = sum_m c_m LN_m(x + op_m) (c_m = coef[m][row /

@@ -244,6 +244,8 @@ _SIGS = {
                                 C.c_void_p],
     "pq3d_add_cast": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_int32,
                       C.c_int64, C.c_void_p],
+    "pq3d_chain_device_ok": [C.c_int32, C.c_void_p],
+    "pq3d_test_occupy_cus": [C.c_int32, C.c_int32, C.c_int64, C.c_void_p],
     "pq3d_split_planes": [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                           C.POINTER(C.c_int64), C.c_int32, C.c_void_p],
     "pq3d_bias_add_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],

@@ -1,0 +1,81 @@
+// Device gate of the one-launch row-local chains (chain_ffn.hip, chain_ca.hip, chain_ffn_bwd.hip, chain_sa_bwd.hip, chain_mh.hip).
+// Their hand-offs are correct only on the device they were built and measured for:
+//   * workgroup id % 8 must be the XCD of the workgroup (rows cross between the 8 members of a group through ONE XCD's L2: stores,
+//     vmcnt(0), a flag, L1-bypassing sc1 loads -- across XCDs those loads could return stale lines);
+//   * all members of every group must be resident together (<= 32 groups x 8 members, one 110 KB-LDS workgroup per CU): 256 CUs in
+//     8 XCDs of 32, i.e. an MI355X in SPX mode with no CU mask.
+// pq3d_chain_device_ok() checks the device properties and, with probe != 0, MEASURES the placement rule: 256 one-wave workgroups
+// record their hardware XCC_ID, every one must equal its id % 8.  Anything else (a CPX / DPX partition, a CU-masked queue, another
+// gfx9 part) makes the host side fall back to the separate launches (fused._chain_on).
+#include <atomic>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+
+__global__ void chain_probe_kernel(unsigned* seen) {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  if (threadIdx.x == 0) seen[blockIdx.x] = v & 0xfu;
+}
+
+// Test support: `workgroups` workgroups that each hold a CU's LDS share for `microseconds` (a stand-in for a collective of another
+// stream that keeps CUs busy next to a chain launch: tests/test_gpu_chain.py)
+__global__ void occupy_kernel(long long ticks, unsigned* sink) {
+  extern __shared__ unsigned occ_lds[];
+  const long long t0 = wall_clock64();
+  unsigned acc = 0;
+  while (wall_clock64() - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(64);
+    acc += occ_lds[threadIdx.x & 63];
+  }
+  if (acc == 0x12345678u && sink) sink[0] = acc;   // keeps the LDS reads alive
+}
+
+}  // namespace
+
+extern "C" int pq3d_test_occupy_cus(int32_t workgroups, int32_t lds_bytes, int64_t microseconds, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
+  PQ_CHECK_ARG(workgroups >= 1 && workgroups <= 256 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && microseconds >= 0 &&
+               microseconds <= 200000, "pq3d_test_occupy_cus: 1..256 workgroups, <= 160 KB of LDS, <= 0.2 s");
+  static std::atomic<unsigned> done{0};
+  if (int e = pq3d_enable_big_lds(occupy_kernel, 160 * 1024, done)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
+  hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, (long long)microseconds * 100,
+                     (unsigned*)nullptr);   // wall_clock64: 100 MHz
+  PQ_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pq3d_chain_device_ok(int32_t probe, void* stream) {
+  PQ_DEVICE_GUARD(stream, nullptr);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  if (strncmp(p.gcnArchName, "gfx950", 6) != 0 || p.multiProcessorCount != 256) return 0;
+  int lds = 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds < 160 * 1024) {
+    // (the opt-in limit is what the kernels use: pq3d_enable_big_lds; older runtimes report the 64 KB default here)
+    if ((size_t)p.maxSharedMemoryPerMultiProcessor < 160u * 1024u) return 0;
+  }
+  if (!probe) return 1;
+  static std::mutex mu;
+  static int verdict[64];   // 0 unknown, 1 ok, 2 not ok
+  std::lock_guard<std::mutex> lk(mu);
+  int& vd = verdict[dev & 63];
+  if (vd) return vd == 1;
+  unsigned* seen = nullptr;
+  if (hipMalloc(&seen, 256 * sizeof(unsigned)) != hipSuccess) return 0;
+  bool ok = hipMemset(seen, 0xff, 256 * sizeof(unsigned)) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(chain_probe_kernel, dim3(256), dim3(64), 0, nullptr, seen);
+    unsigned host[256];
+    ok = hipMemcpy(host, seen, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess;
+    for (int i = 0; ok && i < 256; ++i) ok = host[i] == (unsigned)(i & 7);
+  }
+  (void)hipFree(seen);
+  vd = ok ? 1 : 2;
+  return ok ? 1 : 0;
+}

@@ -109,6 +109,11 @@ def set_chain(on: bool) -> None:
     _CHAIN = bool(on)
 
 
+def _chain_on(dev) -> bool:
+    """Chains requested AND valid on this device (ops.chain_device_ok: MI355X in SPX mode, workgroup id % 8 == XCD measured)."""
+    return _CHAIN and ops.chain_device_ok(dev)
+
+
 class _DwQueue:
     """Deferred weight-gradient GEMMs.  Every dW = g^T (x [+ x2]) of the backward pass only feeds the gradient arena,
     so they are queued and flushed at the end as a few grouped launches per (shape, dtype) bucket instead of one
@@ -181,7 +186,7 @@ def _mh_forward(spec, x, keys, inv_den, seg_pad, rec, call):
     Mm = len(keys)
     mps = list(mh.mask_pred_list)[:Mm]
     Ns = keys[0].shape[1]
-    if _CHAIN and ct == L.BF16X3 and not spec.mh_drop and x.dtype == torch.float32 and x.is_contiguous() and \
+    if _chain_on(x.device) and ct == L.BF16X3 and not spec.mh_drop and x.dtype == torch.float32 and x.is_contiguous() and \
             ops.chain_mh_ok(d, c0.out_features, c4.out_features, Mm, R) and c4.bias is not None:
         # the row-local part (class MLP + the mask predictions' query projections) in one launch (csrc/chain_mh.hip)
         flags = getattr(mh, "_chain_flags", None)
@@ -519,7 +524,7 @@ class _DecoderBackward:
         c0, c4 = mh.cls_head[0], mh.cls_head[4]
         if isinstance(cur, _PendingDx):
             cur = cur.dxr
-        return (dc is not None and dm is not None and _CHAIN and self.ct == BF16 and self.ad == torch.bfloat16 and
+        return (dc is not None and dm is not None and _chain_on(self.dev) and self.ct == BF16 and self.ad == torch.bfloat16 and
                 rec.get("mh_drop") is None and ops.chain_mh_ok(self.d, c0.out_features, c4.out_features, self.spec.mh_count, self.R)
                 and rec["mh_h1"].dtype == torch.float32 and isinstance(cur, torch.Tensor) and cur.dtype == torch.float32
                 and cur.is_contiguous())
@@ -675,13 +680,13 @@ class _DecoderBackward:
 
     def sa_chain_ok(self, rec) -> bool:
         """q / k / v input gradients + merged LayerNorm backward + cross-attention d O as one launch (csrc/chain_sa_bwd.hip)."""
-        return (_CHAIN and self.ct == BF16 and self.ad == torch.bfloat16 and not self.spec.prompt and rec["dr_cr"] is None
+        return (_chain_on(self.dev) and self.ct == BF16 and self.ad == torch.bfloat16 and not self.spec.prompt and rec["dr_cr"] is None
                 and ops.chain_ca_ok(self.R, self.d, self.M) and rec["op_all"].dtype == torch.float32)
 
     def ffn_chain_ok(self, rec, layer, dx) -> bool:
         """The FFN backward + the self-attention post-norm backward can run as ONE launch (csrc/chain_ffn_bwd.hip)."""
         ffn = layer.ffn
-        return (_CHAIN and self.ct == BF16 and self.ad == torch.bfloat16 and self.spec.act == "relu" and isinstance(dx, (torch.Tensor, _PendingDx))
+        return (_chain_on(self.dev) and self.ct == BF16 and self.ad == torch.bfloat16 and self.spec.act == "relu" and isinstance(dx, (torch.Tensor, _PendingDx))
                 and rec["dr_fr"] is None and rec["dr_fi"] is None and rec["dr_sr"] is None and rec["h"].dtype == torch.float32
                 and ops.chain_ffn_ok(self.R, self.d, ffn.linear1.out_features))
 
@@ -1295,7 +1300,7 @@ class _FusedDecoder(Function):
                     Wo, bo = sa.self_attn.out_proj.weight.detach(), sa.self_attn.out_proj.bias.detach()
                 # out-projections + merged post-norm + the self-attention's q / k / v projections: ONE launch when the shapes allow
                 # (csrc/chain_ca.hip: same bits as the three launches below)
-                chain_ca = _CHAIN and ct == BF16 and cq == L.BF16X3 and not spec.prompt and dr_cr is None and \
+                chain_ca = _chain_on(dev) and ct == BF16 and cq == L.BF16X3 and not spec.prompt and dr_cr is None and \
                     ops.chain_ca_ok(R, d, M) and o_all.dtype == torch.bfloat16
                 qkv = None
                 if chain_ca:
@@ -1349,7 +1354,7 @@ class _FusedDecoder(Function):
                 _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ops.sa_ct(ct), False, kpm=qmask, bias=sbias, drop=dr_sa)
                 ffn = layer.ffn
                 F_ = ffn.linear1.out_features
-                chain = _CHAIN and cq == L.BF16X3 and spec.act == "relu" and dr_sr is None and dr_fi is None and dr_fr is None and \
+                chain = _chain_on(dev) and cq == L.BF16X3 and spec.act == "relu" and dr_sr is None and dr_fi is None and dr_fr is None and \
                     ops.chain_ffn_ok(R, d, F_) and sa.norm.weight.shape[0] == d
                 if chain:
                     # the row-local tail of the layer in ONE launch (csrc/chain_ffn.hip: out-projection, post-norm, FFN, post-norm;

@@ -131,9 +131,12 @@ class GraphedQuery3D(nn.Module):
     modes, as after an eager backward (torch.optim.AdamW skips them)."""
 
     def __init__(self, model: nn.Module, sample: Dict[str, object], num_warmup_iters: int = 3, mode: str = "direct",
-                 accumulation: bool = False):
+                 accumulation: bool = False, chain_check_every: int = 64):
         super().__init__()
         assert mode in ("direct", "autograd")
+        # every `chain_check_every` replays the host reads the one-launch chains' error word (ops.chain_check: one stream
+        # synchronisation; a hand-off that timed out raises instead of training on stale rows); 0 = never (call .check() yourself)
+        self.chain_check_every, self._since_check = int(chain_check_every), 0
         assert num_warmup_iters >= 1, "GraphedQuery3D needs at least one eager warm-up iteration before capture"
         self.model, self.mode = model, mode
         specs, sample_tensors, const = [], [], {}
@@ -331,7 +334,16 @@ class GraphedQuery3D(nn.Module):
         for p, v in zip(self._params, self._grad_views):
             p.grad = v
 
+    def check(self) -> None:
+        """Raise ops.ChainHandoffError if a chain launch of the replays since the last check gave up in a hand-off (synchronises)."""
+        from . import ops
+        self._since_check = 0
+        ops.chain_check(self.static_in[0].device if self.static_in else None)
+
     def forward(self, data_dict: Dict[str, object]) -> Dict[str, object]:
+        self._since_check += 1
+        if self.chain_check_every and self._since_check >= self.chain_check_every:
+            self.check()
         args = []
         for (k, i), (shape, dtype) in zip(self.specs, self._shapes):
             t = data_dict[k] if i is None else data_dict[k][i]

@@ -1936,5 +1936,52 @@ def chain_sa_bwd(dqkv, Wl, aux2, x, op_all, gammas, mean, rstd, coef, rows_per_s
 
 def chain_error(device) -> bool:
     """True if a hand-off wait of any chain launch on `device` gave up (synchronises)."""
-    err = _CHAIN_ERR.get(device)
+    err = _CHAIN_ERR.get(torch.device(device) if not isinstance(device, torch.device) else device)
+    if err is None:   # keyed by the tensors' own device objects ('cuda:0'): accept an index-less spelling too
+        err = next((e for d_, e in _CHAIN_ERR.items() if torch.device(device).type == d_.type and
+                    (torch.device(device).index in (None, d_.index))), None)
     return bool(err is not None and int(err.item()) != 0)
+
+
+class ChainHandoffError(L.Pq3dError):
+    """A one-launch chain's in-kernel hand-off gave up (csrc/chain_common.h SPIN_LIMIT): its outputs are NOT valid."""
+
+
+def chain_check(device=None) -> None:
+    """Poll the chains' error word(s) where the host synchronises anyway (end of a training step, after a timed region, a loss
+    .item()): a hand-off that ran past its bound means a member workgroup never became resident next to its group (CUs held by
+    another stream's kernel, a CU-masked queue) and the launch went on with stale rows.  Raises ChainHandoffError, clears the word
+    and turns the chains OFF for the rest of the process (the separate launches compute the same bits) -- never a silent result."""
+    bad = []
+    for dev, err in _CHAIN_ERR.items():
+        if device is not None and torch.device(device).index not in (None, dev.index):
+            continue
+        if int(err.item()) != 0:
+            err.zero_()
+            bad.append(str(dev))
+    if bad:
+        from . import fused
+        fused.set_chain(False)
+        raise ChainHandoffError(f"a row-local chain launch on {', '.join(bad)} timed out in a hand-off: its results (and every "
+                                "result since the last check) are invalid; chains are now disabled in this process "
+                                "(fused.set_chain(False)) -- rerun the step")
+
+
+_CHAIN_DEV_OK = {}
+
+
+def chain_device_ok(device) -> bool:
+    """Device gate of the chains (pq3d_chain_device_ok): gfx950, 256 CUs, 160 KB LDS and the measured 'workgroup id % 8 == XCD'
+    placement.  The measuring launch is skipped while the stream is capturing (property checks only; the probe's verdict is
+    cached from the first eager call -- every capture in this package is preceded by eager warm-up steps)."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    v = _CHAIN_DEV_OK.get(key)
+    if v is not None:
+        return v
+    capturing = torch.cuda.is_current_stream_capturing()
+    with torch.cuda.device(key):
+        ok = bool(L.lib().pq3d_chain_device_ok(0 if capturing else 1, L.stream()))
+    if not capturing or not ok:
+        _CHAIN_DEV_OK[key] = ok
+    return ok

@@ -31,7 +31,11 @@ class TrainStep:
                  opt_groups: Optional[Sequence[dict]] = None, lr: float = 1e-4, betas=(0.9, 0.98), eps: float = 1e-8,
                  grad_norm: Optional[float] = None, sched: str = "warmup_cosine", warmup_steps: int = 0,
                  total_steps: int = 1, sched_gamma: float = 1.0, num_gpu: int = 1, group=None,
-                 unused_parameters=None):
+                 unused_parameters=None, chain_check_every: int = 64):
+        # every `chain_check_every` eager steps the host reads the one-launch chains' error word (ops.chain_check: one stream
+        # synchronisation per N steps; a timed-out hand-off raises instead of stepping on stale rows).  A step replayed from a
+        # HIP graph runs no host code: call .check() next to wherever the loss is read.  0 = never.
+        self.chain_check_every, self._since_check = int(chain_check_every), 0
         groups = list(opt_groups) if opt_groups is not None else model.get_opt_params()
         self.model, self.loss_fn, self.group = model, loss_fn, group
         self.hp = L.AdamWHp()
@@ -190,7 +194,15 @@ class TrainStep:
             loss = self.forward_backward(data_dict)
         self.all_reduce()
         self.optimizer_step()
+        self._since_check += 1
+        if self.chain_check_every and self._since_check >= self.chain_check_every and not torch.cuda.is_current_stream_capturing():
+            self.check()
         return loss
+
+    def check(self) -> None:
+        """Raise ops.ChainHandoffError if a chain launch since the last check gave up in a hand-off (synchronises the stream)."""
+        self._since_check = 0
+        ops.chain_check(self.flat_p.device)
 
     # -- introspection ---------------------------------------------------------------------------------------------
     @property

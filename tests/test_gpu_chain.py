@@ -432,3 +432,106 @@ def test_model_step_is_the_same_with_and_without_chains(case):
         err = float((res[True][1][n] - g0).norm() / max(float(g0.norm()), 1e-3 * gmax))
         tight = n.startswith(last + "ffn.") or n.startswith(last + "self_attn.norm")
         assert err < (2e-5 if tight else 1e-2), (n, err)
+
+
+# ---------------------------------------------------------------------------------------------------- device gate, neighbours, polling
+def test_chain_device_gate_measures_the_placement_rule():
+    """chains are valid only where workgroup id % 8 is the XCD and all members are co-resident.  The gate checks
+    gfx950 / 256 CUs / 160 KB LDS and MEASURES XCC_ID == id % 8 over 256 workgroups (pq3d_chain_device_ok); on this box it must say
+    yes, and fused._chain_on follows it (and fused.set_chain)."""
+    from pq3d_amd import _lib as L, fused, ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    assert L.lib().pq3d_chain_device_ok(1, L.stream()) == 1
+    assert ops.chain_device_ok(dev) and fused._chain_on(dev)
+    try:
+        fused.set_chain(False)
+        assert not fused._chain_on(dev)
+        ops._CHAIN_DEV_OK[dev.index] = False      # a device the gate refused: the chains stay off whatever the switch says
+        fused.set_chain(True)
+        assert not fused._chain_on(dev)
+    finally:
+        ops._CHAIN_DEV_OK.pop(dev.index, None)
+        fused.set_chain(True)
+    assert fused._chain_on(dev)
+
+
+@pytest.mark.parametrize("B", [8, 16], ids=["R800", "R1600"])
+@pytest.mark.parametrize("held,lds_kb,us", [(32, 100, 20000), (96, 100, 3000), (64, 8, 20000)],
+                         ids=["32CUs-held", "96CUs-held-briefly", "64-small-neighbours"])
+@pytest.mark.parametrize("case", ["plain", "mask_head"])
+def test_chain_launches_beside_a_cu_holding_kernel(case, B, held, lds_kb, us):
+    """the data-parallel step reduces gradient buckets UNDER the decoder backward, i.e. an RCCL kernel (one
+    workgroup per channel) holds CUs beside chain_ffn_bwd / chain_sa_bwd.  Stand-in: `held` workgroups that each pin `lds_kb` of a
+    CU's LDS for `us` microseconds on a second stream (pq3d_test_occupy_cus; 100 KB = no chain workgroup fits beside one) while a
+    whole model step (every chain kernel: ffn / ca forward, ffn / sa backward; mask head pair) runs on the main stream at R = 800
+    and R = 1600 query rows.  32 held CUs is the head-room chain_nrt() leaves; 96 makes members WAIT for a CU (bounded polls).
+    Required: forward outputs bit for bit the undisturbed run's, gradients at the chained backward's run-to-run level, error word
+    clear."""
+    from tests import util
+    from pq3d_amd import _lib as L, fused, ops
+    from pq3d_amd.modules import set_compute
+    dev = torch.device("cuda")
+    if case == "mask_head":
+        args = dict(B=B // 2, Ns=512, Nq=200, d=256, H=8, L=2, memories=["voxel", "mv", "pc"], heads=["mask"], spatial=True,
+                    structure="parallel", use_self_mask=True, C=201, foc=(0, 2), seed=0, data_seed=1234)
+    else:
+        args = dict(B=B, Ns=256, Nq=100, d=256, H=8, L=2, memories=["voxel", "mv", "pc"], heads=[], spatial=True,
+                    structure="parallel", seed=0, data_seed=1234)
+    _cfg, model, _sd, dd = util.model_case(args)
+    set_compute(model, "bf16")
+    model.unified_encoder.fused = True
+    model.to(dev)
+    ddv = {k: v.to(dev) for k, v in dd.items()}
+    assert fused._chain_on(dev)
+
+    def step():
+        model.zero_grad()
+        out = model(dict(ddv))
+        util.synthetic_loss(out, args["heads"], out["query_embeds"]).backward()
+        outs = [out["query_embeds"]] + list(out.get("predictions_mask", [])) + list(out.get("predictions_class", []))
+        return [t.detach().clone() for t in outs], {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    step()                                   # warm-up (allocations, LDS opt-ins)
+    torch.cuda.synchronize()
+    ref_o, ref_g = step()
+    torch.cuda.synchronize()
+    assert not ops.chain_error(dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):            # the neighbour starts first and outlives the step's launches
+        L.check(L.lib().pq3d_test_occupy_cus(held, lds_kb * 1024, us, L.stream()), "pq3d_test_occupy_cus")
+        ev = torch.cuda.Event()
+        ev.record()
+    got_o, got_g = step()
+    torch.cuda.current_stream().synchronize()
+    if us >= 20000:
+        assert not ev.query(), "the neighbour ended before the step did: the launches did not run beside it"
+    torch.cuda.synchronize()
+    ops.chain_check(dev)                     # raises ChainHandoffError if any hand-off gave up
+    for a, b in zip(got_o, ref_o):
+        assert torch.equal(a, b)
+    gmax = max(float(v.norm()) for v in ref_g.values())
+    for n, g0 in ref_g.items():
+        assert float((got_g[n] - g0).norm()) <= 1e-2 * max(float(g0.norm()), 1e-3 * gmax), n
+
+
+def test_chain_check_raises_and_disables_on_a_set_error_word():
+    """The polling side of ADVICE r5: a set error word must surface as an exception and switch the chains off (bench.py: exit
+    code 3; TrainStep / GraphedQuery3D: every `chain_check_every` steps and on .check())."""
+    from pq3d_amd import fused, ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x = torch.randn(1, 32, 256, device=dev)
+    flags = ops.chain_flags(32, dev)
+    w = lambda *s: torch.randn(*s, device=dev) * 0.05
+    ops.chain_ffn_fwd(x, w(256, 256), w(256), x, w(256), w(256), 1e-5, w(2048, 256), w(2048), w(256, 2048), w(256), w(256), w(256), 1e-5, flags)
+    torch.cuda.synchronize()
+    ops.chain_check(dev)                     # clean
+    err = next(iter(ops._CHAIN_ERR.values()))
+    try:
+        err.fill_(1)
+        assert ops.chain_error(dev)
+        with pytest.raises(ops.ChainHandoffError):
+            ops.chain_check(dev)
+        assert not fused._CHAIN and not ops.chain_error(dev)   # switched off, word cleared
+    finally:
+        err.zero_()
+        fused.set_chain(True)
