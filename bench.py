@@ -179,134 +179,228 @@ def cpu_baseline(c, sd, dd, steps, warmup, hf_body=None):
                       f"fp32, torch CPU ops, dropout 0, best of the thread counts tried"}
 
 
+DEFAULT_COMPUTE = "bf16"
 FAMILY_KERNELS = {   # GPU kernels behind a C-ABI entry point (rocprofv3 / PMC kernel names, template arguments stripped)
     "pq3d_gemm": ["gemm_wk_kernel", "gemm_fast_kernel", "gemm_slow_kernel", "gemm_nt128_kernel", "gemm_tt128_kernel", "gemm_wktt_kernel",
                   "gemm_cv128_kernel"],
-    "pq3d_attn_fwd": ["attn_fwd_resident_kernel", "attn_sa_fwd_kernel", "attn_small_fwd_kernel", "attn_fwd_kernel", "attn_fwd_combine_kernel"],
+    "pq3d_gemm_tt_multi": ["gemm_tt_multi_kernel"],
+    "pq3d_attn_fwd": ["attn_fwd_resident_kernel", "attn_fwd_x3_kernel", "attn_sa_fwd_kernel", "attn_small_fwd_kernel", "attn_fwd_kernel",
+                      "attn_fwd_combine_kernel"],
     "pq3d_attn_bwd": ["attn_bwd_resident_kernel", "attn_sa_bwd_kernel", "attn_small_bwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
                       "attn_dq_combine_kernel"],
     "pq3d_add_ln_fwd": ["add_ln_fwd_kernel"], "pq3d_add_ln_bwd": ["add_ln_bwd_kernel"],
+    "pq3d_chain_ffn_fwd": ["chain_ffn_fwd_kernel"], "pq3d_chain_ca_fwd": ["chain_ca_fwd_kernel"],
+    "pq3d_chain_ffn_bwd": ["chain_ffn_bwd_kernel"], "pq3d_chain_sa_bwd": ["chain_sa_bwd_kernel"],
+    "pq3d_chain_mh_fwd": ["chain_mh_fwd_kernel"], "pq3d_chain_mh_bwd": ["chain_mh_bwd_kernel"],
 }
-CALIBRATION_BYTES = 100 << 20   # the PMC calibration launch: copy_many_kernel streams this many bytes in and out (16 B / lane)
 
 
-def committed_profiles(config):
-    """The newest committed evidence of this config under profiles/: (PMC traffic json or None, {kernel: (launches per
-    step, avg us in the replayed graph)} from the rocprofv3 --kernel-trace --stats summary or {}, tag)."""
+def kernel_for(entry, key):
+    """The GPU kernel a timed C-ABI call (entry point, shape key of pq3d_amd/ops.py's timers) launches -- the rules of the
+    dispatchers in csrc/ (gemm.hip pq3d_gemm, attention.hip launch_fwd / launch_bwd) restated for the shapes of the BASELINE
+    configurations.  Used to attach the ALGORITHMIC bytes / FLOPs of the eager profiled pass to the kernels of the in-graph trace;
+    every use is verified against the trace's launch counts (`mapping_verified`), so a wrong rule cannot silently price a kernel."""
+    import re
+    fam = FAMILY_KERNELS.get(entry, [])
+    if len(fam) == 1:
+        return fam[0]
+    g = lambda pat, d=0: (lambda m: int(m.group(1)) if m else d)(re.search(pat, key))
+    if entry in ("pq3d_attn_fwd", "pq3d_attn_bwd"):
+        fwd = entry.endswith("fwd")
+        Lq, Lk, dh, ct = g(r"Lq(\d+)"), g(r"Lk(\d+)"), g(r"dh(\d+)"), g(r"ct(\d+)")
+        if ct == 2:   # split-bf16: self-attention kernels (<= 240 tokens) / the key/value-plane forward
+            if Lq <= 240 and Lk <= 240:
+                return "attn_sa_fwd_kernel" if fwd else "attn_sa_bwd_kernel"
+            return "attn_fwd_x3_kernel" if fwd else None
+        if ct == 1:
+            if fwd:
+                return "attn_fwd_resident_kernel" if (Lq <= 128 <= Lk and dh == 32 and "m3" not in key) else "attn_fwd_kernel"
+            return "attn_bwd_resident_kernel" if (Lq <= 256 and Lk >= 128 and dh in (32, 64)) else "attn_bwd_dkv_kernel"
+        return "attn_small_fwd_kernel" if fwd else "attn_small_bwd_kernel"
+    if entry == "pq3d_gemm":
+        M, N, K, ct, sk = g(r"M(\d+)"), g(r"N(\d+)"), g(r"K(\d+)g"), g(r"ct(\d+)"), g(r"s(\d+)ct", 1)
+        tt = "TT" in key
+        if tt:
+            return "gemm_tt128_kernel" if (ct == 1 and K >= 2048 and M % 128 == 0 and N % 128 == 0) else "gemm_wktt_kernel"
+        if M <= 2048:
+            return "gemm_wk_kernel"
+        if ct == 1 and N % 128 == 0 and K % 64 == 0 and sk == 1:
+            return "gemm_nt128_kernel"
+        return "gemm_fast_kernel"
+    return None
+
+
+def step_bytes(c):
+    """SURVEY 8(d) 'Algorithmic bytes (compulsory HBM traffic, forward, ideal fusion, e_b = 2)': per layer weights (4 M d^2 + 4 d^2 + 2 d F)
+    e_b + memories M 2 B N_s d e_b + query state (M + 2) 2 B N_q d e_b; per mask-head call (2 M d^2 + d^2 + d C) e_b + M B N_s d e_b
+    + 4 B N_s N_q + 4 B N_q C.  STEP = 3 x forward (backward = 2 x forward, the convention of the FLOP count)."""
+    B, Ns, Nq, d, L_, F_ = c["B"], c["Ns"], c["Nq"], c["d"], c["L"], 2048
+    M = len([m for m in c["memories"] if m != "prompt"])
+    eb = 2
+    layer = (4 * M * d * d + 4 * d * d + 2 * d * F_) * eb + M * 2 * B * Ns * d * eb + (M + 2) * 2 * B * Nq * d * eb
+    fwd = L_ * c.get("num_blocks", 1) * layer
+    if "mask" in c["heads"]:
+        C_ = c.get("C", 201)
+        fwd += (L_ * c.get("num_blocks", 1) + 1) * ((2 * M * d * d + d * d + d * C_) * eb + M * B * Ns * d * eb + 4 * B * Ns * Nq + 4 * B * Nq * C_)
+    return 3.0 * fwd
+
+
+def live_kernel_trace(args, timeout=300):
+    """In-graph kernel durations of THIS build on THIS box, measured inside this run: a child `rocprofv3 --kernel-trace -- python
+    bench.py --headline-only` of the same config / compute mode (20 replayed steps), its rocpd database read here.  Returns
+    {kernel name (template arguments stripped): (launches per step, us per step)}, meta -- or ({}, reason) when rocprofv3 is not
+    there / the child failed (the roofline then falls back to this run's own HIP-event times and says so)."""
     import glob
     import re
-    pdir = os.path.join(ROOT, "profiles")
-    tags = sorted({m.group(1) for f in glob.glob(os.path.join(pdir, f"*_{config}*")) for m in [re.search(r"_(r\d\d)_", f)] if m})
-    pmc, stats, tag_used = None, {}, None
-    for tag in reversed(tags):
-        mj = os.path.join(pdir, f"pmc_mfma_{tag}_{config}.json")
-        if "_mfma" not in stats and os.path.exists(mj):
-            try:
-                stats["_mfma"] = json.load(open(mj)); stats["_mfma"]["_file"] = f"profiles/{os.path.basename(mj)}"
-            except ValueError:
-                pass
-        pj = os.path.join(pdir, f"pmc_traffic_{tag}_{config}.json")
-        st = os.path.join(pdir, f"rocprofv3_kernel_stats_{tag}_fused_graph_{config}.txt")
-        if pmc is None and os.path.exists(pj):
-            try:
-                pmc = json.load(open(pj)); pmc["_file"] = f"profiles/{os.path.basename(pj)}"
-            except ValueError:
-                pmc = None
-        if "_file" not in stats and os.path.exists(st):
-            lines = open(st).read().splitlines()
-            # steps of the trace = calls of a once-per-step kernel (tools/rocprof_summary.py writes it into the header);
-            # older files: the most common call count of the table
-            m = re.search(r"steps (\d+)", lines[0]) if lines else None
-            steps = float(m.group(1)) if m else None
-            if steps is None:
-                import collections
-                cc = collections.Counter(int(mm.group(2)) for ln in lines[2:]
-                                         for mm in [re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s", ln)] if mm and int(mm.group(2)) >= 3)
-                steps = float(cc.most_common(1)[0][0]) if cc else None
-            for ln in lines[2:]:
-                mm = re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
-                if mm and steps:
-                    name = re.sub(r"[<(].*$", "", mm.group(1).replace("(anonymous namespace)::", "").replace("void ", ""))
-                    c, tot = stats.get(name, (0.0, 0.0))
-                    stats[name] = (c + int(mm.group(2)) / steps, tot + float(mm.group(3)) * 1e3 / steps)   # launches, us per step
-            stats["_file"], stats["_steps"] = f"profiles/{os.path.basename(st)}", steps
-            tag_used = tag
-    return pmc, stats, tag_used
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if os.environ.get("PQ3D_BENCH_CHILD") or args.no_live_trace:
+        return {}, "disabled"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="pq3d_trace_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "-d", tmp, "-o", "t", "--", sys.executable, os.path.abspath(__file__), "--config", args.config,
+           "--compute", args.compute, "--dropout", args.dropout, "--steps", "20", "--warmup", "5", "--cpu-steps", "0", "--profile-steps", "1",
+           "--headline-only", "--min-time", "0", "--no-live-trace"] + (["--no-graph"] if args.no_graph else [])
+    try:
+        t0 = time.perf_counter()
+        subprocess.run(cmd, env=dict(os.environ, PQ3D_BENCH_CHILD="1", TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, timeout=timeout, check=False)
+        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+        if not dbs:
+            return {}, "rocprofv3 child left no database"
+        cur = sqlite3.connect(dbs[0]).cursor()
+        rows = cur.execute("select name, count(*), sum(end-start) from kernels group by name").fetchall()
+        short = lambda n: re.sub(r"[<(].*$", "", n.replace("(anonymous namespace)::", "").replace("void ", ""))
+        import collections
+        marks = [r[1] for r in rows if any(m in r[0] for m in ("fourier_pair_kernel", "pairwise_locs_kernel", "mask_not_kernel"))]
+        cnt = collections.Counter(marks or [r[1] for r in rows if r[1] >= 3])
+        steps = float(cnt.most_common(1)[0][0]) if cnt else 0.0
+        if steps <= 0:
+            return {}, "no once-per-step kernel in the trace"
+        out = {}
+        for n, calls, tot in rows:
+            k = short(n)
+            a = out.get(k, (0.0, 0.0))
+            out[k] = (a[0] + calls / steps, a[1] + tot / 1e3 / steps)
+        return out, {"source": "live: rocprofv3 --kernel-trace child of this run (same build, same box; 20 replayed + 9 warm-up / eager steps)",
+                     "steps": steps, "kernel_us_per_step": sum(v[1] for v in out.values()), "dispatches_per_step": sum(v[0] for v in out.values()),
+                     "child_wall_s": round(time.perf_counter() - t0, 1)}
+    except Exception as e:  # noqa: BLE001
+        return {}, f"{type(e).__name__}: {e}"[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
-def family_block(entry, v, peak_tflops, steps, pmc, stats):
-    """Roofline entry of one C-ABI entry point (= kernel family).  BOTH roofs are reported:
-      frac_mfma = algorithmic FLOPs of the family's launches / their time / the dense MFMA peak of the compute dtype,
-      frac_hbm  = ALGORITHMIC bytes of the family's launches (each launch's compulsory operand + result bytes, as the
-                  timers in pq3d_amd/ops.py count them) / the same time / 8 TB/s,
-      traffic   = measured memory-side bytes per launch (PMC FETCH_SIZE / WRITE_SIZE, corrected by the calibration launch of
-                  the same pass; includes Infinity-Cache hits) with traffic_over_algorithmic = the over-fetch ratio,
-    `bound` = the larger one and `frac` / `achieved` / `peak` / `unit` are that roof's.  Time = the family's kernels in the
-    REPLAYED graph (committed rocprofv3 --kernel-trace --stats summary of the same build, per step = totals / calls of a
-    once-per-step kernel) when profiles/ holds one, else the HIP-event time of this run's eager profiled pass; `timing`
-    says which.  `mfma_busy`: SQ_VALU_MFMA_BUSY_CYCLES of the family per step / (in-graph time x 2.4 GHz x 1024 SIMDs)."""
-    calls, ms = v["calls"], v["ms"]
-    names = FAMILY_KERNELS.get(entry, [])
-    blk = {"kernel": entry, "gpu_kernels": names, "launches_per_step": calls / steps, "avg_launch_us": ms / calls * 1e3,
-           "ms_per_step_eager_events": ms / steps, "algorithmic_gflop_per_step": v["flops"] / steps / 1e9,
-           "algorithmic_bytes_per_launch": v["bytes"] / calls, "traffic": None}
-    t_us, timing, l_graph = ms / steps * 1e3, "HIP events on the launch stream, eager profiled pass of this run", calls / steps
-    hit = [(n, stats[n]) for n in names if n in stats]
-    if hit:
-        l_graph = sum(c for _n, (c, _t) in hit)
-        t_us = sum(t for _n, (_c, t) in hit)
-        timing = f"in-graph kernel durations, {stats.get('_file')} ({stats.get('_steps'):.0f} steps)"
-        blk["in_graph"] = {"launches_per_step": round(l_graph, 2), "avg_launch_us": t_us / max(l_graph, 1e-9),
-                           "ms_per_step": t_us / 1e3, "source": stats.get("_file")}
-    blk["timing"] = timing
-    # HBM-side traffic per launch: PMC sums over the family's kernels / its launches, calibrated
-    traffic_step = None
-    if pmc is not None and "kernels" in pmc:
-        fetch = write = launches = 0.0      # launch-weighted sums over every (kernel, grid) row of the family
-        for n in names:
-            for r in pmc["kernels"].get(n, []):
-                fetch += r["fetch_kib"] * 1024 * r["launches"]
-                write += r["write_kib"] * 1024 * r["launches"]
-                launches += r["launches"]
-        if launches > 0:
-            cal = pmc.get("calibration") or {}
-            cf = 1.0 / cal["fetch_raw_over_true"] if cal.get("fetch_raw_over_true") else 2.0    # guide: x2 for wide reads
-            cw = 1.0 / cal["write_raw_over_true"] if cal.get("write_raw_over_true") else 1.0
-            per_launch = (fetch * cf + write * cw) / launches
-            traffic_step = per_launch * l_graph
-            blk.update({"traffic": per_launch, "traffic_raw_counters": (fetch + write) / launches,
-                        "traffic_correction": {"fetch_x": round(cf, 3), "write_x": round(cw, 3),
-                                               "from": "calibration launch in the same PMC pass" if cal else
-                                               "MI355X_MICROARCH.md HBM section (no calibration in this file)"},
-                        "traffic_source": pmc.get("_file")})
-    # BOTH fractions are on ALGORITHMIC work (VERDICT r4 item 1a): a fraction that rises when a kernel wastes bytes is not a
-    # roofline fraction.  The measured PMC traffic stays beside it as `traffic` (per launch) with its ratio to the
-    # algorithmic bytes -- the over-fetch figure, the first thing to fix when it is well above 1.
-    alg_bytes_step = v["bytes"] / steps
-    tf = v["flops"] / steps / (t_us * 1e-6) / 1e12
-    gbs = alg_bytes_step / (t_us * 1e-6) / 1e9
-    blk["frac_mfma"], blk["frac_hbm"] = tf / peak_tflops, gbs / PEAK_HBM_GBS
-    blk["hbm_bytes_basis"] = "algorithmic bytes (compulsory operand + result bytes of each launch)"
-    if traffic_step is not None:
-        blk["traffic_over_algorithmic"] = traffic_step / max(alg_bytes_step, 1.0)
-        blk["measured_traffic_gbs"] = traffic_step / (t_us * 1e-6) / 1e9
+def pmc_per_launch(pmc, name):
+    """Calibrated memory-side bytes per launch of one kernel from a PMC traffic file (FETCH_SIZE / WRITE_SIZE passes), or None."""
+    rows = (pmc or {}).get("kernels", {}).get(name, [])
+    launches = sum(r["launches"] for r in rows)
+    if not launches:
+        return None, None
+    cal = pmc.get("calibration") or {}
+    cf = 1.0 / cal["fetch_raw_over_true"] if cal.get("fetch_raw_over_true") else 2.0    # guide: x2 for wide reads
+    cw = 1.0 / cal["write_raw_over_true"] if cal.get("write_raw_over_true") else 1.0
+    fetch = sum(r["fetch_kib"] * 1024 * r["launches"] for r in rows)
+    write = sum(r["write_kib"] * 1024 * r["launches"] for r in rows)
+    return (fetch * cf + write * cw) / launches, {"fetch_x": round(cf, 3), "write_x": round(cw, 3),
+                                                  "from": "calibration launch in the same PMC pass" if cal else
+                                                  "MI355X_MICROARCH.md HBM section (no calibration in this file)"}
+
+
+def kernel_block(name, trace, summ, ps, peak_tflops, pmc, mfma):
+    """Roofline entry of ONE GPU kernel: time = its launches in the replayed graph (live trace of this run), work = the ALGORITHMIC
+    bytes / FLOPs of the C-ABI calls that launch it (eager profiled pass of this run, pq3d_amd/ops.py's counts), both fractions
+    reported, `bound` = the larger; `traffic` = calibrated PMC bytes per launch from the committed counter passes of the
+    same build (null when profiles/ holds none for this build)."""
+    l_graph, us_step = trace[name]
+    recs = [(n, k, v) for (n, k), v in summ.items() if kernel_for(n, k) == name]
+    calls = sum(v["calls"] for _n, _k, v in recs) / ps
+    fl = sum(v["flops"] for _n, _k, v in recs) / ps
+    by = sum(v["bytes"] for _n, _k, v in recs) / ps
+    ev_ms = sum(v["ms"] for _n, _k, v in recs) / ps
+    # a C-ABI call may launch helper kernels beside its main one (combine, zero): the main kernel's count is what must agree
+    verified = bool(recs) and abs(calls - l_graph) <= 0.26 * max(l_graph, 1.0)
+    t = us_step * 1e-6
+    tf, gbs = fl / t / 1e12, by / t / 1e9
+    blk = {"kernel": name, "launches_per_step": round(l_graph, 2), "avg_launch_us": us_step / max(l_graph, 1e-9), "ms_per_step": us_step / 1e3,
+           "timing": "in-graph kernel durations of this run (live rocprofv3 --kernel-trace child)",
+           "entry_points": sorted({f"{n} {k}" for n, k, _v in recs})[:8], "mapping_verified": verified,
+           "launches_per_step_eager_calls": round(calls, 2), "ms_per_step_eager_events": ev_ms,
+           "algorithmic_gflop_per_step": fl / 1e9, "algorithmic_bytes_per_launch": by / max(calls, 1e-9),
+           "frac_mfma": tf / peak_tflops, "frac_hbm": gbs / PEAK_HBM_GBS,
+           "hbm_bytes_basis": "algorithmic bytes (compulsory operand + result bytes of each launch)", "traffic": None}
     if blk["frac_mfma"] >= blk["frac_hbm"]:
         blk.update({"bound": "mfma", "achieved": tf, "peak": peak_tflops, "unit": "TFLOP/s", "frac": blk["frac_mfma"]})
     else:
         blk.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": blk["frac_hbm"]})
-    mf = stats.get("_mfma")
-    if mf is not None:
-        cyc = launches = 0.0
-        for n in names:
-            for r in mf["kernels"].get(n, []):
-                cyc += r["mfma_busy_cycles"] * r["launches"]
-                launches += r["launches"]
-        if launches > 0:
-            per_step = cyc / launches * l_graph
-            blk["mfma_busy"] = per_step / (t_us * 1e-6 * mf.get("clock_ghz", 2.4) * 1e9 * mf.get("simds", 1024))
-            blk["mfma_busy_cycles_per_step"] = per_step
-            blk["mfma_busy_source"] = mf.get("_file")
+    per_launch, corr = pmc_per_launch(pmc, name)
+    if per_launch is not None:
+        blk.update({"traffic": per_launch, "traffic_correction": corr, "traffic_source": pmc.get("_file"),
+                    "traffic_over_algorithmic": per_launch * l_graph / max(by, 1.0), "measured_traffic_gbs": per_launch * l_graph / t / 1e9})
+    if mfma is not None:
+        rows = mfma.get("kernels", {}).get(name, [])
+        n = sum(r["launches"] for r in rows)
+        if n:
+            cyc = sum(r["mfma_busy_cycles"] * r["launches"] for r in rows) / n * l_graph
+            blk["mfma_busy"] = cyc / (t * mfma.get("clock_ghz", 2.4) * 1e9 * mfma.get("simds", 1024))
+            blk["mfma_busy_source"] = mfma.get("_file")
     return blk
+
+
+CALIBRATION_BYTES = 100 << 20   # the PMC calibration launch: copy_many_kernel streams this many bytes in and out (16 B / lane)
+
+
+def committed_profiles(config, compute, ids):
+    """The committed evidence of this config / compute mode under profiles/ that belongs to THIS build: a file is used only when the
+    `src_sha256` stamped into it (tools/pmc_*_json.py: "_build"; tools/rocprof_summary.py: "# build:" header) equals the running
+    build's (pq3d_amd.build.build_ids) -- a stale file is refused and named in `refused`.  Returns (PMC traffic json or None, PMC
+    MFMA json or None, {kernel: (launches per step, us per step)} of the committed rocprofv3 kernel stats or {}, info dict)."""
+    import glob
+    import re
+    pdir = os.path.join(ROOT, "profiles")
+    sfx = "" if compute == DEFAULT_COMPUTE else f"_{compute}"
+    tags = sorted({m.group(1) for f in glob.glob(os.path.join(pdir, f"*_{config}{sfx}.*")) for m in [re.search(r"_(r\d\d)_", f)] if m})
+    pmc = mfma = None
+    stats, info = {}, {"build": ids, "refused": []}
+    src = ids.get("src_sha256")
+
+    def load(path):
+        try:
+            j = json.load(open(path))
+        except (OSError, ValueError):
+            return None
+        if (j.get("_build") or {}).get("src_sha256") != src:
+            info["refused"].append(f"profiles/{os.path.basename(path)} (build {(j.get('_build') or {}).get('src_sha256')} != {src})")
+            return None
+        j["_file"] = f"profiles/{os.path.basename(path)}"
+        return j
+    for tag in reversed(tags):
+        if pmc is None:
+            pmc = load(os.path.join(pdir, f"pmc_traffic_{tag}_{config}{sfx}.json"))
+        if mfma is None:
+            mfma = load(os.path.join(pdir, f"pmc_mfma_{tag}_{config}{sfx}.json"))
+        st = os.path.join(pdir, f"rocprofv3_kernel_stats_{tag}_fused_graph_{config}{sfx}.txt")
+        if not stats and os.path.exists(st):
+            lines = open(st).read().splitlines()
+            mb = re.search(r"src_sha256 (\w+)", lines[0]) if lines else None
+            if not mb or mb.group(1) != src:
+                info["refused"].append(f"profiles/{os.path.basename(st)} (build {mb.group(1) if mb else None} != {src})")
+                continue
+            hdr = next((ln for ln in lines[:3] if "steps" in ln), "")
+            m = re.search(r"steps (\d+)", hdr)
+            steps = float(m.group(1)) if m else None
+            for ln in lines:
+                mm = re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+                if mm and steps:
+                    name = re.sub(r"[<(].*$", "", mm.group(1).replace("(anonymous namespace)::", "").replace("void ", ""))
+                    c_, tot = stats.get(name, (0.0, 0.0))
+                    stats[name] = (c_ + int(mm.group(2)) / steps, tot + float(mm.group(3)) * 1e3 / steps)   # launches, us per step
+            info["kernel_stats_file"] = f"profiles/{os.path.basename(st)}"
+    return pmc, mfma, stats, info
 
 
 def main():
@@ -319,7 +413,9 @@ def main():
     ap.add_argument("--pool-nvox", type=int, default=250_000, help="--config pool: voxels per scene")
     ap.add_argument("--pool-pmc", action="store_true", help="--config pool: only the headline launches (counter passes)")
     ap.add_argument("--pool-segments", type=int, default=4096, help="--config pool: segments per scene (max_seg)")
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "bf16x3", "fp32"])
+    ap.add_argument("--compute", default=DEFAULT_COMPUTE, choices=["bf16", "bf16x3", "fp32"])
+    ap.add_argument("--no-live-trace", action="store_true",
+                    help="skip the child rocprofv3 --kernel-trace run that times the kernels of the replayed step for `roofline`")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--min-time", type=float, default=1.0,
                     help="when K timed steps take < 0.5 s, repeat the K-step region until this many seconds are timed in "
@@ -701,20 +797,64 @@ def main():
             f = fams.setdefault(n, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
             for kk in ("ms", "calls", "flops", "bytes"):
                 f[kk] += v[kk]
-        # the committed rocprofv3 / PMC evidence is of the bf16 build of this config: the fp32 compute type has no in-graph leg
-        pmc, stats, tag = committed_profiles(args.config) if args.compute == "bf16" else (None, {}, None)
-        order = sorted(fams, key=lambda n: -fams[n]["ms"])
-        blocks = [family_block(n, fams[n], peak, ps, pmc, stats) for n in order[:3]]
-        for b in blocks:
-            b["share_of_kernel_time"] = fams[b["kernel"]]["ms"] / tot if tot else 0.0
-            mem = sorted(((k, v) for (n, k), v in summ.items() if n == b["kernel"]), key=lambda kv: -kv[1]["ms"])[:6]
-            b["members"] = [{"shape": k, "launches_per_step": v["calls"] / ps, "avg_launch_us": v["ms"] / v["calls"] * 1e3,
-                             "tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "frac": v["flops"] / max(v["ms"], 1e-9) / 1e9 / peak}
-                            for k, v in mem]
-        # the dominant kernel family (largest share of the step's kernel time) is the roofline headline; the next two follow
-        roof = blocks[0] if blocks else {"bound": "mfma", "achieved": 0.0, "peak": peak, "unit": "TFLOP/s", "frac": 0.0, "traffic": None}
+        # ---- roofline of the run's real dominant KERNEL: time = in-graph kernel durations of THIS run (a child
+        # rocprofv3 --kernel-trace of the same build / box / config), work = the algorithmic bytes / FLOPs of the C-ABI calls that
+        # launch the kernel (this run's eager profiled pass), traffic = the committed PMC passes IF they are of this build
+        from pq3d_amd.build import build_ids
+        ids = build_ids()
+        pmc, mfma, cstats, pinfo = committed_profiles(args.config, args.compute, ids)
+        trace, tmeta = ({}, "not the single-GPU headline run") if (world > 1 or dist_on) else live_kernel_trace(args)
+        timing_src = "live"
+        if not trace and cstats:
+            trace, tmeta, timing_src = cstats, {"source": f"committed {pinfo.get('kernel_stats_file')} of this build (src_sha256 {ids['src_sha256']})"}, "committed"
+        blocks = []
+        if trace:
+            order = sorted(trace, key=lambda n: -trace[n][1])
+            blocks = [kernel_block(n, trace, summ, ps, peak, pmc, mfma) for n in order[:4] if not n.startswith("__amd_rocclr")][:3]
+            ktot = sum(v[1] for v in trace.values())
+            for b_ in blocks:
+                b_["share_of_kernel_time"] = trace[b_["kernel"]][1] / ktot if ktot else 0.0
+                if timing_src == "committed":
+                    b_["timing"] = "in-graph kernel durations, " + tmeta["source"]
+                if cstats and b_["kernel"] in cstats and timing_src == "live":   # the committed summary of the same build must agree
+                    b_["committed_profile_avg_launch_us"] = cstats[b_["kernel"]][1] / max(cstats[b_["kernel"]][0], 1e-9)
+        else:
+            # no trace (rocprofv3 absent / child failed): this run's own HIP-event times per C-ABI entry point, stated as such
+            order = sorted(fams, key=lambda n: -fams[n]["ms"])
+            for n in order[:3]:
+                v = fams[n]
+                t = v["ms"] / ps * 1e-3
+                tf, gbs = v["flops"] / ps / t / 1e12, v["bytes"] / ps / t / 1e9
+                blk = {"kernel": n, "gpu_kernels": FAMILY_KERNELS.get(n, []), "launches_per_step": v["calls"] / ps,
+                       "avg_launch_us": v["ms"] / v["calls"] * 1e3, "ms_per_step": v["ms"] / ps,
+                       "timing": "HIP events on the launch stream around each C-ABI call, eager profiled pass of this run (includes launch gaps)",
+                       "frac_mfma": tf / peak, "frac_hbm": gbs / PEAK_HBM_GBS, "traffic": None}
+                blk.update({"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak} if tf / peak >= gbs / PEAK_HBM_GBS
+                           else {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
+                blocks.append(blk)
+        roof = blocks[0] if blocks else {"kernel": None, "bound": "mfma", "achieved": 0.0, "peak": peak, "unit": "TFLOP/s", "frac": 0.0, "traffic": None}
         roof["kernel_ms_per_step_eager_events"] = tot / ps
-        roof["evidence_tag"] = tag
+        roof["trace"] = tmeta
+        roof["build"] = ids
+        if pinfo["refused"]:
+            roof["stale_profiles_refused"] = pinfo["refused"]
+        # step level: measured memory-side bytes of ALL kernels of a step (PMC passes of this build x in-graph launch counts) against
+        # SURVEY 8(d)'s closed-form compulsory bytes (ideal fusion: nothing but weights, memories and the query state moves)
+        step_alg_bytes = step_bytes(c)
+        step_traffic = None
+        if pmc is not None and trace:
+            tb = 0.0
+            for n, (lps, _us) in trace.items():
+                pl, _c = pmc_per_launch(pmc, n)
+                if pl is not None:
+                    tb += pl * lps
+            step_traffic = {"measured_traffic_bytes": tb, "algorithmic_bytes_survey_8d": step_alg_bytes,
+                            "traffic_over_algorithmic": tb / step_alg_bytes, "sustained_gbs": tb / (ms * 1e-3) / 1e9,
+                            "source": pmc.get("_file"), "note": "sum over every kernel of the step: calibrated FETCH_SIZE + WRITE_SIZE per "
+                            "launch x launches per step of the in-graph trace"}
+        else:
+            step_traffic = {"measured_traffic_bytes": None, "algorithmic_bytes_survey_8d": step_alg_bytes, "traffic_over_algorithmic": None,
+                            "note": "no PMC passes of this build under profiles/ (tools/refresh_profiles.sh writes them)"}
         if args.dump_kernels:
             with open(args.dump_kernels, "w") as f:
                 f.write(f"{'entry point':18s} {'shape':44s} {'calls/step':>10s} {'us/launch':>10s} {'ms/step':>8s} "
@@ -752,6 +892,7 @@ def main():
                 "rccl_ranks": (torch.distributed.get_world_size() if backend == "nccl" else 0)} if dist_on else {}),
             "roofline": roof,
             "roofline_next": blocks[1:],
+            "step_traffic": step_traffic,
             "kernel_families_ms_per_step": {k: round(v["ms"] / ps, 4) for k, v in sorted(fams.items())},
         }
         if world == 1 and not dist_on and not args.headline_only:

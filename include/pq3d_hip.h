@@ -422,7 +422,7 @@ typedef struct {
 int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* d, void* stream);
 /* Device gate of every pq3d_chain_* entry point: 1 if the current device of `stream` is the one their in-launch hand-offs are valid
  * on -- gfx950, 256 CUs, 160 KB of LDS per workgroup, and (probe != 0: one 256-workgroup launch + a synchronous copy, cached per
- * device; do not call with probe != 0 while the stream is capturing) the measured placement rule "workgroup id % 8 == XCC_ID" for
+ * device; do not call with probe != 0 while the stream is capturing) the measured placement rule "XCC_ID == (workgroup id + c) % 8, c constant" for
  * all 256 workgroups -- else 0: the caller must use the separate launches (same bits).  The err word of a chain descriptor reports
  * a hand-off that gave up at run time (a member that never became resident: CU-masked queue, a long-running neighbour kernel). */
 int pq3d_chain_device_ok(int32_t probe, void* stream);

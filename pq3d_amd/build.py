@@ -26,6 +26,22 @@ EXTRA = {"attn_resident.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-n
          "attn_ca.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
+def build_ids() -> dict:
+    """Identity of the build a measurement belongs to: sha256 (first 16 hex digits) of the shared library's bytes and of the sources it
+    is built from (csrc/*, the public header, the compile flags).  tools/rocprof_summary.py / pmc_*_json.py write both into every
+    profiles/ file; bench.py uses a committed profile only when its `src_sha256` equals the running build's (a stale file would
+    otherwise silently yield a roofline fraction)."""
+    import hashlib
+    hs = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "pq3d_hip.h")]:
+        path = os.path.join(CSRC, f)
+        if os.path.isfile(path) and (f.endswith((".hip", ".h", ".cpp"))):
+            hs.update(os.path.basename(f).encode()); hs.update(open(path, "rb").read())
+    hs.update(repr((FLAGS, sorted(EXTRA.items()), SOURCES)).encode())
+    lib = hashlib.sha256(open(LIB, "rb").read()).hexdigest()[:16] if os.path.exists(LIB) else None
+    return {"src_sha256": hs.hexdigest()[:16], "lib_sha256": lib}
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True

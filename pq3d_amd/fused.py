@@ -110,7 +110,7 @@ def set_chain(on: bool) -> None:
 
 
 def _chain_on(dev) -> bool:
-    """Chains requested AND valid on this device (ops.chain_device_ok: MI355X in SPX mode, workgroup id % 8 == XCD measured)."""
+    """Chains requested AND valid on this device (ops.chain_device_ok: MI355X in SPX mode, round-robin workgroup -> XCD placement measured)."""
     return _CHAIN and ops.chain_device_ok(dev)
 
 
@@ -299,7 +299,7 @@ def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None,
         if ks > 1:
             d._ws_keepalive = torch.empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
             d.ksplit, d.ws = ks, L.ptr(d._ws_keepalive)
-    key = f"B{B}H{H}Lq{Lq}Lk{Lk}dh{dm // H}ct{ct}"
+    key = f"B{B}H{H}Lq{Lq}Lk{Lk}dh{dm // H}ct{ct}" + ("m3" if mask is not None else "")
     if bwd is None:
         L.check(timed("pq3d_attn_fwd", key, 4.0 * B * Lq * Lk * dm, (q.numel() * 2 + k.numel() * 2) * q.element_size(),
                       L.lib().pq3d_attn_fwd, C.byref(d), L.stream()), "pq3d_attn_fwd")

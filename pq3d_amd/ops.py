@@ -500,7 +500,7 @@ def tt_multi(problems) -> None:
     for s0 in range(0, len(problems), L.TT_MAX_PROBLEMS):
         ch = problems[s0:s0 + L.TT_MAX_PROBLEMS]
         arr = (L.TtProblem * len(ch))()
-        fl = 0.0
+        fl = nb = 0.0
         for q, (g, x, x2, dw, db) in zip(arr, ch):
             N, K = dw.shape[-2], dw.shape[-1]
             R = g.numel() // N
@@ -508,7 +508,9 @@ def tt_multi(problems) -> None:
             q.dtA, q.dtB = L.dt_of(g), L.dt_of(x)
             q.A, q.B, q.B2, q.C, q.colsum = L.ptr(g), L.ptr(x), L.ptr(x2), L.ptr(dw), L.ptr(db)
             fl += 2.0 * N * K * R
-        L.check(timed("pq3d_gemm", f"ttmulti{len(ch)}", fl, 0.0, L.lib().pq3d_gemm_tt_multi, arr, len(ch), L.stream()),
+            nb += float(g.numel() * g.element_size() + x.numel() * x.element_size() + (x2.numel() * x2.element_size() if x2 is not None else 0)
+                        + N * K * 4 + (N * 4 if db is not None else 0))   # compulsory: both operands once, the fp32 result (+ bias gradient)
+        L.check(timed("pq3d_gemm_tt_multi", f"ttmulti{len(ch)}", fl, nb, L.lib().pq3d_gemm_tt_multi, arr, len(ch), L.stream()),
                 "pq3d_gemm_tt_multi")
 
 
@@ -1971,7 +1973,7 @@ _CHAIN_DEV_OK = {}
 
 
 def chain_device_ok(device) -> bool:
-    """Device gate of the chains (pq3d_chain_device_ok): gfx950, 256 CUs, 160 KB LDS and the measured 'workgroup id % 8 == XCD'
+    """Device gate of the chains (pq3d_chain_device_ok): gfx950, 256 CUs, 160 KB LDS and the measured round-robin 'XCD == (workgroup id + c) % 8'
     placement.  The measuring launch is skipped while the stream is capturing (property checks only; the probe's verdict is
     cached from the first eager call -- every capture in this package is preceded by eager warm-up steps)."""
     device = torch.device(device)
@@ -1984,4 +1986,8 @@ def chain_device_ok(device) -> bool:
         ok = bool(L.lib().pq3d_chain_device_ok(0 if capturing else 1, L.stream()))
     if not capturing or not ok:
         _CHAIN_DEV_OK[key] = ok
+        if not ok:
+            import warnings
+            warnings.warn(f"pq3d: the one-launch row-local chains are OFF on cuda:{key} (pq3d_chain_device_ok said no: not a 256-CU gfx950 "
+                          "in SPX mode with the round-robin workgroup -> XCD placement); the separate launches compute the same bits, ~8 % slower", stacklevel=2)
     return ok

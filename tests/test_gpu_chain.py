@@ -437,7 +437,7 @@ def test_model_step_is_the_same_with_and_without_chains(case):
 # ---------------------------------------------------------------------------------------------------- device gate, neighbours, polling
 def test_chain_device_gate_measures_the_placement_rule():
     """chains are valid only where workgroup id % 8 is the XCD and all members are co-resident.  The gate checks
-    gfx950 / 256 CUs / 160 KB LDS and MEASURES XCC_ID == id % 8 over 256 workgroups (pq3d_chain_device_ok); on this box it must say
+    gfx950 / 256 CUs / 160 KB LDS and MEASURES XCC_ID == (id + c) % 8 over 256 workgroups (pq3d_chain_device_ok); on this box it must say
     yes, and fused._chain_on follows it (and fused.set_chain)."""
     from pq3d_amd import _lib as L, fused, ops
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -14,6 +14,16 @@ import sys
 CLOCK_GHZ, SIMDS = 2.4, 1024
 
 
+def _build_ids():
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from pq3d_amd.build import build_ids
+        return build_ids()
+    except Exception as e:  # noqa: BLE001
+        return {"error": type(e).__name__}
+
+
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n)
@@ -45,7 +55,7 @@ def main():
             "sq_busy_cycles": round(e.get("SQ_BUSY_CYCLES", 0.0), 1), "sq_wave_cycles": round(e.get("SQ_WAVE_CYCLES", 0.0), 1),
             "avg_us_this_pass": round(us, 2) if us else None,
             "mfma_busy": round(busy / (us * 1e3 * CLOCK_GHZ * SIMDS), 4) if us else None})
-    print(json.dumps({"_note": "per launch; SQ_VALU_MFMA_BUSY_CYCLES summed over all SIMDs; mfma_busy = cycles / (duration x "
+    print(json.dumps({"_build": _build_ids(), "_note": "per launch; SQ_VALU_MFMA_BUSY_CYCLES summed over all SIMDs; mfma_busy = cycles / (duration x "
                                f"{CLOCK_GHZ} GHz x {SIMDS} SIMDs), duration of the same eager launch in this PMC pass",
                       "clock_ghz": CLOCK_GHZ, "simds": SIMDS, "kernels": out}, indent=1))
 

@@ -11,6 +11,16 @@ import sqlite3
 import sys
 
 
+def _build_ids():
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from pq3d_amd.build import build_ids
+        return build_ids()
+    except Exception as e:  # noqa: BLE001
+        return {"error": type(e).__name__}
+
+
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n)
@@ -42,7 +52,7 @@ def main():
         cal = {"kernel": "copy_many_kernel", "grid": r["grid"], "true_read_kib": true_kib, "true_write_kib": true_kib,
                "fetch_kib_raw": r["fetch_kib"], "write_kib_raw": r["write_kib"],
                "fetch_raw_over_true": round(r["fetch_kib"] / true_kib, 4), "write_raw_over_true": round(r["write_kib"] / true_kib, 4)}
-    print(json.dumps({"calibration": cal, "_note": "per launch, KiB; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py "
+    print(json.dumps({"_build": _build_ids(), "calibration": cal, "_note": "per launch, KiB; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py "
                                "--no-graph --headline-only` (tools/refresh_profiles.sh)", "kernels": out}, indent=1))
 
 

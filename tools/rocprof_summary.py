@@ -29,6 +29,14 @@ def main():
     tot = sum(r[2] for r in rows)
     n = sum(r[1] for r in rows)
     span = cur.execute("select min(start), max(end) from kernels").fetchone()
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from pq3d_amd.build import build_ids
+        ids = build_ids()
+        print(f"# build: src_sha256 {ids['src_sha256']} lib_sha256 {ids['lib_sha256']}")
+    except Exception as e:  # noqa: BLE001
+        print(f"# build: unknown ({type(e).__name__})")
     print(f"# {db}: {n} kernel dispatches, total kernel time {tot / 1e6:.2f} ms, trace span {(span[1] - span[0]) / 1e6:.1f} ms"
           + (f", steps {steps:.0f} (calls of a once-per-step kernel), per step: {n / steps:.1f} dispatches, "
              f"{tot / 1e6 / steps:.3f} ms kernel time" if steps else ""))
