@@ -66,8 +66,9 @@ def no_decay_param_group(parameters, lr, name=""):
 
 class Query3DUnified(nn.Module):
     """model/query3d_unified.py:30-238.  Supported inputs: offline voxel features (``use_offline_voxel_fts``),
-    mv / pc segment features, and a pre-encoded prompt memory (``data_dict['prompt_feat']`` [B,T,d]) in place of the
-    out-of-scope CLIP text encoder.  Heads: 'mask', 'ground', 'generation' (input_proj on the HIP kernels, the HF T5
+    mv / pc segment features, and the prompt memory either pre-encoded (``data_dict['prompt_feat']`` [B,T,d]) or through
+    ``prompt_encoder`` (``prompt`` / ``prompt_type`` / ``prompt_pad_masks``: 'loc' prompts on the HIP encoders, 'txt' prompts
+    through a caller-supplied ``txt_encoder`` -- the CLIP text encoder itself is out of scope).  Heads: 'mask', 'ground', 'generation' (input_proj on the HIP kernels, the HF T5
     decoder body on stock PyTorch-ROCm ops, §8f-3)."""
 
     def __init__(self, cfg, compute: str = "bf16"):
@@ -125,6 +126,39 @@ class Query3DUnified(nn.Module):
                                      [self.coord_encoder[1].bias, self.box_encoder[1].bias],
                                      eps=self.coord_encoder[1].eps, coef=coef)
         return self.coord_encoder(locs[:, :, :3], input_range=[coord_min, coord_max])
+
+    PROMPT_TYPE = {"txt": 1, "image": 2, "loc": 3}   # data/datasets/constant.py:628-631 (PromptType)
+
+    def prompt_encoder(self, data_dict):
+        """query3d_unified.py:80-108: encode the prompt of every scene by its `prompt_type`.  'loc' prompts (the first dim_loc
+        entries of the prompt row are a location) run through the coordinate / box encoders on the HIP kernels and occupy token 0
+        alone (`mask[:, 1:] = False`); 'txt' prompts are handed to ``self.txt_encoder`` -- the reference's CLIP text encoder is out
+        of scope, so a caller that trains with text prompts assigns its own module there (called as
+        ``encoder(token_ids.long(), pad_mask)`` -> [n, T, d], exactly as the reference calls it).  Like the reference, the
+        scenes' `prompt_pad_masks` rows are updated IN PLACE; returns (prompt_feat [B, T, d], key-padding mask = ~pad mask)."""
+        prompt, ppm, ptype = data_dict["prompt"], data_dict["prompt_pad_masks"], data_dict["prompt_type"]
+        prompt_feat = torch.zeros(prompt.shape + (self.hidden_size,), device=prompt.device)
+        for kind in ("txt", "loc"):
+            idx = ptype == self.PROMPT_TYPE[kind]
+            if int(idx.sum()) == 0:
+                continue
+            inp, mask = prompt[idx], ppm[idx]
+            if kind == "txt":
+                enc = getattr(self, "txt_encoder", None)
+                if enc is None:
+                    raise NotImplementedError("text prompts need a text encoder: assign model.txt_encoder (the reference's CLIP "
+                                              "encoder is outside the hot path, SURVEY section 2) or pass data_dict['prompt_feat']")
+                feat = enc(inp.long(), mask)
+            else:
+                loc = inp[:, :self.dim_loc].float()
+                if self.dim_loc > 3:
+                    feat = self._pos(loc[:, None, :6].contiguous(), None, None)            # coord + box embedding, [n, 1, d]
+                else:
+                    feat = self._pos(loc[:, None, :3].contiguous(), data_dict["coord_min"][idx], data_dict["coord_max"][idx])
+                mask[:, 1:] = False
+            prompt_feat[idx] = feat.to(prompt_feat.dtype)      # [n, 1, d] broadcasts over the T token slots, as in the reference
+            ppm[idx] = mask
+        return prompt_feat, ppm.logical_not()
 
     def _pos_pair(self, query_locs, seg_locs, coord_min, coord_max):
         """CoordinateEncoder on queries and segments in ONE Linear+LN pass (same weights, rows concatenated)."""
@@ -195,7 +229,11 @@ class Query3DUnified(nn.Module):
         enc_out = self._encode_scene_memories(data_dict)
         for inp in self.inputs:
             if inp == "prompt":
-                feat, mask, pos = data_dict["prompt_feat"], data_dict["prompt_pad_masks"].logical_not(), None
+                if "prompt_feat" in data_dict:   # pre-encoded prompt memory (the text encoder ran outside)
+                    feat, mask, pos = data_dict["prompt_feat"], data_dict["prompt_pad_masks"].logical_not(), None
+                else:                            # query3d_unified.py:134-136
+                    feat, mask = self.prompt_encoder(data_dict)
+                    pos = None
             elif inp in ("mv", "pc"):
                 feat = enc_out[inp]
                 k = inp + "_seg_pad_masks"

@@ -98,6 +98,17 @@ def synth_data_dict(B: int, n_seg: int, n_q: int, d_in: Mapping[str, int], seed:
     return dd
 
 
+def prompt_loc_inputs(B: int, T: int, seed: int = 77) -> Dict[str, torch.Tensor]:
+    """Location prompts of query3d_unified.py:80-108 (PromptType.LOC = 3): prompt [B, T] whose first entries are a point in the
+    scene's coordinate range, ragged pad masks (True = valid), one prompt type per scene.  Shared by tests/golden/make_golden.py
+    (fixture F20) and the tests."""
+    r = np.random.default_rng(seed)
+    pl = r.integers(1, T + 1, size=B)
+    return {"prompt": torch.from_numpy(r.uniform(0, 4, (B, T)).astype(np.float32)),
+            "prompt_pad_masks": torch.from_numpy(np.arange(T)[None, :] < pl[:, None]),
+            "prompt_type": torch.full((B,), 3, dtype=torch.long)}
+
+
 def criterion_inputs(seed=21, B=3, Ns=70, Nq=12, C=21, n_layers=3, seg_len=(70, 55, 61), n_inst=(5, 9, 3)):
     """Synthetic predictions / targets of the F9 criterion fixture (also rebuilt by the tests)."""
     r = np.random.default_rng(seed)

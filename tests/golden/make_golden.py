@@ -153,25 +153,35 @@ def model_cfg(d, H, L, memories, heads, d_in, *, spatial, structure, use_self_ma
     for mem in memories:
         if mem != "prompt":
             m[f"{mem}_encoder"] = enc(mem)
+        else:
+            # the reference's constructor builds cfg.model.txt_encoder for a prompt memory (query3d_unified.py:47-52: CLIP, not
+            # installable here).  The F20 case feeds LOCATION prompts only, so the text encoder is built but never called: any
+            # registered reference module serves as the placeholder (its parameters are left out of the fixture)
+            m["txt_encoder"] = {"name": "ObjectEncoder", "args": {"input_feat_size": d, "hidden_size": d, "use_projection": True,
+                                                                   "use_cls_head": False, "dropout": 0.1}}
     return Cfg({"model": m, "solver": {"lr": 1e-4}})
 
 
 def run_model_case(ref, name, *, B, Ns, Nq, d, H, L, memories, heads, spatial, structure, train_grads=True,
                    seed=0, data_seed=1234, query_valid_min=None, **kw):
-    d_in = dict(kw.pop("d_in", None) or {m: d for m in memories})
+    d_in = dict(kw.pop("d_in", None) or {m: d for m in memories if m != "prompt"})
+    prompt_loc = kw.pop("prompt_loc", 0)
     if any(v != d for v in d_in.values()):
         kw_din = {"d_in": d_in}
     else:
         kw_din = {}
     cfg = model_cfg(d, H, L, memories, heads, d_in, spatial=spatial, structure=structure, **kw)
-    kw = {**kw, **kw_din}
+    kw = {**kw, **kw_din, **({"prompt_loc": prompt_loc} if prompt_loc else {})}
     torch.manual_seed(0)
     model = ref.model.Query3DUnified(cfg)
     sd = synth.fill_module(model, seed)
+    sd = {k: v for k, v in sd.items() if not k.startswith("txt_encoder.")}   # (the never-called placeholder, see model_cfg)
     model.eval()  # dropout off: parity is only defined at p=0
     dd = synth.synth_data_dict(B, Ns, Nq, d_in, seed=data_seed, memories=memories,
                                query_valid_min=query_valid_min, loc_dim=kw.get("dim_loc", 3))
     dd["tgt_object_id"] = torch.zeros(B, dtype=torch.long)
+    if prompt_loc:
+        dd.update(synth.prompt_loc_inputs(B, prompt_loc, seed=data_seed + 11))
     if kw.get("offline_attn"):
         r = np.random.default_rng(data_seed + 7)
         om = r.random((B, Nq, Ns)) < 0.6
@@ -875,6 +885,12 @@ def main():
     # F19: the reference under its own bf16 autocast at the F4_c2_slice / F15_d768 shapes (yardstick of the bf16 mode)
     run_autocast_case(ref, "F19_autocast_c2_slice", "F4_c2_slice")
     run_autocast_case(ref, "F19_autocast_d768", "F15_d768")
+    # F20: the whole model with a PROMPT memory encoded by Query3DUnified.prompt_encoder (query3d_unified.py:80-108): location
+    # prompts (PromptType.LOC), stage-2 structure 'mixed' (parallel scene memories, then the prompt cross-attention)
+    run_model_case(ref, "F20_prompt_loc", B=3, Ns=60, Nq=11, d=64, H=4, L=2, memories=["mv", "pc", "voxel", "prompt"],
+                   heads=["ground"], spatial=True, structure="mixed", prompt_loc=6)
+    run_model_case(ref, "F20_prompt_loc6", B=2, Ns=40, Nq=8, d=64, H=4, L=1, memories=["voxel", "prompt"], heads=["ground"],
+                   spatial=True, structure="sequential", dim_loc=6, prompt_loc=8)
 
 
 if __name__ == "__main__":

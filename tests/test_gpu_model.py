@@ -258,3 +258,39 @@ def test_bf16_self_mask_first_call_and_flip_rate():
     fin = torch.isfinite(cr)
     assert torch.equal(fin, torch.isfinite(c0))
     assert float((c0[fin] - cr[fin]).abs().max()) < 2e-2 * float(cr[fin].abs().max())
+
+
+@pytest.mark.parametrize("name", ["F4_c2_slice", "F4b_c4_slice", "F15_din", "F1_c1", "F20_prompt_loc", "F15_d768"])
+def test_bf16x3_model_matches_fp32_oracle(name):
+    """Compute mode 'bf16x3' (split-bf16 key/value side; fused.fused_decoder) end to end against the fp32 oracle at north_star's
+    1e-3 -- not a measured-times-1.5 bar.  d = 256 fixtures take the split-bf16 kernels (csrc/attn_x3.hip, PQ3D_ACT_PLANES);
+    F1_c1 (d_h = 16), F20 (prompt memory) and F15_d768 (d_h = 64) are outside their shape and run the exact-f32 kernels: the mode's
+    contract is the accuracy, the kernels are the fast path to it.  Live self-masks (F4b, F15_din): a threshold flip moves a
+    downstream logit by more than rounding, so mask logits are compared where the oracle's own mask agrees (flip rate asserted)."""
+    z, args = util.load_fixture(name)
+    _cfg, model, sd, dd = util.model_case(args)
+    set_compute(model, "bf16x3")
+    out, loss, g = run_hip(model, args, dd)
+    oout, collect, oloss, og = util.run_oracle(args, sd, dd)
+
+    def rel(a, b):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        fin = torch.isfinite(b) & (b > -1e5)
+        assert torch.equal(torch.isfinite(b), torch.isfinite(a))
+        return float((a[fin] - b[fin]).abs().max() / max(float(b[fin].abs().max()), 1e-6))
+
+    flips = 0.0
+    if "mask" in args["heads"]:
+        flips = max(float(((m.detach().float().cpu() < 0) != (r < 0)).float().mean())
+                    for m, r in zip(out["predictions_mask"], oout["predictions_mask"]))
+        assert flips < 2e-4, f"self-mask bit-flip rate {flips:.2e}"
+        assert rel(out["predictions_mask"][0], oout["predictions_mask"][0]) < 1e-3     # first call: no mask feedback yet
+    bar = 1e-3 if flips == 0.0 else 5e-3
+    assert rel(out["query_embeds"], collect[-1]) < bar
+    if "ground" in args["heads"]:
+        assert rel(out["ground_logits"], oout["ground_logits"]) < bar
+    assert abs(loss.item() - oloss.item()) < 1e-3 * max(1.0, abs(oloss.item()))
+    names = sorted(n for n in og if "pairwise_loc_fc" not in n)
+    gmax = max(float(og[n].norm()) for n in names)
+    worst = max((float((g[n].float().cpu() - og[n]).norm() / max(float(og[n].norm()), 1e-2 * gmax)), n) for n in names)
+    assert worst[0] < (2e-2 if flips == 0.0 else 5e-2), f"worst gradient (relative L2) {worst}"

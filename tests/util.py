@@ -22,7 +22,7 @@ def fixtures(prefix=""):
 
 def model_fixtures():
     """Fixtures made by make_golden.run_model_case (whole Query3DUnified forward/backward)."""
-    return [f for f in fixtures() if f.startswith(("F1_", "F2_", "F4_", "F4b_", "F5_", "F15_"))]
+    return [f for f in fixtures() if f.startswith(("F1_", "F2_", "F4_", "F4b_", "F5_", "F15_", "F20_"))]
 
 
 def load_fixture(name):
@@ -67,7 +67,7 @@ def model_case(args, device="cpu"):
                                "skip_pred", "activation") if k in args}
     kw.setdefault("C", 21)
     d = args["d"]
-    d_in = args.get("d_in") or {m: d for m in args["memories"]}
+    d_in = args.get("d_in") or {m: d for m in args["memories"] if m != "prompt"}
     cfg = make_cfg(d=d, H=args["H"], L=args["L"], memories=args["memories"], heads=args["heads"], d_in=d_in,
                    spatial=args["spatial"], structure=args["structure"], ground_hidden=d // 2 * 3 // 3, **kw)
     model = Query3DUnified(cfg, compute="fp32")
@@ -76,6 +76,8 @@ def model_case(args, device="cpu"):
     dd = synth.synth_data_dict(args["B"], args["Ns"], args["Nq"], d_in,
                                seed=args["data_seed"], memories=args["memories"],
                                query_valid_min=args.get("query_valid_min"), loc_dim=args.get("dim_loc", 3))
+    if args.get("prompt_loc"):   # F20: location prompts through Query3DUnified.prompt_encoder
+        dd.update(synth.prompt_loc_inputs(args["B"], args["prompt_loc"], seed=args["data_seed"] + 11))
     if args.get("offline_attn"):
         r = np.random.default_rng(args["data_seed"] + 7)
         om = r.random((args["B"], args["Nq"], args["Ns"])) < 0.6
