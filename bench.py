@@ -549,7 +549,10 @@ def main():
     groups = [P(head_ids)] + layer_groups + [[p for p in params if id(p) not in dec_ids and id(p) not in head_ids]]
     keep = [bool(g) for g in groups]
     bucket_of = [sum(keep[:j]) for j in range(len(groups))]            # index after dropping empty groups
-    reducer = FlatGradAllReducer(params, groups=[g for g in groups if g])
+    # PQ3D_BENCH_WIRE=bf16: gradient buckets cross the links as bf16 with fp32 accumulation (parallel.FlatGradAllReducer wire_dtype;
+    # default fp32 = DDP's arithmetic, trainer/build.py:66-75)
+    wire = os.environ.get("PQ3D_BENCH_WIRE", "fp32")
+    reducer = FlatGradAllReducer(params, groups=[g for g in groups if g], wire_dtype=torch.bfloat16 if wire == "bf16" else None)
     heads_bucket = bucket_of[0] if keep[0] else None
     dec_buckets = [bucket_of[j] for j in range(1, 1 + len(layer_groups)) if keep[j]]
     n_layer_buckets = len(layers) if bucket_mode == "per_layer" else 0
@@ -879,7 +882,7 @@ def main():
                                    f"{c.get('structure', 'parallel')} cross-attn + spatial self-attn + FFN2048, heads={c['heads']}, "
                                    f"fwd+bwd+grad-pack{'+RCCL all-reduce' if dist_on else ''}",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
-                       "step_mode": step_mode,
+                       "step_mode": step_mode, "gradient_wire_dtype": wire,
                        "dropout": 0.0 if args.dropout == "off" else "reference train mode (0.1 / heads 0.1, 0.3)",
                        # the caption body keeps the HF config's dropout_rate under model.train() in BOTH dropout settings
                        # (pq3d_amd/t5.py: the reference never overrides it) -- extra work inside the timed step, stated here

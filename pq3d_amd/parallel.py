@@ -31,9 +31,18 @@ class FlatGradAllReducer:
     its all-reduce can be launched early on a side stream (``launch(0)``) and overlaps that tail."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
-                 keep_order: bool = False, groups=None):
+                 keep_order: bool = False, groups=None, wire_dtype=None):
+        """wire_dtype = torch.bfloat16: the buckets cross the links as bf16 (half the bytes of the fp32 all-reduce: xGMI rings are
+        per-link bound, config 2's 36.8 MB of fp32 gradients are ~0.3 ms of wire time at 8 ranks) with FP32 ACCUMULATION -- not a
+        bf16 all-reduce, whose ring sums in bf16: an all-to-all hands every rank the bf16 pieces of ITS shard from all ranks, it sums
+        them in fp32 (and divides), and an all-gather returns the bf16-rounded means.  Two roundings per element in total (each
+        rank's contribution once, the mean once: ~4e-3 relative, the level the 'bf16' mode's gradients already have); every rank
+        ends with bit-identical buffers.  None (default): fp32 all-reduce, DDP's arithmetic (trainer/build.py:66-75)."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
+        assert wire_dtype in (None, torch.bfloat16, torch.float32)
+        self.wire_dtype = None if wire_dtype == torch.float32 else wire_dtype
+        self._wire = {}          # bucket index -> (send, recv, shard, gathered) staging buffers (fixed addresses: capturable)
         if groups is not None:
             self.buckets = [[p for p in g if p.requires_grad] for g in groups]
             assert sorted(id(p) for b in self.buckets for p in b) == sorted(id(p) for p in self.params), \
@@ -129,6 +138,31 @@ class FlatGradAllReducer:
             return dist.all_reduce(f, op=dist.ReduceOp.AVG, group=self.group, async_op=True), False
         return dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True), True
 
+    def _reduce_wire(self, bi: int) -> None:
+        """Mean over ranks of bucket bi with a bf16 wire format and fp32 accumulation, in place, on the CURRENT stream
+        (stream-ordered collectives: with RCCL the host does not block)."""
+        f, W, g = self.flat[bi], self._world(), self.group
+        n = f.numel()
+        per = -(-n // W)
+        per += (-per) % 8          # 16-byte pieces
+        buf = self._wire.get(bi)
+        if buf is None or buf[0].numel() != W * per:
+            mk = lambda *sh, dt: torch.zeros(*sh, dtype=dt, device=f.device)
+            buf = self._wire[bi] = (mk(W * per, dt=self.wire_dtype), mk(W * per, dt=self.wire_dtype), mk(per, dt=self.wire_dtype),
+                                    mk(W * per, dt=self.wire_dtype))
+        send, recv, shard, gathered = buf
+        send[:n].copy_(f)                                        # fp32 -> bf16 (the padding stays zero)
+        if W > 1:
+            dist.all_to_all_single(recv, send, group=g)          # piece r of every rank -> rank r
+        else:
+            recv.copy_(send)
+        shard.copy_(recv.view(W, per).float().sum(0).div_(float(W)))   # fp32 accumulation, mean, one rounding
+        if W > 1:
+            dist.all_gather_into_tensor(gathered, shard, group=g)
+        else:
+            gathered.copy_(shard)
+        f.copy_(gathered[:n])                                    # bf16 -> fp32: identical bits on every rank
+
     def launch(self, bi: int, after=None, side: bool = True) -> None:
         """Start the all-reduce of bucket ``bi`` on a side stream that waits for the work queued so far on the current
         stream -- or, with ``after`` (an event recorded on the current stream when the bucket became final), only for
@@ -150,7 +184,9 @@ class FlatGradAllReducer:
             # -> cur -- makes hipStreamEndCapture SEGFAULT on this stack (torch 2.10 / ROCm 7.2, found with a one-rank
             # communicator on an MI355X: tools/probes/rccl_capture_probe.py); branches of one graph do not run
             # concurrently on this runtime anyway, so nothing is lost.
-            if dist.get_backend(self.group) == "nccl":
+            if self.wire_dtype is not None:
+                self._reduce_wire(bi)
+            elif dist.get_backend(self.group) == "nccl":
                 dist.all_reduce(self.flat[bi], op=dist.ReduceOp.AVG, group=self.group)
             else:
                 dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group)
@@ -166,9 +202,9 @@ class FlatGradAllReducer:
             else:
                 self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
-                h, div = self._reduce(self.flat[bi])
+                h, div = (self._reduce_wire(bi), False) if self.wire_dtype is not None else self._reduce(self.flat[bi])
         else:
-            h, div = self._reduce(self.flat[bi])
+            h, div = (self._reduce_wire(bi), False) if self.wire_dtype is not None else self._reduce(self.flat[bi])
         self._pending.append((h, bi, div, on_side))
         self._launched.add(bi)
 
@@ -184,11 +220,13 @@ class FlatGradAllReducer:
             if self.flat[bi].is_cuda and on_side:
                 any_side = True
                 with torch.cuda.stream(self._side):
-                    h.wait()
+                    if h is not None:
+                        h.wait()
                     if div:
                         self.flat[bi].div_(world)
             else:
-                h.wait()
+                if h is not None:
+                    h.wait()
                 if div:
                     self.flat[bi].div_(world)
         if self._side is not None and self.flat[0].is_cuda and self._pending and any_side:

@@ -76,6 +76,23 @@ def test_bench_one_rank_rccl(mode):
     assert sm.startswith(want), (sm, p.stderr[-2000:])
 
 
+@pytest.mark.parametrize("mode", ["", "one_graph"])
+def test_bench_one_rank_rccl_bf16_wire(mode):
+    """the bf16 wire format (fp32 accumulation: all-to-all + local fp32 sum + all-gather, pq3d_amd/parallel.py)
+    through RCCL with one rank -- the collectives, the casts and their capture inside the step's graphs all execute; with one rank
+    the result is the bf16 rounding of the rank's own gradients (finite, non-zero, identical fingerprints)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PQ3D_BENCH_FORCE_DIST="1", PQ3D_BENCH_STEP_MODE=mode, PQ3D_BENCH_WIRE="bf16")
+    for k in ("PQ3D_BENCH_BACKEND", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--headline-only"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert r["rccl_ranks"] == 1 and r["config"]["gradient_wire_dtype"] == "bf16"
+    assert r["grads_identical_across_ranks"] is True and r["value"] > 0 and r["chain_error"] is False
+
+
 @pytest.mark.parametrize("buckets", ["coalesced", "per_layer"])
 def test_bench_one_rank_rccl_caption_config_splits_at_the_heads(buckets):
     """Config 5 (caption head) over a one-rank RCCL communicator: the heads' bucket is launched when the decoder backward

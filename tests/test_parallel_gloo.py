@@ -50,6 +50,28 @@ def _worker(rank, world, port, out):
     for i, p in enumerate(params):
         mean = sum(torch.from_numpy(gathered[r][i]) for r in range(world)) / world
         assert torch.allclose(p.grad, mean, atol=1e-6), (rank, i, "groups")
+    # bf16 wire format with fp32 accumulation (wire_dtype): every rank ends with bit-identical buffers = bf16(mean in fp32 of the
+    # bf16-rounded contributions)
+    for p in params:
+        p.grad = None
+    red3 = FlatGradAllReducer(params, groups=[list(lin[2].parameters()), list(lin[0].parameters()) + list(lin[1].parameters()) + [unused]],
+                              wire_dtype=torch.bfloat16)
+    (lin(x) * 0.37).square().mean().backward()
+    local3 = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in params]
+    red3.pack(buckets=[0])
+    red3.launch(0)
+    red3.pack(buckets=[1])
+    red3.finish()
+    red3.unpack_views()
+    dist.all_gather_object(gathered, [g.numpy() for g in local3])
+    for i, p in enumerate(params):
+        contrib = [torch.from_numpy(gathered[r][i]).bfloat16().float() for r in range(world)]
+        want = (sum(contrib) / world).bfloat16().float()
+        assert torch.equal(p.grad, want), (rank, i, "bf16 wire", (p.grad - want).abs().max())
+    flat3 = [f.clone() for f in red3.flat]
+    other = [None] * world
+    dist.all_gather_object(other, [f.numpy() for f in flat3])
+    assert all((other[0][k] == other[1][k]).all() for k in range(len(flat3))), "ranks must hold identical reduced buffers"
     out.put((rank, float(sum(f.abs().sum() for f in red.flat))))
     dist.barrier()
     dist.destroy_process_group()
