@@ -317,8 +317,11 @@ class _RowCE(Function):
         x = logits.contiguous().float().view(-1, logits.shape[-1])
         t = labels.contiguous().view(-1).long()
         R, Ccls = x.shape
-        buf = torch.empty(2 * R + 2, dtype=torch.float32, device=x.device)      # row_loss | lse | loss | 1 / kept
-        row_loss, lse, loss, inv = buf[:R], buf[R:2 * R], buf[2 * R:2 * R + 1], buf[2 * R + 1:]
+        buf = torch.empty(2 * R + 1, dtype=torch.float32, device=x.device)      # row_loss | lse | 1 / kept
+        row_loss, lse, inv = buf[:R], buf[R:2 * R], buf[2 * R:]
+        # the RETURNED scalar lives in a tensor of its own: sharing the saved tensors' buffer (and version counter) made a caller's
+        # in-place `loss /= accum_steps` / `total += aux` fail the backward with "modified by an inplace operation" 
+        loss = torch.empty((), dtype=torch.float32, device=x.device)   # 0-dim, not a view: in-place ops on it are legal
         ce = L.CeDesc()
         ce.layers, ce.C, ce.R, ce.ignore_index = 1, Ccls, R, ignore_index
         ce.logits[0], ce.target, ce.row_loss, ce.lse = L.ptr(x), L.ptr(t), L.ptr(row_loss), L.ptr(lse)
@@ -328,7 +331,7 @@ class _RowCE(Function):
         ctx.has_add = add is not None
         ctx.save_for_backward(x, t, lse, inv)
         ctx.ignore_index, ctx.shape, ctx.dtype = ignore_index, logits.shape, logits.dtype
-        return loss.view(())
+        return loss
 
     @staticmethod
     def backward(ctx, g):

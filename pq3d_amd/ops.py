@@ -431,18 +431,39 @@ def _dw_can_defer(g, x, x2, N, K) -> bool:
                 not g.is_contiguous() or not x.is_contiguous())
 
 
+_DW_NO_DEFER = set()    # id(param): never deferred (dw_defer_exclude)
+
+
+def dw_defer_exclude(params, on: bool = True) -> None:
+    """Exclude parameters from weight-gradient deferral.  REQUIRED for parameters whose gradient is read by a hook Python cannot see:
+    torch DDP's reducer registers its bucket hooks in C++ on the AccumulateGrad node (grad_accumulator->add_post_hook), which neither
+    Tensor._backward_hooks nor _post_accumulate_grad_hooks shows -- under a whole-pass gradient arena such a hook would read a slot
+    whose queued product only runs when the pass ends.  (The package's own data-parallel path, parallel.FlatGradAllReducer, flushes
+    the queue before a bucket leaves and needs no exclusion.)"""
+    for p in params:
+        (_DW_NO_DEFER.add if on else _DW_NO_DEFER.discard)(id(p))
+
+
 def _param_has_hooks(q) -> bool:
+    """Python-visible gradient hooks (tensor hooks, post-accumulate-grad hooks, Python hooks on the AccumulateGrad node) or an
+    explicit exclusion (dw_defer_exclude: C++-side hooks such as DDP's cannot be detected from here)."""
     ent = _Arena.by_ptr.get(q)
     if ent is None:
         return False
     p_ = ent[0]
-    return bool(getattr(p_, "_backward_hooks", None)) or bool(getattr(p_, "_post_accumulate_grad_hooks", None))
+    if id(p_) in _DW_NO_DEFER or getattr(p_, "_backward_hooks", None) or getattr(p_, "_post_accumulate_grad_hooks", None):
+        return True
+    try:   # Python hooks registered on the parameter's AccumulateGrad node itself
+        acc = p_.view_as(p_).grad_fn.next_functions[0][0]
+        return bool(getattr(acc, "_post_hooks", None)) or bool(getattr(acc, "_pre_hooks", None))
+    except Exception:  # noqa: BLE001
+        return False
 
 
 def _dw_defer(g, x, x2, dw, db, N, K, R, ct, pptrs=()) -> bool:
     """Queue dw[N, K] += g^T (x [+ x2]) (and db[N] += column sums of g); False when the pass has no whole-pass arena.
-    A parameter with gradient hooks (a post-accumulate-grad hook, an eager DDP bucket hook) is never deferred: its hook
-    would read the slot before the queued product has run."""
+    A parameter with Python-visible gradient hooks, or one listed through dw_defer_exclude (torch DDP: its C++ bucket hooks are
+    invisible from Python), is never deferred: its hook would read the slot before the queued product has run."""
     if not _dw_can_defer(g, x, x2, N, K) or any(_param_has_hooks(q) for q in pptrs if q is not None):
         return False
     _DwDeferred.nbytes += g.numel() * g.element_size() + x.numel() * x.element_size() + \
@@ -692,7 +713,9 @@ def linear(x, w, b=None, *, ct: int, x2=None, act: Optional[str] = None, out_dty
     (F.linear call sites, see include/pq3d_hip.h)
     masked_grad: a hand-over slot shared with the rmsnorm that consumes y (``rmsnorm(..., grad_drop=(drop, slot))``): that
     norm's backward kernel also writes dropout_mask * dy / (1 - p), which this layer's backward then takes instead of
-    launching a dropout of its own (checked by address: anything else falls back to the launch)."""
+    launching a dropout of its own (checked by address: anything else -- e.g. a second consumer of y, whose gradients autograd
+    sums into a new tensor -- falls back to the launch; tests/test_gpu_t5_head.py).  Unsupported: a tensor hook that rewrites the
+    norm's input gradient IN PLACE (same address) -- the pre-masked copy was formed from the value before the hook ran."""
     return _Linear.apply(x, w, b, x2, row_mask, ct, act, out_dtype, fill_flag, float(fill_value), drop, residual, masked_grad)
 
 
@@ -1279,7 +1302,9 @@ class _LinearLNGroup(Function):
                       L.stream()), "pq3d_add_ln_bwd")
         if fuse and ct == BF16 and not dw_long_path(N, K, R, G, ct) and \
                 all(tt_multi_ok(dlin[g], xs[g], None, dWs[g], dbl[g], N, K, R) for g in range(G)):
-            # few output tiles over a long reduction (config 2: 3 encoders of [256 x 256] over 8192 rows): wide tiles + k-slices
+            # short reductions only (tt_multi_ok refuses R >= 2048 unless PQ3D_TT_MULTI_LONG=1: config 2's 3 encoders of [256 x 256]
+            # over 8192 rows were measured slower on wide tiles + k-slices): the encoders of small batches / short memories --
+            # one launch with the fused bias gradient (tests/test_gpu_ops.py::test_linear_ln_group_backward_tt_multi_path)
             tt_multi([(dlin[g], xs[g], None, dWs[g], dbl[g]) for g in range(G)])
         else:
             ga_, xa_, _ = dw_operands([dlin[g] for g in range(G)], list(xs), None, N, K, R, ct)

@@ -1279,3 +1279,42 @@ def test_scale_rows_many_equals_per_tensor(out_dtype):
     it = torch.int16 if out_dtype == torch.bfloat16 else torch.int32
     for a, b in zip(out, ref):
         assert a.shape == b.shape and torch.equal(a.view(it), b.view(it))
+
+
+@pytest.mark.parametrize("R", [300, 1024])
+def test_linear_ln_group_backward_tt_multi_path(R):
+    """below 2048 rows the grouped Linear+LayerNorm backward sends its weight / bias gradients through the one-launch
+    pq3d_gemm_tt_multi (fused bias column sums) next to the LayerNorm parameter-gradient atomics -- against float64 autograd."""
+    G, K, N = 3, 256, 256
+    xs = [rnd(R, K, seed=40 + g) for g in range(G)]
+    Ws = [rnd(N, K, seed=50 + g, scale=0.06) for g in range(G)]
+    bs = [rnd(N, seed=60 + g, scale=0.1) for g in range(G)]
+    gs = [1 + rnd(N, seed=70 + g, scale=0.1) for g in range(G)]
+    be = [rnd(N, seed=80 + g, scale=0.1) for g in range(G)]
+    gy = [rnd(R, N, seed=90 + g) for g in range(G)]
+    dev = lambda ts, rg=True: [t.to(DEV).requires_grad_(rg) for t in ts]
+    xd, Wd, bd, gd, bed = dev(xs), dev(Ws), dev(bs), dev(gs), dev(be)
+    assert ops.tt_multi_ok(torch.empty(R, N, device=DEV), xd[0].detach(), None, torch.empty(N, K, device=DEV), torch.empty(N, device=DEV), N, K, R)
+    ys = ops.linear_ln_group(xd, Wd, bd, gd, bed, ct=BF16)
+    torch.autograd.backward(list(ys), [g.to(DEV) for g in gy])
+    for g in range(G):
+        ref = [t.double().requires_grad_(True) for t in (xs[g].bfloat16().float(), Ws[g].bfloat16().float(), bs[g], gs[g], be[g])]
+        y = torch.nn.functional.layer_norm(ref[0] @ ref[1].t() + ref[2], (N,), ref[3], ref[4], 1e-5)
+        y.backward(gy[g].double())
+        close(ys[g], y, BF16, f"y{g}")
+        for name, a, r in zip(("dx", "dW", "db", "dgamma", "dbeta"), (xd[g], Wd[g], bd[g], gd[g], bed[g]), ref):
+            close(a.grad, r.grad, BF16, f"{name}{g}")
+
+
+def test_row_ce_loss_can_be_modified_in_place():
+    """the scalar returned by cross_entropy_rows must not share a version counter with the tensors saved for its backward."""
+    from pq3d_amd.losses import cross_entropy_rows
+    x = rnd(64, 50, seed=5).to(DEV).requires_grad_(True)
+    t = torch.randint(0, 50, (64,), generator=torch.Generator().manual_seed(3)).to(DEV)
+    loss = cross_entropy_rows(x, t)
+    loss /= 4.0
+    loss += 1.0
+    loss.backward()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    (torch.nn.functional.cross_entropy(xr, t.cpu()) / 4.0 + 1.0).backward()
+    close(x.grad, xr.grad, F32, "dlogits")

@@ -137,3 +137,44 @@ def test_greedy_generation_through_the_head_and_budget():
     assert torch.equal(logits.argmax(-1), toks)
     with torch.no_grad():
         assert torch.equal(head(q, mask, None), toks)     # cached decoder, replayed
+
+
+@pytest.mark.parametrize("second_consumer", [False, True])
+def test_dropout_gradient_handover_equals_the_fallback_bit_for_bit(second_consumer):
+    """`ops.linear(..., drop=site, masked_grad=slot)` lets the NEXT rmsnorm's backward kernel write the dropout-masked
+    gradient of the projection (pq3d_amd/t5.py proj_residual / norm_res) instead of a launch of its own.  The hand-over is matched
+    by address: it must equal the `_dropout_apply` fallback bit for bit, and with a SECOND consumer of the projection's output
+    autograd hands the projection an accumulated gradient (another address) -> the fallback runs, still correct.
+    (A tensor hook that rewrites the norm's input gradient IN PLACE would not reach the pre-masked copy: unsupported, documented
+    in ops.linear.)"""
+    from pq3d_amd import _lib as L, ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    R, d = 96, 512
+    o = torch.randn(R, d, generator=g).to(dev)
+    x0 = torch.randn(R, d, generator=g).to(dev)
+    w = (torch.randn(d, d, generator=g) * 0.05).to(dev)
+    nw = (1 + 0.1 * torch.randn(d, generator=g)).to(dev)
+    gy = torch.randn(R, d, generator=g).to(dev)
+    drop = ops.make_drop(0.1, ops.drop_site(7 << 20, 0, 0), dev)
+
+    def run(handover):
+        oo, xx, ww, nn_ = (t.clone().requires_grad_(True) for t in (o, x0, w, nw))
+        slot = {} if handover else None
+        y = ops.linear(oo, ww, None, ct=L.BF16, residual=xx, drop=drop, masked_grad=slot)
+        h, y2 = ops.rmsnorm_res(y, nn_, 1e-6, grad_drop=(drop, slot) if handover else None)
+        loss = (h * gy).sum() + (y2 * gy).sum() * 0.5
+        if second_consumer:
+            loss = loss + (y * gy).sum() * 0.25
+        loss.backward()
+        return [t.grad.clone() for t in (oo, xx, ww, nn_)], slot
+
+    ref, _ = run(False)
+    got, slot = run(True)
+    for a, b in zip(got[:3], ref[:3]):     # d o, d residual, d W: everything downstream of the masked gradient
+        assert torch.equal(a, b)
+    assert torch.allclose(got[3], ref[3], rtol=1e-5, atol=1e-5)   # the norm weight's gradient: row-block atomics, order-dependent last bits
+    if second_consumer:
+        assert slot and "g" in slot, "the accumulated gradient has another address: the slot must stay unconsumed (fallback ran)"
+    else:
+        assert not slot, "the hand-over slot must have been consumed"
