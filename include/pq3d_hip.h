@@ -41,7 +41,10 @@ extern "C" {
 #define PQ3D_ACT_ADD 3 /* act_grad mode: C = acc + aux (fused residual / gradient accumulation) */
 #define PQ3D_ACT_PLANES 4 /* act_grad mode: v = act(alpha acc + bias) leaves as two bf16 planes, C = bf16(v), C2 = bf16(v - C)
                              (operand form of the split-bf16 attention, compute mode 'bf16x3'); plain bf16 NT products on the
-                             128-row-tile kernel only (gemm128.hip): any other call is refused */
+                             128-row-tile kernel only (gemm128.hip): any other call is refused.  With ct = PQ3D_BF16X3, bf16 A / B
+                             and A2 / B2 = their RESIDUAL planes the product itself is split-bf16, (A + A2)(B + B2)^T without the
+                             A2 B2 term, 3 MFMAs per term pair on one staging of the four planes (gemm_x3p.hip: N % 128 == 0,
+                             K % 32 == 0) -- the hoisted key/value projection of compute mode 'bf16x3' */
 
 const char* pq3d_last_error(void);
 int pq3d_version(void);

@@ -23,6 +23,7 @@ extern "C" int pq3d_debug_read(long long* out) { return (int)hipMemcpyFromSymbol
 #endif
 
 bool pq3d_gemm_nt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
+bool pq3d_gemm_x3p_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);     // gemm_x3p.hip
 bool pq3d_gemm_tt128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm128.hip
 bool pq3d_gemm_cv128_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s);   // gemm_cv128.hip
 bool pq3d_gemm_wk_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_t s, int* err);   // gemm_wk.hip
@@ -602,7 +603,13 @@ extern "C" int pq3d_gemm(const pq3d_gemm_desc* dp, void* stream) {
                "pq3d_gemm: colsum needs a transA/transB, non-batched, non-concatenated split-K GEMM");
   hipStream_t s = (hipStream_t)stream;
   pq3d_kdesc kd = make_kdesc(d);   // the kernels' compact form of the descriptor (common.h)
-  if (d.act_grad == PQ3D_ACT_PLANES) {   // bf16 hi / lo planes of the result: the 128-row-tile kernel's epilogue only
+  if (d.act_grad == PQ3D_ACT_PLANES) {   // bf16 hi / lo planes of the result: the 128-row-tile kernels' epilogues only
+    if (pq3d_gemm_x3p_try(d, kd, s)) {   // pre-split operands (A2 / B2 = residual planes), ct PQ3D_BF16X3: gemm_x3p.hip
+      PQ_LAUNCH_CHECK();
+      return 0;
+    }
+    PQ_CHECK_ARG(d.ct == PQ3D_BF16, "pq3d_gemm: PQ3D_ACT_PLANES with ct PQ3D_BF16X3 needs bf16 A / B / A2 / B2 planes, N % 128 == 0, "
+                                    "K % 32 == 0 (gemm_x3p.hip)");
     PQ_CHECK_ARG(d.splitk == 1 && pq3d_gemm_nt128_try(d, kd, s),
                  "pq3d_gemm: PQ3D_ACT_PLANES needs a plain bf16 NT product of the 128-row-tile kernel's shape (M >= 128, N % 128 == "
                  "0, K % 64 == 0, >= 256 tiles, bf16 C and C2)");

@@ -1139,9 +1139,9 @@ class _FusedDecoder(Function):
         ctx.wkv, ctx.wkvT = wkv, wkvT
         KV_lo = None
         if kv3:
-            # split-bf16 projection as THREE K-concatenated bf16 groups per output on the 128-row-tile kernel (lo.hi + hi.lo + hi.hi,
-            # small terms first), its fp32 result leaving as hi / lo bf16 planes (PQ3D_ACT_PLANES): KV = exactly the 'bf16'-mode
-            # tensor the backward reads, KV_lo the residual the forward's split-bf16 attention adds (csrc/attn_x3.hip)
+            # split-bf16 projection of pre-split operands (csrc/gemm_x3p.hip: the four planes of a k slice staged once, lo.hi + hi.lo
+            # + hi.hi per term pair), its fp32-grade result leaving as hi / lo bf16 planes (PQ3D_ACT_PLANES): KV = exactly the
+            # 'bf16'-mode tensor the backward reads, KV_lo the residual the forward's split-bf16 attention adds (csrc/attn_x3.hip)
             assert wkv is not None and kvin_lo is not None
             wkv_lo = torch.empty_like(wkv)
             ops.split_planes(f_srcs + [ca.multihead_attn.in_proj_weight.detach()[d:] for i in range(Ln) for ca in cas[i]],
@@ -1149,23 +1149,20 @@ class _FusedDecoder(Function):
                              [kvin_lo[0, u] for u in range(U)] + [kvin_lo[1, u] for u in range(U)] +
                              [wkv_lo[i, j] for i in range(Ln) for j in range(M)])
             KV_lo = torch.empty_like(KV)
-            A, Bw, bs, Cs, C2 = [], [], [], [], []
+            A, A2, Bw, B2, bs, Cs, C2 = [], [], [], [], [], [], []
             for i in range(Ln):
                 for j, ca in enumerate(cas[i]):
                     b = ca.multihead_attn.in_proj_bias.detach()
                     u = src[i][j]
                     for t in (0, 1):
-                        a_hi, a_lo = kvin[t, u], kvin_lo[t, u]
-                        w_hi, w_lo = wkv[i, j, t * d:(t + 1) * d], wkv_lo[i, j, t * d:(t + 1) * d]
-                        A += [a_lo, a_hi, a_hi]
-                        Bw += [w_hi, w_lo, w_hi]
-                        bs += [b[(1 + t) * d:(2 + t) * d], None, None]
-                        Cs += [KV[i, t, j], None, None]
-                        C2 += [KV_lo[i, t, j], None, None]
-            per = (MAXG // 3) * 3
-            for s in range(0, len(A), per):
-                L.gemm(M=Rk, N=d, K=d, A=A[s:s + per], B=Bw[s:s + per], bias=bs[s:s + per], Cs=Cs[s:s + per], C2=C2[s:s + per],
-                       ct=ct, lda=d, ldb=d, ldc=d, kconcat=3, act_grad="planes")
+                        A.append(kvin[t, u]); A2.append(kvin_lo[t, u])
+                        Bw.append(wkv[i, j, t * d:(t + 1) * d]); B2.append(wkv_lo[i, j, t * d:(t + 1) * d])
+                        bs.append(b[(1 + t) * d:(2 + t) * d])
+                        Cs.append(KV[i, t, j]); C2.append(KV_lo[i, t, j])
+            for s in range(0, len(A), MAXG):
+                sl = slice(s, s + MAXG)
+                L.gemm(M=Rk, N=d, K=d, A=A[sl], A2=A2[sl], B=Bw[sl], B2=B2[sl], bias=bs[sl], Cs=Cs[sl], C2=C2[sl],
+                       ct=L.BF16X3, lda=d, ldb=d, ldc=d, act_grad="planes")
         else:
             A, A2, Bw, bs, Cs = [], [], [], [], []
             for i in range(Ln):

@@ -70,6 +70,29 @@ def test_plane_gemm_matches_float64(M, N, K, outs):
         assert float((his[o].float().cpu().double() - ref).abs().max()) <= 2.0 ** -8 * s
 
 
+@pytest.mark.parametrize("M,N,K,groups", [(8192, 256, 256, 24), (130, 256, 256, 1), (1000, 768, 768, 2), (300, 128, 32, 32), (1, 128, 64, 3)])
+def test_presplit_plane_gemm_matches_float64(M, N, K, groups):
+    """csrc/gemm_x3p.hip: ct BF16X3 on pre-split operands (A2 / B2 = residual planes), planes out -- one launch for all groups."""
+    xs = [rnd(M, K, seed=10 + o) for o in range(min(groups, 3))]
+    ws = [rnd(N, K, seed=20 + o, scale=K ** -0.5) for o in range(groups)]
+    bs = [rnd(N, seed=30 + o) for o in range(groups)]
+    xp = [tuple(t.to(DEV) for t in planes(x)) for x in xs]
+    A, A2, B, B2, bias, Cs, C2 = [], [], [], [], [], [], []
+    for o in range(groups):
+        wh, wl = (t.to(DEV) for t in planes(ws[o]))
+        A.append(xp[o % len(xs)][0]); A2.append(xp[o % len(xs)][1]); B.append(wh); B2.append(wl)
+        bias.append(bs[o].to(DEV))
+        Cs.append(torch.empty(M, N, dtype=torch.bfloat16, device=DEV)); C2.append(torch.empty(M, N, dtype=torch.bfloat16, device=DEV))
+    L.gemm(M=M, N=N, K=K, A=A, A2=A2, B=B, B2=B2, bias=bias, Cs=Cs, C2=C2, ct=L.BF16X3, lda=K, ldb=K, ldc=N, act_grad="planes")
+    for o in range(groups):
+        ref = xs[o % len(xs)].double() @ ws[o].double().t() + bs[o].double()
+        got = Cs[o].float().cpu().double() + C2[o].float().cpu().double()
+        s = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 3e-5 * s, (o, float((got - ref).abs().max()) / s)
+        assert torch.equal(Cs[o].cpu(), (Cs[o].float() + C2[o].float()).to(torch.bfloat16).cpu()) or \
+            float((Cs[o].float().cpu().double() - ref).abs().max()) <= 2.0 ** -8 * s
+
+
 def test_plane_gemm_refuses_other_layouts():
     x = torch.zeros(256, 64, dtype=torch.bfloat16, device=DEV)
     w = torch.zeros(100, 64, dtype=torch.bfloat16, device=DEV)   # N % 128 != 0
