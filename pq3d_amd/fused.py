@@ -1182,15 +1182,20 @@ class _FusedDecoder(Function):
         if spec.prompt:
             prompt, prompt_kpm = ops._c(prompt), ops._c(prompt_kpm)
             T = prompt.shape[1]
-            PKV = torch.empty(Ln, 2, B, T, d, dtype=ad, device=dev)
+            # compute mode 'bf16x3': the (short) prompt memory's cross-attention runs at fp32 grade on kernels that exist -- split-bf16
+            # projections with fp32 K / V, the exact-f32 attention -- and leaves bf16 copies as the tape of the single-bf16 backward
+            PKV_f = torch.empty(Ln, 2, B, T, d, dtype=torch.float32, device=dev) if kv3 else None
+            PKV = torch.empty(Ln, 2, B, T, d, dtype=ad, device=dev) if not kv3 else None
             Ap, Bp, bp, Cp = [], [], [], []
             for i in range(Ln):
                 w, b = pcas[i].multihead_attn.in_proj_weight.detach(), pcas[i].multihead_attn.in_proj_bias.detach()
                 Ap += [prompt, prompt]; Bp += [w[d:2 * d], w[2 * d:]]; bp += [b[d:2 * d], b[2 * d:]]
-                Cp += [PKV[i, 0], PKV[i, 1]]
+                Cp += [(PKV_f if kv3 else PKV)[i, 0], (PKV_f if kv3 else PKV)[i, 1]]
             for s_ in range(0, len(Ap), MAXG):
                 L.gemm(M=B * T, N=d, K=d, A=Ap[s_:s_ + MAXG], B=Bp[s_:s_ + MAXG], bias=bp[s_:s_ + MAXG], Cs=Cp[s_:s_ + MAXG],
-                       ct=ct, lda=d, ldb=d, ldc=d)
+                       ct=cq if kv3 else ct, lda=d, ldb=d, ldc=d)
+            if kv3:
+                PKV = ops.cast_bf16([PKV_f])[0]
         kpm_all = None
         if not spec.use_self_mask:
             st = spec.stacked_kpm   # [M, B, Ns] already stacked by the model (same memory order): no copy
@@ -1327,14 +1332,18 @@ class _FusedDecoder(Function):
                     dr_pa = spec.drop(pc, app, ops.DROP_CA_ATTN, dev, m=4)   # sequential slot 4 + 0 (modules.QueryEncoderLayer)
                     dr_pr = spec.drop(pc, app, ops.DROP_CA_RES, dev, m=4)
                     wp, bpq = pc.multihead_attn.in_proj_weight.detach(), pc.multihead_attn.in_proj_bias.detach()
-                    qp = torch.empty(B, Nq, d, dtype=ad, device=dev)
+                    adp = torch.float32 if kv3 else ad
+                    qp = torch.empty(B, Nq, d, dtype=adp, device=dev)
                     L.gemm(M=R, N=d, K=d, A=[x1], A2=[qpos], B=[wp[:d]], bias=[bpq[:d]], Cs=[qp], ct=cq, lda=d, ldb=d, ldc=d)
-                    o_p = torch.empty(B, Nq, d, dtype=ad, device=dev)
+                    o_p = torch.empty(B, Nq, d, dtype=adp, device=dev)
                     lse_p = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
-                    _attn(qp, PKV[i, 0], PKV[i, 1], o_p, lse_p, H, ct, True, kpm=prompt_kpm, drop=dr_pa)
+                    _attn(qp, (PKV_f if kv3 else PKV)[i, 0], (PKV_f if kv3 else PKV)[i, 1], o_p, lse_p, H, L.F32 if kv3 else ct, True,
+                          kpm=prompt_kpm, drop=dr_pa)
                     opp = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                     L.gemm(M=R, N=d, K=d, A=[o_p], B=[pc.multihead_attn.out_proj.weight.detach()],
-                           bias=[pc.multihead_attn.out_proj.bias.detach()], Cs=[opp], ct=ct, lda=d, ldb=d, ldc=d)
+                           bias=[pc.multihead_attn.out_proj.bias.detach()], Cs=[opp], ct=cq if kv3 else ct, lda=d, ldb=d, ldc=d)
+                    if kv3:   # the backward's bf16 tape
+                        qp, o_p = ops.cast_bf16([qp, o_p])
                     x1s, mean_p, rstd_p = _ln_fwd(x1, [opp], [pc.norm.weight.detach()], [pc.norm.bias.detach()], pc.norm.eps,
                                                   None, Nq, drop=dr_pr)
                     rec.update(qp=qp, o_p=o_p, lse_p=lse_p, opp=opp, mean_p=mean_p, rstd_p=rstd_p, dr_pa=dr_pa, dr_pr=dr_pr)
@@ -1509,12 +1518,14 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
                             for a in range(n_app)]).contiguous()
     ct = L.BF16 if layer0.compute in ("bf16", "bf16x3") else L.F32
     # compute mode 'bf16x3': the split-bf16 key/value side where its kernels cover the shape (128-row-tile plane GEMM: d % 128 == 0;
-    # csrc/attn_x3.hip: d_h = 32, <= 256 queries; scene memories only), the exact-f32 kernels otherwise -- same accuracy contract
+    # csrc/attn_x3.hip: d_h = 32, <= 256 queries), the exact-f32 kernels otherwise -- same accuracy contract
     kv3 = False
     if layer0.compute == "bf16x3":
         B_, Ns_, d_ = uniq[0].shape
         kv3 = (d_ % 128 == 0 and d_ == 32 * enc.num_heads and x0.shape[1] <= 256 and B_ * Ns_ >= 128 and 2 * len(uniq) <= MAXG and
-               len(mems) * Ln_ <= MAXG and prompt is None and all(f.dtype == torch.float32 for f in uniq))
+               len(mems) * Ln_ <= MAXG and all(f.dtype == torch.float32 for f in uniq) and
+               (prompt is None or (prompt.dtype == torch.float32 and (prompt.shape[0] * prompt.shape[1] * d_) % 8 == 0 and
+                                   (x0.shape[0] * x0.shape[1] * d_) % 8 == 0)))
         if not kv3:
             ct = L.F32
     drop_base, mh_drop = None, False

@@ -154,6 +154,18 @@ def split_planes(srcs, adds, his, los) -> None:
                 "pq3d_split_planes")
 
 
+def cast_bf16(ts):
+    """bf16 copies of same-sized fp32 tensors in one launch (pq3d_add_cast): the bf16 tape of a split-bf16 forward."""
+    outs = [_empty(t.shape, dtype=torch.bfloat16, device=t.device) for t in ts]
+    n = ts[0].numel()
+    assert all(t.numel() == n and t.dtype == torch.float32 and t.is_contiguous() for t in ts) and n % 8 == 0
+    for i in range(0, len(ts), L.MAXG):
+        k = len(ts[i:i + L.MAXG])
+        arr = lambda xs: (C.c_void_p * k)(*[L.ptr(t) for t in xs])
+        L.check(L.lib().pq3d_add_cast(arr(ts[i:i + k]), arr([None] * k), arr(outs[i:i + k]), k, BF16, n, L.stream()), "pq3d_add_cast")
+    return outs
+
+
 def colsum(x2d: torch.Tensor) -> torch.Tensor:
     R, N = x2d.shape
     out = _empty(N, dtype=torch.float32, device=x2d.device)
