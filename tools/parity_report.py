@@ -53,19 +53,19 @@ def one(name, args, compute, dev="cuda"):
         pl = [n for n in og if "pairwise_loc_fc" in n]
         plw = max((float((g[n].grad.detach().float().cpu() - og[n]).norm() / float(og[n].norm())) for n in pl), default=float("nan"))
         l2n = f"{l2n}   [pairwise_loc_fc worst relL2 {plw:.2e}]"
-    print(f"{name:22s} {compute:6s} {q:9.2e} {head:9.2e} {ml:10.2e} {fl:10.2e} {le:9.2e} {l2:11.2e} {1 - cos:10.2e}  {l2n}")
+    print(f"{name:22s} {compute:7s} {q:9.2e} {head:9.2e} {ml:10.2e} {fl:10.2e} {le:9.2e} {l2:11.2e} {1 - cos:10.2e}  {l2n}")
 
 
 def main():
-    print(f"{'case':22s} {'mode':6s} {'query':>9s} {'head':>9s} {'mask-logit':>10s} {'flip-rate':>10s} {'loss':>9s} "
+    print(f"{'case':22s} {'mode':7s} {'query':>9s} {'head':>9s} {'mask-logit':>10s} {'flip-rate':>10s} {'loss':>9s} "
           f"{'worst-relL2':>11s} {'1-cos(all)':>10s}  worst-gradient parameter     (all vs the fp32 oracle; max|err|/max|ref|)")
     for name in util.model_fixtures():
         _z, args = util.load_fixture(name)
-        for compute in ("fp32", "bf16"):
+        for compute in ("fp32", "bf16x3", "bf16"):
             one(name, args, compute)
     from tests.test_gpu_fullsize import C2, C4, C4_PINNED
     for name, args in (("FULL c2", C2), ("FULL c4 live masks", C4), ("FULL c4 pinned masks", C4_PINNED)):
-        for compute in ("fp32", "bf16"):
+        for compute in ("fp32", "bf16x3", "bf16"):
             one(name, args, compute)
 
 
