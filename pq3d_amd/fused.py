@@ -1450,6 +1450,8 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
     layer0 = enc.unified_encoder[0]
     if layer0.structure not in ("parallel", "mixed"):
         raise NotImplementedError("fused path covers structure='parallel' and 'mixed'")
+    if any(getattr(m_, "normalize_before", False) or getattr(m_, "spatial_attn_fusion", "mul") != "mul" for m_ in enc.modules()):
+        raise NotImplementedError("fused path: post-norm layers with spatial_attn_fusion='mul' (the shipped configurations)")
     training = enc.training
     mems = [m for m in layer0.memories if training or m not in layer0.drop_memories_test]
     prompt = pmask = None

@@ -30,7 +30,7 @@ class Cfg(dict):
             raise AttributeError(k) from e
 
 
-REGISTRY = {c.__name__: c for c in (M.QueryMaskEncoder, M.QueryEncoder, M.MaskHeadSegLevel, M.GroundHead,
+REGISTRY = {c.__name__: c for c in (M.QueryMaskEncoder, M.QueryEncoder, M.MaskHeadSegLevel, M.GroundHead, M.GroundHeadV1,
                                     M.ObjectEncoder, M.T5, M.PCDMask3DSegLevelEncoder)}
 
 

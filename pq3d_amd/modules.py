@@ -210,12 +210,12 @@ class _PostNormBase(nn.Module):
 
 
 class CrossAttentionLayer(_PostNormBase):
-    """query_encoder.py:257-351 (post-norm, add_zero_attn=True)."""
+    """query_encoder.py:257-351 (add_zero_attn=True; post-norm :288-307 as every shipped config uses it, pre-norm :309-335 on the
+    modular path: residual + dropout ride the out-projection's GEMM epilogue)."""
 
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False, batch_first=False):
         super().__init__()
-        if normalize_before:
-            raise NotImplementedError("pre-norm is not used by the reference decoder (prenorm=False)")
+        self.normalize_before = bool(normalize_before)
         self.multihead_attn = _MHAParams(d_model, nhead)
         self.norm = nn.LayerNorm(d_model)
         self.nhead = nhead
@@ -223,8 +223,9 @@ class CrossAttentionLayer(_PostNormBase):
         _xavier(self)
 
     def branch(self, tgt, memory, attn_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
-               row_open=None, _drop=None, _m=0) -> torch.Tensor:
-        """out_proj(MHA(tgt+query_pos, memory+pos, memory)) -- the pre-residual branch output, fp32."""
+               row_open=None, _drop=None, _m=0, residual=None, res_drop=None) -> torch.Tensor:
+        """out_proj(MHA(tgt+query_pos, memory+pos, memory)) -- the pre-residual branch output, fp32 (pre-norm: `residual +
+        dropout(.)` formed by the out-projection's epilogue)."""
         ct, d = self.ct, tgt.shape[-1]
         if self.compute == "bf16x3":
             # modular path (structures the fused executor does not cover): the key/value side on the exact-f32 kernels, forward and
@@ -239,23 +240,27 @@ class CrossAttentionLayer(_PostNormBase):
         v = ops.linear(memory, w[2 * d:], b[2 * d:], ct=ct, out_dtype=ad)
         o = ops.attention(q, k, v, H=self.nhead, ct=ct, zero_attn=True, kpm=memory_key_padding_mask, mask=attn_mask,
                           row_open=row_open, drop=self._drop(_drop, ops.DROP_CA_ATTN, tgt.device, _m))
-        return ops.linear(o, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, ct=ct)
+        return ops.linear(o, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, ct=ct, residual=residual,
+                          drop=res_drop)
 
     def forward(self, tgt, memory, attn_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
                 row_open=None, _drop=None, _m=0):
         ctx = self._drop_ctx(tgt.device, _drop)
+        if self.normalize_before:   # query_encoder.py:309-335: tgt + dropout(MHA(norm(tgt) + query_pos, memory + pos, memory))
+            t2 = ops.add_layernorm(None, [tgt], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+            return self.branch(t2, memory, attn_mask, memory_key_padding_mask, pos, query_pos, row_open, _drop=ctx, _m=_m,
+                               residual=tgt, res_drop=self._drop(ctx, ops.DROP_CA_RES, tgt.device, _m))
         o = self.branch(tgt, memory, attn_mask, memory_key_padding_mask, pos, query_pos, row_open, _drop=ctx, _m=_m)
         return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps, coef=None,
                                  drop=self._drop(ctx, ops.DROP_CA_RES, tgt.device, _m))
 
 
 class SelfAttentionLayer(_PostNormBase):
-    """query_encoder.py:184-254 (stock MHA, no zero-attn)."""
+    """query_encoder.py:184-254 (stock MHA, no zero-attn; pre-norm :229-243 on the modular path)."""
 
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False, batch_first=False):
         super().__init__()
-        if normalize_before:
-            raise NotImplementedError("pre-norm is not used by the reference decoder (prenorm=False)")
+        self.normalize_before = bool(normalize_before)
         self.self_attn = _MHAParams(d_model, nhead)
         self.norm = nn.LayerNorm(d_model)
         self.nhead = nhead
@@ -268,50 +273,65 @@ class SelfAttentionLayer(_PostNormBase):
         ct, d = self.ct_q, tgt.shape[-1]
         ctx = self._drop_ctx(tgt.device, _drop)
         w, b = self.self_attn.in_proj_weight, self.self_attn.in_proj_bias
-        q = ops.linear(tgt, w[:d], b[:d], x2=query_pos, ct=ct)
-        k = ops.linear(tgt, w[d:2 * d], b[d:2 * d], x2=query_pos, ct=ct)
-        v = ops.linear(tgt, w[2 * d:], b[2 * d:], ct=ct)
+        src = tgt
+        if self.normalize_before:   # :229-243: q = k = norm(tgt) + query_pos, value = norm(tgt)
+            src = ops.add_layernorm(None, [tgt], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+        q = ops.linear(src, w[:d], b[:d], x2=query_pos, ct=ct)
+        k = ops.linear(src, w[d:2 * d], b[d:2 * d], x2=query_pos, ct=ct)
+        v = ops.linear(src, w[2 * d:], b[2 * d:], ct=ct)
         o = ops.attention(q, k, v, H=self.nhead, ct=ops.sa_ct(self.ct), kpm=tgt_key_padding_mask, mask=attn_mask,
                           drop=self._drop(ctx, ops.DROP_SA_ATTN, tgt.device))
+        if self.normalize_before:
+            return ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, ct=ct, residual=tgt,
+                              drop=self._drop(ctx, ops.DROP_SA_RES, tgt.device))
         o = ops.linear(o, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, ct=ct)
         return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
                                  drop=self._drop(ctx, ops.DROP_SA_RES, tgt.device))
 
 
 class MultiHeadAttentionSpatial(_PostNormBase):
-    """modules/layers/transformers.py:158-240, spatial_attn_fusion='mul', spatial_multihead=True."""
+    """modules/layers/transformers.py:158-240, spatial_multihead=True, spatial_attn_fusion 'mul' (what the decoder instantiates,
+    query_encoder.py:411-416: softmax(log(clamp(relu(W loc), 1e-6)) + qk)) or 'bias' (softmax(W loc + qk), :196-203, :228-230).
+    'add', 'ctx' and 'cond' belong to model families outside the query-decoder path (TransformerSpatialDecoderLayer) and raise."""
 
     def __init__(self, d_model, n_head, dropout=0.1, spatial_multihead=True, spatial_dim=5, spatial_attn_fusion="mul"):
         super().__init__()
-        if spatial_attn_fusion != "mul" or not spatial_multihead or spatial_dim != 5:
-            raise NotImplementedError("only the configuration the decoder instantiates is implemented "
-                                      "(fusion='mul', multihead, spatial_dim=5; query_encoder.py:411-416)")
+        if spatial_attn_fusion not in ("mul", "bias") or not spatial_multihead or spatial_dim != 5:
+            raise NotImplementedError("spatial_attn_fusion 'mul' / 'bias', multihead, spatial_dim=5 are implemented "
+                                      "(the decoder instantiates 'mul': query_encoder.py:411-416)")
+        self.spatial_attn_fusion = spatial_attn_fusion
         assert d_model % n_head == 0
         self.n_head, self.d_model = n_head, d_model
         self.w_qs, self.w_ks, self.w_vs = (nn.Linear(d_model, d_model) for _ in range(3))
         self.fc = nn.Linear(d_model, d_model)
         self.pairwise_loc_fc = nn.Linear(spatial_dim, n_head)
 
-    def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, q_pos=None, k_pos=None):
+    def forward(self, q, k, v, pairwise_locs, key_padding_mask=None, q_pos=None, k_pos=None, residual=None, res_drop=None):
         """Returns only the output (the reference also returns the fused attention map, which the decoder
-        discards, query_encoder.py:447).  q_pos/k_pos are added to q/k inside the projection kernels."""
+        discards, query_encoder.py:447).  q_pos/k_pos are added to q/k inside the projection kernels; residual / res_drop: the
+        pre-norm layer's `residual + dropout(.)` in fc's epilogue."""
         ct = self.ct_q   # as SelfAttentionLayer: fp32-grade projections, exact-f32 attention core
         qh = ops.linear(q, self.w_qs.weight, self.w_qs.bias, x2=q_pos, ct=ct)
         kh = ops.linear(k, self.w_ks.weight, self.w_ks.bias, x2=k_pos, ct=ct)
         vh = ops.linear(v, self.w_vs.weight, self.w_vs.bias, ct=ct)
-        bias = ops.spatial_bias(pairwise_locs, self.pairwise_loc_fc.weight, self.pairwise_loc_fc.bias)
+        if self.spatial_attn_fusion == "mul":
+            bias = ops.spatial_bias(pairwise_locs, self.pairwise_loc_fc.weight, self.pairwise_loc_fc.bias)
+        else:   # 'bias': the plain 5 -> H projection as the additive term (a [B L T, 5] x [5, H] product at fp32 grade)
+            Bq, Lq, Tk, _ = pairwise_locs.shape
+            pl = ops.linear(pairwise_locs.reshape(Bq * Lq * Tk, -1).contiguous(), self.pairwise_loc_fc.weight,
+                            self.pairwise_loc_fc.bias, ct=F32)
+            bias = pl.view(Bq, Lq, Tk, self.n_head).permute(0, 3, 1, 2).contiguous()
         o = ops.attention(qh, kh, vh, H=self.n_head, ct=ops.sa_ct(self.ct), kpm=key_padding_mask, bias=bias)
-        return ops.linear(o, self.fc.weight, self.fc.bias, ct=ct)
+        return ops.linear(o, self.fc.weight, self.fc.bias, ct=ct, residual=residual, drop=res_drop)
 
 
 class SpatialSelfAttentionLayer(_PostNormBase):
-    """query_encoder.py:402-483."""
+    """query_encoder.py:402-483 (pre-norm :453-468 on the modular path -- NB its VALUE input is the un-normalised tgt)."""
 
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False, batch_first=False,
                  spatial_multihead=True, spatial_dim=5, spatial_attn_fusion="mul"):
         super().__init__()
-        if normalize_before:
-            raise NotImplementedError("pre-norm is not used by the reference decoder (prenorm=False)")
+        self.normalize_before = bool(normalize_before)
         self.self_attn = MultiHeadAttentionSpatial(d_model, nhead, dropout=dropout, spatial_multihead=spatial_multihead,
                                                    spatial_dim=spatial_dim, spatial_attn_fusion=spatial_attn_fusion)
         self.norm = nn.LayerNorm(d_model)
@@ -320,6 +340,10 @@ class SpatialSelfAttentionLayer(_PostNormBase):
 
     def forward(self, tgt, attn_mask=None, tgt_key_padding_mask=None, query_pos=None, pairwise_locs=None, _drop=None):
         ctx = self._drop_ctx(tgt.device, _drop)
+        if self.normalize_before:
+            t2 = ops.add_layernorm(None, [tgt], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+            return self.self_attn(t2, t2, tgt, pairwise_locs, key_padding_mask=tgt_key_padding_mask, q_pos=query_pos, k_pos=query_pos,
+                                  residual=tgt, res_drop=self._drop(ctx, ops.DROP_SA_RES, tgt.device))
         o = self.self_attn(tgt, tgt, tgt, pairwise_locs, key_padding_mask=tgt_key_padding_mask, q_pos=query_pos,
                            k_pos=query_pos)
         return ops.add_layernorm(tgt, [o], [self.norm.weight], [self.norm.bias], eps=self.norm.eps,
@@ -327,12 +351,11 @@ class SpatialSelfAttentionLayer(_PostNormBase):
 
 
 class FFNLayer(_PostNormBase):
-    """query_encoder.py:354-399."""
+    """query_encoder.py:354-399 (pre-norm :390-394 on the modular path)."""
 
     def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
-        if normalize_before:
-            raise NotImplementedError("pre-norm is not used by the reference decoder (prenorm=False)")
+        self.normalize_before = bool(normalize_before)
         if activation not in ("relu", "gelu"):
             raise RuntimeError(f"activation function currently support relu/gelu, not {activation}")
         self.linear1 = nn.Linear(d_model, dim_feedforward)
@@ -345,6 +368,12 @@ class FFNLayer(_PostNormBase):
     def forward(self, tgt, _drop=None):
         ct = self.ct_q   # split-bf16 in 'bf16' mode: the ReLU kink is hit at fp32 grade, the hidden activations stay fp32
         ctx = self._drop_ctx(tgt.device, _drop)
+        if self.normalize_before:   # tgt + dropout(linear2(dropout(act(linear1(norm(tgt))))))
+            t2 = ops.add_layernorm(None, [tgt], [self.norm.weight], [self.norm.bias], eps=self.norm.eps)
+            h = ops.linear(t2, self.linear1.weight, self.linear1.bias, ct=ct, act=self.activation, out_dtype=ops.act_dtype(ct),
+                           drop=self._drop(ctx, ops.DROP_FFN_INNER, tgt.device))
+            return ops.linear(h, self.linear2.weight, self.linear2.bias, ct=ct, residual=tgt,
+                              drop=self._drop(ctx, ops.DROP_FFN_RES, tgt.device))
         h = ops.linear(tgt, self.linear1.weight, self.linear1.bias, ct=ct, act=self.activation,
                        out_dtype=ops.act_dtype(ct), drop=self._drop(ctx, ops.DROP_FFN_INNER, tgt.device))
         # linear2's K range is split into 4 partial GEMMs whose fp32 outputs the LayerNorm kernel adds in a fixed order
@@ -418,10 +447,17 @@ class QueryEncoderLayer(_PostNormBase):
         def parallel_ca(q, memories):
             assert "prompt" not in memories
             cas = [self.memory2ca[m] for m in memories]
-            outs = [ca.branch(q, **ca_args(m), _drop=dctx, _m=j) for j, (ca, m) in enumerate(zip(cas, memories))]
             coef = None
             if self.training and self.memory_dropout > 0.0:  # query_encoder.py:145-151
                 coef = memory_keep_coef(B, len(memories), self.memory_dropout, q.device, _mem_keep)  # [M,B]
+            if cas and cas[0].normalize_before:
+                # pre-norm (not a shipped configuration): every memory's layer output is q + dropout(branch(norm(q))); their (masked)
+                # mean (query_encoder.py:145-152) has no LayerNorm to merge into -- a plain weighted sum of the M outputs
+                full = [ca(q, **ca_args(m), _drop=dctx, _m=j) for j, (ca, m) in enumerate(zip(cas, memories))]
+                if coef is None:
+                    return torch.stack(full, 0).mean(0)
+                return (torch.stack(full, 0) * coef[:, :, None, None]).sum(0)
+            outs = [ca.branch(q, **ca_args(m), _drop=dctx, _m=j) for j, (ca, m) in enumerate(zip(cas, memories))]
             return ops.add_layernorm(q, outs, [c.norm.weight for c in cas], [c.norm.bias for c in cas],
                                      eps=cas[0].norm.eps, coef=coef,
                                      drop=cas[0]._drop(dctx, ops.DROP_CA_RES, q.device) if cas else None)
@@ -676,6 +712,33 @@ class MaskHeadSegLevel(_PostNormBase):
         if offline_attn_masks is not None:
             attn_mask = offline_attn_masks
         return cls_logits, mask_logits, attn_mask
+
+
+class GroundHeadV1(_PostNormBase):
+    """modules/heads/grounding_head.py:7-40: the grounding logits plus three auxiliary classification heads (text token 0, object
+    embeddings, pre-fusion object embeddings), each a get_mlp_head."""
+
+    def __init__(self, cfg, input_size=768, hidden_size=768, sem_cls_size=607, dropout=0.3, detach_all_aux_loss=False):
+        super().__init__()
+        self.og3d_head = get_mlp_head(input_size, hidden_size, 1, dropout=dropout)
+        self.txt_clf_head = get_mlp_head(input_size, hidden_size, sem_cls_size, dropout=dropout)
+        self.obj3d_clf_head = get_mlp_head(input_size, hidden_size, sem_cls_size, dropout=dropout)
+        self.obj3d_clf_pre_head = get_mlp_head(input_size, hidden_size, sem_cls_size, dropout=dropout)
+        self.detach_all_aux_loss = detach_all_aux_loss
+        self.dropout_p, self._drop_base = float(dropout), DROP_BASE_GROUND_HEAD
+
+    def forward(self, txt_embeds, obj_embeds, obj_pre_embeds, obj_masks, **kwargs):
+        dev = obj_embeds.device
+        ctx = self._head_ctx(dev)
+        dr = lambda m: self._drop(ctx, ops.DROP_MLP_HEAD, dev, m)
+        og3d = mlp_head_forward(self.og3d_head, obj_embeds, self.ct, fill_flag=obj_masks.logical_not(), fill_value=float("-inf"),
+                                drop=dr(0)).squeeze(2)
+        if self.detach_all_aux_loss:
+            txt_embeds, obj_embeds, obj_pre_embeds = txt_embeds.detach(), obj_embeds.detach(), obj_pre_embeds.detach()
+        txt = mlp_head_forward(self.txt_clf_head, txt_embeds[:, 0].contiguous(), self.ct, drop=dr(1))
+        obj = mlp_head_forward(self.obj3d_clf_head, obj_embeds, self.ct, drop=dr(2))
+        pre = mlp_head_forward(self.obj3d_clf_pre_head, obj_pre_embeds, self.ct, drop=dr(3))
+        return txt, obj, pre, og3d
 
 
 class GroundHead(_PostNormBase):

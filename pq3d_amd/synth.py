@@ -109,6 +109,24 @@ def prompt_loc_inputs(B: int, T: int, seed: int = 77) -> Dict[str, torch.Tensor]
             "prompt_type": torch.full((B,), 3, dtype=torch.long)}
 
 
+def variant_inputs(B=2, Ns=50, Nq=12, d=64, seed=31):
+    """Inputs of fixture F21 (pre-norm layers, 'bias' spatial fusion, GroundHeadV1), shared by make_golden.py and the tests:
+    a query state, two scene memories with ragged padding, position embeddings, query centres."""
+    r = np.random.default_rng(seed)
+    t = lambda *sh: torch.from_numpy(r.standard_normal(sh).astype(np.float32))
+    vl = r.integers(Ns // 2, Ns + 1, size=B); vl[0] = Ns
+    pad = torch.from_numpy(np.arange(Ns)[None, :] >= vl[:, None])          # True = padded
+    ql = r.integers(Nq // 2, Nq + 1, size=B); ql[0] = Nq
+    qpad = torch.from_numpy(np.arange(Nq)[None, :] >= ql[:, None])
+    feats = {}
+    for m in ("voxel", "mv"):
+        f = t(B, Ns, d); f[pad] = 0.0
+        feats[m] = f
+    return dict(query=t(B, Nq, d), qpos=t(B, Nq, d), fpos=t(B, Ns, d), feats=feats, pad=pad, qpad=qpad,
+                centers=torch.from_numpy(r.uniform(0, 4, (B, Nq, 3)).astype(np.float32)),
+                txt=t(B, 5, d), pre=t(B, Nq, d))
+
+
 def criterion_inputs(seed=21, B=3, Ns=70, Nq=12, C=21, n_layers=3, seg_len=(70, 55, 61), n_inst=(5, 9, 3)):
     """Synthetic predictions / targets of the F9 criterion fixture (also rebuilt by the tests)."""
     r = np.random.default_rng(seed)

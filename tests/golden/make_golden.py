@@ -329,6 +329,51 @@ def run_encoder_case(ref, name, *, B, Ns, Nq, d, H, L, memories, structure, spat
     save(name, out)
 
 
+def run_variants_case(ref, name, *, d=64, H=4, seed=17):
+    """F21: variants the reference defines beside the shipped configuration -- pre-norm sublayers (QueryEncoderLayer(prenorm=True):
+    query_encoder.py:97-106, forward_pre :229-243, :309-335, :390-394, :453-468) with a spatial ('sequential') and a plain
+    ('parallel') self-attention layer, MultiHeadAttentionSpatial with spatial_attn_fusion='bias' (transformers.py:196-230), and
+    GroundHeadV1 (grounding_head.py:7-40)."""
+    v = synth.variant_inputs(d=d)
+    out = {"meta/args": np.array(repr(dict(d=d, H=H, seed=seed)))}
+    pl = ref.utils.calc_pairwise_locs(v["centers"], None, pairwise_rel_type="center", spatial_dist_norm=True, spatial_dim=5)
+    for tag, spatial, structure in (("pre_spatial_seq", True, "sequential"), ("pre_plain_par", False, "parallel")):
+        torch.manual_seed(0)
+        layer = ref.qe.QueryEncoderLayer(d, H, ["voxel", "mv"], dropout=0.1, prenorm=True, spatial_selfattn=spatial, structure=structure)
+        sd = synth.fill_module(layer, seed)
+        layer.eval()
+        out[f"meta/{tag}/weights_checksum"] = np.float64(synth.state_checksum(sd))
+        q = v["query"].clone().requires_grad_(True)
+        input_dict = {"query": (q, v["qpad"], v["qpos"])}
+        for m in ("voxel", "mv"):
+            input_dict[m] = [v["feats"][m], v["pad"], v["fpos"]]
+        y = layer(q, input_dict, pl if spatial else None)
+        put(out, f"{tag}/out", y)
+        (y * loss_weight("query", y.shape)).mean().backward()
+        put(out, f"{tag}/grad_in/query", q.grad)
+        for n, p in layer.named_parameters():
+            if p.grad is not None:
+                put(out, f"{tag}/grad/" + n, p.grad, MAX_GRAD)
+    tr = importlib.import_module("modules.layers.transformers")
+    torch.manual_seed(0)
+    msa = tr.MultiHeadAttentionSpatial(d, H, dropout=0.0, spatial_multihead=True, spatial_dim=5, spatial_attn_fusion="bias")
+    sd = synth.fill_module(msa, seed + 1)
+    msa.eval()
+    out["meta/msa_bias/weights_checksum"] = np.float64(synth.state_checksum(sd))
+    x = v["query"] + v["qpos"]
+    yo, _ = msa(x, x, v["query"], pl, key_padding_mask=v["qpad"])
+    put(out, "msa_bias/out", yo)
+    torch.manual_seed(0)
+    gh = ref.gh.GroundHeadV1(None, input_size=d, hidden_size=d, sem_cls_size=37, dropout=0.3)
+    sd = synth.fill_module(gh, seed + 2)
+    gh.eval()
+    out["meta/ghv1/weights_checksum"] = np.float64(synth.state_checksum(sd))
+    txt, obj, pre, og = gh(v["txt"], v["query"], v["pre"], v["qpad"].logical_not())
+    for k, t_ in (("txt", txt), ("obj", obj), ("pre", pre), ("og3d", og)):
+        put(out, "ghv1/" + k, t_)
+    save(name, out)
+
+
 def encoder_level_inputs(*, B, Ns, Nq, d, memories, n_scales, data_seed):
     """Synthetic inputs of the encoder-level cases F13 / F14 (shared with the tests): scene memories with ragged valid
     lengths, the voxel memory optionally as a LIST of `n_scales` tensors (multi-scale), query / segment positions."""
@@ -889,6 +934,7 @@ def main():
     # prompts (PromptType.LOC), stage-2 structure 'mixed' (parallel scene memories, then the prompt cross-attention)
     run_model_case(ref, "F20_prompt_loc", B=3, Ns=60, Nq=11, d=64, H=4, L=2, memories=["mv", "pc", "voxel", "prompt"],
                    heads=["ground"], spatial=True, structure="mixed", prompt_loc=6)
+    run_variants_case(ref, "F21_variants")
     run_model_case(ref, "F20_prompt_loc6", B=2, Ns=40, Nq=8, d=64, H=4, L=1, memories=["voxel", "prompt"], heads=["ground"],
                    spatial=True, structure="sequential", dim_loc=6, prompt_loc=8)
 

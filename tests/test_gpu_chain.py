@@ -456,13 +456,13 @@ def test_chain_device_gate_measures_the_placement_rule():
 
 
 @pytest.mark.parametrize("B", [8, 16], ids=["R800", "R1600"])
-@pytest.mark.parametrize("held,lds_kb,us", [(32, 100, 20000), (96, 100, 3000), (64, 8, 20000)],
+@pytest.mark.parametrize("held,lds_kb,us", [(32, 100, 150000), (96, 100, 3000), (64, 8, 150000)],
                          ids=["32CUs-held", "96CUs-held-briefly", "64-small-neighbours"])
 @pytest.mark.parametrize("case", ["plain", "mask_head"])
 def test_chain_launches_beside_a_cu_holding_kernel(case, B, held, lds_kb, us):
     """the data-parallel step reduces gradient buckets UNDER the decoder backward, i.e. an RCCL kernel (one
     workgroup per channel) holds CUs beside chain_ffn_bwd / chain_sa_bwd.  Stand-in: `held` workgroups that each pin `lds_kb` of a
-    CU's LDS for `us` microseconds on a second stream (pq3d_test_occupy_cus; 100 KB = no chain workgroup fits beside one) while a
+    CU's LDS for `us` microseconds (150 ms: longer than an eager step) on a second stream (pq3d_test_occupy_cus; 100 KB = no chain workgroup fits beside one) while a
     whole model step (every chain kernel: ffn / ca forward, ffn / sa backward; mask head pair) runs on the main stream at R = 800
     and R = 1600 query rows.  32 held CUs is the head-room chain_nrt() leaves; 96 makes members WAIT for a CU (bounded polls).
     Required: forward outputs bit for bit the undisturbed run's, gradients at the chained backward's run-to-run level, error word
@@ -487,7 +487,13 @@ def test_chain_launches_beside_a_cu_holding_kernel(case, B, held, lds_kb, us):
     def step():
         model.zero_grad()
         out = model(dict(ddv))
-        util.synthetic_loss(out, args["heads"], out["query_embeds"]).backward()
+        # a device-only loss (util.synthetic_loss builds its weights on the host: 100+ ms per call, longer than the neighbour)
+        loss = out["query_embeds"].float().square().mean()
+        for m in out.get("predictions_mask", []):
+            loss = loss + m.float().clamp(min=-50.0).mean()
+        for c_ in out.get("predictions_class", []):
+            loss = loss + torch.where(torch.isfinite(c_), c_, torch.zeros_like(c_)).float().square().mean()
+        loss.backward()
         outs = [out["query_embeds"]] + list(out.get("predictions_mask", [])) + list(out.get("predictions_class", []))
         return [t.detach().clone() for t in outs], {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
 
@@ -496,19 +502,28 @@ def test_chain_launches_beside_a_cu_holding_kernel(case, B, held, lds_kb, us):
     ref_o, ref_g = step()
     torch.cuda.synchronize()
     assert not ops.chain_error(dev)
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):            # the neighbour starts first and outlives the step's launches
-        L.check(L.lib().pq3d_test_occupy_cus(held, lds_kb * 1024, us, L.stream()), "pq3d_test_occupy_cus")
-        ev = torch.cuda.Event()
-        ev.record()
-    got_o, got_g = step()
-    torch.cuda.current_stream().synchronize()
-    if us >= 20000:
-        assert not ev.query(), "the neighbour ended before the step did: the launches did not run beside it"
-    torch.cuda.synchronize()
-    ops.chain_check(dev)                     # raises ChainHandoffError if any hand-off gave up
-    for a, b in zip(got_o, ref_o):
-        assert torch.equal(a, b)
+    beside = False
+    for attempt in range(6):
+        # a fresh stream per attempt: HIP maps streams onto a few hardware queues round-robin, and a side stream that lands on the
+        # SAME queue as the step's stream serialises the step behind the neighbour (measured: tools/probes/chain_neighbour_timing.py
+        # -- sporadically a step takes exactly the neighbour's 100 ms whatever the neighbour's size); the launches must have run
+        # BESIDE the neighbour in at least one attempt, and every attempt must be correct
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            L.check(L.lib().pq3d_test_occupy_cus(held, lds_kb * 1024, us, L.stream()), "pq3d_test_occupy_cus")
+            ev = torch.cuda.Event()
+            ev.record()
+        got_o, got_g = step()
+        torch.cuda.current_stream().synchronize()
+        beside = beside or not ev.query()
+        torch.cuda.synchronize()
+        ops.chain_check(dev)                 # raises ChainHandoffError if any hand-off gave up
+        for a, b in zip(got_o, ref_o):
+            assert torch.equal(a, b)
+        if beside or us < 100000:
+            break
+    if us >= 100000:
+        assert beside, "the neighbour ended before the step did in every attempt: the launches never ran beside it"
     gmax = max(float(v.norm()) for v in ref_g.values())
     for n, g0 in ref_g.items():
         assert float((got_g[n] - g0).norm()) <= 1e-2 * max(float(g0.norm()), 1e-3 * gmax), n
