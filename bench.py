@@ -555,7 +555,14 @@ def main():
     # PQ3D_BENCH_WIRE=bf16: gradient buckets cross the links as bf16 with fp32 accumulation (parallel.FlatGradAllReducer wire_dtype;
     # default fp32 = DDP's arithmetic, trainer/build.py:66-75)
     wire = os.environ.get("PQ3D_BENCH_WIRE", "fp32")
-    reducer = FlatGradAllReducer(params, groups=[g for g in groups if g], wire_dtype=torch.bfloat16 if wire == "bf16" else None)
+    # PQ3D_BENCH_COMM=native: the buckets go through the C-ABI communicator (pq3d_comm_init / pq3d_allreduce_grads[_wire], csrc/comm.hip)
+    # instead of torch.distributed's collectives; torch.distributed still carries the rendezvous and the barriers
+    exchange = os.environ.get("PQ3D_BENCH_COMM", "torch")
+    comm = None
+    if exchange == "native" and dist_on and backend == "nccl":
+        from pq3d_amd.parallel import NativeComm
+        comm = NativeComm.from_process_group()
+    reducer = FlatGradAllReducer(params, groups=[g for g in groups if g], wire_dtype=torch.bfloat16 if wire == "bf16" else None, comm=comm)
     heads_bucket = bucket_of[0] if keep[0] else None
     dec_buckets = [bucket_of[j] for j in range(1, 1 + len(layer_groups)) if keep[j]]
     n_layer_buckets = len(layers) if bucket_mode == "per_layer" else 0
@@ -886,6 +893,7 @@ def main():
                                    f"fwd+bwd+grad-pack{'+RCCL all-reduce' if dist_on else ''}",
                        "global_batch": c["B"] * world, "parallelism": f"dp{world}", "hip_graph": graph is not None,
                        "step_mode": step_mode, "gradient_wire_dtype": wire,
+                       "gradient_exchange": ("pq3d_comm (C-ABI, RCCL)" if comm is not None else "torch.distributed (RCCL)") if dist_on else None,
                        "compute_mode": {"bf16x3": "bf16x3: bf16 MFMA operands, fp32 accumulation; the key/value side AND the query side carry "
                                                   "their fp32 tensors as hi + lo bf16 pairs (3 MFMAs per product) in the forward, single-bf16 "
                                                   "backward -- meets north_star's 1e-3 end to end",

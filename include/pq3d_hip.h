@@ -966,6 +966,35 @@ int pq3d_t5_prep(const int64_t* labels, int64_t start_id, int64_t pad_id, const 
 int pq3d_t5_bias_bwd(const float* dbias, const int64_t* buckets, float* drel, int32_t B, int32_t T, int32_t H, int32_t NB,
                      int32_t accumulate, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange over RCCL / xGMI (SURVEY 8b's export list: pq3d_comm_init, pq3d_allreduce_grads; 8e).
+ * Replaces, for a host that does not go through torch.distributed: DistributedDataParallel's bucketed all-reduce(mean) of
+ * the parameter gradients every step (reference trainer/build.py:66-75 via accelerate; the only collective on the path).
+ * One communicator per process (= per GPU).  librccl is bound at the first call (dlopen; a copy the process already loaded --
+ * torch's -- is reused), so the library itself has no link-time dependency on it; a missing librccl is an error text, not a
+ * load failure.  Everything is stream-ordered: no host synchronisation, capturable where RCCL's collectives are.
+ *   pq3d_comm_unique_id : rank 0 makes the 128-byte rendezvous id (ncclGetUniqueId); the host carries it to the other ranks
+ *   pq3d_comm_init      : collective over all ranks (ncclCommInitRank on the CURRENT device); *comm = opaque handle
+ *   pq3d_allreduce_grads: in-place sum (mean != 0: mean, inside the collective -- ncclAvg) of count elements, dtype PQ3D_F32
+ *                         or PQ3D_BF16 (a bf16 buffer is summed in bf16 by the ring: use the wire form below instead)
+ *   pq3d_allreduce_grads_wire : fp32 gradients, bf16 on the links, FP32 ACCUMULATION: cast -> all-to-all (rank r receives
+ *                         piece r of every rank) -> fp32 sum in rank order (/ world) -> bf16 shard -> all-gather -> fp32.  Half the
+ *                         bytes of the fp32 all-reduce per link, two roundings per element, bit-identical results on every rank.
+ *                         scratch: pq3d_allreduce_wire_scratch_bytes(world, count) bytes of device memory, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------ */
+#define PQ3D_COMM_ID_BYTES 128
+int pq3d_comm_unique_id(void* id);
+int pq3d_comm_init(int32_t rank, int32_t world, const void* unique_id, void** comm);
+int pq3d_comm_destroy(void* comm);
+int pq3d_comm_info(void* comm, int32_t* rank, int32_t* world, int32_t* rccl_version);
+int pq3d_allreduce_grads(void* comm, void* grads, int64_t count, int32_t dtype, int32_t mean, void* stream);
+int64_t pq3d_allreduce_wire_scratch_bytes(int32_t world, int64_t count);
+int pq3d_allreduce_grads_wire(void* comm, float* grads, int64_t count, void* scratch, int64_t scratch_bytes, int32_t mean,
+                              void* stream);
+/* test hook: the wire form's reduce stream alone -- shard[i] = bf16((sum_r float(recv[r * per + i])) / (mean ? world : 1)), bf16 in / out,
+ * per % 8 == 0 -- so that the W > 1 arithmetic is checked on a one-GPU box (tests/test_gpu_comm.py) */
+int pq3d_test_wire_reduce(const void* recv, void* shard, int64_t per, int32_t world, int32_t mean, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -323,8 +323,17 @@ _SIGS = {
     "pq3d_t5_prep": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                      C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p],
     "pq3d_t5_bias_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    # data-parallel gradient exchange over RCCL (csrc/comm.hip)
+    "pq3d_comm_unique_id": [C.c_void_p],
+    "pq3d_comm_init": [C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)],
+    "pq3d_comm_destroy": [C.c_void_p],
+    "pq3d_comm_info": [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "pq3d_allreduce_grads": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p],
+    "pq3d_allreduce_wire_scratch_bytes": [C.c_int32, C.c_int64],
+    "pq3d_allreduce_grads_wire": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p],
+    "pq3d_test_wire_reduce": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p],
 }
-_RET64 = {"pq3d_segment_plan_bytes", "pq3d_segment_ws_bytes"}   # size queries: bytes (or -1), not a status code
+_RET64 = {"pq3d_segment_plan_bytes", "pq3d_segment_ws_bytes", "pq3d_allreduce_wire_scratch_bytes"}   # size queries: bytes (or -1), not a status code
 EXPORTS = sorted(list(_SIGS) + ["pq3d_last_error", "pq3d_version"])
 
 

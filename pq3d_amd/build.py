@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpq3d_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "loss.hip", "pointnet2.hip", "gemm128.hip", "attn_resident.hip", "attn_small.hip", "gemm_wk.hip", "attn_sa.hip", "gemm_wktt.hip", "gemm_cv128.hip", "attn_ca.hip", "segment.hip", "t5glue.hip", "gemm_ttmulti.hip", "chain_ffn.hip", "chain_ca.hip", "chain_ffn_bwd.hip", "chain_sa_bwd.hip", "chain_mh.hip", "attn_x3.hip", "chain_probe.hip", "gemm_x3p.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "optim.hip", "loss.hip", "pointnet2.hip", "gemm128.hip", "attn_resident.hip", "attn_small.hip", "gemm_wk.hip", "attn_sa.hip", "gemm_wktt.hip", "gemm_cv128.hip", "attn_ca.hip", "segment.hip", "t5glue.hip", "gemm_ttmulti.hip", "chain_ffn.hip", "chain_ca.hip", "chain_ffn_bwd.hip", "chain_sa_bwd.hip", "chain_mh.hip", "attn_x3.hip", "chain_probe.hip", "gemm_x3p.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
          "-Wno-unused-result"]
 # per-file extras.  attn_resident.hip: MFMA results feed the softmax VALU code directly; with the default AGPR form of the
@@ -80,7 +80,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out.strip():
             print(out.decode())
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     if verbose:
         print(f"built {LIB} ({len(procs)} of {len(SOURCES)} objects recompiled)")
     return LIB

@@ -24,6 +24,70 @@ class GradSlots(dict):
         self.params = {}
 
 
+class NativeComm:
+    """An RCCL communicator behind the C-ABI (``pq3d_comm_init`` / ``pq3d_allreduce_grads[_wire]``, csrc/comm.hip) --
+    the exchange a host without torch.distributed binds; FlatGradAllReducer(comm=...) routes its buckets through it.  Replaces
+    DDP's gradient all-reduce (reference trainer/build.py:66-75).  One per process, made on the CURRENT device; collective over
+    all ranks.  Everything is stream-ordered on the caller's current stream."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes as C
+        from . import _lib
+        assert len(unique_id) == 128
+        self.rank, self.world = int(rank), int(world)
+        self._h = C.c_void_p()
+        self._scratch = {}
+        _lib.check(_lib.lib().pq3d_comm_init(self.rank, self.world, C.c_char_p(unique_id), C.byref(self._h)), "pq3d_comm_init")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().pq3d_comm_unique_id(buf), "pq3d_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None) -> "NativeComm":
+        """Rendezvous through an initialised torch.distributed group (any backend): rank 0's id is broadcast as an object."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def rccl_version(self) -> int:
+        import ctypes as C
+        from . import _lib
+        v = C.c_int32()
+        _lib.check(_lib.lib().pq3d_comm_info(self._h, None, None, C.byref(v)), "pq3d_comm_info")
+        return v.value
+
+    def all_reduce(self, t: torch.Tensor, mean: bool = True, wire_bf16: bool = False) -> None:
+        """In place on the current stream.  wire_bf16 (fp32 buffers): bf16 on the links, fp32 accumulation (comm.hip)."""
+        from . import _lib
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+        L = _lib.lib()
+        if wire_bf16:
+            assert t.dtype == torch.float32
+            need = L.pq3d_allreduce_wire_scratch_bytes(self.world, t.numel())
+            sc = self._scratch.get(t.data_ptr())
+            if sc is None or sc.numel() < need:     # fixed address per bucket: capturable
+                sc = self._scratch[t.data_ptr()] = torch.empty(need, dtype=torch.uint8, device=t.device)
+            _lib.check(L.pq3d_allreduce_grads_wire(self._h, t.data_ptr(), t.numel(), sc.data_ptr(), sc.numel(), int(mean), _lib.stream()),
+                       "pq3d_allreduce_grads_wire")
+        else:
+            _lib.check(L.pq3d_allreduce_grads(self._h, t.data_ptr(), t.numel(), _lib.dt_of(t), int(mean), _lib.stream()),
+                       "pq3d_allreduce_grads")
+
+    def close(self) -> None:
+        if self._h:
+            from . import _lib
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib().pq3d_comm_destroy(self._h), "pq3d_comm_destroy")
+            self._h = None
+
+
 class FlatGradAllReducer:
     """``groups``: explicit buckets (lists of parameters) in the order their gradients become final -- bench.py /
     TrainStep pass [decoder (+ mask head) parameters, everything else]: the fused decoder backward finishes ALL of the
@@ -31,8 +95,9 @@ class FlatGradAllReducer:
     its all-reduce can be launched early on a side stream (``launch(0)``) and overlaps that tail."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, group=None,
-                 keep_order: bool = False, groups=None, wire_dtype=None):
-        """wire_dtype = torch.bfloat16: the buckets cross the links as bf16 (half the bytes of the fp32 all-reduce: xGMI rings are
+                 keep_order: bool = False, groups=None, wire_dtype=None, comm: "NativeComm" = None):
+        """comm: a NativeComm -- the buckets go through the C-ABI exchange (pq3d_allreduce_grads / _wire) instead of torch.distributed.
+        wire_dtype = torch.bfloat16: the buckets cross the links as bf16 (half the bytes of the fp32 all-reduce: xGMI rings are
         per-link bound, config 2's 36.8 MB of fp32 gradients are ~0.3 ms of wire time at 8 ranks) with FP32 ACCUMULATION -- not a
         bf16 all-reduce, whose ring sums in bf16: an all-to-all hands every rank the bf16 pieces of ITS shard from all ranks, it sums
         them in fp32 (and divides), and an all-gather returns the bf16-rounded means.  Two roundings per element in total (each
@@ -40,6 +105,7 @@ class FlatGradAllReducer:
         ends with bit-identical buffers.  None (default): fp32 all-reduce, DDP's arithmetic (trainer/build.py:66-75)."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
+        self.comm = comm
         assert wire_dtype in (None, torch.bfloat16, torch.float32)
         self.wire_dtype = None if wire_dtype == torch.float32 else wire_dtype
         self._wire = {}          # bucket index -> (send, recv, shard, gathered) staging buffers (fixed addresses: capturable)
@@ -126,10 +192,24 @@ class FlatGradAllReducer:
 
     # ---- collective -------------------------------------------------------------------------------------------------
     def _world(self) -> int:
+        if self.comm is not None:
+            return self.comm.world
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def _active(self) -> bool:
-        return self._world() > 1 or (self.force_collectives and dist.is_initialized())
+        return self._world() > 1 or (self.force_collectives and (self.comm is not None or dist.is_initialized()))
+
+    def _reduce_any(self, bi: int):
+        """(work handle or None, caller divides?) of bucket bi's exchange issued at the current stream's position."""
+        if self.comm is not None:
+            return self._reduce_native(bi), False
+        if self.wire_dtype is not None:
+            return self._reduce_wire(bi), False
+        return self._reduce(self.flat[bi])
+
+    def _reduce_native(self, bi: int) -> None:
+        """Mean over ranks of bucket bi through the C-ABI communicator, in place, on the current stream."""
+        self.comm.all_reduce(self.flat[bi], mean=True, wire_bf16=self.wire_dtype is not None)
 
     def _reduce(self, f: torch.Tensor):
         """mean over ranks, in place.  RCCL ('nccl') averages inside the collective (ReduceOp.AVG: no separate divide
@@ -184,7 +264,9 @@ class FlatGradAllReducer:
             # -> cur -- makes hipStreamEndCapture SEGFAULT on this stack (torch 2.10 / ROCm 7.2, found with a one-rank
             # communicator on an MI355X: tools/probes/rccl_capture_probe.py); branches of one graph do not run
             # concurrently on this runtime anyway, so nothing is lost.
-            if self.wire_dtype is not None:
+            if self.comm is not None:
+                self._reduce_native(bi)
+            elif self.wire_dtype is not None:
                 self._reduce_wire(bi)
             elif dist.get_backend(self.group) == "nccl":
                 dist.all_reduce(self.flat[bi], op=dist.ReduceOp.AVG, group=self.group)
@@ -202,9 +284,9 @@ class FlatGradAllReducer:
             else:
                 self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
-                h, div = (self._reduce_wire(bi), False) if self.wire_dtype is not None else self._reduce(self.flat[bi])
+                h, div = self._reduce_any(bi)
         else:
-            h, div = (self._reduce_wire(bi), False) if self.wire_dtype is not None else self._reduce(self.flat[bi])
+            h, div = self._reduce_any(bi)
         self._pending.append((h, bi, div, on_side))
         self._launched.add(bi)
 

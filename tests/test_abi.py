@@ -95,6 +95,24 @@ def test_argument_errors_are_reported(lib):
     assert lib.pq3d_attn_fwd(ctypes.byref(a), None) == -1 and b"head dim" in lib.pq3d_last_error()
 
 
+def test_comm_entry_points_without_a_gpu(lib):
+    """SURVEY 8b's gradient-exchange exports (csrc/comm.hip): the host-only parts answer without a GPU -- the wire form's scratch size,
+    argument errors before any RCCL call, and (librccl is bound with dlopen at first use) the rendezvous id."""
+    assert lib.pq3d_allreduce_wire_scratch_bytes(8, 1000) == (3 * 8 + 1) * 128 * 2
+    assert lib.pq3d_allreduce_wire_scratch_bytes(1, 0) == 0 and lib.pq3d_allreduce_wire_scratch_bytes(0, 5) == -1
+    junk = ctypes.create_string_buffer(64)
+    assert lib.pq3d_allreduce_grads(junk, None, 8, 0, 1, None) == -1 and b"not a communicator" in lib.pq3d_last_error()
+    assert lib.pq3d_comm_destroy(junk) == -1
+    h = ctypes.c_void_p()
+    assert lib.pq3d_comm_init(2, 2, junk, ctypes.byref(h)) == -1 and b"rank" in lib.pq3d_last_error() and not h.value
+    a, b = ctypes.create_string_buffer(128), ctypes.create_string_buffer(128)
+    rc = lib.pq3d_comm_unique_id(a)
+    if rc == 0:      # (a host without librccl reports an error text instead)
+        assert lib.pq3d_comm_unique_id(b) == 0 and a.raw != b.raw and any(a.raw)
+    else:
+        assert b"rccl" in lib.pq3d_last_error().lower()
+
+
 def test_state_dict_keys_match_reference():
     """Every parameter name/shape of the reference (recorded as grad/<name> in the fixtures) exists in our modules."""
     for name in ("F2_c1_mask", "F4_c2_slice", "F5_dimloc6", "F5_offline_mask"):
