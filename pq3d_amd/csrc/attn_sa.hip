@@ -17,7 +17,9 @@
 //   * backward, no atomics: phase A (wave = query block) recomputes S^T, P = exp(S - lse), dP^T = V dO^T,
 //     dS = P (dP - delta), writes dbias = dS and accumulates dQ^T = K^T dS^T; phase B (wave = key block) recomputes the
 //     same tiles in the S orientation (lane = key column) for dV^T = dO^T P and dK^T = Q^T dS.  Every output element has
-//     one writer; S and dP are formed twice (a few hundred MFMAs per wave).
+//     one writer; S and dP are formed twice (a few hundred MFMAs per wave).  Round 6: with few (scene, head) units the two phases
+//     (and, below a quarter of a chip, two halves of each phase's 16-row blocks) run on separate workgroups that stage the
+//     same planes: grid.z = 2 / 4, the same bits.
 // zero_attn, 3-D masks and attention dropout stay on the general kernels.
 #include <atomic>
 #include <cstdlib>
@@ -63,11 +65,17 @@ bool pq3d_attn_sa_try(const pq3d_attn_desc& d, hipStream_t s, bool bwd) {
   size_t lds = d.dh == 32 ? sa32::sa_lds_bytes(lqp, d.Lk, bwd, fold ? d.proj.dm : 0) : sa64::sa_lds_bytes(lqp, d.Lk, bwd, 0);
   if (lds > 160 * 1024) return false;
   const int blocks = (max(d.Lq, d.Lk) + 15) / 16;
+  // backward with at most half a chip of (scene, head) units: phase A and phase B on separate workgroups, and with at most a
+  // quarter of a chip each phase on two (attn_sa_body.h; PQ3D_SA_BWD_SPLIT=0 / 1 / 2 for an A/B).  Same-box, rocprofv3, per launch:
+  // config 2 (64 units, 100 queries) 22.4 -> 17.9 -> 16.8 us, config 4 (32 units, 200 queries) 41.2 -> 25.9 -> 22.2 us
+  static const int split = [] { const char* e = getenv("PQ3D_SA_BWD_SPLIT"); return e ? atoi(e) : 2; }();
+  // (the forward gains nothing from the same split: 9.4 -> 9.0 us at config 2, 15.7 -> 15.5 at config 4 -- its time is the staging)
+  const int parts = (bwd && split > 0 && (long)d.H * d.B <= 128) ? ((split > 1 && (long)d.H * d.B <= 64 && blocks >= 4) ? 4 : 2) : 1;
 #define SA_LAUNCH(KERN)                                                                              \
   do {                                                                                               \
     static std::atomic<unsigned> done{0};                                                            \
     if (pq3d_enable_big_lds(KERN, 160 * 1024, done)) { (void)hipGetLastError(); return false; }      \
-    hipLaunchKernelGGL(KERN, dim3(d.H, d.B), dim3(blocks * 64), lds, s, d);                          \
+    hipLaunchKernelGGL(KERN, dim3(d.H, d.B, parts), dim3(blocks * 64), lds, s, d);                   \
   } while (0)
   if (d.dh == 32) { if (bwd) SA_LAUNCH(sa32::attn_sa_bwd_kernel); else SA_LAUNCH(sa32::attn_sa_fwd_kernel); }
   else { if (bwd) SA_LAUNCH(sa64::attn_sa_bwd_kernel); else SA_LAUNCH(sa64::attn_sa_fwd_kernel); }

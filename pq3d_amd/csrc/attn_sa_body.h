@@ -248,6 +248,10 @@ __global__ __launch_bounds__(SA_MAXT) void attn_sa_bwd_kernel(const pq3d_attn_de
   const SaLds S = carve(sa_sm, LPq2, LPk, true);   // query planes padded to whole PAIRS of 16-row tiles (phase B walks pairs)
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int b = blockIdx.y, h = blockIdx.x;
+  // grid.z = 2 (few (scene, head) units: most CUs would idle): workgroup z = 0 runs phase A (dQ, dbias, delta), z = 1 phase B
+  // (dK, dV); both stage the same planes.  part 0: one workgroup runs both phases.
+  // grid.z = 4: each phase on two workgroups, the 16-row blocks dealt out alternately (sub).
+  const int part = gridDim.z > 1 ? (int)(blockIdx.z & 1) + 1 : 0, nsub = gridDim.z > 2 ? 2 : 1, sub = (int)blockIdx.z >> 1;
   const float* q = (const float*)d.q + (long)b * d.q_sb + (long)h * d.q_sh;
   const float* k = (const float*)d.k + (long)b * d.k_sb + (long)h * d.k_sh;
   const float* v = (const float*)d.v + (long)b * d.v_sb + (long)h * d.v_sh;
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(SA_MAXT) void attn_sa_bwd_kernel(const pq3d_attn_de
       if (lg == 0) {
         if (ok) {
           l = pre ? lse_e : d.lse[sbase + qrow];
-          d.delta[sbase + qrow] = s;
+          if (part != 2 && sub == 0) d.delta[sbase + qrow] = s;
           if (l == -INFINITY) l = INFINITY;
         }
         S.dl[qrow] = s;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(SA_MAXT) void attn_sa_bwd_kernel(const pq3d_attn_de
         s += (a.x * t.x + a.y * t.y) + (a.z * t.z + a.w * t.w);
       }
       l = d.lse[sbase + i];
-      d.delta[sbase + i] = s;
+      if (part != 2 && sub == 0) d.delta[sbase + i] = s;
       if (l == -INFINITY) l = INFINITY;      // fully masked row: all probabilities 0
     }
     S.dl[i] = s;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(SA_MAXT) void attn_sa_bwd_kernel(const pq3d_attn_de
   const bool dvec = (Lk & 3) == 0 && ((((uintptr_t)dbias)) & 15) == 0;
   // ---------------- phase A: wave = query block; transposed tiles (lane = query column, 4 keys per tile per lane)
   const int q0 = wave * 16;
-  if (q0 < LPq) {
+  if (part != 2 && q0 < LPq && (wave & (nsub - 1)) == sub) {
     const int qrow = q0 + li;
     HL qf[KS], gf[KS];
 #pragma unroll
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(SA_MAXT) void attn_sa_bwd_kernel(const pq3d_attn_de
   SA_TL(5);
   // ---------------- phase B: wave = key block; plain tiles (lane = key column, 4 queries per tile per lane)
   const int k0 = wave * 16;
-  if (k0 >= ((Lk + 15) & ~15)) return;
+  if (part == 1 || k0 >= ((Lk + 15) & ~15) || (wave & (nsub - 1)) != sub) return;
   const int krow = k0 + li;
   HL kf[KS], vf[KS];
 #pragma unroll

@@ -17,22 +17,22 @@
 
 namespace {
 
-constexpr int XM = 128, XN = 128;
+constexpr int XM = 128, XN = 128, XTK = 32;
 constexpr int XLDC = XN + 8;   // bf16 C staging row
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-// TKT: k slice (32 / 64), NBUF: LDS stages (2: the next slice's DMA is issued before this slice's MFMAs, one barrier per slice)
-template <int TKT, int NBUF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void gemm_x3p128_kernel(const pq3d_kdesc d) {
 #ifndef PQ3D_NO_KARG_PIN
   asm volatile("" ::"s"(d.M), "s"(d.N), "s"(d.K), "s"(d.lda), "s"(d.ldb), "s"(d.ldc), "s"(d.alpha), "s"(d.groups), "s"(d.xcd_order));
 #endif
-  constexpr int PL = XM * TKT;                      // elements of one plane's slice
-  constexpr int OPB = NBUF * 4 * PL * 2, STB = XM * XLDC * 2;
-  constexpr int CPR = TKT / 8, NP = CPR / 2;        // 16-byte chunks per row; DMA pieces per thread and plane
+  constexpr int OPB = 4 * XM * XTK * 2, STB = XM * XLDC * 2;
   __shared__ __attribute__((aligned(16))) bf16_t sm[(OPB > STB ? OPB : STB) / 2];
+  bf16_t* const Ah = sm;
+  bf16_t* const Al = Ah + XM * XTK;
+  bf16_t* const Bh = Al + XM * XTK;
+  bf16_t* const Bl = Bh + XN * XTK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const TileIdx ti = tile_index(d.xcd_order);
@@ -41,15 +41,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   const bf16_t* const A2 = (const bf16_t*)d.gp[g].A2;
   const bf16_t* const B = (const bf16_t*)d.gp[g].B;
   const bf16_t* const B2 = (const bf16_t*)d.gp[g].B2;
-  const int nkt = d.K / TKT;
+  const int nkt = d.K / XTK;
 
-  // DMA piece p of this thread: LDS slot (p * 256 + tid) = row slot / CPR, position slot % CPR <- k chunk pos ^ swz(row)
-  // (64-byte rows: swz = (row >> 2) & 3; 128-byte rows: (row >> 1) & 7 -- 16 lanes of a fragment read cover the 64 banks once)
-  int aoff[NP], boff[NP];
+  // DMA piece p of this thread: LDS slot (p * 256 + tid) = row slot / 4, position slot % 4 <- k chunk pos ^ ((row >> 2) & 3)
+  int aoff[2], boff[2];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int slot = p * 256 + tid, row = slot / CPR;
-    const int c = (slot % CPR) ^ (CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7));
+  for (int p = 0; p < 2; ++p) {
+    const int slot = p * 256 + tid, row = slot >> 2, c = (slot & 3) ^ ((row >> 2) & 3);
     aoff[p] = min(m0 + row, d.M - 1) * (int)d.lda + c * 8;   // rows past M: clamped duplicates (never stored)
     boff[p] = (n0 + row) * (int)d.ldb + c * 8;
   }
@@ -58,61 +56,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int sw = CPR == 4 ? ((li >> 2) & 3) : ((li >> 1) & 7);   // row = 16 t + li
+  const int ch = (lg ^ ((li >> 2) & 3)) * 8;   // this lane's chunk slot inside its fragment rows (row = 16 t + li: (row >> 2) & 3 = li >> 2)
 
-  auto stage = [&](int kt, int buf) {
-    bf16_t* const base = sm + buf * 4 * PL;
+  for (int kt = 0; kt < nkt; ++kt) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
+    for (int p = 0; p < 2; ++p) {
       const int lo_ = (p * 256 + wave * 64) * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t*)(A + aoff[p] + kt * TKT), (lptr_t*)(base + lo_), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t*)(A2 + aoff[p] + kt * TKT), (lptr_t*)(base + PL + lo_), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t*)(B + boff[p] + kt * TKT), (lptr_t*)(base + 2 * PL + lo_), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t*)(B2 + boff[p] + kt * TKT), (lptr_t*)(base + 3 * PL + lo_), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t*)(A + aoff[p] + kt * XTK), (lptr_t*)(Ah + lo_), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t*)(A2 + aoff[p] + kt * XTK), (lptr_t*)(Al + lo_), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t*)(B + boff[p] + kt * XTK), (lptr_t*)(Bh + lo_), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t*)(B2 + boff[p] + kt * XTK), (lptr_t*)(Bl + lo_), 16, 0, 0);
     }
-  };
-  auto compute = [&](int buf) {
-    const bf16_t* const Ah = sm + buf * 4 * PL;
-    const bf16_t* const Al = Ah + PL;
-    const bf16_t* const Bh = Al + PL;
-    const bf16_t* const Bl = Bh + PL;
+    __syncthreads();   // the compiler drains the DMA queue (vmcnt(0)) before the barrier
+    u32x4 bh[4], bl[4];
 #pragma unroll
-    for (int ks = 0; ks < TKT / 32; ++ks) {
-      const int ch = ((ks * 4 + lg) ^ sw) * 8;
-      u32x4 bh[4], bl[4];
+    for (int j = 0; j < 4; ++j) {
+      bh[j] = *(const u32x4*)&Bh[(wn + j * 16 + li) * XTK + ch];
+      bl[j] = *(const u32x4*)&Bl[(wn + j * 16 + li) * XTK + ch];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4 ah = *(const u32x4*)&Ah[(wm + i * 16 + li) * XTK + ch];
+      const u32x4 al = *(const u32x4*)&Al[(wm + i * 16 + li) * XTK + ch];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        bh[j] = *(const u32x4*)&Bh[(wn + j * 16 + li) * TKT + ch];
-        bl[j] = *(const u32x4*)&Bl[(wn + j * 16 + li) * TKT + ch];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const u32x4 ah = *(const u32x4*)&Ah[(wm + i * 16 + li) * TKT + ch];
-        const u32x4 al = *(const u32x4*)&Al[(wm + i * 16 + li) * TKT + ch];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          Mma<bf16_t>::mma(acc[i][j], al, bh[j]);
-          Mma<bf16_t>::mma(acc[i][j], ah, bl[j]);
-          Mma<bf16_t>::mma(acc[i][j], ah, bh[j]);
-        }
+        Mma<bf16_t>::mma(acc[i][j], al, bh[j]);
+        Mma<bf16_t>::mma(acc[i][j], ah, bl[j]);
+        Mma<bf16_t>::mma(acc[i][j], ah, bh[j]);
       }
     }
-  };
-  if constexpr (NBUF == 1) {
-    for (int kt = 0; kt < nkt; ++kt) {
-      stage(kt, 0);
-      __syncthreads();   // the compiler drains the DMA queue (vmcnt(0)) before the barrier
-      compute(0);
-      __syncthreads();
-    }
-  } else {
-    stage(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);   // lands under this slice's MFMAs (its buffer was released by the last barrier)
-      compute(kt & 1);
-      __syncthreads();
-    }
   }
 
   // epilogue: + bias, hi plane then residual plane through one LDS staging tile (rows leave in whole 16-byte pieces)
@@ -148,11 +121,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
   }
 }
 
-int x3p_variant() {   // A/B switch (profiles/NOTES_r06.md): PQ3D_X3P_VARIANT = 0 (TK 32, one stage) | 1 (TK 32, two stages) | 2 (TK 64, one stage)
-  static const int v = [] { const char* e = getenv("PQ3D_X3P_VARIANT"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
 }  // namespace
 
 // pq3d_gemm routes here (gemm.hip): ct PQ3D_BF16X3 with bf16 A / B, A2 / B2 = residual planes, act_grad PQ3D_ACT_PLANES.
@@ -160,7 +128,7 @@ bool pq3d_gemm_x3p_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_
   if (d.ct != PQ3D_BF16X3 || d.act_grad != PQ3D_ACT_PLANES) return false;
   if (d.dtA != PQ3D_BF16 || d.dtB != PQ3D_BF16 || d.dtA2 != PQ3D_BF16 || d.dtB2 != PQ3D_BF16 || d.dtC != PQ3D_BF16 || d.dtC2 != PQ3D_BF16) return false;
   if (d.transA || d.transB || d.batch != 1 || d.splitk > 1 || d.kconcat > 1 || d.act != PQ3D_ACT_NONE) return false;
-  if (d.M < 1 || d.N % XN || d.K % 64 || d.K < 64) return false;
+  if (d.M < 1 || d.N % XN || d.K % XTK || d.K < XTK) return false;
   if (d.lda % 8 || d.ldb % 8 || d.ldc % 8) return false;
   if ((long)d.M * d.lda >= (1L << 31) || (long)d.N * d.ldb >= (1L << 31)) return false;
   if (d.row_scale || d.row_fill_flag || d.mask_out || (d.drop.p > 0.f && d.drop.seed)) return false;
@@ -181,11 +149,6 @@ bool pq3d_gemm_x3p_try(const pq3d_gemm_desc& d, const pq3d_kdesc& kd, hipStream_
   }
   const long tiles = (long)((d.M + XM - 1) / XM) * (d.N / XN) * d.groups;
   k.xcd_order = xcd_order_for(tiles, (long)d.N * d.K * 4, run);
-  const dim3 grid((d.M + XM - 1) / XM, d.N / XN, d.groups);
-  switch (x3p_variant()) {
-    case 1: hipLaunchKernelGGL((gemm_x3p128_kernel<32, 2>), grid, dim3(256), 0, s, k); break;
-    case 2: hipLaunchKernelGGL((gemm_x3p128_kernel<64, 1>), grid, dim3(256), 0, s, k); break;
-    default: hipLaunchKernelGGL((gemm_x3p128_kernel<32, 1>), grid, dim3(256), 0, s, k);
-  }
+  hipLaunchKernelGGL(gemm_x3p128_kernel, dim3((d.M + XM - 1) / XM, d.N / XN, d.groups), dim3(256), 0, s, k);
   return true;
 }

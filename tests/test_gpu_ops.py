@@ -2,10 +2,13 @@
 fp32 compute type must match to ~1e-5 (exact-f32 MFMA); bf16 compute type to bf16-operand tolerance."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import pq3d_oracle as O
 from pq3d_amd import _lib as L
@@ -1318,3 +1321,43 @@ def test_row_ce_loss_can_be_modified_in_place():
     xr = x.detach().double().cpu().requires_grad_(True)
     (torch.nn.functional.cross_entropy(xr, t.cpu()) / 4.0 + 1.0).backward()
     close(x.grad, xr.grad, F32, "dlogits")
+
+
+def test_sa_backward_phase_split_keeps_the_bits(tmp_path):
+    """csrc/attn_sa.hip, round 6: with few (scene, head) units the backward's phase A (dQ, dbias) and phase B (dK, dV) -- and halves
+    of each -- run on separate workgroups (grid.z = 2 / 4).  Every output element keeps its one writer and its arithmetic: the
+    gradients are bit for bit those of the one-workgroup form (PQ3D_SA_BWD_SPLIT = 0 / 1 / 2 read once per process -> subprocesses)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from pq3d_amd import ops, _lib as L
+torch.manual_seed(5)
+out = {}
+for name, (B, H, Lq) in {"c2": (8, 8, 100), "c4": (4, 8, 200), "odd": (3, 8, 77)}.items():
+    d = 32 * H
+    q, k, v = [torch.randn(B, Lq, d, device="cuda", requires_grad=True) for _ in range(3)]
+    bias = torch.randn(B, H, Lq, Lq, device="cuda", requires_grad=True)
+    kpm = torch.rand(B, Lq, device="cuda") < 0.1
+    kpm[:, 0] = False
+    o = ops.attention(q, k, v, H=H, ct=L.BF16X3, kpm=kpm, bias=bias)
+    g = torch.randn_like(o)
+    o.backward(g)
+    out[name] = [t.detach().cpu() for t in (o, q.grad, k.grad, v.grad, bias.grad)]
+torch.save(out, sys.argv[1])
+''' % ROOT
+    script = tmp_path / "sa_split.py"
+    script.write_text(code)
+    res = {}
+    for mode in ("0", "1", "2"):
+        f = tmp_path / f"out_{mode}.pt"
+        env = dict(os.environ, PQ3D_SA_BWD_SPLIT=mode)
+        p = subprocess.run([sys.executable, str(script), str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[mode] = torch.load(f)
+    for mode in ("1", "2"):
+        for name in res["0"]:
+            for a, b in zip(res["0"][name], res[mode][name]):
+                assert torch.equal(a, b), (mode, name)
+            assert all(torch.isfinite(t).all() and float(t.abs().max()) > 0 for t in res[mode][name])
