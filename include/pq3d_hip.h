@@ -251,8 +251,8 @@ typedef struct {
    * pq3d_gemm's PQ3D_ACT_PLANES epilogue).  Scores and the value contraction are 3 bf16 MFMAs per term pair (q, P split in
    * registers): fp32-grade results at bf16 MFMA rate, K / V bytes = an fp32 tensor's.  q_bf / o_bf (optional, strides of q / o):
    * bf16 copies of q and of the output for the (single-bf16) backward, which then reads exactly a 'bf16'-mode forward's tensors.
-   * Shape: d_h = 32, Lq <= 128 (<= 256 with a 3-D mask as bit words: two query halves), key padding / zero key / mask_bits,
-   * at most 1024 keys per key split (ksplit >= ceil(Lk / 1024)); any other call with k_lo set is refused. */
+   * Shape: d_h = 32 or 64, Lq <= 256 (two query halves above 128), key padding / zero key / mask_bits, at most 1024 keys per key
+   * split at d_h = 32 and 512 at d_h = 64 (ksplit >= ceil(Lk / 1024) resp. ceil(Lk / 512)); any other call with k_lo set is refused. */
   const void* k_lo;
   const void* v_lo;
   void* q_bf;
@@ -421,6 +421,18 @@ typedef struct {
   const float* bq[3];
   void* qout[3];                /* [R, d] out: bf16, or fp32 when qout_f32 != 0 */
   int32_t qout_f32;
+  /* optional step 0 (round 6): the self-attention CORE of the layer inside this launch -- what pq3d_attn_fwd (ct PQ3D_BF16X3,
+   * d_h = 32, 8 heads, additive bias, key padding) writes for q / k / v [R, d] of scenes of sa_nq rows each, bit for bit
+   * (csrc/attn_sa_body.h's loop): o_s then is an OUTPUT of the launch, sa_lse [R / sa_nq, 8, sa_nq] too.  sa_q = NULL: o_s is an
+   * input as before.  sa_bias [R / sa_nq, 8, sa_nq, sa_nq] or NULL, sa_kpm [R / sa_nq, sa_nq] (non-zero = padded key) or NULL. */
+  const float* sa_q;
+  const float* sa_k;
+  const float* sa_v;
+  const float* sa_bias;
+  const uint8_t* sa_kpm;
+  float* sa_lse;
+  int32_t sa_nq;
+  float sa_scale;
 } pq3d_chain_ffn_desc;
 int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* d, void* stream);
 /* Device gate of every pq3d_chain_* entry point: 1 if the current device of `stream` is the one their in-launch hand-offs are valid

@@ -162,7 +162,8 @@ class ChainFfnDesc(C.Structure):
                [(n, C.c_void_p) for n in ("o_s", "Wo", "bo", "x1s", "g1", "be1", "f", "x2", "mean1", "rstd1", "W1", "b1", "h", "W2",
                                           "b2", "zp", "z", "g2", "be2", "x3", "mean2", "rstd2", "flags", "err")] + \
                [("nq", C.c_int32), ("qpos", C.c_void_p), ("Wq", C.c_void_p * 3), ("bq", C.c_void_p * 3), ("qout", C.c_void_p * 3),
-                ("qout_f32", C.c_int32)]
+                ("qout_f32", C.c_int32)] + [(n, C.c_void_p) for n in ("sa_q", "sa_k", "sa_v", "sa_bias", "sa_kpm", "sa_lse")] + \
+               [("sa_nq", C.c_int32), ("sa_scale", C.c_float)]
 
 
 class ChainCaDesc(C.Structure):

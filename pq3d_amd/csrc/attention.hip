@@ -925,8 +925,9 @@ extern "C" int pq3d_attn_fwd(const pq3d_attn_desc* dp, void* stream) {
     PQ_CHECK_ARG(x3, "pq3d_attn_fwd: k_lo / v_lo need compute type PQ3D_BF16X3");
     if (int e = pq3d_attn_fwd_x3(d, s)) return e;
     if (d.ksplit > 1) {
-      const long n = (long)d.B * d.H * d.Lq * (32 / 4);
-      hipLaunchKernelGGL((attn_fwd_combine_kernel<32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+      const long n = (long)d.B * d.H * d.Lq * (d.dh / 4);
+      if (d.dh == 32) hipLaunchKernelGGL((attn_fwd_combine_kernel<32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
+      else hipLaunchKernelGGL((attn_fwd_combine_kernel<64>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d);
     }
     PQ_LAUNCH_CHECK();
     return 0;

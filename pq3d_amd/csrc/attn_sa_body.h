@@ -153,6 +153,64 @@ PQ_DEV void bias4(const float* bias, int row, int c, int Lq, int Lk, bool vec, f
 // The bias is HBM-cold when the layer's attention runs -- written at the start of the step, 100+ launches earlier -- so
 // whatever requests it earlier pays the same ~2 us in front of the operand staging instead: key loops 4.6 -> 3.6 us, staging
 // 2.4 -> 4.0 us, 17.6 -> 19-21 us per backward launch.  tools/probes/sa_timeline.py)
+// One wave, one 16-query block of the forward: online softmax over all keys of the staged planes.  lrow: the lane's query row in
+// the Q planes; brow: its row of the head's additive bias (>= Lq: no bias -- a row that is not part of this scene).  Returns the
+// unnormalised O^T tiles (tile t = rows d_h 16 t + 4 lg + r, column = query) with the running maximum and sum.  Shared by
+// attn_sa_fwd_kernel and the self-attention step of chain_ffn.hip: the same instructions, hence the same bits.
+struct SaFwdOut { f32x4 ot[OT]; float m, l; };
+PQ_DEV SaFwdOut sa_fwd_block(const SaLds& S, int lrow, int brow, const float* bias, int Lq, int Lk, int LPk, float scale, int lg) {
+  const bool bvec = (Lk & 3) == 0 && ((((uintptr_t)bias) & 15) == 0);
+  HL qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_rm(S.Qh, S.Ql, lrow, lg, ks);
+  const int li = lrow & 15;
+  float m_run = -INFINITY, l_run = 0.f;
+  SaFwdOut r;
+#pragma unroll
+  for (int t = 0; t < OT; ++t) r.ot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bn[8];
+  bias4(bias, brow, 4 * lg, Lq, Lk, bvec, bn);
+  bias4(bias, brow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4);
+  for (int t0 = 0; t0 < LPk; t0 += 32) {
+    float bc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bc[j] = bn[j];
+    if (t0 + 32 < LPk) {   // next pair's bias in flight during this pair's arithmetic
+      bias4(bias, brow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn);
+      bias4(bias, brow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4);
+    }
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    mma3k(s0, S.Kh, S.Kl, t0 + li, lg, qf);
+    mma3k(s1, S.Kh, S.Kl, t0 + 16 + li, lg, qf);
+    float sv[8];
+    const float4 kb0 = *(const float4*)&S.kb[t0 + 4 * lg], kb1 = *(const float4*)&S.kb[t0 + 16 + 4 * lg];
+    const float kbv[8] = {kb0.x, kb0.y, kb0.z, kb0.w, kb1.x, kb1.y, kb1.z, kb1.w};
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sv[j] = (j < 4 ? s0[j] : s1[j - 4]) * scale + bc[j] + kbv[j];
+      mx = fmaxf(mx, sv[j]);
+    }
+    mx = xrow_max(mx);
+    const float m_new = fmaxf(m_run, mx), m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_use);   // m_run = -inf -> 0
+    float p[8], ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { p[j] = __expf(sv[j] - m_use); ps += p[j]; }
+    l_run = l_run * alpha + xrow_sum(ps);
+    m_run = m_new;
+    const HL pf = split8(p);
+#pragma unroll
+    for (int t = 0; t < OT; ++t) {
+      r.ot[t] *= alpha;
+      mma3(r.ot[t], frag_tr(S.Vh, S.Vl, t0, t0 + 16, 16 * t, li, lg), pf);
+    }
+  }
+  r.m = m_run; r.l = l_run;
+  return r;
+}
+
+#ifndef SA_DEVICE_ONLY
 __global__ __launch_bounds__(SA_MAXT) void attn_sa_fwd_kernel(const pq3d_attn_desc d) {
   ATTN_KARG_PIN(d);
   extern __shared__ __attribute__((aligned(16))) unsigned char sa_sm[];
@@ -172,60 +230,14 @@ __global__ __launch_bounds__(SA_MAXT) void attn_sa_fwd_kernel(const pq3d_attn_de
   const int q0 = wave * 16;
   if (q0 >= LPq) return;
   const int qrow = q0 + li;                       // this lane's query (column of the transposed score tiles)
-  const float* bias = gbias;
-  const bool bvec = (Lk & 3) == 0 && ((((uintptr_t)bias) & 15) == 0);
-  HL qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_rm(S.Qh, S.Ql, qrow, lg, ks);
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x4 ot[OT];   // O^T: tile t = rows d_h 16 t + 4 lg + r, column = query
-#pragma unroll
-  for (int t = 0; t < OT; ++t) ot[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bn[8];
-  bias4(bias, qrow, 4 * lg, Lq, Lk, bvec, bn);
-  bias4(bias, qrow, 16 + 4 * lg, Lq, Lk, bvec, bn + 4);
-  for (int t0 = 0; t0 < LPk; t0 += 32) {
-    float bc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bc[j] = bn[j];
-    if (t0 + 32 < LPk) {   // next pair's bias in flight during this pair's arithmetic
-      bias4(bias, qrow, t0 + 32 + 4 * lg, Lq, Lk, bvec, bn);
-      bias4(bias, qrow, t0 + 48 + 4 * lg, Lq, Lk, bvec, bn + 4);
-    }
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    mma3k(s0, S.Kh, S.Kl, t0 + li, lg, qf);
-    mma3k(s1, S.Kh, S.Kl, t0 + 16 + li, lg, qf);
-    float sv[8];
-    const float4 kb0 = *(const float4*)&S.kb[t0 + 4 * lg], kb1 = *(const float4*)&S.kb[t0 + 16 + 4 * lg];
-    const float kbv[8] = {kb0.x, kb0.y, kb0.z, kb0.w, kb1.x, kb1.y, kb1.z, kb1.w};
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sv[j] = (j < 4 ? s0[j] : s1[j - 4]) * d.scale + bc[j] + kbv[j];
-      mx = fmaxf(mx, sv[j]);
-    }
-    mx = xrow_max(mx);
-    const float m_new = fmaxf(m_run, mx), m_use = m_new == -INFINITY ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_use);   // m_run = -inf -> 0
-    float p[8], ps = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { p[j] = __expf(sv[j] - m_use); ps += p[j]; }
-    l_run = l_run * alpha + xrow_sum(ps);
-    m_run = m_new;
-    const HL pf = split8(p);
-#pragma unroll
-    for (int t = 0; t < OT; ++t) {
-      ot[t] *= alpha;
-      mma3(ot[t], frag_tr(S.Vh, S.Vl, t0, t0 + 16, 16 * t, li, lg), pf);
-    }
-  }
+  const SaFwdOut r = sa_fwd_block(S, qrow, qrow, gbias, Lq, Lk, LPk, d.scale, lg);
   if (qrow < Lq) {
-    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    const float inv = r.l > 0.f ? 1.f / r.l : 0.f;
     float* o = (float*)d.o + (long)b * d.o_sb + (long)h * d.o_sh + (long)qrow * d.o_sl;
 #pragma unroll
     for (int t = 0; t < OT; ++t)
-      *(float4*)(o + 16 * t + 4 * lg) = make_float4(ot[t][0] * inv, ot[t][1] * inv, ot[t][2] * inv, ot[t][3] * inv);
-    if (lg == 0) d.lse[((long)b * d.H + h) * Lq + qrow] = l_run > 0.f ? m_run + logf(l_run) : -INFINITY;
+      *(float4*)(o + 16 * t + 4 * lg) = make_float4(r.ot[t][0] * inv, r.ot[t][1] * inv, r.ot[t][2] * inv, r.ot[t][3] * inv);
+    if (lg == 0) d.lse[((long)b * d.H + h) * Lq + qrow] = r.l > 0.f ? r.m + logf(r.l) : -INFINITY;
   }
 }
 
@@ -500,4 +512,4 @@ __global__ __launch_bounds__(SA_MAXT) void attn_sa_bwd_kernel(const pq3d_attn_de
   }
   SA_TL(7);
 }
-
+#endif   // SA_DEVICE_ONLY

@@ -15,6 +15,10 @@
 // key (289 B), so a workgroup holds 512 keys at a time: the compute waves fetch and park the first 512, the loader waves hold
 // the second 512 in registers meanwhile and park them over the first half once it is consumed (<= 1024 keys per key split as
 // before: config 2 needs no split / combine launch).
+// d_h = 64 (the head width of the reference's shipped decoders: hidden 768, 12 heads, configs/instseg_sceneverse.yaml:95,141) runs the
+// same kernel with 256 keys per stage (both planes padded to 144-byte rows), two k steps per score tile and the K / V fragments
+// fetched per tile instead of per block (168 registers per wave): shipped stage-1 / stage-2 decoder steps 14.7 / 15.4 ms in
+// 'bf16x3' against 49.8 / 52.6 ms on the exact-f32 kernels the mode fell back to before, 13.6 / 13.7 ms in 'bf16'.
 // New against the bf16 kernel: a 3-D self-mask as BIT WORDS (pq3d_mask_pack: row_open folded in) staged per 512-key stage, and up
 // to 256 queries as two query halves in grid.x -- config 4's shape (200 queries, 4096 keys, self-mask) stays on this kernel.
 #include <atomic>
@@ -25,11 +29,23 @@ namespace {
 
 constexpr int XW = 8;             // compute waves = 16-query tiles
 constexpr int XLW = 4;            // loader waves
-constexpr int XK = 512;           // keys resident at a time
-constexpr int XNB = XK / KB;      // 64-key blocks per stage (8)
-constexpr int XCH1 = XK * 4 / (XW * 64);    // 16-byte chunks of one plane per compute thread, stage 1 (4)
-constexpr int XCH2 = XK * 4 / (XLW * 64);   // ... per loader thread, stage 2 (8)
-constexpr int XMW = 2 * XNB + 1;  // words per query row of the staged mask bits (16 + 1: conflict-free column reads)
+// per head size: keys resident at a time (16 KB of one K plane), 64-key blocks per stage, LDS row strides.  d_h = 32: K rows unpadded
+// (64 B: the 289 B per key that let 512 keys stay); d_h = 64: both planes padded to 72 elements (144 B rows: 16 lanes of a fragment
+// read cover 16 distinct 4-bank groups; unpadded 128 B rows would be 8-way conflicts), 256 keys per stage.
+template <int DH> struct X3 {
+  static constexpr int XK = 16384 / DH;              // 512 / 256
+  static constexpr int XNB = XK / KB;                // 8 / 4
+  static constexpr int CPR = DH / 8;                 // 16-byte chunks per key row and plane
+  static constexpr int XCH1 = XK * CPR / (XW * 64);  // chunks of one plane per compute thread, stage 1 (4)
+  static constexpr int XCH2 = XK * CPR / (XLW * 64); // ... per loader thread, stage 2 (8)
+  static constexpr int MWR = 2 * XNB;                // mask words per query row and stage
+  static constexpr int XMW = MWR + 1;                // + 1: conflict-free column reads
+  static constexpr int MW1 = MWR * 128 / (XW * 64);  // mask words per compute thread (stage 1) / loader thread (stage 2)
+  static constexpr int MW2 = MWR * 128 / (XLW * 64);
+  static constexpr int LDK = DH == 32 ? 32 : AT<bf16_t, DH>::LDR;
+  static constexpr int LDV = AT<bf16_t, DH>::LDR;
+  static constexpr int KSD = DH / 32;                // k steps of a product over d_h
+};
 
 PQ_DEV void x3_split(const float* v, u32x4& hi, u32x4& lo) {
   hi = pack_frag<bf16_t>(v);
@@ -42,12 +58,13 @@ PQ_DEV void x3_split(const float* v, u32x4& hi, u32x4& lo) {
   lo = pack_frag<bf16_t>(w);
 }
 
-template <bool DROP, bool MASKB>
+template <int DH, bool DROP, bool MASKB>
 __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d_attn_desc d, const int KS, const int per) {
   ATTN_KARG_PIN(d);
-  constexpr int DH = 32;
   typedef AT<bf16_t, DH> A;
-  constexpr int LDK = DH, LDV = A::LDR;
+  typedef X3<DH> X;
+  constexpr int LDK = X::LDK, LDV = X::LDV, XK = X::XK, XNB = X::XNB, CPR = X::CPR, XCH1 = X::XCH1, XCH2 = X::XCH2, XMW = X::XMW,
+                MWR = X::MWR, KSD = X::KSD;
   extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];
   bf16_t* const Kh = (bf16_t*)xsm;
   bf16_t* const Kl = Kh + XK * LDK;
@@ -72,7 +89,7 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
   // one 16-byte chunk of a key row in all four planes: global -> registers (rows past the slice / past Lk: clamped duplicates,
   // never parked / masked through kpm_s)
   auto gload = [&](int stage, int c, u32x4& kh, u32x4& kl, u32x4& vh, u32x4& vl) {
-    const int gk = min(key_lo + stage * XK + (c >> 2), d.Lk - 1), part = (c & 3) * 8;
+    const int gk = min(key_lo + stage * XK + c / CPR, d.Lk - 1), part = (c % CPR) * 8;
     const long ko = koff + (long)gk * d.k_sl + part, vo = voff + (long)gk * d.v_sl + part;
     kh = *(const u32x4*)((const bf16_t*)d.k + ko);
     kl = *(const u32x4*)((const bf16_t*)d.k_lo + ko);
@@ -80,25 +97,25 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
     vl = *(const u32x4*)((const bf16_t*)d.v_lo + vo);
   };
   auto park = [&](int c, const u32x4& kh, const u32x4& kl, const u32x4& vh, const u32x4& vl) {
-    *(u32x4*)&Kh[(c >> 2) * LDK + (c & 3) * 8] = kh;
-    *(u32x4*)&Kl[(c >> 2) * LDK + (c & 3) * 8] = kl;
-    *(u32x4*)&Vh[(c >> 2) * LDV + (c & 3) * 8] = vh;
-    *(u32x4*)&Vl[(c >> 2) * LDV + (c & 3) * 8] = vl;
+    *(u32x4*)&Kh[(c / CPR) * LDK + (c % CPR) * 8] = kh;
+    *(u32x4*)&Kl[(c / CPR) * LDK + (c % CPR) * 8] = kl;
+    *(u32x4*)&Vh[(c / CPR) * LDV + (c % CPR) * 8] = vh;
+    *(u32x4*)&Vl[(c / CPR) * LDV + (c % CPR) * 8] = vl;
   };
   // the stage's mask words of the workgroup's 128 query rows: word (q, w) = bits[bm, q_base + q, 2 (kb_lo + 8 stage) + w]
-  auto mask_words = [&](int stage, int t, int nthreads, uint32_t (&mw)[16 * 128 / (XLW * 64)], int n) {
+  auto mask_words = [&](int stage, int t, int nthreads, uint32_t (&mw)[X::MW2], int n) {
 #pragma unroll
     for (int i = 0; i < n; ++i) {
-      const int c = t + i * nthreads, q = c >> 4, w = c & 15;
+      const int c = t + i * nthreads, q = c / MWR, w = c % MWR;
       const int gq = min(q_base + q, d.Lq - 1), gw = 2 * (kb_lo + XNB * stage) + w;
       mw[i] = gw < nwords ? d.mask_bits[((long)bm * d.Lq + gq) * nwords + gw] : 0u;
     }
   };
-  auto mask_park = [&](int t, int nthreads, const uint32_t (&mw)[16 * 128 / (XLW * 64)], int n) {
+  auto mask_park = [&](int t, int nthreads, const uint32_t (&mw)[X::MW2], int n) {
 #pragma unroll
     for (int i = 0; i < n; ++i) {
       const int c = t + i * nthreads;
-      msk_s[(c >> 4) * XMW + (c & 15)] = mw[i];
+      msk_s[(c / MWR) * XMW + (c % MWR)] = mw[i];
     }
   };
 
@@ -106,12 +123,12 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
   // registers that hold the second half of the slice are not live across the compute waves' code; same barrier sequence
   if (loader) {
     u32x4 kh2[XCH2], kl2[XCH2], vh2[XCH2], vl2[XCH2];
-    uint32_t mw2[16 * 128 / (XLW * 64)];
+    uint32_t mw2[X::MW2];
     const int t2 = tid - XW * 64;
     if (nb > XNB) {
 #pragma unroll
       for (int i = 0; i < XCH2; ++i) gload(1, t2 + i * XLW * 64, kh2[i], kl2[i], vh2[i], vl2[i]);
-      if constexpr (MASKB) mask_words(1, t2, XLW * 64, mw2, 16 * 128 / (XLW * 64));
+      if constexpr (MASKB) mask_words(1, t2, XLW * 64, mw2, X::MW2);
     }
     __syncthreads();   // (A) stage 1 parked
     if (nb > XNB) {
@@ -119,22 +136,23 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
 #pragma unroll
       for (int i = 0; i < XCH2; ++i) {
         const int c = t2 + i * XLW * 64;
-        if (c < (nk - XK) * 4) park(c, kh2[i], kl2[i], vh2[i], vl2[i]);
+        if (c < (nk - XK) * CPR) park(c, kh2[i], kl2[i], vh2[i], vl2[i]);
       }
-      if constexpr (MASKB) mask_park(t2, XLW * 64, mw2, 16 * 128 / (XLW * 64));
+      if constexpr (MASKB) mask_park(t2, XLW * 64, mw2, X::MW2);
       __syncthreads();   // (C) stage 2 parked
     }
     return;
   }
   // ---- compute waves
-  u32x4 qfh, qfl;
+  u32x4 qfh[KSD], qfl[KSD];
   {
-    {   // q row (fp32) -> hi / lo fragments: lane (i, g) holds k = 8 g .. 8 g + 7 of query i
-      const long qo = (long)b * d.q_sb + (long)min(myq, d.Lq - 1) * d.q_sl + (long)h * d.q_sh + 8 * lg;
+#pragma unroll
+    for (int ks = 0; ks < KSD; ++ks) {   // q row (fp32) -> hi / lo fragments: lane (i, g) holds k = 32 ks + 8 g .. + 7 of query i
+      const long qo = (long)b * d.q_sb + (long)min(myq, d.Lq - 1) * d.q_sl + (long)h * d.q_sh + 32 * ks + 8 * lg;
       const float4 a0 = *(const float4*)((const float*)d.q + qo), a1 = *(const float4*)((const float*)d.q + qo + 4);
       const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      x3_split(v, qfh, qfl);
-      if (d.q_bf && split == 0 && qvalid) *(u32x4*)((bf16_t*)d.q_bf + qo) = qfh;
+      x3_split(v, qfh[ks], qfl[ks]);
+      if (d.q_bf && split == 0 && qvalid) *(u32x4*)((bf16_t*)d.q_bf + qo) = qfh[ks];
     }
     uint8_t kp[2 * XK / (XW * 64)];
 #pragma unroll
@@ -142,14 +160,14 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
       const int j = tid + i * XW * 64;
       kp[i] = (j < nk && key_lo + j < d.Lk) ? (d.kpm ? d.kpm[(long)b * d.Lk + key_lo + j] : 0) : 1;
     }
-    uint32_t mw[16 * 128 / (XLW * 64)];
-    if constexpr (MASKB) mask_words(0, tid, XW * 64, mw, 16 * 128 / (XW * 64));
+    uint32_t mw[X::MW2];
+    if constexpr (MASKB) mask_words(0, tid, XW * 64, mw, X::MW1);
     u32x4 kh[XCH1], kl[XCH1], vh[XCH1], vl[XCH1];
 #pragma unroll
     for (int i = 0; i < XCH1; ++i) gload(0, tid + i * XW * 64, kh[i], kl[i], vh[i], vl[i]);
 #pragma unroll
     for (int i = 0; i < 2 * XK / (XW * 64); ++i) kpm_s[tid + i * XW * 64] = kp[i];
-    if constexpr (MASKB) mask_park(tid, XW * 64, mw, 16 * 128 / (XW * 64));
+    if constexpr (MASKB) mask_park(tid, XW * 64, mw, X::MW1);
 #pragma unroll
     for (int i = 0; i < XCH1; ++i) park(tid + i * XW * 64, kh[i], kl[i], vh[i], vl[i]);
   }
@@ -195,7 +213,7 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
     const bf16_t* Vht = Vh + t * KB * LDV;
     const bf16_t* Vlt = Vl + t * KB * LDV;
     f32x4 sc[4];
-    {
+    if constexpr (DH == 32) {
       u32x4 kfh[4], kfl[4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
@@ -205,19 +223,33 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        Mma<bf16_t>::mma(sc[tt], kfl[tt], qfh);
-        Mma<bf16_t>::mma(sc[tt], kfh[tt], qfl);
-        Mma<bf16_t>::mma(sc[tt], kfh[tt], qfh);
+        Mma<bf16_t>::mma(sc[tt], kfl[tt], qfh[0]);
+        Mma<bf16_t>::mma(sc[tt], kfh[tt], qfl[0]);
+        Mma<bf16_t>::mma(sc[tt], kfh[tt], qfh[0]);
+      }
+    } else {   // two k steps over d_h: fragments of one key tile at a time (register budget: 168 per wave)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSD; ++ks) {
+          const u32x4 kh_ = rfrag<bf16_t>(&Kht[(tt * 16 + li) * LDK], ks, lg), kl_ = rfrag<bf16_t>(&Klt[(tt * 16 + li) * LDK], ks, lg);
+          Mma<bf16_t>::mma(sc[tt], kl_, qfh[ks]);
+          Mma<bf16_t>::mma(sc[tt], kh_, qfl[ks]);
+          Mma<bf16_t>::mma(sc[tt], kh_, qfh[ks]);
+        }
       }
     }
-    u32x4 vfh[A::MT][2], vfl[A::MT][2];
+    u32x4 vfh[DH == 32 ? A::MT : 1][2], vfl[DH == 32 ? A::MT : 1][2];
+    if constexpr (DH == 32) {
 #pragma unroll
-    for (int mt = 0; mt < A::MT; ++mt)
+      for (int mt = 0; mt < A::MT; ++mt)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        vfh[mt][u] = tfrag_tr(Vht, LDV, u * 32, mt * 16, li, lg);
-        vfl[mt][u] = tfrag_tr(Vlt, LDV, u * 32, mt * 16, li, lg);
-      }
+        for (int u = 0; u < 2; ++u) {
+          vfh[mt][u] = tfrag_tr(Vht, LDV, u * 32, mt * 16, li, lg);
+          vfl[mt][u] = tfrag_tr(Vlt, LDV, u * 32, mt * 16, li, lg);
+        }
+    }
     if constexpr (MASKB) {
       if (!__all((nib[0] | nib[1] | nib[2] | nib[3]) == 0u)) {
 #pragma unroll
@@ -280,9 +312,16 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
       acc[mt] *= alpha;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        Mma<bf16_t>::mma(acc[mt], vfl[mt][u], pfh[u]);
-        Mma<bf16_t>::mma(acc[mt], vfh[mt][u], pfl[u]);
-        Mma<bf16_t>::mma(acc[mt], vfh[mt][u], pfh[u]);
+        if constexpr (DH == 32) {
+          Mma<bf16_t>::mma(acc[mt], vfl[mt][u], pfh[u]);
+          Mma<bf16_t>::mma(acc[mt], vfh[mt][u], pfl[u]);
+          Mma<bf16_t>::mma(acc[mt], vfh[mt][u], pfh[u]);
+        } else {   // value fragments of one 16-column tile at a time
+          const u32x4 vh_ = tfrag_tr(Vht, LDV, u * 32, mt * 16, li, lg), vl_ = tfrag_tr(Vlt, LDV, u * 32, mt * 16, li, lg);
+          Mma<bf16_t>::mma(acc[mt], vl_, pfh[u]);
+          Mma<bf16_t>::mma(acc[mt], vh_, pfl[u]);
+          Mma<bf16_t>::mma(acc[mt], vh_, pfh[u]);
+        }
       }
     }
   };
@@ -321,9 +360,11 @@ __global__ __launch_bounds__((XW + XLW) * 64) void attn_fwd_x3_kernel(const pq3d
   }
 }
 
-template <bool DROP, bool MASKB> int launch_x3(const pq3d_attn_desc& d, hipStream_t s, int KS, int nqh, int per) {
-  const size_t lds = (size_t)XK * (2 * 32 * 2 + 2 * AT<bf16_t, 32>::LDR * 2) + 2 * XK + (MASKB ? 128 * XMW * 4 : 0) + 16;
-  auto kern = attn_fwd_x3_kernel<DROP, MASKB>;
+template <int DH, bool DROP, bool MASKB> int launch_x3(const pq3d_attn_desc& d, hipStream_t s, int KS, int nqh, int per) {
+  typedef X3<DH> X;
+  const size_t lds = (size_t)X::XK * (2 * X::LDK * 2 + 2 * X::LDV * 2) + 2 * X::XK + (MASKB ? 128 * X::XMW * 4 : 0) + 16;
+  static_assert((size_t)X::XK * (2 * X::LDK * 2 + 2 * X::LDV * 2) + 2 * X::XK + 128 * X::XMW * 4 + 16 <= 160 * 1024, "LDS");
+  auto kern = attn_fwd_x3_kernel<DH, DROP, MASKB>;
   static std::atomic<unsigned> attr_done{0};   // > 64 KB of dynamic LDS: opt-in once per (kernel, device)
   if (int e = pq3d_enable_big_lds(kern, 160 * 1024, attr_done)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
   hipLaunchKernelGGL(kern, dim3(KS * nqh, d.H, d.B), dim3((XW + XLW) * 64), lds, s, d, KS, per);
@@ -335,7 +376,8 @@ template <bool DROP, bool MASKB> int launch_x3(const pq3d_attn_desc& d, hipStrea
 // pq3d_attn_fwd with k_lo set (attention.hip routes here; the caller launches the combine kernel for ksplit > 1)
 int pq3d_attn_fwd_x3(const pq3d_attn_desc& d, hipStream_t s) {
   PQ_CHECK_ARG(d.dt == PQ3D_F32 && d.k_lo && d.v_lo, "pq3d_attn_fwd (split-bf16 planes): q / o must be fp32, k_lo and v_lo set");
-  PQ_CHECK_ARG(d.dh == 32 && !d.bias && d.Lq <= 256 && d.Lk >= 1, "pq3d_attn_fwd (split-bf16 planes): d_h = 32, <= 256 queries, no additive bias");
+  PQ_CHECK_ARG((d.dh == 32 || d.dh == 64) && !d.bias && d.Lq <= 256 && d.Lk >= 1,
+               "pq3d_attn_fwd (split-bf16 planes): d_h = 32 / 64, <= 256 queries, no additive bias");
   PQ_CHECK_ARG(!d.mask || d.mask_bits, "pq3d_attn_fwd (split-bf16 planes): a 3-D mask must come as bit words (pq3d_mask_pack)");
   PQ_CHECK_ARG(!(d.mask && d.kpm), "pq3d_attn_fwd (split-bf16 planes): key padding and a 3-D mask are exclusive");
   PQ_CHECK_ARG(!((d.q_sl | d.q_sb | d.q_sh | d.o_sl | d.o_sb | d.o_sh) & 3) && !((d.k_sl | d.k_sb | d.k_sh | d.v_sl | d.v_sb | d.v_sh) & 7),
@@ -343,9 +385,14 @@ int pq3d_attn_fwd_x3(const pq3d_attn_desc& d, hipStream_t s) {
   PQ_CHECK_ARG(((((uintptr_t)d.k_lo) | ((uintptr_t)d.v_lo) | ((uintptr_t)d.q_bf) | ((uintptr_t)d.o_bf)) & 15) == 0,
                "pq3d_attn_fwd (split-bf16 planes): planes must be 16-byte aligned");
   const int KS = d.ksplit > 1 ? d.ksplit : 1, nkb = (d.Lk + KB - 1) / KB;
-  PQ_CHECK_ARG(((nkb + KS - 1) / KS) * KB <= 2 * XK, "pq3d_attn_fwd (split-bf16 planes): at most 1024 keys per key split");
+  const int xk = d.dh == 32 ? X3<32>::XK : X3<64>::XK;
+  PQ_CHECK_ARG(((nkb + KS - 1) / KS) * KB <= 2 * xk, "pq3d_attn_fwd (split-bf16 planes): at most 1024 (d_h = 64: 512) keys per key split");
   const int nqh = (d.Lq + 127) / 128, per = (d.Lq + nqh - 1) / nqh;
   const bool dr = d.drop.p > 0.f && d.drop.seed, mb = d.mask != nullptr;
-  if (dr) return mb ? launch_x3<true, true>(d, s, KS, nqh, per) : launch_x3<true, false>(d, s, KS, nqh, per);
-  return mb ? launch_x3<false, true>(d, s, KS, nqh, per) : launch_x3<false, false>(d, s, KS, nqh, per);
+  if (d.dh == 32) {
+    if (dr) return mb ? launch_x3<32, true, true>(d, s, KS, nqh, per) : launch_x3<32, true, false>(d, s, KS, nqh, per);
+    return mb ? launch_x3<32, false, true>(d, s, KS, nqh, per) : launch_x3<32, false, false>(d, s, KS, nqh, per);
+  }
+  if (dr) return mb ? launch_x3<64, true, true>(d, s, KS, nqh, per) : launch_x3<64, true, false>(d, s, KS, nqh, per);
+  return mb ? launch_x3<64, false, true>(d, s, KS, nqh, per) : launch_x3<64, false, false>(d, s, KS, nqh, per);
 }

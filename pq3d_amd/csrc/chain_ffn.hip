@@ -15,13 +15,30 @@
 // hi*hi per 32-wide k-step, k ascending, one accumulator per output), bias added to the accumulator, ReLU, two-pass LayerNorm
 // statistics with the same wave reductions, the four partial sums of linear2 added in index order -- tests/test_gpu_chain.py
 // compares every output bit for bit with the five-launch path.
+// Round 6, step 0 (optional, pq3d_chain_ffn_desc.sa_q): the self-attention CORE that used to be a launch of its own between
+// chain_ca and this kernel (sa32::attn_sa_fwd_kernel: 64 workgroups at config 2) -- member j = head j forms o_s[tile rows,
+// 32 j .. 32 j + 32) from the q / k / v the previous launch wrote, with attn_sa_body.h's own block loop (sa_fwd_block: the same
+// instructions, hence the same bits); a tile that straddles scenes runs one (16-row block, scene) task per wave over the planes of
+// up to two scenes at a time.  One more hand-off (o_s crosses members before the out-projection).  config 2: 58 -> 54 dispatches,
+// the step inside the chain 6.5 us against the 9.0 us launch (profiles/NOTES_r06.md section 5).
 // Residency: at most 32 workgroups per XCD (one per CU: 110 KB of LDS each), all resident at once; a hand-off wait that
 // runs out of patience sets *err and goes on (wrong numbers, never a hung GPU).
 #include <atomic>
 
+#include "attn_common.h"
 #include "chain_common.h"
 
 namespace {
+
+namespace sa32 {   // the split-bf16 self-attention forward's device code (attn_sa.hip's d_h = 32 instantiation), kernels left out
+#define SA_DH 32
+#define SA_MAXT 512
+#define SA_DEVICE_ONLY
+#include "attn_sa_body.h"
+#undef SA_DEVICE_ONLY
+#undef SA_DH
+#undef SA_MAXT
+}  // namespace sa32
 
 // steps 3 / 4 (the FFN products): a member owns 256 (linear1) / 128 (linear2) output columns of its row tile, every wave
 // 4 / 2 independent 16 x 16 accumulators, the weights staged in k slabs of 64 / 128 (one 16-dword RawB load each)
@@ -41,9 +58,16 @@ constexpr size_t chain_lds(int nrt) {
   return m > s6 ? m : s6;
 }
 static_assert(chain_lds(2) <= 160 * 1024, "LDS");
+// step 0 (optional): Q planes of the group's rows + K / V planes and the additive key term of `sc` scenes
+constexpr size_t sa_step_lds(int gr, int lpk, int sc) {
+  return (size_t)2 * gr * sa32::LDH * 2 + (size_t)sc * (4 * lpk * sa32::LDH * 2 + lpk * 4) + 16;
+}
 
 // NRT: 32-row tiles per group (1: up to 1024 rows; 2: up to 2048 -- a member converts each weight slab once for both tiles)
-template <int NRT>
+// SA: step 0 -- the self-attention core of the layer (the launch that used to sit between chain_ca and this one) -- runs here:
+// member j = head j forms o_s[rows of the tile, 32 j .. 32 j + 32) from q / k / v written by the PREVIOUS launch (plain loads); a
+// tile that straddles scenes runs one (16-row block, scene) task per wave over the planes of up to two scenes at a time.
+template <int NRT, bool SA>
 __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_desc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ch_smem[];
   Ctx c;
@@ -65,6 +89,99 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
   const unsigned v0 = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // equal for the whole group at launch
 
   CH_TL(0);
+  unsigned tgt = v0;   // hand-off counter (one more hand-off with step 0)
+  if constexpr (SA) {
+    using namespace sa32;
+    const int Nq = d.sa_nq, LPk = (Nq + 31) & ~31;
+    const int row_hi = min(m0 + GR, R) - 1, s_lo = m0 / Nq, s_hi = row_hi / Nq;
+    const int SC = sa_step_lds(GR, LPk, 2) <= 160 * 1024 ? 2 : 1;   // scenes staged at a time
+    bf16_t* const Qh = (bf16_t*)ch_smem;
+    bf16_t* const Ql = Qh + GR * LDH;
+    unsigned char* const kvbase = (unsigned char*)(Ql + GR * LDH);
+    const size_t per_scene = (size_t)4 * LPk * LDH * 2 + (size_t)LPk * 4;
+    // Every load of the step in flight before the first conversion: the Q rows of the group (rows past R: clamped duplicates,
+    // never stored) and, per chunk of scenes, the K / V rows + key padding (attn_sa_body.h's stage_planes, all tensors at once).
+    constexpr int QCH = GR * 4 / CT > 0 ? GR * 4 / CT : 1;   // GR * 4 <= CT: one chunk for the first GR * 4 threads
+    float qv[8];
+    const bool has_q = c.tid < GR * 4;
+    if (has_q) load8<false>(d.sa_q, (long)min(m0 + (c.tid >> 2), R - 1) * D + 32 * j + (c.tid & 3) * 8, qv);
+    static_assert(QCH == 1, "Q chunks per thread");
+    const int nch = LPk * 4;            // 16-byte chunks of one K / V plane pair
+    for (int sc0 = s_lo; sc0 <= s_hi; sc0 += SC) {
+      const int nsc = min(SC, s_hi - sc0 + 1);
+      float kv[2][2][2][8];             // [scene of the chunk][K | V][chunk of the thread]
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const int cidx = c.tid + w * CT, row = cidx >> 2, x = (cidx & 3) * 8;
+          if (u < nsc && cidx < nch) {
+            const long off = ((long)(sc0 + u) * Nq + min(row, Nq - 1)) * D + 32 * j + x;
+            load8<false>(d.sa_k, off, kv[u][0][w]);
+            load8<false>(d.sa_v, off, kv[u][1][w]);
+          }
+        }
+      if (sc0 > s_lo) __syncthreads();   // the previous chunk's planes are consumed
+      else if (has_q) {
+        const HL sp = split8(qv);
+        *(u32x4*)&Qh[(c.tid >> 2) * LDH + (c.tid & 3) * 8] = sp.hi;
+        *(u32x4*)&Ql[(c.tid >> 2) * LDH + (c.tid & 3) * 8] = sp.lo;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u >= nsc) break;
+        bf16_t* const Kh = (bf16_t*)(kvbase + u * per_scene);
+        bf16_t* const Kl = Kh + LPk * LDH;
+        bf16_t* const Vh = Kl + LPk * LDH;
+        bf16_t* const Vl = Vh + LPk * LDH;
+        float* const kb = (float*)(Vl + LPk * LDH);
+        const long r0 = (long)(sc0 + u) * Nq;
+        for (int k = c.tid; k < LPk; k += CT) kb[k] = (k < Nq && !(d.sa_kpm && d.sa_kpm[r0 + k])) ? 0.f : -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const int cidx = c.tid + w * CT, row = cidx >> 2, x = (cidx & 3) * 8;
+          if (cidx < nch) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = row < Nq ? kv[u][t][w][e] : 0.f;   // rows >= N_q of the planes are zero
+              const HL sp = split8(v);
+              bf16_t* const hi = t ? Vh : Kh;
+              bf16_t* const lo = t ? Vl : Kl;
+              *(u32x4*)&hi[row * LDH + x] = sp.hi;
+              *(u32x4*)&lo[row * LDH + x] = sp.lo;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      int task = 0;
+      for (int blk = 0; blk < GR / 16; ++blk)
+        for (int u = 0; u < nsc; ++u) {
+          const int sc = sc0 + u, b0 = m0 + blk * 16;
+          if (b0 > row_hi || b0 + 15 < sc * Nq || b0 >= (sc + 1) * Nq) continue;   // the block has no row of this scene
+          if ((task++ & 7) != c.wave) continue;
+          SaLds S;
+          S.Qh = Qh; S.Ql = Ql;
+          S.Kh = (bf16_t*)(kvbase + u * per_scene); S.Kl = S.Kh + LPk * LDH; S.Vh = S.Kl + LPk * LDH; S.Vl = S.Vh + LPk * LDH;
+          S.kb = (float*)(S.Vl + LPk * LDH);
+          const int lrow = blk * 16 + c.li, grow = m0 + lrow;
+          const bool mine_ = grow <= row_hi && grow >= sc * Nq && grow < (sc + 1) * Nq;
+          const int brow = mine_ ? grow - sc * Nq : Nq;
+          const float* bias = d.sa_bias ? d.sa_bias + ((long)sc * 8 + j) * Nq * (long)Nq : nullptr;
+          const SaFwdOut r = sa_fwd_block(S, lrow, brow, bias, Nq, Nq, LPk, d.sa_scale, c.lg);
+          if (mine_) {
+            const float inv = r.l > 0.f ? 1.f / r.l : 0.f;
+            float* o = (float*)d.o_s + (long)grow * D + 32 * j;
+#pragma unroll
+            for (int t = 0; t < OT; ++t)
+              *(float4*)(o + 16 * t + 4 * c.lg) = make_float4(r.ot[t][0] * inv, r.ot[t][1] * inv, r.ot[t][2] * inv, r.ot[t][3] * inv);
+            if (c.lg == 0) d.sa_lse[((long)sc * 8 + j) * Nq + brow] = r.l > 0.f ? r.m + logf(r.l) : -INFINITY;
+          }
+        }
+    }
+  }
   // Weights do not depend on the chain: the eight slabs a member needs (4 k slabs of its 256 W1 rows, 4 of its 128 W2 rows)
   // are requested ahead of their use through a ring of three register sets -- the first three before anything else, so they
   // travel under the out-projection, the first LayerNorm and two hand-offs.
@@ -84,11 +201,18 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
     RawA ra; RawB rbo;
     const bool on = j < 4 * NRT && m0 + (j >> 2) * TM < R;
     const int mt = m0 + (j >> 2) * TM;
-    if (on) {
-      issue_a<false>(c, ra, d.o_s, D, mt, R, 0);
-      issue_b(c, rbo, d.Wo, D, (j & 3) * TN, 0);
+    if constexpr (SA) {   // Wo and the first weight slabs travel under the hand-off that publishes o_s
+      if (on) issue_b(c, rbo, d.Wo, D, (j & 3) * TN, 0);
+      issue_w(0, ring[0]); issue_w(1, ring[1]); issue_w(2, ring[2]);
+      handoff(c, mine, group, ++tgt, d.err);
+      if (on) issue_a<true>(c, ra, d.o_s, D, mt, R, 0);
+    } else {
+      if (on) {
+        issue_a<false>(c, ra, d.o_s, D, mt, R, 0);
+        issue_b(c, rbo, d.Wo, D, (j & 3) * TN, 0);
+      }
+      issue_w(0, ring[0]); issue_w(1, ring[1]); issue_w(2, ring[2]);
     }
-    issue_w(0, ring[0]); issue_w(1, ring[1]); issue_w(2, ring[2]);
     if (on) {
       put_a(c, ra); put_b(c, rbo);
       __syncthreads();
@@ -98,7 +222,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
     }
   }
   CH_TL(1);
-  handoff(c, mine, group, v0 + 1, d.err);
+  handoff(c, mine, group, ++tgt, d.err);
   CH_TL(2);
   // ---- 2. x2 = LN1(x1s + f): 32 NRT rows over 8 members x 4 NRT waves
   const long lrow = m0 + 4 * NRT * j + c.wave;
@@ -108,7 +232,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
     if (lnw) ln_row<false>(c, lrow, d.x1s, o1, 1, 0, d.g1, d.be1, d.eps1, nullptr, d.x2, d.mean1, d.rstd1);
   }
   CH_TL(3);
-  handoff(c, mine, group, v0 + 2, d.err);
+  handoff(c, mine, group, ++tgt, d.err);
   CH_TL(4);
   const int wr = (c.wave >> 2) * 16;              // steps 3 / 4: this wave's 16 rows of every row tile
   // ---- 3. h = relu(x2 W1^T + b1): member j owns columns [256 j, 256 j + 256); wave = 16 rows x 64 columns per row tile
@@ -193,7 +317,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
     }
   }
   CH_TL(5);
-  handoff(c, mine, group, v0 + 3, d.err);
+  handoff(c, mine, group, ++tgt, d.err);
   CH_TL(6);
   // ---- 4. zp_k = h[:, quarter k] W2[:, quarter k]^T (+ b2 at k = 0): member j owns quarter j / 2 and columns [128 (j & 1), + 128);
   // wave = 16 rows x 32 columns per row tile (2 accumulators), k slabs of 128
@@ -283,7 +407,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
   RawB wq[2];
   if (d.nq > 0) proj_issue_w(c, j, d.nq, d.Wq, wq);
   CH_TL(7);
-  handoff(c, mine, group, v0 + 4, d.err);
+  handoff(c, mine, group, ++tgt, d.err);
   CH_TL(8);
   // ---- 5. z = sum of the partials, x3 = LN2(x2 + z)
   {
@@ -293,7 +417,7 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
   CH_TL(9);
   // ---- 6. (optional) the next layer application's cross-attention query projections from x3 + qpos
   if (d.nq > 0) {   // uniform
-    handoff(c, mine, group, v0 + 5, d.err);
+    handoff(c, mine, group, ++tgt, d.err);
     const void* A[3] = {d.x3, d.x3, d.x3};
     const float* A2[3] = {d.qpos, d.qpos, d.qpos};
     if (d.qout_f32) {   // uniform: fp32 queries (compute mode 'bf16x3': the split-bf16 cross-attention splits them itself)
@@ -326,15 +450,29 @@ extern "C" int pq3d_chain_ffn_fwd(const pq3d_chain_ffn_desc* dp, void* stream) {
   for (int m = 0; m < d.nq; ++m)
     PQ_CHECK_ARG(d.Wq[m] && d.bq[m] && d.qout[m] && ((((uintptr_t)d.Wq[m]) | ((uintptr_t)d.qout[m])) & 15) == 0,
                  "pq3d_chain_ffn_fwd: query-projection operands (non-null, 16-byte aligned)");
-  static std::atomic<unsigned> done1{0}, done2{0};
-  const dim3 grid((unsigned)(8 * G * slots));
-  if (nrt == 1) {
-    if (int e = pq3d_enable_big_lds(chain_ffn_fwd_kernel<1>, (int)chain_lds(1), done1)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
-    hipLaunchKernelGGL(chain_ffn_fwd_kernel<1>, grid, dim3(CT), chain_lds(1), (hipStream_t)stream, d);
-  } else {
-    if (int e = pq3d_enable_big_lds(chain_ffn_fwd_kernel<2>, (int)chain_lds(2), done2)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
-    hipLaunchKernelGGL(chain_ffn_fwd_kernel<2>, grid, dim3(CT), chain_lds(2), (hipStream_t)stream, d);
+  const bool sa = d.sa_q != nullptr;
+  size_t lds = chain_lds(nrt);
+  if (sa) {
+    PQ_CHECK_ARG(d.sa_k && d.sa_v && d.sa_lse && d.sa_nq >= 1 && d.sa_nq <= 240 && d.R % d.sa_nq == 0,
+                 "pq3d_chain_ffn_fwd: self-attention step needs q / k / v / lse, 1 <= sa_nq <= 240 queries per scene dividing R");
+    PQ_CHECK_ARG(((((uintptr_t)d.sa_q) | ((uintptr_t)d.sa_k) | ((uintptr_t)d.sa_v) | ((uintptr_t)d.sa_bias)) & 15) == 0 ,
+                 "pq3d_chain_ffn_fwd: self-attention operands must be 16-byte aligned");
+    const int lpk = (d.sa_nq + 31) & ~31, gr = TM * nrt;
+    const size_t need = sa_step_lds(gr, lpk, 2) <= 160 * 1024 ? sa_step_lds(gr, lpk, 2) : sa_step_lds(gr, lpk, 1);
+    PQ_CHECK_ARG(need <= 160 * 1024, "pq3d_chain_ffn_fwd: self-attention step does not fit the LDS");
+    if (need > lds) lds = need;
   }
+  static std::atomic<unsigned> done[4] = {{0}, {0}, {0}, {0}};
+  const dim3 grid((unsigned)(8 * G * slots));
+  auto go = [&](auto kern, std::atomic<unsigned>& dn) -> int {
+    if (int e = pq3d_enable_big_lds(kern, 160 * 1024, dn)) { pq3d_set_error(hipGetErrorString((hipError_t)e)); return e; }
+    hipLaunchKernelGGL(kern, grid, dim3(CT), lds, (hipStream_t)stream, d);
+    return 0;
+  };
+  int e = 0;
+  if (nrt == 1) e = sa ? go(chain_ffn_fwd_kernel<1, true>, done[0]) : go(chain_ffn_fwd_kernel<1, false>, done[1]);
+  else e = sa ? go(chain_ffn_fwd_kernel<2, true>, done[2]) : go(chain_ffn_fwd_kernel<2, false>, done[3]);
+  if (e) return e;
   PQ_LAUNCH_CHECK();
   return 0;
 }

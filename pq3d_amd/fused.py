@@ -275,10 +275,11 @@ def _ln_bwd(x, os_, gammas, betas, eps, coef, rows_per_scene, mean, rstd, dy, dg
     return dx, d_o
 
 
-def kv3_ks(Lk: int) -> int:
-    """Key splits of the split-bf16 cross-attention forward (csrc/attn_x3.hip: at most 1024 keys per workgroup) -- a function of the
-    key length only, like every forward split factor (a scene's result must not depend on how scenes are batched)."""
-    return max(1, -(-((Lk + 63) // 64) // 16))
+def kv3_ks(Lk: int, dh: int = 32) -> int:
+    """Key splits of the split-bf16 cross-attention forward (csrc/attn_x3.hip: at most 1024 keys per workgroup at d_h = 32, 512 at
+    d_h = 64) -- a function of the key length only, like every forward split factor (a scene's result must not depend on how scenes
+    are batched)."""
+    return max(1, -(-((Lk + 63) // 64) // (16 if dh == 32 else 8)))
 
 
 def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None, bias=None, mask_bmod=0, bwd=None,
@@ -294,7 +295,7 @@ def _attn(q, k, v, o, lse, H, ct, zero_attn, kpm=None, mask=None, row_open=None,
     if planes is not None:
         assert bwd is None and ct == L.BF16X3 and q.dtype == torch.float32 and k.dtype == torch.bfloat16
         d.k_lo, d.v_lo, d.q_bf, d.o_bf = map(L.ptr, planes)
-        ks = kv3_ks(Lk)
+        ks = kv3_ks(Lk, dm // H)
         d.ksplit, d.ws, d._ws_keepalive = 1, None, None
         if ks > 1:
             d._ws_keepalive = torch.empty(ks * B * H * Lq * (dm // H + 2), dtype=torch.float32, device=q.device)
@@ -1357,11 +1358,16 @@ class _FusedDecoder(Function):
                 sbias = sbias_all[i] if spec.spatial else None   # layer-invariant across blocks: computed once above
                 o_s = torch.empty(B, Nq, d, dtype=torch.float32, device=dev)
                 lse_s = torch.empty(B, H, Nq, dtype=torch.float32, device=dev)
-                _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ops.sa_ct(ct), False, kpm=qmask, bias=sbias, drop=dr_sa)
                 ffn = layer.ffn
                 F_ = ffn.linear1.out_features
                 chain = _chain_on(dev) and cq == L.BF16X3 and spec.act == "relu" and dr_sr is None and dr_fi is None and dr_fr is None and \
                     ops.chain_ffn_ok(R, d, F_) and sa.norm.weight.shape[0] == d
+                # the self-attention core as step 0 of that launch (one launch less per layer; same bits as pq3d_attn_fwd's kernel)
+                sa_in = chain and dr_sa is None and ops.sa_ct(ct) == L.BF16X3 and ops.chain_sa_ok(Nq, H, d) and qkv.is_contiguous() and \
+                    (sbias is None or (sbias.is_contiguous() and sbias.dtype == torch.float32)) and \
+                    (qmask is None or (qmask.is_contiguous() and qmask.dtype == torch.bool))
+                if not sa_in:
+                    _attn(qkv[0], qkv[1], qkv[2], o_s, lse_s, H, ops.sa_ct(ct), False, kpm=qmask, bias=sbias, drop=dr_sa)
                 if chain:
                     # the row-local tail of the layer in ONE launch (csrc/chain_ffn.hip: out-projection, post-norm, FFN, post-norm;
                     # 8 workgroups per 32-row tile handing rows over inside one XCD) -- the five launches' bits
@@ -1379,7 +1385,8 @@ class _FusedDecoder(Function):
                         o_s, Wo, bo, x1s, sa.norm.weight.detach(), sa.norm.bias.detach(), sa.norm.eps,
                         ffn.linear1.weight.detach(), ffn.linear1.bias.detach(), ffn.linear2.weight.detach(), ffn.linear2.bias.detach(),
                         ffn.norm.weight.detach(), ffn.norm.bias.detach(), ffn.norm.eps, flags, nextq=nextq,
-                        q_dtype=torch.float32 if kv3 else torch.bfloat16)
+                        q_dtype=torch.float32 if kv3 else torch.bfloat16,
+                        sa=(qkv[0], qkv[1], qkv[2], sbias, qmask, lse_s, 1.0 / math.sqrt(d // H)) if sa_in else None)
                     f, x2, mean_s, rstd_s, h, _zp, z, x3, mean_f, rstd_f = outs[:10]
                     q_next = outs[10] if nextq is not None else None
                     pre = None
@@ -1520,11 +1527,11 @@ def fused_decoder(enc, input_dict, pairwise_locs, mask_head=None, seg_fts_for_ma
                             for a in range(n_app)]).contiguous()
     ct = L.BF16 if layer0.compute in ("bf16", "bf16x3") else L.F32
     # compute mode 'bf16x3': the split-bf16 key/value side where its kernels cover the shape (128-row-tile plane GEMM: d % 128 == 0;
-    # csrc/attn_x3.hip: d_h = 32, <= 256 queries), the exact-f32 kernels otherwise -- same accuracy contract
+    # csrc/attn_x3.hip: d_h = 32 / 64, <= 256 queries), the exact-f32 kernels otherwise -- same accuracy contract
     kv3 = False
     if layer0.compute == "bf16x3":
         B_, Ns_, d_ = uniq[0].shape
-        kv3 = (d_ % 128 == 0 and d_ == 32 * enc.num_heads and x0.shape[1] <= 256 and B_ * Ns_ >= 128 and 2 * len(uniq) <= MAXG and
+        kv3 = (d_ % 128 == 0 and d_ in (32 * enc.num_heads, 64 * enc.num_heads) and x0.shape[1] <= 256 and B_ * Ns_ >= 128 and 2 * len(uniq) <= MAXG and
                len(mems) * Ln_ <= MAXG and all(f.dtype == torch.float32 for f in uniq) and
                (prompt is None or (prompt.dtype == torch.float32 and (prompt.shape[0] * prompt.shape[1] * d_) % 8 == 0 and
                                    (x0.shape[0] * x0.shape[1] * d_) % 8 == 0)))

@@ -1743,10 +1743,17 @@ def chain_ffn_ok(R: int, d: int, F_: int) -> bool:
     return d == 256 and F_ == 2048 and 1 <= R <= 2048
 
 
-def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2, flags, nextq=None, q_dtype=torch.bfloat16):
+def chain_sa_ok(Nq: int, H: int, d: int) -> bool:
+    """The self-attention core can run as step 0 of chain_ffn_fwd (csrc/chain_ffn.hip): 8 heads of 32, <= 240 queries per scene."""
+    return d == 256 and H == 8 and 1 <= Nq <= 240 and os.environ.get("PQ3D_CHAIN_SA", "1") != "0"
+
+
+def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2, flags, nextq=None, q_dtype=torch.bfloat16, sa=None):
     """Returns (f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2[, q_next]); every tensor fp32, rows = o_s.numel() // 256.
     nextq = (qpos, [Wq_m], [bq_m]): also q_next[m] = (x3 + qpos) Wq_m^T + bq_m as bf16 (the next layer's cross-attention queries;
-    q_dtype = torch.float32 for compute mode 'bf16x3')."""
+    q_dtype = torch.float32 for compute mode 'bf16x3').
+    sa = (q, k, v [B, Nq, 256] fp32, bias [B, 8, Nq, Nq] or None, kpm [B, Nq] bool or None, lse [B, 8, Nq], scale): the launch first
+    forms o_s (an OUTPUT then) and lse = the split-bf16 self-attention core of pq3d_attn_fwd, bit for bit."""
     d = o_s.shape[-1]
     R, F_ = o_s.numel() // d, W1.shape[0]
     dev = o_s.device
@@ -1764,6 +1771,19 @@ def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2
                  ("be2", be2), ("x3", x3), ("mean2", mean2), ("rstd2", rstd2), ("flags", flags), ("err", err)):
         assert t.is_contiguous() and (n in ("flags", "err") or t.dtype == torch.float32), n
         setattr(c, n, L.ptr(t))
+    if sa is not None:
+        q_, k_, v_, bias_, kpm_, lse_, scale_ = sa
+        Nq = q_.shape[-2]
+        assert all(t.is_contiguous() and t.dtype == torch.float32 and t.shape == o_s.shape for t in (q_, k_, v_)) and R % Nq == 0
+        assert lse_.is_contiguous() and lse_.dtype == torch.float32 and lse_.numel() == (R // Nq) * 8 * Nq
+        c.sa_q, c.sa_k, c.sa_v, c.sa_lse, c.sa_nq, c.sa_scale = L.ptr(q_), L.ptr(k_), L.ptr(v_), L.ptr(lse_), Nq, float(scale_)
+        if bias_ is not None:
+            assert bias_.is_contiguous() and bias_.dtype == torch.float32 and bias_.numel() == (R // Nq) * 8 * Nq * Nq
+            c.sa_bias = L.ptr(bias_)
+        if kpm_ is not None:
+            assert kpm_.is_contiguous() and kpm_.dtype in (torch.bool, torch.uint8) and kpm_.numel() == R
+            c.sa_kpm = L.ptr(kpm_)
+            c._kpm_keepalive = kpm_
     qn = None
     if nextq is not None:
         qpos, Wqs, bqs = nextq
@@ -1776,6 +1796,9 @@ def chain_ffn_fwd(o_s, Wo, bo, x1s, g1, be1, eps1, W1, b1, W2, b2, g2, be2, eps2
     from .profiler import timed
     fl = 2.0 * R * d * (d + 2 * F_)
     nb = 4.0 * (R * d * 9 + 2 * R * F_ + d * d + 2 * d * F_)
+    if sa is not None:   # the self-attention core of step 0: scores + value contraction, q / k / v in, bias in
+        fl += 4.0 * R * sa[0].shape[-2] * d
+        nb += 4.0 * (3 * R * d + (sa[3].numel() if sa[3] is not None else 0))
     L.check(timed("pq3d_chain_ffn_fwd", f"R{R}d{d}F{F_}", fl, nb, L.lib().pq3d_chain_ffn_fwd, C.byref(c), L.stream()), "pq3d_chain_ffn_fwd")
     return (f, x2, mean1, rstd1, h, zp, z, x3, mean2, rstd2) + ((qn,) if qn is not None else ())
 

@@ -49,6 +49,49 @@ def test_chain_equals_five_launches(B, Nq, F_):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (n, rep, (a - b).abs().max().item())
 
 
+@pytest.mark.parametrize("B,Nq,bias,pad", [(8, 100, True, True), (4, 200, True, True), (16, 100, True, False), (3, 77, False, True),
+                                           (50, 16, True, True), (80, 10, True, True), (2, 240, True, True), (1, 1, False, False),
+                                           (5, 33, True, False), (8, 128, False, False)])
+def test_chain_with_the_self_attention_core_inside(B, Nq, bias, pad):
+    """Step 0 of chain_ffn_fwd (round 6): the split-bf16 self-attention core itself, member j = head j over the tile's rows -- o_s,
+    lse and everything downstream bit for bit what pq3d_attn_fwd + the chain write in two launches; tiles that straddle 2 .. 4 scenes
+    (N_q = 100, 77, 16, 10), two row tiles per group (R = 1600), one scene's planes at a time (N_q = 240), repeated launches."""
+    from pq3d_amd import _lib as L, fused, ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 977 + Nq)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    d, H, F_ = 256, 8, 2048
+    assert ops.chain_sa_ok(Nq, H, d)
+    qkv = r(3, B, Nq, d)
+    sb = r(B, H, Nq, Nq) if bias else None
+    kpm = None
+    if pad:
+        kpm = (torch.rand(B, Nq, generator=g) < 0.2).to(dev)
+        kpm[:, 0] = False
+        if B > 1:
+            kpm[1] = True      # a scene with every key padded: zero output, lse = -inf
+    args = (r(d, d, sc=0.06), r(d, sc=0.1), r(B, Nq, d), 1 + r(d, sc=0.1), r(d, sc=0.1), 1e-5,
+            r(F_, d, sc=0.06), r(F_, sc=0.1), r(d, F_, sc=0.03), r(d, sc=0.1), 1 + r(d, sc=0.1), r(d, sc=0.1), 1e-5)
+    nextq = (r(B, Nq, d), [r(d, d, sc=0.06) for _ in range(3)], [r(d, sc=0.1) for _ in range(3)])
+    scale = 1.0 / (32 ** 0.5)
+    o_ref = torch.empty(B, Nq, d, device=dev)
+    lse_ref = torch.empty(B, H, Nq, device=dev)
+    fused._attn(qkv[0], qkv[1], qkv[2], o_ref, lse_ref, H, L.BF16X3, False, kpm=kpm, bias=sb)
+    flags = ops.chain_flags(max(B * Nq, 2048), dev)
+    ref = ops.chain_ffn_fwd(o_ref, *args, flags, nextq=nextq, q_dtype=torch.float32)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        o_s = torch.full((B, Nq, d), float("nan"), device=dev)
+        lse = torch.full((B, H, Nq), float("nan"), device=dev)
+        out = ops.chain_ffn_fwd(o_s, *args, flags, nextq=nextq, q_dtype=torch.float32, sa=(qkv[0], qkv[1], qkv[2], sb, kpm, lse, scale))
+        torch.cuda.synchronize()
+        assert not ops.chain_error(dev)
+        assert torch.equal(o_s.view(torch.int32), o_ref.view(torch.int32)), (rep, (o_s - o_ref).abs().max().item())
+        assert torch.equal(lse.view(torch.int32), lse_ref.view(torch.int32)), rep
+        for i, (a, b) in enumerate(zip(out, ref)):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (i, rep)
+
+
 def test_chain_refuses_what_it_cannot_hold():
     from pq3d_amd import _lib as L, ops
     assert not ops.chain_ffn_ok(2049, 256, 2048) and not ops.chain_ffn_ok(800, 512, 2048) and ops.chain_ffn_ok(800, 256, 2048) and not ops.chain_ffn_ok(800, 256, 1024)

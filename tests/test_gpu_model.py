@@ -264,7 +264,8 @@ def test_bf16_self_mask_first_call_and_flip_rate():
 def test_bf16x3_model_matches_fp32_oracle(name):
     """Compute mode 'bf16x3' (split-bf16 key/value side; fused.fused_decoder) end to end against the fp32 oracle at north_star's
     1e-3 -- not a measured-times-1.5 bar.  d = 256 fixtures take the split-bf16 kernels (csrc/attn_x3.hip, PQ3D_ACT_PLANES);
-    F1_c1 (d_h = 16), F20 (prompt memory) and F15_d768 (d_h = 64) are outside their shape and run the exact-f32 kernels: the mode's
+    F15_d768 (d_h = 64) too since round 6's last session; F1_c1 (d_h = 16) and F20 (prompt memory) are outside their shape and run the
+    exact-f32 kernels: the mode's
     contract is the accuracy, the kernels are the fast path to it.  Live self-masks (F4b, F15_din): a threshold flip moves a
     downstream logit by more than rounding, so mask logits are compared where the oracle's own mask agrees (flip rate asserted)."""
     z, args = util.load_fixture(name)

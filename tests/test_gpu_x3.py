@@ -128,8 +128,10 @@ def attn_ref(q, k, v, H, kpm=None, mask=None, keep=None):
 @pytest.mark.parametrize("B,H,Lq,Lk,mode", [(3, 8, 100, 1024, "kpm"), (2, 8, 100, 1000, "kpm"), (2, 4, 16, 130, "kpm"), (2, 8, 128, 2048, "kpm"),
                                             (2, 8, 200, 4096, "mask"), (2, 8, 200, 1111, "mask"), (2, 2, 7, 64, "none"),
                                             (2, 8, 100, 3000, "kpm"), (1, 8, 256, 512, "mask"), (2, 8, 129, 600, "kpm")])
-def test_attn_x3_forward_matches_float64(B, H, Lq, Lk, mode):
-    d = 32 * H
+@pytest.mark.parametrize("dh", [32, 64])
+def test_attn_x3_forward_matches_float64(B, H, Lq, Lk, mode, dh):
+    """d_h = 64 (round 6: the head width of the reference's shipped decoders, hidden 768 / 12 heads): 256 keys per stage, 512 per split."""
+    d = dh * H
     q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
     g = torch.Generator().manual_seed(Lq * Lk + H)
     kpm = mask = None
@@ -165,9 +167,10 @@ def test_attn_x3_forward_matches_float64(B, H, Lq, Lk, mode):
     assert torch.equal(q_bf.cpu(), q.to(torch.bfloat16))
 
 
-def test_attn_x3_forward_dropout_uses_the_shared_generator():
+@pytest.mark.parametrize("dh", [32, 64])
+def test_attn_x3_forward_dropout_uses_the_shared_generator(dh):
     B, H, Lq, Lk = 2, 8, 100, 1024
-    d = 32 * H
+    d = dh * H
     q, k, v = rnd(B, Lq, d, seed=1), rnd(B, Lk, d, seed=2), rnd(B, Lk, d, seed=3)
     kh, kl = (t.to(DEV) for t in planes(k))
     vh, vl = (t.to(DEV) for t in planes(v))
@@ -200,14 +203,29 @@ SMALL = [
 ]
 
 
-@pytest.mark.parametrize("args", SMALL, ids=["kpm", "pinned-self-mask"])
+SMALL.append(dict(B=2, Ns=300, Nq=40, d=384, H=6, L=2, memories=["voxel", "mv", "pc"], heads=["ground"], spatial=True, structure="parallel",
+                  seed=0, data_seed=9))   # d_h = 64 (the shipped decoders' head width): modular row-local steps, split-bf16 key/value side
+
+
+@pytest.mark.parametrize("args", SMALL, ids=["kpm", "pinned-self-mask", "dh64"])
 def test_bf16x3_model_is_fp32_grade_and_backward_is_the_bf16_modes(args):
     """Forward within 1e-3 of the fp32 oracle end to end (measured ~2e-5); every gradient within 2e-2 (relative L2 against
     max(|g|, 1e-2 max|g|): the single-bf16 backward); the fused executor takes the split-bf16 path (spec.kv3)."""
     _cfg, model, sd, dd = util.model_case(args)
     set_compute(model, "bf16x3")
     model.to(DEV)
-    out = model({k: v.to(DEV) for k, v in dd.items()})
+    seen = []
+    real_attn = fused._attn
+
+    def spy(*a, **k):
+        seen.append(k.get("planes") is not None)
+        return real_attn(*a, **k)
+    fused._attn = spy
+    try:
+        out = model({k: v.to(DEV) for k, v in dd.items()})
+    finally:
+        fused._attn = real_attn
+    assert sum(seen) >= args["L"], "the split-bf16 cross-attention forward (csrc/attn_x3.hip) must be the one that runs"
     loss = util.synthetic_loss(out, args["heads"], out["query_embeds"])
     loss.backward()
     oout, collect, oloss, og = util.run_oracle(args, sd, dd)
