@@ -101,11 +101,10 @@ __global__ __launch_bounds__(CT) void chain_ffn_fwd_kernel(const pq3d_chain_ffn_
     const size_t per_scene = (size_t)4 * LPk * LDH * 2 + (size_t)LPk * 4;
     // Every load of the step in flight before the first conversion: the Q rows of the group (rows past R: clamped duplicates,
     // never stored) and, per chunk of scenes, the K / V rows + key padding (attn_sa_body.h's stage_planes, all tensors at once).
-    constexpr int QCH = GR * 4 / CT > 0 ? GR * 4 / CT : 1;   // GR * 4 <= CT: one chunk for the first GR * 4 threads
+    static_assert(GR * 4 <= CT, "one 16-byte Q chunk for each of the first 4 GR threads");
     float qv[8];
     const bool has_q = c.tid < GR * 4;
     if (has_q) load8<false>(d.sa_q, (long)min(m0 + (c.tid >> 2), R - 1) * D + 32 * j + (c.tid & 3) * 8, qv);
-    static_assert(QCH == 1, "Q chunks per thread");
     const int nch = LPk * 4;            // 16-byte chunks of one K / V plane pair
     for (int sc0 = s_lo; sc0 <= s_hi; sc0 += SC) {
       const int nsc = min(SC, s_hi - sc0 + 1);

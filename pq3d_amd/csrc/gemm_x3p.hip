@@ -9,6 +9,9 @@
 // MFMAs: 4 tiles and 16 fragment reads per 48 MFMAs, one launch for all (layer, memory, k|v) groups.
 // Tile 128 x 128, k slices of 32 (32 KB of LDS: 4 workgroups per CU cover the single-buffer barriers), LDS-DMA staging with the
 // bank swizzle in the source address (64-byte rows: slot s of row r holds chunk s ^ ((r >> 2) & 3)), XCD-aware tile order.
+// Round 6, last session: the MFMA operands are swapped (C^T tiles: a lane holds 4 consecutive columns of one row), so the epilogue
+// stages 8 bytes per LDS write instead of 2: 107 -> 101.6 us at config 2, 607 -> 595 us for config 5's large launch.  Isolating
+// switches (profiles/NOTES_r06.md section 5): skeleton 30 + MFMAs 34 + operand DMA 30 + stores 24 us -- the parts add up.
 // Bound: the write of C + C2 (an fp32 tensor's bytes) / L2 -> LDS operand traffic; algorithmic bytes per group
 // (M + N) K 4 + M N 4.
 #include <algorithm>
@@ -79,16 +82,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
       const u32x4 ah = *(const u32x4*)&Ah[(wm + i * 16 + li) * XTK + ch];
       const u32x4 al = *(const u32x4*)&Al[(wm + i * 16 + li) * XTK + ch];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        Mma<bf16_t>::mma(acc[i][j], al, bh[j]);
-        Mma<bf16_t>::mma(acc[i][j], ah, bl[j]);
-        Mma<bf16_t>::mma(acc[i][j], ah, bh[j]);
+      for (int j = 0; j < 4; ++j) {   // operands swapped: the lane holds C[m = li][n = 4 lg + r] -- 4 consecutive columns of one row
+        Mma<bf16_t>::mma(acc[i][j], bh[j], al);
+        Mma<bf16_t>::mma(acc[i][j], bl[j], ah);
+        Mma<bf16_t>::mma(acc[i][j], bh[j], ah);
       }
     }
     __syncthreads();
   }
 
-  // epilogue: + bias, hi plane then residual plane through one LDS staging tile (rows leave in whole 16-byte pieces)
+  // epilogue: + bias, hi plane then residual plane through one LDS staging tile (rows leave in whole 16-byte pieces); the
+  // transposed accumulator puts 4 consecutive columns of a row in a lane: 32 eight-byte staging writes per thread and plane pair
+  // where the plain layout needed 128 two-byte ones
   const float* bias = (const float*)d.gp[g].bias;
   bf16_t* const Ct = sm;   // [XM][XLDC]
   constexpr int TPR = XN / 8, RPP = 256 / TPR;
@@ -98,18 +103,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     if (pl) __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = wn + j * 16 + li;
-      const float bn = (pl == 0 && bias) ? bias[n0 + col] : 0.f;
+      const int col = wn + j * 16 + 4 * lg;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (pl == 0 && bias) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 4; ++r) bv[r] = bias[n0 + col + r];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf16_t h[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[i][j][r];
-          if (pl == 0) v = v * d.alpha + bn;
-          const bf16_t h = f2bf(v);
-          Ct[(wm + i * 16 + 4 * lg + r) * XLDC + col] = h;
-          if (pl == 0) acc[i][j][r] = v - bf2f(h);
+          if (pl == 0) v = v * d.alpha + bv[r];
+          h[r] = f2bf(v);
+          if (pl == 0) acc[i][j][r] = v - bf2f(h[r]);
         }
+        *(u32x2*)&Ct[(wm + i * 16 + li) * XLDC + col] = (u32x2){(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+      }
     }
     __syncthreads();
     bf16_t* const C = (bf16_t*)(pl == 0 ? d.gp[g].C : d.gp[g].C2);
